@@ -1,0 +1,549 @@
+/* ref_harness.c -- TEST INFRASTRUCTURE. Thin C entry points around the REFERENCE library, compiled
+ * against the reference's own headers where they lie (oracle/Makefile target `ref`) and linked into
+ * oracle/_ref/liblongtail_ref.so.  Own code, no reference source text; everything it calls is the
+ * reference's public API.  Lets Python (ctypes) tests
+ *   - probe the reference algorithms through the reference's plugin structs (pins oracle/*.c),
+ *   - run Longtail_CreateVersionIndex / Longtail_WriteContent with ANY plugin pointers (reference or
+ *     the HIP ones from liblongtail_hip.so) and compare serialized results byte for byte,
+ *   - time the reference's bikeshed-threaded CPU path (bench.py cpu_baseline kind "reference").
+ */
+#include "src/longtail.h"
+#include "lib/longtail_platform.h"
+#include "lib/atomiccancel/longtail_atomiccancel.h"
+#include "lib/bikeshed/longtail_bikeshed.h"
+#include "lib/blake3/longtail_blake3.h"
+#include "lib/compressblockstore/longtail_compressblockstore.h"
+#include "lib/compressionregistry/longtail_compression_registry.h"
+#include "lib/fsblockstore/longtail_fsblockstore.h"
+#include "lib/hpcdcchunker/longtail_hpcdcchunker.h"
+#include "lib/lz4/longtail_lz4.h"
+#include "lib/memstorage/longtail_memstorage.h"
+#include "lib/zstd/longtail_zstd.h"
+
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+int refh_version(void) { return 2; }
+
+/* ------------------------------------------------------------------------------------------------
+ * algorithm probes through the reference's plugin structs
+ * ---------------------------------------------------------------------------------------------- */
+struct mem_feed
+{
+    const uint8_t* data;
+    uint64_t size;
+    uint64_t pos;
+};
+
+static int mem_feeder(void* context, Longtail_ChunkerAPI_HChunker chunker, uint32_t requested_size, char* buffer,
+                      uint32_t* out_size)
+{
+    struct mem_feed* f = (struct mem_feed*)context;
+    uint64_t n = f->size - f->pos;
+    (void)chunker;
+    if (n > requested_size)
+        n = requested_size;
+    if (n)
+        memcpy(buffer, f->data + f->pos, (size_t)n);
+    f->pos += n;
+    *out_size = (uint32_t)n;
+    return 0;
+}
+
+/* Chunk data[0..size) with ANY ChunkerAPI (0 => reference hpcdc) through NextChunk and hash every
+ * range with ANY HashAPI (0 => reference blake3).  Returns chunk count, or -(errno) on error.
+ * Also checks the API contract the core relies on: ranges are contiguous, buf bytes equal the input. */
+int64_t refh_chunk_stream(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_HashAPI* hash_api,
+                          const uint8_t* data, uint64_t size, uint32_t min, uint32_t avg, uint32_t max,
+                          uint64_t* out_offsets, uint32_t* out_lens, uint64_t* out_hashes, uint64_t cap)
+{
+    struct Longtail_ChunkerAPI* own_c = 0;
+    struct Longtail_HashAPI* own_h = 0;
+    int64_t count = 0;
+    uint64_t expect = 0;
+    if (!chunker_api)
+        chunker_api = own_c = Longtail_CreateHPCDCChunkerAPI();
+    if (!hash_api)
+        hash_api = own_h = Longtail_CreateBlake3HashAPI();
+    Longtail_ChunkerAPI_HChunker c = 0;
+    int err = chunker_api->CreateChunker(chunker_api, min, avg, max, &c);
+    if (err)
+    {
+        count = -err;
+        goto done;
+    }
+    struct mem_feed f = {data, size, 0};
+    for (;;)
+    {
+        struct Longtail_Chunker_ChunkRange r;
+        err = chunker_api->NextChunk(chunker_api, c, mem_feeder, &f, &r);
+        if (err == ESPIPE)
+        {
+            if (r.len != 0 || r.offset != size)
+                count = -1000;
+            break;
+        }
+        if (err)
+        {
+            count = -err;
+            break;
+        }
+        if (r.offset != expect || r.len == 0 || memcmp(r.buf, data + r.offset, r.len) != 0)
+        {
+            count = -1001;
+            break;
+        }
+        uint64_t h = 0;
+        err = hash_api->HashBuffer(hash_api, r.len, r.buf, &h);
+        if (err)
+        {
+            count = -err;
+            break;
+        }
+        if ((uint64_t)count < cap)
+        {
+            if (out_offsets)
+                out_offsets[count] = r.offset;
+            if (out_lens)
+                out_lens[count] = r.len;
+            if (out_hashes)
+                out_hashes[count] = h;
+        }
+        expect += r.len;
+        ++count;
+    }
+    chunker_api->DisposeChunker(chunker_api, c);
+done:
+    SAFE_DISPOSE_API(own_c);
+    SAFE_DISPOSE_API(own_h);
+    return count;
+}
+
+/* Same through NextChunkFromBuffer (the mmap-style entry point, dead in the core but in the struct). */
+int64_t refh_chunk_from_buffer(struct Longtail_ChunkerAPI* chunker_api, const uint8_t* data, uint64_t size,
+                               uint32_t min, uint32_t avg, uint32_t max, uint32_t* out_lens, uint64_t cap)
+{
+    struct Longtail_ChunkerAPI* own_c = 0;
+    int64_t count = 0;
+    if (!chunker_api)
+        chunker_api = own_c = Longtail_CreateHPCDCChunkerAPI();
+    Longtail_ChunkerAPI_HChunker c = 0;
+    int err = chunker_api->CreateChunker(chunker_api, min, avg, max, &c);
+    if (err)
+    {
+        SAFE_DISPOSE_API(own_c);
+        return -err;
+    }
+    const uint8_t* p = data;
+    const uint8_t* end = data + size;
+    while (p != end)
+    {
+        const void* next = 0;
+        err = chunker_api->NextChunkFromBuffer(chunker_api, c, p, (uint64_t)(end - p), &next);
+        if (err)
+        {
+            count = -err;
+            break;
+        }
+        if ((uint64_t)count < cap)
+            out_lens[count] = (uint32_t)((const uint8_t*)next - p);
+        ++count;
+        p = (const uint8_t*)next;
+    }
+    chunker_api->DisposeChunker(chunker_api, c);
+    SAFE_DISPOSE_API(own_c);
+    return count;
+}
+
+uint64_t refh_blake3(const void* data, uint32_t len)
+{
+    struct Longtail_HashAPI* h = Longtail_CreateBlake3HashAPI();
+    uint64_t out = 0;
+    static const char empty = 0;
+    h->HashBuffer(h, len, data ? data : &empty, &out);
+    SAFE_DISPOSE_API(h);
+    return out;
+}
+
+uint32_t refh_blake3_id(void) { return Longtail_GetBlake3HashType(); }
+uint32_t refh_lz4_type(void) { return Longtail_GetLZ4DefaultQuality(); }
+uint32_t refh_zstd_type(int which)
+{
+    switch (which)
+    {
+    case 0: return Longtail_GetZStdMinQuality();
+    case 1: return Longtail_GetZStdDefaultQuality();
+    case 2: return Longtail_GetZStdMaxQuality();
+    case 3: return Longtail_GetZStdHighQuality();
+    default: return Longtail_GetZStdLowQuality();
+    }
+}
+
+/* codec = 0 LZ4, 1 ZStd ; `api` may be a foreign (HIP) CompressionAPI, 0 => reference */
+static struct Longtail_CompressionAPI* make_codec(int codec)
+{
+    return codec == 0 ? Longtail_CreateLZ4CompressionAPI() : Longtail_CreateZStdCompressionAPI();
+}
+
+size_t refh_codec_bound(int codec, uint32_t settings, size_t n)
+{
+    struct Longtail_CompressionAPI* a = make_codec(codec);
+    size_t r = a->GetMaxCompressedSize(a, settings, n);
+    SAFE_DISPOSE_API(a);
+    return r;
+}
+
+int refh_codec_compress(int codec, uint32_t settings, const char* src, size_t n, char* dst, size_t cap, size_t* out_n)
+{
+    struct Longtail_CompressionAPI* a = make_codec(codec);
+    int err = a->Compress(a, settings, src, dst, n, cap, out_n);
+    SAFE_DISPOSE_API(a);
+    return err;
+}
+
+int refh_codec_decompress(int codec, const char* src, size_t n, char* dst, size_t cap, size_t* out_n)
+{
+    struct Longtail_CompressionAPI* a = make_codec(codec);
+    int err = a->Decompress(a, src, dst, n, cap, out_n);
+    SAFE_DISPOSE_API(a);
+    return err;
+}
+
+void refh_free(void* p) { Longtail_Free(p); }
+
+/* ------------------------------------------------------------------------------------------------
+ * end-to-end: in-memory tree -> Longtail_CreateVersionIndex (-> Longtail_WriteContent)
+ * ---------------------------------------------------------------------------------------------- */
+static int make_parent_dirs(struct Longtail_StorageAPI* s, const char* path)
+{
+    char* tmp = Longtail_Strdup(path);
+    int err = 0;
+    for (char* p = tmp; *p && !err; ++p)
+    {
+        if (*p == '/' && p != tmp)
+        {
+            *p = 0;
+            if (!s->IsDir(s, tmp))
+                err = s->CreateDir(s, tmp);
+            *p = '/';
+        }
+    }
+    Longtail_Free(tmp);
+    return err;
+}
+
+static int fill_storage(struct Longtail_StorageAPI* s, const char* root, uint32_t nfiles, const char* const* names,
+                        const uint8_t* const* datas, const uint64_t* sizes)
+{
+    int err = 0;
+    if (!s->IsDir(s, root))
+        err = s->CreateDir(s, root);
+    for (uint32_t i = 0; i < nfiles && !err; ++i)
+    {
+        char* path = s->ConcatPath(s, root, names[i]);
+        err = make_parent_dirs(s, path);
+        if (!err)
+        {
+            Longtail_StorageAPI_HOpenFile w = 0;
+            err = s->OpenWriteFile(s, path, 0, &w);
+            if (!err)
+            {
+                if (sizes[i])
+                    err = s->Write(s, w, 0, sizes[i], datas[i]);
+                s->CloseFile(s, w);
+            }
+        }
+        Longtail_Free(path);
+    }
+    return err;
+}
+
+struct refh_tree
+{
+    struct Longtail_StorageAPI* storage;
+    struct Longtail_JobAPI* jobs;
+    struct Longtail_FileInfos* files;
+    uint32_t* tags;
+};
+
+static void tree_free(struct refh_tree* t)
+{
+    Longtail_Free(t->tags);
+    Longtail_Free(t->files);
+    SAFE_DISPOSE_API(t->jobs);
+    SAFE_DISPOSE_API(t->storage);
+}
+
+static int tree_make(struct refh_tree* t, uint32_t nfiles, const char* const* names, const uint8_t* const* datas,
+                     const uint64_t* sizes, int workers, uint32_t tag)
+{
+    memset(t, 0, sizeof *t);
+    t->storage = Longtail_CreateInMemStorageAPI();
+    t->jobs = Longtail_CreateBikeshedJobAPI((uint32_t)workers, 0);
+    int err = fill_storage(t->storage, "root", nfiles, names, datas, sizes);
+    if (!err)
+        err = Longtail_GetFilesRecursively2(t->storage, t->jobs, 0, 0, 0, "root", &t->files);
+    if (!err)
+    {
+        t->tags = (uint32_t*)Longtail_Alloc("refh", sizeof(uint32_t) * (t->files->m_Count + 1));
+        for (uint32_t i = 0; i < t->files->m_Count; ++i)
+            t->tags[i] = tag;
+    }
+    if (err)
+        tree_free(t);
+    return err;
+}
+
+/* Build the VersionIndex of an in-memory tree with the given plugins (0 => reference plugin) and
+ * return its serialized form (Longtail_WriteVersionIndexToBuffer) -- free with refh_free(). */
+int refh_version_index(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_HashAPI* hash_api, uint32_t nfiles,
+                       const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
+                       uint32_t target_chunk_size, int workers, uint32_t tag, void** out_buf, uint64_t* out_size,
+                       double* out_seconds)
+{
+    struct refh_tree t;
+    struct Longtail_ChunkerAPI* own_c = 0;
+    struct Longtail_HashAPI* own_h = 0;
+    struct Longtail_VersionIndex* vi = 0;
+    int err = tree_make(&t, nfiles, names, datas, sizes, workers, tag);
+    if (err)
+        return err;
+    if (!chunker_api)
+        chunker_api = own_c = Longtail_CreateHPCDCChunkerAPI();
+    if (!hash_api)
+        hash_api = own_h = Longtail_CreateBlake3HashAPI();
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    err = Longtail_CreateVersionIndex(t.storage, hash_api, chunker_api, t.jobs, 0, 0, 0, "root", t.files, t.tags,
+                                      target_chunk_size, 0, &vi);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    if (out_seconds)
+        *out_seconds = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+    if (!err)
+    {
+        size_t sz = 0;
+        err = Longtail_WriteVersionIndexToBuffer(vi, out_buf, &sz);
+        *out_size = sz;
+    }
+    Longtail_Free(vi);
+    SAFE_DISPOSE_API(own_c);
+    SAFE_DISPOSE_API(own_h);
+    tree_free(&t);
+    return err;
+}
+
+/* ---- synchronous wrappers for the async block-store calls ---- */
+struct sync_existing
+{
+    struct Longtail_AsyncGetExistingContentAPI api;
+    HLongtail_Sema sema;
+    struct Longtail_StoreIndex* index;
+    int err;
+};
+static void sync_existing_done(struct Longtail_AsyncGetExistingContentAPI* a, struct Longtail_StoreIndex* si, int err)
+{
+    struct sync_existing* s = (struct sync_existing*)a;
+    s->index = si;
+    s->err = err;
+    Longtail_PostSema(s->sema, 1);
+}
+static int get_existing(struct Longtail_BlockStoreAPI* bs, uint32_t n, const TLongtail_Hash* hashes,
+                        struct Longtail_StoreIndex** out)
+{
+    struct sync_existing s;
+    memset(&s, 0, sizeof s);
+    s.api.OnComplete = sync_existing_done;
+    void* mem = Longtail_Alloc("refh", Longtail_GetSemaSize());
+    Longtail_CreateSema(mem, 0, &s.sema);
+    int err = bs->GetExistingContent(bs, n, hashes, 0, &s.api);
+    if (!err)
+    {
+        Longtail_WaitSema(s.sema, LONGTAIL_TIMEOUT_INFINITE);
+        err = s.err;
+        *out = s.index;
+    }
+    Longtail_DeleteSema(s.sema);
+    Longtail_Free(mem);
+    return err;
+}
+
+/* one compression type -> caller-supplied CompressionAPI (kept alive by the caller) */
+static struct Longtail_CompressionAPI* g_foreign_codec;
+static uint32_t g_foreign_type;
+static struct Longtail_CompressionAPI* foreign_for_type(uint32_t type, uint32_t* out_settings)
+{
+    if (type != g_foreign_type || !g_foreign_codec)
+        return 0;
+    *out_settings = type;
+    return g_foreign_codec;
+}
+
+/* Non-owning wrapper: the registry disposes the APIs it created, the foreign one belongs to the caller. */
+struct borrowed_codec
+{
+    struct Longtail_CompressionAPI api;
+    struct Longtail_CompressionAPI* inner;
+};
+static void borrowed_dispose(struct Longtail_API* a) { Longtail_Free(a); }
+static size_t borrowed_bound(struct Longtail_CompressionAPI* a, uint32_t s, size_t n)
+{
+    struct borrowed_codec* b = (struct borrowed_codec*)a;
+    return b->inner->GetMaxCompressedSize(b->inner, s, n);
+}
+static int borrowed_compress(struct Longtail_CompressionAPI* a, uint32_t s, const char* src, char* dst, size_t n,
+                             size_t cap, size_t* out_n)
+{
+    struct borrowed_codec* b = (struct borrowed_codec*)a;
+    return b->inner->Compress(b->inner, s, src, dst, n, cap, out_n);
+}
+static int borrowed_decompress(struct Longtail_CompressionAPI* a, const char* src, char* dst, size_t n, size_t cap,
+                               size_t* out_n)
+{
+    struct borrowed_codec* b = (struct borrowed_codec*)a;
+    return b->inner->Decompress(b->inner, src, dst, n, cap, out_n);
+}
+static struct Longtail_CompressionAPI* borrowed_for_type(uint32_t type, uint32_t* out_settings)
+{
+    if (!foreign_for_type(type, out_settings))
+        return 0;
+    struct borrowed_codec* b = (struct borrowed_codec*)Longtail_Alloc("refh", sizeof *b);
+    b->api.m_API.Dispose = borrowed_dispose;
+    b->api.GetMaxCompressedSize = borrowed_bound;
+    b->api.Compress = borrowed_compress;
+    b->api.Decompress = borrowed_decompress;
+    b->inner = g_foreign_codec;
+    return &b->api;
+}
+
+static struct Longtail_CompressionRegistryAPI* make_registry(struct Longtail_CompressionAPI* foreign, uint32_t type)
+{
+    Longtail_CompressionRegistry_CreateForTypeFunc funcs[3];
+    uint32_t n = 0;
+    g_foreign_codec = foreign;
+    g_foreign_type = type;
+    if (foreign)
+        funcs[n++] = borrowed_for_type; /* consulted first: overrides the reference codec for `type` */
+    funcs[n++] = Longtail_CompressionRegistry_CreateForLZ4;
+    funcs[n++] = Longtail_CompressionRegistry_CreateForZstd;
+    return Longtail_CreateDefaultCompressionRegistry(n, funcs);
+}
+
+/* Ingest an in-memory tree end to end (UpSync sequence, cmd/main.c:972-1153):
+ *   CreateVersionIndex -> GetExistingContent(empty store) -> CreateMissingContent -> WriteContent
+ * through compressblockstore(fsblockstore(in-mem target)) with block tag `tag`, where the codec for
+ * `tag` is `codec_api` (0 => reference), then RESTORE the tree with a reference-only registry
+ * (Longtail_WriteVersion) and compare every file byte for byte.
+ * Returns 0 when everything round-trips; stats in out_*. */
+int refh_ingest_roundtrip(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_HashAPI* hash_api,
+                          struct Longtail_CompressionAPI* codec_api, uint32_t tag, uint32_t nfiles,
+                          const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
+                          uint32_t target_chunk_size, uint32_t max_block_size, uint32_t max_chunks_per_block,
+                          int workers, uint64_t* out_chunk_count, uint64_t* out_block_count,
+                          uint64_t* out_stored_bytes, double* out_seconds_index, double* out_seconds_write)
+{
+    struct refh_tree t;
+    struct Longtail_ChunkerAPI* own_c = 0;
+    struct Longtail_HashAPI* own_h = 0;
+    struct Longtail_VersionIndex* vi = 0;
+    struct Longtail_StoreIndex* existing = 0;
+    struct Longtail_StoreIndex* missing = 0;
+    struct timespec a, b;
+    int err = tree_make(&t, nfiles, names, datas, sizes, workers, tag);
+    if (err)
+        return err;
+    if (!chunker_api)
+        chunker_api = own_c = Longtail_CreateHPCDCChunkerAPI();
+    if (!hash_api)
+        hash_api = own_h = Longtail_CreateBlake3HashAPI();
+
+    struct Longtail_StorageAPI* target = Longtail_CreateInMemStorageAPI();
+    struct Longtail_CompressionRegistryAPI* reg_w = make_registry(codec_api, tag);
+    struct Longtail_BlockStoreAPI* fs = Longtail_CreateFSBlockStoreAPI(t.jobs, target, "store", 0, 0);
+    struct Longtail_BlockStoreAPI* cbs = Longtail_CreateCompressBlockStoreAPI(fs, reg_w);
+
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    err = Longtail_CreateVersionIndex(t.storage, hash_api, chunker_api, t.jobs, 0, 0, 0, "root", t.files, t.tags,
+                                      target_chunk_size, 0, &vi);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    if (out_seconds_index)
+        *out_seconds_index = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+    if (!err)
+        err = get_existing(cbs, *vi->m_ChunkCount, vi->m_ChunkHashes, &existing);
+    if (!err)
+        err = Longtail_CreateMissingContent(hash_api, existing, vi, max_block_size, max_chunks_per_block, &missing);
+    if (!err)
+    {
+        clock_gettime(CLOCK_MONOTONIC, &a);
+        err = Longtail_WriteContent(t.storage, cbs, t.jobs, 0, 0, 0, missing, vi, "root");
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        if (out_seconds_write)
+            *out_seconds_write = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+    }
+    if (!err)
+    {
+        struct Longtail_BlockStore_Stats st;
+        memset(&st, 0, sizeof st);
+        fs->GetStats(fs, &st);
+        if (out_chunk_count)
+            *out_chunk_count = *vi->m_ChunkCount;
+        if (out_block_count)
+            *out_block_count = *missing->m_BlockCount;
+        if (out_stored_bytes)
+            *out_stored_bytes = st.m_StatU64[Longtail_BlockStoreAPI_StatU64_PutStoredBlock_Byte_Count];
+    }
+    SAFE_DISPOSE_API(cbs);
+    SAFE_DISPOSE_API(reg_w);
+
+    /* restore through a REFERENCE-ONLY registry */
+    if (!err)
+    {
+        struct Longtail_CompressionRegistryAPI* reg_r = make_registry(0, 0);
+        struct Longtail_BlockStoreAPI* cbs_r = Longtail_CreateCompressBlockStoreAPI(fs, reg_r);
+        struct Longtail_StorageAPI* restored = Longtail_CreateInMemStorageAPI();
+        struct Longtail_StoreIndex* have = 0;
+        err = get_existing(cbs_r, *vi->m_ChunkCount, vi->m_ChunkHashes, &have);
+        if (!err)
+            err = Longtail_WriteVersion(cbs_r, restored, t.jobs, 0, 0, 0, have, vi, "out", 1);
+        for (uint32_t i = 0; i < nfiles && !err; ++i)
+        {
+            char* path = restored->ConcatPath(restored, "out", names[i]);
+            Longtail_StorageAPI_HOpenFile r = 0;
+            uint64_t sz = 0;
+            err = restored->OpenReadFile(restored, path, &r);
+            if (!err)
+            {
+                err = restored->GetSize(restored, r, &sz);
+                if (!err && sz != sizes[i])
+                    err = 2000;
+                if (!err && sz)
+                {
+                    void* buf = Longtail_Alloc("refh", (size_t)sz);
+                    err = restored->Read(restored, r, 0, sz, buf);
+                    if (!err && memcmp(buf, datas[i], (size_t)sz) != 0)
+                        err = 2001;
+                    Longtail_Free(buf);
+                }
+                restored->CloseFile(restored, r);
+            }
+            Longtail_Free(path);
+        }
+        Longtail_Free(have);
+        SAFE_DISPOSE_API(cbs_r);
+        SAFE_DISPOSE_API(reg_r);
+        SAFE_DISPOSE_API(restored);
+    }
+    Longtail_Free(missing);
+    Longtail_Free(existing);
+    Longtail_Free(vi);
+    SAFE_DISPOSE_API(fs);
+    SAFE_DISPOSE_API(target);
+    SAFE_DISPOSE_API(own_c);
+    SAFE_DISPOSE_API(own_h);
+    tree_free(&t);
+    return err;
+}
+
+int refh_cpu_count(void) { return (int)Longtail_GetCPUCount(); }
