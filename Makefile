@@ -1,0 +1,44 @@
+# Builds longtail_amd/liblongtail_hip.so (HIP kernels for gfx950 + the plain-C plugin layer), in-tree so that
+# the built library travels with the repository snapshot to the GPU box.
+#   make            product library
+#   make oracle     test infrastructure (oracle/liblongtail_oracle.so and, when /root/reference exists, oracle/_ref)
+#   make all        both
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+CSRC    := longtail_amd/csrc
+OBJDIR  := build/obj
+LIB     := longtail_amd/liblongtail_hip.so
+
+HIP_SRC := $(CSRC)/lthip_ctx.hip $(CSRC)/k_buzhash.hip $(CSRC)/k_blake3.hip $(CSRC)/k_lz4.hip $(CSRC)/k_zstd.hip \
+           $(CSRC)/k_dedup.hip $(CSRC)/k_synth.hip
+C_SRC   := $(CSRC)/plugin/plugin_common.c $(CSRC)/plugin/plugin_chunker.c $(CSRC)/plugin/plugin_hash.c \
+           $(CSRC)/plugin/plugin_codec.c
+HIP_OBJ := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(HIP_SRC))
+C_OBJ   := $(patsubst $(CSRC)/plugin/%.c,$(OBJDIR)/%.o,$(C_SRC))
+
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function
+CFLAGS   := -O2 -std=c99 -D_POSIX_C_SOURCE=200809L -fPIC -fvisibility=hidden -Wall -Wextra -pthread
+
+.PHONY: lib oracle all clean
+lib: $(LIB)
+all: lib oracle
+
+$(OBJDIR):
+	mkdir -p $(OBJDIR)
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/lthip_internal.h include/longtail_hip.h include/longtail_abi.h include/longtail_synth.h | $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJDIR)/%.o: $(CSRC)/plugin/%.c $(CSRC)/plugin/plugin_common.h include/longtail_hip.h include/longtail_abi.h | $(OBJDIR)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(LIB): $(HIP_OBJ) $(C_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJ) $(C_OBJ) -lpthread
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean

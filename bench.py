@@ -1,0 +1,342 @@
+#!/usr/bin/env python3
+"""bench.py -- ingest throughput (chunk + BLAKE3 + LZ4) of the HIP hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2]): a synthetic tree of 1 MiB files, 64 GiB PER GPU (weak scaling:
+rank r owns files [r*F, (r+1)*F) of the N*64 GiB tree), bytes from include/longtail_synth.h, already resident in HBM
+when the timed region starts.  One step = the whole hot path over the rank's shard:
+  plan -> buzhash candidate scan -> cut selection -> compaction -> BLAKE3 leaves/parents            (phase 1)
+  -> [N>1: RCCL all-gather of per-rank chunk hashes] -> first-seen dedup                              (exchange)
+  -> greedy block packing of unique chunks (src/longtail.c:6801-6860, 8 MiB x 1.1, <= 1024 chunks)
+  -> per-block LZ4 (segments + stitch) into a bounded output arena                                    (phase 2)
+value = bytes of all ranks / max-over-ranks wall time of K steps (barrier + synchronize on both sides).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+MASK64 = (1 << 64) - 1
+
+
+def synth_mix(z: np.ndarray) -> np.ndarray:
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def asset_seeds(tree_seed: int, first: int, count: int) -> np.ndarray:
+    """lt_synth_asset_seed (include/longtail_synth.h) vectorised."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(first, first + count, dtype=np.uint64) + np.uint64(1)
+        return synth_mix(np.uint64(tree_seed) + np.uint64(0x9E3779B97F4A7C15) * idx)
+
+
+def pack_blocks(lens: np.ndarray, max_block: int, max_chunks: int):
+    """Greedy packing of Longtail_CreateStoreIndex (src/longtail.c:6801-6860): returns block start indices (+ end)."""
+    n = len(lens)
+    cs = np.cumsum(lens, dtype=np.int64)
+    limit = max_block + max_block // 10
+    starts = []
+    i = 0
+    while i < n:
+        base = int(cs[i - 1]) if i else 0
+        j = int(np.searchsorted(cs, base + limit, side="right"))
+        j = max(min(j, i + max_chunks), i + 1)
+        starts.append(i)
+        i = j
+    starts.append(n)
+    return np.asarray(starts, dtype=np.int64), cs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gib", type=float, default=64.0, help="GiB of assets per GPU")
+    ap.add_argument("--file-mib", type=float, default=1.0)
+    ap.add_argument("--kind", choices=["random", "mixed", "zero"], default="random")
+    ap.add_argument("--target-chunk-size", type=int, default=65536)
+    ap.add_argument("--block-size", type=int, default=8 << 20)
+    ap.add_argument("--max-chunks-per-block", type=int, default=1024)
+    ap.add_argument("--lz4-batch-gib", type=float, default=8.0)
+    ap.add_argument("--segment-log2", type=int, default=0)
+    ap.add_argument("--no-compress", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from longtail_amd.lib import Context, chunker_params, load
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    lib = load()
+    if not torch.cuda.is_available() or lib.device_count() == 0:
+        raise SystemExit("bench.py needs a GPU and liblongtail_hip.so: there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    ctx = Context(local_rank)
+    kind = {"random": 0, "mixed": 1, "zero": 2}[args.kind]
+    mn, av, mx = chunker_params(args.target_chunk_size)
+    file_bytes = int(args.file_mib * (1 << 20))
+    file_bytes -= file_bytes % 16
+    nfiles = max(1, int(args.gib * (1 << 30)) // file_bytes)
+    shard_bytes = nfiles * file_bytes
+
+    # ---- inputs resident in HBM (untimed) ----
+    data = torch.empty(shard_bytes + 256, dtype=torch.uint8, device=dev)
+    part_offsets = np.arange(nfiles, dtype=np.uint64) * np.uint64(file_bytes)
+    part_sizes = np.full(nfiles, file_bytes, dtype=np.uint64)
+    seeds = asset_seeds(0x10C0FFEE, rank * nfiles, nfiles)
+    ctx.synth_fill(data, part_offsets, part_sizes, seeds, kind)
+    ctx.sync()
+
+    # ---- output arenas (allocated once; the hot path never allocates in steady state) ----
+    probe = ctx.make_plan(part_offsets, part_sizes, mn, av, mx)
+    cap = max(1, probe.capacity)
+    probe.close()
+    out_offs = torch.empty(cap, dtype=torch.int64, device=dev)
+    out_lens = torch.empty(cap, dtype=torch.int32, device=dev)
+    out_hash = torch.empty(cap, dtype=torch.int64, device=dev)
+    out_first = torch.empty(nfiles + 1, dtype=torch.int32, device=dev)
+    batch_bytes = int(args.lz4_batch_gib * (1 << 30))
+    limit = args.block_size + args.block_size // 10
+    dst_arena_bytes = batch_bytes + batch_bytes // 255 + (batch_bytes // args.block_size + 2) * 64 + 2 * (limit + limit // 255 + 64)
+    dst = torch.empty(dst_arena_bytes, dtype=torch.uint8, device=dev)
+    gather_buf = None
+    stats = {}
+
+    def step():
+        t0 = time.perf_counter()
+        plan = ctx.make_plan(part_offsets, part_sizes, mn, av, mx)
+        total, _, _, _, _ = ctx.chunk_hash(plan, data, outputs=(out_offs, out_lens, out_hash, out_first), sync=True)
+        plan.close()
+        t1 = time.perf_counter()
+        # ---- exchange + dedup (src/longtail.c:2951-2970) ----
+        if world > 1:
+            counts = torch.zeros(world, dtype=torch.int64, device=dev)
+            mine = torch.tensor([total], dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(counts, mine)
+            counts_h = counts.cpu().numpy()
+            pad = int(counts_h.max())
+            nonlocal gather_buf
+            if gather_buf is None or gather_buf.numel() < pad * world:
+                gather_buf = torch.empty(pad * world, dtype=torch.int64, device=dev)
+            send = out_hash[:pad] if pad <= cap else torch.nn.functional.pad(out_hash[:total], (0, pad - total))
+            dist.all_gather_into_tensor(gather_buf[: pad * world], send.contiguous())
+            pieces = [gather_buf[r * pad : r * pad + int(counts_h[r])] for r in range(world)]
+            all_hashes = torch.cat(pieces)
+            my_base = int(counts_h[:rank].sum())
+        else:
+            all_hashes = out_hash[:total]
+            my_base = 0
+        first_idx, uniq = ctx.dedup_first_seen(all_hashes)
+        mine_first = first_idx[my_base : my_base + total]
+        unique_mask = mine_first == torch.arange(my_base, my_base + total, dtype=torch.int32, device=dev)
+        n_unique_local = int(unique_mask.sum().item())
+        t2 = time.perf_counter()
+        comp_bytes = 0
+        nblocks = 0
+        if not args.no_compress:
+            lens_h = out_lens[:total].cpu().numpy().view(np.uint32).astype(np.int64)
+            offs_h = out_offs[:total].cpu().numpy().view(np.uint64).astype(np.int64)
+            if n_unique_local != total:
+                keep = unique_mask.cpu().numpy()
+                lens_h, offs_h = lens_h[keep], offs_h[keep]
+            starts, cs = pack_blocks(lens_h, args.block_size, args.max_chunks_per_block)
+            b_first, b_last = starts[:-1], starts[1:] - 1
+            b_off = offs_h[b_first]
+            b_size = (offs_h[b_last] + lens_h[b_last]) - b_off
+            packed = cs[b_last] - np.concatenate([[0], cs[b_last[:-1]]]) if len(b_last) else np.zeros(0, np.int64)
+            if not (packed == b_size).all():
+                raise SystemExit("non-contiguous blocks (dedup holes / unaligned files) need the gather path: not in this bench")
+            nblocks = len(b_off)
+            # batches that fit the output arena
+            bounds = b_size + b_size // 255 + 16
+            aligned = (bounds + 63) // 64 * 64
+            i = 0
+            size_tensors = []
+            while i < nblocks:
+                acc = np.cumsum(aligned[i:])
+                j = i + max(1, int(np.searchsorted(acc, dst_arena_bytes, side="right")))
+                j = min(j, i + max(1, int(np.searchsorted(np.cumsum(b_size[i:]), batch_bytes, side="right"))), nblocks)
+                j = max(j, i + 1)
+                d_offs = np.concatenate([[0], np.cumsum(aligned[i:j])[:-1]])
+                size_tensors.append(ctx.lz4_compress_blocks(data, b_off[i:j], b_size[i:j], dst, d_offs, bounds[i:j], args.segment_log2))
+                i = j
+            sizes = torch.cat(size_tensors).to(torch.int64)
+            comp_bytes = int(sizes.sum().item())
+            if int((sizes == 0).sum().item()) != 0:
+                raise SystemExit("a block did not fit its LZ4 bound: encoder bug")
+        ctx.sync()
+        t3 = time.perf_counter()
+        stats.update(chunks=total, unique_local=n_unique_local, unique_global=int(uniq.item()), blocks=nblocks,
+                     compressed_bytes=comp_bytes, t_phase1=t1 - t0, t_exchange=t2 - t1, t_phase2=t3 - t2)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.timing(True)
+    ctx.timing_reset()
+    phase = np.zeros(3)
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        phase += [stats["t_phase1"], stats["t_exchange"], stats["t_phase2"]]
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    ktimes = ctx.timing_get()
+    ctx.timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_bytes = shard_bytes * world
+    value = total_bytes * args.steps / elapsed / 1e9
+
+    # ---- roofline of the dominant kernel (algorithmic bytes / launch; DESIGN.md "Measurement") ----
+    comp = stats["compressed_bytes"]
+    alg_bytes = {
+        "buzhash": shard_bytes,                 # N read once
+        "blake3_leaf": shard_bytes,             # N read once
+        "lz4_segments": shard_bytes,            # N read (sequence streams are a by-product)
+        "lz4_stitch": shard_bytes + comp,       # literals/streams read + payload written
+    }
+    kern = {}
+    for name, (ms, n) in ktimes.items():
+        if n:
+            per_step_ms = ms / args.steps
+            kern[name] = {"ms_per_step": round(per_step_ms, 3), "launches_per_step": n / args.steps}
+            if name in alg_bytes:
+                kern[name]["GBps"] = round(alg_bytes[name] / (per_step_ms * 1e-3) / 1e9, 1)
+    dom = max((k for k in kern if k in alg_bytes), key=lambda k: kern[k]["ms_per_step"], default=None)
+    roofline = None
+    if dom:
+        launches = kern[dom]["launches_per_step"]
+        avg_ms = kern[dom]["ms_per_step"] / launches
+        achieved = alg_bytes[dom] / launches / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(alg_bytes[dom] / launches), "avg_launch_ms": round(avg_ms, 3)}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(args, kind, file_bytes)
+
+    if rank == 0:
+        line = {
+            "metric": "ingest GB/s (chunk+hash+compress)",
+            "value": round(value, 3),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.gib:g} GiB tree of {args.file_mib:g} MiB {args.kind} files per GPU, chunk+BLAKE3+LZ4 "
+                            f"(BASELINE.json configs[2]{'/[3]' if world > 1 else ''})",
+                "target_chunk_size": args.target_chunk_size, "min_avg_max": [mn, av, mx], "block_size": args.block_size,
+                "max_chunks_per_block": args.max_chunks_per_block, "bytes_per_gpu": shard_bytes, "files_per_gpu": nfiles,
+                "sharding": "by file, RCCL all-gather of chunk hashes for dedup" if world > 1 else "single GPU",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "kernels": kern,
+            "phase_ms": {"chunk_hash": round(phase[0] / args.steps * 1e3, 2), "exchange_dedup": round(phase[1] / args.steps * 1e3, 2),
+                         "pack_compress": round(phase[2] / args.steps * 1e3, 2)},
+            "result": {"chunks": stats["chunks"], "unique_chunks_global": stats["unique_global"], "blocks": stats["blocks"],
+                       "compressed_bytes": stats["compressed_bytes"],
+                       "ratio": round(shard_bytes / stats["compressed_bytes"], 4) if stats["compressed_bytes"] else None},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(args, kind, file_bytes):
+    """The reference's bikeshed-threaded CPU path (oracle/_ref) -- or the single-thread port (oracle/) when the
+    reference build is not present -- on a bounded sample of the SAME workload, timed on this host's cores."""
+    from tests._libs import have_ref, oracle, ref
+
+    o = oracle()
+    ncores = os.cpu_count() or 1
+    target = args.cpu_seconds
+
+    def make_files(n):
+        seeds = asset_seeds(0x10C0FFEE, 0, n)
+        return [(f"dir{i % 256:03d}/file{i:05d}.bin", o.synth(file_bytes, int(seeds[i]), kind)) for i in range(n)]
+
+    if have_ref():
+        r = ref()
+        workers = int(r.dll.refh_cpu_count())
+        n = 256
+        best = None
+        spent = 0.0
+        while True:
+            files = make_files(n)
+            t0 = time.perf_counter()
+            res = r.ingest_time(files, args.target_chunk_size, args.block_size, args.max_chunks_per_block, r.lz4_type, workers)
+            wall = time.perf_counter() - t0
+            if res["err"]:
+                return {"error": res["err"]}
+            secs = res["seconds_index"] + res["seconds_write"]
+            best = (n, secs, res)
+            spent += wall
+            if secs * 4 > target / 2 or n * file_bytes >= (8 << 30) or spent > target:
+                break
+            n *= 4
+        n, secs, res = best
+        return {"value": round(n * file_bytes / secs / 1e9, 3), "unit": "GB/s", "cores": workers, "kind": "reference",
+                "sample": f"{n} x {file_bytes} B files of the same tree; Longtail_CreateVersionIndex {res['seconds_index']:.3f} s + "
+                          f"Longtail_WriteContent {res['seconds_write']:.3f} s (reference hpcdc+BLAKE3+LZ4, bikeshed {workers} workers, "
+                          f"in-memory storage, null block sink)",
+                "host_cpus": ncores}
+    from tests._libs import IngestResult
+
+    n = 64
+    files = make_files(n)
+    blob = np.concatenate([d for _, d in files])
+    out = IngestResult()
+    err = o.dll.lto_ingest(blob.ctypes.data, len(blob), file_bytes, args.target_chunk_size, args.block_size, 1, out)
+    secs = out.seconds_chunk + out.seconds_hash + out.seconds_compress
+    return {"value": round(len(blob) / secs / 1e9, 3) if not err else None, "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"{n} x {file_bytes} B files, single-thread C restatement (oracle/)", "host_cpus": ncores}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,185 @@
+/* longtail_hip.h -- C ABI of liblongtail_hip.so: MI355X (gfx950) implementations of longtail's
+ * chunk -> hash -> compress hot path.
+ *
+ * Two layers, both plain C (pointers + sizes, errno-style int results, no C++/torch types):
+ *
+ *  A. PLUGIN CONSTRUCTORS -- what a longtail embedder binds instead of the CPU constructors.  They
+ *     return longtail's own struct-of-function-pointer objects (include/longtail_abi.h), so they drop
+ *     into Longtail_CreateVersionIndex / Longtail_WriteContent / the registries unchanged.
+ *
+ *  B. BULK DEVICE API (lthip_*) -- the thin shim over the HIP kernels that layer A is written on, for
+ *     callers that already hold asset bytes in HBM (bench.py, the multi-GPU driver, tests).
+ *
+ * Every entry point cites the reference interface it replaces.
+ */
+#ifndef LONGTAIL_HIP_H
+#define LONGTAIL_HIP_H
+
+#include "longtail_abi.h"
+
+#if defined(_WIN32)
+#define LTHIP_EXPORT
+#else
+#define LTHIP_EXPORT __attribute__((visibility("default")))
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* =====================================================================================================
+ * A. plugin constructors
+ * =================================================================================================== */
+
+/* Replaces Longtail_CreateHPCDCChunkerAPI() (lib/hpcdcchunker/longtail_hpcdcchunker.h:10,
+ * implementation longtail_hpcdcchunker.c:332-589).  GetMinChunkSize -> 48.  NextChunk drains the
+ * feeder into pinned host memory (windows of up to 64 MiB), computes ALL cut points and ALL chunk
+ * hashes of the window on the GPU, then hands out ranges whose `buf` points into the pinned window;
+ * ESPIPE + {0,total,0} at end of stream exactly like the reference. */
+LTHIP_EXPORT struct Longtail_ChunkerAPI* Longtail_CreateHipChunkerAPI(void);
+
+/* Replaces Longtail_CreateBlake3HashAPI() (lib/blake3/longtail_blake3.h, implementation
+ * longtail_blake3.c:6-141).  GetIdentifier -> 0x626c6b33 ('blk3') so indexes are interchangeable with
+ * CPU-built ones.  HashBuffer on a range previously handed out by a HIP chunker returns the digest the
+ * GPU already computed; any other buffer is hashed on the GPU on demand. */
+LTHIP_EXPORT struct Longtail_HashAPI* Longtail_CreateHipBlake3HashAPI(void);
+
+/* Replaces Longtail_CreateLZ4CompressionAPI() / Longtail_CompressionRegistry_CreateForLZ4()
+ * (lib/lz4/longtail_lz4.h:10-12, longtail_lz4.c:12-23,47-123).  Same type id 'lz42', same bound
+ * (n + n/255 + 16), payload = one LZ4 *block* that LZ4_decompress_safe decodes. */
+LTHIP_EXPORT struct Longtail_CompressionAPI* Longtail_CreateHipLZ4CompressionAPI(void);
+LTHIP_EXPORT struct Longtail_CompressionAPI* Longtail_CompressionRegistry_CreateForHipLZ4(uint32_t compression_type, uint32_t* out_settings);
+LTHIP_EXPORT uint32_t Longtail_GetHipLZ4DefaultQuality(void);
+
+/* Replaces Longtail_CreateZStdCompressionAPI() / Longtail_CompressionRegistry_CreateForZstd()
+ * (lib/zstd/longtail_zstd.h:10-16, longtail_zstd.c:30-41,72-177).  Type ids 'ztd1'..'ztd5'.
+ * Stage 1 encoder: concatenated zstd frames of raw / RLE blocks (valid for ZSTD_decompressDCtx). */
+LTHIP_EXPORT struct Longtail_CompressionAPI* Longtail_CreateHipZStdCompressionAPI(void);
+LTHIP_EXPORT struct Longtail_CompressionAPI* Longtail_CompressionRegistry_CreateForHipZstd(uint32_t compression_type, uint32_t* out_settings);
+
+/* Route the plugins' host allocations through the embedder's allocator, e.g. Longtail_Alloc /
+ * Longtail_Free (src/longtail.h:967-974) so memtracer leak checks see them.  Default malloc/free. */
+typedef void* (*Longtail_Hip_AllocFunc)(const char* context, size_t size);
+typedef void (*Longtail_Hip_FreeFunc)(void* p);
+LTHIP_EXPORT void Longtail_Hip_SetAllocator(Longtail_Hip_AllocFunc alloc_func, Longtail_Hip_FreeFunc free_func);
+
+/* GPU used by plugin objects created afterwards (default: $LONGTAIL_HIP_DEVICE or 0). */
+LTHIP_EXPORT int Longtail_Hip_SetDevice(int device);
+
+/* =====================================================================================================
+ * B. bulk device API
+ * =================================================================================================== */
+
+typedef struct lthip_ctx lthip_ctx;   /* one GPU + one stream + scratch pools; NOT thread-safe: one per host thread */
+typedef struct lthip_plan lthip_plan; /* device-resident description of a batch of parts */
+
+/* hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream), or NULL for
+ * a private non-blocking stream owned by the context. */
+LTHIP_EXPORT int lthip_ctx_create(int device, void* hip_stream, lthip_ctx** out_ctx);
+LTHIP_EXPORT void lthip_ctx_destroy(lthip_ctx* ctx);
+LTHIP_EXPORT int lthip_ctx_sync(lthip_ctx* ctx);
+LTHIP_EXPORT const char* lthip_ctx_error(const lthip_ctx* ctx); /* text of the last failure */
+LTHIP_EXPORT int lthip_device_count(void);
+
+/* Memory helpers so that plain-C callers (the plugin layer) need no HIP headers.  Copies are
+ * asynchronous on the context's stream: lthip_ctx_sync() before reading a d2h destination. */
+LTHIP_EXPORT int lthip_malloc_device(lthip_ctx* ctx, size_t bytes, void** out);
+LTHIP_EXPORT void lthip_free_device(lthip_ctx* ctx, void* p);
+LTHIP_EXPORT int lthip_malloc_pinned(lthip_ctx* ctx, size_t bytes, void** out);
+LTHIP_EXPORT void lthip_free_pinned(lthip_ctx* ctx, void* p);
+LTHIP_EXPORT int lthip_copy_h2d(lthip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+LTHIP_EXPORT int lthip_copy_d2h(lthip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+/* Per-kernel timing with HIP events on the context's stream (bench.py roofline leg). */
+enum lthip_kernel_id
+{
+    LTHIP_K_BUZHASH = 0,  /* candidate scan                     (hpcdcchunker.c:266-306) */
+    LTHIP_K_SELECT = 1,   /* cut selection                      (hpcdcchunker.c:250-264,281-309) */
+    LTHIP_K_COMPACT = 2,  /* scans + compaction of chunk lists  (src/longtail.c:2499-2517) */
+    LTHIP_K_B3_LEAF = 3,  /* BLAKE3 leaves                      (blake3.c:118-151) */
+    LTHIP_K_B3_PARENT = 4,/* BLAKE3 parents + root              (blake3.c:216-249,576-618) */
+    LTHIP_K_LZ4_SEG = 5,  /* LZ4 segment encoder                (lz4.c:930-1338) */
+    LTHIP_K_LZ4_STITCH = 6,/* LZ4 stitch scan + compaction copy */
+    LTHIP_K_OTHER = 7,
+    LTHIP_K_COUNT = 8
+};
+LTHIP_EXPORT int lthip_timing_enable(lthip_ctx* ctx, int on);
+LTHIP_EXPORT int lthip_timing_reset(lthip_ctx* ctx);
+/* resolves pending events (synchronises the stream); total milliseconds and launch count per kernel id */
+LTHIP_EXPORT int lthip_timing_get(lthip_ctx* ctx, int kernel_id, double* out_total_ms, uint64_t* out_launches);
+
+/* ---- phase 1: chunk + hash ------------------------------------------------------------------------
+ * A *part* is what the reference chunks with one chunker: one (asset, target_chunk_size*1024-byte
+ * segment) job of ChunkAssets (src/longtail.c:2396-2458).  Parts live in one device buffer at
+ * 16-byte aligned offsets.  min/avg/max as computed by src/longtail.c:1985-1987. */
+LTHIP_EXPORT int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const uint64_t* part_offsets /*host*/,
+                                   const uint64_t* part_sizes /*host*/, uint32_t min_chunk, uint32_t avg_chunk,
+                                   uint32_t max_chunk, lthip_plan** out_plan);
+LTHIP_EXPORT void lthip_plan_destroy(lthip_ctx* ctx, lthip_plan* plan);
+/* upper bound on the number of chunks the plan can produce (size the output arrays with it) */
+LTHIP_EXPORT uint64_t lthip_plan_chunk_capacity(const lthip_plan* plan);
+
+/* Runs buzhash scan -> cut selection -> compaction -> (if d_chunk_hashes) BLAKE3 on the stream.
+ * Outputs (device pointers, capacity >= lthip_plan_chunk_capacity):
+ *   d_chunk_offsets[i]  byte offset of chunk i in d_data            (dense, parts in order)
+ *   d_chunk_lens[i]     its length
+ *   d_chunk_hashes[i]   first 8 BLAKE3 bytes as LE u64              (may be NULL: chunk only)
+ *   d_part_first[p]     index of the first chunk of part p, d_part_first[part_count] = total
+ * Asynchronous; *out_total (host, may be NULL) is filled after an internal stream sync when given. */
+LTHIP_EXPORT int lthip_chunk_hash(lthip_ctx* ctx, const lthip_plan* plan, const void* d_data, uint64_t* d_chunk_offsets,
+                                  uint32_t* d_chunk_lens, uint64_t* d_chunk_hashes, uint32_t* d_part_first,
+                                  uint64_t* out_total);
+
+/* HPCDCChunker_NextChunkFromBuffer (hpcdcchunker.c:452-523) on a device buffer of `size` > min_chunk bytes:
+ * *out_len = length of the chunk at its front.  Reproduces the reference's window-seeding quirk (the rolling
+ * window starts from buf[0..48) instead of buf[min-48..min), :488-494), which NextChunk does not have.
+ * Synchronous (one small kernel + read-back). */
+LTHIP_EXPORT int lthip_chunk_from_buffer(lthip_ctx* ctx, const void* d_data, uint64_t size, uint32_t min_chunk,
+                                         uint32_t avg_chunk, uint32_t max_chunk, uint64_t* out_len);
+
+/* Host-side evaluation of the division-free cut test the kernels use (1 when h % d == d-1 for the discriminator
+ * d): exported so the arithmetic can be checked exhaustively without a GPU. */
+LTHIP_EXPORT int lthip_divtest_eval(uint32_t discriminator, uint32_t hash);
+
+/* BLAKE3-64 of arbitrary device ranges: d_hashes[i] = blake3(d_data + d_offsets[i], d_lens[i]).
+ * Same contract as Blake3Hash_HashBuffer (longtail_blake3.c:81-102); len 0 is legal. */
+LTHIP_EXPORT int lthip_hash_ranges(lthip_ctx* ctx, const void* d_data, uint64_t range_count, const uint64_t* d_offsets,
+                                   const uint32_t* d_lens, uint32_t max_len /*upper bound of d_lens[], 0 = unknown*/,
+                                   uint64_t* d_hashes);
+
+/* ---- phase 2: per-block compression ----------------------------------------------------------------
+ * One call compresses a batch of stored blocks (the unit of CompressBlock, compressblockstore.c:67-141).
+ * Block b = d_src[src_offsets[b] .. +src_sizes[b]) -> d_dst[dst_offsets[b] ..) with capacity dst_caps[b];
+ * d_out_sizes[b] = payload size, or 0 when it does not fit (LZ4CompressionAPI_Compress -> ENOMEM).
+ * The offset/size tables are HOST arrays (copied to the device by the call). */
+LTHIP_EXPORT size_t lthip_lz4_bound(size_t size); /* LZ4_COMPRESSBOUND, lib/lz4/ext/lz4.h:215 */
+LTHIP_EXPORT int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count,
+                                           const uint64_t* src_offsets, const uint32_t* src_sizes, void* d_dst,
+                                           const uint64_t* dst_offsets, const uint32_t* dst_caps,
+                                           uint32_t* d_out_sizes, int segment_log2 /*0 = default*/);
+/* LZ4_decompress_safe semantics per block; d_out_sizes[b] = decoded size or 0xFFFFFFFF on malformed input */
+LTHIP_EXPORT int lthip_lz4_decompress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count,
+                                             const uint64_t* src_offsets, const uint32_t* src_sizes, void* d_dst,
+                                             const uint64_t* dst_offsets, const uint32_t* dst_caps,
+                                             uint32_t* d_out_sizes);
+
+LTHIP_EXPORT size_t lthip_zstd_bound(size_t size); /* ZSTD_COMPRESSBOUND, lib/zstd/ext/zstd.h:232 */
+LTHIP_EXPORT int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count,
+                                            const uint64_t* src_offsets, const uint32_t* src_sizes, void* d_dst,
+                                            const uint64_t* dst_offsets, const uint32_t* dst_caps,
+                                            uint32_t* d_out_sizes);
+
+/* ---- dedup (serial first-seen pass of Longtail_CreateVersionIndex, src/longtail.c:2951-2970) --------
+ * d_first_index[i] = smallest j with d_hashes[j] == d_hashes[i]; *d_unique_count = number of i with
+ * d_first_index[i] == i. */
+LTHIP_EXPORT int lthip_dedup_first_seen(lthip_ctx* ctx, uint64_t count, const uint64_t* d_hashes,
+                                        uint32_t* d_first_index, uint64_t* d_unique_count);
+
+/* ---- synthetic assets (include/longtail_synth.h), bench/test input generator ------------------------ */
+LTHIP_EXPORT int lthip_synth_fill(lthip_ctx* ctx, void* d_dst, uint32_t asset_count, const uint64_t* asset_offsets /*host*/,
+                                  const uint64_t* asset_sizes /*host*/, const uint64_t* asset_seeds /*host*/, int kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

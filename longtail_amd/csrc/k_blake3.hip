@@ -1,0 +1,352 @@
+// k_blake3.hip -- BLAKE3-64 chunk hashing on gfx950.
+//
+// Reference behaviour: Blake3Hash_HashBuffer (lib/blake3/longtail_blake3.c:81-102) = unkeyed BLAKE3, first 8
+// output bytes as a little-endian u64; arithmetic per lib/blake3/ext/blake3_portable.c:8-98 (compression
+// function), blake3_impl.h:85-97 (IV, message schedule), blake3.c:118-166, 216-249, 576-618 (leaf/"chunk"
+// state machine, left-heavy tree, ROOT finalisation).
+//
+// MI355X formulation: pure 32-bit integer ALU work (no MFMA):
+//   leaf kernel   one thread per 1 KiB leaf of every range: 16 state + 16 message words live in VGPRs, the 7
+//                 rounds are fully unrolled with the message schedule folded into register names; ranges start
+//                 at arbitrary byte offsets, so message words are rebuilt from 4-byte aligned dwords with one
+//                 v_alignbit each.  Leaf -> range mapping is a binary search over the exclusive scan of leaf
+//                 counts (no per-leaf descriptor traffic).
+//   parent kernel in-place left-heavy reduction of each range's chaining values (level by level, stride
+//                 doubling == blake3's compress_parents_parallel with the odd node carried up), ROOT on the
+//                 last merge; writes output words 0,1 as the u64 digest.
+#include "lthip_internal.h"
+
+namespace
+{
+
+enum
+{
+    F_CHUNK_START = 1, // blake3_impl.h:14-22
+    F_CHUNK_END = 2,
+    F_PARENT = 4,
+    F_ROOT = 8
+};
+
+#define B3_IV0 0x6A09E667u
+#define B3_IV1 0xBB67AE85u
+#define B3_IV2 0x3C6EF372u
+#define B3_IV3 0xA54FF53Au
+#define B3_IV4 0x510E527Fu
+#define B3_IV5 0x9B05688Cu
+#define B3_IV6 0x1F83D9ABu
+#define B3_IV7 0x5BE0CD19u
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, uint32_t r) { return __builtin_amdgcn_alignbit(x, x, r); }
+
+__device__ __forceinline__ void b3_g(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, uint32_t mx, uint32_t my)
+{
+    a = a + b + mx;
+    d = rotr32(d ^ a, 16);
+    c = c + d;
+    b = rotr32(b ^ c, 12);
+    a = a + b + my;
+    d = rotr32(d ^ a, 8);
+    c = c + d;
+    b = rotr32(b ^ c, 7);
+}
+
+// one round with message words named explicitly (the schedule is applied by the caller's argument order)
+#define B3_ROUND(m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11, m12, m13, m14, m15) \
+    b3_g(s0, s4, s8, s12, m0, m1);                                                      \
+    b3_g(s1, s5, s9, s13, m2, m3);                                                      \
+    b3_g(s2, s6, s10, s14, m4, m5);                                                     \
+    b3_g(s3, s7, s11, s15, m6, m7);                                                     \
+    b3_g(s0, s5, s10, s15, m8, m9);                                                     \
+    b3_g(s1, s6, s11, s12, m10, m11);                                                   \
+    b3_g(s2, s7, s8, s13, m12, m13);                                                    \
+    b3_g(s3, s4, s9, s14, m14, m15);
+
+// cv <- first 8 output words of compress(cv, m, counter, block_len, flags)
+__device__ __forceinline__ void b3_compress(uint32_t (&cv)[8], const uint32_t (&m)[16], uint32_t counter_lo,
+                                            uint32_t block_len, uint32_t flags)
+{
+    uint32_t s0 = cv[0], s1 = cv[1], s2 = cv[2], s3 = cv[3], s4 = cv[4], s5 = cv[5], s6 = cv[6], s7 = cv[7];
+    uint32_t s8 = B3_IV0, s9 = B3_IV1, s10 = B3_IV2, s11 = B3_IV3;
+    uint32_t s12 = counter_lo, s13 = 0u, s14 = block_len, s15 = flags;
+    // rows of MSG_SCHEDULE (blake3_impl.h:89-97): row r+1 = row r permuted by {2,6,3,10,7,0,4,13,1,11,12,5,9,14,15,8}
+    B3_ROUND(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15])
+    B3_ROUND(m[2], m[6], m[3], m[10], m[7], m[0], m[4], m[13], m[1], m[11], m[12], m[5], m[9], m[14], m[15], m[8])
+    B3_ROUND(m[3], m[4], m[10], m[12], m[13], m[2], m[7], m[14], m[6], m[5], m[9], m[0], m[11], m[15], m[8], m[1])
+    B3_ROUND(m[10], m[7], m[12], m[9], m[14], m[3], m[13], m[15], m[4], m[0], m[11], m[2], m[5], m[8], m[1], m[6])
+    B3_ROUND(m[12], m[13], m[9], m[11], m[15], m[10], m[14], m[8], m[7], m[2], m[5], m[3], m[0], m[1], m[6], m[4])
+    B3_ROUND(m[9], m[14], m[11], m[5], m[8], m[12], m[15], m[1], m[13], m[3], m[0], m[10], m[2], m[6], m[4], m[7])
+    B3_ROUND(m[11], m[15], m[5], m[0], m[1], m[9], m[8], m[6], m[14], m[10], m[2], m[12], m[3], m[4], m[7], m[13])
+    cv[0] = s0 ^ s8;
+    cv[1] = s1 ^ s9;
+    cv[2] = s2 ^ s10;
+    cv[3] = s3 ^ s11;
+    cv[4] = s4 ^ s12;
+    cv[5] = s5 ^ s13;
+    cv[6] = s6 ^ s14;
+    cv[7] = s7 ^ s15;
+}
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// ---------------------------------------------------------------------------------------------------
+// leaf counts
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t leaves_of(uint32_t len) { return len ? (len + 1023u) >> 10 : 1u; }
+
+__global__ void k_leaf_counts(const uint32_t* __restrict__ lens, uint64_t bound, const uint32_t* __restrict__ n_dev,
+                              uint32_t* __restrict__ counts)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t n = n_dev ? (*n_dev < bound ? *n_dev : bound) : bound;
+    if (i < n)
+        counts[i] = leaves_of(lens[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// leaves
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blake3_leaves(const uint8_t* __restrict__ data,
+                                                       const uint64_t* __restrict__ offsets,
+                                                       const uint32_t* __restrict__ lens,
+                                                       const uint32_t* __restrict__ leaf_prefix, // [count+1]
+                                                       uint64_t count_bound, const uint32_t* __restrict__ n_dev,
+                                                       uint32_t* __restrict__ cvs)
+{
+    const uint32_t count = (uint32_t)(n_dev ? (*n_dev < count_bound ? *n_dev : count_bound) : count_bound);
+    const uint32_t total = leaf_prefix[count];
+    const uint64_t g64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g64 >= total)
+        return;
+    const uint32_t g = (uint32_t)g64;
+    // range c with leaf_prefix[c] <= g < leaf_prefix[c+1]
+    uint32_t lo = 0, hi = count;
+    while (hi - lo > 1)
+    {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (leaf_prefix[mid] <= g)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t c = lo;
+    const uint32_t first = leaf_prefix[c];
+    const uint32_t k = g - first; // leaf index inside the range == BLAKE3 chunk counter
+    const uint32_t rlen = lens[c];
+    const uint32_t nleaf = leaves_of(rlen);
+    const uint32_t llen = rlen - (k << 10) < 1024u ? rlen - (k << 10) : 1024u; // 0 only for the empty range
+    const uint8_t* p = data + offsets[c] + ((uint64_t)k << 10);
+    const uint32_t root = nleaf == 1u ? (uint32_t)F_ROOT : 0u;
+
+    const uint32_t mis = (uint32_t)((uintptr_t)p & 3u);
+    const uint32_t sh = mis * 8u;
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p - mis); // 4-byte aligned
+
+    uint32_t cv[8] = {B3_IV0, B3_IV1, B3_IV2, B3_IV3, B3_IV4, B3_IV5, B3_IV6, B3_IV7};
+    const uint32_t nblocks = llen ? (llen + 63u) >> 6 : 1u;
+
+    // interior blocks: the 64 bytes (and the spill-over dword when misaligned) are inside the leaf
+    for (uint32_t b = 0; b + 1 < nblocks; ++b)
+    {
+        const uint32_t* src = q + b * 16u;
+        uint32_t w[17];
+        const u32x4_a4 v0 = *reinterpret_cast<const u32x4_a4*>(src);
+        const u32x4_a4 v1 = *reinterpret_cast<const u32x4_a4*>(src + 4);
+        const u32x4_a4 v2 = *reinterpret_cast<const u32x4_a4*>(src + 8);
+        const u32x4_a4 v3 = *reinterpret_cast<const u32x4_a4*>(src + 12);
+        w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
+        w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+        w[8] = v2.x; w[9] = v2.y; w[10] = v2.z; w[11] = v2.w;
+        w[12] = v3.x; w[13] = v3.y; w[14] = v3.z; w[15] = v3.w;
+        w[16] = mis ? src[16] : 0u;
+        uint32_t m[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            m[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], sh);
+        b3_compress(cv, m, k, 64u, b == 0 ? (uint32_t)F_CHUNK_START : 0u);
+    }
+    // last block: 0..64 bytes, touch only dwords that hold at least one byte of the leaf
+    {
+        const uint32_t b = nblocks - 1u;
+        const uint32_t bl = llen - b * 64u;
+        const uint32_t* src = q + b * 16u;
+        const uint32_t nd = bl ? (mis + bl + 3u) >> 2 : 0u; // dwords that intersect [p, p+bl)
+        uint32_t w[17];
+#pragma unroll
+        for (int i = 0; i < 17; ++i)
+            w[i] = (uint32_t)i < nd ? src[i] : 0u;
+        uint32_t m[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+        {
+            uint32_t v = __builtin_amdgcn_alignbit(w[i + 1], w[i], sh);
+            const int rem = (int)bl - 4 * i; // valid bytes in this word
+            if (rem <= 0)
+                v = 0u;
+            else if (rem < 4)
+                v &= (1u << (8 * rem)) - 1u;
+            m[i] = v;
+        }
+        uint32_t fl = (uint32_t)F_CHUNK_END | root;
+        if (b == 0)
+            fl |= (uint32_t)F_CHUNK_START;
+        b3_compress(cv, m, k, bl, fl);
+    }
+    uint4* out = reinterpret_cast<uint4*>(cvs + (uint64_t)g * 8u);
+    out[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    out[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// parents
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void b3_parent(uint32_t* __restrict__ left, const uint32_t* __restrict__ right, uint32_t flags)
+{
+    uint32_t m[16];
+    const uint4 a0 = reinterpret_cast<const uint4*>(left)[0], a1 = reinterpret_cast<const uint4*>(left)[1];
+    const uint4 b0 = reinterpret_cast<const uint4*>(right)[0], b1 = reinterpret_cast<const uint4*>(right)[1];
+    m[0] = a0.x; m[1] = a0.y; m[2] = a0.z; m[3] = a0.w; m[4] = a1.x; m[5] = a1.y; m[6] = a1.z; m[7] = a1.w;
+    m[8] = b0.x; m[9] = b0.y; m[10] = b0.z; m[11] = b0.w; m[12] = b1.x; m[13] = b1.y; m[14] = b1.z; m[15] = b1.w;
+    uint32_t cv[8] = {B3_IV0, B3_IV1, B3_IV2, B3_IV3, B3_IV4, B3_IV5, B3_IV6, B3_IV7};
+    b3_compress(cv, m, 0u, 64u, flags);
+    reinterpret_cast<uint4*>(left)[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    reinterpret_cast<uint4*>(left)[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+
+// small trees: one thread reduces one range in place (stride doubling keeps every node at the slot of its
+// left-most leaf; an odd node simply stays put == carried up)
+__global__ __launch_bounds__(256) void k_blake3_parents_small(const uint32_t* __restrict__ lens,
+                                                              const uint32_t* __restrict__ leaf_prefix,
+                                                              uint64_t count_bound, const uint32_t* __restrict__ n_dev,
+                                                              uint32_t* __restrict__ cvs, uint64_t* __restrict__ hashes)
+{
+    const uint32_t count = (uint32_t)(n_dev ? (*n_dev < count_bound ? *n_dev : count_bound) : count_bound);
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= count)
+        return;
+    const uint32_t slot0 = leaf_prefix[c];
+    const uint32_t n = leaf_prefix[c + 1] - slot0;
+    uint32_t* base = cvs + (uint64_t)slot0 * 8u;
+    for (uint32_t stride = 1; stride < n; stride <<= 1)
+    {
+        const uint32_t last = (stride << 1) >= n; // top level: exactly one merge, it carries ROOT
+        for (uint32_t k = 0; k + stride < n; k += stride << 1)
+            b3_parent(base + (uint64_t)k * 8u, base + (uint64_t)(k + stride) * 8u,
+                      (uint32_t)F_PARENT | (last ? (uint32_t)F_ROOT : 0u));
+    }
+    hashes[c] = (uint64_t)base[0] | ((uint64_t)base[1] << 32);
+}
+
+// big trees: one launch per level, one thread per leaf slot
+__global__ __launch_bounds__(256) void k_blake3_parents_level(const uint32_t* __restrict__ leaf_prefix, uint32_t count,
+                                                              uint32_t stride, uint32_t* __restrict__ cvs)
+{
+    const uint32_t total = leaf_prefix[count];
+    const uint64_t g64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g64 >= total)
+        return;
+    const uint32_t g = (uint32_t)g64;
+    uint32_t lo = 0, hi = count;
+    while (hi - lo > 1)
+    {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (leaf_prefix[mid] <= g)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t slot0 = leaf_prefix[lo];
+    const uint32_t n = leaf_prefix[lo + 1] - slot0;
+    const uint32_t k = g - slot0;
+    if ((k & ((stride << 1) - 1u)) != 0u || k + stride >= n)
+        return;
+    const uint32_t last = (stride << 1) >= n;
+    b3_parent(cvs + (uint64_t)g * 8u, cvs + (uint64_t)(g + stride) * 8u, (uint32_t)F_PARENT | (last ? (uint32_t)F_ROOT : 0u));
+}
+
+__global__ void k_blake3_emit(const uint32_t* __restrict__ leaf_prefix, uint32_t count, const uint32_t* __restrict__ cvs,
+                              uint64_t* __restrict__ hashes)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= count)
+        return;
+    const uint32_t* base = cvs + (uint64_t)leaf_prefix[c] * 8u;
+    hashes[c] = (uint64_t)base[0] | ((uint64_t)base[1] << 32);
+}
+
+} // namespace
+
+int lthip_launch_blake3(lthip_ctx* ctx, const uint8_t* d_data, const uint64_t* d_offsets, const uint32_t* d_lens,
+                        const uint32_t* d_count, uint64_t count_bound, uint64_t leaf_bound, uint64_t max_len,
+                        uint64_t* d_hashes)
+{
+    if (count_bound == 0)
+        return 0;
+    void *lc, *lp, *cv;
+    int err;
+    if ((err = lthip_scratch(ctx, S_LEAF_COUNT, (count_bound + 1) * 4, &lc)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_LEAF_PREFIX, (count_bound + 1) * 4, &lp)))
+        return err;
+    {
+        LaunchTimer t(ctx, LTHIP_K_COMPACT);
+        hipLaunchKernelGGL(k_leaf_counts, dim3((uint32_t)div_up_u64(count_bound, 256)), dim3(256), 0, ctx->stream, d_lens,
+                           count_bound, d_count, (uint32_t*)lc);
+        LTHIP_LAUNCH_CHECK(ctx);
+    }
+    if ((err = lthip_exclusive_scan_u32(ctx, (const uint32_t*)lc, (uint32_t*)lp, count_bound, d_count, LTHIP_K_COMPACT)))
+        return err;
+
+    const bool small_trees = max_len != 0 && max_len <= 256u * 1024u;
+    uint32_t host_count = 0;
+    if (leaf_bound == 0 || !small_trees)
+    {
+        // need exact numbers on the host: the count (when it lives on the device) and the leaf total
+        if (d_count)
+        {
+            LTHIP_CHECK(ctx, hipMemcpyAsync(&host_count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+            LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (host_count > count_bound)
+                host_count = (uint32_t)count_bound;
+        }
+        else
+            host_count = (uint32_t)count_bound;
+        uint32_t total = 0;
+        LTHIP_CHECK(ctx, hipMemcpyAsync(&total, (const uint32_t*)lp + host_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        leaf_bound = total;
+        if (host_count == 0)
+            return 0;
+    }
+    if (leaf_bound == 0)
+        return 0;
+    if (leaf_bound > 0xFFFFFFF0ull)
+        return lthip_fail(ctx, EINVAL, "blake3", "too many leaves in one batch");
+    if ((err = lthip_scratch(ctx, S_CV, leaf_bound * 32, &cv)))
+        return err;
+    {
+        LaunchTimer t(ctx, LTHIP_K_B3_LEAF);
+        hipLaunchKernelGGL(k_blake3_leaves, dim3((uint32_t)div_up_u64(leaf_bound, 256)), dim3(256), 0, ctx->stream, d_data,
+                           d_offsets, d_lens, (const uint32_t*)lp, count_bound, d_count, (uint32_t*)cv);
+        LTHIP_LAUNCH_CHECK(ctx);
+    }
+    if (small_trees)
+    {
+        LaunchTimer t(ctx, LTHIP_K_B3_PARENT);
+        hipLaunchKernelGGL(k_blake3_parents_small, dim3((uint32_t)div_up_u64(count_bound, 256)), dim3(256), 0, ctx->stream,
+                           d_lens, (const uint32_t*)lp, count_bound, d_count, (uint32_t*)cv, d_hashes);
+        LTHIP_LAUNCH_CHECK(ctx);
+    }
+    else
+    {
+        LaunchTimer t(ctx, LTHIP_K_B3_PARENT);
+        // deepest possible tree: a u32 length has at most 2^22 leaves
+        uint64_t max_leaves = max_len ? div_up_u64(max_len, 1024) : (1ull << 22);
+        for (uint64_t stride = 1; stride < max_leaves; stride <<= 1)
+            hipLaunchKernelGGL(k_blake3_parents_level, dim3((uint32_t)div_up_u64(leaf_bound, 256)), dim3(256), 0,
+                               ctx->stream, (const uint32_t*)lp, host_count, (uint32_t)stride, (uint32_t*)cv);
+        hipLaunchKernelGGL(k_blake3_emit, dim3((uint32_t)div_up_u64(host_count, 256)), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)lp, host_count, (const uint32_t*)cv, d_hashes);
+        LTHIP_LAUNCH_CHECK(ctx);
+    }
+    return 0;
+}

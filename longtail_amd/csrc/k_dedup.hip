@@ -1,0 +1,126 @@
+// k_dedup.hip -- first-seen dedup of chunk hashes on gfx950.
+//
+// Reference behaviour: the serial pass of Longtail_CreateVersionIndex (src/longtail.c:2951-2970):
+// LookupTable_PutUnique over all chunk hashes in (asset, part, chunk) order; a chunk is "unique" the first time
+// its hash appears and every later occurrence maps to that first index.  On the GPU the same mapping is the
+// minimum index per key in an open-addressing table (atomicCAS on the key, atomicMin on the index), which is
+// order independent, so 8 ranks that all-gather their hash arrays (RCCL) derive identical results.
+#include "lthip_internal.h"
+
+namespace
+{
+
+constexpr uint64_t EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 33)) * 0xff51afd7ed558ccdull;
+    z = (z ^ (z >> 33)) * 0xc4ceb9fe1a85ec53ull;
+    return z ^ (z >> 33);
+}
+
+__global__ void k_dedup_clear(uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint64_t slots, uint32_t* special,
+                              unsigned long long* unique)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        keys[i] = EMPTY_KEY;
+        idx[i] = 0xFFFFFFFFu;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        *special = 0xFFFFFFFFu;
+        *unique = 0ull;
+    }
+}
+
+__global__ void k_dedup_insert(const uint64_t* __restrict__ hashes, uint64_t n, uint64_t* __restrict__ keys,
+                               uint32_t* __restrict__ idx, uint64_t mask, uint32_t* special)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint64_t h = hashes[i];
+    if (h == EMPTY_KEY)
+    {
+        atomicMin(special, (uint32_t)i);
+        return;
+    }
+    uint64_t slot = mix64(h) & mask;
+    for (;;)
+    {
+        const unsigned long long prev =
+            atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]), (unsigned long long)EMPTY_KEY, (unsigned long long)h);
+        if (prev == EMPTY_KEY || prev == h)
+        {
+            atomicMin(&idx[slot], (uint32_t)i);
+            return;
+        }
+        slot = (slot + 1) & mask;
+    }
+}
+
+__global__ void k_dedup_lookup(const uint64_t* __restrict__ hashes, uint64_t n, const uint64_t* __restrict__ keys,
+                               const uint32_t* __restrict__ idx, uint64_t mask, const uint32_t* special,
+                               uint32_t* __restrict__ first_index, unsigned long long* unique)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t mine = 0;
+    if (i < n)
+    {
+        const uint64_t h = hashes[i];
+        uint32_t f;
+        if (h == EMPTY_KEY)
+            f = *special;
+        else
+        {
+            uint64_t slot = mix64(h) & mask;
+            while (keys[slot] != h)
+                slot = (slot + 1) & mask;
+            f = idx[slot];
+        }
+        first_index[i] = f;
+        mine = f == (uint32_t)i;
+    }
+    const uint64_t b = __builtin_amdgcn_ballot_w64(mine != 0);
+    if ((threadIdx.x & 63) == 0 && b)
+        atomicAdd(unique, (unsigned long long)__builtin_popcountll(b));
+}
+
+} // namespace
+
+extern "C" int lthip_dedup_first_seen(lthip_ctx* ctx, uint64_t count, const uint64_t* d_hashes, uint32_t* d_first_index,
+                                      uint64_t* d_unique_count)
+{
+    if (!ctx || !d_unique_count || (count && (!d_hashes || !d_first_index)))
+        return EINVAL;
+    if (count > 0x7FFFFFFFull)
+        return lthip_fail(ctx, EINVAL, "dedup", "too many hashes");
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    uint64_t slots = 1024;
+    while (slots < count * 2)
+        slots <<= 1;
+    void *keys, *idx, *misc;
+    int err;
+    if ((err = lthip_scratch(ctx, S_TABLES, slots * 8, &keys)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_TABLES2, slots * 4, &idx)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_MISC, 64, &misc)))
+        return err;
+    uint32_t* special = (uint32_t*)misc;
+    LaunchTimer t(ctx, LTHIP_K_OTHER);
+    hipLaunchKernelGGL(k_dedup_clear, dim3(2048), dim3(256), 0, ctx->stream, (uint64_t*)keys, (uint32_t*)idx, slots, special,
+                       (unsigned long long*)d_unique_count);
+    if (count)
+    {
+        const uint32_t blocks = (uint32_t)div_up_u64(count, 256);
+        hipLaunchKernelGGL(k_dedup_insert, dim3(blocks), dim3(256), 0, ctx->stream, d_hashes, count, (uint64_t*)keys,
+                           (uint32_t*)idx, slots - 1, special);
+        hipLaunchKernelGGL(k_dedup_lookup, dim3(blocks), dim3(256), 0, ctx->stream, d_hashes, count, (const uint64_t*)keys,
+                           (const uint32_t*)idx, slots - 1, (const uint32_t*)special, d_first_index,
+                           (unsigned long long*)d_unique_count);
+    }
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
+}

@@ -1,0 +1,652 @@
+// k_lz4.hip -- per-block LZ4 (block format) compression and decompression on gfx950.
+//
+// Reference behaviour: LZ4CompressionAPI_Compress/_Decompress (lib/lz4/longtail_lz4.c:52-102) =
+// LZ4_compress_fast(acc 1) / LZ4_decompress_safe of the vendored LZ4 1.10.0 (lib/lz4/ext/lz4.c:930-1338,
+// 2016-2445).  The contract kept is the FORMAT one: every payload is one LZ4 block that the
+// reference decoder expands to the original bytes; the parse itself is re-designed for a GPU:
+//
+//   K5 lz4_segments  a stored block (<= 8.8 MiB) is cut into independent segments (default 32 KiB); one wave
+//                    compresses one segment out of LDS (segment bytes + a 4096 x u16 hash table).  All 64 lanes
+//                    probe 64 positions per step (hash of 4 bytes, single-probe table like lz4.c:777-783), the
+//                    first hit is extended forwards/backwards with wave ballots, and -- like the reference's
+//                    skip acceleration (lz4.c:1044-1053) -- the probe stride grows by one for every 64 misses,
+//                    so incompressible data costs ~45 steps per 64 KiB.  Sequences go to a per-segment stream.
+//   K6 lz4_stitch    per block: a serial walk over the segment results turns trailing literals of one segment
+//                    into leading literals of the next sequence (re-emitting its token / length bytes) and
+//                    assigns exact output offsets, honouring the end-of-block rules (last 5 bytes literal,
+//                    last match starts >= 12 bytes before the end; lz4.c:242-246, 2279-2329, 2421-2423); then
+//                    one workgroup per segment copies header, literals (from the source) and sequence body
+//                    (from the stream) into the single final block with 16-byte stores.
+//   decode           one wave per block, sequences parsed wave-uniformly, copies spread over the lanes.
+#include "lthip_internal.h"
+
+namespace
+{
+
+struct Lz4Block
+{
+    uint64_t src_off;
+    uint64_t dst_off;
+    uint32_t size;
+    uint32_t dst_cap;
+    uint32_t seg_base;
+    uint32_t nseg;
+};
+
+struct Lz4Meta // result of one segment
+{
+    uint32_t seq_bytes;       // bytes of complete sequences in the segment stream (0 = no match found)
+    uint32_t tail_lits;       // trailing literal bytes not covered by a sequence
+    uint32_t first_lit_len;   // literal length of the first sequence
+    uint32_t first_hdr_bytes; // token + literal-length bytes of the first sequence
+};
+
+struct Lz4Plan // where one segment's pieces go, dst offsets relative to the block's output
+{
+    uint32_t hdr_pos;       // rewritten first token position (valid when the segment has a match)
+    uint32_t hdr_lits;      // literal length to encode there (carry-in + first_lit_len)
+    uint32_t first_lit_dst; // destination of the segment's own leading literals
+    uint32_t body_dst;      // destination of the rest of the stream
+    uint32_t tail_dst;      // destination of the trailing literals
+};
+
+struct Lz4BlockOut
+{
+    uint32_t final_hdr_pos;
+    uint32_t final_lits;
+    uint32_t total; // 0 = does not fit
+    uint32_t pad;
+};
+
+constexpr int LZ4_HASH_LOG2 = 12;
+constexpr uint32_t LZ4_EMPTY = 0xFFFFu;
+
+__host__ __device__ __forceinline__ uint32_t lz4_stream_stride(uint32_t seg) { return (seg + seg / 255u + 16u + 15u) & ~15u; }
+__host__ __device__ __forceinline__ uint32_t lz4_len_bytes(uint32_t len) { return len >= 15u ? (len - 15u) / 255u + 1u : 0u; }
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// ---------------------------------------------------------------------------------------------------
+// K5
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lds_read32(const uint32_t* sdata, uint32_t byte_idx)
+{
+    const uint32_t w = byte_idx >> 2;
+    return __builtin_amdgcn_alignbyte(sdata[w + 1], sdata[w], byte_idx & 3u);
+}
+
+// wave-cooperative emission of a length (already reduced by 15) as 255,255,...,rem
+__device__ __forceinline__ void emit_len(uint8_t* out, uint32_t len, int lane)
+{
+    const uint32_t n = len / 255u + 1u;
+    for (uint32_t j = lane; j < n; j += 64)
+        out[j] = j + 1 == n ? (uint8_t)(len % 255u) : (uint8_t)255;
+}
+
+template <int SEG_LOG2>
+__global__ __launch_bounds__(64) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
+                                                     uint32_t nblocks, uint8_t* __restrict__ streams,
+                                                     Lz4Meta* __restrict__ meta)
+{
+    constexpr uint32_t SEG = 1u << SEG_LOG2;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* sdata = smem;                                              // SEG + 32 bytes
+    uint16_t* tab = reinterpret_cast<uint16_t*>(smem + SEG / 4 + 8);     // 4096 entries
+    const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(sdata);
+
+    const int lane = threadIdx.x;
+    const uint32_t seg = blockIdx.x;
+    // block that owns this segment
+    uint32_t lo = 0, hi = nblocks;
+    while (hi - lo > 1)
+    {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (blocks[mid].seg_base <= seg)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const Lz4Block blk = blocks[lo];
+    const uint32_t seg_start = (seg - blk.seg_base) << SEG_LOG2;
+    const uint32_t len = blk.size - seg_start < SEG ? blk.size - seg_start : SEG;
+    const uint8_t* g = src + blk.src_off + seg_start;
+
+    // ---- stage the segment (16-byte loads from the aligned-down address) and clear the table ----
+    const uint32_t head = (uint32_t)((uintptr_t)g & 15u);
+    {
+        const uint4* gv = reinterpret_cast<const uint4*>(g - head);
+        const uint32_t nvec = (head + len + 15u) >> 4;
+        uint4* sv = reinterpret_cast<uint4*>(sdata);
+        for (uint32_t v = lane; v < nvec; v += 64)
+            sv[v] = gv[v];
+        uint4* tv = reinterpret_cast<uint4*>(tab);
+        const uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        for (uint32_t v = lane; v < (1u << LZ4_HASH_LOG2) * 2 / 16; v += 64)
+            tv[v] = e;
+    }
+    __syncthreads();
+
+    // parsing limits, segment relative (lz4.c:963-964: mflimit / matchlimit, applied at the block end)
+    const int64_t blk_left = (int64_t)blk.size - (int64_t)seg_start;     // bytes from segment start to block end
+    int32_t start_limit = (int32_t)len - 4;                              // 4 bytes must be readable
+    if ((int64_t)start_limit > blk_left - 12)
+        start_limit = (int32_t)(blk_left - 12);
+    const uint32_t end_limit = (int64_t)len < blk_left - 5 ? len : (uint32_t)(blk_left - 5 > 0 ? blk_left - 5 : 0);
+
+    uint8_t* out = streams + (uint64_t)seg * lz4_stream_stride(SEG);
+    uint32_t op = 0, anchor = 0, pos = 0, nfail = 0;
+    uint32_t first_lit = 0, first_hdr = 0;
+    bool have_first = false;
+
+    while ((int32_t)pos <= start_limit)
+    {
+        const uint32_t stride = 1u + nfail;
+        const uint32_t p = pos + (uint32_t)lane * stride;
+        const bool valid = (int32_t)p <= start_limit;
+        uint32_t v = 0, cand = LZ4_EMPTY, h = 0;
+        if (valid)
+        {
+            v = lds_read32(sdata, p + head);
+            h = (v * 2654435761u) >> (32 - LZ4_HASH_LOG2);
+            cand = tab[h];
+        }
+        // all lanes have read the table before anyone updates it (same wave: LDS ops issue in order)
+        if (valid)
+            tab[h] = (uint16_t)p;
+        bool ok = false;
+        if (valid && cand != LZ4_EMPTY && cand < p)
+            ok = lds_read32(sdata, cand + head) == v;
+        const uint64_t hits = __builtin_amdgcn_ballot_w64(ok);
+        if (hits == 0ull)
+        {
+            pos += 64u * stride;
+            ++nfail;
+            continue;
+        }
+        const int f = __builtin_ctzll(hits);
+        uint32_t pf = pos + (uint32_t)f * stride;
+        uint32_t cf = __builtin_amdgcn_readlane(cand, f);
+
+        // backwards (lz4.c:1104-1109): at most up to the anchor / segment start
+        {
+            uint32_t room = pf - anchor < cf ? pf - anchor : cf;
+            while (room)
+            {
+                const uint32_t j = (uint32_t)lane;
+                const bool same = j < room && sbytes[pf - 1 - j + head] == sbytes[cf - 1 - j + head];
+                const uint64_t diff = __builtin_amdgcn_ballot_w64(!same);
+                const uint32_t n = diff ? (uint32_t)__builtin_ctzll(diff) : 64u;
+                pf -= n;
+                cf -= n;
+                room -= n;
+                if (n < 64u)
+                    break;
+            }
+        }
+        // forwards
+        uint32_t mlen = 4;
+        for (;;)
+        {
+            const uint32_t i = pf + mlen + (uint32_t)lane;
+            const bool same = i < end_limit && sbytes[i + head] == sbytes[cf + mlen + (uint32_t)lane + head];
+            const uint64_t diff = __builtin_amdgcn_ballot_w64(!same);
+            if (diff)
+            {
+                mlen += (uint32_t)__builtin_ctzll(diff);
+                break;
+            }
+            mlen += 64u;
+        }
+
+        // ---- emit  token | literal length | literals | offset | match length  (lz4.c:1111-1226) ----
+        const uint32_t lit = pf - anchor;
+        const uint32_t mcode = mlen - 4u;
+        const uint32_t hdr = 1u + lz4_len_bytes(lit);
+        if (lane == 0)
+            out[op] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
+        if (lit >= 15u)
+            emit_len(out + op + 1, lit - 15u, lane);
+        for (uint32_t j = lane; j < lit; j += 64)
+            out[op + hdr + j] = sbytes[anchor + j + head];
+        uint32_t o2 = op + hdr + lit;
+        if (lane == 0)
+        {
+            const uint32_t off = pf - cf;
+            out[o2] = (uint8_t)off;
+            out[o2 + 1] = (uint8_t)(off >> 8);
+        }
+        o2 += 2;
+        if (mcode >= 15u)
+        {
+            emit_len(out + o2, mcode - 15u, lane);
+            o2 += lz4_len_bytes(mcode);
+        }
+        if (!have_first)
+        {
+            have_first = true;
+            first_lit = lit;
+            first_hdr = hdr;
+        }
+        op = o2;
+        anchor = pos = pf + mlen;
+        nfail = 0;
+    }
+    if (lane == 0)
+    {
+        Lz4Meta m;
+        m.seq_bytes = op;
+        m.tail_lits = len - anchor;
+        m.first_lit_len = first_lit;
+        m.first_hdr_bytes = first_hdr;
+        meta[seg] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K6a: per-block serial walk over segment results
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_lz4_stitch_scan(const Lz4Block* __restrict__ blocks, uint32_t nblocks, uint32_t seg_log2,
+                                  const Lz4Meta* __restrict__ meta, Lz4Plan* __restrict__ plan,
+                                  Lz4BlockOut* __restrict__ bout, uint32_t* __restrict__ out_sizes)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks)
+        return;
+    const Lz4Block blk = blocks[b];
+    const uint32_t SEG = 1u << seg_log2;
+    uint64_t out_pos = 0; // 64-bit: detect overflow of pathological inputs against dst_cap
+    uint32_t carry = 0;
+    uint32_t pend = 0; // first segment whose tail belongs to the open literal run
+    for (uint32_t i = 0; i < blk.nseg; ++i)
+    {
+        const uint32_t s = blk.seg_base + i;
+        const Lz4Meta m = meta[s];
+        const uint32_t seg_len = blk.size - (i << seg_log2) < SEG ? blk.size - (i << seg_log2) : SEG;
+        Lz4Plan pl;
+        pl.hdr_pos = 0xFFFFFFFFu;
+        pl.hdr_lits = 0;
+        pl.first_lit_dst = 0;
+        pl.body_dst = 0;
+        pl.tail_dst = 0;
+        if (m.seq_bytes)
+        {
+            const uint32_t L = carry + m.first_lit_len;
+            const uint32_t hdr = 1u + lz4_len_bytes(L);
+            const uint64_t lit_dst = out_pos + hdr;
+            for (uint32_t j = pend; j < i; ++j)
+                plan[blk.seg_base + j].tail_dst += (uint32_t)lit_dst; // relative -> absolute
+            pl.hdr_pos = (uint32_t)out_pos;
+            pl.hdr_lits = L;
+            pl.first_lit_dst = (uint32_t)(lit_dst + carry);
+            pl.body_dst = pl.first_lit_dst + m.first_lit_len;
+            out_pos = (uint64_t)pl.body_dst + (m.seq_bytes - m.first_hdr_bytes - m.first_lit_len);
+            pl.tail_dst = 0; // relative position inside the run that starts with this segment's tail
+            carry = m.tail_lits;
+            pend = i;
+        }
+        else
+        {
+            pl.tail_dst = carry;
+            carry += seg_len;
+        }
+        plan[s] = pl;
+    }
+    // final literal-only sequence (lz4.c:1302-1329)
+    const uint32_t hdr = 1u + lz4_len_bytes(carry);
+    const uint64_t lit_dst = out_pos + hdr;
+    for (uint32_t j = pend; j < blk.nseg; ++j)
+        plan[blk.seg_base + j].tail_dst += (uint32_t)lit_dst;
+    const uint64_t total = lit_dst + carry;
+    Lz4BlockOut bo;
+    bo.final_hdr_pos = (uint32_t)out_pos;
+    bo.final_lits = carry;
+    bo.total = total <= (uint64_t)blk.dst_cap ? (uint32_t)total : 0u;
+    bo.pad = 0;
+    bout[b] = bo;
+    out_sizes[b] = bo.total;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K6b: one workgroup per segment moves its pieces into place
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wg_copy(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, int tid,
+                                        int nthreads)
+{
+    if (n == 0)
+        return;
+    uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+    if (head > n)
+        head = n;
+    if ((uint32_t)tid < head)
+        dst[tid] = src[tid];
+    dst += head;
+    src += head;
+    n -= head;
+    const uint32_t nvec = n >> 4;
+    const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
+    const uint32_t sh = mis * 8u;
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src - mis);
+    for (uint32_t v = tid; v < nvec; v += nthreads)
+    {
+        const uint32_t* q = s4 + v * 4u;
+        const u32x4_a4 a = *reinterpret_cast<const u32x4_a4*>(q);
+        const uint32_t e = mis ? q[4] : 0u;
+        uint4 o;
+        o.x = __builtin_amdgcn_alignbit(a.y, a.x, sh);
+        o.y = __builtin_amdgcn_alignbit(a.z, a.y, sh);
+        o.z = __builtin_amdgcn_alignbit(a.w, a.z, sh);
+        o.w = __builtin_amdgcn_alignbit(e, a.w, sh);
+        *reinterpret_cast<uint4*>(dst + (uint64_t)v * 16u) = o;
+    }
+    const uint32_t done = nvec << 4;
+    if ((uint32_t)tid < n - done)
+        dst[done + tid] = src[done + tid];
+}
+
+__device__ __forceinline__ void wg_emit_header(uint8_t* dst, uint32_t lits, uint32_t match_nibble, int tid, int nthreads)
+{
+    if (tid == 0)
+        dst[0] = (uint8_t)(((lits < 15u ? lits : 15u) << 4) | match_nibble);
+    if (lits >= 15u)
+    {
+        const uint32_t len = lits - 15u;
+        const uint32_t n = len / 255u + 1u;
+        for (uint32_t j = tid; j < n; j += nthreads)
+            dst[1 + j] = j + 1 == n ? (uint8_t)(len % 255u) : (uint8_t)255;
+    }
+}
+
+constexpr int K6_THREADS = 256;
+
+__global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* __restrict__ src,
+                                                                 const Lz4Block* __restrict__ blocks, uint32_t nblocks,
+                                                                 uint32_t seg_log2, const uint8_t* __restrict__ streams,
+                                                                 const Lz4Meta* __restrict__ meta,
+                                                                 const Lz4Plan* __restrict__ plan,
+                                                                 const Lz4BlockOut* __restrict__ bout,
+                                                                 uint8_t* __restrict__ dst)
+{
+    const int tid = threadIdx.x;
+    const uint32_t seg = blockIdx.x;
+    uint32_t lo = 0, hi = nblocks;
+    while (hi - lo > 1)
+    {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (blocks[mid].seg_base <= seg)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const Lz4Block blk = blocks[lo];
+    const Lz4BlockOut bo = bout[lo];
+    if (bo.total == 0)
+        return; // does not fit: nothing is written, size 0 reported
+    const uint32_t SEG = 1u << seg_log2;
+    const uint32_t i = seg - blk.seg_base;
+    const uint32_t seg_start = i << seg_log2;
+    const uint32_t len = blk.size - seg_start < SEG ? blk.size - seg_start : SEG;
+    const Lz4Meta m = meta[seg];
+    const Lz4Plan pl = plan[seg];
+    const uint8_t* s = src + blk.src_off + seg_start;
+    uint8_t* d = dst + blk.dst_off;
+    const uint8_t* stream = streams + (uint64_t)seg * lz4_stream_stride(SEG);
+
+    uint32_t tail = len;
+    if (m.seq_bytes)
+    {
+        wg_emit_header(d + pl.hdr_pos, pl.hdr_lits, stream[0] & 15u, tid, K6_THREADS);
+        wg_copy(d + pl.first_lit_dst, s, m.first_lit_len, tid, K6_THREADS);
+        const uint32_t skip = m.first_hdr_bytes + m.first_lit_len;
+        wg_copy(d + pl.body_dst, stream + skip, m.seq_bytes - skip, tid, K6_THREADS);
+        tail = m.tail_lits;
+    }
+    wg_copy(d + pl.tail_dst, s + (len - tail), tail, tid, K6_THREADS);
+    if (i + 1 == blk.nseg)
+        wg_emit_header(d + bo.final_hdr_pos, bo.final_lits, 0u, tid, K6_THREADS);
+}
+
+// empty blocks have no segment: their single 0x00 token is written here
+__global__ void k_lz4_empty_blocks(const Lz4Block* __restrict__ blocks, uint32_t nblocks,
+                                   const Lz4BlockOut* __restrict__ bout, uint8_t* __restrict__ dst)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks)
+        return;
+    if (blocks[b].nseg == 0 && bout[b].total == 1)
+        dst[blocks[b].dst_off] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// decoder: LZ4_decompress_safe rules (lz4.c:2215-2435), one wave per block
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_lz4_decode(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
+                                                   uint32_t nblocks, uint8_t* __restrict__ dst,
+                                                   uint32_t* __restrict__ out_sizes)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks)
+        return;
+    const int lane = threadIdx.x;
+    const Lz4Block blk = blocks[b];
+    const uint8_t* in = src + blk.src_off;
+    uint8_t* out = dst + blk.dst_off;
+    const int64_t n = blk.size, cap = blk.dst_cap;
+    uint32_t result = 0xFFFFFFFFu;
+    if (cap == 0)
+    {
+        if (n == 1 && in[0] == 0)
+            result = 0;
+    }
+    else if (n > 0)
+    {
+        int64_t ip = 0, op = 0;
+        for (;;)
+        {
+            if (ip >= n)
+                break;
+            const uint32_t token = in[ip++];
+            int64_t len = token >> 4;
+            bool bad = false;
+            if (len == 15)
+            { // read_variable_length(&ip, iend-RUN_MASK, 1), lz4.c:1979-2013
+                uint32_t v;
+                if (ip >= n - 15)
+                    bad = true;
+                else
+                    do
+                    {
+                        v = in[ip++];
+                        len += v;
+                        if (ip > n - 15)
+                        {
+                            bad = true;
+                            break;
+                        }
+                    } while (v == 255);
+            }
+            if (bad)
+                break;
+            if (op + len > cap - 12 || ip + len > n - 8)
+            {
+                if (ip + len != n || op + len > cap)
+                    break;
+                for (int64_t j = lane; j < len; j += 64)
+                    out[op + j] = in[ip + j];
+                result = (uint32_t)(op + len);
+                break;
+            }
+            for (int64_t j = lane; j < len; j += 64)
+                out[op + j] = in[ip + j];
+            ip += len;
+            op += len;
+            const uint32_t off = (uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8);
+            ip += 2;
+            if (off == 0 || (int64_t)off > op)
+                break;
+            int64_t ml = token & 15;
+            if (ml == 15)
+            {
+                uint32_t v;
+                do
+                {
+                    if (ip >= n - 5 + 1)
+                    {
+                        bad = true;
+                        break;
+                    }
+                    v = in[ip++];
+                    ml += v;
+                } while (v == 255);
+            }
+            if (bad)
+                break;
+            ml += 4;
+            if (op + ml > cap - 5)
+                break;
+            // the literal bytes written above must be visible to every lane before they are read back
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            if ((int64_t)off >= ml)
+            {
+                for (int64_t j = lane; j < ml; j += 64)
+                    out[op + j] = out[op - off + j];
+            }
+            else
+            {
+                // overlapping copy: byte j of the match equals byte (j mod off) of the seed
+                for (int64_t j = lane; j < ml; j += 64)
+                    out[op + j] = out[op - off + (j % (int64_t)off)];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            op += ml;
+        }
+    }
+    if (lane == 0)
+        out_sizes[b] = result;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+extern "C" size_t lthip_lz4_bound(size_t size) { return size > 0x7E000000u ? 0 : size + size / 255 + 16; }
+
+static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* src_offsets, const uint32_t* src_sizes,
+                         const uint64_t* dst_offsets, const uint32_t* dst_caps, uint32_t seg_log2, Lz4Block** d_blocks,
+                         uint64_t* out_nseg)
+{
+    std::vector<Lz4Block> hb(block_count);
+    uint64_t nseg = 0;
+    for (uint32_t b = 0; b < block_count; ++b)
+    {
+        if (src_sizes[b] > 0x7E000000u)
+            return lthip_fail(ctx, EINVAL, "lz4", "block larger than LZ4_MAX_INPUT_SIZE");
+        hb[b].src_off = src_offsets[b];
+        hb[b].dst_off = dst_offsets[b];
+        hb[b].size = src_sizes[b];
+        hb[b].dst_cap = dst_caps[b];
+        hb[b].seg_base = (uint32_t)nseg;
+        hb[b].nseg = seg_log2 ? (uint32_t)((src_sizes[b] + (1ull << seg_log2) - 1) >> seg_log2) : 0;
+        nseg += hb[b].nseg;
+    }
+    if (nseg > 0x7FFFFFF0ull)
+        return lthip_fail(ctx, EINVAL, "lz4", "too many segments in one batch");
+    void* p;
+    int err = lthip_scratch(ctx, S_LZ4_BLOCKS, sizeof(Lz4Block) * (size_t)block_count, &p);
+    if (err)
+        return err;
+    LTHIP_CHECK(ctx, hipMemcpyAsync(p, hb.data(), sizeof(Lz4Block) * (size_t)block_count, hipMemcpyHostToDevice, ctx->stream));
+    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // hb is a local
+    *d_blocks = (Lz4Block*)p;
+    *out_nseg = nseg;
+    return 0;
+}
+
+template <int SEG_LOG2>
+static void launch_segments(lthip_ctx* ctx, uint32_t nseg, const uint8_t* d_src, const Lz4Block* d_blocks, uint32_t nblocks,
+                            uint8_t* streams, Lz4Meta* meta)
+{
+    const size_t lds = (1u << SEG_LOG2) + 32 + (1u << LZ4_HASH_LOG2) * 2;
+    hipLaunchKernelGGL(k_lz4_segments<SEG_LOG2>, dim3(nseg), dim3(64), lds, ctx->stream, d_src, d_blocks, nblocks, streams,
+                       meta);
+}
+
+extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
+                                         const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
+                                         const uint32_t* dst_caps, uint32_t* d_out_sizes, int segment_log2)
+{
+    if (!ctx || !d_out_sizes || (block_count && (!src_offsets || !src_sizes || !dst_offsets || !dst_caps || !d_dst)))
+        return EINVAL;
+    if (block_count == 0)
+        return 0;
+    if (segment_log2 == 0)
+        segment_log2 = 15;
+    if (segment_log2 < 13 || segment_log2 > 16)
+        return lthip_fail(ctx, EINVAL, "lz4", "segment_log2 must be 13..16");
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    Lz4Block* d_blocks = nullptr;
+    uint64_t nseg64 = 0;
+    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, (uint32_t)segment_log2, &d_blocks,
+                            &nseg64);
+    if (err)
+        return err;
+    const uint32_t nseg = (uint32_t)nseg64;
+    const uint32_t SEG = 1u << segment_log2;
+    void *meta, *plan, *bout, *streams;
+    if ((err = lthip_scratch(ctx, S_LZ4_META, sizeof(Lz4Meta) * ((size_t)nseg + 1), &meta)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_LZ4_SEGS, sizeof(Lz4Plan) * ((size_t)nseg + 1), &plan)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_MISC, sizeof(Lz4BlockOut) * (size_t)block_count, &bout)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_LZ4_STREAM, (size_t)lz4_stream_stride(SEG) * ((size_t)nseg + 1), &streams)))
+        return err;
+    if (nseg)
+    {
+        LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
+        switch (segment_log2)
+        {
+        case 13: launch_segments<13>(ctx, nseg, (const uint8_t*)d_src, d_blocks, block_count, (uint8_t*)streams, (Lz4Meta*)meta); break;
+        case 14: launch_segments<14>(ctx, nseg, (const uint8_t*)d_src, d_blocks, block_count, (uint8_t*)streams, (Lz4Meta*)meta); break;
+        case 15: launch_segments<15>(ctx, nseg, (const uint8_t*)d_src, d_blocks, block_count, (uint8_t*)streams, (Lz4Meta*)meta); break;
+        default: launch_segments<16>(ctx, nseg, (const uint8_t*)d_src, d_blocks, block_count, (uint8_t*)streams, (Lz4Meta*)meta); break;
+        }
+        LTHIP_LAUNCH_CHECK(ctx);
+    }
+    {
+        LaunchTimer t(ctx, LTHIP_K_LZ4_STITCH);
+        hipLaunchKernelGGL(k_lz4_stitch_scan, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, d_blocks, block_count,
+                           (uint32_t)segment_log2, (const Lz4Meta*)meta, (Lz4Plan*)plan, (Lz4BlockOut*)bout, d_out_sizes);
+        if (nseg)
+            hipLaunchKernelGGL(k_lz4_stitch_copy, dim3(nseg), dim3(K6_THREADS), 0, ctx->stream, (const uint8_t*)d_src, d_blocks,
+                               block_count, (uint32_t)segment_log2, (const uint8_t*)streams, (const Lz4Meta*)meta,
+                               (const Lz4Plan*)plan, (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
+        hipLaunchKernelGGL(k_lz4_empty_blocks, dim3((block_count + 255) / 256), dim3(256), 0, ctx->stream, d_blocks, block_count,
+                           (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
+        LTHIP_LAUNCH_CHECK(ctx);
+    }
+    return 0;
+}
+
+extern "C" int lthip_lz4_decompress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
+                                           const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
+                                           const uint32_t* dst_caps, uint32_t* d_out_sizes)
+{
+    if (!ctx || !d_out_sizes || (block_count && (!src_offsets || !src_sizes || !dst_offsets || !dst_caps)))
+        return EINVAL;
+    if (block_count == 0)
+        return 0;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    Lz4Block* d_blocks = nullptr;
+    uint64_t nseg = 0;
+    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, 0, &d_blocks, &nseg);
+    if (err)
+        return err;
+    LaunchTimer t(ctx, LTHIP_K_OTHER);
+    hipLaunchKernelGGL(k_lz4_decode, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, block_count,
+                       (uint8_t*)d_dst, d_out_sizes);
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
+}

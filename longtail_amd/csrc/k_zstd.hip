@@ -1,0 +1,233 @@
+// k_zstd.hip -- ZStd CompressionAPI, encoder stage 1: every stored block becomes
+// ONE zstd frame made of Raw_Block / RLE_Block blocks (<= 128 KiB each), which the reference's
+// ZSTD_decompressDCtx (lib/zstd/longtail_zstd.c:144-177, ext/decompress/zstd_decompress.c) accepts like any
+// other frame.  This pins the container format, the block splitting and the output compaction on the GPU; the
+// entropy stages (Huffman literals, FSE sequences) are later rounds and will replace Raw blocks in place.
+//
+// Frame layout written here (RFC 8878 §3.1.1): magic 0xFD2FB528 | FHD 0xE0 (single segment, 8-byte content
+// size, no checksum, no dictionary) | u64 content size | blocks, each: 3-byte header {last:1, type:2, size:21}.
+#include "lthip_internal.h"
+
+namespace
+{
+
+struct ZBlock
+{
+    uint64_t src_off;
+    uint64_t dst_off;
+    uint32_t size;
+    uint32_t dst_cap;
+    uint32_t zb_base; // first 128 KiB piece of this stored block
+    uint32_t nzb;
+};
+
+constexpr uint32_t ZB = 128u * 1024u;
+constexpr uint32_t ZHDR = 13u;
+constexpr int ZT = 256;
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// per 128 KiB piece: 1 if all bytes are equal
+__global__ __launch_bounds__(ZT) void k_zstd_classify(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks,
+                                                      uint32_t nblocks, uint8_t* __restrict__ is_rle)
+{
+    __shared__ uint32_t sh_diff;
+    const uint32_t zb = blockIdx.x;
+    uint32_t lo = 0, hi = nblocks;
+    while (hi - lo > 1)
+    {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (blocks[mid].zb_base <= zb)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const ZBlock b = blocks[lo];
+    const uint32_t start = (zb - b.zb_base) * ZB;
+    const uint32_t len = b.size - start < ZB ? b.size - start : ZB;
+    const uint8_t* p = src + b.src_off + start;
+    if (threadIdx.x == 0)
+        sh_diff = 0;
+    __syncthreads();
+    const uint8_t first = p[0];
+    uint32_t diff = 0;
+    for (uint32_t i = threadIdx.x; i < len; i += ZT)
+        diff |= (uint32_t)(p[i] != first);
+    if (diff)
+        atomicOr(&sh_diff, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        is_rle[zb] = sh_diff ? 0 : 1;
+}
+
+// serial per stored block: destination offset of every piece, total size
+__global__ void k_zstd_scan(const ZBlock* __restrict__ blocks, uint32_t nblocks, const uint8_t* __restrict__ is_rle,
+                            uint32_t* __restrict__ zb_dst, uint32_t* __restrict__ out_sizes)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks)
+        return;
+    const ZBlock blk = blocks[b];
+    uint64_t pos = ZHDR;
+    if (blk.nzb == 0)
+        pos += 3; // one empty raw block
+    for (uint32_t i = 0; i < blk.nzb; ++i)
+    {
+        const uint32_t len = blk.size - i * ZB < ZB ? blk.size - i * ZB : ZB;
+        zb_dst[blk.zb_base + i] = (uint32_t)pos;
+        pos += 3u + (is_rle[blk.zb_base + i] ? 1u : len);
+    }
+    out_sizes[b] = pos <= (uint64_t)blk.dst_cap ? (uint32_t)pos : 0u;
+}
+
+__device__ __forceinline__ void wg_copy16(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, int tid)
+{
+    uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+    if (head > n)
+        head = n;
+    if ((uint32_t)tid < head)
+        dst[tid] = src[tid];
+    dst += head;
+    src += head;
+    n -= head;
+    const uint32_t nvec = n >> 4;
+    const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
+    const uint32_t sh = mis * 8u;
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src - mis);
+    for (uint32_t v = tid; v < nvec; v += ZT)
+    {
+        const uint32_t* q = s4 + v * 4u;
+        const u32x4_a4 a = *reinterpret_cast<const u32x4_a4*>(q);
+        const uint32_t e = mis ? q[4] : 0u;
+        uint4 o;
+        o.x = __builtin_amdgcn_alignbit(a.y, a.x, sh);
+        o.y = __builtin_amdgcn_alignbit(a.z, a.y, sh);
+        o.z = __builtin_amdgcn_alignbit(a.w, a.z, sh);
+        o.w = __builtin_amdgcn_alignbit(e, a.w, sh);
+        *reinterpret_cast<uint4*>(dst + (uint64_t)v * 16u) = o;
+    }
+    const uint32_t done = nvec << 4;
+    if ((uint32_t)tid < n - done)
+        dst[done + tid] = src[done + tid];
+}
+
+__global__ __launch_bounds__(ZT) void k_zstd_emit(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks,
+                                                  uint32_t nblocks, const uint8_t* __restrict__ is_rle,
+                                                  const uint32_t* __restrict__ zb_dst, const uint32_t* __restrict__ out_sizes,
+                                                  uint8_t* __restrict__ dst)
+{
+    const uint32_t zb = blockIdx.x;
+    uint32_t lo = 0, hi = nblocks;
+    while (hi - lo > 1)
+    {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (blocks[mid].zb_base <= zb)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const ZBlock b = blocks[lo];
+    if (out_sizes[lo] == 0)
+        return;
+    const uint32_t i = zb - b.zb_base;
+    const uint32_t start = i * ZB;
+    const uint32_t len = b.size - start < ZB ? b.size - start : ZB;
+    const uint8_t* p = src + b.src_off + start;
+    uint8_t* d = dst + b.dst_off + zb_dst[zb];
+    const uint32_t rle = is_rle[zb];
+    if (threadIdx.x == 0)
+    {
+        const uint32_t h = (i + 1 == b.nzb ? 1u : 0u) | (rle << 1) | (len << 3);
+        d[0] = (uint8_t)h;
+        d[1] = (uint8_t)(h >> 8);
+        d[2] = (uint8_t)(h >> 16);
+        if (rle)
+            d[3] = p[0];
+    }
+    if (!rle)
+        wg_copy16(d + 3, p, len, threadIdx.x);
+}
+
+// frame headers (and the lone empty block of empty inputs)
+__global__ void k_zstd_headers(const ZBlock* __restrict__ blocks, uint32_t nblocks, const uint32_t* __restrict__ out_sizes,
+                               uint8_t* __restrict__ dst)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks || out_sizes[b] == 0)
+        return;
+    const ZBlock blk = blocks[b];
+    uint8_t* d = dst + blk.dst_off;
+    d[0] = 0x28;
+    d[1] = 0xB5;
+    d[2] = 0x2F;
+    d[3] = 0xFD;
+    d[4] = 0xE0;
+    uint64_t n = blk.size;
+    for (int i = 0; i < 8; ++i)
+        d[5 + i] = (uint8_t)(n >> (8 * i));
+    if (blk.nzb == 0)
+    {
+        d[13] = 1; // last block, raw, size 0
+        d[14] = 0;
+        d[15] = 0;
+    }
+}
+
+} // namespace
+
+// ZSTD_COMPRESSBOUND, lib/zstd/ext/zstd.h:231-232
+extern "C" size_t lthip_zstd_bound(size_t n)
+{
+    if (n >= 0xFF00FF00FF00FF00ull)
+        return 0;
+    return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0);
+}
+
+extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
+                                          const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
+                                          const uint32_t* dst_caps, uint32_t* d_out_sizes)
+{
+    if (!ctx || !d_out_sizes || (block_count && (!src_offsets || !src_sizes || !dst_offsets || !dst_caps || !d_dst)))
+        return EINVAL;
+    if (block_count == 0)
+        return 0;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::vector<ZBlock> hb(block_count);
+    uint64_t nzb = 0;
+    for (uint32_t b = 0; b < block_count; ++b)
+    {
+        hb[b].src_off = src_offsets[b];
+        hb[b].dst_off = dst_offsets[b];
+        hb[b].size = src_sizes[b];
+        hb[b].dst_cap = dst_caps[b];
+        hb[b].zb_base = (uint32_t)nzb;
+        hb[b].nzb = (uint32_t)div_up_u64(src_sizes[b], ZB);
+        nzb += hb[b].nzb;
+    }
+    if (nzb > 0x7FFFFFF0ull)
+        return lthip_fail(ctx, EINVAL, "zstd", "batch too large");
+    void *d_blocks, *d_rle, *d_zdst;
+    int err;
+    if ((err = lthip_scratch(ctx, S_LZ4_BLOCKS, sizeof(ZBlock) * (size_t)block_count, &d_blocks)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_LZ4_META, (size_t)nzb + 16, &d_rle)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_LZ4_SEGS, ((size_t)nzb + 4) * 4, &d_zdst)))
+        return err;
+    LTHIP_CHECK(ctx, hipMemcpyAsync(d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, hipMemcpyHostToDevice, ctx->stream));
+    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    LaunchTimer t(ctx, LTHIP_K_OTHER);
+    if (nzb)
+        hipLaunchKernelGGL(k_zstd_classify, dim3((uint32_t)nzb), dim3(ZT), 0, ctx->stream, (const uint8_t*)d_src,
+                           (const ZBlock*)d_blocks, block_count, (uint8_t*)d_rle);
+    hipLaunchKernelGGL(k_zstd_scan, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
+                       block_count, (const uint8_t*)d_rle, (uint32_t*)d_zdst, d_out_sizes);
+    hipLaunchKernelGGL(k_zstd_headers, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
+                       block_count, (const uint32_t*)d_out_sizes, (uint8_t*)d_dst);
+    if (nzb)
+        hipLaunchKernelGGL(k_zstd_emit, dim3((uint32_t)nzb), dim3(ZT), 0, ctx->stream, (const uint8_t*)d_src,
+                           (const ZBlock*)d_blocks, block_count, (const uint8_t*)d_rle, (const uint32_t*)d_zdst,
+                           (const uint32_t*)d_out_sizes, (uint8_t*)d_dst);
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
+}

@@ -1,0 +1,525 @@
+// lthip_ctx.hip -- context, scratch pools, per-kernel event timing, plans and the phase-1 orchestration
+// of liblongtail_hip.so.  Host code only; the kernels live in k_*.hip.
+#include "lthip_internal.h"
+
+#include <stdlib.h>
+
+// ---------------------------------------------------------------------------------------------------
+// errors / scratch
+// ---------------------------------------------------------------------------------------------------
+int lthip_fail(lthip_ctx* ctx, int code, const char* what, const char* detail)
+{
+    if (ctx)
+        snprintf(ctx->err, sizeof ctx->err, "%s: %s", what ? what : "?", detail ? detail : "");
+    return code;
+}
+
+int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out)
+{
+    if (bytes == 0)
+        bytes = 256;
+    if (ctx->scratch_cap[slot] < bytes)
+    {
+        if (ctx->scratch[slot])
+        {
+            // the old buffer may still be in use by work queued on the stream
+            LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            LTHIP_CHECK(ctx, hipFree(ctx->scratch[slot]));
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_cap[slot] = 0;
+        }
+        size_t cap = bytes + bytes / 8 + 4096; // head-room so slowly growing batches do not realloc
+        LTHIP_CHECK(ctx, hipMalloc(&ctx->scratch[slot], cap));
+        ctx->scratch_cap[slot] = cap;
+    }
+    *out = ctx->scratch[slot];
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------
+extern "C" int lthip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+extern "C" int lthip_ctx_create(int device, void* hip_stream, lthip_ctx** out_ctx)
+{
+    if (!out_ctx)
+        return EINVAL;
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return ENODEV; // fail loudly: there is no CPU fallback in this library
+    if (device < 0 || device >= n)
+        return EINVAL;
+    if (hipSetDevice(device) != hipSuccess)
+        return EIO;
+    lthip_ctx* ctx = new (std::nothrow) lthip_ctx();
+    if (!ctx)
+        return ENOMEM;
+    ctx->device = device;
+    ctx->err[0] = 0;
+    ctx->timing = false;
+    memset(ctx->scratch, 0, sizeof ctx->scratch);
+    memset(ctx->scratch_cap, 0, sizeof ctx->scratch_cap);
+    memset(ctx->total_ms, 0, sizeof ctx->total_ms);
+    memset(ctx->launches, 0, sizeof ctx->launches);
+    if (hip_stream)
+    {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    }
+    else
+    {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+        {
+            delete ctx;
+            return EIO;
+        }
+        ctx->own_stream = true;
+    }
+    *out_ctx = ctx;
+    return 0;
+}
+
+extern "C" void lthip_ctx_destroy(lthip_ctx* ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& r : ctx->pending)
+    {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : ctx->free_events)
+        (void)hipEventDestroy(e);
+    for (int i = 0; i < S_COUNT; ++i)
+        if (ctx->scratch[i])
+            (void)hipFree(ctx->scratch[i]);
+    if (ctx->own_stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int lthip_ctx_sync(lthip_ctx* ctx)
+{
+    if (!ctx)
+        return EINVAL;
+    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" const char* lthip_ctx_error(const lthip_ctx* ctx) { return ctx ? ctx->err : "no context"; }
+
+// ---------------------------------------------------------------------------------------------------
+// memory helpers for plain-C callers
+// ---------------------------------------------------------------------------------------------------
+extern "C" int lthip_malloc_device(lthip_ctx* ctx, size_t bytes, void** out)
+{
+    if (!ctx || !out)
+        return EINVAL;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    LTHIP_CHECK(ctx, hipMalloc(out, bytes ? bytes : 16));
+    return 0;
+}
+
+extern "C" void lthip_free_device(lthip_ctx* ctx, void* p)
+{
+    if (!p)
+        return;
+    if (ctx)
+    {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(p);
+}
+
+extern "C" int lthip_malloc_pinned(lthip_ctx* ctx, size_t bytes, void** out)
+{
+    if (!ctx || !out)
+        return EINVAL;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    LTHIP_CHECK(ctx, hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+    return 0;
+}
+
+extern "C" void lthip_free_pinned(lthip_ctx* ctx, void* p)
+{
+    if (!p)
+        return;
+    if (ctx)
+    {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipHostFree(p);
+}
+
+extern "C" int lthip_copy_h2d(lthip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!ctx || (bytes && (!d_dst || !h_src)))
+        return EINVAL;
+    if (bytes == 0)
+        return 0;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    LTHIP_CHECK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+extern "C" int lthip_copy_d2h(lthip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
+{
+    if (!ctx || (bytes && (!h_dst || !d_src)))
+        return EINVAL;
+    if (bytes == 0)
+        return 0;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    LTHIP_CHECK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// timing
+// ---------------------------------------------------------------------------------------------------
+static hipEvent_t take_event(lthip_ctx* ctx)
+{
+    if (!ctx->free_events.empty())
+    {
+        hipEvent_t e = ctx->free_events.back();
+        ctx->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+LaunchTimer::LaunchTimer(lthip_ctx* c, int kid) : ctx(c), on(c->timing)
+{
+    if (on)
+    {
+        rec.kid = kid;
+        rec.a = take_event(ctx);
+        rec.b = take_event(ctx);
+        (void)hipEventRecord(rec.a, ctx->stream);
+    }
+}
+
+LaunchTimer::~LaunchTimer()
+{
+    if (on)
+    {
+        (void)hipEventRecord(rec.b, ctx->stream);
+        ctx->pending.push_back(rec);
+    }
+}
+
+static int timing_collect(lthip_ctx* ctx)
+{
+    if (ctx->pending.empty())
+        return 0;
+    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& r : ctx->pending)
+    {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess)
+        {
+            ctx->total_ms[r.kid] += (double)ms;
+            ctx->launches[r.kid] += 1;
+        }
+        ctx->free_events.push_back(r.a);
+        ctx->free_events.push_back(r.b);
+    }
+    ctx->pending.clear();
+    return 0;
+}
+
+extern "C" int lthip_timing_enable(lthip_ctx* ctx, int on)
+{
+    if (!ctx)
+        return EINVAL;
+    int err = timing_collect(ctx);
+    ctx->timing = on != 0;
+    return err;
+}
+
+extern "C" int lthip_timing_reset(lthip_ctx* ctx)
+{
+    if (!ctx)
+        return EINVAL;
+    int err = timing_collect(ctx);
+    memset(ctx->total_ms, 0, sizeof ctx->total_ms);
+    memset(ctx->launches, 0, sizeof ctx->launches);
+    return err;
+}
+
+extern "C" int lthip_timing_get(lthip_ctx* ctx, int kernel_id, double* out_total_ms, uint64_t* out_launches)
+{
+    if (!ctx || kernel_id < 0 || kernel_id >= LTHIP_K_COUNT)
+        return EINVAL;
+    int err = timing_collect(ctx);
+    if (out_total_ms)
+        *out_total_ms = ctx->total_ms[kernel_id];
+    if (out_launches)
+        *out_launches = ctx->launches[kernel_id];
+    return err;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// plans
+// ---------------------------------------------------------------------------------------------------
+// hpcdcchunker.c:126-129 -- the one floating-point step of the path, evaluated on the host in double
+// exactly like the reference.
+static uint32_t discriminator_from_avg(uint32_t avg)
+{
+    double a = (double)avg;
+    return (uint32_t)(a / (-1.42888852e-7 * a + 1.33237515));
+}
+
+// Division-free form of the reference's cut test `hash % d == d-1` (hpcdcchunker.c:298).
+//   h % d == d-1  <=>  x = h+1 (as an integer in [1, 2^32]) is a multiple of d.
+// Write d = dodd * 2^k2, inv = dodd^-1 (mod 2^32).  Multiplication by inv permutes Z/2^32 and maps the
+// multiples of dodd onto [0, floor((2^32-1)/dodd)], so for x in [1, 2^32-1]:
+//   d | x  <=>  M = x*inv (mod 2^32) has k2 trailing zero bits and 1 <= M >> k2 <= q,  q = floor((2^32-1)/d)
+//          <=>  ror32(M - 2^k2, k2) <= q-1          (a wrong low bit, or M = 0, lands in the top bits)
+// and M - 2^k2 = h*inv + (inv - 2^k2), one multiply-add.  x = 2^32 (h = 0xFFFFFFFF) gives M = 0, which is
+// rejected -- correct unless d is a power of two, which gets its own mask test.
+static DivTest make_div_test(uint32_t d)
+{
+    DivTest t;
+    memset(&t, 0, sizeof t);
+    t.d = d;
+    if (d == 0)
+        return t; // rejected by plan_create
+    uint32_t k2 = 0, dodd = d;
+    while ((dodd & 1u) == 0)
+    {
+        dodd >>= 1;
+        ++k2;
+    }
+    uint32_t inv = dodd; // Newton iteration, 5 steps give 32 bits
+    for (int i = 0; i < 5; ++i)
+        inv *= 2u - dodd * inv;
+    t.inv = inv;
+    t.k2 = k2;
+    t.addc = inv - (1u << k2);
+    t.qlim = (uint32_t)(0xFFFFFFFFull / d) - 1u;
+    t.pow2 = dodd == 1u;
+    return t;
+}
+
+extern "C" int lthip_divtest_eval(uint32_t discriminator, uint32_t hash)
+{
+    if (discriminator == 0)
+        return 0;
+    const DivTest t = make_div_test(discriminator);
+    if (t.pow2)
+        return (hash & (t.d - 1u)) == t.d - 1u;
+    const uint32_t m = hash * t.inv + t.addc;
+    const uint32_t r = t.k2 ? ((m >> t.k2) | (m << (32u - t.k2))) : m;
+    return r <= t.qlim;
+}
+
+extern "C" int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const uint64_t* part_offsets,
+                                 const uint64_t* part_sizes, uint32_t min_chunk, uint32_t avg_chunk, uint32_t max_chunk,
+                                 lthip_plan** out_plan)
+{
+    if (!ctx || !out_plan || (part_count && (!part_offsets || !part_sizes)))
+        return EINVAL;
+    *out_plan = nullptr;
+    // same parameter contract as Longtail_HPCDCCreateChunker (hpcdcchunker.c:143-146)
+    if (min_chunk < 48 || min_chunk > avg_chunk || avg_chunk > max_chunk)
+        return lthip_fail(ctx, EINVAL, "lthip_plan_create", "need 48 <= min <= avg <= max");
+    uint32_t d = discriminator_from_avg(avg_chunk);
+    if (d == 0)
+        return lthip_fail(ctx, EINVAL, "lthip_plan_create", "discriminator is zero");
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+
+    lthip_plan* plan = new (std::nothrow) lthip_plan();
+    if (!plan)
+        return ENOMEM;
+    memset(plan, 0, sizeof *plan);
+    plan->nparts = part_count;
+    plan->min_chunk = min_chunk;
+    plan->avg_chunk = avg_chunk;
+    plan->max_chunk = max_chunk;
+    plan->div = make_div_test(d);
+
+    std::vector<PartDev> parts(part_count ? part_count : 1);
+    uint64_t tiles = 0, bm0 = 0, bm1 = 0, region = 0, bytes = 0, leaves = 0;
+    for (uint32_t p = 0; p < part_count; ++p)
+    {
+        uint64_t sz = part_sizes[p];
+        if ((part_offsets[p] & 15u) != 0 || sz > 0xFFFFFFFFull)
+        {
+            delete plan;
+            return lthip_fail(ctx, EINVAL, "lthip_plan_create", "part offsets must be 16-byte aligned, sizes < 4 GiB");
+        }
+        PartDev& pd = parts[p];
+        pd.off = part_offsets[p];
+        pd.size = sz;
+        pd.bm0_base = bm0;
+        pd.bm1_base = bm1;
+        pd.region_base = region;
+        pd.tile_base = (uint32_t)tiles;
+        uint64_t cap = sz ? sz / min_chunk + 1 : 0; // every chunk but the last is >= min bytes
+        pd.region_cap = (uint32_t)cap;
+        uint64_t t = div_up_u64(sz, 16384);
+        tiles += t;
+        bm0 += t * 256; // one 64-bit word per 64-byte run, whole tiles
+        bm1 += t * 4;   // one 64-bit word per 4 KiB
+        region += cap;
+        bytes += sz;
+        leaves += div_up_u64(sz, 1024) + cap;
+    }
+    if (tiles > 0xFFFFFFF0ull)
+    {
+        delete plan;
+        return lthip_fail(ctx, EINVAL, "lthip_plan_create", "batch too large");
+    }
+    plan->ntiles = tiles;
+    plan->bm0_words = bm0;
+    plan->bm1_words = bm1;
+    plan->chunk_cap = region;
+    plan->total_bytes = bytes;
+    plan->leaf_cap = leaves;
+
+    hipError_t e = hipMalloc((void**)&plan->d_parts, sizeof(PartDev) * (part_count ? part_count : 1));
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&plan->d_tile_part, sizeof(uint32_t) * (tiles ? tiles : 1));
+    if (e == hipSuccess && part_count)
+        e = hipMemcpyAsync(plan->d_parts, parts.data(), sizeof(PartDev) * part_count, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream); // `parts` is a local
+    if (e != hipSuccess)
+    {
+        lthip_plan_destroy(ctx, plan);
+        return lthip_fail(ctx, e == hipErrorOutOfMemory ? ENOMEM : EIO, "lthip_plan_create", hipGetErrorString(e));
+    }
+    int err = lthip_launch_tile_table(ctx, plan);
+    if (err)
+    {
+        lthip_plan_destroy(ctx, plan);
+        return err;
+    }
+    *out_plan = plan;
+    return 0;
+}
+
+extern "C" void lthip_plan_destroy(lthip_ctx* ctx, lthip_plan* plan)
+{
+    if (!plan)
+        return;
+    if (ctx)
+    {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (plan->d_parts)
+        (void)hipFree(plan->d_parts);
+    if (plan->d_tile_part)
+        (void)hipFree(plan->d_tile_part);
+    delete plan;
+}
+
+extern "C" uint64_t lthip_plan_chunk_capacity(const lthip_plan* plan) { return plan ? plan->chunk_cap : 0; }
+
+// ---------------------------------------------------------------------------------------------------
+// phase 1
+// ---------------------------------------------------------------------------------------------------
+extern "C" int lthip_chunk_hash(lthip_ctx* ctx, const lthip_plan* plan, const void* d_data, uint64_t* d_chunk_offsets,
+                                uint32_t* d_chunk_lens, uint64_t* d_chunk_hashes, uint32_t* d_part_first,
+                                uint64_t* out_total)
+{
+    if (!ctx || !plan || !d_chunk_offsets || !d_chunk_lens || !d_part_first || (plan->total_bytes && !d_data))
+        return EINVAL;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    void *bm0, *bm1, *region, *pcount;
+    int err;
+    if ((err = lthip_scratch(ctx, S_BM0, plan->bm0_words * 8, &bm0)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_BM1, plan->bm1_words * 8, &bm1)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_REGION, plan->chunk_cap * sizeof(uint2), &region)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_PART_COUNT, ((size_t)plan->nparts + 1) * 4, &pcount)))
+        return err;
+
+    if (plan->nparts)
+    {
+        if ((err = lthip_launch_buzhash(ctx, plan, (const uint8_t*)d_data, (uint64_t*)bm0, (uint64_t*)bm1)))
+            return err;
+        if ((err = lthip_launch_select(ctx, plan, (const uint64_t*)bm0, (const uint64_t*)bm1, (uint2*)region,
+                                       (uint32_t*)pcount)))
+            return err;
+    }
+    if ((err = lthip_launch_compact(ctx, plan, (const uint2*)region, (const uint32_t*)pcount, d_part_first,
+                                    d_chunk_offsets, d_chunk_lens)))
+        return err;
+    if (d_chunk_hashes)
+    {
+        if ((err = lthip_launch_blake3(ctx, (const uint8_t*)d_data, d_chunk_offsets, d_chunk_lens,
+                                       d_part_first + plan->nparts, plan->chunk_cap, plan->leaf_cap, plan->max_chunk,
+                                       d_chunk_hashes)))
+            return err;
+    }
+    if (out_total)
+    {
+        uint32_t total = 0;
+        LTHIP_CHECK(ctx, hipMemcpyAsync(&total, d_part_first + plan->nparts, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        *out_total = total;
+    }
+    return 0;
+}
+
+extern "C" int lthip_chunk_from_buffer(lthip_ctx* ctx, const void* d_data, uint64_t size, uint32_t min_chunk,
+                                       uint32_t avg_chunk, uint32_t max_chunk, uint64_t* out_len)
+{
+    if (!ctx || !d_data || !out_len || size == 0)
+        return EINVAL;
+    if (min_chunk < 48 || min_chunk > avg_chunk || avg_chunk > max_chunk)
+        return lthip_fail(ctx, EINVAL, "lthip_chunk_from_buffer", "need 48 <= min <= avg <= max");
+    if (size <= min_chunk)
+    {
+        *out_len = size; // hpcdcchunker.c:479-484
+        return 0;
+    }
+    const uint32_t d = discriminator_from_avg(avg_chunk);
+    if (d == 0)
+        return lthip_fail(ctx, EINVAL, "lthip_chunk_from_buffer", "discriminator is zero");
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    void* d_out;
+    int err = lthip_scratch(ctx, S_MISC, 64, &d_out);
+    if (err)
+        return err;
+    const uint32_t n = (uint32_t)(size > max_chunk ? max_chunk : size);
+    if ((err = lthip_launch_from_buffer(ctx, (const uint8_t*)d_data, n, min_chunk, make_div_test(d), (uint64_t*)d_out)))
+        return err;
+    uint64_t len = 0;
+    LTHIP_CHECK(ctx, hipMemcpyAsync(&len, d_out, 8, hipMemcpyDeviceToHost, ctx->stream));
+    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *out_len = len;
+    return 0;
+}
+
+extern "C" int lthip_hash_ranges(lthip_ctx* ctx, const void* d_data, uint64_t range_count, const uint64_t* d_offsets,
+                                 const uint32_t* d_lens, uint32_t max_len, uint64_t* d_hashes)
+{
+    if (!ctx || (range_count && (!d_offsets || !d_lens || !d_hashes)))
+        return EINVAL;
+    if (range_count == 0)
+        return 0;
+    if (range_count > 0xFFFFFFF0ull)
+        return EINVAL;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // leaf bound unknown without reading the lengths: 0 => the launcher sizes the grid from the scanned total
+    return lthip_launch_blake3(ctx, (const uint8_t*)d_data, d_offsets, d_lens, nullptr, range_count, 0, max_len, d_hashes);
+}

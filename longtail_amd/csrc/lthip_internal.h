@@ -1,0 +1,150 @@
+// lthip_internal.h -- shared declarations of liblongtail_hip.so (C++/HIP side, gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <errno.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/longtail_hip.h"
+
+// ---------------------------------------------------------------------------------------------------
+// device-side descriptors
+// ---------------------------------------------------------------------------------------------------
+struct PartDev
+{
+    uint64_t off;         // byte offset of the part in the data buffer (16-byte aligned)
+    uint64_t size;        // bytes (< 2^32)
+    uint64_t bm0_base;    // first 64-bit word of this part in the level-0 candidate bitmap (1 bit / byte)
+    uint64_t bm1_base;    // first 64-bit word in the level-1 summary (1 bit / 64-byte run)
+    uint64_t region_base; // first slot of this part in the bounded (rel_off,len) chunk region
+    uint32_t tile_base;   // first buzhash tile of this part
+    uint32_t region_cap;  // slots in the region
+};
+
+// exact "H % d == d-1" test without a division:  d = dodd << k2 ;  inv = dodd^-1 mod 2^32
+//   t = ror32(h*inv + addc, k2) <= qlim            (lthip_plan.cpp explains the derivation)
+struct DivTest
+{
+    uint32_t d;
+    uint32_t inv;
+    uint32_t addc;
+    uint32_t k2;
+    uint32_t qlim;
+    uint32_t pow2; // d is a power of two: test (h & (d-1)) == d-1 instead
+};
+
+struct lthip_plan
+{
+    uint32_t nparts;
+    uint32_t min_chunk, avg_chunk, max_chunk;
+    DivTest div;
+    uint64_t total_bytes;
+    uint64_t ntiles;
+    uint64_t chunk_cap;
+    uint64_t bm0_words;
+    uint64_t bm1_words;
+    uint64_t leaf_cap;
+    PartDev* d_parts;
+    uint32_t* d_tile_part;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------
+enum ScratchSlot
+{
+    S_BM0 = 0,
+    S_BM1,
+    S_REGION,      // uint2 {rel_off, len} per bounded chunk slot
+    S_PART_COUNT,  // u32 per part
+    S_LEAF_COUNT,  // u32 per dense chunk (+1)
+    S_LEAF_PREFIX, // u32 per dense chunk (+1)
+    S_SCAN_TMP,
+    S_CV,          // 8 x u32 per leaf
+    S_LZ4_SEGS,    // segment descriptors
+    S_LZ4_META,    // per-segment results
+    S_LZ4_STREAM,  // per-segment sequence streams
+    S_LZ4_BLOCKS,  // block tables
+    S_TABLES,      // small H2D tables
+    S_TABLES2,
+    S_MISC,
+    S_COUNT
+};
+
+struct TimingRec
+{
+    int kid;
+    hipEvent_t a, b;
+};
+
+struct lthip_ctx
+{
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    char err[320];
+    void* scratch[S_COUNT];
+    size_t scratch_cap[S_COUNT];
+    bool timing;
+    std::vector<TimingRec> pending;
+    std::vector<hipEvent_t> free_events;
+    double total_ms[LTHIP_K_COUNT];
+    uint64_t launches[LTHIP_K_COUNT];
+};
+
+int lthip_fail(lthip_ctx* ctx, int code, const char* what, const char* detail);
+int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out);
+
+#define LTHIP_CHECK(ctx, expr)                                                          \
+    do                                                                                  \
+    {                                                                                   \
+        hipError_t e__ = (expr);                                                        \
+        if (e__ != hipSuccess)                                                          \
+            return lthip_fail((ctx), e__ == hipErrorOutOfMemory ? ENOMEM : EIO, #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+// timing brackets around a launch on ctx->stream
+struct LaunchTimer
+{
+    lthip_ctx* ctx;
+    TimingRec rec;
+    bool on;
+    LaunchTimer(lthip_ctx* c, int kid);
+    ~LaunchTimer();
+};
+
+#define LTHIP_LAUNCH_CHECK(ctx)                                                          \
+    do                                                                                   \
+    {                                                                                    \
+        hipError_t e__ = hipGetLastError();                                              \
+        if (e__ != hipSuccess)                                                           \
+            return lthip_fail((ctx), EIO, "kernel launch", hipGetErrorString(e__));      \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// kernel launchers implemented in the k_*.hip files
+// ---------------------------------------------------------------------------------------------------
+int lthip_launch_tile_table(lthip_ctx* ctx, lthip_plan* plan);
+int lthip_launch_buzhash(lthip_ctx* ctx, const lthip_plan* plan, const uint8_t* d_data, uint64_t* bm0, uint64_t* bm1);
+int lthip_launch_select(lthip_ctx* ctx, const lthip_plan* plan, const uint64_t* bm0, const uint64_t* bm1, uint2* region,
+                        uint32_t* part_count);
+int lthip_launch_compact(lthip_ctx* ctx, const lthip_plan* plan, const uint2* region, const uint32_t* part_count,
+                         uint32_t* d_part_first, uint64_t* d_chunk_offsets, uint32_t* d_chunk_lens);
+int lthip_exclusive_scan_u32(lthip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64_t n_bound, const uint32_t* d_n,
+                             int kid);
+// BLAKE3-64 of count ranges (count = min(count_bound, *d_count) when d_count != null).  leaf_bound = upper bound on
+// the total number of 1 KiB leaves (0 = unknown: read it back from the device), max_len = upper bound on a single
+// range's length (0 = unknown).
+int lthip_launch_blake3(lthip_ctx* ctx, const uint8_t* d_data, const uint64_t* d_offsets, const uint32_t* d_lens,
+                        const uint32_t* d_count, uint64_t count_bound, uint64_t leaf_bound, uint64_t max_len,
+                        uint64_t* d_hashes);
+
+int lthip_launch_from_buffer(lthip_ctx* ctx, const uint8_t* d_data, uint32_t n, uint32_t min_chunk, const DivTest& dv,
+                             uint64_t* d_out);
+
+static inline uint64_t div_up_u64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,155 @@
+/* plugin_codec.c -- Longtail_CompressionAPI objects (LZ4, ZStd) on the GPU; C99 host code over lthip_*.
+ *
+ * Mirrors the reference wrappers
+ *   lib/lz4/longtail_lz4.c   : type id 'lz42' (:10), CreateForLZ4 (:12-23), bound (:47-50), Compress (:52-77,
+ *                              0 bytes -> ENOMEM), Decompress (:79-102, malformed -> EBADF)
+ *   lib/zstd/longtail_zstd.c : type ids 'ztd1'..'ztd5' (:17-22), CreateForZstd (:30-41), bound (:72-75),
+ *                              Compress (:107-141), Decompress (:144-177)
+ * Called by CompressBlock / DecompressBlock only (lib/compressblockstore/longtail_compressblockstore.c:106,121,321);
+ * `compressed` there is &header[2], i.e. only 4-byte aligned host memory -- nothing here assumes more.
+ */
+#include "plugin_common.h"
+
+#define LTP_LZ4_TYPE ((((uint32_t)'l') << 24) + (((uint32_t)'z') << 16) + (((uint32_t)'4') << 8) + ((uint32_t)'2'))
+#define LTP_ZSTD_TYPE ((((uint32_t)'z') << 24) + (((uint32_t)'t') << 16) + (((uint32_t)'d') << 8))
+
+enum
+{
+    CODEC_LZ4 = 0,
+    CODEC_ZSTD = 1
+};
+
+struct HipCodecAPI
+{
+    struct Longtail_CompressionAPI api;
+    int codec;
+};
+
+static void HipCodec_Dispose(struct Longtail_API* api) { ltp_free(api); }
+
+static size_t HipCodec_GetMaxCompressedSize(struct Longtail_CompressionAPI* compression_api, uint32_t settings_id, size_t size)
+{
+    (void)settings_id;
+    struct HipCodecAPI* a = (struct HipCodecAPI*)compression_api;
+    return a->codec == CODEC_LZ4 ? lthip_lz4_bound(size) : lthip_zstd_bound(size);
+}
+
+/* one block through the bulk API: host -> device -> kernels -> host */
+static int run_block(int codec, int decompress, const char* src, char* dst, size_t n, size_t cap, size_t* out_n)
+{
+    struct ltp_thread_state* ts = ltp_thread_state_get();
+    if (!ts)
+        return ENODEV;
+    if (n > 0x7E000000u || cap > 0xFFFFFFF0u)
+        return EINVAL;
+    lthip_ctx* ctx = ts->ctx;
+    int err = ltp_dev_reserve(ctx, &ts->d_in, n + 64);
+    if (!err)
+        err = ltp_dev_reserve(ctx, &ts->d_out, cap + 64);
+    if (!err)
+        err = ltp_dev_reserve(ctx, &ts->d_aux, 64);
+    if (!err)
+        err = ltp_pin_reserve(ctx, &ts->h_pin, 64);
+    if (!err && n)
+        err = lthip_copy_h2d(ctx, ts->d_in.p, src, n);
+    if (err)
+        return err;
+    const uint64_t zero = 0;
+    const uint32_t sz = (uint32_t)n, dcap = (uint32_t)cap;
+    if (decompress)
+        err = lthip_lz4_decompress_blocks(ctx, ts->d_in.p, 1, &zero, &sz, ts->d_out.p, &zero, &dcap, (uint32_t*)ts->d_aux.p);
+    else if (codec == CODEC_LZ4)
+        err = lthip_lz4_compress_blocks(ctx, ts->d_in.p, 1, &zero, &sz, ts->d_out.p, &zero, &dcap, (uint32_t*)ts->d_aux.p, 0);
+    else
+        err = lthip_zstd_compress_blocks(ctx, ts->d_in.p, 1, &zero, &sz, ts->d_out.p, &zero, &dcap, (uint32_t*)ts->d_aux.p);
+    uint32_t* h_size = (uint32_t*)ts->h_pin.p;
+    if (!err)
+        err = lthip_copy_d2h(ctx, h_size, ts->d_aux.p, 4);
+    if (!err)
+        err = lthip_ctx_sync(ctx);
+    if (err)
+        return err;
+    const uint32_t produced = *h_size;
+    if (decompress)
+    {
+        if (produced == 0xFFFFFFFFu)
+            return EBADF; /* longtail_lz4.c:95-99 */
+    }
+    else if (produced == 0)
+        return ENOMEM; /* longtail_lz4.c:70-74 */
+    if (produced > cap)
+        return EIO;
+    if (produced)
+    {
+        err = lthip_copy_d2h(ctx, dst, ts->d_out.p, produced);
+        if (!err)
+            err = lthip_ctx_sync(ctx);
+    }
+    if (!err)
+        *out_n = produced;
+    return err;
+}
+
+static int HipCodec_Compress(struct Longtail_CompressionAPI* compression_api, uint32_t settings_id, const char* uncompressed,
+                             char* compressed, size_t uncompressed_size, size_t max_compressed_size,
+                             size_t* out_compressed_size)
+{
+    if (!compression_api || !compressed || !out_compressed_size || (uncompressed_size && !uncompressed))
+        return EINVAL;
+    struct HipCodecAPI* a = (struct HipCodecAPI*)compression_api;
+    if (a->codec == CODEC_LZ4 && settings_id != LTP_LZ4_TYPE)
+        return EINVAL; /* longtail_lz4.c:33 */
+    if (a->codec == CODEC_ZSTD && (settings_id & 0xffffff00u) != LTP_ZSTD_TYPE)
+        return EINVAL;
+    return run_block(a->codec, 0, uncompressed, compressed, uncompressed_size, max_compressed_size, out_compressed_size);
+}
+
+static int HipCodec_Decompress(struct Longtail_CompressionAPI* compression_api, const char* compressed, char* uncompressed,
+                               size_t compressed_size, size_t max_uncompressed_size, size_t* out_uncompressed_size)
+{
+    if (!compression_api || !compressed || !out_uncompressed_size || (max_uncompressed_size && !uncompressed))
+        return EINVAL;
+    struct HipCodecAPI* a = (struct HipCodecAPI*)compression_api;
+    if (a->codec != CODEC_LZ4)
+        return ENOTSUP; /* GPU zstd decoder: SURVEY.md §8 f3, not built yet -- register the reference decoder for reads */
+    return run_block(a->codec, 1, compressed, uncompressed, compressed_size, max_uncompressed_size, out_uncompressed_size);
+}
+
+static struct Longtail_CompressionAPI* make_codec(int codec)
+{
+    if (lthip_device_count() <= 0)
+        return 0; /* no GPU: fail loudly */
+    struct HipCodecAPI* a = (struct HipCodecAPI*)ltp_alloc("HipCompressionAPI", sizeof *a);
+    if (!a)
+        return 0;
+    a->api.m_API.Dispose = HipCodec_Dispose;
+    a->api.GetMaxCompressedSize = HipCodec_GetMaxCompressedSize;
+    a->api.Compress = HipCodec_Compress;
+    a->api.Decompress = HipCodec_Decompress;
+    a->codec = codec;
+    return &a->api;
+}
+
+uint32_t Longtail_GetHipLZ4DefaultQuality(void) { return LTP_LZ4_TYPE; }
+
+struct Longtail_CompressionAPI* Longtail_CreateHipLZ4CompressionAPI(void) { return make_codec(CODEC_LZ4); }
+
+struct Longtail_CompressionAPI* Longtail_CompressionRegistry_CreateForHipLZ4(uint32_t compression_type, uint32_t* out_settings)
+{
+    if (compression_type != LTP_LZ4_TYPE)
+        return 0;
+    if (out_settings)
+        *out_settings = compression_type;
+    return Longtail_CreateHipLZ4CompressionAPI();
+}
+
+struct Longtail_CompressionAPI* Longtail_CreateHipZStdCompressionAPI(void) { return make_codec(CODEC_ZSTD); }
+
+struct Longtail_CompressionAPI* Longtail_CompressionRegistry_CreateForHipZstd(uint32_t compression_type, uint32_t* out_settings)
+{
+    if ((compression_type & 0xffffff00u) != LTP_ZSTD_TYPE)
+        return 0;
+    if (out_settings)
+        *out_settings = compression_type;
+    return Longtail_CreateHipZStdCompressionAPI();
+}

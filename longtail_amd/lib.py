@@ -1,0 +1,301 @@
+"""ctypes binding of liblongtail_hip.so (include/longtail_hip.h) + thin torch-tensor conveniences.
+
+Nothing here computes anything on the CPU: every call goes through the C ABI into the HIP kernels, and loading
+fails loudly when the library (or a GPU, for the compute entry points) is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import errno
+import os
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+_LIB_PATH = Path(__file__).resolve().parent / "liblongtail_hip.so"
+
+KERNEL_IDS = {
+    "buzhash": 0,
+    "select": 1,
+    "compact": 2,
+    "blake3_leaf": 3,
+    "blake3_parent": 4,
+    "lz4_segments": 5,
+    "lz4_stitch": 6,
+    "other": 7,
+}
+
+
+class LongtailHipError(RuntimeError):
+    def __init__(self, code: int, what: str, detail: str = ""):
+        self.code = code
+        super().__init__(f"{what}: errno {code} ({errno.errorcode.get(code, '?')}) {detail}")
+
+
+def _u64arr(a: Sequence[int]) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+
+
+def _u32arr(a: Sequence[int]) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint32))
+
+
+class HipLib:
+    """The loaded shared library with argtypes/restypes set."""
+
+    def __init__(self, path: Optional[os.PathLike] = None):
+        p = Path(path) if path else _LIB_PATH
+        if not p.exists():
+            raise FileNotFoundError(
+                f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` or `make` first "
+                "(there is no CPU fallback)"
+            )
+        self.path = p
+        self.dll = C.CDLL(str(p))
+        d = self.dll
+        vp, u64, u32, i32, sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_size_t
+        P = C.POINTER
+
+        def sig(name, res, args):
+            f = getattr(d, name)
+            f.restype = res
+            f.argtypes = args
+            return f
+
+        # --- plugin constructors ---
+        sig("Longtail_CreateHipChunkerAPI", vp, [])
+        sig("Longtail_CreateHipBlake3HashAPI", vp, [])
+        sig("Longtail_CreateHipLZ4CompressionAPI", vp, [])
+        sig("Longtail_CompressionRegistry_CreateForHipLZ4", vp, [u32, P(u32)])
+        sig("Longtail_GetHipLZ4DefaultQuality", u32, [])
+        sig("Longtail_CreateHipZStdCompressionAPI", vp, [])
+        sig("Longtail_CompressionRegistry_CreateForHipZstd", vp, [u32, P(u32)])
+        sig("Longtail_Hip_SetAllocator", None, [vp, vp])
+        sig("Longtail_Hip_SetDevice", i32, [i32])
+        # --- bulk API ---
+        sig("lthip_ctx_create", i32, [i32, vp, P(vp)])
+        sig("lthip_ctx_destroy", None, [vp])
+        sig("lthip_ctx_sync", i32, [vp])
+        sig("lthip_ctx_error", C.c_char_p, [vp])
+        sig("lthip_device_count", i32, [])
+        sig("lthip_malloc_device", i32, [vp, sz, P(vp)])
+        sig("lthip_free_device", None, [vp, vp])
+        sig("lthip_malloc_pinned", i32, [vp, sz, P(vp)])
+        sig("lthip_free_pinned", None, [vp, vp])
+        sig("lthip_copy_h2d", i32, [vp, vp, vp, sz])
+        sig("lthip_copy_d2h", i32, [vp, vp, vp, sz])
+        sig("lthip_timing_enable", i32, [vp, i32])
+        sig("lthip_timing_reset", i32, [vp])
+        sig("lthip_timing_get", i32, [vp, i32, P(C.c_double), P(u64)])
+        sig("lthip_plan_create", i32, [vp, u32, vp, vp, u32, u32, u32, P(vp)])
+        sig("lthip_plan_destroy", None, [vp, vp])
+        sig("lthip_plan_chunk_capacity", u64, [vp])
+        sig("lthip_chunk_hash", i32, [vp, vp, vp, vp, vp, vp, vp, P(u64)])
+        sig("lthip_chunk_from_buffer", i32, [vp, vp, u64, u32, u32, u32, P(u64)])
+        sig("lthip_hash_ranges", i32, [vp, vp, u64, vp, vp, u32, vp])
+        sig("lthip_lz4_bound", sz, [sz])
+        sig("lthip_lz4_compress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp, i32])
+        sig("lthip_lz4_decompress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
+        sig("lthip_zstd_bound", sz, [sz])
+        sig("lthip_zstd_compress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
+        sig("lthip_dedup_first_seen", i32, [vp, u64, vp, vp, vp])
+        sig("lthip_synth_fill", i32, [vp, vp, u32, vp, vp, vp, i32])
+        sig("lthip_divtest_eval", i32, [u32, u32])
+
+    def device_count(self) -> int:
+        return int(self.dll.lthip_device_count())
+
+
+_lib: Optional[HipLib] = None
+
+
+def load(path: Optional[os.PathLike] = None) -> HipLib:
+    global _lib
+    if _lib is None or path is not None:
+        _lib = HipLib(path)
+    return _lib
+
+
+def _ptr(t) -> int:
+    """device/host pointer of a torch tensor or numpy array (0 for None)."""
+    if t is None:
+        return 0
+    if isinstance(t, np.ndarray):
+        return t.ctypes.data
+    return int(t.data_ptr())
+
+
+class Context:
+    """One lthip_ctx bound to a torch device and (by default) torch's current stream on it."""
+
+    def __init__(self, device: int = 0, stream: "object | None" = "torch", lib: Optional[HipLib] = None):
+        import torch
+
+        self.lib = lib or load()
+        self.torch = torch
+        self.device = device
+        raw_stream = 0
+        if stream == "torch":
+            raw_stream = int(torch.cuda.current_stream(device).cuda_stream)
+        elif stream is not None:
+            raw_stream = int(stream)
+        h = C.c_void_p()
+        err = self.lib.dll.lthip_ctx_create(device, C.c_void_p(raw_stream), C.byref(h))
+        if err:
+            raise LongtailHipError(err, "lthip_ctx_create", "(no GPU?)" if err == errno.ENODEV else "")
+        self.h = h
+
+    # -- plumbing --
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dll.lthip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, err: int, what: str):
+        if err:
+            msg = self.lib.dll.lthip_ctx_error(self.h)
+            raise LongtailHipError(err, what, msg.decode() if msg else "")
+
+    def sync(self):
+        self._check(self.lib.dll.lthip_ctx_sync(self.h), "lthip_ctx_sync")
+
+    def timing(self, on: bool):
+        self._check(self.lib.dll.lthip_timing_enable(self.h, 1 if on else 0), "lthip_timing_enable")
+
+    def timing_reset(self):
+        self._check(self.lib.dll.lthip_timing_reset(self.h), "lthip_timing_reset")
+
+    def timing_get(self) -> dict:
+        out = {}
+        for name, kid in KERNEL_IDS.items():
+            ms, n = C.c_double(0), C.c_uint64(0)
+            self._check(self.lib.dll.lthip_timing_get(self.h, kid, C.byref(ms), C.byref(n)), "lthip_timing_get")
+            out[name] = (ms.value, n.value)
+        return out
+
+    def _dev(self):
+        return self.torch.device("cuda", self.device)
+
+    # -- synthetic data --
+    def synth_fill(self, dst, offsets, sizes, seeds, kind: int):
+        o, s, sd = _u64arr(offsets), _u64arr(sizes), _u64arr(seeds)
+        self._check(
+            self.lib.dll.lthip_synth_fill(self.h, _ptr(dst), len(o), o.ctypes.data, s.ctypes.data, sd.ctypes.data, kind),
+            "lthip_synth_fill",
+        )
+
+    # -- phase 1 --
+    def make_plan(self, part_offsets, part_sizes, min_chunk: int, avg_chunk: int, max_chunk: int) -> "Plan":
+        return Plan(self, part_offsets, part_sizes, min_chunk, avg_chunk, max_chunk)
+
+    def chunk_hash(self, plan: "Plan", data, want_hashes: bool = True, outputs=None, sync: bool = True):
+        """-> (total, offsets u64[cap], lens u32[cap], hashes u64[cap] | None, part_first u32[nparts+1]) torch tensors."""
+        torch = self.torch
+        cap = max(1, plan.capacity)
+        if outputs is None:
+            dev = self._dev()
+            offs = torch.empty(cap, dtype=torch.int64, device=dev)
+            lens = torch.empty(cap, dtype=torch.int32, device=dev)
+            hashes = torch.empty(cap, dtype=torch.int64, device=dev) if want_hashes else None
+            first = torch.empty(plan.nparts + 1, dtype=torch.int32, device=dev)
+        else:
+            offs, lens, hashes, first = outputs
+        total = C.c_uint64(0)
+        err = self.lib.dll.lthip_chunk_hash(
+            self.h, plan.h, _ptr(data), _ptr(offs), _ptr(lens), _ptr(hashes), _ptr(first), C.byref(total) if sync else None
+        )
+        self._check(err, "lthip_chunk_hash")
+        return (int(total.value) if sync else None), offs, lens, hashes, first
+
+    def hash_ranges(self, data, offsets, lens, max_len: int = 0):
+        torch = self.torch
+        n = int(offsets.numel())
+        out = torch.empty(max(1, n), dtype=torch.int64, device=self._dev())
+        self._check(
+            self.lib.dll.lthip_hash_ranges(self.h, _ptr(data), n, _ptr(offsets), _ptr(lens), max_len, _ptr(out)),
+            "lthip_hash_ranges",
+        )
+        return out[:n]
+
+    def chunk_from_buffer(self, data, size: int, min_chunk: int, avg_chunk: int, max_chunk: int) -> int:
+        out = C.c_uint64(0)
+        self._check(
+            self.lib.dll.lthip_chunk_from_buffer(self.h, _ptr(data), size, min_chunk, avg_chunk, max_chunk, C.byref(out)),
+            "lthip_chunk_from_buffer",
+        )
+        return int(out.value)
+
+    # -- phase 2 --
+    def _codec(self, fn, src, src_offsets, src_sizes, dst, dst_offsets, dst_caps, extra=()):
+        torch = self.torch
+        so, ss = _u64arr(src_offsets), _u32arr(src_sizes)
+        do, dc = _u64arr(dst_offsets), _u32arr(dst_caps)
+        n = len(so)
+        out_sizes = torch.empty(max(1, n), dtype=torch.int32, device=self._dev())
+        err = fn(self.h, _ptr(src), n, so.ctypes.data, ss.ctypes.data, _ptr(dst), do.ctypes.data, dc.ctypes.data,
+                 _ptr(out_sizes), *extra)
+        self._check(err, fn.__name__)
+        return out_sizes[:n]
+
+    def lz4_compress_blocks(self, src, src_offsets, src_sizes, dst, dst_offsets, dst_caps, segment_log2: int = 0):
+        return self._codec(self.lib.dll.lthip_lz4_compress_blocks, src, src_offsets, src_sizes, dst, dst_offsets,
+                           dst_caps, (segment_log2,))
+
+    def lz4_decompress_blocks(self, src, src_offsets, src_sizes, dst, dst_offsets, dst_caps):
+        return self._codec(self.lib.dll.lthip_lz4_decompress_blocks, src, src_offsets, src_sizes, dst, dst_offsets,
+                           dst_caps)
+
+    def zstd_compress_blocks(self, src, src_offsets, src_sizes, dst, dst_offsets, dst_caps):
+        return self._codec(self.lib.dll.lthip_zstd_compress_blocks, src, src_offsets, src_sizes, dst, dst_offsets,
+                           dst_caps)
+
+    # -- dedup --
+    def dedup_first_seen(self, hashes):
+        torch = self.torch
+        n = int(hashes.numel())
+        first = torch.empty(max(1, n), dtype=torch.int32, device=self._dev())
+        uniq = torch.zeros(1, dtype=torch.int64, device=self._dev())
+        self._check(self.lib.dll.lthip_dedup_first_seen(self.h, n, _ptr(hashes), _ptr(first), _ptr(uniq)),
+                    "lthip_dedup_first_seen")
+        return first[:n], uniq
+
+
+class Plan:
+    def __init__(self, ctx: Context, part_offsets, part_sizes, min_chunk: int, avg_chunk: int, max_chunk: int):
+        self.ctx = ctx
+        o, s = _u64arr(part_offsets), _u64arr(part_sizes)
+        assert len(o) == len(s)
+        self.nparts = len(o)
+        h = C.c_void_p()
+        err = ctx.lib.dll.lthip_plan_create(ctx.h, self.nparts, o.ctypes.data, s.ctypes.data, min_chunk, avg_chunk,
+                                            max_chunk, C.byref(h))
+        ctx._check(err, "lthip_plan_create")
+        self.h = h
+        self.capacity = int(ctx.lib.dll.lthip_plan_chunk_capacity(h))
+        self.total_bytes = int(s.sum()) if len(s) else 0
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.dll.lthip_plan_destroy(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def chunker_params(target_chunk_size: int, chunker_min: int = 48):
+    """min/avg/max as DynamicChunking derives them (src/longtail.c:1985-1987, 2111-2113)."""
+    mn = max(chunker_min, target_chunk_size // 8)
+    av = max(chunker_min, target_chunk_size // 2)
+    mx = max(chunker_min, target_chunk_size * 2)
+    return mn, av, mx

@@ -7,7 +7,10 @@
  * (hash of 4 bytes -> 13 bits, lz4.c:777-783) else 4096 u32 (hash of 5 bytes -> 12 bits, :785-795).
  * Bit-exact with the reference (tests/test_oracle_lz4.py) -- the GPU encoder is NOT required to be
  * (payloads must round-trip through the reference decoder).
- * Decoder: the strict full-block rules of LZ4_decompress_generic's safe loop, lz4.c:2215-2435.
+ * Decoder: the strict full-block rules of LZ4_decompress_generic's safe loop, lz4.c:2215-2435.  The reference's
+ * "shortcut" / fast-loop paths (lz4.c:2083-2208, 2230-2261) skip some end-of-input checks on MALFORMED streams;
+ * this restatement applies the strict rules everywhere, so it accepts a subset of what the reference accepts and
+ * decodes identically whenever it accepts (tests/test_oracle_vs_ref.py) -- the right polarity for a checker.
  */
 #include "oracle.h"
 
@@ -224,14 +227,16 @@ int lto_lz4_decompress(const uint8_t* src, int n, uint8_t* dst, int cap)
         uint32_t token = src[ip++];
         int64_t len = token >> 4;
         if (len == 15)
-        {
+        { /* read_variable_length(&ip, iend-RUN_MASK, 1), lz4.c:1979-2013 */
             uint32_t b;
+            if (ip >= (int64_t)n - 15)
+                return -1;
             do
             {
-                if (ip >= n)
-                    return -1;
                 b = src[ip++];
                 len += b;
+                if (ip > (int64_t)n - 15)
+                    return -1;
             } while (b == 255);
         }
         /* lz4.c:2279-2329: close to either end => must be the final, literal-only sequence */

@@ -370,6 +370,72 @@ static int get_existing(struct Longtail_BlockStoreAPI* bs, uint32_t n, const TLo
     return err;
 }
 
+/* ---- null backing block store for timing runs ("null / in-memory backing block store") ---- */
+struct null_store
+{
+    struct Longtail_BlockStoreAPI api;
+    TLongtail_Atomic64 bytes;
+    TLongtail_Atomic64 blocks;
+};
+static void null_dispose(struct Longtail_API* a) { Longtail_Free(a); }
+static int null_put(struct Longtail_BlockStoreAPI* a, struct Longtail_StoredBlock* b, struct Longtail_AsyncPutStoredBlockAPI* done)
+{
+    struct null_store* s = (struct null_store*)a;
+    Longtail_AtomicAdd64(&s->bytes, (int64_t)b->m_BlockChunksDataSize);
+    Longtail_AtomicAdd64(&s->blocks, 1);
+    done->OnComplete(done, 0);
+    return 0;
+}
+static int null_preflight(struct Longtail_BlockStoreAPI* a, uint32_t n, const TLongtail_Hash* h, struct Longtail_AsyncPreflightStartedAPI* done)
+{
+    (void)a; (void)n; (void)h;
+    if (done)
+        done->OnComplete(done, 0, 0, 0);
+    return 0;
+}
+static int null_get(struct Longtail_BlockStoreAPI* a, uint64_t h, struct Longtail_AsyncGetStoredBlockAPI* done)
+{
+    (void)a; (void)h; (void)done;
+    return ENOENT;
+}
+static int null_existing(struct Longtail_BlockStoreAPI* a, uint32_t n, const TLongtail_Hash* h, uint32_t pct, struct Longtail_AsyncGetExistingContentAPI* done)
+{
+    (void)a; (void)n; (void)h; (void)pct;
+    struct Longtail_StoreIndex* idx = 0;
+    int err = Longtail_CreateStoreIndexFromBlocks(0, 0, &idx);
+    if (err)
+        return err;
+    done->OnComplete(done, idx, 0);
+    return 0;
+}
+static int null_prune(struct Longtail_BlockStoreAPI* a, uint32_t n, const TLongtail_Hash* h, struct Longtail_AsyncPruneBlocksAPI* done)
+{
+    (void)a; (void)n; (void)h; (void)done;
+    return ENOTSUP;
+}
+static int null_stats(struct Longtail_BlockStoreAPI* a, struct Longtail_BlockStore_Stats* st)
+{
+    struct null_store* s = (struct null_store*)a;
+    memset(st, 0, sizeof *st);
+    st->m_StatU64[Longtail_BlockStoreAPI_StatU64_PutStoredBlock_Byte_Count] = (uint64_t)s->bytes;
+    st->m_StatU64[Longtail_BlockStoreAPI_StatU64_PutStoredBlock_Count] = (uint64_t)s->blocks;
+    return 0;
+}
+static int null_flush(struct Longtail_BlockStoreAPI* a, struct Longtail_AsyncFlushAPI* done)
+{
+    (void)a;
+    if (done)
+        done->OnComplete(done, 0);
+    return 0;
+}
+static struct Longtail_BlockStoreAPI* make_null_store(void)
+{
+    struct null_store* s = (struct null_store*)Longtail_Alloc("refh", sizeof *s);
+    memset(s, 0, sizeof *s);
+    return Longtail_MakeBlockStoreAPI(s, null_dispose, null_put, null_preflight, null_get, null_existing, null_prune,
+                                      null_stats, null_flush);
+}
+
 /* one compression type -> caller-supplied CompressionAPI (kept alive by the caller) */
 static struct Longtail_CompressionAPI* g_foreign_codec;
 static uint32_t g_foreign_type;
@@ -437,12 +503,12 @@ static struct Longtail_CompressionRegistryAPI* make_registry(struct Longtail_Com
  * `tag` is `codec_api` (0 => reference), then RESTORE the tree with a reference-only registry
  * (Longtail_WriteVersion) and compare every file byte for byte.
  * Returns 0 when everything round-trips; stats in out_*. */
-int refh_ingest_roundtrip(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_HashAPI* hash_api,
-                          struct Longtail_CompressionAPI* codec_api, uint32_t tag, uint32_t nfiles,
-                          const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
-                          uint32_t target_chunk_size, uint32_t max_block_size, uint32_t max_chunks_per_block,
-                          int workers, uint64_t* out_chunk_count, uint64_t* out_block_count,
-                          uint64_t* out_stored_bytes, double* out_seconds_index, double* out_seconds_write)
+static int ingest_impl(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_HashAPI* hash_api,
+                       struct Longtail_CompressionAPI* codec_api, uint32_t tag, uint32_t nfiles,
+                       const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
+                       uint32_t target_chunk_size, uint32_t max_block_size, uint32_t max_chunks_per_block,
+                       int workers, int verify, uint64_t* out_chunk_count, uint64_t* out_block_count,
+                       uint64_t* out_stored_bytes, double* out_seconds_index, double* out_seconds_write)
 {
     struct refh_tree t;
     struct Longtail_ChunkerAPI* own_c = 0;
@@ -461,7 +527,7 @@ int refh_ingest_roundtrip(struct Longtail_ChunkerAPI* chunker_api, struct Longta
 
     struct Longtail_StorageAPI* target = Longtail_CreateInMemStorageAPI();
     struct Longtail_CompressionRegistryAPI* reg_w = make_registry(codec_api, tag);
-    struct Longtail_BlockStoreAPI* fs = Longtail_CreateFSBlockStoreAPI(t.jobs, target, "store", 0, 0);
+    struct Longtail_BlockStoreAPI* fs = verify ? Longtail_CreateFSBlockStoreAPI(t.jobs, target, "store", 0, 0) : make_null_store();
     struct Longtail_BlockStoreAPI* cbs = Longtail_CreateCompressBlockStoreAPI(fs, reg_w);
 
     clock_gettime(CLOCK_MONOTONIC, &a);
@@ -498,7 +564,7 @@ int refh_ingest_roundtrip(struct Longtail_ChunkerAPI* chunker_api, struct Longta
     SAFE_DISPOSE_API(reg_w);
 
     /* restore through a REFERENCE-ONLY registry */
-    if (!err)
+    if (!err && verify)
     {
         struct Longtail_CompressionRegistryAPI* reg_r = make_registry(0, 0);
         struct Longtail_BlockStoreAPI* cbs_r = Longtail_CreateCompressBlockStoreAPI(fs, reg_r);
@@ -544,6 +610,30 @@ int refh_ingest_roundtrip(struct Longtail_ChunkerAPI* chunker_api, struct Longta
     SAFE_DISPOSE_API(own_h);
     tree_free(&t);
     return err;
+}
+
+int refh_ingest_roundtrip(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_HashAPI* hash_api,
+                          struct Longtail_CompressionAPI* codec_api, uint32_t tag, uint32_t nfiles,
+                          const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
+                          uint32_t target_chunk_size, uint32_t max_block_size, uint32_t max_chunks_per_block,
+                          int workers, uint64_t* out_chunk_count, uint64_t* out_block_count,
+                          uint64_t* out_stored_bytes, double* out_seconds_index, double* out_seconds_write)
+{
+    return ingest_impl(chunker_api, hash_api, codec_api, tag, nfiles, names, datas, sizes, target_chunk_size,
+                       max_block_size, max_chunks_per_block, workers, 1, out_chunk_count, out_block_count,
+                       out_stored_bytes, out_seconds_index, out_seconds_write);
+}
+
+/* bench.py cpu_baseline leg: the same UpSync sequence, reference plugins, no restore pass */
+int refh_ingest_time(uint32_t tag, uint32_t nfiles, const char* const* names, const uint8_t* const* datas,
+                     const uint64_t* sizes, uint32_t target_chunk_size, uint32_t max_block_size,
+                     uint32_t max_chunks_per_block, int workers, uint64_t* out_chunk_count,
+                     uint64_t* out_block_count, uint64_t* out_stored_bytes, double* out_seconds_index,
+                     double* out_seconds_write)
+{
+    return ingest_impl(0, 0, 0, tag, nfiles, names, datas, sizes, target_chunk_size, max_block_size,
+                       max_chunks_per_block, workers, 0, out_chunk_count, out_block_count, out_stored_bytes,
+                       out_seconds_index, out_seconds_write);
 }
 
 int refh_cpu_count(void) { return (int)Longtail_GetCPUCount(); }

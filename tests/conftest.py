@@ -1,0 +1,70 @@
+"""pytest configuration: `-m gpu` = parity tests that need an MI355X, everything else runs on CPU."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from tests._libs import oracle as _o
+
+    return _o()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    from tests._libs import have_ref, ref as _r
+
+    if not have_ref():
+        pytest.skip("oracle/_ref/liblongtail_ref.so not built (needs /root/reference at build time)")
+    return _r()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+
+    import numpy as np
+
+    from tests._libs import GOLDEN
+
+    j = json.load(open(GOLDEN / "reference_tests.json"))
+    v = np.load(GOLDEN / "ref_vectors.npz")
+    inp = np.fromfile(GOLDEN / "chunker.input", dtype=np.uint8)
+    return {"tests": j, "vec": v, "chunker_input": inp, "cases": json.loads(str(v["chunk_cases"]))}
+
+
+@pytest.fixture(scope="session")
+def hiplib():
+    from longtail_amd.lib import load
+
+    p = ROOT / "longtail_amd" / "liblongtail_hip.so"
+    if not p.exists():
+        import __graft_entry__ as g
+
+        g.build()
+    return load()
+
+
+@pytest.fixture(scope="session")
+def gpu(hiplib):
+    """A Context on cuda:0.  GPU tests must exercise the native library: no fallback, fail loudly."""
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    assert hiplib.device_count() > 0, "liblongtail_hip.so sees no GPU"
+    from longtail_amd.lib import Context
+
+    ctx = Context(0)
+    yield ctx
+    ctx.close()

@@ -1,0 +1,83 @@
+"""CPU-only checks of the drop-in boundary: the library loads, exports exactly what include/longtail_hip.h declares,
+refuses to work without a GPU (no CPU fallback), and the host arithmetic the kernels rely on is exact."""
+import ctypes as C
+import errno
+import re
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "longtail_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#define LTHIP_EXPORT.*", "", text)
+    names = re.findall(r"LTHIP_EXPORT[^;(]*?\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_header_symbols_are_exported(hiplib):
+    names = declared_symbols()
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(hiplib.dll, n)]
+    assert not missing, missing
+
+
+def test_no_gpu_means_loud_failure(hiplib):
+    """In the build container there is no GPU: every constructor must refuse instead of falling back to the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("this check is for the GPU-less container")
+    d = hiplib.dll
+    assert d.lthip_device_count() == 0
+    h = C.c_void_p()
+    assert d.lthip_ctx_create(0, None, C.byref(h)) == errno.ENODEV and not h.value
+    assert not d.Longtail_CreateHipChunkerAPI()
+    assert not d.Longtail_CreateHipBlake3HashAPI()
+    assert not d.Longtail_CreateHipLZ4CompressionAPI()
+    assert not d.Longtail_CreateHipZStdCompressionAPI()
+    st = C.c_uint32(0)
+    assert not d.Longtail_CompressionRegistry_CreateForHipLZ4(0x6C7A3432, C.byref(st))
+
+
+def test_product_does_not_link_or_reference_the_oracle(hiplib):
+    import subprocess
+
+    out = subprocess.run(["ldd", str(hiplib.path)], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "longtail_ref" not in out
+    for src in (ROOT / "longtail_amd").rglob("*"):
+        if src.suffix in (".hip", ".c", ".h", ".py") and src.is_file():
+            t = src.read_text()
+            assert "oracle/" not in t.replace("oracle/Makefile", "").replace("oracle/_ref", "").replace("oracle/*.c", "") or src.name in ("__init__.py",), src
+
+
+def test_bounds(hiplib, golden):
+    d = hiplib.dll
+    for n in (0, 1, 254, 255, 256, 65536, (8 << 20) + 800000, 0x7E000000):
+        assert d.lthip_lz4_bound(n) == n + n // 255 + 16      # lz4.h:215
+    assert d.lthip_lz4_bound(0x7E000001) == 0
+    for n in (0, 1, 1000, 131071, 131072, 131073, 9 << 20):
+        exp = n + (n >> 8) + (((128 << 10) - n) >> 11 if n < (128 << 10) else 0)
+        assert d.lthip_zstd_bound(n) == exp                   # zstd.h:232
+    assert d.Longtail_GetHipLZ4DefaultQuality() == golden["tests"]["lz4_type"]
+
+
+def test_division_free_cut_test_is_exact(hiplib, oracle):
+    """`hash % d == d-1` (hpcdcchunker.c:298) as multiply-add + rotate + compare, for every discriminator shape."""
+    f = hiplib.dll.lthip_divtest_eval
+    rng = np.random.default_rng(0)
+    ds = [oracle.dll.lto_hpcdc_discriminator(a) for a in (48, 64, 100, 2048, 16384, 32768, 65536, 131072, 1 << 20)]
+    ds += [1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 96, 1024, 65536, 12345, 99991, 2**31, 2**31 + 1, 0xFFFFFFFF, 0xFFFFFFFE]
+    ds += [int(x) for x in rng.integers(1, 2**32, size=40)]
+    assert 24680 in ds and 49535 in ds  # target 65536 / 131072
+    for d in ds:
+        hs = [0, 1, d - 1, d, max(d - 2, 0), (2 * d - 1) & 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFE, 0x7FFFFFFF, 0x80000000]
+        hs += [int(x) for x in rng.integers(0, 2**32, size=200)]
+        hs += [int(k) * d + d - 1 for k in rng.integers(0, max(1, 2**32 // d), size=200) if int(k) * d + d - 1 < 2**32]
+        for h in hs:
+            assert f(d, h & 0xFFFFFFFF) == (1 if (h & 0xFFFFFFFF) % d == d - 1 else 0), (d, h)

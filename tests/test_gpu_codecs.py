@@ -1,0 +1,133 @@
+"""-m gpu: HIP LZ4 / ZStd block codecs through the C ABI.  Payloads must decode to the original bytes with the
+oracle's LZ4 decoder and -- when oracle/_ref is present -- with the REFERENCE decoders; the HIP LZ4 decoder must
+agree with LZ4_decompress_safe on reference-produced payloads."""
+import numpy as np
+import pytest
+import torch
+
+from tests._libs import have_ref, ref as get_ref
+from tests.gpu_util import layout, to_device, u32
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_lz4(gpu, blocks, seg_log2=0, caps=None):
+    dev, offs = to_device(blocks)
+    bounds = [len(b) + len(b) // 255 + 16 for b in blocks]
+    caps = caps or bounds
+    d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
+    dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+    sizes = u32(gpu.lz4_compress_blocks(dev, offs, [len(b) for b in blocks], dst, d_offs, caps, seg_log2))
+    host = dst.cpu().numpy()
+    return [host[o : o + int(s)].copy() for o, s in zip(d_offs, sizes)], sizes
+
+
+def check_lz4_payload(oracle, data, payload):
+    assert len(payload) > 0
+    assert len(payload) <= len(data) + len(data) // 255 + 16
+    n, out = oracle.lz4_decompress(payload, len(data))  # exact capacity, like DecompressBlock (compressblockstore.c:321)
+    assert n == len(data), f"oracle decoder rejected payload ({n})"
+    assert (out == data).all()
+    if have_ref():
+        r = get_ref()
+        err, out2 = r.decompress(0, payload, len(data))
+        assert err == 0 and len(out2) == len(data) and (out2 == data).all(), "reference LZ4_decompress_safe rejected payload"
+
+
+@pytest.mark.parametrize("seg_log2", [0, 13, 14, 16])
+def test_lz4_roundtrip_kinds(gpu, oracle, seg_log2):
+    blocks = []
+    for kind in (0, 1, 2):
+        for n in [1, 5, 11, 12, 13, 14, 64, 4096, 8191, 8192, 8193, 32767, 32768, 32769, 65535, 65536, 65537, 65541, 65548, 200000,
+                  (1 << 20) + 7]:
+            blocks.append(oracle.synth(n, 50 + n + kind, kind))
+    payloads, _ = gpu_lz4(gpu, blocks, seg_log2)
+    for b, p in zip(blocks, payloads):
+        check_lz4_payload(oracle, b, p)
+
+
+def test_lz4_empty_block(gpu, oracle):
+    payloads, sizes = gpu_lz4(gpu, [np.zeros(0, np.uint8), oracle.synth(100, 1, 1)])
+    assert int(sizes[0]) == 1 and payloads[0][0] == 0  # lz4.c:1361-1371
+    check_lz4_payload(oracle, oracle.synth(100, 1, 1), payloads[1])
+
+
+def test_lz4_reference_test_block(gpu, oracle, golden):
+    lb = golden["tests"]["lz4_block"]  # the block of test/test.cpp:2092-2192
+    blk = np.concatenate([np.full(n, v, np.uint8) for n, v in lb["runs"]])
+    (p,), _ = gpu_lz4(gpu, [blk])
+    check_lz4_payload(oracle, blk, p)
+    assert len(p) < 200  # two long runs must collapse to a handful of sequences
+
+
+def test_lz4_structured_inputs(gpu, oracle):
+    rng = np.random.default_rng(2)
+    text = np.frombuffer((b"the quick brown fox jumps over the lazy dog, " * 30000)[: 1 << 20], dtype=np.uint8).copy()
+    lowent = rng.integers(0, 4, 1 << 20, dtype=np.uint8)
+    rep = rng.integers(0, 256, 1 << 20, dtype=np.uint8)
+    for i in range(0, len(rep) - 300, 997):
+        rep[i + 100 : i + 300] = rep[i : i + 200]
+    tail_match = np.concatenate([rng.integers(0, 256, 70000, dtype=np.uint8), np.zeros(40, np.uint8)])  # matches right up to the end
+    blocks = [text, lowent, rep, tail_match, np.zeros(65536 + 3, np.uint8), np.zeros(32768 * 3 + 11, np.uint8)]
+    payloads, _ = gpu_lz4(gpu, blocks)
+    for b, p in zip(blocks, payloads):
+        check_lz4_payload(oracle, b, p)
+    assert len(payloads[0]) < len(text) // 10
+    assert len(payloads[4]) < 2000
+
+
+def test_lz4_ratio_vs_reference(gpu, oracle, golden):
+    """Not a parity requirement, a sanity bound: the segmented GPU parse must stay in the reference's neighbourhood."""
+    for kind, size, seed, ref_size in golden["vec"]["lz4_ref_sizes"]:
+        d = oracle.synth(int(size), int(seed), int(kind))
+        (p,), _ = gpu_lz4(gpu, [d])
+        check_lz4_payload(oracle, d, p)
+        assert len(p) <= int(ref_size) * 1.25 + 64, (kind, size, len(p), ref_size)
+
+
+def test_lz4_many_blocks_and_capacity(gpu, oracle):
+    blocks = [oracle.synth(int(n), 700 + i, i % 3) for i, n in enumerate(np.random.default_rng(4).integers(1, 400000, 60))]
+    payloads, _ = gpu_lz4(gpu, blocks)
+    for b, p in zip(blocks, payloads):
+        check_lz4_payload(oracle, b, p)
+    # too small a destination -> size 0 (LZ4CompressionAPI_Compress turns that into ENOMEM, longtail_lz4.c:70-74)
+    rnd = oracle.synth(100000, 5, 0)
+    _, sizes = gpu_lz4(gpu, [rnd, rnd], caps=[100, 100000 + 100000 // 255 + 16])
+    assert int(sizes[0]) == 0 and int(sizes[1]) > 100000
+
+
+def test_lz4_gpu_decoder_on_reference_payloads(gpu, oracle):
+    blocks = [oracle.synth(n, 900 + n, k) for k in (0, 1, 2) for n in (0, 1, 13, 100, 70000, 300000)]
+    comps = [oracle.lz4_compress(b) for b in blocks]  # bit-exact with LZ4_compress_fast (tests/test_oracle_vs_ref.py)
+    dev, offs = to_device(comps)
+    d_offs, total = layout(blocks)
+    dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+    sizes = u32(gpu.lz4_decompress_blocks(dev, offs, [len(c) for c in comps], dst, d_offs, [len(b) for b in blocks]))
+    host = dst.cpu().numpy()
+    for b, o, s in zip(blocks, d_offs, sizes):
+        assert int(s) == len(b)
+        assert (host[o : o + len(b)] == b).all()
+    # malformed input is reported, not decoded
+    bad = comps[4].copy()
+    bad[len(bad) // 2 :] = 0
+    dev, offs = to_device([bad])
+    sizes = u32(gpu.lz4_decompress_blocks(dev, offs, [len(bad)], dst, [0], [len(blocks[4])]))
+    n, _ = oracle.lz4_decompress(bad, len(blocks[4]))
+    assert (int(sizes[0]) == 0xFFFFFFFF) == (n < 0)
+
+
+def test_zstd_stage1_frames_decode_with_reference(gpu, oracle, ref):
+    blocks = [oracle.synth(n, 40 + n, k) for k in (0, 1, 2) for n in (0, 1, 100, 131071, 131072, 131073, 400000)]
+    dev, offs = to_device(blocks)
+    caps = [len(b) + (len(b) >> 8) + 64 for b in blocks]
+    d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
+    dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+    sizes = u32(gpu.zstd_compress_blocks(dev, offs, [len(b) for b in blocks], dst, d_offs, caps))
+    host = dst.cpu().numpy()
+    for b, o, s in zip(blocks, d_offs, sizes):
+        assert int(s) > 0
+        err, out = ref.decompress(1, host[o : o + int(s)].copy(), len(b))
+        assert err == 0 and len(out) == len(b) and (out == b).all()
+    # all-zero input collapses to RLE blocks
+    z = [i for i, b in enumerate(blocks) if len(b) == 400000 and not b.any()]
+    assert z and int(sizes[z[0]]) < 100

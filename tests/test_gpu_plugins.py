@@ -1,0 +1,204 @@
+"""-m gpu: the drop-in boundary.  The HIP Longtail_ChunkerAPI / HashAPI / CompressionAPI objects are plugged into the
+UNMODIFIED reference core (oracle/_ref/liblongtail_ref.so, built from /root/reference by oracle/Makefile) exactly
+where the CPU plugins go; results must be byte-identical (VersionIndex) / round-trip through the reference decoder."""
+import ctypes as C
+import errno
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def params(target):
+    return max(48, target // 8), max(48, target // 2), max(48, target * 2)
+
+
+class HashAPIStruct(C.Structure):
+    _fields_ = [
+        ("Dispose", C.CFUNCTYPE(None, C.c_void_p)),
+        ("GetIdentifier", C.CFUNCTYPE(C.c_uint32, C.c_void_p)),
+        ("BeginContext", C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p))),
+        ("Hash", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p)),
+        ("EndContext", C.CFUNCTYPE(C.c_uint64, C.c_void_p, C.c_void_p)),
+        ("HashBuffer", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64))),
+    ]
+
+
+class CompressionAPIStruct(C.Structure):
+    _fields_ = [
+        ("Dispose", C.CFUNCTYPE(None, C.c_void_p)),
+        ("GetMaxCompressedSize", C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_uint32, C.c_size_t)),
+        ("Compress", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t))),
+        ("Decompress", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t))),
+    ]
+
+
+class ChunkerAPIStruct(C.Structure):
+    _fields_ = [
+        ("Dispose", C.CFUNCTYPE(None, C.c_void_p)),
+        ("GetMinChunkSize", C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32))),
+    ]
+
+
+@pytest.fixture(scope="module")
+def plugins(gpu, hiplib):
+    d = hiplib.dll
+    chunker = d.Longtail_CreateHipChunkerAPI()
+    hasher = d.Longtail_CreateHipBlake3HashAPI()
+    lz4 = d.Longtail_CreateHipLZ4CompressionAPI()
+    zstd = d.Longtail_CreateHipZStdCompressionAPI()
+    assert chunker and hasher and lz4 and zstd, "plugin constructors returned NULL on a GPU box"
+    yield dict(chunker=chunker, hash=hasher, lz4=lz4, zstd=zstd)
+    for k, st in (("chunker", ChunkerAPIStruct), ("hash", HashAPIStruct), ("lz4", CompressionAPIStruct), ("zstd", CompressionAPIStruct)):
+        ptr = dict(chunker=chunker, hash=hasher, lz4=lz4, zstd=zstd)[k]
+        st.from_address(ptr).Dispose(ptr)
+
+
+def test_identifiers(plugins, golden, hiplib):
+    h = HashAPIStruct.from_address(plugins["hash"])
+    assert h.GetIdentifier(plugins["hash"]) == golden["tests"]["blake3_id"] == 0x626C6B33  # longtail_blake3.c:6
+    assert hiplib.dll.Longtail_GetHipLZ4DefaultQuality() == golden["tests"]["lz4_type"]      # longtail_lz4.c:10
+    mn = C.c_uint32(0)
+    c = ChunkerAPIStruct.from_address(plugins["chunker"])
+    assert c.GetMinChunkSize(plugins["chunker"], C.byref(mn)) == 0 and mn.value == 48       # hpcdcchunker.c:343
+
+
+def test_hash_api_entry_points(plugins, oracle, golden):
+    ptr = plugins["hash"]
+    h = HashAPIStruct.from_address(ptr)
+    kat = golden["tests"]["blake3_kat"]
+    s = kat["string_plus_nul"].encode() + b"\0"
+    out = C.c_uint64(0)
+    assert h.HashBuffer(ptr, len(s), s, C.byref(out)) == 0
+    assert "%016x" % out.value == kat["hash_hex"]
+    empty = b"\0"
+    assert h.HashBuffer(ptr, 0, empty, C.byref(out)) == 0  # empty asset content hash (src/longtail.c:2521-2522)
+    assert out.value == oracle.blake3(np.zeros(0, np.uint8))
+    data = oracle.synth(300000, 8, 0)
+    for n in (1, 64, 1024, 1025, 70000, 300000):
+        assert h.HashBuffer(ptr, n, data.ctypes.data, C.byref(out)) == 0
+        assert out.value == oracle.blake3(data[:n]), n
+    # streaming trio (longtail_blake3.c:24-79)
+    ctx = C.c_void_p()
+    assert h.BeginContext(ptr, C.byref(ctx)) == 0
+    for a, b in ((0, 1000), (1000, 1001), (1001, 150000), (150000, 300000)):
+        h.Hash(ptr, ctx, b - a, data[a:b].ctypes.data)
+    assert h.EndContext(ptr, ctx) == oracle.blake3(data)
+
+
+@pytest.mark.parametrize("which", ["hip+hip", "hip+cpu", "cpu+hip"])
+def test_chunker_hash_pairings_through_reference_driver(plugins, ref, oracle, which, golden):
+    """NextChunk/HashBuffer exactly as DynamicChunking drives them (src/longtail.c:2231-2296), all plugin pairings."""
+    chunker = plugins["chunker"] if which.startswith("hip") else None
+    hasher = plugins["hash"] if which.endswith("hip") else None
+    ci = golden["tests"]["chunker_input"]
+    offs, lens, hashes = ref.chunk_and_hash(golden["chunker_input"], ci["min"], ci["avg"], ci["max"], chunker, hasher)
+    assert [(int(a), int(b)) for a, b in zip(offs, lens)] == [tuple(r) for r in ci["ranges"]]
+    for kind, size, target in [(0, 3 << 20, 65536), (1, (2 << 20) + 99, 32768), (2, 1 << 20, 65536), (0, 1000, 65536), (0, 0, 65536),
+                               (1, 100000, 16)]:
+        data = oracle.synth(size, 321 + size, kind)
+        mn, av, mx = params(target)
+        e = ref.chunk_and_hash(data, mn, av, mx)
+        g = ref.chunk_and_hash(data, mn, av, mx, chunker, hasher)
+        assert all((a == b).all() for a, b in zip(e, g)) and len(e[1]) == len(g[1]), (which, kind, size, target)
+
+
+def test_chunker_streams_longer_than_one_window(plugins, ref, oracle):
+    """> 64 MiB through ONE chunker: windows must reproduce the reference's stream semantics."""
+    data = oracle.synth((64 << 20) * 2 + 12345, 99, 1)
+    mn, av, mx = params(65536)
+    e = ref.chunk_and_hash(data, mn, av, mx)
+    g = ref.chunk_and_hash(data, mn, av, mx, plugins["chunker"], plugins["hash"])
+    assert len(e[1]) == len(g[1]) and all((a == b).all() for a, b in zip(e, g))
+
+
+def test_next_chunk_from_buffer(plugins, ref, oracle):
+    for kind, size, target in [(0, 2 << 20, 65536), (1, 1 << 20, 32768), (0, 3000, 16)]:
+        data = oracle.synth(size, 55 + size, kind)
+        mn, av, mx = params(target)
+        e = ref.chunk_from_buffer(data, mn, av, mx)
+        g = ref.chunk_from_buffer(data, mn, av, mx, plugins["chunker"])
+        assert len(e) == len(g) and (e == g).all()
+
+
+def make_tree(oracle, spec, seed=1):
+    files = []
+    for i, (size, kind) in enumerate(spec):
+        files.append((f"dir{i % 3}/sub{i % 2}/file{i:04d}.bin", oracle.synth(size, oracle.asset_seed(seed, i), kind)))
+    return files
+
+
+@pytest.mark.parametrize("workers", [0, 4])
+def test_version_index_is_byte_identical(plugins, ref, oracle, workers):
+    """Longtail_CreateVersionIndex with HIP plugins == with CPU plugins, serialized byte for byte."""
+    spec = [(0, 0), (1, 0), (47, 1), (48, 0), (49, 1), (1000, 0), (65536, 1), (200000, 0), (1 << 20, 1), (3 << 20, 0), (1 << 20, 2),
+            (1 << 20, 1)]
+    files = make_tree(oracle, spec)
+    files.append(("dup/copy.bin", files[8][1].copy()))  # duplicate content -> dedup path (src/longtail.c:2951-2970)
+    for target in (65536, 4096):  # 4096 -> 4 MiB parts: the 3 MiB+ assets stay single-part, use 1024 for multi-part
+        cpu, _ = ref.version_index(files, target, workers=workers, tag=ref.lz4_type)
+        hip, _ = ref.version_index(files, target, workers=workers, tag=ref.lz4_type, chunker_api=plugins["chunker"],
+                                   hash_api=plugins["hash"])
+        assert cpu == hip, f"VersionIndex differs (target {target}, workers {workers})"
+    cpu, _ = ref.version_index(files, 1024, workers=workers)  # 1 MiB parts -> multi-part assets, empty trailing parts
+    hip, _ = ref.version_index(files, 1024, workers=workers, chunker_api=plugins["chunker"], hash_api=plugins["hash"])
+    assert cpu == hip
+
+
+def test_write_content_roundtrips_through_reference(plugins, ref, oracle):
+    """UpSync sequence with HIP chunker+hash+LZ4, then restore with a REFERENCE-ONLY registry and compare files."""
+    spec = [(0, 0), (100, 1), (70000, 1), (1 << 20, 1), (2 << 20, 0), (1 << 20, 2), (300000, 1), (5, 0)]
+    files = make_tree(oracle, spec, seed=7)
+    for block_size, per_block in ((8 << 20, 1024), (262144, 64)):
+        base = ref.ingest_roundtrip(files, 65536, block_size, per_block, ref.lz4_type)
+        assert base["err"] == 0
+        got = ref.ingest_roundtrip(files, 65536, block_size, per_block, ref.lz4_type, workers=2, chunker_api=plugins["chunker"],
+                                   hash_api=plugins["hash"], codec_api=plugins["lz4"])
+        assert got["err"] == 0, got
+        assert got["chunks"] == base["chunks"] and got["blocks"] == base["blocks"]
+        assert got["stored_bytes"] <= base["stored_bytes"] * 1.25 + 4096
+
+
+def test_zstd_plugin_compress_decodes_with_reference(plugins, ref, oracle):
+    api = CompressionAPIStruct.from_address(plugins["zstd"])
+    tag = ref.zstd_default
+    for n, kind in ((0, 0), (1000, 1), (400000, 1), (400000, 2)):
+        d = oracle.synth(n, 12 + n, kind)
+        cap = api.GetMaxCompressedSize(plugins["zstd"], tag, n)
+        assert cap == ref.dll.refh_codec_bound(1, tag, n)  # ZSTD_COMPRESSBOUND
+        out = np.zeros(cap + 8, np.uint8)
+        got = C.c_size_t(0)
+        assert api.Compress(plugins["zstd"], tag, d.ctypes.data if n else out.ctypes.data, out.ctypes.data, n, cap, C.byref(got)) == 0
+        err, back = ref.decompress(1, out[: got.value].copy(), n)
+        assert err == 0 and len(back) == n and (back == d).all()
+
+
+def test_lz4_plugin_entry_points(plugins, ref, oracle):
+    ptr = plugins["lz4"]
+    api = CompressionAPIStruct.from_address(ptr)
+    tag = ref.lz4_type
+    for n, kind in ((1, 0), (5858, 2), (100000, 1), (1 << 20, 0), ((8 << 20) + 800000, 1)):
+        d = oracle.synth(n, 3 + n, kind)
+        cap = api.GetMaxCompressedSize(ptr, tag, n)
+        assert cap == n + n // 255 + 16  # LZ4_COMPRESSBOUND
+        out = np.zeros(cap + 12, np.uint8)
+        got = C.c_size_t(0)
+        # destination only 4-byte aligned like &header[2] (compressblockstore.c:117-125)
+        assert api.Compress(ptr, tag, d.ctypes.data, out.ctypes.data + 4, n, cap, C.byref(got)) == 0
+        payload = out[4 : 4 + got.value].copy()
+        err, back = ref.decompress(0, payload, n)
+        assert err == 0 and len(back) == n and (back == d).all()
+        # HIP Decompress on a REFERENCE payload (tags are persisted: both directions must interoperate)
+        refp = ref.compress(0, tag, d)
+        back2 = np.zeros(n + 8, np.uint8)
+        got2 = C.c_size_t(0)
+        assert api.Decompress(ptr, refp.ctypes.data, back2.ctypes.data, len(refp), n, C.byref(got2)) == 0
+        assert got2.value == n and (back2[:n] == d).all()
+    # errors: too small a destination -> ENOMEM (longtail_lz4.c:70-74); garbage -> EBADF (:95-99)
+    d = oracle.synth(50000, 1, 0)
+    out = np.zeros(60000, np.uint8)
+    got = C.c_size_t(0)
+    assert api.Compress(ptr, tag, d.ctypes.data, out.ctypes.data, len(d), 100, C.byref(got)) == errno.ENOMEM
+    junk = np.full(100, 0xFF, np.uint8)
+    assert api.Decompress(ptr, junk.ctypes.data, out.ctypes.data, len(junk), 1000, C.byref(got)) == errno.EBADF
