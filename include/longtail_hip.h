@@ -73,8 +73,10 @@ LTHIP_EXPORT int Longtail_Hip_SetDevice(int device);
 typedef struct lthip_ctx lthip_ctx;   /* one GPU + one stream + scratch pools; NOT thread-safe: one per host thread */
 typedef struct lthip_plan lthip_plan; /* device-resident description of a batch of parts */
 
-/* hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream), or NULL for
- * a private non-blocking stream owned by the context. */
+/* hip_stream: the hipStream_t to launch on, e.g. torch.cuda.current_stream().cuda_stream; NULL is HIP's default
+ * (null) stream, exactly as in every HIP API; LTHIP_STREAM_PRIVATE asks for a private non-blocking stream owned
+ * by the context (what the plugin layer uses: one per host thread). */
+#define LTHIP_STREAM_PRIVATE ((void*)(intptr_t)-1)
 LTHIP_EXPORT int lthip_ctx_create(int device, void* hip_stream, lthip_ctx** out_ctx);
 LTHIP_EXPORT void lthip_ctx_destroy(lthip_ctx* ctx);
 LTHIP_EXPORT int lthip_ctx_sync(lthip_ctx* ctx);
@@ -115,6 +117,7 @@ LTHIP_EXPORT int lthip_timing_get(lthip_ctx* ctx, int kernel_id, double* out_tot
 LTHIP_EXPORT int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const uint64_t* part_offsets /*host*/,
                                    const uint64_t* part_sizes /*host*/, uint32_t min_chunk, uint32_t avg_chunk,
                                    uint32_t max_chunk, lthip_plan** out_plan);
+/* ctx may be NULL (e.g. the creating thread's context is gone): the device is synchronised instead of the stream */
 LTHIP_EXPORT void lthip_plan_destroy(lthip_ctx* ctx, lthip_plan* plan);
 /* upper bound on the number of chunks the plan can produce (size the output arrays with it) */
 LTHIP_EXPORT uint64_t lthip_plan_chunk_capacity(const lthip_plan* plan);

@@ -69,9 +69,9 @@ extern "C" int lthip_ctx_create(int device, void* hip_stream, lthip_ctx** out_ct
     memset(ctx->scratch_cap, 0, sizeof ctx->scratch_cap);
     memset(ctx->total_ms, 0, sizeof ctx->total_ms);
     memset(ctx->launches, 0, sizeof ctx->launches);
-    if (hip_stream)
+    if (hip_stream != LTHIP_STREAM_PRIVATE)
     {
-        ctx->stream = (hipStream_t)hip_stream;
+        ctx->stream = (hipStream_t)hip_stream; // may be the null stream
         ctx->own_stream = false;
     }
     else
@@ -347,6 +347,7 @@ extern "C" int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const uint
         return ENOMEM;
     memset(plan, 0, sizeof *plan);
     plan->nparts = part_count;
+    plan->device = ctx->device;
     plan->min_chunk = min_chunk;
     plan->avg_chunk = avg_chunk;
     plan->max_chunk = max_chunk;
@@ -417,11 +418,13 @@ extern "C" void lthip_plan_destroy(lthip_ctx* ctx, lthip_plan* plan)
 {
     if (!plan)
         return;
+    // A plan is plain device memory: it may outlive the context (and host thread) that created it.  With a
+    // context only its stream is drained; without one the whole device is.
+    (void)hipSetDevice(plan->device);
     if (ctx)
-    {
-        (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
-    }
+    else
+        (void)hipDeviceSynchronize();
     if (plan->d_parts)
         (void)hipFree(plan->d_parts);
     if (plan->d_tile_part)

@@ -40,6 +40,7 @@ struct DivTest
 
 struct lthip_plan
 {
+    int device;
     uint32_t nparts;
     uint32_t min_chunk, avg_chunk, max_chunk;
     DivTest div;

@@ -42,7 +42,7 @@ struct HipChunker
     /* cached plan */
     lthip_plan* plan;
     uint64_t plan_size;
-    lthip_ctx* plan_ctx;
+    uint32_t plan_min, plan_avg, plan_max;
     int slot; /* window registry slot */
 };
 
@@ -57,7 +57,7 @@ struct HipChunkerAPI
 static void chunker_release_buffers(struct HipChunker* c)
 {
     if (c->plan)
-        lthip_plan_destroy(c->plan_ctx, c->plan);
+        lthip_plan_destroy(0, c->plan); /* the creating thread (and its context) may be gone */
     c->plan = 0;
     lthip_free_pinned(0, c->h_win);
     lthip_free_device(0, c->d_win);
@@ -163,17 +163,19 @@ static int chunker_refill(struct HipChunker* c, Longtail_Chunker_Feeder feeder, 
     if (c->have == 0)
         return 0;
 
-    if (!c->plan || c->plan_size != c->have || c->plan_ctx != ctx)
+    if (!c->plan || c->plan_size != c->have || c->plan_min != c->min || c->plan_avg != c->avg || c->plan_max != c->max)
     {
         if (c->plan)
-            lthip_plan_destroy(c->plan_ctx, c->plan);
+            lthip_plan_destroy(0, c->plan);
         c->plan = 0;
         const uint64_t off0 = 0, sz = c->have;
         err = lthip_plan_create(ctx, 1, &off0, &sz, c->min, c->avg, c->max, &c->plan);
         if (err)
             return err;
         c->plan_size = c->have;
-        c->plan_ctx = ctx;
+        c->plan_min = c->min;
+        c->plan_avg = c->avg;
+        c->plan_max = c->max;
     }
     uint64_t total = 0;
     err = lthip_copy_h2d(ctx, c->d_win, c->h_win, (size_t)c->have);

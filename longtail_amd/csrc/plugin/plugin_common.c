@@ -81,7 +81,7 @@ struct ltp_thread_state* ltp_thread_state_get(void)
     ts = (struct ltp_thread_state*)calloc(1, sizeof *ts);
     if (!ts)
         return 0;
-    if (lthip_ctx_create(ltp_device(), 0, &ts->ctx) != 0)
+    if (lthip_ctx_create(ltp_device(), LTHIP_STREAM_PRIVATE, &ts->ctx) != 0)
     {
         free(ts);
         return 0;

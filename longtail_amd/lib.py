@@ -52,6 +52,12 @@ class HipLib:
                 "(there is no CPU fallback)"
             )
         self.path = p
+        # torch bundles its own HIP/HSA runtime; when it is going to be used in this process it must be loaded
+        # first so that the library binds to the SAME runtime (two runtimes in one process -> no devices).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         self.dll = C.CDLL(str(p))
         d = self.dll
         vp, u64, u32, i32, sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_size_t
@@ -135,10 +141,11 @@ class Context:
         self.lib = lib or load()
         self.torch = torch
         self.device = device
-        raw_stream = 0
         if stream == "torch":
-            raw_stream = int(torch.cuda.current_stream(device).cuda_stream)
-        elif stream is not None:
+            raw_stream = int(torch.cuda.current_stream(device).cuda_stream)  # 0 = the null stream, also valid
+        elif stream is None:
+            raw_stream = -1  # LTHIP_STREAM_PRIVATE
+        else:
             raw_stream = int(stream)
         h = C.c_void_p()
         err = self.lib.dll.lthip_ctx_create(device, C.c_void_p(raw_stream), C.byref(h))

@@ -36,7 +36,7 @@ def test_no_gpu_means_loud_failure(hiplib):
     d = hiplib.dll
     assert d.lthip_device_count() == 0
     h = C.c_void_p()
-    assert d.lthip_ctx_create(0, None, C.byref(h)) == errno.ENODEV and not h.value
+    assert d.lthip_ctx_create(0, C.c_void_p(-1), C.byref(h)) == errno.ENODEV and not h.value
     assert not d.Longtail_CreateHipChunkerAPI()
     assert not d.Longtail_CreateHipBlake3HashAPI()
     assert not d.Longtail_CreateHipLZ4CompressionAPI()
