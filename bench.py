@@ -82,6 +82,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    from longtail_amd.dist import allgather_hashes
     from longtail_amd.lib import Context, chunker_params, load
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,7 +127,6 @@ def main():
     limit = args.block_size + args.block_size // 10
     dst_arena_bytes = batch_bytes + batch_bytes // 255 + (batch_bytes // args.block_size + 2) * 64 + 2 * (limit + limit // 255 + 64)
     dst = torch.empty(dst_arena_bytes, dtype=torch.uint8, device=dev)
-    gather_buf = None
     stats = {}
 
     def step():
@@ -136,23 +136,7 @@ def main():
         plan.close()
         t1 = time.perf_counter()
         # ---- exchange + dedup (src/longtail.c:2951-2970) ----
-        if world > 1:
-            counts = torch.zeros(world, dtype=torch.int64, device=dev)
-            mine = torch.tensor([total], dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(counts, mine)
-            counts_h = counts.cpu().numpy()
-            pad = int(counts_h.max())
-            nonlocal gather_buf
-            if gather_buf is None or gather_buf.numel() < pad * world:
-                gather_buf = torch.empty(pad * world, dtype=torch.int64, device=dev)
-            send = out_hash[:pad] if pad <= cap else torch.nn.functional.pad(out_hash[:total], (0, pad - total))
-            dist.all_gather_into_tensor(gather_buf[: pad * world], send.contiguous())
-            pieces = [gather_buf[r * pad : r * pad + int(counts_h[r])] for r in range(world)]
-            all_hashes = torch.cat(pieces)
-            my_base = int(counts_h[:rank].sum())
-        else:
-            all_hashes = out_hash[:total]
-            my_base = 0
+        all_hashes, my_base, _counts = allgather_hashes(out_hash, total)
         first_idx, uniq = ctx.dedup_first_seen(all_hashes)
         mine_first = first_idx[my_base : my_base + total]
         unique_mask = mine_first == torch.arange(my_base, my_base + total, dtype=torch.int32, device=dev)
