@@ -26,8 +26,7 @@ constexpr int K1_THREADS = 256;
 constexpr int RUN = 64;                      // bytes per thread
 constexpr int TILE = K1_THREADS * RUN;       // 16 KiB
 constexpr int ROW_DW = 17;                   // 16 data dwords + 1 pad: thread-strided ds_read_b32 hits 32 distinct banks
-constexpr int ROWS = K1_THREADS + 1;         // +1 halo row in front
-constexpr int TAB_REP = 32;                  // T[v] replicated once per bank
+constexpr int TAB_REP = 32;                  // T[v] replicated once per bank: lookups never conflict
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, uint32_t r) { return __builtin_amdgcn_alignbit(x, x, (32u - r) & 31u); }
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, uint32_t r) { return __builtin_amdgcn_alignbit(x, x, r & 31u); }
@@ -57,46 +56,30 @@ __global__ void k_tile_table(const PartDev* __restrict__ parts, uint32_t nparts,
 // ---------------------------------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------------------------------
-template <int MODE> // 0 = general d (multiply test), 1 = power-of-two d (mask test)
-__global__ __launch_bounds__(K1_THREADS) void k_buzhash_candidates(const uint8_t* __restrict__ data,
-                                                                    const PartDev* __restrict__ parts,
-                                                                    const uint32_t* __restrict__ tile_part,
-                                                                    uint32_t ntiles, DivTest dv,
-                                                                    uint64_t* __restrict__ bm0,
-                                                                    uint64_t* __restrict__ bm1)
+// The unit of work is a WAVE-tile: 4 KiB of one part (+64 B halo in front) staged into the wave's private LDS
+// rows; waves of a workgroup share nothing but the read-only table, so there is no barrier in the loop.  The loads
+// of the next wave-tile are issued before the current one is hashed (register double buffering).
+constexpr int WROWS = 64 + 1;            // 64 data rows + 1 halo row
+constexpr int WVECS = WROWS * 4;         // 260 16-byte vectors per wave-tile
+constexpr int WTILE = 64 * RUN;          // 4 KiB
+
+struct TileRegs
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t* tab = smem;                      // [256][32]
-    uint32_t* rows = smem + 256 * TAB_REP;     // [ROWS][ROW_DW]
+    uint4 q[5];
+};
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-
-    // replicated substitution table: tab[v*32 + r] = T[v]
-    {
-        const uint32_t tv = c_buztab[tid];
-        uint4 q = make_uint4(tv, tv, tv, tv);
-        uint4* dst = reinterpret_cast<uint4*>(tab + tid * TAB_REP);
+__device__ __forceinline__ void tile_load(TileRegs& r, const uint8_t* __restrict__ data, const PartDev& pd,
+                                          uint64_t span_start, int lane)
+{
+    const uint8_t* src = data + pd.off;
 #pragma unroll
-        for (int j = 0; j < TAB_REP / 4; ++j)
-            dst[j] = q;
-    }
-    const uint32_t* tabl = tab + (tid & 31);
-
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+    for (int u = 0; u < 5; ++u)
     {
-        const uint32_t pidx = tile_part[tile];
-        const PartDev pd = parts[pidx];
-        const uint64_t tile_start = (uint64_t)(tile - pd.tile_base) * TILE; // part-relative
-        const uint8_t* src = data + pd.off;
-
-        __syncthreads(); // previous tile's rows fully consumed (and table visible on the first trip)
-        // ---- stage [tile_start-64, tile_start+TILE) as 1028 16-byte vectors ----
-        for (int v = tid; v < ROWS * 4; v += K1_THREADS)
+        const int v = lane + u * 64;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (v < WVECS)
         {
-            const int64_t g = (int64_t)tile_start - 64 + 16 * (int64_t)v;
-            uint4 q = make_uint4(0, 0, 0, 0);
+            const int64_t g = (int64_t)span_start - 64 + 16 * (int64_t)v;
             if (g >= 0)
             {
                 if ((uint64_t)g + 16 <= pd.size)
@@ -110,21 +93,90 @@ __global__ __launch_bounds__(K1_THREADS) void k_buzhash_candidates(const uint8_t
                     q = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             }
-            uint32_t* d = rows + (v >> 2) * ROW_DW + (v & 3) * 4;
-            d[0] = q.x;
-            d[1] = q.y;
-            d[2] = q.z;
-            d[3] = q.w;
         }
-        __syncthreads();
+        r.q[u] = q;
+    }
+}
 
-        const uint64_t q0 = tile_start + (uint64_t)tid * RUN; // first byte of my run
+__device__ __forceinline__ void tile_store(const TileRegs& r, uint32_t* __restrict__ rows, int lane)
+{
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+    {
+        const int v = lane + u * 64;
+        if (v < WVECS)
+        {
+            uint32_t* d = rows + (v >> 2) * ROW_DW + (v & 3) * 4;
+            d[0] = r.q[u].x;
+            d[1] = r.q[u].y;
+            d[2] = r.q[u].z;
+            d[3] = r.q[u].w;
+        }
+    }
+}
+
+template <int MODE> // 0 = general d (multiply test), 1 = power-of-two d (mask test)
+__global__ __launch_bounds__(K1_THREADS, 3) void k_buzhash_candidates(const uint8_t* __restrict__ data,
+                                                                       const PartDev* __restrict__ parts,
+                                                                       const uint32_t* __restrict__ tile_part,
+                                                                       uint32_t ntiles, DivTest dv,
+                                                                       uint64_t* __restrict__ bm0,
+                                                                       uint64_t* __restrict__ bm1)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* tab = smem; // [256][TAB_REP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: tile bookkeeping stays in SGPRs
+    uint32_t* rows = smem + 256 * TAB_REP + wave * (WROWS * ROW_DW); // this wave's [WROWS][ROW_DW]
+
+    // replicated substitution table: tab[v*TAB_REP + r] = T[v]
+    {
+        const uint32_t tv = c_buztab[tid];
+        uint4 q = make_uint4(tv, tv, tv, tv);
+        uint4* dst = reinterpret_cast<uint4*>(tab + tid * TAB_REP);
+#pragma unroll
+        for (int j = 0; j < TAB_REP / 4; ++j)
+            dst[j] = q;
+    }
+    __syncthreads(); // the only barrier: table visible to every wave
+    const uint32_t* tabl = tab + (tid & (TAB_REP - 1));
+
+    const uint64_t nwt = (uint64_t)ntiles * 4u; // wave-tiles; wave-tile wt is quarter (wt & 3) of 16 KiB tile (wt >> 2)
+    const uint64_t wstride = (uint64_t)gridDim.x * 4u;
+    uint64_t wt = (uint64_t)blockIdx.x * 4u + (uint64_t)wave;
+    if (wt >= nwt)
+        return;
+    PartDev pd = parts[tile_part[wt >> 2]];
+    uint64_t span = ((wt >> 2) - pd.tile_base) * (uint64_t)TILE + (wt & 3u) * (uint64_t)WTILE; // part-relative
+    TileRegs regs;
+    tile_load(regs, data, pd, span, lane);
+
+    for (;;)
+    {
+        __builtin_amdgcn_wave_barrier();
+        tile_store(regs, rows, lane);
+        __builtin_amdgcn_wave_barrier();
+
+        // issue the next wave-tile's global loads now; they land while this one is being hashed
+        const uint64_t next = wt + wstride;
+        PartDev npd = pd;
+        uint64_t next_span = 0;
+        if (next < nwt)
+        {
+            npd = parts[tile_part[next >> 2]];
+            next_span = ((next >> 2) - npd.tile_base) * (uint64_t)TILE + (next & 3u) * (uint64_t)WTILE;
+            tile_load(regs, data, npd, next_span, lane);
+        }
+
+        const uint64_t q0 = span + (uint64_t)lane * RUN; // first byte of my run
         uint32_t mlo = 0, mhi = 0;
         if (q0 < pd.size)
         {
             // window bytes: j in [0,112): j<48 = the 48 bytes before the run, j>=48 = the run
             uint32_t win[28];
-            const uint32_t* prev = rows + tid * ROW_DW;
+            const uint32_t* prev = rows + lane * ROW_DW;
 #pragma unroll
             for (int i = 0; i < 12; ++i)
                 win[i] = prev[4 + i];
@@ -132,36 +184,52 @@ __global__ __launch_bounds__(K1_THREADS) void k_buzhash_candidates(const uint8_t
             for (int i = 0; i < 16; ++i)
                 win[12 + i] = prev[ROW_DW + i];
 
+            // T[byte] of the window bytes is fetched in two batches of independent LDS reads (80 + 32) that stream
+            // through the LDS pipe back to back, each followed by pure register arithmetic.  The value that enters
+            // the hash at step k leaves it at step k+48 (hpcdcchunker.c:294-296; rotl(T[out], 48 & 31)).
+            uint32_t tv[48 + RUN];
             uint32_t h = 0;
+#define LT_LOOKUP(j) tv[j] = tabl[((win[(j) >> 2] >> (8 * ((j) & 3))) & 0xffu) * TAB_REP]
+#define LT_STEP(k)                                                                                                   \
+    {                                                                                                                \
+        h = rotl32(h, 1) ^ rotl32(tv[k], 16) ^ tv[48 + (k)];                                                         \
+        bool hit;                                                                                                    \
+        if (MODE == 1)                                                                                               \
+            hit = (h & (dv.d - 1u)) == dv.d - 1u;                                                                    \
+        else                                                                                                         \
+            hit = rotr32(h * dv.inv + dv.addc, dv.k2) <= dv.qlim; /* == (h % d == d-1), see lthip_ctx.hip */         \
+        if (__builtin_amdgcn_ballot_w64(hit) != 0ull) /* wave-uniform and rare (1 position in d) */                  \
+        {                                                                                                            \
+            asm volatile(""); /* keep this a real scalar branch (no if-conversion of the bit-set) */                 \
+            if (hit)                                                                                                 \
+            {                                                                                                        \
+                if ((k) < 32)                                                                                        \
+                    mlo |= 1u << (k);                                                                                \
+                else                                                                                                 \
+                    mhi |= 1u << ((k)-32);                                                                           \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+#pragma unroll
+            for (int j = 0; j < 80; ++j)
+                LT_LOOKUP(j);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 48; ++j)
-            {
-                const uint32_t b = (win[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                h = rotl32(h, 1) ^ tabl[b * TAB_REP];
-            }
+                h = rotl32(h, 1) ^ tv[j];
 #pragma unroll
-            for (int k = 0; k < RUN; ++k)
-            {
-                const uint32_t bi = (win[(48 + k) >> 2] >> (8 * ((48 + k) & 3))) & 0xffu;
-                const uint32_t bo = (win[k >> 2] >> (8 * (k & 3))) & 0xffu;
-                // hpcdcchunker.c:294-296 ; rotl(T[out], 48 & 31)
-                h = rotl32(h, 1) ^ rotl32(tabl[bo * TAB_REP], 16) ^ tabl[bi * TAB_REP];
-                bool hit;
-                if (MODE == 1)
-                    hit = (h & (dv.d - 1u)) == dv.d - 1u;
-                else
-                    hit = rotr32(h * dv.inv + dv.addc, dv.k2) <= dv.qlim; // == (h % d == d-1), see lthip_ctx.hip
-                if (__builtin_amdgcn_ballot_w64(hit) != 0ull) // wave-uniform and rare
-                {
-                    if (hit)
-                    {
-                        if (k < 32)
-                            mlo |= 1u << k;
-                        else
-                            mhi |= 1u << (k - 32);
-                    }
-                }
-            }
+            for (int k = 0; k < 32; ++k)
+                LT_STEP(k)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 80; j < 48 + RUN; ++j)
+                LT_LOOKUP(j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 32; k < RUN; ++k)
+                LT_STEP(k)
+#undef LT_LOOKUP
+#undef LT_STEP
             // bit k <=> cut position p = q0+k+1 ; legal cuts are 48 <= p <= size
             uint64_t m = ((uint64_t)mhi << 32) | mlo;
             if (q0 < 47)
@@ -174,11 +242,16 @@ __global__ __launch_bounds__(K1_THREADS) void k_buzhash_candidates(const uint8_t
         }
         const uint64_t m = ((uint64_t)mhi << 32) | mlo;
         const uint64_t summary = __builtin_amdgcn_ballot_w64(m != 0ull);
-        const uint64_t run_index = (tile_start >> 6) + (uint64_t)tid; // 64-byte run number within the part
         if (m != 0ull)
-            bm0[pd.bm0_base + run_index] = m;
+            bm0[pd.bm0_base + (span >> 6) + (uint64_t)lane] = m; // one word per 64-byte run
         if (lane == 0)
-            bm1[pd.bm1_base + (tile_start >> 12) + (uint64_t)wave] = summary;
+            bm1[pd.bm1_base + (span >> 12)] = summary;            // one word per 4 KiB
+
+        if (next >= nwt)
+            break;
+        wt = next;
+        pd = npd;
+        span = next_span;
     }
 }
 
@@ -487,9 +560,9 @@ int lthip_launch_buzhash(lthip_ctx* ctx, const lthip_plan* plan, const uint8_t* 
 {
     if (plan->ntiles == 0)
         return 0;
-    static_assert(sizeof(uint32_t) * (256 * TAB_REP + ROWS * ROW_DW) < 64 * 1024, "LDS budget");
-    const size_t lds = sizeof(uint32_t) * (256 * TAB_REP + ROWS * ROW_DW);
-    // 3 workgroups / CU fit in LDS (50 KiB each); persistent grid amortises the table fill
+    static_assert(sizeof(uint32_t) * (256 * TAB_REP + 4 * WROWS * ROW_DW) < 53 * 1024, "LDS budget: 3 workgroups per CU");
+    const size_t lds = sizeof(uint32_t) * (256 * TAB_REP + 4 * WROWS * ROW_DW);
+    // 4 workgroups / CU fit in LDS (33.5 KiB each); persistent grid amortises the table fill
     uint32_t grid = 256 * 3;
     if ((uint64_t)grid > plan->ntiles)
         grid = (uint32_t)plan->ntiles;

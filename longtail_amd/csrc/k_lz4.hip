@@ -58,7 +58,6 @@ struct Lz4BlockOut
     uint32_t pad;
 };
 
-constexpr int LZ4_HASH_LOG2 = 12;
 constexpr uint32_t LZ4_EMPTY = 0xFFFFu;
 
 __host__ __device__ __forceinline__ uint32_t lz4_stream_stride(uint32_t seg) { return (seg + seg / 255u + 16u + 15u) & ~15u; }
@@ -83,15 +82,16 @@ __device__ __forceinline__ void emit_len(uint8_t* out, uint32_t len, int lane)
         out[j] = j + 1 == n ? (uint8_t)(len % 255u) : (uint8_t)255;
 }
 
-template <int SEG_LOG2>
+// segment geometry is a runtime value: seg_bytes need not be a power of two (the default, 32704, is chosen so that
+// segment + 32 B slack + 8 KiB table = 40928 B and FOUR single-wave workgroups share a CU's 160 KiB of LDS)
+template <int HASH_LOG2>
 __global__ __launch_bounds__(64) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
-                                                     uint32_t nblocks, uint8_t* __restrict__ streams,
+                                                     uint32_t nblocks, uint32_t seg_bytes, uint8_t* __restrict__ streams,
                                                      Lz4Meta* __restrict__ meta)
 {
-    constexpr uint32_t SEG = 1u << SEG_LOG2;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t* sdata = smem;                                              // SEG + 32 bytes
-    uint16_t* tab = reinterpret_cast<uint16_t*>(smem + SEG / 4 + 8);     // 4096 entries
+    uint32_t* sdata = smem;                                                                  // seg_bytes + 32
+    uint16_t* tab = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + seg_bytes + 32); // 2^HASH_LOG2 entries
     const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(sdata);
 
     const int lane = threadIdx.x;
@@ -107,22 +107,38 @@ __global__ __launch_bounds__(64) void k_lz4_segments(const uint8_t* __restrict__
             hi = mid;
     }
     const Lz4Block blk = blocks[lo];
-    const uint32_t seg_start = (seg - blk.seg_base) << SEG_LOG2;
-    const uint32_t len = blk.size - seg_start < SEG ? blk.size - seg_start : SEG;
+    const uint32_t seg_start = (seg - blk.seg_base) * seg_bytes;
+    const uint32_t len = blk.size - seg_start < seg_bytes ? blk.size - seg_start : seg_bytes;
     const uint8_t* g = src + blk.src_off + seg_start;
 
-    // ---- stage the segment (16-byte loads from the aligned-down address) and clear the table ----
+    // ---- stage the segment: 16-byte loads from the aligned-down address, 8 in flight per lane; clear the table ----
     const uint32_t head = (uint32_t)((uintptr_t)g & 15u);
     {
         const uint4* gv = reinterpret_cast<const uint4*>(g - head);
         const uint32_t nvec = (head + len + 15u) >> 4;
         uint4* sv = reinterpret_cast<uint4*>(sdata);
-        for (uint32_t v = lane; v < nvec; v += 64)
-            sv[v] = gv[v];
+        for (uint32_t v0 = 0; v0 < nvec; v0 += 64 * 8)
+        {
+            uint4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+                const uint32_t v = v0 + u * 64 + lane;
+                q[u] = v < nvec ? gv[v] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+                const uint32_t v = v0 + u * 64 + lane;
+                if (v < nvec)
+                    sv[v] = q[u];
+            }
+        }
         uint4* tv = reinterpret_cast<uint4*>(tab);
         const uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        for (uint32_t v = lane; v < (1u << LZ4_HASH_LOG2) * 2 / 16; v += 64)
-            tv[v] = e;
+#pragma unroll
+        for (uint32_t v = 0; v < (1u << HASH_LOG2) * 2 / 16 / 64; ++v)
+            tv[v * 64 + lane] = e;
     }
     __syncthreads();
 
@@ -133,13 +149,14 @@ __global__ __launch_bounds__(64) void k_lz4_segments(const uint8_t* __restrict__
         start_limit = (int32_t)(blk_left - 12);
     const uint32_t end_limit = (int64_t)len < blk_left - 5 ? len : (uint32_t)(blk_left - 5 > 0 ? blk_left - 5 : 0);
 
-    uint8_t* out = streams + (uint64_t)seg * lz4_stream_stride(SEG);
+    uint8_t* out = streams + (uint64_t)seg * lz4_stream_stride(seg_bytes);
     uint32_t op = 0, anchor = 0, pos = 0, nfail = 0;
     uint32_t first_lit = 0, first_hdr = 0;
     bool have_first = false;
 
     while ((int32_t)pos <= start_limit)
     {
+        // ---- probe 64 positions (stride grows with consecutive misses, lz4.c:1044-1053) ----
         const uint32_t stride = 1u + nfail;
         const uint32_t p = pos + (uint32_t)lane * stride;
         const bool valid = (int32_t)p <= start_limit;
@@ -147,88 +164,143 @@ __global__ __launch_bounds__(64) void k_lz4_segments(const uint8_t* __restrict__
         if (valid)
         {
             v = lds_read32(sdata, p + head);
-            h = (v * 2654435761u) >> (32 - LZ4_HASH_LOG2);
+            h = (v * 2654435761u) >> (32 - HASH_LOG2);
             cand = tab[h];
         }
-        // all lanes have read the table before anyone updates it (same wave: LDS ops issue in order)
+        // every lane has read the table before anyone updates it (same wave: LDS operations execute in order)
         if (valid)
             tab[h] = (uint16_t)p;
         bool ok = false;
         if (valid && cand != LZ4_EMPTY && cand < p)
             ok = lds_read32(sdata, cand + head) == v;
-        const uint64_t hits = __builtin_amdgcn_ballot_w64(ok);
+        // matches whose source lies in the same batch are invisible to the table: look 1, 2, 4, 8 lanes back
+        {
+            const uint32_t vkey = valid ? v : (0x80000000u | (uint32_t)lane); // invalid lanes never compare equal... 
+            uint32_t best = 0;
+            bool found = false;
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) // smallest distance wins (assigned last)
+            {
+                const uint32_t ov = __shfl_up(vkey, d, 64);
+                const bool ovalid = __shfl_up((int)valid, d, 64) != 0;
+                if (valid && lane >= d && ovalid && ov == v)
+                {
+                    best = p - (uint32_t)d * stride;
+                    found = true;
+                }
+            }
+            if (found && (!ok || best > cand))
+            {
+                cand = best;
+                ok = true;
+            }
+        }
+        uint64_t hits = __builtin_amdgcn_ballot_w64(ok);
         if (hits == 0ull)
         {
             pos += 64u * stride;
             ++nfail;
             continue;
         }
-        const int f = __builtin_ctzll(hits);
-        uint32_t pf = pos + (uint32_t)f * stride;
-        uint32_t cf = __builtin_amdgcn_readlane(cand, f);
-
-        // backwards (lz4.c:1104-1109): at most up to the anchor / segment start
+        // ---- take every hit of the batch that starts at or after the end of the previous match ----
+        do
         {
+            const int f = __builtin_ctzll(hits);
+            hits &= hits - 1ull;
+            uint32_t pf = pos + (uint32_t)f * stride;
+            if (pf < anchor)
+                continue;
+            uint32_t cf = __builtin_amdgcn_readlane(cand, f);
+
+            // first round: lanes 0..31 compare forwards from +4, lanes 32..63 backwards from -1 (lz4.c:1104-1109)
             uint32_t room = pf - anchor < cf ? pf - anchor : cf;
-            while (room)
+            uint32_t nf, nb;
             {
-                const uint32_t j = (uint32_t)lane;
-                const bool same = j < room && sbytes[pf - 1 - j + head] == sbytes[cf - 1 - j + head];
+                const uint32_t j = (uint32_t)lane & 31u;
+                bool same;
+                if (lane < 32)
+                {
+                    const uint32_t i = pf + 4u + j;
+                    same = i < end_limit && sbytes[i + head] == sbytes[cf + 4u + j + head];
+                }
+                else
+                    same = j < room && sbytes[pf - 1u - j + head] == sbytes[cf - 1u - j + head];
                 const uint64_t diff = __builtin_amdgcn_ballot_w64(!same);
-                const uint32_t n = diff ? (uint32_t)__builtin_ctzll(diff) : 64u;
-                pf -= n;
-                cf -= n;
-                room -= n;
-                if (n < 64u)
-                    break;
+                const uint32_t dl = (uint32_t)diff, dh = (uint32_t)(diff >> 32);
+                nf = dl ? (uint32_t)__builtin_ctz(dl) : 32u;
+                nb = dh ? (uint32_t)__builtin_ctz(dh) : 32u;
             }
-        }
-        // forwards
-        uint32_t mlen = 4;
-        for (;;)
-        {
-            const uint32_t i = pf + mlen + (uint32_t)lane;
-            const bool same = i < end_limit && sbytes[i + head] == sbytes[cf + mlen + (uint32_t)lane + head];
-            const uint64_t diff = __builtin_amdgcn_ballot_w64(!same);
-            if (diff)
+            uint32_t mlen = 4u + nf;
+            if (nf == 32u)
             {
-                mlen += (uint32_t)__builtin_ctzll(diff);
-                break;
+                for (;;)
+                {
+                    const uint32_t i = pf + mlen + (uint32_t)lane;
+                    const bool same = i < end_limit && sbytes[i + head] == sbytes[cf + mlen + (uint32_t)lane + head];
+                    const uint64_t diff = __builtin_amdgcn_ballot_w64(!same);
+                    if (diff)
+                    {
+                        mlen += (uint32_t)__builtin_ctzll(diff);
+                        break;
+                    }
+                    mlen += 64u;
+                }
             }
-            mlen += 64u;
-        }
+            if (nb == 32u && room > 32u)
+            {
+                uint32_t back = 32u;
+                for (;;)
+                {
+                    const uint32_t j = back + (uint32_t)lane;
+                    const bool same = j < room && sbytes[pf - 1u - j + head] == sbytes[cf - 1u - j + head];
+                    const uint64_t diff = __builtin_amdgcn_ballot_w64(!same);
+                    if (diff)
+                    {
+                        back += (uint32_t)__builtin_ctzll(diff);
+                        break;
+                    }
+                    back += 64u;
+                }
+                nb = back;
+            }
+            pf -= nb;
+            cf -= nb;
+            mlen += nb;
 
-        // ---- emit  token | literal length | literals | offset | match length  (lz4.c:1111-1226) ----
-        const uint32_t lit = pf - anchor;
-        const uint32_t mcode = mlen - 4u;
-        const uint32_t hdr = 1u + lz4_len_bytes(lit);
-        if (lane == 0)
-            out[op] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
-        if (lit >= 15u)
-            emit_len(out + op + 1, lit - 15u, lane);
-        for (uint32_t j = lane; j < lit; j += 64)
-            out[op + hdr + j] = sbytes[anchor + j + head];
-        uint32_t o2 = op + hdr + lit;
-        if (lane == 0)
-        {
-            const uint32_t off = pf - cf;
-            out[o2] = (uint8_t)off;
-            out[o2 + 1] = (uint8_t)(off >> 8);
-        }
-        o2 += 2;
-        if (mcode >= 15u)
-        {
-            emit_len(out + o2, mcode - 15u, lane);
-            o2 += lz4_len_bytes(mcode);
-        }
-        if (!have_first)
-        {
-            have_first = true;
-            first_lit = lit;
-            first_hdr = hdr;
-        }
-        op = o2;
-        anchor = pos = pf + mlen;
+            // ---- emit  token | literal length | literals | offset | match length  (lz4.c:1111-1226) ----
+            const uint32_t lit = pf - anchor;
+            const uint32_t mcode = mlen - 4u;
+            const uint32_t hdr = 1u + lz4_len_bytes(lit);
+            if (lane == 0)
+                out[op] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
+            if (lit >= 15u)
+                emit_len(out + op + 1, lit - 15u, lane);
+            for (uint32_t j = lane; j < lit; j += 64)
+                out[op + hdr + j] = sbytes[anchor + j + head];
+            uint32_t o2 = op + hdr + lit;
+            if (lane == 0)
+            {
+                const uint32_t off = pf - cf;
+                out[o2] = (uint8_t)off;
+                out[o2 + 1] = (uint8_t)(off >> 8);
+            }
+            o2 += 2;
+            if (mcode >= 15u)
+            {
+                emit_len(out + o2, mcode - 15u, lane);
+                o2 += lz4_len_bytes(mcode);
+            }
+            if (!have_first)
+            {
+                have_first = true;
+                first_lit = lit;
+                first_hdr = hdr;
+            }
+            op = o2;
+            anchor = pf + mlen;
+        } while (hits);
+        const uint32_t np = pos + 64u * stride;
+        pos = np > anchor ? np : anchor;
         nfail = 0;
     }
     if (lane == 0)
@@ -245,7 +317,7 @@ __global__ __launch_bounds__(64) void k_lz4_segments(const uint8_t* __restrict__
 // ---------------------------------------------------------------------------------------------------
 // K6a: per-block serial walk over segment results
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_lz4_stitch_scan(const Lz4Block* __restrict__ blocks, uint32_t nblocks, uint32_t seg_log2,
+__global__ void k_lz4_stitch_scan(const Lz4Block* __restrict__ blocks, uint32_t nblocks, uint32_t SEG,
                                   const Lz4Meta* __restrict__ meta, Lz4Plan* __restrict__ plan,
                                   Lz4BlockOut* __restrict__ bout, uint32_t* __restrict__ out_sizes)
 {
@@ -253,7 +325,6 @@ __global__ void k_lz4_stitch_scan(const Lz4Block* __restrict__ blocks, uint32_t 
     if (b >= nblocks)
         return;
     const Lz4Block blk = blocks[b];
-    const uint32_t SEG = 1u << seg_log2;
     uint64_t out_pos = 0; // 64-bit: detect overflow of pathological inputs against dst_cap
     uint32_t carry = 0;
     uint32_t pend = 0; // first segment whose tail belongs to the open literal run
@@ -261,7 +332,7 @@ __global__ void k_lz4_stitch_scan(const Lz4Block* __restrict__ blocks, uint32_t 
     {
         const uint32_t s = blk.seg_base + i;
         const Lz4Meta m = meta[s];
-        const uint32_t seg_len = blk.size - (i << seg_log2) < SEG ? blk.size - (i << seg_log2) : SEG;
+        const uint32_t seg_len = blk.size - i * SEG < SEG ? blk.size - i * SEG : SEG;
         Lz4Plan pl;
         pl.hdr_pos = 0xFFFFFFFFu;
         pl.hdr_lits = 0;
@@ -360,7 +431,7 @@ constexpr int K6_THREADS = 256;
 
 __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* __restrict__ src,
                                                                  const Lz4Block* __restrict__ blocks, uint32_t nblocks,
-                                                                 uint32_t seg_log2, const uint8_t* __restrict__ streams,
+                                                                 uint32_t SEG, const uint8_t* __restrict__ streams,
                                                                  const Lz4Meta* __restrict__ meta,
                                                                  const Lz4Plan* __restrict__ plan,
                                                                  const Lz4BlockOut* __restrict__ bout,
@@ -381,9 +452,8 @@ __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* _
     const Lz4BlockOut bo = bout[lo];
     if (bo.total == 0)
         return; // does not fit: nothing is written, size 0 reported
-    const uint32_t SEG = 1u << seg_log2;
     const uint32_t i = seg - blk.seg_base;
-    const uint32_t seg_start = i << seg_log2;
+    const uint32_t seg_start = i * SEG;
     const uint32_t len = blk.size - seg_start < SEG ? blk.size - seg_start : SEG;
     const Lz4Meta m = meta[seg];
     const Lz4Plan pl = plan[seg];
@@ -534,7 +604,7 @@ __global__ __launch_bounds__(64) void k_lz4_decode(const uint8_t* __restrict__ s
 extern "C" size_t lthip_lz4_bound(size_t size) { return size > 0x7E000000u ? 0 : size + size / 255 + 16; }
 
 static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* src_offsets, const uint32_t* src_sizes,
-                         const uint64_t* dst_offsets, const uint32_t* dst_caps, uint32_t seg_log2, Lz4Block** d_blocks,
+                         const uint64_t* dst_offsets, const uint32_t* dst_caps, uint32_t seg_bytes, Lz4Block** d_blocks,
                          uint64_t* out_nseg)
 {
     std::vector<Lz4Block> hb(block_count);
@@ -548,7 +618,7 @@ static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* s
         hb[b].size = src_sizes[b];
         hb[b].dst_cap = dst_caps[b];
         hb[b].seg_base = (uint32_t)nseg;
-        hb[b].nseg = seg_log2 ? (uint32_t)((src_sizes[b] + (1ull << seg_log2) - 1) >> seg_log2) : 0;
+        hb[b].nseg = seg_bytes ? (uint32_t)(((uint64_t)src_sizes[b] + seg_bytes - 1) / seg_bytes) : 0;
         nseg += hb[b].nseg;
     }
     if (nseg > 0x7FFFFFF0ull)
@@ -564,14 +634,8 @@ static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* s
     return 0;
 }
 
-template <int SEG_LOG2>
-static void launch_segments(lthip_ctx* ctx, uint32_t nseg, const uint8_t* d_src, const Lz4Block* d_blocks, uint32_t nblocks,
-                            uint8_t* streams, Lz4Meta* meta)
-{
-    const size_t lds = (1u << SEG_LOG2) + 32 + (1u << LZ4_HASH_LOG2) * 2;
-    hipLaunchKernelGGL(k_lz4_segments<SEG_LOG2>, dim3(nseg), dim3(64), lds, ctx->stream, d_src, d_blocks, nblocks, streams,
-                       meta);
-}
+// default geometry: 32704-byte segments + 32 B slack + 4096 x u16 table = 40928 B of LDS -> 4 waves per CU
+static const uint32_t LZ4_DEFAULT_SEG_BYTES = 32768u - 64u;
 
 extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                                          const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
@@ -581,19 +645,16 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
         return EINVAL;
     if (block_count == 0)
         return 0;
-    if (segment_log2 == 0)
-        segment_log2 = 15;
-    if (segment_log2 < 13 || segment_log2 > 16)
-        return lthip_fail(ctx, EINVAL, "lz4", "segment_log2 must be 13..16");
+    if (segment_log2 != 0 && (segment_log2 < 12 || segment_log2 > 16))
+        return lthip_fail(ctx, EINVAL, "lz4", "segment_log2 must be 0 (default) or 12..16");
+    const uint32_t SEG = segment_log2 ? (segment_log2 == 16 ? 65536u - 64u : 1u << segment_log2) : LZ4_DEFAULT_SEG_BYTES;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     Lz4Block* d_blocks = nullptr;
     uint64_t nseg64 = 0;
-    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, (uint32_t)segment_log2, &d_blocks,
-                            &nseg64);
+    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, SEG, &d_blocks, &nseg64);
     if (err)
         return err;
     const uint32_t nseg = (uint32_t)nseg64;
-    const uint32_t SEG = 1u << segment_log2;
     void *meta, *plan, *bout, *streams;
     if ((err = lthip_scratch(ctx, S_LZ4_META, sizeof(Lz4Meta) * ((size_t)nseg + 1), &meta)))
         return err;
@@ -606,23 +667,23 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
     if (nseg)
     {
         LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
-        switch (segment_log2)
-        {
-        case 13: launch_segments<13>(ctx, nseg, (const uint8_t*)d_src, d_blocks, block_count, (uint8_t*)streams, (Lz4Meta*)meta); break;
-        case 14: launch_segments<14>(ctx, nseg, (const uint8_t*)d_src, d_blocks, block_count, (uint8_t*)streams, (Lz4Meta*)meta); break;
-        case 15: launch_segments<15>(ctx, nseg, (const uint8_t*)d_src, d_blocks, block_count, (uint8_t*)streams, (Lz4Meta*)meta); break;
-        default: launch_segments<16>(ctx, nseg, (const uint8_t*)d_src, d_blocks, block_count, (uint8_t*)streams, (Lz4Meta*)meta); break;
-        }
+        // positions are u16: a 64 KiB segment keeps 64 bytes of head-room; small segments use a smaller table
+        if (SEG <= 8192u)
+            hipLaunchKernelGGL(k_lz4_segments<11>, dim3(nseg), dim3(64), SEG + 32 + (1u << 11) * 2, ctx->stream,
+                               (const uint8_t*)d_src, d_blocks, block_count, SEG, (uint8_t*)streams, (Lz4Meta*)meta);
+        else
+            hipLaunchKernelGGL(k_lz4_segments<12>, dim3(nseg), dim3(64), SEG + 32 + (1u << 12) * 2, ctx->stream,
+                               (const uint8_t*)d_src, d_blocks, block_count, SEG, (uint8_t*)streams, (Lz4Meta*)meta);
         LTHIP_LAUNCH_CHECK(ctx);
     }
     {
         LaunchTimer t(ctx, LTHIP_K_LZ4_STITCH);
-        hipLaunchKernelGGL(k_lz4_stitch_scan, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, d_blocks, block_count,
-                           (uint32_t)segment_log2, (const Lz4Meta*)meta, (Lz4Plan*)plan, (Lz4BlockOut*)bout, d_out_sizes);
+        hipLaunchKernelGGL(k_lz4_stitch_scan, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, d_blocks, block_count, SEG,
+                           (const Lz4Meta*)meta, (Lz4Plan*)plan, (Lz4BlockOut*)bout, d_out_sizes);
         if (nseg)
             hipLaunchKernelGGL(k_lz4_stitch_copy, dim3(nseg), dim3(K6_THREADS), 0, ctx->stream, (const uint8_t*)d_src, d_blocks,
-                               block_count, (uint32_t)segment_log2, (const uint8_t*)streams, (const Lz4Meta*)meta,
-                               (const Lz4Plan*)plan, (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
+                               block_count, SEG, (const uint8_t*)streams, (const Lz4Meta*)meta, (const Lz4Plan*)plan,
+                               (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
         hipLaunchKernelGGL(k_lz4_empty_blocks, dim3((block_count + 255) / 256), dim3(256), 0, ctx->stream, d_blocks, block_count,
                            (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
         LTHIP_LAUNCH_CHECK(ctx);
