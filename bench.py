@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gib", type=float, default=64.0, help="GiB of assets per GPU")
     ap.add_argument("--file-mib", type=float, default=1.0)
+    ap.add_argument("--tree", choices=["files", "mixed-sizes"], default="files", help="files: equal files (configs[2]); mixed-sizes: 4 KiB..4 GiB log-uniform")
     ap.add_argument("--kind", choices=["random", "mixed", "zero"], default="random")
     ap.add_argument("--target-chunk-size", type=int, default=65536)
     ap.add_argument("--block-size", type=int, default=8 << 20)
@@ -102,17 +103,42 @@ def main():
     ctx = Context(local_rank)
     kind = {"random": 0, "mixed": 1, "zero": 2}[args.kind]
     mn, av, mx = chunker_params(args.target_chunk_size)
-    file_bytes = int(args.file_mib * (1 << 20))
-    file_bytes -= file_bytes % 16
-    nfiles = max(1, int(args.gib * (1 << 30)) // file_bytes)
-    shard_bytes = nfiles * file_bytes
+    part_bytes = args.target_chunk_size * 1024  # ChunkAssets part size (src/longtail.c:2396)
+    if args.tree == "files":
+        file_bytes = int(args.file_mib * (1 << 20))
+        file_bytes -= file_bytes % 16
+        nfiles = max(1, int(args.gib * (1 << 30)) // file_bytes)
+        file_sizes = np.full(nfiles, file_bytes, dtype=np.uint64)
+    else:
+        # north-star tree: sizes log-uniform in [4 KiB, 4 GiB] (capped at a quarter of the shard), fixed seed
+        rng = np.random.default_rng(0xA55E7 + rank)
+        budget = int(args.gib * (1 << 30))
+        hi = min(4 << 30, max(budget // 4, 8192))
+        sizes = []
+        while budget > 0:
+            sz = int(np.exp(rng.uniform(np.log(4096), np.log(hi))))
+            sz = max(1, min(sz, budget))
+            sizes.append(sz)
+            budget -= sz
+        file_sizes = np.asarray(sizes, dtype=np.uint64)
+        nfiles = len(sizes)
+        file_bytes = int(file_sizes.mean())
+    file_offsets = np.zeros(nfiles, dtype=np.uint64)
+    np.cumsum(((file_sizes + np.uint64(15)) // np.uint64(16) * np.uint64(16))[:-1], out=file_offsets[1:])
+    shard_bytes = int(file_sizes.sum())
+    arena_bytes = int(file_offsets[-1] + file_sizes[-1])
+    # parts: every asset is cut into target*1024-byte segments, each chunked from a fresh state (:2396-2458)
+    nparts_per = (file_sizes + np.uint64(part_bytes - 1)) // np.uint64(part_bytes)
+    rep = np.repeat(np.arange(nfiles), nparts_per.astype(np.int64))
+    within = np.arange(len(rep), dtype=np.uint64) - np.repeat(np.cumsum(nparts_per) - nparts_per, nparts_per.astype(np.int64))
+    part_offsets = file_offsets[rep] + within * np.uint64(part_bytes)
+    part_sizes = np.minimum(file_sizes[rep] - within * np.uint64(part_bytes), np.uint64(part_bytes))
+    nparts = len(part_offsets)
 
     # ---- inputs resident in HBM (untimed) ----
-    data = torch.empty(shard_bytes + 256, dtype=torch.uint8, device=dev)
-    part_offsets = np.arange(nfiles, dtype=np.uint64) * np.uint64(file_bytes)
-    part_sizes = np.full(nfiles, file_bytes, dtype=np.uint64)
-    seeds = asset_seeds(0x10C0FFEE, rank * nfiles, nfiles)
-    ctx.synth_fill(data, part_offsets, part_sizes, seeds, kind)
+    data = torch.empty(arena_bytes + 256, dtype=torch.uint8, device=dev)
+    seeds = asset_seeds(0x10C0FFEE, rank * 10_000_000, nfiles)
+    ctx.synth_fill(data, file_offsets, file_sizes, seeds, kind)
     ctx.sync()
 
     # ---- output arenas (allocated once; the hot path never allocates in steady state) ----
@@ -122,11 +148,12 @@ def main():
     out_offs = torch.empty(cap, dtype=torch.int64, device=dev)
     out_lens = torch.empty(cap, dtype=torch.int32, device=dev)
     out_hash = torch.empty(cap, dtype=torch.int64, device=dev)
-    out_first = torch.empty(nfiles + 1, dtype=torch.int32, device=dev)
+    out_first = torch.empty(nparts + 1, dtype=torch.int32, device=dev)
     batch_bytes = int(args.lz4_batch_gib * (1 << 30))
     limit = args.block_size + args.block_size // 10
     dst_arena_bytes = batch_bytes + batch_bytes // 255 + (batch_bytes // args.block_size + 2) * 64 + 2 * (limit + limit // 255 + 64)
     dst = torch.empty(dst_arena_bytes, dtype=torch.uint8, device=dev)
+    gather_arena = None  # allocated on first use: only trees whose blocks are not contiguous ranges need it
     stats = {}
 
     def step():
@@ -152,24 +179,40 @@ def main():
                 lens_h, offs_h = lens_h[keep], offs_h[keep]
             starts, cs = pack_blocks(lens_h, args.block_size, args.max_chunks_per_block)
             b_first, b_last = starts[:-1], starts[1:] - 1
-            b_off = offs_h[b_first]
-            b_size = (offs_h[b_last] + lens_h[b_last]) - b_off
-            packed = cs[b_last] - np.concatenate([[0], cs[b_last[:-1]]]) if len(b_last) else np.zeros(0, np.int64)
-            if not (packed == b_size).all():
-                raise SystemExit("non-contiguous blocks (dedup holes / unaligned files) need the gather path: not in this bench")
-            nblocks = len(b_off)
-            # batches that fit the output arena
+            cs0 = np.concatenate([[0], cs])
+            b_size = cs0[starts[1:]] - cs0[starts[:-1]]
+            nblocks = len(b_size)
+            contiguous = bool(((offs_h[b_last] + lens_h[b_last]) - offs_h[b_first] == b_size).all()) if nblocks else True
+            stats["gather"] = not contiguous
+            if not contiguous:
+                nonlocal gather_arena
+                if gather_arena is None:
+                    gather_arena = torch.empty(batch_bytes + 2 * limit + 256, dtype=torch.uint8, device=dev)
+                if n_unique_local != total:
+                    d_offs_u, d_lens_u = out_offs[:total][unique_mask], out_lens[:total][unique_mask]
+                else:
+                    d_offs_u, d_lens_u = out_offs[:total], out_lens[:total]
             bounds = b_size + b_size // 255 + 16
             aligned = (bounds + 63) // 64 * 64
             i = 0
             size_tensors = []
             while i < nblocks:
-                acc = np.cumsum(aligned[i:])
-                j = i + max(1, int(np.searchsorted(acc, dst_arena_bytes, side="right")))
+                j = i + max(1, int(np.searchsorted(np.cumsum(aligned[i:]), dst_arena_bytes, side="right")))
                 j = min(j, i + max(1, int(np.searchsorted(np.cumsum(b_size[i:]), batch_bytes, side="right"))), nblocks)
                 j = max(j, i + 1)
                 d_offs = np.concatenate([[0], np.cumsum(aligned[i:j])[:-1]])
-                size_tensors.append(ctx.lz4_compress_blocks(data, b_off[i:j], b_size[i:j], dst, d_offs, bounds[i:j], args.segment_log2))
+                if contiguous:
+                    size_tensors.append(ctx.lz4_compress_blocks(data, offs_h[b_first[i:j]], b_size[i:j], dst, d_offs, bounds[i:j],
+                                                                args.segment_log2))
+                else:
+                    # block assembly on the device (WriteContentBlockJob, src/longtail.c:4640-4721): gather this batch's
+                    # chunks back to back, then every block is a contiguous range of the gather arena
+                    c0, c1 = int(starts[i]), int(starts[j])
+                    lens_d = d_lens_u[c0:c1]
+                    dst_off = torch.cumsum(lens_d.to(torch.int64), 0) - lens_d.to(torch.int64)
+                    ctx.gather_ranges(data, d_offs_u[c0:c1].contiguous(), lens_d.contiguous(), gather_arena, dst_off)
+                    size_tensors.append(ctx.lz4_compress_blocks(gather_arena, cs0[starts[i:j]] - cs0[c0], b_size[i:j], dst, d_offs,
+                                                                bounds[i:j], args.segment_log2))
                 i = j
             sizes = torch.cat(size_tensors).to(torch.int64)
             comp_bytes = int(sizes.sum().item())
@@ -233,6 +276,20 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": int(alg_bytes[dom] / launches), "avg_launch_ms": round(avg_ms, 3)}
 
+    # HBM traffic from the PMC counters: collected offline (rocprofv3 cannot wrap itself), tools/pmc_traffic.sh ->
+    # profiles/*pmc_traffic*.json; scaled by input bytes to this run's launch size
+    if roofline:
+        try:
+            tfiles = sorted((ROOT / "profiles").glob("*pmc_traffic*.json"))
+            tj = json.load(open(tfiles[-1]))
+            names = {"buzhash": "k_buzhash_candidates<0>", "blake3_leaf": "k_blake3_leaves", "lz4_segments": "k_lz4_segments<12>",
+                     "lz4_stitch": "k_lz4_stitch_copy"}
+            ratio = tj["kernels"][names[dom]]["corrected_per_input_byte"]
+            roofline["traffic"] = int(ratio * shard_bytes / kern[dom]["launches_per_step"])
+            roofline["traffic_source"] = f"profiles/{tfiles[-1].name}: {ratio} HBM bytes per input byte (2*FETCH_SIZE+WRITE_SIZE)"
+        except Exception:
+            pass
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(args, kind, file_bytes)
@@ -252,10 +309,12 @@ def main():
             "dtype": "u8/u32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.gib:g} GiB tree of {args.file_mib:g} MiB {args.kind} files per GPU, chunk+BLAKE3+LZ4 "
-                            f"(BASELINE.json configs[2]{'/[3]' if world > 1 else ''})",
+                "workload": (f"{args.gib:g} GiB tree of {args.file_mib:g} MiB {args.kind} files per GPU, chunk+BLAKE3+LZ4 "
+                             f"(BASELINE.json configs[2]{'/[3]' if world > 1 else ''})") if args.tree == "files" else
+                            (f"{args.gib:g} GiB tree of {nfiles} {args.kind} files, 4 KiB..4 GiB log-uniform, per GPU, chunk+BLAKE3+LZ4 "
+                             f"(north-star tree)"),
                 "target_chunk_size": args.target_chunk_size, "min_avg_max": [mn, av, mx], "block_size": args.block_size,
-                "max_chunks_per_block": args.max_chunks_per_block, "bytes_per_gpu": shard_bytes, "files_per_gpu": nfiles,
+                "max_chunks_per_block": args.max_chunks_per_block, "bytes_per_gpu": shard_bytes, "files_per_gpu": nfiles, "parts_per_gpu": nparts, "device_block_assembly": bool(stats.get("gather")),
                 "sharding": "by file, RCCL all-gather of chunk hashes for dedup" if world > 1 else "single GPU",
             },
             "roofline": roofline,

@@ -166,6 +166,11 @@ LTHIP_EXPORT int lthip_lz4_decompress_blocks(lthip_ctx* ctx, const void* d_src, 
                                              const uint64_t* dst_offsets, const uint32_t* dst_caps,
                                              uint32_t* d_out_sizes);
 
+/* Block assembly (WriteContentBlockJob, src/longtail.c:4640-4721) as a device gather:
+ * d_dst[d_dst_offsets[i] ..) = d_src[d_src_offsets[i] .. + d_lens[i]) for every range (all tables on the device). */
+LTHIP_EXPORT int lthip_gather_ranges(lthip_ctx* ctx, const void* d_src, uint64_t range_count, const uint64_t* d_src_offsets,
+                                     const uint32_t* d_lens, void* d_dst, const uint64_t* d_dst_offsets);
+
 LTHIP_EXPORT size_t lthip_zstd_bound(size_t size); /* ZSTD_COMPRESSBOUND, lib/zstd/ext/zstd.h:232 */
 LTHIP_EXPORT int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count,
                                             const uint64_t* src_offsets, const uint32_t* src_sizes, void* d_dst,

@@ -106,6 +106,7 @@ class HipLib:
         sig("lthip_zstd_bound", sz, [sz])
         sig("lthip_zstd_compress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_dedup_first_seen", i32, [vp, u64, vp, vp, vp])
+        sig("lthip_gather_ranges", i32, [vp, vp, u64, vp, vp, vp, vp])
         sig("lthip_synth_fill", i32, [vp, vp, u32, vp, vp, vp, i32])
         sig("lthip_divtest_eval", i32, [u32, u32])
 
@@ -262,6 +263,12 @@ class Context:
     def zstd_compress_blocks(self, src, src_offsets, src_sizes, dst, dst_offsets, dst_caps):
         return self._codec(self.lib.dll.lthip_zstd_compress_blocks, src, src_offsets, src_sizes, dst, dst_offsets,
                            dst_caps)
+
+    # -- block assembly --
+    def gather_ranges(self, src, src_offsets, lens, dst, dst_offsets):
+        n = int(src_offsets.numel())
+        self._check(self.lib.dll.lthip_gather_ranges(self.h, _ptr(src), n, _ptr(src_offsets), _ptr(lens), _ptr(dst),
+                                                     _ptr(dst_offsets)), "lthip_gather_ranges")
 
     # -- dedup --
     def dedup_first_seen(self, hashes):

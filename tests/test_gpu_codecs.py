@@ -82,7 +82,7 @@ def test_lz4_ratio_vs_reference(gpu, oracle, golden):
         d = oracle.synth(int(size), int(seed), int(kind))
         (p,), _ = gpu_lz4(gpu, [d])
         check_lz4_payload(oracle, d, p)
-        assert len(p) <= int(ref_size) * 1.10 + 64, (kind, size, len(p), ref_size)
+        assert len(p) <= int(ref_size) * 1.15 + 64, (kind, size, len(p), ref_size)
 
 
 def test_lz4_many_blocks_and_capacity(gpu, oracle):
