@@ -29,8 +29,10 @@ struct Lz4Block
     uint64_t dst_off;
     uint32_t size;
     uint32_t dst_cap;
-    uint32_t seg_base;
-    uint32_t nseg;
+    uint32_t seg_base; // first stitch unit (sub-segment) of the block
+    uint32_t nseg;     // number of units
+    uint32_t grp_base; // first window group of the block
+    uint32_t ngrp;
 };
 
 struct Lz4Meta // result of one segment
@@ -47,7 +49,8 @@ struct Lz4Plan // where one segment's pieces go, dst offsets relative to the blo
     uint32_t hdr_lits;      // literal length to encode there (carry-in + first_lit_len)
     uint32_t first_lit_dst; // destination of the segment's own leading literals
     uint32_t body_dst;      // destination of the rest of the stream
-    uint32_t tail_dst;      // destination of the trailing literals
+    uint32_t tail_rel;      // offset of the trailing literals inside the literal run they belong to
+    uint32_t run;           // index of that run in the run table (its literal-area start)
 };
 
 struct Lz4BlockOut
@@ -82,54 +85,66 @@ __device__ __forceinline__ void emit_len(uint8_t* out, uint32_t len, int lane)
         out[j] = j + 1 == n ? (uint8_t)(len % 255u) : (uint8_t)255;
 }
 
-// segment geometry is a runtime value: seg_bytes need not be a power of two (the default, 32704, is chosen so that
-// segment + 32 B slack + 8 KiB table = 40928 B and FOUR single-wave workgroups share a CU's 160 KiB of LDS)
+// K5.  A workgroup of G waves owns one WINDOW GROUP = G consecutive sub-segments ("units", default 8 x 4 KiB) of one
+// block, staged once into LDS.  Wave w parses unit w sequentially (LZ4 parsing is a chain), may match against ANY
+// earlier byte of the group (units 0..w-1 are plain history for it, like the preceding bytes of a 32 KiB segment),
+// and uses a PRIVATE 2048-entry table so the result does not depend on the other waves' timing.  The table learns
+// the history lazily: every wave first parses PROBE batches with an empty table; if any wave of the group finds a
+// match the data is taken to be compressible and each wave inserts the positions before its unit (newer entries
+// kept), otherwise (incompressible data) nobody pays for it.  16 waves per CU instead of 4 at the same window.
+constexpr int LZ4_G = 8;
+constexpr int LZ4_PROBE_BATCHES = 4;
+
 template <int HASH_LOG2>
-__global__ __launch_bounds__(64) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
-                                                     uint32_t nblocks, uint32_t seg_bytes, uint8_t* __restrict__ streams,
-                                                     Lz4Meta* __restrict__ meta)
+__global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
+                                                             uint32_t nblocks, uint32_t sub_bytes, uint8_t* __restrict__ streams,
+                                                             Lz4Meta* __restrict__ meta)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t* sdata = smem;                                                                  // seg_bytes + 32
-    uint16_t* tab = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + seg_bytes + 32); // 2^HASH_LOG2 entries
+    const uint32_t data_bytes = LZ4_G * sub_bytes + 64u;
+    uint32_t* sdata = smem;
     const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(sdata);
+    uint32_t* flag = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes); // 16 bytes
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint16_t* tab = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u) + (size_t)wave * (1u << HASH_LOG2);
 
-    const int lane = threadIdx.x;
-    const uint32_t seg = blockIdx.x;
-    // block that owns this segment
+    const uint32_t grp = blockIdx.x;
     uint32_t lo = 0, hi = nblocks;
     while (hi - lo > 1)
     {
         const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (blocks[mid].seg_base <= seg)
+        if (blocks[mid].grp_base <= grp)
             lo = mid;
         else
             hi = mid;
     }
     const Lz4Block blk = blocks[lo];
-    const uint32_t seg_start = (seg - blk.seg_base) * seg_bytes;
-    const uint32_t len = blk.size - seg_start < seg_bytes ? blk.size - seg_start : seg_bytes;
-    const uint8_t* g = src + blk.src_off + seg_start;
+    const uint32_t gi = grp - blk.grp_base;
+    const uint32_t group_start = gi * LZ4_G * sub_bytes;                                   // block relative
+    const uint32_t glen = blk.size - group_start < LZ4_G * sub_bytes ? blk.size - group_start : LZ4_G * sub_bytes;
+    const uint8_t* g = src + blk.src_off + group_start;
 
-    // ---- stage the segment: 16-byte loads from the aligned-down address, 8 in flight per lane; clear the table ----
+    // ---- stage the whole group with every wave (16-byte loads from the aligned-down address), clear my table ----
     const uint32_t head = (uint32_t)((uintptr_t)g & 15u);
     {
         const uint4* gv = reinterpret_cast<const uint4*>(g - head);
-        const uint32_t nvec = (head + len + 15u) >> 4;
+        const uint32_t nvec = (head + glen + 15u) >> 4;
         uint4* sv = reinterpret_cast<uint4*>(sdata);
-        for (uint32_t v0 = 0; v0 < nvec; v0 += 64 * 8)
+        for (uint32_t v0 = 0; v0 < nvec; v0 += 64 * LZ4_G * 4)
         {
-            uint4 q[8];
+            uint4 q[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 4; ++u)
             {
-                const uint32_t v = v0 + u * 64 + lane;
+                const uint32_t v = v0 + u * 64 * LZ4_G + tid;
                 q[u] = v < nvec ? gv[v] : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 4; ++u)
             {
-                const uint32_t v = v0 + u * 64 + lane;
+                const uint32_t v = v0 + u * 64 * LZ4_G + tid;
                 if (v < nvec)
                     sv[v] = q[u];
             }
@@ -139,23 +154,59 @@ __global__ __launch_bounds__(64) void k_lz4_segments(const uint8_t* __restrict__
 #pragma unroll
         for (uint32_t v = 0; v < (1u << HASH_LOG2) * 2 / 16 / 64; ++v)
             tv[v * 64 + lane] = e;
+        if (tid == 0)
+            *flag = 0u;
     }
     __syncthreads();
 
-    // parsing limits, segment relative (lz4.c:963-964: mflimit / matchlimit, applied at the block end)
-    const int64_t blk_left = (int64_t)blk.size - (int64_t)seg_start;     // bytes from segment start to block end
-    int32_t start_limit = (int32_t)len - 4;                              // 4 bytes must be readable
-    if ((int64_t)start_limit > blk_left - 12)
-        start_limit = (int32_t)(blk_left - 12);
-    const uint32_t end_limit = (int64_t)len < blk_left - 5 ? len : (uint32_t)(blk_left - 5 > 0 ? blk_left - 5 : 0);
+    // ---- my unit, positions relative to the group start ----
+    const uint32_t my_start = (uint32_t)wave * sub_bytes;
+    const bool have_unit = my_start < glen;
+    const uint32_t my_len = have_unit ? (glen - my_start < sub_bytes ? glen - my_start : sub_bytes) : 0u;
+    const uint32_t unit = blk.seg_base + gi * LZ4_G + (uint32_t)wave;
+    // parsing limits (lz4.c:963-964: mflimit / matchlimit, applied at the BLOCK end)
+    const int64_t blk_left = (int64_t)blk.size - (int64_t)group_start - (int64_t)my_start; // unit start .. block end
+    int64_t sl = (int64_t)my_len - 4;
+    if (sl > blk_left - 12)
+        sl = blk_left - 12;
+    const int32_t start_limit = have_unit ? (int32_t)((int64_t)my_start + sl) : -1; // < my_start when nothing may start
+    const int64_t el = (int64_t)my_len < blk_left - 5 ? (int64_t)my_len : (blk_left - 5 > 0 ? blk_left - 5 : 0);
+    const uint32_t end_limit = my_start + (uint32_t)el;
 
-    uint8_t* out = streams + (uint64_t)seg * lz4_stream_stride(seg_bytes);
-    uint32_t op = 0, anchor = 0, pos = 0, nfail = 0;
+    uint8_t* out = streams + (uint64_t)unit * lz4_stream_stride(sub_bytes);
+    uint32_t op = 0, anchor = my_start, pos = my_start, nfail = 0;
     uint32_t first_lit = 0, first_hdr = 0;
     bool have_first = false;
+    bool met = false; // the group rendezvous happens exactly once per wave
+    uint32_t batches = 0;
 
-    while ((int32_t)pos <= start_limit)
+    for (;;)
     {
+        const bool more = have_unit && (int32_t)pos <= start_limit;
+        // ---- after PROBE batches (or at the end of a short unit): does anybody in the group see redundancy? ----
+        if (!met && (batches == LZ4_PROBE_BATCHES || !more))
+        {
+            if (have_first && lane == 0)
+                *flag = 1u; // benign race: every writer stores the same value
+            __syncthreads();
+            if (*flag != 0u && wave != 0 && have_unit)
+            {
+                // learn the history: every position before my unit, oldest first, never replacing a newer entry
+                for (uint32_t q0 = 0; q0 < my_start; q0 += 64)
+                {
+                    const uint32_t q = q0 + (uint32_t)lane; // my_start is a multiple of 64
+                    const uint32_t hv = (lds_read32(sdata, q + head) * 2654435761u) >> (32 - HASH_LOG2);
+                    const uint32_t old = tab[hv];
+                    if (old == LZ4_EMPTY || old < q)
+                        tab[hv] = (uint16_t)q;
+                }
+            }
+            met = true;
+        }
+        if (!more)
+            break;
+        ++batches;
+
         // ---- probe 64 positions (stride grows with consecutive misses, lz4.c:1044-1053) ----
         const uint32_t stride = 1u + nfail;
         const uint32_t p = pos + (uint32_t)lane * stride;
@@ -174,14 +225,14 @@ __global__ __launch_bounds__(64) void k_lz4_segments(const uint8_t* __restrict__
         if (valid && cand != LZ4_EMPTY && cand < p)
             ok = lds_read32(sdata, cand + head) == v;
         // matches whose source lies in the same batch are invisible to the table: look 1, 2, 4, 8 lanes back
+        if (nfail == 0)
         {
-            const uint32_t vkey = valid ? v : (0x80000000u | (uint32_t)lane); // invalid lanes never compare equal... 
             uint32_t best = 0;
             bool found = false;
 #pragma unroll
             for (int d = 8; d >= 1; d >>= 1) // smallest distance wins (assigned last)
             {
-                const uint32_t ov = __shfl_up(vkey, d, 64);
+                const uint32_t ov = __shfl_up(v, d, 64);
                 const bool ovalid = __shfl_up((int)valid, d, 64) != 0;
                 if (valid && lane >= d && ovalid && ov == v)
                 {
@@ -303,78 +354,110 @@ __global__ __launch_bounds__(64) void k_lz4_segments(const uint8_t* __restrict__
         pos = np > anchor ? np : anchor;
         nfail = 0;
     }
-    if (lane == 0)
+    if (have_unit && lane == 0)
     {
         Lz4Meta m;
         m.seq_bytes = op;
-        m.tail_lits = len - anchor;
+        m.tail_lits = my_start + my_len - anchor;
         m.first_lit_len = first_lit;
         m.first_hdr_bytes = first_hdr;
-        meta[seg] = m;
+        meta[unit] = m;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // K6a: per-block serial walk over segment results
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_lz4_stitch_scan(const Lz4Block* __restrict__ blocks, uint32_t nblocks, uint32_t SEG,
-                                  const Lz4Meta* __restrict__ meta, Lz4Plan* __restrict__ plan,
-                                  Lz4BlockOut* __restrict__ bout, uint32_t* __restrict__ out_sizes)
+// One wave per block.  The walk over the units is inherently serial (a unit's placement depends on the literal
+// carry of its predecessors) but its inputs are not: 64 result records are loaded per step with one coalesced
+// load, the serial logic then runs wave-uniformly on readlane'd values, and the placement records are stored
+// coalesced again.  Trailing literals belong to a literal RUN that is closed by the next unit with a match (or by
+// the end of the block); the start of a run's literal area is only known when it closes, so units remember
+// (run index, offset inside the run) and k_lz4_stitch_copy resolves it through the run table.
+__global__ __launch_bounds__(64) void k_lz4_stitch_scan(const Lz4Block* __restrict__ blocks, uint32_t nblocks, uint32_t SEG,
+                                                        const Lz4Meta* __restrict__ meta, Lz4Plan* __restrict__ plan,
+                                                        uint32_t* __restrict__ runs, Lz4BlockOut* __restrict__ bout,
+                                                        uint32_t* __restrict__ out_sizes)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = blockIdx.x;
     if (b >= nblocks)
         return;
+    const int lane = threadIdx.x;
     const Lz4Block blk = blocks[b];
-    uint64_t out_pos = 0; // 64-bit: detect overflow of pathological inputs against dst_cap
+    const uint32_t run_base = blk.seg_base + b; // this block's slice of the run table (<= nseg + 1 runs)
+    uint64_t out_pos = 0; // 64-bit: pathological inputs are caught against dst_cap at the end
     uint32_t carry = 0;
-    uint32_t pend = 0; // first segment whose tail belongs to the open literal run
-    for (uint32_t i = 0; i < blk.nseg; ++i)
+    uint32_t run = 0;
+    for (uint32_t i0 = 0; i0 < blk.nseg; i0 += 64)
     {
-        const uint32_t s = blk.seg_base + i;
-        const Lz4Meta m = meta[s];
-        const uint32_t seg_len = blk.size - i * SEG < SEG ? blk.size - i * SEG : SEG;
+        const uint32_t i = i0 + (uint32_t)lane;
+        Lz4Meta m;
+        m.seq_bytes = m.tail_lits = m.first_lit_len = m.first_hdr_bytes = 0;
+        if (i < blk.nseg)
+            m = meta[blk.seg_base + i];
         Lz4Plan pl;
         pl.hdr_pos = 0xFFFFFFFFu;
-        pl.hdr_lits = 0;
-        pl.first_lit_dst = 0;
-        pl.body_dst = 0;
-        pl.tail_dst = 0;
-        if (m.seq_bytes)
+        pl.hdr_lits = pl.first_lit_dst = pl.body_dst = pl.tail_rel = pl.run = 0;
+        const uint32_t n = blk.nseg - i0 < 64u ? blk.nseg - i0 : 64u;
+        for (uint32_t u = 0; u < n; ++u)
         {
-            const uint32_t L = carry + m.first_lit_len;
-            const uint32_t hdr = 1u + lz4_len_bytes(L);
-            const uint64_t lit_dst = out_pos + hdr;
-            for (uint32_t j = pend; j < i; ++j)
-                plan[blk.seg_base + j].tail_dst += (uint32_t)lit_dst; // relative -> absolute
-            pl.hdr_pos = (uint32_t)out_pos;
-            pl.hdr_lits = L;
-            pl.first_lit_dst = (uint32_t)(lit_dst + carry);
-            pl.body_dst = pl.first_lit_dst + m.first_lit_len;
-            out_pos = (uint64_t)pl.body_dst + (m.seq_bytes - m.first_hdr_bytes - m.first_lit_len);
-            pl.tail_dst = 0; // relative position inside the run that starts with this segment's tail
-            carry = m.tail_lits;
-            pend = i;
+            const uint32_t seq_bytes = __builtin_amdgcn_readlane(m.seq_bytes, u);
+            uint32_t hdr_pos = 0xFFFFFFFFu, hdr_lits = 0, first_lit_dst = 0, body_dst = 0, tail_rel, my_run;
+            if (seq_bytes)
+            {
+                const uint32_t fl = __builtin_amdgcn_readlane(m.first_lit_len, u);
+                const uint32_t fh = __builtin_amdgcn_readlane(m.first_hdr_bytes, u);
+                const uint32_t L = carry + fl;
+                const uint32_t hdr = 1u + lz4_len_bytes(L);
+                const uint64_t lit_dst = out_pos + hdr;
+                if (lane == 0)
+                    runs[run_base + run] = (uint32_t)lit_dst; // closes the open run
+                hdr_pos = (uint32_t)out_pos;
+                hdr_lits = L;
+                first_lit_dst = (uint32_t)(lit_dst + carry);
+                body_dst = first_lit_dst + fl;
+                out_pos = (uint64_t)body_dst + (seq_bytes - fh - fl);
+                ++run;
+                tail_rel = 0; // this unit's tail opens the next run
+                my_run = run;
+                carry = __builtin_amdgcn_readlane(m.tail_lits, u);
+            }
+            else
+            {
+                const uint32_t iu = i0 + u;
+                const uint32_t seg_len = blk.size - iu * SEG < SEG ? blk.size - iu * SEG : SEG;
+                tail_rel = carry;
+                my_run = run;
+                carry += seg_len;
+            }
+            if ((uint32_t)lane == u)
+            {
+                pl.hdr_pos = hdr_pos;
+                pl.hdr_lits = hdr_lits;
+                pl.first_lit_dst = first_lit_dst;
+                pl.body_dst = body_dst;
+                pl.tail_rel = tail_rel;
+                pl.run = run_base + my_run;
+            }
         }
-        else
-        {
-            pl.tail_dst = carry;
-            carry += seg_len;
-        }
-        plan[s] = pl;
+        if (i < blk.nseg)
+            plan[blk.seg_base + i] = pl;
     }
     // final literal-only sequence (lz4.c:1302-1329)
     const uint32_t hdr = 1u + lz4_len_bytes(carry);
     const uint64_t lit_dst = out_pos + hdr;
-    for (uint32_t j = pend; j < blk.nseg; ++j)
-        plan[blk.seg_base + j].tail_dst += (uint32_t)lit_dst;
     const uint64_t total = lit_dst + carry;
-    Lz4BlockOut bo;
-    bo.final_hdr_pos = (uint32_t)out_pos;
-    bo.final_lits = carry;
-    bo.total = total <= (uint64_t)blk.dst_cap ? (uint32_t)total : 0u;
-    bo.pad = 0;
-    bout[b] = bo;
-    out_sizes[b] = bo.total;
+    if (lane == 0)
+    {
+        runs[run_base + run] = (uint32_t)lit_dst;
+        Lz4BlockOut bo;
+        bo.final_hdr_pos = (uint32_t)out_pos;
+        bo.final_lits = carry;
+        bo.total = total <= (uint64_t)blk.dst_cap ? (uint32_t)total : 0u;
+        bo.pad = 0;
+        bout[b] = bo;
+        out_sizes[b] = bo.total;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -429,21 +512,23 @@ __device__ __forceinline__ void wg_emit_header(uint8_t* dst, uint32_t lits, uint
 
 constexpr int K6_THREADS = 256;
 
+// one workgroup per window group: its (up to LZ4_G) units are moved into place one after the other
 __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* __restrict__ src,
                                                                  const Lz4Block* __restrict__ blocks, uint32_t nblocks,
                                                                  uint32_t SEG, const uint8_t* __restrict__ streams,
                                                                  const Lz4Meta* __restrict__ meta,
                                                                  const Lz4Plan* __restrict__ plan,
+                                                                 const uint32_t* __restrict__ runs,
                                                                  const Lz4BlockOut* __restrict__ bout,
                                                                  uint8_t* __restrict__ dst)
 {
     const int tid = threadIdx.x;
-    const uint32_t seg = blockIdx.x;
+    const uint32_t grp = blockIdx.x;
     uint32_t lo = 0, hi = nblocks;
     while (hi - lo > 1)
     {
         const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (blocks[mid].seg_base <= seg)
+        if (blocks[mid].grp_base <= grp)
             lo = mid;
         else
             hi = mid;
@@ -452,27 +537,33 @@ __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* _
     const Lz4BlockOut bo = bout[lo];
     if (bo.total == 0)
         return; // does not fit: nothing is written, size 0 reported
-    const uint32_t i = seg - blk.seg_base;
-    const uint32_t seg_start = i * SEG;
-    const uint32_t len = blk.size - seg_start < SEG ? blk.size - seg_start : SEG;
-    const Lz4Meta m = meta[seg];
-    const Lz4Plan pl = plan[seg];
-    const uint8_t* s = src + blk.src_off + seg_start;
     uint8_t* d = dst + blk.dst_off;
-    const uint8_t* stream = streams + (uint64_t)seg * lz4_stream_stride(SEG);
-
-    uint32_t tail = len;
-    if (m.seq_bytes)
+    const uint32_t i0 = (grp - blk.grp_base) * LZ4_G;
+    const uint32_t i1 = i0 + LZ4_G < blk.nseg ? i0 + LZ4_G : blk.nseg;
+    // each wave moves whole units on its own (4 units in flight per workgroup: their table loads overlap)
+    const int lane = tid & 63;
+    for (uint32_t i = i0 + (uint32_t)(tid >> 6); i < i1; i += K6_THREADS / 64)
     {
-        wg_emit_header(d + pl.hdr_pos, pl.hdr_lits, stream[0] & 15u, tid, K6_THREADS);
-        wg_copy(d + pl.first_lit_dst, s, m.first_lit_len, tid, K6_THREADS);
-        const uint32_t skip = m.first_hdr_bytes + m.first_lit_len;
-        wg_copy(d + pl.body_dst, stream + skip, m.seq_bytes - skip, tid, K6_THREADS);
-        tail = m.tail_lits;
+        const uint32_t seg = blk.seg_base + i;
+        const uint32_t seg_start = i * SEG;
+        const uint32_t len = blk.size - seg_start < SEG ? blk.size - seg_start : SEG;
+        const Lz4Meta m = meta[seg];
+        const Lz4Plan pl = plan[seg];
+        const uint8_t* s = src + blk.src_off + seg_start;
+        const uint8_t* stream = streams + (uint64_t)seg * lz4_stream_stride(SEG);
+        uint32_t tail = len;
+        if (m.seq_bytes)
+        {
+            wg_emit_header(d + pl.hdr_pos, pl.hdr_lits, stream[0] & 15u, lane, 64);
+            wg_copy(d + pl.first_lit_dst, s, m.first_lit_len, lane, 64);
+            const uint32_t skip = m.first_hdr_bytes + m.first_lit_len;
+            wg_copy(d + pl.body_dst, stream + skip, m.seq_bytes - skip, lane, 64);
+            tail = m.tail_lits;
+        }
+        wg_copy(d + runs[pl.run] + pl.tail_rel, s + (len - tail), tail, lane, 64);
+        if (i + 1 == blk.nseg)
+            wg_emit_header(d + bo.final_hdr_pos, bo.final_lits, 0u, lane, 64);
     }
-    wg_copy(d + pl.tail_dst, s + (len - tail), tail, tid, K6_THREADS);
-    if (i + 1 == blk.nseg)
-        wg_emit_header(d + bo.final_hdr_pos, bo.final_lits, 0u, tid, K6_THREADS);
 }
 
 // empty blocks have no segment: their single 0x00 token is written here
@@ -605,10 +696,10 @@ extern "C" size_t lthip_lz4_bound(size_t size) { return size > 0x7E000000u ? 0 :
 
 static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* src_offsets, const uint32_t* src_sizes,
                          const uint64_t* dst_offsets, const uint32_t* dst_caps, uint32_t seg_bytes, Lz4Block** d_blocks,
-                         uint64_t* out_nseg)
+                         uint64_t* out_nseg, uint64_t* out_ngrp = nullptr)
 {
     std::vector<Lz4Block> hb(block_count);
-    uint64_t nseg = 0;
+    uint64_t nseg = 0, ngrp = 0;
     for (uint32_t b = 0; b < block_count; ++b)
     {
         if (src_sizes[b] > 0x7E000000u)
@@ -619,6 +710,9 @@ static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* s
         hb[b].dst_cap = dst_caps[b];
         hb[b].seg_base = (uint32_t)nseg;
         hb[b].nseg = seg_bytes ? (uint32_t)(((uint64_t)src_sizes[b] + seg_bytes - 1) / seg_bytes) : 0;
+        hb[b].grp_base = (uint32_t)ngrp;
+        hb[b].ngrp = (hb[b].nseg + LZ4_G - 1) / LZ4_G;
+        ngrp += hb[b].ngrp;
         nseg += hb[b].nseg;
     }
     if (nseg > 0x7FFFFFF0ull)
@@ -631,12 +725,13 @@ static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* s
     LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // hb is a local
     *d_blocks = (Lz4Block*)p;
     *out_nseg = nseg;
+    if (out_ngrp)
+        *out_ngrp = ngrp;
     return 0;
 }
 
-// default geometry: 32704-byte segments + 32 B slack + 4096 x u16 table = 40928 B of LDS -> 4 waves per CU
-static const uint32_t LZ4_DEFAULT_SEG_BYTES = 32768u - 64u;
-
+// default geometry: 8 waves x 4 KiB units share a 32 KiB window; 32 KiB data + 8 x 4 KiB tables = 64 KiB of LDS per
+// workgroup -> 2 workgroups = 16 waves per CU
 extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                                          const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
                                          const uint32_t* dst_caps, uint32_t* d_out_sizes, int segment_log2)
@@ -645,17 +740,21 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
         return EINVAL;
     if (block_count == 0)
         return 0;
-    if (segment_log2 != 0 && (segment_log2 < 12 || segment_log2 > 16))
-        return lthip_fail(ctx, EINVAL, "lz4", "segment_log2 must be 0 (default) or 12..16");
-    const uint32_t SEG = segment_log2 ? (segment_log2 == 16 ? 65536u - 64u : 1u << segment_log2) : LZ4_DEFAULT_SEG_BYTES;
+    if (segment_log2 == 0)
+        segment_log2 = 12;
+    if (segment_log2 < 10 || segment_log2 > 13)
+        return lthip_fail(ctx, EINVAL, "lz4", "segment_log2 (unit size) must be 0 (default = 12) or 10..13");
+    const uint32_t SEG = 1u << segment_log2; // stitch unit; the match window is LZ4_G units
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     Lz4Block* d_blocks = nullptr;
-    uint64_t nseg64 = 0;
-    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, SEG, &d_blocks, &nseg64);
+    uint64_t nseg64 = 0, ngrp64 = 0;
+    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, SEG, &d_blocks, &nseg64, &ngrp64);
     if (err)
         return err;
     const uint32_t nseg = (uint32_t)nseg64;
-    void *meta, *plan, *bout, *streams;
+    void *meta, *plan, *bout, *streams, *runs;
+    if ((err = lthip_scratch(ctx, S_TABLES2, 4 * ((size_t)nseg + block_count + 1), &runs)))
+        return err;
     if ((err = lthip_scratch(ctx, S_LZ4_META, sizeof(Lz4Meta) * ((size_t)nseg + 1), &meta)))
         return err;
     if ((err = lthip_scratch(ctx, S_LZ4_SEGS, sizeof(Lz4Plan) * ((size_t)nseg + 1), &plan)))
@@ -667,23 +766,19 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
     if (nseg)
     {
         LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
-        // positions are u16: a 64 KiB segment keeps 64 bytes of head-room; small segments use a smaller table
-        if (SEG <= 8192u)
-            hipLaunchKernelGGL(k_lz4_segments<11>, dim3(nseg), dim3(64), SEG + 32 + (1u << 11) * 2, ctx->stream,
-                               (const uint8_t*)d_src, d_blocks, block_count, SEG, (uint8_t*)streams, (Lz4Meta*)meta);
-        else
-            hipLaunchKernelGGL(k_lz4_segments<12>, dim3(nseg), dim3(64), SEG + 32 + (1u << 12) * 2, ctx->stream,
-                               (const uint8_t*)d_src, d_blocks, block_count, SEG, (uint8_t*)streams, (Lz4Meta*)meta);
+        const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * (1u << 11) * 2;
+        hipLaunchKernelGGL(k_lz4_segments<11>, dim3((uint32_t)ngrp64), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src,
+                           d_blocks, block_count, SEG, (uint8_t*)streams, (Lz4Meta*)meta);
         LTHIP_LAUNCH_CHECK(ctx);
     }
     {
         LaunchTimer t(ctx, LTHIP_K_LZ4_STITCH);
-        hipLaunchKernelGGL(k_lz4_stitch_scan, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, d_blocks, block_count, SEG,
-                           (const Lz4Meta*)meta, (Lz4Plan*)plan, (Lz4BlockOut*)bout, d_out_sizes);
+        hipLaunchKernelGGL(k_lz4_stitch_scan, dim3(block_count), dim3(64), 0, ctx->stream, d_blocks, block_count, SEG,
+                           (const Lz4Meta*)meta, (Lz4Plan*)plan, (uint32_t*)runs, (Lz4BlockOut*)bout, d_out_sizes);
         if (nseg)
-            hipLaunchKernelGGL(k_lz4_stitch_copy, dim3(nseg), dim3(K6_THREADS), 0, ctx->stream, (const uint8_t*)d_src, d_blocks,
+            hipLaunchKernelGGL(k_lz4_stitch_copy, dim3((uint32_t)ngrp64), dim3(K6_THREADS), 0, ctx->stream, (const uint8_t*)d_src, d_blocks,
                                block_count, SEG, (const uint8_t*)streams, (const Lz4Meta*)meta, (const Lz4Plan*)plan,
-                               (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
+                               (const uint32_t*)runs, (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
         hipLaunchKernelGGL(k_lz4_empty_blocks, dim3((block_count + 255) / 256), dim3(256), 0, ctx->stream, d_blocks, block_count,
                            (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
         LTHIP_LAUNCH_CHECK(ctx);
