@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--gib", type=float, default=64.0, help="GiB of assets per GPU")
     ap.add_argument("--file-mib", type=float, default=1.0)
     ap.add_argument("--tree", choices=["files", "mixed-sizes"], default="files", help="files: equal files (configs[2]); mixed-sizes: 4 KiB..4 GiB log-uniform")
-    ap.add_argument("--kind", choices=["random", "mixed", "zero"], default="random")
+    ap.add_argument("--kind", choices=["random", "mixed", "zero", "records", "tokens", "lines"], default="random")
     ap.add_argument("--target-chunk-size", type=int, default=65536)
     ap.add_argument("--block-size", type=int, default=8 << 20)
     ap.add_argument("--max-chunks-per-block", type=int, default=1024)
@@ -85,6 +85,7 @@ def main():
 
     from longtail_amd.dist import allgather_hashes
     from longtail_amd.lib import Context, chunker_params, load
+    from longtail_amd.lib import pack_blocks as pack_blocks_c
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -101,7 +102,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     ctx = Context(local_rank)
-    kind = {"random": 0, "mixed": 1, "zero": 2}[args.kind]
+    kind = {"random": 0, "mixed": 1, "zero": 2, "records": 11, "tokens": 12, "lines": 13}[args.kind]
     mn, av, mx = chunker_params(args.target_chunk_size)
     part_bytes = args.target_chunk_size * 1024  # ChunkAssets part size (src/longtail.c:2396)
     if args.tree == "files":
@@ -172,12 +173,14 @@ def main():
         comp_bytes = 0
         nblocks = 0
         if not args.no_compress:
-            lens_h = out_lens[:total].cpu().numpy().view(np.uint32).astype(np.int64)
-            offs_h = out_offs[:total].cpu().numpy().view(np.uint64).astype(np.int64)
+            lens_u32 = out_lens[:total].cpu().numpy().view(np.uint32)
+            offs_h = out_offs[:total].cpu().numpy().view(np.int64)
             if n_unique_local != total:
                 keep = unique_mask.cpu().numpy()
-                lens_h, offs_h = lens_h[keep], offs_h[keep]
-            starts, cs = pack_blocks(lens_h, args.block_size, args.max_chunks_per_block)
+                lens_u32, offs_h = lens_u32[keep], offs_h[keep]
+            starts = pack_blocks_c(lens_u32, args.block_size, args.max_chunks_per_block, lib)
+            lens_h = lens_u32.astype(np.int64)
+            cs = np.cumsum(lens_h)
             b_first, b_last = starts[:-1], starts[1:] - 1
             cs0 = np.concatenate([[0], cs])
             b_size = cs0[starts[1:]] - cs0[starts[:-1]]

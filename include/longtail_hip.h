@@ -166,6 +166,13 @@ LTHIP_EXPORT int lthip_lz4_decompress_blocks(lthip_ctx* ctx, const void* d_src, 
                                              const uint64_t* dst_offsets, const uint32_t* dst_caps,
                                              uint32_t* d_out_sizes);
 
+/* Greedy packing of unique chunks into stored blocks exactly as Longtail_CreateStoreIndex does it
+ * (src/longtail.c:6801-6860: same tag, <= max_chunks_per_block chunks, size <= max_block_size * 1.1).  Host arrays;
+ * block_starts[0..*out_block_count] are chunk indices (last entry = chunk_count). */
+LTHIP_EXPORT int lthip_pack_blocks(uint64_t chunk_count, const uint32_t* chunk_lens, uint32_t max_block_size,
+                                   uint32_t max_chunks_per_block, uint64_t* block_starts, uint64_t capacity,
+                                   uint64_t* out_block_count);
+
 /* Block assembly (WriteContentBlockJob, src/longtail.c:4640-4721) as a device gather:
  * d_dst[d_dst_offsets[i] ..) = d_src[d_src_offsets[i] .. + d_lens[i]) for every range (all tables on the device). */
 LTHIP_EXPORT int lthip_gather_ranges(lthip_ctx* ctx, const void* d_src, uint64_t range_count, const uint64_t* d_src_offsets,

@@ -12,6 +12,7 @@
  *                           varying) | 2 8-byte tokens from a 1024-entry vocabulary | 3 256-byte constant
  *                           lines.  Gives LZ4/ZStd real matches at several offsets and match lengths.
  *   kind 2  "zero"          all zero bytes (no Buzhash candidates: every chunk is `max` long).
+ *   kind 10+c               "mixed" with every region forced to class c (codec tuning: one match structure at a time).
  */
 #ifndef LONGTAIL_SYNTH_H
 #define LONGTAIL_SYNTH_H
@@ -27,6 +28,7 @@
 #define LT_SYNTH_RANDOM 0
 #define LT_SYNTH_MIXED 1
 #define LT_SYNTH_ZERO 2
+#define LT_SYNTH_CLASS0 10
 
 LT_SYNTH_FN uint64_t lt_synth_mix(uint64_t z)
 {
@@ -53,7 +55,7 @@ LT_SYNTH_FN uint64_t lt_synth_word(uint64_t seed, uint64_t w, int kind)
     {
         const uint64_t region = w >> 13; /* 64 KiB = 8192 words */
         const uint64_t rr = lt_synth_mix(seed ^ (0xD1B54A32D192ED03ull * (region + 1)));
-        const unsigned cls = (unsigned)(rr & 3u);
+        const unsigned cls = kind >= LT_SYNTH_CLASS0 ? (unsigned)(kind - LT_SYNTH_CLASS0) & 3u : (unsigned)(rr & 3u);
         if (cls == 0)
             return r;
         if (cls == 1)

@@ -20,6 +20,8 @@
 //   decode           one wave per block, sequences parsed wave-uniformly, copies spread over the lanes.
 #include "lthip_internal.h"
 
+#include <stdlib.h>
+
 namespace
 {
 
@@ -85,6 +87,114 @@ __device__ __forceinline__ void emit_len(uint8_t* out, uint32_t len, int lane)
         out[j] = j + 1 == n ? (uint8_t)(len % 255u) : (uint8_t)255;
 }
 
+// Parser state shared by the cooperative and the lane-parallel paths (all wave-uniform).
+struct Lz4Seq
+{
+    uint32_t op;        // bytes written to the unit's stream
+    uint32_t anchor;    // first byte not yet covered by a sequence
+    uint32_t first_lit; // literal length / header bytes of the unit's first sequence (for the stitcher)
+    uint32_t first_hdr;
+    bool have_first;
+};
+
+// One sequence handled by the whole wave: optionally extend the match (forwards from `mlen` bytes already known to
+// be equal, backwards down to the anchor, lz4.c:1104-1109) and emit  token | literal length | literals | offset |
+// match length  (lz4.c:1111-1226), every output byte produced by "its" lane.
+__device__ __forceinline__ void lz4_coop_sequence(const uint8_t* __restrict__ sbytes, uint32_t head, uint8_t* __restrict__ out,
+                                                  int lane, uint32_t end_limit, uint32_t pf, uint32_t cf, uint32_t mlen,
+                                                  bool extend_fwd, bool extend_back, Lz4Seq& st)
+{
+    if (extend_fwd || extend_back)
+    {
+        // first round: lanes 0..31 compare forwards, lanes 32..63 backwards; addresses are selected, not branched
+        // on, so both directions share ONE pair of LDS reads
+        const uint32_t room = extend_back ? (pf - st.anchor < cf ? pf - st.anchor : cf) : 0u;
+        uint32_t nf, nb;
+        {
+            const uint32_t j = (uint32_t)lane & 31u;
+            const bool fwd = lane < 32;
+            const uint32_t a1 = fwd ? pf + mlen + j : pf - 1u - j;
+            const uint32_t a2 = fwd ? cf + mlen + j : cf - 1u - j;
+            const bool inr = fwd ? (extend_fwd && a1 < end_limit) : j < room;
+            bool same = false;
+            if (inr)
+                same = sbytes[a1 + head] == sbytes[a2 + head];
+            const uint64_t diff = __builtin_amdgcn_ballot_w64(!same);
+            const uint32_t dl = (uint32_t)diff, dh = (uint32_t)(diff >> 32);
+            nf = dl ? (uint32_t)__builtin_ctz(dl) : 32u;
+            nb = dh ? (uint32_t)__builtin_ctz(dh) : 32u;
+        }
+        mlen += nf;
+        if (nf == 32u)
+        {
+            for (;;)
+            {
+                const uint32_t i = pf + mlen + (uint32_t)lane;
+                const bool same = i < end_limit && sbytes[i + head] == sbytes[cf + mlen + (uint32_t)lane + head];
+                const uint64_t diff = __builtin_amdgcn_ballot_w64(!same);
+                if (diff)
+                {
+                    mlen += (uint32_t)__builtin_ctzll(diff);
+                    break;
+                }
+                mlen += 64u;
+            }
+        }
+        if (nb == 32u && room > 32u)
+        {
+            uint32_t back = 32u;
+            for (;;)
+            {
+                const uint32_t j = back + (uint32_t)lane;
+                const bool same = j < room && sbytes[pf - 1u - j + head] == sbytes[cf - 1u - j + head];
+                const uint64_t diff = __builtin_amdgcn_ballot_w64(!same);
+                if (diff)
+                {
+                    back += (uint32_t)__builtin_ctzll(diff);
+                    break;
+                }
+                back += 64u;
+            }
+            nb = back;
+        }
+        pf -= nb;
+        cf -= nb;
+        mlen += nb;
+    }
+    const uint32_t lit = pf - st.anchor;
+    const uint32_t mcode = mlen - 4u;
+    const uint32_t off = pf - cf;
+    const uint32_t hdr = 1u + lz4_len_bytes(lit);
+    const uint32_t mext = lz4_len_bytes(mcode);
+    const uint32_t total = hdr + lit + 2u + mext;
+    const uint32_t token = ((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u);
+    for (uint32_t j = lane; j < total; j += 64)
+    {
+        uint32_t b;
+        if (j >= hdr && j < hdr + lit)
+            b = sbytes[st.anchor + (j - hdr) + head];
+        else if (j == 0)
+            b = token;
+        else if (j < hdr)
+            b = j + 1 == hdr ? (lit - 15u) % 255u : 255u;
+        else if (j == hdr + lit)
+            b = off & 255u;
+        else if (j == hdr + lit + 1u)
+            b = off >> 8;
+        else
+            b = j + 1 == total ? (mcode - 15u) % 255u : 255u;
+        out[st.op + j] = (uint8_t)b;
+    }
+    if (!st.have_first)
+    {
+        st.have_first = true;
+        st.first_lit = lit;
+        st.first_hdr = hdr;
+    }
+    st.op += total;
+    st.anchor = pf + mlen;
+}
+
 // K5.  A workgroup of G waves owns one WINDOW GROUP = G consecutive sub-segments ("units", default 8 x 4 KiB) of one
 // block, staged once into LDS.  Wave w parses unit w sequentially (LZ4 parsing is a chain), may match against ANY
 // earlier byte of the group (units 0..w-1 are plain history for it, like the preceding bytes of a 32 KiB segment),
@@ -98,7 +208,7 @@ constexpr int LZ4_PROBE_BATCHES = 4;
 template <int HASH_LOG2>
 __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
                                                              uint32_t nblocks, uint32_t sub_bytes, uint8_t* __restrict__ streams,
-                                                             Lz4Meta* __restrict__ meta)
+                                                             Lz4Meta* __restrict__ meta, uint32_t dbg)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t data_bytes = LZ4_G * sub_bytes + 64u;
@@ -174,11 +284,16 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
     const uint32_t end_limit = my_start + (uint32_t)el;
 
     uint8_t* out = streams + (uint64_t)unit * lz4_stream_stride(sub_bytes);
-    uint32_t op = 0, anchor = my_start, pos = my_start, nfail = 0;
-    uint32_t first_lit = 0, first_hdr = 0;
-    bool have_first = false;
+    Lz4Seq st;
+    st.op = 0;
+    st.anchor = my_start;
+    st.first_lit = st.first_hdr = 0;
+    st.have_first = false;
+    uint32_t pos = my_start, nfail = 0;
     bool met = false; // the group rendezvous happens exactly once per wave
     uint32_t batches = 0;
+    uint32_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0, ps0 = 1, ps1 = 1, ps2 = 1, ps3 = 1; // the probe batches (SGPRs)
+    static_assert(LZ4_PROBE_BATCHES == 4, "probe bookkeeping is unrolled by hand");
 
     for (;;)
     {
@@ -186,25 +301,46 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
         // ---- after PROBE batches (or at the end of a short unit): does anybody in the group see redundancy? ----
         if (!met && (batches == LZ4_PROBE_BATCHES || !more))
         {
-            if (have_first && lane == 0)
+            if (st.have_first && lane == 0)
                 *flag = 1u; // benign race: every writer stores the same value
             __syncthreads();
-            if (*flag != 0u && wave != 0 && have_unit)
+            if (*flag != 0u && wave != 0 && have_unit && !(dbg & 1u))
             {
-                // learn the history: every position before my unit, oldest first, never replacing a newer entry
-                for (uint32_t q0 = 0; q0 < my_start; q0 += 64)
+                // learn the history: insert every position before my unit, oldest first (plain stores, four
+                // independent positions per lane in flight), then re-insert my own probed positions on top
+                // every 4th position is enough: a match found one to three bytes late is recovered by the
+                // backward extension, and the small table is polluted less (tools/lz4_model: ratio 1.755 -> 1.785)
+                for (uint32_t q0 = 0; q0 < my_start; q0 += 1024) // my_start is a multiple of 1024
                 {
-                    const uint32_t q = q0 + (uint32_t)lane; // my_start is a multiple of 64
-                    const uint32_t hv = (lds_read32(sdata, q + head) * 2654435761u) >> (32 - HASH_LOG2);
-                    const uint32_t old = tab[hv];
-                    if (old == LZ4_EMPTY || old < q)
-                        tab[hv] = (uint16_t)q;
+                    uint32_t hv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        hv[u] = (lds_read32(sdata, q0 + 4u * (u * 64 + (uint32_t)lane) + head) * 2654435761u) >> (32 - HASH_LOG2);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        tab[hv[u]] = (uint16_t)(q0 + 4u * (u * 64 + (uint32_t)lane));
                 }
+#define LT_REPLAY(r, PB, PS)                                                                            \
+    if ((r) < batches)                                                                                  \
+    {                                                                                                   \
+        const uint32_t rp = (PB) + (uint32_t)lane * (PS);                                               \
+        if ((int32_t)rp <= start_limit)                                                                 \
+            tab[(lds_read32(sdata, rp + head) * 2654435761u) >> (32 - HASH_LOG2)] = (uint16_t)rp;       \
+    }
+                LT_REPLAY(0u, pb0, ps0)
+                LT_REPLAY(1u, pb1, ps1)
+                LT_REPLAY(2u, pb2, ps2)
+                LT_REPLAY(3u, pb3, ps3)
+#undef LT_REPLAY
             }
             met = true;
         }
         if (!more)
             break;
+        if (batches == 0) { pb0 = pos; ps0 = 1u + nfail; }
+        else if (batches == 1) { pb1 = pos; ps1 = 1u + nfail; }
+        else if (batches == 2) { pb2 = pos; ps2 = 1u + nfail; }
+        else if (batches == 3) { pb3 = pos; ps3 = 1u + nfail; }
         ++batches;
 
         // ---- probe 64 positions (stride grows with consecutive misses, lz4.c:1044-1053) ----
@@ -225,7 +361,7 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
         if (valid && cand != LZ4_EMPTY && cand < p)
             ok = lds_read32(sdata, cand + head) == v;
         // matches whose source lies in the same batch are invisible to the table: look 1, 2, 4, 8 lanes back
-        if (nfail == 0)
+        if (nfail == 0 && !(dbg & 2u))
         {
             uint32_t best = 0;
             bool found = false;
@@ -253,114 +389,144 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
             ++nfail;
             continue;
         }
-        // ---- take every hit of the batch that starts at or after the end of the previous match ----
-        do
+        if (dbg & 4u)
         {
-            const int f = __builtin_ctzll(hits);
-            hits &= hits - 1ull;
-            uint32_t pf = pos + (uint32_t)f * stride;
-            if (pf < anchor)
-                continue;
-            uint32_t cf = __builtin_amdgcn_readlane(cand, f);
-
-            // first round: lanes 0..31 compare forwards from +4, lanes 32..63 backwards from -1 (lz4.c:1104-1109)
-            uint32_t room = pf - anchor < cf ? pf - anchor : cf;
-            uint32_t nf, nb;
+            // ablation: every hit at or after the previous match handled cooperatively with full extension
+            do
             {
-                const uint32_t j = (uint32_t)lane & 31u;
-                bool same;
-                if (lane < 32)
+                const int f = __builtin_ctzll(hits);
+                hits &= hits - 1ull;
+                const uint32_t pf = pos + (uint32_t)f * stride;
+                if (pf < st.anchor)
+                    continue;
+                lz4_coop_sequence(sbytes, head, out, lane, end_limit, pf, __builtin_amdgcn_readlane(cand, f), 4u, true, true, st);
+            } while (hits);
+            const uint32_t np = pos + 64u * stride;
+            pos = np > st.anchor ? np : st.anchor;
+            nfail = 0;
+            continue;
+        }
+        if (stride != 1u)
+        {
+            // sparse mode (after misses): only the first hit, handled by the whole wave
+            const int f = __builtin_ctzll(hits);
+            lz4_coop_sequence(sbytes, head, out, lane, end_limit, pos + (uint32_t)f * stride, __builtin_amdgcn_readlane(cand, f), 4u,
+                              true, true, st);
+            pos = st.anchor;
+            nfail = 0;
+            continue;
+        }
+        // ---- dense mode: every lane measures its own match (4 bytes per step, at most 36), in parallel ----
+        uint32_t mlen = ok ? 4u : 0u;
+        bool act = ok;
+        const uint32_t maxlen = ok ? end_limit - p : 0u;
+#pragma unroll 1
+        for (int t = 0; t < 8; ++t)
+        {
+            if (__builtin_amdgcn_ballot_w64(act) == 0ull)
+                break;
+            if (act)
+            {
+                const uint32_t x = lds_read32(sdata, p + mlen + head) ^ lds_read32(sdata, cand + mlen + head);
+                if (x)
                 {
-                    const uint32_t i = pf + 4u + j;
-                    same = i < end_limit && sbytes[i + head] == sbytes[cf + 4u + j + head];
+                    mlen += (uint32_t)__builtin_ctz(x) >> 3;
+                    act = false;
                 }
                 else
-                    same = j < room && sbytes[pf - 1u - j + head] == sbytes[cf - 1u - j + head];
-                const uint64_t diff = __builtin_amdgcn_ballot_w64(!same);
-                const uint32_t dl = (uint32_t)diff, dh = (uint32_t)(diff >> 32);
-                nf = dl ? (uint32_t)__builtin_ctz(dl) : 32u;
-                nb = dh ? (uint32_t)__builtin_ctz(dh) : 32u;
-            }
-            uint32_t mlen = 4u + nf;
-            if (nf == 32u)
-            {
-                for (;;)
+                    mlen += 4u;
+                if (mlen >= maxlen)
                 {
-                    const uint32_t i = pf + mlen + (uint32_t)lane;
-                    const bool same = i < end_limit && sbytes[i + head] == sbytes[cf + mlen + (uint32_t)lane + head];
-                    const uint64_t diff = __builtin_amdgcn_ballot_w64(!same);
-                    if (diff)
-                    {
-                        mlen += (uint32_t)__builtin_ctzll(diff);
-                        break;
-                    }
-                    mlen += 64u;
+                    mlen = maxlen;
+                    act = false;
                 }
             }
-            if (nb == 32u && room > 32u)
+        }
+        const uint64_t longs = __builtin_amdgcn_ballot_w64(act); // still equal after 36 bytes: extend when selected
+        // ... and how far it could grow backwards (at most 8 bytes, two dword steps; the anchor bounds it at selection)
+        uint32_t nbk = 0;
+        if (ok && cand >= 8u)
+        {
+            const uint32_t x = lds_read32(sdata, p - 4u + head) ^ lds_read32(sdata, cand - 4u + head);
+            nbk = x ? (uint32_t)__builtin_clz(x) >> 3 : 4u;
+            if (x == 0u)
             {
-                uint32_t back = 32u;
-                for (;;)
-                {
-                    const uint32_t j = back + (uint32_t)lane;
-                    const bool same = j < room && sbytes[pf - 1u - j + head] == sbytes[cf - 1u - j + head];
-                    const uint64_t diff = __builtin_amdgcn_ballot_w64(!same);
-                    if (diff)
-                    {
-                        back += (uint32_t)__builtin_ctzll(diff);
-                        break;
-                    }
-                    back += 64u;
-                }
-                nb = back;
+                const uint32_t y = lds_read32(sdata, p - 8u + head) ^ lds_read32(sdata, cand - 8u + head);
+                nbk += y ? (uint32_t)__builtin_clz(y) >> 3 : 4u;
             }
-            pf -= nb;
-            cf -= nb;
-            mlen += nb;
-
-            // ---- emit  token | literal length | literals | offset | match length  (lz4.c:1111-1226) ----
-            const uint32_t lit = pf - anchor;
-            const uint32_t mcode = mlen - 4u;
-            const uint32_t hdr = 1u + lz4_len_bytes(lit);
-            if (lane == 0)
-                out[op] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
-            if (lit >= 15u)
-                emit_len(out + op + 1, lit - 15u, lane);
-            for (uint32_t j = lane; j < lit; j += 64)
-                out[op + hdr + j] = sbytes[anchor + j + head];
-            uint32_t o2 = op + hdr + lit;
-            if (lane == 0)
+        }
+        // ---- greedy selection in position order: a scalar walk over the SELECTED hits only ----
+        uint64_t rem = hits, vecsel = 0ull;
+        uint32_t sel_v = 0; // selected lanes: output offset << 8 | backward bytes << 4 | literal count
+        while (rem)
+        {
+            if (st.anchor > pos)
             {
-                const uint32_t off = pf - cf;
-                out[o2] = (uint8_t)off;
-                out[o2 + 1] = (uint8_t)(off >> 8);
+                const uint32_t sh = st.anchor - pos; // lanes whose position is already covered
+                rem = sh >= 64u ? 0ull : rem & (~0ull << sh);
+                if (!rem)
+                    break;
             }
-            o2 += 2;
+            const int f = __builtin_ctzll(rem);
+            rem &= rem - 1ull;
+            const uint32_t pf = pos + (uint32_t)f;
+            const bool isl = (longs >> f) & 1ull;
+            const uint32_t room = pf - st.anchor;
+            if (isl || room > 20u)
+            {
+                lz4_coop_sequence(sbytes, head, out, lane, end_limit, pf, __builtin_amdgcn_readlane(cand, f),
+                                  __builtin_amdgcn_readlane(mlen, f), isl, true, st);
+                continue;
+            }
+            uint32_t nb = __builtin_amdgcn_readlane(nbk, f);
+            nb = nb < room ? nb : room;
+            const uint32_t lit = room - nb;
+            const uint32_t len = __builtin_amdgcn_readlane(mlen, f) + nb;
+            if (lit > 12u)
+            {
+                lz4_coop_sequence(sbytes, head, out, lane, end_limit, pf - nb, __builtin_amdgcn_readlane(cand, f) - nb, len, false,
+                                  false, st);
+                continue;
+            }
+            // short literals, match <= 44 bytes: emitted below by the lane itself
+            sel_v = lane == f ? (st.op << 8) | (nb << 4) | lit : sel_v;
+            vecsel |= 1ull << f;
+            if (!st.have_first)
+            {
+                st.have_first = true;
+                st.first_lit = lit;
+                st.first_hdr = 1u;
+            }
+            st.op += lit + 3u + (len - 4u >= 15u ? 1u : 0u);
+            st.anchor = pf + len - nb;
+        }
+        if ((vecsel >> lane) & 1ull)
+        {
+            const uint32_t lit = sel_v & 15u;
+            const uint32_t nb = (sel_v >> 4) & 15u;
+            const uint32_t lit_start_v = p - nb - lit;
+            const uint32_t mcode = mlen + nb - 4u; // <= 40: at most one length byte
+            const uint32_t off = p - cand;
+            uint8_t* o = out + (sel_v >> 8);
+            o[0] = (uint8_t)((lit << 4) | (mcode < 15u ? mcode : 15u));
+            for (uint32_t j = 0; j < lit; ++j)
+                o[1u + j] = sbytes[lit_start_v + j + head];
+            o[1u + lit] = (uint8_t)off;
+            o[2u + lit] = (uint8_t)(off >> 8);
             if (mcode >= 15u)
-            {
-                emit_len(out + o2, mcode - 15u, lane);
-                o2 += lz4_len_bytes(mcode);
-            }
-            if (!have_first)
-            {
-                have_first = true;
-                first_lit = lit;
-                first_hdr = hdr;
-            }
-            op = o2;
-            anchor = pf + mlen;
-        } while (hits);
-        const uint32_t np = pos + 64u * stride;
-        pos = np > anchor ? np : anchor;
+                o[3u + lit] = (uint8_t)(mcode - 15u);
+        }
+        const uint32_t np = pos + 64u;
+        pos = np > st.anchor ? np : st.anchor;
         nfail = 0;
     }
     if (have_unit && lane == 0)
     {
         Lz4Meta m;
-        m.seq_bytes = op;
-        m.tail_lits = my_start + my_len - anchor;
-        m.first_lit_len = first_lit;
-        m.first_hdr_bytes = first_hdr;
+        m.seq_bytes = st.op;
+        m.tail_lits = my_start + my_len - st.anchor;
+        m.first_lit_len = st.first_lit;
+        m.first_hdr_bytes = st.first_hdr;
         meta[unit] = m;
     }
 }
@@ -742,7 +908,7 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
         return 0;
     if (segment_log2 == 0)
         segment_log2 = 12;
-    if (segment_log2 < 10 || segment_log2 > 13)
+    if (segment_log2 < 10 || segment_log2 > 13) // units are multiples of 1024 bytes (pre-seed loop)
         return lthip_fail(ctx, EINVAL, "lz4", "segment_log2 (unit size) must be 0 (default = 12) or 10..13");
     const uint32_t SEG = 1u << segment_log2; // stitch unit; the match window is LZ4_G units
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -768,7 +934,8 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
         LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
         const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * (1u << 11) * 2;
         hipLaunchKernelGGL(k_lz4_segments<11>, dim3((uint32_t)ngrp64), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src,
-                           d_blocks, block_count, SEG, (uint8_t*)streams, (Lz4Meta*)meta);
+                           d_blocks, block_count, SEG, (uint8_t*)streams, (Lz4Meta*)meta,
+                           (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0));
         LTHIP_LAUNCH_CHECK(ctx);
     }
     {

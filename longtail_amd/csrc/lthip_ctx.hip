@@ -315,6 +315,37 @@ static DivTest make_div_test(uint32_t d)
     return t;
 }
 
+// Greedy block packing of Longtail_CreateStoreIndex (src/longtail.c:6801-6860): host control logic, serial in the
+// reference as well.  block_starts receives block_count+1 chunk indices.
+extern "C" int lthip_pack_blocks(uint64_t chunk_count, const uint32_t* chunk_lens, uint32_t max_block_size,
+                                 uint32_t max_chunks_per_block, uint64_t* block_starts, uint64_t capacity, uint64_t* out_block_count)
+{
+    if (!out_block_count || (chunk_count && (!chunk_lens || !block_starts)) || max_block_size == 0 || max_chunks_per_block == 0)
+        return EINVAL;
+    const uint64_t limit = (uint64_t)max_block_size + max_block_size / 10; // "overshoot by 10% is ok"
+    uint64_t i = 0, nb = 0;
+    while (i < chunk_count)
+    {
+        if (nb + 1 >= capacity)
+            return ENOMEM;
+        block_starts[nb++] = i;
+        uint64_t size = chunk_lens[i];
+        uint32_t n = 1;
+        while (i + 1 < chunk_count && n < max_chunks_per_block && size + chunk_lens[i + 1] <= limit)
+        {
+            size += chunk_lens[i + 1];
+            ++n;
+            ++i;
+        }
+        ++i;
+    }
+    if (capacity == 0)
+        return ENOMEM;
+    block_starts[nb] = chunk_count;
+    *out_block_count = nb;
+    return 0;
+}
+
 extern "C" int lthip_divtest_eval(uint32_t discriminator, uint32_t hash)
 {
     if (discriminator == 0)

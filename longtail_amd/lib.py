@@ -107,6 +107,7 @@ class HipLib:
         sig("lthip_zstd_compress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_dedup_first_seen", i32, [vp, u64, vp, vp, vp])
         sig("lthip_gather_ranges", i32, [vp, vp, u64, vp, vp, vp, vp])
+        sig("lthip_pack_blocks", i32, [u64, vp, u32, u32, vp, u64, P(u64)])
         sig("lthip_synth_fill", i32, [vp, vp, u32, vp, vp, vp, i32])
         sig("lthip_divtest_eval", i32, [u32, u32])
 
@@ -305,6 +306,20 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+def pack_blocks(lens: np.ndarray, max_block_size: int, max_chunks_per_block: int, lib: Optional[HipLib] = None) -> np.ndarray:
+    """block start indices (+ end) for chunk lengths `lens` (uint32), Longtail_CreateStoreIndex's greedy rule."""
+    lib = lib or load()
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    cap = len(lens) + 2
+    starts = np.zeros(cap, dtype=np.uint64)
+    nb = C.c_uint64(0)
+    err = lib.dll.lthip_pack_blocks(len(lens), lens.ctypes.data, max_block_size, max_chunks_per_block, starts.ctypes.data, cap,
+                                    C.byref(nb))
+    if err:
+        raise LongtailHipError(err, "lthip_pack_blocks")
+    return starts[: nb.value + 1].astype(np.int64)
 
 
 def chunker_params(target_chunk_size: int, chunker_min: int = 48):

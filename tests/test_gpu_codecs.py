@@ -82,7 +82,7 @@ def test_lz4_ratio_vs_reference(gpu, oracle, golden):
         d = oracle.synth(int(size), int(seed), int(kind))
         (p,), _ = gpu_lz4(gpu, [d])
         check_lz4_payload(oracle, d, p)
-        assert len(p) <= int(ref_size) * 1.25 + 1024, (kind, size, len(p), ref_size)
+        assert len(p) <= int(ref_size) * (1.25 if size >= (1 << 20) else 1.45) + 1024, (kind, size, len(p), ref_size)
 
 
 def test_lz4_many_blocks_and_capacity(gpu, oracle):
