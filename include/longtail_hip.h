@@ -103,7 +103,8 @@ enum lthip_kernel_id
     LTHIP_K_LZ4_SEG = 5,  /* LZ4 segment encoder                (lz4.c:930-1338) */
     LTHIP_K_LZ4_STITCH = 6,/* LZ4 stitch scan + compaction copy */
     LTHIP_K_OTHER = 7,
-    LTHIP_K_COUNT = 8
+    LTHIP_K_ZSTD_ENC = 8, /* zstd entropy stage (Huffman literals, FSE sequences), one wave per 128 KiB piece */
+    LTHIP_K_COUNT = 9
 };
 LTHIP_EXPORT int lthip_timing_enable(lthip_ctx* ctx, int on);
 LTHIP_EXPORT int lthip_timing_reset(lthip_ctx* ctx);
@@ -178,11 +179,19 @@ LTHIP_EXPORT int lthip_pack_blocks(uint64_t chunk_count, const uint32_t* chunk_l
 LTHIP_EXPORT int lthip_gather_ranges(lthip_ctx* ctx, const void* d_src, uint64_t range_count, const uint64_t* d_src_offsets,
                                      const uint32_t* d_lens, void* d_dst, const uint64_t* d_dst_offsets);
 
+/* ZStd (ZStdCompressionAPI_Compress, lib/zstd/longtail_zstd.c:105-142): one zstd frame per block, 128 KiB pieces
+ * stored as RLE / Compressed (LZ sequences + Huffman literals + FSE) / Raw blocks; decodable by the reference's
+ * ZSTD_decompressDCtx.  Same calling convention as lthip_lz4_compress_blocks. */
 LTHIP_EXPORT size_t lthip_zstd_bound(size_t size); /* ZSTD_COMPRESSBOUND, lib/zstd/ext/zstd.h:232 */
 LTHIP_EXPORT int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count,
                                             const uint64_t* src_offsets, const uint32_t* src_sizes, void* d_dst,
                                             const uint64_t* dst_offsets, const uint32_t* dst_caps,
                                             uint32_t* d_out_sizes);
+/* Diagnostics (parity tests): match-finder output of the last lthip_zstd_compress_blocks call on this context for the
+ * 4 KiB units [first, first + count) -- 16 bytes of meta {nseq, nlit, tail, 0}, 4096 literal bytes and 1024 u64
+ * records {lit | mlen << 16 | offset << 32} per unit (host buffers, any may be NULL). */
+LTHIP_EXPORT int lthip_zstd_debug_units(lthip_ctx* ctx, uint64_t first, uint64_t count, void* h_meta, void* h_lits,
+                                        void* h_recs);
 
 /* ---- dedup (serial first-seen pass of Longtail_CreateVersionIndex, src/longtail.c:2951-2970) --------
  * d_first_index[i] = smallest j with d_hashes[j] == d_hashes[i]; *d_unique_count = number of i with

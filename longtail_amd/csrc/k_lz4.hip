@@ -94,15 +94,19 @@ struct Lz4Seq
     uint32_t anchor;    // first byte not yet covered by a sequence
     uint32_t first_lit; // literal length / header bytes of the unit's first sequence (for the stitcher)
     uint32_t first_hdr;
+    uint32_t nseq; // FMT 1: sequences emitted so far
     bool have_first;
 };
 
 // One sequence handled by the whole wave: optionally extend the match (forwards from `mlen` bytes already known to
 // be equal, backwards down to the anchor, lz4.c:1104-1109) and emit  token | literal length | literals | offset |
 // match length  (lz4.c:1111-1226), every output byte produced by "its" lane.
+// FMT 0 writes the LZ4 byte stream; FMT 1 (zstd front end) appends the literals to `out` and one
+// {literals, match length, offset} record to `recs` (zstd_block_core.h ZB_REC).
+template <int FMT>
 __device__ __forceinline__ void lz4_coop_sequence(const uint8_t* __restrict__ sbytes, uint32_t head, uint8_t* __restrict__ out,
-                                                  int lane, uint32_t end_limit, uint32_t pf, uint32_t cf, uint32_t mlen,
-                                                  bool extend_fwd, bool extend_back, Lz4Seq& st)
+                                                  uint64_t* __restrict__ recs, int lane, uint32_t end_limit, uint32_t pf, uint32_t cf,
+                                                  uint32_t mlen, bool extend_fwd, bool extend_back, Lz4Seq& st)
 {
     if (extend_fwd || extend_back)
     {
@@ -164,6 +168,18 @@ __device__ __forceinline__ void lz4_coop_sequence(const uint8_t* __restrict__ sb
     const uint32_t lit = pf - st.anchor;
     const uint32_t mcode = mlen - 4u;
     const uint32_t off = pf - cf;
+    if constexpr (FMT == 1)
+    {
+        for (uint32_t j = lane; j < lit; j += 64)
+            out[st.op + j] = sbytes[st.anchor + j + head];
+        if (lane == 0)
+            recs[st.nseq] = (uint64_t)lit | ((uint64_t)mlen << 16) | ((uint64_t)off << 32);
+        st.have_first = true;
+        st.nseq += 1u;
+        st.op += lit;
+        st.anchor = pf + mlen;
+        return;
+    }
     const uint32_t hdr = 1u + lz4_len_bytes(lit);
     const uint32_t mext = lz4_len_bytes(mcode);
     const uint32_t total = hdr + lit + 2u + mext;
@@ -205,10 +221,10 @@ __device__ __forceinline__ void lz4_coop_sequence(const uint8_t* __restrict__ sb
 constexpr int LZ4_G = 8;
 constexpr int LZ4_PROBE_BATCHES = 4;
 
-template <int HASH_LOG2>
+template <int HASH_LOG2, int FMT>
 __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
                                                              uint32_t nblocks, uint32_t sub_bytes, uint8_t* __restrict__ streams,
-                                                             Lz4Meta* __restrict__ meta, uint32_t dbg)
+                                                             Lz4Meta* __restrict__ meta, uint64_t* __restrict__ zrecs, uint32_t dbg)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t data_bytes = LZ4_G * sub_bytes + 64u;
@@ -283,9 +299,11 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
     const int64_t el = (int64_t)my_len < blk_left - 5 ? (int64_t)my_len : (blk_left - 5 > 0 ? blk_left - 5 : 0);
     const uint32_t end_limit = my_start + (uint32_t)el;
 
-    uint8_t* out = streams + (uint64_t)unit * lz4_stream_stride(sub_bytes);
+    uint8_t* out = streams + (uint64_t)unit * (FMT == 1 ? sub_bytes : lz4_stream_stride(sub_bytes));
+    uint64_t* recs = FMT == 1 ? zrecs + (uint64_t)unit * (sub_bytes >> 2) : nullptr;
     Lz4Seq st;
     st.op = 0;
+    st.nseq = 0;
     st.anchor = my_start;
     st.first_lit = st.first_hdr = 0;
     st.have_first = false;
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
                 const uint32_t pf = pos + (uint32_t)f * stride;
                 if (pf < st.anchor)
                     continue;
-                lz4_coop_sequence(sbytes, head, out, lane, end_limit, pf, __builtin_amdgcn_readlane(cand, f), 4u, true, true, st);
+                lz4_coop_sequence<FMT>(sbytes, head, out, recs, lane, end_limit, pf, __builtin_amdgcn_readlane(cand, f), 4u, true, true, st);
             } while (hits);
             const uint32_t np = pos + 64u * stride;
             pos = np > st.anchor ? np : st.anchor;
@@ -410,7 +428,7 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
         {
             // sparse mode (after misses): only the first hit, handled by the whole wave
             const int f = __builtin_ctzll(hits);
-            lz4_coop_sequence(sbytes, head, out, lane, end_limit, pos + (uint32_t)f * stride, __builtin_amdgcn_readlane(cand, f), 4u,
+            lz4_coop_sequence<FMT>(sbytes, head, out, recs, lane, end_limit, pos + (uint32_t)f * stride, __builtin_amdgcn_readlane(cand, f), 4u,
                               true, true, st);
             pos = st.anchor;
             nfail = 0;
@@ -474,7 +492,7 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
             const uint32_t room = pf - st.anchor;
             if (isl || room > 20u)
             {
-                lz4_coop_sequence(sbytes, head, out, lane, end_limit, pf, __builtin_amdgcn_readlane(cand, f),
+                lz4_coop_sequence<FMT>(sbytes, head, out, recs, lane, end_limit, pf, __builtin_amdgcn_readlane(cand, f),
                                   __builtin_amdgcn_readlane(mlen, f), isl, true, st);
                 continue;
             }
@@ -484,12 +502,12 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
             const uint32_t len = __builtin_amdgcn_readlane(mlen, f) + nb;
             if (lit > 12u)
             {
-                lz4_coop_sequence(sbytes, head, out, lane, end_limit, pf - nb, __builtin_amdgcn_readlane(cand, f) - nb, len, false,
+                lz4_coop_sequence<FMT>(sbytes, head, out, recs, lane, end_limit, pf - nb, __builtin_amdgcn_readlane(cand, f) - nb, len, false,
                                   false, st);
                 continue;
             }
             // short literals, match <= 44 bytes: emitted below by the lane itself
-            sel_v = lane == f ? (st.op << 8) | (nb << 4) | lit : sel_v;
+            sel_v = lane == f ? (FMT == 1 ? st.nseq << 20 : 0u) | (st.op << 8) | (nb << 4) | lit : sel_v;
             vecsel |= 1ull << f;
             if (!st.have_first)
             {
@@ -497,7 +515,13 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
                 st.first_lit = lit;
                 st.first_hdr = 1u;
             }
-            st.op += lit + 3u + (len - 4u >= 15u ? 1u : 0u);
+            if constexpr (FMT == 1)
+            {
+                st.op += lit;
+                st.nseq += 1u;
+            }
+            else
+                st.op += lit + 3u + (len - 4u >= 15u ? 1u : 0u);
             st.anchor = pf + len - nb;
         }
         if ((vecsel >> lane) & 1ull)
@@ -505,20 +529,40 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
             const uint32_t lit = sel_v & 15u;
             const uint32_t nb = (sel_v >> 4) & 15u;
             const uint32_t lit_start_v = p - nb - lit;
-            const uint32_t mcode = mlen + nb - 4u; // <= 40: at most one length byte
             const uint32_t off = p - cand;
-            uint8_t* o = out + (sel_v >> 8);
-            o[0] = (uint8_t)((lit << 4) | (mcode < 15u ? mcode : 15u));
-            for (uint32_t j = 0; j < lit; ++j)
-                o[1u + j] = sbytes[lit_start_v + j + head];
-            o[1u + lit] = (uint8_t)off;
-            o[2u + lit] = (uint8_t)(off >> 8);
-            if (mcode >= 15u)
-                o[3u + lit] = (uint8_t)(mcode - 15u);
+            if constexpr (FMT == 1)
+            {
+                uint8_t* o = out + ((sel_v >> 8) & 0xFFFu);
+                for (uint32_t j = 0; j < lit; ++j)
+                    o[j] = sbytes[lit_start_v + j + head];
+                recs[sel_v >> 20] = (uint64_t)lit | ((uint64_t)(mlen + nb) << 16) | ((uint64_t)off << 32);
+            }
+            else
+            {
+                const uint32_t mcode = mlen + nb - 4u; // <= 40: at most one length byte
+                uint8_t* o = out + (sel_v >> 8);
+                o[0] = (uint8_t)((lit << 4) | (mcode < 15u ? mcode : 15u));
+                for (uint32_t j = 0; j < lit; ++j)
+                    o[1u + j] = sbytes[lit_start_v + j + head];
+                o[1u + lit] = (uint8_t)off;
+                o[2u + lit] = (uint8_t)(off >> 8);
+                if (mcode >= 15u)
+                    o[3u + lit] = (uint8_t)(mcode - 15u);
+            }
         }
         const uint32_t np = pos + 64u;
         pos = np > st.anchor ? np : st.anchor;
         nfail = 0;
+    }
+    if constexpr (FMT == 1)
+    {
+        // the unit's trailing literals complete its literal buffer; meta = ZbUnitMeta {nseq, nlit, tail, 0}
+        const uint32_t tail = have_unit ? my_start + my_len - st.anchor : 0u;
+        for (uint32_t j = lane; j < tail; j += 64)
+            out[st.op + j] = sbytes[st.anchor + j + head];
+        if (have_unit && lane == 0)
+            reinterpret_cast<uint4*>(meta)[unit] = make_uint4(st.nseq, st.op + tail, tail, 0u);
+        return;
     }
     if (have_unit && lane == 0)
     {
@@ -933,8 +977,8 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
     {
         LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
         const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * (1u << 11) * 2;
-        hipLaunchKernelGGL(k_lz4_segments<11>, dim3((uint32_t)ngrp64), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src,
-                           d_blocks, block_count, SEG, (uint8_t*)streams, (Lz4Meta*)meta,
+        hipLaunchKernelGGL((k_lz4_segments<11, 0>), dim3((uint32_t)ngrp64), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src,
+                           d_blocks, block_count, SEG, (uint8_t*)streams, (Lz4Meta*)meta, (uint64_t*)nullptr,
                            (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0));
         LTHIP_LAUNCH_CHECK(ctx);
     }
@@ -950,6 +994,47 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
                            (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
         LTHIP_LAUNCH_CHECK(ctx);
     }
+    return 0;
+}
+
+int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
+                              const uint32_t* src_sizes, uint8_t** d_lits, uint64_t** d_recs, void** d_meta,
+                              uint32_t* unit_base, uint64_t* total_units)
+{
+    const uint32_t SEG = 4096u; // ZB_UNIT
+    std::vector<uint64_t> zero64(block_count, 0);
+    std::vector<uint32_t> zero32(block_count, 0);
+    Lz4Block* d_blocks = nullptr;
+    uint64_t nseg64 = 0, ngrp64 = 0;
+    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, zero64.data(), zero32.data(), SEG, &d_blocks, &nseg64, &ngrp64);
+    if (err)
+        return err;
+    uint64_t nseg = 0;
+    for (uint32_t b = 0; b < block_count; ++b)
+    {
+        unit_base[b] = (uint32_t)nseg;
+        nseg += ((uint64_t)src_sizes[b] + SEG - 1) / SEG;
+    }
+    *total_units = nseg;
+    void *lits, *recs, *meta;
+    if ((err = lthip_scratch(ctx, S_Z_LITS, (size_t)SEG * (nseg + 1), &lits)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_Z_RECS, (size_t)SEG * 2 * (nseg + 1), &recs)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_LZ4_META, sizeof(Lz4Meta) * ((size_t)nseg + 1), &meta)))
+        return err;
+    if (nseg)
+    {
+        LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
+        const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * (1u << 11) * 2;
+        hipLaunchKernelGGL((k_lz4_segments<11, 1>), dim3((uint32_t)ngrp64), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src,
+                           d_blocks, block_count, SEG, (uint8_t*)lits, (Lz4Meta*)meta, (uint64_t*)recs,
+                           (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0));
+        LTHIP_LAUNCH_CHECK(ctx);
+    }
+    *d_lits = (uint8_t*)lits;
+    *d_recs = (uint64_t*)recs;
+    *d_meta = meta;
     return 0;
 }
 

@@ -1,12 +1,21 @@
-// k_zstd.hip -- ZStd CompressionAPI, encoder stage 1: every stored block becomes
-// ONE zstd frame made of Raw_Block / RLE_Block blocks (<= 128 KiB each), which the reference's
-// ZSTD_decompressDCtx (lib/zstd/longtail_zstd.c:144-177, ext/decompress/zstd_decompress.c) accepts like any
-// other frame.  This pins the container format, the block splitting and the output compaction on the GPU; the
-// entropy stages (Huffman literals, FSE sequences) are later rounds and will replace Raw blocks in place.
-//
-// Frame layout written here (RFC 8878 §3.1.1): magic 0xFD2FB528 | FHD 0xE0 (single segment, 8-byte content
-// size, no checksum, no dictionary) | u64 content size | blocks, each: 3-byte header {last:1, type:2, size:21}.
+// k_zstd.hip -- ZStd CompressionAPI, GPU encoder.  Every stored block becomes ONE zstd frame
+// (RFC 8878 §3.1.1: magic 0xFD2FB528 | FHD 0xE0 = single segment, 8-byte content size, no checksum, no dictionary |
+// u64 content size | blocks, each with a 3-byte header {last:1, type:2, size:21}) whose 128 KiB pieces are
+//   RLE_Block         all bytes equal                                   (k_zstd_classify)
+//   Compressed_Block  LZ sequences from the LZ4 match finder run with sequence output (k_lz4.hip, FMT 1), literals
+//                     Huffman-coded in 4 streams, the three symbol streams FSE-coded (predefined / RLE / described
+//                     tables) -- zstd_block_core.h, one wavefront per piece (k_zstd_encode)
+//   Raw_Block         whenever that would not be smaller.
+// The reference's ZSTD_decompressDCtx (lib/zstd/longtail_zstd.c:144-177) decodes these like any other frame; the
+// settings ('ztd1'..'ztd5', longtail_zstd.c:12-22) select nothing here: there is one parse.
 #include "lthip_internal.h"
+
+#define ZB_LANES 64u
+#define ZB_FN __device__
+#define ZB_SYNC() __syncthreads() /* the encoder runs in one-wave workgroups */
+__device__ __forceinline__ void zb_atomic_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
+__device__ __forceinline__ void zb_atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+#include "zstd_block_core.h"
 
 namespace
 {
@@ -19,9 +28,13 @@ struct ZBlock
     uint32_t dst_cap;
     uint32_t zb_base; // first 128 KiB piece of this stored block
     uint32_t nzb;
+    uint32_t unit_base; // first 4 KiB match-finder unit of this stored block
+    uint32_t pad;
 };
 
-constexpr uint32_t ZB = 128u * 1024u;
+constexpr uint32_t ZB = ZB_BLOCK_MAX;
+constexpr size_t Z_WORK_LITS = ZB_BLOCK_MAX + 64, Z_WORK_SEQS = sizeof(uint64_t) * ZB_SEQ_MAX, Z_WORK_SBITS = sizeof(uint16_t) * 3 * ZB_SEQ_MAX;
+constexpr size_t Z_WORK_STRIDE = Z_WORK_LITS + Z_WORK_SEQS + Z_WORK_SBITS;
 constexpr uint32_t ZHDR = 13u;
 constexpr int ZT = 256;
 
@@ -62,7 +75,8 @@ __global__ __launch_bounds__(ZT) void k_zstd_classify(const uint8_t* __restrict_
 
 // serial per stored block: destination offset of every piece, total size
 __global__ void k_zstd_scan(const ZBlock* __restrict__ blocks, uint32_t nblocks, const uint8_t* __restrict__ is_rle,
-                            uint32_t* __restrict__ zb_dst, uint32_t* __restrict__ out_sizes)
+                            const uint32_t* __restrict__ enc_size, uint32_t* __restrict__ zb_dst,
+                            uint32_t* __restrict__ out_sizes)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks)
@@ -75,7 +89,8 @@ __global__ void k_zstd_scan(const ZBlock* __restrict__ blocks, uint32_t nblocks,
     {
         const uint32_t len = blk.size - i * ZB < ZB ? blk.size - i * ZB : ZB;
         zb_dst[blk.zb_base + i] = (uint32_t)pos;
-        pos += 3u + (is_rle[blk.zb_base + i] ? 1u : len);
+        const uint32_t enc = enc_size[blk.zb_base + i];
+        pos += 3u + (is_rle[blk.zb_base + i] ? 1u : enc ? enc : len);
     }
     out_sizes[b] = pos <= (uint64_t)blk.dst_cap ? (uint32_t)pos : 0u;
 }
@@ -113,6 +128,7 @@ __device__ __forceinline__ void wg_copy16(uint8_t* __restrict__ dst, const uint8
 
 __global__ __launch_bounds__(ZT) void k_zstd_emit(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks,
                                                   uint32_t nblocks, const uint8_t* __restrict__ is_rle,
+                                                  const uint32_t* __restrict__ enc_size, const uint8_t* __restrict__ enc,
                                                   const uint32_t* __restrict__ zb_dst, const uint32_t* __restrict__ out_sizes,
                                                   uint8_t* __restrict__ dst)
 {
@@ -135,17 +151,68 @@ __global__ __launch_bounds__(ZT) void k_zstd_emit(const uint8_t* __restrict__ sr
     const uint8_t* p = src + b.src_off + start;
     uint8_t* d = dst + b.dst_off + zb_dst[zb];
     const uint32_t rle = is_rle[zb];
+    const uint32_t csize = rle ? 0u : enc_size[zb];
     if (threadIdx.x == 0)
     {
-        const uint32_t h = (i + 1 == b.nzb ? 1u : 0u) | (rle << 1) | (len << 3);
+        const uint32_t h = (i + 1 == b.nzb ? 1u : 0u) | ((csize ? 2u : rle) << 1) | ((csize ? csize : len) << 3);
         d[0] = (uint8_t)h;
         d[1] = (uint8_t)(h >> 8);
         d[2] = (uint8_t)(h >> 16);
         if (rle)
             d[3] = p[0];
     }
-    if (!rle)
+    if (csize)
+        wg_copy16(d + 3, enc + (uint64_t)zb * ZB_OUT_BYTES, csize, threadIdx.x);
+    else if (!rle)
         wg_copy16(d + 3, p, len, threadIdx.x);
+}
+
+// One wavefront per 128 KiB piece, persistent over the pieces: the entropy stage of zstd_block_core.h.
+__global__ __launch_bounds__(64) void k_zstd_encode(const ZBlock* __restrict__ blocks, uint32_t nblocks, uint32_t npieces,
+                                                    const uint8_t* __restrict__ is_rle, const ZbUnitMeta* __restrict__ unit_meta,
+                                                    const uint8_t* __restrict__ unit_lits, const uint64_t* __restrict__ unit_recs,
+                                                    uint8_t* __restrict__ work, uint8_t* __restrict__ enc,
+                                                    uint32_t* __restrict__ enc_size)
+{
+    __shared__ ZbShared sh;
+    ZbScratch sc;
+    uint8_t* w = work + (uint64_t)blockIdx.x * Z_WORK_STRIDE;
+    sc.lits = w;
+    sc.seqs = reinterpret_cast<uint64_t*>(w + Z_WORK_LITS);
+    sc.sbits = reinterpret_cast<uint16_t*>(w + Z_WORK_LITS + Z_WORK_SEQS);
+    for (uint32_t zb = blockIdx.x; zb < npieces; zb += gridDim.x)
+    {
+        if (is_rle[zb])
+        {
+            if (threadIdx.x == 0)
+                enc_size[zb] = 0;
+            continue;
+        }
+        uint32_t lo = 0, hi = nblocks;
+        while (hi - lo > 1)
+        {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (blocks[mid].zb_base <= zb)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const ZBlock b = blocks[lo];
+        const uint32_t i = zb - b.zb_base;
+        const uint32_t len = b.size - i * ZB < ZB ? b.size - i * ZB : ZB;
+        const uint64_t u0 = (uint64_t)b.unit_base + (uint64_t)i * ZB_MAX_UNITS;
+        ZbInput in;
+        in.meta = unit_meta + u0;
+        in.unit_lits = unit_lits + u0 * ZB_UNIT;
+        in.unit_recs = unit_recs + u0 * ZB_UNIT_SEQ_MAX;
+        in.nunits = (len + ZB_UNIT - 1u) / ZB_UNIT;
+        in.raw_size = len;
+        sc.out = reinterpret_cast<uint32_t*>(enc + (uint64_t)zb * ZB_OUT_BYTES);
+        const uint32_t n = zb_encode_block(&in, &sc, &sh, threadIdx.x);
+        if (threadIdx.x == 0)
+            enc_size[zb] = n;
+        __syncthreads();
+    }
 }
 
 // frame headers (and the lone empty block of empty inputs)
@@ -193,6 +260,7 @@ extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uin
         return 0;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     std::vector<ZBlock> hb(block_count);
+    std::vector<uint32_t> unit_base(block_count);
     uint64_t nzb = 0;
     for (uint32_t b = 0; b < block_count; ++b)
     {
@@ -202,32 +270,78 @@ extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uin
         hb[b].dst_cap = dst_caps[b];
         hb[b].zb_base = (uint32_t)nzb;
         hb[b].nzb = (uint32_t)div_up_u64(src_sizes[b], ZB);
+        hb[b].pad = 0;
         nzb += hb[b].nzb;
     }
-    if (nzb > 0x7FFFFFF0ull)
+    if (nzb > 0x7FFFF0ull)
         return lthip_fail(ctx, EINVAL, "zstd", "batch too large");
-    void *d_blocks, *d_rle, *d_zdst;
+    // ---- match finder: sequences + literals per 4 KiB unit ----
+    uint8_t* d_lits = nullptr;
+    uint64_t* d_recs = nullptr;
+    void* d_meta = nullptr;
+    uint64_t nunits = 0;
     int err;
+    if ((err = lthip_launch_lz_sequences(ctx, d_src, block_count, src_offsets, src_sizes, &d_lits, &d_recs, &d_meta, unit_base.data(),
+                                         &nunits)))
+        return err;
+    for (uint32_t b = 0; b < block_count; ++b)
+        hb[b].unit_base = unit_base[b];
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const uint32_t nwg = (uint32_t)(nzb < (uint64_t)ncu * 12 ? nzb : (uint64_t)ncu * 12);
+    void *d_blocks, *d_rle, *d_zdst, *d_enc, *d_encsz, *d_work;
     if ((err = lthip_scratch(ctx, S_LZ4_BLOCKS, sizeof(ZBlock) * (size_t)block_count, &d_blocks)))
         return err;
-    if ((err = lthip_scratch(ctx, S_LZ4_META, (size_t)nzb + 16, &d_rle)))
+    if ((err = lthip_scratch(ctx, S_TABLES2, (size_t)nzb + 16, &d_rle)))
         return err;
     if ((err = lthip_scratch(ctx, S_LZ4_SEGS, ((size_t)nzb + 4) * 4, &d_zdst)))
         return err;
+    if ((err = lthip_scratch(ctx, S_MISC, ((size_t)nzb + 4) * 4, &d_encsz)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_Z_ENC, (size_t)ZB_OUT_BYTES * ((size_t)nzb + 1), &d_enc)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_Z_WORK, Z_WORK_STRIDE * ((size_t)nwg + 1), &d_work)))
+        return err;
     LTHIP_CHECK(ctx, hipMemcpyAsync(d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, hipMemcpyHostToDevice, ctx->stream));
     LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    LaunchTimer t(ctx, LTHIP_K_OTHER);
     if (nzb)
+    {
+        LaunchTimer t(ctx, LTHIP_K_ZSTD_ENC);
         hipLaunchKernelGGL(k_zstd_classify, dim3((uint32_t)nzb), dim3(ZT), 0, ctx->stream, (const uint8_t*)d_src,
                            (const ZBlock*)d_blocks, block_count, (uint8_t*)d_rle);
+        hipLaunchKernelGGL(k_zstd_encode, dim3(nwg), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks, block_count, (uint32_t)nzb,
+                           (const uint8_t*)d_rle, (const ZbUnitMeta*)d_meta, (const uint8_t*)d_lits, (const uint64_t*)d_recs,
+                           (uint8_t*)d_work, (uint8_t*)d_enc, (uint32_t*)d_encsz);
+        LTHIP_LAUNCH_CHECK(ctx);
+    }
+    LaunchTimer t(ctx, LTHIP_K_OTHER);
     hipLaunchKernelGGL(k_zstd_scan, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
-                       block_count, (const uint8_t*)d_rle, (uint32_t*)d_zdst, d_out_sizes);
+                       block_count, (const uint8_t*)d_rle, (const uint32_t*)d_encsz, (uint32_t*)d_zdst, d_out_sizes);
     hipLaunchKernelGGL(k_zstd_headers, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
                        block_count, (const uint32_t*)d_out_sizes, (uint8_t*)d_dst);
     if (nzb)
         hipLaunchKernelGGL(k_zstd_emit, dim3((uint32_t)nzb), dim3(ZT), 0, ctx->stream, (const uint8_t*)d_src,
-                           (const ZBlock*)d_blocks, block_count, (const uint8_t*)d_rle, (const uint32_t*)d_zdst,
-                           (const uint32_t*)d_out_sizes, (uint8_t*)d_dst);
+                           (const ZBlock*)d_blocks, block_count, (const uint8_t*)d_rle, (const uint32_t*)d_encsz,
+                           (const uint8_t*)d_enc, (const uint32_t*)d_zdst, (const uint32_t*)d_out_sizes, (uint8_t*)d_dst);
     LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// Diagnostics for the parity tests: the match finder's output of the LAST lthip_zstd_compress_blocks call on this
+// context (units [first, first+count)), so that the host model of the entropy stage can be run on the same input.
+extern "C" int lthip_zstd_debug_units(lthip_ctx* ctx, uint64_t first, uint64_t count, void* h_meta, void* h_lits, void* h_recs)
+{
+    if (!ctx || !ctx->scratch[S_Z_LITS] || !ctx->scratch[S_Z_RECS] || !ctx->scratch[S_LZ4_META])
+        return EINVAL;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_meta)
+        LTHIP_CHECK(ctx, hipMemcpy(h_meta, (const uint8_t*)ctx->scratch[S_LZ4_META] + first * sizeof(ZbUnitMeta), count * sizeof(ZbUnitMeta),
+                                   hipMemcpyDeviceToHost));
+    if (h_lits)
+        LTHIP_CHECK(ctx, hipMemcpy(h_lits, (const uint8_t*)ctx->scratch[S_Z_LITS] + first * ZB_UNIT, count * ZB_UNIT, hipMemcpyDeviceToHost));
+    if (h_recs)
+        LTHIP_CHECK(ctx, hipMemcpy(h_recs, (const uint8_t*)ctx->scratch[S_Z_RECS] + first * ZB_UNIT_SEQ_MAX * 8, count * ZB_UNIT_SEQ_MAX * 8,
+                                   hipMemcpyDeviceToHost));
     return 0;
 }

@@ -74,6 +74,10 @@ enum ScratchSlot
     S_TABLES,      // small H2D tables
     S_TABLES2,
     S_MISC,
+    S_Z_LITS,  // zstd: literals per 4 KiB unit
+    S_Z_RECS,  // zstd: sequence records per unit
+    S_Z_ENC,   // zstd: encoded 128 KiB pieces
+    S_Z_WORK,  // zstd: per-encoder-wave work area
     S_COUNT
 };
 
@@ -147,5 +151,12 @@ int lthip_launch_blake3(lthip_ctx* ctx, const uint8_t* d_data, const uint64_t* d
 
 int lthip_launch_from_buffer(lthip_ctx* ctx, const uint8_t* d_data, uint32_t n, uint32_t min_chunk, const DivTest& dv,
                              uint64_t* d_out);
+
+// zstd front end (k_lz4.hip): the LZ4 match finder run with sequence output.  Per 4 KiB unit u of the batch (units
+// are numbered block after block, `unit_base[b]` first): literals at d_lits + u*4096, records at d_recs + u*1024,
+// ZbUnitMeta at d_meta + u (zstd_block_core.h).
+int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
+                              const uint32_t* src_sizes, uint8_t** d_lits, uint64_t** d_recs, void** d_meta,
+                              uint32_t* unit_base, uint64_t* total_units);
 
 static inline uint64_t div_up_u64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }

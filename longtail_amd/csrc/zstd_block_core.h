@@ -1,0 +1,1123 @@
+/* zstd_block_core.h -- encoder for ONE zstd Compressed_Block (RFC 8878 §3.1.1.2-3.1.1.4) from LZ sequences.
+ *
+ * What the reference does on this path: `ZStdCompressionAPI_Compress` hands each stored block to
+ * `ZSTD_compressCCtx` (lib/zstd/longtail_zstd.c:105-142); the bytes that come back only have to be a zstd frame the
+ * reference's `ZSTD_decompressDCtx` (longtail_zstd.c:144-177) turns back into the block.  This file is NOT a
+ * restatement of zstd's compressor: it is our own entropy stage, written against the FORMAT as the reference's
+ * decoder implements it (file:line citations are to /root/reference/lib/zstd/ext):
+ *   literals section, Huffman tree description, 4-stream layout   decompress/zstd_decompress_block.c:135-345,
+ *                                                                 common/entropy_common.c:236-327 (HUF_readStats)
+ *   FSE table description (NCount)                                common/entropy_common.c:42-187
+ *   FSE decoding table construction (symbol spread, nbBits/base)  decompress/zstd_decompress_block.c:484-603
+ *   sequences section header, modes, decode order of the fields   decompress/zstd_decompress_block.c:700-760, 1240-1345
+ *   predefined distributions, LL/ML code bit counts               common/zstd_internal.h:123-168
+ *   two-state FSE stream of the Huffman weights                   common/fse_decompress.c:174-238
+ *
+ * ONE source, two execution models.  The includer defines
+ *   ZB_LANES          number of cooperating lanes (64 on the GPU: one wavefront per zstd block; 1 on the host)
+ *   ZB_FN             function qualifiers
+ *   ZB_SYNC()         make earlier writes of all lanes visible to all lanes
+ *   zb_atomic_add(p,v) / zb_atomic_or(p,v)   32-bit atomics on shared / global words
+ * Every phase is either `ZB_SERIAL(zl)` (lane 0), or a `ZB_PAR_FOR` whose iterations only interact through those
+ * commutative atomics, so the bytes produced do not depend on ZB_LANES: the one-lane host build (zstd_model.c in the test
+ * infrastructure) is a bit-exact model of the kernel (k_zstd.hip), and runs here without a GPU against the
+ * reference decoder.
+ */
+#ifndef ZSTD_BLOCK_CORE_H
+#define ZSTD_BLOCK_CORE_H
+
+#include <stdint.h>
+
+#ifndef ZB_DBG
+#define ZB_DBG 0u /* host model only: 1 raw literals, 2 never predefined, 4 never FSE-compressed tables */
+#endif
+#define ZB_PAR_FOR(i, n) for (uint32_t i = zl; i < (uint32_t)(n); i += ZB_LANES)
+#define ZB_SERIAL(zl) if ((zl) == 0)
+
+#define ZB_BLOCK_MAX (128u * 1024u) /* Block_Maximum_Size, zstd.h:142-143 */
+#define ZB_UNIT 4096u               /* bytes of input per match-finder unit */
+#define ZB_UNIT_SEQ_MAX 1024u       /* a sequence covers >= 4 bytes */
+#define ZB_MAX_UNITS (ZB_BLOCK_MAX / ZB_UNIT)
+#define ZB_SEQ_MAX (ZB_MAX_UNITS * ZB_UNIT_SEQ_MAX)
+#define ZB_CHUNKS 64u               /* bit-stream work items: 4 literal streams x 16, or 64 runs of sequences */
+#define ZB_OUT_BYTES (ZB_BLOCK_MAX + 2048u)
+#define ZB_HUF_MAXBITS 11u          /* LitHufLog, zstd_internal.h:105 */
+
+/* match-finder record of one sequence inside a unit: literals before the match, match length, offset */
+#define ZB_REC(lit, mlen, off) ((uint64_t)(lit) | ((uint64_t)(mlen) << 16) | ((uint64_t)(off) << 32))
+/* merged sequence of the block: lit 20 bits | mlen 16 bits | off 17 bits */
+#define ZB_SEQ_LIT(s) ((uint32_t)((s) & 0xFFFFFu))
+#define ZB_SEQ_ML(s) ((uint32_t)(((s) >> 20) & 0xFFFFu))
+#define ZB_SEQ_OFF(s) ((uint32_t)((s) >> 36))
+
+typedef struct ZbUnitMeta
+{
+    uint32_t nseq; /* sequences found in the unit */
+    uint32_t nlit; /* literal bytes of the unit (all runs, tail included), stored contiguously */
+    uint32_t tail; /* literals after the unit's last sequence (== nlit when nseq == 0) */
+    uint32_t pad;
+} ZbUnitMeta;
+
+typedef struct ZbInput
+{
+    const ZbUnitMeta* meta;  /* [nunits] */
+    const uint8_t* unit_lits; /* unit u at + u * ZB_UNIT */
+    const uint64_t* unit_recs; /* unit u at + u * ZB_UNIT_SEQ_MAX */
+    uint32_t nunits;
+    uint32_t raw_size;
+} ZbInput;
+
+typedef struct ZbScratch /* global memory owned by the lanes of one block encoder */
+{
+    uint8_t* lits;   /* [ZB_BLOCK_MAX + 8]  the block's literals, concatenated */
+    uint64_t* seqs;  /* [ZB_SEQ_MAX]        merged sequences */
+    uint16_t* sbits; /* [3 * ZB_SEQ_MAX]    FSE state-transition bits per sequence: nbBits << 10 | bits */
+    uint32_t* out;   /* [ZB_OUT_BYTES / 4]  the encoded block */
+} ZbScratch;
+
+enum
+{
+    ZV_NBSEQ,
+    ZV_NLIT,
+    ZV_HUF_OK,
+    ZV_HUF_MAXBITS,
+    ZV_HUF_MAXSYM,
+    ZV_LIT_MODE, /* 0 raw, 2 huffman */
+    ZV_LIT_HDR,  /* bytes of the literals section header */
+    ZV_TREE_BYTES,
+    ZV_LIT_END, /* byte offset just after the literals section */
+    ZV_SEQ_BITS0, /* byte offset of the sequence bit-stream */
+    ZV_SEQ_TOTALBITS,
+    ZV_OUT_SIZE,
+    ZV_STREAM_BYTES, /* +0..3 */
+    ZV_STREAM_BASE = ZV_STREAM_BYTES + 4, /* +0..3, byte offsets */
+    ZV_FINAL_STATE = ZV_STREAM_BASE + 4,  /* +0..2 */
+    ZV_COUNT = ZV_FINAL_STATE + 3
+};
+
+typedef struct ZbShared /* LDS on the GPU (about 9.5 KiB per wave) */
+{
+    uint32_t lit_hist[256];
+    uint32_t sort_key[256]; /* Huffman construction: present symbols sorted by count */
+    uint32_t huf_w[256];    /* ... weights / parent links / depths (Moffat-Katajainen, in place) */
+    uint8_t huf_l[256];     /* ... code length per sorted position */
+    uint8_t tree[160];      /* Huffman tree description */
+    uint16_t cursor[3][64];
+    uint16_t huf_code[256];
+    uint8_t huf_len[256];
+    uint32_t sym_hist[3][64]; /* LL / OF / ML code histograms */
+    int16_t norm[3][64];
+    uint16_t sym_start[3][64];
+    uint16_t state_tab[3][512];
+    uint8_t spread[3][512];
+    uint8_t mode[4], table_log[4], rle_sym[4];
+    uint32_t useq_base[ZB_MAX_UNITS + 1], ulit_base[ZB_MAX_UNITS + 1], carry[ZB_MAX_UNITS];
+    uint32_t part[ZB_CHUNKS + 1];
+    uint32_t part2[ZB_CHUNKS + 1];
+    uint32_t v[ZV_COUNT];
+} ZbShared;
+
+/* table indices */
+#define ZT_LL 0
+#define ZT_OF 1
+#define ZT_ML 2
+
+/* ------------------------------------------------------------------------------------------------------------
+ * constants of the format
+ * ---------------------------------------------------------------------------------------------------------- */
+ZB_FN uint32_t zb_highbit(uint32_t v) /* v > 0 */
+{
+    uint32_t r = 0;
+    while (v >>= 1)
+        ++r;
+    return r;
+}
+
+/* Literals_Length_Code: zstd_internal.h:123-129 gives the number of extra bits per code, which fixes the baselines:
+ * 0..15 direct, then 16,18,20,22 (1 bit), 24,28 (2), 32,40 (3), 48 (4), 64 (6), 128 (7) ... */
+ZB_FN uint32_t zb_ll_code(uint32_t v)
+{
+    if (v < 16u)
+        return v;
+    if (v < 24u)
+        return 16u + ((v - 16u) >> 1);
+    if (v < 32u)
+        return 20u + ((v - 24u) >> 2);
+    if (v < 48u)
+        return 22u + ((v - 32u) >> 3);
+    if (v < 64u)
+        return 24u;
+    return zb_highbit(v) + 19u;
+}
+ZB_FN uint32_t zb_ll_bits(uint32_t code)
+{
+    if (code < 16u)
+        return 0u;
+    if (code < 20u)
+        return 1u;
+    if (code < 22u)
+        return 2u;
+    if (code < 24u)
+        return 3u;
+    if (code == 24u)
+        return 4u;
+    return code - 19u;
+}
+ZB_FN uint32_t zb_ll_base(uint32_t code)
+{
+    if (code < 16u)
+        return code;
+    if (code < 20u)
+        return 16u + ((code - 16u) << 1);
+    if (code < 22u)
+        return 24u + ((code - 20u) << 2);
+    if (code < 24u)
+        return 32u + ((code - 22u) << 3);
+    if (code == 24u)
+        return 48u;
+    return 1u << (code - 19u);
+}
+/* Match_Length_Code on mlBase = match length - 3 (zstd_internal.h:140-148): 0..31 direct, then 32,34,36,38 (1 bit),
+ * 40,44 (2), 48,56 (3), 64,80 (4), 96 (5), 128 (7), 256 (8) ... */
+ZB_FN uint32_t zb_ml_code(uint32_t m)
+{
+    if (m < 32u)
+        return m;
+    if (m < 40u)
+        return 32u + ((m - 32u) >> 1);
+    if (m < 48u)
+        return 36u + ((m - 40u) >> 2);
+    if (m < 64u)
+        return 38u + ((m - 48u) >> 3);
+    if (m < 96u)
+        return 40u + ((m - 64u) >> 4);
+    if (m < 128u)
+        return 42u;
+    return zb_highbit(m) + 36u;
+}
+ZB_FN uint32_t zb_ml_bits(uint32_t code)
+{
+    if (code < 32u)
+        return 0u;
+    if (code < 36u)
+        return 1u;
+    if (code < 38u)
+        return 2u;
+    if (code < 40u)
+        return 3u;
+    if (code < 42u)
+        return 4u;
+    if (code == 42u)
+        return 5u;
+    return code - 36u;
+}
+ZB_FN uint32_t zb_ml_base(uint32_t code)
+{
+    if (code < 32u)
+        return code;
+    if (code < 36u)
+        return 32u + ((code - 32u) << 1);
+    if (code < 38u)
+        return 40u + ((code - 36u) << 2);
+    if (code < 40u)
+        return 48u + ((code - 38u) << 3);
+    if (code < 42u)
+        return 64u + ((code - 40u) << 4);
+    if (code == 42u)
+        return 96u;
+    return 1u << (code - 36u);
+}
+
+/* predefined distributions, zstd_internal.h:130-136, 149-157, 161-166 */
+ZB_FN int zb_default_norm(int t, uint32_t s)
+{
+    if (t == ZT_LL)
+    {
+        if (s == 0u)
+            return 4;
+        if (s == 1u || s == 25u)
+            return 3;
+        if (s >= 32u)
+            return -1;
+        if ((s >= 13u && s <= 15u) || s >= 27u)
+            return 1;
+        return 2;
+    }
+    if (t == ZT_ML)
+    {
+        if (s == 0u)
+            return 1;
+        if (s == 1u)
+            return 4;
+        if (s == 2u)
+            return 3;
+        if (s <= 8u)
+            return 2;
+        if (s >= 46u)
+            return -1;
+        return 1;
+    }
+    if (s >= 24u)
+        return -1;
+    if (s >= 6u && s <= 8u)
+        return 2;
+    return 1;
+}
+ZB_FN uint32_t zb_table_nsym(int t) { return t == ZT_LL ? 36u : t == ZT_ML ? 53u : 29u; }
+ZB_FN uint32_t zb_table_default_log(int t) { return t == ZT_OF ? 5u : 6u; }
+ZB_FN uint32_t zb_table_max_log(int t) { return t == ZT_OF ? 8u : 9u; } /* zstd_internal.h:112-114 */
+
+/* ------------------------------------------------------------------------------------------------------------
+ * little-endian bit writer on 32-bit words (the destination is zeroed first; neighbours share words -> atomics)
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct ZbBits
+{
+    uint32_t* dst;
+    uint64_t acc;
+    uint32_t nacc; /* < 32 between calls */
+    uint32_t word;
+} ZbBits;
+
+ZB_FN void zb_bits_open(ZbBits* b, uint32_t* dst, uint32_t bitpos)
+{
+    b->dst = dst;
+    b->acc = 0;
+    b->nacc = bitpos & 31u;
+    b->word = bitpos >> 5;
+}
+ZB_FN void zb_bits_put(ZbBits* b, uint32_t value, uint32_t n) /* n <= 32, value < 2^n */
+{
+    b->acc |= (uint64_t)value << b->nacc;
+    b->nacc += n;
+    if (b->nacc >= 32u)
+    {
+        zb_atomic_or(b->dst + b->word, (uint32_t)b->acc);
+        ++b->word;
+        b->acc >>= 32;
+        b->nacc -= 32u;
+    }
+}
+ZB_FN void zb_bits_close(ZbBits* b)
+{
+    if (b->acc)
+        zb_atomic_or(b->dst + b->word, (uint32_t)b->acc);
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * FSE: normalisation, table description, encoding table
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Scale `hist` (nsym entries, sum `total` >= 2, at least two non-zero) to sum 2^tl with every present symbol >= 1. */
+ZB_FN void zb_normalize(const uint32_t* hist, uint32_t nsym, uint32_t total, uint32_t tl, int16_t* norm)
+{
+    const uint32_t size = 1u << tl;
+    uint32_t sum = 0;
+    for (uint32_t s = 0; s < nsym; ++s)
+    {
+        uint32_t v = 0;
+        if (hist[s])
+        {
+            v = (uint32_t)(((uint64_t)hist[s] << tl) / total);
+            if (v == 0u)
+                v = 1u;
+        }
+        norm[s] = (int16_t)v;
+        sum += v;
+    }
+    while (sum != size)
+    {
+        uint32_t best = 0;
+        for (uint32_t s = 1; s < nsym; ++s)
+            if (norm[s] > norm[best])
+                best = s;
+        if (sum < size)
+        {
+            norm[best] = (int16_t)(norm[best] + (int)(size - sum));
+            sum = size;
+        }
+        else
+        {
+            uint32_t take = sum - size;
+            if (take > (uint32_t)norm[best] - 1u)
+                take = (uint32_t)norm[best] - 1u;
+            norm[best] = (int16_t)(norm[best] - (int)take);
+            sum -= take;
+        }
+    }
+}
+
+/* NCount writer: the exact inverse of FSE_readNCount_body (entropy_common.c:42-187).  Returns bytes written. */
+ZB_FN uint32_t zb_write_ncount(uint8_t* dst, const int16_t* norm, uint32_t nsym, uint32_t tl)
+{
+    uint64_t acc = 0;
+    uint32_t nacc = 0, pos = 0;
+    int remaining = (int)(1u << tl) + 1;
+    int threshold = (int)(1u << tl);
+    uint32_t nbits = tl + 1u;
+    uint32_t last = nsym;
+    while (last > 0u && norm[last - 1u] == 0)
+        --last; /* symbols after the last present one are implied */
+    acc = tl - 5u;
+    nacc = 4;
+    uint32_t s = 0;
+    while (s < last && remaining > 1)
+    {
+        const int count = norm[s++];
+        const int maxv = (2 * threshold - 1) - remaining;
+        uint32_t v = (uint32_t)(count + 1);
+        remaining -= count < 0 ? -count : count;
+        if ((int)v >= threshold)
+            v += (uint32_t)maxv;
+        /* small values take nbits-1 bits */
+        {
+            const uint32_t nb = (int)v < maxv ? nbits - 1u : nbits;
+            acc |= (uint64_t)v << nacc;
+            nacc += nb;
+        }
+        if (count == 0)
+        {
+            /* run of further zero-probability symbols: 2-bit repeat codes, 3 = "three more and continue" */
+            uint32_t run = 0;
+            while (s + run < last && norm[s + run] == 0)
+                ++run;
+            s += run;
+            for (;;)
+            {
+                while (nacc >= 8u)
+                {
+                    dst[pos++] = (uint8_t)acc;
+                    acc >>= 8;
+                    nacc -= 8u;
+                }
+                if (run >= 3u)
+                {
+                    acc |= (uint64_t)3u << nacc;
+                    nacc += 2u;
+                    run -= 3u;
+                }
+                else
+                {
+                    acc |= (uint64_t)run << nacc;
+                    nacc += 2u;
+                    break;
+                }
+            }
+        }
+        while (remaining < threshold && threshold > 1)
+        {
+            --nbits;
+            threshold >>= 1;
+        }
+        while (nacc >= 8u)
+        {
+            dst[pos++] = (uint8_t)acc;
+            acc >>= 8;
+            nacc -= 8u;
+        }
+    }
+    if (nacc)
+        dst[pos++] = (uint8_t)acc;
+    return pos;
+}
+
+/* Encoding table of one FSE distribution.  The decoder (zstd_decompress_block.c:484-603, fse_decompress.c:60-140)
+ * spreads the symbols over the 2^tl states with step (size>>1)+(size>>3)+3, "less than one" symbols (-1) taking
+ * the last cells, and gives the k-th cell of symbol s (in state order) nextState = count+k, nbBits = tl -
+ * highbit(nextState).  Inverting that: from state x in [size, 2*size), emitting symbol s with `count` cells means
+ * writing the low nb bits of x, nb chosen so that (x >> nb) lies in [count, 2*count), and moving to
+ * size + cell[(x >> nb) - count].  state_tab lists the cells of every symbol in state order; sym_start[s] is the
+ * first entry of s. */
+ZB_FN void zb_build_enc_table(const int16_t* norm, uint32_t nsym, uint32_t tl, uint8_t* spread, uint16_t* state_tab,
+                              uint16_t* sym_start, uint16_t* cursor)
+{
+    const uint32_t size = 1u << tl, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
+    uint32_t high = size - 1u, pos = 0, cum = 0;
+    for (uint32_t s = 0; s < nsym; ++s)
+        if (norm[s] == -1)
+            spread[high--] = (uint8_t)s;
+    for (uint32_t s = 0; s < nsym; ++s)
+    {
+        sym_start[s] = (uint16_t)cum;
+        cum += (uint32_t)(norm[s] < 0 ? 1 : norm[s]);
+        for (int i = 0; i < norm[s]; ++i)
+        {
+            spread[pos] = (uint8_t)s;
+            pos = (pos + step) & mask;
+            while (pos > high)
+                pos = (pos + step) & mask;
+        }
+    }
+    /* cells in state order -> per-symbol lists */
+    {
+        for (uint32_t s = 0; s < nsym; ++s)
+            cursor[s] = sym_start[s];
+        for (uint32_t u = 0; u < size; ++u)
+            state_tab[cursor[spread[u]]++] = (uint16_t)u;
+    }
+}
+
+ZB_FN uint32_t zb_sym_count(const int16_t* norm, uint32_t s) { return (uint32_t)(norm[s] < 0 ? 1 : norm[s]); }
+
+/* One encoding step; returns nbBits << 10 | bits and updates *x. */
+ZB_FN uint32_t zb_fse_step(uint32_t* x, uint32_t s, const int16_t* norm, const uint16_t* state_tab, const uint16_t* sym_start,
+                           uint32_t tl)
+{
+    const uint32_t c = zb_sym_count(norm, s);
+    uint32_t nb = tl - zb_highbit(c);
+    if ((*x >> nb) < c)
+        --nb; /* cannot underflow: x >= 2^tl >= ... see zb_build_enc_table */
+    {
+        const uint32_t bits = *x & ((1u << nb) - 1u);
+        *x = (1u << tl) + state_tab[sym_start[s] + ((*x >> nb) - c)];
+        return (nb << 10) | bits;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Huffman code lengths (<= 11 bits) for the literals
+ * ---------------------------------------------------------------------------------------------------------- */
+/* In: sh->lit_hist.  Out: sh->huf_len / huf_code, v[ZV_HUF_*].  Serial (one lane). */
+ZB_FN void zb_huffman_build(ZbShared* sh)
+{
+    uint32_t* A = sh->sort_key;
+    uint32_t n = 0, maxsym = 0;
+    sh->v[ZV_HUF_OK] = 0;
+    for (uint32_t s = 0; s < 256u; ++s)
+    {
+        sh->huf_len[s] = 0;
+        if (sh->lit_hist[s])
+        {
+            A[n++] = s;
+            maxsym = s;
+        }
+    }
+    sh->v[ZV_HUF_MAXSYM] = maxsym;
+    if (n < 2u)
+        return;
+    /* sort the present symbols by (count, symbol) ascending: insertion sort on indices */
+    for (uint32_t i = 1; i < n; ++i)
+    {
+        const uint32_t s = A[i], c = sh->lit_hist[s];
+        uint32_t j = i;
+        while (j > 0u && sh->lit_hist[A[j - 1u]] > c)
+        {
+            A[j] = A[j - 1u];
+            --j;
+        }
+        A[j] = s;
+    }
+    /* minimum-redundancy code lengths in place (Moffat & Katajainen): W[i] starts as the sorted weights */
+    {
+        uint32_t* W = sh->huf_w;
+        uint8_t* L = sh->huf_l;
+        for (uint32_t i = 0; i < n; ++i)
+            W[i] = sh->lit_hist[A[i]];
+        if (n == 2u)
+        {
+            L[0] = L[1] = 1;
+        }
+        else
+        {
+            uint32_t root = 0, leaf = 2, next;
+            W[0] += W[1];
+            for (next = 1; next < n - 1u; ++next)
+            {
+                if (leaf >= n || W[root] < W[leaf])
+                {
+                    W[next] = W[root];
+                    W[root++] = next;
+                }
+                else
+                    W[next] = W[leaf++];
+                if (leaf >= n || (root < next && W[root] < W[leaf]))
+                {
+                    W[next] += W[root];
+                    W[root++] = next;
+                }
+                else
+                    W[next] += W[leaf++];
+            }
+            W[n - 2u] = 0;
+            for (int k = (int)n - 3; k >= 0; --k)
+                W[k] = W[W[k]] + 1u;
+            {
+                int avbl = 1, used = 0, dpth = 0, r = (int)n - 2, nx = (int)n - 1;
+                while (avbl > 0)
+                {
+                    while (r >= 0 && (int)W[r] == dpth)
+                    {
+                        ++used;
+                        --r;
+                    }
+                    while (avbl > used)
+                    {
+                        W[nx--] = (uint32_t)dpth;
+                        --avbl;
+                    }
+                    avbl = 2 * used;
+                    ++dpth;
+                    used = 0;
+                }
+            }
+            for (uint32_t i = 0; i < n; ++i)
+                L[i] = (uint8_t)(W[i] > 255u ? 255u : W[i]);
+        }
+        /* L is non-increasing (rarest symbol first).  Limit to 11 bits and restore Kraft equality. */
+        if (L[0] > ZB_HUF_MAXBITS)
+        {
+            const uint32_t full = 1u << ZB_HUF_MAXBITS;
+            uint32_t kraft = 0;
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                if (L[i] > ZB_HUF_MAXBITS)
+                    L[i] = (uint8_t)ZB_HUF_MAXBITS;
+                kraft += full >> L[i];
+            }
+            /* too full: lengthen the rarest symbols that are still shorter than 11 */
+            for (uint32_t i = 0; i < n && kraft > full; ++i)
+            {
+                while (L[i] < ZB_HUF_MAXBITS && kraft > full)
+                {
+                    kraft -= full >> (L[i] + 1u);
+                    ++L[i];
+                }
+            }
+            /* slack left by the last step: shorten the most frequent symbols that fit exactly */
+            for (int i = (int)n - 1; i >= 0 && kraft < full; --i)
+            {
+                while (L[i] > 1u && kraft + (full >> L[i]) <= full)
+                {
+                    kraft += full >> L[i];
+                    --L[i];
+                }
+            }
+            if (kraft != full)
+                return; /* literals stay raw */
+        }
+        {
+            uint32_t maxbits = 0;
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                sh->huf_len[A[i]] = L[i];
+                if (L[i] > maxbits)
+                    maxbits = L[i];
+            }
+            sh->v[ZV_HUF_MAXBITS] = maxbits;
+        }
+    }
+    /* canonical codes as the decoder assigns them (huf_decompress.c HUF_readDTableX1 / RFC 8878 §4.2.1.3): the
+     * longest codes get the smallest values, symbols of equal length in symbol order */
+    {
+        uint32_t count[ZB_HUF_MAXBITS + 2u], start[ZB_HUF_MAXBITS + 2u];
+        const uint32_t maxbits = sh->v[ZV_HUF_MAXBITS];
+        for (uint32_t l = 0; l <= ZB_HUF_MAXBITS + 1u; ++l)
+            count[l] = 0;
+        for (uint32_t s = 0; s < 256u; ++s)
+            ++count[sh->huf_len[s]];
+        {
+            uint32_t code = 0;
+            for (uint32_t l = maxbits; l >= 1u; --l)
+            {
+                start[l] = code;
+                code = (code + count[l]) >> 1;
+            }
+        }
+        for (uint32_t s = 0; s < 256u; ++s)
+        {
+            const uint32_t l = sh->huf_len[s];
+            sh->huf_code[s] = (uint16_t)(l ? start[l]++ : 0u);
+        }
+    }
+    sh->v[ZV_HUF_OK] = 1;
+}
+
+/* Huffman tree description (RFC 8878 §4.2.1; HUF_readStats, entropy_common.c:236-327).  Weights of symbols
+ * 0..maxsym-1; the last present symbol is implied.  Returns bytes written, 0 if it cannot be represented. */
+ZB_FN uint32_t zb_write_huf_tree(ZbShared* sh, uint8_t* dst)
+{
+    const uint32_t maxbits = sh->v[ZV_HUF_MAXBITS], nw = sh->v[ZV_HUF_MAXSYM];
+    if (nw <= 128u)
+    {
+        /* direct: header 127 + number of weights, two 4-bit weights per byte, first in the high nibble */
+        dst[0] = (uint8_t)(127u + nw);
+        for (uint32_t i = 0; i < nw; i += 2u)
+        {
+            const uint32_t l0 = sh->huf_len[i], l1 = i + 1u < nw ? sh->huf_len[i + 1u] : 0u;
+            const uint32_t w0 = l0 ? maxbits + 1u - l0 : 0u, w1 = l1 ? maxbits + 1u - l1 : 0u;
+            dst[1u + (i >> 1)] = (uint8_t)((w0 << 4) | w1);
+        }
+        return 1u + ((nw + 1u) >> 1);
+    }
+    /* FSE-compressed weights: table log <= 6, two interleaved states (fse_decompress.c:174-238) */
+    {
+        uint32_t hist[16];
+        int16_t* norm = sh->norm[0];
+        uint32_t distinct = 0;
+        for (uint32_t w = 0; w < 16u; ++w)
+            hist[w] = 0;
+        for (uint32_t i = 0; i < nw; ++i)
+        {
+            const uint32_t l = sh->huf_len[i];
+            ++hist[l ? maxbits + 1u - l : 0u];
+        }
+        for (uint32_t w = 0; w < 13u; ++w)
+            distinct += hist[w] != 0u;
+        if (distinct < 2u)
+            return 0;
+        {
+            const uint32_t tl = 6u;
+            uint32_t pos;
+            zb_normalize(hist, 13u, nw, tl, norm);
+            pos = 1u + zb_write_ncount(dst + 1, norm, 13u, tl);
+            zb_build_enc_table(norm, 13u, tl, sh->spread[0], sh->state_tab[0], sh->sym_start[0], sh->cursor[0]);
+            /* Weights are decoded alternately by state 1 (even indices) and state 2 (odd); the two last weights
+             * are carried by the initial states (first cell of their symbol, so that the decoder's final state
+             * update over-reads and stops, fse_decompress.c:214-236); the others are encoded from the end. */
+            {
+                uint32_t x[2];
+                uint64_t acc = 0;
+                uint32_t nacc = 0;
+                int i = (int)nw - 1;
+                for (int k = 0; k < 2; ++k, --i)
+                {
+                    const uint32_t l = sh->huf_len[i];
+                    const uint32_t w = l ? maxbits + 1u - l : 0u;
+                    x[i & 1] = (1u << tl) + sh->state_tab[0][sh->sym_start[0][w]];
+                }
+                for (; i >= 0; --i)
+                {
+                    const uint32_t l = sh->huf_len[i];
+                    const uint32_t w = l ? maxbits + 1u - l : 0u;
+                    const uint32_t r = zb_fse_step(&x[i & 1], w, norm, sh->state_tab[0], sh->sym_start[0], tl);
+                    acc |= (uint64_t)(r & 1023u) << nacc;
+                    nacc += r >> 10;
+                    while (nacc >= 8u)
+                    {
+                        dst[pos++] = (uint8_t)acc;
+                        acc >>= 8;
+                        nacc -= 8u;
+                    }
+                }
+                /* the decoder reads state 1 first: it is written last */
+                acc |= (uint64_t)(x[1] - (1u << tl)) << nacc;
+                nacc += tl;
+                acc |= (uint64_t)(x[0] - (1u << tl)) << nacc;
+                nacc += tl;
+                acc |= (uint64_t)1u << nacc; /* end mark */
+                nacc += 1u;
+                while (nacc > 0u)
+                {
+                    dst[pos++] = (uint8_t)acc;
+                    acc >>= 8;
+                    nacc = nacc >= 8u ? nacc - 8u : 0u;
+                }
+            }
+            if (pos - 1u >= 128u)
+                return 0;
+            dst[0] = (uint8_t)(pos - 1u);
+            return pos;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * the block encoder
+ * ---------------------------------------------------------------------------------------------------------- */
+ZB_FN uint32_t zb_of_code(uint32_t off) { return zb_highbit(off + 3u); }
+
+/* Encodes one block.  Returns the size of the Compressed_Block content in sc->out, or 0 when it would not be
+ * smaller than the raw bytes (the caller then stores a Raw_Block). */
+ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared* sh, uint32_t zl)
+{
+    uint8_t* const out8 = (uint8_t*)sc->out;
+
+    /* ---- phase 0: unit bases; zero the histograms and the output ---- */
+    ZB_SERIAL(zl)
+    {
+        uint32_t nseq = 0, nlit = 0, carry = 0;
+        for (uint32_t u = 0; u < in->nunits; ++u)
+        {
+            sh->useq_base[u] = nseq;
+            sh->ulit_base[u] = nlit;
+            sh->carry[u] = carry;
+            nseq += in->meta[u].nseq;
+            nlit += in->meta[u].nlit;
+            carry = in->meta[u].nseq ? in->meta[u].tail : carry + in->meta[u].nlit;
+        }
+        sh->useq_base[in->nunits] = nseq;
+        sh->ulit_base[in->nunits] = nlit;
+        sh->v[ZV_NBSEQ] = nseq;
+        sh->v[ZV_NLIT] = nlit;
+    }
+    ZB_PAR_FOR(i, 256u) sh->lit_hist[i] = 0;
+    ZB_PAR_FOR(i, 3u * 64u) sh->sym_hist[i >> 6][i & 63u] = 0;
+    ZB_PAR_FOR(i, ZB_OUT_BYTES / 4u) sc->out[i] = 0;
+    ZB_SYNC();
+    const uint32_t nbseq = sh->v[ZV_NBSEQ], nlit = sh->v[ZV_NLIT];
+
+    /* ---- phase 1: merge the units: sequences (with their symbol histograms) and literals (with theirs) ---- */
+    ZB_PAR_FOR(i, nbseq)
+    {
+        uint32_t lo = 0, hi = in->nunits;
+        while (hi - lo > 1u)
+        {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (sh->useq_base[mid] <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        {
+            const uint32_t k = i - sh->useq_base[lo];
+            const uint64_t r = in->unit_recs[(uint64_t)lo * ZB_UNIT_SEQ_MAX + k];
+            const uint32_t lit = (uint32_t)(r & 0xFFFFu) + (k == 0u ? sh->carry[lo] : 0u);
+            const uint32_t ml = (uint32_t)((r >> 16) & 0xFFFFu), off = (uint32_t)(r >> 32);
+            sc->seqs[i] = (uint64_t)lit | ((uint64_t)ml << 20) | ((uint64_t)off << 36);
+            zb_atomic_add(&sh->sym_hist[ZT_LL][zb_ll_code(lit)], 1u);
+            zb_atomic_add(&sh->sym_hist[ZT_ML][zb_ml_code(ml - 3u)], 1u);
+            zb_atomic_add(&sh->sym_hist[ZT_OF][zb_of_code(off)], 1u);
+        }
+    }
+    for (uint32_t u = 0; u < in->nunits; ++u)
+    {
+        const uint8_t* src = in->unit_lits + (uint64_t)u * ZB_UNIT;
+        uint8_t* dst = sc->lits + sh->ulit_base[u];
+        ZB_PAR_FOR(j, in->meta[u].nlit)
+        {
+            const uint8_t b = src[j];
+            dst[j] = b;
+            zb_atomic_add(&sh->lit_hist[b], 1u);
+        }
+    }
+    ZB_SYNC();
+
+    /* ---- phase 2: Huffman code for the literals (lane 0), FSE tables for the three symbol types (lanes 0..2) ---- */
+    ZB_SERIAL(zl)
+    {
+        sh->v[ZV_HUF_OK] = 0;
+        sh->v[ZV_TREE_BYTES] = 0;
+        if (nlit >= 256u && !(ZB_DBG & 1u))
+            zb_huffman_build(sh);
+        if (sh->v[ZV_HUF_OK]) /* uses table slot 0 as work space: must precede the FSE tables below */
+            sh->v[ZV_TREE_BYTES] = zb_write_huf_tree(sh, sh->tree);
+    }
+    ZB_SYNC();
+    ZB_PAR_FOR(t, 3u)
+    {
+        if (nbseq)
+        {
+            const uint32_t nsym = zb_table_nsym((int)t);
+            uint32_t distinct = 0, only = 0, maxs = 0;
+            for (uint32_t s = 0; s < 64u; ++s)
+                if (sh->sym_hist[t][s])
+                {
+                    ++distinct;
+                    only = s;
+                    maxs = s;
+                }
+            if (distinct == 1u)
+            {
+                sh->mode[t] = 1; /* RLE_Mode */
+                sh->rle_sym[t] = (uint8_t)only;
+                sh->table_log[t] = 0;
+            }
+            else if (((nbseq < 64u && !(ZB_DBG & 2u)) || (ZB_DBG & 4u)) && maxs < nsym)
+            {
+                sh->mode[t] = 0; /* Predefined_Mode */
+                sh->table_log[t] = (uint8_t)zb_table_default_log((int)t);
+                for (uint32_t s = 0; s < 64u; ++s)
+                    sh->norm[t][s] = (int16_t)(s < nsym ? zb_default_norm((int)t, s) : 0);
+                zb_build_enc_table(sh->norm[t], nsym, sh->table_log[t], sh->spread[t], sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
+            }
+            else
+            {
+                uint32_t tl = zb_highbit(nbseq) - 1u;
+                const uint32_t minlog = distinct > 32u ? 6u : 5u, maxlog = zb_table_max_log((int)t);
+                if (tl < minlog)
+                    tl = minlog;
+                if (tl > maxlog)
+                    tl = maxlog;
+                sh->mode[t] = 2; /* FSE_Compressed_Mode */
+                sh->table_log[t] = (uint8_t)tl;
+                zb_normalize(sh->sym_hist[t], maxs + 1u, nbseq, tl, sh->norm[t]);
+                zb_build_enc_table(sh->norm[t], maxs + 1u, tl, sh->spread[t], sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
+                sh->rle_sym[t] = (uint8_t)maxs; /* highest present symbol, for the NCount writer */
+            }
+        }
+    }
+    ZB_SYNC();
+
+    /* ---- phase 3: size of the four Huffman streams (64 chunks; a stream is written from its LAST symbol) ---- */
+    const uint32_t seg = (nlit + 3u) >> 2;
+    if (sh->v[ZV_HUF_OK])
+    {
+        ZB_PAR_FOR(c, ZB_CHUNKS)
+        {
+            const uint32_t st = c >> 4, j = c & 15u;
+            const uint32_t s0 = st * seg < nlit ? st * seg : nlit;
+            const uint32_t s1 = st == 3u ? nlit : (s0 + seg < nlit ? s0 + seg : nlit);
+            const uint32_t csz = (s1 - s0 + 15u) >> 4;
+            const uint32_t a = s0 + j * csz < s1 ? s0 + j * csz : s1, b = a + csz < s1 ? a + csz : s1;
+            uint32_t bits = 0;
+            for (uint32_t k = a; k < b; ++k)
+                bits += sh->huf_len[sc->lits[k]];
+            sh->part[c] = bits;
+        }
+    }
+    ZB_SYNC();
+
+    /* ---- phase 4 (lane 0): decide the literals mode, write every header, lay out the bit streams ---- */
+    ZB_SERIAL(zl)
+    {
+        uint32_t pos = 0, use_huf = 0;
+        if (sh->v[ZV_HUF_OK])
+        {
+            const uint8_t* tree = sh->tree;
+            const uint32_t tb = sh->v[ZV_TREE_BYTES];
+            uint32_t csize = tb + 6u;
+            for (uint32_t st = 0; st < 4u; ++st)
+            {
+                uint32_t bits = 0;
+                /* chunk j of a stream starts after the bits of the chunks that follow it */
+                for (int j = 15; j >= 0; --j)
+                {
+                    const uint32_t b = sh->part[st * 16u + (uint32_t)j];
+                    sh->part[st * 16u + (uint32_t)j] = bits;
+                    bits += b;
+                }
+                sh->v[ZV_STREAM_BYTES + st] = (bits + 1u + 7u) >> 3; /* + end mark */
+                sh->part2[st] = bits;
+                csize += sh->v[ZV_STREAM_BYTES + st];
+            }
+            {
+                const uint32_t hdr = nlit < 1024u ? 3u : nlit < 16384u ? 4u : 5u;
+                const uint32_t rawhdr = nlit < 32u ? 1u : nlit < 4096u ? 2u : 3u;
+                /* every stream must hold at least its end mark plus one symbol for the decoder's 4-stream path */
+                if (tb && csize + hdr < nlit + rawhdr && seg >= 1u && nlit >= 4u * 1u + 252u)
+                {
+                    const uint32_t sf = nlit < 1024u ? 1u : nlit < 16384u ? 2u : 3u;
+                    const uint32_t nb = sf == 1u ? 10u : sf == 2u ? 14u : 18u;
+                    const uint64_t h = 2u | (sf << 2) | ((uint64_t)nlit << 4) | ((uint64_t)csize << (4u + nb));
+                    for (uint32_t k = 0; k < hdr; ++k)
+                        out8[pos++] = (uint8_t)(h >> (8u * k));
+                    for (uint32_t k = 0; k < tb; ++k)
+                        out8[pos++] = tree[k];
+                    for (uint32_t st = 0; st < 3u; ++st)
+                    {
+                        out8[pos++] = (uint8_t)sh->v[ZV_STREAM_BYTES + st];
+                        out8[pos++] = (uint8_t)(sh->v[ZV_STREAM_BYTES + st] >> 8);
+                    }
+                    for (uint32_t st = 0; st < 4u; ++st)
+                    {
+                        sh->v[ZV_STREAM_BASE + st] = pos;
+                        pos += sh->v[ZV_STREAM_BYTES + st];
+                    }
+                    use_huf = 1;
+                }
+            }
+        }
+        if (!use_huf)
+        {
+            /* Raw_Literals_Block: header then the bytes (copied below) */
+            if (nlit < 32u)
+                out8[pos++] = (uint8_t)(nlit << 3);
+            else if (nlit < 4096u)
+            {
+                const uint32_t h = 4u | (nlit << 4);
+                out8[pos++] = (uint8_t)h;
+                out8[pos++] = (uint8_t)(h >> 8);
+            }
+            else
+            {
+                const uint32_t h = 12u | (nlit << 4);
+                out8[pos++] = (uint8_t)h;
+                out8[pos++] = (uint8_t)(h >> 8);
+                out8[pos++] = (uint8_t)(h >> 16);
+            }
+            sh->v[ZV_STREAM_BASE] = pos;
+            pos += nlit;
+        }
+        sh->v[ZV_LIT_MODE] = use_huf ? 2u : 0u;
+        sh->v[ZV_LIT_END] = pos;
+        /* sequences section header (zstd_decompress_block.c:700-760) */
+        if (nbseq == 0u)
+            out8[pos++] = 0;
+        else
+        {
+            if (nbseq < 128u)
+                out8[pos++] = (uint8_t)nbseq;
+            else if (nbseq < 0x7F00u)
+            {
+                out8[pos++] = (uint8_t)((nbseq >> 8) + 128u);
+                out8[pos++] = (uint8_t)nbseq;
+            }
+            else
+            {
+                out8[pos++] = 255;
+                out8[pos++] = (uint8_t)(nbseq - 0x7F00u);
+                out8[pos++] = (uint8_t)((nbseq - 0x7F00u) >> 8);
+            }
+            out8[pos++] = (uint8_t)((sh->mode[ZT_LL] << 6) | (sh->mode[ZT_OF] << 4) | (sh->mode[ZT_ML] << 2));
+            for (uint32_t t = 0; t < 3u; ++t) /* LL, OF, ML in this order */
+            {
+                if (sh->mode[t] == 1u)
+                    out8[pos++] = sh->rle_sym[t];
+                else if (sh->mode[t] == 2u)
+                    pos += zb_write_ncount(out8 + pos, sh->norm[t], (uint32_t)sh->rle_sym[t] + 1u, sh->table_log[t]);
+            }
+        }
+        sh->v[ZV_SEQ_BITS0] = pos;
+    }
+    ZB_SYNC();
+
+    /* ---- phase 5: literals ---- */
+    if (sh->v[ZV_LIT_MODE] == 2u)
+    {
+        ZB_PAR_FOR(c, ZB_CHUNKS)
+        {
+            const uint32_t st = c >> 4, j = c & 15u;
+            const uint32_t s0 = st * seg < nlit ? st * seg : nlit;
+            const uint32_t s1 = st == 3u ? nlit : (s0 + seg < nlit ? s0 + seg : nlit);
+            const uint32_t csz = (s1 - s0 + 15u) >> 4;
+            const uint32_t a = s0 + j * csz < s1 ? s0 + j * csz : s1, b = a + csz < s1 ? a + csz : s1;
+            ZbBits bw;
+            zb_bits_open(&bw, sc->out, sh->v[ZV_STREAM_BASE + st] * 8u + sh->part[c]);
+            for (uint32_t k = b; k > a; --k)
+            {
+                const uint32_t s = sc->lits[k - 1u];
+                zb_bits_put(&bw, sh->huf_code[s], sh->huf_len[s]);
+            }
+            if (j == 0u)
+                zb_bits_put(&bw, 1u, 1u); /* end mark after the stream's first symbol */
+            zb_bits_close(&bw);
+        }
+    }
+    else
+    {
+        uint8_t* dst = out8 + sh->v[ZV_STREAM_BASE];
+        ZB_PAR_FOR(k, nlit) dst[k] = sc->lits[k];
+    }
+
+    /* ---- phase 6: the three FSE state chains, last sequence first (lanes 0..2) ---- */
+    ZB_PAR_FOR(t, 3u)
+    {
+        if (nbseq && sh->mode[t] != 1u)
+        {
+            const uint32_t tl = sh->table_log[t];
+            uint16_t* sb = sc->sbits + (uint64_t)t * ZB_SEQ_MAX;
+            uint32_t x;
+            {
+                const uint64_t q = sc->seqs[nbseq - 1u];
+                const uint32_t s = t == ZT_LL ? zb_ll_code(ZB_SEQ_LIT(q)) : t == ZT_ML ? zb_ml_code(ZB_SEQ_ML(q) - 3u) : zb_of_code(ZB_SEQ_OFF(q));
+                x = (1u << tl) + sh->state_tab[t][sh->sym_start[t][s]];
+            }
+            for (uint32_t n = nbseq - 1u; n-- > 0u;)
+            {
+                const uint64_t q = sc->seqs[n];
+                const uint32_t s = t == ZT_LL ? zb_ll_code(ZB_SEQ_LIT(q)) : t == ZT_ML ? zb_ml_code(ZB_SEQ_ML(q) - 3u) : zb_of_code(ZB_SEQ_OFF(q));
+                sb[n] = (uint16_t)zb_fse_step(&x, s, sh->norm[t], sh->state_tab[t], sh->sym_start[t], tl);
+            }
+            sh->v[ZV_FINAL_STATE + t] = x - (1u << tl);
+        }
+    }
+    ZB_SYNC();
+
+    /* ---- phase 7: sequence bit-stream: sizes of 64 runs, then the bits ---- */
+    const uint32_t run = (nbseq + ZB_CHUNKS - 1u) / ZB_CHUNKS;
+    for (int pass = 0; pass < 2; ++pass)
+    {
+        if (nbseq)
+        {
+            ZB_PAR_FOR(c, ZB_CHUNKS)
+            {
+                const uint32_t a = c * run < nbseq ? c * run : nbseq, b = a + run < nbseq ? a + run : nbseq;
+                uint32_t bits = 0;
+                ZbBits bw;
+                if (pass)
+                    zb_bits_open(&bw, sc->out, sh->v[ZV_SEQ_BITS0] * 8u + sh->part[c]);
+                for (uint32_t n = b; n > a; --n)
+                {
+                    const uint64_t q = sc->seqs[n - 1u];
+                    const uint32_t lit = ZB_SEQ_LIT(q), ml = ZB_SEQ_ML(q) - 3u, ofv = ZB_SEQ_OFF(q) + 3u;
+                    const uint32_t lc = zb_ll_code(lit), mc = zb_ml_code(ml), oc = zb_highbit(ofv);
+                    const uint32_t lb = zb_ll_bits(lc), mb = zb_ml_bits(mc);
+                    uint32_t so = 0, sm = 0, sl = 0;
+                    if (n - 1u < nbseq - 1u)
+                    {
+                        /* state updates of this sequence: OF, ML, LL (read back as LL, ML, OF) */
+                        if (sh->mode[ZT_OF] != 1u)
+                            so = sc->sbits[(uint64_t)ZT_OF * ZB_SEQ_MAX + n - 1u];
+                        if (sh->mode[ZT_ML] != 1u)
+                            sm = sc->sbits[(uint64_t)ZT_ML * ZB_SEQ_MAX + n - 1u];
+                        if (sh->mode[ZT_LL] != 1u)
+                            sl = sc->sbits[(uint64_t)ZT_LL * ZB_SEQ_MAX + n - 1u];
+                    }
+                    if (!pass)
+                        bits += (so >> 10) + (sm >> 10) + (sl >> 10) + lb + mb + oc;
+                    else
+                    {
+                        zb_bits_put(&bw, so & 1023u, so >> 10);
+                        zb_bits_put(&bw, sm & 1023u, sm >> 10);
+                        zb_bits_put(&bw, sl & 1023u, sl >> 10);
+                        zb_bits_put(&bw, lit - zb_ll_base(lc), lb);
+                        zb_bits_put(&bw, ml - zb_ml_base(mc), mb);
+                        zb_bits_put(&bw, ofv - (1u << oc), oc);
+                    }
+                }
+                if (!pass)
+                    sh->part2[c] = bits;
+                else
+                    zb_bits_close(&bw);
+            }
+        }
+        ZB_SYNC();
+        if (!pass)
+        {
+            ZB_SERIAL(zl)
+            {
+                uint32_t bits = 0;
+                for (int c = (int)ZB_CHUNKS - 1; c >= 0; --c) /* the last sequence is written first */
+                {
+                    sh->part[c] = bits;
+                    bits += sh->part2[c];
+                }
+                sh->v[ZV_SEQ_TOTALBITS] = bits;
+            }
+            ZB_SYNC();
+        }
+    }
+
+    /* ---- phase 8 (lane 0): final states (ML, OF, LL: read back as LL, OF, ML), end mark, size ---- */
+    ZB_SERIAL(zl)
+    {
+        uint32_t size = sh->v[ZV_SEQ_BITS0];
+        if (nbseq)
+        {
+            ZbBits bw;
+            uint32_t bits = sh->v[ZV_SEQ_TOTALBITS];
+            zb_bits_open(&bw, sc->out, size * 8u + bits);
+            if (sh->mode[ZT_ML] != 1u)
+            {
+                zb_bits_put(&bw, sh->v[ZV_FINAL_STATE + ZT_ML], sh->table_log[ZT_ML]);
+                bits += sh->table_log[ZT_ML];
+            }
+            if (sh->mode[ZT_OF] != 1u)
+            {
+                zb_bits_put(&bw, sh->v[ZV_FINAL_STATE + ZT_OF], sh->table_log[ZT_OF]);
+                bits += sh->table_log[ZT_OF];
+            }
+            if (sh->mode[ZT_LL] != 1u)
+            {
+                zb_bits_put(&bw, sh->v[ZV_FINAL_STATE + ZT_LL], sh->table_log[ZT_LL]);
+                bits += sh->table_log[ZT_LL];
+            }
+            zb_bits_put(&bw, 1u, 1u);
+            zb_bits_close(&bw);
+            size += (bits + 1u + 7u) >> 3;
+        }
+        sh->v[ZV_OUT_SIZE] = size < in->raw_size ? size : 0u;
+    }
+    ZB_SYNC();
+    return sh->v[ZV_OUT_SIZE];
+}
+
+#endif /* ZSTD_BLOCK_CORE_H */

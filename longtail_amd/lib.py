@@ -24,6 +24,7 @@ KERNEL_IDS = {
     "lz4_segments": 5,
     "lz4_stitch": 6,
     "other": 7,
+    "zstd_encode": 8,
 }
 
 
@@ -105,6 +106,7 @@ class HipLib:
         sig("lthip_lz4_decompress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_zstd_bound", sz, [sz])
         sig("lthip_zstd_compress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
+        sig("lthip_zstd_debug_units", i32, [vp, u64, u64, vp, vp, vp])
         sig("lthip_dedup_first_seen", i32, [vp, u64, vp, vp, vp])
         sig("lthip_gather_ranges", i32, [vp, vp, u64, vp, vp, vp, vp])
         sig("lthip_pack_blocks", i32, [u64, vp, u32, u32, vp, u64, P(u64)])
@@ -264,6 +266,16 @@ class Context:
     def zstd_compress_blocks(self, src, src_offsets, src_sizes, dst, dst_offsets, dst_caps):
         return self._codec(self.lib.dll.lthip_zstd_compress_blocks, src, src_offsets, src_sizes, dst, dst_offsets,
                            dst_caps)
+
+    def zstd_debug_units(self, first: int, count: int):
+        """Match-finder output of the last zstd_compress_blocks call: (meta[count,4] u32, lits[count,4096] u8,
+        recs[count,1024] u64) for the 4 KiB units [first, first+count)."""
+        meta = np.zeros((count, 4), np.uint32)
+        lits = np.zeros((count, 4096), np.uint8)
+        recs = np.zeros((count, 1024), np.uint64)
+        self._check(self.lib.dll.lthip_zstd_debug_units(self.h, first, count, meta.ctypes.data, lits.ctypes.data,
+                                                        recs.ctypes.data), "lthip_zstd_debug_units")
+        return meta, lits, recs
 
     # -- block assembly --
     def gather_ranges(self, src, src_offsets, lens, dst, dst_offsets):

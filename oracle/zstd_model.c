@@ -1,0 +1,165 @@
+/* zstd_model.c -- TEST INFRASTRUCTURE (see oracle/oracle.h): host build of the zstd block encoder that the GPU runs.
+ *
+ * longtail_amd/csrc/zstd_block_core.h is written once for two execution models; this file instantiates it with ONE
+ * lane, which makes it a bit-exact, GPU-free model of k_zstd.hip's entropy stage.  Tests use it two ways:
+ *   - here (no GPU): model frames are fed to the REFERENCE decoder (oracle/_ref, ZSTD_decompressDCtx behind
+ *     ZStdCompressionAPI_Decompress, lib/zstd/longtail_zstd.c:144-177) on many inputs, which pins the format work;
+ *   - on the GPU box: the match-finder output of the kernel is pushed through ltz_model_encode_block and must give
+ *     the kernel's bytes exactly.
+ * The sequences of ltz_model_compress come from a small greedy matcher below (any valid parse does; it is not a
+ * model of the GPU match finder).  Nothing in the product links this file.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ZB_LANES 1u
+#define ZB_FN static inline
+#define ZB_SYNC() ((void)0)
+static inline void zb_atomic_add(uint32_t* p, uint32_t v) { *p += v; }
+static inline void zb_atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
+
+static uint32_t g_ltz_dbg;
+#define ZB_DBG g_ltz_dbg
+#include "../longtail_amd/csrc/zstd_block_core.h"
+void ltz_model_debug(uint32_t flags) { g_ltz_dbg = flags; }
+
+#include "oracle.h"
+
+uint32_t ltz_model_encode_block(const void* meta, const uint8_t* unit_lits, const uint64_t* unit_recs, uint32_t nunits,
+                                uint32_t raw_size, uint8_t* out)
+{
+    ZbInput in;
+    ZbScratch sc;
+    ZbShared* sh = (ZbShared*)calloc(1, sizeof(ZbShared));
+    uint32_t n;
+    in.meta = (const ZbUnitMeta*)meta;
+    in.unit_lits = unit_lits;
+    in.unit_recs = unit_recs;
+    in.nunits = nunits;
+    in.raw_size = raw_size;
+    sc.lits = (uint8_t*)malloc(ZB_BLOCK_MAX + 8);
+    sc.seqs = (uint64_t*)malloc(sizeof(uint64_t) * ZB_SEQ_MAX);
+    sc.sbits = (uint16_t*)malloc(sizeof(uint16_t) * 3 * ZB_SEQ_MAX);
+    sc.out = (uint32_t*)malloc(ZB_OUT_BYTES);
+    n = zb_encode_block(&in, &sc, sh, 0);
+    if (n)
+        memcpy(out, sc.out, n);
+    free(sc.lits);
+    free(sc.seqs);
+    free(sc.sbits);
+    free(sc.out);
+    free(sh);
+    return n;
+}
+
+/* greedy matcher over one block: 4 KiB units, matches never cross a unit end, offsets < 65536 within the frame */
+static void model_match_block(const uint8_t* base, size_t block_off, uint32_t size, uint32_t* table, ZbUnitMeta* meta,
+                              uint8_t* unit_lits, uint64_t* unit_recs)
+{
+    const uint8_t* blk = base + block_off;
+    const uint32_t nunits = (size + ZB_UNIT - 1u) / ZB_UNIT;
+    for (uint32_t u = 0; u < nunits; ++u)
+    {
+        const uint32_t start = u * ZB_UNIT, end = start + ZB_UNIT < size ? start + ZB_UNIT : size;
+        uint32_t p = start, anchor = start, nseq = 0, nlit = 0;
+        uint8_t* lits = unit_lits + (size_t)u * ZB_UNIT;
+        uint64_t* recs = unit_recs + (size_t)u * ZB_UNIT_SEQ_MAX;
+        while (p + 4u <= end)
+        {
+            uint32_t v, h;
+            size_t abs_p = block_off + p, cand;
+            memcpy(&v, blk + p, 4);
+            h = (v * 2654435761u) >> 18;
+            cand = table[h];
+            table[h] = (uint32_t)abs_p + 1u;
+            if (cand && abs_p - (cand - 1u) < 65536u && abs_p - (cand - 1u) > 0 && memcmp(base + cand - 1u, blk + p, 4) == 0)
+            {
+                const uint8_t* m = base + cand - 1u;
+                uint32_t len = 4;
+                while (p + len < end && m[len] == blk[p + len])
+                    ++len;
+                memcpy(lits + nlit, blk + anchor, p - anchor);
+                nlit += p - anchor;
+                recs[nseq++] = ZB_REC(p - anchor, len, abs_p - (cand - 1u));
+                p += len;
+                anchor = p;
+            }
+            else
+                ++p;
+        }
+        memcpy(lits + nlit, blk + anchor, end - anchor);
+        nlit += end - anchor;
+        meta[u].nseq = nseq;
+        meta[u].nlit = nlit;
+        meta[u].tail = end - anchor;
+        meta[u].pad = 0;
+    }
+}
+
+size_t ltz_model_bound(size_t n) { return n + (n >> 8) + 64 + 3 * (n / ZB_BLOCK_MAX + 1); }
+
+/* One frame: magic | FHD 0xE0 | u64 content size | blocks {last:1,type:2,size:21} (same container as k_zstd.hip). */
+int ltz_model_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n)
+{
+    size_t pos = 0, off = 0;
+    uint32_t* table;
+    ZbUnitMeta meta[ZB_MAX_UNITS];
+    uint8_t* unit_lits;
+    uint64_t* unit_recs;
+    uint8_t* enc;
+    if (cap < ltz_model_bound(n))
+        return -1;
+    table = (uint32_t*)calloc(1u << 14, sizeof(uint32_t));
+    unit_lits = (uint8_t*)malloc(ZB_BLOCK_MAX);
+    unit_recs = (uint64_t*)malloc(sizeof(uint64_t) * ZB_SEQ_MAX);
+    enc = (uint8_t*)malloc(ZB_OUT_BYTES);
+    dst[pos++] = 0x28;
+    dst[pos++] = 0xB5;
+    dst[pos++] = 0x2F;
+    dst[pos++] = 0xFD;
+    dst[pos++] = 0xE0;
+    for (int i = 0; i < 8; ++i)
+        dst[pos++] = (uint8_t)((uint64_t)n >> (8 * i));
+    if (n == 0)
+    {
+        dst[pos++] = 1;
+        dst[pos++] = 0;
+        dst[pos++] = 0;
+    }
+    while (off < n)
+    {
+        const uint32_t size = n - off < ZB_BLOCK_MAX ? (uint32_t)(n - off) : ZB_BLOCK_MAX;
+        const uint32_t last = off + size == n;
+        uint32_t csize, rle = 1;
+        for (uint32_t i = 1; i < size && rle; ++i)
+            rle = src[off + i] == src[off];
+        if (rle)
+        {
+            const uint32_t h = last | (1u << 1) | (size << 3);
+            dst[pos++] = (uint8_t)h;
+            dst[pos++] = (uint8_t)(h >> 8);
+            dst[pos++] = (uint8_t)(h >> 16);
+            dst[pos++] = src[off];
+            off += size;
+            continue;
+        }
+        model_match_block(src, off, size, table, meta, unit_lits, unit_recs);
+        csize = ltz_model_encode_block(meta, unit_lits, unit_recs, (size + ZB_UNIT - 1u) / ZB_UNIT, size, enc);
+        {
+            const uint32_t h = last | ((csize ? 2u : 0u) << 1) | ((csize ? csize : size) << 3);
+            dst[pos++] = (uint8_t)h;
+            dst[pos++] = (uint8_t)(h >> 8);
+            dst[pos++] = (uint8_t)(h >> 16);
+            memcpy(dst + pos, csize ? enc : src + off, csize ? csize : size);
+            pos += csize ? csize : size;
+        }
+        off += size;
+    }
+    free(table);
+    free(unit_lits);
+    free(unit_recs);
+    free(enc);
+    *out_n = pos;
+    return 0;
+}

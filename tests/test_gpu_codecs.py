@@ -116,18 +116,86 @@ def test_lz4_gpu_decoder_on_reference_payloads(gpu, oracle):
     assert (int(sizes[0]) == 0xFFFFFFFF) == (n < 0)
 
 
-def test_zstd_stage1_frames_decode_with_reference(gpu, oracle, ref):
-    blocks = [oracle.synth(n, 40 + n, k) for k in (0, 1, 2) for n in (0, 1, 100, 131071, 131072, 131073, 400000)]
+def gpu_zstd(gpu, blocks):
     dev, offs = to_device(blocks)
     caps = [len(b) + (len(b) >> 8) + 64 for b in blocks]
     d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
     dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
     sizes = u32(gpu.zstd_compress_blocks(dev, offs, [len(b) for b in blocks], dst, d_offs, caps))
     host = dst.cpu().numpy()
-    for b, o, s in zip(blocks, d_offs, sizes):
-        assert int(s) > 0
-        err, out = ref.decompress(1, host[o : o + int(s)].copy(), len(b))
+    return [host[o : o + int(s)].copy() for o, s in zip(d_offs, sizes)]
+
+
+def zstd_pieces(frame: np.ndarray):
+    """[(type, payload bytes)] of a single-segment frame with an 8-byte content size (the layout k_zstd.hip writes)."""
+    assert bytes(frame[:5]) == bytes([0x28, 0xB5, 0x2F, 0xFD, 0xE0])
+    pos, out = 13, []
+    while True:
+        h = int(frame[pos]) | int(frame[pos + 1]) << 8 | int(frame[pos + 2]) << 16
+        last, typ, size = h & 1, (h >> 1) & 3, h >> 3
+        n = 1 if typ == 1 else size
+        out.append((typ, frame[pos + 3 : pos + 3 + n]))
+        pos += 3 + n
+        if last:
+            break
+    assert pos == len(frame)
+    return out
+
+
+def test_zstd_frames_decode_with_reference(gpu, oracle, ref):
+    blocks = [oracle.synth(n, 40 + n, k) for k in (0, 1, 2, 11, 12, 13) for n in (0, 1, 100, 5000, 131071, 131072, 131073, 400000)]
+    blocks.append(oracle.synth((8 << 20) + 12345, 7, 1))
+    rng = np.random.default_rng(3)
+    blocks.append((np.abs(rng.normal(128, 20, 700000)).astype(np.int64) % 256).astype(np.uint8))  # Huffman, FSE-coded weights
+    blocks.append(np.frombuffer(b"the quick brown fox jumps over the lazy dog. " * 9000, np.uint8).copy())
+    frames = gpu_zstd(gpu, blocks)
+    for b, f in zip(blocks, frames):
+        assert len(f) > 0
+        err, out = ref.decompress(1, f, len(b))
         assert err == 0 and len(out) == len(b) and (out == b).all()
     # all-zero input collapses to RLE blocks
     z = [i for i, b in enumerate(blocks) if len(b) == 400000 and not b.any()]
-    assert z and int(sizes[z[0]]) < 100
+    assert z and len(frames[z[0]]) < 100
+
+
+def test_zstd_compresses(gpu, oracle):
+    """Compressed_Blocks are really produced, and beat the LZ4 payload of the same parse on entropy-codable data."""
+    blocks = [oracle.synth(2 << 20, 3, k) for k in (1, 11, 12, 13)]
+    frames = gpu_zstd(gpu, blocks)
+    lz4, _ = gpu_lz4(gpu, blocks)
+    for b, f, l in zip(blocks, frames, lz4):
+        kinds = [t for t, _ in zstd_pieces(f)]
+        assert kinds.count(2) >= len(kinds) // 2
+        assert len(f) < len(l)
+
+
+def test_zstd_entropy_stage_is_bit_exact_with_host_model(gpu, oracle):
+    """k_zstd_encode and oracle/zstd_model.c compile the SAME zstd_block_core.h (64 lanes vs 1): fed with the GPU match
+    finder's own output, the host model must reproduce every Compressed_Block byte for byte."""
+    import ctypes as C
+
+    d = oracle.dll
+    d.ltz_model_encode_block.restype = C.c_uint32
+    d.ltz_model_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    rng = np.random.default_rng(5)
+    blocks = [oracle.synth(n, 90 + n, k) for k, n in ((1, 1 << 20), (11, 300000), (12, 131072), (13, 200000), (0, 140000))]
+    blocks.append((np.abs(rng.normal(128, 20, 400000)).astype(np.int64) % 256).astype(np.uint8))
+    frames = gpu_zstd(gpu, blocks)
+    unit0 = 0
+    checked = 0
+    for b, f in zip(blocks, frames):
+        nunits = (len(b) + 4095) // 4096
+        meta, lits, recs = gpu.zstd_debug_units(unit0, nunits)
+        for i, (typ, payload) in enumerate(zstd_pieces(f)):
+            raw = min(131072, len(b) - i * 131072)
+            nu = (raw + 4095) // 4096
+            out = np.zeros(140000, np.uint8)
+            m, l, r = (np.ascontiguousarray(a[i * 32 : i * 32 + nu]) for a in (meta, lits, recs))
+            n = d.ltz_model_encode_block(m.ctypes.data, l.ctypes.data, r.ctypes.data, nu, raw, out.ctypes.data)
+            if typ == 2:
+                assert n == len(payload) and (out[:n] == payload).all()
+                checked += 1
+            elif typ == 0:
+                assert n == 0
+        unit0 += nunits
+    assert checked >= 10

@@ -1,0 +1,112 @@
+"""The zstd block encoder (longtail_amd/csrc/zstd_block_core.h) instantiated on the host (oracle/zstd_model.c) against the
+REFERENCE decoder: ZStdCompressionAPI_Decompress -> ZSTD_decompressDCtx (lib/zstd/longtail_zstd.c:144-177).  The same
+source runs one wavefront per piece on the GPU (k_zstd.hip) and must give these bytes (tests/test_gpu_codecs.py), so
+this file pins the format work -- literals section / Huffman tree description / 4 streams, NCount, FSE tables and the
+sequence bit-stream -- without a GPU.  Needs oracle/_ref (built by `make -C oracle` where /root/reference exists)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests._libs import have_ref, oracle as get_oracle, ref as get_ref
+
+pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
+
+CODEC_ZSTD = 1
+
+
+@pytest.fixture(scope="module")
+def model():
+    o = get_oracle()
+    d = o.dll
+    d.ltz_model_bound.restype = C.c_size_t
+    d.ltz_model_bound.argtypes = [C.c_size_t]
+    d.ltz_model_compress.restype = C.c_int
+    d.ltz_model_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    d.ltz_model_encode_block.restype = C.c_uint32
+    d.ltz_model_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    d.ltz_model_debug.restype = None
+    d.ltz_model_debug.argtypes = [C.c_uint32]
+    return o
+
+
+def compress(o, b: np.ndarray) -> np.ndarray:
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    cap = o.dll.ltz_model_bound(len(b))
+    out = np.zeros(cap + 8, np.uint8)
+    n = C.c_size_t(0)
+    assert o.dll.ltz_model_compress(b.ctypes.data, len(b), out.ctypes.data, cap, C.byref(n)) == 0
+    return out[: n.value].copy()
+
+
+def roundtrip(o, b: np.ndarray) -> int:
+    c = compress(o, b)
+    err, out = get_ref().decompress(CODEC_ZSTD, c, len(b))
+    assert err == 0 and len(out) == len(b) and (out == b).all()
+    return len(c)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 11, 12, 13])
+@pytest.mark.parametrize("n", [0, 1, 100, 255, 256, 257, 5000, 131071, 131072, 131073, 400000])
+def test_synthetic_kinds_decode_with_reference(model, kind, n):
+    roundtrip(model, model.synth(n, 1000 + n + kind, kind))
+
+
+def test_compressible_data_gets_smaller_than_lz4(model):
+    b = model.synth(2 << 20, 5, 1)
+    assert roundtrip(model, b) < len(model.lz4_compress(b))
+
+
+def _alphabets():
+    rng = np.random.default_rng(11)
+    yield "two symbols", rng.choice(2, 3000, p=[0.9, 0.1]).astype(np.uint8)
+    yield "deep tree (length limit)", (rng.geometric(0.5, 200000) - 1).clip(0, 40).astype(np.uint8)
+    yield "128 symbols flat (direct weights, all equal)", rng.integers(0, 128, 100000).astype(np.uint8)
+    yield "129 symbols (FSE-compressed weights)", rng.integers(0, 129, 100000).astype(np.uint8)
+    yield "high bytes only", (rng.geometric(0.3, 50000).clip(1, 30) + 200).astype(np.uint8)
+    yield "gaussian bytes", (np.abs(rng.normal(128, 20, 300000)).astype(np.int64) % 256).astype(np.uint8)
+    yield "nibbles then noise", np.concatenate([rng.integers(0, 16, 100000), rng.integers(0, 256, 100000)]).astype(np.uint8)
+    yield "text", np.frombuffer((b"the quick brown fox jumps over the lazy dog. " * 4000), np.uint8).copy()
+    t = rng.integers(0, 256, (4096, 8)).astype(np.uint8)
+    yield "vocabulary of 8-byte tokens", t[rng.integers(0, 4096, 60000)].reshape(-1)
+    yield "long literal runs and long matches", np.concatenate([rng.integers(0, 256, 70000).astype(np.uint8)] * 3)
+
+
+@pytest.mark.parametrize("name,data", list(_alphabets()), ids=[n for n, _ in _alphabets()])
+def test_literal_and_sequence_shapes(model, name, data):
+    roundtrip(model, data)
+
+
+@pytest.mark.parametrize("flags", [1, 2, 4, 6])
+def test_every_table_mode(model, flags):
+    """1: raw literals; 2: never the predefined distributions; 4: only predefined / RLE."""
+    model.dll.ltz_model_debug(flags)
+    try:
+        for kind, n in [(1, 300000), (11, 5000), (12, 70000), (13, 131072)]:
+            roundtrip(model, model.synth(n, 9 + n, kind))
+    finally:
+        model.dll.ltz_model_debug(0)
+
+
+def test_encode_block_from_records_maximum_sequence_count(model):
+    """32 units x 1024 sequences of 4 bytes (the 3-byte Number_of_Sequences form, >= 0x7F00)."""
+    nunits = 32
+    meta = np.zeros((nunits, 4), np.uint32)
+    lits = np.zeros((nunits, 4096), np.uint8)
+    recs = np.zeros((nunits, 1024), np.uint64)
+    pat = np.array([1, 2, 3, 4], np.uint8)
+    for u in range(nunits):
+        first_lit = 4 if u == 0 else 0
+        nseq = 1023 if u == 0 else 1024
+        recs[u, :nseq] = 4 << 16 | 4 << 32
+        recs[u, 0] |= first_lit
+        lits[u, :first_lit] = pat[:first_lit]
+        meta[u] = (nseq, first_lit, 0, 0)
+    out = np.zeros(140000, np.uint8)
+    n = model.dll.ltz_model_encode_block(meta.ctypes.data, lits.ctypes.data, recs.ctypes.data, nunits, 131072, out.ctypes.data)
+    assert 0 < n < 131072
+    raw = np.tile(pat, 32768)
+    frame = np.concatenate([np.frombuffer(bytes([0x28, 0xB5, 0x2F, 0xFD, 0xE0]) + (131072).to_bytes(8, "little"), np.uint8),
+                            np.frombuffer((1 | 2 << 1 | n << 3).to_bytes(3, "little"), np.uint8), out[:n]])
+    err, dec = get_ref().decompress(CODEC_ZSTD, frame, len(raw))
+    assert err == 0 and (dec == raw).all()
