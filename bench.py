@@ -73,7 +73,8 @@ def main():
     ap.add_argument("--target-chunk-size", type=int, default=65536)
     ap.add_argument("--block-size", type=int, default=8 << 20)
     ap.add_argument("--max-chunks-per-block", type=int, default=1024)
-    ap.add_argument("--lz4-batch-gib", type=float, default=8.0)
+    ap.add_argument("--lz4-batch-gib", "--batch-gib", dest="lz4_batch_gib", type=float, default=8.0)
+    ap.add_argument("--codec", choices=["lz4", "zstd"], default="lz4", help="block codec of phase 2 (BASELINE.json configs[4] uses zstd)")
     ap.add_argument("--segment-log2", type=int, default=0)
     ap.add_argument("--no-compress", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,6 +158,11 @@ def main():
     gather_arena = None  # allocated on first use: only trees whose blocks are not contiguous ranges need it
     stats = {}
 
+    def compress(src, s_offs, s_sizes, dst_t, d_offs, caps):
+        if args.codec == "zstd":
+            return ctx.zstd_compress_blocks(src, s_offs, s_sizes, dst_t, d_offs, caps)
+        return ctx.lz4_compress_blocks(src, s_offs, s_sizes, dst_t, d_offs, caps, args.segment_log2)
+
     def step():
         t0 = time.perf_counter()
         plan = ctx.make_plan(part_offsets, part_sizes, mn, av, mx)
@@ -195,7 +201,7 @@ def main():
                     d_offs_u, d_lens_u = out_offs[:total][unique_mask], out_lens[:total][unique_mask]
                 else:
                     d_offs_u, d_lens_u = out_offs[:total], out_lens[:total]
-            bounds = b_size + b_size // 255 + 16
+            bounds = b_size + b_size // 255 + 16 if args.codec == "lz4" else b_size + (b_size >> 8) + 64
             aligned = (bounds + 63) // 64 * 64
             i = 0
             size_tensors = []
@@ -205,8 +211,7 @@ def main():
                 j = max(j, i + 1)
                 d_offs = np.concatenate([[0], np.cumsum(aligned[i:j])[:-1]])
                 if contiguous:
-                    size_tensors.append(ctx.lz4_compress_blocks(data, offs_h[b_first[i:j]], b_size[i:j], dst, d_offs, bounds[i:j],
-                                                                args.segment_log2))
+                    size_tensors.append(compress(data, offs_h[b_first[i:j]], b_size[i:j], dst, d_offs, bounds[i:j]))
                 else:
                     # block assembly on the device (WriteContentBlockJob, src/longtail.c:4640-4721): gather this batch's
                     # chunks back to back, then every block is a contiguous range of the gather arena
@@ -214,13 +219,12 @@ def main():
                     lens_d = d_lens_u[c0:c1]
                     dst_off = torch.cumsum(lens_d.to(torch.int64), 0) - lens_d.to(torch.int64)
                     ctx.gather_ranges(data, d_offs_u[c0:c1].contiguous(), lens_d.contiguous(), gather_arena, dst_off)
-                    size_tensors.append(ctx.lz4_compress_blocks(gather_arena, cs0[starts[i:j]] - cs0[c0], b_size[i:j], dst, d_offs,
-                                                                bounds[i:j], args.segment_log2))
+                    size_tensors.append(compress(gather_arena, cs0[starts[i:j]] - cs0[c0], b_size[i:j], dst, d_offs, bounds[i:j]))
                 i = j
             sizes = torch.cat(size_tensors).to(torch.int64)
             comp_bytes = int(sizes.sum().item())
             if int((sizes == 0).sum().item()) != 0:
-                raise SystemExit("a block did not fit its LZ4 bound: encoder bug")
+                raise SystemExit("a block did not fit its bound: encoder bug")
         ctx.sync()
         t3 = time.perf_counter()
         stats.update(chunks=total, unique_local=n_unique_local, unique_global=int(uniq.item()), blocks=nblocks,
@@ -261,6 +265,7 @@ def main():
         "blake3_leaf": shard_bytes,             # N read once
         "lz4_segments": shard_bytes,            # N read (sequence streams are a by-product)
         "lz4_stitch": shard_bytes + comp,       # literals/streams read + payload written
+        "zstd_encode": shard_bytes + comp,      # literals + sequences read, pieces written
     }
     kern = {}
     for name, (ms, n) in ktimes.items():
@@ -312,9 +317,9 @@ def main():
             "dtype": "u8/u32",
             "data": "synthetic",
             "config": {
-                "workload": (f"{args.gib:g} GiB tree of {args.file_mib:g} MiB {args.kind} files per GPU, chunk+BLAKE3+LZ4 "
+                "workload": (f"{args.gib:g} GiB tree of {args.file_mib:g} MiB {args.kind} files per GPU, chunk+BLAKE3+{args.codec.upper()} "
                              f"(BASELINE.json configs[2]{'/[3]' if world > 1 else ''})") if args.tree == "files" else
-                            (f"{args.gib:g} GiB tree of {nfiles} {args.kind} files, 4 KiB..4 GiB log-uniform, per GPU, chunk+BLAKE3+LZ4 "
+                            (f"{args.gib:g} GiB tree of {nfiles} {args.kind} files, 4 KiB..4 GiB log-uniform, per GPU, chunk+BLAKE3+{args.codec.upper()} "
                              f"(north-star tree)"),
                 "target_chunk_size": args.target_chunk_size, "min_avg_max": [mn, av, mx], "block_size": args.block_size,
                 "max_chunks_per_block": args.max_chunks_per_block, "bytes_per_gpu": shard_bytes, "files_per_gpu": nfiles, "parts_per_gpu": nparts, "device_block_assembly": bool(stats.get("gather")),

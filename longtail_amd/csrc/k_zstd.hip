@@ -11,10 +11,24 @@
 #include "lthip_internal.h"
 
 #define ZB_LANES 64u
-#define ZB_FN __device__
+#define ZB_FN __device__ __forceinline__ /* inlined so that LDS / global address spaces are known at every access */
 #define ZB_SYNC() __syncthreads() /* the encoder runs in one-wave workgroups */
 __device__ __forceinline__ void zb_atomic_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 __device__ __forceinline__ void zb_atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+#ifdef LTHIP_ZB_PROF /* debug build only: cycles per phase of zb_encode_block, summed over all pieces (lane 0) */
+__device__ unsigned long long g_zb_prof[16];
+__device__ unsigned long long g_zb_last[1 << 16];
+#define ZB_MARK(i)                                                                                     \
+    do                                                                                                 \
+    {                                                                                                  \
+        if (threadIdx.x == 0)                                                                          \
+        {                                                                                              \
+            const unsigned long long now__ = wall_clock64();                                           \
+            atomicAdd(&g_zb_prof[i], now__ - g_zb_last[blockIdx.x]);                                   \
+            g_zb_last[blockIdx.x] = now__;                                                             \
+        }                                                                                              \
+    } while (0)
+#endif
 #include "zstd_block_core.h"
 
 namespace
@@ -33,8 +47,8 @@ struct ZBlock
 };
 
 constexpr uint32_t ZB = ZB_BLOCK_MAX;
-constexpr size_t Z_WORK_LITS = ZB_BLOCK_MAX + 64, Z_WORK_SEQS = sizeof(uint64_t) * ZB_SEQ_MAX, Z_WORK_SBITS = sizeof(uint16_t) * 3 * ZB_SEQ_MAX;
-constexpr size_t Z_WORK_STRIDE = Z_WORK_LITS + Z_WORK_SEQS + Z_WORK_SBITS;
+constexpr size_t Z_WORK_SEQS = sizeof(uint64_t) * ZB_SEQ_MAX, Z_WORK_SBITS = sizeof(uint16_t) * 3 * ZB_SEQ_MAX;
+constexpr size_t Z_WORK_STRIDE = Z_WORK_SEQS + Z_WORK_SBITS;
 constexpr uint32_t ZHDR = 13u;
 constexpr int ZT = 256;
 
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(ZT) void k_zstd_emit(const uint8_t* __restrict__ sr
 }
 
 // One wavefront per 128 KiB piece, persistent over the pieces: the entropy stage of zstd_block_core.h.
-__global__ __launch_bounds__(64) void k_zstd_encode(const ZBlock* __restrict__ blocks, uint32_t nblocks, uint32_t npieces,
+__global__ __launch_bounds__(64, 3) void k_zstd_encode(const ZBlock* __restrict__ blocks, uint32_t nblocks, uint32_t npieces,
                                                     const uint8_t* __restrict__ is_rle, const ZbUnitMeta* __restrict__ unit_meta,
                                                     const uint8_t* __restrict__ unit_lits, const uint64_t* __restrict__ unit_recs,
                                                     uint8_t* __restrict__ work, uint8_t* __restrict__ enc,
@@ -177,9 +191,8 @@ __global__ __launch_bounds__(64) void k_zstd_encode(const ZBlock* __restrict__ b
     __shared__ ZbShared sh;
     ZbScratch sc;
     uint8_t* w = work + (uint64_t)blockIdx.x * Z_WORK_STRIDE;
-    sc.lits = w;
-    sc.seqs = reinterpret_cast<uint64_t*>(w + Z_WORK_LITS);
-    sc.sbits = reinterpret_cast<uint16_t*>(w + Z_WORK_LITS + Z_WORK_SEQS);
+    sc.seqs = reinterpret_cast<uint64_t*>(w);
+    sc.sbits = reinterpret_cast<uint16_t*>(w + Z_WORK_SEQS);
     for (uint32_t zb = blockIdx.x; zb < npieces; zb += gridDim.x)
     {
         if (is_rle[zb])
@@ -208,6 +221,10 @@ __global__ __launch_bounds__(64) void k_zstd_encode(const ZBlock* __restrict__ b
         in.nunits = (len + ZB_UNIT - 1u) / ZB_UNIT;
         in.raw_size = len;
         sc.out = reinterpret_cast<uint32_t*>(enc + (uint64_t)zb * ZB_OUT_BYTES);
+#ifdef LTHIP_ZB_PROF
+        if (threadIdx.x == 0)
+            g_zb_last[blockIdx.x] = wall_clock64();
+#endif
         const uint32_t n = zb_encode_block(&in, &sc, &sh, threadIdx.x);
         if (threadIdx.x == 0)
             enc_size[zb] = n;
@@ -326,6 +343,21 @@ extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uin
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
 }
+
+#ifdef LTHIP_ZB_PROF
+extern "C" __attribute__((visibility("default"))) int lthip_zb_prof_dump(void)
+{
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_zb_prof), sizeof(h)) != hipSuccess)
+        return -1;
+    for (int i = 0; i < 16; ++i)
+        if (h[i])
+            fprintf(stderr, "zb phase ending at mark %2d: %.3f ms wave-time (100 MHz clock)\n", i, (double)h[i] / 1e5);
+    memset(h, 0, sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_zb_prof), h, sizeof(h));
+    return 0;
+}
+#endif
 
 // Diagnostics for the parity tests: the match finder's output of the LAST lthip_zstd_compress_blocks call on this
 // context (units [first, first+count)), so that the host model of the entropy stage can be run on the same input.

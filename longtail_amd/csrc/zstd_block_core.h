@@ -31,6 +31,9 @@
 #ifndef ZB_DBG
 #define ZB_DBG 0u /* host model only: 1 raw literals, 2 never predefined, 4 never FSE-compressed tables */
 #endif
+#ifndef ZB_MARK
+#define ZB_MARK(i) ((void)0) /* profiling hook of the kernel build (phase boundaries) */
+#endif
 #define ZB_PAR_FOR(i, n) for (uint32_t i = zl; i < (uint32_t)(n); i += ZB_LANES)
 #define ZB_SERIAL(zl) if ((zl) == 0)
 
@@ -69,7 +72,6 @@ typedef struct ZbInput
 
 typedef struct ZbScratch /* global memory owned by the lanes of one block encoder */
 {
-    uint8_t* lits;   /* [ZB_BLOCK_MAX + 8]  the block's literals, concatenated */
     uint64_t* seqs;  /* [ZB_SEQ_MAX]        merged sequences */
     uint16_t* sbits; /* [3 * ZB_SEQ_MAX]    FSE state-transition bits per sequence: nbBits << 10 | bits */
     uint32_t* out;   /* [ZB_OUT_BYTES / 4]  the encoded block */
@@ -82,6 +84,8 @@ enum
     ZV_HUF_OK,
     ZV_HUF_MAXBITS,
     ZV_HUF_MAXSYM,
+    ZV_HUF_NSYM,
+    ZV_SKIP,
     ZV_LIT_MODE, /* 0 raw, 2 huffman */
     ZV_LIT_HDR,  /* bytes of the literals section header */
     ZV_TREE_BYTES,
@@ -98,7 +102,7 @@ enum
 typedef struct ZbShared /* LDS on the GPU (about 9.5 KiB per wave) */
 {
     uint32_t lit_hist[256];
-    uint32_t sort_key[256]; /* Huffman construction: present symbols sorted by count */
+    uint32_t sort_key[256]; /* Huffman construction: present symbols sorted by count (sort_key+huf_w: FSE code tile) */
     uint32_t huf_w[256];    /* ... weights / parent links / depths (Moffat-Katajainen, in place) */
     uint8_t huf_l[256];     /* ... code length per sorted position */
     uint8_t tree[160];      /* Huffman tree description */
@@ -475,36 +479,43 @@ ZB_FN uint32_t zb_fse_step(uint32_t* x, uint32_t s, const int16_t* norm, const u
 /* ------------------------------------------------------------------------------------------------------------
  * Huffman code lengths (<= 11 bits) for the literals
  * ---------------------------------------------------------------------------------------------------------- */
-/* In: sh->lit_hist.  Out: sh->huf_len / huf_code, v[ZV_HUF_*].  Serial (one lane). */
+/* Rank sort of the present literal symbols by (count, symbol) ascending into sh->sort_key; v[ZV_HUF_NSYM] = how
+ * many.  All lanes (256 independent rank computations; the inner reads are wave-uniform LDS broadcasts). */
+ZB_FN void zb_huffman_sort(ZbShared* sh, uint32_t zl)
+{
+    ZB_PAR_FOR(s, 256u)
+    {
+        const uint32_t c = sh->lit_hist[s];
+        sh->huf_len[s] = 0;
+        if (c)
+        {
+            uint32_t rank = 0;
+            for (uint32_t t = 0; t < 256u; ++t)
+            {
+                const uint32_t ct = sh->lit_hist[t];
+                rank += (ct != 0u) & ((ct < c) | ((ct == c) & (t < s)));
+            }
+            sh->sort_key[rank] = s;
+            zb_atomic_add(&sh->v[ZV_HUF_NSYM], 1u);
+        }
+    }
+}
+
+/* In: sh->lit_hist, sh->sort_key (zb_huffman_sort).  Out: sh->huf_len / huf_code, v[ZV_HUF_*].  Serial (one lane). */
 ZB_FN void zb_huffman_build(ZbShared* sh)
 {
     uint32_t* A = sh->sort_key;
-    uint32_t n = 0, maxsym = 0;
+    const uint32_t n = sh->v[ZV_HUF_NSYM];
     sh->v[ZV_HUF_OK] = 0;
-    for (uint32_t s = 0; s < 256u; ++s)
-    {
-        sh->huf_len[s] = 0;
-        if (sh->lit_hist[s])
-        {
-            A[n++] = s;
-            maxsym = s;
-        }
-    }
-    sh->v[ZV_HUF_MAXSYM] = maxsym;
     if (n < 2u)
         return;
-    /* sort the present symbols by (count, symbol) ascending: insertion sort on indices */
-    for (uint32_t i = 1; i < n; ++i)
-    {
-        const uint32_t s = A[i], c = sh->lit_hist[s];
-        uint32_t j = i;
-        while (j > 0u && sh->lit_hist[A[j - 1u]] > c)
+    sh->v[ZV_HUF_MAXSYM] = 0;
+    for (uint32_t s = 256u; s-- > 0u;)
+        if (sh->lit_hist[s])
         {
-            A[j] = A[j - 1u];
-            --j;
+            sh->v[ZV_HUF_MAXSYM] = s;
+            break;
         }
-        A[j] = s;
-    }
     /* minimum-redundancy code lengths in place (Moffat & Katajainen): W[i] starts as the sorted weights */
     {
         uint32_t* W = sh->huf_w;
@@ -722,6 +733,63 @@ ZB_FN uint32_t zb_write_huf_tree(ZbShared* sh, uint8_t* dst)
 /* ------------------------------------------------------------------------------------------------------------
  * the block encoder
  * ---------------------------------------------------------------------------------------------------------- */
+/* The block's literals are the units' literal buffers back to back (unit u holds literals ulit_base[u] ..
+ * ulit_base[u+1]).  A lane walks its run of literal indices up or down; the reader keeps the current unit and one
+ * cached 32-bit word. */
+typedef struct ZbLitReader
+{
+    const uint8_t* unit_lits;
+    const uint32_t* ulit_base; /* [nunits + 1] */
+    uint32_t nunits, u, lo, hi, cw, cwi;
+} ZbLitReader;
+
+ZB_FN void zb_lit_open(ZbLitReader* r, const uint8_t* unit_lits, const uint32_t* ulit_base, uint32_t nunits, uint32_t k)
+{
+    uint32_t lo = 0, hi = nunits;
+    r->unit_lits = unit_lits;
+    r->ulit_base = ulit_base;
+    r->nunits = nunits;
+    while (hi - lo > 1u)
+    {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ulit_base[mid] <= k)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    r->u = lo;
+    r->lo = ulit_base[lo];
+    r->hi = ulit_base[lo + 1u];
+    r->cw = 0;
+    r->cwi = 0xFFFFFFFFu;
+}
+
+ZB_FN uint32_t zb_lit_get(ZbLitReader* r, uint32_t k) /* k < total literals */
+{
+    while (k >= r->hi)
+    {
+        ++r->u;
+        r->lo = r->hi;
+        r->hi = r->ulit_base[r->u + 1u];
+    }
+    while (k < r->lo)
+    {
+        --r->u;
+        r->hi = r->lo;
+        r->lo = r->ulit_base[r->u];
+    }
+    {
+        const uint32_t addr = r->u * ZB_UNIT + (k - r->lo);
+        const uint32_t wi = addr >> 2;
+        if (wi != r->cwi)
+        {
+            r->cw = ((const uint32_t*)r->unit_lits)[wi];
+            r->cwi = wi;
+        }
+        return (r->cw >> (8u * (addr & 3u))) & 255u;
+    }
+}
+
 ZB_FN uint32_t zb_of_code(uint32_t off) { return zb_highbit(off + 3u); }
 
 /* Encodes one block.  Returns the size of the Compressed_Block content in sc->out, or 0 when it would not be
@@ -730,18 +798,27 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
 {
     uint8_t* const out8 = (uint8_t*)sc->out;
 
-    /* ---- phase 0: unit bases; zero the histograms and the output ---- */
+    /* ---- phase 0: unit bases; zero the histograms ---- */
+    ZB_PAR_FOR(u, in->nunits)
+    {
+        const ZbUnitMeta m = in->meta[u];
+        sh->useq_base[u] = m.nseq; /* counts now, bases after the scan below */
+        sh->ulit_base[u] = m.nlit;
+        sh->carry[u] = m.tail;
+    }
+    ZB_SYNC();
     ZB_SERIAL(zl)
     {
         uint32_t nseq = 0, nlit = 0, carry = 0;
         for (uint32_t u = 0; u < in->nunits; ++u)
         {
+            const uint32_t un = sh->useq_base[u], ul = sh->ulit_base[u], ut = sh->carry[u];
             sh->useq_base[u] = nseq;
             sh->ulit_base[u] = nlit;
             sh->carry[u] = carry;
-            nseq += in->meta[u].nseq;
-            nlit += in->meta[u].nlit;
-            carry = in->meta[u].nseq ? in->meta[u].tail : carry + in->meta[u].nlit;
+            nseq += un;
+            nlit += ul;
+            carry = un ? ut : carry + ul;
         }
         sh->useq_base[in->nunits] = nseq;
         sh->ulit_base[in->nunits] = nlit;
@@ -750,10 +827,10 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     }
     ZB_PAR_FOR(i, 256u) sh->lit_hist[i] = 0;
     ZB_PAR_FOR(i, 3u * 64u) sh->sym_hist[i >> 6][i & 63u] = 0;
-    ZB_PAR_FOR(i, ZB_OUT_BYTES / 4u) sc->out[i] = 0;
     ZB_SYNC();
     const uint32_t nbseq = sh->v[ZV_NBSEQ], nlit = sh->v[ZV_NLIT];
 
+    ZB_MARK(1);
     /* ---- phase 1: merge the units: sequences (with their symbol histograms) and literals (with theirs) ---- */
     ZB_PAR_FOR(i, nbseq)
     {
@@ -779,28 +856,58 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     }
     for (uint32_t u = 0; u < in->nunits; ++u)
     {
-        const uint8_t* src = in->unit_lits + (uint64_t)u * ZB_UNIT;
-        uint8_t* dst = sc->lits + sh->ulit_base[u];
-        ZB_PAR_FOR(j, in->meta[u].nlit)
+        /* histogram only (the unit buffers are 4 KiB aligned; bytes past nlit are masked off): most incompressible
+         * blocks stop right after it */
+        const uint32_t* src = (const uint32_t*)(in->unit_lits + (uint64_t)u * ZB_UNIT);
+        const uint32_t n = sh->ulit_base[u + 1u] - sh->ulit_base[u];
+        ZB_PAR_FOR(j, (n + 3u) >> 2)
         {
-            const uint8_t b = src[j];
-            dst[j] = b;
-            zb_atomic_add(&sh->lit_hist[b], 1u);
+            const uint32_t w = src[j];
+            const uint32_t k = n - 4u * j; /* valid bytes in this word, >= 1 */
+            zb_atomic_add(&sh->lit_hist[w & 255u], 1u);
+            if (k > 1u)
+                zb_atomic_add(&sh->lit_hist[(w >> 8) & 255u], 1u);
+            if (k > 2u)
+                zb_atomic_add(&sh->lit_hist[(w >> 16) & 255u], 1u);
+            if (k > 3u)
+                zb_atomic_add(&sh->lit_hist[w >> 24], 1u);
         }
     }
     ZB_SYNC();
 
+    ZB_MARK(2);
     /* ---- phase 2: Huffman code for the literals (lane 0), FSE tables for the three symbol types (lanes 0..2) ---- */
     ZB_SERIAL(zl)
     {
+        /* Is it worth going on?  Literals whose most frequent byte is as rare as in noise stay raw (the test zstd's
+         * own HUF_compress uses, huf_compress.c "largest <= (srcSize >> 7)+4"), and then the block can only shrink
+         * by what the matches remove minus about three bytes per sequence. */
+        uint32_t largest = 0;
+        for (uint32_t s2 = 0; s2 < 256u; ++s2)
+            if (sh->lit_hist[s2] > largest)
+                largest = sh->lit_hist[s2];
         sh->v[ZV_HUF_OK] = 0;
         sh->v[ZV_TREE_BYTES] = 0;
-        if (nlit >= 256u && !(ZB_DBG & 1u))
+        sh->v[ZV_HUF_NSYM] = 0;
+        sh->v[ZV_LIT_HDR] = (nlit >= 256u && !(ZB_DBG & 1u) && largest > (nlit >> 7) + 4u) ? 1u : 0u; /* try Huffman */
+        sh->v[ZV_SKIP] = (!sh->v[ZV_LIT_HDR] && in->raw_size - nlit < 3u * nbseq + 32u) ? 1u : 0u;
+    }
+    ZB_SYNC();
+    if (sh->v[ZV_SKIP])
+        return 0;
+    ZB_PAR_FOR(i, ZB_OUT_BYTES / 4u) sc->out[i] = 0;
+    if (sh->v[ZV_LIT_HDR])
+        zb_huffman_sort(sh, zl);
+    ZB_SYNC();
+    ZB_SERIAL(zl)
+    {
+        if (sh->v[ZV_LIT_HDR])
             zb_huffman_build(sh);
         if (sh->v[ZV_HUF_OK]) /* uses table slot 0 as work space: must precede the FSE tables below */
             sh->v[ZV_TREE_BYTES] = zb_write_huf_tree(sh, sh->tree);
     }
     ZB_SYNC();
+    ZB_MARK(9);
     ZB_PAR_FOR(t, 3u)
     {
         if (nbseq)
@@ -846,6 +953,7 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     }
     ZB_SYNC();
 
+    ZB_MARK(3);
     /* ---- phase 3: size of the four Huffman streams (64 chunks; a stream is written from its LAST symbol) ---- */
     const uint32_t seg = (nlit + 3u) >> 2;
     if (sh->v[ZV_HUF_OK])
@@ -858,13 +966,19 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
             const uint32_t csz = (s1 - s0 + 15u) >> 4;
             const uint32_t a = s0 + j * csz < s1 ? s0 + j * csz : s1, b = a + csz < s1 ? a + csz : s1;
             uint32_t bits = 0;
-            for (uint32_t k = a; k < b; ++k)
-                bits += sh->huf_len[sc->lits[k]];
+            if (a < b)
+            {
+                ZbLitReader lr;
+                zb_lit_open(&lr, in->unit_lits, sh->ulit_base, in->nunits, a);
+                for (uint32_t k = a; k < b; ++k)
+                    bits += sh->huf_len[zb_lit_get(&lr, k)];
+            }
             sh->part[c] = bits;
         }
     }
     ZB_SYNC();
 
+    ZB_MARK(4);
     /* ---- phase 4 (lane 0): decide the literals mode, write every header, lay out the bit streams ---- */
     ZB_SERIAL(zl)
     {
@@ -969,6 +1083,7 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     }
     ZB_SYNC();
 
+    ZB_MARK(5);
     /* ---- phase 5: literals ---- */
     if (sh->v[ZV_LIT_MODE] == 2u)
     {
@@ -981,9 +1096,11 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
             const uint32_t a = s0 + j * csz < s1 ? s0 + j * csz : s1, b = a + csz < s1 ? a + csz : s1;
             ZbBits bw;
             zb_bits_open(&bw, sc->out, sh->v[ZV_STREAM_BASE + st] * 8u + sh->part[c]);
+            ZbLitReader lr;
+            zb_lit_open(&lr, in->unit_lits, sh->ulit_base, in->nunits, a < b ? b - 1u : 0u);
             for (uint32_t k = b; k > a; --k)
             {
-                const uint32_t s = sc->lits[k - 1u];
+                const uint32_t s = zb_lit_get(&lr, k - 1u);
                 zb_bits_put(&bw, sh->huf_code[s], sh->huf_len[s]);
             }
             if (j == 0u)
@@ -994,33 +1111,65 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     else
     {
         uint8_t* dst = out8 + sh->v[ZV_STREAM_BASE];
-        ZB_PAR_FOR(k, nlit) dst[k] = sc->lits[k];
+        for (uint32_t u = 0; u < in->nunits; ++u)
+        {
+            const uint8_t* src = in->unit_lits + (uint64_t)u * ZB_UNIT;
+            uint8_t* d2 = dst + sh->ulit_base[u];
+            ZB_PAR_FOR(j, sh->ulit_base[u + 1u] - sh->ulit_base[u]) d2[j] = src[j];
+        }
     }
 
-    /* ---- phase 6: the three FSE state chains, last sequence first (lanes 0..2) ---- */
-    ZB_PAR_FOR(t, 3u)
+    ZB_MARK(6);
+    /* ---- phase 6: the three FSE state chains, last sequence first.  A chain is serial, so it must not wait on
+     * global memory: tiles of 512 sequences get their three codes computed by all lanes into LDS (the Huffman work
+     * arrays are free by now), then lanes 0..2 walk the tile. ---- */
+    if (nbseq)
     {
-        if (nbseq && sh->mode[t] != 1u)
+        uint32_t* const codes = sh->sort_key; /* [512], spans sort_key + huf_w */
+        const uint32_t ntiles = (nbseq + 511u) >> 9;
+        ZB_PAR_FOR(t, 3u)
         {
-            const uint32_t tl = sh->table_log[t];
-            uint16_t* sb = sc->sbits + (uint64_t)t * ZB_SEQ_MAX;
-            uint32_t x;
+            if (sh->mode[t] != 1u)
             {
                 const uint64_t q = sc->seqs[nbseq - 1u];
-                const uint32_t s = t == ZT_LL ? zb_ll_code(ZB_SEQ_LIT(q)) : t == ZT_ML ? zb_ml_code(ZB_SEQ_ML(q) - 3u) : zb_of_code(ZB_SEQ_OFF(q));
-                x = (1u << tl) + sh->state_tab[t][sh->sym_start[t][s]];
+                const uint32_t s2 = t == ZT_LL ? zb_ll_code(ZB_SEQ_LIT(q)) : t == ZT_ML ? zb_ml_code(ZB_SEQ_ML(q) - 3u) : zb_of_code(ZB_SEQ_OFF(q));
+                sh->v[ZV_FINAL_STATE + t] = (1u << sh->table_log[t]) + sh->state_tab[t][sh->sym_start[t][s2]];
             }
-            for (uint32_t n = nbseq - 1u; n-- > 0u;)
+        }
+        for (uint32_t tile = ntiles; tile-- > 0u;)
+        {
+            const uint32_t n0 = tile << 9;
+            const uint32_t n1 = n0 + 512u < nbseq - 1u ? n0 + 512u : nbseq - 1u; /* the last sequence has no transition */
+            ZB_SYNC();
+            ZB_PAR_FOR(k, n1 > n0 ? n1 - n0 : 0u)
             {
-                const uint64_t q = sc->seqs[n];
-                const uint32_t s = t == ZT_LL ? zb_ll_code(ZB_SEQ_LIT(q)) : t == ZT_ML ? zb_ml_code(ZB_SEQ_ML(q) - 3u) : zb_of_code(ZB_SEQ_OFF(q));
-                sb[n] = (uint16_t)zb_fse_step(&x, s, sh->norm[t], sh->state_tab[t], sh->sym_start[t], tl);
+                const uint64_t q = sc->seqs[n0 + k];
+                codes[k] = zb_ll_code(ZB_SEQ_LIT(q)) | (zb_of_code(ZB_SEQ_OFF(q)) << 8) | (zb_ml_code(ZB_SEQ_ML(q) - 3u) << 16);
             }
-            sh->v[ZV_FINAL_STATE + t] = x - (1u << tl);
+            ZB_SYNC();
+            ZB_PAR_FOR(t, 3u)
+            {
+                if (sh->mode[t] != 1u)
+                {
+                    const uint32_t tl = sh->table_log[t];
+                    uint16_t* sb = sc->sbits + (uint64_t)t * ZB_SEQ_MAX;
+                    uint32_t x = sh->v[ZV_FINAL_STATE + t];
+                    for (uint32_t n = n1; n-- > n0;)
+                        sb[n] = (uint16_t)zb_fse_step(&x, (codes[n - n0] >> (8u * t)) & 255u, sh->norm[t], sh->state_tab[t], sh->sym_start[t], tl);
+                    sh->v[ZV_FINAL_STATE + t] = x;
+                }
+            }
+        }
+        ZB_SYNC();
+        ZB_PAR_FOR(t, 3u)
+        {
+            if (sh->mode[t] != 1u)
+                sh->v[ZV_FINAL_STATE + t] -= 1u << sh->table_log[t];
         }
     }
     ZB_SYNC();
 
+    ZB_MARK(7);
     /* ---- phase 7: sequence bit-stream: sizes of 64 runs, then the bits ---- */
     const uint32_t run = (nbseq + ZB_CHUNKS - 1u) / ZB_CHUNKS;
     for (int pass = 0; pass < 2; ++pass)
@@ -1032,8 +1181,7 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
                 const uint32_t a = c * run < nbseq ? c * run : nbseq, b = a + run < nbseq ? a + run : nbseq;
                 uint32_t bits = 0;
                 ZbBits bw;
-                if (pass)
-                    zb_bits_open(&bw, sc->out, sh->v[ZV_SEQ_BITS0] * 8u + sh->part[c]);
+                zb_bits_open(&bw, sc->out, pass ? sh->v[ZV_SEQ_BITS0] * 8u + sh->part[c] : 0u);
                 for (uint32_t n = b; n > a; --n)
                 {
                     const uint64_t q = sc->seqs[n - 1u];
@@ -1086,6 +1234,7 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
         }
     }
 
+    ZB_MARK(8);
     /* ---- phase 8 (lane 0): final states (ML, OF, LL: read back as LL, OF, ML), end mark, size ---- */
     ZB_SERIAL(zl)
     {
@@ -1117,6 +1266,7 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
         sh->v[ZV_OUT_SIZE] = size < in->raw_size ? size : 0u;
     }
     ZB_SYNC();
+    ZB_MARK(10);
     return sh->v[ZV_OUT_SIZE];
 }
 

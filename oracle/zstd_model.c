@@ -38,14 +38,12 @@ uint32_t ltz_model_encode_block(const void* meta, const uint8_t* unit_lits, cons
     in.unit_recs = unit_recs;
     in.nunits = nunits;
     in.raw_size = raw_size;
-    sc.lits = (uint8_t*)malloc(ZB_BLOCK_MAX + 8);
     sc.seqs = (uint64_t*)malloc(sizeof(uint64_t) * ZB_SEQ_MAX);
     sc.sbits = (uint16_t*)malloc(sizeof(uint16_t) * 3 * ZB_SEQ_MAX);
     sc.out = (uint32_t*)malloc(ZB_OUT_BYTES);
     n = zb_encode_block(&in, &sc, sh, 0);
     if (n)
         memcpy(out, sc.out, n);
-    free(sc.lits);
     free(sc.seqs);
     free(sc.sbits);
     free(sc.out);
