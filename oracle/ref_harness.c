@@ -18,6 +18,7 @@
 #include "lib/hpcdcchunker/longtail_hpcdcchunker.h"
 #include "lib/lz4/longtail_lz4.h"
 #include "lib/memstorage/longtail_memstorage.h"
+#include "lib/filestorage/longtail_filestorage.h"
 #include "lib/zstd/longtail_zstd.h"
 
 #include <errno.h>
@@ -25,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 int refh_version(void) { return 2; }
 
@@ -261,8 +263,20 @@ static int fill_storage(struct Longtail_StorageAPI* s, const char* root, uint32_
     return err;
 }
 
+/* Where the source tree lives: 0 (default) = the reference's in-memory storage; a directory (use tmpfs, e.g. /dev/shm)
+ * = the reference's file storage below it, which is what SURVEY.md §8(d) asks the CPU baseline to read from
+ * ("page-cache-warm, from tmpfs"): the in-memory storage serialises every read behind one lock. */
+static char g_tree_dir[512];
+void refh_set_tree_dir(const char* dir)
+{
+    g_tree_dir[0] = 0;
+    if (dir && strlen(dir) < sizeof(g_tree_dir) - 64)
+        strcpy(g_tree_dir, dir);
+}
+
 struct refh_tree
 {
+    char root[600];
     struct Longtail_StorageAPI* storage;
     struct Longtail_JobAPI* jobs;
     struct Longtail_FileInfos* files;
@@ -275,17 +289,33 @@ static void tree_free(struct refh_tree* t)
     Longtail_Free(t->files);
     SAFE_DISPOSE_API(t->jobs);
     SAFE_DISPOSE_API(t->storage);
+    if (g_tree_dir[0] && strncmp(t->root, g_tree_dir, strlen(g_tree_dir)) == 0 && strstr(t->root, "/refh_tree_"))
+    {
+        char cmd[700];
+        snprintf(cmd, sizeof cmd, "rm -rf '%s'", t->root); /* our own scratch directory */
+        if (system(cmd) != 0)
+            fprintf(stderr, "refh: could not remove %s\n", t->root);
+    }
 }
 
 static int tree_make(struct refh_tree* t, uint32_t nfiles, const char* const* names, const uint8_t* const* datas,
                      const uint64_t* sizes, int workers, uint32_t tag)
 {
     memset(t, 0, sizeof *t);
-    t->storage = Longtail_CreateInMemStorageAPI();
+    if (g_tree_dir[0])
+    {
+        snprintf(t->root, sizeof t->root, "%s/refh_tree_%d", g_tree_dir, (int)getpid());
+        t->storage = Longtail_CreateFSStorageAPI();
+    }
+    else
+    {
+        strcpy(t->root, "root");
+        t->storage = Longtail_CreateInMemStorageAPI();
+    }
     t->jobs = Longtail_CreateBikeshedJobAPI((uint32_t)workers, 0);
-    int err = fill_storage(t->storage, "root", nfiles, names, datas, sizes);
+    int err = fill_storage(t->storage, t->root, nfiles, names, datas, sizes);
     if (!err)
-        err = Longtail_GetFilesRecursively2(t->storage, t->jobs, 0, 0, 0, "root", &t->files);
+        err = Longtail_GetFilesRecursively2(t->storage, t->jobs, 0, 0, 0, t->root, &t->files);
     if (!err)
     {
         t->tags = (uint32_t*)Longtail_Alloc("refh", sizeof(uint32_t) * (t->files->m_Count + 1));
@@ -317,7 +347,7 @@ int refh_version_index(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_
         hash_api = own_h = Longtail_CreateBlake3HashAPI();
     struct timespec a, b;
     clock_gettime(CLOCK_MONOTONIC, &a);
-    err = Longtail_CreateVersionIndex(t.storage, hash_api, chunker_api, t.jobs, 0, 0, 0, "root", t.files, t.tags,
+    err = Longtail_CreateVersionIndex(t.storage, hash_api, chunker_api, t.jobs, 0, 0, 0, t.root, t.files, t.tags,
                                       target_chunk_size, 0, &vi);
     clock_gettime(CLOCK_MONOTONIC, &b);
     if (out_seconds)
@@ -531,7 +561,7 @@ static int ingest_impl(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_
     struct Longtail_BlockStoreAPI* cbs = Longtail_CreateCompressBlockStoreAPI(fs, reg_w);
 
     clock_gettime(CLOCK_MONOTONIC, &a);
-    err = Longtail_CreateVersionIndex(t.storage, hash_api, chunker_api, t.jobs, 0, 0, 0, "root", t.files, t.tags,
+    err = Longtail_CreateVersionIndex(t.storage, hash_api, chunker_api, t.jobs, 0, 0, 0, t.root, t.files, t.tags,
                                       target_chunk_size, 0, &vi);
     clock_gettime(CLOCK_MONOTONIC, &b);
     if (out_seconds_index)
@@ -543,7 +573,7 @@ static int ingest_impl(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_
     if (!err)
     {
         clock_gettime(CLOCK_MONOTONIC, &a);
-        err = Longtail_WriteContent(t.storage, cbs, t.jobs, 0, 0, 0, missing, vi, "root");
+        err = Longtail_WriteContent(t.storage, cbs, t.jobs, 0, 0, 0, missing, vi, t.root);
         clock_gettime(CLOCK_MONOTONIC, &b);
         if (out_seconds_write)
             *out_seconds_write = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
