@@ -351,6 +351,8 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
                 LT_REPLAY(3u, pb3, ps3)
 #undef LT_REPLAY
             }
+            else if (*flag == 0u && more && !(dbg & 16u))
+                nfail += 4u; // nobody in the 32 KiB group matched anything in its probe batches: skim faster
             met = true;
         }
         if (!more)
@@ -362,22 +364,72 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
         ++batches;
 
         // ---- probe 64 positions (stride grows with consecutive misses, lz4.c:1044-1053) ----
-        const uint32_t stride = 1u + nfail;
-        const uint32_t p = pos + (uint32_t)lane * stride;
-        const bool valid = (int32_t)p <= start_limit;
+        uint32_t stride = 1u + nfail;
+        uint32_t p = pos + (uint32_t)lane * stride;
+        bool valid = (int32_t)p <= start_limit;
         uint32_t v = 0, cand = LZ4_EMPTY, h = 0;
-        if (valid)
-        {
-            v = lds_read32(sdata, p + head);
-            h = (v * 2654435761u) >> (32 - HASH_LOG2);
-            cand = tab[h];
-        }
-        // every lane has read the table before anyone updates it (same wave: LDS operations execute in order)
-        if (valid)
-            tab[h] = (uint16_t)p;
         bool ok = false;
-        if (valid && cand != LZ4_EMPTY && cand < p)
-            ok = lds_read32(sdata, cand + head) == v;
+        if (met && nfail != 0u && !(dbg & 8u))
+        {
+            // Miss mode: the NEXT batch is probed in the same breath (its LDS round trips overlap this batch's): a
+            // unit of incompressible data is a chain of dependent probes and nothing else, so this halves its
+            // latency.  The second batch reads the table before the first one's inserts and is only inserted if the
+            // first one missed.
+            const uint32_t pos2 = pos + 64u * stride;
+            const uint32_t p2 = pos2 + (uint32_t)lane * (stride + 1u);
+            const bool valid2 = (int32_t)p2 <= start_limit;
+            uint32_t v2 = 0, cand2 = LZ4_EMPTY, h2 = 0;
+            if (valid)
+            {
+                v = lds_read32(sdata, p + head);
+                h = (v * 2654435761u) >> (32 - HASH_LOG2);
+                cand = tab[h];
+            }
+            if (valid2)
+            {
+                v2 = lds_read32(sdata, p2 + head);
+                h2 = (v2 * 2654435761u) >> (32 - HASH_LOG2);
+                cand2 = tab[h2];
+            }
+            if (valid)
+                tab[h] = (uint16_t)p;
+            bool ok2 = false;
+            if (valid && cand != LZ4_EMPTY && cand < p)
+                ok = lds_read32(sdata, cand + head) == v;
+            if (valid2 && cand2 != LZ4_EMPTY && cand2 < p2)
+                ok2 = lds_read32(sdata, cand2 + head) == v2;
+            if (__builtin_amdgcn_ballot_w64(ok) == 0ull)
+            {
+                if (valid2)
+                    tab[h2] = (uint16_t)p2;
+                if (__builtin_amdgcn_ballot_w64(ok2) == 0ull)
+                {
+                    pos = pos2 + 64u * (stride + 1u);
+                    nfail += 2u;
+                    continue;
+                }
+                pos = pos2; // the second batch becomes the current one
+                ++nfail;
+                stride += 1u;
+                p = p2;
+                cand = cand2;
+                ok = ok2;
+            }
+        }
+        else
+        {
+            if (valid)
+            {
+                v = lds_read32(sdata, p + head);
+                h = (v * 2654435761u) >> (32 - HASH_LOG2);
+                cand = tab[h];
+            }
+            // every lane has read the table before anyone updates it (same wave: LDS operations execute in order)
+            if (valid)
+                tab[h] = (uint16_t)p;
+            if (valid && cand != LZ4_EMPTY && cand < p)
+                ok = lds_read32(sdata, cand + head) == v;
+        }
         // matches whose source lies in the same batch are invisible to the table: look 1, 2, 4, 8 lanes back
         if (nfail == 0 && !(dbg & 2u))
         {
