@@ -223,8 +223,9 @@ constexpr int LZ4_PROBE_BATCHES = 4;
 
 template <int HASH_LOG2, int FMT>
 __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
-                                                             uint32_t nblocks, uint32_t sub_bytes, uint8_t* __restrict__ streams,
-                                                             Lz4Meta* __restrict__ meta, uint64_t* __restrict__ zrecs, uint32_t dbg)
+                                                             uint32_t nblocks, uint32_t grp0, uint32_t sub_bytes,
+                                                             uint8_t* __restrict__ streams, Lz4Meta* __restrict__ meta,
+                                                             uint64_t* __restrict__ zrecs, uint32_t dbg)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t data_bytes = LZ4_G * sub_bytes + 64u;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint16_t* tab = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u) + (size_t)wave * (1u << HASH_LOG2);
 
-    const uint32_t grp = blockIdx.x;
+    const uint32_t grp = blockIdx.x + grp0;
     uint32_t lo = 0, hi = nblocks;
     while (hi - lo > 1)
     {
@@ -636,12 +637,12 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
 // coalesced again.  Trailing literals belong to a literal RUN that is closed by the next unit with a match (or by
 // the end of the block); the start of a run's literal area is only known when it closes, so units remember
 // (run index, offset inside the run) and k_lz4_stitch_copy resolves it through the run table.
-__global__ __launch_bounds__(64) void k_lz4_stitch_scan(const Lz4Block* __restrict__ blocks, uint32_t nblocks, uint32_t SEG,
+__global__ __launch_bounds__(64) void k_lz4_stitch_scan(const Lz4Block* __restrict__ blocks, uint32_t b0, uint32_t nblocks, uint32_t SEG,
                                                         const Lz4Meta* __restrict__ meta, Lz4Plan* __restrict__ plan,
                                                         uint32_t* __restrict__ runs, Lz4BlockOut* __restrict__ bout,
                                                         uint32_t* __restrict__ out_sizes)
 {
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = blockIdx.x + b0;
     if (b >= nblocks)
         return;
     const int lane = threadIdx.x;
@@ -777,7 +778,7 @@ constexpr int K6_THREADS = 256;
 // one workgroup per window group: its (up to LZ4_G) units are moved into place one after the other
 __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* __restrict__ src,
                                                                  const Lz4Block* __restrict__ blocks, uint32_t nblocks,
-                                                                 uint32_t SEG, const uint8_t* __restrict__ streams,
+                                                                 uint32_t grp0, uint32_t SEG, const uint8_t* __restrict__ streams,
                                                                  const Lz4Meta* __restrict__ meta,
                                                                  const Lz4Plan* __restrict__ plan,
                                                                  const uint32_t* __restrict__ runs,
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* _
                                                                  uint8_t* __restrict__ dst)
 {
     const int tid = threadIdx.x;
-    const uint32_t grp = blockIdx.x;
+    const uint32_t grp = blockIdx.x + grp0;
     uint32_t lo = 0, hi = nblocks;
     while (hi - lo > 1)
     {
@@ -1025,26 +1026,74 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
         return err;
     if ((err = lthip_scratch(ctx, S_LZ4_STREAM, (size_t)lz4_stream_stride(SEG) * ((size_t)nseg + 1), &streams)))
         return err;
-    if (nseg)
+    // Optional (LTHIP_LZ4_DBG bit 5): the match finder is latency / LDS bound, the stitch copy HBM bound, so the batch can
+    // be cut into up to four slices by bytes with slice i's stitch on the context's second stream while slice i+1 is
+    // parsed on the main one.  MEASURED SLOWER on MI355X (64 GiB random: 151.6 vs 137.6 ms per step: the copy's traffic
+    // lengthens every probe's LDS-fill latency and both kernels lose more than the overlap wins), hence off by default.
+    const uint32_t dbg = (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0);
+    uint64_t total_bytes = 0;
+    for (uint32_t b = 0; b < block_count; ++b)
+        total_bytes += src_sizes[b];
+    const uint32_t want = !(dbg & 32u) ? 1u : (total_bytes >= (1ull << 30) ? 4u : (total_bytes >= (256ull << 20) ? 2u : 1u));
+    std::vector<uint32_t> cut{0};
     {
-        LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
-        const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * (1u << 11) * 2;
-        hipLaunchKernelGGL((k_lz4_segments<11, 0>), dim3((uint32_t)ngrp64), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src,
-                           d_blocks, block_count, SEG, (uint8_t*)streams, (Lz4Meta*)meta, (uint64_t*)nullptr,
-                           (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0));
-        LTHIP_LAUNCH_CHECK(ctx);
+        uint64_t acc = 0;
+        for (uint32_t b = 0; b < block_count; ++b)
+        {
+            acc += src_sizes[b];
+            if (cut.size() < want && acc * want >= total_bytes * cut.size() && b + 1 < block_count)
+                cut.push_back(b + 1);
+        }
+        cut.push_back(block_count);
     }
+    // per-block first segment / group (same arithmetic as upload_blocks)
+    std::vector<uint32_t> grp_first(block_count + 1, 0);
+    for (uint32_t b = 0; b < block_count; ++b)
+        grp_first[b + 1] = grp_first[b] + (uint32_t)(((((uint64_t)src_sizes[b] + SEG - 1) / SEG) + LZ4_G - 1) / LZ4_G);
+    const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * (1u << 11) * 2;
+    const bool overlap = cut.size() > 2;
+    hipStream_t s2 = ctx->stream;
+    if (overlap)
     {
-        LaunchTimer t(ctx, LTHIP_K_LZ4_STITCH);
-        hipLaunchKernelGGL(k_lz4_stitch_scan, dim3(block_count), dim3(64), 0, ctx->stream, d_blocks, block_count, SEG,
-                           (const Lz4Meta*)meta, (Lz4Plan*)plan, (uint32_t*)runs, (Lz4BlockOut*)bout, d_out_sizes);
-        if (nseg)
-            hipLaunchKernelGGL(k_lz4_stitch_copy, dim3((uint32_t)ngrp64), dim3(K6_THREADS), 0, ctx->stream, (const uint8_t*)d_src, d_blocks,
-                               block_count, SEG, (const uint8_t*)streams, (const Lz4Meta*)meta, (const Lz4Plan*)plan,
-                               (const uint32_t*)runs, (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
-        hipLaunchKernelGGL(k_lz4_empty_blocks, dim3((block_count + 255) / 256), dim3(256), 0, ctx->stream, d_blocks, block_count,
-                           (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
-        LTHIP_LAUNCH_CHECK(ctx);
+        if ((err = lthip_second_stream(ctx, &s2)))
+            return err;
+    }
+    for (size_t i = 0; i + 1 < cut.size(); ++i)
+    {
+        const uint32_t b0 = cut[i], b1 = cut[i + 1];
+        const uint32_t g0 = grp_first[b0], g1 = grp_first[b1];
+        if (g1 > g0)
+        {
+            LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
+            hipLaunchKernelGGL((k_lz4_segments<11, 0>), dim3(g1 - g0), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
+                               block_count, g0, SEG, (uint8_t*)streams, (Lz4Meta*)meta, (uint64_t*)nullptr, dbg);
+            LTHIP_LAUNCH_CHECK(ctx);
+        }
+        if (overlap)
+        {
+            hipEvent_t e = lthip_sync_event(ctx);
+            LTHIP_CHECK(ctx, hipEventRecord(e, ctx->stream));
+            LTHIP_CHECK(ctx, hipStreamWaitEvent(s2, e, 0));
+        }
+        {
+            LaunchTimer t(ctx, LTHIP_K_LZ4_STITCH, s2);
+            hipLaunchKernelGGL(k_lz4_stitch_scan, dim3(b1 - b0), dim3(64), 0, s2, d_blocks, b0, b1, SEG, (const Lz4Meta*)meta,
+                               (Lz4Plan*)plan, (uint32_t*)runs, (Lz4BlockOut*)bout, d_out_sizes);
+            if (g1 > g0)
+                hipLaunchKernelGGL(k_lz4_stitch_copy, dim3(g1 - g0), dim3(K6_THREADS), 0, s2, (const uint8_t*)d_src, d_blocks, block_count, g0,
+                                   SEG, (const uint8_t*)streams, (const Lz4Meta*)meta, (const Lz4Plan*)plan, (const uint32_t*)runs,
+                                   (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
+            if (i + 2 == cut.size())
+                hipLaunchKernelGGL(k_lz4_empty_blocks, dim3((block_count + 255) / 256), dim3(256), 0, s2, d_blocks, block_count,
+                                   (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
+            LTHIP_LAUNCH_CHECK(ctx);
+        }
+    }
+    if (overlap)
+    {
+        hipEvent_t e = lthip_sync_event(ctx);
+        LTHIP_CHECK(ctx, hipEventRecord(e, s2));
+        LTHIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, e, 0));
     }
     return 0;
 }
@@ -1080,7 +1129,7 @@ int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_
         LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
         const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * (1u << 11) * 2;
         hipLaunchKernelGGL((k_lz4_segments<11, 1>), dim3((uint32_t)ngrp64), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src,
-                           d_blocks, block_count, SEG, (uint8_t*)lits, (Lz4Meta*)meta, (uint64_t*)recs,
+                           d_blocks, block_count, 0u, SEG, (uint8_t*)lits, (Lz4Meta*)meta, (uint64_t*)recs,
                            (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0));
         LTHIP_LAUNCH_CHECK(ctx);
     }

@@ -100,6 +100,13 @@ extern "C" void lthip_ctx_destroy(lthip_ctx* ctx)
     }
     for (auto e : ctx->free_events)
         (void)hipEventDestroy(e);
+    for (auto e : ctx->sync_events)
+        (void)hipEventDestroy(e);
+    if (ctx->stream2)
+    {
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamDestroy(ctx->stream2);
+    }
     for (int i = 0; i < S_COUNT; ++i)
         if (ctx->scratch[i])
             (void)hipFree(ctx->scratch[i]);
@@ -201,22 +208,44 @@ static hipEvent_t take_event(lthip_ctx* ctx)
     return e;
 }
 
-LaunchTimer::LaunchTimer(lthip_ctx* c, int kid) : ctx(c), on(c->timing)
+LaunchTimer::LaunchTimer(lthip_ctx* c, int kid, hipStream_t s) : ctx(c), on(c->timing), stream(s ? s : c->stream)
 {
     if (on)
     {
         rec.kid = kid;
         rec.a = take_event(ctx);
         rec.b = take_event(ctx);
-        (void)hipEventRecord(rec.a, ctx->stream);
+        (void)hipEventRecord(rec.a, stream);
     }
+}
+
+int lthip_second_stream(lthip_ctx* ctx, hipStream_t* out)
+{
+    if (!ctx->stream2)
+        LTHIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    *out = ctx->stream2;
+    return 0;
+}
+
+hipEvent_t lthip_sync_event(lthip_ctx* ctx)
+{
+    // 16 events in rotation: an event is re-recorded only long after the wait that used it has been queued behind
+    // newer work on both streams
+    if (ctx->sync_events.size() < 16)
+    {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        ctx->sync_events.push_back(e);
+        return e;
+    }
+    return ctx->sync_events[ctx->sync_next++ % ctx->sync_events.size()];
 }
 
 LaunchTimer::~LaunchTimer()
 {
     if (on)
     {
-        (void)hipEventRecord(rec.b, ctx->stream);
+        (void)hipEventRecord(rec.b, stream);
         ctx->pending.push_back(rec);
     }
 }

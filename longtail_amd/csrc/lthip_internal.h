@@ -92,6 +92,9 @@ struct lthip_ctx
     int device;
     hipStream_t stream;
     bool own_stream;
+    hipStream_t stream2;                 // lazily created side stream (non-blocking), see lthip_second_stream
+    std::vector<hipEvent_t> sync_events; // ordering events between the two streams, reused round-robin
+    size_t sync_next;
     char err[320];
     void* scratch[S_COUNT];
     size_t scratch_cap[S_COUNT];
@@ -104,6 +107,10 @@ struct lthip_ctx
 
 int lthip_fail(lthip_ctx* ctx, int code, const char* what, const char* detail);
 int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out);
+// A second in-order queue of the context for work that should overlap the main stream (callers order the two with
+// events from lthip_sync_event and must make the main stream wait for the side stream before they return).
+int lthip_second_stream(lthip_ctx* ctx, hipStream_t* out);
+hipEvent_t lthip_sync_event(lthip_ctx* ctx);
 
 #define LTHIP_CHECK(ctx, expr)                                                          \
     do                                                                                  \
@@ -119,7 +126,8 @@ struct LaunchTimer
     lthip_ctx* ctx;
     TimingRec rec;
     bool on;
-    LaunchTimer(lthip_ctx* c, int kid);
+    hipStream_t stream;
+    LaunchTimer(lthip_ctx* c, int kid, hipStream_t s = nullptr); // s == nullptr: the context's main stream
     ~LaunchTimer();
 };
 
