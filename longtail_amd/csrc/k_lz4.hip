@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
 #undef LT_REPLAY
             }
             else if (*flag == 0u && more && !(dbg & 16u))
-                nfail += 4u; // nobody in the 32 KiB group matched anything in its probe batches: skim faster
+                nfail += (dbg >> 8) ? (dbg >> 8) : 24u; // nobody in the 32 KiB group matched anything in its probe batches: one twin round skims the rest
             met = true;
         }
         if (!more)
