@@ -79,6 +79,35 @@ __device__ __forceinline__ uint32_t lds_read32(const uint32_t* sdata, uint32_t b
     return __builtin_amdgcn_alignbyte(sdata[w + 1], sdata[w], byte_idx & 3u);
 }
 
+// n bytes of the LDS window (from byte `sbyte`) to global memory, one wave, 16-byte stores on the aligned part
+__device__ __forceinline__ void wave_copy_lds_to_global(uint8_t* __restrict__ dst, const uint32_t* sdata, uint32_t sbyte, uint32_t n,
+                                                        int lane)
+{
+    const uint8_t* sb = reinterpret_cast<const uint8_t*>(sdata);
+    uint32_t headb = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+    if (headb > n)
+        headb = n;
+    if ((uint32_t)lane < headb)
+        dst[lane] = sb[sbyte + (uint32_t)lane];
+    dst += headb;
+    sbyte += headb;
+    n -= headb;
+    const uint32_t nvec = n >> 4;
+    for (uint32_t v = lane; v < nvec; v += 64)
+    {
+        const uint32_t b = sbyte + 16u * v;
+        uint4 o;
+        o.x = lds_read32(sdata, b);
+        o.y = lds_read32(sdata, b + 4u);
+        o.z = lds_read32(sdata, b + 8u);
+        o.w = lds_read32(sdata, b + 12u);
+        *reinterpret_cast<uint4*>(dst + (uint64_t)v * 16u) = o;
+    }
+    const uint32_t done = nvec << 4;
+    if ((uint32_t)lane < n - done)
+        dst[done + (uint32_t)lane] = sb[sbyte + done + (uint32_t)lane];
+}
+
 // wave-cooperative emission of a length (already reduced by 15) as 255,255,...,rem
 __device__ __forceinline__ void emit_len(uint8_t* out, uint32_t len, int lane)
 {
@@ -225,7 +254,7 @@ template <int HASH_LOG2, int FMT>
 __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
                                                              uint32_t nblocks, uint32_t grp0, uint32_t sub_bytes,
                                                              uint8_t* __restrict__ streams, Lz4Meta* __restrict__ meta,
-                                                             uint64_t* __restrict__ zrecs, uint32_t dbg)
+                                                             uint64_t* __restrict__ zrecs, uint8_t* __restrict__ spec_dst, uint32_t dbg)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t data_bytes = LZ4_G * sub_bytes + 64u;
@@ -617,6 +646,17 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
             reinterpret_cast<uint4*>(meta)[unit] = make_uint4(st.nseq, st.op + tail, tail, 0u);
         return;
     }
+    // A unit without a single match is all literals.  If that turns out to be true of the WHOLE block (incompressible
+    // data -- the common case for already-compressed assets), the payload is one literal run: header, then the source
+    // bytes, and this unit's bytes belong at  header + its offset in the block.  They are still in LDS, so they are put
+    // there now, speculatively; the stitch then only writes the header for such blocks instead of reading and writing
+    // them again (a block that does have matches is laid out by the stitch as usual, overwriting these bytes).
+    if (FMT == 0 && spec_dst && have_unit && !st.have_first)
+    {
+        const uint64_t o = (uint64_t)(1u + lz4_len_bytes(blk.size)) + group_start + my_start;
+        if (o + my_len <= (uint64_t)blk.dst_cap)
+            wave_copy_lds_to_global(spec_dst + blk.dst_off + o, sdata, my_start + head, my_len, lane);
+    }
     if (have_unit && lane == 0)
     {
         Lz4Meta m;
@@ -717,7 +757,7 @@ __global__ __launch_bounds__(64) void k_lz4_stitch_scan(const Lz4Block* __restri
         bo.final_hdr_pos = (uint32_t)out_pos;
         bo.final_lits = carry;
         bo.total = total <= (uint64_t)blk.dst_cap ? (uint32_t)total : 0u;
-        bo.pad = 0;
+        bo.pad = run == 0u ? 1u : 0u; // no unit found a match: the literals were placed by the match finder already
         bout[b] = bo;
         out_sizes[b] = bo.total;
     }
@@ -783,7 +823,7 @@ __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* _
                                                                  const Lz4Plan* __restrict__ plan,
                                                                  const uint32_t* __restrict__ runs,
                                                                  const Lz4BlockOut* __restrict__ bout,
-                                                                 uint8_t* __restrict__ dst)
+                                                                 uint8_t* __restrict__ dst, uint32_t spec)
 {
     const int tid = threadIdx.x;
     const uint32_t grp = blockIdx.x + grp0;
@@ -823,7 +863,8 @@ __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* _
             wg_copy(d + pl.body_dst, stream + skip, m.seq_bytes - skip, lane, 64);
             tail = m.tail_lits;
         }
-        wg_copy(d + runs[pl.run] + pl.tail_rel, s + (len - tail), tail, lane, 64);
+        if (!(bo.pad && spec))
+            wg_copy(d + runs[pl.run] + pl.tail_rel, s + (len - tail), tail, lane, 64);
         if (i + 1 == blk.nseg)
             wg_emit_header(d + bo.final_hdr_pos, bo.final_lits, 0u, lane, 64);
     }
@@ -1066,7 +1107,8 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
         {
             LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
             hipLaunchKernelGGL((k_lz4_segments<11, 0>), dim3(g1 - g0), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
-                               block_count, g0, SEG, (uint8_t*)streams, (Lz4Meta*)meta, (uint64_t*)nullptr, dbg);
+                               block_count, g0, SEG, (uint8_t*)streams, (Lz4Meta*)meta, (uint64_t*)nullptr,
+                               (dbg & 64u) ? (uint8_t*)nullptr : (uint8_t*)d_dst, dbg);
             LTHIP_LAUNCH_CHECK(ctx);
         }
         if (overlap)
@@ -1082,7 +1124,7 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
             if (g1 > g0)
                 hipLaunchKernelGGL(k_lz4_stitch_copy, dim3(g1 - g0), dim3(K6_THREADS), 0, s2, (const uint8_t*)d_src, d_blocks, block_count, g0,
                                    SEG, (const uint8_t*)streams, (const Lz4Meta*)meta, (const Lz4Plan*)plan, (const uint32_t*)runs,
-                                   (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
+                                   (const Lz4BlockOut*)bout, (uint8_t*)d_dst, (dbg & 64u) ? 0u : 1u);
             if (i + 2 == cut.size())
                 hipLaunchKernelGGL(k_lz4_empty_blocks, dim3((block_count + 255) / 256), dim3(256), 0, s2, d_blocks, block_count,
                                    (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
@@ -1129,7 +1171,7 @@ int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_
         LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
         const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * (1u << 11) * 2;
         hipLaunchKernelGGL((k_lz4_segments<11, 1>), dim3((uint32_t)ngrp64), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src,
-                           d_blocks, block_count, 0u, SEG, (uint8_t*)lits, (Lz4Meta*)meta, (uint64_t*)recs,
+                           d_blocks, block_count, 0u, SEG, (uint8_t*)lits, (Lz4Meta*)meta, (uint64_t*)recs, (uint8_t*)nullptr,
                            (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0));
         LTHIP_LAUNCH_CHECK(ctx);
     }
