@@ -843,6 +843,13 @@ __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* _
     uint8_t* d = dst + blk.dst_off;
     const uint32_t i0 = (grp - blk.grp_base) * LZ4_G;
     const uint32_t i1 = i0 + LZ4_G < blk.nseg ? i0 + LZ4_G : blk.nseg;
+    if (bo.pad && spec)
+    {
+        // all-literal block whose bytes are in place already: only the header of its single run is missing
+        if (i1 == blk.nseg && tid < 64)
+            wg_emit_header(d + bo.final_hdr_pos, bo.final_lits, 0u, tid, 64);
+        return;
+    }
     // each wave moves whole units on its own (4 units in flight per workgroup: their table loads overlap)
     const int lane = tid & 63;
     for (uint32_t i = i0 + (uint32_t)(tid >> 6); i < i1; i += K6_THREADS / 64)
@@ -863,8 +870,7 @@ __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* _
             wg_copy(d + pl.body_dst, stream + skip, m.seq_bytes - skip, lane, 64);
             tail = m.tail_lits;
         }
-        if (!(bo.pad && spec))
-            wg_copy(d + runs[pl.run] + pl.tail_rel, s + (len - tail), tail, lane, 64);
+        wg_copy(d + runs[pl.run] + pl.tail_rel, s + (len - tail), tail, lane, 64);
         if (i + 1 == blk.nseg)
             wg_emit_header(d + bo.final_hdr_pos, bo.final_lits, 0u, lane, 64);
     }
