@@ -642,8 +642,27 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
         const uint32_t tail = have_unit ? my_start + my_len - st.anchor : 0u;
         for (uint32_t j = lane; j < tail; j += 64)
             out[st.op + j] = sbytes[st.anchor + j + head];
+        // is the unit one repeated byte?  (zstd stores a 128 KiB piece made of such units as an RLE_Block)
+        uint32_t uniform = 0;
+        if (have_unit)
+        {
+            const uint32_t b0 = sbytes[my_start + head];
+            const uint32_t rep = b0 * 0x01010101u;
+            uint32_t diff = 0;
+#pragma unroll 4
+            for (uint32_t j = 0; j < 16u; ++j)
+            {
+                const uint32_t o = 64u * (uint32_t)lane + 4u * j;
+                if (o + 4u <= my_len)
+                    diff |= lds_read32(sdata, my_start + o + head) ^ rep;
+                else if (o < my_len)
+                    for (uint32_t k = o; k < my_len; ++k)
+                        diff |= (uint32_t)sbytes[my_start + k + head] ^ b0;
+            }
+            uniform = __builtin_amdgcn_ballot_w64(diff != 0u) == 0ull ? (0x100u | b0) : 0u;
+        }
         if (have_unit && lane == 0)
-            reinterpret_cast<uint4*>(meta)[unit] = make_uint4(st.nseq, st.op + tail, tail, 0u);
+            reinterpret_cast<uint4*>(meta)[unit] = make_uint4(st.nseq, st.op + tail, tail, uniform);
         return;
     }
     // A unit without a single match is all literals.  If that turns out to be true of the WHOLE block (incompressible

@@ -1,7 +1,7 @@
 // k_zstd.hip -- ZStd CompressionAPI, GPU encoder.  Every stored block becomes ONE zstd frame
 // (RFC 8878 §3.1.1: magic 0xFD2FB528 | FHD 0xE0 = single segment, 8-byte content size, no checksum, no dictionary |
 // u64 content size | blocks, each with a 3-byte header {last:1, type:2, size:21}) whose 128 KiB pieces are
-//   RLE_Block         all bytes equal                                   (k_zstd_classify)
+//   RLE_Block         all bytes equal (per-unit flags from the match finder, checked in k_zstd_encode)
 //   Compressed_Block  LZ sequences from the LZ4 match finder run with sequence output (k_lz4.hip, FMT 1), literals
 //                     Huffman-coded in 4 streams, the three symbol streams FSE-coded (predefined / RLE / described
 //                     tables) -- zstd_block_core.h, one wavefront per piece (k_zstd_encode)
@@ -53,39 +53,6 @@ constexpr uint32_t ZHDR = 13u;
 constexpr int ZT = 256;
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-
-// per 128 KiB piece: 1 if all bytes are equal
-__global__ __launch_bounds__(ZT) void k_zstd_classify(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks,
-                                                      uint32_t nblocks, uint8_t* __restrict__ is_rle)
-{
-    __shared__ uint32_t sh_diff;
-    const uint32_t zb = blockIdx.x;
-    uint32_t lo = 0, hi = nblocks;
-    while (hi - lo > 1)
-    {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (blocks[mid].zb_base <= zb)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    const ZBlock b = blocks[lo];
-    const uint32_t start = (zb - b.zb_base) * ZB;
-    const uint32_t len = b.size - start < ZB ? b.size - start : ZB;
-    const uint8_t* p = src + b.src_off + start;
-    if (threadIdx.x == 0)
-        sh_diff = 0;
-    __syncthreads();
-    const uint8_t first = p[0];
-    uint32_t diff = 0;
-    for (uint32_t i = threadIdx.x; i < len; i += ZT)
-        diff |= (uint32_t)(p[i] != first);
-    if (diff)
-        atomicOr(&sh_diff, 1u);
-    __syncthreads();
-    if (threadIdx.x == 0)
-        is_rle[zb] = sh_diff ? 0 : 1;
-}
 
 // serial per stored block: destination offset of every piece, total size
 __global__ void k_zstd_scan(const ZBlock* __restrict__ blocks, uint32_t nblocks, const uint8_t* __restrict__ is_rle,
@@ -183,7 +150,7 @@ __global__ __launch_bounds__(ZT) void k_zstd_emit(const uint8_t* __restrict__ sr
 
 // One wavefront per 128 KiB piece, persistent over the pieces: the entropy stage of zstd_block_core.h.
 __global__ __launch_bounds__(64, 3) void k_zstd_encode(const ZBlock* __restrict__ blocks, uint32_t nblocks, uint32_t npieces,
-                                                    const uint8_t* __restrict__ is_rle, const ZbUnitMeta* __restrict__ unit_meta,
+                                                    uint8_t* __restrict__ is_rle, const ZbUnitMeta* __restrict__ unit_meta,
                                                     const uint8_t* __restrict__ unit_lits, const uint64_t* __restrict__ unit_recs,
                                                     uint8_t* __restrict__ work, uint8_t* __restrict__ enc,
                                                     uint32_t* __restrict__ enc_size)
@@ -195,12 +162,6 @@ __global__ __launch_bounds__(64, 3) void k_zstd_encode(const ZBlock* __restrict_
     sc.sbits = reinterpret_cast<uint16_t*>(w + Z_WORK_SEQS);
     for (uint32_t zb = blockIdx.x; zb < npieces; zb += gridDim.x)
     {
-        if (is_rle[zb])
-        {
-            if (threadIdx.x == 0)
-                enc_size[zb] = 0;
-            continue;
-        }
         uint32_t lo = 0, hi = nblocks;
         while (hi - lo > 1)
         {
@@ -220,6 +181,20 @@ __global__ __launch_bounds__(64, 3) void k_zstd_encode(const ZBlock* __restrict_
         in.unit_recs = unit_recs + u0 * ZB_UNIT_SEQ_MAX;
         in.nunits = (len + ZB_UNIT - 1u) / ZB_UNIT;
         in.raw_size = len;
+        {
+            // RLE_Block: every unit of the piece is one repeated byte (flagged by the match finder) and it is the same one
+            const uint32_t f = threadIdx.x < in.nunits ? in.meta[threadIdx.x].uniform : in.meta[0].uniform;
+            const uint32_t f0 = __builtin_amdgcn_readfirstlane(f);
+            const bool rle = f0 != 0u && __builtin_amdgcn_ballot_w64(f != f0) == 0ull;
+            if (threadIdx.x == 0)
+            {
+                is_rle[zb] = rle ? 1 : 0;
+                if (rle)
+                    enc_size[zb] = 0;
+            }
+            if (rle)
+                continue;
+        }
         sc.out = reinterpret_cast<uint32_t*>(enc + (uint64_t)zb * ZB_OUT_BYTES);
 #ifdef LTHIP_ZB_PROF
         if (threadIdx.x == 0)
@@ -324,10 +299,8 @@ extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uin
     if (nzb)
     {
         LaunchTimer t(ctx, LTHIP_K_ZSTD_ENC);
-        hipLaunchKernelGGL(k_zstd_classify, dim3((uint32_t)nzb), dim3(ZT), 0, ctx->stream, (const uint8_t*)d_src,
-                           (const ZBlock*)d_blocks, block_count, (uint8_t*)d_rle);
         hipLaunchKernelGGL(k_zstd_encode, dim3(nwg), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks, block_count, (uint32_t)nzb,
-                           (const uint8_t*)d_rle, (const ZbUnitMeta*)d_meta, (const uint8_t*)d_lits, (const uint64_t*)d_recs,
+                           (uint8_t*)d_rle, (const ZbUnitMeta*)d_meta, (const uint8_t*)d_lits, (const uint64_t*)d_recs,
                            (uint8_t*)d_work, (uint8_t*)d_enc, (uint32_t*)d_encsz);
         LTHIP_LAUNCH_CHECK(ctx);
     }

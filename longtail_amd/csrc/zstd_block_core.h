@@ -58,7 +58,7 @@ typedef struct ZbUnitMeta
     uint32_t nseq; /* sequences found in the unit */
     uint32_t nlit; /* literal bytes of the unit (all runs, tail included), stored contiguously */
     uint32_t tail; /* literals after the unit's last sequence (== nlit when nseq == 0) */
-    uint32_t pad;
+    uint32_t uniform; /* 0x100 | b when every byte of the unit equals b, else 0 */
 } ZbUnitMeta;
 
 typedef struct ZbInput

@@ -91,7 +91,7 @@ static void model_match_block(const uint8_t* base, size_t block_off, uint32_t si
         meta[u].nseq = nseq;
         meta[u].nlit = nlit;
         meta[u].tail = end - anchor;
-        meta[u].pad = 0;
+        meta[u].uniform = 0;
     }
 }
 

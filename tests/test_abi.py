@@ -81,3 +81,25 @@ def test_division_free_cut_test_is_exact(hiplib, oracle):
         hs += [int(k) * d + d - 1 for k in rng.integers(0, max(1, 2**32 // d), size=200) if int(k) * d + d - 1 < 2**32]
         for h in hs:
             assert f(d, h & 0xFFFFFFFF) == (1 if (h & 0xFFFFFFFF) % d == d - 1 else 0), (d, h)
+
+
+def test_pack_blocks_matches_reference_store_index(hiplib, oracle, ref):
+    """lthip_pack_blocks (host logic of the bulk path) against Longtail_CreateMissingContent -> Longtail_CreateStoreIndex
+    (src/longtail.c:6745-6880) run by the reference itself on the same chunk list: same number of blocks."""
+    from longtail_amd.lib import pack_blocks
+
+    rng = np.random.default_rng(21)
+    for target, max_block, max_chunks in [(65536, 8 << 20, 1024), (32768, 1 << 20, 16), (16384, 262144, 1024), (65536, 300000, 3)]:
+        files = [(f"d/f{i:03d}.bin", oracle.synth(int(rng.integers(1, 3 << 20)), 900 + i, 0)) for i in range(12)]
+        res = ref.ingest_time(files, target, max_block, max_chunks, ref.lz4_type, 2)
+        assert res["err"] == 0
+        mn, av, mx = max(48, target // 8), max(48, target // 2), max(48, target * 2)
+        lens = []
+        for name, data in sorted(files, key=lambda f: f[0]):  # version index order = sorted paths; random data: no duplicates
+            part = target * 1024
+            for s in range(0, len(data), part):
+                lens.append(oracle.chunk_and_hash(data[s : s + part], mn, av, mx)[1])
+        lens = np.concatenate(lens).astype(np.uint32)
+        assert len(lens) == res["chunks"]
+        starts = pack_blocks(lens, max_block, max_chunks, hiplib)
+        assert len(starts) - 1 == res["blocks"], (target, max_block, max_chunks)
