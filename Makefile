@@ -11,7 +11,7 @@ OBJDIR  := build/obj
 LIB     := longtail_amd/liblongtail_hip.so
 
 HIP_SRC := $(CSRC)/lthip_ctx.hip $(CSRC)/k_buzhash.hip $(CSRC)/k_blake3.hip $(CSRC)/k_lz4.hip $(CSRC)/k_zstd.hip \
-           $(CSRC)/k_dedup.hip $(CSRC)/k_gather.hip $(CSRC)/k_synth.hip
+           $(CSRC)/k_dedup.hip $(CSRC)/k_gather.hip $(CSRC)/k_synth.hip $(CSRC)/version_index.hip
 C_SRC   := $(CSRC)/plugin/plugin_common.c $(CSRC)/plugin/plugin_chunker.c $(CSRC)/plugin/plugin_hash.c \
            $(CSRC)/plugin/plugin_codec.c
 HIP_OBJ := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(HIP_SRC))
@@ -27,7 +27,7 @@ all: lib oracle
 $(OBJDIR):
 	mkdir -p $(OBJDIR)
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/lthip_internal.h include/longtail_hip.h include/longtail_abi.h include/longtail_synth.h | $(OBJDIR)
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/lthip_internal.h $(CSRC)/zstd_block_core.h include/longtail_hip.h include/longtail_abi.h include/longtail_synth.h | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(OBJDIR)/%.o: $(CSRC)/plugin/%.c $(CSRC)/plugin/plugin_common.h include/longtail_hip.h include/longtail_abi.h | $(OBJDIR)

@@ -199,6 +199,21 @@ LTHIP_EXPORT int lthip_zstd_debug_units(lthip_ctx* ctx, uint64_t first, uint64_t
 LTHIP_EXPORT int lthip_dedup_first_seen(lthip_ctx* ctx, uint64_t count, const uint64_t* d_hashes,
                                         uint32_t* d_first_index, uint64_t* d_unique_count);
 
+/* ---- bulk Longtail_CreateVersionIndex tail (src/longtail.c:2808-3017, layout :2551-2584, :2709-2806) ---
+ * From the device-resident chunk lists of lthip_chunk_hash -- all assets' chunks concatenated in (asset, part, chunk) order,
+ * asset a owning asset_chunk_counts[a] of them -- to the SERIALIZED VersionIndex (the bytes Longtail_WriteVersionIndexToBuffer
+ * produces, :3415): first-seen unique chunk list + per-asset-chunk indexes, content hash per asset (BLAKE3 of its chunk-hash
+ * array), path hashes.  The file list is a struct Longtail_FileInfos taken apart (src/longtail.h:1684-1692); directories are
+ * assets with zero chunks.  Host arrays unless marked d_.  Returns ENOMEM with *out_size set when `out` is too small. */
+LTHIP_EXPORT size_t lthip_version_index_size(uint32_t asset_count, uint64_t unique_chunk_count, uint64_t asset_chunk_index_count,
+                                             uint32_t path_data_size);
+LTHIP_EXPORT int lthip_build_version_index(lthip_ctx* ctx, uint32_t asset_count, const uint64_t* asset_sizes,
+                                           const uint32_t* path_start_offsets, const uint16_t* permissions, const char* path_data,
+                                           uint32_t path_data_size, const uint32_t* asset_chunk_counts, uint64_t chunk_total,
+                                           const uint64_t* d_chunk_hashes, const uint32_t* d_chunk_lens,
+                                           const uint32_t* asset_tags /* may be NULL */, uint32_t hash_identifier,
+                                           uint32_t target_chunk_size, void* out, size_t out_capacity, size_t* out_size);
+
 /* ---- synthetic assets (include/longtail_synth.h), bench/test input generator ------------------------ */
 LTHIP_EXPORT int lthip_synth_fill(lthip_ctx* ctx, void* d_dst, uint32_t asset_count, const uint64_t* asset_offsets /*host*/,
                                   const uint64_t* asset_sizes /*host*/, const uint64_t* asset_seeds /*host*/, int kind);

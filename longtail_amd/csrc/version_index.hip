@@ -1,0 +1,212 @@
+// version_index.hip -- SURVEY.md §8 f1: the tail of Longtail_CreateVersionIndex as one bulk call.
+//
+// The reference (src/longtail.c:2808-3017) takes the per-asset chunk lists that ChunkAssets concatenated in (asset,
+// part, chunk) order (:2499-2517), hashes every asset's array of chunk hashes into its content hash (:2518-2537), hashes
+// every path (:2008, 1269-1300), walks all chunks once to keep the FIRST occurrence of every chunk hash -- the unique
+// chunk list and the per-asset-chunk index into it (:2951-2970) -- and lays the result out with
+// Longtail_BuildVersionIndex (:2709-2806, layout :2551-2584).  Here the chunk lists are already on the device
+// (lthip_chunk_hash), so the same steps run there: first-seen table (k_dedup.hip), a scan that turns "is first" into the
+// unique index, BLAKE3 of the hash arrays and of the path strings (k_blake3.hip), and a final copy into the serialized
+// layout, byte for byte what Longtail_WriteVersionIndexToBuffer (:3415) would write.
+#include "lthip_internal.h"
+
+namespace
+{
+
+// is_first[i] = first_index[i] == i
+__global__ void k_vi_mark(const uint32_t* __restrict__ first_index, uint64_t n, uint32_t* __restrict__ is_first)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        is_first[i] = first_index[i] == (uint32_t)i ? 1u : 0u;
+}
+
+// asset_chunk_indexes[i] = rank[first_index[i]]; first occurrences also fill the compact arrays
+__global__ void k_vi_compact(const uint32_t* __restrict__ first_index, const uint32_t* __restrict__ rank, uint64_t n,
+                             const uint64_t* __restrict__ hashes, const uint32_t* __restrict__ lens,
+                             const uint32_t* __restrict__ asset_first_chunk /* [assets + 1] */, uint32_t asset_count,
+                             const uint32_t* __restrict__ asset_tags /* may be null */, uint32_t* __restrict__ indexes,
+                             uint64_t* __restrict__ uniq_hashes, uint32_t* __restrict__ uniq_sizes, uint32_t* __restrict__ uniq_tags)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t f = first_index[i];
+    const uint32_t r = rank[f];
+    indexes[i] = r;
+    if (f == (uint32_t)i)
+    {
+        uniq_hashes[r] = hashes[i];
+        uniq_sizes[r] = lens[i];
+        uint32_t tag = 0;
+        if (asset_tags)
+        {
+            uint32_t lo = 0, hi = asset_count; // asset a with asset_first_chunk[a] <= i < asset_first_chunk[a + 1]
+            while (hi - lo > 1)
+            {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (asset_first_chunk[mid] <= (uint32_t)i)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            tag = asset_tags[lo];
+        }
+        uniq_tags[r] = tag;
+    }
+}
+
+struct DevBuf
+{
+    void* p = nullptr;
+    ~DevBuf()
+    {
+        if (p)
+            (void)hipFree(p);
+    }
+    int alloc(lthip_ctx* ctx, size_t bytes)
+    {
+        LTHIP_CHECK(ctx, hipMalloc(&p, bytes ? bytes : 16));
+        return 0;
+    }
+};
+
+} // namespace
+
+extern "C" size_t lthip_version_index_size(uint32_t asset_count, uint64_t unique_chunk_count, uint64_t asset_chunk_index_count,
+                                           uint32_t path_data_size)
+{
+    // Longtail_GetVersionIndexDataSize, src/longtail.c:2551-2584
+    return 6 * sizeof(uint32_t) + (size_t)asset_count * (8 + 8 + 8 + 4 + 4) + (size_t)asset_chunk_index_count * 4 +
+           (size_t)unique_chunk_count * (8 + 4 + 4) + (size_t)asset_count * (4 + 2) + path_data_size;
+}
+
+extern "C" int lthip_build_version_index(lthip_ctx* ctx, uint32_t asset_count, const uint64_t* asset_sizes,
+                                         const uint32_t* path_start_offsets, const uint16_t* permissions, const char* path_data,
+                                         uint32_t path_data_size, const uint32_t* asset_chunk_counts, uint64_t chunk_total,
+                                         const uint64_t* d_chunk_hashes, const uint32_t* d_chunk_lens, const uint32_t* asset_tags,
+                                         uint32_t hash_identifier, uint32_t target_chunk_size, void* out, size_t out_capacity,
+                                         size_t* out_size)
+{
+    if (!ctx || !out_size || (asset_count && (!asset_sizes || !path_start_offsets || !permissions || !path_data || !asset_chunk_counts)) ||
+        (chunk_total && (!d_chunk_hashes || !d_chunk_lens)))
+        return EINVAL;
+    if (chunk_total > 0x7FFFFFF0ull)
+        return lthip_fail(ctx, EINVAL, "version index", "more than 2^31 chunks");
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = (uint32_t)chunk_total;
+    std::vector<uint32_t> starts((size_t)asset_count + 1, 0);
+    for (uint32_t a = 0; a < asset_count; ++a)
+        starts[a + 1] = starts[a] + asset_chunk_counts[a];
+    if (starts[asset_count] != n)
+        return lthip_fail(ctx, EINVAL, "version index", "asset chunk counts do not add up to the chunk total");
+
+    int err;
+    DevBuf d_first, d_isfirst, d_rank, d_idx, d_uh, d_us, d_ut, d_starts, d_tags, d_uniq, d_paths, d_off, d_len, d_ph, d_ch;
+    if ((err = d_first.alloc(ctx, (size_t)n * 4)) || (err = d_isfirst.alloc(ctx, (size_t)n * 4)) ||
+        (err = d_rank.alloc(ctx, ((size_t)n + 1) * 4)) || (err = d_idx.alloc(ctx, (size_t)n * 4)) ||
+        (err = d_uh.alloc(ctx, (size_t)n * 8)) || (err = d_us.alloc(ctx, (size_t)n * 4)) || (err = d_ut.alloc(ctx, (size_t)n * 4)) ||
+        (err = d_starts.alloc(ctx, ((size_t)asset_count + 1) * 4)) || (err = d_tags.alloc(ctx, (size_t)asset_count * 4)) ||
+        (err = d_uniq.alloc(ctx, 8)) || (err = d_paths.alloc(ctx, (size_t)path_data_size + 16)) ||
+        (err = d_off.alloc(ctx, (size_t)asset_count * 8)) || (err = d_len.alloc(ctx, (size_t)asset_count * 4)) ||
+        (err = d_ph.alloc(ctx, (size_t)asset_count * 8)) || (err = d_ch.alloc(ctx, (size_t)asset_count * 8)))
+        return err;
+
+    // ---- first-seen dedup -> unique index of every asset chunk, compact unique arrays (:2951-2970) ----
+    uint64_t unique = 0;
+    if ((err = lthip_dedup_first_seen(ctx, n, d_chunk_hashes, (uint32_t*)d_first.p, (uint64_t*)d_uniq.p)))
+        return err;
+    LTHIP_CHECK(ctx, hipMemcpyAsync(d_starts.p, starts.data(), ((size_t)asset_count + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (asset_tags && asset_count)
+        LTHIP_CHECK(ctx, hipMemcpyAsync(d_tags.p, asset_tags, (size_t)asset_count * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n)
+    {
+        const uint32_t blocks = (uint32_t)div_up_u64(n, 256);
+        hipLaunchKernelGGL(k_vi_mark, dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t*)d_first.p, (uint64_t)n,
+                           (uint32_t*)d_isfirst.p);
+        if ((err = lthip_exclusive_scan_u32(ctx, (const uint32_t*)d_isfirst.p, (uint32_t*)d_rank.p, n, nullptr, LTHIP_K_OTHER)))
+            return err;
+        hipLaunchKernelGGL(k_vi_compact, dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t*)d_first.p, (const uint32_t*)d_rank.p,
+                           (uint64_t)n, d_chunk_hashes, d_chunk_lens, (const uint32_t*)d_starts.p, asset_count,
+                           asset_tags ? (const uint32_t*)d_tags.p : (const uint32_t*)nullptr, (uint32_t*)d_idx.p, (uint64_t*)d_uh.p,
+                           (uint32_t*)d_us.p, (uint32_t*)d_ut.p);
+        LTHIP_LAUNCH_CHECK(ctx);
+    }
+    LTHIP_CHECK(ctx, hipMemcpyAsync(&unique, d_uniq.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+
+    // ---- content hash of every asset = BLAKE3 of its chunk-hash array (:2518-2537); path hashes (:1269-1300) ----
+    std::vector<uint64_t> h_off(asset_count);
+    std::vector<uint32_t> h_len(asset_count);
+    uint32_t max_len = 0;
+    for (uint32_t a = 0; a < asset_count; ++a)
+    {
+        h_off[a] = (uint64_t)starts[a] * 8u;
+        if ((uint64_t)asset_chunk_counts[a] * 8u > 0xFFFFFFFFull)
+            return lthip_fail(ctx, EINVAL, "version index", "asset with more than 2^29 chunks");
+        h_len[a] = asset_chunk_counts[a] * 8u; // the reference's hash_size is a uint32_t as well (:2522)
+        max_len = h_len[a] > max_len ? h_len[a] : max_len;
+    }
+    if (asset_count)
+    {
+        LTHIP_CHECK(ctx, hipMemcpyAsync(d_off.p, h_off.data(), (size_t)asset_count * 8, hipMemcpyHostToDevice, ctx->stream));
+        LTHIP_CHECK(ctx, hipMemcpyAsync(d_len.p, h_len.data(), (size_t)asset_count * 4, hipMemcpyHostToDevice, ctx->stream));
+        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // h_off / h_len are reused below
+        if ((err = lthip_hash_ranges(ctx, d_chunk_hashes ? (const void*)d_chunk_hashes : d_paths.p, asset_count, (const uint64_t*)d_off.p,
+                                     (const uint32_t*)d_len.p, max_len, (uint64_t*)d_ch.p)))
+            return err;
+        max_len = 0;
+        for (uint32_t a = 0; a < asset_count; ++a)
+        {
+            if (path_start_offsets[a] >= path_data_size)
+                return lthip_fail(ctx, EINVAL, "version index", "path offset outside the path data");
+            h_off[a] = path_start_offsets[a];
+            h_len[a] = (uint32_t)strnlen(path_data + path_start_offsets[a], path_data_size - path_start_offsets[a]);
+            max_len = h_len[a] > max_len ? h_len[a] : max_len;
+        }
+        LTHIP_CHECK(ctx, hipMemcpyAsync(d_paths.p, path_data, path_data_size, hipMemcpyHostToDevice, ctx->stream));
+        LTHIP_CHECK(ctx, hipMemcpyAsync(d_off.p, h_off.data(), (size_t)asset_count * 8, hipMemcpyHostToDevice, ctx->stream));
+        LTHIP_CHECK(ctx, hipMemcpyAsync(d_len.p, h_len.data(), (size_t)asset_count * 4, hipMemcpyHostToDevice, ctx->stream));
+        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if ((err = lthip_hash_ranges(ctx, d_paths.p, asset_count, (const uint64_t*)d_off.p, (const uint32_t*)d_len.p, max_len,
+                                     (uint64_t*)d_ph.p)))
+            return err;
+    }
+    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+    // ---- serialized layout (Longtail_BuildVersionIndex :2757-2806 over InitVersionIndexFromData's section order) ----
+    const size_t size = lthip_version_index_size(asset_count, unique, n, path_data_size);
+    *out_size = size;
+    if (!out || out_capacity < size)
+        return ENOMEM;
+    uint8_t* w = (uint8_t*)out;
+    const uint32_t head[6] = {(0u << 24) | (0u << 16) | 2u /* LONGTAIL_VERSION_INDEX_VERSION_0_0_2, :16-22 */, hash_identifier,
+                              target_chunk_size, asset_count, (uint32_t)unique, n};
+    memcpy(w, head, sizeof head);
+    w += sizeof head;
+#define LT_D2H(SRC, BYTES)                                                                      \
+    do                                                                                          \
+    {                                                                                           \
+        if (BYTES)                                                                              \
+            LTHIP_CHECK(ctx, hipMemcpy(w, (SRC), (BYTES), hipMemcpyDeviceToHost));              \
+        w += (BYTES);                                                                           \
+    } while (0)
+    LT_D2H(d_ph.p, (size_t)asset_count * 8);                  // m_PathHashes
+    LT_D2H(d_ch.p, (size_t)asset_count * 8);                  // m_ContentHashes
+    memcpy(w, asset_sizes, (size_t)asset_count * 8);          // m_AssetSizes
+    w += (size_t)asset_count * 8;
+    memcpy(w, asset_chunk_counts, (size_t)asset_count * 4);   // m_AssetChunkCounts
+    w += (size_t)asset_count * 4;
+    memcpy(w, starts.data(), (size_t)asset_count * 4);        // m_AssetChunkIndexStarts
+    w += (size_t)asset_count * 4;
+    LT_D2H(d_idx.p, (size_t)n * 4);                           // m_AssetChunkIndexes
+    LT_D2H(d_uh.p, (size_t)unique * 8);                       // m_ChunkHashes
+    LT_D2H(d_us.p, (size_t)unique * 4);                       // m_ChunkSizes
+    LT_D2H(d_ut.p, (size_t)unique * 4);                       // m_ChunkTags
+#undef LT_D2H
+    memcpy(w, path_start_offsets, (size_t)asset_count * 4);   // m_NameOffsets
+    w += (size_t)asset_count * 4;
+    memcpy(w, permissions, (size_t)asset_count * 2);          // m_Permissions
+    w += (size_t)asset_count * 2;
+    memcpy(w, path_data, path_data_size);                     // m_NameData
+    return 0;
+}

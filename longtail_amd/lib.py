@@ -107,6 +107,8 @@ class HipLib:
         sig("lthip_zstd_bound", sz, [sz])
         sig("lthip_zstd_compress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_zstd_debug_units", i32, [vp, u64, u64, vp, vp, vp])
+        sig("lthip_version_index_size", sz, [u32, u64, u64, u32])
+        sig("lthip_build_version_index", i32, [vp, u32, vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, u32, u32, vp, sz, vp])
         sig("lthip_dedup_first_seen", i32, [vp, u64, vp, vp, vp])
         sig("lthip_gather_ranges", i32, [vp, vp, u64, vp, vp, vp, vp])
         sig("lthip_pack_blocks", i32, [u64, vp, u32, u32, vp, u64, P(u64)])
@@ -276,6 +278,25 @@ class Context:
         self._check(self.lib.dll.lthip_zstd_debug_units(self.h, first, count, meta.ctypes.data, lits.ctypes.data,
                                                         recs.ctypes.data), "lthip_zstd_debug_units")
         return meta, lits, recs
+
+    def build_version_index(self, asset_sizes, path_start_offsets, permissions, path_data: bytes, asset_chunk_counts,
+                            chunk_hashes, chunk_lens, chunk_total: int, target_chunk_size: int, asset_tags=None,
+                            hash_identifier: int = 0x626C6B33) -> bytes:
+        """Serialized VersionIndex (== Longtail_WriteVersionIndexToBuffer) from device chunk lists; see longtail_hip.h."""
+        n = len(asset_sizes)
+        a_sz, a_off = _u64arr(asset_sizes), _u32arr(path_start_offsets)
+        a_perm = np.ascontiguousarray(np.asarray(permissions, dtype=np.uint16))
+        a_cnt = _u32arr(asset_chunk_counts)
+        a_tag = _u32arr(asset_tags) if asset_tags is not None else None
+        cap = self.lib.dll.lthip_version_index_size(n, chunk_total, chunk_total, len(path_data))
+        out = np.zeros(cap + 16, np.uint8)
+        size = C.c_size_t(0)
+        err = self.lib.dll.lthip_build_version_index(
+            self.h, n, a_sz.ctypes.data, a_off.ctypes.data, a_perm.ctypes.data, path_data, len(path_data), a_cnt.ctypes.data,
+            chunk_total, _ptr(chunk_hashes), _ptr(chunk_lens), a_tag.ctypes.data if a_tag is not None else None, hash_identifier,
+            target_chunk_size, out.ctypes.data, cap, C.byref(size))
+        self._check(err, "lthip_build_version_index")
+        return out[: size.value].tobytes()
 
     # -- block assembly --
     def gather_ranges(self, src, src_offsets, lens, dst, dst_offsets):

@@ -365,6 +365,36 @@ int refh_version_index(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_
     return err;
 }
 
+/* The struct Longtail_FileInfos the reference builds for a tree (Longtail_GetFilesRecursively2), flattened:
+ * [u32 count][u32 path_data_size][u64 sizes[count]][u32 path_start_offsets[count]][u16 permissions[count]][path data].
+ * Free with refh_free().  Lets the tests lay a tree out on the GPU in the reference's asset order. */
+int refh_tree_file_infos(uint32_t nfiles, const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
+                         void** out_buf, uint64_t* out_size)
+{
+    struct refh_tree t;
+    int err = tree_make(&t, nfiles, names, datas, sizes, 0, 0);
+    if (err)
+        return err;
+    const uint32_t n = t.files->m_Count, pd = t.files->m_PathDataSize;
+    const size_t size = 8 + (size_t)n * (8 + 4 + 2) + pd;
+    uint8_t* b = (uint8_t*)Longtail_Alloc("refh", size);
+    uint8_t* w = b;
+    memcpy(w, &n, 4);
+    memcpy(w + 4, &pd, 4);
+    w += 8;
+    memcpy(w, t.files->m_Sizes, (size_t)n * 8);
+    w += (size_t)n * 8;
+    memcpy(w, t.files->m_PathStartOffsets, (size_t)n * 4);
+    w += (size_t)n * 4;
+    memcpy(w, t.files->m_Permissions, (size_t)n * 2);
+    w += (size_t)n * 2;
+    memcpy(w, t.files->m_PathData, pd);
+    *out_buf = b;
+    *out_size = size;
+    tree_free(&t);
+    return 0;
+}
+
 /* ---- synchronous wrappers for the async block-store calls ---- */
 struct sync_existing
 {

@@ -125,6 +125,7 @@ class Ref:
         sig("refh_ingest_time", i32, [u32, u32, vp, vp, vp, u32, u32, u32, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64),
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)])
         sig("refh_cpu_count", i32, [])
+        sig("refh_tree_file_infos", i32, [u32, vp, vp, vp, C.POINTER(vp), C.POINTER(u64)])
         self.lz4_type = int(d.refh_lz4_type())
         self.zstd_default = int(d.refh_zstd_type(1))
 
@@ -184,6 +185,26 @@ class Ref:
         out = bytes((C.c_ubyte * size.value).from_address(buf.value))
         self.dll.refh_free(buf)
         return out, secs.value
+
+    def tree_file_infos(self, files):
+        """The reference's Longtail_FileInfos for the tree: (paths list, sizes u64, path_start_offsets u32, permissions u16,
+        path_data bytes), in the reference's asset order (directories included, with a trailing '/')."""
+        n, c_names, c_datas, c_sizes, keep = self._tree_args(files)
+        buf, size = vp(), u64(0)
+        err = self.dll.refh_tree_file_infos(n, c_names, c_datas, c_sizes, C.byref(buf), C.byref(size))
+        if err:
+            raise RuntimeError(f"refh_tree_file_infos failed: {err}")
+        raw = bytes((C.c_ubyte * size.value).from_address(buf.value))
+        self.dll.refh_free(buf)
+        cnt, pd = np.frombuffer(raw[:8], np.uint32)
+        cnt, pd = int(cnt), int(pd)
+        o = 8
+        sizes = np.frombuffer(raw[o : o + cnt * 8], np.uint64).copy(); o += cnt * 8
+        offs = np.frombuffer(raw[o : o + cnt * 4], np.uint32).copy(); o += cnt * 4
+        perms = np.frombuffer(raw[o : o + cnt * 2], np.uint16).copy(); o += cnt * 2
+        path_data = raw[o : o + pd]
+        paths = [path_data[int(a) : path_data.index(b"\0", int(a))].decode() for a in offs]
+        return paths, sizes, offs, perms, path_data
 
     def ingest_roundtrip(self, files, target_chunk_size, max_block_size, max_chunks_per_block, tag, workers=0,
                          chunker_api=None, hash_api=None, codec_api=None):
