@@ -97,13 +97,20 @@ def main():
     lib = load()
     if not torch.cuda.is_available() or lib.device_count() == 0:
         raise SystemExit("bench.py needs a GPU and liblongtail_hip.so: there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LONGTAIL_DIST_BACKEND=gloo runs the multi-rank flow with all ranks on the GPUs that exist (rank % device_count) and
+    # the exchange staged through host memory: a functional check of the N>1 path on a 1-GPU box, not a measurement
+    backend = os.environ.get("LONGTAIL_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
     kind = {"random": 0, "mixed": 1, "zero": 2, "records": 11, "tokens": 12, "lines": 13}[args.kind]
     mn, av, mx = chunker_params(args.target_chunk_size)
     part_bytes = args.target_chunk_size * 1024  # ChunkAssets part size (src/longtail.c:2396)
@@ -252,7 +259,7 @@ def main():
     ktimes = ctx.timing_get()
     ctx.timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -23,6 +23,9 @@ def allgather_hashes(local_hashes: torch.Tensor, total: int, group=None):
     if world == 1:
         return local_hashes[:total], 0, [total]
     rank = dist.get_rank(group)
+    out_dev = local_hashes.device
+    if out_dev.type == "cuda" and dist.get_backend(group) != "nccl":
+        local_hashes = local_hashes[:total].cpu()  # functional fallback for CPU-only backends (tests on a 1-GPU box)
     dev = local_hashes.device
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, torch.tensor([total], dtype=torch.int64, device=dev), group=group)
@@ -34,4 +37,4 @@ def allgather_hashes(local_hashes: torch.Tensor, total: int, group=None):
     recv = torch.empty(pad * world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
     pieces = [recv[r * pad : r * pad + counts_h[r]] for r in range(world)]
-    return torch.cat(pieces), sum(counts_h[:rank]), counts_h
+    return torch.cat(pieces).to(out_dev), sum(counts_h[:rank]), counts_h
