@@ -687,6 +687,19 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
     }
 }
 
+__device__ __forceinline__ void wg_emit_header(uint8_t* dst, uint32_t lits, uint32_t match_nibble, int tid, int nthreads)
+{
+    if (tid == 0)
+        dst[0] = (uint8_t)(((lits < 15u ? lits : 15u) << 4) | match_nibble);
+    if (lits >= 15u)
+    {
+        const uint32_t len = lits - 15u;
+        const uint32_t n = len / 255u + 1u;
+        for (uint32_t j = tid; j < n; j += nthreads)
+            dst[1 + j] = j + 1 == n ? (uint8_t)(len % 255u) : (uint8_t)255;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K6a: per-block serial walk over segment results
 // ---------------------------------------------------------------------------------------------------
@@ -699,7 +712,8 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
 __global__ __launch_bounds__(64) void k_lz4_stitch_scan(const Lz4Block* __restrict__ blocks, uint32_t b0, uint32_t nblocks, uint32_t SEG,
                                                         const Lz4Meta* __restrict__ meta, Lz4Plan* __restrict__ plan,
                                                         uint32_t* __restrict__ runs, Lz4BlockOut* __restrict__ bout,
-                                                        uint32_t* __restrict__ out_sizes)
+                                                        uint32_t* __restrict__ out_sizes, uint8_t* __restrict__ dst, uint32_t spec,
+                                                        uint32_t* __restrict__ worklist /* [0] = count, then group ids */)
 {
     const uint32_t b = blockIdx.x + b0;
     if (b >= nblocks)
@@ -769,6 +783,25 @@ __global__ __launch_bounds__(64) void k_lz4_stitch_scan(const Lz4Block* __restri
     const uint32_t hdr = 1u + lz4_len_bytes(carry);
     const uint64_t lit_dst = out_pos + hdr;
     const uint64_t total = lit_dst + carry;
+    // Which groups does the copy kernel have to visit?  A block without a single match was laid out by the match finder
+    // (spec): its one header is written here and the copy kernel never hears of it.
+    if (total <= (uint64_t)blk.dst_cap)
+    {
+        if (run == 0u && spec)
+        {
+            if (blk.nseg)
+                wg_emit_header(dst + blk.dst_off + out_pos, carry, 0u, lane, 64);
+        }
+        else
+        {
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(worklist, blk.ngrp);
+            base = __builtin_amdgcn_readfirstlane(base);
+            for (uint32_t k = lane; k < blk.ngrp; k += 64)
+                worklist[1u + base + k] = blk.grp_base + k;
+        }
+    }
     if (lane == 0)
     {
         runs[run_base + run] = (uint32_t)lit_dst;
@@ -819,33 +852,24 @@ __device__ __forceinline__ void wg_copy(uint8_t* __restrict__ dst, const uint8_t
         dst[done + tid] = src[done + tid];
 }
 
-__device__ __forceinline__ void wg_emit_header(uint8_t* dst, uint32_t lits, uint32_t match_nibble, int tid, int nthreads)
-{
-    if (tid == 0)
-        dst[0] = (uint8_t)(((lits < 15u ? lits : 15u) << 4) | match_nibble);
-    if (lits >= 15u)
-    {
-        const uint32_t len = lits - 15u;
-        const uint32_t n = len / 255u + 1u;
-        for (uint32_t j = tid; j < n; j += nthreads)
-            dst[1 + j] = j + 1 == n ? (uint8_t)(len % 255u) : (uint8_t)255;
-    }
-}
 
 constexpr int K6_THREADS = 256;
 
 // one workgroup per window group: its (up to LZ4_G) units are moved into place one after the other
 __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* __restrict__ src,
                                                                  const Lz4Block* __restrict__ blocks, uint32_t nblocks,
-                                                                 uint32_t grp0, uint32_t SEG, const uint8_t* __restrict__ streams,
+                                                                 uint32_t SEG, const uint8_t* __restrict__ streams,
                                                                  const Lz4Meta* __restrict__ meta,
                                                                  const Lz4Plan* __restrict__ plan,
                                                                  const uint32_t* __restrict__ runs,
                                                                  const Lz4BlockOut* __restrict__ bout,
-                                                                 uint8_t* __restrict__ dst, uint32_t spec)
+                                                                 uint8_t* __restrict__ dst, const uint32_t* __restrict__ worklist)
 {
     const int tid = threadIdx.x;
-    const uint32_t grp = blockIdx.x + grp0;
+    const uint32_t nwork = worklist[0];
+  for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x)
+  {
+    const uint32_t grp = worklist[1u + wi];
     uint32_t lo = 0, hi = nblocks;
     while (hi - lo > 1)
     {
@@ -857,18 +881,9 @@ __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* _
     }
     const Lz4Block blk = blocks[lo];
     const Lz4BlockOut bo = bout[lo];
-    if (bo.total == 0)
-        return; // does not fit: nothing is written, size 0 reported
     uint8_t* d = dst + blk.dst_off;
     const uint32_t i0 = (grp - blk.grp_base) * LZ4_G;
     const uint32_t i1 = i0 + LZ4_G < blk.nseg ? i0 + LZ4_G : blk.nseg;
-    if (bo.pad && spec)
-    {
-        // all-literal block whose bytes are in place already: only the header of its single run is missing
-        if (i1 == blk.nseg && tid < 64)
-            wg_emit_header(d + bo.final_hdr_pos, bo.final_lits, 0u, tid, 64);
-        return;
-    }
     // each wave moves whole units on its own (4 units in flight per workgroup: their table loads overlap)
     const int lane = tid & 63;
     for (uint32_t i = i0 + (uint32_t)(tid >> 6); i < i1; i += K6_THREADS / 64)
@@ -893,6 +908,7 @@ __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* _
         if (i + 1 == blk.nseg)
             wg_emit_header(d + bo.final_hdr_pos, bo.final_lits, 0u, lane, 64);
     }
+  }
 }
 
 // empty blocks have no segment: their single 0x00 token is written here
@@ -1118,6 +1134,12 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
         grp_first[b + 1] = grp_first[b] + (uint32_t)(((((uint64_t)src_sizes[b] + SEG - 1) / SEG) + LZ4_G - 1) / LZ4_G);
     const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * (1u << 11) * 2;
     const bool overlap = cut.size() > 2;
+    void* worklist;
+    if ((err = lthip_scratch(ctx, S_LZ4_WORKLIST, 4 * ((size_t)ngrp64 + 1) * (cut.size() - 1), &worklist)))
+        return err;
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const uint32_t copy_grid = (uint32_t)ncu * 8u; // persistent over the work list
     hipStream_t s2 = ctx->stream;
     if (overlap)
     {
@@ -1144,12 +1166,15 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
         }
         {
             LaunchTimer t(ctx, LTHIP_K_LZ4_STITCH, s2);
+            uint32_t* wl = (uint32_t*)worklist + (size_t)i * ((size_t)ngrp64 + 1); // one list per slice
+            LTHIP_CHECK(ctx, hipMemsetAsync(wl, 0, 4, s2));
             hipLaunchKernelGGL(k_lz4_stitch_scan, dim3(b1 - b0), dim3(64), 0, s2, d_blocks, b0, b1, SEG, (const Lz4Meta*)meta,
-                               (Lz4Plan*)plan, (uint32_t*)runs, (Lz4BlockOut*)bout, d_out_sizes);
+                               (Lz4Plan*)plan, (uint32_t*)runs, (Lz4BlockOut*)bout, d_out_sizes, (uint8_t*)d_dst, (dbg & 64u) ? 0u : 1u, wl);
             if (g1 > g0)
-                hipLaunchKernelGGL(k_lz4_stitch_copy, dim3(g1 - g0), dim3(K6_THREADS), 0, s2, (const uint8_t*)d_src, d_blocks, block_count, g0,
-                                   SEG, (const uint8_t*)streams, (const Lz4Meta*)meta, (const Lz4Plan*)plan, (const uint32_t*)runs,
-                                   (const Lz4BlockOut*)bout, (uint8_t*)d_dst, (dbg & 64u) ? 0u : 1u);
+                hipLaunchKernelGGL(k_lz4_stitch_copy, dim3(g1 - g0 < copy_grid ? g1 - g0 : copy_grid), dim3(K6_THREADS), 0, s2,
+                                   (const uint8_t*)d_src, d_blocks, block_count, SEG, (const uint8_t*)streams, (const Lz4Meta*)meta,
+                                   (const Lz4Plan*)plan, (const uint32_t*)runs, (const Lz4BlockOut*)bout, (uint8_t*)d_dst,
+                                   (const uint32_t*)wl);
             if (i + 2 == cut.size())
                 hipLaunchKernelGGL(k_lz4_empty_blocks, dim3((block_count + 255) / 256), dim3(256), 0, s2, d_blocks, block_count,
                                    (const Lz4BlockOut*)bout, (uint8_t*)d_dst);

@@ -78,6 +78,7 @@ enum ScratchSlot
     S_Z_RECS,  // zstd: sequence records per unit
     S_Z_ENC,   // zstd: encoded 128 KiB pieces
     S_Z_WORK,  // zstd: per-encoder-wave work area
+    S_LZ4_WORKLIST, // groups the stitch copy has to visit
     S_COUNT
 };
 
