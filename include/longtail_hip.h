@@ -187,6 +187,13 @@ LTHIP_EXPORT int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, u
                                             const uint64_t* src_offsets, const uint32_t* src_sizes, void* d_dst,
                                             const uint64_t* dst_offsets, const uint32_t* dst_caps,
                                             uint32_t* d_out_sizes);
+/* ZStdCompressionAPI_Decompress (longtail_zstd.c:144-177): every payload is one or more zstd frames (any encoder's: Huffman /
+ * FSE / repeat modes / repeat offsets / skippable frames; no dictionaries; a content checksum is skipped, not verified).
+ * d_out_sizes[b] = decoded size, or 0xFFFFFFFF when the payload is malformed or does not fit dst_caps[b]. */
+LTHIP_EXPORT int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count,
+                                              const uint64_t* src_offsets, const uint32_t* src_sizes, void* d_dst,
+                                              const uint64_t* dst_offsets, const uint32_t* dst_caps,
+                                              uint32_t* d_out_sizes);
 /* Diagnostics (parity tests): match-finder output of the last lthip_zstd_compress_blocks call on this context for the
  * 4 KiB units [first, first + count) -- 16 bytes of meta {nseq, nlit, tail, 0}, 4096 literal bytes and 1024 u64
  * records {lit | mlen << 16 | offset << 32} per unit (host buffers, any may be NULL). */

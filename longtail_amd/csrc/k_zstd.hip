@@ -29,7 +29,7 @@ __device__ unsigned long long g_zb_last[1 << 16];
         }                                                                                              \
     } while (0)
 #endif
-#include "zstd_block_core.h"
+#include "zstd_decode_core.h" /* includes zstd_block_core.h */
 
 namespace
 {
@@ -331,6 +331,64 @@ extern "C" __attribute__((visibility("default"))) int lthip_zb_prof_dump(void)
     return 0;
 }
 #endif
+
+// ---------------------------------------------------------------------------------------------------
+// decoder: one wavefront per payload, persistent over the payloads (zstd_decode_core.h)
+// ---------------------------------------------------------------------------------------------------
+namespace
+{
+__global__ __launch_bounds__(64) void k_zstd_decode(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t nblocks,
+                                                    uint8_t* __restrict__ dst, uint8_t* __restrict__ lit_scratch,
+                                                    uint32_t* __restrict__ out_sizes)
+{
+    __shared__ ZdShared sh;
+    uint8_t* lits = lit_scratch + (uint64_t)blockIdx.x * (ZD_LIT_MAX + 64u);
+    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x)
+    {
+        const ZBlock blk = blocks[b];
+        const uint32_t n = zd_decode_payload(src + blk.src_off, blk.size, dst + blk.dst_off, blk.dst_cap, lits, &sh, threadIdx.x);
+        if (threadIdx.x == 0)
+            out_sizes[b] = n; // ZD_ERROR (0xFFFFFFFF) for malformed input, like lthip_lz4_decompress_blocks
+        __syncthreads();
+    }
+}
+} // namespace
+
+extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
+                                            const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
+                                            const uint32_t* dst_caps, uint32_t* d_out_sizes)
+{
+    if (!ctx || !d_out_sizes || (block_count && (!src_offsets || !src_sizes || !dst_offsets || !dst_caps)))
+        return EINVAL;
+    if (block_count == 0)
+        return 0;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::vector<ZBlock> hb(block_count);
+    for (uint32_t b = 0; b < block_count; ++b)
+    {
+        hb[b].src_off = src_offsets[b];
+        hb[b].dst_off = dst_offsets[b];
+        hb[b].size = src_sizes[b];
+        hb[b].dst_cap = dst_caps[b];
+        hb[b].zb_base = hb[b].nzb = hb[b].unit_base = hb[b].pad = 0;
+    }
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const uint32_t nwg = block_count < (uint32_t)ncu * 8u ? block_count : (uint32_t)ncu * 8u;
+    void *d_blocks, *d_lits;
+    int err;
+    if ((err = lthip_scratch(ctx, S_LZ4_BLOCKS, sizeof(ZBlock) * (size_t)block_count, &d_blocks)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_Z_WORK, (size_t)(ZD_LIT_MAX + 64u) * nwg, &d_lits)))
+        return err;
+    LTHIP_CHECK(ctx, hipMemcpyAsync(d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, hipMemcpyHostToDevice, ctx->stream));
+    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    LaunchTimer t(ctx, LTHIP_K_OTHER);
+    hipLaunchKernelGGL(k_zstd_decode, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks, block_count,
+                       (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes);
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
+}
 
 // Diagnostics for the parity tests: the match finder's output of the LAST lthip_zstd_compress_blocks call on this
 // context (units [first, first+count)), so that the host model of the entropy stage can be run on the same input.

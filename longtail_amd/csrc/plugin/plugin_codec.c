@@ -56,7 +56,9 @@ static int run_block(int codec, int decompress, const char* src, char* dst, size
         return err;
     const uint64_t zero = 0;
     const uint32_t sz = (uint32_t)n, dcap = (uint32_t)cap;
-    if (decompress)
+    if (decompress && codec == CODEC_ZSTD)
+        err = lthip_zstd_decompress_blocks(ctx, ts->d_in.p, 1, &zero, &sz, ts->d_out.p, &zero, &dcap, (uint32_t*)ts->d_aux.p);
+    else if (decompress)
         err = lthip_lz4_decompress_blocks(ctx, ts->d_in.p, 1, &zero, &sz, ts->d_out.p, &zero, &dcap, (uint32_t*)ts->d_aux.p);
     else if (codec == CODEC_LZ4)
         err = lthip_lz4_compress_blocks(ctx, ts->d_in.p, 1, &zero, &sz, ts->d_out.p, &zero, &dcap, (uint32_t*)ts->d_aux.p, 0);
@@ -73,7 +75,7 @@ static int run_block(int codec, int decompress, const char* src, char* dst, size
     if (decompress)
     {
         if (produced == 0xFFFFFFFFu)
-            return EBADF; /* longtail_lz4.c:95-99 */
+            return codec == CODEC_ZSTD ? EINVAL : EBADF; /* longtail_lz4.c:95-99; longtail_zstd.c:168-172 */
     }
     else if (produced == 0)
         return ENOMEM; /* longtail_lz4.c:70-74 */
@@ -110,8 +112,6 @@ static int HipCodec_Decompress(struct Longtail_CompressionAPI* compression_api, 
     if (!compression_api || !compressed || !out_uncompressed_size || (max_uncompressed_size && !uncompressed))
         return EINVAL;
     struct HipCodecAPI* a = (struct HipCodecAPI*)compression_api;
-    if (a->codec != CODEC_LZ4)
-        return ENOTSUP; /* GPU zstd decoder: SURVEY.md §8 f3, not built yet -- register the reference decoder for reads */
     return run_block(a->codec, 1, compressed, uncompressed, compressed_size, max_uncompressed_size, out_uncompressed_size);
 }
 

@@ -106,6 +106,7 @@ class HipLib:
         sig("lthip_lz4_decompress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_zstd_bound", sz, [sz])
         sig("lthip_zstd_compress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
+        sig("lthip_zstd_decompress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_zstd_debug_units", i32, [vp, u64, u64, vp, vp, vp])
         sig("lthip_version_index_size", sz, [u32, u64, u64, u32])
         sig("lthip_build_version_index", i32, [vp, u32, vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, u32, u32, vp, sz, vp])
@@ -267,6 +268,10 @@ class Context:
 
     def zstd_compress_blocks(self, src, src_offsets, src_sizes, dst, dst_offsets, dst_caps):
         return self._codec(self.lib.dll.lthip_zstd_compress_blocks, src, src_offsets, src_sizes, dst, dst_offsets,
+                           dst_caps)
+
+    def zstd_decompress_blocks(self, src, src_offsets, src_sizes, dst, dst_offsets, dst_caps):
+        return self._codec(self.lib.dll.lthip_zstd_decompress_blocks, src, src_offsets, src_sizes, dst, dst_offsets,
                            dst_caps)
 
     def zstd_debug_units(self, first: int, count: int):

@@ -21,7 +21,7 @@ static inline void zb_atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
 
 static uint32_t g_ltz_dbg;
 #define ZB_DBG g_ltz_dbg
-#include "../longtail_amd/csrc/zstd_block_core.h"
+#include "../longtail_amd/csrc/zstd_decode_core.h" /* includes zstd_block_core.h */
 void ltz_model_debug(uint32_t flags) { g_ltz_dbg = flags; }
 
 #include "oracle.h"
@@ -159,5 +159,25 @@ int ltz_model_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, s
     free(unit_recs);
     free(enc);
     *out_n = pos;
+    return 0;
+}
+
+static uint32_t g_ltz_fail_line;
+uint32_t ltz_model_fail_line(void) { return g_ltz_fail_line; }
+
+/* Host instantiation of the GPU's zstd decoder (zstd_decode_core.h).  Returns 0 and *out_n, or -1 on malformed input. */
+int ltz_model_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n)
+{
+    ZdShared* sh = (ZdShared*)calloc(1, sizeof(ZdShared));
+    uint8_t* lits = (uint8_t*)malloc(ZD_LIT_MAX + 32);
+    uint32_t r = ZD_ERROR;
+    if (n <= 0xFFFFFFF0u && cap <= 0xFFFFFFF0u)
+        r = zd_decode_payload(src, (uint32_t)n, dst, (uint32_t)cap, lits, sh, 0);
+    g_ltz_fail_line = r == ZD_ERROR ? sh->v[ZDV_SRC] : 0;
+    free(lits);
+    free(sh);
+    if (r == ZD_ERROR)
+        return -1;
+    *out_n = r;
     return 0;
 }

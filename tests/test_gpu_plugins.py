@@ -174,6 +174,31 @@ def test_zstd_plugin_compress_decodes_with_reference(plugins, ref, oracle):
         assert err == 0 and len(back) == n and (back == d).all()
 
 
+def test_zstd_plugin_decompress_reads_reference_frames(plugins, ref, oracle):
+    """ZStdCompressionAPI_Decompress on the GPU: frames written by the REFERENCE encoder at every longtail setting
+    ('ztd1'..'ztd5', lib/zstd/longtail_zstd.c:12-22) and frames written by the HIP encoder itself; malformed -> EINVAL."""
+    ptr = plugins["zstd"]
+    api = CompressionAPIStruct.from_address(ptr)
+    for n, kind in ((0, 0), (1000, 1), (400000, 1), (400000, 2), (700000, 12), ((1 << 20) + 3, 11)):
+        d = oracle.synth(n, 12 + n, kind)
+        frames = [ref.compress(1, ref.dll.refh_zstd_type(w), d) for w in range(5)]
+        cap = api.GetMaxCompressedSize(ptr, ref.zstd_default, n)
+        own = np.zeros(cap + 8, np.uint8)
+        got = C.c_size_t(0)
+        assert api.Compress(ptr, ref.zstd_default, d.ctypes.data if n else own.ctypes.data, own.ctypes.data, n, cap, C.byref(got)) == 0
+        frames.append(own[: got.value].copy())
+        for f in frames:
+            back = np.zeros(n + 8, np.uint8)
+            m = C.c_size_t(0)
+            assert api.Decompress(ptr, f.ctypes.data, back.ctypes.data, len(f), n, C.byref(m)) == 0
+            assert m.value == n and (back[:n] == d).all()
+        if n > 1000:
+            bad = frames[0].copy()
+            bad[len(bad) // 2 :] = 0
+            m = C.c_size_t(0)
+            assert api.Decompress(ptr, bad.ctypes.data, np.zeros(n + 8, np.uint8).ctypes.data, len(bad), n, C.byref(m)) == errno.EINVAL
+
+
 def test_lz4_plugin_entry_points(plugins, ref, oracle):
     ptr = plugins["lz4"]
     api = CompressionAPIStruct.from_address(ptr)

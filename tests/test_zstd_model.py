@@ -110,3 +110,64 @@ def test_encode_block_from_records_maximum_sequence_count(model):
                             np.frombuffer((1 | 2 << 1 | n << 3).to_bytes(3, "little"), np.uint8), out[:n]])
     err, dec = get_ref().decompress(CODEC_ZSTD, frame, len(raw))
     assert err == 0 and (dec == raw).all()
+
+
+# ---- decoder (zstd_decode_core.h, host instantiation) ----
+def model_decode(o, frame: np.ndarray, cap: int):
+    o.dll.ltz_model_decompress.restype = C.c_int
+    o.dll.ltz_model_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    out = np.zeros(cap + 8, np.uint8)
+    n = C.c_size_t(0)
+    err = o.dll.ltz_model_decompress(frame.ctypes.data, len(frame), out.ctypes.data, cap, C.byref(n))
+    return err, out[: n.value]
+
+
+@pytest.mark.parametrize("setting", range(5))
+def test_decoder_reads_reference_encoder_output(model, setting):
+    """Frames from the reference's ZSTD_compressCCtx at longtail's five settings (levels 3, 3, 22, 8, 22): Huffman with
+    direct and FSE-coded weights, treeless blocks, all FSE modes incl. Repeat, repeat offsets, 1- and 4-stream literals."""
+    r = get_ref()
+    st = r.dll.refh_zstd_type(setting)
+    rng = np.random.default_rng(setting)
+    datas = [model.synth(n, 5 + n + k, k) for k in (0, 1, 2, 11, 12, 13) for n in (0, 1, 100, 5000, 131072, 131073, 400000, 3 << 20)]
+    datas.append((np.abs(rng.normal(128, 20, 700000)).astype(np.int64) % 256).astype(np.uint8))
+    datas.append(np.frombuffer(b"the quick brown fox jumps over the lazy dog. " * 9000, np.uint8).copy())
+    for d in datas:
+        err, out = model_decode(model, r.compress(1, st, d), len(d))
+        assert err == 0 and len(out) == len(d) and (out == d).all()
+
+
+def test_decoder_reads_own_encoder_and_concatenated_frames(model):
+    a, b = model.synth(300000, 1, 1), model.synth(70000, 2, 12)
+    fa, fb = compress(model, a), compress(model, b)
+    skippable = np.frombuffer(bytes([0x5A, 0x2A, 0x4D, 0x18, 2, 0, 0, 0, 9, 9]), np.uint8)
+    err, out = model_decode(model, np.concatenate([fa, skippable, fb]), len(a) + len(b))
+    assert err == 0 and (out == np.concatenate([a, b])).all()
+    assert model_decode(model, fa, len(a) - 1)[0] != 0  # destination too small
+    assert model_decode(model, fa[:-1].copy(), len(a))[0] != 0  # truncated
+
+
+def test_decoder_never_accepts_what_the_reference_rejects(model):
+    """Differential fuzz on mutated reference frames: whenever the model accepts, the reference accepts with identical
+    bytes.  (The converse does not hold: the reference's fast 4-stream Huffman loop does not verify that each literal
+    stream is consumed exactly, huf_decompress.c:872-887, RFC 8878 §4.2.2 says it must be.)"""
+    r = get_ref()
+    rng = np.random.default_rng(9)
+    both = 0
+    for kind, n in ((1, 200000), (11, 30000), (12, 100000), (13, 60000), (1, 3000)):
+        b = model.synth(n, 31 + n, kind)
+        for w in (0, 2):
+            c = r.compress(1, r.dll.refh_zstd_type(w), b)
+            for _ in range(150):
+                x = c.copy()
+                if rng.integers(0, 4) == 0:
+                    x = x[: rng.integers(0, len(x) + 1)].copy()
+                else:
+                    for _ in range(int(rng.integers(1, 4))):
+                        x[rng.integers(0, len(x))] ^= np.uint8(1 << rng.integers(0, 8))
+                e2, o2 = model_decode(model, x, n)
+                if e2 == 0:
+                    e1, o1 = r.decompress(1, x, n)
+                    assert e1 == 0 and len(o1) == len(o2) and (o1 == o2).all()
+                    both += 1
+    assert both > 100
