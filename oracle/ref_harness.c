@@ -18,6 +18,7 @@
 #include "lib/hpcdcchunker/longtail_hpcdcchunker.h"
 #include "lib/lz4/longtail_lz4.h"
 #include "lib/memstorage/longtail_memstorage.h"
+#include "lib/memtracer/longtail_memtracer.h"
 #include "lib/filestorage/longtail_filestorage.h"
 #include "lib/zstd/longtail_zstd.h"
 
@@ -394,6 +395,23 @@ int refh_tree_file_infos(uint32_t nfiles, const char* const* names, const uint8_
     tree_free(&t);
     return 0;
 }
+
+/* Leak accounting with the reference's own tracer (lib/memtracer): everything allocated through Longtail_Alloc --
+ * including the HIP plugins' objects once Longtail_Hip_SetAllocator(refh_alloc_ptr(), refh_free_ptr()) is in effect --
+ * is counted; after every API object is disposed the outstanding count must be back to zero. */
+void refh_memtrace_begin(void)
+{
+    Longtail_MemTracer_Init();
+    Longtail_SetReAllocAndFree(Longtail_MemTracer_ReAlloc, Longtail_MemTracer_Free);
+}
+uint64_t refh_memtrace_outstanding(void) { return Longtail_MemTracer_GetAllocationCount(0); }
+void refh_memtrace_end(void)
+{
+    Longtail_SetReAllocAndFree(0, 0);
+    Longtail_MemTracer_Dispose();
+}
+void* refh_alloc_ptr(void) { return (void*)Longtail_Alloc; }
+void* refh_free_ptr(void) { return (void*)Longtail_Free; }
 
 /* ---- synchronous wrappers for the async block-store calls ---- */
 struct sync_existing

@@ -227,3 +227,18 @@ def test_lz4_plugin_entry_points(plugins, ref, oracle):
     assert api.Compress(ptr, tag, d.ctypes.data, out.ctypes.data, len(d), 100, C.byref(got)) == errno.ENOMEM
     junk = np.full(100, 0xFF, np.uint8)
     assert api.Decompress(ptr, junk.ctypes.data, out.ctypes.data, len(junk), 1000, C.byref(got)) == errno.EBADF
+
+
+def test_plugins_do_not_leak_under_the_reference_memtracer():
+    """Own process: Longtail_Hip_SetAllocator(Longtail_Alloc, Longtail_Free) + lib/memtracer around VersionIndex and UpSync
+    runs with 0 and 4 bikeshed workers; after disposing the four HIP API objects nothing they allocated is outstanding."""
+    import subprocess
+    import sys
+
+    from tests._libs import ROOT
+
+    out = subprocess.run([sys.executable, str(ROOT / "tools" / "memtrace_check.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("outstanding")][-1].split()
+    assert int(line[1]) == 0, line
+    assert int(line[-1]) >= 4  # the objects were really counted while alive
