@@ -221,6 +221,20 @@ LTHIP_EXPORT int lthip_build_version_index(lthip_ctx* ctx, uint32_t asset_count,
                                            const uint32_t* asset_tags /* may be NULL */, uint32_t hash_identifier,
                                            uint32_t target_chunk_size, void* out, size_t out_capacity, size_t* out_size);
 
+/* ---- stored blocks ------------------------------------------------------------------
+ * The bytes of a stored block file (Longtail_WriteStoredBlockToBuffer, src/longtail.c:4111-4150) around a compressed
+ * payload: BlockIndex data (block hash = hash of the chunk-hash array :3753-3757, hash identifier, chunk count, tag,
+ * chunk hashes, chunk sizes, layout :3585-3601) then [u32 raw size][u32 compressed size] (compressblockstore.c:103-139).
+ * Compress block b to  image_offsets[b] + lthip_stored_block_header_size(chunks of b)  first; this call fills in the rest,
+ * so the image of block b is  d_arena[image_offsets[b] .. + header size + compressed size).  Block b holds the chunks
+ * [block_first_chunk[b], block_first_chunk[b+1]) of the (unique, first-seen ordered) device arrays; image offsets must be
+ * 8-byte aligned; host arrays unless marked d_. */
+LTHIP_EXPORT size_t lthip_stored_block_header_size(uint32_t chunk_count);
+LTHIP_EXPORT int lthip_write_stored_block_headers(lthip_ctx* ctx, uint32_t block_count, const uint64_t* block_first_chunk,
+                                                  const uint64_t* d_chunk_hashes, const uint32_t* d_chunk_lens,
+                                                  uint32_t hash_identifier, uint32_t tag, const uint32_t* raw_sizes,
+                                                  const uint32_t* d_comp_sizes, void* d_arena, const uint64_t* image_offsets);
+
 /* ---- synthetic assets (include/longtail_synth.h), bench/test input generator ------------------------ */
 LTHIP_EXPORT int lthip_synth_fill(lthip_ctx* ctx, void* d_dst, uint32_t asset_count, const uint64_t* asset_offsets /*host*/,
                                   const uint64_t* asset_sizes /*host*/, const uint64_t* asset_seeds /*host*/, int kind);

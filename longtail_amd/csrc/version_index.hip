@@ -210,3 +210,112 @@ extern "C" int lthip_build_version_index(lthip_ctx* ctx, uint32_t asset_count, c
     memcpy(w, path_data, path_data_size);                     // m_NameData
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// stored blocks.  What fsblockstore puts in a .lsb file (Longtail_WriteStoredBlockToBuffer,
+// src/longtail.c:4111-4150) is the BlockIndex data (layout :3585-3601: block hash, hash identifier, chunk count, tag,
+// chunk hashes, chunk sizes; the block hash is the hash of the block's chunk-hash array, :3753-3757) followed by the
+// block data, which for a compressed store is [u32 raw size][u32 compressed size][payload] (CompressBlock,
+// lib/compressblockstore/longtail_compressblockstore.c:103-139).  The bulk path compresses straight to
+// image_offset + lthip_stored_block_header_size(chunk count), so the payload is never copied; the kernel below writes
+// the bytes around it.
+// ---------------------------------------------------------------------------------------------------
+namespace
+{
+__global__ __launch_bounds__(64) void k_stored_block_headers(const uint32_t* __restrict__ block_first_chunk /* [nblocks + 1] */,
+                                                             uint32_t nblocks, const uint64_t* __restrict__ chunk_hashes,
+                                                             const uint32_t* __restrict__ chunk_lens,
+                                                             const uint64_t* __restrict__ block_hashes, uint32_t hash_identifier,
+                                                             uint32_t tag, const uint32_t* __restrict__ raw_sizes,
+                                                             const uint32_t* __restrict__ comp_sizes,
+                                                             const uint64_t* __restrict__ image_offsets, uint8_t* __restrict__ arena)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks)
+        return;
+    const uint32_t c0 = block_first_chunk[b], n = block_first_chunk[b + 1] - c0;
+    uint8_t* w = arena + image_offsets[b]; // 8-byte aligned by contract
+    const int lane = threadIdx.x;
+    if (lane == 0)
+    {
+        *reinterpret_cast<uint64_t*>(w) = block_hashes[b];
+        uint32_t* h = reinterpret_cast<uint32_t*>(w + 8);
+        h[0] = hash_identifier;
+        h[1] = n;
+        h[2] = tag;
+    }
+    uint8_t* hashes = w + 20; // only 4-byte aligned
+    for (uint32_t i = lane; i < n; i += 64)
+    {
+        const uint64_t v = chunk_hashes[c0 + i];
+        uint32_t* p = reinterpret_cast<uint32_t*>(hashes + (size_t)i * 8);
+        p[0] = (uint32_t)v;
+        p[1] = (uint32_t)(v >> 32);
+    }
+    uint32_t* sizes = reinterpret_cast<uint32_t*>(hashes + (size_t)n * 8);
+    for (uint32_t i = lane; i < n; i += 64)
+        sizes[i] = chunk_lens[c0 + i];
+    if (lane == 0)
+    {
+        sizes[n] = raw_sizes[b];
+        sizes[n + 1] = comp_sizes[b];
+    }
+}
+} // namespace
+
+extern "C" size_t lthip_stored_block_header_size(uint32_t chunk_count)
+{
+    return 8 + 4 + 4 + 4 + (size_t)chunk_count * 12 /* Longtail_GetBlockIndexDataSize */ + 8 /* raw + compressed size */;
+}
+
+extern "C" int lthip_write_stored_block_headers(lthip_ctx* ctx, uint32_t block_count, const uint64_t* block_first_chunk,
+                                                const uint64_t* d_chunk_hashes, const uint32_t* d_chunk_lens,
+                                                uint32_t hash_identifier, uint32_t tag, const uint32_t* raw_sizes,
+                                                const uint32_t* d_comp_sizes, void* d_arena, const uint64_t* image_offsets)
+{
+    if (!ctx || (block_count && (!block_first_chunk || !d_chunk_hashes || !d_chunk_lens || !raw_sizes || !d_comp_sizes || !d_arena ||
+                                 !image_offsets)))
+        return EINVAL;
+    if (block_count == 0)
+        return 0;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> first((size_t)block_count + 1), lens(block_count);
+    std::vector<uint64_t> offs(block_count);
+    uint32_t max_len = 0;
+    for (uint32_t b = 0; b <= block_count; ++b)
+    {
+        if (block_first_chunk[b] > 0x7FFFFFF0ull || (b && block_first_chunk[b] < block_first_chunk[b - 1]))
+            return lthip_fail(ctx, EINVAL, "stored blocks", "block_first_chunk must be non-decreasing and below 2^31");
+        first[b] = (uint32_t)block_first_chunk[b];
+    }
+    for (uint32_t b = 0; b < block_count; ++b)
+    {
+        if (image_offsets[b] & 7u)
+            return lthip_fail(ctx, EINVAL, "stored blocks", "image offsets must be 8-byte aligned");
+        offs[b] = (uint64_t)first[b] * 8u;
+        lens[b] = (first[b + 1] - first[b]) * 8u;
+        max_len = lens[b] > max_len ? lens[b] : max_len;
+    }
+    DevBuf d_first, d_off, d_len, d_bh, d_raw, d_img;
+    int err;
+    if ((err = d_first.alloc(ctx, ((size_t)block_count + 1) * 4)) || (err = d_off.alloc(ctx, (size_t)block_count * 8)) ||
+        (err = d_len.alloc(ctx, (size_t)block_count * 4)) || (err = d_bh.alloc(ctx, (size_t)block_count * 8)) ||
+        (err = d_raw.alloc(ctx, (size_t)block_count * 4)) || (err = d_img.alloc(ctx, (size_t)block_count * 8)))
+        return err;
+    LTHIP_CHECK(ctx, hipMemcpyAsync(d_first.p, first.data(), ((size_t)block_count + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    LTHIP_CHECK(ctx, hipMemcpyAsync(d_off.p, offs.data(), (size_t)block_count * 8, hipMemcpyHostToDevice, ctx->stream));
+    LTHIP_CHECK(ctx, hipMemcpyAsync(d_len.p, lens.data(), (size_t)block_count * 4, hipMemcpyHostToDevice, ctx->stream));
+    LTHIP_CHECK(ctx, hipMemcpyAsync(d_raw.p, raw_sizes, (size_t)block_count * 4, hipMemcpyHostToDevice, ctx->stream));
+    LTHIP_CHECK(ctx, hipMemcpyAsync(d_img.p, image_offsets, (size_t)block_count * 8, hipMemcpyHostToDevice, ctx->stream));
+    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // host vectors go out of scope
+    if ((err = lthip_hash_ranges(ctx, d_chunk_hashes, block_count, (const uint64_t*)d_off.p, (const uint32_t*)d_len.p, max_len,
+                                 (uint64_t*)d_bh.p)))
+        return err;
+    LaunchTimer t(ctx, LTHIP_K_OTHER);
+    hipLaunchKernelGGL(k_stored_block_headers, dim3(block_count), dim3(64), 0, ctx->stream, (const uint32_t*)d_first.p, block_count,
+                       d_chunk_hashes, d_chunk_lens, (const uint64_t*)d_bh.p, hash_identifier, tag, (const uint32_t*)d_raw.p, d_comp_sizes,
+                       (const uint64_t*)d_img.p, (uint8_t*)d_arena);
+    LTHIP_LAUNCH_CHECK(ctx);
+    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // the DevBufs are freed on return
+    return 0;
+}

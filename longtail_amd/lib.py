@@ -108,6 +108,8 @@ class HipLib:
         sig("lthip_zstd_compress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_zstd_decompress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_zstd_debug_units", i32, [vp, u64, u64, vp, vp, vp])
+        sig("lthip_stored_block_header_size", sz, [u32])
+        sig("lthip_write_stored_block_headers", i32, [vp, u32, vp, vp, vp, u32, u32, vp, vp, vp, vp])
         sig("lthip_version_index_size", sz, [u32, u64, u64, u32])
         sig("lthip_build_version_index", i32, [vp, u32, vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, u32, u32, vp, sz, vp])
         sig("lthip_dedup_first_seen", i32, [vp, u64, vp, vp, vp])
@@ -302,6 +304,14 @@ class Context:
             target_chunk_size, out.ctypes.data, cap, C.byref(size))
         self._check(err, "lthip_build_version_index")
         return out[: size.value].tobytes()
+
+    def write_stored_block_headers(self, block_first_chunk, chunk_hashes, chunk_lens, tag: int, raw_sizes, comp_sizes, arena,
+                                   image_offsets, hash_identifier: int = 0x626C6B33):
+        """BlockIndex + [raw][compressed] size words around payloads already compressed into `arena` (see longtail_hip.h)."""
+        bf, rs, io = _u64arr(block_first_chunk), _u32arr(raw_sizes), _u64arr(image_offsets)
+        self._check(self.lib.dll.lthip_write_stored_block_headers(self.h, len(io), bf.ctypes.data, _ptr(chunk_hashes), _ptr(chunk_lens),
+                                                                  hash_identifier, tag, rs.ctypes.data, _ptr(comp_sizes), _ptr(arena),
+                                                                  io.ctypes.data), "lthip_write_stored_block_headers")
 
     # -- block assembly --
     def gather_ranges(self, src, src_offsets, lens, dst, dst_offsets):

@@ -413,6 +413,62 @@ void refh_memtrace_end(void)
 void* refh_alloc_ptr(void) { return (void*)Longtail_Alloc; }
 void* refh_free_ptr(void) { return (void*)Longtail_Free; }
 
+static struct Longtail_CompressionRegistryAPI* make_registry(struct Longtail_CompressionAPI* foreign, uint32_t type);
+
+/* A stored block image (the bytes of a .lsb file) through the reference: Longtail_ReadStoredBlockFromBuffer, then its
+ * BlockIndex is compared field by field with Longtail_CreateBlockIndex over the expected chunks (same block hash) and
+ * the [raw][compressed] payload is decompressed with the reference codec its tag names.  Returns 0 and the raw bytes. */
+int refh_open_stored_block(const void* image, uint64_t size, uint32_t chunk_count, const uint64_t* chunk_hashes,
+                           const uint32_t* chunk_sizes, uint32_t tag, uint8_t* out_raw, uint64_t out_cap, uint64_t* out_raw_size)
+{
+    struct Longtail_StoredBlock* sb = 0;
+    int err = Longtail_ReadStoredBlockFromBuffer(image, (size_t)size, &sb);
+    if (err)
+        return err;
+    struct Longtail_HashAPI* h = Longtail_CreateBlake3HashAPI();
+    struct Longtail_BlockIndex* expect = 0;
+    uint32_t* idx = (uint32_t*)Longtail_Alloc("refh", sizeof(uint32_t) * (chunk_count + 1));
+    for (uint32_t i = 0; i < chunk_count; ++i)
+        idx[i] = i;
+    err = Longtail_CreateBlockIndex(h, tag, chunk_count, idx, chunk_hashes, chunk_sizes, &expect);
+    if (!err)
+    {
+        const struct Longtail_BlockIndex* bi = sb->m_BlockIndex;
+        if (*bi->m_BlockHash != *expect->m_BlockHash || *bi->m_HashIdentifier != *expect->m_HashIdentifier ||
+            *bi->m_ChunkCount != chunk_count || *bi->m_Tag != tag ||
+            memcmp(bi->m_ChunkHashes, expect->m_ChunkHashes, sizeof(uint64_t) * chunk_count) != 0 ||
+            memcmp(bi->m_ChunkSizes, expect->m_ChunkSizes, sizeof(uint32_t) * chunk_count) != 0)
+            err = 3000;
+    }
+    if (!err)
+    {
+        const uint32_t* hdr = (const uint32_t*)sb->m_BlockData;
+        if (sb->m_BlockChunksDataSize < 8 || hdr[1] != sb->m_BlockChunksDataSize - 8 || hdr[0] > out_cap)
+            err = 3001;
+        else
+        {
+            struct Longtail_CompressionRegistryAPI* reg = make_registry(0, 0);
+            struct Longtail_CompressionAPI* api = 0;
+            uint32_t settings = 0;
+            err = reg->GetCompressionAPI(reg, tag, &api, &settings);
+            if (!err)
+            {
+                size_t n = 0;
+                err = api->Decompress(api, (const char*)&hdr[2], (char*)out_raw, hdr[1], hdr[0], &n);
+                if (!err && n != hdr[0])
+                    err = 3002;
+                *out_raw_size = n;
+            }
+            SAFE_DISPOSE_API(reg);
+        }
+    }
+    Longtail_Free(expect);
+    Longtail_Free(idx);
+    SAFE_DISPOSE_API(h);
+    sb->Dispose(sb);
+    return err;
+}
+
 /* ---- synchronous wrappers for the async block-store calls ---- */
 struct sync_existing
 {

@@ -57,3 +57,57 @@ def test_bulk_version_index_empty_tree_of_directories(gpu, ref):
     files = [("only/empty.bin", np.zeros(0, np.uint8))]
     expect, _ = ref.version_index(files, 65536, 0, 0)
     assert bulk_version_index(gpu, ref, files, 65536) == expect
+
+
+@pytest.mark.parametrize("codec", ["lz4", "zstd"])
+def test_bulk_stored_blocks_open_with_the_reference(gpu, oracle, ref, codec):
+    """chunk -> dedup -> pack -> device block assembly -> compress -> stored-block images, all on the device.
+    Every image must be a stored block the REFERENCE reads (Longtail_ReadStoredBlockFromBuffer): BlockIndex equal to
+    Longtail_CreateBlockIndex over the same chunks, payload decoded by the reference codec == the chunks' bytes."""
+    import ctypes as C
+
+    from longtail_amd.lib import pack_blocks
+
+    target, max_block, max_chunks = 32768, 1 << 20, 64
+    mn, av, mx = chunker_params(target)
+    files = [oracle.synth(int(n), 300 + i, i % 3) for i, n in enumerate([3 << 20, 70000, 2 << 20, 1 << 20, 5, 2 << 20])]
+    files.append(files[2].copy())  # duplicate content: its chunks must not be stored twice
+    dev, offs = to_device(files)
+    plan = gpu.make_plan(offs, [len(f) for f in files], mn, av, mx)
+    total, d_off, d_len, d_hash, _ = gpu.chunk_hash(plan, dev)
+    plan.close()
+    first_idx, uniq = gpu.dedup_first_seen(d_hash[:total])
+    keep = first_idx.to(torch.int64) == torch.arange(total, device="cuda")
+    u_off, u_len, u_hash = d_off[:total][keep].contiguous(), d_len[:total][keep].contiguous(), d_hash[:total][keep].contiguous()
+    nu = int(u_len.numel())
+    assert nu == int(uniq.item()) < total
+    lens_h = u_len.cpu().numpy().view(np.uint32)
+    starts = pack_blocks(lens_h, max_block, max_chunks)
+    nb = len(starts) - 1
+    cs = np.concatenate([[0], np.cumsum(lens_h.astype(np.int64))])
+    raw_sizes = (cs[starts[1:]] - cs[starts[:-1]]).astype(np.int64)
+    # device block assembly: the unique chunks back to back == the blocks back to back
+    gathered = torch.empty(int(cs[-1]) + 64, dtype=torch.uint8, device="cuda")
+    gpu.gather_ranges(dev, u_off, u_len, gathered, torch.from_numpy(cs[:-1].copy()).cuda())
+    tag = ref.lz4_type if codec == "lz4" else ref.zstd_default
+    bound = raw_sizes + raw_sizes // 255 + 16 if codec == "lz4" else raw_sizes + (raw_sizes >> 8) + 64
+    hdr = np.array([gpu.lib.dll.lthip_stored_block_header_size(int(starts[b + 1] - starts[b])) for b in range(nb)], np.int64)
+    img = np.concatenate([[0], np.cumsum((hdr + bound + 7) // 8 * 8)])
+    arena = torch.zeros(int(img[-1]) + 64, dtype=torch.uint8, device="cuda")
+    fn = gpu.lz4_compress_blocks if codec == "lz4" else gpu.zstd_compress_blocks
+    comp = fn(gathered, cs[starts[:-1]], raw_sizes, arena, img[:-1] + hdr, bound)
+    gpu.write_stored_block_headers(starts, u_hash, u_len, tag, raw_sizes, comp, arena, img[:-1])
+    gpu.sync()
+    host = arena.cpu().numpy()
+    comp_h = comp.cpu().numpy().view(np.uint32)
+    hashes_h, raw_all = u_hash.cpu().numpy().view(np.uint64), gathered.cpu().numpy()
+    for b in range(nb):
+        image = host[int(img[b]) : int(img[b]) + int(hdr[b]) + int(comp_h[b])].copy()
+        c0, c1 = int(starts[b]), int(starts[b + 1])
+        h, s = np.ascontiguousarray(hashes_h[c0:c1]), np.ascontiguousarray(lens_h[c0:c1])
+        out = np.zeros(int(raw_sizes[b]) + 8, np.uint8)
+        n = C.c_uint64(0)
+        err = ref.dll.refh_open_stored_block(image.ctypes.data, len(image), c1 - c0, h.ctypes.data, s.ctypes.data, tag, out.ctypes.data,
+                                             int(raw_sizes[b]), C.byref(n))
+        assert err == 0, (b, err)
+        assert n.value == raw_sizes[b] and (out[: n.value] == raw_all[int(cs[c0]) : int(cs[c1])]).all()
