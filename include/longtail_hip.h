@@ -235,6 +235,17 @@ LTHIP_EXPORT int lthip_write_stored_block_headers(lthip_ctx* ctx, uint32_t block
                                                   uint32_t hash_identifier, uint32_t tag, const uint32_t* raw_sizes,
                                                   const uint32_t* d_comp_sizes, void* d_arena, const uint64_t* image_offsets);
 
+/* ---- bulk Longtail_CreateMissingContent (src/longtail.c:6882-6998 with DiffHashes :6620-6743 and
+ * Longtail_CreateStoreIndex :6745-6880) -------------------------------------------------------------------------------
+ * Which of the version's chunks (unique list, version order: device hashes + sizes, host tags or NULL) does a store holding
+ * d_existing_hashes lack, and how are they packed into blocks?  Output: the serialized StoreIndex of the missing content
+ * (the bytes Longtail_WriteStoreIndexToBuffer produces: blocks with their BLAKE3 block hashes, chunk lists, tags).
+ * Returns ENOMEM with *out_size set when `out` is too small. */
+LTHIP_EXPORT int lthip_create_missing_content(lthip_ctx* ctx, uint64_t existing_count, const uint64_t* d_existing_hashes,
+                                              uint64_t chunk_count, const uint64_t* d_chunk_hashes, const uint32_t* d_chunk_lens,
+                                              const uint32_t* chunk_tags, uint32_t hash_identifier, uint32_t max_block_size,
+                                              uint32_t max_chunks_per_block, void* out, size_t out_capacity, size_t* out_size);
+
 /* ---- synthetic assets (include/longtail_synth.h), bench/test input generator ------------------------ */
 LTHIP_EXPORT int lthip_synth_fill(lthip_ctx* ctx, void* d_dst, uint32_t asset_count, const uint64_t* asset_offsets /*host*/,
                                   const uint64_t* asset_sizes /*host*/, const uint64_t* asset_seeds /*host*/, int kind);

@@ -319,3 +319,118 @@ extern "C" int lthip_write_stored_block_headers(lthip_ctx* ctx, uint32_t block_c
     LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // the DevBufs are freed on return
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Longtail_CreateMissingContent (src/longtail.c:6882-6998) as a bulk call.
+// DiffHashes (:6620-6743) keeps the version's chunks that the store does not have, in the order of their first occurrence
+// in the version; Longtail_CreateStoreIndex (:6745-6880) packs them into blocks (same tag, <= max_chunks_per_block chunks,
+// size <= max_block_size * 1.1) and Longtail_CreateStoreIndexFromBlocks (:9060-9125) lays the StoreIndex out (layout
+// :8913-8931).  The set difference runs on the first-seen table: store hashes and version hashes are concatenated, a
+// version chunk is missing iff its first occurrence in the concatenation is itself.  Block hashes come from the BLAKE3
+// kernels.  Output: the bytes Longtail_WriteStoreIndexToBuffer would produce.
+// ---------------------------------------------------------------------------------------------------
+extern "C" int lthip_create_missing_content(lthip_ctx* ctx, uint64_t existing_count, const uint64_t* d_existing_hashes,
+                                            uint64_t chunk_count, const uint64_t* d_chunk_hashes, const uint32_t* d_chunk_lens,
+                                            const uint32_t* chunk_tags, uint32_t hash_identifier, uint32_t max_block_size,
+                                            uint32_t max_chunks_per_block, void* out, size_t out_capacity, size_t* out_size)
+{
+    if (!ctx || !out_size || (existing_count && !d_existing_hashes) || (chunk_count && (!d_chunk_hashes || !d_chunk_lens)) ||
+        max_chunks_per_block == 0)
+        return EINVAL;
+    if (existing_count + chunk_count > 0x7FFFFFF0ull)
+        return lthip_fail(ctx, EINVAL, "missing content", "more than 2^31 hashes");
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t ne = (size_t)existing_count, n = (size_t)chunk_count;
+    int err;
+    DevBuf d_all, d_first, d_uniq;
+    if ((err = d_all.alloc(ctx, (ne + n) * 8)) || (err = d_first.alloc(ctx, (ne + n) * 4)) || (err = d_uniq.alloc(ctx, 8)))
+        return err;
+    if (ne)
+        LTHIP_CHECK(ctx, hipMemcpyAsync(d_all.p, d_existing_hashes, ne * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (n)
+        LTHIP_CHECK(ctx, hipMemcpyAsync((uint8_t*)d_all.p + ne * 8, d_chunk_hashes, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if ((err = lthip_dedup_first_seen(ctx, ne + n, (const uint64_t*)d_all.p, (uint32_t*)d_first.p, (uint64_t*)d_uniq.p)))
+        return err;
+    std::vector<uint32_t> first(n), lens(n);
+    std::vector<uint64_t> hashes(n);
+    if (n)
+    {
+        LTHIP_CHECK(ctx, hipMemcpyAsync(first.data(), (const uint32_t*)d_first.p + ne, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LTHIP_CHECK(ctx, hipMemcpyAsync(lens.data(), d_chunk_lens, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LTHIP_CHECK(ctx, hipMemcpyAsync(hashes.data(), d_chunk_hashes, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // the missing chunks, version order
+    std::vector<uint64_t> m_hash;
+    std::vector<uint32_t> m_size, m_tag;
+    for (size_t i = 0; i < n; ++i)
+        if (first[i] == (uint32_t)(ne + i))
+        {
+            m_hash.push_back(hashes[i]);
+            m_size.push_back(lens[i]);
+            m_tag.push_back(chunk_tags ? chunk_tags[i] : 0u);
+        }
+    const size_t m = m_hash.size();
+    // greedy packing, :6801-6860
+    std::vector<uint32_t> b_off, b_cnt, b_tag;
+    const uint64_t limit = (uint64_t)max_block_size + max_block_size / 10;
+    for (size_t i = 0; i < m;)
+    {
+        uint64_t size = m_size[i];
+        size_t j = i + 1;
+        while (j < m && m_tag[j] == m_tag[i] && j - i < max_chunks_per_block && size + m_size[j] <= limit)
+            size += m_size[j++];
+        b_off.push_back((uint32_t)i);
+        b_cnt.push_back((uint32_t)(j - i));
+        b_tag.push_back(m_tag[i]);
+        i = j;
+    }
+    const size_t nb = b_off.size();
+    // block hashes = BLAKE3 of each block's chunk-hash array (:3753-3757)
+    std::vector<uint64_t> b_hash(nb);
+    if (nb)
+    {
+        DevBuf d_mh, d_o, d_l, d_bh;
+        std::vector<uint64_t> o(nb);
+        std::vector<uint32_t> l(nb);
+        uint32_t max_len = 0;
+        for (size_t b = 0; b < nb; ++b)
+        {
+            o[b] = (uint64_t)b_off[b] * 8u;
+            l[b] = b_cnt[b] * 8u;
+            max_len = l[b] > max_len ? l[b] : max_len;
+        }
+        if ((err = d_mh.alloc(ctx, m * 8)) || (err = d_o.alloc(ctx, nb * 8)) || (err = d_l.alloc(ctx, nb * 4)) ||
+            (err = d_bh.alloc(ctx, nb * 8)))
+            return err;
+        LTHIP_CHECK(ctx, hipMemcpyAsync(d_mh.p, m_hash.data(), m * 8, hipMemcpyHostToDevice, ctx->stream));
+        LTHIP_CHECK(ctx, hipMemcpyAsync(d_o.p, o.data(), nb * 8, hipMemcpyHostToDevice, ctx->stream));
+        LTHIP_CHECK(ctx, hipMemcpyAsync(d_l.p, l.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if ((err = lthip_hash_ranges(ctx, d_mh.p, nb, (const uint64_t*)d_o.p, (const uint32_t*)d_l.p, max_len, (uint64_t*)d_bh.p)))
+            return err;
+        LTHIP_CHECK(ctx, hipMemcpyAsync(b_hash.data(), d_bh.p, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // Longtail_GetStoreIndexDataSize, :8913-8931
+    const size_t size = 16 + nb * 8 + m * 8 + nb * 12 + m * 4;
+    *out_size = size;
+    if (!out || out_capacity < size)
+        return ENOMEM;
+    uint8_t* w = (uint8_t*)out;
+    const uint32_t head[4] = {(1u << 24) /* LONGTAIL_STORE_INDEX_VERSION_1_0_0, :19-23 */, hash_identifier, (uint32_t)nb, (uint32_t)m};
+    memcpy(w, head, 16);
+    w += 16;
+    memcpy(w, b_hash.data(), nb * 8);  // m_BlockHashes
+    w += nb * 8;
+    memcpy(w, m_hash.data(), m * 8);   // m_ChunkHashes
+    w += m * 8;
+    memcpy(w, b_off.data(), nb * 4);   // m_BlockChunksOffsets
+    w += nb * 4;
+    memcpy(w, b_cnt.data(), nb * 4);   // m_BlockChunkCounts
+    w += nb * 4;
+    memcpy(w, b_tag.data(), nb * 4);   // m_BlockTags
+    w += nb * 4;
+    memcpy(w, m_size.data(), m * 4);   // m_ChunkSizes
+    return 0;
+}

@@ -110,6 +110,7 @@ class HipLib:
         sig("lthip_zstd_debug_units", i32, [vp, u64, u64, vp, vp, vp])
         sig("lthip_stored_block_header_size", sz, [u32])
         sig("lthip_write_stored_block_headers", i32, [vp, u32, vp, vp, vp, u32, u32, vp, vp, vp, vp])
+        sig("lthip_create_missing_content", i32, [vp, u64, vp, u64, vp, vp, vp, u32, u32, u32, vp, sz, vp])
         sig("lthip_version_index_size", sz, [u32, u64, u64, u32])
         sig("lthip_build_version_index", i32, [vp, u32, vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, u32, u32, vp, sz, vp])
         sig("lthip_dedup_first_seen", i32, [vp, u64, vp, vp, vp])
@@ -312,6 +313,22 @@ class Context:
         self._check(self.lib.dll.lthip_write_stored_block_headers(self.h, len(io), bf.ctypes.data, _ptr(chunk_hashes), _ptr(chunk_lens),
                                                                   hash_identifier, tag, rs.ctypes.data, _ptr(comp_sizes), _ptr(arena),
                                                                   io.ctypes.data), "lthip_write_stored_block_headers")
+
+    def create_missing_content(self, existing_hashes, chunk_hashes, chunk_lens, chunk_tags, max_block_size: int,
+                               max_chunks_per_block: int, hash_identifier: int = 0x626C6B33) -> bytes:
+        """Serialized StoreIndex of the version chunks a store with `existing_hashes` lacks (see longtail_hip.h)."""
+        ne = int(existing_hashes.numel()) if existing_hashes is not None else 0
+        n = int(chunk_hashes.numel())
+        tags = _u32arr(chunk_tags) if chunk_tags is not None else None
+        cap = 16 + 20 * n + 12 * n + 64
+        out = np.zeros(cap, np.uint8)
+        size = C.c_size_t(0)
+        err = self.lib.dll.lthip_create_missing_content(
+            self.h, ne, _ptr(existing_hashes) if ne else None, n, _ptr(chunk_hashes), _ptr(chunk_lens),
+            tags.ctypes.data if tags is not None else None, hash_identifier, max_block_size, max_chunks_per_block, out.ctypes.data,
+            cap, C.byref(size))
+        self._check(err, "lthip_create_missing_content")
+        return out[: size.value].tobytes()
 
     # -- block assembly --
     def gather_ranges(self, src, src_offsets, lens, dst, dst_offsets):

@@ -469,6 +469,36 @@ int refh_open_stored_block(const void* image, uint64_t size, uint32_t chunk_coun
     return err;
 }
 
+/* Longtail_CreateMissingContent on bare arrays: a store that has `existing` chunk hashes, a version with the unique chunk
+ * list (hashes, sizes, tags).  Returns the serialized StoreIndex (Longtail_WriteStoreIndexToBuffer); free with refh_free. */
+int refh_missing_content(const uint64_t* existing, uint32_t existing_count, const uint64_t* chunk_hashes, const uint32_t* chunk_sizes,
+                         const uint32_t* chunk_tags, uint32_t chunk_count, uint32_t max_block_size, uint32_t max_chunks_per_block,
+                         void** out_buf, uint64_t* out_size)
+{
+    struct Longtail_StoreIndex si;
+    struct Longtail_VersionIndex vi;
+    struct Longtail_StoreIndex* missing = 0;
+    struct Longtail_HashAPI* h = Longtail_CreateBlake3HashAPI();
+    memset(&si, 0, sizeof si);
+    memset(&vi, 0, sizeof vi);
+    si.m_ChunkCount = &existing_count;
+    si.m_ChunkHashes = (TLongtail_Hash*)existing;
+    vi.m_ChunkCount = &chunk_count;
+    vi.m_ChunkHashes = (TLongtail_Hash*)chunk_hashes;
+    vi.m_ChunkSizes = (uint32_t*)chunk_sizes;
+    vi.m_ChunkTags = (uint32_t*)chunk_tags;
+    int err = Longtail_CreateMissingContent(h, &si, &vi, max_block_size, max_chunks_per_block, &missing);
+    if (!err)
+    {
+        size_t sz = 0;
+        err = Longtail_WriteStoreIndexToBuffer(missing, out_buf, &sz);
+        *out_size = sz;
+    }
+    Longtail_Free(missing);
+    SAFE_DISPOSE_API(h);
+    return err;
+}
+
 /* ---- synchronous wrappers for the async block-store calls ---- */
 struct sync_existing
 {

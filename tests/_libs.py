@@ -126,6 +126,7 @@ class Ref:
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)])
         sig("refh_cpu_count", i32, [])
         sig("refh_tree_file_infos", i32, [u32, vp, vp, vp, C.POINTER(vp), C.POINTER(u64)])
+        sig("refh_missing_content", i32, [vp, u32, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(u64)])
         sig("refh_open_stored_block", i32, [vp, u64, u32, vp, vp, u32, vp, u64, C.POINTER(u64)])
         self.lz4_type = int(d.refh_lz4_type())
         self.zstd_default = int(d.refh_zstd_type(1))

@@ -111,3 +111,31 @@ def test_bulk_stored_blocks_open_with_the_reference(gpu, oracle, ref, codec):
                                              int(raw_sizes[b]), C.byref(n))
         assert err == 0, (b, err)
         assert n.value == raw_sizes[b] and (out[: n.value] == raw_all[int(cs[c0]) : int(cs[c1])]).all()
+
+
+def test_bulk_missing_content_store_index_is_byte_identical(gpu, ref):
+    """which chunks does the store lack and how are they blocked -- the serialized StoreIndex must equal
+    Longtail_CreateMissingContent + Longtail_WriteStoreIndexToBuffer on the same arrays (first-occurrence order, tag breaks,
+    block hashes)."""
+    import ctypes as C
+
+    rng = np.random.default_rng(17)
+    for n, ne, max_block, max_chunks, ntags in ((5000, 1500, 1 << 20, 64, 1), (20000, 0, 8 << 20, 1024, 3), (300, 300, 65536, 4, 2),
+                                                (4000, 9000, 262144, 1024, 1)):
+        hashes = rng.integers(1, 2**63, n, dtype=np.int64).astype(np.uint64)
+        sizes = rng.integers(1, 131072, n, dtype=np.int64).astype(np.uint32)
+        tags = (np.arange(n) * ntags // n).astype(np.uint32) * 7 + 1  # runs of equal tags
+        # the store holds a random subset of the version's chunks plus unrelated ones
+        existing = np.concatenate([rng.choice(hashes, min(ne, n) // 2, replace=False),
+                                   rng.integers(1, 2**63, ne - min(ne, n) // 2, dtype=np.int64).astype(np.uint64)]) if ne else np.zeros(0, np.uint64)
+        rng.shuffle(existing)
+        buf, size = C.c_void_p(), C.c_uint64(0)
+        err = ref.dll.refh_missing_content(existing.ctypes.data if ne else None, ne, hashes.ctypes.data, sizes.ctypes.data, tags.ctypes.data,
+                                           n, max_block, max_chunks, C.byref(buf), C.byref(size))
+        assert err == 0
+        expect = bytes((C.c_ubyte * size.value).from_address(buf.value))
+        ref.dll.refh_free(buf)
+        got = gpu.create_missing_content(torch.from_numpy(existing.view(np.int64)).cuda() if ne else None,
+                                         torch.from_numpy(hashes.view(np.int64)).cuda(), torch.from_numpy(sizes.view(np.int32)).cuda(),
+                                         tags, max_block, max_chunks)
+        assert got == expect, (n, ne, len(got), len(expect))
