@@ -142,6 +142,8 @@ __global__ __launch_bounds__(K1_THREADS, 3) void k_buzhash_candidates(const uint
     }
     __syncthreads(); // the only barrier: table visible to every wave
     const uint32_t* tabl = tab + (tid & (TAB_REP - 1));
+    // x divisible by odd d' <=> x * d'^-1 mod 2^32 <= (2^32-1)/d'
+    const uint32_t qodd = MODE == 1 ? 0u : 0xFFFFFFFFu / (dv.d >> dv.k2);
 
     const uint64_t nwt = (uint64_t)ntiles * 4u; // wave-tiles; wave-tile wt is quarter (wt & 3) of 16 KiB tile (wt >> 2)
     const uint64_t wstride = (uint64_t)gridDim.x * 4u;
@@ -193,14 +195,15 @@ __global__ __launch_bounds__(K1_THREADS, 3) void k_buzhash_candidates(const uint
 #define LT_STEP(k)                                                                                                   \
     {                                                                                                                \
         h = rotl32(h, 1) ^ rotl32(tv[k], 16) ^ tv[48 + (k)];                                                         \
-        bool hit;                                                                                                    \
+        bool pre;                                                                                                    \
         if (MODE == 1)                                                                                               \
-            hit = (h & (dv.d - 1u)) == dv.d - 1u;                                                                    \
-        else                                                                                                         \
-            hit = rotr32(h * dv.inv + dv.addc, dv.k2) <= dv.qlim; /* == (h % d == d-1), see lthip_ctx.hip */         \
-        if (__builtin_amdgcn_ballot_w64(hit) != 0ull) /* wave-uniform and rare (1 position in d) */                  \
+            pre = (h & (dv.d - 1u)) == dv.d - 1u;                                                                    \
+        else /* necessary: the odd part of d divides h+1 (3 ops); the exact test waits in the rare branch */        \
+            pre = h * dv.inv + dv.inv <= qodd;                                                                       \
+        if (__builtin_amdgcn_ballot_w64(pre) != 0ull) /* wave-uniform and rare (1 position in d's odd part) */       \
         {                                                                                                            \
             asm volatile(""); /* keep this a real scalar branch (no if-conversion of the bit-set) */                 \
+            const bool hit = MODE == 1 ? pre : rotr32(h * dv.inv + dv.addc, dv.k2) <= dv.qlim; /* h % d == d-1 */   \
             if (hit)                                                                                                 \
             {                                                                                                        \
                 if ((k) < 32)                                                                                        \
