@@ -516,25 +516,35 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
             nfail = 0;
             continue;
         }
-        // ---- dense mode: every lane measures its own match (4 bytes per step, at most 36), in parallel ----
+        // ---- dense mode: every lane measures its own match, in parallel: 16 bytes per LDS round trip (four dword pairs
+        // in flight at once -- the batch is a latency chain, not a bandwidth problem), at most 36 bytes ----
         uint32_t mlen = ok ? 4u : 0u;
         bool act = ok;
         const uint32_t maxlen = ok ? end_limit - p : 0u;
 #pragma unroll 1
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < 2; ++t)
         {
             if (__builtin_amdgcn_ballot_w64(act) == 0ull)
                 break;
             if (act)
             {
-                const uint32_t x = lds_read32(sdata, p + mlen + head) ^ lds_read32(sdata, cand + mlen + head);
-                if (x)
-                {
-                    mlen += (uint32_t)__builtin_ctz(x) >> 3;
+                const uint32_t a0 = p + mlen + head, b0 = cand + mlen + head;
+                const uint32_t x0 = lds_read32(sdata, a0) ^ lds_read32(sdata, b0);
+                const uint32_t x1 = lds_read32(sdata, a0 + 4u) ^ lds_read32(sdata, b0 + 4u);
+                const uint32_t x2 = lds_read32(sdata, a0 + 8u) ^ lds_read32(sdata, b0 + 8u);
+                const uint32_t x3 = lds_read32(sdata, a0 + 12u) ^ lds_read32(sdata, b0 + 12u);
+                uint32_t add = 16u;
+                if (x0)
+                    add = (uint32_t)__builtin_ctz(x0) >> 3;
+                else if (x1)
+                    add = 4u + ((uint32_t)__builtin_ctz(x1) >> 3);
+                else if (x2)
+                    add = 8u + ((uint32_t)__builtin_ctz(x2) >> 3);
+                else if (x3)
+                    add = 12u + ((uint32_t)__builtin_ctz(x3) >> 3);
+                mlen += add;
+                if (add != 16u)
                     act = false;
-                }
-                else
-                    mlen += 4u;
                 if (mlen >= maxlen)
                 {
                     mlen = maxlen;
@@ -543,17 +553,14 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
             }
         }
         const uint64_t longs = __builtin_amdgcn_ballot_w64(act); // still equal after 36 bytes: extend when selected
-        // ... and how far it could grow backwards (at most 8 bytes, two dword steps; the anchor bounds it at selection)
+        // ... and how far it could grow backwards (at most 8 bytes, both dword pairs read at once; the anchor bounds it
+        // at selection)
         uint32_t nbk = 0;
         if (ok && cand >= 8u)
         {
             const uint32_t x = lds_read32(sdata, p - 4u + head) ^ lds_read32(sdata, cand - 4u + head);
-            nbk = x ? (uint32_t)__builtin_clz(x) >> 3 : 4u;
-            if (x == 0u)
-            {
-                const uint32_t y = lds_read32(sdata, p - 8u + head) ^ lds_read32(sdata, cand - 8u + head);
-                nbk += y ? (uint32_t)__builtin_clz(y) >> 3 : 4u;
-            }
+            const uint32_t y = lds_read32(sdata, p - 8u + head) ^ lds_read32(sdata, cand - 8u + head);
+            nbk = x ? (uint32_t)__builtin_clz(x) >> 3 : (y ? 4u + ((uint32_t)__builtin_clz(y) >> 3) : 8u);
         }
         // ---- greedy selection in position order: a scalar walk over the SELECTED hits only ----
         uint64_t rem = hits, vecsel = 0ull;
