@@ -15,6 +15,20 @@
 #define ZB_SYNC() __syncthreads() /* the encoder runs in one-wave workgroups */
 __device__ __forceinline__ void zb_atomic_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 __device__ __forceinline__ void zb_atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+// exclusive prefix sum over the 64 lanes of the (single-wave) workgroup, lane 0 first
+__device__ __forceinline__ uint32_t zb_scan_excl(uint32_t v, uint32_t* total)
+{
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if ((int)(threadIdx.x & 63) >= d)
+            incl += o;
+    }
+    *total = __shfl(incl, 63, 64);
+    return incl - v;
+}
 #ifdef LTHIP_ZB_PROF /* debug build only: cycles per phase of zb_encode_block, summed over all pieces (lane 0) */
 __device__ unsigned long long g_zb_prof[16];
 __device__ unsigned long long g_zb_last[1 << 16];

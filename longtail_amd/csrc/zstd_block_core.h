@@ -18,6 +18,8 @@
  *   ZB_FN             function qualifiers
  *   ZB_SYNC()         make earlier writes of all lanes visible to all lanes
  *   zb_atomic_add(p,v) / zb_atomic_or(p,v)   32-bit atomics on shared / global words
+ *   zb_scan_excl(v, &total)                  exclusive prefix sum of v over the lanes (lane 0 first) and its total;
+ *                                            called by all lanes together (with one lane: 0 and v)
  * Every phase is either `ZB_SERIAL(zl)` (lane 0), or a `ZB_PAR_FOR` whose iterations only interact through those
  * commutative atomics, so the bytes produced do not depend on ZB_LANES: the one-lane host build (zstd_model.c in the test
  * infrastructure) is a bit-exact model of the kernel (k_zstd.hip), and runs here without a GPU against the
@@ -954,26 +956,26 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     ZB_SYNC();
 
     ZB_MARK(3);
-    /* ---- phase 3: size of the four Huffman streams (64 chunks; a stream is written from its LAST symbol) ---- */
+    /* ---- phase 3: bits of the four Huffman streams: lane-strided sums (coalesced reads, independent table look-ups) ---- */
     const uint32_t seg = (nlit + 3u) >> 2;
     if (sh->v[ZV_HUF_OK])
     {
-        ZB_PAR_FOR(c, ZB_CHUNKS)
+        ZB_PAR_FOR(c, 4u) sh->part2[c] = 0;
+        ZB_SYNC();
+        for (uint32_t st = 0; st < 4u; ++st)
         {
-            const uint32_t st = c >> 4, j = c & 15u;
             const uint32_t s0 = st * seg < nlit ? st * seg : nlit;
             const uint32_t s1 = st == 3u ? nlit : (s0 + seg < nlit ? s0 + seg : nlit);
-            const uint32_t csz = (s1 - s0 + 15u) >> 4;
-            const uint32_t a = s0 + j * csz < s1 ? s0 + j * csz : s1, b = a + csz < s1 ? a + csz : s1;
             uint32_t bits = 0;
-            if (a < b)
+            if (s0 + zl < s1)
             {
                 ZbLitReader lr;
-                zb_lit_open(&lr, in->unit_lits, sh->ulit_base, in->nunits, a);
-                for (uint32_t k = a; k < b; ++k)
+                zb_lit_open(&lr, in->unit_lits, sh->ulit_base, in->nunits, s0 + zl);
+                for (uint32_t k = s0 + zl; k < s1; k += ZB_LANES)
                     bits += sh->huf_len[zb_lit_get(&lr, k)];
             }
-            sh->part[c] = bits;
+            if (bits)
+                zb_atomic_add(&sh->part2[st], bits);
         }
     }
     ZB_SYNC();
@@ -990,16 +992,7 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
             uint32_t csize = tb + 6u;
             for (uint32_t st = 0; st < 4u; ++st)
             {
-                uint32_t bits = 0;
-                /* chunk j of a stream starts after the bits of the chunks that follow it */
-                for (int j = 15; j >= 0; --j)
-                {
-                    const uint32_t b = sh->part[st * 16u + (uint32_t)j];
-                    sh->part[st * 16u + (uint32_t)j] = bits;
-                    bits += b;
-                }
-                sh->v[ZV_STREAM_BYTES + st] = (bits + 1u + 7u) >> 3; /* + end mark */
-                sh->part2[st] = bits;
+                sh->v[ZV_STREAM_BYTES + st] = (sh->part2[st] + 1u + 7u) >> 3; /* + end mark */
                 csize += sh->v[ZV_STREAM_BYTES + st];
             }
             {
@@ -1087,25 +1080,51 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     /* ---- phase 5: literals ---- */
     if (sh->v[ZV_LIT_MODE] == 2u)
     {
-        ZB_PAR_FOR(c, ZB_CHUNKS)
+        /* A stream is written from its LAST literal.  Per step every lane takes the next four literals (lane 0 the
+         * last four), packs their codes, a wave prefix sum of the bit counts gives its position, and the <= 44 bits go
+         * out with one or two atomicOr: no lane ever walks a long serial run. */
+        for (uint32_t st = 0; st < 4u; ++st)
         {
-            const uint32_t st = c >> 4, j = c & 15u;
             const uint32_t s0 = st * seg < nlit ? st * seg : nlit;
             const uint32_t s1 = st == 3u ? nlit : (s0 + seg < nlit ? s0 + seg : nlit);
-            const uint32_t csz = (s1 - s0 + 15u) >> 4;
-            const uint32_t a = s0 + j * csz < s1 ? s0 + j * csz : s1, b = a + csz < s1 ? a + csz : s1;
-            ZbBits bw;
-            zb_bits_open(&bw, sc->out, sh->v[ZV_STREAM_BASE + st] * 8u + sh->part[c]);
+            uint32_t running = sh->v[ZV_STREAM_BASE + st] * 8u;
             ZbLitReader lr;
-            zb_lit_open(&lr, in->unit_lits, sh->ulit_base, in->nunits, a < b ? b - 1u : 0u);
-            for (uint32_t k = b; k > a; --k)
+            zb_lit_open(&lr, in->unit_lits, sh->ulit_base, in->nunits, s1 ? s1 - 1u : 0u);
+            for (uint32_t done = 0; done < s1 - s0; done += 4u * ZB_LANES)
             {
-                const uint32_t s = zb_lit_get(&lr, k - 1u);
-                zb_bits_put(&bw, sh->huf_code[s], sh->huf_len[s]);
+                /* my literals: indices s1-1 - (done + 4*zl + j), j = 0..3, as far as they exist */
+                uint64_t acc = 0;
+                uint32_t nb = 0;
+                for (uint32_t j = 0; j < 4u; ++j)
+                {
+                    const uint32_t r = done + 4u * zl + j;
+                    if (r < s1 - s0)
+                    {
+                        const uint32_t sy = zb_lit_get(&lr, s1 - 1u - r);
+                        acc |= (uint64_t)sh->huf_code[sy] << nb;
+                        nb += sh->huf_len[sy];
+                    }
+                }
+                {
+                    uint32_t total;
+                    const uint32_t off = zb_scan_excl(nb, &total);
+                    if (nb)
+                    {
+                        const uint32_t bp = running + off;
+                        const uint64_t v = acc << (bp & 31u); /* nb <= 44, shift <= 31: fits 75 bits -> three words */
+                        zb_atomic_or(sc->out + (bp >> 5), (uint32_t)v);
+                        if ((bp & 31u) + nb > 32u)
+                            zb_atomic_or(sc->out + (bp >> 5) + 1u, (uint32_t)(v >> 32));
+                        if ((bp & 31u) + nb > 64u)
+                            zb_atomic_or(sc->out + (bp >> 5) + 2u, (uint32_t)(acc >> (64u - (bp & 31u))));
+                    }
+                    running += total;
+                }
             }
-            if (j == 0u)
-                zb_bits_put(&bw, 1u, 1u); /* end mark after the stream's first symbol */
-            zb_bits_close(&bw);
+            ZB_SERIAL(zl)
+            {
+                zb_atomic_or(sc->out + (running >> 5), 1u << (running & 31u)); /* end mark after the stream's first symbol */
+            }
         }
     }
     else
@@ -1170,69 +1189,59 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     ZB_SYNC();
 
     ZB_MARK(7);
-    /* ---- phase 7: sequence bit-stream: sizes of 64 runs, then the bits ---- */
-    const uint32_t run = (nbseq + ZB_CHUNKS - 1u) / ZB_CHUNKS;
-    for (int pass = 0; pass < 2; ++pass)
+    /* ---- phase 7: sequence bit-stream, last sequence first: one sequence per lane and step, a wave prefix sum of the bit
+     * counts places it (same scheme as the literal streams) ---- */
     {
-        if (nbseq)
+        uint32_t running = sh->v[ZV_SEQ_BITS0] * 8u;
+        for (uint32_t done = 0; done < nbseq; done += ZB_LANES)
         {
-            ZB_PAR_FOR(c, ZB_CHUNKS)
+            const uint32_t r = done + zl;
+            uint32_t bits = 0, lit = 0, ml = 0, ofv = 4, lc = 0, mc = 0, oc = 2, lb = 0, mb = 0, so = 0, sm = 0, sl = 0;
+            if (r < nbseq)
             {
-                const uint32_t a = c * run < nbseq ? c * run : nbseq, b = a + run < nbseq ? a + run : nbseq;
-                uint32_t bits = 0;
-                ZbBits bw;
-                zb_bits_open(&bw, sc->out, pass ? sh->v[ZV_SEQ_BITS0] * 8u + sh->part[c] : 0u);
-                for (uint32_t n = b; n > a; --n)
+                const uint32_t n = nbseq - 1u - r;
+                const uint64_t q = sc->seqs[n];
+                lit = ZB_SEQ_LIT(q);
+                ml = ZB_SEQ_ML(q) - 3u;
+                ofv = ZB_SEQ_OFF(q) + 3u;
+                lc = zb_ll_code(lit);
+                mc = zb_ml_code(ml);
+                oc = zb_highbit(ofv);
+                lb = zb_ll_bits(lc);
+                mb = zb_ml_bits(mc);
+                if (n < nbseq - 1u)
                 {
-                    const uint64_t q = sc->seqs[n - 1u];
-                    const uint32_t lit = ZB_SEQ_LIT(q), ml = ZB_SEQ_ML(q) - 3u, ofv = ZB_SEQ_OFF(q) + 3u;
-                    const uint32_t lc = zb_ll_code(lit), mc = zb_ml_code(ml), oc = zb_highbit(ofv);
-                    const uint32_t lb = zb_ll_bits(lc), mb = zb_ml_bits(mc);
-                    uint32_t so = 0, sm = 0, sl = 0;
-                    if (n - 1u < nbseq - 1u)
-                    {
-                        /* state updates of this sequence: OF, ML, LL (read back as LL, ML, OF) */
-                        if (sh->mode[ZT_OF] != 1u)
-                            so = sc->sbits[(uint64_t)ZT_OF * ZB_SEQ_MAX + n - 1u];
-                        if (sh->mode[ZT_ML] != 1u)
-                            sm = sc->sbits[(uint64_t)ZT_ML * ZB_SEQ_MAX + n - 1u];
-                        if (sh->mode[ZT_LL] != 1u)
-                            sl = sc->sbits[(uint64_t)ZT_LL * ZB_SEQ_MAX + n - 1u];
-                    }
-                    if (!pass)
-                        bits += (so >> 10) + (sm >> 10) + (sl >> 10) + lb + mb + oc;
-                    else
-                    {
-                        zb_bits_put(&bw, so & 1023u, so >> 10);
-                        zb_bits_put(&bw, sm & 1023u, sm >> 10);
-                        zb_bits_put(&bw, sl & 1023u, sl >> 10);
-                        zb_bits_put(&bw, lit - zb_ll_base(lc), lb);
-                        zb_bits_put(&bw, ml - zb_ml_base(mc), mb);
-                        zb_bits_put(&bw, ofv - (1u << oc), oc);
-                    }
+                    /* state updates of this sequence: OF, ML, LL (read back as LL, ML, OF) */
+                    if (sh->mode[ZT_OF] != 1u)
+                        so = sc->sbits[(uint64_t)ZT_OF * ZB_SEQ_MAX + n];
+                    if (sh->mode[ZT_ML] != 1u)
+                        sm = sc->sbits[(uint64_t)ZT_ML * ZB_SEQ_MAX + n];
+                    if (sh->mode[ZT_LL] != 1u)
+                        sl = sc->sbits[(uint64_t)ZT_LL * ZB_SEQ_MAX + n];
                 }
-                if (!pass)
-                    sh->part2[c] = bits;
-                else
+                bits = (so >> 10) + (sm >> 10) + (sl >> 10) + lb + mb + oc;
+            }
+            {
+                uint32_t total;
+                const uint32_t off = zb_scan_excl(bits, &total);
+                if (bits)
+                {
+                    ZbBits bw;
+                    zb_bits_open(&bw, sc->out, running + off);
+                    zb_bits_put(&bw, so & 1023u, so >> 10);
+                    zb_bits_put(&bw, sm & 1023u, sm >> 10);
+                    zb_bits_put(&bw, sl & 1023u, sl >> 10);
+                    zb_bits_put(&bw, lit - zb_ll_base(lc), lb);
+                    zb_bits_put(&bw, ml - zb_ml_base(mc), mb);
+                    zb_bits_put(&bw, ofv - (1u << oc), oc);
                     zb_bits_close(&bw);
-            }
-        }
-        ZB_SYNC();
-        if (!pass)
-        {
-            ZB_SERIAL(zl)
-            {
-                uint32_t bits = 0;
-                for (int c = (int)ZB_CHUNKS - 1; c >= 0; --c) /* the last sequence is written first */
-                {
-                    sh->part[c] = bits;
-                    bits += sh->part2[c];
                 }
-                sh->v[ZV_SEQ_TOTALBITS] = bits;
+                running += total;
             }
-            ZB_SYNC();
         }
+        ZB_SERIAL(zl) { sh->v[ZV_SEQ_TOTALBITS] = running - sh->v[ZV_SEQ_BITS0] * 8u; }
     }
+    ZB_SYNC();
 
     ZB_MARK(8);
     /* ---- phase 8 (lane 0): final states (ML, OF, LL: read back as LL, OF, ML), end mark, size ---- */

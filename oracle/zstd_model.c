@@ -18,6 +18,11 @@
 #define ZB_SYNC() ((void)0)
 static inline void zb_atomic_add(uint32_t* p, uint32_t v) { *p += v; }
 static inline void zb_atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
+static inline uint32_t zb_scan_excl(uint32_t v, uint32_t* total)
+{
+    *total = v;
+    return 0;
+}
 
 static uint32_t g_ltz_dbg;
 #define ZB_DBG g_ltz_dbg
