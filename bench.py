@@ -231,6 +231,9 @@ def main():
                 i = j
             sizes = torch.cat(size_tensors).to(torch.int64)
             comp_bytes = int(sizes.sum().item())
+            # blocks without any match are laid out by the match finder itself (it writes their literals): count them
+            stats["placed_by_matcher"] = int(torch.from_numpy(b_size).to(dev)[sizes >= torch.from_numpy(b_size).to(dev)].sum().item()) \
+                if args.codec == "lz4" else 0
             if int((sizes == 0).sum().item()) != 0:
                 raise SystemExit("a block did not fit its bound: encoder bug")
         ctx.sync()
@@ -271,7 +274,7 @@ def main():
     alg_bytes = {
         "buzhash": shard_bytes,                 # N read once
         "blake3_leaf": shard_bytes,             # N read once
-        "lz4_segments": shard_bytes,            # N read (it also places the literals of match-less blocks: not counted)
+        "lz4_segments": shard_bytes + stats.get("placed_by_matcher", 0),  # N read + the blocks it lays out itself (all-literal)
         "zstd_encode": shard_bytes + comp,      # literals + sequences read, pieces written
     }
     # lz4_stitch has no fixed algorithmic figure any more: for blocks without matches it only writes a header
