@@ -207,31 +207,47 @@ ZB_FN int zd_build_fse(ZdFse* t, const int16_t* norm, uint32_t maxsym, uint32_t 
 typedef struct ZdBack
 {
     const uint8_t* p;
+    uint32_t size;
     uint32_t pos; /* bits not yet consumed: the next read takes the n bits just below bit `pos` */
     int over;     /* a read went below bit 0 */
+    uint64_t cont; /* cached bits [cpos, cpos + 64) of the stream; cpos is a multiple of 8 */
+    uint32_t cpos, cvalid;
 } ZdBack;
 
 ZB_FN int zd_back_open(ZdBack* r, const uint8_t* p, uint32_t size)
 {
     r->p = p;
+    r->size = size;
     r->over = 0;
+    r->cvalid = 0;
+    r->cpos = 0;
+    r->cont = 0;
     if (size == 0u || p[size - 1u] == 0u)
         return 1;
     r->pos = (size - 1u) * 8u + zb_highbit(p[size - 1u]);
     return 0;
 }
-ZB_FN uint32_t zd_back_peek_at(const ZdBack* r, uint32_t bitpos, uint32_t n) /* n <= 24, bits [bitpos, bitpos+n) */
+ZB_FN uint32_t zd_back_peek_at(ZdBack* r, uint32_t bitpos, uint32_t n) /* n <= 24, bits [bitpos, bitpos+n) */
 {
-    const uint32_t b0 = bitpos >> 3;
-    uint32_t v = (uint32_t)r->p[b0];
-    const uint32_t need = ((bitpos & 7u) + n + 7u) >> 3; /* bytes touched: all inside the stream because bitpos+n <= pos */
-    if (need > 1u)
-        v |= (uint32_t)r->p[b0 + 1u] << 8;
-    if (need > 2u)
-        v |= (uint32_t)r->p[b0 + 2u] << 16;
-    if (need > 3u)
-        v |= (uint32_t)r->p[b0 + 3u] << 24;
-    return (v >> (bitpos & 7u)) & ((1u << n) - 1u);
+    /* a 64-bit window is kept in registers and slid down the stream: about one 8-byte load per 40 bits consumed */
+    if (!r->cvalid || bitpos < r->cpos || bitpos + n > r->cpos + 64u)
+    {
+        const uint32_t top = bitpos + n; /* <= 8 * size */
+        uint32_t b0 = top > 64u ? (top - 64u + 7u) >> 3 : 0u;
+        if (b0 + 8u > r->size)
+            b0 = r->size >= 8u ? r->size - 8u : 0u;
+        if (b0 + 8u <= r->size)
+            __builtin_memcpy(&r->cont, r->p + b0, 8);
+        else
+        {
+            r->cont = 0;
+            for (uint32_t i = 0; i < r->size; ++i)
+                r->cont |= (uint64_t)r->p[i] << (8u * i);
+        }
+        r->cpos = b0 * 8u;
+        r->cvalid = 1;
+    }
+    return (uint32_t)(r->cont >> (bitpos - r->cpos)) & ((1u << n) - 1u);
 }
 ZB_FN uint32_t zd_back_read(ZdBack* r, uint32_t n) /* n <= 24; reading past the start yields zeros and sets over */
 {
@@ -762,8 +778,11 @@ ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t*
                             uint32_t st[3] = {0, 0, 0};
                             uint32_t litpos = 0;
                             br.p = 0;
+                            br.size = 0;
                             br.pos = 0;
                             br.over = 0;
+                            br.cont = 0;
+                            br.cpos = br.cvalid = 0;
                             ZB_SERIAL(zl)
                             {
                                 if (zd_back_open(&br, blk + seq_pos, bsize - seq_pos))
