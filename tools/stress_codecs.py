@@ -1,0 +1,40 @@
+"""Randomised GPU stress (not part of the pytest suite): usage  python tools/<this>.py [seed]"""
+import sys, numpy as np, torch
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent))
+from tests._libs import oracle, ref
+from tests.gpu_util import layout, to_device, u32
+from longtail_amd.lib import Context
+o, r, ctx = oracle(), ref(), Context(0)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+kinds = [0, 1, 2, 11, 12, 13]
+tot = 0
+for rnd in range(12):
+    blocks = []
+    for _ in range(150):
+        k = int(rng.choice(kinds)); n = int(rng.choice([rng.integers(0, 200), rng.integers(0, 9000), rng.integers(0, 300000), rng.integers(0, 1200000)]))
+        b = o.synth(n, int(rng.integers(1, 1 << 30)), k)
+        if n > 16 and rng.integers(0, 4) == 0:  # splice: repeat an earlier part of the block
+            a = int(rng.integers(0, n // 2)); l = int(rng.integers(1, n - a)); p = int(rng.integers(0, n - l + 1)); b = b.copy(); b[p:p + l] = b[a:a + l][: len(b[p:p + l])]
+        blocks.append(b)
+    dev, offs = to_device(blocks)
+    sizes = [len(b) for b in blocks]
+    for codec in ("lz4", "zstd"):
+        caps = [s + s // 255 + 16 if codec == "lz4" else s + (s >> 8) + 64 for s in sizes]
+        d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
+        dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+        fn = ctx.lz4_compress_blocks if codec == "lz4" else ctx.zstd_compress_blocks
+        cs = u32(fn(dev, offs, sizes, dst, d_offs, caps)).astype(np.int64)
+        assert (cs > 0).all(), codec
+        b_offs, btot = layout([np.zeros(s, np.uint8) for s in sizes])
+        back = torch.zeros(btot + 64, dtype=torch.uint8, device="cuda")
+        dfn = ctx.lz4_decompress_blocks if codec == "lz4" else ctx.zstd_decompress_blocks
+        ds = u32(dfn(dst, d_offs, cs, back, b_offs, sizes))
+        host, bh = dst.cpu().numpy(), back.cpu().numpy()
+        for i, b in enumerate(blocks):
+            assert int(ds[i]) == len(b), (codec, i, int(ds[i]), len(b))
+            assert (bh[b_offs[i]: b_offs[i] + len(b)] == b).all(), (codec, i)
+            if i % 5 == 0:
+                err, out = r.decompress(0 if codec == "lz4" else 1, host[d_offs[i]: d_offs[i] + int(cs[i])].copy(), len(b))
+                assert err == 0 and len(out) == len(b) and (out == b).all(), (codec, i, "reference decoder")
+        tot += len(blocks)
+print("ok", tot, "payloads")
