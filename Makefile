@@ -20,7 +20,7 @@ C_OBJ   := $(patsubst $(CSRC)/plugin/%.c,$(OBJDIR)/%.o,$(C_SRC))
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function
 CFLAGS   := -O2 -std=c99 -D_POSIX_C_SOURCE=200809L -fPIC -fvisibility=hidden -Wall -Wextra -pthread
 
-.PHONY: lib oracle all clean
+.PHONY: lib oracle all clean prof
 lib: $(LIB)
 all: lib oracle
 
@@ -38,6 +38,12 @@ $(LIB): $(HIP_OBJ) $(C_OBJ)
 
 oracle:
 	$(MAKE) -C oracle
+
+# debug build for tools/zb_prof.sh: the zstd entropy kernel with per-phase cycle counters (-DLTHIP_ZB_PROF)
+prof: $(LIB)
+	mkdir -p build/prof
+	$(HIPCC) $(HIPFLAGS) -DLTHIP_ZB_PROF -c $(CSRC)/k_zstd.hip -o build/prof/k_zstd.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/prof/liblongtail_hip_prof.so $(filter-out $(OBJDIR)/k_zstd.o,$(HIP_OBJ)) build/prof/k_zstd.o $(C_OBJ) -lpthread
 
 clean:
 	rm -rf build $(LIB)
