@@ -163,3 +163,20 @@ def test_lz4_and_zstd_compressible_roundtrip(gpu, oracle):
             err, out = r.decompress(1, frame, BLOCK)
             assert err == 0 and len(out) == BLOCK
             assert (out == data[int(b_off[k]) : int(b_off[k]) + BLOCK].cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("target", [65536, 4 << 20])
+def test_one_gigabyte_part_through_one_chunker(gpu, oracle, target):
+    """Maximum sizes: a single part of 1 GiB + 12345 bytes (what one reference chunker would see for a huge target), with
+    the default chunk sizes (one wave walks ~27 000 cuts) and with 8 MiB maximum chunks (level-synchronous BLAKE3 trees)."""
+    n = (1 << 30) + 12345
+    data = torch.empty(n + 256, dtype=torch.uint8, device="cuda")
+    gpu.synth_fill(data, np.array([0], np.uint64), np.array([n], np.uint64), asset_seeds(5, 0, 1), 1)
+    mn, av, mx = chunker_params(target)
+    plan = gpu.make_plan([0], [n], mn, av, mx)
+    total, d_off, d_len, d_hash, _ = gpu.chunk_hash(plan, data)
+    plan.close()
+    e_off, e_len, e_hash = oracle.chunk_and_hash(data[:n].cpu().numpy(), mn, av, mx)
+    assert total == len(e_len)
+    assert (d_len[:total].cpu().numpy().view(np.uint32) == e_len).all()
+    assert (d_hash[:total].cpu().numpy().view(np.uint64) == e_hash).all()
