@@ -179,8 +179,7 @@ def main():
         t1 = time.perf_counter()
         # ---- exchange + dedup (src/longtail.c:2951-2970) ----
         all_hashes, my_base, _counts = allgather_hashes(out_hash, total)
-        first_idx, uniq = ctx.dedup_first_seen(all_hashes)
-        mine_first = first_idx[my_base : my_base + total]
+        mine_first, uniq = ctx.dedup_first_seen_range(all_hashes, my_base, total)  # table over all ranks, answers for mine
         unique_mask = mine_first == torch.arange(my_base, my_base + total, dtype=torch.int32, device=dev)
         n_unique_local = int(unique_mask.sum().item())
         t2 = time.perf_counter()

@@ -205,6 +205,11 @@ LTHIP_EXPORT int lthip_zstd_debug_units(lthip_ctx* ctx, uint64_t first, uint64_t
  * d_first_index[i] == i. */
 LTHIP_EXPORT int lthip_dedup_first_seen(lthip_ctx* ctx, uint64_t count, const uint64_t* d_hashes,
                                         uint32_t* d_first_index, uint64_t* d_unique_count);
+/* Multi-GPU form: all `count` (all-gathered) hashes go into the table, but only this rank's own range
+ * [lookup_first, lookup_first + lookup_count) is answered (d_first_index[j] for hash lookup_first + j, global indices);
+ * *d_unique_count = distinct hashes among all `count`. */
+LTHIP_EXPORT int lthip_dedup_first_seen_range(lthip_ctx* ctx, uint64_t count, const uint64_t* d_hashes, uint64_t lookup_first,
+                                              uint64_t lookup_count, uint32_t* d_first_index, uint64_t* d_unique_count);
 
 /* ---- bulk Longtail_CreateVersionIndex tail (src/longtail.c:2808-3017, layout :2551-2584, :2709-2806) ---
  * From the device-resident chunk lists of lthip_chunk_hash -- all assets' chunks concatenated in (asset, part, chunk) order,

@@ -35,7 +35,7 @@ __global__ void k_dedup_clear(uint64_t* __restrict__ keys, uint32_t* __restrict_
 }
 
 __global__ void k_dedup_insert(const uint64_t* __restrict__ hashes, uint64_t n, uint64_t* __restrict__ keys,
-                               uint32_t* __restrict__ idx, uint64_t mask, uint32_t* special)
+                               uint32_t* __restrict__ idx, uint64_t mask, uint32_t* special, unsigned long long* distinct)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -43,7 +43,8 @@ __global__ void k_dedup_insert(const uint64_t* __restrict__ hashes, uint64_t n, 
     const uint64_t h = hashes[i];
     if (h == EMPTY_KEY)
     {
-        atomicMin(special, (uint32_t)i);
+        if (atomicMin(special, (uint32_t)i) == 0xFFFFFFFFu && distinct)
+            atomicAdd(distinct, 1ull);
         return;
     }
     uint64_t slot = mix64(h) & mask;
@@ -54,19 +55,21 @@ __global__ void k_dedup_insert(const uint64_t* __restrict__ hashes, uint64_t n, 
         if (prev == EMPTY_KEY || prev == h)
         {
             atomicMin(&idx[slot], (uint32_t)i);
+            if (distinct && prev == EMPTY_KEY)
+                atomicAdd(distinct, 1ull); // this insert claimed the slot: one more distinct hash
             return;
         }
         slot = (slot + 1) & mask;
     }
 }
 
-__global__ void k_dedup_lookup(const uint64_t* __restrict__ hashes, uint64_t n, const uint64_t* __restrict__ keys,
+__global__ void k_dedup_lookup(const uint64_t* __restrict__ hashes, uint64_t i0, uint64_t n, const uint64_t* __restrict__ keys,
                                const uint32_t* __restrict__ idx, uint64_t mask, const uint32_t* special,
                                uint32_t* __restrict__ first_index, unsigned long long* unique)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t mine = 0;
-    if (i < n)
+    if (i < i0 + n)
     {
         const uint64_t h = hashes[i];
         uint32_t f;
@@ -79,20 +82,23 @@ __global__ void k_dedup_lookup(const uint64_t* __restrict__ hashes, uint64_t n, 
                 slot = (slot + 1) & mask;
             f = idx[slot];
         }
-        first_index[i] = f;
+        first_index[i - i0] = f;
         mine = f == (uint32_t)i;
     }
     const uint64_t b = __builtin_amdgcn_ballot_w64(mine != 0);
-    if ((threadIdx.x & 63) == 0 && b)
+    if (unique && (threadIdx.x & 63) == 0 && b)
         atomicAdd(unique, (unsigned long long)__builtin_popcountll(b));
 }
 
 } // namespace
 
-extern "C" int lthip_dedup_first_seen(lthip_ctx* ctx, uint64_t count, const uint64_t* d_hashes, uint32_t* d_first_index,
-                                      uint64_t* d_unique_count)
+// Inserts all `count` hashes, answers for [lookup_first, lookup_first + lookup_count): d_first_index[j] = global index of the
+// first occurrence of hash lookup_first + j.  *d_unique_count = number of DISTINCT hashes among all `count` (counted at
+// insertion, so it does not need the lookups of the other ranks' ranges).
+extern "C" int lthip_dedup_first_seen_range(lthip_ctx* ctx, uint64_t count, const uint64_t* d_hashes, uint64_t lookup_first,
+                                            uint64_t lookup_count, uint32_t* d_first_index, uint64_t* d_unique_count)
 {
-    if (!ctx || !d_unique_count || (count && (!d_hashes || !d_first_index)))
+    if (!ctx || !d_unique_count || (count && !d_hashes) || (lookup_count && !d_first_index) || lookup_first + lookup_count > count)
         return EINVAL;
     if (count > 0x7FFFFFFFull)
         return lthip_fail(ctx, EINVAL, "dedup", "too many hashes");
@@ -113,14 +119,20 @@ extern "C" int lthip_dedup_first_seen(lthip_ctx* ctx, uint64_t count, const uint
     hipLaunchKernelGGL(k_dedup_clear, dim3(2048), dim3(256), 0, ctx->stream, (uint64_t*)keys, (uint32_t*)idx, slots, special,
                        (unsigned long long*)d_unique_count);
     if (count)
-    {
-        const uint32_t blocks = (uint32_t)div_up_u64(count, 256);
-        hipLaunchKernelGGL(k_dedup_insert, dim3(blocks), dim3(256), 0, ctx->stream, d_hashes, count, (uint64_t*)keys,
-                           (uint32_t*)idx, slots - 1, special);
-        hipLaunchKernelGGL(k_dedup_lookup, dim3(blocks), dim3(256), 0, ctx->stream, d_hashes, count, (const uint64_t*)keys,
-                           (const uint32_t*)idx, slots - 1, (const uint32_t*)special, d_first_index,
-                           (unsigned long long*)d_unique_count);
-    }
+        hipLaunchKernelGGL(k_dedup_insert, dim3((uint32_t)div_up_u64(count, 256)), dim3(256), 0, ctx->stream, d_hashes, count,
+                           (uint64_t*)keys, (uint32_t*)idx, slots - 1, special, (unsigned long long*)d_unique_count);
+    if (lookup_count)
+        hipLaunchKernelGGL(k_dedup_lookup, dim3((uint32_t)div_up_u64(lookup_count, 256)), dim3(256), 0, ctx->stream, d_hashes,
+                           lookup_first, lookup_count, (const uint64_t*)keys, (const uint32_t*)idx, slots - 1, (const uint32_t*)special,
+                           d_first_index, (unsigned long long*)nullptr);
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
+}
+
+extern "C" int lthip_dedup_first_seen(lthip_ctx* ctx, uint64_t count, const uint64_t* d_hashes, uint32_t* d_first_index,
+                                      uint64_t* d_unique_count)
+{
+    if (count && !d_first_index)
+        return EINVAL;
+    return lthip_dedup_first_seen_range(ctx, count, d_hashes, 0, count, d_first_index, d_unique_count);
 }

@@ -114,6 +114,7 @@ class HipLib:
         sig("lthip_version_index_size", sz, [u32, u64, u64, u32])
         sig("lthip_build_version_index", i32, [vp, u32, vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, u32, u32, vp, sz, vp])
         sig("lthip_dedup_first_seen", i32, [vp, u64, vp, vp, vp])
+        sig("lthip_dedup_first_seen_range", i32, [vp, u64, vp, u64, u64, vp, vp])
         sig("lthip_gather_ranges", i32, [vp, vp, u64, vp, vp, vp, vp])
         sig("lthip_pack_blocks", i32, [u64, vp, u32, u32, vp, u64, P(u64)])
         sig("lthip_synth_fill", i32, [vp, vp, u32, vp, vp, vp, i32])
@@ -337,6 +338,16 @@ class Context:
                                                      _ptr(dst_offsets)), "lthip_gather_ranges")
 
     # -- dedup --
+    def dedup_first_seen_range(self, hashes, first: int, count: int):
+        """All hashes inserted, first-occurrence (global) indices returned for [first, first+count) only; + distinct count."""
+        torch = self.torch
+        n = int(hashes.numel())
+        out = torch.empty(max(1, count), dtype=torch.int32, device=self._dev())
+        uniq = torch.zeros(1, dtype=torch.int64, device=self._dev())
+        self._check(self.lib.dll.lthip_dedup_first_seen_range(self.h, n, _ptr(hashes), first, count, _ptr(out), _ptr(uniq)),
+                    "lthip_dedup_first_seen_range")
+        return out[:count], uniq
+
     def dedup_first_seen(self, hashes):
         torch = self.torch
         n = int(hashes.numel())

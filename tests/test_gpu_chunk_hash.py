@@ -155,3 +155,7 @@ def test_dedup_first_seen(gpu):
         exp[i] = seen.setdefault(x, i)
     assert (u32(first) == exp).all()
     assert int(uniq.item()) == len(seen)
+    # multi-GPU form: same table, answers only for one rank's range, distinct count from the insertions
+    for lo, cnt in ((0, 0), (0, 100), (12345, 20000), (39999, 1), (0, len(h))):
+        part, uniq2 = gpu.dedup_first_seen_range(torch.from_numpy(h).cuda(), lo, cnt)
+        assert (u32(part) == exp[lo : lo + cnt]).all() and int(uniq2.item()) == len(seen)
