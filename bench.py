@@ -164,6 +164,8 @@ def main():
     dst_arena_bytes = batch_bytes + batch_bytes // 255 + (batch_bytes // args.block_size + 2) * 64 + 2 * (limit + limit // 255 + 64)
     dst = torch.empty(dst_arena_bytes, dtype=torch.uint8, device=dev)
     gather_arena = None  # allocated on first use: only trees whose blocks are not contiguous ranges need it
+    h_lens = torch.empty(cap, dtype=torch.int32).pin_memory()
+    h_offs = torch.empty(cap, dtype=torch.int64).pin_memory()
     stats = {}
 
     def compress(src, s_offs, s_sizes, dst_t, d_offs, caps):
@@ -186,19 +188,21 @@ def main():
         comp_bytes = 0
         nblocks = 0
         if not args.no_compress:
-            lens_u32 = out_lens[:total].cpu().numpy().view(np.uint32)
-            offs_h = out_offs[:total].cpu().numpy().view(np.int64)
+            # chunk lists to pinned host memory (one async copy each, one sync), then the serial packing in C
+            h_lens[:total].copy_(out_lens[:total], non_blocking=True)
+            h_offs[:total].copy_(out_offs[:total], non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()
+            lens_u32 = h_lens[:total].numpy().view(np.uint32)
+            offs_h = h_offs[:total].numpy().view(np.int64)
             if n_unique_local != total:
                 keep = unique_mask.cpu().numpy()
                 lens_u32, offs_h = lens_u32[keep], offs_h[keep]
             starts = pack_blocks_c(lens_u32, args.block_size, args.max_chunks_per_block, lib)
-            lens_h = lens_u32.astype(np.int64)
-            cs = np.cumsum(lens_h)
             b_first, b_last = starts[:-1], starts[1:] - 1
-            cs0 = np.concatenate([[0], cs])
-            b_size = cs0[starts[1:]] - cs0[starts[:-1]]
-            nblocks = len(b_size)
-            contiguous = bool(((offs_h[b_last] + lens_h[b_last]) - offs_h[b_first] == b_size).all()) if nblocks else True
+            nblocks = len(b_first)
+            b_size = np.add.reduceat(lens_u32, b_first, dtype=np.int64) if nblocks else np.zeros(0, np.int64)
+            contiguous = bool(((offs_h[b_last] + lens_u32[b_last]) - offs_h[b_first] == b_size).all()) if nblocks else True
+            cs0 = None if contiguous else np.concatenate([[0], np.cumsum(lens_u32, dtype=np.int64)])
             stats["gather"] = not contiguous
             if not contiguous:
                 nonlocal gather_arena
@@ -228,12 +232,11 @@ def main():
                     ctx.gather_ranges(data, d_offs_u[c0:c1].contiguous(), lens_d.contiguous(), gather_arena, dst_off)
                     size_tensors.append(compress(gather_arena, cs0[starts[i:j]] - cs0[c0], b_size[i:j], dst, d_offs, bounds[i:j]))
                 i = j
-            sizes = torch.cat(size_tensors).to(torch.int64)
-            comp_bytes = int(sizes.sum().item())
+            sizes = torch.cat(size_tensors).cpu().numpy().view(np.uint32).astype(np.int64)  # one D2H, waits for the codec
+            comp_bytes = int(sizes.sum())
             # blocks without any match are laid out by the match finder itself (it writes their literals): count them
-            stats["placed_by_matcher"] = int(torch.from_numpy(b_size).to(dev)[sizes >= torch.from_numpy(b_size).to(dev)].sum().item()) \
-                if args.codec == "lz4" else 0
-            if int((sizes == 0).sum().item()) != 0:
+            stats["placed_by_matcher"] = int(b_size[sizes >= b_size].sum()) if args.codec == "lz4" else 0
+            if int((sizes == 0).sum()) != 0:
                 raise SystemExit("a block did not fit its bound: encoder bug")
         ctx.sync()
         t3 = time.perf_counter()
