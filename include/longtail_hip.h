@@ -52,8 +52,10 @@ LTHIP_EXPORT struct Longtail_CompressionAPI* Longtail_CompressionRegistry_Create
 LTHIP_EXPORT uint32_t Longtail_GetHipLZ4DefaultQuality(void);
 
 /* Replaces Longtail_CreateZStdCompressionAPI() / Longtail_CompressionRegistry_CreateForZstd()
- * (lib/zstd/longtail_zstd.h:10-16, longtail_zstd.c:30-41,72-177).  Type ids 'ztd1'..'ztd5'.
- * Stage 1 encoder: concatenated zstd frames of raw / RLE blocks (valid for ZSTD_decompressDCtx). */
+ * (lib/zstd/longtail_zstd.h:10-16, longtail_zstd.c:30-41,72-177).  Type ids 'ztd1'..'ztd5' (one parse whatever the
+ * setting).  Compress: one zstd frame per block -- RLE / Compressed (LZ sequences, Huffman literals, FSE sequences) / Raw
+ * blocks -- that ZSTD_decompressDCtx decodes.  Decompress: any zstd frame(s) without a dictionary, e.g. the reference
+ * encoder's; malformed input -> EINVAL (longtail_zstd.c:168-172). */
 LTHIP_EXPORT struct Longtail_CompressionAPI* Longtail_CreateHipZStdCompressionAPI(void);
 LTHIP_EXPORT struct Longtail_CompressionAPI* Longtail_CompressionRegistry_CreateForHipZstd(uint32_t compression_type, uint32_t* out_settings);
 
