@@ -249,9 +249,13 @@ __device__ __forceinline__ void lz4_coop_sequence(const uint8_t* __restrict__ sb
 // kept), otherwise (incompressible data) nobody pays for it.  16 waves per CU instead of 4 at the same window.
 constexpr int LZ4_G = 8;
 constexpr int LZ4_PROBE_BATCHES = 4;
+// table entries per wave: with 1536 the LZ4 flavour needs 57 KiB of LDS per workgroup... see the host launcher
+constexpr int LZ4_TAB_LZ4 = 1024 + 256;  // 32 KiB window + 8 x 2.5 KiB tables = 52 KiB: THREE workgroups (24 waves) per CU
+constexpr int LZ4_TAB_ZSTD = 1024 + 256;
 
-template <int HASH_LOG2, int FMT>
-__global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
+// TAB = entries of a wave's private table (any multiple of 8: the index is mulhi(hash, TAB), not a mask)
+template <int TAB, int FMT>
+__global__ __launch_bounds__(64 * LZ4_G, 6) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
                                                              uint32_t nblocks, uint32_t grp0, uint32_t sub_bytes,
                                                              uint8_t* __restrict__ streams, Lz4Meta* __restrict__ meta,
                                                              uint64_t* __restrict__ zrecs, uint8_t* __restrict__ spec_dst, uint32_t dbg)
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint16_t* tab = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u) + (size_t)wave * (1u << HASH_LOG2);
+    uint16_t* tab = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u) + (size_t)wave * TAB;
 
     const uint32_t grp = blockIdx.x + grp0;
     uint32_t lo = 0, hi = nblocks;
@@ -308,8 +312,9 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
         uint4* tv = reinterpret_cast<uint4*>(tab);
         const uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
 #pragma unroll
-        for (uint32_t v = 0; v < (1u << HASH_LOG2) * 2 / 16 / 64; ++v)
-            tv[v * 64 + lane] = e;
+        for (uint32_t v = 0; v < (TAB * 2 / 16 + 63) / 64; ++v) // TAB * 2 bytes, 64 lanes x 16 bytes per step
+            if (v * 64 + lane < TAB * 2 / 16)
+                tv[v * 64 + lane] = e;
         if (tid == 0)
             *flag = 0u;
     }
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
                     uint32_t hv[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        hv[u] = (lds_read32(sdata, q0 + 4u * (u * 64 + (uint32_t)lane) + head) * 2654435761u) >> (32 - HASH_LOG2);
+                        hv[u] = __umulhi(lds_read32(sdata, q0 + 4u * (u * 64 + (uint32_t)lane) + head) * 2654435761u, (uint32_t)TAB);
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         tab[hv[u]] = (uint16_t)(q0 + 4u * (u * 64 + (uint32_t)lane));
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
     {                                                                                                   \
         const uint32_t rp = (PB) + (uint32_t)lane * (PS);                                               \
         if ((int32_t)rp <= start_limit)                                                                 \
-            tab[(lds_read32(sdata, rp + head) * 2654435761u) >> (32 - HASH_LOG2)] = (uint16_t)rp;       \
+            tab[__umulhi(lds_read32(sdata, rp + head) * 2654435761u, (uint32_t)TAB)] = (uint16_t)rp;         \
     }
                 LT_REPLAY(0u, pb0, ps0)
                 LT_REPLAY(1u, pb1, ps1)
@@ -412,13 +417,13 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
             if (valid)
             {
                 v = lds_read32(sdata, p + head);
-                h = (v * 2654435761u) >> (32 - HASH_LOG2);
+                h = __umulhi(v * 2654435761u, (uint32_t)TAB);
                 cand = tab[h];
             }
             if (valid2)
             {
                 v2 = lds_read32(sdata, p2 + head);
-                h2 = (v2 * 2654435761u) >> (32 - HASH_LOG2);
+                h2 = __umulhi(v2 * 2654435761u, (uint32_t)TAB);
                 cand2 = tab[h2];
             }
             if (valid)
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(64 * LZ4_G) void k_lz4_segments(const uint8_t* __re
             if (valid)
             {
                 v = lds_read32(sdata, p + head);
-                h = (v * 2654435761u) >> (32 - HASH_LOG2);
+                h = __umulhi(v * 2654435761u, (uint32_t)TAB);
                 cand = tab[h];
             }
             // every lane has read the table before anyone updates it (same wave: LDS operations execute in order)
@@ -1139,7 +1144,7 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
     std::vector<uint32_t> grp_first(block_count + 1, 0);
     for (uint32_t b = 0; b < block_count; ++b)
         grp_first[b + 1] = grp_first[b] + (uint32_t)(((((uint64_t)src_sizes[b] + SEG - 1) / SEG) + LZ4_G - 1) / LZ4_G);
-    const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * (1u << 11) * 2;
+    const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * LZ4_TAB_LZ4 * 2;
     const bool overlap = cut.size() > 2;
     void* worklist;
     if ((err = lthip_scratch(ctx, S_LZ4_WORKLIST, 4 * ((size_t)ngrp64 + 1) * (cut.size() - 1), &worklist)))
@@ -1160,7 +1165,7 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
         if (g1 > g0)
         {
             LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
-            hipLaunchKernelGGL((k_lz4_segments<11, 0>), dim3(g1 - g0), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
+            hipLaunchKernelGGL((k_lz4_segments<LZ4_TAB_LZ4, 0>), dim3(g1 - g0), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
                                block_count, g0, SEG, (uint8_t*)streams, (Lz4Meta*)meta, (uint64_t*)nullptr,
                                (dbg & 64u) ? (uint8_t*)nullptr : (uint8_t*)d_dst, dbg);
             LTHIP_LAUNCH_CHECK(ctx);
@@ -1226,8 +1231,8 @@ int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_
     if (nseg)
     {
         LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
-        const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * (1u << 11) * 2;
-        hipLaunchKernelGGL((k_lz4_segments<11, 1>), dim3((uint32_t)ngrp64), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src,
+        const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * LZ4_TAB_ZSTD * 2;
+        hipLaunchKernelGGL((k_lz4_segments<LZ4_TAB_ZSTD, 1>), dim3((uint32_t)ngrp64), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src,
                            d_blocks, block_count, 0u, SEG, (uint8_t*)lits, (Lz4Meta*)meta, (uint64_t*)recs, (uint8_t*)nullptr,
                            (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0));
         LTHIP_LAUNCH_CHECK(ctx);
