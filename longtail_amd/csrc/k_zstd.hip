@@ -163,7 +163,7 @@ __global__ __launch_bounds__(ZT) void k_zstd_emit(const uint8_t* __restrict__ sr
 }
 
 // One wavefront per 128 KiB piece, persistent over the pieces: the entropy stage of zstd_block_core.h.
-__global__ __launch_bounds__(64, 3) void k_zstd_encode(const ZBlock* __restrict__ blocks, uint32_t nblocks, uint32_t npieces,
+__global__ __launch_bounds__(64, 4) void k_zstd_encode(const ZBlock* __restrict__ blocks, uint32_t nblocks, uint32_t npieces,
                                                     uint8_t* __restrict__ is_rle, const ZbUnitMeta* __restrict__ unit_meta,
                                                     const uint8_t* __restrict__ unit_lits, const uint64_t* __restrict__ unit_recs,
                                                     uint8_t* __restrict__ work, uint8_t* __restrict__ enc,
@@ -294,7 +294,7 @@ extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uin
         hb[b].unit_base = unit_base[b];
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const uint32_t nwg = (uint32_t)(nzb < (uint64_t)ncu * 12 ? nzb : (uint64_t)ncu * 12);
+    const uint32_t nwg = (uint32_t)(nzb < (uint64_t)ncu * 16 ? nzb : (uint64_t)ncu * 16);
     void *d_blocks, *d_rle, *d_zdst, *d_enc, *d_encsz, *d_work;
     if ((err = lthip_scratch(ctx, S_LZ4_BLOCKS, sizeof(ZBlock) * (size_t)block_count, &d_blocks)))
         return err;

@@ -104,7 +104,8 @@ enum
 typedef struct ZbShared /* LDS on the GPU (about 9.5 KiB per wave) */
 {
     uint32_t lit_hist[256];
-    uint32_t sort_key[256]; /* Huffman construction: present symbols sorted by count (sort_key+huf_w: FSE code tile) */
+    uint32_t sort_key[256]; /* Huffman construction: present symbols sorted by count.  sort_key + huf_w (2 KiB) are reused
+                             * once the code lengths exist: symbol spread of the FSE table builds, then the FSE code tile */
     uint32_t huf_w[256];    /* ... weights / parent links / depths (Moffat-Katajainen, in place) */
     uint8_t huf_l[256];     /* ... code length per sorted position */
     uint8_t tree[160];      /* Huffman tree description */
@@ -115,13 +116,14 @@ typedef struct ZbShared /* LDS on the GPU (about 9.5 KiB per wave) */
     int16_t norm[3][64];
     uint16_t sym_start[3][64];
     uint16_t state_tab[3][512];
-    uint8_t spread[3][512];
     uint8_t mode[4], table_log[4], rle_sym[4];
     uint32_t useq_base[ZB_MAX_UNITS + 1], ulit_base[ZB_MAX_UNITS + 1], carry[ZB_MAX_UNITS];
-    uint32_t part[ZB_CHUNKS + 1];
-    uint32_t part2[ZB_CHUNKS + 1];
+    uint32_t part2[4]; /* bits of the four literal streams */
     uint32_t v[ZV_COUNT];
 } ZbShared;
+
+/* work space of the FSE table builds: 3 x 512 bytes over sort_key / huf_w */
+#define ZB_SPREAD(sh, t) (((uint8_t*)(sh)->sort_key) + 512u * (uint32_t)(t))
 
 /* table indices */
 #define ZT_LL 0
@@ -681,7 +683,7 @@ ZB_FN uint32_t zb_write_huf_tree(ZbShared* sh, uint8_t* dst)
             uint32_t pos;
             zb_normalize(hist, 13u, nw, tl, norm);
             pos = 1u + zb_write_ncount(dst + 1, norm, 13u, tl);
-            zb_build_enc_table(norm, 13u, tl, sh->spread[0], sh->state_tab[0], sh->sym_start[0], sh->cursor[0]);
+            zb_build_enc_table(norm, 13u, tl, ZB_SPREAD(sh, 0), sh->state_tab[0], sh->sym_start[0], sh->cursor[0]);
             /* Weights are decoded alternately by state 1 (even indices) and state 2 (odd); the two last weights
              * are carried by the initial states (first cell of their symbol, so that the decoder's final state
              * update over-reads and stops, fse_decompress.c:214-236); the others are encoded from the end. */
@@ -935,7 +937,7 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
                 sh->table_log[t] = (uint8_t)zb_table_default_log((int)t);
                 for (uint32_t s = 0; s < 64u; ++s)
                     sh->norm[t][s] = (int16_t)(s < nsym ? zb_default_norm((int)t, s) : 0);
-                zb_build_enc_table(sh->norm[t], nsym, sh->table_log[t], sh->spread[t], sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
+                zb_build_enc_table(sh->norm[t], nsym, sh->table_log[t], ZB_SPREAD(sh, t), sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
             }
             else
             {
@@ -948,7 +950,7 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
                 sh->mode[t] = 2; /* FSE_Compressed_Mode */
                 sh->table_log[t] = (uint8_t)tl;
                 zb_normalize(sh->sym_hist[t], maxs + 1u, nbseq, tl, sh->norm[t]);
-                zb_build_enc_table(sh->norm[t], maxs + 1u, tl, sh->spread[t], sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
+                zb_build_enc_table(sh->norm[t], maxs + 1u, tl, ZB_SPREAD(sh, t), sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
                 sh->rle_sym[t] = (uint8_t)maxs; /* highest present symbol, for the NCount writer */
             }
         }
