@@ -87,7 +87,7 @@ def main():
 
     from longtail_amd.dist import allgather_hashes
     from longtail_amd.lib import Context, chunker_params, load
-    from longtail_amd.lib import pack_blocks as pack_blocks_c
+    from longtail_amd.lib import BatchPacker
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -197,42 +197,45 @@ def main():
             if n_unique_local != total:
                 keep = unique_mask.cpu().numpy()
                 lens_u32, offs_h = lens_u32[keep], offs_h[keep]
-            starts = pack_blocks_c(lens_u32, args.block_size, args.max_chunks_per_block, lib)
-            b_first, b_last = starts[:-1], starts[1:] - 1
-            nblocks = len(b_first)
-            b_size = np.add.reduceat(lens_u32, b_first, dtype=np.int64) if nblocks else np.zeros(0, np.int64)
-            contiguous = bool(((offs_h[b_last] + lens_u32[b_last]) - offs_h[b_first] == b_size).all()) if nblocks else True
-            cs0 = None if contiguous else np.concatenate([[0], np.cumsum(lens_u32, dtype=np.int64)])
-            stats["gather"] = not contiguous
-            if not contiguous:
-                nonlocal gather_arena
-                if gather_arena is None:
-                    gather_arena = torch.empty(batch_bytes + 2 * limit + 256, dtype=torch.uint8, device=dev)
-                if n_unique_local != total:
-                    d_offs_u, d_lens_u = out_offs[:total][unique_mask], out_lens[:total][unique_mask]
-                else:
-                    d_offs_u, d_lens_u = out_offs[:total], out_lens[:total]
-            bounds = b_size + b_size // 255 + 16 if args.codec == "lz4" else b_size + (b_size >> 8) + 64
-            aligned = (bounds + 63) // 64 * 64
-            i = 0
-            size_tensors = []
-            while i < nblocks:
-                j = i + max(1, int(np.searchsorted(np.cumsum(aligned[i:]), dst_arena_bytes, side="right")))
-                j = min(j, i + max(1, int(np.searchsorted(np.cumsum(b_size[i:]), batch_bytes, side="right"))), nblocks)
-                j = max(j, i + 1)
-                d_offs = np.concatenate([[0], np.cumsum(aligned[i:j])[:-1]])
-                if contiguous:
-                    size_tensors.append(compress(data, offs_h[b_first[i:j]], b_size[i:j], dst, d_offs, bounds[i:j]))
+            # greedy packing, one batch at a time: batch k+1 is packed on the host while the device compresses batch k
+            lz = args.codec == "lz4"
+            packer = BatchPacker(lens_u32, args.block_size, args.max_chunks_per_block, batch_bytes, dst_arena_bytes,
+                                 255 if lz else 256, 16 if lz else 64, lib)
+            d_offs_u = d_lens_u = None
+            size_tensors, b_size_all = [], []
+            stats["gather"] = False
+            while True:
+                nxt = packer.next()
+                if nxt is None:
+                    break
+                starts, b_size = nxt
+                b_first, b_last = starts[:-1], starts[1:] - 1
+                nblocks += len(b_first)
+                b_size_all.append(b_size)
+                bounds = b_size + b_size // 255 + 16 if lz else b_size + (b_size >> 8) + 64
+                aligned = (bounds + 63) // 64 * 64
+                d_offs = np.concatenate([[0], np.cumsum(aligned)[:-1]])
+                if bool(((offs_h[b_last] + lens_u32[b_last]) - offs_h[b_first] == b_size).all()):
+                    size_tensors.append(compress(data, offs_h[b_first], b_size, dst, d_offs, bounds))
                 else:
                     # block assembly on the device (WriteContentBlockJob, src/longtail.c:4640-4721): gather this batch's
                     # chunks back to back, then every block is a contiguous range of the gather arena
-                    c0, c1 = int(starts[i]), int(starts[j])
+                    stats["gather"] = True
+                    nonlocal gather_arena
+                    if gather_arena is None:
+                        gather_arena = torch.empty(batch_bytes + 2 * limit + 256, dtype=torch.uint8, device=dev)
+                    if d_offs_u is None:
+                        if n_unique_local != total:
+                            d_offs_u, d_lens_u = out_offs[:total][unique_mask], out_lens[:total][unique_mask]
+                        else:
+                            d_offs_u, d_lens_u = out_offs[:total], out_lens[:total]
+                    c0, c1 = int(starts[0]), int(starts[-1])
                     lens_d = d_lens_u[c0:c1]
                     dst_off = torch.cumsum(lens_d.to(torch.int64), 0) - lens_d.to(torch.int64)
                     ctx.gather_ranges(data, d_offs_u[c0:c1].contiguous(), lens_d.contiguous(), gather_arena, dst_off)
-                    size_tensors.append(compress(gather_arena, cs0[starts[i:j]] - cs0[c0], b_size[i:j], dst, d_offs, bounds[i:j]))
-                i = j
-            sizes = torch.cat(size_tensors).cpu().numpy().view(np.uint32).astype(np.int64)  # one D2H, waits for the codec
+                    size_tensors.append(compress(gather_arena, np.cumsum(b_size) - b_size, b_size, dst, d_offs, bounds))
+            b_size = np.concatenate(b_size_all) if b_size_all else np.zeros(0, np.int64)
+            sizes = (torch.cat(size_tensors).cpu().numpy().view(np.uint32).astype(np.int64) if size_tensors else np.zeros(0, np.int64))  # one D2H, waits for the codec
             comp_bytes = int(sizes.sum())
             # blocks without any match are laid out by the match finder itself (it writes their literals): count them
             stats["placed_by_matcher"] = int(b_size[sizes >= b_size].sum()) if args.codec == "lz4" else 0
@@ -303,11 +306,12 @@ def main():
         try:
             tfiles = sorted((ROOT / "profiles").glob("*pmc_traffic*.json"))
             tj = json.load(open(tfiles[-1]))
-            names = {"buzhash": "k_buzhash_candidates<0>", "blake3_leaf": "k_blake3_leaves", "lz4_segments": "k_lz4_segments<11, 0>",
+            names = {"buzhash": "k_buzhash_candidates<0>", "blake3_leaf": "k_blake3_leaves", "lz4_segments": "k_lz4_segments<",
                      "lz4_stitch": "k_lz4_stitch_copy"}
             if dom == "lz4_segments" and args.codec != "lz4":
                 raise KeyError("no PMC pass for the sequence-output variant of the match finder")
-            ratio = tj["kernels"][names[dom]]["corrected_per_input_byte"]
+            key = next(k for k in tj["kernels"] if k.startswith(names[dom]) and (dom != "lz4_segments" or k.endswith(", 0>")))
+            ratio = tj["kernels"][key]["corrected_per_input_byte"]
             roofline["traffic"] = int(ratio * shard_bytes / kern[dom]["launches_per_step"])
             roofline["traffic_source"] = f"profiles/{tfiles[-1].name}: {ratio} HBM bytes per input byte (2*FETCH_SIZE+WRITE_SIZE)"
         except Exception:

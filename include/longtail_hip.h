@@ -176,6 +176,16 @@ LTHIP_EXPORT int lthip_pack_blocks(uint64_t chunk_count, const uint32_t* chunk_l
                                    uint32_t max_chunks_per_block, uint64_t* block_starts, uint64_t capacity,
                                    uint64_t* out_block_count);
 
+/* The same greedy rule, resumable: packs from chunk `first_chunk` until the batch holds max_batch_bytes of chunk data or
+ * the blocks' codec bounds (size + size / bound_div + bound_add, rounded up to 64) fill arena_bytes -- always at least one
+ * block.  block_starts[0..n] (n = *out_block_count, last entry = *out_next_chunk) and block_sizes[0..n) are host arrays of
+ * `capacity` entries.  Lets the caller pack batch k+1 while the device compresses batch k. */
+LTHIP_EXPORT int lthip_pack_blocks_batch(uint64_t chunk_count, const uint32_t* chunk_lens, uint64_t first_chunk,
+                                         uint32_t max_block_size, uint32_t max_chunks_per_block, uint64_t max_batch_bytes,
+                                         uint64_t arena_bytes, uint32_t bound_div, uint32_t bound_add,
+                                         uint64_t* block_starts, uint64_t* block_sizes, uint64_t capacity,
+                                         uint64_t* out_block_count, uint64_t* out_next_chunk);
+
 /* Block assembly (WriteContentBlockJob, src/longtail.c:4640-4721) as a device gather:
  * d_dst[d_dst_offsets[i] ..) = d_src[d_src_offsets[i] .. + d_lens[i]) for every range (all tables on the device). */
 LTHIP_EXPORT int lthip_gather_ranges(lthip_ctx* ctx, const void* d_src, uint64_t range_count, const uint64_t* d_src_offsets,

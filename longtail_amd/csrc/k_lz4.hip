@@ -736,60 +736,79 @@ __global__ __launch_bounds__(64) void k_lz4_stitch_scan(const Lz4Block* __restri
     uint64_t out_pos = 0; // 64-bit: pathological inputs are caught against dst_cap at the end
     uint32_t carry = 0;
     uint32_t run = 0;
+    // The walk is a recurrence over (literal carry, output position, run count), restated as three wave scans per 64
+    // units so that no step is serial:  a unit WITH a match resets the carry to its tail literals, one without adds its
+    // length (segmented inclusive scan);  only units with a match advance the output (prefix sum of token + length
+    // bytes + literals + body, all functions of the carry that reaches them) and close a run (prefix count).
+    Lz4Meta m;
+    m.seq_bytes = m.tail_lits = m.first_lit_len = m.first_hdr_bytes = 0;
+    if ((uint32_t)lane < blk.nseg)
+        m = meta[blk.seg_base + (uint32_t)lane];
     for (uint32_t i0 = 0; i0 < blk.nseg; i0 += 64)
     {
         const uint32_t i = i0 + (uint32_t)lane;
-        Lz4Meta m;
-        m.seq_bytes = m.tail_lits = m.first_lit_len = m.first_hdr_bytes = 0;
-        if (i < blk.nseg)
-            m = meta[blk.seg_base + i];
-        Lz4Plan pl;
-        pl.hdr_pos = 0xFFFFFFFFu;
-        pl.hdr_lits = pl.first_lit_dst = pl.body_dst = pl.tail_rel = pl.run = 0;
-        const uint32_t n = blk.nseg - i0 < 64u ? blk.nseg - i0 : 64u;
-        for (uint32_t u = 0; u < n; ++u)
+        const Lz4Meta cur = m;
+        if (i + 64u < blk.nseg) // next step's records are in flight while this one is scanned
+            m = meta[blk.seg_base + i + 64u];
+        const bool valid = i < blk.nseg;
+        const bool has = valid && cur.seq_bytes != 0u;
+        const uint32_t seg_len = valid ? (blk.size - i * SEG < SEG ? blk.size - i * SEG : SEG) : 0u;
+        // inclusive segmented scan of the carry each unit leaves behind
+        uint32_t sv = has ? cur.tail_lits : seg_len;
+        uint32_t sf = has ? 1u : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1)
         {
-            const uint32_t seq_bytes = __builtin_amdgcn_readlane(m.seq_bytes, u);
-            uint32_t hdr_pos = 0xFFFFFFFFu, hdr_lits = 0, first_lit_dst = 0, body_dst = 0, tail_rel, my_run;
-            if (seq_bytes)
+            const uint32_t pv = __shfl_up(sv, d, 64);
+            const uint32_t pf = __shfl_up(sf, d, 64);
+            if (lane >= d)
             {
-                const uint32_t fl = __builtin_amdgcn_readlane(m.first_lit_len, u);
-                const uint32_t fh = __builtin_amdgcn_readlane(m.first_hdr_bytes, u);
-                const uint32_t L = carry + fl;
-                const uint32_t hdr = 1u + lz4_len_bytes(L);
-                const uint64_t lit_dst = out_pos + hdr;
-                if (lane == 0)
-                    runs[run_base + run] = (uint32_t)lit_dst; // closes the open run
-                hdr_pos = (uint32_t)out_pos;
-                hdr_lits = L;
-                first_lit_dst = (uint32_t)(lit_dst + carry);
-                body_dst = first_lit_dst + fl;
-                out_pos = (uint64_t)body_dst + (seq_bytes - fh - fl);
-                ++run;
-                tail_rel = 0; // this unit's tail opens the next run
-                my_run = run;
-                carry = __builtin_amdgcn_readlane(m.tail_lits, u);
-            }
-            else
-            {
-                const uint32_t iu = i0 + u;
-                const uint32_t seg_len = blk.size - iu * SEG < SEG ? blk.size - iu * SEG : SEG;
-                tail_rel = carry;
-                my_run = run;
-                carry += seg_len;
-            }
-            if ((uint32_t)lane == u)
-            {
-                pl.hdr_pos = hdr_pos;
-                pl.hdr_lits = hdr_lits;
-                pl.first_lit_dst = first_lit_dst;
-                pl.body_dst = body_dst;
-                pl.tail_rel = tail_rel;
-                pl.run = run_base + my_run;
+                if (!sf)
+                    sv += pv;
+                sf |= pf;
             }
         }
-        if (i < blk.nseg)
+        if (!sf)
+            sv += carry; // nobody before me in this step had a match: the carry of the previous steps reaches me
+        uint32_t cin = __shfl_up(sv, 1, 64); // the carry that reaches me
+        if (lane == 0)
+            cin = carry;
+        // output advance of the units with a match
+        const uint32_t L = cin + cur.first_lit_len;
+        const uint32_t hdr = 1u + lz4_len_bytes(L);
+        const uint64_t adv = has ? (uint64_t)hdr + L + (cur.seq_bytes - cur.first_hdr_bytes - cur.first_lit_len) : 0ull;
+        uint64_t pos = adv; // inclusive prefix sum
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1)
+        {
+            const uint64_t pv = __shfl_up(pos, d, 64);
+            if (lane >= d)
+                pos += pv;
+        }
+        const uint64_t my_pos = out_pos + pos - adv;
+        const uint64_t hm = __builtin_amdgcn_ballot_w64(has);
+        const uint32_t before = (uint32_t)__builtin_popcountll(hm & ((1ull << lane) - 1ull));
+        Lz4Plan pl;
+        pl.hdr_pos = 0xFFFFFFFFu;
+        pl.hdr_lits = pl.first_lit_dst = pl.body_dst = 0;
+        pl.tail_rel = cin;
+        pl.run = run_base + run + before;
+        if (has)
+        {
+            const uint64_t lit_dst = my_pos + hdr;
+            runs[run_base + run + before] = (uint32_t)lit_dst; // closes the open run
+            pl.hdr_pos = (uint32_t)my_pos;
+            pl.hdr_lits = L;
+            pl.first_lit_dst = (uint32_t)(lit_dst + cin);
+            pl.body_dst = pl.first_lit_dst + cur.first_lit_len;
+            pl.tail_rel = 0; // this unit's tail opens the next run
+            pl.run = run_base + run + before + 1u;
+        }
+        if (valid)
             plan[blk.seg_base + i] = pl;
+        out_pos += __shfl(pos, 63, 64);
+        carry = __shfl(sv, 63, 64); // lanes past the end add nothing
+        run += (uint32_t)__builtin_popcountll(hm);
     }
     // final literal-only sequence (lz4.c:1302-1329)
     const uint32_t hdr = 1u + lz4_len_bytes(carry);
@@ -1078,8 +1097,8 @@ static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* s
     int err = lthip_scratch(ctx, S_LZ4_BLOCKS, sizeof(Lz4Block) * (size_t)block_count, &p);
     if (err)
         return err;
-    LTHIP_CHECK(ctx, hipMemcpyAsync(p, hb.data(), sizeof(Lz4Block) * (size_t)block_count, hipMemcpyHostToDevice, ctx->stream));
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // hb is a local
+    if ((err = lthip_stage_upload(ctx, p, hb.data(), sizeof(Lz4Block) * (size_t)block_count, ctx->stream))) // no host stall
+        return err;
     *d_blocks = (Lz4Block*)p;
     *out_nseg = nseg;
     if (out_ngrp)

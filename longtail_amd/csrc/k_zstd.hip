@@ -308,8 +308,8 @@ extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uin
         return err;
     if ((err = lthip_scratch(ctx, S_Z_WORK, Z_WORK_STRIDE * ((size_t)nwg + 1), &d_work)))
         return err;
-    LTHIP_CHECK(ctx, hipMemcpyAsync(d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, hipMemcpyHostToDevice, ctx->stream));
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((err = lthip_stage_upload(ctx, d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, ctx->stream)))
+        return err;
     if (nzb)
     {
         LaunchTimer t(ctx, LTHIP_K_ZSTD_ENC);
@@ -395,8 +395,8 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
         return err;
     if ((err = lthip_scratch(ctx, S_Z_WORK, (size_t)(ZD_LIT_MAX + 64u) * nwg, &d_lits)))
         return err;
-    LTHIP_CHECK(ctx, hipMemcpyAsync(d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, hipMemcpyHostToDevice, ctx->stream));
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((err = lthip_stage_upload(ctx, d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, ctx->stream)))
+        return err;
     LaunchTimer t(ctx, LTHIP_K_OTHER);
     hipLaunchKernelGGL(k_zstd_decode, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks, block_count,
                        (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes);

@@ -66,6 +66,8 @@ extern "C" int lthip_ctx_create(int device, void* hip_stream, lthip_ctx** out_ct
     ctx->err[0] = 0;
     ctx->timing = false;
     memset(ctx->scratch, 0, sizeof ctx->scratch);
+    memset(ctx->stage, 0, sizeof ctx->stage);
+    ctx->stage_next = 0;
     memset(ctx->scratch_cap, 0, sizeof ctx->scratch_cap);
     memset(ctx->total_ms, 0, sizeof ctx->total_ms);
     memset(ctx->launches, 0, sizeof ctx->launches);
@@ -110,6 +112,13 @@ extern "C" void lthip_ctx_destroy(lthip_ctx* ctx)
     for (int i = 0; i < S_COUNT; ++i)
         if (ctx->scratch[i])
             (void)hipFree(ctx->scratch[i]);
+    for (auto& st : ctx->stage)
+    {
+        if (st.done)
+            (void)hipEventDestroy(st.done);
+        if (st.p)
+            (void)hipHostFree(st.p);
+    }
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -224,6 +233,32 @@ int lthip_second_stream(lthip_ctx* ctx, hipStream_t* out)
     if (!ctx->stream2)
         LTHIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     *out = ctx->stream2;
+    return 0;
+}
+
+int lthip_stage_upload(lthip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0)
+        return 0;
+    lthip_ctx::Stage& st = ctx->stage[ctx->stage_next++ % (sizeof(ctx->stage) / sizeof(ctx->stage[0]))];
+    if (st.used)
+        LTHIP_CHECK(ctx, hipEventSynchronize(st.done)); // eight uploads ago: long finished in steady state
+    if (st.cap < bytes)
+    {
+        if (st.p)
+            LTHIP_CHECK(ctx, hipHostFree(st.p));
+        st.p = nullptr;
+        st.cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        LTHIP_CHECK(ctx, hipHostMalloc(&st.p, want, hipHostMallocDefault));
+        st.cap = want;
+    }
+    if (!st.done)
+        LTHIP_CHECK(ctx, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    memcpy(st.p, h_src, bytes);
+    LTHIP_CHECK(ctx, hipMemcpyAsync(d_dst, st.p, bytes, hipMemcpyHostToDevice, stream));
+    LTHIP_CHECK(ctx, hipEventRecord(st.done, stream));
+    st.used = true;
     return 0;
 }
 
@@ -372,6 +407,50 @@ extern "C" int lthip_pack_blocks(uint64_t chunk_count, const uint32_t* chunk_len
         return ENOMEM;
     block_starts[nb] = chunk_count;
     *out_block_count = nb;
+    return 0;
+}
+
+// The same rule, resumable: packs blocks from chunk `first_chunk` on until the batch holds max_batch_bytes of chunk data
+// or its codec output bounds (size + size / bound_div + bound_add, rounded up to 64) fill arena_bytes -- always at least
+// one block -- so that a caller can hand batch k to the device and pack batch k+1 while it is being compressed.
+extern "C" int lthip_pack_blocks_batch(uint64_t chunk_count, const uint32_t* chunk_lens, uint64_t first_chunk,
+                                       uint32_t max_block_size, uint32_t max_chunks_per_block, uint64_t max_batch_bytes,
+                                       uint64_t arena_bytes, uint32_t bound_div, uint32_t bound_add, uint64_t* block_starts,
+                                       uint64_t* block_sizes, uint64_t capacity, uint64_t* out_block_count,
+                                       uint64_t* out_next_chunk)
+{
+    if (!out_block_count || !out_next_chunk || !block_starts || !block_sizes || (chunk_count && !chunk_lens) ||
+        max_block_size == 0 || max_chunks_per_block == 0 || bound_div == 0 || capacity < 2 || first_chunk > chunk_count)
+        return EINVAL;
+    const uint64_t limit = (uint64_t)max_block_size + max_block_size / 10;
+    uint64_t i = first_chunk, nb = 0, bytes = 0, arena = 0;
+    while (i < chunk_count && nb + 1 < capacity)
+    {
+        const uint64_t start = i;
+        uint64_t size = chunk_lens[i];
+        uint32_t n = 1;
+        while (i + 1 < chunk_count && n < max_chunks_per_block && size + chunk_lens[i + 1] <= limit)
+        {
+            size += chunk_lens[i + 1];
+            ++n;
+            ++i;
+        }
+        ++i;
+        const uint64_t bound = (size + size / bound_div + bound_add + 63u) & ~(uint64_t)63u;
+        if (nb && (bytes + size > max_batch_bytes || arena + bound > arena_bytes))
+        {
+            i = start; // this block opens the next batch
+            break;
+        }
+        block_starts[nb] = start;
+        block_sizes[nb] = size;
+        ++nb;
+        bytes += size;
+        arena += bound;
+    }
+    block_starts[nb] = i;
+    *out_block_count = nb;
+    *out_next_chunk = i;
     return 0;
 }
 

@@ -97,6 +97,14 @@ struct lthip_ctx
     std::vector<hipEvent_t> sync_events; // ordering events between the two streams, reused round-robin
     size_t sync_next;
     char err[320];
+    struct Stage // pinned staging slot of lthip_stage_upload
+    {
+        void* p;
+        size_t cap;
+        hipEvent_t done;
+        bool used;
+    } stage[8];
+    size_t stage_next;
     void* scratch[S_COUNT];
     size_t scratch_cap[S_COUNT];
     bool timing;
@@ -112,6 +120,10 @@ int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out);
 // events from lthip_sync_event and must make the main stream wait for the side stream before they return).
 int lthip_second_stream(lthip_ctx* ctx, hipStream_t* out);
 hipEvent_t lthip_sync_event(lthip_ctx* ctx);
+// Host table -> device without stalling the caller: the bytes are copied into one of a ring of pinned staging buffers and
+// queued on `stream`; `h_src` may be freed on return, and the host does not wait for earlier work of the stream (a
+// pageable hipMemcpyAsync + hipStreamSynchronize would wait for every kernel queued before it).
+int lthip_stage_upload(lthip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hipStream_t stream);
 
 #define LTHIP_CHECK(ctx, expr)                                                          \
     do                                                                                  \

@@ -117,6 +117,7 @@ class HipLib:
         sig("lthip_dedup_first_seen_range", i32, [vp, u64, vp, u64, u64, vp, vp])
         sig("lthip_gather_ranges", i32, [vp, vp, u64, vp, vp, vp, vp])
         sig("lthip_pack_blocks", i32, [u64, vp, u32, u32, vp, u64, P(u64)])
+        sig("lthip_pack_blocks_batch", i32, [u64, vp, u64, u32, u32, u64, u64, u32, u32, vp, vp, u64, P(u64), P(u64)])
         sig("lthip_synth_fill", i32, [vp, vp, u32, vp, vp, vp, i32])
         sig("lthip_divtest_eval", i32, [u32, u32])
 
@@ -396,6 +397,35 @@ def pack_blocks(lens: np.ndarray, max_block_size: int, max_chunks_per_block: int
     if err:
         raise LongtailHipError(err, "lthip_pack_blocks")
     return starts[: nb.value + 1].astype(np.int64)
+
+
+class BatchPacker:
+    """Resumable greedy packing (lthip_pack_blocks_batch): next() -> (starts[n+1], sizes[n]) of the next batch of blocks, or
+    None when every chunk is packed.  The work arrays are allocated once."""
+
+    def __init__(self, lens: np.ndarray, max_block_size: int, max_chunks_per_block: int, max_batch_bytes: int, arena_bytes: int,
+                 bound_div: int, bound_add: int, lib: Optional[HipLib] = None):
+        self.lib = lib or load()
+        self.lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        self.args = (max_block_size, max_chunks_per_block, max_batch_bytes, arena_bytes, bound_div, bound_add)
+        self.pos = 0
+        # a batch of B bytes holds at most B / (limit/2) + 2 blocks that were closed by size, or one per max_chunks chunks
+        self.cap = int(min(len(self.lens), max_batch_bytes // max(1, max_block_size // 2) + len(self.lens) // max_chunks_per_block + 8) + 2)
+        self.starts = np.empty(self.cap, dtype=np.uint64)
+        self.sizes = np.empty(self.cap, dtype=np.uint64)
+
+    def next(self):
+        if self.pos >= len(self.lens):
+            return None
+        nb, nxt = C.c_uint64(0), C.c_uint64(0)
+        mb, mc, bb, ab, bd, ba = self.args
+        err = self.lib.dll.lthip_pack_blocks_batch(len(self.lens), self.lens.ctypes.data, self.pos, mb, mc, bb, ab, bd, ba,
+                                                   self.starts.ctypes.data, self.sizes.ctypes.data, self.cap, C.byref(nb), C.byref(nxt))
+        if err:
+            raise LongtailHipError(err, "lthip_pack_blocks_batch")
+        self.pos = nxt.value
+        n = nb.value
+        return self.starts[: n + 1].astype(np.int64), self.sizes[:n].astype(np.int64)
 
 
 def chunker_params(target_chunk_size: int, chunker_min: int = 48):

@@ -103,3 +103,33 @@ def test_pack_blocks_matches_reference_store_index(hiplib, oracle, ref):
         assert len(lens) == res["chunks"]
         starts = pack_blocks(lens, max_block, max_chunks, hiplib)
         assert len(starts) - 1 == res["blocks"], (target, max_block, max_chunks)
+
+
+def test_pack_blocks_batch_resumes_to_the_same_blocks(hiplib):
+    """lthip_pack_blocks_batch: the batches concatenated are exactly lthip_pack_blocks' blocks, every batch respects the byte
+    and arena limits (or holds a single block), sizes are the sums of the chunk lengths."""
+    from longtail_amd.lib import BatchPacker, pack_blocks
+
+    rng = np.random.default_rng(5)
+    for n, max_block, max_chunks, batch, arena in [(20000, 1 << 20, 1024, 16 << 20, 17 << 20), (5000, 300000, 3, 1 << 20, 1 << 30),
+                                                   (3000, 65536, 1024, 1, 1), (1, 8 << 20, 1024, 8 << 30, 9 << 30), (0, 8 << 20, 1024, 1, 1),
+                                                   (40000, 8 << 20, 4, 4 << 20, 1 << 20)]:
+        lens = rng.integers(1, 200000, n).astype(np.uint32)
+        want = pack_blocks(lens, max_block, max_chunks, hiplib)
+        packer = BatchPacker(lens, max_block, max_chunks, batch, arena, 255, 16, hiplib)
+        got, sizes, nbatches = [], [], 0
+        while (nxt := packer.next()) is not None:
+            starts, bs = nxt
+            assert len(starts) == len(bs) + 1 and len(bs) >= 1
+            if got:
+                assert starts[0] == got[-1][-1]
+            bounds = (bs + bs // 255 + 16 + 63) // 64 * 64
+            assert len(bs) == 1 or (int(bs.sum()) <= batch and int(bounds.sum()) <= arena)
+            got.append(starts)
+            sizes.append(bs)
+            nbatches += 1
+        flat = np.concatenate([g[:-1] for g in got] + [[n]]) if got else np.array([0])
+        assert (flat == want).all(), (n, max_block, max_chunks)
+        if n:
+            cs = np.concatenate([[0], np.cumsum(lens, dtype=np.int64)])
+            assert (np.concatenate(sizes) == cs[want[1:]] - cs[want[:-1]]).all()
