@@ -105,12 +105,16 @@ __global__ void k_leaf_counts(const uint32_t* __restrict__ lens, uint64_t bound,
 // ---------------------------------------------------------------------------------------------------
 // leaves
 // ---------------------------------------------------------------------------------------------------
+constexpr int PW = 1024;     // parents kernel: window of leaf slots per workgroup
+constexpr int PW_MAXN = 256; // leaves of the largest range (small trees: <= 256 KiB)
+constexpr int PW_SLOTS = PW + PW_MAXN;
+
 __global__ __launch_bounds__(256) void k_blake3_leaves(const uint8_t* __restrict__ data,
                                                        const uint64_t* __restrict__ offsets,
                                                        const uint32_t* __restrict__ lens,
                                                        const uint32_t* __restrict__ leaf_prefix, // [count+1]
                                                        uint64_t count_bound, const uint32_t* __restrict__ n_dev,
-                                                       uint32_t* __restrict__ cvs)
+                                                       uint32_t* __restrict__ cvs, uint32_t* __restrict__ win_first)
 {
     const uint32_t count = (uint32_t)(n_dev ? (*n_dev < count_bound ? *n_dev : count_bound) : count_bound);
     const uint32_t total = leaf_prefix[count];
@@ -131,6 +135,8 @@ __global__ __launch_bounds__(256) void k_blake3_leaves(const uint8_t* __restrict
     const uint32_t c = lo;
     const uint32_t first = leaf_prefix[c];
     const uint32_t k = g - first; // leaf index inside the range == BLAKE3 chunk counter
+    if (win_first && (g & (uint32_t)(PW - 1)) == 0u)
+        win_first[g / (uint32_t)PW] = k == 0u ? c : c + 1u; // first range that starts at or after this window (parents kernel)
     const uint32_t rlen = lens[c];
     const uint32_t nleaf = leaves_of(rlen);
     const uint32_t llen = rlen - (k << 10) < 1024u ? rlen - (k << 10) : 1024u; // 0 only for the empty range
@@ -236,6 +242,113 @@ __global__ __launch_bounds__(256) void k_blake3_parents_small(const uint32_t* __
     hashes[c] = (uint64_t)base[0] | ((uint64_t)base[1] << 32);
 }
 
+// small trees, lane-dense: a workgroup owns the ranges whose first leaf slot lies in its window of PW slots, keeps their
+// chaining values in LDS and reduces ALL of them level by level -- the merges of one level (any range, any position) are
+// compacted into a list so that every lane of every wave has one, instead of one thread walking one tree serially with
+// its 2 x 32-byte loads uncoalesced (k_blake3_parents_small).  Left-heavy tree as above: the node of leaves [k, k + 2 st)
+// lives at slot k; a level's merges read slots (k, k + st) and write slot k, so they are independent.
+__global__ __launch_bounds__(256) void k_blake3_parents_window(const uint32_t* __restrict__ leaf_prefix, uint64_t count_bound,
+                                                               const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ cvs,
+                                                               const uint32_t* __restrict__ win_first, uint64_t* __restrict__ hashes)
+{
+    __shared__ uint4 s_cv[PW_SLOTS * 2];
+    __shared__ uint32_t s_info[PW_SLOTS]; // leaf index inside its range | leaves of the range << 16
+    __shared__ uint16_t s_list[PW_SLOTS / 2 + 64];
+    __shared__ uint32_t s_cnt, s_maxn;
+    const uint32_t count = (uint32_t)(n_dev ? (*n_dev < count_bound ? *n_dev : count_bound) : count_bound);
+    const uint32_t total = leaf_prefix[count];
+    const uint64_t w0 = (uint64_t)blockIdx.x * PW;
+    if (w0 >= total)
+        return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    // first range that starts at or after the window / the next window: noted by the leaf kernel's thread of that slot (a
+    // binary search here would be ~40 dependent loads before the workgroup can start)
+    const uint32_t c_lo = win_first[blockIdx.x];
+    const uint32_t c_hi = w0 + PW >= total ? count : win_first[blockIdx.x + 1u];
+    const uint32_t nch = c_hi - c_lo;
+    if (nch == 0)
+        return;
+    const uint32_t wbase = leaf_prefix[c_lo];
+    const uint32_t nslots = leaf_prefix[c_hi] - wbase;
+    if (tid == 0)
+    {
+        s_cnt = 0;
+        s_maxn = 0;
+    }
+    {
+        const uint4* g = reinterpret_cast<const uint4*>(cvs) + (uint64_t)wbase * 2u;
+        for (uint32_t v = tid; v < nslots * 2u; v += 256)
+            s_cv[v] = g[v];
+    }
+    __syncthreads();
+    if (nch * 8u < nslots)
+    {
+        // few large ranges: a wave per range
+        for (uint32_t j = tid >> 6; j < nch; j += 4)
+        {
+            const uint32_t p0 = leaf_prefix[c_lo + j], n = leaf_prefix[c_lo + j + 1] - p0;
+            for (uint32_t k = lane; k < n; k += 64)
+                s_info[p0 - wbase + k] = k | (n << 16);
+            if (lane == 0)
+                atomicMax(&s_maxn, n);
+        }
+    }
+    else
+    {
+        for (uint32_t j = tid; j < nch; j += 256)
+        {
+            const uint32_t p0 = leaf_prefix[c_lo + j], n = leaf_prefix[c_lo + j + 1] - p0;
+            for (uint32_t k = 0; k < n; ++k)
+                s_info[p0 - wbase + k] = k | (n << 16);
+            atomicMax(&s_maxn, n);
+        }
+    }
+    __syncthreads();
+    const uint32_t maxn = s_maxn;
+    uint32_t rot = blockIdx.x; // which wave takes the first 64 merges of a level: rotates, or the SIMD of wave 0 does all the thin levels
+    for (uint32_t st = 1; st < maxn; st <<= 1, ++rot)
+    {
+        for (uint32_t s0 = 0; s0 < nslots; s0 += 256)
+        {
+            const uint32_t sl = s0 + (uint32_t)tid;
+            const uint32_t info = sl < nslots ? s_info[sl] : 0u;
+            const uint32_t k = info & 0xFFFFu, n = info >> 16;
+            const bool is = (k & ((st << 1) - 1u)) == 0u && k + st < n;
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(is);
+            uint32_t base = 0;
+            if (lane == 0 && mask)
+                base = atomicAdd(&s_cnt, (uint32_t)__builtin_popcountll(mask));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (is)
+                s_list[base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint16_t)sl;
+        }
+        __syncthreads();
+        const uint32_t nm = s_cnt;
+        for (uint32_t mi = ((uint32_t)tid + 64u * rot) & 255u; mi < nm; mi += 256)
+        {
+            const uint32_t sl = s_list[mi];
+            const uint32_t n = s_info[sl] >> 16;
+            const uint4 a0 = s_cv[2u * sl], a1 = s_cv[2u * sl + 1u];
+            const uint4 b0 = s_cv[2u * (sl + st)], b1 = s_cv[2u * (sl + st) + 1u];
+            uint32_t m[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            uint32_t cv[8] = {B3_IV0, B3_IV1, B3_IV2, B3_IV3, B3_IV4, B3_IV5, B3_IV6, B3_IV7};
+            b3_compress(cv, m, 0u, 64u, (uint32_t)F_PARENT | ((st << 1) >= n ? (uint32_t)F_ROOT : 0u));
+            s_cv[2u * sl] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+            s_cv[2u * sl + 1u] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+        }
+        __syncthreads();
+        if (tid == 0)
+            s_cnt = 0;
+        __syncthreads();
+    }
+    for (uint32_t j = tid; j < nch; j += 256)
+    {
+        const uint4 r = s_cv[2u * (leaf_prefix[c_lo + j] - wbase)];
+        hashes[c_lo + j] = (uint64_t)r.x | ((uint64_t)r.y << 32);
+    }
+}
+
 // big trees: one launch per level, one thread per leaf slot
 __global__ __launch_bounds__(256) void k_blake3_parents_level(const uint32_t* __restrict__ leaf_prefix, uint32_t count,
                                                               uint32_t stride, uint32_t* __restrict__ cvs)
@@ -323,17 +436,25 @@ int lthip_launch_blake3(lthip_ctx* ctx, const uint8_t* d_data, const uint64_t* d
         return lthip_fail(ctx, EINVAL, "blake3", "too many leaves in one batch");
     if ((err = lthip_scratch(ctx, S_CV, leaf_bound * 32, &cv)))
         return err;
+    void* wf = nullptr;
+    if (small_trees && (err = lthip_scratch(ctx, S_B3_WINDOWS, (leaf_bound / PW + 2) * 4, &wf)))
+        return err;
     {
         LaunchTimer t(ctx, LTHIP_K_B3_LEAF);
         hipLaunchKernelGGL(k_blake3_leaves, dim3((uint32_t)div_up_u64(leaf_bound, 256)), dim3(256), 0, ctx->stream, d_data,
-                           d_offsets, d_lens, (const uint32_t*)lp, count_bound, d_count, (uint32_t*)cv);
+                           d_offsets, d_lens, (const uint32_t*)lp, count_bound, d_count, (uint32_t*)cv, (uint32_t*)wf);
         LTHIP_LAUNCH_CHECK(ctx);
     }
     if (small_trees)
     {
         LaunchTimer t(ctx, LTHIP_K_B3_PARENT);
-        hipLaunchKernelGGL(k_blake3_parents_small, dim3((uint32_t)div_up_u64(count_bound, 256)), dim3(256), 0, ctx->stream,
-                           d_lens, (const uint32_t*)lp, count_bound, d_count, (uint32_t*)cv, d_hashes);
+        static const bool serial = getenv("LTHIP_B3_SERIAL_PARENTS") != nullptr; // ablation: one thread per tree
+        if (serial)
+            hipLaunchKernelGGL(k_blake3_parents_small, dim3((uint32_t)div_up_u64(count_bound, 256)), dim3(256), 0, ctx->stream,
+                               d_lens, (const uint32_t*)lp, count_bound, d_count, (uint32_t*)cv, d_hashes);
+        else
+            hipLaunchKernelGGL(k_blake3_parents_window, dim3((uint32_t)div_up_u64(leaf_bound, PW)), dim3(256), 0, ctx->stream,
+                               (const uint32_t*)lp, count_bound, d_count, (const uint32_t*)cv, (const uint32_t*)wf, d_hashes);
         LTHIP_LAUNCH_CHECK(ctx);
     }
     else

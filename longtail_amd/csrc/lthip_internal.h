@@ -79,6 +79,7 @@ enum ScratchSlot
     S_Z_ENC,   // zstd: encoded 128 KiB pieces
     S_Z_WORK,  // zstd: per-encoder-wave work area
     S_LZ4_WORKLIST, // groups the stitch copy has to visit
+    S_B3_WINDOWS,   // first range of every window of leaf slots (parents kernel)
     S_COUNT
 };
 
