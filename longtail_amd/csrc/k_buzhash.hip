@@ -22,11 +22,13 @@ __constant__ uint32_t c_buztab[256] = {
 #include "buzhash_table.inc"
 };
 
-constexpr int K1_THREADS = 256;
+constexpr int K1_WAVES = 12;                 // one workgroup per CU: 3 waves per SIMD, <= 168 VGPRs each
+constexpr int K1_THREADS = 64 * K1_WAVES;
 constexpr int RUN = 64;                      // bytes per thread
-constexpr int TILE = K1_THREADS * RUN;       // 16 KiB
+constexpr int TILE = 256 * RUN;              // 16 KiB: the plan's tile (four wave-tiles)
 constexpr int ROW_DW = 17;                   // 16 data dwords + 1 pad: thread-strided ds_read_b32 hits 32 distinct banks
-constexpr int TAB_REP = 32;                  // T[v] replicated once per bank: lookups never conflict
+constexpr int TAB_REP = 64;                  // T[v] replicated once per lane, 256 bytes apart: a lookup address is
+                                             // {byte, lane * 4} = ONE v_perm_b32 of the data dword, and never conflicts
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, uint32_t r) { return __builtin_amdgcn_alignbit(x, x, (32u - r) & 31u); }
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, uint32_t r) { return __builtin_amdgcn_alignbit(x, x, r & 31u); }
@@ -116,7 +118,7 @@ __device__ __forceinline__ void tile_store(const TileRegs& r, uint32_t* __restri
 }
 
 template <int MODE> // 0 = general d (multiply test), 1 = power-of-two d (mask test)
-__global__ __launch_bounds__(K1_THREADS, 3) void k_buzhash_candidates(const uint8_t* __restrict__ data,
+__global__ __launch_bounds__(K1_THREADS, 1) void k_buzhash_candidates(const uint8_t* __restrict__ data,
                                                                        const PartDev* __restrict__ parts,
                                                                        const uint32_t* __restrict__ tile_part,
                                                                        uint32_t ntiles, DivTest dv,
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(K1_THREADS, 3) void k_buzhash_candidates(const uint
     uint32_t* rows = smem + 256 * TAB_REP + wave * (WROWS * ROW_DW); // this wave's [WROWS][ROW_DW]
 
     // replicated substitution table: tab[v*TAB_REP + r] = T[v]
+    if (tid < 256)
     {
         const uint32_t tv = c_buztab[tid];
         uint4 q = make_uint4(tv, tv, tv, tv);
@@ -141,13 +144,18 @@ __global__ __launch_bounds__(K1_THREADS, 3) void k_buzhash_candidates(const uint
             dst[j] = q;
     }
     __syncthreads(); // the only barrier: table visible to every wave
-    const uint32_t* tabl = tab + (tid & (TAB_REP - 1));
+    // The table is the first thing in LDS and the kernel has no static LDS, so its LDS address is 0 and a lookup address
+    // is the v_perm result itself (no base add); checked, not assumed.
+    typedef const __attribute__((address_space(3))) uint32_t lds_cu32;
+    if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)smem != 0u)
+        __builtin_trap();
+    const uint32_t lane4 = (uint32_t)lane * 4u;
     // x divisible by odd d' <=> x * d'^-1 mod 2^32 <= (2^32-1)/d'
     const uint32_t qodd = MODE == 1 ? 0u : 0xFFFFFFFFu / (dv.d >> dv.k2);
 
     const uint64_t nwt = (uint64_t)ntiles * 4u; // wave-tiles; wave-tile wt is quarter (wt & 3) of 16 KiB tile (wt >> 2)
-    const uint64_t wstride = (uint64_t)gridDim.x * 4u;
-    uint64_t wt = (uint64_t)blockIdx.x * 4u + (uint64_t)wave;
+    const uint64_t wstride = (uint64_t)gridDim.x * (uint64_t)K1_WAVES;
+    uint64_t wt = (uint64_t)blockIdx.x * (uint64_t)K1_WAVES + (uint64_t)wave;
     if (wt >= nwt)
         return;
     PartDev pd = parts[tile_part[wt >> 2]];
@@ -191,7 +199,9 @@ __global__ __launch_bounds__(K1_THREADS, 3) void k_buzhash_candidates(const uint
             // the hash at step k leaves it at step k+48 (hpcdcchunker.c:294-296; rotl(T[out], 48 & 31)).
             uint32_t tv[48 + RUN];
             uint32_t h = 0;
-#define LT_LOOKUP(j) tv[j] = tabl[((win[(j) >> 2] >> (8 * ((j) & 3))) & 0xffu) * TAB_REP]
+    // byte offset of T[b] for this lane = b * 256 + lane * 4 = bytes {lane4, b, 0, 0}
+#define LT_LOOKUP(j)                                                                                                 \
+    tv[j] = *(lds_cu32*)(__builtin_amdgcn_perm(win[(j) >> 2], lane4, 0x0c0c0400u | ((uint32_t)((j) & 3) << 8)))
 #define LT_STEP(k)                                                                                                   \
     {                                                                                                                \
         h = rotl32(h, 1) ^ rotl32(tv[k], 16) ^ tv[48 + (k)];                                                         \
@@ -563,12 +573,21 @@ int lthip_launch_buzhash(lthip_ctx* ctx, const lthip_plan* plan, const uint8_t* 
 {
     if (plan->ntiles == 0)
         return 0;
-    static_assert(sizeof(uint32_t) * (256 * TAB_REP + 4 * WROWS * ROW_DW) < 53 * 1024, "LDS budget: 3 workgroups per CU");
-    const size_t lds = sizeof(uint32_t) * (256 * TAB_REP + 4 * WROWS * ROW_DW);
-    // 4 workgroups / CU fit in LDS (33.5 KiB each); persistent grid amortises the table fill
-    uint32_t grid = 256 * 3;
-    if ((uint64_t)grid > plan->ntiles)
-        grid = (uint32_t)plan->ntiles;
+    static_assert(sizeof(uint32_t) * (256 * TAB_REP + K1_WAVES * WROWS * ROW_DW) <= 160 * 1024, "LDS budget: one workgroup per CU");
+    const size_t lds = sizeof(uint32_t) * (256 * TAB_REP + K1_WAVES * WROWS * ROW_DW);
+    static bool attr_done = false;
+    if (!attr_done)
+    {
+        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_buzhash_candidates<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_buzhash_candidates<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    // one persistent workgroup of 12 waves per CU (64 KiB table + 12 wave row buffers = 117 KiB of LDS)
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    uint32_t grid = (uint32_t)ncu;
+    if ((uint64_t)grid * K1_WAVES > plan->ntiles * 4u)
+        grid = (uint32_t)div_up_u64(plan->ntiles * 4u, K1_WAVES);
     LaunchTimer t(ctx, LTHIP_K_BUZHASH);
     if (plan->div.pow2)
         hipLaunchKernelGGL(k_buzhash_candidates<1>, dim3(grid), dim3(K1_THREADS), lds, ctx->stream, d_data, plan->d_parts,
