@@ -211,15 +211,17 @@ def main():
                 starts, b_size = nxt
                 b_first, b_last = starts[:-1], starts[1:] - 1
                 nblocks += len(b_first)
-                b_size_all.append(b_size)
                 bounds = b_size + b_size // 255 + 16 if lz else b_size + (b_size >> 8) + 64
                 aligned = (bounds + 63) // 64 * 64
                 d_offs = np.concatenate([[0], np.cumsum(aligned)[:-1]])
-                if bool(((offs_h[b_last] + lens_u32[b_last]) - offs_h[b_first] == b_size).all()):
+                is_range = (offs_h[b_last] + lens_u32[b_last]) - offs_h[b_first] == b_size  # block == one contiguous byte range
+                if bool(is_range.all()):
+                    b_size_all.append(b_size)
                     size_tensors.append(compress(data, offs_h[b_first], b_size, dst, d_offs, bounds))
                 else:
-                    # block assembly on the device (WriteContentBlockJob, src/longtail.c:4640-4721): gather this batch's
-                    # chunks back to back, then every block is a contiguous range of the gather arena
+                    # block assembly on the device (WriteContentBlockJob, src/longtail.c:4640-4721) for the blocks that
+                    # are not one range (they span assets): gather their chunks back to back, then each of them is a
+                    # contiguous range of the gather arena; the others are compressed where they lie
                     stats["gather"] = True
                     nonlocal gather_arena
                     if gather_arena is None:
@@ -229,11 +231,18 @@ def main():
                             d_offs_u, d_lens_u = out_offs[:total][unique_mask], out_lens[:total][unique_mask]
                         else:
                             d_offs_u, d_lens_u = out_offs[:total], out_lens[:total]
-                    c0, c1 = int(starts[0]), int(starts[-1])
-                    lens_d = d_lens_u[c0:c1]
+                    r, g = np.flatnonzero(is_range), np.flatnonzero(~is_range)
+                    cnt = (starts[g + 1] - starts[g]).astype(np.int64)
+                    first_of = np.repeat(starts[g] - (np.cumsum(cnt) - cnt), cnt)
+                    chunk_idx = torch.from_numpy(first_of + np.arange(int(cnt.sum()), dtype=np.int64)).to(dev)
+                    lens_d = d_lens_u[chunk_idx]
                     dst_off = torch.cumsum(lens_d.to(torch.int64), 0) - lens_d.to(torch.int64)
-                    ctx.gather_ranges(data, d_offs_u[c0:c1].contiguous(), lens_d.contiguous(), gather_arena, dst_off)
-                    size_tensors.append(compress(gather_arena, np.cumsum(b_size) - b_size, b_size, dst, d_offs, bounds))
+                    ctx.gather_ranges(data, d_offs_u[chunk_idx].contiguous(), lens_d.contiguous(), gather_arena, dst_off)
+                    if len(r):
+                        b_size_all.append(b_size[r])
+                        size_tensors.append(compress(data, offs_h[b_first[r]], b_size[r], dst, d_offs[r], bounds[r]))
+                    b_size_all.append(b_size[g])
+                    size_tensors.append(compress(gather_arena, np.cumsum(b_size[g]) - b_size[g], b_size[g], dst, d_offs[g], bounds[g]))
             b_size = np.concatenate(b_size_all) if b_size_all else np.zeros(0, np.int64)
             sizes = (torch.cat(size_tensors).cpu().numpy().view(np.uint32).astype(np.int64) if size_tensors else np.zeros(0, np.int64))  # one D2H, waits for the codec
             comp_bytes = int(sizes.sum())

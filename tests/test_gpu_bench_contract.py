@@ -1,0 +1,43 @@
+"""-m gpu: bench.py end to end on a small tree: the JSON contract line, and that the result does not depend on how the
+blocks were batched or assembled (blocks that span assets go through the device gather, the others are compressed where
+they lie; src/longtail.c:4640-4721)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def run_bench(*args):
+    env = dict(os.environ, PYTHONPATH=str(ROOT))
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", *args],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("codec", ["lz4", "zstd"])
+def test_bench_line_and_batching_independence(codec):
+    base = ["--gib", "0.5", "--tree", "mixed-sizes", "--kind", "mixed", "--codec", codec]
+    a = run_bench(*base)
+    b = run_bench(*base, "--batch-gib", "0.05")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in a, key
+    assert a["n_gpus"] == 1 and a["higher_is_better"] is True and a["scaling"] == "weak" and a["value"] > 0
+    assert a["config"]["device_block_assembly"] is True  # files are not multiples of 16 bytes: some blocks span assets
+    for key in ("chunks", "unique_chunks_global", "blocks", "compressed_bytes"):
+        assert a["result"][key] == b["result"][key], key
+    assert a["result"]["ratio"] > 1.3
+
+
+def test_bench_equal_files_need_no_gather():
+    j = run_bench("--gib", "0.25", "--kind", "random")
+    assert j["config"]["device_block_assembly"] is False and 0.99 < j["result"]["ratio"] <= 1.0
