@@ -208,7 +208,8 @@ LTHIP_EXPORT int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src,
                                               uint32_t* d_out_sizes);
 /* Diagnostics (parity tests): match-finder output of the last lthip_zstd_compress_blocks call on this context for the
  * 4 KiB units [first, first + count) -- 16 bytes of meta {nseq, nlit, tail, 0}, 4096 literal bytes and 1024 u64
- * records {lit | mlen << 16 | offset << 32} per unit (host buffers, any may be NULL). */
+ * records {lit | mlen << 16 | offset << 32} per unit (host buffers, any may be NULL).  A unit with nseq == 0 has no
+ * literal buffer (its 4096 bytes here are unspecified): its literals are its source bytes. */
 LTHIP_EXPORT int lthip_zstd_debug_units(lthip_ctx* ctx, uint64_t first, uint64_t count, void* h_meta, void* h_lits,
                                         void* h_recs);
 

@@ -249,6 +249,7 @@ __device__ __forceinline__ void lz4_coop_sequence(const uint8_t* __restrict__ sb
 // kept), otherwise (incompressible data) nobody pays for it.  16 waves per CU instead of 4 at the same window.
 constexpr int LZ4_G = 8;
 constexpr int LZ4_PROBE_BATCHES = 4;
+constexpr uint32_t Z_PIECE = 128u << 10; // zstd Block_Maximum_Size (ZB_BLOCK_MAX of zstd_block_core.h, asserted in k_zstd.hip)
 // table entries per wave: with 1536 the LZ4 flavour needs 57 KiB of LDS per workgroup... see the host launcher
 constexpr int LZ4_TAB_LZ4 = 1024 + 256;  // 32 KiB window + 8 x 2.5 KiB tables = 52 KiB: THREE workgroups (24 waves) per CU
 constexpr int LZ4_TAB_ZSTD = 1024 + 256;
@@ -652,8 +653,23 @@ __global__ __launch_bounds__(64 * LZ4_G, 6) void k_lz4_segments(const uint8_t* _
     {
         // the unit's trailing literals complete its literal buffer; meta = ZbUnitMeta {nseq, nlit, tail, 0}
         const uint32_t tail = have_unit ? my_start + my_len - st.anchor : 0u;
-        for (uint32_t j = lane; j < tail; j += 64)
-            out[st.op + j] = sbytes[st.anchor + j + head];
+        if (st.nseq != 0u)
+        {
+            for (uint32_t j = lane; j < tail; j += 64)
+                out[st.op + j] = sbytes[st.anchor + j + head];
+        }
+        else if (have_unit && spec_dst)
+        {
+            // A unit without a sequence has no literal buffer (the entropy stage reads its bytes from the source,
+            // ZbInput.src).  If its whole 128 KiB piece is like that the piece will most likely be a Raw_Block, and if the
+            // pieces before it are raw too its bytes belong at  frame header + pieces * (3 + 128 KiB) + 3 + offset: put
+            // them there now, from LDS; k_zstd_emit then only writes the 3-byte block header (and copies as usual when
+            // the guess was wrong).
+            const uint32_t pos = group_start + my_start;
+            const uint64_t o = 13u + (uint64_t)(pos / Z_PIECE) * (Z_PIECE + 3u) + 3u + pos % Z_PIECE;
+            if (o + my_len <= (uint64_t)blk.dst_cap)
+                wave_copy_lds_to_global(spec_dst + blk.dst_off + o, sdata, my_start + head, my_len, lane);
+        }
         // is the unit one repeated byte?  (zstd stores a 128 KiB piece made of such units as an RLE_Block)
         uint32_t uniform = 0;
         if (have_unit)
@@ -661,6 +677,10 @@ __global__ __launch_bounds__(64 * LZ4_G, 6) void k_lz4_segments(const uint8_t* _
             const uint32_t b0 = sbytes[my_start + head];
             const uint32_t rep = b0 * 0x01010101u;
             uint32_t diff = 0;
+            // almost always settled by the first dword of every lane's 64 bytes
+            if (64u * (uint32_t)lane + 4u <= my_len)
+                diff = lds_read32(sdata, my_start + 64u * (uint32_t)lane + head) ^ rep;
+            if (__builtin_amdgcn_ballot_w64(diff != 0u) == 0ull)
 #pragma unroll 4
             for (uint32_t j = 0; j < 16u; ++j)
             {
@@ -1222,15 +1242,13 @@ extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint
 }
 
 int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
-                              const uint32_t* src_sizes, uint8_t** d_lits, uint64_t** d_recs, void** d_meta,
-                              uint32_t* unit_base, uint64_t* total_units)
+                              const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets, const uint32_t* dst_caps,
+                              uint8_t** d_lits, uint64_t** d_recs, void** d_meta, uint32_t* unit_base, uint64_t* total_units)
 {
     const uint32_t SEG = 4096u; // ZB_UNIT
-    std::vector<uint64_t> zero64(block_count, 0);
-    std::vector<uint32_t> zero32(block_count, 0);
     Lz4Block* d_blocks = nullptr;
     uint64_t nseg64 = 0, ngrp64 = 0;
-    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, zero64.data(), zero32.data(), SEG, &d_blocks, &nseg64, &ngrp64);
+    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, SEG, &d_blocks, &nseg64, &ngrp64);
     if (err)
         return err;
     uint64_t nseg = 0;
@@ -1252,7 +1270,7 @@ int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_
         LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
         const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * LZ4_TAB_ZSTD * 2;
         hipLaunchKernelGGL((k_lz4_segments<LZ4_TAB_ZSTD, 1>), dim3((uint32_t)ngrp64), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src,
-                           d_blocks, block_count, 0u, SEG, (uint8_t*)lits, (Lz4Meta*)meta, (uint64_t*)recs, (uint8_t*)nullptr,
+                           d_blocks, block_count, 0u, SEG, (uint8_t*)lits, (Lz4Meta*)meta, (uint64_t*)recs, (uint8_t*)d_dst,
                            (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0));
         LTHIP_LAUNCH_CHECK(ctx);
     }

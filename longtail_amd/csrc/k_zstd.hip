@@ -61,6 +61,7 @@ struct ZBlock
 };
 
 constexpr uint32_t ZB = ZB_BLOCK_MAX;
+static_assert(ZB_BLOCK_MAX == (128u << 10) && ZB_UNIT == 4096u, "k_lz4.hip's Z_PIECE and unit size");
 constexpr size_t Z_WORK_SEQS = sizeof(uint64_t) * ZB_SEQ_MAX, Z_WORK_SBITS = sizeof(uint16_t) * 3 * ZB_SEQ_MAX;
 constexpr size_t Z_WORK_STRIDE = Z_WORK_SEQS + Z_WORK_SBITS;
 constexpr uint32_t ZHDR = 13u;
@@ -85,7 +86,7 @@ __global__ void k_zstd_scan(const ZBlock* __restrict__ blocks, uint32_t nblocks,
         const uint32_t len = blk.size - i * ZB < ZB ? blk.size - i * ZB : ZB;
         zb_dst[blk.zb_base + i] = (uint32_t)pos;
         const uint32_t enc = enc_size[blk.zb_base + i];
-        pos += 3u + (is_rle[blk.zb_base + i] ? 1u : enc ? enc : len);
+        pos += 3u + ((is_rle[blk.zb_base + i] & 1u) ? 1u : enc ? enc : len);
     }
     out_sizes[b] = pos <= (uint64_t)blk.dst_cap ? (uint32_t)pos : 0u;
 }
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(ZT) void k_zstd_emit(const uint8_t* __restrict__ sr
     const uint32_t len = b.size - start < ZB ? b.size - start : ZB;
     const uint8_t* p = src + b.src_off + start;
     uint8_t* d = dst + b.dst_off + zb_dst[zb];
-    const uint32_t rle = is_rle[zb];
+    const uint32_t flags = is_rle[zb]; // 1 = RLE_Block, 2 = every unit without a sequence (bytes placed by the match finder)
+    const uint32_t rle = flags & 1u;
     const uint32_t csize = rle ? 0u : enc_size[zb];
     if (threadIdx.x == 0)
     {
@@ -158,13 +160,14 @@ __global__ __launch_bounds__(ZT) void k_zstd_emit(const uint8_t* __restrict__ sr
     }
     if (csize)
         wg_copy16(d + 3, enc + (uint64_t)zb * ZB_OUT_BYTES, csize, threadIdx.x);
-    else if (!rle)
-        wg_copy16(d + 3, p, len, threadIdx.x);
+    else if (!rle && !((flags & 2u) && zb_dst[zb] == ZHDR + i * (ZB + 3u)))
+        wg_copy16(d + 3, p, len, threadIdx.x); // (otherwise the Raw_Block's bytes are already in place, k_lz4.hip)
 }
 
 // One wavefront per 128 KiB piece, persistent over the pieces: the entropy stage of zstd_block_core.h.
 __global__ __launch_bounds__(64, 4) void k_zstd_encode(const ZBlock* __restrict__ blocks, uint32_t nblocks, uint32_t npieces,
-                                                    uint8_t* __restrict__ is_rle, const ZbUnitMeta* __restrict__ unit_meta,
+                                                    const uint8_t* __restrict__ src, uint8_t* __restrict__ is_rle,
+                                                    const ZbUnitMeta* __restrict__ unit_meta,
                                                     const uint8_t* __restrict__ unit_lits, const uint64_t* __restrict__ unit_recs,
                                                     uint8_t* __restrict__ work, uint8_t* __restrict__ enc,
                                                     uint32_t* __restrict__ enc_size)
@@ -195,14 +198,16 @@ __global__ __launch_bounds__(64, 4) void k_zstd_encode(const ZBlock* __restrict_
         in.unit_recs = unit_recs + u0 * ZB_UNIT_SEQ_MAX;
         in.nunits = (len + ZB_UNIT - 1u) / ZB_UNIT;
         in.raw_size = len;
+        in.src = src + b.src_off + (uint64_t)i * ZB;
         {
             // RLE_Block: every unit of the piece is one repeated byte (flagged by the match finder) and it is the same one
             const uint32_t f = threadIdx.x < in.nunits ? in.meta[threadIdx.x].uniform : in.meta[0].uniform;
             const uint32_t f0 = __builtin_amdgcn_readfirstlane(f);
             const bool rle = f0 != 0u && __builtin_amdgcn_ballot_w64(f != f0) == 0ull;
+            const bool matchless = __builtin_amdgcn_ballot_w64(threadIdx.x < in.nunits && in.meta[threadIdx.x].nseq != 0u) == 0ull;
             if (threadIdx.x == 0)
             {
-                is_rle[zb] = rle ? 1 : 0;
+                is_rle[zb] = (rle ? 1 : 0) | (matchless ? 2 : 0);
                 if (rle)
                     enc_size[zb] = 0;
             }
@@ -287,8 +292,8 @@ extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uin
     void* d_meta = nullptr;
     uint64_t nunits = 0;
     int err;
-    if ((err = lthip_launch_lz_sequences(ctx, d_src, block_count, src_offsets, src_sizes, &d_lits, &d_recs, &d_meta, unit_base.data(),
-                                         &nunits)))
+    if ((err = lthip_launch_lz_sequences(ctx, d_src, block_count, src_offsets, src_sizes, d_dst, dst_offsets, dst_caps, &d_lits, &d_recs,
+                                         &d_meta, unit_base.data(), &nunits)))
         return err;
     for (uint32_t b = 0; b < block_count; ++b)
         hb[b].unit_base = unit_base[b];
@@ -314,7 +319,7 @@ extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uin
     {
         LaunchTimer t(ctx, LTHIP_K_ZSTD_ENC);
         hipLaunchKernelGGL(k_zstd_encode, dim3(nwg), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks, block_count, (uint32_t)nzb,
-                           (uint8_t*)d_rle, (const ZbUnitMeta*)d_meta, (const uint8_t*)d_lits, (const uint64_t*)d_recs,
+                           (const uint8_t*)d_src, (uint8_t*)d_rle, (const ZbUnitMeta*)d_meta, (const uint8_t*)d_lits, (const uint64_t*)d_recs,
                            (uint8_t*)d_work, (uint8_t*)d_enc, (uint32_t*)d_encsz);
         LTHIP_LAUNCH_CHECK(ctx);
     }

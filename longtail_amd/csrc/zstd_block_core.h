@@ -31,7 +31,7 @@
 #include <stdint.h>
 
 #ifndef ZB_DBG
-#define ZB_DBG 0u /* host model only: 1 raw literals, 2 never predefined, 4 never FSE-compressed tables */
+#define ZB_DBG 0u /* host model only: 1 raw literals, 2 never predefined, 4 never FSE-compressed tables, 8 no sampled noise test */
 #endif
 #ifndef ZB_MARK
 #define ZB_MARK(i) ((void)0) /* profiling hook of the kernel build (phase boundaries) */
@@ -70,6 +70,9 @@ typedef struct ZbInput
     const uint64_t* unit_recs; /* unit u at + u * ZB_UNIT_SEQ_MAX */
     uint32_t nunits;
     uint32_t raw_size;
+    const uint8_t* src; /* the block's raw bytes (any alignment) or NULL.  When given, a unit WITHOUT a sequence has no
+                         * literal buffer: its literals are its own bytes, src + u * ZB_UNIT (the match finder does not
+                         * copy what nobody may ever need) */
 } ZbInput;
 
 typedef struct ZbScratch /* global memory owned by the lanes of one block encoder */
@@ -95,6 +98,7 @@ enum
     ZV_SEQ_BITS0, /* byte offset of the sequence bit-stream */
     ZV_SEQ_TOTALBITS,
     ZV_OUT_SIZE,
+    ZV_SRCMASK,      /* bit u: the literals of unit u are read from in->src */
     ZV_STREAM_BYTES, /* +0..3 */
     ZV_STREAM_BASE = ZV_STREAM_BYTES + 4, /* +0..3, byte offsets */
     ZV_FINAL_STATE = ZV_STREAM_BASE + 4,  /* +0..2 */
@@ -742,15 +746,37 @@ ZB_FN uint32_t zb_write_huf_tree(ZbShared* sh, uint8_t* dst)
  * cached 32-bit word. */
 typedef struct ZbLitReader
 {
-    const uint8_t* unit_lits;
+    const ZbInput* in;
     const uint32_t* ulit_base; /* [nunits + 1] */
-    uint32_t nunits, u, lo, hi, cw, cwi;
+    uint32_t srcmask, nunits, u, lo, hi, cw, cwi;
 } ZbLitReader;
 
-ZB_FN void zb_lit_open(ZbLitReader* r, const uint8_t* unit_lits, const uint32_t* ulit_base, uint32_t nunits, uint32_t k)
+/* 32-bit word wi of unit u's literals (nbytes of them; bytes at or past nbytes are unspecified).  Source-resident units
+ * are read with aligned loads and a funnel shift, never touching a word that holds none of their bytes. */
+ZB_FN uint32_t zb_unit_word(const ZbInput* in, uint32_t srcmask, uint32_t u, uint32_t wi, uint32_t nbytes)
+{
+    if ((srcmask >> u) & 1u)
+    {
+        const uint8_t* p = in->src + (size_t)u * ZB_UNIT + 4u * (size_t)wi;
+        const uint32_t mis = (uint32_t)((uintptr_t)p & 3u);
+        const uint32_t* q = (const uint32_t*)(p - mis);
+        uint32_t w = q[0];
+        if (mis)
+        {
+            w >>= 8u * mis;
+            if (4u * wi + 4u - mis < nbytes)
+                w |= q[1] << (32u - 8u * mis);
+        }
+        return w;
+    }
+    return ((const uint32_t*)(in->unit_lits + (size_t)u * ZB_UNIT))[wi];
+}
+
+ZB_FN void zb_lit_open(ZbLitReader* r, const ZbInput* in, uint32_t srcmask, const uint32_t* ulit_base, uint32_t nunits, uint32_t k)
 {
     uint32_t lo = 0, hi = nunits;
-    r->unit_lits = unit_lits;
+    r->in = in;
+    r->srcmask = srcmask;
     r->ulit_base = ulit_base;
     r->nunits = nunits;
     while (hi - lo > 1u)
@@ -783,14 +809,14 @@ ZB_FN uint32_t zb_lit_get(ZbLitReader* r, uint32_t k) /* k < total literals */
         r->lo = r->ulit_base[r->u];
     }
     {
-        const uint32_t addr = r->u * ZB_UNIT + (k - r->lo);
-        const uint32_t wi = addr >> 2;
+        const uint32_t o = k - r->lo;
+        const uint32_t wi = (r->u << 10) | (o >> 2); /* units hold at most 4096 literals = 1024 words */
         if (wi != r->cwi)
         {
-            r->cw = ((const uint32_t*)r->unit_lits)[wi];
+            r->cw = zb_unit_word(r->in, r->srcmask, r->u, o >> 2, r->hi - r->lo);
             r->cwi = wi;
         }
-        return (r->cw >> (8u * (addr & 3u))) & 255u;
+        return (r->cw >> (8u * (o & 3u))) & 255u;
     }
 }
 
@@ -813,10 +839,12 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     ZB_SYNC();
     ZB_SERIAL(zl)
     {
-        uint32_t nseq = 0, nlit = 0, carry = 0;
+        uint32_t nseq = 0, nlit = 0, carry = 0, srcmask = 0;
         for (uint32_t u = 0; u < in->nunits; ++u)
         {
             const uint32_t un = sh->useq_base[u], ul = sh->ulit_base[u], ut = sh->carry[u];
+            if (in->src && un == 0u)
+                srcmask |= 1u << u;
             sh->useq_base[u] = nseq;
             sh->ulit_base[u] = nlit;
             sh->carry[u] = carry;
@@ -828,11 +856,12 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
         sh->ulit_base[in->nunits] = nlit;
         sh->v[ZV_NBSEQ] = nseq;
         sh->v[ZV_NLIT] = nlit;
+        sh->v[ZV_SRCMASK] = srcmask;
     }
     ZB_PAR_FOR(i, 256u) sh->lit_hist[i] = 0;
     ZB_PAR_FOR(i, 3u * 64u) sh->sym_hist[i >> 6][i & 63u] = 0;
     ZB_SYNC();
-    const uint32_t nbseq = sh->v[ZV_NBSEQ], nlit = sh->v[ZV_NLIT];
+    const uint32_t nbseq = sh->v[ZV_NBSEQ], nlit = sh->v[ZV_NLIT], srcmask = sh->v[ZV_SRCMASK];
 
     ZB_MARK(1);
     /* ---- phase 1: merge the units: sequences (with their symbol histograms) and literals (with theirs) ---- */
@@ -858,15 +887,50 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
             zb_atomic_add(&sh->sym_hist[ZT_OF][zb_of_code(off)], 1u);
         }
     }
+    /* Plainly noise?  When the matches alone cannot pay for a compressed block (the second half of the test in phase 2),
+     * the only open question is whether the literals deserve a Huffman table.  Every eighth unit's literals (4 KiB runs,
+     * read exactly like the full pass below) answer that for blocks of noise, which stop here without the full
+     * histogram; everything else goes on to the exact test. */
+    if (nlit >= 32768u && in->raw_size - nlit < 3u * nbseq + 32u && !(ZB_DBG & 8u))
+    {
+        for (uint32_t u = (nlit >> 12) & 7u; u < in->nunits; u += 8u)
+        {
+            const uint32_t n = sh->ulit_base[u + 1u] - sh->ulit_base[u];
+            ZB_PAR_FOR(j, n >> 2)
+            {
+                const uint32_t w = zb_unit_word(in, srcmask, u, j, n);
+                zb_atomic_add(&sh->lit_hist[w & 255u], 1u);
+                zb_atomic_add(&sh->lit_hist[(w >> 8) & 255u], 1u);
+                zb_atomic_add(&sh->lit_hist[(w >> 16) & 255u], 1u);
+                zb_atomic_add(&sh->lit_hist[w >> 24], 1u);
+            }
+        }
+        ZB_SYNC();
+        ZB_SERIAL(zl)
+        {
+            uint32_t largest = 0, ns = 0;
+            for (uint32_t s2 = 0; s2 < 256u; ++s2)
+            {
+                ns += sh->lit_hist[s2];
+                if (sh->lit_hist[s2] > largest)
+                    largest = sh->lit_hist[s2];
+            }
+            sh->v[ZV_SKIP] = (ns >= 2048u && largest <= (ns >> 7) + 4u) ? 1u : 0u;
+        }
+        ZB_SYNC();
+        if (sh->v[ZV_SKIP])
+            return 0;
+        ZB_PAR_FOR(i, 256u) sh->lit_hist[i] = 0;
+        ZB_SYNC();
+    }
     for (uint32_t u = 0; u < in->nunits; ++u)
     {
         /* histogram only (the unit buffers are 4 KiB aligned; bytes past nlit are masked off): most incompressible
          * blocks stop right after it */
-        const uint32_t* src = (const uint32_t*)(in->unit_lits + (uint64_t)u * ZB_UNIT);
         const uint32_t n = sh->ulit_base[u + 1u] - sh->ulit_base[u];
         ZB_PAR_FOR(j, (n + 3u) >> 2)
         {
-            const uint32_t w = src[j];
+            const uint32_t w = zb_unit_word(in, srcmask, u, j, n);
             const uint32_t k = n - 4u * j; /* valid bytes in this word, >= 1 */
             zb_atomic_add(&sh->lit_hist[w & 255u], 1u);
             if (k > 1u)
@@ -972,7 +1036,7 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
             if (s0 + zl < s1)
             {
                 ZbLitReader lr;
-                zb_lit_open(&lr, in->unit_lits, sh->ulit_base, in->nunits, s0 + zl);
+                zb_lit_open(&lr, in, srcmask, sh->ulit_base, in->nunits, s0 + zl);
                 for (uint32_t k = s0 + zl; k < s1; k += ZB_LANES)
                     bits += sh->huf_len[zb_lit_get(&lr, k)];
             }
@@ -1091,7 +1155,7 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
             const uint32_t s1 = st == 3u ? nlit : (s0 + seg < nlit ? s0 + seg : nlit);
             uint32_t running = sh->v[ZV_STREAM_BASE + st] * 8u;
             ZbLitReader lr;
-            zb_lit_open(&lr, in->unit_lits, sh->ulit_base, in->nunits, s1 ? s1 - 1u : 0u);
+            zb_lit_open(&lr, in, srcmask, sh->ulit_base, in->nunits, s1 ? s1 - 1u : 0u);
             for (uint32_t done = 0; done < s1 - s0; done += 4u * ZB_LANES)
             {
                 /* my literals: indices s1-1 - (done + 4*zl + j), j = 0..3, as far as they exist */
@@ -1134,7 +1198,7 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
         uint8_t* dst = out8 + sh->v[ZV_STREAM_BASE];
         for (uint32_t u = 0; u < in->nunits; ++u)
         {
-            const uint8_t* src = in->unit_lits + (uint64_t)u * ZB_UNIT;
+            const uint8_t* src = ((srcmask >> u) & 1u) ? in->src + (size_t)u * ZB_UNIT : in->unit_lits + (uint64_t)u * ZB_UNIT;
             uint8_t* d2 = dst + sh->ulit_base[u];
             ZB_PAR_FOR(j, sh->ulit_base[u + 1u] - sh->ulit_base[u]) d2[j] = src[j];
         }

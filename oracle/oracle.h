@@ -90,6 +90,8 @@ int lto_ingest(const uint8_t* data, uint64_t size, uint64_t part_size, uint32_t 
 size_t ltz_model_bound(size_t n);
 int ltz_model_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n);
 int ltz_model_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n);
+uint32_t ltz_model_encode_block_src(const void* unit_meta, const uint8_t* unit_lits, const uint64_t* unit_recs, uint32_t nunits,
+                                    uint32_t raw_size, const uint8_t* src, uint8_t* out); /* units without a sequence: literals = src */
 uint32_t ltz_model_encode_block(const void* unit_meta, const uint8_t* unit_lits, const uint64_t* unit_recs, uint32_t nunits,
                                 uint32_t raw_size, uint8_t* out);
 

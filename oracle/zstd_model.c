@@ -31,8 +31,9 @@ void ltz_model_debug(uint32_t flags) { g_ltz_dbg = flags; }
 
 #include "oracle.h"
 
-uint32_t ltz_model_encode_block(const void* meta, const uint8_t* unit_lits, const uint64_t* unit_recs, uint32_t nunits,
-                                uint32_t raw_size, uint8_t* out)
+/* src != NULL: units without a sequence have no literal buffer, their literals are src + u * 4096 (ZbInput.src) */
+uint32_t ltz_model_encode_block_src(const void* meta, const uint8_t* unit_lits, const uint64_t* unit_recs, uint32_t nunits,
+                                    uint32_t raw_size, const uint8_t* src, uint8_t* out)
 {
     ZbInput in;
     ZbScratch sc;
@@ -43,6 +44,7 @@ uint32_t ltz_model_encode_block(const void* meta, const uint8_t* unit_lits, cons
     in.unit_recs = unit_recs;
     in.nunits = nunits;
     in.raw_size = raw_size;
+    in.src = src;
     sc.seqs = (uint64_t*)malloc(sizeof(uint64_t) * ZB_SEQ_MAX);
     sc.sbits = (uint16_t*)malloc(sizeof(uint16_t) * 3 * ZB_SEQ_MAX);
     sc.out = (uint32_t*)malloc(ZB_OUT_BYTES);
@@ -54,6 +56,12 @@ uint32_t ltz_model_encode_block(const void* meta, const uint8_t* unit_lits, cons
     free(sc.out);
     free(sh);
     return n;
+}
+
+uint32_t ltz_model_encode_block(const void* meta, const uint8_t* unit_lits, const uint64_t* unit_recs, uint32_t nunits,
+                                uint32_t raw_size, uint8_t* out)
+{
+    return ltz_model_encode_block_src(meta, unit_lits, unit_recs, nunits, raw_size, NULL, out);
 }
 
 /* greedy matcher over one block: 4 KiB units, matches never cross a unit end, offsets < 65536 within the frame */
@@ -91,7 +99,10 @@ static void model_match_block(const uint8_t* base, size_t block_off, uint32_t si
             else
                 ++p;
         }
-        memcpy(lits + nlit, blk + anchor, end - anchor);
+        if (nseq)
+            memcpy(lits + nlit, blk + anchor, end - anchor);
+        else
+            memset(lits, 0xA5, ZB_UNIT); /* like the GPU match finder: no copy for a unit without a match (ZbInput.src) */
         nlit += end - anchor;
         meta[u].nseq = nseq;
         meta[u].nlit = nlit;
@@ -148,7 +159,7 @@ int ltz_model_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, s
             continue;
         }
         model_match_block(src, off, size, table, meta, unit_lits, unit_recs);
-        csize = ltz_model_encode_block(meta, unit_lits, unit_recs, (size + ZB_UNIT - 1u) / ZB_UNIT, size, enc);
+        csize = ltz_model_encode_block_src(meta, unit_lits, unit_recs, (size + ZB_UNIT - 1u) / ZB_UNIT, size, src + off, enc);
         {
             const uint32_t h = last | ((csize ? 2u : 0u) << 1) | ((csize ? csize : size) << 3);
             dst[pos++] = (uint8_t)h;

@@ -169,21 +169,21 @@ def test_zstd_compresses(gpu, oracle):
         assert len(f) < len(l)
 
 
-def test_zstd_entropy_stage_is_bit_exact_with_host_model(gpu, oracle):
-    """k_zstd_encode and oracle/zstd_model.c compile the SAME zstd_block_core.h (64 lanes vs 1): fed with the GPU match
-    finder's own output, the host model must reproduce every Compressed_Block byte for byte."""
+def _model_src(oracle):
     import ctypes as C
 
     d = oracle.dll
-    d.ltz_model_encode_block.restype = C.c_uint32
-    d.ltz_model_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
-    rng = np.random.default_rng(5)
-    blocks = [oracle.synth(n, 90 + n, k) for k, n in ((1, 1 << 20), (11, 300000), (12, 131072), (13, 200000), (0, 140000))]
-    blocks.append((np.abs(rng.normal(128, 20, 400000)).astype(np.int64) % 256).astype(np.uint8))
-    frames = gpu_zstd(gpu, blocks)
+    d.ltz_model_encode_block_src.restype = C.c_uint32
+    d.ltz_model_encode_block_src.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    return d
+
+
+def _check_against_model(gpu, d, blocks, frames):
+    """every Compressed_Block of `frames` == the host model run on the GPU match finder's units; Raw where the model says so"""
     unit0 = 0
     checked = 0
     for b, f in zip(blocks, frames):
+        b = np.ascontiguousarray(b)
         nunits = (len(b) + 4095) // 4096
         meta, lits, recs = gpu.zstd_debug_units(unit0, nunits)
         for i, (typ, payload) in enumerate(zstd_pieces(f)):
@@ -191,14 +191,61 @@ def test_zstd_entropy_stage_is_bit_exact_with_host_model(gpu, oracle):
             nu = (raw + 4095) // 4096
             out = np.zeros(140000, np.uint8)
             m, l, r = (np.ascontiguousarray(a[i * 32 : i * 32 + nu]) for a in (meta, lits, recs))
-            n = d.ltz_model_encode_block(m.ctypes.data, l.ctypes.data, r.ctypes.data, nu, raw, out.ctypes.data)
+            l[m[:, 0] == 0] = 0x5A  # units without a sequence have no literal buffer: their literals are the source bytes
+            piece = b[i * 131072 : i * 131072 + raw]
+            n = d.ltz_model_encode_block_src(m.ctypes.data, l.ctypes.data, r.ctypes.data, nu, raw, piece.ctypes.data, out.ctypes.data)
             if typ == 2:
                 assert n == len(payload) and (out[:n] == payload).all()
                 checked += 1
             elif typ == 0:
                 assert n == 0
         unit0 += nunits
-    assert checked >= 10
+    return checked
+
+
+def test_zstd_entropy_stage_is_bit_exact_with_host_model(gpu, oracle):
+    """k_zstd_encode and oracle/zstd_model.c compile the SAME zstd_block_core.h (64 lanes vs 1): fed with the GPU match
+    finder's own output, the host model must reproduce every Compressed_Block byte for byte."""
+    d = _model_src(oracle)
+    rng = np.random.default_rng(5)
+    blocks = [oracle.synth(n, 90 + n, k) for k, n in ((1, 1 << 20), (11, 300000), (12, 131072), (13, 200000), (0, 140000))]
+    blocks.append((np.abs(rng.normal(128, 20, 400000)).astype(np.int64) % 256).astype(np.uint8))
+    frames = gpu_zstd(gpu, blocks)
+    assert _check_against_model(gpu, d, blocks, frames) >= 10
+
+
+def test_zstd_unaligned_sources_and_literals_read_from_the_source(gpu, oracle, ref):
+    """Units without a sequence keep their literals in the source (no copy by the match finder), wherever the block lies:
+    blocks at odd device offsets, with entropy-codable literals but no matches (Huffman from the source), noise (sampled
+    early-out -> Raw, bytes placed by the match finder), and a mix, must equal the host model and decode with the reference."""
+    d = _model_src(oracle)
+    rng = np.random.default_rng(11)
+    skew = (np.abs(rng.normal(128, 12, 500001)).astype(np.int64) % 256).astype(np.uint8)
+    noise = rng.integers(0, 256, 400003, dtype=np.uint8)
+    half = np.concatenate([rng.integers(0, 256, 200000, dtype=np.uint8), oracle.synth(300000, 4, 1), skew[:150000]])
+    blocks = [skew, noise, half, oracle.synth(131072 * 2 + 5, 3, 12)]
+    for shift in (1, 2, 3, 7):
+        offs, pos = [], shift
+        for b in blocks:
+            offs.append(pos)
+            pos += len(b) + shift + 8
+        host = np.zeros(pos + 64, np.uint8)
+        for o, b in zip(offs, blocks):
+            host[o : o + len(b)] = b
+        dev = torch.from_numpy(host).cuda()
+        caps = [len(b) + (len(b) >> 8) + 64 for b in blocks]
+        d_offs, total = layout([np.zeros(c + shift, np.uint8) for c in caps], align=1)
+        d_offs = [o + shift for o in d_offs]
+        dst = torch.full((total + 64 + shift,), 0xEE, dtype=torch.uint8, device="cuda")
+        sizes = u32(gpu.zstd_compress_blocks(dev, offs, [len(b) for b in blocks], dst, d_offs, caps))
+        out = dst.cpu().numpy()
+        frames = [out[o : o + int(n)].copy() for o, n in zip(d_offs, sizes)]
+        kinds = [[t for t, _ in zstd_pieces(f)] for f in frames]
+        assert kinds[0].count(2) == len(kinds[0]) and kinds[1].count(0) == len(kinds[1])  # all Huffman / all Raw
+        assert _check_against_model(gpu, d, blocks, frames) >= 8
+        for b, f in zip(blocks, frames):
+            err, back = ref.decompress(1, f, len(b))
+            assert err == 0 and len(back) == len(b) and (back == b).all()
 
 
 def gpu_zstd_decode(gpu, frames, caps):
