@@ -1083,6 +1083,205 @@ __global__ __launch_bounds__(64) void k_lz4_decode(const uint8_t* __restrict__ s
         out_sizes[b] = result;
 }
 
+// The same rules, restructured around what made the wave-per-block decoder above slow (about 1600 cycles per sequence): every
+// token, length byte and offset was a dependent GLOBAL load, and every match waited for the literal stores to come back.
+//   * the payload streams through a 4 KiB LDS window (16-byte coalesced refills); 64 payload bytes at a time sit in a register
+//     window (one byte per lane), so token, extension bytes and offset of a short sequence are `readlane`s of ONE LDS round
+//     trip, and several short sequences share it;
+//   * the last 8 KiB of OUTPUT are mirrored in an LDS ring: matches with offset <= 8192 (the bulk) never read global memory;
+//     farther ones do, and a wait for outstanding stores is only needed when their source is younger than the last wait --
+//     at most once per 4 KiB of output.
+constexpr uint32_t DEC_IN = 4096u, DEC_RING = 8192u;
+
+__global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
+                                                       uint32_t nblocks, uint8_t* __restrict__ dst,
+                                                       uint32_t* __restrict__ out_sizes)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[DEC_RING];
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks)
+        return;
+    const int lane = threadIdx.x;
+    const Lz4Block blk = blocks[b];
+    const uint8_t* in = src + blk.src_off;
+    uint8_t* out = dst + blk.dst_off;
+    const int64_t n = blk.size, cap = blk.dst_cap;
+    const uint32_t head = (uint32_t)((uintptr_t)in & 15u);
+    const uint8_t* in_al = in - head; // 16-byte aligned; payload byte p sits at aligned offset p + head
+    uint32_t result = 0xFFFFFFFFu;
+    int64_t wa = -(int64_t)DEC_IN; // aligned offset of s_in[0]; nothing loaded yet
+    // make payload bytes [p, p + k) (k <= 64; bytes at or past n are never used) resident; returns the index of p in s_in
+    auto need = [&](int64_t p, uint32_t k) -> uint32_t {
+        const int64_t a = p + head;
+        if (a < wa || a + k > wa + (int64_t)DEC_IN)
+        {
+            wa = a & ~(int64_t)15;
+            const int64_t end = n + head; // first aligned offset past the payload
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+                const int64_t o = wa + 16 * (int64_t)(u * 64 + lane);
+                uint4 q = make_uint4(0, 0, 0, 0);
+                if (o < end)
+                    q = *reinterpret_cast<const uint4*>(in_al + o);
+                reinterpret_cast<uint4*>(s_in)[u * 64 + lane] = q;
+            }
+            __syncthreads();
+        }
+        return (uint32_t)(a - wa);
+    };
+    if (cap == 0)
+    {
+        if (n == 1 && in[0] == 0)
+            result = 0;
+    }
+    else if (n > 0)
+    {
+        int64_t ip = 0, op = 0, synced = 0;
+        int64_t w0 = -1000; // payload position of lane 0 of the register window
+        uint32_t w = 0;
+        // byte at payload position p through the register window (refreshed when p is not in it)
+        auto byte_at = [&](int64_t p) -> uint32_t {
+            if (p < w0 || p >= w0 + 64)
+            {
+                const uint32_t i = need(p, 64);
+                w = s_in[i + (uint32_t)lane < DEC_IN ? i + (uint32_t)lane : DEC_IN - 1u];
+                w0 = p;
+            }
+            return __builtin_amdgcn_readlane(w, (int)(p - w0));
+        };
+        // literals: payload [p, p + len) -> out[o ...) and the ring
+        auto copy_lits = [&](int64_t p, int64_t o, int64_t len) {
+            while (len > 0)
+            {
+                const uint32_t i = need(p, 1);
+                const int64_t avail = (int64_t)DEC_IN - i;
+                const int64_t c = len < avail ? len : avail;
+                for (int64_t j = lane; j < c; j += 64)
+                {
+                    const uint8_t v = s_in[i + (uint32_t)j];
+                    out[o + j] = v;
+                    s_ring[(uint32_t)(o + j) & (DEC_RING - 1u)] = v;
+                }
+                p += c;
+                o += c;
+                len -= c;
+            }
+        };
+        for (;;)
+        {
+            if (ip >= n)
+                break;
+            if (ip - w0 > 40) // keep token + a few length bytes + offset of a short sequence inside one window
+                w0 = -1000;
+            const uint32_t token = byte_at(ip++);
+            int64_t len = token >> 4;
+            bool bad = false;
+            if (len == 15)
+            { // read_variable_length(&ip, iend-RUN_MASK, 1), lz4.c:1979-2013
+                uint32_t v;
+                if (ip >= n - 15)
+                    bad = true;
+                else
+                    do
+                    {
+                        v = byte_at(ip++);
+                        len += v;
+                        if (ip > n - 15)
+                        {
+                            bad = true;
+                            break;
+                        }
+                    } while (v == 255);
+            }
+            if (bad)
+                break;
+            if (op + len > cap - 12 || ip + len > n - 8)
+            {
+                if (ip + len != n || op + len > cap)
+                    break;
+                copy_lits(ip, op, len);
+                result = (uint32_t)(op + len);
+                break;
+            }
+            copy_lits(ip, op, len);
+            ip += len;
+            op += len;
+            const uint32_t off = byte_at(ip) | (byte_at(ip + 1) << 8);
+            ip += 2;
+            if (off == 0 || (int64_t)off > op)
+                break;
+            int64_t ml = token & 15;
+            if (ml == 15)
+            {
+                uint32_t v;
+                do
+                {
+                    if (ip >= n - 5 + 1)
+                    {
+                        bad = true;
+                        break;
+                    }
+                    v = byte_at(ip++);
+                    ml += v;
+                } while (v == 255);
+            }
+            if (bad)
+                break;
+            ml += 4;
+            if (op + ml > cap - 5)
+                break;
+            // the match, in segments of <= 4 KiB (out[q] = out[q - off] holds for every q of a match, so a segment is a match
+            // of its own; with <= 4 KiB a ring slot is never overwritten before its last read)
+            int64_t rem = ml;
+            while (rem > 0)
+            {
+                const uint32_t seg = rem < 4096 ? (uint32_t)rem : 4096u;
+                if (off <= DEC_RING)
+                {
+                    const uint32_t base = (uint32_t)(op - off);
+                    if (off >= 64u) // a 64-byte step never reads what it writes
+                        for (uint32_t j = lane; j < seg; j += 64)
+                        {
+                            const uint8_t v = s_ring[(base + j) & (DEC_RING - 1u)];
+                            out[op + j] = v;
+                            s_ring[((uint32_t)op + j) & (DEC_RING - 1u)] = v;
+                        }
+                    else // overlapping copy: byte j of the match equals byte (j mod off) of the seed
+                        for (uint32_t j = lane; j < seg; j += 64)
+                        {
+                            const uint8_t v = s_ring[(base + j % off) & (DEC_RING - 1u)];
+                            out[op + j] = v;
+                            s_ring[((uint32_t)op + j) & (DEC_RING - 1u)] = v;
+                        }
+                }
+                else
+                {
+                    if (op - off + seg > synced)
+                    {
+                        // the source was written by this wave's own earlier stores: they must have landed
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_s_waitcnt(0);
+                        synced = op;
+                    }
+                    for (uint32_t j = lane; j < seg; j += 64) // off > 8192 >= seg: no overlap
+                    {
+                        const uint8_t v = out[op - off + j];
+                        out[op + j] = v;
+                        s_ring[((uint32_t)op + j) & (DEC_RING - 1u)] = v;
+                    }
+                }
+                op += seg;
+                rem -= seg;
+            }
+        }
+    }
+    if (lane == 0)
+        out_sizes[b] = result;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -1295,8 +1494,13 @@ extern "C" int lthip_lz4_decompress_blocks(lthip_ctx* ctx, const void* d_src, ui
     if (err)
         return err;
     LaunchTimer t(ctx, LTHIP_K_OTHER);
-    hipLaunchKernelGGL(k_lz4_decode, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, block_count,
-                       (uint8_t*)d_dst, d_out_sizes);
+    static const bool plain = getenv("LTHIP_LZ4_PLAIN_DECODER") != nullptr; // ablation: every byte through global memory
+    if (plain)
+        hipLaunchKernelGGL(k_lz4_decode, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, block_count,
+                           (uint8_t*)d_dst, d_out_sizes);
+    else
+        hipLaunchKernelGGL(k_lz4_decode_lds, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, block_count,
+                           (uint8_t*)d_dst, d_out_sizes);
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
 }

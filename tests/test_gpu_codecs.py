@@ -320,3 +320,47 @@ def test_zstd_decoder_agrees_with_host_model_and_reference_on_damaged_frames(gpu
                 err, r_out = ref.decompress(1, f, cap)
                 assert err == 0 and (r_out == o).all()
     assert 20 < accepted < len(frames)
+
+
+def test_lz4_gpu_decoder_differential_fuzz(gpu, oracle):
+    """Damaged payloads: the HIP decoder accepts exactly what the oracle's strict LZ4_decompress_safe restatement accepts
+    (lz4.c:2215-2435), with the same size and bytes -- truncations, bit flips, zeroed tails, wrong capacities."""
+    rng = np.random.default_rng(77)
+    raws = [oracle.synth(n, 300 + n, k) for k, n in ((1, 70000), (1, 9000), (2, 5000), (0, 3000), (11, 40000), (12, 20000))]
+    raws.append(np.frombuffer(b"abcdefgh" * 3000 + b"x" * 70000 + bytes(range(256)) * 40, np.uint8).copy())  # long matches, far offsets
+    far = rng.integers(0, 256, 30000, dtype=np.uint8)
+    raws.append(np.concatenate([far, rng.integers(0, 256, 20000, dtype=np.uint8), far]))  # offsets beyond the 8 KiB ring
+    cases = []
+    for raw in raws:
+        comp = oracle.lz4_compress(raw)
+        cases.append((comp, len(raw)))
+        for _ in range(24):
+            c = comp.copy()
+            kind = rng.integers(0, 5)
+            if kind == 0 and len(c) > 2:
+                c = c[: rng.integers(1, len(c))]
+            elif kind == 1:
+                for _ in range(rng.integers(1, 4)):
+                    c[rng.integers(0, len(c))] ^= 1 << rng.integers(0, 8)
+            elif kind == 2:
+                c[rng.integers(0, len(c)) :] = 0
+            elif kind == 3:
+                c[rng.integers(0, len(c))] = 255
+            cap = len(raw) if kind != 4 else max(0, len(raw) + int(rng.integers(-20, 20)))
+            cases.append((c, cap))
+    comps = [c for c, _ in cases]
+    caps = [cap for _, cap in cases]
+    dev, offs = to_device(comps)
+    d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
+    dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+    sizes = u32(gpu.lz4_decompress_blocks(dev, offs, [len(c) for c in comps], dst, d_offs, caps))
+    host = dst.cpu().numpy()
+    accepted = 0
+    for (c, cap), o, s in zip(cases, d_offs, sizes):
+        n, out = oracle.lz4_decompress(c, cap)
+        if n < 0:
+            assert int(s) == 0xFFFFFFFF
+        else:
+            assert int(s) == n and (host[o : o + n] == out[:n]).all()
+            accepted += 1
+    assert 8 <= accepted < len(cases)
