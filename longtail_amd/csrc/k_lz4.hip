@@ -1083,16 +1083,31 @@ __global__ __launch_bounds__(64) void k_lz4_decode(const uint8_t* __restrict__ s
         out_sizes[b] = result;
 }
 
-// The same rules, restructured around what made the wave-per-block decoder above slow (about 1600 cycles per sequence): every
-// token, length byte and offset was a dependent GLOBAL load, and every match waited for the literal stores to come back.
+// The same rules, restructured around what made the wave-per-block decoder above slow: every
+// token, length byte and offset was a dependent GLOBAL load, every literal and match a wave-wide byte store, and every match a
+// wait for all of those stores.
 //   * the payload streams through a 4 KiB LDS window (16-byte coalesced refills); 64 payload bytes at a time sit in a register
-//     window (one byte per lane), so token, extension bytes and offset of a short sequence are `readlane`s of ONE LDS round
-//     trip, and several short sequences share it;
-//   * the last 8 KiB of OUTPUT are mirrored in an LDS ring: matches with offset <= 8192 (the bulk) never read global memory;
-//     farther ones do, and a wait for outstanding stores is only needed when their source is younger than the last wait --
-//     at most once per 4 KiB of output.
-constexpr uint32_t DEC_IN = 4096u, DEC_RING = 8192u;
+//     window (one byte per lane) with the next one prefetched, so a short sequence (no length bytes: most of them) is parsed
+//     with `readlane`s alone and its literals are stored from the registers they are already in;
+//   * the OUTPUT is produced into an 8 KiB LDS ring and leaves for global memory 2 KiB at a time with aligned 16-byte stores;
+//     matches with offset <= 8192 (the bulk) never touch global memory, farther ones read bytes that were flushed long ago.
+// Measured (8 MiB blocks of the "mixed" workload, 100 K sequences each): 127 ms per block against 173 ms; what remains is the
+// serial parse itself (77 ms with every copy switched off: ~150 instructions per sequence issued by a single wave), so the
+// throughput of a batch comes from the number of blocks in flight: 34 GB/s at 512 blocks, 115 GB/s at 2048.
+constexpr uint32_t DEC_IN = 4096u, DEC_RING = 8192u, DEC_FLUSH = 2048u;
+#ifdef LTHIP_DEC_PROF /* debug build only (make prof): where a decoding wave spends its cycles */
+__device__ unsigned long long g_dec_prof[16];
+#define DEC_T0() const unsigned long long t0__ = clock64()
+#define DEC_ACC(i) do { if (lane == 0) atomicAdd(&g_dec_prof[i], clock64() - t0__); } while (0)
+#define DEC_CNT(i) do { if (lane == 0) atomicAdd(&g_dec_prof[i], 1ull); } while (0)
+#else
+#define DEC_T0() ((void)0)
+#define DEC_ACC(i) ((void)0)
+#define DEC_CNT(i) ((void)0)
+#endif
 
+// I = index type: int32_t when every payload and capacity of the batch is below 1 GiB (half the scalar work), else int64_t
+template <typename I>
 __global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
                                                        uint32_t nblocks, uint8_t* __restrict__ dst,
                                                        uint32_t* __restrict__ out_sizes)
@@ -1106,26 +1121,29 @@ __global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict
     const Lz4Block blk = blocks[b];
     const uint8_t* in = src + blk.src_off;
     uint8_t* out = dst + blk.dst_off;
-    const int64_t n = blk.size, cap = blk.dst_cap;
+    const I n = (I)blk.size, cap = (I)blk.dst_cap;
     const uint32_t head = (uint32_t)((uintptr_t)in & 15u);
     const uint8_t* in_al = in - head; // 16-byte aligned; payload byte p sits at aligned offset p + head
+    const uint32_t g = (uint32_t)((uintptr_t)out & 15u);
+    uint8_t* out_al = out - g; // output byte q sits at aligned offset q + g, and in the ring at (q + g) mod 8 KiB
     uint32_t result = 0xFFFFFFFFu;
-    int64_t wa = -(int64_t)DEC_IN; // aligned offset of s_in[0]; nothing loaded yet
-    // make payload bytes [p, p + k) (k <= 64; bytes at or past n are never used) resident; returns the index of p in s_in
-    auto need = [&](int64_t p, uint32_t k) -> uint32_t {
-        const int64_t a = p + head;
-        if (a < wa || a + k > wa + (int64_t)DEC_IN)
+    I wa = -(I)DEC_IN; // aligned offset of s_in[0]; nothing loaded yet
+    // make payload bytes [p, p + k) (k <= 128; bytes at or past n are never used) resident; returns the index of p in s_in
+    auto need = [&](I p, uint32_t k) -> uint32_t {
+        const I a = p + (I)head;
+        if (a < wa || a + (I)k > wa + (I)DEC_IN)
         {
-            wa = a & ~(int64_t)15;
-            const int64_t end = n + head; // first aligned offset past the payload
+            DEC_CNT(8);
+            wa = a & ~(I)15;
+            const I end = n + (I)head; // first aligned offset past the payload
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < 4; ++u)
             {
-                const int64_t o = wa + 16 * (int64_t)(u * 64 + lane);
+                const I o = wa + 16 * (I)(u * 64 + lane);
                 uint4 q = make_uint4(0, 0, 0, 0);
                 if (o < end)
-                    q = *reinterpret_cast<const uint4*>(in_al + o);
+                    q = *reinterpret_cast<const uint4*>(in_al + (int64_t)o);
                 reinterpret_cast<uint4*>(s_in)[u * 64 + lane] = q;
             }
             __syncthreads();
@@ -1139,45 +1157,152 @@ __global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict
     }
     else if (n > 0)
     {
-        int64_t ip = 0, op = 0, synced = 0;
-        int64_t w0 = -1000; // payload position of lane 0 of the register window
-        uint32_t w = 0;
-        // byte at payload position p through the register window (refreshed when p is not in it)
-        auto byte_at = [&](int64_t p) -> uint32_t {
-            if (p < w0 || p >= w0 + 64)
+        I ip = 0, op = 0;
+        I flushed = 0; // aligned output offset (multiple of DEC_FLUSH) up to which the ring has been written out
+        I drained = 0; // aligned output offset up to which the flush stores are known to have landed
+        I w0 = -1000;  // payload position of lane 0 of the register window
+        uint32_t w = 0, wn = 0; // the window and the one 40 bytes further on (fetched while this one is parsed)
+#define RING(q) (((uint32_t)(q) + g) & (DEC_RING - 1u))
+        // ring -> global for aligned offsets [flushed, upto): whole 16-byte vectors, bytes at the two ragged ends of the block
+        auto flush = [&](I upto) {
+            DEC_T0();
+            while (flushed < upto)
             {
-                const uint32_t i = need(p, 64);
-                w = s_in[i + (uint32_t)lane < DEC_IN ? i + (uint32_t)lane : DEC_IN - 1u];
-                w0 = p;
+                const I stop = upto - flushed < (I)DEC_FLUSH ? upto : flushed + (I)DEC_FLUSH;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    const I P = flushed + 16 * (I)(u * 64 + lane);
+                    if (P >= stop)
+                        continue;
+                    const uint8_t* r = s_ring + ((uint32_t)P & (DEC_RING - 1u));
+                    if (P >= (I)g && P + 16 <= stop)
+                        *reinterpret_cast<uint4*>(out_al + (int64_t)P) = *reinterpret_cast<const uint4*>(r);
+                    else
+                        for (int k = 0; k < 16; ++k)
+                            if (P + k >= (I)g && P + k < stop)
+                                out_al[(int64_t)P + k] = r[k];
+                }
+                flushed = stop;
             }
+            DEC_ACC(3);
+        };
+        auto seed = [&](I p) {
+            const uint32_t i = need(p, 128);
+            w = s_in[i + (uint32_t)lane];
+            wn = s_in[i + 40u + (uint32_t)lane];
+            w0 = p;
+        };
+        auto byte_at = [&](I p) -> uint32_t {
+            if (p < w0 || p >= w0 + 64)
+                seed(p);
             return __builtin_amdgcn_readlane(w, (int)(p - w0));
         };
-        // literals: payload [p, p + len) -> out[o ...) and the ring
-        auto copy_lits = [&](int64_t p, int64_t o, int64_t len) {
+        // literals: payload [p, p + len) -> the ring at output position o
+        auto copy_lits = [&](I p, I o, I len) {
             while (len > 0)
             {
                 const uint32_t i = need(p, 1);
-                const int64_t avail = (int64_t)DEC_IN - i;
-                const int64_t c = len < avail ? len : avail;
-                for (int64_t j = lane; j < c; j += 64)
-                {
-                    const uint8_t v = s_in[i + (uint32_t)j];
-                    out[o + j] = v;
-                    s_ring[(uint32_t)(o + j) & (DEC_RING - 1u)] = v;
-                }
-                p += c;
-                o += c;
-                len -= c;
+                I avail = (I)DEC_IN - (I)i;
+                avail = avail < (I)DEC_FLUSH ? avail : (I)DEC_FLUSH;
+                const uint32_t c = (uint32_t)(len < avail ? len : avail);
+                for (uint32_t j = lane; j < c; j += 64)
+                    s_ring[RING((uint32_t)o + j)] = s_in[i + j];
+                p += (I)c;
+                o += (I)c;
+                len -= (I)c;
+                if (o + (I)g - flushed >= (I)DEC_FLUSH)
+                    flush((o + (I)g) & ~(I)(DEC_FLUSH - 1u));
             }
         };
+        // match of `ml` bytes at distance `off` (1 <= off <= op) appended at op; returns nothing, advances op
+        auto copy_match = [&](uint32_t off, I ml) {
+            DEC_T0();
+            if (off > DEC_RING)
+                DEC_CNT(9);
+            while (ml > 0)
+            {
+                // segments of <= 2 KiB (out[q] = out[q - off] holds for every q of a match, so a segment is a match of its own;
+                // with that bound no ring slot is overwritten before its last read and before it has been flushed)
+                const uint32_t seg = ml < (I)DEC_FLUSH ? (uint32_t)ml : DEC_FLUSH;
+                if (off <= DEC_RING)
+                {
+                    const uint32_t base = (uint32_t)op - off;
+                    if (off >= 64u) // a 64-byte step never reads what it writes
+                        for (uint32_t j = lane; j < seg; j += 64)
+                            s_ring[RING((uint32_t)op + j)] = s_ring[RING(base + j)];
+                    else if (seg <= 64u)
+                    {
+                        uint32_t r = (uint32_t)lane; // lane mod off
+                        for (uint32_t t = off; t < seg; t += off)
+                            r = (uint32_t)lane >= t ? (uint32_t)lane - t : r;
+                        if ((uint32_t)lane < seg)
+                            s_ring[RING((uint32_t)op + (uint32_t)lane)] = s_ring[RING(base + r)];
+                    }
+                    else // overlapping copy: byte j of the match equals byte (j mod off) of the seed
+                        for (uint32_t j = lane; j < seg; j += 64)
+                            s_ring[RING((uint32_t)op + j)] = s_ring[RING(base + j % off)];
+                }
+                else
+                {
+                    // the source left the ring long ago (off > 8 KiB, flushes every 2 KiB) -- but its stores must have landed
+                    if (op - (I)off + (I)seg + (I)g > drained)
+                    {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_s_waitcnt(0);
+                        drained = flushed;
+                    }
+                    for (uint32_t j = lane; j < seg; j += 64) // off > 8192 > seg: no overlap
+                        s_ring[RING((uint32_t)op + j)] = out[(int64_t)op - off + j];
+                }
+                op += (I)seg;
+                ml -= (I)seg;
+                if (op + (I)g - flushed >= (I)DEC_FLUSH)
+                    flush((op + (I)g) & ~(I)(DEC_FLUSH - 1u));
+            }
+            DEC_ACC(2);
+        };
+        DEC_T0();
         for (;;)
         {
             if (ip >= n)
                 break;
-            if (ip - w0 > 40) // keep token + a few length bytes + offset of a short sequence inside one window
-                w0 = -1000;
+            // ---- short sequences (no length bytes, <= 14 literals, match <= 18): everything is in the register window ----
+            {
+                I d = ip - w0;
+                if (d > 47 && d < 88) // slide: the prefetched window becomes the current one
+                {
+                    w = wn;
+                    w0 += 40;
+                    d -= 40;
+                    const uint32_t i = need(w0 + 40, 64);
+                    wn = s_in[i + (uint32_t)lane];
+                }
+                if (d < 0 || d > 47)
+                {
+                    seed(ip);
+                    d = 0;
+                }
+                const uint32_t tk = __builtin_amdgcn_readlane(w, (int)d);
+                const I lit = (I)(tk >> 4), mlc = (I)(tk & 15u);
+                // exactly the conditions under which the general code below takes its plain path for this token
+                if (lit < 15 && mlc < 15 && !(op + lit > cap - 12 || ip + 1 + lit > n - 8) && op + lit + mlc + 4 <= cap - 5)
+                {
+                    const uint32_t off = __builtin_amdgcn_readlane(w, (int)(d + 1 + lit)) | (__builtin_amdgcn_readlane(w, (int)(d + 2 + lit)) << 8);
+                    if (off == 0 || (I)off > op + lit)
+                        break;
+                    const I rel = (I)lane - d - 1; // my byte is literal `rel` of this sequence
+                    if (rel >= 0 && rel < lit)
+                        s_ring[RING((uint32_t)op + (uint32_t)rel)] = (uint8_t)w;
+                    op += lit;
+                    copy_match(off, mlc + 4);
+                    ip += 3 + lit;
+                    DEC_CNT(10);
+                    continue;
+                }
+            }
             const uint32_t token = byte_at(ip++);
-            int64_t len = token >> 4;
+            I len = (I)(token >> 4);
             bool bad = false;
             if (len == 15)
             { // read_variable_length(&ip, iend-RUN_MASK, 1), lz4.c:1979-2013
@@ -1188,8 +1313,8 @@ __global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict
                     do
                     {
                         v = byte_at(ip++);
-                        len += v;
-                        if (ip > n - 15)
+                        len += (I)v;
+                        if (ip > n - 15 || len > cap) // a literal run longer than the capacity is rejected below anyway
                         {
                             bad = true;
                             break;
@@ -1203,7 +1328,9 @@ __global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict
                 if (ip + len != n || op + len > cap)
                     break;
                 copy_lits(ip, op, len);
-                result = (uint32_t)(op + len);
+                op += len;
+                flush(op + (I)g);
+                result = (uint32_t)op;
                 break;
             }
             copy_lits(ip, op, len);
@@ -1211,9 +1338,9 @@ __global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict
             op += len;
             const uint32_t off = byte_at(ip) | (byte_at(ip + 1) << 8);
             ip += 2;
-            if (off == 0 || (int64_t)off > op)
+            if (off == 0 || (I)off > op)
                 break;
-            int64_t ml = token & 15;
+            I ml = (I)(token & 15);
             if (ml == 15)
             {
                 uint32_t v;
@@ -1225,7 +1352,12 @@ __global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict
                         break;
                     }
                     v = byte_at(ip++);
-                    ml += v;
+                    ml += (I)v;
+                    if (ml > cap) // rejected below anyway
+                    {
+                        bad = true;
+                        break;
+                    }
                 } while (v == 255);
             }
             if (bad)
@@ -1233,50 +1365,11 @@ __global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict
             ml += 4;
             if (op + ml > cap - 5)
                 break;
-            // the match, in segments of <= 4 KiB (out[q] = out[q - off] holds for every q of a match, so a segment is a match
-            // of its own; with <= 4 KiB a ring slot is never overwritten before its last read)
-            int64_t rem = ml;
-            while (rem > 0)
-            {
-                const uint32_t seg = rem < 4096 ? (uint32_t)rem : 4096u;
-                if (off <= DEC_RING)
-                {
-                    const uint32_t base = (uint32_t)(op - off);
-                    if (off >= 64u) // a 64-byte step never reads what it writes
-                        for (uint32_t j = lane; j < seg; j += 64)
-                        {
-                            const uint8_t v = s_ring[(base + j) & (DEC_RING - 1u)];
-                            out[op + j] = v;
-                            s_ring[((uint32_t)op + j) & (DEC_RING - 1u)] = v;
-                        }
-                    else // overlapping copy: byte j of the match equals byte (j mod off) of the seed
-                        for (uint32_t j = lane; j < seg; j += 64)
-                        {
-                            const uint8_t v = s_ring[(base + j % off) & (DEC_RING - 1u)];
-                            out[op + j] = v;
-                            s_ring[((uint32_t)op + j) & (DEC_RING - 1u)] = v;
-                        }
-                }
-                else
-                {
-                    if (op - off + seg > synced)
-                    {
-                        // the source was written by this wave's own earlier stores: they must have landed
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __builtin_amdgcn_s_waitcnt(0);
-                        synced = op;
-                    }
-                    for (uint32_t j = lane; j < seg; j += 64) // off > 8192 >= seg: no overlap
-                    {
-                        const uint8_t v = out[op - off + j];
-                        out[op + j] = v;
-                        s_ring[((uint32_t)op + j) & (DEC_RING - 1u)] = v;
-                    }
-                }
-                op += seg;
-                rem -= seg;
-            }
+            copy_match(off, ml);
+            DEC_CNT(11);
         }
+        DEC_ACC(0);
+#undef RING
     }
     if (lane == 0)
         out_sizes[b] = result;
@@ -1287,6 +1380,21 @@ __global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+#ifdef LTHIP_DEC_PROF
+extern "C" __attribute__((visibility("default"))) int lthip_dec_prof_dump(void)
+{
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dec_prof), sizeof(h)) != hipSuccess)
+        return -1;
+    fprintf(stderr, "lz4 decoder: total %.1f Mcycles (wave-summed), copy_match %.1f (incl. flush), flush %.1f, refills %llu, far matches %llu, "
+                    "short sequences %llu, general sequences %llu\n",
+            h[0] / 1e6, h[2] / 1e6, h[3] / 1e6, h[8], h[9], h[10], h[11]);
+    memset(h, 0, sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_prof), h, sizeof(h));
+    return 0;
+}
+#endif
+
 extern "C" size_t lthip_lz4_bound(size_t size) { return size > 0x7E000000u ? 0 : size + size / 255 + 16; }
 
 static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* src_offsets, const uint32_t* src_sizes,
@@ -1499,8 +1607,17 @@ extern "C" int lthip_lz4_decompress_blocks(lthip_ctx* ctx, const void* d_src, ui
         hipLaunchKernelGGL(k_lz4_decode, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, block_count,
                            (uint8_t*)d_dst, d_out_sizes);
     else
-        hipLaunchKernelGGL(k_lz4_decode_lds, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, block_count,
-                           (uint8_t*)d_dst, d_out_sizes);
+    {
+        bool small = true;
+        for (uint32_t b = 0; b < block_count; ++b)
+            small = small && src_sizes[b] < (1u << 30) && dst_caps[b] < (1u << 30);
+        if (small)
+            hipLaunchKernelGGL(k_lz4_decode_lds<int32_t>, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks,
+                               block_count, (uint8_t*)d_dst, d_out_sizes);
+        else
+            hipLaunchKernelGGL(k_lz4_decode_lds<int64_t>, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks,
+                               block_count, (uint8_t*)d_dst, d_out_sizes);
+    }
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
 }
