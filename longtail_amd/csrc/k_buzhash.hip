@@ -22,13 +22,24 @@ __constant__ uint32_t c_buztab[256] = {
 #include "buzhash_table.inc"
 };
 
-constexpr int K1_WAVES = 12;                 // one workgroup per CU: 3 waves per SIMD, <= 168 VGPRs each
+constexpr int K1_WAVES = 12;                 // one workgroup per CU: 3 waves per SIMD, <= 168 VGPRs each (16 waves at 128 VGPRs spill and gain nothing: measured)
 constexpr int K1_THREADS = 64 * K1_WAVES;
 constexpr int RUN = 64;                      // bytes per thread
 constexpr int TILE = 256 * RUN;              // 16 KiB: the plan's tile (four wave-tiles)
 constexpr int ROW_DW = 17;                   // 16 data dwords + 1 pad: thread-strided ds_read_b32 hits 32 distinct banks
 constexpr int TAB_REP = 64;                  // T[v] replicated once per lane, 256 bytes apart: a lookup address is
                                              // {byte, lane * 4} = ONE v_perm_b32 of the data dword, and never conflicts
+
+// 32-bit load from a raw LDS byte address (the device pass only: LDS pointers are 32 bits wide there)
+__device__ __forceinline__ uint32_t lds_load_u32(uint32_t byte_addr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(3))) uint32_t*)byte_addr;
+#else
+    (void)byte_addr;
+    return 0u;
+#endif
+}
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, uint32_t r) { return __builtin_amdgcn_alignbit(x, x, (32u - r) & 31u); }
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, uint32_t r) { return __builtin_amdgcn_alignbit(x, x, r & 31u); }
@@ -146,7 +157,6 @@ __global__ __launch_bounds__(K1_THREADS, 1) void k_buzhash_candidates(const uint
     __syncthreads(); // the only barrier: table visible to every wave
     // The table is the first thing in LDS and the kernel has no static LDS, so its LDS address is 0 and a lookup address
     // is the v_perm result itself (no base add); checked, not assumed.
-    typedef const __attribute__((address_space(3))) uint32_t lds_cu32;
     if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)smem != 0u)
         __builtin_trap();
     const uint32_t lane4 = (uint32_t)lane * 4u;
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(K1_THREADS, 1) void k_buzhash_candidates(const uint
             uint32_t h = 0;
     // byte offset of T[b] for this lane = b * 256 + lane * 4 = bytes {lane4, b, 0, 0}
 #define LT_LOOKUP(j)                                                                                                 \
-    tv[j] = *(lds_cu32*)(__builtin_amdgcn_perm(win[(j) >> 2], lane4, 0x0c0c0400u | ((uint32_t)((j) & 3) << 8)))
+    tv[j] = lds_load_u32(__builtin_amdgcn_perm(win[(j) >> 2], lane4, 0x0c0c0400u | ((uint32_t)((j) & 3) << 8)))
 #define LT_STEP(k)                                                                                                   \
     {                                                                                                                \
         h = rotl32(h, 1) ^ rotl32(tv[k], 16) ^ tv[48 + (k)];                                                         \
@@ -214,13 +224,13 @@ __global__ __launch_bounds__(K1_THREADS, 1) void k_buzhash_candidates(const uint
         {                                                                                                            \
             asm volatile(""); /* keep this a real scalar branch (no if-conversion of the bit-set) */                 \
             const bool hit = MODE == 1 ? pre : rotr32(h * dv.inv + dv.addc, dv.k2) <= dv.qlim; /* h % d == d-1 */   \
-            if (hit)                                                                                                 \
-            {                                                                                                        \
-                if ((k) < 32)                                                                                        \
-                    mlo |= 1u << (k);                                                                                \
-                else                                                                                                 \
-                    mhi |= 1u << ((k)-32);                                                                           \
-            }                                                                                                        \
+            /* 0/1 shifted by an inline constant: a select between 0 and 1 << k would park 64 constants in VGPRs */ \
+            uint32_t hb;                                                                                             \
+            asm volatile("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(hb) : "s"(__builtin_amdgcn_ballot_w64(hit)));       \
+            if ((k) < 32)                                                                                            \
+                mlo |= hb << (k);                                                                                    \
+            else                                                                                                     \
+                mhi |= hb << ((k)-32);                                                                               \
         }                                                                                                            \
     }
 #pragma unroll
@@ -575,12 +585,11 @@ int lthip_launch_buzhash(lthip_ctx* ctx, const lthip_plan* plan, const uint8_t* 
         return 0;
     static_assert(sizeof(uint32_t) * (256 * TAB_REP + K1_WAVES * WROWS * ROW_DW) <= 160 * 1024, "LDS budget: one workgroup per CU");
     const size_t lds = sizeof(uint32_t) * (256 * TAB_REP + K1_WAVES * WROWS * ROW_DW);
-    static bool attr_done = false;
-    if (!attr_done)
+    if (!ctx->k1_lds_enabled) // per context = per device: more than 64 KiB of dynamic LDS has to be granted explicitly
     {
         LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_buzhash_candidates<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_buzhash_candidates<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        ctx->k1_lds_enabled = true;
     }
     // one persistent workgroup of 12 waves per CU (64 KiB table + 12 wave row buffers = 117 KiB of LDS)
     int ncu = 256;

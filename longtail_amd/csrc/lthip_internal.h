@@ -106,6 +106,7 @@ struct lthip_ctx
         bool used;
     } stage[8];
     size_t stage_next;
+    bool k1_lds_enabled; // hipFuncAttributeMaxDynamicSharedMemorySize set for K1 on this context's device
     void* scratch[S_COUNT];
     size_t scratch_cap[S_COUNT];
     bool timing;
