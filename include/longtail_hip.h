@@ -157,7 +157,9 @@ LTHIP_EXPORT int lthip_hash_ranges(lthip_ctx* ctx, const void* d_data, uint64_t 
  * One call compresses a batch of stored blocks (the unit of CompressBlock, compressblockstore.c:67-141).
  * Block b = d_src[src_offsets[b] .. +src_sizes[b]) -> d_dst[dst_offsets[b] ..) with capacity dst_caps[b];
  * d_out_sizes[b] = payload size, or 0 when it does not fit (LZ4CompressionAPI_Compress -> ENOMEM).
- * The offset/size tables are HOST arrays (copied to the device by the call). */
+ * The offset/size tables are HOST arrays (copied to the device by the call).  The calls queue their work on the context's
+ * stream and return (results are ready after lthip_ctx_sync or any later work on the stream); a call of any size is cut
+ * into internal batches of LTHIP_BATCH_BYTES of input (environment, default 8 GiB) so that the scratch stays bounded. */
 LTHIP_EXPORT size_t lthip_lz4_bound(size_t size); /* LZ4_COMPRESSBOUND, lib/lz4/ext/lz4.h:215 */
 LTHIP_EXPORT int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count,
                                            const uint64_t* src_offsets, const uint32_t* src_sizes, void* d_dst,
@@ -206,7 +208,8 @@ LTHIP_EXPORT int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src,
                                               const uint64_t* src_offsets, const uint32_t* src_sizes, void* d_dst,
                                               const uint64_t* dst_offsets, const uint32_t* dst_caps,
                                               uint32_t* d_out_sizes);
-/* Diagnostics (parity tests): match-finder output of the last lthip_zstd_compress_blocks call on this context for the
+/* Diagnostics (parity tests): match-finder output of the last lthip_zstd_compress_blocks call (its last internal batch:
+ * calls above LTHIP_BATCH_BYTES = 8 GiB of input are processed in several) on this context for the
  * 4 KiB units [first, first + count) -- 16 bytes of meta {nseq, nlit, tail, 0}, 4096 literal bytes and 1024 u64
  * records {lit | mlen << 16 | offset << 32} per unit (host buffers, any may be NULL).  A unit with nseq == 0 has no
  * literal buffer (its 4096 bytes here are unspecified): its literals are its source bytes. */

@@ -1435,14 +1435,48 @@ static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* s
 
 // default geometry: 8 waves x 4 KiB units share a 32 KiB window; 32 KiB data + 8 x 4 KiB tables = 64 KiB of LDS per
 // workgroup -> 2 workgroups = 16 waves per CU
+static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
+                              const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets, const uint32_t* dst_caps,
+                              uint32_t* d_out_sizes, int segment_log2);
+
+// The per-unit scratch of one launch sequence is about as large as its input, so a call of any size is cut into batches of
+// LTHIP_BATCH_BYTES (default 8 GiB, the size bench.py uses) that reuse the same scratch one after the other on the stream.
+uint64_t lthip_codec_batch_bytes()
+{
+    static const uint64_t v = [] {
+        const char* e = getenv("LTHIP_BATCH_BYTES");
+        const uint64_t x = e ? strtoull(e, nullptr, 10) : 0;
+        return x ? x : (8ull << 30);
+    }();
+    return v;
+}
+
 extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                                          const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
                                          const uint32_t* dst_caps, uint32_t* d_out_sizes, int segment_log2)
 {
     if (!ctx || !d_out_sizes || (block_count && (!src_offsets || !src_sizes || !dst_offsets || !dst_caps || !d_dst)))
         return EINVAL;
-    if (block_count == 0)
-        return 0;
+    const uint64_t budget = lthip_codec_batch_bytes();
+    for (uint32_t b0 = 0; b0 < block_count;)
+    {
+        uint64_t bytes = src_sizes[b0];
+        uint32_t b1 = b0 + 1;
+        while (b1 < block_count && bytes + src_sizes[b1] <= budget)
+            bytes += src_sizes[b1++];
+        const int err = lz4_compress_batch(ctx, d_src, b1 - b0, src_offsets + b0, src_sizes + b0, d_dst, dst_offsets + b0, dst_caps + b0,
+                                           d_out_sizes + b0, segment_log2);
+        if (err)
+            return err;
+        b0 = b1;
+    }
+    return 0;
+}
+
+static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
+                              const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets, const uint32_t* dst_caps,
+                              uint32_t* d_out_sizes, int segment_log2)
+{
     if (segment_log2 == 0)
         segment_log2 = 12;
     if (segment_log2 < 10 || segment_log2 > 13) // units are multiples of 1024 bytes (pre-seed loop)

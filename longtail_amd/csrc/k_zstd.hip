@@ -261,14 +261,36 @@ extern "C" size_t lthip_zstd_bound(size_t n)
     return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0);
 }
 
+static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
+                               const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets, const uint32_t* dst_caps,
+                               uint32_t* d_out_sizes);
+
 extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                                           const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
                                           const uint32_t* dst_caps, uint32_t* d_out_sizes)
 {
     if (!ctx || !d_out_sizes || (block_count && (!src_offsets || !src_sizes || !dst_offsets || !dst_caps || !d_dst)))
         return EINVAL;
-    if (block_count == 0)
-        return 0;
+    const uint64_t budget = lthip_codec_batch_bytes(); // scratch (unit literals + records + piece slots): about three times that
+    for (uint32_t b0 = 0; b0 < block_count;)
+    {
+        uint64_t bytes = src_sizes[b0];
+        uint32_t b1 = b0 + 1;
+        while (b1 < block_count && bytes + src_sizes[b1] <= budget)
+            bytes += src_sizes[b1++];
+        const int err = zstd_compress_batch(ctx, d_src, b1 - b0, src_offsets + b0, src_sizes + b0, d_dst, dst_offsets + b0, dst_caps + b0,
+                                            d_out_sizes + b0);
+        if (err)
+            return err;
+        b0 = b1;
+    }
+    return 0;
+}
+
+static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
+                               const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets, const uint32_t* dst_caps,
+                               uint32_t* d_out_sizes)
+{
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     std::vector<ZBlock> hb(block_count);
     std::vector<uint32_t> unit_base(block_count);

@@ -122,6 +122,7 @@ int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out);
 // events from lthip_sync_event and must make the main stream wait for the side stream before they return).
 int lthip_second_stream(lthip_ctx* ctx, hipStream_t* out);
 hipEvent_t lthip_sync_event(lthip_ctx* ctx);
+uint64_t lthip_codec_batch_bytes(); // input bytes per internal codec batch (LTHIP_BATCH_BYTES, default 8 GiB)
 // Host table -> device without stalling the caller: the bytes are copied into one of a ring of pinned staging buffers and
 // queued on `stream`; `h_src` may be freed on return, and the host does not wait for earlier work of the stream (a
 // pageable hipMemcpyAsync + hipStreamSynchronize would wait for every kernel queued before it).

@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def run_bench(*args):
-    env = dict(os.environ, PYTHONPATH=str(ROOT))
+def run_bench(*args, extra_env=None):
+    env = dict(os.environ, PYTHONPATH=str(ROOT), **(extra_env or {}))
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", *args],
                          capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -33,8 +33,10 @@ def test_bench_line_and_batching_independence(codec):
         assert key in a, key
     assert a["n_gpus"] == 1 and a["higher_is_better"] is True and a["scaling"] == "weak" and a["value"] > 0
     assert a["config"]["device_block_assembly"] is True  # files are not multiples of 16 bytes: some blocks span assets
+    # the codec entry points cut large calls into internal batches (LTHIP_BATCH_BYTES): same payloads whatever the cut
+    c = run_bench(*base, extra_env={"LTHIP_BATCH_BYTES": str(48 << 20)})
     for key in ("chunks", "unique_chunks_global", "blocks", "compressed_bytes"):
-        assert a["result"][key] == b["result"][key], key
+        assert a["result"][key] == b["result"][key] == c["result"][key], key
     assert a["result"]["ratio"] > 1.3
 
 
