@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64 * LZ4_G, 6) void k_lz4_segments(const uint8_t* _
                 // learn the history: insert every position before my unit, oldest first (plain stores, four
                 // independent positions per lane in flight), then re-insert my own probed positions on top
                 // every 4th position is enough: a match found one to three bytes late is recovered by the
-                // backward extension, and the small table is polluted less (tools/lz4_model: ratio 1.755 -> 1.785)
+                // backward extension, and the small table is polluted less (CPU model of this parse: ratio 1.755 -> 1.785)
                 for (uint32_t q0 = 0; q0 < my_start; q0 += 1024) // my_start is a multiple of 1024
                 {
                     uint32_t hv[4];
