@@ -159,3 +159,20 @@ def test_dedup_first_seen(gpu):
     for lo, cnt in ((0, 0), (0, 100), (12345, 20000), (39999, 1), (0, len(h))):
         part, uniq2 = gpu.dedup_first_seen_range(torch.from_numpy(h).cuda(), lo, cnt)
         assert (u32(part) == exp[lo : lo + cnt]).all() and int(uniq2.item()) == len(seen)
+
+
+@pytest.mark.parametrize("nbytes,target", [(1000, 65536), (1 << 20, 32768), (64 << 20, 65536)])
+def test_survey_probed_reference_values_on_gpu(gpu, oracle, nbytes, target):
+    """SURVEY.md §8(c)'s reference-measured chunk counts / first chunks / hashes for xorshift64 streams, through the C ABI; the
+    whole list equals the oracle's."""
+    from longtail_amd.lib import chunker_params
+    from tests.survey_vectors import EXPECTED, xorshift_stream
+
+    count, first = EXPECTED[(nbytes, target)]
+    data = xorshift_stream(nbytes)
+    mn, av, mx = chunker_params(target)
+    ((off, lens, hashes),) = gpu_chunk_hash(gpu, [data], mn, av, mx)
+    assert len(lens) == count
+    assert [(int(o), int(l), int(h)) for o, l, h in zip(off[: len(first)], lens[: len(first)], hashes[: len(first)])] == first
+    e_off, e_len, e_hash = oracle.chunk_and_hash(data, mn, av, mx)
+    assert (lens == e_len).all() and (hashes == e_hash).all()

@@ -1,6 +1,7 @@
 """The oracle (oracle/*.c) against the golden vectors the reference's own tests hold and against vectors produced by
 the reference library (tools/gen_golden.py).  CPU only."""
 import numpy as np
+import pytest
 
 
 def params(target):
@@ -87,3 +88,16 @@ def test_lz4_reference_sizes(oracle, golden):
         assert len(c) == int(ref_size)
         n, out = oracle.lz4_decompress(c, len(d))
         assert n == len(d) and (out == d).all()
+
+
+@pytest.mark.parametrize("nbytes,target", [(1000, 65536), (1 << 20, 32768), (64 << 20, 65536)])
+def test_survey_probed_reference_values(oracle, nbytes, target):
+    """chunk counts, first chunks and hashes the survey measured on the reference for xorshift64 streams."""
+    from longtail_amd.lib import chunker_params
+    from tests.survey_vectors import EXPECTED, xorshift_stream
+
+    count, first = EXPECTED[(nbytes, target)]
+    off, lens, hashes = oracle.chunk_and_hash(xorshift_stream(nbytes), *chunker_params(target))
+    assert len(lens) == count
+    got = [(int(o), int(l), int(h)) for o, l, h in zip(off[: len(first)], lens[: len(first)], hashes[: len(first)])]
+    assert got == first
