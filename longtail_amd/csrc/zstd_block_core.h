@@ -923,23 +923,52 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
         ZB_PAR_FOR(i, 256u) sh->lit_hist[i] = 0;
         ZB_SYNC();
     }
+    /* The literal histogram is taken PER HUFFMAN STREAM (the four quarters of the literals), two 16-bit counters to a word
+     * (a stream has at most 32 768 literals): the streams' bit totals then follow from the code lengths without a second
+     * pass over the literals.  The counters borrow the FSE state tables, which are not built before the totals are taken. */
+    uint32_t* const hist4 = (uint32_t*)sh->state_tab; /* [2][256]: streams 0|1 and 2|3 */
+    const uint32_t qseg = (nlit + 3u) >> 2;           /* literals per stream (the last one takes the rest) */
+    ZB_PAR_FOR(i, 512u) hist4[i] = 0;
+    ZB_SYNC();
     for (uint32_t u = 0; u < in->nunits; ++u)
     {
-        /* histogram only (the unit buffers are 4 KiB aligned; bytes past nlit are masked off): most incompressible
-         * blocks stop right after it */
+        /* (the unit buffers are 4 KiB aligned; bytes past nlit are masked off) */
         const uint32_t n = sh->ulit_base[u + 1u] - sh->ulit_base[u];
+        const uint32_t kbase = sh->ulit_base[u];
         ZB_PAR_FOR(j, (n + 3u) >> 2)
         {
             const uint32_t w = zb_unit_word(in, srcmask, u, j, n);
             const uint32_t k = n - 4u * j; /* valid bytes in this word, >= 1 */
-            zb_atomic_add(&sh->lit_hist[w & 255u], 1u);
-            if (k > 1u)
-                zb_atomic_add(&sh->lit_hist[(w >> 8) & 255u], 1u);
-            if (k > 2u)
-                zb_atomic_add(&sh->lit_hist[(w >> 16) & 255u], 1u);
-            if (k > 3u)
-                zb_atomic_add(&sh->lit_hist[w >> 24], 1u);
+            const uint32_t k0 = kbase + 4u * j;
+            uint32_t st0 = (k0 >= qseg) + (k0 >= 2u * qseg) + (k0 >= 3u * qseg);
+            const uint32_t k3 = k0 + 3u;
+            const uint32_t st3 = (k3 >= qseg) + (k3 >= 2u * qseg) + (k3 >= 3u * qseg);
+            if (st0 == st3)
+            {
+                uint32_t* const h = hist4 + ((st0 >> 1) << 8);
+                const uint32_t one = 1u << ((st0 & 1u) << 4);
+                zb_atomic_add(&h[w & 255u], one);
+                if (k > 1u)
+                    zb_atomic_add(&h[(w >> 8) & 255u], one);
+                if (k > 2u)
+                    zb_atomic_add(&h[(w >> 16) & 255u], one);
+                if (k > 3u)
+                    zb_atomic_add(&h[w >> 24], one);
+            }
+            else /* a stream boundary inside the word */
+                for (uint32_t b = 0; b < 4u && b < k; ++b)
+                {
+                    const uint32_t kb = k0 + b;
+                    const uint32_t stb = (kb >= qseg) + (kb >= 2u * qseg) + (kb >= 3u * qseg);
+                    zb_atomic_add(&hist4[((stb >> 1) << 8) + ((w >> (8u * b)) & 255u)], 1u << ((stb & 1u) << 4));
+                }
         }
+    }
+    ZB_SYNC();
+    ZB_PAR_FOR(i, 256u)
+    {
+        const uint32_t a = hist4[i], b = hist4[256u + i];
+        sh->lit_hist[i] = (a & 0xFFFFu) + (a >> 16) + (b & 0xFFFFu) + (b >> 16);
     }
     ZB_SYNC();
 
@@ -971,6 +1000,32 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     {
         if (sh->v[ZV_LIT_HDR])
             zb_huffman_build(sh);
+    }
+    ZB_PAR_FOR(c, 4u) sh->part2[c] = 0;
+    ZB_SYNC();
+    /* bits of the four Huffman streams = per-stream symbol counts x code lengths (before the tree description and the FSE
+     * tables, which reuse the counters' memory) */
+    if (sh->v[ZV_HUF_OK])
+    {
+        ZB_PAR_FOR(i, 256u)
+        {
+            const uint32_t a = hist4[i], b = hist4[256u + i], l = sh->huf_len[i];
+            if (a | b)
+            {
+                if (a & 0xFFFFu)
+                    zb_atomic_add(&sh->part2[0], (a & 0xFFFFu) * l);
+                if (a >> 16)
+                    zb_atomic_add(&sh->part2[1], (a >> 16) * l);
+                if (b & 0xFFFFu)
+                    zb_atomic_add(&sh->part2[2], (b & 0xFFFFu) * l);
+                if (b >> 16)
+                    zb_atomic_add(&sh->part2[3], (b >> 16) * l);
+            }
+        }
+    }
+    ZB_SYNC();
+    ZB_SERIAL(zl)
+    {
         if (sh->v[ZV_HUF_OK]) /* uses table slot 0 as work space: must precede the FSE tables below */
             sh->v[ZV_TREE_BYTES] = zb_write_huf_tree(sh, sh->tree);
     }
@@ -1022,29 +1077,8 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     ZB_SYNC();
 
     ZB_MARK(3);
-    /* ---- phase 3: bits of the four Huffman streams: lane-strided sums (coalesced reads, independent table look-ups) ---- */
+    /* ---- (phase 3, the streams' bit totals, is folded into the histogram: see above) ---- */
     const uint32_t seg = (nlit + 3u) >> 2;
-    if (sh->v[ZV_HUF_OK])
-    {
-        ZB_PAR_FOR(c, 4u) sh->part2[c] = 0;
-        ZB_SYNC();
-        for (uint32_t st = 0; st < 4u; ++st)
-        {
-            const uint32_t s0 = st * seg < nlit ? st * seg : nlit;
-            const uint32_t s1 = st == 3u ? nlit : (s0 + seg < nlit ? s0 + seg : nlit);
-            uint32_t bits = 0;
-            if (s0 + zl < s1)
-            {
-                ZbLitReader lr;
-                zb_lit_open(&lr, in, srcmask, sh->ulit_base, in->nunits, s0 + zl);
-                for (uint32_t k = s0 + zl; k < s1; k += ZB_LANES)
-                    bits += sh->huf_len[zb_lit_get(&lr, k)];
-            }
-            if (bits)
-                zb_atomic_add(&sh->part2[st], bits);
-        }
-    }
-    ZB_SYNC();
 
     ZB_MARK(4);
     /* ---- phase 4 (lane 0): decide the literals mode, write every header, lay out the bit streams ---- */
