@@ -233,10 +233,11 @@ class Context:
         self._check(err, "lthip_chunk_hash")
         return (int(total.value) if sync else None), offs, lens, hashes, first
 
-    def hash_ranges(self, data, offsets, lens, max_len: int = 0):
+    def hash_ranges(self, data, offsets, lens, max_len: int = 0, out=None):
         torch = self.torch
         n = int(offsets.numel())
-        out = torch.empty(max(1, n), dtype=torch.int64, device=self._dev())
+        if out is None:
+            out = torch.empty(max(1, n), dtype=torch.int64, device=self._dev())
         self._check(
             self.lib.dll.lthip_hash_ranges(self.h, _ptr(data), n, _ptr(offsets), _ptr(lens), max_len, _ptr(out)),
             "lthip_hash_ranges",
