@@ -243,10 +243,10 @@ __device__ __forceinline__ void lz4_coop_sequence(const uint8_t* __restrict__ sb
 // K5.  A workgroup of G waves owns one WINDOW GROUP = G consecutive sub-segments ("units", default 8 x 4 KiB) of one
 // block, staged once into LDS.  Wave w parses unit w sequentially (LZ4 parsing is a chain), may match against ANY
 // earlier byte of the group (units 0..w-1 are plain history for it, like the preceding bytes of a 32 KiB segment),
-// and uses a PRIVATE 2048-entry table so the result does not depend on the other waves' timing.  The table learns
+// and uses a PRIVATE table (TAB entries) so the result does not depend on the other waves' timing.  The table learns
 // the history lazily: every wave first parses PROBE batches with an empty table; if any wave of the group finds a
 // match the data is taken to be compressible and each wave inserts the positions before its unit (newer entries
-// kept), otherwise (incompressible data) nobody pays for it.  16 waves per CU instead of 4 at the same window.
+// kept), otherwise (incompressible data) nobody pays for it.  24 waves per CU instead of 4 at the same window.
 constexpr int LZ4_G = 8;
 constexpr int LZ4_PROBE_BATCHES = 4;
 constexpr uint32_t Z_PIECE = 128u << 10; // zstd Block_Maximum_Size (ZB_BLOCK_MAX of zstd_block_core.h, asserted in k_zstd.hip)
@@ -1433,8 +1433,8 @@ static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* s
     return 0;
 }
 
-// default geometry: 8 waves x 4 KiB units share a 32 KiB window; 32 KiB data + 8 x 4 KiB tables = 64 KiB of LDS per
-// workgroup -> 2 workgroups = 16 waves per CU
+// default geometry: 8 waves x 4 KiB units share a 32 KiB window; 32 KiB data + 8 x 2.5 KiB tables = 53 KiB of LDS per
+// workgroup -> 3 workgroups = 24 waves per CU
 static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                               const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets, const uint32_t* dst_caps,
                               uint32_t* d_out_sizes, int segment_log2);
