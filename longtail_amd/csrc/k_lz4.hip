@@ -1137,15 +1137,16 @@ __global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict
             wa = a & ~(I)15;
             const I end = n + (I)head; // first aligned offset past the payload
             __syncthreads();
+            uint4 q[4]; // four loads in flight; vectors past the payload re-read the window's first one (their bytes are never used)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
             {
                 const I o = wa + 16 * (I)(u * 64 + lane);
-                uint4 q = make_uint4(0, 0, 0, 0);
-                if (o < end)
-                    q = *reinterpret_cast<const uint4*>(in_al + (int64_t)o);
-                reinterpret_cast<uint4*>(s_in)[u * 64 + lane] = q;
+                q[u] = *reinterpret_cast<const uint4*>(in_al + (int64_t)(o < end ? o : wa));
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                reinterpret_cast<uint4*>(s_in)[u * 64 + lane] = q[u];
             __syncthreads();
         }
         return (uint32_t)(a - wa);
@@ -1285,20 +1286,35 @@ __global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict
                 }
                 const uint32_t tk = __builtin_amdgcn_readlane(w, (int)d);
                 const I lit = (I)(tk >> 4), mlc = (I)(tk & 15u);
-                // exactly the conditions under which the general code below takes its plain path for this token
-                if (lit < 15 && mlc < 15 && !(op + lit > cap - 12 || ip + 1 + lit > n - 8) && op + lit + mlc + 4 <= cap - 5)
+                // exactly the conditions under which the general code below takes its plain path for this token; a match
+                // length with ONE extension byte (19..272 bytes) is still read from the window
+                if (lit < 15 && !(op + lit > cap - 12 || ip + 1 + lit > n - 8))
                 {
-                    const uint32_t off = __builtin_amdgcn_readlane(w, (int)(d + 1 + lit)) | (__builtin_amdgcn_readlane(w, (int)(d + 2 + lit)) << 8);
-                    if (off == 0 || (I)off > op + lit)
-                        break;
-                    const I rel = (I)lane - d - 1; // my byte is literal `rel` of this sequence
-                    if (rel >= 0 && rel < lit)
-                        s_ring[RING((uint32_t)op + (uint32_t)rel)] = (uint8_t)w;
-                    op += lit;
-                    copy_match(off, mlc + 4);
-                    ip += 3 + lit;
-                    DEC_CNT(10);
-                    continue;
+                    I ml = mlc + 4, adv = 3 + lit;
+                    bool fast = true;
+                    if (mlc == 15)
+                    {
+                        // its position ip + 3 + lit <= n - 6 satisfies the general path's "ip < n - 4" test by construction
+                        const I e = d + 3 + lit;
+                        const uint32_t v = e <= 63 ? (uint32_t)__builtin_amdgcn_readlane(w, (int)(e <= 63 ? e : 0)) : 255u;
+                        fast = v != 255u;
+                        ml += (I)v;
+                        adv += 1;
+                    }
+                    if (fast && op + lit + ml <= cap - 5)
+                    {
+                        const uint32_t off = __builtin_amdgcn_readlane(w, (int)(d + 1 + lit)) | (__builtin_amdgcn_readlane(w, (int)(d + 2 + lit)) << 8);
+                        if (off == 0 || (I)off > op + lit)
+                            break;
+                        const I rel = (I)lane - d - 1; // my byte is literal `rel` of this sequence
+                        if (rel >= 0 && rel < lit)
+                            s_ring[RING((uint32_t)op + (uint32_t)rel)] = (uint8_t)w;
+                        op += lit;
+                        copy_match(off, ml);
+                        ip += adv;
+                        DEC_CNT(10);
+                        continue;
+                    }
                 }
             }
             const uint32_t token = byte_at(ip++);
