@@ -364,3 +364,37 @@ def test_lz4_gpu_decoder_differential_fuzz(gpu, oracle):
             assert int(s) == n and (host[o : o + n] == out[:n]).all()
             accepted += 1
     assert 8 <= accepted < len(cases)
+
+
+def test_lz4_gpu_decoder_structured_cases(gpu, oracle):
+    """The decoder's internal boundaries, one by one: overlapping matches of every small period (lane-modulo path), periods
+    around 64 (step path), offsets around the 8 KiB output ring and at the format's maximum, matches longer than a ring
+    segment, literal runs longer than the payload window, output sizes around the 2 KiB flush granule and odd alignments."""
+    rng = np.random.default_rng(123)
+    raws = []
+    for period in (1, 2, 3, 7, 31, 62, 63, 64, 65, 127, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193, 16384, 65534, 65535):
+        seed = rng.integers(0, 256, period, dtype=np.uint8)
+        reps = max(3, 150000 // period)
+        raws.append(np.concatenate([np.tile(seed, reps), rng.integers(0, 256, 13, dtype=np.uint8)]))
+    raws.append(np.concatenate([rng.integers(0, 256, 20000, dtype=np.uint8), np.zeros(300000, np.uint8), rng.integers(0, 256, 5000, dtype=np.uint8)]))
+    for n in (2047, 2048, 2049, 4095, 4096, 4097, 6143, 6144, 6145):  # flush granule
+        raws.append(np.concatenate([np.zeros(n - 20, np.uint8), rng.integers(0, 256, 20, dtype=np.uint8)]))
+    comps = [oracle.lz4_compress(r) for r in raws]
+    for shift in (0, 1, 5, 15):  # source / destination alignment relative to 16 bytes
+        offs, pos = [], shift
+        for c in comps:
+            offs.append(pos)
+            pos += len(c) + 16 + shift
+        host = np.zeros(pos + 64, np.uint8)
+        for o, c in zip(offs, comps):
+            host[o : o + len(c)] = c
+        dev = torch.from_numpy(host).cuda()
+        d_offs, total = layout([np.zeros(len(r) + 32, np.uint8) for r in raws])
+        d_offs = [o + shift for o in d_offs]
+        dst = torch.full((total + 64 + shift,), 0xCD, dtype=torch.uint8, device="cuda")
+        sizes = u32(gpu.lz4_decompress_blocks(dev, offs, [len(c) for c in comps], dst, d_offs, [len(r) for r in raws]))
+        out = dst.cpu().numpy()
+        for r, o, s in zip(raws, d_offs, sizes):
+            assert int(s) == len(r)
+            assert (out[o : o + len(r)] == r).all()
+            assert (out[o + len(r) : o + len(r) + 8] == 0xCD).all()  # nothing written past the block
