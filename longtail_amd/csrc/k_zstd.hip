@@ -13,6 +13,13 @@
 #define ZB_LANES 64u
 #define ZB_FN __device__ __forceinline__ /* inlined so that LDS / global address spaces are known at every access */
 #define ZB_SYNC() __syncthreads() /* the encoder runs in one-wave workgroups */
+/* LDS traffic of ONE wave is executed in program order: only the compiler has to be kept from moving it */
+#define ZB_SYNC_LDS()                                          \
+    do                                                         \
+    {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
 __device__ __forceinline__ void zb_atomic_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 __device__ __forceinline__ void zb_atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 // exclusive prefix sum over the 64 lanes of the (single-wave) workgroup, lane 0 first
@@ -42,6 +49,7 @@ __device__ unsigned long long g_zb_last[1 << 16];
             g_zb_last[blockIdx.x] = now__;                                                             \
         }                                                                                              \
     } while (0)
+#define ZD_MARK(i) ZB_MARK(i)
 #endif
 #include "zstd_decode_core.h" /* includes zstd_block_core.h */
 
@@ -387,6 +395,10 @@ __global__ __launch_bounds__(64) void k_zstd_decode(const uint8_t* __restrict__ 
     for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x)
     {
         const ZBlock blk = blocks[b];
+#ifdef LTHIP_ZB_PROF
+        if (threadIdx.x == 0)
+            g_zb_last[blockIdx.x] = wall_clock64();
+#endif
         const uint32_t n = zd_decode_payload(src + blk.src_off, blk.size, dst + blk.dst_off, blk.dst_cap, lits, &sh, threadIdx.x);
         if (threadIdx.x == 0)
             out_sizes[b] = n; // ZD_ERROR (0xFFFFFFFF) for malformed input, like lthip_lz4_decompress_blocks

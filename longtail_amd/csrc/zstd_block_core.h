@@ -30,6 +30,9 @@
 
 #include <stdint.h>
 
+#ifndef ZB_SYNC_LDS /* orders the lanes' LDS (shared-struct) accesses only; the host model needs nothing */
+#define ZB_SYNC_LDS() ZB_SYNC()
+#endif
 #ifndef ZB_DBG
 #define ZB_DBG 0u /* host model only: 1 raw literals, 2 never predefined, 4 never FSE-compressed tables, 8 no sampled noise test */
 #endif

@@ -203,6 +203,10 @@ ZB_FN int zd_build_fse(ZdFse* t, const int16_t* norm, uint32_t maxsym, uint32_t 
     return 0;
 }
 
+#ifndef ZD_MARK
+#define ZD_MARK(i) ((void)0) /* profiling hook of the kernel build */
+#endif
+
 /* ---- backward bit reader: the stream ends with a 1 bit followed by zero padding ---- */
 typedef struct ZdBack
 {
@@ -406,9 +410,32 @@ ZB_FN int zd_huf_stream(const ZdShared* sh, const uint8_t* p, uint32_t size, uin
 {
     ZdBack br;
     const uint32_t tl = sh->huf_log;
+    uint32_t i = 0;
     if (zd_back_open(&br, p, size))
         return 1;
-    for (uint32_t i = 0; i < count; ++i)
+    /* Four symbols per refill while at least 64 bits are left (4 x huf_log <= 44 of the >= 57 bits of one 8-byte load, so no
+     * symbol of a group can run out of bits and nothing has to be checked inside it); the careful loop below finishes the
+     * stream and reports every malformation exactly as before. */
+    while (count - i >= 4u && br.pos >= 64u)
+    {
+        const uint32_t b0 = ((br.pos + 7u) >> 3) - 8u; /* the 8 bytes that end at the byte holding bit pos-1 */
+        uint64_t t;
+        uint32_t used = 0, packed = 0;
+        __builtin_memcpy(&t, p + b0, 8);
+        t <<= (8u - (br.pos & 7u)) & 7u; /* bit pos-1 on top */
+        for (uint32_t k = 0; k < 4u; ++k)
+        {
+            const uint32_t e = sh->huf[(uint32_t)(t >> (64u - tl))];
+            const uint32_t nb = e >> 8;
+            t <<= nb;
+            used += nb;
+            packed |= (e & 255u) << (8u * k);
+        }
+        __builtin_memcpy(out + i, &packed, 4);
+        br.pos -= used;
+        i += 4u;
+    }
+    for (; i < count; ++i)
     {
         /* peek tl bits (zero-filled below the start), consume only the code's length */
         uint32_t idx;
@@ -598,6 +625,7 @@ ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t*
             else
             {
                 /* ---------------- Compressed_Block ---------------- */
+                ZD_MARK(11);
                 const uint8_t* blk = src + ip;
                 uint32_t nlit = 0, lit_mode = 0, lit_src = 0, lit_csize = 0, lit_hdr = 0, seq_pos = 0;
                 if (bsize > src_size - ip || bsize < 2u)
@@ -708,6 +736,7 @@ ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t*
                 ZB_SYNC();
                 if (sh->v[ZDV_ERR])
                     return ZD_FAIL_AT(sh);
+                ZD_MARK(12);
                 /* sequences section */
                 seq_pos = lit_hdr + lit_csize;
                 {
@@ -796,6 +825,11 @@ ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t*
                                         ZD_SET_ERR(sh);
                                 }
                             }
+                            /* Output positions below `synced` are known to have landed (the last full ZB_SYNC); a match only
+                             * waits for the stores before it when its source reaches past that -- near matches do, the
+                             * others (and every literal run) are issued back to back. */
+                            uint32_t synced = out_total;
+                            ZD_MARK(13); /* 12: literals section, 13: sequence tables + setup */
                             for (uint32_t n = 0; n < nbseq; ++n)
                             {
                                 uint32_t ll, ml, off;
@@ -850,7 +884,8 @@ ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t*
                                         sh->v[ZDV_OFF] = o;
                                     }
                                 }
-                                ZB_SYNC();
+                                ZB_SYNC_LDS();
+                                ZD_MARK(14); /* sequence decode (lane 0) */
                                 if (sh->v[ZDV_ERR])
                                     return ZD_FAIL_AT(sh);
                                 ll = sh->v[ZDV_LL];
@@ -860,7 +895,15 @@ ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t*
                                     uint8_t* o = dst + out_total;
                                     const uint8_t* l = lits + litpos;
                                     ZB_PAR_FOR(i, ll) o[i] = l[i];
-                                    ZB_SYNC(); /* a match may start inside the literals just written */
+                                    {
+                                        const uint32_t mpos = out_total + ll;
+                                        const uint32_t src_hi = off >= ml ? mpos - off + ml : mpos; /* one past the last byte read */
+                                        if (src_hi > synced)
+                                        {
+                                            ZB_SYNC(); /* the match reads bytes (maybe the literals just written) that are in flight */
+                                            synced = mpos;
+                                        }
+                                    }
                                     {
                                         uint8_t* m = o + ll;
                                         const uint8_t* ref = m - off;
@@ -876,8 +919,10 @@ ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t*
                                 }
                                 litpos += ll;
                                 out_total += ll + ml;
-                                ZB_SYNC();
+                                ZB_SYNC_LDS(); /* lane 0 rewrites the sequence slots next */
+                                ZD_MARK(15); /* copies */
                             }
+                            ZB_SYNC();
                             /* literals after the last sequence */
                             if (nlit - litpos > dst_cap - out_total)
                                 return ZD_FAIL_AT(sh);
