@@ -844,9 +844,40 @@ ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t*
                                         uint32_t ov, o;
                                         if (oc > 31u || lc > 35u || mc > 52u)
                                             ZD_SET_ERR(sh);
+                                        /* All bit fields of a sequence -- offset, match length and literal length extra bits,
+                                         * then the three state updates -- come out of ONE 8-byte load when they add up to at
+                                         * most 56 bits and 64 bits are left (nothing can run out, so nothing is checked); the
+                                         * field-by-field reader handles everything else, and every malformation. */
+                                        const uint32_t ob = oc & 31u, mb = zb_ml_bits(mc & 63u), lb = zb_ll_bits(lc & 63u);
+                                        const uint32_t more = n + 1u < nbseq ? 1u : 0u;
+                                        const uint32_t nbl = more ? fl->nb[st[ZT_LL]] : 0u, nbm = more ? fm->nb[st[ZT_ML]] : 0u,
+                                                       nbo = more ? fo->nb[st[ZT_OF]] : 0u;
+                                        const uint32_t total = ob + mb + lb + nbl + nbm + nbo;
+                                        uint64_t t = 0;
+                                        const int fastbits = total <= 56u && br.pos >= 64u && !sh->v[ZDV_ERR];
+                                        if (fastbits)
+                                        {
+                                            const uint32_t b0 = ((br.pos + 7u) >> 3) - 8u;
+                                            __builtin_memcpy(&t, br.p + b0, 8);
+                                            t <<= (8u - (br.pos & 7u)) & 7u; /* bit pos-1 on top */
+                                            br.pos -= total;
+                                        }
+#define ZD_TAKE(nb) ((uint32_t)((t >> 1) >> (63u - (nb)))) /* the top nb bits (0 for nb == 0) */
+                                        if (fastbits)
+                                        {
+                                            ov = (1u << ob) + ZD_TAKE(ob);
+                                            t <<= ob;
+                                            ml = zb_ml_base(mc) + 3u + ZD_TAKE(mb);
+                                            t <<= mb;
+                                            ll = zb_ll_base(lc) + ZD_TAKE(lb);
+                                            t <<= lb;
+                                        }
+                                        else
+                                        {
                                         ov = (1u << (oc & 31u)) + zd_back_read32(&br, oc & 31u);
                                         ml = zb_ml_base(mc) + 3u + zd_back_read(&br, zb_ml_bits(mc));
                                         ll = zb_ll_base(lc) + zd_back_read(&br, zb_ll_bits(lc));
+                                        }
                                         if (ov > 3u)
                                         {
                                             o = ov - 3u;
@@ -868,12 +899,24 @@ ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t*
                                                 sh->rep[0] = o;
                                             }
                                         }
-                                        if (n + 1u < nbseq)
+                                        if (fastbits)
+                                        {
+                                            if (more)
+                                            {
+                                                st[ZT_LL] = fl->base[st[ZT_LL]] + ZD_TAKE(nbl);
+                                                t <<= nbl;
+                                                st[ZT_ML] = fm->base[st[ZT_ML]] + ZD_TAKE(nbm);
+                                                t <<= nbm;
+                                                st[ZT_OF] = fo->base[st[ZT_OF]] + ZD_TAKE(nbo);
+                                            }
+                                        }
+                                        else if (n + 1u < nbseq)
                                         {
                                             st[ZT_LL] = fl->base[st[ZT_LL]] + zd_back_read(&br, fl->nb[st[ZT_LL]]);
                                             st[ZT_ML] = fm->base[st[ZT_ML]] + zd_back_read(&br, fm->nb[st[ZT_ML]]);
                                             st[ZT_OF] = fo->base[st[ZT_OF]] + zd_back_read(&br, fo->nb[st[ZT_OF]]);
                                         }
+#undef ZD_TAKE
                                         if (br.over || o == 0u || ll > nlit - litpos || ll > dst_cap - out_total ||
                                             ml > dst_cap - out_total - ll || o > out_total - frame_start_out + ll)
                                             ZD_SET_ERR(sh);
