@@ -73,6 +73,8 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 // ---------------------------------------------------------------------------------------------------
 // K5
 // ---------------------------------------------------------------------------------------------------
+// four bytes at any byte position of the LDS window: two aligned reads (one ds_read2_b32) and a v_alignbyte.  A single
+// unaligned ds_read_b32 is legal on gfx950 but measured slower (K5 +15 %: the LDS splits misaligned dwords expensively).
 __device__ __forceinline__ uint32_t lds_read32(const uint32_t* sdata, uint32_t byte_idx)
 {
     const uint32_t w = byte_idx >> 2;
@@ -471,12 +473,17 @@ __global__ __launch_bounds__(64 * LZ4_G, 6) void k_lz4_segments(const uint8_t* _
         {
             uint32_t best = 0;
             bool found = false;
+            // the four exchanges are issued together (one LDS round trip instead of four); a valid lane's lower neighbours
+            // are valid too (their positions are smaller), so their validity needs no exchange
+            uint32_t ovs[4];
 #pragma unroll
-            for (int d = 8; d >= 1; d >>= 1) // smallest distance wins (assigned last)
+            for (int t = 0; t < 4; ++t)
+                ovs[t] = __shfl_up(v, 8 >> t, 64);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) // smallest distance wins (assigned last)
             {
-                const uint32_t ov = __shfl_up(v, d, 64);
-                const bool ovalid = __shfl_up((int)valid, d, 64) != 0;
-                if (valid && lane >= d && ovalid && ov == v)
+                const int d = 8 >> t;
+                if (valid && lane >= d && ovs[t] == v)
                 {
                     best = p - (uint32_t)d * stride;
                     found = true;
