@@ -162,17 +162,27 @@ __device__ __forceinline__ void lz4_coop_sequence(const uint8_t* __restrict__ sb
         mlen += nf;
         if (nf == 32u)
         {
+            // the match goes on: 256 bytes per LDS round trip (a dword pair per lane)
+            const uint32_t* sdata = reinterpret_cast<const uint32_t*>(sbytes);
             for (;;)
             {
-                const uint32_t i = pf + mlen + (uint32_t)lane;
-                const bool same = i < end_limit && sbytes[i + head] == sbytes[cf + mlen + (uint32_t)lane + head];
-                const uint64_t diff = __builtin_amdgcn_ballot_w64(!same);
+                const uint32_t i = pf + mlen + 4u * (uint32_t)lane;
+                uint32_t cnt = 0; // equal bytes of my four, as far as the unit goes
+                if (i < end_limit)
+                {
+                    const uint32_t x = lds_read32(sdata, i + head) ^ lds_read32(sdata, cf + mlen + 4u * (uint32_t)lane + head);
+                    const uint32_t lim = end_limit - i < 4u ? end_limit - i : 4u;
+                    cnt = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+                    cnt = cnt < lim ? cnt : lim;
+                }
+                const uint64_t diff = __builtin_amdgcn_ballot_w64(cnt < 4u);
                 if (diff)
                 {
-                    mlen += (uint32_t)__builtin_ctzll(diff);
+                    const int f = __builtin_ctzll(diff);
+                    mlen += 4u * (uint32_t)f + __builtin_amdgcn_readlane(cnt, f);
                     break;
                 }
-                mlen += 64u;
+                mlen += 256u;
             }
         }
         if (nb == 32u && room > 32u)
