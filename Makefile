@@ -13,12 +13,18 @@ LIB     := longtail_amd/liblongtail_hip.so
 HIP_SRC := $(CSRC)/lthip_ctx.hip $(CSRC)/k_buzhash.hip $(CSRC)/k_blake3.hip $(CSRC)/k_lz4.hip $(CSRC)/k_zstd.hip \
            $(CSRC)/k_dedup.hip $(CSRC)/k_gather.hip $(CSRC)/k_synth.hip $(CSRC)/version_index.hip
 C_SRC   := $(CSRC)/plugin/plugin_common.c $(CSRC)/plugin/plugin_chunker.c $(CSRC)/plugin/plugin_hash.c \
-           $(CSRC)/plugin/plugin_codec.c
+           $(CSRC)/plugin/plugin_codec.c $(CSRC)/plugin/build_id.c
 HIP_OBJ := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(HIP_SRC))
 C_OBJ   := $(patsubst $(CSRC)/plugin/%.c,$(OBJDIR)/%.o,$(C_SRC))
 
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function
-CFLAGS   := -O2 -std=c99 -D_POSIX_C_SOURCE=200809L -fPIC -fvisibility=hidden -Wall -Wextra -pthread
+GENDIR  := build/gen
+# header dependencies come from the compilers (-MMD -MP -> build/obj/*.d), never from a hand-written list: a header edit
+# rebuilds exactly the objects that include it
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -Iinclude -MMD -MP
+CFLAGS   := -O2 -std=c99 -D_POSIX_C_SOURCE=200809L -fPIC -fvisibility=hidden -Wall -Wextra -pthread -Iinclude -I$(GENDIR) -MMD -MP
+
+# identity of the source tree (tools/build_id.py), refreshed on every make run; the stamp only changes when a source does
+BUILD_ID := $(shell python3 tools/build_id.py --stamp $(GENDIR)/build_id.h)
 
 .PHONY: lib oracle all clean prof
 lib: $(LIB)
@@ -27,11 +33,13 @@ all: lib oracle
 $(OBJDIR):
 	mkdir -p $(OBJDIR)
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/lthip_internal.h $(CSRC)/zstd_block_core.h include/longtail_hip.h include/longtail_abi.h include/longtail_synth.h | $(OBJDIR)
+$(OBJDIR)/%.o: $(CSRC)/%.hip | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(OBJDIR)/%.o: $(CSRC)/plugin/%.c $(CSRC)/plugin/plugin_common.h include/longtail_hip.h include/longtail_abi.h | $(OBJDIR)
+$(OBJDIR)/%.o: $(CSRC)/plugin/%.c | $(OBJDIR)
 	$(CC) $(CFLAGS) -c $< -o $@
+
+-include $(HIP_OBJ:.o=.d) $(C_OBJ:.o=.d)
 
 $(LIB): $(HIP_OBJ) $(C_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJ) $(C_OBJ) -lpthread

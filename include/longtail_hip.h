@@ -84,6 +84,9 @@ LTHIP_EXPORT void lthip_ctx_destroy(lthip_ctx* ctx);
 LTHIP_EXPORT int lthip_ctx_sync(lthip_ctx* ctx);
 LTHIP_EXPORT const char* lthip_ctx_error(const lthip_ctx* ctx); /* text of the last failure */
 LTHIP_EXPORT int lthip_device_count(void);
+/* Identity of the sources the library was built from: the first 16 hex digits of the sha256 tools/build_id.py computes over
+ * longtail_amd/csrc/ and include/.  A test recomputes it from the tree, so a stale binary cannot pass for HEAD. */
+LTHIP_EXPORT const char* lthip_build_id(void);
 
 /* Memory helpers so that plain-C callers (the plugin layer) need no HIP headers.  Copies are
  * asynchronous on the context's stream: lthip_ctx_sync() before reading a d2h destination. */

@@ -86,6 +86,7 @@ class HipLib:
         sig("lthip_ctx_sync", i32, [vp])
         sig("lthip_ctx_error", C.c_char_p, [vp])
         sig("lthip_device_count", i32, [])
+        sig("lthip_build_id", C.c_char_p, [])
         sig("lthip_malloc_device", i32, [vp, sz, P(vp)])
         sig("lthip_free_device", None, [vp, vp])
         sig("lthip_malloc_pinned", i32, [vp, sz, P(vp)])
@@ -123,6 +124,9 @@ class HipLib:
 
     def device_count(self) -> int:
         return int(self.dll.lthip_device_count())
+
+    def build_id(self) -> str:
+        return self.dll.lthip_build_id().decode()
 
 
 _lib: Optional[HipLib] = None

@@ -25,6 +25,17 @@ def test_header_symbols_are_exported(hiplib):
     assert not missing, missing
 
 
+def test_library_is_built_from_this_tree(hiplib):
+    """lthip_build_id() is the hash of csrc/ + include/ the Makefile baked in; a stale .so (round 1: k_zstd.o older than
+    zstd_decode_core.h) must fail here and in tests/test_gpu_build_id.py on the GPU box."""
+    import sys
+
+    sys.path.insert(0, str(ROOT / "tools"))
+    from build_id import build_id
+
+    assert hiplib.build_id() == build_id(ROOT), "liblongtail_hip.so was not built from the sources beside it: run make"
+
+
 def test_no_gpu_means_loud_failure(hiplib):
     """In the build container there is no GPU: every constructor must refuse instead of falling back to the CPU."""
     import torch
