@@ -71,6 +71,8 @@ int lto_lz4_decompress(const uint8_t* src, int n, uint8_t* dst, int cap);
 /* ---- synthetic data (include/longtail_synth.h; not reference-derived) ---- */
 void lto_synth_fill(uint8_t* dst, uint64_t nbytes, uint64_t seed, uint64_t byte_offset, int kind);
 uint64_t lto_synth_asset_seed(uint64_t tree_seed, uint64_t index);
+/* SURVEY.md §8(c,d)'s xorshift64 stream: s ^= s << 13; s ^= s >> 7; s ^= s << 17, the state after each step as 8 LE bytes */
+void lto_xorshift_fill(uint8_t* dst, uint64_t nbytes, uint64_t seed);
 
 /* ---- whole-path CPU timing leg for bench.py (single thread): chunk + hash + lz4 over parts ---- */
 struct lto_ingest_result

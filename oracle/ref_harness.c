@@ -29,7 +29,7 @@
 #include <time.h>
 #include <unistd.h>
 
-int refh_version(void) { return 2; }
+int refh_version(void) { return 3; }
 
 /* ------------------------------------------------------------------------------------------------
  * algorithm probes through the reference's plugin structs
@@ -122,6 +122,78 @@ int64_t refh_chunk_stream(struct Longtail_ChunkerAPI* chunker_api, struct Longta
 done:
     SAFE_DISPOSE_API(own_c);
     SAFE_DISPOSE_API(own_h);
+    return count;
+}
+
+/* A feeder that serves `fail_at` bytes and then fails with `fail_errno` (a storage Read error, src/longtail.c:1950-1954).
+ * Drives NextChunk like DynamicChunking does and reports what the failing call returned: the reference turns a feeder
+ * failure into an empty range + ESPIPE (hpcdcchunker.c:244-248, 420-423).  Returns the number of chunks handed out before
+ * the failing call (their lengths in out_lens), or -1001 when a range's bytes are not the input's.
+ * out_fail[0] = errno of the failing call, [1] = range.len, [2] = range.offset, [3] = (range.buf != 0). */
+struct failing_feed
+{
+    struct mem_feed mem;
+    uint64_t fail_at;
+    int fail_errno;
+    uint32_t calls_after_failure;
+};
+
+static int failing_feeder(void* context, Longtail_ChunkerAPI_HChunker chunker, uint32_t requested_size, char* buffer,
+                          uint32_t* out_size)
+{
+    struct failing_feed* f = (struct failing_feed*)context;
+    if (f->mem.pos >= f->fail_at)
+    {
+        ++f->calls_after_failure;
+        return f->fail_errno;
+    }
+    if (f->mem.pos + requested_size > f->fail_at)
+        requested_size = (uint32_t)(f->fail_at - f->mem.pos);
+    return mem_feeder(&f->mem, chunker, requested_size, buffer, out_size);
+}
+
+int64_t refh_chunk_stream_failing_feeder(struct Longtail_ChunkerAPI* chunker_api, const uint8_t* data, uint64_t size,
+                                         uint32_t min, uint32_t avg, uint32_t max, uint64_t fail_at, int fail_errno,
+                                         uint32_t* out_lens, uint64_t cap, uint64_t* out_fail)
+{
+    struct Longtail_ChunkerAPI* own_c = 0;
+    int64_t count = 0;
+    uint64_t expect = 0;
+    if (!chunker_api)
+        chunker_api = own_c = Longtail_CreateHPCDCChunkerAPI();
+    Longtail_ChunkerAPI_HChunker c = 0;
+    int err = chunker_api->CreateChunker(chunker_api, min, avg, max, &c);
+    if (err)
+    {
+        SAFE_DISPOSE_API(own_c);
+        return -err;
+    }
+    struct failing_feed f = {{data, size, 0}, fail_at, fail_errno, 0};
+    for (;;)
+    {
+        struct Longtail_Chunker_ChunkRange r = {(const uint8_t*)1, 77, 77};
+        err = chunker_api->NextChunk(chunker_api, c, failing_feeder, &f, &r);
+        if (err)
+        {
+            out_fail[0] = (uint64_t)err;
+            out_fail[1] = r.len;
+            out_fail[2] = r.offset;
+            out_fail[3] = r.buf != 0;
+            break;
+        }
+        if (r.offset != expect || r.len == 0 || memcmp(r.buf, data + r.offset, r.len) != 0)
+        {
+            count = -1001;
+            break;
+        }
+        if ((uint64_t)count < cap)
+            out_lens[count] = r.len;
+        expect += r.len;
+        ++count;
+    }
+    /* the handle must stay usable for DisposeChunker after a failure (src/longtail.c:2296) */
+    chunker_api->DisposeChunker(chunker_api, c);
+    SAFE_DISPOSE_API(own_c);
     return count;
 }
 
@@ -360,6 +432,69 @@ int refh_version_index(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_
         *out_size = sz;
     }
     Longtail_Free(vi);
+    SAFE_DISPOSE_API(own_c);
+    SAFE_DISPOSE_API(own_h);
+    tree_free(&t);
+    return err;
+}
+
+/* Longtail_CreateVersionIndex under cancellation (test/test.cpp:4733-4837 TestCreateVersionCancelOperation): the token is
+ * cancelled before the call (cancel_after_progress == 0) or from the progress callback after that many OnProgress calls,
+ * i.e. while chunking jobs are in flight on the bikeshed workers.  Returns the error of Longtail_CreateVersionIndex
+ * (ECANCELED expected); *out_index_is_null tells whether the output pointer stayed 0. */
+struct cancel_progress
+{
+    struct Longtail_ProgressAPI api;
+    struct Longtail_CancelAPI* cancel_api;
+    Longtail_CancelAPI_HCancelToken token;
+    uint32_t calls, cancel_after;
+};
+
+static void cancel_progress_dispose(struct Longtail_API* a) { (void)a; }
+static void cancel_progress_on(struct Longtail_ProgressAPI* a, uint32_t total, uint32_t done)
+{
+    struct cancel_progress* p = (struct cancel_progress*)a;
+    (void)total;
+    (void)done;
+    if (++p->calls == p->cancel_after)
+        p->cancel_api->Cancel(p->cancel_api, p->token);
+}
+
+int refh_version_index_cancel(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_HashAPI* hash_api, uint32_t nfiles,
+                              const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
+                              uint32_t target_chunk_size, int workers, uint32_t cancel_after_progress,
+                              int* out_index_is_null, uint32_t* out_progress_calls)
+{
+    struct refh_tree t;
+    struct Longtail_ChunkerAPI* own_c = 0;
+    struct Longtail_HashAPI* own_h = 0;
+    struct Longtail_VersionIndex* vi = 0;
+    int err = tree_make(&t, nfiles, names, datas, sizes, workers, 0);
+    if (err)
+        return -err;
+    if (!chunker_api)
+        chunker_api = own_c = Longtail_CreateHPCDCChunkerAPI();
+    if (!hash_api)
+        hash_api = own_h = Longtail_CreateBlake3HashAPI();
+    struct Longtail_CancelAPI* cancel_api = Longtail_CreateAtomicCancelAPI();
+    Longtail_CancelAPI_HCancelToken token = 0;
+    cancel_api->CreateToken(cancel_api, &token);
+    struct cancel_progress prog;
+    memset(&prog, 0, sizeof prog);
+    prog.api.m_API.Dispose = cancel_progress_dispose;
+    prog.api.OnProgress = cancel_progress_on;
+    prog.cancel_api = cancel_api;
+    prog.token = token;
+    prog.cancel_after = cancel_after_progress;
+    if (cancel_after_progress == 0)
+        cancel_api->Cancel(cancel_api, token);
+    err = Longtail_CreateVersionIndex(t.storage, hash_api, chunker_api, t.jobs, cancel_after_progress ? &prog.api : 0,
+                                      cancel_api, token, t.root, t.files, t.tags, target_chunk_size, 0, &vi);
+    *out_index_is_null = vi == 0;
+    *out_progress_calls = prog.calls;
+    Longtail_Free(vi);
+    cancel_api->DisposeToken(cancel_api, token);
+    SAFE_DISPOSE_API(cancel_api);
     SAFE_DISPOSE_API(own_c);
     SAFE_DISPOSE_API(own_h);
     tree_free(&t);

@@ -125,3 +125,17 @@ int lto_ingest(const uint8_t* data, uint64_t size, uint64_t part_size, uint32_t 
     free(hashes);
     return 0;
 }
+
+void lto_xorshift_fill(uint8_t* dst, uint64_t nbytes, uint64_t seed)
+{
+    uint64_t s = seed;
+    for (uint64_t o = 0; o < nbytes; o += 8)
+    {
+        s ^= s << 13;
+        s ^= s >> 7;
+        s ^= s << 17;
+        uint64_t n = nbytes - o < 8 ? nbytes - o : 8;
+        for (uint64_t k = 0; k < n; ++k)
+            dst[o + k] = (uint8_t)(s >> (8 * k));
+    }
+}

@@ -50,6 +50,7 @@ class Oracle:
         sig("lto_lz4_decompress", i32, [vp, i32, vp, i32])
         sig("lto_synth_fill", None, [vp, u64, u64, u64, i32])
         sig("lto_synth_asset_seed", u64, [u64, u64])
+        sig("lto_xorshift_fill", None, [vp, u64, u64])
         sig("lto_ingest", i32, [vp, u64, u64, u32, u32, i32, C.POINTER(IngestResult)])
 
     # -- conveniences on numpy uint8 arrays --
@@ -94,6 +95,13 @@ class Oracle:
             self.dll.lto_synth_fill(out.ctypes.data, nbytes, seed, offset, kind)
         return out
 
+    def xorshift(self, nbytes: int, seed: int = 0x9E3779B97F4A7C15) -> np.ndarray:
+        """SURVEY.md §8(c)'s stream (tests/survey_vectors.py holds the slow Python statement of it)."""
+        out = np.zeros(nbytes, np.uint8)
+        if nbytes:
+            self.dll.lto_xorshift_fill(out.ctypes.data, nbytes, seed)
+        return out
+
     def asset_seed(self, tree_seed: int, index: int) -> int:
         return int(self.dll.lto_synth_asset_seed(tree_seed, index))
 
@@ -125,6 +133,8 @@ class Ref:
         sig("refh_ingest_time", i32, [u32, u32, vp, vp, vp, u32, u32, u32, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64),
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)])
         sig("refh_cpu_count", i32, [])
+        sig("refh_chunk_stream_failing_feeder", i64, [vp, vp, u64, u32, u32, u32, u64, i32, vp, u64, vp])
+        sig("refh_version_index_cancel", i32, [vp, vp, u32, vp, vp, vp, u32, i32, u32, C.POINTER(i32), C.POINTER(u32)])
         sig("refh_tree_file_infos", i32, [u32, vp, vp, vp, C.POINTER(vp), C.POINTER(u64)])
         sig("refh_missing_content", i32, [vp, u32, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(u64)])
         sig("refh_open_stored_block", i32, [vp, u64, u32, vp, vp, u32, vp, u64, C.POINTER(u64)])
@@ -147,6 +157,26 @@ class Ref:
         if n < 0:
             raise RuntimeError(f"refh_chunk_from_buffer failed: {n}")
         return lens[:n].copy()
+
+    def chunk_failing_feeder(self, data: np.ndarray, mn, av, mx, fail_at: int, fail_errno: int, chunker_api=None):
+        """NextChunk with a feeder that fails after fail_at bytes -> (lens handed out before, dict of the failing call)."""
+        cap = len(data) // mn + 8
+        lens = np.zeros(cap, np.uint32)
+        fail = np.zeros(4, np.uint64)
+        n = self.dll.refh_chunk_stream_failing_feeder(chunker_api, data.ctypes.data, len(data), mn, av, mx, fail_at, fail_errno,
+                                                      lens.ctypes.data, cap, fail.ctypes.data)
+        if n < 0:
+            raise RuntimeError(f"refh_chunk_stream_failing_feeder failed: {n}")
+        return lens[:n].copy(), dict(err=int(fail[0]), len=int(fail[1]), offset=int(fail[2]), has_buf=bool(fail[3]))
+
+    def version_index_cancel(self, files, target_chunk_size: int, workers: int, cancel_after_progress: int, chunker_api=None,
+                             hash_api=None):
+        """Longtail_CreateVersionIndex with a cancel token (test.cpp:4733-4837) -> (errno, index pointer stayed NULL, progress calls)."""
+        n, c_names, c_datas, c_sizes, keep = self._tree_args(files)
+        is_null, calls = i32(0), u32(0)
+        err = self.dll.refh_version_index_cancel(chunker_api, hash_api, n, c_names, c_datas, c_sizes, target_chunk_size, workers,
+                                                 cancel_after_progress, C.byref(is_null), C.byref(calls))
+        return err, bool(is_null.value), calls.value
 
     def blake3(self, data: np.ndarray) -> int:
         return int(self.dll.refh_blake3(data.ctypes.data if len(data) else None, len(data)))
