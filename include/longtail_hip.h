@@ -270,6 +270,37 @@ LTHIP_EXPORT int lthip_create_missing_content(lthip_ctx* ctx, uint64_t existing_
                                               const uint32_t* chunk_tags, uint32_t hash_identifier, uint32_t max_block_size,
                                               uint32_t max_chunks_per_block, void* out, size_t out_capacity, size_t* out_size);
 
+/* ---- multi-GPU work division, host functions -----------------------------------------------------------
+ * The unit of independence is the reference's own job: one (asset, target_chunk_size*1024-byte part) of ChunkAssets
+ * (src/longtail.c:2396-2458).  lthip_job_count / lthip_make_jobs list the jobs of a tree exactly as :2399-2404 / :2432-2457 do
+ * (asset order, 1 + size / part jobs per asset: an exact multiple ends with an empty job, a directory is one empty job).
+ * lthip_partition_jobs assigns them to ranks -- deterministic, so every rank computes the same table without communication:
+ *   LTHIP_PARTITION_RANGE  contiguous job ranges with equal byte shares (rank-major order == job order; an asset's parts may
+ *                          straddle ranks: intra-file segment sharding, BASELINE.json configs[4])
+ *   LTHIP_PARTITION_LPT    longest processing time first: jobs by size descending, each to the least loaded rank
+ *   LTHIP_PARTITION_MOD    job index mod rank_count (uniform trees)
+ * rank_bytes[r] (may be NULL) receives the bytes assigned to rank r. */
+enum lthip_partition_policy
+{
+    LTHIP_PARTITION_RANGE = 0,
+    LTHIP_PARTITION_LPT = 1,
+    LTHIP_PARTITION_MOD = 2
+};
+LTHIP_EXPORT uint64_t lthip_job_count(uint32_t asset_count, const uint64_t* asset_sizes, uint32_t target_chunk_size);
+LTHIP_EXPORT int lthip_make_jobs(uint32_t asset_count, const uint64_t* asset_sizes, uint32_t target_chunk_size, uint64_t capacity,
+                                 uint32_t* job_asset, uint64_t* job_offset /* within the asset */, uint64_t* job_size);
+LTHIP_EXPORT int lthip_partition_jobs(uint64_t job_count, const uint64_t* job_sizes, uint32_t rank_count, int policy,
+                                      uint32_t* job_rank, uint64_t* rank_bytes);
+/* The exchange: every rank chunks + hashes its jobs in ascending job order, then the ranks all-gather (1) their per-job chunk
+ * counts, padded to count_stride entries per rank, and (2) their chunk hash / length arrays, padded to chunk_stride entries per
+ * rank.  This function says where job j's run of chunks sits in the gathered arrays (job_src[j], element index) and where it
+ * belongs in job order (job_dst[j]; job_dst[job_count] = total chunks) -- the order ChunkAssets concatenates in (:2499-2517),
+ * which the serial first-seen pass (:2951-2970) depends on.  One lthip_gather_ranges per array applies it.  EINVAL when the
+ * counts disagree with the assignment. */
+LTHIP_EXPORT int lthip_exchange_layout(uint64_t job_count, const uint32_t* job_rank, uint32_t rank_count,
+                                       const uint32_t* gathered_counts, uint64_t count_stride, uint64_t chunk_stride,
+                                       uint64_t* job_src, uint64_t* job_dst /* job_count + 1 */, uint32_t* job_chunks /* may be NULL */);
+
 /* ---- synthetic assets (include/longtail_synth.h), bench/test input generator ------------------------ */
 LTHIP_EXPORT int lthip_synth_fill(lthip_ctx* ctx, void* d_dst, uint32_t asset_count, const uint64_t* asset_offsets /*host*/,
                                   const uint64_t* asset_sizes /*host*/, const uint64_t* asset_seeds /*host*/, int kind);

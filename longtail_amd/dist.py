@@ -1,31 +1,155 @@
-"""Multi-GPU exchange step of the ingest path: ranks own disjoint file ranges, chunk + hash them
-locally, then all-gather their chunk-hash arrays so that every rank can run the same first-seen dedup
-(src/longtail.c:2951-2970) over the tree-ordered concatenation.  backend "nccl" is RCCL on ROCm; the same code runs
-on CPU tensors with "gloo" (tests/test_dist_gloo.py).  This is the only collective on the path."""
+"""Multi-GPU exchange step of the ingest path.
+
+The unit of independence is the reference's own job = one (asset, 64 MiB part) of ChunkAssets (src/longtail.c:2396-2458).
+`JobPartition` lists the jobs of a GIVEN tree and assigns them to ranks (C host code: lthip_make_jobs /
+lthip_partition_jobs -- contiguous byte-balanced ranges, LPT or job mod R; deterministic, so no communication); every rank
+chunks + hashes its own jobs in ascending job order; `exchange_chunks` all-gathers the per-job chunk counts and the chunk
+hash / length arrays and puts the runs back into JOB order (lthip_exchange_layout), which is the order the serial
+first-seen pass (:2951-2970) and the VersionIndex layout depend on.  backend "nccl" is RCCL on ROCm; the same code runs on
+CPU tensors with "gloo" (tests/test_dist_gloo.py).  These two all-gathers are the only collectives on the path.
+"""
 from __future__ import annotations
 
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
+POLICIES = {"range": 0, "lpt": 1, "mod": 2}
+
 
 def shard_range(n_items: int, world: int, rank: int):
-    """Contiguous, balanced [lo, hi) of items (files / parts, already in the tree's strcmp order) for `rank`."""
+    """Contiguous, balanced [lo, hi) of equal items for `rank` (weak-scaling trees of equal files)."""
     base, extra = divmod(n_items, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+class JobPartition:
+    """The (asset, part) jobs of a tree and their assignment to `world` ranks."""
+
+    def __init__(self, asset_sizes, target_chunk_size: int, world: int, policy: str = "range", lib=None):
+        from .lib import load
+
+        self.lib = lib or load()
+        d = self.lib.dll
+        sizes = np.ascontiguousarray(asset_sizes, dtype=np.uint64)
+        self.asset_sizes = sizes
+        self.world = world
+        self.policy = policy
+        n = int(d.lthip_job_count(len(sizes), sizes.ctypes.data, target_chunk_size))
+        self.job_asset = np.zeros(n, np.uint32)
+        self.job_offset = np.zeros(n, np.uint64)
+        self.job_size = np.zeros(n, np.uint64)
+        err = d.lthip_make_jobs(len(sizes), sizes.ctypes.data, target_chunk_size, n, self.job_asset.ctypes.data,
+                                self.job_offset.ctypes.data, self.job_size.ctypes.data)
+        if err:
+            raise RuntimeError(f"lthip_make_jobs: errno {err}")
+        self.job_rank = np.zeros(n, np.uint32)
+        self.rank_bytes = np.zeros(world, np.uint64)
+        err = d.lthip_partition_jobs(n, self.job_size.ctypes.data, world, POLICIES[policy], self.job_rank.ctypes.data,
+                                     self.rank_bytes.ctypes.data)
+        if err:
+            raise RuntimeError(f"lthip_partition_jobs: errno {err}")
+        self.job_count = n
+        self.jobs_per_rank = np.bincount(self.job_rank, minlength=world).astype(np.int64)
+
+    def jobs_of(self, rank: int) -> np.ndarray:
+        """Indices of the rank's jobs, ascending (= the order it must process them in)."""
+        return np.flatnonzero(self.job_rank == rank)
+
+    def is_rank_major(self) -> bool:
+        """True when the rank-major concatenation of the ranks' job lists is already job order."""
+        return bool((np.diff(self.job_rank.astype(np.int64)) >= 0).all())
+
+    def layout(self, gathered_counts: np.ndarray, count_stride: int, chunk_stride: int):
+        n = self.job_count
+        src, dst, cnt = np.zeros(n, np.uint64), np.zeros(n + 1, np.uint64), np.zeros(n, np.uint32)
+        g = np.ascontiguousarray(gathered_counts, dtype=np.uint32)
+        err = self.lib.dll.lthip_exchange_layout(n, self.job_rank.ctypes.data, self.world, g.ctypes.data, count_stride, chunk_stride,
+                                                 src.ctypes.data, dst.ctypes.data, cnt.ctypes.data)
+        if err:
+            raise RuntimeError(f"lthip_exchange_layout: errno {err} (per-job counts do not match the assignment)")
+        return src, dst, cnt
+
+
+def _allgather(t: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    out = torch.empty(t.numel() * world, dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return out
+
+
+def exchange_chunks(part: JobPartition, job_counts: torch.Tensor, hashes: torch.Tensor, lens: torch.Tensor | None, total: int,
+                    ctx=None, group=None):
+    """job_counts: int32 tensor, chunk count of each of THIS rank's jobs (ascending job order); hashes (int64) / lens (int32):
+    tensors whose first `total` entries are this rank's chunks in that order.  Returns a dict:
+      hashes, lens   all ranks' chunks in JOB order (lens None when not given)
+      job_first      int64 numpy [job_count + 1]: index of each job's first chunk (last entry = total chunks)
+      mine           (job indices of this rank, ascending)
+    On CUDA tensors with a context the reorder is one lthip_gather_ranges per array; CPU tensors (gloo tests) are indexed.
+    """
+    world = part.world
+    rank = dist.get_rank(group) if (dist.is_initialized() and world > 1) else 0
+    mine = part.jobs_of(rank)
+    assert job_counts.numel() == len(mine), "one chunk count per own job"
+    if world == 1:
+        first = np.zeros(part.job_count + 1, np.int64)
+        np.cumsum(job_counts.cpu().numpy().astype(np.int64), out=first[1:])
+        return dict(hashes=hashes[:total], lens=None if lens is None else lens[:total], job_first=first, mine=mine)
+    out_dev = hashes.device
+    staged = out_dev.type == "cuda" and dist.get_backend(group) != "nccl"  # functional path for CPU-only backends on a GPU box
+    if staged:
+        job_counts, hashes, lens = job_counts.cpu(), hashes[:total].cpu(), None if lens is None else lens[:total].cpu()
+    dev = hashes.device
+    # (1) per-job counts, padded to the largest job list
+    count_stride = max(int(part.jobs_per_rank.max()), 1)
+    send = torch.zeros(count_stride, dtype=torch.int32, device=dev)
+    send[: len(mine)] = job_counts.to(torch.int32)
+    gathered_counts = _allgather(send, world, group).cpu().numpy().view(np.uint32)
+    per_rank_total = gathered_counts.reshape(world, count_stride).astype(np.int64).sum(axis=1)
+    assert int(per_rank_total[rank]) == total
+    # (2) chunk arrays, padded to the largest rank
+    chunk_stride = max(int(per_rank_total.max()), 1)
+
+    def padded(t):
+        if t.numel() >= chunk_stride:
+            return t[:chunk_stride]
+        return torch.nn.functional.pad(t[:total], (0, chunk_stride - total))
+
+    g_hash = _allgather(padded(hashes), world, group)
+    g_lens = _allgather(padded(lens), world, group) if lens is not None else None
+    src, dst, cnt = part.layout(gathered_counts, count_stride, chunk_stride)
+    n_all = int(dst[-1])
+    if out_dev.type == "cuda" and ctx is not None and not staged:
+        d_src = torch.from_numpy(src.view(np.int64)).to(out_dev)
+        d_dst = torch.from_numpy(dst[:-1].view(np.int64).copy()).to(out_dev)
+        d_cnt = torch.from_numpy(cnt.view(np.int32)).to(out_dev)
+        o_hash = torch.empty(n_all, dtype=torch.int64, device=out_dev)
+        ctx.gather_ranges(g_hash.view(torch.uint8), d_src * 8, d_cnt * 8, o_hash.view(torch.uint8), d_dst * 8)
+        o_lens = None
+        if g_lens is not None:
+            o_lens = torch.empty(n_all, dtype=torch.int32, device=out_dev)
+            ctx.gather_ranges(g_lens.view(torch.uint8), d_src * 4, d_cnt * 4, o_lens.view(torch.uint8), d_dst * 4)
+    else:
+        c64 = cnt.astype(np.int64)
+        perm = np.repeat(src.astype(np.int64) - dst[:-1].astype(np.int64), c64) + np.arange(n_all, dtype=np.int64)
+        idx = torch.from_numpy(perm).to(dev)
+        o_hash = g_hash[idx].to(out_dev)
+        o_lens = g_lens[idx].to(out_dev) if g_lens is not None else None
+    return dict(hashes=o_hash, lens=o_lens, job_first=dst.astype(np.int64), mine=mine)
+
+
 def allgather_hashes(local_hashes: torch.Tensor, total: int, group=None):
-    """local_hashes: int64 tensor whose first `total` entries are this rank's chunk hashes in (asset, part, chunk) order.
-    Returns (all_hashes, my_base, counts): the rank-major concatenation (= tree order when ranks own contiguous file
-    ranges), the index of this rank's first chunk in it, and the per-rank counts (host list)."""
+    """Weak-scaling form for trees where rank r owns a contiguous file range: the rank-major concatenation of the ranks' hash
+    arrays IS tree order.  Returns (all_hashes, my_base, counts)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local_hashes[:total], 0, [total]
     rank = dist.get_rank(group)
     out_dev = local_hashes.device
     if out_dev.type == "cuda" and dist.get_backend(group) != "nccl":
-        local_hashes = local_hashes[:total].cpu()  # functional fallback for CPU-only backends (tests on a 1-GPU box)
+        local_hashes = local_hashes[:total].cpu()  # functional path for CPU-only backends (tests on a 1-GPU box)
     dev = local_hashes.device
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, torch.tensor([total], dtype=torch.int64, device=dev), group=group)

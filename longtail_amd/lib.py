@@ -121,6 +121,10 @@ class HipLib:
         sig("lthip_pack_blocks_batch", i32, [u64, vp, u64, u32, u32, u64, u64, u32, u32, vp, vp, u64, P(u64), P(u64)])
         sig("lthip_synth_fill", i32, [vp, vp, u32, vp, vp, vp, i32])
         sig("lthip_divtest_eval", i32, [u32, u32])
+        sig("lthip_job_count", u64, [u32, vp, u32])
+        sig("lthip_make_jobs", i32, [u32, vp, u32, u64, vp, vp, vp])
+        sig("lthip_partition_jobs", i32, [u64, vp, u32, i32, vp, vp])
+        sig("lthip_exchange_layout", i32, [u64, vp, u32, vp, u64, u64, vp, vp, vp])
 
     def device_count(self) -> int:
         return int(self.dll.lthip_device_count())
