@@ -1,17 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- ingest throughput (chunk + BLAKE3 + LZ4) of the HIP hot path on MI355X.
+"""bench.py -- ingest throughput of the HIP hot path on MI355X: SURVEY.md §8(d)'s metric.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2]): a synthetic tree of 1 MiB files, 64 GiB PER GPU (weak scaling:
-rank r owns files [r*F, (r+1)*F) of the N*64 GiB tree), bytes from include/longtail_synth.h, already resident in HBM
-when the timed region starts.  One step = the whole hot path over the rank's shard:
-  plan -> buzhash candidate scan -> cut selection -> compaction -> BLAKE3 leaves/parents            (phase 1)
-  -> [N>1: RCCL all-gather of per-rank chunk hashes] -> first-seen dedup                              (exchange)
-  -> greedy block packing of unique chunks (src/longtail.c:6801-6860, 8 MiB x 1.1, <= 1024 chunks)
-  -> per-block LZ4 (segments + stitch) into a bounded output arena                                    (phase 2)
-value = bytes of all ranks / max-over-ranks wall time of K steps (barrier + synchronize on both sides).
+One step = the three reference calls the metric is defined over, on a synthetic tree whose bytes are already resident in HBM:
+
+  Longtail_CreateVersionIndex   (src/longtail.c:2808)  plan -> buzhash candidate scan -> cut selection -> compaction -> BLAKE3
+                                                       leaves / parents over the rank's own (asset, 64 MiB part) jobs;
+                                                       [N > 1: RCCL all-gather of per-job chunk counts, hashes, lengths];
+                                                       first-seen dedup, content + path hashes, SERIALIZED VersionIndex on the host
+  Longtail_CreateMissingContent (src/longtail.c:6882)  the chunks this rank writes, greedy block packing (:6801-6860), block hashes
+  Longtail_WriteContent         (src/longtail.c:4760)  device block assembly where needed, per-block LZ4 / ZStd into stored-block
+                                                       images (BlockIndex + [raw][compressed] + payload) in a bounded arena (null
+                                                       sink), SERIALIZED StoreIndex on the host
+  (lthip_chunk_hash + lthip_ingest_index / _write / _finish, include/longtail_hip.h)
+
+Workload (default = BASELINE.json configs[2]): a tree of 1 MiB random files, 64 GiB PER GPU (--scaling weak: the tree has
+N x 64 GiB) or in total (--scaling strong, configs[3]); the tree's jobs are assigned to ranks by lthip_partition_jobs
+(byte-balanced contiguous ranges by default: an asset's parts may straddle ranks, configs[4]); every rank synthesizes only its own
+parts.  value = bytes of the whole tree / max-over-ranks wall time of K steps (barrier + synchronize on both sides).
+The default run also measures, after the headline, the compressible variant and the north-star mixed-size tree ("secondary"),
+and times the reference's bikeshed-threaded CPU path on a bounded sample ("cpu_baseline").
 """
 from __future__ import annotations
 
@@ -29,7 +39,11 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-MASK64 = (1 << 64) - 1
+KINDS = {"random": 0, "mixed": 1, "zero": 2, "records": 11, "tokens": 12, "lines": 13}
+# wave-instructions per 4 KiB of input (one wave: 64 lanes x 64 bytes), from the ISA dumps / SQ_INSTS_VALU, priced at
+# one VALU instruction per SIMD per 4 cycles at the nominal 2.4 GHz on 256 CUs x 4 SIMDs: the integer-issue roof of K1 / K3
+VALU_INSTR_PER_4KIB = {"buzhash": 735, "blake3_leaf": 695}
+VALU_ISSUE_PER_S = 256 * 4 * 2.4e9 / 4.0
 
 
 def synth_mix(z: np.ndarray) -> np.ndarray:
@@ -45,21 +59,238 @@ def asset_seeds(tree_seed: int, first: int, count: int) -> np.ndarray:
         return synth_mix(np.uint64(tree_seed) + np.uint64(0x9E3779B97F4A7C15) * idx)
 
 
-def pack_blocks(lens: np.ndarray, max_block: int, max_chunks: int):
-    """Greedy packing of Longtail_CreateStoreIndex (src/longtail.c:6801-6860): returns block start indices (+ end)."""
-    n = len(lens)
-    cs = np.cumsum(lens, dtype=np.int64)
-    limit = max_block + max_block // 10
-    starts = []
-    i = 0
-    while i < n:
-        base = int(cs[i - 1]) if i else 0
-        j = int(np.searchsorted(cs, base + limit, side="right"))
-        j = max(min(j, i + max_chunks), i + 1)
-        starts.append(i)
-        i = j
-    starts.append(n)
-    return np.asarray(starts, dtype=np.int64), cs
+def make_tree(kind_of_tree: str, total_bytes: int, file_bytes: int):
+    """The tree as a struct Longtail_FileInfos taken apart (src/longtail.h:1684-1692): sizes, path data, offsets, permissions."""
+    if kind_of_tree == "files":
+        n = max(1, total_bytes // file_bytes)
+        sizes = np.full(n, file_bytes, dtype=np.uint64)
+    else:
+        # north-star tree: sizes log-uniform in [4 KiB, 4 GiB] (capped at a quarter of the tree), fixed seed
+        rng = np.random.default_rng(0xA55E7)
+        budget, hi, out = total_bytes, min(4 << 30, max(total_bytes // 4, 8192)), []
+        while budget > 0:
+            sz = max(1, min(int(np.exp(rng.uniform(np.log(4096), np.log(hi)))), budget))
+            out.append(sz)
+            budget -= sz
+        sizes = np.asarray(out, dtype=np.uint64)
+        n = len(out)
+    names = [f"dir{i % 256:03d}/file{i:06d}.bin" for i in range(n)]
+    lens = np.fromiter((len(s) + 1 for s in names), dtype=np.int64, count=n)
+    path_offsets = np.zeros(n, np.uint32)
+    np.cumsum(lens[:-1], out=path_offsets[1:])
+    path_data = ("\0".join(names) + "\0").encode()
+    return dict(sizes=sizes, path_data=path_data, path_offsets=path_offsets, perms=np.full(n, 0o644, np.uint16), nfiles=n)
+
+
+class Bench:
+    """Device buffers shared by the configurations measured in one process."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+
+        from longtail_amd.lib import Context, load
+
+        self.torch, self.dist, self.args = torch, dist, args
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus and self.world > 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        self.lib = load()
+        if not torch.cuda.is_available() or self.lib.device_count() == 0:
+            raise SystemExit("bench.py needs a GPU and liblongtail_hip.so: there is no CPU fallback")
+        # LONGTAIL_DIST_BACKEND=gloo runs the multi-rank flow with all ranks on the GPUs that exist (rank % device_count) and the
+        # exchange staged through host memory: a functional check of the N>1 path on a 1-GPU box, not a measurement
+        self.backend = os.environ.get("LONGTAIL_DIST_BACKEND", "nccl")
+        dev_index = local_rank % torch.cuda.device_count() if self.backend != "nccl" else local_rank
+        torch.cuda.set_device(dev_index)
+        self.dev = torch.device("cuda", dev_index)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+        self.ctx = Context(dev_index)
+        self.bufs = {}
+
+    def buf(self, name, nbytes, dtype=None, pinned=False):
+        """A named buffer of at least nbytes, kept across configurations."""
+        torch = self.torch
+        dtype = dtype or torch.uint8
+        n = (nbytes + dtype.itemsize - 1) // dtype.itemsize if hasattr(dtype, "itemsize") else nbytes
+        t = self.bufs.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            self.bufs[name] = None
+            t = torch.empty(max(n, 16), dtype=dtype).pin_memory() if pinned else torch.empty(max(n, 16), dtype=dtype, device=self.dev)
+            self.bufs[name] = t
+        return t
+
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize(self.dev)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def run(self, cfg, steps, warmup):
+        """cfg: dict(tree, kind, codec, gib, file_mib, scaling, partition).  Returns the measurements of this configuration."""
+        torch, args, ctx, world, rank = self.torch, self.args, self.ctx, self.world, self.rank
+        from longtail_amd.dist import JobPartition, exchange_chunks
+        from longtail_amd.lib import Ingest, chunker_params
+
+        mn, av, mx = chunker_params(args.target_chunk_size)
+        total_bytes = int(cfg["gib"] * (1 << 30)) * (world if cfg["scaling"] == "weak" else 1)
+        file_bytes = int(cfg["file_mib"] * (1 << 20))
+        file_bytes -= file_bytes % 16
+        tree = make_tree(cfg["tree"], total_bytes, file_bytes)
+        tree_bytes = int(tree["sizes"].sum())
+        part = JobPartition(tree["sizes"], args.target_chunk_size, world, cfg["partition"], self.lib)
+        mine = part.jobs_of(rank)
+        # ---- the rank's parts, back to back at 16-byte aligned offsets: consecutive parts of one asset stay contiguous ----
+        p_size = part.job_size[mine]
+        p_off = np.zeros(len(mine), np.uint64)
+        if len(mine) > 1:
+            np.cumsum(((p_size + np.uint64(15)) // np.uint64(16) * np.uint64(16))[:-1], out=p_off[1:])
+        my_bytes = int(p_size.sum())
+        arena_in = int(p_off[-1] + p_size[-1]) if len(mine) else 0
+        data = self.buf("data", arena_in + 256)
+        seeds = asset_seeds(0x10C0FFEE, 0, tree["nfiles"])
+        ctx.synth_fill(data, p_off, p_size, seeds[part.job_asset[mine]], KINDS[cfg["kind"]], skips=part.job_offset[mine])
+        ctx.sync()
+
+        # ---- output arrays and arenas (allocated once; nothing is allocated in steady state) ----
+        probe = ctx.make_plan(p_off, p_size, mn, av, mx)
+        cap = max(1, probe.capacity)
+        probe.close()
+        out_offs = self.buf("offs", cap * 8, torch.int64)
+        out_lens = self.buf("lens", cap * 4, torch.int32)
+        out_hash = self.buf("hash", cap * 8, torch.int64)
+        out_first = self.buf("first", (len(mine) + 1) * 4, torch.int32)
+        batch_bytes = int(args.batch_gib * (1 << 30))
+        limit = args.block_size + args.block_size // 10
+        arena_bytes = batch_bytes + batch_bytes // 128 + (batch_bytes // args.block_size + 4) * (16384 + 64) + 2 * (limit + limit // 128 + 16384)
+        arena = self.buf("arena", arena_bytes)
+        est_chunks = cap * (world if world > 1 else 1)
+        vi_cap = int(self.lib.dll.lthip_version_index_size(tree["nfiles"], est_chunks, est_chunks, len(tree["path_data"]))) + 64
+        h_vi = self.buf("vi", vi_cap, pinned=True) if rank == 0 else None
+        h_si = self.buf("si", 16 + 32 * cap + 64, pinned=True)
+        ing = Ingest(ctx, args.target_chunk_size, args.block_size, args.max_chunks_per_block, cfg["codec"], batch_bytes=batch_bytes)
+        stats = {}
+
+        def step():
+            t0 = time.perf_counter()
+            plan = ctx.make_plan(p_off, p_size, mn, av, mx)
+            total, _, _, _, _ = ctx.chunk_hash(plan, data, outputs=(out_offs, out_lens, out_hash, out_first), sync=True)
+            plan.close()
+            t1 = time.perf_counter()
+            if world > 1:
+                counts = out_first[1 : len(mine) + 1] - out_first[: len(mine)]
+                ex = exchange_chunks(part, counts, out_hash, out_lens, total, ctx)
+                all_hash, all_lens, job_first = ex["hashes"], ex["lens"], ex["job_first"].astype(np.uint64)
+                my_jobs = mine
+            else:
+                all_hash, all_lens = out_hash, out_lens
+                job_first = out_first[: len(mine) + 1].cpu().numpy().view(np.uint32).astype(np.uint64)
+                my_jobs = None
+            n_all = int(job_first[-1])
+            t2 = time.perf_counter()
+            tr, keep = Ingest.tree(tree["sizes"], tree["path_offsets"], tree["perms"], tree["path_data"], part.job_asset, job_first, my_jobs)
+            ing.index(tr, all_hash, all_lens, n_all, out_offs, out_first, total, h_vi)
+            t3 = time.perf_counter()
+            if not args.no_compress:
+                ing.write(data, arena)
+            res = ing.finish(h_si)
+            t4 = time.perf_counter()
+            stats.update(res=res, t=(t1 - t0, t2 - t1, t3 - t2, t4 - t3))
+
+        for _ in range(warmup):
+            step()
+        ctx.timing(True)
+        ctx.timing_reset()
+        phase = np.zeros(4)
+        self.barrier()
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            step()
+            phase += stats["t"]
+        self.barrier()
+        elapsed = time.perf_counter() - t_start
+        ktimes = ctx.timing_get()
+        ctx.timing(False)
+        res = stats["res"]
+        comp, blocks, raw = res.compressed_bytes, res.blocks, res.raw_bytes
+        if world > 1:
+            on = self.dev if self.backend == "nccl" else "cpu"
+            t = torch.tensor([elapsed], dtype=torch.float64, device=on)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            s = torch.tensor([comp, blocks, raw], dtype=torch.int64, device=on)
+            self.dist.all_reduce(s)
+            comp, blocks, raw = (int(x) for x in s.tolist())
+        sizes = ing.compressed_sizes(res.blocks)
+        ing.close()
+
+        # ---- per-kernel rates: ALGORITHMIC bytes per launch (DESIGN.md §3) / average launch duration (HIP events on the stream) ----
+        alg_bytes = {"buzhash": my_bytes, "blake3_leaf": my_bytes, "lz4_segments": my_bytes, "zstd_encode": my_bytes + res.compressed_bytes}
+        kern = {}
+        for name, (ms, n) in ktimes.items():
+            if n:
+                per_step = ms / steps
+                kern[name] = {"ms_per_step": round(per_step, 3), "launches_per_step": n / steps}
+                if name in alg_bytes:
+                    kern[name]["GBps"] = round(alg_bytes[name] / (per_step * 1e-3) / 1e9, 1)
+        dom = max((k for k in kern if k in alg_bytes), key=lambda k: kern[k]["ms_per_step"], default=None)
+        roofline = None
+        if dom:
+            launches = kern[dom]["launches_per_step"]
+            avg_ms = kern[dom]["ms_per_step"] / launches
+            achieved = alg_bytes[dom] / launches / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": int(alg_bytes[dom] / launches), "avg_launch_ms": round(avg_ms, 3)}
+            if dom in VALU_INSTR_PER_4KIB:
+                roof = VALU_ISSUE_PER_S / VALU_INSTR_PER_4KIB[dom] * 4096 / 1e9
+                roofline["valu"] = {"instr_per_4KiB_wave_tile": VALU_INSTR_PER_4KIB[dom], "issue_roof_GBps": round(roof, 1),
+                                    "valu_frac": round(achieved / roof, 4),
+                                    "note": "integer-issue roof: one VALU instruction per SIMD per 4 cycles at 2.4 GHz, 1024 SIMDs"}
+            # HBM traffic from the PMC counters: collected offline (rocprofv3 cannot wrap itself), tools/pmc_traffic.sh ->
+            # profiles/*pmc_traffic*.json; per input byte, scaled to this run's launch size
+            try:
+                tfiles = sorted((ROOT / "profiles").glob("*pmc_traffic*.json"))
+                tj = json.load(open(tfiles[-1]))
+                names = {"buzhash": "k_buzhash_candidates<0>", "blake3_leaf": "k_blake3_leaves", "lz4_segments": "k_lz4_segments<"}
+                if dom == "lz4_segments" and cfg["codec"] != "lz4":
+                    raise KeyError("no PMC pass for the sequence-output variant of the match finder")
+                key = next(k for k in tj["kernels"] if k.startswith(names[dom]) and (dom != "lz4_segments" or k.endswith(", 0>")))
+                ratio = tj["kernels"][key]["corrected_per_input_byte"]
+                roofline["traffic"] = int(ratio * my_bytes / launches)
+                roofline["traffic_source"] = f"profiles/{tfiles[-1].name}: {ratio} HBM bytes per input byte (2*FETCH_SIZE+WRITE_SIZE)"
+            except Exception:
+                pass
+        label = {"files": f"{cfg['gib']:g} GiB tree of {cfg['file_mib']:g} MiB {cfg['kind']} files",
+                 "mixed-sizes": f"{cfg['gib']:g} GiB tree of {cfg['kind']} files, 4 KiB..4 GiB log-uniform (north-star tree)"}[cfg["tree"]]
+        per = "per GPU" if cfg["scaling"] == "weak" else "in total"
+        which = ""
+        if cfg["tree"] == "files" and cfg["kind"] == "random" and cfg["codec"] == "lz4" and abs(cfg["file_mib"] - 1.0) < 1e-9:
+            which = " (BASELINE.json configs[2])" if world == 1 else " (BASELINE.json configs[3])"
+        elif cfg["tree"] == "files" and cfg["codec"] == "zstd" and cfg["file_mib"] >= 16384:
+            which = " (BASELINE.json configs[4] shape)"
+        return {
+            "value": tree_bytes * steps / elapsed / 1e9,
+            "ms_per_step": elapsed / steps * 1e3,
+            "workload": f"{label} {per}, CreateVersionIndex + CreateMissingContent + WriteContent, chunk+BLAKE3+{cfg['codec'].upper()}{which}",
+            "tree_bytes": tree_bytes, "bytes_this_rank": my_bytes, "files": tree["nfiles"], "jobs": int(part.job_count),
+            "jobs_this_rank": int(len(mine)), "min_avg_max": [mn, av, mx],
+            "roofline": roofline, "kernels": kern,
+            "phase_ms": {"chunk_hash": round(phase[0] / steps * 1e3, 2), "exchange": round(phase[1] / steps * 1e3, 2),
+                         "index": round(phase[2] / steps * 1e3, 2), "write_finish": round(phase[3] / steps * 1e3, 2)},
+            "result": {"chunks": int(res.chunks_all), "unique_chunks": int(res.unique_all), "blocks": int(blocks),
+                       "raw_bytes_written": int(raw), "compressed_bytes": int(comp),
+                       "ratio": round(raw / comp, 4) if comp else None, "gathered_blocks_rank0": int(res.gathered_blocks),
+                       "version_index_bytes": int(res.version_index_size), "store_index_bytes_rank0": int(res.store_index_size)},
+        }
 
 
 def main():
@@ -67,366 +298,155 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--gib", type=float, default=64.0, help="GiB of assets per GPU")
+    ap.add_argument("--gib", type=float, default=64.0, help="GiB of assets per GPU (weak) or in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--partition", choices=["range", "lpt", "mod"], default="range", help="lthip_partition_jobs policy (N > 1)")
     ap.add_argument("--file-mib", type=float, default=1.0)
     ap.add_argument("--tree", choices=["files", "mixed-sizes"], default="files", help="files: equal files (configs[2]); mixed-sizes: 4 KiB..4 GiB log-uniform")
-    ap.add_argument("--kind", choices=["random", "mixed", "zero", "records", "tokens", "lines"], default="random")
+    ap.add_argument("--kind", choices=sorted(KINDS), default="random")
     ap.add_argument("--target-chunk-size", type=int, default=65536)
     ap.add_argument("--block-size", type=int, default=8 << 20)
     ap.add_argument("--max-chunks-per-block", type=int, default=1024)
-    ap.add_argument("--lz4-batch-gib", "--batch-gib", dest="lz4_batch_gib", type=float, default=8.0)
-    ap.add_argument("--codec", choices=["lz4", "zstd"], default="lz4", help="block codec of phase 2 (BASELINE.json configs[4] uses zstd)")
-    ap.add_argument("--segment-log2", type=int, default=0)
-    ap.add_argument("--no-compress", action="store_true")
+    ap.add_argument("--batch-gib", "--lz4-batch-gib", dest="batch_gib", type=float, default=8.0)
+    ap.add_argument("--codec", choices=["lz4", "zstd"], default="lz4", help="block codec (BASELINE.json configs[4] uses zstd)")
+    ap.add_argument("--no-compress", action="store_true", help="diagnostic: skip WriteContent (the line is then not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the compressible / mixed-size-tree measurements")
+    ap.add_argument("--cpu-gib", type=float, default=8.0, help="sample size of the CPU baseline")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
-    from longtail_amd.dist import allgather_hashes
-    from longtail_amd.lib import Context, chunker_params, load
-    from longtail_amd.lib import BatchPacker
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    lib = load()
-    if not torch.cuda.is_available() or lib.device_count() == 0:
-        raise SystemExit("bench.py needs a GPU and liblongtail_hip.so: there is no CPU fallback")
-    # LONGTAIL_DIST_BACKEND=gloo runs the multi-rank flow with all ranks on the GPUs that exist (rank % device_count) and
-    # the exchange staged through host memory: a functional check of the N>1 path on a 1-GPU box, not a measurement
-    backend = os.environ.get("LONGTAIL_DIST_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
-    ctx = Context(dev_index)
-    kind = {"random": 0, "mixed": 1, "zero": 2, "records": 11, "tokens": 12, "lines": 13}[args.kind]
-    mn, av, mx = chunker_params(args.target_chunk_size)
-    part_bytes = args.target_chunk_size * 1024  # ChunkAssets part size (src/longtail.c:2396)
-    if args.tree == "files":
-        file_bytes = int(args.file_mib * (1 << 20))
-        file_bytes -= file_bytes % 16
-        nfiles = max(1, int(args.gib * (1 << 30)) // file_bytes)
-        file_sizes = np.full(nfiles, file_bytes, dtype=np.uint64)
-    else:
-        # north-star tree: sizes log-uniform in [4 KiB, 4 GiB] (capped at a quarter of the shard), fixed seed
-        rng = np.random.default_rng(0xA55E7 + rank)
-        budget = int(args.gib * (1 << 30))
-        hi = min(4 << 30, max(budget // 4, 8192))
-        sizes = []
-        while budget > 0:
-            sz = int(np.exp(rng.uniform(np.log(4096), np.log(hi))))
-            sz = max(1, min(sz, budget))
-            sizes.append(sz)
-            budget -= sz
-        file_sizes = np.asarray(sizes, dtype=np.uint64)
-        nfiles = len(sizes)
-        file_bytes = int(file_sizes.mean())
-    file_offsets = np.zeros(nfiles, dtype=np.uint64)
-    np.cumsum(((file_sizes + np.uint64(15)) // np.uint64(16) * np.uint64(16))[:-1], out=file_offsets[1:])
-    shard_bytes = int(file_sizes.sum())
-    arena_bytes = int(file_offsets[-1] + file_sizes[-1])
-    # parts: every asset is cut into target*1024-byte segments, each chunked from a fresh state (:2396-2458)
-    nparts_per = (file_sizes + np.uint64(part_bytes - 1)) // np.uint64(part_bytes)
-    rep = np.repeat(np.arange(nfiles), nparts_per.astype(np.int64))
-    within = np.arange(len(rep), dtype=np.uint64) - np.repeat(np.cumsum(nparts_per) - nparts_per, nparts_per.astype(np.int64))
-    part_offsets = file_offsets[rep] + within * np.uint64(part_bytes)
-    part_sizes = np.minimum(file_sizes[rep] - within * np.uint64(part_bytes), np.uint64(part_bytes))
-    nparts = len(part_offsets)
-
-    # ---- inputs resident in HBM (untimed) ----
-    data = torch.empty(arena_bytes + 256, dtype=torch.uint8, device=dev)
-    seeds = asset_seeds(0x10C0FFEE, rank * 10_000_000, nfiles)
-    ctx.synth_fill(data, file_offsets, file_sizes, seeds, kind)
-    ctx.sync()
-
-    # ---- output arenas (allocated once; the hot path never allocates in steady state) ----
-    probe = ctx.make_plan(part_offsets, part_sizes, mn, av, mx)
-    cap = max(1, probe.capacity)
-    probe.close()
-    out_offs = torch.empty(cap, dtype=torch.int64, device=dev)
-    out_lens = torch.empty(cap, dtype=torch.int32, device=dev)
-    out_hash = torch.empty(cap, dtype=torch.int64, device=dev)
-    out_first = torch.empty(nparts + 1, dtype=torch.int32, device=dev)
-    batch_bytes = int(args.lz4_batch_gib * (1 << 30))
-    limit = args.block_size + args.block_size // 10
-    dst_arena_bytes = batch_bytes + batch_bytes // 255 + (batch_bytes // args.block_size + 2) * 64 + 2 * (limit + limit // 255 + 64)
-    dst = torch.empty(dst_arena_bytes, dtype=torch.uint8, device=dev)
-    gather_arena = None  # allocated on first use: only trees whose blocks are not contiguous ranges need it
-    h_lens = torch.empty(cap, dtype=torch.int32).pin_memory()
-    h_offs = torch.empty(cap, dtype=torch.int64).pin_memory()
-    stats = {}
-
-    def compress(src, s_offs, s_sizes, dst_t, d_offs, caps):
-        if args.codec == "zstd":
-            return ctx.zstd_compress_blocks(src, s_offs, s_sizes, dst_t, d_offs, caps)
-        return ctx.lz4_compress_blocks(src, s_offs, s_sizes, dst_t, d_offs, caps, args.segment_log2)
-
-    def step():
-        t0 = time.perf_counter()
-        plan = ctx.make_plan(part_offsets, part_sizes, mn, av, mx)
-        total, _, _, _, _ = ctx.chunk_hash(plan, data, outputs=(out_offs, out_lens, out_hash, out_first), sync=True)
-        plan.close()
-        t1 = time.perf_counter()
-        # ---- exchange + dedup (src/longtail.c:2951-2970) ----
-        all_hashes, my_base, _counts = allgather_hashes(out_hash, total)
-        mine_first, uniq = ctx.dedup_first_seen_range(all_hashes, my_base, total)  # table over all ranks, answers for mine
-        unique_mask = mine_first == torch.arange(my_base, my_base + total, dtype=torch.int32, device=dev)
-        n_unique_local = int(unique_mask.sum().item())
-        t2 = time.perf_counter()
-        comp_bytes = 0
-        nblocks = 0
-        if not args.no_compress:
-            # chunk lists to pinned host memory (one async copy each, one sync), then the serial packing in C
-            h_lens[:total].copy_(out_lens[:total], non_blocking=True)
-            h_offs[:total].copy_(out_offs[:total], non_blocking=True)
-            torch.cuda.current_stream(dev).synchronize()
-            lens_u32 = h_lens[:total].numpy().view(np.uint32)
-            offs_h = h_offs[:total].numpy().view(np.int64)
-            if n_unique_local != total:
-                keep = unique_mask.cpu().numpy()
-                lens_u32, offs_h = lens_u32[keep], offs_h[keep]
-            # greedy packing, one batch at a time: batch k+1 is packed on the host while the device compresses batch k
-            lz = args.codec == "lz4"
-            packer = BatchPacker(lens_u32, args.block_size, args.max_chunks_per_block, batch_bytes, dst_arena_bytes,
-                                 255 if lz else 256, 16 if lz else 64, lib)
-            d_offs_u = d_lens_u = None
-            size_tensors, b_size_all = [], []
-            stats["gather"] = False
-            while True:
-                nxt = packer.next()
-                if nxt is None:
-                    break
-                starts, b_size = nxt
-                b_first, b_last = starts[:-1], starts[1:] - 1
-                nblocks += len(b_first)
-                bounds = b_size + b_size // 255 + 16 if lz else b_size + (b_size >> 8) + 64
-                aligned = (bounds + 63) // 64 * 64
-                d_offs = np.concatenate([[0], np.cumsum(aligned)[:-1]])
-                is_range = (offs_h[b_last] + lens_u32[b_last]) - offs_h[b_first] == b_size  # block == one contiguous byte range
-                if bool(is_range.all()):
-                    b_size_all.append(b_size)
-                    size_tensors.append(compress(data, offs_h[b_first], b_size, dst, d_offs, bounds))
-                else:
-                    # block assembly on the device (WriteContentBlockJob, src/longtail.c:4640-4721) for the blocks that
-                    # are not one range (they span assets): gather their chunks back to back, then each of them is a
-                    # contiguous range of the gather arena; the others are compressed where they lie
-                    stats["gather"] = True
-                    nonlocal gather_arena
-                    if gather_arena is None:
-                        gather_arena = torch.empty(batch_bytes + 2 * limit + 256, dtype=torch.uint8, device=dev)
-                    if d_offs_u is None:
-                        if n_unique_local != total:
-                            d_offs_u, d_lens_u = out_offs[:total][unique_mask], out_lens[:total][unique_mask]
-                        else:
-                            d_offs_u, d_lens_u = out_offs[:total], out_lens[:total]
-                    r, g = np.flatnonzero(is_range), np.flatnonzero(~is_range)
-                    cnt = (starts[g + 1] - starts[g]).astype(np.int64)
-                    first_of = np.repeat(starts[g] - (np.cumsum(cnt) - cnt), cnt)
-                    chunk_idx = torch.from_numpy(first_of + np.arange(int(cnt.sum()), dtype=np.int64)).to(dev)
-                    lens_d = d_lens_u[chunk_idx]
-                    dst_off = torch.cumsum(lens_d.to(torch.int64), 0) - lens_d.to(torch.int64)
-                    ctx.gather_ranges(data, d_offs_u[chunk_idx].contiguous(), lens_d.contiguous(), gather_arena, dst_off)
-                    if len(r):
-                        b_size_all.append(b_size[r])
-                        size_tensors.append(compress(data, offs_h[b_first[r]], b_size[r], dst, d_offs[r], bounds[r]))
-                    b_size_all.append(b_size[g])
-                    size_tensors.append(compress(gather_arena, np.cumsum(b_size[g]) - b_size[g], b_size[g], dst, d_offs[g], bounds[g]))
-            b_size = np.concatenate(b_size_all) if b_size_all else np.zeros(0, np.int64)
-            sizes = (torch.cat(size_tensors).cpu().numpy().view(np.uint32).astype(np.int64) if size_tensors else np.zeros(0, np.int64))  # one D2H, waits for the codec
-            comp_bytes = int(sizes.sum())
-            # blocks without any match are laid out by the match finder itself (it writes their literals): count them
-            stats["placed_by_matcher"] = int(b_size[sizes >= b_size].sum()) if args.codec == "lz4" else 0
-            if int((sizes == 0).sum()) != 0:
-                raise SystemExit("a block did not fit its bound: encoder bug")
-        ctx.sync()
-        t3 = time.perf_counter()
-        stats.update(chunks=total, unique_local=n_unique_local, unique_global=int(uniq.item()), blocks=nblocks,
-                     compressed_bytes=comp_bytes, t_phase1=t1 - t0, t_exchange=t2 - t1, t_phase2=t3 - t2)
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    ctx.timing(True)
-    ctx.timing_reset()
-    phase = np.zeros(3)
-    barrier()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        phase += [stats["t_phase1"], stats["t_exchange"], stats["t_phase2"]]
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    ktimes = ctx.timing_get()
-    ctx.timing(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    total_bytes = shard_bytes * world
-    value = total_bytes * args.steps / elapsed / 1e9
-
-    # ---- roofline of the dominant kernel (algorithmic bytes / launch; DESIGN.md "Measurement") ----
-    comp = stats["compressed_bytes"]
-    alg_bytes = {
-        "buzhash": shard_bytes,                 # N read once
-        "blake3_leaf": shard_bytes,             # N read once
-        "lz4_segments": shard_bytes + stats.get("placed_by_matcher", 0),  # N read + the blocks it lays out itself (all-literal)
-        "zstd_encode": shard_bytes + comp,      # literals + sequences read, pieces written
-    }
-    # lz4_stitch has no fixed algorithmic figure any more: for blocks without matches it only writes a header
-    kern = {}
-    for name, (ms, n) in ktimes.items():
-        if n:
-            per_step_ms = ms / args.steps
-            kern[name] = {"ms_per_step": round(per_step_ms, 3), "launches_per_step": n / args.steps}
-            if name in alg_bytes:
-                kern[name]["GBps"] = round(alg_bytes[name] / (per_step_ms * 1e-3) / 1e9, 1)
-    dom = max((k for k in kern if k in alg_bytes), key=lambda k: kern[k]["ms_per_step"], default=None)
-    roofline = None
-    if dom:
-        launches = kern[dom]["launches_per_step"]
-        avg_ms = kern[dom]["ms_per_step"] / launches
-        achieved = alg_bytes[dom] / launches / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "algorithmic_bytes_per_launch": int(alg_bytes[dom] / launches), "avg_launch_ms": round(avg_ms, 3)}
-
-    # HBM traffic from the PMC counters: collected offline (rocprofv3 cannot wrap itself), tools/pmc_traffic.sh ->
-    # profiles/*pmc_traffic*.json; scaled by input bytes to this run's launch size
-    if roofline:
-        try:
-            tfiles = sorted((ROOT / "profiles").glob("*pmc_traffic*.json"))
-            tj = json.load(open(tfiles[-1]))
-            names = {"buzhash": "k_buzhash_candidates<0>", "blake3_leaf": "k_blake3_leaves", "lz4_segments": "k_lz4_segments<",
-                     "lz4_stitch": "k_lz4_stitch_copy"}
-            if dom == "lz4_segments" and args.codec != "lz4":
-                raise KeyError("no PMC pass for the sequence-output variant of the match finder")
-            key = next(k for k in tj["kernels"] if k.startswith(names[dom]) and (dom != "lz4_segments" or k.endswith(", 0>")))
-            ratio = tj["kernels"][key]["corrected_per_input_byte"]
-            roofline["traffic"] = int(ratio * shard_bytes / kern[dom]["launches_per_step"])
-            roofline["traffic_source"] = f"profiles/{tfiles[-1].name}: {ratio} HBM bytes per input byte (2*FETCH_SIZE+WRITE_SIZE)"
-        except Exception:
-            pass
-
+    b = Bench(args)
+    cfg = dict(tree=args.tree, kind=args.kind, codec=args.codec, gib=args.gib, file_mib=args.file_mib, scaling=args.scaling,
+               partition=args.partition)
+    main_res = b.run(cfg, args.steps, args.warmup)
+    secondary = None
+    default_headline = args.tree == "files" and args.kind == "random" and args.codec == "lz4" and not args.no_compress
+    if not args.no_secondary and default_headline:
+        # "report both" -- the compressible variant (match path + a real ratio) and the north-star tree
+        secondary = {}
+        for name, over in (("compressible", dict(kind="mixed")), ("north_star_tree", dict(tree="mixed-sizes")),
+                           ("north_star_tree_compressible", dict(tree="mixed-sizes", kind="mixed"))):
+            r = b.run(dict(cfg, **over), max(1, min(args.steps, 2)), 1)
+            secondary[name] = {"value": round(r["value"], 3), "unit": "GB/s", "ms_per_step": round(r["ms_per_step"], 3),
+                               "workload": r["workload"], "ratio": r["result"]["ratio"], "phase_ms": r["phase_ms"],
+                               "dominant_kernel": r["roofline"] and {k: r["roofline"][k] for k in ("kernel", "achieved", "frac")}}
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(args, kind, file_bytes)
-
-    if rank == 0:
+    if b.rank == 0 and b.world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(args)
+    if b.rank == 0:
         line = {
             "metric": "ingest GB/s (chunk+hash+compress)",
-            "value": round(value, 3),
+            "value": round(main_res["value"], 3),
             "unit": "GB/s",
-            "n_gpus": world,
+            "n_gpus": b.world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step": round(main_res["ms_per_step"], 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8/u32",
             "data": "synthetic",
             "config": {
-                "workload": (f"{args.gib:g} GiB tree of {args.file_mib:g} MiB {args.kind} files per GPU, chunk+BLAKE3+{args.codec.upper()} "
-                             f"(BASELINE.json configs[2]{'/[3]' if world > 1 else ''})") if args.tree == "files" else
-                            (f"{args.gib:g} GiB tree of {nfiles} {args.kind} files, 4 KiB..4 GiB log-uniform, per GPU, chunk+BLAKE3+{args.codec.upper()} "
-                             f"(north-star tree)"),
-                "target_chunk_size": args.target_chunk_size, "min_avg_max": [mn, av, mx], "block_size": args.block_size,
-                "max_chunks_per_block": args.max_chunks_per_block, "bytes_per_gpu": shard_bytes, "files_per_gpu": nfiles, "parts_per_gpu": nparts, "device_block_assembly": bool(stats.get("gather")),
-                "sharding": "by file, RCCL all-gather of chunk hashes for dedup" if world > 1 else "single GPU",
+                "workload": main_res["workload"],
+                "target_chunk_size": args.target_chunk_size, "min_avg_max": main_res["min_avg_max"], "block_size": args.block_size,
+                "max_chunks_per_block": args.max_chunks_per_block, "tree_bytes": main_res["tree_bytes"], "files": main_res["files"],
+                "jobs": main_res["jobs"], "bytes_rank0": main_res["bytes_this_rank"], "jobs_rank0": main_res["jobs_this_rank"],
+                "device_block_assembly": main_res["result"]["gathered_blocks_rank0"] > 0,
+                "sharding": (f"(asset, part) jobs over {b.world} ranks by lthip_partition_jobs('{args.partition}'), RCCL all-gather of "
+                             "per-job chunk counts + hashes + lengths") if b.world > 1 else "single GPU",
+                "metric_definition": "wall time of CreateVersionIndex + CreateMissingContent + WriteContent equivalents (SURVEY.md §8d), "
+                                     "serialized VersionIndex and StoreIndex delivered to host memory, stored-block images to a null sink",
             },
-            "roofline": roofline,
+            "roofline": main_res["roofline"],
             "cpu_baseline": cpu_baseline,
-            "kernels": kern,
-            "phase_ms": {"chunk_hash": round(phase[0] / args.steps * 1e3, 2), "exchange_dedup": round(phase[1] / args.steps * 1e3, 2),
-                         "pack_compress": round(phase[2] / args.steps * 1e3, 2)},
-            "result": {"chunks": stats["chunks"], "unique_chunks_global": stats["unique_global"], "blocks": stats["blocks"],
-                       "compressed_bytes": stats["compressed_bytes"],
-                       "ratio": round(shard_bytes / stats["compressed_bytes"], 4) if stats["compressed_bytes"] else None},
+            "secondary": secondary,
+            "kernels": main_res["kernels"],
+            "phase_ms": main_res["phase_ms"],
+            "result": main_res["result"],
         }
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    if b.world > 1:
+        b.dist.destroy_process_group()
 
 
-def run_cpu_baseline(args, kind, file_bytes):
-    """The reference's bikeshed-threaded CPU path (oracle/_ref) -- or the single-thread port (oracle/) when the
-    reference build is not present -- on a bounded sample of the SAME workload, timed on this host's cores."""
+def run_cpu_baseline(args):
+    """SURVEY.md §8(d) protocol: the reference's own code (oracle/_ref: Longtail_CreateVersionIndex + Longtail_CreateMissingContent +
+    Longtail_WriteContent with the reference hpcdc + BLAKE3 + LZ4/ZStd plugins and Longtail_CreateBikeshedJobAPI(W, 0)), source tree
+    on tmpfs behind the reference's file storage, null block sink, W in {1, 32, physical cores, all hardware threads}, 3 repetitions,
+    median; on a bounded sample of the headline tree and on BASELINE.json configs[0] (one 256 MiB file: only 4 non-empty jobs).
+    Without the reference build: the single-thread C restatement (oracle/)."""
     from tests._libs import have_ref, oracle, ref
 
     o = oracle()
-    ncores = os.cpu_count() or 1
-    target = args.cpu_seconds
+    ncpu = os.cpu_count() or 1
+    kind = KINDS[args.kind]
+    file_bytes = int(args.file_mib * (1 << 20))
+    file_bytes -= file_bytes % 16
 
-    def make_files(n):
-        seeds = asset_seeds(0x10C0FFEE, 0, n)
-        return [(f"dir{i % 256:03d}/file{i:05d}.bin", o.synth(file_bytes, int(seeds[i]), kind)) for i in range(n)]
+    def make_files(n, nbytes, first=0):
+        seeds = asset_seeds(0x10C0FFEE, first, n)
+        return [(f"dir{i % 256:03d}/file{i:06d}.bin", o.synth(nbytes, int(seeds[i]), kind)) for i in range(n)]
 
-    if have_ref():
-        r = ref()
-        workers = int(r.dll.refh_cpu_count())
-        # source tree on tmpfs through the reference's file storage (SURVEY.md §8d: "page-cache-warm, from tmpfs"); its
-        # in-memory storage serialises reads behind one lock and is only the fallback
-        storage = "in-memory storage"
-        shm = "/dev/shm"
-        try:
-            st = os.statvfs(shm)
-            if os.access(shm, os.W_OK) and st.f_bavail * st.f_frsize > (20 << 30):
-                r.dll.refh_set_tree_dir.argtypes = [ctypes.c_char_p]
-                r.dll.refh_set_tree_dir(shm.encode())
-                storage = f"file storage on tmpfs ({shm})"
-        except OSError:
-            pass
-        n = 256
-        best = None
-        spent = 0.0
-        while True:
-            files = make_files(n)
-            t0 = time.perf_counter()
-            res = r.ingest_time(files, args.target_chunk_size, args.block_size, args.max_chunks_per_block, r.lz4_type, workers)
-            wall = time.perf_counter() - t0
-            if res["err"]:
-                return {"error": res["err"]}
-            secs = res["seconds_index"] + res["seconds_write"]
-            best = (n, secs, res)
-            spent += wall
-            if secs * 4 > target / 2 or n * file_bytes >= (8 << 30) or spent > target:
-                break
-            n *= 4
-        n, secs, res = best
-        return {"value": round(n * file_bytes / secs / 1e9, 3), "unit": "GB/s", "cores": workers, "kind": "reference",
-                "sample": f"{n} x {file_bytes} B files of the same tree; Longtail_CreateVersionIndex {res['seconds_index']:.3f} s + "
-                          f"Longtail_WriteContent {res['seconds_write']:.3f} s (reference hpcdc+BLAKE3+LZ4, bikeshed {workers} workers, "
-                          f"{storage}, null block sink)",
-                "host_cpus": ncores}
-    from tests._libs import IngestResult
+    if not have_ref():
+        from tests._libs import IngestResult
 
-    n = 64
-    files = make_files(n)
-    blob = np.concatenate([d for _, d in files])
-    out = IngestResult()
-    err = o.dll.lto_ingest(blob.ctypes.data, len(blob), file_bytes, args.target_chunk_size, args.block_size, 1, out)
-    secs = out.seconds_chunk + out.seconds_hash + out.seconds_compress
-    return {"value": round(len(blob) / secs / 1e9, 3) if not err else None, "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"{n} x {file_bytes} B files, single-thread C restatement (oracle/)", "host_cpus": ncores}
+        files = make_files(64, file_bytes)
+        blob = np.concatenate([d for _, d in files])
+        out = IngestResult()
+        err = o.dll.lto_ingest(blob.ctypes.data, len(blob), file_bytes, args.target_chunk_size, args.block_size, 1, out)
+        secs = out.seconds_chunk + out.seconds_hash + out.seconds_compress
+        return {"value": round(len(blob) / secs / 1e9, 3) if not err else None, "unit": "GB/s", "cores": 1, "kind": "port",
+                "sample": f"64 x {file_bytes} B files, single-thread C restatement (oracle/)", "host_cpus": ncpu}
+    r = ref()
+    tag = r.lz4_type if args.codec == "lz4" else r.zstd_default
+    storage = "reference in-memory storage"
+    shm = "/dev/shm"
+    try:
+        st = os.statvfs(shm)
+        if os.access(shm, os.W_OK) and st.f_bavail * st.f_frsize > (24 << 30):
+            r.dll.refh_set_tree_dir.argtypes = [ctypes.c_char_p]
+            r.dll.refh_set_tree_dir(shm.encode())
+            storage = f"reference file storage on tmpfs ({shm})"
+    except OSError:
+        pass
+    physical = max(1, ncpu // 2)
+    sweep = sorted({1, min(32, ncpu), physical, ncpu})
+    reps = 3
+
+    def measure(files, workers):
+        res = r.ingest_sweep(files, args.target_chunk_size, args.block_size, args.max_chunks_per_block, tag, workers, reps)
+        if res["err"]:
+            return None
+        nbytes = sum(len(d) for _, d in files)
+        out = {}
+        for wi, w in enumerate(workers):
+            tot = np.sort(res["seconds"][wi].sum(axis=1))
+            med = int(np.argsort(res["seconds"][wi].sum(axis=1))[reps // 2])
+            s = res["seconds"][wi][med]
+            out[str(w)] = {"GBps": round(nbytes / float(tot[reps // 2]) / 1e9, 3), "median_s": round(float(tot[reps // 2]), 4),
+                           "index_s": round(float(s[0]), 4), "missing_s": round(float(s[1]), 4), "write_s": round(float(s[2]), 4)}
+        return out
+
+    # the single-thread leg on a smaller sample (0.5 GB/s would take 16 s per repetition on 8 GiB)
+    n_big = max(1, int(args.cpu_gib * (1 << 30)) // file_bytes)
+    n_small = max(1, min(n_big, (1 << 30) // file_bytes))
+    files = make_files(n_big, file_bytes)
+    by_w = measure(files, [w for w in sweep if w > 1]) or {}
+    one = measure(files[:n_small], [1])
+    if one:
+        by_w["1"] = dict(one["1"], sample_files=n_small)
+    del files
+    cfg0 = measure(make_files(1, 268_435_456, first=1), [w for w in sweep if w > 1][:1] + [ncpu])  # BASELINE.json configs[0]
+    if not by_w:
+        return {"error": "reference ingest failed"}
+    best_w = max(by_w, key=lambda k: by_w[k]["GBps"])
+    return {"value": by_w[best_w]["GBps"], "unit": "GB/s", "cores": int(best_w), "kind": "reference",
+            "sample": f"{n_big} x {file_bytes} B files of the headline tree ({n_small} files for W=1); Longtail_CreateVersionIndex + "
+                      f"Longtail_CreateMissingContent + Longtail_WriteContent, reference hpcdc+BLAKE3+{args.codec.upper()}, bikeshed W workers, "
+                      f"{storage}, null block sink; median of {reps}; value = best W",
+            "by_workers": by_w, "physical_cores": physical, "host_cpus": ncpu,
+            "configs0_one_256MiB_file": cfg0}
 
 
 if __name__ == "__main__":

@@ -270,6 +270,73 @@ LTHIP_EXPORT int lthip_create_missing_content(lthip_ctx* ctx, uint64_t existing_
                                               const uint32_t* chunk_tags, uint32_t hash_identifier, uint32_t max_block_size,
                                               uint32_t max_chunks_per_block, void* out, size_t out_capacity, size_t* out_size);
 
+/* ---- the ingest metric as one native session (CreateVersionIndex + CreateMissingContent + WriteContent) --------
+ * For assets already resident in HBM.  The caller runs lthip_chunk_hash over its own jobs (one part per job, ascending job order),
+ * then
+ *   lthip_ingest_index   tail of Longtail_CreateVersionIndex (src/longtail.c:2808-3017: first-seen pass :2951-2970, content hashes
+ *                        :2518-2537, path hashes :1269-1300, serialized layout :2551-2584) + Longtail_CreateMissingContent
+ *                        (:6882-6998) for the chunks THIS rank writes: packing (:6801-6860), block hashes (:3753-3757)
+ *   lthip_ingest_write   Longtail_WriteContent (:4760; WriteContentBlockJob :4559-4758, CompressBlock compressblockstore.c:67-141):
+ *                        block assembly on the device only for blocks that are not one byte range of the data, per-block codec
+ *                        straight into the stored-block image, BlockIndex + [raw][compressed] around it (:4111-4150).  The images
+ *                        are produced batch after batch in the caller's arena and dropped (null sink).
+ *   lthip_ingest_finish  serialized StoreIndex of what was written (:8913-8931), the session's one full synchronisation, statistics.
+ * Single GPU: the "all" arrays are the local ones and tree->my_jobs is NULL.  Multi-GPU: the "all" arrays hold every rank's
+ * chunks in job order (see lthip_exchange_layout) and tree->my_jobs lists this rank's jobs; a rank writes the chunks that are
+ * first-seen and lie in its own jobs, i.e. Longtail_CreateMissingContent against a store that already holds the other ranks'
+ * chunks.  h_version_index (may be NULL: this rank does not serialize the index) and h_store_index should be pinned memory so
+ * the copies overlap the kernels.  asset_tags NULL = every asset carries cfg.compression_type (what UpSync passes). */
+enum lthip_codec
+{
+    LTHIP_CODEC_NONE = 0,
+    LTHIP_CODEC_LZ4 = 1,
+    LTHIP_CODEC_ZSTD = 2
+};
+typedef struct lthip_ingest lthip_ingest;
+typedef struct lthip_ingest_config
+{
+    uint32_t target_chunk_size;    /* recorded in the VersionIndex */
+    uint32_t hash_identifier;      /* 0x626c6b33 */
+    uint32_t max_block_size;       /* cmd/main.c:3006-3009 defaults: 8 MiB */
+    uint32_t max_chunks_per_block; /*                                 1024  */
+    uint32_t compression_type;     /* the tag stored with chunks and blocks: 'lz42', 'ztd1'..'ztd5' */
+    uint32_t codec;                /* enum lthip_codec */
+    uint64_t batch_bytes;          /* raw bytes per codec batch, 0 = 8 GiB */
+} lthip_ingest_config;
+typedef struct lthip_ingest_tree
+{
+    uint32_t asset_count;               /* struct Longtail_FileInfos taken apart (src/longtail.h:1684-1692) */
+    const uint64_t* asset_sizes;
+    const uint32_t* path_start_offsets;
+    const uint16_t* permissions;
+    const char* path_data;
+    uint32_t path_data_size;
+    const uint32_t* asset_tags;         /* may be NULL */
+    uint64_t job_count;                 /* lthip_make_jobs */
+    const uint32_t* job_asset;
+    const uint64_t* job_first;          /* [job_count + 1] index of each job's first chunk in the "all" arrays */
+    uint64_t my_job_count;
+    const uint64_t* my_jobs;            /* ascending job indices of this rank; NULL = all jobs */
+} lthip_ingest_tree;
+typedef struct lthip_ingest_result
+{
+    uint64_t chunks_all, unique_all;      /* chunks / distinct chunks of the whole tree */
+    uint64_t chunks_local, unique_local;  /* chunks of this rank's jobs / those of them this rank writes */
+    uint64_t blocks, raw_bytes, compressed_bytes, gathered_blocks;
+    uint64_t version_index_size, store_index_size;
+} lthip_ingest_result;
+LTHIP_EXPORT int lthip_ingest_create(lthip_ctx* ctx, const lthip_ingest_config* config, lthip_ingest** out);
+LTHIP_EXPORT void lthip_ingest_destroy(lthip_ingest* ingest);
+LTHIP_EXPORT int lthip_ingest_index(lthip_ingest* ingest, const lthip_ingest_tree* tree, const uint64_t* d_all_hashes,
+                                    const uint32_t* d_all_lens, uint64_t all_chunks, const uint64_t* d_local_offsets,
+                                    const uint32_t* d_local_part_first, uint64_t local_chunks, void* h_version_index,
+                                    size_t version_index_capacity);
+LTHIP_EXPORT int lthip_ingest_write(lthip_ingest* ingest, const void* d_data, void* d_arena, uint64_t arena_bytes);
+LTHIP_EXPORT int lthip_ingest_finish(lthip_ingest* ingest, void* h_store_index, size_t store_index_capacity,
+                                     lthip_ingest_result* out_result);
+/* per-block compressed sizes of the last lthip_ingest_write (host, valid after lthip_ingest_finish) */
+LTHIP_EXPORT const uint32_t* lthip_ingest_compressed_sizes(const lthip_ingest* ingest);
+
 /* ---- multi-GPU work division, host functions -----------------------------------------------------------
  * The unit of independence is the reference's own job: one (asset, target_chunk_size*1024-byte part) of ChunkAssets
  * (src/longtail.c:2396-2458).  lthip_job_count / lthip_make_jobs list the jobs of a tree exactly as :2399-2404 / :2432-2457 do
@@ -304,6 +371,11 @@ LTHIP_EXPORT int lthip_exchange_layout(uint64_t job_count, const uint32_t* job_r
 /* ---- synthetic assets (include/longtail_synth.h), bench/test input generator ------------------------ */
 LTHIP_EXPORT int lthip_synth_fill(lthip_ctx* ctx, void* d_dst, uint32_t asset_count, const uint64_t* asset_offsets /*host*/,
                                   const uint64_t* asset_sizes /*host*/, const uint64_t* asset_seeds /*host*/, int kind);
+/* the same for RANGES of assets: range i = bytes [asset_skips[i], asset_skips[i] + asset_sizes[i]) of the asset with seed
+ * asset_seeds[i] (skips are multiples of 16) -- a rank generates only the parts of a large asset it owns */
+LTHIP_EXPORT int lthip_synth_fill_ranges(lthip_ctx* ctx, void* d_dst, uint32_t asset_count, const uint64_t* asset_offsets /*host*/,
+                                         const uint64_t* asset_sizes /*host*/, const uint64_t* asset_seeds /*host*/,
+                                         const uint64_t* asset_skips /*host, may be NULL*/, int kind);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ struct SynthAsset
     uint64_t size;
     uint64_t seed;
     uint64_t vec_base; // first 16-byte vector of this asset in the launch's flat index space
+    uint64_t vec_skip; // 16-byte vectors of the asset before the range that is generated (a part of a large asset)
 };
 
 __global__ __launch_bounds__(256) void k_synth_fill(uint8_t* __restrict__ dst, const SynthAsset* __restrict__ assets,
@@ -31,8 +32,8 @@ __global__ __launch_bounds__(256) void k_synth_fill(uint8_t* __restrict__ dst, c
                 hi = mid;
         }
         const SynthAsset a = assets[lo];
-        const uint64_t local = v - a.vec_base; // vector index inside the asset
-        const uint64_t b = local * 16u;
+        const uint64_t b = (v - a.vec_base) * 16u;    // byte inside the generated range
+        const uint64_t local = v - a.vec_base + a.vec_skip; // vector index inside the asset
         if (b >= a.size)
             continue;
         const uint64_t w0 = lt_synth_word(a.seed, local * 2u, kind);
@@ -56,6 +57,12 @@ __global__ __launch_bounds__(256) void k_synth_fill(uint8_t* __restrict__ dst, c
 extern "C" int lthip_synth_fill(lthip_ctx* ctx, void* d_dst, uint32_t asset_count, const uint64_t* asset_offsets,
                                 const uint64_t* asset_sizes, const uint64_t* asset_seeds, int kind)
 {
+    return lthip_synth_fill_ranges(ctx, d_dst, asset_count, asset_offsets, asset_sizes, asset_seeds, nullptr, kind);
+}
+
+extern "C" int lthip_synth_fill_ranges(lthip_ctx* ctx, void* d_dst, uint32_t asset_count, const uint64_t* asset_offsets,
+                                       const uint64_t* asset_sizes, const uint64_t* asset_seeds, const uint64_t* asset_skips, int kind)
+{
     if (!ctx || (asset_count && (!d_dst || !asset_offsets || !asset_sizes || !asset_seeds)))
         return EINVAL;
     if (asset_count == 0)
@@ -75,6 +82,13 @@ extern "C" int lthip_synth_fill(lthip_ctx* ctx, void* d_dst, uint32_t asset_coun
         a.size = asset_sizes[i];
         a.seed = asset_seeds[i];
         a.vec_base = nvec;
+        a.vec_skip = 0;
+        if (asset_skips)
+        {
+            if (asset_skips[i] & 15u)
+                return lthip_fail(ctx, EINVAL, "lthip_synth_fill", "range starts must be multiples of 16 bytes");
+            a.vec_skip = asset_skips[i] / 16u;
+        }
         nvec += div_up_u64(a.size, 16);
         h.push_back(a);
     }

@@ -120,6 +120,13 @@ class HipLib:
         sig("lthip_pack_blocks", i32, [u64, vp, u32, u32, vp, u64, P(u64)])
         sig("lthip_pack_blocks_batch", i32, [u64, vp, u64, u32, u32, u64, u64, u32, u32, vp, vp, u64, P(u64), P(u64)])
         sig("lthip_synth_fill", i32, [vp, vp, u32, vp, vp, vp, i32])
+        sig("lthip_synth_fill_ranges", i32, [vp, vp, u32, vp, vp, vp, vp, i32])
+        sig("lthip_ingest_create", i32, [vp, vp, P(vp)])
+        sig("lthip_ingest_destroy", None, [vp])
+        sig("lthip_ingest_index", i32, [vp, vp, vp, vp, u64, vp, vp, u64, vp, sz])
+        sig("lthip_ingest_write", i32, [vp, vp, vp, u64])
+        sig("lthip_ingest_finish", i32, [vp, vp, sz, vp])
+        sig("lthip_ingest_compressed_sizes", vp, [vp])
         sig("lthip_divtest_eval", i32, [u32, u32])
         sig("lthip_job_count", u64, [u32, vp, u32])
         sig("lthip_make_jobs", i32, [u32, vp, u32, u64, vp, vp, vp])
@@ -211,11 +218,14 @@ class Context:
         return self.torch.device("cuda", self.device)
 
     # -- synthetic data --
-    def synth_fill(self, dst, offsets, sizes, seeds, kind: int):
+    def synth_fill(self, dst, offsets, sizes, seeds, kind: int, skips=None):
+        """Ranges [skips[i], skips[i] + sizes[i]) of the assets with the given seeds -> dst + offsets[i] (include/longtail_synth.h)."""
         o, s, sd = _u64arr(offsets), _u64arr(sizes), _u64arr(seeds)
+        sk = _u64arr(skips) if skips is not None else None
         self._check(
-            self.lib.dll.lthip_synth_fill(self.h, _ptr(dst), len(o), o.ctypes.data, s.ctypes.data, sd.ctypes.data, kind),
-            "lthip_synth_fill",
+            self.lib.dll.lthip_synth_fill_ranges(self.h, _ptr(dst), len(o), o.ctypes.data, s.ctypes.data, sd.ctypes.data,
+                                                 sk.ctypes.data if sk is not None else None, kind),
+            "lthip_synth_fill_ranges",
         )
 
     # -- phase 1 --
@@ -366,6 +376,93 @@ class Context:
         self._check(self.lib.dll.lthip_dedup_first_seen(self.h, n, _ptr(hashes), _ptr(first), _ptr(uniq)),
                     "lthip_dedup_first_seen")
         return first[:n], uniq
+
+
+class IngestConfig(C.Structure):
+    _fields_ = [("target_chunk_size", C.c_uint32), ("hash_identifier", C.c_uint32), ("max_block_size", C.c_uint32),
+                ("max_chunks_per_block", C.c_uint32), ("compression_type", C.c_uint32), ("codec", C.c_uint32),
+                ("batch_bytes", C.c_uint64)]
+
+
+class IngestTree(C.Structure):
+    _fields_ = [("asset_count", C.c_uint32), ("asset_sizes", C.c_void_p), ("path_start_offsets", C.c_void_p),
+                ("permissions", C.c_void_p), ("path_data", C.c_char_p), ("path_data_size", C.c_uint32), ("asset_tags", C.c_void_p),
+                ("job_count", C.c_uint64), ("job_asset", C.c_void_p), ("job_first", C.c_void_p), ("my_job_count", C.c_uint64),
+                ("my_jobs", C.c_void_p)]
+
+
+class IngestResult(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("chunks_all", "unique_all", "chunks_local", "unique_local", "blocks", "raw_bytes",
+                                          "compressed_bytes", "gathered_blocks", "version_index_size", "store_index_size")]
+
+
+CODECS = {"none": 0, "lz4": 1, "zstd": 2}
+LZ4_TYPE = 0x6C7A3432    # 'lz42', lib/lz4/longtail_lz4.c:10
+ZSTD_DEFAULT = 0x7A746432  # 'ztd2', lib/zstd/longtail_zstd.c:12-22 (ZSTD default quality)
+
+
+class Ingest:
+    """lthip_ingest: CreateVersionIndex tail + CreateMissingContent + WriteContent over device-resident chunk lists."""
+
+    def __init__(self, ctx: "Context", target_chunk_size: int, max_block_size: int, max_chunks_per_block: int, codec: str,
+                 compression_type: Optional[int] = None, batch_bytes: int = 0, hash_identifier: int = 0x626C6B33):
+        self.ctx = ctx
+        if compression_type is None:
+            compression_type = LZ4_TYPE if codec == "lz4" else ZSTD_DEFAULT
+        self.cfg = IngestConfig(target_chunk_size, hash_identifier, max_block_size, max_chunks_per_block, compression_type,
+                                CODECS[codec], batch_bytes)
+        h = C.c_void_p()
+        ctx._check(ctx.lib.dll.lthip_ingest_create(ctx.h, C.byref(self.cfg), C.byref(h)), "lthip_ingest_create")
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.dll.lthip_ingest_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def tree(asset_sizes, path_start_offsets, permissions, path_data: bytes, job_asset, job_first, my_jobs=None, asset_tags=None):
+        """-> (IngestTree, keep-alive list)."""
+        a_sz, a_off = _u64arr(asset_sizes), _u32arr(path_start_offsets)
+        a_perm = np.ascontiguousarray(np.asarray(permissions, dtype=np.uint16))
+        j_as, j_first = _u32arr(job_asset), _u64arr(job_first)
+        mine = _u64arr(my_jobs) if my_jobs is not None else None
+        tags = _u32arr(asset_tags) if asset_tags is not None else None
+        t = IngestTree(len(a_sz), a_sz.ctypes.data, a_off.ctypes.data, a_perm.ctypes.data, path_data, len(path_data),
+                       tags.ctypes.data if tags is not None else None, len(j_as), j_as.ctypes.data, j_first.ctypes.data,
+                       len(mine) if mine is not None else 0, mine.ctypes.data if mine is not None else None)
+        return t, [a_sz, a_off, a_perm, path_data, j_as, j_first, mine, tags]
+
+    def index(self, tree: IngestTree, all_hashes, all_lens, all_chunks: int, local_offsets, local_part_first, local_chunks: int,
+              version_index_out=None):
+        """version_index_out: a (pinned) uint8 torch tensor or numpy array, or None."""
+        cap = 0 if version_index_out is None else (version_index_out.numel() if hasattr(version_index_out, "numel") else len(version_index_out))
+        err = self.ctx.lib.dll.lthip_ingest_index(self.h, C.byref(tree), _ptr(all_hashes), _ptr(all_lens), all_chunks, _ptr(local_offsets),
+                                                  _ptr(local_part_first), local_chunks, _ptr(version_index_out) or None, cap)
+        self.ctx._check(err, "lthip_ingest_index")
+
+    def write(self, data, arena):
+        self.ctx._check(self.ctx.lib.dll.lthip_ingest_write(self.h, _ptr(data), _ptr(arena), int(arena.numel())), "lthip_ingest_write")
+
+    def finish(self, store_index_out=None) -> IngestResult:
+        cap = 0 if store_index_out is None else (store_index_out.numel() if hasattr(store_index_out, "numel") else len(store_index_out))
+        res = IngestResult()
+        err = self.ctx.lib.dll.lthip_ingest_finish(self.h, _ptr(store_index_out) or None, cap, C.byref(res))
+        self.ctx._check(err, "lthip_ingest_finish")
+        return res
+
+    def compressed_sizes(self, nblocks: int) -> np.ndarray:
+        p = self.ctx.lib.dll.lthip_ingest_compressed_sizes(self.h)
+        if not p or nblocks == 0:
+            return np.zeros(0, np.uint32)
+        return np.ctypeslib.as_array((C.c_uint32 * nblocks).from_address(p)).copy()
 
 
 class Plan:

@@ -935,4 +935,82 @@ int refh_ingest_time(uint32_t tag, uint32_t nfiles, const char* const* names, co
                        out_seconds_index, out_seconds_write);
 }
 
+/* bench.py cpu_baseline leg, SURVEY.md §8(d) protocol: ONE source tree (tmpfs file storage when refh_set_tree_dir was called),
+ * then for every worker count W of `workers` and every repetition the timed sequence
+ *     Longtail_CreateVersionIndex -> [GetExistingContent on the empty null store, untimed] -> Longtail_CreateMissingContent
+ *     -> Longtail_WriteContent (compressblockstore over a null block sink)
+ * with the reference's plugins and Longtail_CreateBikeshedJobAPI(W, 0).  out_seconds[(w * reps + r) * 3 + {0,1,2}] = seconds of
+ * the three calls. */
+int refh_ingest_sweep(uint32_t tag, uint32_t nfiles, const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
+                      uint32_t target_chunk_size, uint32_t max_block_size, uint32_t max_chunks_per_block, uint32_t n_workers,
+                      const int* workers, uint32_t reps, double* out_seconds, uint64_t* out_chunk_count, uint64_t* out_block_count,
+                      uint64_t* out_stored_bytes)
+{
+    struct refh_tree t;
+    int err = tree_make(&t, nfiles, names, datas, sizes, 1, tag);
+    if (err)
+        return err;
+    struct Longtail_ChunkerAPI* chunker_api = Longtail_CreateHPCDCChunkerAPI();
+    struct Longtail_HashAPI* hash_api = Longtail_CreateBlake3HashAPI();
+    for (uint32_t w = 0; w < n_workers && !err; ++w)
+    {
+        struct Longtail_JobAPI* jobs = Longtail_CreateBikeshedJobAPI((uint32_t)workers[w], 0);
+        for (uint32_t r = 0; r < reps && !err; ++r)
+        {
+            struct Longtail_VersionIndex* vi = 0;
+            struct Longtail_StoreIndex* existing = 0;
+            struct Longtail_StoreIndex* missing = 0;
+            struct Longtail_CompressionRegistryAPI* reg = make_registry(0, tag);
+            struct Longtail_BlockStoreAPI* sink = make_null_store();
+            struct Longtail_BlockStoreAPI* cbs = Longtail_CreateCompressBlockStoreAPI(sink, reg);
+            double* secs = out_seconds + ((size_t)w * reps + r) * 3;
+            struct timespec a, b;
+            clock_gettime(CLOCK_MONOTONIC, &a);
+            err = Longtail_CreateVersionIndex(t.storage, hash_api, chunker_api, jobs, 0, 0, 0, t.root, t.files, t.tags,
+                                              target_chunk_size, 0, &vi);
+            clock_gettime(CLOCK_MONOTONIC, &b);
+            secs[0] = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+            if (!err)
+                err = get_existing(cbs, *vi->m_ChunkCount, vi->m_ChunkHashes, &existing);
+            if (!err)
+            {
+                clock_gettime(CLOCK_MONOTONIC, &a);
+                err = Longtail_CreateMissingContent(hash_api, existing, vi, max_block_size, max_chunks_per_block, &missing);
+                clock_gettime(CLOCK_MONOTONIC, &b);
+                secs[1] = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+            }
+            if (!err)
+            {
+                clock_gettime(CLOCK_MONOTONIC, &a);
+                err = Longtail_WriteContent(t.storage, cbs, jobs, 0, 0, 0, missing, vi, t.root);
+                clock_gettime(CLOCK_MONOTONIC, &b);
+                secs[2] = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+            }
+            if (!err)
+            {
+                struct Longtail_BlockStore_Stats st;
+                memset(&st, 0, sizeof st);
+                sink->GetStats(sink, &st);
+                if (out_chunk_count)
+                    *out_chunk_count = *vi->m_ChunkCount;
+                if (out_block_count)
+                    *out_block_count = *missing->m_BlockCount;
+                if (out_stored_bytes)
+                    *out_stored_bytes = st.m_StatU64[Longtail_BlockStoreAPI_StatU64_PutStoredBlock_Byte_Count];
+            }
+            SAFE_DISPOSE_API(cbs);
+            SAFE_DISPOSE_API(reg);
+            SAFE_DISPOSE_API(sink);
+            Longtail_Free(missing);
+            Longtail_Free(existing);
+            Longtail_Free(vi);
+        }
+        SAFE_DISPOSE_API(jobs);
+    }
+    SAFE_DISPOSE_API(chunker_api);
+    SAFE_DISPOSE_API(hash_api);
+    tree_free(&t);
+    return err;
+}
+
 int refh_cpu_count(void) { return (int)Longtail_GetCPUCount(); }

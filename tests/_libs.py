@@ -133,6 +133,7 @@ class Ref:
         sig("refh_ingest_time", i32, [u32, u32, vp, vp, vp, u32, u32, u32, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64),
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)])
         sig("refh_cpu_count", i32, [])
+        sig("refh_ingest_sweep", i32, [u32, u32, vp, vp, vp, u32, u32, u32, u32, vp, u32, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)])
         sig("refh_chunk_stream_failing_feeder", i64, [vp, vp, u64, u32, u32, u32, u64, i32, vp, u64, vp])
         sig("refh_version_index_cancel", i32, [vp, vp, u32, vp, vp, vp, u32, i32, u32, C.POINTER(i32), C.POINTER(u32)])
         sig("refh_tree_file_infos", i32, [u32, vp, vp, vp, C.POINTER(vp), C.POINTER(u64)])
@@ -260,6 +261,18 @@ class Ref:
                                         C.byref(t_index), C.byref(t_write))
         return dict(err=err, chunks=nchunks.value, blocks=nblocks.value, stored_bytes=stored.value,
                     seconds_index=t_index.value, seconds_write=t_write.value)
+
+
+    def ingest_sweep(self, files, target_chunk_size, max_block_size, max_chunks_per_block, tag, workers, reps):
+        """One tree, then CreateVersionIndex + CreateMissingContent + WriteContent timed for every W of `workers`, `reps` times.
+        -> dict(err, chunks, blocks, stored_bytes, seconds[w][r] = (index, missing, write))"""
+        n, c_names, c_datas, c_sizes, keep = self._tree_args(files)
+        w = np.ascontiguousarray(workers, dtype=np.int32)
+        secs = np.zeros((len(w), reps, 3), np.float64)
+        nchunks, nblocks, stored = u64(0), u64(0), u64(0)
+        err = self.dll.refh_ingest_sweep(tag, n, c_names, c_datas, c_sizes, target_chunk_size, max_block_size, max_chunks_per_block,
+                                         len(w), w.ctypes.data, reps, secs.ctypes.data, C.byref(nchunks), C.byref(nblocks), C.byref(stored))
+        return dict(err=err, chunks=nchunks.value, blocks=nblocks.value, stored_bytes=stored.value, seconds=secs)
 
 
 _oracle = None

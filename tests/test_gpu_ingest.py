@@ -1,0 +1,199 @@
+"""-m gpu: the native ingest session (lthip_ingest_*, SURVEY.md §8d's metric = CreateVersionIndex + CreateMissingContent +
+WriteContent) against the reference run on the same tree (oracle/_ref):
+
+  * serialized VersionIndex          == Longtail_CreateVersionIndex + Longtail_WriteVersionIndexToBuffer, byte for byte
+  * serialized StoreIndex            == Longtail_CreateMissingContent + Longtail_WriteStoreIndexToBuffer on the version's chunks
+  * every stored-block image         opens with Longtail_ReadStoredBlockFromBuffer, BlockIndex == Longtail_CreateBlockIndex,
+                                       payload decoded by the REFERENCE codec == the block's chunk bytes
+  * R ranks (1 process, R sessions fed the job-ordered arrays the exchange would deliver, LPT / range / mod assignments, an
+    asset whose parts straddle ranks): rank 0's VersionIndex is the single-rank one; every rank's StoreIndex equals
+    Longtail_CreateMissingContent against a store holding the other ranks' chunks; the ranks' chunk sets partition the
+    version's unique chunks."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from longtail_amd.dist import JobPartition
+from longtail_amd.lib import Ingest, chunker_params
+from tests.gpu_util import to_device
+
+pytestmark = pytest.mark.gpu
+
+
+def make_files(oracle, target):
+    part = target * 1024
+    rng = np.random.default_rng(target)
+    files = []
+    for i in range(12):
+        files.append((f"dir{i % 3}/sub{i % 2}/file{i:02d}.bin", oracle.synth(int(rng.integers(1, 3 << 20)), 70 + i, i % 3)))
+    files.append(("dir0/copy_of_03.bin", files[3][1].copy()))                # duplicate content
+    files.append(("empty.bin", np.zeros(0, np.uint8)))
+    files.append(("zeros/all_zero.bin", np.zeros(2 << 20, np.uint8)))         # every chunk identical
+    files.append(("big/multi_part.bin", oracle.synth(min(part * 3 + 4321, 9 << 20), 5, 1)))  # several jobs
+    if part <= (4 << 20):
+        files.append(("big/exact_parts.bin", oracle.synth(part * 2, 6, 0)))  # ends with an empty job
+    return files
+
+
+def rank_session(gpu, ref, files, target, world, rank, policy, codec, max_block, max_chunks, tag, all_lists=None, arena_bytes=None):
+    """Chunk + hash the rank's jobs on the GPU; with all_lists (job -> (hashes, lens) of every job) run the session."""
+    by_name = {n: d for n, d in files}
+    paths, sizes, offs, perms, path_data = ref.tree_file_infos(files)
+    part = JobPartition(sizes, target, world, policy)
+    mine = part.jobs_of(rank)
+    blobs = []
+    for j in mine:
+        data = by_name.get(paths[int(part.job_asset[j])], np.zeros(0, np.uint8))
+        o, s = int(part.job_offset[j]), int(part.job_size[j])
+        blobs.append(data[o : o + s])
+    dev, part_offs = to_device(blobs) if blobs else (torch.zeros(64, dtype=torch.uint8, device="cuda"), [])
+    mn, av, mx = chunker_params(target)
+    plan = gpu.make_plan(part_offs, [len(b) for b in blobs], mn, av, mx)
+    total, d_off, d_len, d_hash, d_first = gpu.chunk_hash(plan, dev)
+    plan.close()
+    first = d_first.cpu().numpy().view(np.uint32).astype(np.int64)
+    local = dict(part=part, mine=mine, dev=dev, total=total, d_off=d_off, d_len=d_len, d_hash=d_hash, d_first=d_first, first=first,
+                 infos=(paths, sizes, offs, perms, path_data))
+    if all_lists is None:
+        return local
+    # the job-ordered arrays of all ranks (what dist.exchange_chunks delivers)
+    all_hash = torch.cat([all_lists[j][0] for j in range(part.job_count)]) if part.job_count else torch.zeros(0, dtype=torch.int64, device="cuda")
+    all_lens = torch.cat([all_lists[j][1] for j in range(part.job_count)]) if part.job_count else torch.zeros(0, dtype=torch.int32, device="cuda")
+    job_first = np.concatenate([[0], np.cumsum([int(all_lists[j][0].numel()) for j in range(part.job_count)])]).astype(np.uint64)
+    n_all = int(job_first[-1])
+    ing = Ingest(gpu, target, max_block, max_chunks, codec, compression_type=tag)
+    tree, keep = Ingest.tree(sizes, offs, perms, path_data, part.job_asset, job_first, my_jobs=None if world == 1 else mine)
+    vi = torch.zeros(gpu.lib.dll.lthip_version_index_size(len(sizes), n_all, n_all, len(path_data)) + 64, dtype=torch.uint8).pin_memory()
+    ing.index(tree, all_hash, all_lens, n_all, d_off, d_first, total, vi if rank == 0 else None)
+    arena = torch.zeros(arena_bytes or (64 << 20), dtype=torch.uint8, device="cuda")
+    ing.write(dev, arena)
+    si = torch.zeros(16 + 32 * max(total, 1) + 64, dtype=torch.uint8).pin_memory()
+    res = ing.finish(si)
+    local.update(ing=ing, res=res, vi=bytes(vi.numpy()[: res.version_index_size]) if rank == 0 else None,
+                 si=bytes(si.numpy()[: res.store_index_size]), arena=arena, comp=ing.compressed_sizes(res.blocks),
+                 all_hash=all_hash, all_lens=all_lens, job_first=job_first)
+    return local
+
+
+def parse_store_index(blob):
+    head = np.frombuffer(blob[:16], np.uint32)
+    nb, m = int(head[2]), int(head[3])
+    o = 16
+    bh = np.frombuffer(blob[o : o + nb * 8], np.uint64); o += nb * 8
+    ch = np.frombuffer(blob[o : o + m * 8], np.uint64); o += m * 8
+    bo = np.frombuffer(blob[o : o + nb * 4], np.uint32); o += nb * 4
+    bc = np.frombuffer(blob[o : o + nb * 4], np.uint32); o += nb * 4
+    bt = np.frombuffer(blob[o : o + nb * 4], np.uint32); o += nb * 4
+    cs = np.frombuffer(blob[o : o + m * 4], np.uint32); o += m * 4
+    assert o == len(blob)
+    return dict(block_hashes=bh, chunk_hashes=ch, block_offsets=bo, block_counts=bc, block_tags=bt, chunk_sizes=cs)
+
+
+def ref_missing_content(ref, existing, hashes, sizes, tags, max_block, max_chunks):
+    buf, size = C.c_void_p(), C.c_uint64(0)
+    existing = np.ascontiguousarray(existing, dtype=np.uint64)
+    hashes, sizes, tags = (np.ascontiguousarray(a) for a in (hashes, sizes, tags))
+    err = ref.dll.refh_missing_content(existing.ctypes.data if len(existing) else None, len(existing), hashes.ctypes.data, sizes.ctypes.data,
+                                       tags.ctypes.data, len(hashes), max_block, max_chunks, C.byref(buf), C.byref(size))
+    assert err == 0
+    out = bytes((C.c_ubyte * size.value).from_address(buf.value))
+    ref.dll.refh_free(buf)
+    return out
+
+
+def version_unique_lists(vi_blob):
+    """(chunk hashes, sizes, tags) of a serialized VersionIndex (layout src/longtail.c:2551-2584)."""
+    h = np.frombuffer(vi_blob[:24], np.uint32)
+    na, nu, ni = int(h[3]), int(h[4]), int(h[5])
+    o = 24 + na * (8 + 8 + 8 + 4 + 4) + ni * 4
+    hashes = np.frombuffer(vi_blob[o : o + nu * 8], np.uint64); o += nu * 8
+    sizes = np.frombuffer(vi_blob[o : o + nu * 4], np.uint32); o += nu * 4
+    tags = np.frombuffer(vi_blob[o : o + nu * 4], np.uint32)
+    return hashes, sizes, tags
+
+
+def check_images(gpu, ref, sess, codec_id, tag, max_block):
+    """Every stored-block image of the (single-batch) arena through the reference's reader and codec."""
+    si = parse_store_index(sess["si"])
+    res, comp = sess["res"], sess["comp"]
+    host = sess["arena"].cpu().numpy()
+    # owned chunks' bytes in version order: offsets from the session's inputs
+    first_idx, _ = gpu.dedup_first_seen(sess["all_hash"])
+    pos = 0
+    bound = (lambda n: n + n // 255 + 16) if codec_id == 0 else (lambda n: int(gpu.lib.dll.lthip_zstd_bound(n)))
+    data_host = sess["dev"].cpu().numpy()
+    # owned chunk byte ranges: recompute from local chunk lists + ownership (store index lists them in order)
+    l_off = sess["d_off"].cpu().numpy().view(np.uint64)[: sess["total"]]
+    l_len = sess["d_len"].cpu().numpy().view(np.uint32)[: sess["total"]]
+    l_hash = sess["d_hash"].cpu().numpy().view(np.uint64)[: sess["total"]]
+    owned_pos = {}
+    for k in range(sess["total"]):
+        owned_pos.setdefault(int(l_hash[k]), (int(l_off[k]), int(l_len[k])))
+    for b in range(res.blocks):
+        c0, n = int(si["block_offsets"][b]), int(si["block_counts"][b])
+        raw = int(si["chunk_sizes"][c0 : c0 + n].astype(np.int64).sum())
+        hdr = int(gpu.lib.dll.lthip_stored_block_header_size(n))
+        image = host[pos : pos + hdr + int(comp[b])].copy()
+        pos += (hdr + bound(raw) + 63) // 64 * 64
+        h = np.ascontiguousarray(si["chunk_hashes"][c0 : c0 + n])
+        s = np.ascontiguousarray(si["chunk_sizes"][c0 : c0 + n])
+        out = np.zeros(raw + 8, np.uint8)
+        got = C.c_uint64(0)
+        err = ref.dll.refh_open_stored_block(image.ctypes.data, len(image), n, h.ctypes.data, s.ctypes.data, int(si["block_tags"][b]),
+                                             out.ctypes.data, raw, C.byref(got))
+        assert err == 0, (b, err)
+        expect = np.concatenate([data_host[owned_pos[int(x)][0] : owned_pos[int(x)][0] + owned_pos[int(x)][1]] for x in h])
+        assert got.value == raw and (out[:raw] == expect).all(), b
+
+
+@pytest.mark.parametrize("target,codec,max_block,max_chunks", [(65536, "lz4", 8 << 20, 1024), (4096, "zstd", 1 << 20, 64), (1024, "lz4", 262144, 16)])
+def test_ingest_session_single_rank_matches_reference(gpu, oracle, ref, target, codec, max_block, max_chunks):
+    files = make_files(oracle, target)
+    tag = ref.lz4_type if codec == "lz4" else ref.zstd_default
+    probe = rank_session(gpu, ref, files, target, 1, 0, "range", codec, max_block, max_chunks, tag)
+    lists = {int(j): (probe["d_hash"][int(probe["first"][m]) : int(probe["first"][m + 1])], probe["d_len"][int(probe["first"][m]) : int(probe["first"][m + 1])])
+             for m, j in enumerate(probe["mine"])}
+    sess = rank_session(gpu, ref, files, target, 1, 0, "range", codec, max_block, max_chunks, tag, lists, arena_bytes=96 << 20)
+    expect_vi, _ = ref.version_index(files, target, 0, tag)
+    assert sess["vi"] == expect_vi, "VersionIndex differs from Longtail_CreateVersionIndex"
+    uh, us, ut = version_unique_lists(expect_vi)
+    expect_si = ref_missing_content(ref, np.zeros(0, np.uint64), uh, us, ut, max_block, max_chunks)
+    assert sess["si"] == expect_si, "StoreIndex differs from Longtail_CreateMissingContent"
+    res = sess["res"]
+    assert res.chunks_all == res.chunks_local and res.unique_all == res.unique_local == len(uh) < res.chunks_all
+    assert res.raw_bytes == int(us.astype(np.int64).sum()) and 0 < res.compressed_bytes == int(sess["comp"].astype(np.int64).sum())
+    assert res.gathered_blocks > 0  # the duplicate / zero files leave holes: some blocks are not one byte range
+    check_images(gpu, ref, sess, 0 if codec == "lz4" else 1, tag, max_block)
+
+
+@pytest.mark.parametrize("world,policy", [(2, "range"), (3, "lpt"), (4, "range"), (4, "mod")])
+def test_ingest_sessions_of_r_ranks_partition_the_reference_result(gpu, oracle, ref, world, policy):
+    target, codec, max_block, max_chunks = 1024, "lz4", 262144, 64
+    tag = ref.lz4_type
+    files = make_files(oracle, target)
+    probes = [rank_session(gpu, ref, files, target, world, r, policy, codec, max_block, max_chunks, tag) for r in range(world)]
+    lists = {}
+    for p in probes:
+        for m, j in enumerate(p["mine"]):
+            a, b = int(p["first"][m]), int(p["first"][m + 1])
+            lists[int(j)] = (p["d_hash"][a:b].clone(), p["d_len"][a:b].clone())
+    part = probes[0]["part"]
+    assert len(lists) == part.job_count
+    multi = int(np.flatnonzero(np.bincount(part.job_asset) > 2)[0])
+    if policy != "lpt" or world > 1:
+        assert len(set(part.job_rank[part.job_asset == multi].tolist())) > 1  # an asset's parts straddle ranks
+    sessions = [rank_session(gpu, ref, files, target, world, r, policy, codec, max_block, max_chunks, tag, lists, arena_bytes=64 << 20)
+                for r in range(world)]
+    expect_vi, _ = ref.version_index(files, target, 0, tag)
+    assert sessions[0]["vi"] == expect_vi, "rank 0's VersionIndex differs from the single-process reference"
+    uh, us, ut = version_unique_lists(expect_vi)
+    owned = [parse_store_index(s["si"])["chunk_hashes"] for s in sessions]
+    allc = np.concatenate(owned)
+    assert len(allc) == len(uh) and set(allc.tolist()) == set(uh.tolist())  # a partition of the version's unique chunks
+    for r, s in enumerate(sessions):
+        others = np.concatenate([owned[q] for q in range(world) if q != r]) if world > 1 else np.zeros(0, np.uint64)
+        assert s["si"] == ref_missing_content(ref, others, uh, us, ut, max_block, max_chunks), f"rank {r} StoreIndex"
+        assert s["res"].unique_all == len(uh) and s["res"].unique_local == len(owned[r])
+        check_images(gpu, ref, s, 0, tag, max_block)
