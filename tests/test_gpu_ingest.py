@@ -181,9 +181,10 @@ def test_ingest_sessions_of_r_ranks_partition_the_reference_result(gpu, oracle, 
             lists[int(j)] = (p["d_hash"][a:b].clone(), p["d_len"][a:b].clone())
     part = probes[0]["part"]
     assert len(lists) == part.job_count
-    multi = int(np.flatnonzero(np.bincount(part.job_asset) > 2)[0])
-    if policy != "lpt" or world > 1:
-        assert len(set(part.job_rank[part.job_asset == multi].tolist())) > 1  # an asset's parts straddle ranks
+    multi = np.flatnonzero(np.bincount(part.job_asset) > 2)
+    straddling = [a for a in multi if len(set(part.job_rank[part.job_asset == a].tolist())) > 1]
+    if policy == "mod":
+        assert straddling  # consecutive jobs alternate ranks: the multi-part assets' parts straddle ranks
     sessions = [rank_session(gpu, ref, files, target, world, r, policy, codec, max_block, max_chunks, tag, lists, arena_bytes=64 << 20)
                 for r in range(world)]
     expect_vi, _ = ref.version_index(files, target, 0, tag)
