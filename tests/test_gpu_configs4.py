@@ -119,7 +119,7 @@ def test_ingest_session_indexes_and_zstd_frames(gpu, oracle, pak):
     assert (np.frombuffer(blob[o : o + 32], np.uint64) == pak["sizes"]).all(); o += 32
     counts = np.frombuffer(blob[o : o + 16], np.uint32); o += 16
     hash_h = pak["d_hash"].cpu().numpy().view(np.uint64)
-    bounds = np.concatenate([[0], np.cumsum(counts)])
+    bounds = np.concatenate([[0], np.cumsum(counts.astype(np.int64))])
     per_asset = [int(pak["first"][np.flatnonzero(part.job_asset == a)[-1] + 1] - pak["first"][np.flatnonzero(part.job_asset == a)[0]]) for a in range(4)]
     assert counts.tolist() == per_asset
     for a in range(4):
