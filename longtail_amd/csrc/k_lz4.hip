@@ -259,22 +259,347 @@ __device__ __forceinline__ void lz4_coop_sequence(const uint8_t* __restrict__ sb
 // the history lazily: every wave first parses PROBE batches with an empty table; if any wave of the group finds a
 // match the data is taken to be compressible and each wave inserts the positions before its unit (newer entries
 // kept), otherwise (incompressible data) nobody pays for it.  24 waves per CU instead of 4 at the same window.
-constexpr int LZ4_G = 8;
+constexpr int LZ4_G_BATCH = 8;   // MODE 0 (batch parser): 8 x 4 KiB units per 32 KiB window group
+constexpr int LZ4_G_LANES = 16;  // MODE 1 (lane parser): 16 x 4 KiB units per 64 KiB window group, one workgroup per CU
 constexpr int LZ4_PROBE_BATCHES = 4;
+constexpr int LZ4_LANE_PROBES = 8; // MODE 1: positions every lane probes before the group decides whether the data is worth parsing
 constexpr uint32_t Z_PIECE = 128u << 10; // zstd Block_Maximum_Size (ZB_BLOCK_MAX of zstd_block_core.h, asserted in k_zstd.hip)
-// table entries per wave: with 1536 the LZ4 flavour needs 57 KiB of LDS per workgroup... see the host launcher
-constexpr int LZ4_TAB_LZ4 = 1024 + 256;  // 32 KiB window + 8 x 2.5 KiB tables = 52 KiB: THREE workgroups (24 waves) per CU
+// table entries per wave.  MODE 0: 32 KiB window + 8 x 2.5 KiB tables = 52 KiB: THREE workgroups (24 waves) per CU.
+// MODE 1: 64 KiB window + 16 x 5 KiB tables = 144 KiB: one workgroup of 16 waves per CU (the lane parser is not issue bound, it
+// wants history: tools/lz4_lane_model.c -- mixed 1.72 at 8 x 1280, 1.85 at 16 x 2048, 1.89 at 16 x 2560; reference 1.92)
+constexpr int LZ4_TAB_LZ4 = 1024 + 256;
 constexpr int LZ4_TAB_ZSTD = 1024 + 256;
+constexpr int LZ4_TAB_LANES = 2560;
 
-// TAB = entries of a wave's private table (any multiple of 8: the index is mulhi(hash, TAB), not a mask)
+// ---------------------------------------------------------------------------------------------------
+// K5, lane-sequential parse (MODE 1).  The batch parser above looks at 64 CONSECUTIVE positions per step and then has to choose
+// among the hits -- a scalar walk that costs ~400 wave instructions per 64 positions on compressible data.  Here every lane owns
+// a SUB-UNIT (unit / 64 bytes) and runs the reference's greedy loop on it (lz4.c:1019-1110: probe; on a hit extend, record,
+// jump; else step one byte): 64 independent parsers in lock step, one probe per lane per iteration, no selection at all.
+//   * the table is the wave's private one; positions of all lanes go into it.  Lanes are mapped to sub-units in REVERSE
+//     (lane 63 = first sub-unit) so that when two lanes write one slot in the same instruction the surviving entry is the lower
+//     position, which every later sub-unit can use (tools/lz4_lane_model.c: "lines" 8.4 -> 20.7, mixed 1.66 -> 1.72)
+//   * a match may run past its lane's sub-unit (up to the unit's end); what it covers is dropped from the later lanes'
+//     records afterwards (exclusive prefix maximum of the lanes' match ends) and lanes that are covered while a long match
+//     is being extended stop parsing
+//   * records {start, length, offset} go to a per-unit scratch area (8 per lane); after the parse three wave scans (cover,
+//     previous kept end, output offset) place every lane's sequences and each lane writes its own bytes; literal runs longer
+//     than 16 bytes are copied by the whole wave
+// Results are a function of the data only (the table is private, the wave runs in lock step).
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t LZ4_LANE_MAXREC = 8; // sequences a lane may record (tools/lz4_lane_model.c: 8 costs nothing, 6 does)
+
+// value held by the lane that owns sub-unit `s` (s outside 0..63: `ident`)
+__device__ __forceinline__ uint32_t sub_shfl(uint32_t x, int s, bool rev, uint32_t ident)
+{
+    const int src = rev ? 63 - s : s;
+    const uint32_t v = __shfl(x, src & 63, 64);
+    return (s < 0 || s > 63) ? ident : v;
+}
+
 template <int TAB, int FMT>
-__global__ __launch_bounds__(64 * LZ4_G, 6) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
+__device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t head, uint16_t* tab, int lane, uint32_t my_start,
+                                               uint32_t my_len, int32_t start_limit, uint32_t end_limit, uint32_t sub, uint8_t* __restrict__ out,
+                                               uint64_t* __restrict__ zrecs, uint64_t* __restrict__ lrecs, Lz4Seq& st, uint32_t dbg)
+{
+    const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(sdata);
+    const bool rev = !(dbg & 128u);
+    const int sidx = rev ? 63 - lane : lane; // my sub-unit
+    const uint32_t unit_end = my_start + my_len;
+    const uint32_t s0 = my_start + (uint32_t)sidx * sub;
+    const uint32_t lend = s0 + sub < unit_end ? s0 + sub : unit_end;
+    uint32_t p = s0, anchor = s0, nrec = 0, last_end = 0;
+    uint64_t* myrecs = lrecs + (uint32_t)sidx * LZ4_LANE_MAXREC;
+
+    for (;;)
+    {
+        const bool act = p < lend && (int32_t)p <= start_limit && nrec < LZ4_LANE_MAXREC;
+        if (__builtin_amdgcn_ballot_w64(act) == 0ull)
+            break;
+        uint32_t v = 0, h = 0, cand = LZ4_EMPTY;
+        if (act)
+        {
+            v = lds_read32(sdata, p + head);
+            h = __umulhi(v * 2654435761u, (uint32_t)TAB);
+            cand = tab[h];
+        }
+        if (act)
+        {
+            // every lane has read before anyone writes (one wave: LDS operations execute in order) ... and reads again after
+            // everyone has written: when several lanes insert the same slot in this step the entry that survives (the lowest
+            // position: lanes are mapped to sub-units in reverse) is a candidate for the others at once
+            tab[h] = (uint16_t)p;
+            const uint32_t fresh = *reinterpret_cast<volatile uint16_t*>(&tab[h]); // volatile: not the value this lane just stored
+            if (fresh < p)
+                cand = fresh;
+        }
+        bool ok = false;
+        if (act && cand != LZ4_EMPTY && cand < p)
+            ok = lds_read32(sdata, cand + head) == v;
+        if (__builtin_amdgcn_ballot_w64(ok) == 0ull)
+        {
+            p += act ? 1u : 0u;
+            continue;
+        }
+        // ---- forwards, every hit lane for itself: 16 bytes per LDS round trip, at most 36 bytes ----
+        uint32_t mlen = ok ? 4u : 0u;
+        bool grow = ok;
+        const uint32_t maxlen = ok ? end_limit - p : 0u; // p <= start_limit: at least 4
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t)
+        {
+            if (__builtin_amdgcn_ballot_w64(grow) == 0ull)
+                break;
+            if (grow)
+            {
+                const uint32_t a0 = p + mlen + head, b0 = cand + mlen + head;
+                const uint32_t x0 = lds_read32(sdata, a0) ^ lds_read32(sdata, b0);
+                const uint32_t x1 = lds_read32(sdata, a0 + 4u) ^ lds_read32(sdata, b0 + 4u);
+                const uint32_t x2 = lds_read32(sdata, a0 + 8u) ^ lds_read32(sdata, b0 + 8u);
+                const uint32_t x3 = lds_read32(sdata, a0 + 12u) ^ lds_read32(sdata, b0 + 12u);
+                uint32_t add = 16u;
+                if (x0)
+                    add = (uint32_t)__builtin_ctz(x0) >> 3;
+                else if (x1)
+                    add = 4u + ((uint32_t)__builtin_ctz(x1) >> 3);
+                else if (x2)
+                    add = 8u + ((uint32_t)__builtin_ctz(x2) >> 3);
+                else if (x3)
+                    add = 12u + ((uint32_t)__builtin_ctz(x3) >> 3);
+                mlen += add;
+                if (add != 16u)
+                    grow = false;
+                if (mlen >= maxlen)
+                {
+                    mlen = maxlen;
+                    grow = false;
+                }
+            }
+        }
+        // ---- backwards, at most 8 bytes (the history was inserted every 4th position: a match is found up to 3 bytes late) ----
+        uint32_t nbk = 0;
+        if (ok && cand >= 8u && p - anchor != 0u)
+        {
+            const uint32_t x = lds_read32(sdata, p - 4u + head) ^ lds_read32(sdata, cand - 4u + head);
+            const uint32_t y = lds_read32(sdata, p - 8u + head) ^ lds_read32(sdata, cand - 8u + head);
+            nbk = x ? (uint32_t)__builtin_clz(x) >> 3 : (y ? 4u + ((uint32_t)__builtin_clz(y) >> 3) : 8u);
+            nbk = nbk < p - anchor ? nbk : p - anchor;
+        }
+        // ---- matches still equal after 36 bytes: extended by the whole wave, lowest position first; the lanes whose position
+        // such a match covers give up what they hold (it would be dropped below anyway) and continue behind it ----
+        uint64_t longs = __builtin_amdgcn_ballot_w64(grow);
+        bool covered = false;
+        while (longs)
+        {
+            const int f = rev ? 63 - __builtin_clzll(longs) : __builtin_ctzll(longs);
+            longs &= ~(1ull << f);
+            const uint32_t pf = __builtin_amdgcn_readlane(p, f), cf = __builtin_amdgcn_readlane(cand, f);
+            uint32_t ml = __builtin_amdgcn_readlane(mlen, f);
+            for (;;)
+            {
+                const uint32_t i = pf + ml + 4u * (uint32_t)lane;
+                uint32_t cnt = 0; // equal bytes of my four, as far as the unit goes
+                if (i < end_limit)
+                {
+                    const uint32_t x = lds_read32(sdata, i + head) ^ lds_read32(sdata, cf + ml + 4u * (uint32_t)lane + head);
+                    const uint32_t lim = end_limit - i < 4u ? end_limit - i : 4u;
+                    cnt = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+                    cnt = cnt < lim ? cnt : lim;
+                }
+                const uint64_t diff = __builtin_amdgcn_ballot_w64(cnt < 4u);
+                if (diff)
+                {
+                    const int g = __builtin_ctzll(diff);
+                    ml += 4u * (uint32_t)g + __builtin_amdgcn_readlane(cnt, g);
+                    break;
+                }
+                ml += 256u;
+            }
+            if (lane == f)
+                mlen = ml;
+            const uint32_t cov = pf + ml;
+            const bool cv = lane != f && p > pf && p < cov;
+            if (cv)
+            {
+                p = cov;
+                anchor = anchor > cov ? anchor : cov;
+                ok = false;
+                covered = true;
+            }
+            longs &= ~__builtin_amdgcn_ballot_w64(cv);
+        }
+        if (ok)
+        {
+            const uint32_t s = p - nbk, len = mlen + nbk;
+            myrecs[nrec] = (uint64_t)s | ((uint64_t)len << 16) | ((uint64_t)(p - cand) << 32);
+            ++nrec;
+            p = s + len;
+            anchor = p;
+            last_end = p;
+        }
+        else if (act && !covered)
+            p += 1u;
+    }
+
+    // ---- what earlier sub-units' matches cover is dropped: exclusive prefix maximum of the match ends, in sub-unit order ----
+    uint32_t incl = last_end;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const uint32_t o = sub_shfl(incl, sidx - d, rev, 0u);
+        incl = incl > o ? incl : o;
+    }
+    const uint32_t cover = sub_shfl(incl, sidx - 1, rev, 0u);
+    uint32_t k0 = 0; // my first record that starts at or after the cover
+    while (k0 < nrec && (uint32_t)(myrecs[k0] & 0xFFFFu) < cover)
+        ++k0;
+    const bool have = k0 < nrec;
+    const uint32_t first_start_v = have ? (uint32_t)(myrecs[k0] & 0xFFFFu) : 0u;
+    // previous kept end = where the literals of my first kept sequence begin
+    uint32_t kincl = have ? last_end : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const uint32_t o = sub_shfl(kincl, sidx - d, rev, 0u);
+        kincl = kincl > o ? kincl : o;
+    }
+    uint32_t prev0 = sub_shfl(kincl, sidx - 1, rev, 0u);
+    prev0 = prev0 > my_start ? prev0 : my_start;
+    // sizes
+    uint32_t bytes = 0, nlit = 0;
+    {
+        uint32_t prev = prev0;
+        for (uint32_t k = k0; k < nrec; ++k)
+        {
+            const uint64_t r = myrecs[k];
+            const uint32_t s = (uint32_t)(r & 0xFFFFu), len = (uint32_t)(r >> 16) & 0xFFFFu;
+            const uint32_t lit = s - prev;
+            bytes += 1u + lz4_len_bytes(lit) + lit + 2u + lz4_len_bytes(len - 4u);
+            nlit += lit;
+            prev = s + len;
+        }
+    }
+    const uint32_t cnt = have ? nrec - k0 : 0u;
+    // exclusive prefix sums in sub-unit order: output bytes (FMT 0) or literal bytes and sequence numbers (FMT 1)
+    uint32_t a_incl = FMT == 1 ? nlit : bytes, c_incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        a_incl += sub_shfl(a_incl, sidx - d, rev, 0u);
+        if constexpr (FMT == 1)
+            c_incl += sub_shfl(c_incl, sidx - d, rev, 0u);
+    }
+    const uint32_t a_total = sub_shfl(a_incl, 63, rev, 0u);
+    uint32_t o_pos = a_incl - (FMT == 1 ? nlit : bytes);
+    uint32_t q_pos = FMT == 1 ? c_incl - cnt : 0u;
+    const uint32_t last_kept_end = sub_shfl(kincl, 63, rev, 0u);
+
+    // ---- emission: every lane writes its own sequences; literal runs above 16 bytes are copied by the whole wave ----
+    {
+        uint32_t prev = prev0;
+        uint32_t kmax = cnt;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1)
+        {
+            const uint32_t o = __shfl_xor(kmax, d, 64);
+            kmax = kmax > o ? kmax : o;
+        }
+        for (uint32_t t = 0; t < kmax; ++t)
+        {
+            const bool on = t < cnt;
+            uint32_t lit = 0, lit_src = 0, lit_dst = 0;
+            if (on)
+            {
+                const uint64_t r = myrecs[k0 + t];
+                const uint32_t s = (uint32_t)(r & 0xFFFFu), len = (uint32_t)(r >> 16) & 0xFFFFu, off = (uint32_t)(r >> 32);
+                lit = s - prev;
+                lit_src = prev;
+                if constexpr (FMT == 1)
+                {
+                    lit_dst = o_pos;
+                    zrecs[q_pos] = (uint64_t)lit | ((uint64_t)len << 16) | ((uint64_t)off << 32);
+                    ++q_pos;
+                    o_pos += lit;
+                }
+                else
+                {
+                    uint8_t* o = out + o_pos;
+                    const uint32_t mcode = len - 4u;
+                    o[0] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
+                    uint32_t idx = 1u;
+                    if (lit >= 15u)
+                    {
+                        uint32_t rem = lit - 15u;
+                        for (; rem >= 255u; rem -= 255u)
+                            o[idx++] = 255;
+                        o[idx++] = (uint8_t)rem;
+                    }
+                    lit_dst = o_pos + idx;
+                    idx += lit;
+                    o[idx] = (uint8_t)off;
+                    o[idx + 1u] = (uint8_t)(off >> 8);
+                    idx += 2u;
+                    if (mcode >= 15u)
+                    {
+                        uint32_t rem = mcode - 15u;
+                        for (; rem >= 255u; rem -= 255u)
+                            o[idx++] = 255;
+                        o[idx++] = (uint8_t)rem;
+                    }
+                    o_pos += idx;
+                }
+                prev = s + len;
+                if (lit <= 16u)
+                {
+                    uint8_t* o = out + lit_dst;
+                    for (uint32_t j = 0; j < lit; ++j)
+                        o[j] = sbytes[lit_src + j + head];
+                }
+            }
+            uint64_t big = __builtin_amdgcn_ballot_w64(on && lit > 16u);
+            while (big)
+            {
+                const int f = __builtin_ctzll(big);
+                big &= big - 1ull;
+                wave_copy_lds_to_global(out + __builtin_amdgcn_readlane(lit_dst, f), sdata, __builtin_amdgcn_readlane(lit_src, f) + head,
+                                        __builtin_amdgcn_readlane(lit, f), lane);
+            }
+        }
+    }
+    // ---- the unit's result, as the batch parser leaves it ----
+    const uint64_t hm = __builtin_amdgcn_ballot_w64(have);
+    st.have_first = hm != 0ull;
+    st.anchor = hm ? last_kept_end : my_start;
+    if constexpr (FMT == 1)
+    {
+        st.op = a_total; // literal bytes so far
+        st.nseq = sub_shfl(c_incl, 63, rev, 0u);
+    }
+    else
+    {
+        st.op = a_total;
+        if (hm)
+        {
+            const int f = rev ? 63 - __builtin_clzll(hm) : __builtin_ctzll(hm); // the lane of the first sub-unit with a sequence
+            const uint32_t first_start = __builtin_amdgcn_readlane(first_start_v, f);
+            st.first_lit = first_start - my_start;
+            st.first_hdr = 1u + lz4_len_bytes(st.first_lit);
+        }
+    }
+}
+
+// TAB = entries of a wave's private table (any multiple of 8: the index is mulhi(hash, TAB), not a mask); G = units per window
+// group = waves per workgroup; MODE 0 = batch parser, 1 = lane parser for groups whose probe finds redundancy (incompressible
+// groups are skimmed by the batch parser's miss mode either way)
+template <int G, int TAB, int FMT, int MODE>
+__global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
                                                              uint32_t nblocks, uint32_t grp0, uint32_t sub_bytes,
                                                              uint8_t* __restrict__ streams, Lz4Meta* __restrict__ meta,
-                                                             uint64_t* __restrict__ zrecs, uint8_t* __restrict__ spec_dst, uint32_t dbg)
+                                                             uint64_t* __restrict__ zrecs, uint8_t* __restrict__ spec_dst, uint32_t dbg,
+                                                             uint64_t* __restrict__ lane_recs)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t data_bytes = LZ4_G * sub_bytes + 64u;
+    const uint32_t data_bytes = G * sub_bytes + 64u;
     uint32_t* sdata = smem;
     const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(sdata);
     uint32_t* flag = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes); // 16 bytes
@@ -295,8 +620,8 @@ __global__ __launch_bounds__(64 * LZ4_G, 6) void k_lz4_segments(const uint8_t* _
     }
     const Lz4Block blk = blocks[lo];
     const uint32_t gi = grp - blk.grp_base;
-    const uint32_t group_start = gi * LZ4_G * sub_bytes;                                   // block relative
-    const uint32_t glen = blk.size - group_start < LZ4_G * sub_bytes ? blk.size - group_start : LZ4_G * sub_bytes;
+    const uint32_t group_start = gi * G * sub_bytes;                                   // block relative
+    const uint32_t glen = blk.size - group_start < G * sub_bytes ? blk.size - group_start : G * sub_bytes;
     const uint8_t* g = src + blk.src_off + group_start;
 
     // ---- stage the whole group with every wave (16-byte loads from the aligned-down address), clear my table ----
@@ -305,19 +630,19 @@ __global__ __launch_bounds__(64 * LZ4_G, 6) void k_lz4_segments(const uint8_t* _
         const uint4* gv = reinterpret_cast<const uint4*>(g - head);
         const uint32_t nvec = (head + glen + 15u) >> 4;
         uint4* sv = reinterpret_cast<uint4*>(sdata);
-        for (uint32_t v0 = 0; v0 < nvec; v0 += 64 * LZ4_G * 4)
+        for (uint32_t v0 = 0; v0 < nvec; v0 += 64 * G * 4)
         {
             uint4 q[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
             {
-                const uint32_t v = v0 + u * 64 * LZ4_G + tid;
+                const uint32_t v = v0 + u * 64 * G + tid;
                 q[u] = v < nvec ? gv[v] : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
             {
-                const uint32_t v = v0 + u * 64 * LZ4_G + tid;
+                const uint32_t v = v0 + u * 64 * G + tid;
                 if (v < nvec)
                     sv[v] = q[u];
             }
@@ -337,7 +662,7 @@ __global__ __launch_bounds__(64 * LZ4_G, 6) void k_lz4_segments(const uint8_t* _
     const uint32_t my_start = (uint32_t)wave * sub_bytes;
     const bool have_unit = my_start < glen;
     const uint32_t my_len = have_unit ? (glen - my_start < sub_bytes ? glen - my_start : sub_bytes) : 0u;
-    const uint32_t unit = blk.seg_base + gi * LZ4_G + (uint32_t)wave;
+    const uint32_t unit = blk.seg_base + gi * G + (uint32_t)wave;
     // parsing limits (lz4.c:963-964: mflimit / matchlimit, applied at the BLOCK end)
     const int64_t blk_left = (int64_t)blk.size - (int64_t)group_start - (int64_t)my_start; // unit start .. block end
     int64_t sl = (int64_t)my_len - 4;
@@ -361,6 +686,90 @@ __global__ __launch_bounds__(64 * LZ4_G, 6) void k_lz4_segments(const uint8_t* _
     uint32_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0, ps0 = 1, ps1 = 1, ps2 = 1, ps3 = 1; // the probe batches (SGPRs)
     static_assert(LZ4_PROBE_BATCHES == 4, "probe bookkeeping is unrolled by hand");
 
+    bool parsed = false;
+    if constexpr (MODE == 1)
+    {
+        // ---- probe: every lane looks at the first positions of its sub-unit (512 positions spread over the unit); one repeat
+        // anywhere in the group and the group is parsed by lanes, none and the batch parser's miss mode skims it ----
+        const uint32_t sub = sub_bytes >> 6;
+        if (have_unit)
+        {
+            const uint32_t sidx = (dbg & 128u) ? (uint32_t)lane : 63u - (uint32_t)lane;
+            uint32_t p = my_start + sidx * sub;
+            const uint32_t lend = p + sub < my_start + my_len ? p + sub : my_start + my_len;
+            // All eight positions of a lane in ONE pass over the LDS pipeline (three dependent round trips instead of 24): the 11
+            // bytes they span are read once, the table is written and read back per position back to back (LDS operations of a
+            // wave execute in order: the read sees this step's writes of ALL lanes, so repeats between sub-units that run in phase
+            // -- records, tokens -- are seen although every lane inserts them in the same instruction), then the candidates'
+            // bytes are compared.
+            static_assert(LZ4_LANE_PROBES == 8, "the probe reads four dwords per lane");
+            const uint32_t w0 = (p + head) >> 2, sh = ((p + head) & 3u) * 8u;
+            const uint32_t d0 = sdata[w0], d1 = sdata[w0 + 1], d2 = sdata[w0 + 2], d3 = sdata[w0 + 3];
+            const uint64_t q0 = ((uint64_t)d1 << 32 | d0) >> sh, q1 = ((uint64_t)d2 << 32 | d1) >> sh, q2 = ((uint64_t)d3 << 32 | d2) >> sh;
+            uint32_t vv[LZ4_LANE_PROBES], hh[LZ4_LANE_PROBES], cc[LZ4_LANE_PROBES];
+            vv[0] = (uint32_t)q0;
+            vv[1] = (uint32_t)(q0 >> 8) | ((uint32_t)q1 << 24);
+            vv[2] = (uint32_t)(q0 >> 16) | ((uint32_t)q1 << 16);
+            vv[3] = (uint32_t)(q0 >> 24) | ((uint32_t)q1 << 8);
+            vv[4] = (uint32_t)q1;
+            vv[5] = (uint32_t)(q1 >> 8) | ((uint32_t)q2 << 24);
+            vv[6] = (uint32_t)(q1 >> 16) | ((uint32_t)q2 << 16);
+            vv[7] = (uint32_t)(q1 >> 24) | ((uint32_t)q2 << 8);
+#pragma unroll
+            for (int it = 0; it < LZ4_LANE_PROBES; ++it)
+                hh[it] = __umulhi(vv[it] * 2654435761u, (uint32_t)TAB);
+#pragma unroll
+            for (int it = 0; it < LZ4_LANE_PROBES; ++it)
+            {
+                const bool act = p + it < lend && (int32_t)(p + it) <= start_limit;
+                cc[it] = LZ4_EMPTY;
+                if (act)
+                {
+                    tab[hh[it]] = (uint16_t)(p + it);
+                    cc[it] = *reinterpret_cast<volatile uint16_t*>(&tab[hh[it]]); // volatile: not the value this lane just stored
+                }
+            }
+            bool any = false;
+#pragma unroll
+            for (int it = 0; it < LZ4_LANE_PROBES; ++it)
+                if (cc[it] != LZ4_EMPTY && cc[it] != ((p + it) & 0xFFFFu))
+                    any |= lds_read32(sdata, cc[it] + head) == vv[it];
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull && lane == 0)
+                *flag = 1u; // benign race: every writer stores the same value
+        }
+        __syncthreads();
+        met = true;
+        if (*flag != 0u && !(dbg & 16u))
+        {
+            if (have_unit)
+            {
+                uint4* tv = reinterpret_cast<uint4*>(tab);
+                const uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+#pragma unroll
+                for (uint32_t v = 0; v < (TAB * 2 / 16 + 63) / 64; ++v)
+                    if (v * 64 + lane < TAB * 2 / 16)
+                        tv[v * 64 + lane] = e;
+                if (wave != 0 && !(dbg & 1u))
+                    for (uint32_t q0 = 0; q0 < my_start; q0 += 1024) // every 4th position of the history, oldest first
+                    {
+                        uint32_t hv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            hv[u] = __umulhi(lds_read32(sdata, q0 + 4u * (u * 64 + (uint32_t)lane) + head) * 2654435761u, (uint32_t)TAB);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            tab[hv[u]] = (uint16_t)(q0 + 4u * (u * 64 + (uint32_t)lane));
+                    }
+                lz4_lane_parse<TAB, FMT>(sdata, head, tab, lane, my_start, my_len, start_limit, end_limit, sub, out, recs,
+                                         lane_recs + (uint64_t)unit * (64u * LZ4_LANE_MAXREC), st, dbg);
+            }
+            parsed = true;
+        }
+        else if (*flag == 0u && have_unit && (int32_t)pos <= start_limit)
+            nfail = (dbg >> 8) ? (dbg >> 8) : 24u; // incompressible: one twin round of the miss mode skims the unit
+    }
+
+    if (!parsed)
     for (;;)
     {
         const bool more = have_unit && (int32_t)pos <= start_limit;
@@ -923,7 +1332,7 @@ __device__ __forceinline__ void wg_copy(uint8_t* __restrict__ dst, const uint8_t
 
 constexpr int K6_THREADS = 256;
 
-// one workgroup per window group: its (up to LZ4_G) units are moved into place one after the other
+// one workgroup per window group: its (up to gunits) units are moved into place one after the other
 __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* __restrict__ src,
                                                                  const Lz4Block* __restrict__ blocks, uint32_t nblocks,
                                                                  uint32_t SEG, const uint8_t* __restrict__ streams,
@@ -931,7 +1340,8 @@ __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* _
                                                                  const Lz4Plan* __restrict__ plan,
                                                                  const uint32_t* __restrict__ runs,
                                                                  const Lz4BlockOut* __restrict__ bout,
-                                                                 uint8_t* __restrict__ dst, const uint32_t* __restrict__ worklist)
+                                                                 uint8_t* __restrict__ dst, const uint32_t* __restrict__ worklist,
+                                                                 uint32_t gunits /* units per window group */)
 {
     const int tid = threadIdx.x;
     const uint32_t nwork = worklist[0];
@@ -950,8 +1360,8 @@ __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* _
     const Lz4Block blk = blocks[lo];
     const Lz4BlockOut bo = bout[lo];
     uint8_t* d = dst + blk.dst_off;
-    const uint32_t i0 = (grp - blk.grp_base) * LZ4_G;
-    const uint32_t i1 = i0 + LZ4_G < blk.nseg ? i0 + LZ4_G : blk.nseg;
+    const uint32_t i0 = (grp - blk.grp_base) * gunits;
+    const uint32_t i1 = i0 + gunits < blk.nseg ? i0 + gunits : blk.nseg;
     // each wave moves whole units on its own (4 units in flight per workgroup: their table loads overlap)
     const int lane = tid & 63;
     for (uint32_t i = i0 + (uint32_t)(tid >> 6); i < i1; i += K6_THREADS / 64)
@@ -1431,7 +1841,7 @@ extern "C" __attribute__((visibility("default"))) int lthip_dec_prof_dump(void)
 extern "C" size_t lthip_lz4_bound(size_t size) { return size > 0x7E000000u ? 0 : size + size / 255 + 16; }
 
 static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* src_offsets, const uint32_t* src_sizes,
-                         const uint64_t* dst_offsets, const uint32_t* dst_caps, uint32_t seg_bytes, Lz4Block** d_blocks,
+                         const uint64_t* dst_offsets, const uint32_t* dst_caps, uint32_t seg_bytes, uint32_t gunits, Lz4Block** d_blocks,
                          uint64_t* out_nseg, uint64_t* out_ngrp = nullptr)
 {
     std::vector<Lz4Block> hb(block_count);
@@ -1447,7 +1857,7 @@ static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* s
         hb[b].seg_base = (uint32_t)nseg;
         hb[b].nseg = seg_bytes ? (uint32_t)(((uint64_t)src_sizes[b] + seg_bytes - 1) / seg_bytes) : 0;
         hb[b].grp_base = (uint32_t)ngrp;
-        hb[b].ngrp = (hb[b].nseg + LZ4_G - 1) / LZ4_G;
+        hb[b].ngrp = (hb[b].nseg + gunits - 1) / gunits;
         ngrp += hb[b].ngrp;
         nseg += hb[b].nseg;
     }
@@ -1466,8 +1876,37 @@ static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* s
     return 0;
 }
 
-// default geometry: 8 waves x 4 KiB units share a 32 KiB window; 32 KiB data + 8 x 2.5 KiB tables = 53 KiB of LDS per
-// workgroup -> 3 workgroups = 24 waves per CU
+// The parser of the match finder: "lanes" (default, MODE 1: 16 x 4 KiB units share a 64 KiB window, every lane parses its own
+// 64-byte sub-unit; 144 KiB of LDS, one workgroup of 16 waves per CU) or "batch" (LTHIP_LZ4_PARSER=batch, MODE 0: the round-1
+// parser, 8 x 4 KiB units per 32 KiB window, 52 KiB of LDS, 24 waves per CU).
+static bool lz4_lane_parser()
+{
+    static const bool v = [] {
+        const char* e = getenv("LTHIP_LZ4_PARSER");
+        return !(e && strcmp(e, "batch") == 0);
+    }();
+    return v;
+}
+
+template <int G, int TAB, int FMT, int MODE>
+static int launch_segments(lthip_ctx* ctx, uint32_t groups, uint32_t SEG, const void* d_src, const Lz4Block* d_blocks, uint32_t block_count,
+                           uint32_t g0, uint8_t* streams, Lz4Meta* meta, uint64_t* zrecs, uint8_t* spec_dst, uint32_t dbg, uint64_t* lane_recs)
+{
+    const size_t lds = (size_t)G * SEG + 64 + 16 + (size_t)G * TAB * 2;
+    if (lds > 64u * 1024u && !ctx->k5_lds_enabled)
+    {
+        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_LANES, 0, 1>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_LANES, 1, 1>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->k5_lds_enabled = true;
+    }
+    hipLaunchKernelGGL((k_lz4_segments<G, TAB, FMT, MODE>), dim3(groups), dim3(64 * G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
+                       block_count, g0, SEG, streams, meta, zrecs, spec_dst, dbg, lane_recs);
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
 static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                               const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets, const uint32_t* dst_caps,
                               uint32_t* d_out_sizes, int segment_log2);
@@ -1518,11 +1957,15 @@ static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     Lz4Block* d_blocks = nullptr;
     uint64_t nseg64 = 0, ngrp64 = 0;
-    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, SEG, &d_blocks, &nseg64, &ngrp64);
+    const bool lanes = lz4_lane_parser() && SEG == 4096u; // other unit sizes (tests, ablations) keep the batch parser's geometry
+    const uint32_t GU = lanes ? LZ4_G_LANES : LZ4_G_BATCH;
+    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, SEG, GU, &d_blocks, &nseg64, &ngrp64);
     if (err)
         return err;
     const uint32_t nseg = (uint32_t)nseg64;
-    void *meta, *plan, *bout, *streams, *runs;
+    void *meta, *plan, *bout, *streams, *runs, *lrecs = nullptr;
+    if (lanes && (err = lthip_scratch(ctx, S_LZ4_LANE_RECS, (size_t)64 * LZ4_LANE_MAXREC * 8 * ((size_t)nseg + 1), &lrecs)))
+        return err;
     if ((err = lthip_scratch(ctx, S_TABLES2, 4 * ((size_t)nseg + block_count + 1), &runs)))
         return err;
     if ((err = lthip_scratch(ctx, S_LZ4_META, sizeof(Lz4Meta) * ((size_t)nseg + 1), &meta)))
@@ -1556,8 +1999,7 @@ static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_
     // per-block first segment / group (same arithmetic as upload_blocks)
     std::vector<uint32_t> grp_first(block_count + 1, 0);
     for (uint32_t b = 0; b < block_count; ++b)
-        grp_first[b + 1] = grp_first[b] + (uint32_t)(((((uint64_t)src_sizes[b] + SEG - 1) / SEG) + LZ4_G - 1) / LZ4_G);
-    const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * LZ4_TAB_LZ4 * 2;
+        grp_first[b + 1] = grp_first[b] + (uint32_t)(((((uint64_t)src_sizes[b] + SEG - 1) / SEG) + GU - 1) / GU);
     const bool overlap = cut.size() > 2;
     void* worklist;
     if ((err = lthip_scratch(ctx, S_LZ4_WORKLIST, 4 * ((size_t)ngrp64 + 1) * (cut.size() - 1), &worklist)))
@@ -1578,10 +2020,15 @@ static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_
         if (g1 > g0)
         {
             LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
-            hipLaunchKernelGGL((k_lz4_segments<LZ4_TAB_LZ4, 0>), dim3(g1 - g0), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
-                               block_count, g0, SEG, (uint8_t*)streams, (Lz4Meta*)meta, (uint64_t*)nullptr,
-                               (dbg & 64u) ? (uint8_t*)nullptr : (uint8_t*)d_dst, dbg);
-            LTHIP_LAUNCH_CHECK(ctx);
+            uint8_t* spec = (dbg & 64u) ? (uint8_t*)nullptr : (uint8_t*)d_dst;
+            if (lanes)
+                err = launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, 0, 1>(ctx, g1 - g0, SEG, d_src, d_blocks, block_count, g0, (uint8_t*)streams,
+                                                                        (Lz4Meta*)meta, nullptr, spec, dbg, (uint64_t*)lrecs);
+            else
+                err = launch_segments<LZ4_G_BATCH, LZ4_TAB_LZ4, 0, 0>(ctx, g1 - g0, SEG, d_src, d_blocks, block_count, g0, (uint8_t*)streams,
+                                                                      (Lz4Meta*)meta, nullptr, spec, dbg, nullptr);
+            if (err)
+                return err;
         }
         if (overlap)
         {
@@ -1599,7 +2046,7 @@ static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_
                 hipLaunchKernelGGL(k_lz4_stitch_copy, dim3(g1 - g0 < copy_grid ? g1 - g0 : copy_grid), dim3(K6_THREADS), 0, s2,
                                    (const uint8_t*)d_src, d_blocks, block_count, SEG, (const uint8_t*)streams, (const Lz4Meta*)meta,
                                    (const Lz4Plan*)plan, (const uint32_t*)runs, (const Lz4BlockOut*)bout, (uint8_t*)d_dst,
-                                   (const uint32_t*)wl);
+                                   (const uint32_t*)wl, GU);
             if (i + 2 == cut.size())
                 hipLaunchKernelGGL(k_lz4_empty_blocks, dim3((block_count + 255) / 256), dim3(256), 0, s2, d_blocks, block_count,
                                    (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
@@ -1622,7 +2069,9 @@ int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_
     const uint32_t SEG = 4096u; // ZB_UNIT
     Lz4Block* d_blocks = nullptr;
     uint64_t nseg64 = 0, ngrp64 = 0;
-    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, SEG, &d_blocks, &nseg64, &ngrp64);
+    const bool lanes = lz4_lane_parser();
+    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, SEG, lanes ? LZ4_G_LANES : LZ4_G_BATCH, &d_blocks,
+                            &nseg64, &ngrp64);
     if (err)
         return err;
     uint64_t nseg = 0;
@@ -1639,14 +2088,21 @@ int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_
         return err;
     if ((err = lthip_scratch(ctx, S_LZ4_META, sizeof(Lz4Meta) * ((size_t)nseg + 1), &meta)))
         return err;
+    void* lrecs = nullptr;
+    if (lanes && (err = lthip_scratch(ctx, S_LZ4_LANE_RECS, (size_t)64 * LZ4_LANE_MAXREC * 8 * ((size_t)nseg + 1), &lrecs)))
+        return err;
     if (nseg)
     {
         LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
-        const size_t lds = (size_t)LZ4_G * SEG + 64 + 16 + (size_t)LZ4_G * LZ4_TAB_ZSTD * 2;
-        hipLaunchKernelGGL((k_lz4_segments<LZ4_TAB_ZSTD, 1>), dim3((uint32_t)ngrp64), dim3(64 * LZ4_G), lds, ctx->stream, (const uint8_t*)d_src,
-                           d_blocks, block_count, 0u, SEG, (uint8_t*)lits, (Lz4Meta*)meta, (uint64_t*)recs, (uint8_t*)d_dst,
-                           (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0));
-        LTHIP_LAUNCH_CHECK(ctx);
+        const uint32_t dbg = (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0);
+        if (lanes)
+            err = launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, 1, 1>(ctx, (uint32_t)ngrp64, SEG, d_src, d_blocks, block_count, 0u, (uint8_t*)lits,
+                                                                    (Lz4Meta*)meta, (uint64_t*)recs, (uint8_t*)d_dst, dbg, (uint64_t*)lrecs);
+        else
+            err = launch_segments<LZ4_G_BATCH, LZ4_TAB_ZSTD, 1, 0>(ctx, (uint32_t)ngrp64, SEG, d_src, d_blocks, block_count, 0u, (uint8_t*)lits,
+                                                                   (Lz4Meta*)meta, (uint64_t*)recs, (uint8_t*)d_dst, dbg, nullptr);
+        if (err)
+            return err;
     }
     *d_lits = (uint8_t*)lits;
     *d_recs = (uint64_t*)recs;
@@ -1665,7 +2121,7 @@ extern "C" int lthip_lz4_decompress_blocks(lthip_ctx* ctx, const void* d_src, ui
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     Lz4Block* d_blocks = nullptr;
     uint64_t nseg = 0;
-    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, 0, &d_blocks, &nseg);
+    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, 0, 1, &d_blocks, &nseg);
     if (err)
         return err;
     LaunchTimer t(ctx, LTHIP_K_OTHER);

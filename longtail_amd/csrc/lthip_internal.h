@@ -79,6 +79,7 @@ enum ScratchSlot
     S_Z_ENC,   // zstd: encoded 128 KiB pieces
     S_Z_WORK,  // zstd: per-encoder-wave work area
     S_LZ4_WORKLIST, // groups the stitch copy has to visit
+    S_LZ4_LANE_RECS, // lane parser: {start, length, offset} records, 8 per lane and unit
     S_B3_WINDOWS,   // first range of every window of leaf slots (parents kernel)
     S_COUNT
 };
@@ -107,6 +108,7 @@ struct lthip_ctx
     } stage[8];
     size_t stage_next;
     bool k1_lds_enabled; // hipFuncAttributeMaxDynamicSharedMemorySize set for K1 on this context's device
+    bool k5_lds_enabled; // ... and for the lane-parser flavours of K5
     void* scratch[S_COUNT];
     size_t scratch_cap[S_COUNT];
     bool timing;

@@ -634,6 +634,28 @@ int refh_missing_content(const uint64_t* existing, uint32_t existing_count, cons
     return err;
 }
 
+/* Longtail_GetExistingStoreIndex (src/longtail.c:7087-7325) on a SERIALIZED store index: which blocks of the store cover the
+ * given chunk hashes (usage filter, most-used blocks first).  Returns the serialized result; free with refh_free. */
+int refh_get_existing_store_index(const void* store_index_buf, uint64_t store_index_size, const uint64_t* chunks, uint32_t chunk_count,
+                                  uint32_t min_block_usage_percent, void** out_buf, uint64_t* out_size)
+{
+    struct Longtail_StoreIndex* si = 0;
+    struct Longtail_StoreIndex* existing = 0;
+    int err = Longtail_ReadStoreIndexFromBuffer(store_index_buf, (size_t)store_index_size, &si);
+    if (err)
+        return err;
+    err = Longtail_GetExistingStoreIndex(si, chunk_count, (const TLongtail_Hash*)chunks, min_block_usage_percent, &existing);
+    if (!err)
+    {
+        size_t sz = 0;
+        err = Longtail_WriteStoreIndexToBuffer(existing, out_buf, &sz);
+        *out_size = sz;
+    }
+    Longtail_Free(existing);
+    Longtail_Free(si);
+    return err;
+}
+
 /* ---- synchronous wrappers for the async block-store calls ---- */
 struct sync_existing
 {

@@ -133,6 +133,7 @@ class Ref:
         sig("refh_ingest_time", i32, [u32, u32, vp, vp, vp, u32, u32, u32, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64),
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)])
         sig("refh_cpu_count", i32, [])
+        sig("refh_get_existing_store_index", i32, [vp, u64, vp, u32, u32, C.POINTER(vp), C.POINTER(u64)])
         sig("refh_ingest_sweep", i32, [u32, u32, vp, vp, vp, u32, u32, u32, u32, vp, u32, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)])
         sig("refh_chunk_stream_failing_feeder", i64, [vp, vp, u64, u32, u32, u32, u64, i32, vp, u64, vp])
         sig("refh_version_index_cancel", i32, [vp, vp, u32, vp, vp, vp, u32, i32, u32, C.POINTER(i32), C.POINTER(u32)])
@@ -262,6 +263,18 @@ class Ref:
         return dict(err=err, chunks=nchunks.value, blocks=nblocks.value, stored_bytes=stored.value,
                     seconds_index=t_index.value, seconds_write=t_write.value)
 
+
+    def get_existing_store_index(self, store_index: bytes, chunks: np.ndarray, min_block_usage_percent: int) -> bytes:
+        chunks = np.ascontiguousarray(chunks, dtype=np.uint64)
+        buf, size = vp(), u64(0)
+        raw = np.frombuffer(store_index, np.uint8)
+        err = self.dll.refh_get_existing_store_index(raw.ctypes.data, len(raw), chunks.ctypes.data if len(chunks) else None, len(chunks),
+                                                     min_block_usage_percent, C.byref(buf), C.byref(size))
+        if err:
+            raise RuntimeError(f"refh_get_existing_store_index failed: {err}")
+        out = bytes((C.c_ubyte * size.value).from_address(buf.value))
+        self.dll.refh_free(buf)
+        return out
 
     def ingest_sweep(self, files, target_chunk_size, max_block_size, max_chunks_per_block, tag, workers, reps):
         """One tree, then CreateVersionIndex + CreateMissingContent + WriteContent timed for every W of `workers`, `reps` times.
