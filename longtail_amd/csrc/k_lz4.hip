@@ -33,8 +33,10 @@ struct Lz4Block
     uint32_t dst_cap;
     uint32_t seg_base; // first stitch unit (sub-segment) of the block
     uint32_t nseg;     // number of units
-    uint32_t grp_base; // first window group of the block
+    uint32_t grp_base; // first window group of the block (groups of `gunits` units: the parser's and the stitch's)
     uint32_t ngrp;
+    uint32_t cgrp_base; // first group of the classification pass (LZ4_G_BATCH units per group), see lz4_compress_batch
+    uint32_t ncgrp;
 };
 
 struct Lz4Meta // result of one segment
@@ -313,7 +315,7 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
 
     for (;;)
     {
-        const bool act = p < lend && (int32_t)p <= start_limit && nrec < LZ4_LANE_MAXREC;
+        const bool act = p < lend && (int32_t)p <= start_limit && nrec < LZ4_LANE_MAXREC && !(dbg & 2048u);
         if (__builtin_amdgcn_ballot_w64(act) == 0ull)
             break;
         uint32_t v = 0, h = 0, cand = LZ4_EMPTY;
@@ -329,9 +331,14 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
             // everyone has written: when several lanes insert the same slot in this step the entry that survives (the lowest
             // position: lanes are mapped to sub-units in reverse) is a candidate for the others at once
             tab[h] = (uint16_t)p;
-            const uint32_t fresh = *reinterpret_cast<volatile uint16_t*>(&tab[h]); // volatile: not the value this lane just stored
-            if (fresh < p)
-                cand = fresh;
+            if (!(dbg & 512u))
+            {
+                uint32_t hr = h;
+                asm volatile("" : "+v"(hr)); // the compiler must not know that this is the slot just written (it would forward the store)
+                const uint32_t fresh = tab[hr];
+                if (fresh < p)
+                    cand = fresh;
+            }
         }
         bool ok = false;
         if (act && cand != LZ4_EMPTY && cand < p)
@@ -504,6 +511,8 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
             const uint32_t o = __shfl_xor(kmax, d, 64);
             kmax = kmax > o ? kmax : o;
         }
+        if (dbg & 1024u)
+            kmax = 0; // ablation: no emission (the output is garbage)
         for (uint32_t t = 0; t < kmax; ++t)
         {
             const bool on = t < cnt;
@@ -591,12 +600,15 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
 // TAB = entries of a wave's private table (any multiple of 8: the index is mulhi(hash, TAB), not a mask); G = units per window
 // group = waves per workgroup; MODE 0 = batch parser, 1 = lane parser for groups whose probe finds redundancy (incompressible
 // groups are skimmed by the batch parser's miss mode either way)
-template <int G, int TAB, int FMT, int MODE>
+// CLS (MODE 0 only) = classification pass of the two-pass scheme: groups without redundancy are skimmed here and now (the fast
+// geometry: 24 waves per CU), groups with redundancy are only NOTED -- the 16-unit group they belong to goes onto `worklist` --
+// and left to the lane parser, which then runs over that list.
+template <int G, int TAB, int FMT, int MODE, int CLS = 0>
 __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
                                                              uint32_t nblocks, uint32_t grp0, uint32_t sub_bytes,
                                                              uint8_t* __restrict__ streams, Lz4Meta* __restrict__ meta,
                                                              uint64_t* __restrict__ zrecs, uint8_t* __restrict__ spec_dst, uint32_t dbg,
-                                                             uint64_t* __restrict__ lane_recs)
+                                                             uint64_t* __restrict__ lane_recs, uint32_t ngroups, uint32_t* __restrict__ worklist)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t data_bytes = G * sub_bytes + 64u;
@@ -608,18 +620,29 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint16_t* tab = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u) + (size_t)wave * TAB;
 
-    const uint32_t grp = blockIdx.x + grp0;
+    // MODE 0: one window group per workgroup.  MODE 1: the workgroup is alone on its CU (144 KiB of LDS), so it is PERSISTENT over
+    // the groups grp0 + blockIdx.x, + gridDim.x, ... and the next group's bytes are fetched into registers (80 bytes per thread)
+    // while the current one is parsed -- without that the memory pipe idles during every parse and the ALUs during every load.
+    uint4 pre[5];
+    bool have_pre = false;
+    // with a worklist (MODE 1 behind the classification pass) the loop runs over its entries: worklist[0] = count, then group ids
+    const bool listed = MODE == 1 && worklist != nullptr;
+    const uint32_t grp_end = listed ? worklist[0] : (MODE == 1 ? grp0 + ngroups : grp0 + blockIdx.x + 1u);
+    const uint32_t grp_step = MODE == 1 ? gridDim.x : 1u;
+    for (uint32_t gidx = blockIdx.x + (listed ? 0u : grp0); gidx < grp_end; gidx += grp_step)
+    {
+    const uint32_t grp = listed ? worklist[1u + gidx] : gidx;
     uint32_t lo = 0, hi = nblocks;
     while (hi - lo > 1)
     {
         const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (blocks[mid].grp_base <= grp)
+        if ((CLS ? blocks[mid].cgrp_base : blocks[mid].grp_base) <= grp)
             lo = mid;
         else
             hi = mid;
     }
     const Lz4Block blk = blocks[lo];
-    const uint32_t gi = grp - blk.grp_base;
+    const uint32_t gi = grp - (CLS ? blk.cgrp_base : blk.grp_base);
     const uint32_t group_start = gi * G * sub_bytes;                                   // block relative
     const uint32_t glen = blk.size - group_start < G * sub_bytes ? blk.size - group_start : G * sub_bytes;
     const uint8_t* g = src + blk.src_off + group_start;
@@ -630,6 +653,17 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         const uint4* gv = reinterpret_cast<const uint4*>(g - head);
         const uint32_t nvec = (head + glen + 15u) >> 4;
         uint4* sv = reinterpret_cast<uint4*>(sdata);
+        if (MODE == 1 && have_pre)
+        {
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+            {
+                const uint32_t v = u * 64 * G + tid;
+                if (v < nvec)
+                    sv[v] = pre[u];
+            }
+        }
+        else
         for (uint32_t v0 = 0; v0 < nvec; v0 += 64 * G * 4)
         {
             uint4 q[4];
@@ -657,6 +691,39 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             *flag = 0u;
     }
     __syncthreads();
+    if constexpr (MODE == 1)
+    {
+        // the next group of this workgroup: its loads are in flight during the parse below
+        const uint32_t nidx = gidx + grp_step;
+        have_pre = false;
+        if (nidx < grp_end && !(dbg & 4096u))
+        {
+            const uint32_t nxt = listed ? worklist[1u + nidx] : nidx;
+            uint32_t lo2 = 0, hi2 = nblocks;
+            while (hi2 - lo2 > 1)
+            {
+                const uint32_t mid = lo2 + ((hi2 - lo2) >> 1);
+                if (blocks[mid].grp_base <= nxt)
+                    lo2 = mid;
+                else
+                    hi2 = mid;
+            }
+            const Lz4Block b2 = blocks[lo2];
+            const uint32_t gs2 = (nxt - b2.grp_base) * G * sub_bytes;
+            const uint32_t gl2 = b2.size - gs2 < G * sub_bytes ? b2.size - gs2 : G * sub_bytes;
+            const uint8_t* g2 = src + b2.src_off + gs2;
+            const uint32_t head2 = (uint32_t)((uintptr_t)g2 & 15u);
+            const uint4* gv2 = reinterpret_cast<const uint4*>(g2 - head2);
+            const uint32_t nvec2 = (head2 + gl2 + 15u) >> 4;
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+            {
+                const uint32_t v = u * 64 * G + tid;
+                pre[u] = v < nvec2 ? gv2[v] : make_uint4(0, 0, 0, 0);
+            }
+            have_pre = true;
+        }
+    }
 
     // ---- my unit, positions relative to the group start ----
     const uint32_t my_start = (uint32_t)wave * sub_bytes;
@@ -691,8 +758,15 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     {
         // ---- probe: every lane looks at the first positions of its sub-unit (512 positions spread over the unit); one repeat
         // anywhere in the group and the group is parsed by lanes, none and the batch parser's miss mode skims it ----
-        const uint32_t sub = sub_bytes >> 6;
-        if (have_unit)
+        // sub-unit pitch = unit / 64 bytes.  (An odd number of dwords -- 68 bytes, 61 lanes busy -- so that lanes running in phase do
+        // not all hit the same two LDS banks was measured: 6 % SLOWER and a worse ratio; dbg bit 8 keeps the experiment.)
+        const uint32_t sub = (dbg & 256u) ? ((sub_bytes >> 6) | 4u) : sub_bytes >> 6;
+        if (listed)
+        {
+            if (tid == 0)
+                *flag = 1u; // the classification pass found redundancy in this group
+        }
+        else if (have_unit && !(dbg & 8192u))
         {
             const uint32_t sidx = (dbg & 128u) ? (uint32_t)lane : 63u - (uint32_t)lane;
             uint32_t p = my_start + sidx * sub;
@@ -726,7 +800,9 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
                 if (act)
                 {
                     tab[hh[it]] = (uint16_t)(p + it);
-                    cc[it] = *reinterpret_cast<volatile uint16_t*>(&tab[hh[it]]); // volatile: not the value this lane just stored
+                    uint32_t hr = hh[it];
+                    asm volatile("" : "+v"(hr)); // the compiler must not know that this is the slot just written (it would forward the store)
+                    cc[it] = tab[hr];
                 }
             }
             bool any = false;
@@ -779,6 +855,20 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             if (st.have_first && lane == 0)
                 *flag = 1u; // benign race: every writer stores the same value
             __syncthreads();
+            if constexpr (CLS != 0)
+            {
+                if (*flag != 0u)
+                {
+                    // redundancy: this group is the lane parser's.  Note the 16-unit group it belongs to (once) and leave.
+                    if (tid == 0)
+                    {
+                        const uint32_t g16 = blk.grp_base + gi / (uint32_t)(LZ4_G_LANES / LZ4_G_BATCH);
+                        if (atomicExch(&worklist[1u + ngroups + g16], 1u) == 0u)
+                            worklist[1u + atomicAdd(&worklist[0], 1u)] = g16;
+                    }
+                    return;
+                }
+            }
             if (*flag != 0u && wave != 0 && have_unit && !(dbg & 1u))
             {
                 // learn the history: insert every position before my unit, oldest first (plain stores, four
@@ -1121,8 +1211,9 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         }
         if (have_unit && lane == 0)
             reinterpret_cast<uint4*>(meta)[unit] = make_uint4(st.nseq, st.op + tail, tail, uniform);
-        return;
     }
+    else
+    {
     // A unit without a single match is all literals.  If that turns out to be true of the WHOLE block (incompressible
     // data -- the common case for already-compressed assets), the payload is one literal run: header, then the source
     // bytes, and this unit's bytes belong at  header + its offset in the block.  They are still in LDS, so they are put
@@ -1143,6 +1234,10 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         m.first_hdr_bytes = st.first_hdr;
         meta[unit] = m;
     }
+    } // FMT 0
+    if constexpr (MODE == 1)
+        __syncthreads(); // every wave is done with the window before the next group overwrites it
+    } // groups of this workgroup
 }
 
 __device__ __forceinline__ void wg_emit_header(uint8_t* dst, uint32_t lits, uint32_t match_nibble, int tid, int nthreads)
@@ -1842,10 +1937,10 @@ extern "C" size_t lthip_lz4_bound(size_t size) { return size > 0x7E000000u ? 0 :
 
 static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* src_offsets, const uint32_t* src_sizes,
                          const uint64_t* dst_offsets, const uint32_t* dst_caps, uint32_t seg_bytes, uint32_t gunits, Lz4Block** d_blocks,
-                         uint64_t* out_nseg, uint64_t* out_ngrp = nullptr)
+                         uint64_t* out_nseg, uint64_t* out_ngrp = nullptr, uint64_t* out_ncgrp = nullptr)
 {
     std::vector<Lz4Block> hb(block_count);
-    uint64_t nseg = 0, ngrp = 0;
+    uint64_t nseg = 0, ngrp = 0, ncgrp = 0;
     for (uint32_t b = 0; b < block_count; ++b)
     {
         if (src_sizes[b] > 0x7E000000u)
@@ -1859,6 +1954,9 @@ static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* s
         hb[b].grp_base = (uint32_t)ngrp;
         hb[b].ngrp = (hb[b].nseg + gunits - 1) / gunits;
         ngrp += hb[b].ngrp;
+        hb[b].cgrp_base = (uint32_t)ncgrp;
+        hb[b].ncgrp = (hb[b].nseg + LZ4_G_BATCH - 1) / LZ4_G_BATCH;
+        ncgrp += hb[b].ncgrp;
         nseg += hb[b].nseg;
     }
     if (nseg > 0x7FFFFFF0ull)
@@ -1873,6 +1971,8 @@ static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* s
     *out_nseg = nseg;
     if (out_ngrp)
         *out_ngrp = ngrp;
+    if (out_ncgrp)
+        *out_ncgrp = ncgrp;
     return 0;
 }
 
@@ -1888,9 +1988,10 @@ static bool lz4_lane_parser()
     return v;
 }
 
-template <int G, int TAB, int FMT, int MODE>
+template <int G, int TAB, int FMT, int MODE, int CLS = 0>
 static int launch_segments(lthip_ctx* ctx, uint32_t groups, uint32_t SEG, const void* d_src, const Lz4Block* d_blocks, uint32_t block_count,
-                           uint32_t g0, uint8_t* streams, Lz4Meta* meta, uint64_t* zrecs, uint8_t* spec_dst, uint32_t dbg, uint64_t* lane_recs)
+                           uint32_t g0, uint8_t* streams, Lz4Meta* meta, uint64_t* zrecs, uint8_t* spec_dst, uint32_t dbg, uint64_t* lane_recs,
+                           uint32_t ngroups, uint32_t* worklist)
 {
     const size_t lds = (size_t)G * SEG + 64 + 16 + (size_t)G * TAB * 2;
     if (lds > 64u * 1024u && !ctx->k5_lds_enabled)
@@ -1901,10 +2002,45 @@ static int launch_segments(lthip_ctx* ctx, uint32_t groups, uint32_t SEG, const 
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->k5_lds_enabled = true;
     }
-    hipLaunchKernelGGL((k_lz4_segments<G, TAB, FMT, MODE>), dim3(groups), dim3(64 * G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
-                       block_count, g0, SEG, streams, meta, zrecs, spec_dst, dbg, lane_recs);
+    uint32_t grid = groups;
+    if (MODE == 1)
+    {
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        grid = groups < (uint32_t)ncu ? groups : (uint32_t)ncu; // one persistent workgroup per CU
+    }
+    hipLaunchKernelGGL((k_lz4_segments<G, TAB, FMT, MODE, CLS>), dim3(grid), dim3(64 * G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
+                       block_count, g0, SEG, streams, meta, zrecs, spec_dst, dbg, lane_recs, ngroups, worklist);
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
+}
+
+// The match finder of one batch (FMT 0: LZ4 streams, FMT 1: zstd sequences).  Lane parser (default): two passes -- the batch parser's
+// geometry (8 units per group, 24 waves per CU) classifies every group with its four probe batches and skims the ones without
+// redundancy on the spot (incompressible data never sees the slower one-workgroup-per-CU geometry); the 16-unit groups that hold
+// redundancy are listed and parsed by the lane kernel, persistent over the list.
+template <int FMT>
+static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const void* d_src, const Lz4Block* d_blocks, uint32_t block_count,
+                               uint32_t g0, uint32_t g1, uint64_t ngrp, uint64_t ncgrp, uint8_t* streams, Lz4Meta* meta, uint64_t* zrecs,
+                               uint8_t* spec_dst, uint32_t dbg, uint64_t* lane_recs)
+{
+    if (!lanes)
+        return launch_segments<LZ4_G_BATCH, FMT == 1 ? LZ4_TAB_ZSTD : LZ4_TAB_LZ4, FMT, 0>(ctx, g1 - g0, SEG, d_src, d_blocks, block_count, g0, streams,
+                                                                                            meta, zrecs, spec_dst, dbg, nullptr, 0, nullptr);
+    if (dbg & 16384u) // ablation: the lane kernel alone, with its own probe
+        return launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, FMT, 1>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta, zrecs,
+                                                                   spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr);
+    void* wl;
+    int err = lthip_scratch(ctx, S_LZ4_CLASSIFY, 4 * (2 * (size_t)ngrp + 2), &wl);
+    if (err)
+        return err;
+    LTHIP_CHECK(ctx, hipMemsetAsync(wl, 0, 4 * (2 * (size_t)ngrp + 2), ctx->stream));
+    if ((err = launch_segments<LZ4_G_BATCH, FMT == 1 ? LZ4_TAB_ZSTD : LZ4_TAB_LZ4, FMT, 0, 1>(ctx, (uint32_t)ncgrp, SEG, d_src, d_blocks, block_count, 0,
+                                                                                             streams, meta, zrecs, spec_dst, dbg, nullptr,
+                                                                                             (uint32_t)ngrp, (uint32_t*)wl)))
+        return err;
+    return launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, FMT, 1>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta, zrecs,
+                                                               spec_dst, dbg, lane_recs, (uint32_t)ngrp, (uint32_t*)wl);
 }
 
 static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
@@ -1959,7 +2095,8 @@ static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_
     uint64_t nseg64 = 0, ngrp64 = 0;
     const bool lanes = lz4_lane_parser() && SEG == 4096u; // other unit sizes (tests, ablations) keep the batch parser's geometry
     const uint32_t GU = lanes ? LZ4_G_LANES : LZ4_G_BATCH;
-    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, SEG, GU, &d_blocks, &nseg64, &ngrp64);
+    uint64_t ncgrp64 = 0;
+    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, SEG, GU, &d_blocks, &nseg64, &ngrp64, &ncgrp64);
     if (err)
         return err;
     const uint32_t nseg = (uint32_t)nseg64;
@@ -1984,7 +2121,7 @@ static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_
     uint64_t total_bytes = 0;
     for (uint32_t b = 0; b < block_count; ++b)
         total_bytes += src_sizes[b];
-    const uint32_t want = !(dbg & 32u) ? 1u : (total_bytes >= (1ull << 30) ? 4u : (total_bytes >= (256ull << 20) ? 2u : 1u));
+    const uint32_t want = (!(dbg & 32u) || lanes) ? 1u : (total_bytes >= (1ull << 30) ? 4u : (total_bytes >= (256ull << 20) ? 2u : 1u));
     std::vector<uint32_t> cut{0};
     {
         uint64_t acc = 0;
@@ -2021,13 +2158,8 @@ static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_
         {
             LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
             uint8_t* spec = (dbg & 64u) ? (uint8_t*)nullptr : (uint8_t*)d_dst;
-            if (lanes)
-                err = launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, 0, 1>(ctx, g1 - g0, SEG, d_src, d_blocks, block_count, g0, (uint8_t*)streams,
-                                                                        (Lz4Meta*)meta, nullptr, spec, dbg, (uint64_t*)lrecs);
-            else
-                err = launch_segments<LZ4_G_BATCH, LZ4_TAB_LZ4, 0, 0>(ctx, g1 - g0, SEG, d_src, d_blocks, block_count, g0, (uint8_t*)streams,
-                                                                      (Lz4Meta*)meta, nullptr, spec, dbg, nullptr);
-            if (err)
+            if ((err = launch_match_finder<0>(ctx, lanes, SEG, d_src, d_blocks, block_count, g0, g1, ngrp64, ncgrp64, (uint8_t*)streams, (Lz4Meta*)meta,
+                                              nullptr, spec, dbg, (uint64_t*)lrecs)))
                 return err;
         }
         if (overlap)
@@ -2070,8 +2202,9 @@ int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_
     Lz4Block* d_blocks = nullptr;
     uint64_t nseg64 = 0, ngrp64 = 0;
     const bool lanes = lz4_lane_parser();
+    uint64_t ncgrp64 = 0;
     int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, SEG, lanes ? LZ4_G_LANES : LZ4_G_BATCH, &d_blocks,
-                            &nseg64, &ngrp64);
+                            &nseg64, &ngrp64, &ncgrp64);
     if (err)
         return err;
     uint64_t nseg = 0;
@@ -2095,13 +2228,8 @@ int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_
     {
         LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
         const uint32_t dbg = (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0);
-        if (lanes)
-            err = launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, 1, 1>(ctx, (uint32_t)ngrp64, SEG, d_src, d_blocks, block_count, 0u, (uint8_t*)lits,
-                                                                    (Lz4Meta*)meta, (uint64_t*)recs, (uint8_t*)d_dst, dbg, (uint64_t*)lrecs);
-        else
-            err = launch_segments<LZ4_G_BATCH, LZ4_TAB_ZSTD, 1, 0>(ctx, (uint32_t)ngrp64, SEG, d_src, d_blocks, block_count, 0u, (uint8_t*)lits,
-                                                                   (Lz4Meta*)meta, (uint64_t*)recs, (uint8_t*)d_dst, dbg, nullptr);
-        if (err)
+        if ((err = launch_match_finder<1>(ctx, lanes, SEG, d_src, d_blocks, block_count, 0u, (uint32_t)ngrp64, ngrp64, ncgrp64, (uint8_t*)lits,
+                                          (Lz4Meta*)meta, (uint64_t*)recs, (uint8_t*)d_dst, dbg, (uint64_t*)lrecs)))
             return err;
     }
     *d_lits = (uint8_t*)lits;

@@ -80,6 +80,7 @@ enum ScratchSlot
     S_Z_WORK,  // zstd: per-encoder-wave work area
     S_LZ4_WORKLIST, // groups the stitch copy has to visit
     S_LZ4_LANE_RECS, // lane parser: {start, length, offset} records, 8 per lane and unit
+    S_LZ4_CLASSIFY,  // two-pass match finder: list + flags of the groups with redundancy
     S_B3_WINDOWS,   // first range of every window of leaf slots (parents kernel)
     S_COUNT
 };
