@@ -311,43 +311,70 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
     const uint32_t s0 = my_start + (uint32_t)sidx * sub;
     const uint32_t lend = s0 + sub < unit_end ? s0 + sub : unit_end;
     uint32_t p = s0, anchor = s0, nrec = 0, last_end = 0;
+    uint32_t nmiss = 0; // consecutive misses of this lane: it steps 1 + nmiss / 4 bytes (the reference accelerates the same way,
+                        // lz4.c:1044-1053, only 16 times slower; tools/lz4_lane_model.c: half the iterations for 0.3 % of the ratio)
+    const uint32_t ashift = (dbg >> 16) & 7u ? (dbg >> 16) & 7u : 2u;
     uint64_t* myrecs = lrecs + (uint32_t)sidx * LZ4_LANE_MAXREC;
 
+    // A verified hit WAITS (the lane keeps its position and candidate, `pend`) until at least `wait_for` lanes hold one or nobody can
+    // probe any more: the extension below costs the wave the same whether one lane or sixty need it, the probe of the others is
+    // cheap, so hits are measured in bulk.
+    const uint32_t wait_for = (dbg >> 20) & 63u ? (dbg >> 20) & 63u : 16u;
+    bool pend = false;
+    uint32_t cand = LZ4_EMPTY;
     for (;;)
     {
-        const bool act = p < lend && (int32_t)p <= start_limit && nrec < LZ4_LANE_MAXREC && !(dbg & 2048u);
-        if (__builtin_amdgcn_ballot_w64(act) == 0ull)
+        const bool act = !pend && p < lend && (int32_t)p <= start_limit && nrec < LZ4_LANE_MAXREC && !(dbg & 2048u);
+        const uint64_t am = __builtin_amdgcn_ballot_w64(act);
+        if (am == 0ull && __builtin_amdgcn_ballot_w64(pend) == 0ull)
             break;
-        uint32_t v = 0, h = 0, cand = LZ4_EMPTY;
-        if (act)
+        if (am)
         {
-            v = lds_read32(sdata, p + head);
-            h = __umulhi(v * 2654435761u, (uint32_t)TAB);
-            cand = tab[h];
-        }
-        if (act)
-        {
-            // every lane has read before anyone writes (one wave: LDS operations execute in order) ... and reads again after
-            // everyone has written: when several lanes insert the same slot in this step the entry that survives (the lowest
-            // position: lanes are mapped to sub-units in reverse) is a candidate for the others at once
-            tab[h] = (uint16_t)p;
-            if (!(dbg & 512u))
+            uint32_t v = 0, h = 0, c = LZ4_EMPTY;
+            if (act)
             {
-                uint32_t hr = h;
-                asm volatile("" : "+v"(hr)); // the compiler must not know that this is the slot just written (it would forward the store)
-                const uint32_t fresh = tab[hr];
-                if (fresh < p)
-                    cand = fresh;
+                v = lds_read32(sdata, p + head);
+                h = __umulhi(v * 2654435761u, (uint32_t)TAB);
+                c = tab[h];
+            }
+            if (act)
+            {
+                // every lane has read before anyone writes (one wave: LDS operations execute in order) ... and reads again after
+                // everyone has written: when several lanes insert the same slot in this step the entry that survives (the lowest
+                // position: lanes are mapped to sub-units in reverse) is a candidate for the others at once
+                tab[h] = (uint16_t)p;
+                if (!(dbg & 512u))
+                {
+                    uint32_t hr = h;
+                    asm volatile("" : "+v"(hr)); // the compiler must not know that this is the slot just written (it would forward the store)
+                    const uint32_t fresh = tab[hr];
+                    if (fresh < p)
+                        c = fresh;
+                }
+            }
+            bool hit = false;
+            if (act && c != LZ4_EMPTY && c < p)
+                hit = lds_read32(sdata, c + head) == v;
+            if (hit)
+            {
+                pend = true;
+                cand = c;
+            }
+            else if (act)
+            {
+                p += 1u + (nmiss >> ashift);
+                ++nmiss;
             }
         }
-        bool ok = false;
-        if (act && cand != LZ4_EMPTY && cand < p)
-            ok = lds_read32(sdata, cand + head) == v;
-        if (__builtin_amdgcn_ballot_w64(ok) == 0ull)
-        {
-            p += act ? 1u : 0u;
+        const uint64_t pm = __builtin_amdgcn_ballot_w64(pend);
+        if (pm == 0ull)
             continue;
-        }
+        if ((uint32_t)__builtin_popcountll(pm) < wait_for &&
+            __builtin_amdgcn_ballot_w64(!pend && p < lend && (int32_t)p <= start_limit && nrec < LZ4_LANE_MAXREC) != 0ull)
+            continue; // somebody can still probe: let the hits pile up
+        const bool ok0 = pend;
+        bool ok = ok0;
+        pend = false;
         // ---- forwards, every hit lane for itself: 16 bytes per LDS round trip, at most 36 bytes ----
         uint32_t mlen = ok ? 4u : 0u;
         bool grow = ok;
@@ -443,9 +470,13 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
             p = s + len;
             anchor = p;
             last_end = p;
+            nmiss = 0;
         }
-        else if (act && !covered)
+        else if (ok0 && !covered)
+        {
+            // (cannot happen: a waiting hit is either recorded or covered) -- step on so that the loop always advances
             p += 1u;
+        }
     }
 
     // ---- what earlier sub-units' matches cover is dropped: exclusive prefix maximum of the match ends, in sub-unit order ----
@@ -826,16 +857,40 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
                     if (v * 64 + lane < TAB * 2 / 16)
                         tv[v * 64 + lane] = e;
                 if (wave != 0 && !(dbg & 1u))
-                    for (uint32_t q0 = 0; q0 < my_start; q0 += 1024) // every 4th position of the history, oldest first
+                {
+                    // Every 4th position of the history, oldest first -- the positions whose four bytes are an ALIGNED dword of the
+                    // window (position + head = 0 mod 4), so that one 16-byte LDS read delivers four of them: per 1024 inserts 4
+                    // reads instead of 16.  History older than 16 KiB is inserted every 16th position only (LTHIP_LZ4_DBG bit 15
+                    // inserts all of it: the far history hardly pays, tools/lz4_lane_model.c).
+                    const uint4* s128 = reinterpret_cast<const uint4*>(sdata);
+                    const uint32_t nlines = (my_start + head + 15u) >> 4; // 16-byte lines of the window that hold history
+                    const uint32_t near0 = (dbg & 32768u) || my_start <= 16384u ? 0u : ((my_start - 16384u + head) >> 4);
+                    for (uint32_t j0 = 0; j0 < nlines; j0 += 256)
                     {
-                        uint32_t hv[4];
+                        uint4 w[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            hv[u] = __umulhi(lds_read32(sdata, q0 + 4u * (u * 64 + (uint32_t)lane) + head) * 2654435761u, (uint32_t)TAB);
+                        {
+                            const uint32_t j = j0 + u * 64 + (uint32_t)lane;
+                            w[u] = j < nlines ? s128[j] : make_uint4(0, 0, 0, 0);
+                        }
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            tab[hv[u]] = (uint16_t)(q0 + 4u * (u * 64 + (uint32_t)lane));
+                        {
+                            const uint32_t j = j0 + u * 64 + (uint32_t)lane;
+                            const uint32_t q = 16u * j - head; // position of the line's first byte (may be "negative" in line 0)
+                            const uint32_t g[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+                            const bool far = j < near0;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                            {
+                                const uint32_t pk = q + 4u * k;
+                                if (j < nlines && pk < my_start && (!far || k == 0)) // pk wraps above my_start when negative
+                                    tab[__umulhi(g[k] * 2654435761u, (uint32_t)TAB)] = (uint16_t)pk;
+                            }
+                        }
                     }
+                }
                 lz4_lane_parse<TAB, FMT>(sdata, head, tab, lane, my_start, my_len, start_limit, end_limit, sub, out, recs,
                                          lane_recs + (uint64_t)unit * (64u * LZ4_LANE_MAXREC), st, dbg);
             }
@@ -848,7 +903,12 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     if (!parsed)
     for (;;)
     {
-        const bool more = have_unit && (int32_t)pos <= start_limit;
+        bool more = have_unit && (int32_t)pos <= start_limit;
+        if constexpr (CLS != 0)
+        {
+            if (!met && *reinterpret_cast<volatile uint32_t*>(flag) != 0u)
+                more = false; // another wave of the group has found redundancy: straight to the rendezvous
+        }
         // ---- after PROBE batches (or at the end of a short unit): does anybody in the group see redundancy? ----
         if (!met && (batches == LZ4_PROBE_BATCHES || !more))
         {
@@ -1010,6 +1070,19 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             pos += 64u * stride;
             ++nfail;
             continue;
+        }
+        if constexpr (CLS != 0)
+        {
+            if (!met)
+            {
+                // classification pass: one hit settles it -- the group is the lane parser's.  Raise the flag now (the other waves
+                // poll it before every batch) and go to the rendezvous without parsing anything.
+                st.have_first = true;
+                if (lane == 0)
+                    *flag = 1u;
+                pos = (uint32_t)(start_limit + 1);
+                continue;
+            }
         }
         if (dbg & 4u)
         {

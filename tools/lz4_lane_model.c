@@ -33,6 +33,9 @@ struct params
     int ways;           /* 1 or 2 entries per bucket (2: newest + previous, one 32-bit word) */
     int policy;         /* same-step write conflicts: 0 highest lane wins, 1 lowest lane wins */
     int maxrec;         /* sequences a lane may record for its sub-unit */
+    uint32_t near_bytes;/* history older than this is pre-seeded at far_stride instead of seed_stride (0 = all at seed_stride) */
+    int far_stride;     /* 0 = the far history is not inserted at all */
+    int accel;          /* a lane steps 1 + (consecutive misses >> accel) bytes after a miss (0 = always 1) */
     int raw;            /* 1: the table is read again AFTER the step's writes: the surviving entry of a write conflict is a candidate at once */
 };
 
@@ -64,6 +67,7 @@ static uint64_t model_block(const uint8_t* src, uint32_t n, const struct params*
     uint32_t* lane_anchor = (uint32_t*)malloc(4 * L);
     struct seq* lane_seqs = (struct seq*)malloc(sizeof(struct seq) * L * (sub / 4 + 2));
     uint32_t* lane_ns = (uint32_t*)malloc(4 * L);
+    uint32_t* lane_miss = (uint32_t*)malloc(4 * L);
     for (uint32_t g0 = 0; g0 < n; g0 += gbytes)
     {
         const uint32_t glen = n - g0 < gbytes ? n - g0 : gbytes;
@@ -85,8 +89,19 @@ static uint64_t model_block(const uint8_t* src, uint32_t n, const struct params*
         tab[2 * (H)] = (POS);                                \
     } while (0)
             if (P->seed_stride)
-                for (uint32_t q = hist0; q + 4 <= ustart; q += (uint32_t)P->seed_stride)
+            {
+                uint32_t q = hist0;
+                if (P->near_bytes && ustart - hist0 > P->near_bytes)
+                {
+                    const uint32_t near0 = ustart - P->near_bytes;
+                    if (P->far_stride)
+                        for (; q < near0; q += (uint32_t)P->far_stride)
+                            TAB_INSERT(hidx(rd32(src + q), NB), q);
+                    q = near0;
+                }
+                for (; q + 4 <= ustart; q += (uint32_t)P->seed_stride)
                     TAB_INSERT(hidx(rd32(src + q), NB), q);
+            }
             uint32_t active = 0;
             for (uint32_t l = 0; l < L; ++l)
             {
@@ -94,6 +109,7 @@ static uint64_t model_block(const uint8_t* src, uint32_t n, const struct params*
                 lane_end[l] = ustart + (l + 1) * sub < ustart + ulen ? ustart + (l + 1) * sub : ustart + ulen;
                 lane_anchor[l] = p[l];
                 lane_ns[l] = 0;
+                lane_miss[l] = 0;
                 if (p[l] < ustart + ulen)
                     ++active;
             }
@@ -164,6 +180,7 @@ static uint64_t model_block(const uint8_t* src, uint32_t n, const struct params*
                             p[l] += 1;
                             continue;
                         }
+                        lane_miss[l] = 0;
                         if (P->back)
                             while (s > lane_anchor[l] && cs > 0 && src[s - 1] == src[cs - 1])
                             {
@@ -181,7 +198,10 @@ static uint64_t model_block(const uint8_t* src, uint32_t n, const struct params*
                             TAB_INSERT(hidx(rd32(src + p[l] - 2), NB), p[l] - 2);
                     }
                     else
-                        p[l] += 1;
+                    {
+                        p[l] += 1 + (P->accel ? (lane_miss[l] >> P->accel) : 0);
+                        ++lane_miss[l];
+                    }
                 }
             }
             /* cover: a lane drops (or trims) what earlier lanes' matches already cover */
@@ -224,6 +244,7 @@ static uint64_t model_block(const uint8_t* src, uint32_t n, const struct params*
     free(lane_anchor);
     free(lane_seqs);
     free(lane_ns);
+    free(lane_miss);
     return out;
 }
 
@@ -236,13 +257,15 @@ int main(int argc, char** argv)
     uint8_t* buf = (uint8_t*)malloc(block);
     uint8_t* dst = (uint8_t*)malloc(lto_lz4_bound(block));
     struct params variants[] = {
-        /* unit group tab lanes cross seed inm back hist trim ways policy maxrec raw */
-        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 0},
-        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 1},
-        {4096, 16, 2048, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 1},
-        {4096, 8, 1280, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 1},
-        {4096, 12, 1280, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 1},
-        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 0, 8, 1},
+        /* unit group tab lanes cross seed inm back hist trim ways policy maxrec near far accel raw */
+        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1},
+        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 8, 2, 1},
+        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 8192, 8, 2, 1},
+        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 16, 2, 1},
+        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 32768, 0, 2, 1},
+        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 0, 2, 1},
+        {4096, 16, 2560, 64, 1, 8, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1},
+        {4096, 16, 2560, 64, 1, 6, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1},
     };
     printf("%-58s", "variant (unit group tab lanes cross seed inm back hist trim)");
     for (int k = 0; k < 4; ++k)
@@ -271,7 +294,7 @@ int main(int argc, char** argv)
         char label[128];
         snprintf(label, sizeof label, "%5u %3u %5u %3u   %d    %d    %d    %d    %d    %d  w%d p%d", P->unit, P->group, P->tab, P->lanes, P->cross, P->seed_stride,
                  P->insert_in_match, P->back, P->history_groups, P->trim, P->ways, P->policy);
-        snprintf(label + strlen(label), sizeof label - strlen(label), " m%d raw%d", P->maxrec, P->raw);
+        snprintf(label + strlen(label), sizeof label - strlen(label), " m%d n%u f%d a%d", P->maxrec, P->near_bytes, P->far_stride, P->accel);
         printf("%-58s", label);
         double it_mixed = 0;
         for (int k = 0; k < 4; ++k)
