@@ -270,6 +270,16 @@ LTHIP_EXPORT int lthip_create_missing_content(lthip_ctx* ctx, uint64_t existing_
                                               const uint32_t* chunk_tags, uint32_t hash_identifier, uint32_t max_block_size,
                                               uint32_t max_chunks_per_block, void* out, size_t out_capacity, size_t* out_size);
 
+/* ---- bulk Longtail_GetExistingStoreIndex (src/longtail.c:7087-7325) -------------------------------------------
+ * Which blocks of a store (its serialized StoreIndex, host memory, the bytes Longtail_WriteStoreIndexToBuffer produces) cover the
+ * given chunk hashes (device)?  Blocks are kept when at least min_block_usage_percent of their bytes are wanted, walked most-used
+ * first, and taken when they hold a wanted chunk no earlier block of the walk held.  Output: the serialized StoreIndex of the taken
+ * blocks (== Longtail_GetExistingStoreIndex + Longtail_WriteStoreIndexToBuffer, including the reference's habit of reading a taken
+ * block's tag at its first chunk's index).  Returns ENOMEM with *out_size set when `out` is too small, EBADF for a malformed index. */
+LTHIP_EXPORT int lthip_get_existing_store_index(lthip_ctx* ctx, const void* store_index, size_t store_index_size, uint64_t chunk_count,
+                                                const uint64_t* d_chunk_hashes, uint32_t min_block_usage_percent, void* out,
+                                                size_t out_capacity, size_t* out_size);
+
 /* ---- the ingest metric as one native session (CreateVersionIndex + CreateMissingContent + WriteContent) --------
  * For assets already resident in HBM.  The caller runs lthip_chunk_hash over its own jobs (one part per job, ascending job order),
  * then

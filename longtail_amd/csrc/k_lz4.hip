@@ -264,7 +264,6 @@ __device__ __forceinline__ void lz4_coop_sequence(const uint8_t* __restrict__ sb
 constexpr int LZ4_G_BATCH = 8;   // MODE 0 (batch parser): 8 x 4 KiB units per 32 KiB window group
 constexpr int LZ4_G_LANES = 16;  // MODE 1 (lane parser): 16 x 4 KiB units per 64 KiB window group, one workgroup per CU
 constexpr int LZ4_PROBE_BATCHES = 4;
-constexpr int LZ4_LANE_PROBES = 8; // MODE 1: positions every lane probes before the group decides whether the data is worth parsing
 constexpr uint32_t Z_PIECE = 128u << 10; // zstd Block_Maximum_Size (ZB_BLOCK_MAX of zstd_block_core.h, asserted in k_zstd.hip)
 // table entries per wave.  MODE 0: 32 KiB window + 8 x 2.5 KiB tables = 52 KiB: THREE workgroups (24 waves) per CU.
 // MODE 1: 64 KiB window + 16 x 5 KiB tables = 144 KiB: one workgroup of 16 waves per CU (the lane parser is not issue bound, it
@@ -784,78 +783,16 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     uint32_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0, ps0 = 1, ps1 = 1, ps2 = 1, ps3 = 1; // the probe batches (SGPRs)
     static_assert(LZ4_PROBE_BATCHES == 4, "probe bookkeeping is unrolled by hand");
 
-    bool parsed = false;
     if constexpr (MODE == 1)
     {
-        // ---- probe: every lane looks at the first positions of its sub-unit (512 positions spread over the unit); one repeat
-        // anywhere in the group and the group is parsed by lanes, none and the batch parser's miss mode skims it ----
         // sub-unit pitch = unit / 64 bytes.  (An odd number of dwords -- 68 bytes, 61 lanes busy -- so that lanes running in phase do
         // not all hit the same two LDS banks was measured: 6 % SLOWER and a worse ratio; dbg bit 8 keeps the experiment.)
         const uint32_t sub = (dbg & 256u) ? ((sub_bytes >> 6) | 4u) : sub_bytes >> 6;
-        if (listed)
-        {
-            if (tid == 0)
-                *flag = 1u; // the classification pass found redundancy in this group
-        }
-        else if (have_unit && !(dbg & 8192u))
-        {
-            const uint32_t sidx = (dbg & 128u) ? (uint32_t)lane : 63u - (uint32_t)lane;
-            uint32_t p = my_start + sidx * sub;
-            const uint32_t lend = p + sub < my_start + my_len ? p + sub : my_start + my_len;
-            // All eight positions of a lane in ONE pass over the LDS pipeline (three dependent round trips instead of 24): the 11
-            // bytes they span are read once, the table is written and read back per position back to back (LDS operations of a
-            // wave execute in order: the read sees this step's writes of ALL lanes, so repeats between sub-units that run in phase
-            // -- records, tokens -- are seen although every lane inserts them in the same instruction), then the candidates'
-            // bytes are compared.
-            static_assert(LZ4_LANE_PROBES == 8, "the probe reads four dwords per lane");
-            const uint32_t w0 = (p + head) >> 2, sh = ((p + head) & 3u) * 8u;
-            const uint32_t d0 = sdata[w0], d1 = sdata[w0 + 1], d2 = sdata[w0 + 2], d3 = sdata[w0 + 3];
-            const uint64_t q0 = ((uint64_t)d1 << 32 | d0) >> sh, q1 = ((uint64_t)d2 << 32 | d1) >> sh, q2 = ((uint64_t)d3 << 32 | d2) >> sh;
-            uint32_t vv[LZ4_LANE_PROBES], hh[LZ4_LANE_PROBES], cc[LZ4_LANE_PROBES];
-            vv[0] = (uint32_t)q0;
-            vv[1] = (uint32_t)(q0 >> 8) | ((uint32_t)q1 << 24);
-            vv[2] = (uint32_t)(q0 >> 16) | ((uint32_t)q1 << 16);
-            vv[3] = (uint32_t)(q0 >> 24) | ((uint32_t)q1 << 8);
-            vv[4] = (uint32_t)q1;
-            vv[5] = (uint32_t)(q1 >> 8) | ((uint32_t)q2 << 24);
-            vv[6] = (uint32_t)(q1 >> 16) | ((uint32_t)q2 << 16);
-            vv[7] = (uint32_t)(q1 >> 24) | ((uint32_t)q2 << 8);
-#pragma unroll
-            for (int it = 0; it < LZ4_LANE_PROBES; ++it)
-                hh[it] = __umulhi(vv[it] * 2654435761u, (uint32_t)TAB);
-#pragma unroll
-            for (int it = 0; it < LZ4_LANE_PROBES; ++it)
-            {
-                const bool act = p + it < lend && (int32_t)(p + it) <= start_limit;
-                cc[it] = LZ4_EMPTY;
-                if (act)
-                {
-                    tab[hh[it]] = (uint16_t)(p + it);
-                    uint32_t hr = hh[it];
-                    asm volatile("" : "+v"(hr)); // the compiler must not know that this is the slot just written (it would forward the store)
-                    cc[it] = tab[hr];
-                }
-            }
-            bool any = false;
-#pragma unroll
-            for (int it = 0; it < LZ4_LANE_PROBES; ++it)
-                if (cc[it] != LZ4_EMPTY && cc[it] != ((p + it) & 0xFFFFu))
-                    any |= lds_read32(sdata, cc[it] + head) == vv[it];
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull && lane == 0)
-                *flag = 1u; // benign race: every writer stores the same value
-        }
-        __syncthreads();
-        met = true;
-        if (*flag != 0u && !(dbg & 16u))
+        // every group this kernel sees holds redundancy (the classification pass listed it; LTHIP_LZ4_DBG bit 14 sends ALL groups
+        // here, an ablation): no probe, no rendezvous -- the waves of the group only share the window
         {
             if (have_unit)
             {
-                uint4* tv = reinterpret_cast<uint4*>(tab);
-                const uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-#pragma unroll
-                for (uint32_t v = 0; v < (TAB * 2 / 16 + 63) / 64; ++v)
-                    if (v * 64 + lane < TAB * 2 / 16)
-                        tv[v * 64 + lane] = e;
                 if (wave != 0 && !(dbg & 1u))
                 {
                     // Every 4th position of the history, oldest first -- the positions whose four bytes are an ALIGNED dword of the
@@ -894,21 +831,13 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
                 lz4_lane_parse<TAB, FMT>(sdata, head, tab, lane, my_start, my_len, start_limit, end_limit, sub, out, recs,
                                          lane_recs + (uint64_t)unit * (64u * LZ4_LANE_MAXREC), st, dbg);
             }
-            parsed = true;
         }
-        else if (*flag == 0u && have_unit && (int32_t)pos <= start_limit)
-            nfail = (dbg >> 8) ? (dbg >> 8) : 24u; // incompressible: one twin round of the miss mode skims the unit
     }
 
-    if (!parsed)
+    if constexpr (MODE == 0)
     for (;;)
     {
-        bool more = have_unit && (int32_t)pos <= start_limit;
-        if constexpr (CLS != 0)
-        {
-            if (!met && *reinterpret_cast<volatile uint32_t*>(flag) != 0u)
-                more = false; // another wave of the group has found redundancy: straight to the rendezvous
-        }
+        const bool more = have_unit && (int32_t)pos <= start_limit;
         // ---- after PROBE batches (or at the end of a short unit): does anybody in the group see redundancy? ----
         if (!met && (batches == LZ4_PROBE_BATCHES || !more))
         {
@@ -1075,8 +1004,9 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         {
             if (!met)
             {
-                // classification pass: one hit settles it -- the group is the lane parser's.  Raise the flag now (the other waves
-                // poll it before every batch) and go to the rendezvous without parsing anything.
+                // classification pass: one hit settles it -- the group is the lane parser's.  Raise the flag and go to the rendezvous
+                // without parsing anything.  (The other waves are NOT polled out of their probe batches: a flag read per batch is one
+                // more dependent LDS round trip in the chain that incompressible data consists of -- measured +8 % on random data.)
                 st.have_first = true;
                 if (lane == 0)
                     *flag = 1u;

@@ -11,6 +11,8 @@
 #include "lthip_internal.h"
 #include "index_kernels.h"
 
+#include <algorithm>
+
 namespace
 {
 
@@ -348,5 +350,324 @@ extern "C" int lthip_create_missing_content(lthip_ctx* ctx, uint64_t existing_co
     memcpy(w, b_tag.data(), nb * 4);   // m_BlockTags
     w += nb * 4;
     memcpy(w, m_size.data(), m * 4);   // m_ChunkSizes
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SURVEY.md §8 f4 (second half): Longtail_GetExistingStoreIndex (src/longtail.c:7087-7325) as a bulk call.
+// Which blocks of a store cover the given chunk hashes?  The reference (1) counts the distinct wanted hashes, (2) measures every
+// store block's usage = bytes of wanted chunks / block bytes and keeps the blocks at or above min_block_usage_percent, (3) sorts
+// them by usage, most used first (qsort_r with a usage-only comparator: glibc's merge sort keeps equal usages in store order, and
+// that is the order reproduced here), (4) walks them in that order: a block is taken when it holds a wanted chunk that no earlier
+// block of the walk held, (5) lays the taken blocks out with Longtail_CreateStoreIndexFromBlocks (:9063-9125).
+// On the device the serial walk (4) becomes order independent: every wanted chunk is claimed by the block of smallest RANK that
+// holds it (atomicMin), and a block is taken iff it claims something.  The hash-set membership tests of (2) and the claims of (4)
+// run over the store's chunk list in parallel; the sort of a few thousand blocks stays on the host.
+// One quirk is mirrored, not fixed: the reference takes a taken block's tag from m_BlockTags[first chunk index] instead of
+// m_BlockTags[block index] (:7307) -- an index that can run past the tag array into the chunk sizes that follow it.
+// ---------------------------------------------------------------------------------------------------
+namespace
+{
+constexpr uint64_t GE_EMPTY = 0xFFFFFFFFFFFFFFFFull;
+
+__device__ __forceinline__ uint64_t ge_mix(uint64_t z)
+{
+    z = (z ^ (z >> 33)) * 0xff51afd7ed558ccdull;
+    z = (z ^ (z >> 33)) * 0xc4ceb9fe1a85ec53ull;
+    return z ^ (z >> 33);
+}
+
+__global__ void k_ge_clear(uint64_t* __restrict__ keys, uint32_t* __restrict__ val, uint64_t slots, uint32_t* __restrict__ misc)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        keys[i] = GE_EMPTY;
+        val[i] = 0xFFFFFFFFu;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 4)
+        misc[threadIdx.x] = threadIdx.x == 1 ? 0xFFFFFFFFu : 0u; // [0] distinct wanted, [1] rank of the all-ones hash, [2] all-ones wanted
+}
+
+__global__ void k_ge_insert(const uint64_t* __restrict__ wanted, uint64_t n, uint64_t* __restrict__ keys, uint64_t mask,
+                            uint32_t* __restrict__ misc)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint64_t h = wanted[i];
+    if (h == GE_EMPTY)
+    {
+        if (atomicExch(&misc[2], 1u) == 0u)
+            atomicAdd(&misc[0], 1u);
+        return;
+    }
+    uint64_t slot = ge_mix(h) & mask;
+    for (;;)
+    {
+        const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]), (unsigned long long)GE_EMPTY, (unsigned long long)h);
+        if (prev == GE_EMPTY)
+        {
+            atomicAdd(&misc[0], 1u);
+            return;
+        }
+        if (prev == h)
+            return;
+        slot = (slot + 1) & mask;
+    }
+}
+
+// slot of a store chunk hash in the wanted set, or ~0 (the all-ones hash lives in misc)
+__device__ __forceinline__ uint64_t ge_find(uint64_t h, const uint64_t* __restrict__ keys, uint64_t mask)
+{
+    uint64_t slot = ge_mix(h) & mask;
+    for (;;)
+    {
+        const uint64_t k = keys[slot];
+        if (k == h)
+            return slot;
+        if (k == GE_EMPTY)
+            return ~0ull;
+        slot = (slot + 1) & mask;
+    }
+}
+
+// one wave per store block: bytes of the block, bytes of its wanted chunks
+__global__ __launch_bounds__(64) void k_ge_usage(const uint32_t* __restrict__ b_off, const uint32_t* __restrict__ b_cnt, uint32_t nblocks,
+                                                 const uint64_t* __restrict__ c_hash, const uint32_t* __restrict__ c_size,
+                                                 const uint64_t* __restrict__ keys, uint64_t mask, const uint32_t* __restrict__ misc,
+                                                 uint32_t* __restrict__ use, uint32_t* __restrict__ size)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks)
+        return;
+    const uint32_t o = b_off[b], n = b_cnt[b];
+    uint32_t u = 0, s = 0; // uint32_t like the reference's block_use / block_size
+    for (uint32_t i = threadIdx.x; i < n; i += 64)
+    {
+        const uint64_t h = c_hash[o + i];
+        const uint32_t sz = c_size[o + i];
+        s += sz;
+        const bool in = h == GE_EMPTY ? misc[2] != 0u : ge_find(h, keys, mask) != ~0ull;
+        u += in ? sz : 0u;
+    }
+    for (int d = 32; d > 0; d >>= 1)
+    {
+        u += __shfl_down(u, d, 64);
+        s += __shfl_down(s, d, 64);
+    }
+    if (threadIdx.x == 0)
+    {
+        use[b] = u;
+        size[b] = s;
+    }
+}
+
+// every wanted chunk of a ranked block: claimed by the smallest rank
+__global__ __launch_bounds__(64) void k_ge_claim(const uint32_t* __restrict__ b_off, const uint32_t* __restrict__ b_cnt, uint32_t nblocks,
+                                                 const uint32_t* __restrict__ rank, const uint64_t* __restrict__ c_hash,
+                                                 const uint64_t* __restrict__ keys, uint32_t* __restrict__ val, uint64_t mask,
+                                                 uint32_t* __restrict__ misc)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks || rank[b] == 0xFFFFFFFFu)
+        return;
+    const uint32_t o = b_off[b], n = b_cnt[b], r = rank[b];
+    for (uint32_t i = threadIdx.x; i < n; i += 64)
+    {
+        const uint64_t h = c_hash[o + i];
+        if (h == GE_EMPTY)
+        {
+            if (misc[2] != 0u)
+                atomicMin(&misc[1], r);
+            continue;
+        }
+        const uint64_t slot = ge_find(h, keys, mask);
+        if (slot != ~0ull)
+            atomicMin(&val[slot], r);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_ge_taken(const uint32_t* __restrict__ b_off, const uint32_t* __restrict__ b_cnt, uint32_t nblocks,
+                                                 const uint32_t* __restrict__ rank, const uint64_t* __restrict__ c_hash,
+                                                 const uint64_t* __restrict__ keys, const uint32_t* __restrict__ val, uint64_t mask,
+                                                 const uint32_t* __restrict__ misc, uint32_t* __restrict__ taken)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks)
+        return;
+    const uint32_t o = b_off[b], n = b_cnt[b], r = rank[b];
+    bool mine = false;
+    if (r != 0xFFFFFFFFu)
+        for (uint32_t i = threadIdx.x; i < n; i += 64)
+        {
+            const uint64_t h = c_hash[o + i];
+            if (h == GE_EMPTY)
+                mine |= misc[2] != 0u && misc[1] == r;
+            else
+            {
+                const uint64_t slot = ge_find(h, keys, mask);
+                mine |= slot != ~0ull && val[slot] == r;
+            }
+        }
+    const uint64_t any = __builtin_amdgcn_ballot_w64(mine);
+    if (threadIdx.x == 0)
+        taken[b] = any != 0ull ? 1u : 0u;
+}
+} // namespace
+
+extern "C" int lthip_get_existing_store_index(lthip_ctx* ctx, const void* store_index, size_t store_index_size, uint64_t chunk_count,
+                                              const uint64_t* d_chunk_hashes, uint32_t min_block_usage_percent, void* out, size_t out_capacity,
+                                              size_t* out_size)
+{
+    if (!ctx || !store_index || !out_size || (chunk_count && !d_chunk_hashes))
+        return EINVAL;
+    if (store_index_size < 16)
+        return lthip_fail(ctx, EBADF, "existing store index", "store index shorter than its header");
+    const uint8_t* r = (const uint8_t*)store_index;
+    uint32_t head[4];
+    memcpy(head, r, 16);
+    const uint32_t nb = head[2], m = head[3];
+    if (head[0] != (1u << 24)) // LONGTAIL_STORE_INDEX_VERSION_1_0_0 (src/longtail.c:19-23; InitStoreIndexFromData rejects others)
+        return lthip_fail(ctx, EBADF, "existing store index", "unsupported store index version");
+    const size_t need = 16 + (size_t)nb * 8 + (size_t)m * 8 + (size_t)nb * 12 + (size_t)m * 4;
+    if (store_index_size < need || chunk_count > 0x7FFFFFF0ull)
+        return lthip_fail(ctx, EBADF, "existing store index", "store index truncated");
+    // unaligned-safe views (the serialized index is only 4-byte aligned after its 16-byte header)
+    const uint8_t* p_bhash = r + 16;
+    const uint8_t* p_chash = p_bhash + (size_t)nb * 8;
+    const uint8_t* p_boff = p_chash + (size_t)m * 8;
+    const uint8_t* p_bcnt = p_boff + (size_t)nb * 4;
+    const uint8_t* p_btag = p_bcnt + (size_t)nb * 4;
+    const uint8_t* p_csize = p_btag + (size_t)nb * 4;
+    std::vector<uint32_t> b_off(nb), b_cnt(nb);
+    if (nb)
+    {
+        memcpy(b_off.data(), p_boff, (size_t)nb * 4);
+        memcpy(b_cnt.data(), p_bcnt, (size_t)nb * 4);
+    }
+    for (uint32_t b = 0; b < nb; ++b)
+        if ((uint64_t)b_off[b] + b_cnt[b] > m)
+            return lthip_fail(ctx, EBADF, "existing store index", "block chunk range outside the chunk list");
+    auto write_empty = [&]() -> int {
+        // Longtail_CreateStoreIndexFromBlocks(0, 0): hash identifier 0, no blocks, no chunks
+        *out_size = 16;
+        if (!out || out_capacity < 16)
+            return ENOMEM;
+        const uint32_t e[4] = {1u << 24, 0u, 0u, 0u};
+        memcpy(out, e, 16);
+        return 0;
+    };
+    if (nb == 0 || min_block_usage_percent > 100)
+        return write_empty();
+
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    uint64_t slots = 1024;
+    while (slots < chunk_count * 2)
+        slots <<= 1;
+    DevBuf d_keys, d_val, d_misc, d_chash, d_csize, d_boff, d_bcnt, d_use, d_size, d_rank, d_taken;
+    int err;
+    if ((err = d_keys.alloc(ctx, slots * 8)) || (err = d_val.alloc(ctx, slots * 4)) || (err = d_misc.alloc(ctx, 16)) ||
+        (err = d_chash.alloc(ctx, (size_t)m * 8)) || (err = d_csize.alloc(ctx, (size_t)m * 4)) || (err = d_boff.alloc(ctx, (size_t)nb * 4)) ||
+        (err = d_bcnt.alloc(ctx, (size_t)nb * 4)) || (err = d_use.alloc(ctx, (size_t)nb * 4)) || (err = d_size.alloc(ctx, (size_t)nb * 4)) ||
+        (err = d_rank.alloc(ctx, (size_t)nb * 4)) || (err = d_taken.alloc(ctx, (size_t)nb * 4)))
+        return err;
+    if (m)
+    {
+        LTHIP_CHECK(ctx, hipMemcpyAsync(d_chash.p, p_chash, (size_t)m * 8, hipMemcpyHostToDevice, s));
+        LTHIP_CHECK(ctx, hipMemcpyAsync(d_csize.p, p_csize, (size_t)m * 4, hipMemcpyHostToDevice, s));
+    }
+    LTHIP_CHECK(ctx, hipMemcpyAsync(d_boff.p, b_off.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+    LTHIP_CHECK(ctx, hipMemcpyAsync(d_bcnt.p, b_cnt.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+    const uint64_t mask = slots - 1;
+    hipLaunchKernelGGL(k_ge_clear, dim3(1024), dim3(256), 0, s, (uint64_t*)d_keys.p, (uint32_t*)d_val.p, slots, (uint32_t*)d_misc.p);
+    if (chunk_count)
+        hipLaunchKernelGGL(k_ge_insert, dim3((uint32_t)div_up_u64(chunk_count, 256)), dim3(256), 0, s, d_chunk_hashes, chunk_count,
+                           (uint64_t*)d_keys.p, mask, (uint32_t*)d_misc.p);
+    hipLaunchKernelGGL(k_ge_usage, dim3(nb), dim3(64), 0, s, (const uint32_t*)d_boff.p, (const uint32_t*)d_bcnt.p, nb, (const uint64_t*)d_chash.p,
+                       (const uint32_t*)d_csize.p, (const uint64_t*)d_keys.p, mask, (const uint32_t*)d_misc.p, (uint32_t*)d_use.p,
+                       (uint32_t*)d_size.p);
+    LTHIP_LAUNCH_CHECK(ctx);
+    std::vector<uint32_t> use(nb), size(nb);
+    LTHIP_CHECK(ctx, hipMemcpyAsync(use.data(), d_use.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+    LTHIP_CHECK(ctx, hipMemcpyAsync(size.data(), d_size.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+    LTHIP_CHECK(ctx, hipStreamSynchronize(s));
+    // (2)+(3): the potential blocks, most used first, equal usages in store order
+    std::vector<uint32_t> order, pct(nb, 0);
+    for (uint32_t b = 0; b < nb; ++b)
+        if (use[b] > 0)
+        {
+            pct[b] = (uint32_t)(((uint64_t)use[b] * 100) / size[b]);
+            if (min_block_usage_percent > 0 && pct[b] < min_block_usage_percent)
+                continue;
+            order.push_back(b);
+        }
+    if (order.empty())
+        return write_empty();
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pct[a] > pct[b]; });
+    std::vector<uint32_t> rank(nb, 0xFFFFFFFFu);
+    for (size_t i = 0; i < order.size(); ++i)
+        rank[order[i]] = (uint32_t)i;
+    LTHIP_CHECK(ctx, hipMemcpyAsync(d_rank.p, rank.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+    // (4): claims
+    hipLaunchKernelGGL(k_ge_claim, dim3(nb), dim3(64), 0, s, (const uint32_t*)d_boff.p, (const uint32_t*)d_bcnt.p, nb, (const uint32_t*)d_rank.p,
+                       (const uint64_t*)d_chash.p, (const uint64_t*)d_keys.p, (uint32_t*)d_val.p, mask, (uint32_t*)d_misc.p);
+    hipLaunchKernelGGL(k_ge_taken, dim3(nb), dim3(64), 0, s, (const uint32_t*)d_boff.p, (const uint32_t*)d_bcnt.p, nb, (const uint32_t*)d_rank.p,
+                       (const uint64_t*)d_chash.p, (const uint64_t*)d_keys.p, (const uint32_t*)d_val.p, mask, (const uint32_t*)d_misc.p,
+                       (uint32_t*)d_taken.p);
+    LTHIP_LAUNCH_CHECK(ctx);
+    std::vector<uint32_t> taken(nb);
+    LTHIP_CHECK(ctx, hipMemcpyAsync(taken.data(), d_taken.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+    LTHIP_CHECK(ctx, hipStreamSynchronize(s));
+    // (5): the taken blocks in walk order; a block hash that occurs twice in the store is taken once (block_to_index_lookup, :7246)
+    std::vector<uint32_t> found;
+    {
+        std::vector<uint64_t> seen;
+        for (uint32_t b : order)
+            if (taken[b])
+            {
+                uint64_t bh;
+                memcpy(&bh, p_bhash + (size_t)b * 8, 8);
+                if (std::find(seen.begin(), seen.end(), bh) != seen.end())
+                    continue;
+                seen.push_back(bh);
+                found.push_back(b);
+            }
+    }
+    if (found.empty())
+        return write_empty();
+    size_t fm = 0;
+    for (uint32_t b : found)
+        fm += b_cnt[b];
+    const size_t fb = found.size();
+    const size_t osize = 16 + fb * 8 + fm * 8 + fb * 12 + fm * 4;
+    *out_size = osize;
+    if (!out || out_capacity < osize)
+        return ENOMEM;
+    uint8_t* w = (uint8_t*)out;
+    const uint32_t ohead[4] = {1u << 24, head[1], (uint32_t)fb, (uint32_t)fm};
+    memcpy(w, ohead, 16);
+    uint8_t* o_bhash = w + 16;
+    uint8_t* o_chash = o_bhash + fb * 8;
+    uint8_t* o_boff = o_chash + fm * 8;
+    uint8_t* o_bcnt = o_boff + fb * 4;
+    uint8_t* o_btag = o_bcnt + fb * 4;
+    uint8_t* o_csize = o_btag + fb * 4;
+    uint32_t c = 0;
+    for (size_t i = 0; i < fb; ++i)
+    {
+        const uint32_t b = found[i], n = b_cnt[b], off = b_off[b];
+        memcpy(o_bhash + i * 8, p_bhash + (size_t)b * 8, 8);
+        // the reference's tag quirk: m_BlockTags[first chunk index] (:7307), read where that index lands in the serialized arrays
+        uint32_t tag = 0;
+        if ((size_t)(p_btag - r) + (size_t)off * 4 + 4 <= store_index_size)
+            memcpy(&tag, p_btag + (size_t)off * 4, 4);
+        memcpy(o_btag + i * 4, &tag, 4);
+        memcpy(o_bcnt + i * 4, &n, 4);
+        memcpy(o_boff + i * 4, &c, 4);
+        memcpy(o_chash + (size_t)c * 8, p_chash + (size_t)off * 8, (size_t)n * 8);
+        memcpy(o_csize + (size_t)c * 4, p_csize + (size_t)off * 4, (size_t)n * 4);
+        c += n;
+    }
     return 0;
 }

@@ -112,6 +112,7 @@ class HipLib:
         sig("lthip_stored_block_header_size", sz, [u32])
         sig("lthip_write_stored_block_headers", i32, [vp, u32, vp, vp, vp, u32, u32, vp, vp, vp, vp])
         sig("lthip_create_missing_content", i32, [vp, u64, vp, u64, vp, vp, vp, u32, u32, u32, vp, sz, vp])
+        sig("lthip_get_existing_store_index", i32, [vp, vp, sz, u64, vp, u32, vp, sz, vp])
         sig("lthip_version_index_size", sz, [u32, u64, u64, u32])
         sig("lthip_build_version_index", i32, [vp, u32, vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, u32, u32, vp, sz, vp])
         sig("lthip_dedup_first_seen", i32, [vp, u64, vp, vp, vp])
@@ -349,6 +350,17 @@ class Context:
             tags.ctypes.data if tags is not None else None, hash_identifier, max_block_size, max_chunks_per_block, out.ctypes.data,
             cap, C.byref(size))
         self._check(err, "lthip_create_missing_content")
+        return out[: size.value].tobytes()
+
+    def get_existing_store_index(self, store_index: bytes, chunk_hashes, min_block_usage_percent: int) -> bytes:
+        """Serialized StoreIndex of the store's blocks that cover `chunk_hashes` (device int64/uint64 tensor); see longtail_hip.h."""
+        raw = np.frombuffer(store_index, np.uint8)
+        n = int(chunk_hashes.numel()) if chunk_hashes is not None else 0
+        out = np.zeros(len(raw) + 64, np.uint8)
+        size = C.c_size_t(0)
+        err = self.lib.dll.lthip_get_existing_store_index(self.h, raw.ctypes.data, len(raw), n, _ptr(chunk_hashes) if n else None,
+                                                          min_block_usage_percent, out.ctypes.data, len(out), C.byref(size))
+        self._check(err, "lthip_get_existing_store_index")
         return out[: size.value].tobytes()
 
     # -- block assembly --

@@ -139,3 +139,40 @@ def test_bulk_missing_content_store_index_is_byte_identical(gpu, ref):
                                          torch.from_numpy(hashes.view(np.int64)).cuda(), torch.from_numpy(sizes.view(np.int32)).cuda(),
                                          tags, max_block, max_chunks)
         assert got == expect, (n, ne, len(got), len(expect))
+
+
+def make_store_index(rng, nblocks, max_chunks, pool, ntags=3):
+    """A serialized StoreIndex (layout src/longtail.c:8913-8931) whose blocks draw their chunks from `pool` WITH repetition across
+    blocks (a chunk can live in several blocks: what GetExistingStoreIndex's most-used-first walk is about)."""
+    counts = rng.integers(1, max_chunks + 1, nblocks).astype(np.uint32)
+    m = int(counts.sum())
+    chunk_hashes = rng.choice(pool, m).astype(np.uint64)
+    chunk_sizes = rng.integers(1, 100000, m).astype(np.uint32)
+    offsets = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint32)
+    block_hashes = rng.integers(1, 2**63, nblocks, dtype=np.int64).astype(np.uint64)
+    tags = rng.integers(1, ntags + 1, nblocks).astype(np.uint32)
+    head = np.array([1 << 24, 0x626C6B33, nblocks, m], np.uint32)
+    return b"".join(a.tobytes() for a in (head, block_hashes, chunk_hashes, offsets, counts, tags, chunk_sizes))
+
+
+def test_bulk_existing_store_index_is_byte_identical(gpu, ref):
+    """lthip_get_existing_store_index == Longtail_GetExistingStoreIndex + Longtail_WriteStoreIndexToBuffer."""
+    rng = np.random.default_rng(23)
+    for nblocks, max_chunks, npool, nwant in ((40, 12, 200, 120), (300, 64, 5000, 3000), (8, 4, 10, 10), (100, 1024, 40000, 100),
+                                              (50, 20, 300, 0)):
+        pool = rng.integers(1, 2**63, npool, dtype=np.int64).astype(np.uint64)
+        si = make_store_index(rng, nblocks, max_chunks, pool)
+        wanted = np.concatenate([rng.choice(pool, nwant // 2 * 2 // 2), rng.integers(1, 2**63, nwant - nwant // 2, dtype=np.int64).astype(np.uint64)]) \
+            if nwant else np.zeros(0, np.uint64)
+        wanted = np.concatenate([wanted, wanted[: len(wanted) // 5]])  # duplicates in the request
+        rng.shuffle(wanted)
+        d_wanted = torch.from_numpy(wanted.view(np.int64).copy()).cuda() if len(wanted) else None
+        for pct in (0, 1, 30, 75, 100, 101):
+            expect = ref.get_existing_store_index(si, wanted, pct)
+            got = gpu.get_existing_store_index(si, d_wanted, pct)
+            assert got == expect, (nblocks, max_chunks, npool, nwant, pct, len(got), len(expect))
+    # the whole store is wanted: every block that brings something new is taken
+    pool = rng.integers(1, 2**63, 1000, dtype=np.int64).astype(np.uint64)
+    si = make_store_index(rng, 60, 50, pool)
+    everything = torch.from_numpy(pool.view(np.int64).copy()).cuda()
+    assert gpu.get_existing_store_index(si, everything, 0) == ref.get_existing_store_index(si, pool, 0)
