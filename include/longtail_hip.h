@@ -68,6 +68,16 @@ LTHIP_EXPORT void Longtail_Hip_SetAllocator(Longtail_Hip_AllocFunc alloc_func, L
 /* GPU used by plugin objects created afterwards (default: $LONGTAIL_HIP_DEVICE or 0). */
 LTHIP_EXPORT int Longtail_Hip_SetDevice(int device);
 
+/* HashAPI.Hash / EndContext return no error code (longtail_blake3.c:43-79 cannot fail; a GPU path can: allocation, copy, no
+ * device).  The first errno of such a call on the calling thread is latched; this returns and clears it (0 = none). */
+LTHIP_EXPORT int Longtail_Hip_GetLastError(void);
+
+/* Pinned host memory currently held by the chunker windows.  Windows are pooled in two classes -- 2 MiB (at most
+ * $LONGTAIL_HIP_SMALL_WINDOWS, default 256) and 64 MiB (at most $LONGTAIL_HIP_LARGE_WINDOWS, default 32) -- so the bound is
+ * about 0.5 + 2 GiB (and as much HBM) however many chunkers longtail's job system keeps alive; a thread that needs a window beyond
+ * the cap waits for one to be released.  The reference pools 4 * max_chunk bytes per chunker (hpcdcchunker.c:148-171). */
+LTHIP_EXPORT uint64_t Longtail_Hip_PinnedBytes(void);
+
 /* =====================================================================================================
  * B. bulk device API
  * =================================================================================================== */
@@ -123,6 +133,9 @@ LTHIP_EXPORT int lthip_timing_get(lthip_ctx* ctx, int kernel_id, double* out_tot
 LTHIP_EXPORT int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const uint64_t* part_offsets /*host*/,
                                    const uint64_t* part_sizes /*host*/, uint32_t min_chunk, uint32_t avg_chunk,
                                    uint32_t max_chunk, lthip_plan** out_plan);
+/* A plan of ONE part (created with part_count 1, offset 0, size = capacity) aimed at `size` <= capacity bytes: no allocation, no
+ * kernel, no synchronisation -- the plugin chunker keeps one plan per window and re-aims it at every refill. */
+LTHIP_EXPORT int lthip_plan_resize_single(lthip_ctx* ctx, lthip_plan* plan, uint64_t size);
 /* ctx may be NULL (e.g. the creating thread's context is gone): the device is synchronised instead of the stream */
 LTHIP_EXPORT void lthip_plan_destroy(lthip_ctx* ctx, lthip_plan* plan);
 /* upper bound on the number of chunks the plan can produce (size the output arrays with it) */

@@ -3,13 +3,18 @@
 // Reference behaviour: lib/hpcdcchunker/longtail_hpcdcchunker.c (Longtail_HPCDCNextChunk :225-310).
 // MI355X formulation:
 //   K1 buzhash_candidates : H(p) = XOR_{j<48} rotl(T[byte[p-1-j]], j) is a pure function of the 48 bytes before
-//                           p, so every position of every part is evaluated independently.  A 256-thread
-//                           workgroup stages a 16 KiB tile (+64 B halo) through LDS with coalesced 16-byte
-//                           loads; each thread rolls the hash over its own 64-byte run (window = 28 dwords
-//                           in VGPRs), looking T up in a 32x bank-replicated LDS copy (conflict-free), and
-//                           tests `H % d == d-1` with a multiply-add + rotate + compare.  Output is a two
-//                           level bitmap: level 0 one bit per byte (only non-zero words are stored), level 1
-//                           one bit per 64-byte run (wave ballot, always stored).
+//                           p, so every position of every part is evaluated independently.  ONE persistent
+//                           768-thread workgroup per CU (12 waves, 156 VGPRs, no scratch); each WAVE owns 4 KiB
+//                           wave-tiles end to end -- no workgroup barrier in the loop: the next tile is
+//                           prefetched into registers (coalesced 16-byte loads) while the current one is hashed
+//                           from the wave's private LDS rows (17-dword pitch, conflict-free); every lane rolls
+//                           the 48-byte window over its own 64-byte run.  T[256] is replicated 64x in LDS with
+//                           a 256-byte stride (one copy per lane): the LDS address of T[b] is {lane*4, b} =
+//                           ONE v_perm_b32 of the data dword, and lookups never conflict.  `H % d == d-1` is a
+//                           3-instruction necessary test on the odd part of d, the exact multiply-add + rotate
+//                           + compare only in the rare wave-uniform branch.  Output is a two level bitmap:
+//                           level 0 one bit per byte (only non-zero words are stored), level 1 one bit per
+//                           64-byte run (wave ballot, always stored).
 //   K2 select_cuts        : one wave per part walks chunk by chunk: wave-wide load of the level-1 words that
 //                           cover (start+min, start+max], first flagged run, one level-0 word, ffs.
 //   K3 compact            : scan of per-part counts, gather into dense (offset,len) arrays.

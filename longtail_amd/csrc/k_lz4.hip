@@ -5,18 +5,30 @@
 // 2016-2445).  The contract kept is the FORMAT one: every payload is one LZ4 block that the
 // reference decoder expands to the original bytes; the parse itself is re-designed for a GPU:
 //
-//   K5 lz4_segments  a stored block (<= 8.8 MiB) is cut into independent segments (default 32 KiB); one wave
-//                    compresses one segment out of LDS (segment bytes + a 4096 x u16 hash table).  All 64 lanes
-//                    probe 64 positions per step (hash of 4 bytes, single-probe table like lz4.c:777-783), the
-//                    first hit is extended forwards/backwards with wave ballots, and -- like the reference's
-//                    skip acceleration (lz4.c:1044-1053) -- the probe stride grows by one for every 64 misses,
-//                    so incompressible data costs ~45 steps per 64 KiB.  Sequences go to a per-segment stream.
-//   K6 lz4_stitch    per block: a serial walk over the segment results turns trailing literals of one segment
-//                    into leading literals of the next sequence (re-emitting its token / length bytes) and
-//                    assigns exact output offsets, honouring the end-of-block rules (last 5 bytes literal,
-//                    last match starts >= 12 bytes before the end; lz4.c:242-246, 2279-2329, 2421-2423); then
-//                    one workgroup per segment copies header, literals (from the source) and sequence body
-//                    (from the stream) into the single final block with 16-byte stores.
+//   K5 lz4_segments  a stored block (<= 8.8 MiB) is cut into 4 KiB UNITS; consecutive units form a window group that is staged
+//                    once into LDS and parsed by one workgroup, one wave per unit, each with a PRIVATE u16 hash table (results
+//                    do not depend on timing).  Two passes (launch_match_finder):
+//                      1. classification, batch geometry (8 units / 32 KiB, 1280-entry tables, 24 waves per CU): four probe
+//                         batches of 64 positions decide whether the group holds redundancy.  If not -- incompressible
+//                         data -- the same workgroup skims it (probe stride grows with the misses, lz4.c:1044-1053; units
+//                         without a match put their bytes where an all-literal block wants them); if so the 16-unit group is
+//                         put on a list and left alone.
+//                      2. lane parser (16 units / 64 KiB, 2560-entry tables, one persistent workgroup per CU) over the list:
+//                         every LANE owns a 64-byte sub-unit and runs the reference's greedy loop on it (probe; on a hit extend
+//                         forwards 36 bytes on its own -- longer ones with the whole wave -- and 8 backwards, record, jump;
+//                         else step 1 + misses / 4): 64 parsers in lock step, no selection among hits.  History enters the
+//                         table every 4th position (aligned dwords, one 16-byte read per four inserts); lanes map to
+//                         sub-units in reverse so that the lowest position survives a write conflict; matches may cross
+//                         sub-units, what they cover is dropped from the later lanes' records (prefix maximum); three wave
+//                         scans place the sequences and every lane writes its own bytes.
+//                    LTHIP_LZ4_PARSER=batch keeps the round-1 batch parser for everything (64 consecutive positions per step,
+//                    scalar selection among the hits).  Sequences go to a per-unit stream.
+//   K6 lz4_stitch    per block: three wave scans over the units' results (literal carry, output position, run count) turn
+//                    trailing literals of one unit into leading literals of the next sequence and assign exact output offsets,
+//                    honouring the end-of-block rules (last 5 bytes literal, last match starts >= 12 bytes before the end;
+//                    lz4.c:242-246, 2279-2329, 2421-2423); then one wave per unit, persistent over a work list, copies header,
+//                    literals (from the source) and sequence body (from the stream) into the single final block with 16-byte
+//                    stores.  Blocks without a single match were laid out by K5: only their header is written.
 //   decode           one wave per block, sequences parsed wave-uniformly, copies spread over the lanes.
 #include "lthip_internal.h"
 

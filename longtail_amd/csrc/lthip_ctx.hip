@@ -532,6 +532,7 @@ extern "C" int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const uint
     plan->chunk_cap = region;
     plan->total_bytes = bytes;
     plan->leaf_cap = leaves;
+    plan->capacity_bytes = bytes;
 
     hipError_t e = hipMalloc((void**)&plan->d_parts, sizeof(PartDev) * (part_count ? part_count : 1));
     if (e == hipSuccess)
@@ -553,6 +554,32 @@ extern "C" int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const uint
     }
     *out_plan = plan;
     return 0;
+}
+
+// A single-part plan sized once for a CAPACITY and re-aimed at the bytes actually present: what the plugin chunker needs (one
+// window of varying fill per refill) without two hipMalloc + a kernel + a synchronisation per file.  The tile -> part table of a
+// single part is all zeros whatever the size, so only the part descriptor and the host-side extents change.
+extern "C" int lthip_plan_resize_single(lthip_ctx* ctx, lthip_plan* plan, uint64_t size)
+{
+    if (!ctx || !plan || plan->nparts != 1)
+        return EINVAL;
+    if (size > plan->capacity_bytes)
+        return lthip_fail(ctx, EINVAL, "lthip_plan_resize_single", "size above the capacity the plan was created with");
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    PartDev pd;
+    memset(&pd, 0, sizeof pd);
+    pd.off = 0;
+    pd.size = size;
+    const uint64_t cap = size ? size / plan->min_chunk + 1 : 0;
+    pd.region_cap = (uint32_t)cap;
+    const uint64_t t = div_up_u64(size, 16384);
+    plan->ntiles = t;
+    plan->bm0_words = t * 256;
+    plan->bm1_words = t * 4;
+    plan->chunk_cap = cap;
+    plan->total_bytes = size;
+    plan->leaf_cap = div_up_u64(size, 1024) + cap;
+    return lthip_stage_upload(ctx, plan->d_parts, &pd, sizeof pd, ctx->stream);
 }
 
 extern "C" void lthip_plan_destroy(lthip_ctx* ctx, lthip_plan* plan)

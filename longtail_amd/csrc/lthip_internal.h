@@ -50,6 +50,7 @@ struct lthip_plan
     uint64_t bm0_words;
     uint64_t bm1_words;
     uint64_t leaf_cap;
+    uint64_t capacity_bytes; // bytes the plan was created for (lthip_plan_resize_single may aim it at fewer)
     PartDev* d_parts;
     uint32_t* d_tile_part;
 };

@@ -13,37 +13,27 @@
  * ranges.  A cut depends only on the chunk start and the next `max` bytes, so windows reproduce the
  * reference's stream semantics exactly: chunks that start less than `max` bytes before the end of a
  * non-final window are recomputed in the next window.
+ *
+ * Memory: a chunker owns no buffers.  It borrows a WINDOW (pinned host + device memory, result tables, a plan of the window's
+ * capacity) from the bounded pool of plugin_common.c when its stream starts -- a 2 MiB one; a stream that fills it moves to a
+ * 64 MiB one (= one reference part at target 65536, src/longtail.c:2396) -- and returns it when it is disposed.  However many
+ * chunkers longtail's job system keeps alive, pinned memory stays below the pool's cap (include/longtail_hip.h,
+ * Longtail_Hip_PinnedBytes).
  */
 #include "plugin_common.h"
 
-#define HIP_CHUNKER_WINDOW_BYTES (64u << 20) /* one reference part at target_chunk_size 65536 (src/longtail.c:2396) */
-#define HIP_CHUNKER_POOL 232                 /* HPCDCCHUNKER_MAX_CACHED_CHUNKER_COUNT, hpcdcchunker.c:102 */
+#define HIP_CHUNKER_POOL 232 /* HPCDCCHUNKER_MAX_CACHED_CHUNKER_COUNT, hpcdcchunker.c:102 (handles only: a few hundred bytes each) */
 
 struct HipChunker
 {
     uint32_t min, avg, max;
-    /* window */
-    uint8_t* h_win;   /* pinned */
-    void* d_win;
-    uint64_t cap;     /* bytes */
-    uint64_t have;    /* valid bytes in the window */
-    uint64_t base;    /* stream offset of window byte 0 */
+    struct ltp_chunk_window* w; /* borrowed while a stream is in progress */
+    uint64_t have;              /* valid bytes in the window */
+    uint64_t base;              /* stream offset of window byte 0 */
     int eof;
-    /* results of the current window */
-    uint64_t* d_off;
-    uint32_t* d_len;
-    uint64_t* d_hash;
-    uint32_t* d_first;
-    uint64_t* h_off;
-    uint32_t* h_len;
-    uint64_t* h_hash;
-    uint64_t ccap;
-    uint32_t ntotal, nfinal, next;
-    /* cached plan */
-    lthip_plan* plan;
-    uint64_t plan_size;
-    uint32_t plan_min, plan_avg, plan_max;
-    int slot; /* window registry slot */
+    uint32_t ntotal, nfinal, next; /* chunks of the current window: computed / final / handed out */
+    struct ltp_window pub;         /* what the HashAPI may look up */
+    int slot;                      /* window registry slot */
 };
 
 struct HipChunkerAPI
@@ -54,71 +44,32 @@ struct HipChunkerAPI
     uint32_t pool_count;
 };
 
-static void chunker_release_buffers(struct HipChunker* c)
+static uint32_t g_api_count; /* live HipChunkerAPI objects: the last one to go trims the window pool */
+
+static void chunker_unpublish(struct HipChunker* c)
 {
-    if (c->plan)
-        lthip_plan_destroy(0, c->plan); /* the creating thread (and its context) may be gone */
-    c->plan = 0;
-    lthip_free_pinned(0, c->h_win);
-    lthip_free_device(0, c->d_win);
-    lthip_free_device(0, c->d_off);
-    lthip_free_device(0, c->d_len);
-    lthip_free_device(0, c->d_hash);
-    lthip_free_device(0, c->d_first);
-    lthip_free_pinned(0, c->h_off);
-    lthip_free_pinned(0, c->h_len);
-    lthip_free_pinned(0, c->h_hash);
-    c->h_win = 0;
-    c->d_win = 0;
-    c->d_off = 0;
-    c->d_len = 0;
-    c->d_hash = 0;
-    c->d_first = 0;
-    c->h_off = 0;
-    c->h_len = 0;
-    c->h_hash = 0;
-    c->cap = 0;
-    c->ccap = 0;
+    memset(&c->pub, 0, sizeof c->pub);
+    ltp_window_publish(c->slot, &c->pub); /* ranges of the old window are no longer valid */
+    ltp_window_set_current(-1);
+}
+
+static void chunker_drop_window(struct HipChunker* c)
+{
+    if (c->w)
+    {
+        chunker_unpublish(c);
+        ltp_window_release(c->w);
+        c->w = 0;
+    }
 }
 
 static void chunker_free(struct HipChunker* c)
 {
     if (!c)
         return;
+    chunker_drop_window(c);
     ltp_window_unregister(c->slot);
-    chunker_release_buffers(c);
     ltp_free(c);
-}
-
-static int chunker_reserve(struct HipChunker* c, lthip_ctx* ctx)
-{
-    uint64_t cap = HIP_CHUNKER_WINDOW_BYTES;
-    if (cap < (uint64_t)c->max * 4u)
-        cap = (uint64_t)c->max * 4u; /* the reference buffers 4*max (hpcdcchunker.c:148) */
-    if (cap > 0xF0000000ull)
-        cap = 0xF0000000ull;
-    const uint64_t ccap = cap / c->min + 2;
-    if (c->cap >= cap && c->ccap >= ccap)
-        return 0;
-    chunker_release_buffers(c);
-    int err = 0;
-    if (!err) err = lthip_malloc_pinned(ctx, cap, (void**)&c->h_win);
-    if (!err) err = lthip_malloc_device(ctx, cap + 64, &c->d_win);
-    if (!err) err = lthip_malloc_device(ctx, ccap * 8, (void**)&c->d_off);
-    if (!err) err = lthip_malloc_device(ctx, ccap * 4, (void**)&c->d_len);
-    if (!err) err = lthip_malloc_device(ctx, ccap * 8, (void**)&c->d_hash);
-    if (!err) err = lthip_malloc_device(ctx, 16, (void**)&c->d_first);
-    if (!err) err = lthip_malloc_pinned(ctx, ccap * 8, (void**)&c->h_off);
-    if (!err) err = lthip_malloc_pinned(ctx, ccap * 4, (void**)&c->h_len);
-    if (!err) err = lthip_malloc_pinned(ctx, ccap * 8, (void**)&c->h_hash);
-    if (err)
-    {
-        chunker_release_buffers(c);
-        return err;
-    }
-    c->cap = cap;
-    c->ccap = ccap;
-    return 0;
 }
 
 /* fill the window from the feeder and run the GPU over it */
@@ -127,67 +78,69 @@ static int chunker_refill(struct HipChunker* c, Longtail_Chunker_Feeder feeder, 
     lthip_ctx* ctx = ltp_thread_ctx();
     if (!ctx)
         return ENODEV;
-    int err = chunker_reserve(c, ctx);
-    if (err)
-        return err;
+    int err = 0;
+    const uint64_t need_min = (uint64_t)c->max * 4u; /* the reference buffers 4 * max (hpcdcchunker.c:148) */
+    if (!c->w)
+    {
+        c->w = ltp_window_acquire(ctx, need_min > LTP_WINDOW_SMALL ? need_min : LTP_WINDOW_SMALL, c->min, c->avg, c->max, &err);
+        if (!c->w)
+            return err ? err : ENOMEM;
+    }
+    struct ltp_chunk_window* w = c->w;
 
     /* keep the bytes whose chunking is not final yet */
-    const uint64_t keep_from = c->nfinal < c->ntotal ? c->h_off[c->nfinal] : c->have;
-    {
-        struct ltp_window none;
-        memset(&none, 0, sizeof none);
-        ltp_window_publish(c->slot, &none); /* ranges of the old window are no longer valid */
-    }
+    const uint64_t keep_from = c->nfinal < c->ntotal ? w->h_off[c->nfinal] : c->have;
+    chunker_unpublish(c);
     if (keep_from < c->have && keep_from > 0)
-        memmove(c->h_win, c->h_win + keep_from, (size_t)(c->have - keep_from));
+        memmove(w->h_win, w->h_win + keep_from, (size_t)(c->have - keep_from));
     c->base += keep_from;
     c->have -= keep_from;
     c->ntotal = c->nfinal = c->next = 0;
 
-    while (c->have < c->cap && !c->eof)
+    for (;;)
     {
-        uint64_t want = c->cap - c->have;
-        if (want > 0x7FFFFFFFu)
-            want = 0x7FFFFFFFu;
-        uint32_t got = 0;
-        err = feeder(feeder_context, (Longtail_ChunkerAPI_HChunker)c, (uint32_t)want, (char*)c->h_win + c->have, &got);
-        if (err)
+        while (c->have < w->cap && !c->eof)
         {
-            *feeder_failed = 1;
-            return err;
+            uint64_t want = w->cap - c->have;
+            if (want > 0x7FFFFFFFu)
+                want = 0x7FFFFFFFu;
+            uint32_t got = 0;
+            err = feeder(feeder_context, (Longtail_ChunkerAPI_HChunker)c, (uint32_t)want, (char*)w->h_win + c->have, &got);
+            if (err)
+            {
+                *feeder_failed = 1;
+                return err;
+            }
+            if (got == 0)
+                c->eof = 1;
+            c->have += got;
         }
-        if (got == 0)
-            c->eof = 1;
-        c->have += got;
+        if (c->eof || w->cls != 0)
+            break;
+        /* the small window is full and the stream goes on: move to a large one (its bytes come along) */
+        struct ltp_chunk_window* big = ltp_window_acquire(ctx, (uint64_t)LTP_WINDOW_SMALL + 1u, c->min, c->avg, c->max, &err);
+        if (!big)
+            return err ? err : ENOMEM;
+        memcpy(big->h_win, w->h_win, (size_t)c->have);
+        ltp_window_release(w);
+        c->w = w = big;
     }
     if (c->have == 0)
         return 0;
 
-    if (!c->plan || c->plan_size != c->have || c->plan_min != c->min || c->plan_avg != c->avg || c->plan_max != c->max)
-    {
-        if (c->plan)
-            lthip_plan_destroy(0, c->plan);
-        c->plan = 0;
-        const uint64_t off0 = 0, sz = c->have;
-        err = lthip_plan_create(ctx, 1, &off0, &sz, c->min, c->avg, c->max, &c->plan);
-        if (err)
-            return err;
-        c->plan_size = c->have;
-        c->plan_min = c->min;
-        c->plan_avg = c->avg;
-        c->plan_max = c->max;
-    }
     uint64_t total = 0;
-    err = lthip_copy_h2d(ctx, c->d_win, c->h_win, (size_t)c->have);
+    err = lthip_plan_resize_single(ctx, w->plan, c->have);
     if (!err)
-        err = lthip_chunk_hash(ctx, c->plan, c->d_win, c->d_off, c->d_len, c->d_hash, c->d_first, &total);
+        err = lthip_copy_h2d(ctx, w->d_win, w->h_win, (size_t)c->have);
+    if (!err)
+        err = lthip_chunk_hash(ctx, w->plan, w->d_win, w->d_off, w->d_len, w->d_hash, w->d_first, &total);
     if (err)
         return err;
-    if (total > c->ccap)
+    if (total > w->ccap)
         return EIO;
-    err = lthip_copy_d2h(ctx, c->h_off, c->d_off, (size_t)total * 8);
-    if (!err) err = lthip_copy_d2h(ctx, c->h_len, c->d_len, (size_t)total * 4);
-    if (!err) err = lthip_copy_d2h(ctx, c->h_hash, c->d_hash, (size_t)total * 8);
+    err = lthip_copy_d2h(ctx, w->h_off, w->d_off, (size_t)total * 8);
+    if (!err) err = lthip_copy_d2h(ctx, w->h_len, w->d_len, (size_t)total * 4);
+    if (!err) err = lthip_copy_d2h(ctx, w->h_hash, w->d_hash, (size_t)total * 8);
     if (!err) err = lthip_ctx_sync(ctx);
     if (err)
         return err;
@@ -198,18 +151,20 @@ static int chunker_refill(struct HipChunker* c, Longtail_Chunker_Feeder feeder, 
     {
         /* a cut decision looks at most `max` bytes ahead of the chunk start */
         uint32_t n = 0;
-        while (n < c->ntotal && c->h_off[n] + c->max <= c->have)
+        while (n < c->ntotal && w->h_off[n] + c->max <= c->have)
             ++n;
         c->nfinal = n;
+        if (n == 0)
+            return EIO; /* cannot happen while the window holds 4 * max bytes: never hand out an early end of stream instead */
     }
-    struct ltp_window w;
-    w.base = c->h_win;
-    w.size = c->have;
-    w.offsets = c->h_off;
-    w.lens = c->h_len;
-    w.hashes = c->h_hash;
-    w.count = c->nfinal;
-    ltp_window_publish(c->slot, &w);
+    c->pub.base = w->h_win;
+    c->pub.size = c->have;
+    c->pub.offsets = w->h_off;
+    c->pub.lens = w->h_len;
+    c->pub.hashes = w->h_hash;
+    c->pub.count = c->nfinal;
+    ltp_window_publish(c->slot, &c->pub);
+    ltp_window_set_current(c->slot);
     return 0;
 }
 
@@ -227,6 +182,8 @@ static void HipChunker_Dispose(struct Longtail_API* base_api)
     pthread_mutex_unlock(&api->lock);
     pthread_mutex_destroy(&api->lock);
     ltp_free(api);
+    if (__atomic_sub_fetch(&g_api_count, 1, __ATOMIC_ACQ_REL) == 0)
+        ltp_window_pool_trim();
 }
 
 static int HipChunker_GetMinChunkSize(struct Longtail_ChunkerAPI* chunker_api, uint32_t* out_min_chunk_size)
@@ -245,6 +202,10 @@ static int HipChunker_CreateChunker(struct Longtail_ChunkerAPI* chunker_api, uin
         return EINVAL;
     /* hpcdcchunker.c:143-146 */
     if (min_chunk_size < 48u || min_chunk_size > avg_chunk_size || avg_chunk_size > max_chunk_size)
+        return EINVAL;
+    /* a window holds 4 * max bytes and a part handed to the kernels is below 4 GiB: larger maxima cannot be served (the reference's
+     * own buffer arithmetic is 32-bit as well, hpcdcchunker.c:148-171) */
+    if ((uint64_t)max_chunk_size * 4u > 0xF0000000ull)
         return EINVAL;
     struct HipChunkerAPI* api = (struct HipChunkerAPI*)chunker_api;
     struct HipChunker* c = 0;
@@ -301,9 +262,9 @@ static int HipChunker_NextChunk(struct Longtail_ChunkerAPI* chunker_api, Longtai
         return ESPIPE;
     }
     const uint32_t i = c->next++;
-    out_chunk_range->buf = c->h_win + c->h_off[i];
-    out_chunk_range->offset = c->base + c->h_off[i];
-    out_chunk_range->len = c->h_len[i];
+    out_chunk_range->buf = c->w->h_win + c->w->h_off[i];
+    out_chunk_range->offset = c->base + c->w->h_off[i];
+    out_chunk_range->len = c->w->h_len[i];
     return 0;
 }
 
@@ -313,9 +274,7 @@ static int HipChunker_DisposeChunker(struct Longtail_ChunkerAPI* chunker_api, Lo
         return EINVAL;
     struct HipChunkerAPI* api = (struct HipChunkerAPI*)chunker_api;
     struct HipChunker* c = (struct HipChunker*)chunker;
-    struct ltp_window none;
-    memset(&none, 0, sizeof none);
-    ltp_window_publish(c->slot, &none);
+    chunker_drop_window(c); /* the window goes back to the pool at once: only the handle is cached */
     pthread_mutex_lock(&api->lock);
     if (api->pool_count < HIP_CHUNKER_POOL)
     {
@@ -370,5 +329,6 @@ struct Longtail_ChunkerAPI* Longtail_CreateHipChunkerAPI(void)
     api->api.DisposeChunker = HipChunker_DisposeChunker;
     api->api.NextChunkFromBuffer = HipChunker_NextChunkFromBuffer;
     pthread_mutex_init(&api->lock, 0);
+    __atomic_add_fetch(&g_api_count, 1, __ATOMIC_ACQ_REL);
     return &api->api;
 }

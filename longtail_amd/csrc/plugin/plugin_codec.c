@@ -34,7 +34,11 @@ static size_t HipCodec_GetMaxCompressedSize(struct Longtail_CompressionAPI* comp
     return a->codec == CODEC_LZ4 ? lthip_lz4_bound(size) : lthip_zstd_bound(size);
 }
 
-/* one block through the bulk API: host -> device -> kernels -> host */
+/* One block through the bulk API: host -> pinned staging -> device -> kernels -> pinned staging -> host.  The caller's buffers
+ * are pageable (`compressed` is &header[2] of a Longtail_Alloc block, compressblockstore.c:117-125); copying them through the
+ * calling thread's own pinned buffers keeps the DMA engine at full rate and lets the 32..256 bikeshed workers that call Compress
+ * concurrently (one context + stream each) overlap their copies and kernels.  Two synchronisations per call: the payload size
+ * has to be known before the payload is fetched. */
 static int run_block(int codec, int decompress, const char* src, char* dst, size_t n, size_t cap, size_t* out_n)
 {
     struct ltp_thread_state* ts = ltp_thread_state_get();
@@ -49,11 +53,17 @@ static int run_block(int codec, int decompress, const char* src, char* dst, size
     if (!err)
         err = ltp_dev_reserve(ctx, &ts->d_aux, 64);
     if (!err)
-        err = ltp_pin_reserve(ctx, &ts->h_pin, 64);
-    if (!err && n)
-        err = lthip_copy_h2d(ctx, ts->d_in.p, src, n);
+        err = ltp_pin_reserve(ctx, &ts->h_pin, 64 + (n > cap ? n : cap));
     if (err)
         return err;
+    uint8_t* stage = (uint8_t*)ts->h_pin.p + 64;
+    if (n)
+    {
+        memcpy(stage, src, n);
+        err = lthip_copy_h2d(ctx, ts->d_in.p, stage, n);
+        if (err)
+            return err;
+    }
     const uint64_t zero = 0;
     const uint32_t sz = (uint32_t)n, dcap = (uint32_t)cap;
     if (decompress && codec == CODEC_ZSTD)
@@ -68,7 +78,7 @@ static int run_block(int codec, int decompress, const char* src, char* dst, size
     if (!err)
         err = lthip_copy_d2h(ctx, h_size, ts->d_aux.p, 4);
     if (!err)
-        err = lthip_ctx_sync(ctx);
+        err = lthip_ctx_sync(ctx); /* the input staging is free again from here on */
     if (err)
         return err;
     const uint32_t produced = *h_size;
@@ -83,9 +93,11 @@ static int run_block(int codec, int decompress, const char* src, char* dst, size
         return EIO;
     if (produced)
     {
-        err = lthip_copy_d2h(ctx, dst, ts->d_out.p, produced);
+        err = lthip_copy_d2h(ctx, stage, ts->d_out.p, produced);
         if (!err)
             err = lthip_ctx_sync(ctx);
+        if (!err)
+            memcpy(dst, stage, produced);
     }
     if (!err)
         *out_n = produced;

@@ -31,24 +31,46 @@ void ltp_free(void* p)
 /* ---------------------------------------------------------------------------------------------------
  * device selection + per-thread context
  * ------------------------------------------------------------------------------------------------- */
-static int g_device = -1;
+static int g_device = -1; /* read and written with atomics: plugin objects are created from any thread */
 
 int Longtail_Hip_SetDevice(int device)
 {
     if (device < 0 || device >= lthip_device_count())
         return EINVAL;
-    g_device = device;
+    __atomic_store_n(&g_device, device, __ATOMIC_RELEASE);
     return 0;
 }
 
 int ltp_device(void)
 {
-    if (g_device < 0)
+    int d = __atomic_load_n(&g_device, __ATOMIC_ACQUIRE);
+    if (d < 0)
     {
         const char* e = getenv("LONGTAIL_HIP_DEVICE");
-        g_device = e ? atoi(e) : 0;
+        int want = e ? atoi(e) : 0;
+        int expected = -1;
+        __atomic_compare_exchange_n(&g_device, &expected, want, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+        d = __atomic_load_n(&g_device, __ATOMIC_ACQUIRE);
     }
-    return g_device;
+    return d;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * error latch
+ * ------------------------------------------------------------------------------------------------- */
+static __thread int t_last_error;
+
+void ltp_latch_error(int err)
+{
+    if (err && !t_last_error)
+        t_last_error = err;
+}
+
+int Longtail_Hip_GetLastError(void)
+{
+    const int e = t_last_error;
+    t_last_error = 0;
+    return e;
 }
 
 static pthread_key_t g_key;
@@ -176,9 +198,39 @@ void ltp_window_unregister(int slot)
     pthread_rwlock_unlock(&g_win_lock);
 }
 
+/* points into g_windows (static storage): a stale pointer can at worst see another chunker's published window, whose digests are
+ * correct for the memory they describe */
+static __thread const struct ltp_window* t_current_window;
+
+void ltp_window_set_current(int slot) { t_current_window = slot >= 0 ? &g_windows[slot] : 0; }
+
+static int window_find(const struct ltp_window* w, const uint8_t* p, uint32_t len, uint64_t* out_hash)
+{
+    const uint64_t rel = (uint64_t)(p - w->base);
+    uint32_t lo = 0, hi = w->count;
+    while (lo < hi)
+    {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (w->offsets[mid] < rel)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if (lo < w->count && w->offsets[lo] == rel && w->lens[lo] == len)
+    {
+        *out_hash = w->hashes[lo];
+        return 1;
+    }
+    return 0;
+}
+
 int ltp_window_lookup(const void* data, uint32_t len, uint64_t* out_hash)
 {
     const uint8_t* p = (const uint8_t*)data;
+    /* the calling thread's own chunker first: no lock, no scan (the common case by far, src/longtail.c:2231-2296) */
+    const struct ltp_window* cur = t_current_window;
+    if (cur && cur->base && p >= cur->base && p < cur->base + cur->size)
+        return window_find(cur, p, len, out_hash);
     int found = 0;
     pthread_rwlock_rdlock(&g_win_lock);
     for (int i = 0; i < g_window_high && !found; ++i)
@@ -206,3 +258,204 @@ int ltp_window_lookup(const void* data, uint32_t len, uint64_t* out_hash)
     pthread_rwlock_unlock(&g_win_lock);
     return found;
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * window pool
+ * ------------------------------------------------------------------------------------------------- */
+static pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_pool_cond = PTHREAD_COND_INITIALIZER;
+static struct ltp_chunk_window* g_pool_free[2];
+static uint32_t g_pool_alive[2]; /* windows of the class in existence (idle + handed out) */
+static uint64_t g_pool_pinned;   /* bytes of pinned memory held by windows */
+
+static uint32_t pool_cap(int cls)
+{
+    static uint32_t caps[2];
+    if (!caps[cls])
+    {
+        const char* e = getenv(cls ? "LONGTAIL_HIP_LARGE_WINDOWS" : "LONGTAIL_HIP_SMALL_WINDOWS");
+        int v = e ? atoi(e) : 0;
+        caps[cls] = v > 0 ? (uint32_t)v : (cls ? 32u : 256u);
+    }
+    return caps[cls];
+}
+
+static void window_destroy(struct ltp_chunk_window* w)
+{
+    if (!w)
+        return;
+    if (w->plan)
+        lthip_plan_destroy(0, w->plan);
+    lthip_free_pinned(0, w->h_win);
+    lthip_free_device(0, w->d_win);
+    lthip_free_device(0, w->d_off);
+    lthip_free_device(0, w->d_len);
+    lthip_free_device(0, w->d_hash);
+    lthip_free_device(0, w->d_first);
+    lthip_free_pinned(0, w->h_off);
+    lthip_free_pinned(0, w->h_len);
+    lthip_free_pinned(0, w->h_hash);
+    free(w);
+}
+
+static uint64_t window_pinned_bytes(const struct ltp_chunk_window* w) { return w->cap + w->ccap * 20u; }
+
+static struct ltp_chunk_window* window_create(lthip_ctx* ctx, uint64_t cap, uint32_t min_chunk, uint32_t avg_chunk, uint32_t max_chunk, int cls,
+                                              int* out_err)
+{
+    struct ltp_chunk_window* w = (struct ltp_chunk_window*)calloc(1, sizeof *w);
+    if (!w)
+    {
+        *out_err = ENOMEM;
+        return 0;
+    }
+    /* result tables for the smallest chunks the API allows (48 bytes, hpcdcchunker.c:143) would be a third of the window: size them
+     * for this chunker's minimum and rebuild them when a later user of the window needs more */
+    const uint64_t ccap = cap / min_chunk + 2;
+    int err = 0;
+    if (!err) err = lthip_malloc_pinned(ctx, cap, (void**)&w->h_win);
+    if (!err) err = lthip_malloc_device(ctx, cap + 64, &w->d_win);
+    if (!err) err = lthip_malloc_device(ctx, ccap * 8, (void**)&w->d_off);
+    if (!err) err = lthip_malloc_device(ctx, ccap * 4, (void**)&w->d_len);
+    if (!err) err = lthip_malloc_device(ctx, ccap * 8, (void**)&w->d_hash);
+    if (!err) err = lthip_malloc_device(ctx, 16, (void**)&w->d_first);
+    if (!err) err = lthip_malloc_pinned(ctx, ccap * 8, (void**)&w->h_off);
+    if (!err) err = lthip_malloc_pinned(ctx, ccap * 4, (void**)&w->h_len);
+    if (!err) err = lthip_malloc_pinned(ctx, ccap * 8, (void**)&w->h_hash);
+    if (!err)
+    {
+        const uint64_t off0 = 0;
+        err = lthip_plan_create(ctx, 1, &off0, &cap, min_chunk, avg_chunk, max_chunk, &w->plan);
+    }
+    if (err)
+    {
+        window_destroy(w);
+        *out_err = err;
+        return 0;
+    }
+    w->cap = cap;
+    w->ccap = ccap;
+    w->min_chunk = min_chunk;
+    w->avg_chunk = avg_chunk;
+    w->max_chunk = max_chunk;
+    w->cls = cls;
+    return w;
+}
+
+struct ltp_chunk_window* ltp_window_acquire(lthip_ctx* ctx, uint64_t bytes, uint32_t min_chunk, uint32_t avg_chunk, uint32_t max_chunk, int* out_err)
+{
+    *out_err = 0;
+    if (bytes > LTP_WINDOW_LARGE)
+    {
+        struct ltp_chunk_window* w = window_create(ctx, bytes, min_chunk, avg_chunk, max_chunk, 2, out_err);
+        if (w)
+        {
+            pthread_mutex_lock(&g_pool_lock);
+            g_pool_pinned += window_pinned_bytes(w);
+            pthread_mutex_unlock(&g_pool_lock);
+        }
+        return w;
+    }
+    const int cls = bytes > LTP_WINDOW_SMALL ? 1 : 0;
+    const uint64_t cap = cls ? LTP_WINDOW_LARGE : LTP_WINDOW_SMALL;
+    struct ltp_chunk_window* w = 0;
+    int create = 0;
+    pthread_mutex_lock(&g_pool_lock);
+    for (;;)
+    {
+        /* an idle window made for the same chunk parameters (the plan holds the discriminator and the table capacities) */
+        struct ltp_chunk_window** pp = &g_pool_free[cls];
+        while (*pp && !((*pp)->min_chunk == min_chunk && (*pp)->avg_chunk == avg_chunk && (*pp)->max_chunk == max_chunk))
+            pp = &(*pp)->next;
+        if (*pp)
+        {
+            w = *pp;
+            *pp = w->next;
+            w->next = 0;
+            break;
+        }
+        if (g_pool_alive[cls] < pool_cap(cls))
+        {
+            ++g_pool_alive[cls];
+            create = 1;
+            break;
+        }
+        if (g_pool_free[cls])
+        {
+            /* at the cap, but an idle window with other parameters exists: replace it */
+            struct ltp_chunk_window* victim = g_pool_free[cls];
+            g_pool_free[cls] = victim->next;
+            g_pool_pinned -= window_pinned_bytes(victim);
+            pthread_mutex_unlock(&g_pool_lock);
+            window_destroy(victim);
+            pthread_mutex_lock(&g_pool_lock);
+            create = 1;
+            break;
+        }
+        pthread_cond_wait(&g_pool_cond, &g_pool_lock);
+    }
+    pthread_mutex_unlock(&g_pool_lock);
+    if (create)
+    {
+        w = window_create(ctx, cap, min_chunk, avg_chunk, max_chunk, cls, out_err);
+        pthread_mutex_lock(&g_pool_lock);
+        if (w)
+            g_pool_pinned += window_pinned_bytes(w);
+        else
+        {
+            --g_pool_alive[cls];
+            pthread_cond_signal(&g_pool_cond);
+        }
+        pthread_mutex_unlock(&g_pool_lock);
+    }
+    return w;
+}
+
+void ltp_window_release(struct ltp_chunk_window* w)
+{
+    if (!w)
+        return;
+    if (w->cls == 2)
+    {
+        pthread_mutex_lock(&g_pool_lock);
+        g_pool_pinned -= window_pinned_bytes(w);
+        pthread_mutex_unlock(&g_pool_lock);
+        window_destroy(w);
+        return;
+    }
+    pthread_mutex_lock(&g_pool_lock);
+    w->next = g_pool_free[w->cls];
+    g_pool_free[w->cls] = w;
+    pthread_cond_signal(&g_pool_cond);
+    pthread_mutex_unlock(&g_pool_lock);
+}
+
+void ltp_window_pool_trim(void)
+{
+    for (int cls = 0; cls < 2; ++cls)
+        for (;;)
+        {
+            pthread_mutex_lock(&g_pool_lock);
+            struct ltp_chunk_window* w = g_pool_free[cls];
+            if (w)
+            {
+                g_pool_free[cls] = w->next;
+                --g_pool_alive[cls];
+                g_pool_pinned -= window_pinned_bytes(w);
+            }
+            pthread_mutex_unlock(&g_pool_lock);
+            if (!w)
+                break;
+            window_destroy(w);
+        }
+}
+
+uint64_t ltp_window_pool_pinned_bytes(void)
+{
+    pthread_mutex_lock(&g_pool_lock);
+    const uint64_t v = g_pool_pinned;
+    pthread_mutex_unlock(&g_pool_lock);
+    return v;
+}
+
+uint64_t Longtail_Hip_PinnedBytes(void) { return ltp_window_pool_pinned_bytes(); }

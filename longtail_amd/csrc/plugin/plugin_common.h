@@ -53,5 +53,44 @@ void ltp_window_publish(int slot, const struct ltp_window* w);
 void ltp_window_unregister(int slot);
 /* returns 1 and the digest when (data,len) is exactly a chunk of a published window */
 int ltp_window_lookup(const void* data, uint32_t len, uint64_t* out_hash);
+/* The window the CALLING thread's chunker handed ranges out of last (DynamicChunking calls NextChunk and HashBuffer alternately on
+ * one thread, src/longtail.c:2231-2296): looked at first, without any lock.  -1 clears it. */
+void ltp_window_set_current(int slot);
+
+/* ---- bounded pool of chunker windows: pinned host window + device window + result tables + a plan of that capacity ----
+ * Two size classes (LTP_WINDOW_SMALL / LTP_WINDOW_LARGE bytes); the number of windows alive per class is capped
+ * (LONGTAIL_HIP_SMALL_WINDOWS, default 256; LONGTAIL_HIP_LARGE_WINDOWS, default 32: at most 0.5 + 2 GiB of pinned memory and as
+ * much HBM), a thread that needs one beyond the cap waits for a release.  Windows that do not fit a class (4 * max_chunk above the
+ * large size) are allocated for their chunker alone and freed with it. */
+#define LTP_WINDOW_SMALL (2u << 20)
+#define LTP_WINDOW_LARGE (64u << 20) /* one reference part at target_chunk_size 65536 (src/longtail.c:2396) */
+struct ltp_chunk_window
+{
+    uint8_t* h_win; /* pinned */
+    void* d_win;
+    uint64_t cap;   /* bytes */
+    uint64_t ccap;  /* chunk slots of the result tables */
+    uint32_t min_chunk; /* the chunk parameters the plan was made for */
+    uint32_t avg_chunk, max_chunk;
+    uint64_t* d_off;
+    uint32_t* d_len;
+    uint64_t* d_hash;
+    uint32_t* d_first;
+    uint64_t* h_off; /* pinned */
+    uint32_t* h_len;
+    uint64_t* h_hash;
+    lthip_plan* plan; /* one part of `cap` bytes, re-aimed per refill (lthip_plan_resize_single) */
+    int cls;          /* 0 small, 1 large, 2 private */
+    struct ltp_chunk_window* next;
+};
+/* a window of at least `bytes` for chunks of (min, avg, max); blocks while the class is at its cap; 0 + *err on failure */
+struct ltp_chunk_window* ltp_window_acquire(lthip_ctx* ctx, uint64_t bytes, uint32_t min_chunk, uint32_t avg_chunk, uint32_t max_chunk, int* err);
+void ltp_window_release(struct ltp_chunk_window* w);
+void ltp_window_pool_trim(void); /* frees the idle windows (called when the last HIP ChunkerAPI is disposed) */
+uint64_t ltp_window_pool_pinned_bytes(void);
+
+/* ---- error latch: void / value-returning entry points of the plugin structs (HashAPI.Hash, EndContext) cannot report failure;
+ * the first errno of such a call on a thread is kept until read.  Exported as Longtail_Hip_GetLastError(). ---- */
+void ltp_latch_error(int err);
 
 #endif

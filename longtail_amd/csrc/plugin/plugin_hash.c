@@ -26,6 +26,7 @@ struct HipHashContext
     uint8_t* data;
     uint64_t size;
     uint64_t cap;
+    int err; /* first failure of a Hash() call on this context: EndContext reports it through the error latch */
 };
 
 static int gpu_hash(const void* data, uint32_t length, uint64_t* out_hash)
@@ -84,7 +85,7 @@ static void HipHash_Hash(struct Longtail_HashAPI* hash_api, Longtail_HashAPI_HCo
                          const void* data)
 {
     struct HipHashContext* c = (struct HipHashContext*)context;
-    if (!hash_api || !c || !length || !data)
+    if (!hash_api || !c || !length || !data || c->err)
         return;
     if (c->size + length > c->cap)
     {
@@ -93,7 +94,13 @@ static void HipHash_Hash(struct Longtail_HashAPI* hash_api, Longtail_HashAPI_HCo
             cap *= 2;
         uint8_t* n = (uint8_t*)ltp_alloc("HipHash_Hash", (size_t)cap);
         if (!n)
-            return; /* void function in the reference ABI as well */
+        {
+            /* a void function in the ABI (src/longtail.h:205): the failure is remembered and surfaces at EndContext, which then
+             * returns 0 and latches ENOMEM (Longtail_Hip_GetLastError) instead of the digest of a truncated stream */
+            c->err = ENOMEM;
+            ltp_latch_error(ENOMEM);
+            return;
+        }
         if (c->size)
             memcpy(n, c->data, (size_t)c->size);
         ltp_free(c->data);
@@ -110,8 +117,16 @@ static uint64_t HipHash_EndContext(struct Longtail_HashAPI* hash_api, Longtail_H
     uint64_t h = 0;
     if (!hash_api || !c)
         return 0;
-    if (c->size <= 0xFFFFFFFFull)
-        (void)gpu_hash(c->data, (uint32_t)c->size, &h);
+    int err = c->err;
+    if (!err && c->size > 0xFFFFFFFFull)
+        err = EFBIG; /* one BLAKE3 input of the kernels is below 4 GiB (HashBuffer's length is a uint32_t as well, src/longtail.h:207) */
+    if (!err)
+        err = gpu_hash(c->data, (uint32_t)c->size, &h);
+    if (err)
+    {
+        ltp_latch_error(err);
+        h = 0;
+    }
     ltp_free(c->data);
     ltp_free(c);
     return h;

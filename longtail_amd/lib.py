@@ -80,6 +80,8 @@ class HipLib:
         sig("Longtail_CompressionRegistry_CreateForHipZstd", vp, [u32, P(u32)])
         sig("Longtail_Hip_SetAllocator", None, [vp, vp])
         sig("Longtail_Hip_SetDevice", i32, [i32])
+        sig("Longtail_Hip_GetLastError", i32, [])
+        sig("Longtail_Hip_PinnedBytes", u64, [])
         # --- bulk API ---
         sig("lthip_ctx_create", i32, [i32, vp, P(vp)])
         sig("lthip_ctx_destroy", None, [vp])
@@ -98,6 +100,7 @@ class HipLib:
         sig("lthip_timing_get", i32, [vp, i32, P(C.c_double), P(u64)])
         sig("lthip_plan_create", i32, [vp, u32, vp, vp, u32, u32, u32, P(vp)])
         sig("lthip_plan_destroy", None, [vp, vp])
+        sig("lthip_plan_resize_single", i32, [vp, vp, u64])
         sig("lthip_plan_chunk_capacity", u64, [vp])
         sig("lthip_chunk_hash", i32, [vp, vp, vp, vp, vp, vp, vp, P(u64)])
         sig("lthip_chunk_from_buffer", i32, [vp, vp, u64, u32, u32, u32, P(u64)])
