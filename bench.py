@@ -261,10 +261,17 @@ class Bench:
                 tfiles = sorted((ROOT / "profiles").glob("*pmc_traffic*.json"))
                 tj = json.load(open(tfiles[-1]))
                 names = {"buzhash": "k_buzhash_candidates<0>", "blake3_leaf": "k_blake3_leaves", "lz4_segments": "k_lz4_segments<"}
-                if dom == "lz4_segments" and cfg["codec"] != "lz4":
-                    raise KeyError("no PMC pass for the sequence-output variant of the match finder")
-                key = next(k for k in tj["kernels"] if k.startswith(names[dom]) and (dom != "lz4_segments" or k.endswith(", 0>")))
-                ratio = tj["kernels"][key]["corrected_per_input_byte"]
+
+                def fmt_of(k):  # k_lz4_segments<G, TAB, FMT, MODE, CLS>: the LZ4 flavours have FMT 0
+                    args = k[k.index("<") + 1 : k.rindex(">")].split(",")
+                    return int(args[2]) if len(args) >= 3 else int(args[-1])
+
+                want_fmt = 0 if cfg["codec"] == "lz4" else 1
+                keys = [k for k in tj["kernels"] if k.startswith(names[dom]) and (dom != "lz4_segments" or fmt_of(k) == want_fmt)]
+                if not keys:
+                    raise KeyError(dom)
+                # the match finder is two kernels (classification pass + lane parser) under one timer: their traffic adds up
+                ratio = round(sum(tj["kernels"][k]["corrected_per_input_byte"] for k in keys), 4)
                 roofline["traffic"] = int(ratio * my_bytes / launches)
                 roofline["traffic_source"] = f"profiles/{tfiles[-1].name}: {ratio} HBM bytes per input byte (2*FETCH_SIZE+WRITE_SIZE)"
             except Exception:

@@ -1,0 +1,202 @@
+/* mock_lthip.c -- TEST INFRASTRUCTURE: a CPU stand-in for the lthip_* device API, built ONLY into tests/san/plugin_san (the
+ * AddressSanitizer / UBSan run of the plain-C plugin layer, which cannot run in a sanitized process on a GPU-less container
+ * otherwise).  "Device memory" is host memory, the kernels are the oracle's C restatement.  Nothing here is part of the
+ * product: liblongtail_hip.so never links it (tests/test_abi.py checks the product for oracle references). */
+#include "../../include/longtail_hip.h"
+#include "../../oracle/oracle.h"
+
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+
+int ltz_model_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n);
+int ltz_model_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n);
+
+struct lthip_ctx
+{
+    int dummy;
+};
+struct lthip_plan
+{
+    uint64_t capacity, size;
+    uint32_t min, avg, max;
+};
+
+static int g_fail_alloc_after = -1; /* fault injection: the n-th allocation from now fails */
+void mock_fail_alloc_after(int n) { g_fail_alloc_after = n; }
+static int alloc_fails(void)
+{
+    if (g_fail_alloc_after < 0)
+        return 0;
+    if (g_fail_alloc_after-- == 0)
+        return 1;
+    return 0;
+}
+
+int lthip_device_count(void) { return 1; }
+int lthip_ctx_create(int device, void* s, lthip_ctx** out)
+{
+    (void)device;
+    (void)s;
+    *out = (lthip_ctx*)calloc(1, sizeof(lthip_ctx));
+    return *out ? 0 : ENOMEM;
+}
+void lthip_ctx_destroy(lthip_ctx* c) { free(c); }
+int lthip_ctx_sync(lthip_ctx* c) { return c ? 0 : EINVAL; }
+const char* lthip_ctx_error(const lthip_ctx* c)
+{
+    (void)c;
+    return "";
+}
+int lthip_malloc_device(lthip_ctx* c, size_t n, void** out)
+{
+    (void)c;
+    if (alloc_fails())
+        return ENOMEM;
+    *out = malloc(n ? n : 16);
+    return *out ? 0 : ENOMEM;
+}
+void lthip_free_device(lthip_ctx* c, void* p)
+{
+    (void)c;
+    free(p);
+}
+int lthip_malloc_pinned(lthip_ctx* c, size_t n, void** out) { return lthip_malloc_device(c, n, out); }
+void lthip_free_pinned(lthip_ctx* c, void* p)
+{
+    (void)c;
+    free(p);
+}
+int lthip_copy_h2d(lthip_ctx* c, void* d, const void* h, size_t n)
+{
+    (void)c;
+    memcpy(d, h, n);
+    return 0;
+}
+int lthip_copy_d2h(lthip_ctx* c, void* h, const void* d, size_t n)
+{
+    (void)c;
+    memcpy(h, d, n);
+    return 0;
+}
+int lthip_plan_create(lthip_ctx* c, uint32_t parts, const uint64_t* offs, const uint64_t* sizes, uint32_t mn, uint32_t av, uint32_t mx,
+                      lthip_plan** out)
+{
+    (void)c;
+    if (parts != 1 || offs[0] != 0 || mn < 48 || mn > av || av > mx)
+        return EINVAL;
+    if (alloc_fails())
+        return ENOMEM;
+    lthip_plan* p = (lthip_plan*)calloc(1, sizeof *p);
+    if (!p)
+        return ENOMEM;
+    p->capacity = p->size = sizes[0];
+    p->min = mn;
+    p->avg = av;
+    p->max = mx;
+    *out = p;
+    return 0;
+}
+int lthip_plan_resize_single(lthip_ctx* c, lthip_plan* p, uint64_t size)
+{
+    (void)c;
+    if (size > p->capacity)
+        return EINVAL;
+    p->size = size;
+    return 0;
+}
+void lthip_plan_destroy(lthip_ctx* c, lthip_plan* p)
+{
+    (void)c;
+    free(p);
+}
+uint64_t lthip_plan_chunk_capacity(const lthip_plan* p) { return p->size / p->min + 1; }
+int lthip_chunk_hash(lthip_ctx* c, const lthip_plan* p, const void* d, uint64_t* offs, uint32_t* lens, uint64_t* hashes, uint32_t* first,
+                     uint64_t* out_total)
+{
+    (void)c;
+    const uint64_t cap = p->size / p->min + 2;
+    const uint64_t n = lto_hpcdc_chunk_stream((const uint8_t*)d, p->size, p->min, p->avg, p->max, lens, cap);
+    uint64_t o = 0;
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        offs[i] = o;
+        o += lens[i];
+    }
+    if (hashes)
+        lto_blake3_u64_many((const uint8_t*)d, offs, lens, n, hashes);
+    first[0] = 0;
+    first[1] = (uint32_t)n;
+    if (out_total)
+        *out_total = n;
+    return 0;
+}
+int lthip_chunk_from_buffer(lthip_ctx* c, const void* d, uint64_t size, uint32_t mn, uint32_t av, uint32_t mx, uint64_t* out_len)
+{
+    (void)c;
+    *out_len = lto_hpcdc_next_from_buffer((const uint8_t*)d, size, mn, av, mx);
+    return 0;
+}
+int lthip_hash_ranges(lthip_ctx* c, const void* d, uint64_t n, const uint64_t* offs, const uint32_t* lens, uint32_t max_len, uint64_t* out)
+{
+    (void)c;
+    (void)max_len;
+    lto_blake3_u64_many((const uint8_t*)d, offs, lens, n, out);
+    return 0;
+}
+size_t lthip_lz4_bound(size_t n) { return n > 0x7E000000u ? 0 : n + n / 255 + 16; }
+size_t lthip_zstd_bound(size_t n) { return n + (n >> 8) + (n < (128u << 10) ? ((128u << 10) - n) >> 11 : 0); }
+int lthip_lz4_compress_blocks(lthip_ctx* c, const void* s, uint32_t nb, const uint64_t* so, const uint32_t* ss, void* d, const uint64_t* dof,
+                              const uint32_t* dc, uint32_t* out, int seg)
+{
+    (void)c;
+    (void)seg;
+    for (uint32_t b = 0; b < nb; ++b)
+    {
+        const int k = lto_lz4_compress((const uint8_t*)s + so[b], (int)ss[b], (uint8_t*)d + dof[b], (int)dc[b]);
+        out[b] = k > 0 ? (uint32_t)k : 0u;
+    }
+    return 0;
+}
+int lthip_lz4_decompress_blocks(lthip_ctx* c, const void* s, uint32_t nb, const uint64_t* so, const uint32_t* ss, void* d, const uint64_t* dof,
+                                const uint32_t* dc, uint32_t* out)
+{
+    (void)c;
+    for (uint32_t b = 0; b < nb; ++b)
+    {
+        const int k = lto_lz4_decompress((const uint8_t*)s + so[b], (int)ss[b], (uint8_t*)d + dof[b], (int)dc[b]);
+        out[b] = k >= 0 ? (uint32_t)k : 0xFFFFFFFFu;
+    }
+    return 0;
+}
+int lthip_zstd_compress_blocks(lthip_ctx* c, const void* s, uint32_t nb, const uint64_t* so, const uint32_t* ss, void* d, const uint64_t* dof,
+                               const uint32_t* dc, uint32_t* out)
+{
+    (void)c;
+    for (uint32_t b = 0; b < nb; ++b)
+    {
+        /* the model wants its own (larger) bound: encode into a scratch buffer and copy what fits the caller's capacity */
+        const size_t bound = ss[b] + (ss[b] >> 8) + 64 + 3 * ((size_t)ss[b] / (128u << 10) + 1);
+        uint8_t* tmp = (uint8_t*)malloc(bound);
+        size_t k = 0;
+        out[b] = 0u;
+        if (tmp && ltz_model_compress((const uint8_t*)s + so[b], ss[b], tmp, bound, &k) == 0 && k <= dc[b])
+        {
+            memcpy((uint8_t*)d + dof[b], tmp, k);
+            out[b] = (uint32_t)k;
+        }
+        free(tmp);
+    }
+    return 0;
+}
+int lthip_zstd_decompress_blocks(lthip_ctx* c, const void* s, uint32_t nb, const uint64_t* so, const uint32_t* ss, void* d, const uint64_t* dof,
+                                 const uint32_t* dc, uint32_t* out)
+{
+    (void)c;
+    for (uint32_t b = 0; b < nb; ++b)
+    {
+        size_t k = 0;
+        out[b] = ltz_model_decompress((const uint8_t*)s + so[b], ss[b], (uint8_t*)d + dof[b], dc[b], &k) == 0 ? (uint32_t)k : 0xFFFFFFFFu;
+    }
+    return 0;
+}
