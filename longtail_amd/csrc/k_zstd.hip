@@ -77,10 +77,30 @@ constexpr int ZT = 256;
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
+// The pieces (zstd blocks) of a frame written here are independent of each other: matches never leave their 64 KiB window group,
+// offsets are never repeat codes, every block carries its own entropy tables.  A frame of two or more pieces says so in a trailing
+// SKIPPABLE frame (magic 0x184D2A5D, 4 bytes of data "LTP\1": any zstd decoder skips it, zstd_decompress.c:1068-1085), which lets
+// lthip_zstd_decompress_blocks decode the pieces on separate waves.
+constexpr uint32_t ZTRAILER = 12u;
+__device__ __forceinline__ void z_write_trailer(uint8_t* d)
+{
+    const uint8_t t[ZTRAILER] = {0x5D, 0x2A, 0x4D, 0x18, 4, 0, 0, 0, 'L', 'T', 'P', 1};
+    for (uint32_t i = 0; i < ZTRAILER; ++i)
+        d[i] = t[i];
+}
+__device__ __forceinline__ bool z_is_trailer(const uint8_t* d)
+{
+    const uint8_t t[ZTRAILER] = {0x5D, 0x2A, 0x4D, 0x18, 4, 0, 0, 0, 'L', 'T', 'P', 1};
+    bool same = true;
+    for (uint32_t i = 0; i < ZTRAILER; ++i)
+        same &= d[i] == t[i];
+    return same;
+}
+
 // serial per stored block: destination offset of every piece, total size
 __global__ void k_zstd_scan(const ZBlock* __restrict__ blocks, uint32_t nblocks, const uint8_t* __restrict__ is_rle,
                             const uint32_t* __restrict__ enc_size, uint32_t* __restrict__ zb_dst,
-                            uint32_t* __restrict__ out_sizes)
+                            uint32_t* __restrict__ out_sizes, uint8_t* __restrict__ dst, uint32_t dbg)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks)
@@ -95,6 +115,11 @@ __global__ void k_zstd_scan(const ZBlock* __restrict__ blocks, uint32_t nblocks,
         zb_dst[blk.zb_base + i] = (uint32_t)pos;
         const uint32_t enc = enc_size[blk.zb_base + i];
         pos += 3u + ((is_rle[blk.zb_base + i] & 1u) ? 1u : enc ? enc : len);
+    }
+    if (blk.nzb >= 2u && pos + ZTRAILER <= (uint64_t)blk.dst_cap && !(dbg & 2u))
+    {
+        z_write_trailer(dst + blk.dst_off + pos);
+        pos += ZTRAILER;
     }
     out_sizes[b] = pos <= (uint64_t)blk.dst_cap ? (uint32_t)pos : 0u;
 }
@@ -355,7 +380,8 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
     }
     LaunchTimer t(ctx, LTHIP_K_OTHER);
     hipLaunchKernelGGL(k_zstd_scan, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
-                       block_count, (const uint8_t*)d_rle, (const uint32_t*)d_encsz, (uint32_t*)d_zdst, d_out_sizes);
+                       block_count, (const uint8_t*)d_rle, (const uint32_t*)d_encsz, (uint32_t*)d_zdst, d_out_sizes, (uint8_t*)d_dst,
+                       (uint32_t)(getenv("LTHIP_ZSTD_DBG") ? atoi(getenv("LTHIP_ZSTD_DBG")) : 0)); // bit 1: no independence marker
     hipLaunchKernelGGL(k_zstd_headers, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
                        block_count, (const uint32_t*)d_out_sizes, (uint8_t*)d_dst);
     if (nzb)
@@ -382,26 +408,133 @@ extern "C" __attribute__((visibility("default"))) int lthip_zb_prof_dump(void)
 #endif
 
 // ---------------------------------------------------------------------------------------------------
-// decoder: one wavefront per payload, persistent over the payloads (zstd_decode_core.h)
+// decoder (zstd_decode_core.h): one wavefront per WORK ITEM, persistent over the items.  A payload is one item -- decoded serially,
+// frame by frame, block by block -- unless it is a frame of this library's own encoder that carries the independence marker
+// (z_write_trailer): then every 128 KiB piece is an item of its own (k_zstd_split lists them), and a stored block of 8 MiB is
+// decoded by 64 waves instead of one.  Anything about a marked payload that is not exactly what the encoder writes (header form,
+// block count, sizes) sends it down the serial path, which accepts and rejects what it always did.
 // ---------------------------------------------------------------------------------------------------
 namespace
 {
-__global__ __launch_bounds__(64) void k_zstd_decode(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t nblocks,
-                                                    uint8_t* __restrict__ dst, uint8_t* __restrict__ lit_scratch,
-                                                    uint32_t* __restrict__ out_sizes)
+struct ZItem
+{
+    uint64_t src_off; // absolute, of the block header (piece) or the payload (whole)
+    uint32_t size;    // bytes of the item's source
+    uint32_t out0;    // piece: first output byte inside the payload's destination; whole: unused
+    uint32_t payload;
+    uint32_t kind;    // 0 nothing, 1 whole payload, 2 piece
+};
+
+// one thread per payload: is it a marked frame of ours?  then list its pieces, else list the payload
+// The list is DENSE (items are appended through a counter): with one slot per possible piece the whole-payload items of equal-sized
+// payloads sit a power of two apart and land on a handful of the persistent workgroups (measured: 128 payloads on 32 of 2048).
+__global__ void k_zstd_split(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t nblocks, ZItem* __restrict__ items,
+                             uint32_t* __restrict__ item_count, uint32_t* __restrict__ out_sizes, uint32_t dbg)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks)
+        return;
+    const ZBlock blk = blocks[b];
+    const uint8_t* p = src + blk.src_off;
+    bool pieces = false;
+    uint32_t np = 0;
+    uint64_t content = 0;
+    if (!(dbg & 1u) && blk.size >= ZHDR + 3u + ZTRAILER && z_is_trailer(p + blk.size - ZTRAILER) && p[0] == 0x28 && p[1] == 0xB5 &&
+        p[2] == 0x2F && p[3] == 0xFD && p[4] == 0xE0)
+    {
+        for (int i = 0; i < 8; ++i)
+            content |= (uint64_t)p[5 + i] << (8 * i);
+        const uint32_t end = blk.size - ZTRAILER;
+        const uint64_t want = (content + ZB - 1u) / ZB;
+        if (content != 0 && content <= (uint64_t)blk.dst_cap && want <= (uint64_t)blk.nzb)
+        {
+            // first walk: is the block structure what the encoder writes?  second walk (below): list the pieces
+            uint32_t ip = ZHDR;
+            bool ok = true, last = false;
+            while (ok && !last && np < (uint32_t)want)
+            {
+                if (end - ip < 3u)
+                {
+                    ok = false;
+                    break;
+                }
+                const uint32_t bh = (uint32_t)p[ip] | ((uint32_t)p[ip + 1] << 8) | ((uint32_t)p[ip + 2] << 16);
+                const uint32_t type = (bh >> 1) & 3u, bsize = bh >> 3;
+                last = (bh & 1u) != 0u;
+                const uint32_t body = type == 1u ? 1u : bsize;
+                if (type == 3u || body > end - ip - 3u)
+                {
+                    ok = false;
+                    break;
+                }
+                ip += 3u + body;
+                ++np;
+            }
+            pieces = ok && last && np == (uint32_t)want && ip == end;
+        }
+    }
+    if (pieces)
+    {
+        ZItem* out = items + atomicAdd(item_count, np);
+        uint32_t ip = ZHDR;
+        for (uint32_t i = 0; i < np; ++i)
+        {
+            const uint32_t bh = (uint32_t)p[ip] | ((uint32_t)p[ip + 1] << 8) | ((uint32_t)p[ip + 2] << 16);
+            const uint32_t body = ((bh >> 1) & 3u) == 1u ? 1u : bh >> 3;
+            out[i].src_off = blk.src_off + ip;
+            out[i].size = 3u + body;
+            out[i].out0 = i * ZB;
+            out[i].payload = b;
+            out[i].kind = 2;
+            ip += 3u + body;
+        }
+        out_sizes[b] = (uint32_t)content; // a piece that fails replaces it by ZD_ERROR
+    }
+    else
+    {
+        ZItem* it = items + atomicAdd(item_count, 1u);
+        it->src_off = blk.src_off;
+        it->size = blk.size;
+        it->out0 = 0;
+        it->payload = b;
+        it->kind = 1;
+    }
+}
+
+// PIECES selects the item kind the launch works on: the mode of the decoder core is then a compile-time constant (with a run-time
+// mode the whole-payload path ran 4.6x slower per wave -- measured; the two flavours are launched back to back)
+template <bool PIECES>
+__global__ __launch_bounds__(64) void k_zstd_decode(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, const ZItem* __restrict__ items,
+                                                    const uint32_t* __restrict__ item_count, uint8_t* __restrict__ dst,
+                                                    uint8_t* __restrict__ lit_scratch, uint32_t* __restrict__ out_sizes)
 {
     __shared__ ZdShared sh;
     uint8_t* lits = lit_scratch + (uint64_t)blockIdx.x * (ZD_LIT_MAX + 64u);
-    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x)
+    const uint32_t nitems = *item_count;
+    for (uint32_t i = blockIdx.x; i < nitems; i += gridDim.x)
     {
-        const ZBlock blk = blocks[b];
+        const ZItem it = items[i];
+        if (it.kind != (PIECES ? 2u : 1u))
+            continue;
+        const ZBlock blk = blocks[it.payload];
 #ifdef LTHIP_ZB_PROF
         if (threadIdx.x == 0)
             g_zb_last[blockIdx.x] = wall_clock64();
 #endif
-        const uint32_t n = zd_decode_payload(src + blk.src_off, blk.size, dst + blk.dst_off, blk.dst_cap, lits, &sh, threadIdx.x);
-        if (threadIdx.x == 0)
-            out_sizes[b] = n; // ZD_ERROR (0xFFFFFFFF) for malformed input, like lthip_lz4_decompress_blocks
+        if constexpr (!PIECES)
+        {
+            const uint32_t n = zd_decode_payload_ex(src + it.src_off, it.size, dst + blk.dst_off, blk.dst_cap, lits, &sh, threadIdx.x, ZD_WHOLE);
+            if (threadIdx.x == 0)
+                out_sizes[it.payload] = n; // ZD_ERROR (0xFFFFFFFF) for malformed input, like lthip_lz4_decompress_blocks
+        }
+        else
+        {
+            const uint32_t content = out_sizes[it.payload] == ZD_ERROR ? 0u : out_sizes[it.payload]; // (another piece may have failed)
+            const uint32_t n = zd_decode_payload_ex(src + it.src_off, it.size, dst + blk.dst_off, blk.dst_cap, lits, &sh, threadIdx.x, it.out0);
+            const uint32_t expect = content > it.out0 ? (content - it.out0 < ZB ? content - it.out0 : ZB) : 0u;
+            if (threadIdx.x == 0 && (n != expect || content == 0u))
+                atomicExch(&out_sizes[it.payload], ZD_ERROR);
+        }
         __syncthreads();
     }
 }
@@ -417,28 +550,46 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
         return 0;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     std::vector<ZBlock> hb(block_count);
+    uint64_t nitems = 0;
     for (uint32_t b = 0; b < block_count; ++b)
     {
         hb[b].src_off = src_offsets[b];
         hb[b].dst_off = dst_offsets[b];
         hb[b].size = src_sizes[b];
         hb[b].dst_cap = dst_caps[b];
-        hb[b].zb_base = hb[b].nzb = hb[b].unit_base = hb[b].pad = 0;
+        hb[b].zb_base = (uint32_t)nitems; // item slots of the payload: one per 128 KiB of destination, at least one
+        hb[b].nzb = dst_caps[b] ? (uint32_t)(((uint64_t)dst_caps[b] + ZB - 1u) / ZB) : 1u;
+        hb[b].unit_base = hb[b].pad = 0;
+        nitems += hb[b].nzb;
     }
+    if (nitems > 0x7FFFFFF0ull)
+        return lthip_fail(ctx, EINVAL, "zstd decode", "too many pieces in one call");
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const uint32_t nwg = block_count < (uint32_t)ncu * 8u ? block_count : (uint32_t)ncu * 8u;
-    void *d_blocks, *d_lits;
+    // 8 single-wave workgroups per CU (12 would be resident at 143 VGPRs, measured slower: 190 vs 160 ms for 512 blocks)
+    uint32_t nwg = nitems < (uint64_t)ncu * 8u ? (uint32_t)nitems : (uint32_t)ncu * 8u;
+    if (getenv("LTHIP_ZSTD_NWG"))
+        nwg = (uint32_t)atoi(getenv("LTHIP_ZSTD_NWG"));
+    void *d_blocks, *d_lits, *d_items;
     int err;
     if ((err = lthip_scratch(ctx, S_LZ4_BLOCKS, sizeof(ZBlock) * (size_t)block_count, &d_blocks)))
         return err;
     if ((err = lthip_scratch(ctx, S_Z_WORK, (size_t)(ZD_LIT_MAX + 64u) * nwg, &d_lits)))
         return err;
+    if ((err = lthip_scratch(ctx, S_Z_ENC, sizeof(ZItem) * (size_t)nitems + 16, &d_items)))
+        return err;
+    uint32_t* d_count = (uint32_t*)((uint8_t*)d_items + sizeof(ZItem) * (size_t)nitems);
+    LTHIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 4, ctx->stream));
     if ((err = lthip_stage_upload(ctx, d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, ctx->stream)))
         return err;
+    const uint32_t dbg = (uint32_t)(getenv("LTHIP_ZSTD_DBG") ? atoi(getenv("LTHIP_ZSTD_DBG")) : 0); // 1: never decode by pieces
     LaunchTimer t(ctx, LTHIP_K_OTHER);
-    hipLaunchKernelGGL(k_zstd_decode, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks, block_count,
-                       (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes);
+    hipLaunchKernelGGL(k_zstd_split, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
+                       block_count, (ZItem*)d_items, d_count, d_out_sizes, dbg);
+    hipLaunchKernelGGL(k_zstd_decode<false>, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
+                       (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes);
+    hipLaunchKernelGGL(k_zstd_decode<true>, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
+                       (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes);
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
 }

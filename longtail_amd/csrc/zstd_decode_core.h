@@ -497,11 +497,19 @@ ZB_FN int zd_set_table(ZdShared* sh, int t, uint32_t mode, const uint8_t* p, uin
  * One payload (one or more frames) -> dst.  Returns the number of bytes produced or ZD_ERROR.
  * lits: scratch of ZD_LIT_MAX + 32 bytes (global memory on the GPU).
  * ---------------------------------------------------------------------------------------------------------- */
-ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t* dst, uint32_t dst_cap, uint8_t* lits, ZdShared* sh,
-                                 uint32_t zl)
+/* piece_out0 == ZD_WHOLE: the payload as described above.
+ * Otherwise PIECE mode, for frames whose blocks are known to be independent of each other (this library's own encoder, which says
+ * so in a trailing skippable frame -- k_zstd.hip): src is ONE block (3-byte header + content) that regenerates the bytes from
+ * dst[piece_out0] on; returns the number of bytes it produced.  The mode is STRICT: a match may not reach below piece_out0, repeat
+ * offsets, treeless literals and repeated FSE tables are errors (they would need the state the previous block left) -- so a frame
+ * that carries the marker without keeping its promise is rejected, never decoded differently from the serial decoder. */
+#define ZD_WHOLE 0xFFFFFFFFu
+ZB_FN uint32_t zd_decode_payload_ex(const uint8_t* src, uint32_t src_size, uint8_t* dst, uint32_t dst_cap, uint8_t* lits, ZdShared* sh,
+                                    uint32_t zl, uint32_t piece_out0)
 {
+    const int piece = piece_out0 != ZD_WHOLE;
     uint32_t ip = 0;     /* every lane tracks the parse position through sh->v broadcasts */
-    uint32_t out_total = 0;
+    uint32_t out_total = piece ? piece_out0 : 0u;
     ZB_SERIAL(zl) { sh->v[ZDV_ERR] = 0; }
     ZB_SYNC();
     for (;;) /* frames */
@@ -514,7 +522,20 @@ ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t*
         {
             sh->v[ZDV_DONE] = 0;
             sh->v[ZDV_LEN] = 0;
-            if (src_size - ip < 4u)
+            if (piece)
+            {
+                /* no frame header: the state a frame starts with */
+                sh->v[ZDV_NLIT] = 0xFFFFFFFFu;
+                sh->v[ZDV_MODE] = ZB_BLOCK_MAX;
+                sh->v[ZDV_DONE] = 1;
+                sh->v[ZDV_BYTE] = 0;
+                sh->rep[0] = 1;
+                sh->rep[1] = 4;
+                sh->rep[2] = 8;
+                sh->huf_valid = 0;
+                sh->fse[0].valid = sh->fse[1].valid = sh->fse[2].valid = 0;
+            }
+            else if (src_size - ip < 4u)
                 ZD_SET_ERR(sh);
             else
             {
@@ -918,7 +939,7 @@ ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t*
                                         }
 #undef ZD_TAKE
                                         if (br.over || o == 0u || ll > nlit - litpos || ll > dst_cap - out_total ||
-                                            ml > dst_cap - out_total - ll || o > out_total - frame_start_out + ll)
+                                            ml > dst_cap - out_total - ll || o > out_total - frame_start_out + ll || (piece && ov <= 3u))
                                             ZD_SET_ERR(sh);
                                         if (n + 1u == nbseq && br.pos != 0u)
                                             ZD_SET_ERR(sh); /* the bit-stream must be consumed exactly */
@@ -978,8 +999,14 @@ ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t*
             }
             if (out_total - block_out0 > block_max)
                 return ZD_FAIL_AT(sh); /* Block_Maximum_Size = min(window, 128 KiB) */
-            if (last)
+            if (last || piece)
                 break;
+        }
+        if (piece)
+        {
+            if (ip != src_size)
+                return ZD_FAIL_AT(sh);
+            break;
         }
         if (content_size != 0xFFFFFFFFu && out_total - frame_start_out != content_size)
             return ZD_FAIL_AT(sh);
@@ -993,7 +1020,13 @@ ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t*
     ZB_SYNC();
     if (sh->v[ZDV_ERR])
         return ZD_FAIL_AT(sh);
-    return out_total;
+    return piece ? out_total - piece_out0 : out_total;
+}
+
+ZB_FN uint32_t zd_decode_payload(const uint8_t* src, uint32_t src_size, uint8_t* dst, uint32_t dst_cap, uint8_t* lits, ZdShared* sh,
+                                 uint32_t zl)
+{
+    return zd_decode_payload_ex(src, src_size, dst, dst_cap, lits, sh, zl, ZD_WHOLE);
 }
 
 #endif /* ZSTD_DECODE_CORE_H */
