@@ -324,6 +324,56 @@ def test_zstd_decoder_agrees_with_host_model_and_reference_on_damaged_frames(gpu
     assert 20 < accepted < len(frames)
 
 
+MARKER = bytes([0x5D, 0x2A, 0x4D, 0x18, 4, 0, 0, 0]) + b"LTP\x01"  # k_zstd.hip z_write_trailer
+
+
+def test_zstd_piece_decoder_is_the_serial_decoder_on_own_frames_and_strict_on_false_promises(gpu, oracle, ref, monkeypatch):
+    """Frames of two or more pieces end with the independence marker and are decoded piece by piece on separate waves.
+    (1) same bytes as the serial decoder (LTHIP_ZSTD_DBG=1) and as the reference on the encoder's own frames, also damaged ones:
+        the piece decoder never ACCEPTS what the serial one rejects, and what it accepts is identical;
+    (2) a frame that carries the marker without keeping its promise -- the REFERENCE encoder's output (matches across blocks,
+        repeat offsets, repeated tables) with the marker appended -- is rejected or decoded exactly like the reference, never
+        decoded differently."""
+    rng = np.random.default_rng(12)
+    datas = [oracle.synth(n, 90 + n, k) for k, n in ((1, 131073), (1, 600000), (11, 400000), (12, 300000), (13, 262144), (0, 500000),
+                                                    (2, 400000), (1, (8 << 20) + 5))]
+    own = gpu_zstd(gpu, datas)
+    assert all(bytes(f[-12:]) == MARKER for f in own)  # >= 2 pieces each
+    frames, caps = list(own), [len(d) for d in datas]
+    for f, d in zip(own[:6], datas[:6]):
+        for _ in range(25):
+            x = f.copy()
+            k = rng.integers(0, 4)
+            if k == 0:
+                x = np.concatenate([x[: rng.integers(13, len(x) - 12)], x[-12:]])  # truncated, marker kept
+            else:
+                for _ in range(int(rng.integers(1, 4))):
+                    x[rng.integers(0, len(x) - 12)] ^= np.uint8(1 << rng.integers(0, 8))  # bit flips before the marker
+            frames.append(x)
+            caps.append(len(d))
+    pieces = gpu_zstd_decode(gpu, frames, caps)
+    monkeypatch.setenv("LTHIP_ZSTD_DBG", "1")
+    serial = gpu_zstd_decode(gpu, frames, caps)
+    monkeypatch.delenv("LTHIP_ZSTD_DBG")
+    for i, (f, cap, p_out, s_out) in enumerate(zip(frames, caps, pieces, serial)):
+        if i < len(own):
+            assert p_out is not None and (p_out == datas[i]).all() and (s_out == datas[i]).all()
+        if p_out is not None:
+            assert s_out is not None and len(p_out) == len(s_out) and (p_out == s_out).all(), i
+    assert sum(o is None for o in pieces[len(own):]) > 20  # the damage is really detected
+    # (2) false promises
+    lying, raws = [], []
+    for d in datas[:5]:
+        for w in (0, 2, 3):
+            lying.append(np.concatenate([ref.compress(1, ref.dll.refh_zstd_type(w), d), np.frombuffer(MARKER, np.uint8)]))
+            raws.append(d)
+    outs = gpu_zstd_decode(gpu, lying, [len(r) for r in raws])
+    for f, r, o in zip(lying, raws, outs):
+        err, r_out = ref.decompress(1, f, len(r))
+        assert err == 0 and (r_out == r).all()          # the reference skips the marker and decodes the frame
+        assert o is None or (len(o) == len(r) and (o == r).all())
+
+
 def test_lz4_gpu_decoder_differential_fuzz(gpu, oracle):
     """Damaged payloads: the HIP decoder accepts exactly what the oracle's strict LZ4_decompress_safe restatement accepts
     (lz4.c:2215-2435), with the same size and bytes -- truncations, bit flips, zeroed tails, wrong capacities."""
