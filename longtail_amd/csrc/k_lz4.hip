@@ -1647,7 +1647,7 @@ __device__ unsigned long long g_dec_prof[16];
 template <typename I>
 __global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
                                                        uint32_t nblocks, uint8_t* __restrict__ dst,
-                                                       uint32_t* __restrict__ out_sizes)
+                                                       uint32_t* __restrict__ out_sizes, uint32_t dec_nobatch)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN];
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[DEC_RING];
@@ -1820,6 +1820,118 @@ __global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict
                 {
                     seed(ip);
                     d = 0;
+                }
+                // ---- batch path: SEVERAL short sequences per step.  Every lane reads "its" byte of the window as if it were a
+                // token (<= 14 literals, match <= 18, everything it needs inside the window); a scalar walk follows the chain of
+                // real tokens from the current position (a few SALU instructions per token instead of the ~120 of the
+                // one-sequence path); all their literals go into the ring with ONE store (a lane's byte belongs to the nearest
+                // token before it), the matches are copied by the tokens' own lanes, all at once when their sources lie before
+                // the batch, otherwise in dependency order.  The conditions are the one-sequence path's, token by token: the first
+                // token that fails any of them ends the batch and is left to the code below (which also decides about errors).
+                if (d <= 40 && !dec_nobatch)
+                {
+                    const uint32_t litl = w >> 4, mlcl = w & 15u;
+                    const int e1 = lane + 1 + (int)litl;
+                    const bool simple = litl < 15u && mlcl < 15u && e1 + 1 < 64;
+                    const uint32_t offl = (uint32_t)__shfl((int)w, e1 & 63, 64) | ((uint32_t)__shfl((int)w, (e1 + 1) & 63, 64) << 8);
+                    const uint32_t seqlen = 3u + litl, mll = mlcl + 4u;
+                    const uint64_t okm = __builtin_amdgcn_ballot_w64(simple);
+                    uint64_t vis = 0ull;
+                    int cur = (int)d, ntok = 0;
+                    while (cur < 64 && ((okm >> cur) & 1ull) && ntok < 16)
+                    {
+                        vis |= 1ull << cur;
+                        cur += (int)__builtin_amdgcn_readlane(seqlen, cur);
+                        ++ntok;
+                    }
+                    if (ntok >= 2)
+                    {
+                        const bool tv = (vis >> lane) & 1ull;
+                        const uint32_t adv = tv ? litl + mll : 0u;
+                        uint32_t incl = adv; // inclusive prefix sum over the lanes
+#pragma unroll
+                        for (int sh = 1; sh < 64; sh <<= 1)
+                        {
+                            const uint32_t o = (uint32_t)__shfl_up((int)incl, sh, 64);
+                            if (lane >= sh)
+                                incl += o;
+                        }
+                        const I opl = op + (I)(incl - adv);   // where my literals go (if I am a token)
+                        const I ipl = w0 + (I)lane;           // my payload position
+                        const I opm = opl + (I)litl;          // where my match goes
+                        const bool bad = tv && (opl + (I)litl > cap - 12 || ipl + 1 + (I)litl > n - 8 || opm + (I)mll > cap - 5 || offl == 0u ||
+                                                (I)offl > opm);
+                        const uint64_t badm = __builtin_amdgcn_ballot_w64(bad);
+                        if (badm)
+                            vis &= (1ull << __builtin_ctzll(badm)) - 1ull;
+                        if (__builtin_popcountll(vis) >= 2)
+                        {
+                            const bool tk2 = (vis >> lane) & 1ull;
+                            const int lastl = 63 - __builtin_clzll(vis);
+                            // literals, all tokens at once
+                            {
+                                const uint64_t below = vis & ((1ull << lane) - 1ull);
+                                const int pi = below ? 63 - __builtin_clzll(below) : 0;
+                                const uint32_t plit = (uint32_t)__shfl((int)litl, pi, 64);
+                                const uint32_t pop = (uint32_t)__shfl((int)(uint32_t)opl, pi, 64);
+                                const uint32_t rel = (uint32_t)(lane - pi - 1);
+                                if (below && rel < plit)
+                                    s_ring[RING(pop + rel)] = (uint8_t)w;
+                            }
+                            // matches: sources further back than the ring safely holds come from global memory -- landed?
+                            constexpr uint32_t RING_SAFE = DEC_RING - 768u; // the batch writes up to 16 x 32 bytes ahead of `op`
+                            const bool glob = tk2 && offl > RING_SAFE;
+                            if (__builtin_amdgcn_ballot_w64(glob && opm - (I)offl + (I)mll + (I)g > drained))
+                            {
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                __builtin_amdgcn_s_waitcnt(0);
+                                drained = flushed;
+                            }
+                            uint64_t pend = vis;
+                            while (pend)
+                            {
+                                const int first = __builtin_ctzll(pend);
+                                // positions relative to `op` (a batch appends at most 512 bytes): everything before the first pending
+                                // token's match is final
+                                const int32_t rel_m = (int32_t)(opm - op);
+                                const int32_t frontier = (int32_t)__builtin_amdgcn_readlane((uint32_t)rel_m, first);
+                                const bool ready = ((pend >> lane) & 1ull) && (lane == first || rel_m - (int32_t)offl + (int32_t)mll <= frontier);
+                                if (ready)
+                                {
+                                    // byte by byte in the lane (a match of a batch token is at most 18 bytes; overlapping ones,
+                                    // offset < length, replicate their seed exactly because every byte is stored before the next
+                                    // is read).  "All reads first, then all stores" was measured SLOWER (155 vs 141 ms / 4 GiB).
+                                    if (!glob)
+                                    {
+                                        const uint32_t so = (uint32_t)opm - offl;
+                                        for (uint32_t k = 0; k < mll; ++k)
+                                            s_ring[RING((uint32_t)opm + k)] = s_ring[RING(so + k)];
+                                    }
+                                    else
+                                    {
+                                        // from global memory the source lies > RING_SAFE bytes back: it cannot overlap the target
+                                        const uint8_t* sp = out + ((int64_t)opm - (int64_t)offl);
+                                        uint32_t bytes[18];
+#pragma unroll
+                                        for (uint32_t k = 0; k < 18u; ++k)
+                                            bytes[k] = k < mll ? sp[k] : 0u;
+#pragma unroll
+                                        for (uint32_t k = 0; k < 18u; ++k)
+                                            if (k < mll)
+                                                s_ring[RING((uint32_t)opm + k)] = (uint8_t)bytes[k];
+                                    }
+                                }
+                                pend &= ~__builtin_amdgcn_ballot_w64(ready);
+                            }
+                            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, lastl);
+                            op += (I)total;
+                            ip = w0 + (I)lastl + (I)__builtin_amdgcn_readlane(seqlen, lastl);
+                            if (op + (I)g - flushed >= (I)DEC_FLUSH)
+                                flush((op + (I)g) & ~(I)(DEC_FLUSH - 1u));
+                            DEC_CNT(10);
+                            continue;
+                        }
+                    }
                 }
                 const uint32_t tk = __builtin_amdgcn_readlane(w, (int)d);
                 const I lit = (I)(tk >> 4), mlc = (I)(tk & 15u);
@@ -2269,6 +2381,7 @@ extern "C" int lthip_lz4_decompress_blocks(lthip_ctx* ctx, const void* d_src, ui
         return err;
     LaunchTimer t(ctx, LTHIP_K_OTHER);
     static const bool plain = getenv("LTHIP_LZ4_PLAIN_DECODER") != nullptr; // ablation: every byte through global memory
+    const uint32_t nobatch = getenv("LTHIP_LZ4_NO_BATCH_DECODE") ? 1u : 0u; // ablation: one sequence per step only
     if (plain)
         hipLaunchKernelGGL(k_lz4_decode, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, block_count,
                            (uint8_t*)d_dst, d_out_sizes);
@@ -2279,10 +2392,10 @@ extern "C" int lthip_lz4_decompress_blocks(lthip_ctx* ctx, const void* d_src, ui
             small = small && src_sizes[b] < (1u << 30) && dst_caps[b] < (1u << 30);
         if (small)
             hipLaunchKernelGGL(k_lz4_decode_lds<int32_t>, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks,
-                               block_count, (uint8_t*)d_dst, d_out_sizes);
+                               block_count, (uint8_t*)d_dst, d_out_sizes, nobatch);
         else
             hipLaunchKernelGGL(k_lz4_decode_lds<int64_t>, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks,
-                               block_count, (uint8_t*)d_dst, d_out_sizes);
+                               block_count, (uint8_t*)d_dst, d_out_sizes, nobatch);
     }
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
