@@ -1510,555 +1510,11 @@ __global__ void k_lz4_empty_blocks(const Lz4Block* __restrict__ blocks, uint32_t
         dst[blocks[b].dst_off] = 0;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// decoder: LZ4_decompress_safe rules (lz4.c:2215-2435), one wave per block
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_lz4_decode(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
-                                                   uint32_t nblocks, uint8_t* __restrict__ dst,
-                                                   uint32_t* __restrict__ out_sizes)
-{
-    const uint32_t b = blockIdx.x;
-    if (b >= nblocks)
-        return;
-    const int lane = threadIdx.x;
-    const Lz4Block blk = blocks[b];
-    const uint8_t* in = src + blk.src_off;
-    uint8_t* out = dst + blk.dst_off;
-    const int64_t n = blk.size, cap = blk.dst_cap;
-    uint32_t result = 0xFFFFFFFFu;
-    if (cap == 0)
-    {
-        if (n == 1 && in[0] == 0)
-            result = 0;
-    }
-    else if (n > 0)
-    {
-        int64_t ip = 0, op = 0;
-        for (;;)
-        {
-            if (ip >= n)
-                break;
-            const uint32_t token = in[ip++];
-            int64_t len = token >> 4;
-            bool bad = false;
-            if (len == 15)
-            { // read_variable_length(&ip, iend-RUN_MASK, 1), lz4.c:1979-2013
-                uint32_t v;
-                if (ip >= n - 15)
-                    bad = true;
-                else
-                    do
-                    {
-                        v = in[ip++];
-                        len += v;
-                        if (ip > n - 15)
-                        {
-                            bad = true;
-                            break;
-                        }
-                    } while (v == 255);
-            }
-            if (bad)
-                break;
-            if (op + len > cap - 12 || ip + len > n - 8)
-            {
-                if (ip + len != n || op + len > cap)
-                    break;
-                for (int64_t j = lane; j < len; j += 64)
-                    out[op + j] = in[ip + j];
-                result = (uint32_t)(op + len);
-                break;
-            }
-            for (int64_t j = lane; j < len; j += 64)
-                out[op + j] = in[ip + j];
-            ip += len;
-            op += len;
-            const uint32_t off = (uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8);
-            ip += 2;
-            if (off == 0 || (int64_t)off > op)
-                break;
-            int64_t ml = token & 15;
-            if (ml == 15)
-            {
-                uint32_t v;
-                do
-                {
-                    if (ip >= n - 5 + 1)
-                    {
-                        bad = true;
-                        break;
-                    }
-                    v = in[ip++];
-                    ml += v;
-                } while (v == 255);
-            }
-            if (bad)
-                break;
-            ml += 4;
-            if (op + ml > cap - 5)
-                break;
-            // the literal bytes written above must be visible to every lane before they are read back
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_waitcnt(0);
-            if ((int64_t)off >= ml)
-            {
-                for (int64_t j = lane; j < ml; j += 64)
-                    out[op + j] = out[op - off + j];
-            }
-            else
-            {
-                // overlapping copy: byte j of the match equals byte (j mod off) of the seed
-                for (int64_t j = lane; j < ml; j += 64)
-                    out[op + j] = out[op - off + (j % (int64_t)off)];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_waitcnt(0);
-            op += ml;
-        }
-    }
-    if (lane == 0)
-        out_sizes[b] = result;
-}
-
-// The same rules, restructured around what made the wave-per-block decoder above slow: every
-// token, length byte and offset was a dependent GLOBAL load, every literal and match a wave-wide byte store, and every match a
-// wait for all of those stores.
-//   * the payload streams through a 4 KiB LDS window (16-byte coalesced refills); 64 payload bytes at a time sit in a register
-//     window (one byte per lane) with the next one prefetched, so a short sequence (no length bytes: most of them) is parsed
-//     with `readlane`s alone and its literals are stored from the registers they are already in;
-//   * the OUTPUT is produced into an 8 KiB LDS ring and leaves for global memory 2 KiB at a time with aligned 16-byte stores;
-//     matches with offset <= 8192 (the bulk) never touch global memory, farther ones read bytes that were flushed long ago.
-// Measured (8 MiB blocks of the "mixed" workload, 100-160 K sequences each): 106 ms per block against 173 ms; what remains is the
-// serial parse itself (77 ms with every copy switched off: ~280 instructions per sequence issued by a single wave), so the
-// throughput of a batch comes from the number of blocks in flight: 41 GB/s at 512 blocks, 140 GB/s at 2048.
-constexpr uint32_t DEC_IN = 4096u, DEC_RING = 8192u, DEC_FLUSH = 2048u;
-#ifdef LTHIP_DEC_PROF /* debug build only (make prof): where a decoding wave spends its cycles */
-__device__ unsigned long long g_dec_prof[16];
-#define DEC_T0() const unsigned long long t0__ = clock64()
-#define DEC_ACC(i) do { if (lane == 0) atomicAdd(&g_dec_prof[i], clock64() - t0__); } while (0)
-#define DEC_CNT(i) do { if (lane == 0) atomicAdd(&g_dec_prof[i], 1ull); } while (0)
-#else
-#define DEC_T0() ((void)0)
-#define DEC_ACC(i) ((void)0)
-#define DEC_CNT(i) ((void)0)
-#endif
-
-// I = index type: int32_t when every payload and capacity of the batch is below 1 GiB (half the scalar work), else int64_t
-template <typename I>
-__global__ __launch_bounds__(64) void k_lz4_decode_lds(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
-                                                       uint32_t nblocks, uint8_t* __restrict__ dst,
-                                                       uint32_t* __restrict__ out_sizes, uint32_t dec_nobatch)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN];
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[DEC_RING];
-    const uint32_t b = blockIdx.x;
-    if (b >= nblocks)
-        return;
-    const int lane = threadIdx.x;
-    const Lz4Block blk = blocks[b];
-    const uint8_t* in = src + blk.src_off;
-    uint8_t* out = dst + blk.dst_off;
-    const I n = (I)blk.size, cap = (I)blk.dst_cap;
-    const uint32_t head = (uint32_t)((uintptr_t)in & 15u);
-    const uint8_t* in_al = in - head; // 16-byte aligned; payload byte p sits at aligned offset p + head
-    const uint32_t g = (uint32_t)((uintptr_t)out & 15u);
-    uint8_t* out_al = out - g; // output byte q sits at aligned offset q + g, and in the ring at (q + g) mod 8 KiB
-    uint32_t result = 0xFFFFFFFFu;
-    I wa = -(I)DEC_IN; // aligned offset of s_in[0]; nothing loaded yet
-    // make payload bytes [p, p + k) (k <= 128; bytes at or past n are never used) resident; returns the index of p in s_in
-    auto need = [&](I p, uint32_t k) -> uint32_t {
-        const I a = p + (I)head;
-        if (a < wa || a + (I)k > wa + (I)DEC_IN)
-        {
-            DEC_CNT(8);
-            wa = a & ~(I)15;
-            const I end = n + (I)head; // first aligned offset past the payload
-            __syncthreads();
-            uint4 q[4]; // four loads in flight; vectors past the payload re-read the window's first one (their bytes are never used)
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-            {
-                const I o = wa + 16 * (I)(u * 64 + lane);
-                q[u] = *reinterpret_cast<const uint4*>(in_al + (int64_t)(o < end ? o : wa));
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                reinterpret_cast<uint4*>(s_in)[u * 64 + lane] = q[u];
-            __syncthreads();
-        }
-        return (uint32_t)(a - wa);
-    };
-    if (cap == 0)
-    {
-        if (n == 1 && in[0] == 0)
-            result = 0;
-    }
-    else if (n > 0)
-    {
-        I ip = 0, op = 0;
-        I flushed = 0; // aligned output offset (multiple of DEC_FLUSH) up to which the ring has been written out
-        I drained = 0; // aligned output offset up to which the flush stores are known to have landed
-        I w0 = -1000;  // payload position of lane 0 of the register window
-        uint32_t w = 0, wn = 0; // the window and the one 40 bytes further on (fetched while this one is parsed)
-#define RING(q) (((uint32_t)(q) + g) & (DEC_RING - 1u))
-        // ring -> global for aligned offsets [flushed, upto): whole 16-byte vectors, bytes at the two ragged ends of the block
-        auto flush = [&](I upto) {
-            DEC_T0();
-            while (flushed < upto)
-            {
-                const I stop = upto - flushed < (I)DEC_FLUSH ? upto : flushed + (I)DEC_FLUSH;
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                {
-                    const I P = flushed + 16 * (I)(u * 64 + lane);
-                    if (P >= stop)
-                        continue;
-                    const uint8_t* r = s_ring + ((uint32_t)P & (DEC_RING - 1u));
-                    if (P >= (I)g && P + 16 <= stop)
-                        *reinterpret_cast<uint4*>(out_al + (int64_t)P) = *reinterpret_cast<const uint4*>(r);
-                    else
-                        for (int k = 0; k < 16; ++k)
-                            if (P + k >= (I)g && P + k < stop)
-                                out_al[(int64_t)P + k] = r[k];
-                }
-                flushed = stop;
-            }
-            DEC_ACC(3);
-        };
-        auto seed = [&](I p) {
-            const uint32_t i = need(p, 128);
-            w = s_in[i + (uint32_t)lane];
-            wn = s_in[i + 40u + (uint32_t)lane];
-            w0 = p;
-        };
-        auto byte_at = [&](I p) -> uint32_t {
-            if (p < w0 || p >= w0 + 64)
-                seed(p);
-            return __builtin_amdgcn_readlane(w, (int)(p - w0));
-        };
-        // literals: payload [p, p + len) -> the ring at output position o
-        auto copy_lits = [&](I p, I o, I len) {
-            while (len > 0)
-            {
-                const uint32_t i = need(p, 1);
-                I avail = (I)DEC_IN - (I)i;
-                avail = avail < (I)DEC_FLUSH ? avail : (I)DEC_FLUSH;
-                const uint32_t c = (uint32_t)(len < avail ? len : avail);
-                for (uint32_t j = lane; j < c; j += 64)
-                    s_ring[RING((uint32_t)o + j)] = s_in[i + j];
-                p += (I)c;
-                o += (I)c;
-                len -= (I)c;
-                if (o + (I)g - flushed >= (I)DEC_FLUSH)
-                    flush((o + (I)g) & ~(I)(DEC_FLUSH - 1u));
-            }
-        };
-        // match of `ml` bytes at distance `off` (1 <= off <= op) appended at op; returns nothing, advances op
-        auto copy_match = [&](uint32_t off, I ml) {
-            DEC_T0();
-            if (off > DEC_RING)
-                DEC_CNT(9);
-            while (ml > 0)
-            {
-                // segments of <= 2 KiB (out[q] = out[q - off] holds for every q of a match, so a segment is a match of its own;
-                // with that bound no ring slot is overwritten before its last read and before it has been flushed)
-                const uint32_t seg = ml < (I)DEC_FLUSH ? (uint32_t)ml : DEC_FLUSH;
-                if (off <= DEC_RING)
-                {
-                    const uint32_t base = (uint32_t)op - off;
-                    if (off >= 64u) // a 64-byte step never reads what it writes
-                        for (uint32_t j = lane; j < seg; j += 64)
-                            s_ring[RING((uint32_t)op + j)] = s_ring[RING(base + j)];
-                    else if (seg <= 64u)
-                    {
-                        uint32_t r = (uint32_t)lane; // lane mod off
-                        for (uint32_t t = off; t < seg; t += off)
-                            r = (uint32_t)lane >= t ? (uint32_t)lane - t : r;
-                        if ((uint32_t)lane < seg)
-                            s_ring[RING((uint32_t)op + (uint32_t)lane)] = s_ring[RING(base + r)];
-                    }
-                    else // overlapping copy: byte j of the match equals byte (j mod off) of the seed
-                        for (uint32_t j = lane; j < seg; j += 64)
-                            s_ring[RING((uint32_t)op + j)] = s_ring[RING(base + j % off)];
-                }
-                else
-                {
-                    // the source left the ring long ago (off > 8 KiB, flushes every 2 KiB) -- but its stores must have landed
-                    if (op - (I)off + (I)seg + (I)g > drained)
-                    {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __builtin_amdgcn_s_waitcnt(0);
-                        drained = flushed;
-                    }
-                    for (uint32_t j = lane; j < seg; j += 64) // off > 8192 > seg: no overlap
-                        s_ring[RING((uint32_t)op + j)] = out[(int64_t)op - off + j];
-                }
-                op += (I)seg;
-                ml -= (I)seg;
-                if (op + (I)g - flushed >= (I)DEC_FLUSH)
-                    flush((op + (I)g) & ~(I)(DEC_FLUSH - 1u));
-            }
-            DEC_ACC(2);
-        };
-        DEC_T0();
-        for (;;)
-        {
-            if (ip >= n)
-                break;
-            // ---- short sequences (no length bytes, <= 14 literals, match <= 18): everything is in the register window ----
-            {
-                I d = ip - w0;
-                if (d > 47 && d < 88) // slide: the prefetched window becomes the current one
-                {
-                    w = wn;
-                    w0 += 40;
-                    d -= 40;
-                    const uint32_t i = need(w0 + 40, 64);
-                    wn = s_in[i + (uint32_t)lane];
-                }
-                if (d < 0 || d > 47)
-                {
-                    seed(ip);
-                    d = 0;
-                }
-                // ---- batch path: SEVERAL short sequences per step.  Every lane reads "its" byte of the window as if it were a
-                // token (<= 14 literals, match <= 18, everything it needs inside the window); a scalar walk follows the chain of
-                // real tokens from the current position (a few SALU instructions per token instead of the ~120 of the
-                // one-sequence path); all their literals go into the ring with ONE store (a lane's byte belongs to the nearest
-                // token before it), the matches are copied by the tokens' own lanes, all at once when their sources lie before
-                // the batch, otherwise in dependency order.  The conditions are the one-sequence path's, token by token: the first
-                // token that fails any of them ends the batch and is left to the code below (which also decides about errors).
-                if (d <= 40 && !dec_nobatch)
-                {
-                    const uint32_t litl = w >> 4, mlcl = w & 15u;
-                    const int e1 = lane + 1 + (int)litl;
-                    const bool simple = litl < 15u && mlcl < 15u && e1 + 1 < 64;
-                    const uint32_t offl = (uint32_t)__shfl((int)w, e1 & 63, 64) | ((uint32_t)__shfl((int)w, (e1 + 1) & 63, 64) << 8);
-                    const uint32_t seqlen = 3u + litl, mll = mlcl + 4u;
-                    const uint64_t okm = __builtin_amdgcn_ballot_w64(simple);
-                    uint64_t vis = 0ull;
-                    int cur = (int)d, ntok = 0;
-                    while (cur < 64 && ((okm >> cur) & 1ull) && ntok < 16)
-                    {
-                        vis |= 1ull << cur;
-                        cur += (int)__builtin_amdgcn_readlane(seqlen, cur);
-                        ++ntok;
-                    }
-                    if (ntok >= 2)
-                    {
-                        const bool tv = (vis >> lane) & 1ull;
-                        const uint32_t adv = tv ? litl + mll : 0u;
-                        uint32_t incl = adv; // inclusive prefix sum over the lanes
-#pragma unroll
-                        for (int sh = 1; sh < 64; sh <<= 1)
-                        {
-                            const uint32_t o = (uint32_t)__shfl_up((int)incl, sh, 64);
-                            if (lane >= sh)
-                                incl += o;
-                        }
-                        const I opl = op + (I)(incl - adv);   // where my literals go (if I am a token)
-                        const I ipl = w0 + (I)lane;           // my payload position
-                        const I opm = opl + (I)litl;          // where my match goes
-                        const bool bad = tv && (opl + (I)litl > cap - 12 || ipl + 1 + (I)litl > n - 8 || opm + (I)mll > cap - 5 || offl == 0u ||
-                                                (I)offl > opm);
-                        const uint64_t badm = __builtin_amdgcn_ballot_w64(bad);
-                        if (badm)
-                            vis &= (1ull << __builtin_ctzll(badm)) - 1ull;
-                        if (__builtin_popcountll(vis) >= 2)
-                        {
-                            const bool tk2 = (vis >> lane) & 1ull;
-                            const int lastl = 63 - __builtin_clzll(vis);
-                            // literals, all tokens at once
-                            {
-                                const uint64_t below = vis & ((1ull << lane) - 1ull);
-                                const int pi = below ? 63 - __builtin_clzll(below) : 0;
-                                const uint32_t plit = (uint32_t)__shfl((int)litl, pi, 64);
-                                const uint32_t pop = (uint32_t)__shfl((int)(uint32_t)opl, pi, 64);
-                                const uint32_t rel = (uint32_t)(lane - pi - 1);
-                                if (below && rel < plit)
-                                    s_ring[RING(pop + rel)] = (uint8_t)w;
-                            }
-                            // matches: sources further back than the ring safely holds come from global memory -- landed?
-                            constexpr uint32_t RING_SAFE = DEC_RING - 768u; // the batch writes up to 16 x 32 bytes ahead of `op`
-                            const bool glob = tk2 && offl > RING_SAFE;
-                            if (__builtin_amdgcn_ballot_w64(glob && opm - (I)offl + (I)mll + (I)g > drained))
-                            {
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                                __builtin_amdgcn_s_waitcnt(0);
-                                drained = flushed;
-                            }
-                            uint64_t pend = vis;
-                            while (pend)
-                            {
-                                const int first = __builtin_ctzll(pend);
-                                // positions relative to `op` (a batch appends at most 512 bytes): everything before the first pending
-                                // token's match is final
-                                const int32_t rel_m = (int32_t)(opm - op);
-                                const int32_t frontier = (int32_t)__builtin_amdgcn_readlane((uint32_t)rel_m, first);
-                                const bool ready = ((pend >> lane) & 1ull) && (lane == first || rel_m - (int32_t)offl + (int32_t)mll <= frontier);
-                                if (ready)
-                                {
-                                    // byte by byte in the lane (a match of a batch token is at most 18 bytes; overlapping ones,
-                                    // offset < length, replicate their seed exactly because every byte is stored before the next
-                                    // is read).  "All reads first, then all stores" was measured SLOWER (155 vs 141 ms / 4 GiB).
-                                    if (!glob)
-                                    {
-                                        const uint32_t so = (uint32_t)opm - offl;
-                                        for (uint32_t k = 0; k < mll; ++k)
-                                            s_ring[RING((uint32_t)opm + k)] = s_ring[RING(so + k)];
-                                    }
-                                    else
-                                    {
-                                        // from global memory the source lies > RING_SAFE bytes back: it cannot overlap the target
-                                        const uint8_t* sp = out + ((int64_t)opm - (int64_t)offl);
-                                        uint32_t bytes[18];
-#pragma unroll
-                                        for (uint32_t k = 0; k < 18u; ++k)
-                                            bytes[k] = k < mll ? sp[k] : 0u;
-#pragma unroll
-                                        for (uint32_t k = 0; k < 18u; ++k)
-                                            if (k < mll)
-                                                s_ring[RING((uint32_t)opm + k)] = (uint8_t)bytes[k];
-                                    }
-                                }
-                                pend &= ~__builtin_amdgcn_ballot_w64(ready);
-                            }
-                            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, lastl);
-                            op += (I)total;
-                            ip = w0 + (I)lastl + (I)__builtin_amdgcn_readlane(seqlen, lastl);
-                            if (op + (I)g - flushed >= (I)DEC_FLUSH)
-                                flush((op + (I)g) & ~(I)(DEC_FLUSH - 1u));
-                            DEC_CNT(10);
-                            continue;
-                        }
-                    }
-                }
-                const uint32_t tk = __builtin_amdgcn_readlane(w, (int)d);
-                const I lit = (I)(tk >> 4), mlc = (I)(tk & 15u);
-                // exactly the conditions under which the general code below takes its plain path for this token; a match
-                // length with ONE extension byte (19..272 bytes) is still read from the window
-                if (lit < 15 && !(op + lit > cap - 12 || ip + 1 + lit > n - 8))
-                {
-                    I ml = mlc + 4, adv = 3 + lit;
-                    bool fast = true;
-                    if (mlc == 15)
-                    {
-                        // its position ip + 3 + lit <= n - 6 satisfies the general path's "ip < n - 4" test by construction
-                        const I e = d + 3 + lit;
-                        const uint32_t v = e <= 63 ? (uint32_t)__builtin_amdgcn_readlane(w, (int)(e <= 63 ? e : 0)) : 255u;
-                        fast = v != 255u;
-                        ml += (I)v;
-                        adv += 1;
-                    }
-                    if (fast && op + lit + ml <= cap - 5)
-                    {
-                        const uint32_t off = __builtin_amdgcn_readlane(w, (int)(d + 1 + lit)) | (__builtin_amdgcn_readlane(w, (int)(d + 2 + lit)) << 8);
-                        if (off == 0 || (I)off > op + lit)
-                            break;
-                        const I rel = (I)lane - d - 1; // my byte is literal `rel` of this sequence
-                        if (rel >= 0 && rel < lit)
-                            s_ring[RING((uint32_t)op + (uint32_t)rel)] = (uint8_t)w;
-                        op += lit;
-                        copy_match(off, ml);
-                        ip += adv;
-                        DEC_CNT(10);
-                        continue;
-                    }
-                }
-            }
-            const uint32_t token = byte_at(ip++);
-            I len = (I)(token >> 4);
-            bool bad = false;
-            if (len == 15)
-            { // read_variable_length(&ip, iend-RUN_MASK, 1), lz4.c:1979-2013
-                uint32_t v;
-                if (ip >= n - 15)
-                    bad = true;
-                else
-                    do
-                    {
-                        v = byte_at(ip++);
-                        len += (I)v;
-                        if (ip > n - 15 || len > cap) // a literal run longer than the capacity is rejected below anyway
-                        {
-                            bad = true;
-                            break;
-                        }
-                    } while (v == 255);
-            }
-            if (bad)
-                break;
-            if (op + len > cap - 12 || ip + len > n - 8)
-            {
-                if (ip + len != n || op + len > cap)
-                    break;
-                copy_lits(ip, op, len);
-                op += len;
-                flush(op + (I)g);
-                result = (uint32_t)op;
-                break;
-            }
-            copy_lits(ip, op, len);
-            ip += len;
-            op += len;
-            const uint32_t off = byte_at(ip) | (byte_at(ip + 1) << 8);
-            ip += 2;
-            if (off == 0 || (I)off > op)
-                break;
-            I ml = (I)(token & 15);
-            if (ml == 15)
-            {
-                uint32_t v;
-                do
-                {
-                    if (ip >= n - 5 + 1)
-                    {
-                        bad = true;
-                        break;
-                    }
-                    v = byte_at(ip++);
-                    ml += (I)v;
-                    if (ml > cap) // rejected below anyway
-                    {
-                        bad = true;
-                        break;
-                    }
-                } while (v == 255);
-            }
-            if (bad)
-                break;
-            ml += 4;
-            if (op + ml > cap - 5)
-                break;
-            copy_match(off, ml);
-            DEC_CNT(11);
-        }
-        DEC_ACC(0);
-#undef RING
-    }
-    if (lane == 0)
-        out_sizes[b] = result;
-}
-
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-#ifdef LTHIP_DEC_PROF
-extern "C" __attribute__((visibility("default"))) int lthip_dec_prof_dump(void)
-{
-    unsigned long long h[16];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dec_prof), sizeof(h)) != hipSuccess)
-        return -1;
-    fprintf(stderr, "lz4 decoder: total %.1f Mcycles (wave-summed), copy_match %.1f (incl. flush), flush %.1f, refills %llu, far matches %llu, "
-                    "short sequences %llu, general sequences %llu\n",
-            h[0] / 1e6, h[2] / 1e6, h[3] / 1e6, h[8], h[9], h[10], h[11]);
-    memset(h, 0, sizeof(h));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_prof), h, sizeof(h));
-    return 0;
-}
-#endif
 
 extern "C" size_t lthip_lz4_bound(size_t size) { return size > 0x7E000000u ? 0 : size + size / 255 + 16; }
 
@@ -2362,41 +1818,5 @@ int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_
     *d_lits = (uint8_t*)lits;
     *d_recs = (uint64_t*)recs;
     *d_meta = meta;
-    return 0;
-}
-
-extern "C" int lthip_lz4_decompress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
-                                           const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
-                                           const uint32_t* dst_caps, uint32_t* d_out_sizes)
-{
-    if (!ctx || !d_out_sizes || (block_count && (!src_offsets || !src_sizes || !dst_offsets || !dst_caps)))
-        return EINVAL;
-    if (block_count == 0)
-        return 0;
-    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
-    Lz4Block* d_blocks = nullptr;
-    uint64_t nseg = 0;
-    int err = upload_blocks(ctx, block_count, src_offsets, src_sizes, dst_offsets, dst_caps, 0, 1, &d_blocks, &nseg);
-    if (err)
-        return err;
-    LaunchTimer t(ctx, LTHIP_K_OTHER);
-    static const bool plain = getenv("LTHIP_LZ4_PLAIN_DECODER") != nullptr; // ablation: every byte through global memory
-    const uint32_t nobatch = getenv("LTHIP_LZ4_NO_BATCH_DECODE") ? 1u : 0u; // ablation: one sequence per step only
-    if (plain)
-        hipLaunchKernelGGL(k_lz4_decode, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, block_count,
-                           (uint8_t*)d_dst, d_out_sizes);
-    else
-    {
-        bool small = true;
-        for (uint32_t b = 0; b < block_count; ++b)
-            small = small && src_sizes[b] < (1u << 30) && dst_caps[b] < (1u << 30);
-        if (small)
-            hipLaunchKernelGGL(k_lz4_decode_lds<int32_t>, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks,
-                               block_count, (uint8_t*)d_dst, d_out_sizes, nobatch);
-        else
-            hipLaunchKernelGGL(k_lz4_decode_lds<int64_t>, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks,
-                               block_count, (uint8_t*)d_dst, d_out_sizes, nobatch);
-    }
-    LTHIP_LAUNCH_CHECK(ctx);
     return 0;
 }

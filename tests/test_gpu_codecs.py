@@ -450,3 +450,87 @@ def test_lz4_gpu_decoder_structured_cases(gpu, oracle):
             assert int(s) == len(r)
             assert (out[o : o + len(r)] == r).all()
             assert (out[o + len(r) : o + len(r) + 8] == 0xCD).all()  # nothing written past the block
+
+
+def test_lz4_block_parallel_decoder(gpu, oracle):
+    """Blocks of two or more 64 KiB units take the block-parallel path (tile walk, link pass, one wave per unit): payloads with a
+    sliding window (the reference's parse: every unit reads what the unit before wrote), payloads of the HIP encoder (independent
+    groups), incompressible and run-length blocks (one sequence spanning many units), sizes around the unit, odd alignments, and a
+    call that mixes them with blocks of the wave-per-block decoder.  Sizes and bytes must be the oracle decoder's."""
+    rng = np.random.default_rng(2024)
+    raws = []
+    for kind, n in ((1, 131072), (1, 131073), (1, 200000), (11, 65536 * 3), (12, 65536 * 5 + 1), (0, 300001), (1, (3 << 20) + 5), (13, 1 << 20)):
+        raws.append(oracle.synth(n, 900 + n % 1000, kind))
+    raws.append(np.zeros(700000, np.uint8))  # one match across ten units
+    raws.append(np.concatenate([rng.integers(0, 256, 100000, dtype=np.uint8), np.zeros(400000, np.uint8), oracle.synth(200000, 5, 1)]))
+    far = rng.integers(0, 256, 60000, dtype=np.uint8)
+    raws.append(np.concatenate([far, oracle.synth(5000, 6, 1), far, far[:30000], oracle.synth(70000, 7, 12), far]))  # offsets near 64 KiB across units
+    raws.append(oracle.synth(4000, 8, 1))  # a small block in the same call: wave-per-block decoder
+    raws.append(oracle.synth(131071, 9, 1))  # one byte short of two units
+    comps_ref = [oracle.lz4_compress(r) for r in raws]
+    comps_hip, _ = gpu_lz4(gpu, raws)
+    for comps in (comps_ref, comps_hip):
+        for shift in (0, 3):
+            offs, pos = [], shift
+            for c in comps:
+                offs.append(pos)
+                pos += len(c) + 16 + shift
+            host = np.zeros(pos + 64, np.uint8)
+            for o, c in zip(offs, comps):
+                host[o : o + len(c)] = c
+            dev = torch.from_numpy(host).cuda()
+            d_offs, total = layout([np.zeros(len(r) + 32, np.uint8) for r in raws])
+            d_offs = [o + shift for o in d_offs]
+            dst = torch.full((total + 64 + shift,), 0xCD, dtype=torch.uint8, device="cuda")
+            sizes = u32(gpu.lz4_decompress_blocks(dev, offs, [len(c) for c in comps], dst, d_offs, [len(r) for r in raws]))
+            out = dst.cpu().numpy()
+            for i, (r, o, s) in enumerate(zip(raws, d_offs, sizes)):
+                assert int(s) == len(r), (i, int(s), len(r))
+                assert (out[o : o + len(r)] == r).all(), i
+                assert (out[o + len(r) : o + len(r) + 8] == 0xCD).all()  # nothing written past the block
+
+
+def test_lz4_block_parallel_decoder_differential_fuzz(gpu, oracle):
+    """Damaged payloads of several units: accepted exactly when the oracle's strict decoder accepts them, with its size and bytes."""
+    rng = np.random.default_rng(4711)
+    raws = [oracle.synth(n, 40 + k, k) for k, n in ((1, 400000), (11, 262144), (12, 150000), (0, 140000))]
+    raws.append(np.concatenate([oracle.synth(100000, 3, 1), np.zeros(300000, np.uint8), oracle.synth(50000, 4, 1)]))
+    hip, _ = gpu_lz4(gpu, raws)
+    cases = []
+    for raw, own in zip(raws, hip):
+        for comp in (oracle.lz4_compress(raw), own):
+            cases.append((comp, len(raw)))
+            for _ in range(16):
+                c = comp.copy()
+                kind = rng.integers(0, 6)
+                if kind == 0:
+                    c = c[: rng.integers(1, len(c))]
+                elif kind == 1:
+                    for _ in range(rng.integers(1, 4)):
+                        c[rng.integers(0, len(c))] ^= 1 << rng.integers(0, 8)
+                elif kind == 2:
+                    c[rng.integers(0, len(c)) :] = 0
+                elif kind == 3:
+                    c[rng.integers(0, len(c))] = 255
+                elif kind == 4:
+                    a = rng.integers(0, len(c) - 2)
+                    c[a : a + 2] = 0  # a zero offset (or a token) somewhere
+                cap = len(raw) if kind != 5 else max(131072, len(raw) + int(rng.integers(-70000, 70000)))
+                cases.append((c, cap))
+    comps = [c for c, _ in cases]
+    caps = [cap for _, cap in cases]
+    dev, offs = to_device(comps)
+    d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
+    dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+    sizes = u32(gpu.lz4_decompress_blocks(dev, offs, [len(c) for c in comps], dst, d_offs, caps))
+    host = dst.cpu().numpy()
+    accepted = 0
+    for i, ((c, cap), o, s) in enumerate(zip(cases, d_offs, sizes)):
+        n, out = oracle.lz4_decompress(c, cap)
+        if n < 0:
+            assert int(s) == 0xFFFFFFFF, (i, int(s))
+        else:
+            assert int(s) == n, (i, int(s), n)
+            assert (host[o : o + n] == out[:n]).all(), i
+            accepted += 1
+    assert 10 <= accepted < len(cases)
