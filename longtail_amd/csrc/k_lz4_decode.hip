@@ -140,7 +140,8 @@ __global__ __launch_bounds__(64) void k_lz4_decode(const uint8_t* __restrict__ s
 // Measured (8 MiB blocks of the "mixed" workload, 100-160 K sequences each): 106 ms per block against 173 ms; what remains is the
 // serial parse itself (77 ms with every copy switched off: ~280 instructions per sequence issued by a single wave), so the
 // throughput of a batch comes from the number of blocks in flight: 41 GB/s at 512 blocks, 140 GB/s at 2048.
-constexpr uint32_t DEC_IN = 4096u, DEC_RING = 8192u, DEC_FLUSH = 2048u;
+constexpr uint32_t DEC_IN = 2048u, DEC_RING = 8192u, DEC_FLUSH = 2048u; // 10 KiB of LDS per decoding wave: 16 per CU
+constexpr int DEC_IN_VECS = DEC_IN / 1024; // 16-byte vectors per lane and refill
 #ifdef LTHIP_DEC_PROF /* debug build only (make prof): where a decoding wave spends its cycles */
 __device__ unsigned long long g_dec_prof[16];
 #define DEC_T0() const unsigned long long t0__ = clock64()
@@ -205,15 +206,15 @@ struct PdReader
                 wa = a & ~(int64_t)15;
                 const int64_t end = (int64_t)n + head;
                 __syncthreads();
-                uint4 q[4];
+                uint4 q[DEC_IN_VECS];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < DEC_IN_VECS; ++u)
                 {
                     const int64_t o = wa + 16 * (int64_t)(u * 64 + lane);
                     q[u] = *reinterpret_cast<const uint4*>(in_al + (o < end ? o : wa));
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < DEC_IN_VECS; ++u)
                     reinterpret_cast<uint4*>(s_in)[u * 64 + lane] = q[u];
                 __syncthreads();
             }
@@ -287,6 +288,7 @@ struct PdPos
 // time: every lane reads its byte of the window as a token and computes where the next token would be and what the sequence
 // would produce (no length bytes, or one match-length byte below 255 inside the window; anything else is left to pd_hop), then
 // the chain is a walk over two registers: two readlanes and a dozen scalar instructions per sequence (pd_hop: ~80).
+template <bool OPSTOP> // OPSTOP = false: op_stop is "never" (the test per sequence is compiled out)
 __device__ __forceinline__ PdPos pd_walk(PdReader& r, int64_t ip, uint64_t op, const int64_t ip_stop, const uint64_t op_stop, const uint64_t cap)
 {
     const int32_t n = (int32_t)r.n; // below 2^31 (LZ4_MAX_INPUT_SIZE)
@@ -313,35 +315,29 @@ __device__ __forceinline__ PdPos pd_walk(PdReader& r, int64_t ip, uint64_t op, c
             simple = simple && e < 64u && pl + 3 + (int32_t)litl < n - 4 && ext != 255u;
         const uint32_t outv = litl + mlcl + 4u + (one ? ext : 0u);
         const uint32_t nxtv = e + (one ? 1u : 0u);
-        const uint64_t ok = __builtin_amdgcn_ballot_w64(simple);
-        // 32-bit running values: op stays below op_limit + 300 < 2^32
+        // 32-bit running values: op stays below op_limit + 64 x 300 < 2^32
         uint32_t o32 = (uint32_t)op;
         const uint32_t stop32 = op_stop < 0xFFFFFFFFull ? (uint32_t)op_stop : 0xFFFFFFFFu;
         const uint32_t limit32 = (uint32_t)op_limit;
         const uint32_t left = ip_stop - ip < 0x7FFFFFFF ? (uint32_t)(ip_stop - ip) : 0x7FFFFFFFu; // the walk stops at relative position >= left
+        uint64_t ok = __builtin_amdgcn_ballot_w64(simple);
+        if (left < 64u)
+            ok &= (1ull << left) - 1ull; // no token at or past the bound is followed
         uint32_t cur = 0;
         int why = 0; // 1: bound reached, 2: damage, 0: window exhausted or a token for pd_hop
-        while (cur < 64u && ((ok >> cur) & 1ull))
+        while (cur < 64u && ((ok >> cur) & 1ull)) // per sequence: a bit test, two readlanes, an add
         {
             const uint32_t o = __builtin_amdgcn_readlane(outv, (int)cur);
-            if (o32 + o > stop32)
+            if (OPSTOP && o32 + o > stop32)
             {
                 why = 1;
                 break;
             }
             o32 += o;
-            if (o32 > limit32)
-            {
-                why = 2;
-                break;
-            }
             cur = __builtin_amdgcn_readlane(nxtv, (int)cur);
-            if (cur >= left)
-            {
-                why = 1;
-                break;
-            }
         }
+        if (!why)
+            why = o32 > limit32 ? 2 : cur >= left ? 1 : 0;
         ip += cur;
         op = (op & ~0xFFFFFFFFull) | o32;
         if (why)
@@ -369,11 +365,11 @@ __device__ __forceinline__ PdPos pd_walk(PdReader& r, int64_t ip, uint64_t op, c
 __device__ __forceinline__ PdTile pd_walk_tile(PdReader& r, int64_t start, const int64_t t0, const int64_t t1, const uint64_t cap)
 {
     PdTile rec{PD_NONE, 0u, 0u, 0u};
-    PdPos a = pd_walk(r, start, 0, t0, ~0ull, cap); // to the first token at or past t0
+    PdPos a = pd_walk<false>(r, start, 0, t0, ~0ull, cap); // to the first token at or past t0
     if (a.kind == 0 && a.ip < t1)
     {
         rec.entry = (uint32_t)a.ip;
-        a = pd_walk(r, a.ip, 0, t1, ~0ull, cap);
+        a = pd_walk<false>(r, a.ip, 0, t1, ~0ull, cap);
     }
     else if (a.kind == 0)
         a.op = 0; // jumped over the tile
@@ -422,15 +418,15 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
             wa = a & ~(I)15;
             const I end = n + (I)head; // first aligned offset past the payload
             __syncthreads();
-            uint4 q[4]; // four loads in flight; vectors past the payload re-read the window's first one (their bytes are never used)
+            uint4 q[DEC_IN_VECS]; // loads in flight; vectors past the payload re-read the window's first one (their bytes are never used)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < DEC_IN_VECS; ++u)
             {
                 const I o = wa + 16 * (I)(u * 64 + lane);
                 q[u] = *reinterpret_cast<const uint4*>(in_al + (int64_t)(o < end ? o : wa));
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < DEC_IN_VECS; ++u)
                 reinterpret_cast<uint4*>(s_in)[u * 64 + lane] = q[u];
             __syncthreads();
         }
@@ -614,7 +610,7 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
                 {
                     PdReader rd;
                     rd.init(in, (uint32_t)n, s_in, lane);
-                    const PdPos at = pd_walk(rd, un.ip0, (uint64_t)un.op0, INT64_MAX, (uint64_t)lo, (uint64_t)cap);
+                    const PdPos at = pd_walk<true>(rd, un.ip0, (uint64_t)un.op0, INT64_MAX, (uint64_t)lo, (uint64_t)cap);
                     ip = (I)at.ip; // the covering sequence (or where the chain broke: the loop below reports it)
                     op = (I)at.op;
                     wa = -(I)DEC_IN; // the reader went through s_in: nothing the decoder knows about is in it any more
@@ -1093,16 +1089,42 @@ __device__ __forceinline__ uint32_t pd_block_of(const PdBlock* __restrict__ bloc
     return lo;
 }
 
+// Where the first sequence of every block ends: a block of incompressible data is ONE sequence (a token, 32 K length bytes, the
+// literals); tiles that lie inside it need no walk.
+__global__ __launch_bounds__(64) void k_lz4_pd_first(const uint8_t* __restrict__ src, const PdBlock* __restrict__ blocks, uint32_t nblocks,
+                                                     uint32_t* __restrict__ first_end)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN];
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks)
+        return;
+    const PdBlock blk = blocks[b];
+    PdReader r;
+    r.init(src + blk.src_off, blk.size, s_in, threadIdx.x);
+    int64_t next = 0;
+    uint64_t out = 0;
+    const int kind = pd_hop(r, 0, blk.dst_cap, next, out);
+    if (threadIdx.x == 0)
+        first_end[b] = kind == 2 ? 0u : (uint32_t)next;
+}
+
 __global__ __launch_bounds__(64) void k_lz4_pd_tiles(const uint8_t* __restrict__ src, const PdBlock* __restrict__ blocks, uint32_t nblocks,
-                                                     uint32_t ntiles, PdTile* __restrict__ tiles)
+                                                     uint32_t ntiles, PdTile* __restrict__ tiles, const uint32_t* __restrict__ first_end)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN];
     const uint32_t t = blockIdx.x;
     if (t >= ntiles)
         return;
     const int lane = threadIdx.x;
-    const PdBlock blk = blocks[pd_block_of(blocks, nblocks, t, true)];
+    const uint32_t b = pd_block_of(blocks, nblocks, t, true);
+    const PdBlock blk = blocks[b];
     const uint32_t j = t - blk.tile_base;
+    if (j > 0 && ((uint64_t)j + 1) * PD_TILE <= first_end[b]) // inside the block's first sequence: no token of the chain is here
+    {
+        if (threadIdx.x == 0)
+            tiles[t] = PdTile{PD_NONE, 0u, 0u, 0u};
+        return;
+    }
     PdReader r;
     r.init(src + blk.src_off, blk.size, s_in, lane);
     const int64_t t0 = (int64_t)j * PD_TILE;
@@ -1387,10 +1409,10 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
         for (uint32_t k = 0; k < rows; ++k)
             row_base[(size_t)k + 1] = row_base[k] + count[k];
     }
-    // device tables: [PdTile x ntiles][tile_op x ntiles][unit_tile x nunits][state x nb][order x nb][row_base x rows+1][done x nunits][counters x 8]
+    // device tables: [PdTile x ntiles][tile_op x ntiles][unit_tile x nunits][state x nb][order x nb][row_base x rows+1][done x nunits][counters x 8][first_end x nb]
     const size_t o_tiles = 0, o_top = o_tiles + sizeof(PdTile) * ntiles, o_ut = o_top + 4 * ntiles, o_state = o_ut + 4 * nunits,
                  o_order = o_state + sizeof(PdState) * nb, o_rows = o_order + 4 * (size_t)nb, o_done = o_rows + 4 * ((size_t)rows + 1),
-                 o_cnt = o_done + 4 * nunits, o_end = o_cnt + 32;
+                 o_cnt = o_done + 4 * nunits, o_first = o_cnt + 32, o_end = o_first + 4 * (size_t)nb;
     void *tab, *blk;
     int err = lthip_scratch(ctx, S_LZ4_STREAM, o_end, &tab);
     if (!err)
@@ -1406,7 +1428,7 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     if (err)
         return err;
     uint8_t* t8 = (uint8_t*)tab;
-    LTHIP_CHECK(ctx, hipMemsetAsync(t8 + o_done, 0, o_end - o_done, ctx->stream)); // flags and counters: zero before every launch
+    LTHIP_CHECK(ctx, hipMemsetAsync(t8 + o_done, 0, o_first - o_done, ctx->stream)); // flags and counters: zero before every launch
     const PdBlock* d_blocks = (const PdBlock*)blk;
     PdTile* d_tiles = (PdTile*)(t8 + o_tiles);
     uint32_t* d_top = (uint32_t*)(t8 + o_top);
@@ -1414,6 +1436,7 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     PdState* d_state = (PdState*)(t8 + o_state);
     uint32_t* d_done = (uint32_t*)(t8 + o_done);
     uint32_t* d_cnt = (uint32_t*)(t8 + o_cnt);
+    uint32_t* d_first = (uint32_t*)(t8 + o_first);
     static const bool stats = getenv("LTHIP_LZ4_PD_STATS") != nullptr;
     static const bool trace = getenv("LTHIP_LZ4_PD_TRACE") != nullptr; // debugging: synchronize and report after every launch
 #define PD_TRACE(what)                                                                 \
@@ -1425,7 +1448,10 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
             fprintf(stderr, "lz4 parallel decode: %s -> %s\n", what, hipGetErrorString(e__)); \
         }                                                                              \
     } while (0)
-    hipLaunchKernelGGL(k_lz4_pd_tiles, dim3((uint32_t)ntiles), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, nb, (uint32_t)ntiles, d_tiles);
+    hipLaunchKernelGGL(k_lz4_pd_first, dim3(nb), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, nb, d_first);
+    LTHIP_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_lz4_pd_tiles, dim3((uint32_t)ntiles), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, nb, (uint32_t)ntiles, d_tiles,
+                       d_first);
     LTHIP_LAUNCH_CHECK(ctx);
     PD_TRACE("tiles");
     hipLaunchKernelGGL(k_lz4_pd_link, dim3(nb), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, nb, d_tiles, d_top, d_ut, d_state,
@@ -1443,7 +1469,7 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     static const uint32_t per_cu = [] {
         const char* e = getenv("LTHIP_LZ4_PD_WG_PER_CU");
         const int v = e ? atoi(e) : 0;
-        return (uint32_t)(v > 0 ? v : 13); // 12 KiB of LDS each
+        return (uint32_t)(v > 0 ? v : 16); // 10 KiB of LDS each
     }();
     const uint64_t resident = (uint64_t)ncu * per_cu;
     const uint32_t grid = (uint32_t)(tk.total < resident ? tk.total : resident);
