@@ -51,6 +51,8 @@ __device__ unsigned long long g_zb_last[1 << 16];
     } while (0)
 #define ZD_MARK(i) ZB_MARK(i)
 #endif
+__device__ uint32_t g_zd_ablate; /* timing experiments only (LTHIP_ZSTD_ABLATE): 1 = no sequence execution, 2 = no Huffman decode */
+#define ZD_ABLATE g_zd_ablate
 #include "zstd_decode_core.h" /* includes zstd_block_core.h */
 
 namespace
@@ -501,20 +503,39 @@ __global__ void k_zstd_split(const uint8_t* __restrict__ src, const ZBlock* __re
     }
 }
 
+// What k_zstd_prepare leaves for k_zstd_execute about one piece
+enum : uint32_t { ZP_READY = 0u, ZP_DONE = 1u, ZP_SERIAL = 2u };
+struct ZPrep
+{
+    uint64_t bits_off;  // absolute offset (in the source arena) of the sequences' bit-stream
+    uint32_t bits_size;
+    uint32_t nbseq;
+    uint32_t nlit;
+    uint32_t status;    // ZP_READY: literals + tables exported; ZP_DONE: nothing left to do; ZP_SERIAL: the serial piece decoder takes it
+    uint32_t log[3];    // table logs (0: an RLE table, one entry)
+    uint32_t expect;    // bytes the piece has to produce
+};
+constexpr uint32_t ZT_ENTRIES = 512u; // per table and piece: u64 {new-state base:16 | state bits:8 | extra bits:8 | baseline:32}
+
 // PIECES selects the item kind the launch works on: the mode of the decoder core is then a compile-time constant (with a run-time
 // mode the whole-payload path ran 4.6x slower per wave -- measured; the two flavours are launched back to back)
 template <bool PIECES>
 __global__ __launch_bounds__(64) void k_zstd_decode(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, const ZItem* __restrict__ items,
                                                     const uint32_t* __restrict__ item_count, uint8_t* __restrict__ dst,
-                                                    uint8_t* __restrict__ lit_scratch, uint32_t* __restrict__ out_sizes)
+                                                    uint8_t* __restrict__ lit_scratch, uint32_t* __restrict__ out_sizes,
+                                                    const ZPrep* __restrict__ prep)
 {
     __shared__ ZdShared sh;
     uint8_t* lits = lit_scratch + (uint64_t)blockIdx.x * (ZD_LIT_MAX + 64u);
     const uint32_t nitems = *item_count;
+    if (threadIdx.x == 0)
+        sh.v[ZDV_PREP] = 0;
     for (uint32_t i = blockIdx.x; i < nitems; i += gridDim.x)
     {
         const ZItem it = items[i];
         if (it.kind != (PIECES ? 2u : 1u))
+            continue;
+        if (PIECES && prep && prep[i].status != ZP_SERIAL) // the two-stage path below has done it (or will report it)
             continue;
         const ZBlock blk = blocks[it.payload];
 #ifdef LTHIP_ZB_PROF
@@ -538,6 +559,517 @@ __global__ __launch_bounds__(64) void k_zstd_decode(const uint8_t* __restrict__ 
         __syncthreads();
     }
 }
+// ---------------------------------------------------------------------------------------------------
+// Two-stage decoding of pieces.  The serial piece decoder above spends 3/4 of its time in the sequence decoder: lane 0 of a wave
+// walks the FSE state machine with vector instructions and a dependent global load per sequence, and then the whole wave copies ONE
+// sequence through global memory.  Here:
+//   k_zstd_prepare  runs the decoder core up to the sequence loop (block header, literals -- Huffman streams on four lanes --, the
+//                   three FSE tables) and exports the literals and the tables of the piece to global memory, the tables with the
+//                   code's baseline and extra-bit count folded into every entry;
+//   k_zstd_execute  per piece: the state machine runs on the SCALAR unit (tables and bit-stream are read-only here, every load is
+//                   an s_load; 64 sequences at a time, each dropped into "its" lane with v_writelane), then the vector unit executes
+//                   the 64 sequences together: prefix sums place them, short literal runs and matches are copied by the
+//                   sequences' own lanes (dependency rounds as in the LZ4 batch decoder), long ones by the whole wave, all through
+//                   an 8 KiB LDS ring that leaves for global memory with aligned 16-byte stores.
+// Anything unusual (a check that fails, a table or literal form the export does not cover) marks the piece ZP_SERIAL: the serial
+// piece decoder then decodes it and reports errors exactly as it always did.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_zstd_prepare(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, const ZItem* __restrict__ items,
+                                                     const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
+                                                     uint8_t* __restrict__ dst, uint8_t* __restrict__ lit_scratch, uint64_t* __restrict__ tables,
+                                                     ZPrep* __restrict__ prep, const uint32_t* __restrict__ out_sizes)
+{
+    __shared__ ZdShared sh;
+    const uint32_t nitems = *item_count < item1 ? *item_count : item1;
+    const int lane = threadIdx.x;
+    for (uint32_t i = item0 + blockIdx.x; i < nitems; i += gridDim.x)
+    {
+        const ZItem it = items[i];
+        if (it.kind != 2u)
+            continue;
+        const ZBlock blk = blocks[it.payload];
+        const uint32_t slot = i - item0;
+        uint8_t* lits = lit_scratch + (uint64_t)slot * (ZD_LIT_MAX + 64u);
+        if (lane == 0)
+            sh.v[ZDV_PREP] = 1;
+        __syncthreads();
+        const uint32_t content = out_sizes[it.payload] == ZD_ERROR ? 0u : out_sizes[it.payload]; // k_zstd_split stated it
+        const uint32_t expect = content > it.out0 ? (content - it.out0 < ZB ? content - it.out0 : ZB) : 0u;
+        const uint32_t n = zd_decode_payload_ex(src + it.src_off, it.size, dst + blk.dst_off, blk.dst_cap, lits, &sh, lane, it.out0);
+        ZPrep pr;
+        pr.bits_off = 0;
+        pr.bits_size = pr.nbseq = pr.nlit = 0;
+        pr.log[0] = pr.log[1] = pr.log[2] = 0;
+        pr.expect = expect;
+        pr.status = ZP_SERIAL;
+        if (n == ZD_PREPARED)
+        {
+            pr.bits_off = it.src_off + sh.v[ZDV_OFF];
+            pr.bits_size = sh.v[ZDV_LEN];
+            pr.nbseq = sh.v[ZDV_LL];
+            pr.nlit = sh.v[ZDV_ML];
+            bool ok = expect != 0u && pr.bits_size != 0u;
+            uint64_t* tp = tables + (uint64_t)slot * 3u * ZT_ENTRIES;
+            for (int t = 0; t < 3; ++t)
+            {
+                const ZdFse* f = &sh.fse[t];
+                const uint32_t size = f->valid == 2u ? 1u : f->valid == 1u ? 1u << f->log : 0u;
+                ok = ok && size != 0u && size <= ZT_ENTRIES;
+                pr.log[t] = f->valid == 2u ? 0u : f->log;
+                for (uint32_t e = lane; e < size && size <= ZT_ENTRIES; e += 64)
+                {
+                    const uint32_t sym = f->sym[e];
+                    uint32_t baseline, ebits;
+                    if (t == ZT_LL)
+                    {
+                        baseline = zb_ll_base(sym & 63u);
+                        ebits = zb_ll_bits(sym & 63u);
+                        ok = ok && sym <= 35u;
+                    }
+                    else if (t == ZT_ML)
+                    {
+                        baseline = zb_ml_base(sym & 63u) + 3u;
+                        ebits = zb_ml_bits(sym & 63u);
+                        ok = ok && sym <= 52u;
+                    }
+                    else
+                    {
+                        baseline = 1u << (sym & 31u);
+                        ebits = sym & 31u;
+                        ok = ok && sym <= 31u;
+                    }
+                    tp[(uint32_t)t * ZT_ENTRIES + e] = (uint64_t)f->base[e] | ((uint64_t)f->nb[e] << 16) | ((uint64_t)ebits << 24) | ((uint64_t)baseline << 32);
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull)
+                pr.status = ZP_READY;
+        }
+        else if (n != ZD_ERROR && n == expect && content != 0u)
+            pr.status = ZP_DONE; // a raw or RLE block, or one without sequences: the core has written it
+        if (lane == 0)
+            prep[i] = pr;
+        __syncthreads();
+    }
+}
+
+constexpr uint32_t ZX_RING = 8192u, ZX_FLUSH = 2048u, ZX_LIT = 2048u;
+constexpr uint32_t ZX_LL_LANE = 16u, ZX_ML_LANE = 64u;       // what a sequence's own lane copies
+constexpr uint32_t ZX_RING_SAFE = ZX_RING - 64u * 80u - 64u; // a run appends at most 64 x (16 + 64) bytes ahead of `op`
+
+// output of one piece: LDS ring + flush, literal stream through an LDS window (piece-local 32-bit positions)
+struct ZxOut
+{
+    uint8_t* s_ring;
+    uint8_t* s_lit;
+    uint8_t* out_al;       // piece output byte q is out_al[q + g]
+    const uint8_t* lit_al; // literal p is lit_al[p + lh]
+    uint32_t g, lh, nlit, cap;
+    int lane;
+    uint32_t op, flushed, drained;
+    int32_t lwa; // aligned literal offset of s_lit[0]
+
+    __device__ __forceinline__ uint32_t ring(uint32_t q) const { return (q + g) & (ZX_RING - 1u); }
+    __device__ __forceinline__ void flush(uint32_t upto) // aligned offsets [flushed, upto)
+    {
+        while (flushed < upto)
+        {
+            const uint32_t stop = upto - flushed < ZX_FLUSH ? upto : flushed + ZX_FLUSH;
+            const uint32_t lim = stop < cap + g ? stop : cap + g;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+            {
+                const uint32_t P = flushed + 16u * (uint32_t)(u * 64 + lane);
+                if (P >= stop)
+                    continue;
+                const uint8_t* r = s_ring + (P & (ZX_RING - 1u));
+                if (P >= g && P + 16u <= lim)
+                    *reinterpret_cast<uint4*>(out_al + P) = *reinterpret_cast<const uint4*>(r);
+                else
+                    for (uint32_t k = 0; k < 16u; ++k)
+                        if (P + k >= g && P + k < lim)
+                            out_al[P + k] = r[k];
+            }
+            flushed = stop;
+        }
+    }
+    __device__ __forceinline__ void maybe_flush()
+    {
+        if (op + g - flushed >= ZX_FLUSH)
+            flush((op + g) & ~(ZX_FLUSH - 1u));
+    }
+    // literals [p, p + k) resident in s_lit (k <= 1100); returns the index of p
+    __device__ __forceinline__ uint32_t need_lit(uint32_t p, uint32_t k)
+    {
+        const int32_t a = (int32_t)(p + lh);
+        if (a < lwa || a + (int32_t)k > lwa + (int32_t)ZX_LIT)
+        {
+            lwa = a & ~15;
+            __builtin_amdgcn_wave_barrier();
+            uint4 q[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                q[u] = *reinterpret_cast<const uint4*>(lit_al + lwa + 16 * (u * 64 + lane)); // the scratch slot is padded: always readable
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                reinterpret_cast<uint4*>(s_lit)[u * 64 + lane] = q[u];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        return (uint32_t)(a - lwa);
+    }
+    __device__ __forceinline__ void copy_lits(uint32_t p, uint32_t len) // the whole wave, appended at op
+    {
+        while (len)
+        {
+            const uint32_t i = need_lit(p, 1);
+            uint32_t c = ZX_LIT - i;
+            c = c < ZX_FLUSH ? c : ZX_FLUSH;
+            c = c < len ? c : len;
+            for (uint32_t j = lane; j < c; j += 64)
+                s_ring[ring(op + j)] = s_lit[i + j];
+            p += c;
+            op += c;
+            len -= c;
+            maybe_flush();
+        }
+    }
+    __device__ __forceinline__ void copy_match(uint32_t off, uint32_t ml) // the whole wave, appended at op; 1 <= off <= op
+    {
+        while (ml)
+        {
+            const uint32_t seg = ml < ZX_FLUSH ? ml : ZX_FLUSH;
+            if (off <= ZX_RING)
+            {
+                const uint32_t base = op - off;
+                if (off >= 64u)
+                    for (uint32_t j = lane; j < seg; j += 64)
+                        s_ring[ring(op + j)] = s_ring[ring(base + j)];
+                else
+                    for (uint32_t j0 = 0; j0 < seg; j0 += 64) // 64 bytes at a time read only what is final: byte j = seed byte j mod off
+                    {
+                        const uint32_t j = j0 + (uint32_t)lane;
+                        if (j < seg)
+                            s_ring[ring(op + j)] = s_ring[ring(base + j % off)];
+                    }
+            }
+            else
+            {
+                if (op - off + seg + g > drained) // the source was flushed: have those stores landed?
+                {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_s_waitcnt(0);
+                    drained = flushed;
+                }
+                for (uint32_t j = lane; j < seg; j += 64) // off > 8192 >= seg: no overlap
+                    s_ring[ring(op + j)] = out_al[op - off + j + g];
+            }
+            op += seg;
+            ml -= seg;
+            maybe_flush();
+        }
+    }
+};
+
+__device__ __forceinline__ uint32_t zx_u(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// The sequences' bit-stream, read backwards, on the scalar unit.  Per sequence ONE aligned 16-byte load that ends with the dword holding
+// the next bit (a sequence takes at most 89 bits: offset 31, lengths 16 + 16, states 9 + 9 + 8), then two 64-bit accumulators with
+// the next bits on top -- the three extra-bit fields (<= 63 bits) come out of the first, the three state fields out of the second --
+// so that a field costs two shifts.  Values only, no indexing: everything stays in SGPRs.
+struct ZxBits
+{
+    const uint32_t* arena; // dword view of the source
+    uint64_t base;         // arena bit of the stream's bit 0
+    uint64_t lo, hi;       // window bits 0..63 / 64..127
+    uint64_t wbit0;        // arena bit of window bit 0
+    uint64_t acc;          // the next bits to read, first one on top
+    uint32_t pos;          // bits of the stream not consumed yet
+    __device__ __forceinline__ void load_window()
+    {
+        const uint64_t top = base + (uint64_t)pos; // arena bit one past the next bit to read
+        uint64_t d = (top + 31ull) >> 5;           // dword one past the one holding bit top - 1
+        d = d >= 4ull ? d - 4ull : 0ull;
+        const uint32_t a = zx_u(arena[d]), b = zx_u(arena[d + 1]), c = zx_u(arena[d + 2]), e = zx_u(arena[d + 3]);
+        lo = ((uint64_t)b << 32) | a;
+        hi = ((uint64_t)e << 32) | c;
+        wbit0 = d * 32ull;
+    }
+    // acc = the 64 bits below pos (zeros below the window's bit 0, which only happens where the stream has no bits either)
+    __device__ __forceinline__ void normalize()
+    {
+        const uint32_t r = (uint32_t)(base + (uint64_t)pos - wbit0); // window bit one past the next bit: 1 .. 128
+        const uint32_t s = 128u - r;                                  // shift the 128-bit window left by s, keep the upper half
+        const uint64_t up = (hi << (s & 63u)) | ((s & 63u) ? lo >> (64u - (s & 63u)) : 0ull);
+        acc = s < 64u ? up : lo << (s & 63u);
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t n) // n <= 32 bits off the top of acc (at most 64 between two normalize())
+    {
+        const uint32_t v = (uint32_t)((acc >> 1) >> (63u - n));
+        acc <<= n;
+        pos -= n;
+        return v;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_zstd_execute(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, const ZItem* __restrict__ items,
+                                                     const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
+                                                     uint8_t* __restrict__ dst, const uint8_t* __restrict__ lit_scratch,
+                                                     const uint64_t* __restrict__ tables, const ZPrep* __restrict__ prep,
+                                                     uint32_t* __restrict__ status_out)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZX_RING];
+    __shared__ __attribute__((aligned(16))) uint8_t s_lit[ZX_LIT];
+    const uint32_t i = item0 + blockIdx.x;
+    if (i >= item1 || i >= *item_count)
+        return;
+    const ZItem it = items[i];
+    if (it.kind != 2u)
+        return;
+    const ZPrep pr = prep[i];
+    if (pr.status != ZP_READY)
+        return;
+    const int lane = threadIdx.x;
+    const ZBlock blk = blocks[it.payload];
+    const uint32_t slot = i - item0;
+    const uint64_t* tl = tables + (uint64_t)slot * 3u * ZT_ENTRIES + ZT_LL * ZT_ENTRIES;
+    const uint64_t* to = tables + (uint64_t)slot * 3u * ZT_ENTRIES + ZT_OF * ZT_ENTRIES;
+    const uint64_t* tm = tables + (uint64_t)slot * 3u * ZT_ENTRIES + ZT_ML * ZT_ENTRIES;
+    const uint8_t* lits = lit_scratch + (uint64_t)slot * (ZD_LIT_MAX + 64u);
+    uint8_t* out = dst + blk.dst_off + it.out0;
+
+    ZxOut zx;
+    zx.s_ring = s_ring;
+    zx.s_lit = s_lit;
+    zx.g = (uint32_t)((uintptr_t)out & 15u);
+    zx.out_al = out - zx.g;
+    zx.lh = (uint32_t)((uintptr_t)lits & 15u);
+    zx.lit_al = lits - zx.lh;
+    zx.nlit = pr.nlit;
+    zx.cap = pr.expect;
+    zx.lane = lane;
+    zx.op = 0;
+    zx.flushed = zx.drained = 0;
+    zx.lwa = -(int32_t)ZX_LIT;
+
+    // ---- the bit-stream, read backwards: bit k of the stream is bit (8 * bits_off + k) of the arena; a sequence takes at most 89 bits
+    // (offset 31 + lengths 16 + 16 + states 9 + 9 + 8): four aligned dwords that end with the dword holding the next bit cover it ----
+    const uint64_t base_bit = pr.bits_off * 8ull;
+    const uint32_t* arena = reinterpret_cast<const uint32_t*>(src - ((uintptr_t)src & 3u)); // dword view; bit b of src = bit b + 8 * skew here
+    const uint64_t skew_bits = 8ull * ((uintptr_t)src & 3u);
+    bool bad = false;
+    uint32_t pos = 0; // bits of the stream not consumed yet
+    {
+        const uint32_t last = src[pr.bits_off + pr.bits_size - 1u];
+        if (last == 0u)
+            bad = true;
+        else
+            pos = (pr.bits_size - 1u) * 8u + (31u - (uint32_t)__builtin_clz(last));
+    }
+    pos = zx_u(pos);
+    ZxBits br;
+    br.arena = arena;
+    br.base = base_bit + skew_bits;
+    br.pos = pos;
+    br.lo = br.hi = br.acc = 0;
+    br.wbit0 = 0;
+    uint32_t sl = 0, so = 0, sm = 0;
+    if (!bad)
+    {
+        if (pr.log[ZT_LL] + pr.log[ZT_OF] + pr.log[ZT_ML] > br.pos)
+            bad = true;
+        else
+        {
+            br.load_window();
+            br.normalize();
+            sl = br.take(pr.log[ZT_LL]);
+            so = br.take(pr.log[ZT_OF]);
+            sm = br.take(pr.log[ZT_ML]);
+        }
+    }
+    uint32_t litpos = 0, produced = 0; // what the decoded sequences consume / produce (scalar bookkeeping of the checks)
+    for (uint32_t s0 = 0; s0 < pr.nbseq && !bad; s0 += 64u)
+    {
+        const uint32_t cnt = pr.nbseq - s0 < 64u ? pr.nbseq - s0 : 64u;
+        // ---- scalar unit: the next `cnt` sequences into lanes 0 .. cnt-1 ----
+        uint32_t r_ll = 0, r_ml = 0, r_off = 0;
+        for (uint32_t k = 0; k < cnt; ++k)
+        {
+            const uint2 ql = *reinterpret_cast<const uint2*>(tl + sl), qo = *reinterpret_cast<const uint2*>(to + so),
+                        qm = *reinterpret_cast<const uint2*>(tm + sm);
+            const uint64_t el = ((uint64_t)zx_u(ql.y) << 32) | zx_u(ql.x), eo = ((uint64_t)zx_u(qo.y) << 32) | zx_u(qo.x),
+                           em = ((uint64_t)zx_u(qm.y) << 32) | zx_u(qm.x);
+            const uint32_t ob = (uint32_t)(eo >> 24) & 255u, mb = (uint32_t)(em >> 24) & 255u, lb = (uint32_t)(el >> 24) & 255u;
+            const bool more = s0 + k + 1u < pr.nbseq;
+            const uint32_t nbl = more ? (uint32_t)(el >> 16) & 255u : 0u, nbm = more ? (uint32_t)(em >> 16) & 255u : 0u,
+                           nbo = more ? (uint32_t)(eo >> 16) & 255u : 0u;
+            if (ob + mb + lb + nbl + nbm + nbo > br.pos)
+            {
+                bad = true; // the stream runs out: the serial decoder says how
+                break;
+            }
+            br.load_window();
+            br.normalize();
+            const uint32_t ov = (uint32_t)(eo >> 32) + br.take(ob);
+            const uint32_t ml = (uint32_t)(em >> 32) + br.take(mb);
+            const uint32_t ll = (uint32_t)(el >> 32) + br.take(lb);
+            if (more)
+            {
+                br.normalize();
+                sl = ((uint32_t)el & 0xFFFFu) + br.take(nbl);
+                sm = ((uint32_t)em & 0xFFFFu) + br.take(nbm);
+                so = ((uint32_t)eo & 0xFFFFu) + br.take(nbo);
+            }
+            // (what the serial decoder checks per sequence is checked for the whole batch by the vector unit below)
+            {
+                // into lane k of the three record registers (gfx9 allows one SGPR per VOP3: the lane select goes through M0)
+                const uint32_t a = zx_u(ll), b = zx_u(ml), c = zx_u(ov), kk = zx_u(k);
+                uint32_t keep;
+                asm volatile("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %7\n\ts_nop 4\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\t"
+                             "v_writelane_b32 %2, %6, m0\n\ts_mov_b32 m0, %3"
+                             : "+v"(r_ll), "+v"(r_ml), "+v"(r_off), "=&s"(keep)
+                             : "s"(a), "s"(b), "s"(c), "s"(kk));
+            }
+        }
+        if (bad)
+            break;
+        if (s0 + cnt == pr.nbseq && br.pos != 0u)
+        {
+            bad = true; // the bit-stream must be consumed exactly
+            break;
+        }
+        // ---- vector unit: the serial decoder's checks for all of them at once, then execution ----
+        const uint32_t ll = (uint32_t)lane < cnt ? r_ll : 0u, ml = (uint32_t)lane < cnt ? r_ml : 0u, off = r_off - 3u;
+        uint32_t batch_ll, batch_adv;
+        {
+            uint32_t i_l = ll, i_a = ll + ml; // inclusive prefix sums: literals / output up to and including my sequence
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1)
+            {
+                const uint32_t x = (uint32_t)__shfl_up((int)i_l, d, 64), y = (uint32_t)__shfl_up((int)i_a, d, 64);
+                if (lane >= d)
+                {
+                    i_l += x;
+                    i_a += y;
+                }
+            }
+            batch_ll = (uint32_t)__shfl((int)i_l, 63, 64);
+            batch_adv = (uint32_t)__shfl((int)i_a, 63, 64);
+            // a piece may not use repeat offsets (ov <= 3); literals and output must fit; an offset may not reach below the piece
+            const bool wrong = (uint32_t)lane < cnt && (r_off <= 3u || ll > 131072u || ml > 131075u || litpos + i_l > pr.nlit ||
+                                                         produced + i_a > pr.expect || off > produced + i_a - ml);
+            if (__builtin_amdgcn_ballot_w64(wrong))
+            {
+                bad = true;
+                break;
+            }
+        }
+        const bool small = ll <= ZX_LL_LANE && ml <= ZX_ML_LANE && !(ml > 18u && off > ZX_RING_SAFE);
+        const uint64_t smallm = __builtin_amdgcn_ballot_w64(small && (uint32_t)lane < cnt);
+        uint32_t start = 0;
+        static_assert(ZX_RING_SAFE > 2048u, "ring too small for a run");
+        uint32_t lit_cur = litpos; // literal position of sequence `start`
+        litpos += batch_ll;
+        produced += batch_adv;
+        while (start < cnt)
+        {
+            if (!((smallm >> start) & 1ull))
+            {
+                // one sequence by the whole wave
+                const uint32_t gl = zx_u((uint32_t)__builtin_amdgcn_readlane(r_ll, (int)start)), gm = zx_u((uint32_t)__builtin_amdgcn_readlane(r_ml, (int)start)),
+                               go = zx_u((uint32_t)__builtin_amdgcn_readlane(r_off, (int)start)) - 3u;
+                zx.copy_lits(lit_cur, gl);
+                lit_cur += gl;
+                zx.copy_match(go, gm);
+                ++start;
+                continue;
+            }
+            // a run of small sequences: lanes [start, start + k)
+            uint64_t runm = smallm >> start;
+            const uint32_t k = runm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~runm);
+            const bool in = (uint32_t)lane >= start && (uint32_t)lane < start + k;
+            const uint32_t a_ll = in ? ll : 0u, a_adv = in ? ll + ml : 0u;
+            uint32_t i_ll = a_ll, i_adv = a_adv; // inclusive prefix sums
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1)
+            {
+                const uint32_t x = (uint32_t)__shfl_up((int)i_ll, d, 64), y = (uint32_t)__shfl_up((int)i_adv, d, 64);
+                if (lane >= d)
+                {
+                    i_ll += x;
+                    i_adv += y;
+                }
+            }
+            const uint32_t t_ll = (uint32_t)__shfl((int)i_ll, 63, 64), t_adv = (uint32_t)__shfl((int)i_adv, 63, 64);
+            const uint32_t o_l = zx.op + i_adv - a_adv; // where my literals go
+            const uint32_t o_m = o_l + ll;              // where my match goes
+            // literals: each sequence's own lane, from the LDS window
+            {
+                const uint32_t li = zx.need_lit(lit_cur, t_ll + 1u) + (i_ll - a_ll);
+                if (in)
+                    for (uint32_t b = 0; b < ll; ++b)
+                        s_ring[zx.ring(o_l + b)] = s_lit[li + b];
+            }
+            // matches in dependency rounds: everything before the first pending sequence's match is final
+            // a source the ring may lose while this run appends (it holds the 8 KiB below op + t_adv) was flushed long ago: from
+            // global memory then; only offsets above ZX_RING_SAFE can be that far back, and those come with at most 18 bytes
+            const bool glob = in && o_m - off + ZX_RING < zx.op + t_adv;
+            if (__builtin_amdgcn_ballot_w64(glob && o_m - off + ml + zx.g > zx.drained))
+            {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+                zx.drained = zx.flushed;
+            }
+            uint64_t pend = __builtin_amdgcn_ballot_w64(in && ml != 0u);
+            while (pend)
+            {
+                const int first = __builtin_ctzll(pend);
+                const int32_t rel_m = (int32_t)(o_m - zx.op);
+                const int32_t frontier = (int32_t)__builtin_amdgcn_readlane((uint32_t)rel_m, first);
+                const bool ready = ((pend >> lane) & 1ull) && (lane == first || rel_m - (int32_t)off + (int32_t)ml <= frontier);
+                if (ready)
+                {
+                    if (!glob)
+                    {
+                        const uint32_t so2 = o_m - off;
+                        for (uint32_t b = 0; b < ml; ++b)
+                            s_ring[zx.ring(o_m + b)] = s_ring[zx.ring(so2 + b)];
+                    }
+                    else
+                    {
+                        uint32_t bytes[18];
+#pragma unroll
+                        for (uint32_t b = 0; b < 18u; ++b)
+                            bytes[b] = b < ml ? zx.out_al[o_m - off + b + zx.g] : 0u;
+#pragma unroll
+                        for (uint32_t b = 0; b < 18u; ++b)
+                            if (b < ml)
+                                s_ring[zx.ring(o_m + b)] = (uint8_t)bytes[b];
+                    }
+                }
+                pend &= ~__builtin_amdgcn_ballot_w64(ready);
+            }
+            zx.op += t_adv;
+            lit_cur += t_ll;
+            zx.maybe_flush();
+            start += k;
+        }
+    }
+    if (!bad)
+    {
+        // literals after the last sequence; the piece must come out at exactly its size
+        const uint32_t rest = pr.nlit - litpos;
+        if (rest != pr.expect - produced)
+            bad = true;
+        else
+        {
+            zx.copy_lits(litpos, rest);
+            zx.flush(zx.op + zx.g);
+        }
+    }
+    if (bad && lane == 0)
+        status_out[(size_t)i * (sizeof(ZPrep) / 4u)] = ZP_SERIAL; // = prep[i].status (a second view: `prep` itself is read-only here)
+}
+
 } // namespace
 
 extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
@@ -583,13 +1115,48 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     if ((err = lthip_stage_upload(ctx, d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, ctx->stream)))
         return err;
     const uint32_t dbg = (uint32_t)(getenv("LTHIP_ZSTD_DBG") ? atoi(getenv("LTHIP_ZSTD_DBG")) : 0); // 1: never decode by pieces
+    if (getenv("LTHIP_ZSTD_ABLATE"))
+    {
+        const uint32_t a = (uint32_t)atoi(getenv("LTHIP_ZSTD_ABLATE"));
+        LTHIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_zd_ablate), &a, sizeof(a)));
+    }
     LaunchTimer t(ctx, LTHIP_K_OTHER);
     hipLaunchKernelGGL(k_zstd_split, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                        block_count, (ZItem*)d_items, d_count, d_out_sizes, dbg);
     hipLaunchKernelGGL(k_zstd_decode<false>, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
-                       (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes);
+                       (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes, (const ZPrep*)nullptr);
+    LTHIP_LAUNCH_CHECK(ctx);
+    // pieces: two stages (k_zstd_prepare / k_zstd_execute) in rounds of ZROUND pieces, whose literals and tables live in scratch;
+    // what they leave (ZP_SERIAL) goes to the serial piece decoder.  LTHIP_ZSTD_DBG & 4: the serial piece decoder for everything.
+    ZPrep* d_prep = nullptr;
+    if (!(dbg & 4u)) // (pieces exist only in marked frames; the kernels look at the item list)
+    {
+        constexpr uint32_t ZROUND = 16384u;
+        const uint32_t per_round = nitems < ZROUND ? (uint32_t)nitems : ZROUND;
+        void *d_plits, *d_tabs, *d_pr;
+        if ((err = lthip_scratch(ctx, S_Z_LITS, (size_t)(ZD_LIT_MAX + 64u) * per_round + 4096, &d_plits)))
+            return err;
+        if ((err = lthip_scratch(ctx, S_Z_RECS, (size_t)3u * ZT_ENTRIES * 8u * per_round, &d_tabs)))
+            return err;
+        if ((err = lthip_scratch(ctx, S_LZ4_META, sizeof(ZPrep) * (size_t)nitems, &d_pr)))
+            return err;
+        d_prep = (ZPrep*)d_pr;
+        for (uint64_t i0 = 0; i0 < nitems; i0 += per_round)
+        {
+            const uint32_t i1 = (uint32_t)(i0 + per_round < nitems ? i0 + per_round : nitems);
+            const uint32_t n = i1 - (uint32_t)i0;
+            hipLaunchKernelGGL(k_zstd_prepare, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
+                               (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, (uint8_t*)d_plits,
+                               (uint64_t*)d_tabs, d_prep, (const uint32_t*)d_out_sizes);
+            LTHIP_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL(k_zstd_execute, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
+                               (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, (const uint8_t*)d_plits,
+                               (const uint64_t*)d_tabs, (const ZPrep*)d_prep, &d_prep->status);
+            LTHIP_LAUNCH_CHECK(ctx);
+        }
+    }
     hipLaunchKernelGGL(k_zstd_decode<true>, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
-                       (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes);
+                       (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes, (const ZPrep*)d_prep);
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -22,6 +22,8 @@
 #include "zstd_block_core.h"
 
 #define ZD_ERROR 0xFFFFFFFFu
+#define ZD_PREPARED 0xFFFFFFFEu /* see ZDV_PREP: literals are in lits[], the three tables in sh->fse[]; v[ZDV_LL] = number of sequences,
+                                 * v[ZDV_ML] = number of literals, v[ZDV_OFF] / v[ZDV_LEN] = offset (in src) / size of the bit-stream */
 /* where the payload was found malformed (source line, diagnostics only) */
 #define ZD_SET_ERR(sh) ((sh)->v[ZDV_SRC] = __LINE__, (sh)->v[ZDV_ERR] = 1)
 #define ZD_FAIL_AT(sh) ((sh)->v[ZDV_SRC] = (sh)->v[ZDV_ERR] ? (sh)->v[ZDV_SRC] : __LINE__, ZD_ERROR)
@@ -50,6 +52,7 @@ enum
     ZDV_LEN,
     ZDV_BYTE,
     ZDV_DONE,
+    ZDV_PREP,   /* != 0 (kernel build, piece mode): stop in front of the sequence loop and hand the block's state over (ZD_PREPARED) */
     ZDV_COUNT
 };
 
@@ -205,6 +208,9 @@ ZB_FN int zd_build_fse(ZdFse* t, const int16_t* norm, uint32_t maxsym, uint32_t 
 
 #ifndef ZD_MARK
 #define ZD_MARK(i) ((void)0) /* profiling hook of the kernel build */
+#endif
+#ifndef ZD_ABLATE
+#define ZD_ABLATE 0u /* timing experiments of the kernel build */
 #endif
 
 /* ---- backward bit reader: the stream ends with a 1 bit followed by zero padding ---- */
@@ -743,6 +749,7 @@ ZB_FN uint32_t zd_decode_payload_ex(const uint8_t* src, uint32_t src_size, uint8
                             const uint32_t seg = (nlit + 3u) >> 2;
                             if (s1 + s2 + s3 >= body || 3u * seg > nlit)
                                 return ZD_FAIL_AT(sh);
+                            if (!(ZD_ABLATE & 2u))
                             ZB_PAR_FOR(k, 4u)
                             {
                                 const uint32_t so = k == 0u ? 0u : k == 1u ? s1 : k == 2u ? s1 + s2 : s1 + s2 + s3;
@@ -823,6 +830,18 @@ ZB_FN uint32_t zd_decode_payload_ex(const uint8_t* src, uint32_t src_size, uint8
                         seq_pos = sh->v[ZDV_LEN];
                         if (seq_pos >= bsize)
                             return ZD_FAIL_AT(sh);
+                        if (piece && sh->v[ZDV_PREP])
+                        {
+                            ZB_SERIAL(zl)
+                            {
+                                sh->v[ZDV_LL] = nbseq;
+                                sh->v[ZDV_ML] = nlit;
+                                sh->v[ZDV_OFF] = ip + seq_pos;
+                                sh->v[ZDV_LEN] = bsize - seq_pos;
+                            }
+                            ZB_SYNC();
+                            return ZD_PREPARED;
+                        }
                         {
                             ZdBack br;
                             uint32_t st[3] = {0, 0, 0};
@@ -955,6 +974,7 @@ ZB_FN uint32_t zd_decode_payload_ex(const uint8_t* src, uint32_t src_size, uint8
                                 ll = sh->v[ZDV_LL];
                                 ml = sh->v[ZDV_ML];
                                 off = sh->v[ZDV_OFF];
+                                if (!(ZD_ABLATE & 1u))
                                 {
                                     uint8_t* o = dst + out_total;
                                     const uint8_t* l = lits + litpos;
