@@ -811,7 +811,7 @@ struct ZxBits
     }
 };
 
-__global__ __launch_bounds__(64) void k_zstd_execute(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, const ZItem* __restrict__ items,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_zstd_execute(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, const ZItem* __restrict__ items,
                                                      const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
                                                      uint8_t* __restrict__ dst, const uint8_t* __restrict__ lit_scratch,
                                                      const uint64_t* __restrict__ tables, const ZPrep* __restrict__ prep,
