@@ -1134,10 +1134,44 @@ __global__ __launch_bounds__(64) void k_lz4_pd_tiles(const uint8_t* __restrict__
         tiles[t] = rec;
 }
 
+// Second guess per tile.  Where a tile's chain leaves it (rec.exit) is, if that chain was the true one by then, where the true chain
+// enters the tile it lands in; when that tile's own guess recorded another entry -- it began inside a long literal run, or the
+// data kept two chains apart for more than the run-in -- the tile is walked again from there, here, by one wave per case and all
+// cases at once, instead of one after the other by the link pass (a lone wave needs ~100 us per tile).  The result goes to the
+// tile's ALTERNATIVE record (first come, first served).
+__global__ __launch_bounds__(64) void k_lz4_pd_patch(const uint8_t* __restrict__ src, const PdBlock* __restrict__ blocks, uint32_t nblocks,
+                                                     uint32_t ntiles, const PdTile* __restrict__ tiles, PdTile* __restrict__ alt,
+                                                     uint32_t* __restrict__ claim)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN];
+    const uint32_t t = blockIdx.x;
+    if (t >= ntiles)
+        return;
+    const PdTile mine = tiles[t];
+    if (mine.entry == PD_NONE || mine.flags)
+        return;
+    const PdBlock blk = blocks[pd_block_of(blocks, nblocks, t, true)];
+    const uint32_t j = mine.exit / PD_TILE;
+    if (j >= blk.ntiles || tiles[blk.tile_base + j].entry == mine.exit)
+        return;
+    uint32_t won = 0;
+    if (threadIdx.x == 0)
+        won = atomicCAS(&claim[blk.tile_base + j], 0u, 1u) == 0u ? 1u : 0u;
+    if (!__builtin_amdgcn_readfirstlane(won))
+        return;
+    PdReader r;
+    r.init(src + blk.src_off, blk.size, s_in, threadIdx.x);
+    const int64_t t0 = (int64_t)j * PD_TILE;
+    const int64_t t1 = t0 + PD_TILE < (int64_t)blk.size ? t0 + PD_TILE : (int64_t)blk.size;
+    const PdTile rec = pd_walk_tile(r, mine.exit, t0, t1, blk.dst_cap);
+    if (threadIdx.x == 0)
+        alt[blk.tile_base + j] = rec;
+}
+
 __global__ __launch_bounds__(64) void k_lz4_pd_link(const uint8_t* __restrict__ src, const PdBlock* __restrict__ blocks, uint32_t nblocks,
-                                                    PdTile* __restrict__ tiles, uint32_t* __restrict__ tile_op,
-                                                    uint32_t* __restrict__ unit_tile, PdState* __restrict__ state,
-                                                    uint32_t* __restrict__ stats)
+                                                    PdTile* __restrict__ tiles, const PdTile* __restrict__ alt,
+                                                    uint32_t* __restrict__ tile_op, uint32_t* __restrict__ unit_tile,
+                                                    PdState* __restrict__ state, uint32_t* __restrict__ stats)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN];
     const uint32_t b = blockIdx.x;
@@ -1152,6 +1186,8 @@ __global__ __launch_bounds__(64) void k_lz4_pd_link(const uint8_t* __restrict__ 
     int64_t p = 0;
     uint64_t op = 0;
     uint32_t next_unit = 0, err = 0, rewalks = 0;
+    long long walk_cycles = 0;
+    const long long k0 = stats ? clock64() : 0;
     // 64 tile records at a time, one per lane
     uint32_t cj = PD_NONE;
     PdTile mine{PD_NONE, 0u, 0u, 0u};
@@ -1176,13 +1212,26 @@ __global__ __launch_bounds__(64) void k_lz4_pd_link(const uint8_t* __restrict__ 
         rec.flags = __builtin_amdgcn_readlane(mine.flags, src_lane);
         if (rec.entry != (uint32_t)p)
         {
-            // the guess of the tile pass was not the true entry: walk the tile from where the chain really enters it
+            const PdTile second = alt[blk.tile_base + j]; // (all lanes read the same record)
+            if (second.entry == (uint32_t)p)
+            {
+                rec = second;
+                if (lane == 0)
+                    bt[j] = rec; // the units start from this record
+            }
+        }
+        if (rec.entry != (uint32_t)p)
+        {
+            // neither guess was the true entry: walk the tile from where the chain really enters it
             const int64_t t0 = (int64_t)j * PD_TILE;
             const int64_t t1 = t0 + PD_TILE < (int64_t)blk.size ? t0 + PD_TILE : (int64_t)blk.size;
+            const long long c0 = stats ? clock64() : 0;
             rec = pd_walk_tile(r, p, t0, t1, cap);
             if (lane == 0)
                 bt[j] = rec; // the units start from this record
             ++rewalks;
+            if (stats)
+                walk_cycles += clock64() - c0;
         }
         if (lane == 0)
             tile_op[blk.tile_base + j] = (uint32_t)op;
@@ -1226,6 +1275,8 @@ __global__ __launch_bounds__(64) void k_lz4_pd_link(const uint8_t* __restrict__ 
         {
             atomicAdd(&stats[0], rewalks);
             atomicAdd(&stats[1], blk.ntiles);
+            atomicAdd(&stats[2], (uint32_t)(walk_cycles >> 10));
+            atomicAdd(&stats[3], (uint32_t)((clock64() - k0) >> 10));
         }
     }
 }
@@ -1409,10 +1460,11 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
         for (uint32_t k = 0; k < rows; ++k)
             row_base[(size_t)k + 1] = row_base[k] + count[k];
     }
-    // device tables: [PdTile x ntiles][tile_op x ntiles][unit_tile x nunits][state x nb][order x nb][row_base x rows+1][done x nunits][counters x 8][first_end x nb]
+    // device tables: [PdTile x ntiles][tile_op x ntiles][unit_tile x nunits][state x nb][order x nb][row_base x rows+1][done x nunits][counters x 8][first_end x nb][alt PdTile x ntiles][claim x ntiles]
     const size_t o_tiles = 0, o_top = o_tiles + sizeof(PdTile) * ntiles, o_ut = o_top + 4 * ntiles, o_state = o_ut + 4 * nunits,
                  o_order = o_state + sizeof(PdState) * nb, o_rows = o_order + 4 * (size_t)nb, o_done = o_rows + 4 * ((size_t)rows + 1),
-                 o_cnt = o_done + 4 * nunits, o_first = o_cnt + 32, o_end = o_first + 4 * (size_t)nb;
+                 o_cnt = o_done + 4 * nunits, o_first = o_cnt + 32, o_alt = (o_first + 4 * (size_t)nb + 15) & ~(size_t)15, o_claim = o_alt + sizeof(PdTile) * ntiles,
+                 o_end = o_claim + 4 * ntiles;
     void *tab, *blk;
     int err = lthip_scratch(ctx, S_LZ4_STREAM, o_end, &tab);
     if (!err)
@@ -1428,7 +1480,9 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     if (err)
         return err;
     uint8_t* t8 = (uint8_t*)tab;
-    LTHIP_CHECK(ctx, hipMemsetAsync(t8 + o_done, 0, o_first - o_done, ctx->stream)); // flags and counters: zero before every launch
+    LTHIP_CHECK(ctx, hipMemsetAsync(t8 + o_done, 0, o_first - o_done, ctx->stream));
+    LTHIP_CHECK(ctx, hipMemsetAsync(t8 + o_alt, 0xFF, sizeof(PdTile) * ntiles, ctx->stream)); // entry = PD_NONE
+    LTHIP_CHECK(ctx, hipMemsetAsync(t8 + o_claim, 0, 4 * ntiles, ctx->stream)); // flags and counters: zero before every launch
     const PdBlock* d_blocks = (const PdBlock*)blk;
     PdTile* d_tiles = (PdTile*)(t8 + o_tiles);
     uint32_t* d_top = (uint32_t*)(t8 + o_top);
@@ -1454,8 +1508,12 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
                        d_first);
     LTHIP_LAUNCH_CHECK(ctx);
     PD_TRACE("tiles");
-    hipLaunchKernelGGL(k_lz4_pd_link, dim3(nb), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, nb, d_tiles, d_top, d_ut, d_state,
-                       stats ? d_cnt + 4 : nullptr);
+    hipLaunchKernelGGL(k_lz4_pd_patch, dim3((uint32_t)ntiles), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, nb, (uint32_t)ntiles,
+                       (const PdTile*)d_tiles, (PdTile*)(t8 + o_alt), (uint32_t*)(t8 + o_claim));
+    LTHIP_LAUNCH_CHECK(ctx);
+    PD_TRACE("patch");
+    hipLaunchKernelGGL(k_lz4_pd_link, dim3(nb), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, nb, d_tiles, (const PdTile*)(t8 + o_alt), d_top, d_ut,
+                       d_state, stats ? d_cnt + 4 : nullptr);
     LTHIP_LAUNCH_CHECK(ctx);
     PD_TRACE("link");
     PdTickets tk;
@@ -1511,6 +1569,7 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
         LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         fprintf(stderr, "lz4 parallel decode: %u blocks, %llu tiles (%u walked again by the link pass), %llu units, %u tickets, timeouts %u\n", nb,
                 (unsigned long long)ntiles, h[4], (unsigned long long)nunits, tk.total, h[1]);
+        fprintf(stderr, "   link pass: %u Kcycles in all, %u Kcycles walking tiles again (summed over the blocks)\n", h[7], h[6]);
     }
     return 0;
 }
