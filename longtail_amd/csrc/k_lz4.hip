@@ -29,7 +29,7 @@
 //                    lz4.c:242-246, 2279-2329, 2421-2423); then one wave per unit, persistent over a work list, copies header,
 //                    literals (from the source) and sequence body (from the stream) into the single final block with 16-byte
 //                    stores.  Blocks without a single match were laid out by K5: only their header is written.
-//   decode           one wave per block, sequences parsed wave-uniformly, copies spread over the lanes.
+//   decode           k_lz4_decode.hip
 #include "lthip_internal.h"
 
 #include <stdlib.h>
