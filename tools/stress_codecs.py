@@ -37,4 +37,31 @@ for rnd in range(12):
                 err, out = r.decompress(0 if codec == "lz4" else 1, host[d_offs[i]: d_offs[i] + int(cs[i])].copy(), len(b))
                 assert err == 0 and len(out) == len(b) and (out == b).all(), (codec, i, "reference decoder")
         tot += len(blocks)
+    # the LZ4 decoder on payloads with a sliding window (the reference's parse: units of the block-parallel path wait for each other)
+    # and on damaged ones: size, bytes and verdict are the oracle decoder's
+    big = [b for b in blocks if len(b) >= 100000][:40]
+    comps, caps = [], []
+    for b in big:
+        c = o.lz4_compress(b)
+        kind = int(rng.integers(0, 5))
+        if kind == 1:
+            c = c[: int(rng.integers(1, len(c)))]
+        elif kind == 2:
+            c = c.copy(); c[int(rng.integers(0, len(c)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 3:
+            c = c.copy(); c[int(rng.integers(0, len(c))):] = 0
+        comps.append(c); caps.append(len(b) if kind != 4 else max(1, len(b) + int(rng.integers(-70000, 70000))))
+    if comps:
+        cdev, coffs = to_device(comps)
+        b_offs, btot = layout([np.zeros(c, np.uint8) for c in caps])
+        back = torch.zeros(btot + 64, dtype=torch.uint8, device="cuda")
+        ds = u32(ctx.lz4_decompress_blocks(cdev, coffs, [len(c) for c in comps], back, b_offs, caps))
+        bh = back.cpu().numpy()
+        for i, (c, cap) in enumerate(zip(comps, caps)):
+            n, out = o.lz4_decompress(c, cap)
+            if n < 0:
+                assert int(ds[i]) == 0xFFFFFFFF, ("lz4 verdict", i, int(ds[i]))
+            else:
+                assert int(ds[i]) == n and (bh[b_offs[i]: b_offs[i] + n] == out[:n]).all(), ("lz4 sliding window", i, int(ds[i]), n)
+        tot += len(comps)
 print("ok", tot, "payloads")
