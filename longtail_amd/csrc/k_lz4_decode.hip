@@ -763,7 +763,49 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
                 // token before it), the matches are copied by the tokens' own lanes, all at once when their sources lie before
                 // the batch, otherwise in dependency order.  The conditions are the one-sequence path's, token by token: the first
                 // token that fails any of them ends the batch and is left to the code below (which also decides about errors).
-                if (d <= 40 && !dec_nobatch)
+                // ---- a literal run of 15..269 bytes (ONE length byte) and its match, the wave together: what the general code below does
+                // for such a sequence, without its window re-seeds and loops (it is 8-10 % of the sequences of this library's encoder
+                // and cost half the time).  Same conditions, same verdicts; everything else is left to the general code. ----
+                if constexpr (UNIT)
+                {
+                    const uint32_t tk0 = __builtin_amdgcn_readlane(w, 0); // d == 0 here
+                    const uint32_t e0 = __builtin_amdgcn_readlane(w, 1);
+                    if ((tk0 >> 4) == 15u && e0 != 255u)
+                    {
+                        const I lit = (I)(15u + e0), lp = ip + 2;
+                        I ml = (I)(tk0 & 15u) + 4;
+                        if (ip + 2 <= n - 15 && !(op + lit > cap - 12 || lp + lit > n - 8))
+                        {
+                            const uint32_t i = need(lp, (uint32_t)lit + 3u);
+                            const uint32_t b0 = __builtin_amdgcn_readfirstlane((uint32_t)s_in[i + (uint32_t)lit]),
+                                           b1 = __builtin_amdgcn_readfirstlane((uint32_t)s_in[i + (uint32_t)lit + 1u]),
+                                           b2 = __builtin_amdgcn_readfirstlane((uint32_t)s_in[i + (uint32_t)lit + 2u]);
+                            I adv = 2 + lit + 2;
+                            bool take = true;
+                            if ((tk0 & 15u) == 15u)
+                            {
+                                take = b2 != 255u; // longer matches: general code
+                                ml += (I)b2;
+                                adv += 1;
+                            }
+                            if (take && (un.last || op + lit + ml <= hi))
+                            {
+                                const uint32_t off = b0 | (b1 << 8);
+                                if (off == 0 || (I)off > op + lit || op + lit + ml > cap - 5)
+                                    break;
+                                for (uint32_t j = lane; j < (uint32_t)lit; j += 64)
+                                    s_ring[RING((uint32_t)op + j)] = s_in[i + j];
+                                op += lit;
+                                copy_match(off, ml);
+                                ip += adv;
+                                DEC_CNT(11);
+                                continue;
+                            }
+                        }
+                    }
+                }
+                // (a first token with 15 or more literals is for the general code: do not set a batch up for it)
+                if (d <= 40 && !dec_nobatch && (__builtin_amdgcn_readlane(w, (int)d) >> 4) != 15u)
                 {
                     constexpr uint32_t INLANE_MAX = 64u;                    // longest match a lane copies on its own
                     constexpr uint32_t RING_SAFE = DEC_RING - 1280u;        // a batch writes up to 16 x (14 + 64) bytes ahead of `op`
