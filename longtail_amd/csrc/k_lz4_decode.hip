@@ -307,13 +307,19 @@ __device__ __forceinline__ PdPos pd_walk(PdReader& r, int64_t ip, uint64_t op, c
         const uint32_t w = r.w;
         const uint32_t litl = w >> 4, mlcl = w & 15u;
         const int32_t pl = (int32_t)ip + r.lane;
-        const uint32_t e = (uint32_t)r.lane + 3u + litl; // where a match-length byte would be, relative to the window
+        // literal length: the nibble, or 15 + ONE length byte (the byte after the token, when it is in the window and below 255)
+        const bool big = litl == 15u;
+        const uint32_t after = (uint32_t)__shfl((int)w, (r.lane + 1) & 63, 64);
+        const uint32_t lit = big ? 15u + after : litl, hdr = big ? 2u : 1u;
+        const uint32_t e = (uint32_t)r.lane + hdr + lit + 2u; // where a match-length byte would be, relative to the window
         const uint32_t ext = (uint32_t)__shfl((int)w, (int)(e & 63u), 64);
         const bool one = mlcl == 15u;
-        bool simple = litl < 15u && pl + 1 + (int32_t)litl <= n - 8; // "ip + len > n - 8" ends the payload
+        bool simple = pl + (int32_t)(hdr + lit) <= n - 8; // "ip + len > n - 8" ends the payload
+        if (big) // its length byte: "ip >= n - 15" before it, "ip > n - 15" after it
+            simple = simple && r.lane < 63 && after != 255u && pl + 2 <= n - 15;
         if (one)
-            simple = simple && e < 64u && pl + 3 + (int32_t)litl < n - 4 && ext != 255u;
-        const uint32_t outv = litl + mlcl + 4u + (one ? ext : 0u);
+            simple = simple && e < 64u && pl + (int32_t)(hdr + lit) + 2 < n - 4 && ext != 255u;
+        const uint32_t outv = lit + mlcl + 4u + (one ? ext : 0u);
         const uint32_t nxtv = e + (one ? 1u : 0u);
         // 32-bit running values: op stays below op_limit + 64 x 300 < 2^32
         uint32_t o32 = (uint32_t)op;
@@ -325,7 +331,27 @@ __device__ __forceinline__ PdPos pd_walk(PdReader& r, int64_t ip, uint64_t op, c
             ok &= (1ull << left) - 1ull; // no token at or past the bound is followed
         uint32_t cur = 0;
         int why = 0; // 1: bound reached, 2: damage, 0: window exhausted or a token for pd_hop
-        while (cur < 64u && ((ok >> cur) & 1ull)) // per sequence: a bit test, two readlanes, an add
+        if constexpr (!OPSTOP)
+        {
+            // No test per sequence is needed: the chain through the window is resolved for all 64 possible starts at once by pointer
+            // doubling on the vector unit (the scalar unit is what these kernels are short of).  Per lane one word {bytes produced
+            // << 10 | position reached}, position >= 512 = final (>= 64 + 512: left the window; 512 + i: stands on token i, which
+            // the walk does not follow); five rounds of "take over what the position I reached has reached" cover 32 sequences,
+            // a window holds at most 21.
+            const bool follow = (ok >> r.lane) & 1ull;
+            uint32_t st = follow ? (outv << 10) | (nxtv >= 64u ? 512u + nxtv : nxtv) : 512u + (uint32_t)r.lane;
+#pragma unroll
+            for (int round = 0; round < 5; ++round)
+            {
+                const uint32_t there = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((st & 63u) << 2), (int)st);
+                if (!(st & 512u))
+                    st = ((st & ~1023u) + (there & ~1023u)) | (there & 1023u);
+            }
+            const uint32_t s0 = __builtin_amdgcn_readlane(st, 0);
+            o32 += s0 >> 10;
+            cur = (s0 & 1023u) - 512u; // always final after five rounds: >= 64 = left the window there, < 64 = stands on that token
+        }
+        while (OPSTOP && cur < 64u && ((ok >> cur) & 1ull)) // per sequence: a bit test, two readlanes, an add
         {
             const uint32_t o = __builtin_amdgcn_readlane(outv, (int)cur);
             if (OPSTOP && o32 + o > stop32)
