@@ -64,6 +64,11 @@ typedef struct ZdShared
     ZdFse wtab;   /* FSE table of the Huffman weights */
     int16_t norm[256];
     uint8_t weights[256];
+    /* small tables the builders index dynamically: in shared memory, because a local array indexed by data is private memory on
+     * the GPU (one memory round trip, or a 64-way select chain, per access -- the FSE builder alone cost 1.7 ms per block) */
+    uint16_t next[64];
+    uint32_t rank_start[ZB_HUF_MAXBITS + 3u];
+    uint32_t rank_cnt[ZB_HUF_MAXBITS + 3u];
     uint32_t rep[3];
     uint32_t v[ZDV_COUNT];
 } ZdShared;
@@ -167,11 +172,10 @@ ZB_FN uint32_t zd_read_ncount(const uint8_t* p, uint32_t size, int16_t* norm, ui
 }
 
 /* decoding table from a normalised distribution (zstd_decompress_block.c:484-603) */
-ZB_FN int zd_build_fse(ZdFse* t, const int16_t* norm, uint32_t maxsym, uint32_t tl)
+ZB_FN int zd_build_fse(ZdFse* t, const int16_t* norm, uint32_t maxsym, uint32_t tl, uint16_t* next /* 64 entries of scratch */)
 {
     const uint32_t size = 1u << tl, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
     uint32_t high = size - 1u, pos = 0;
-    uint16_t next[64];
     if (maxsym > 63u || tl > 9u)
         return 1;
     for (uint32_t s = 0; s <= maxsym; ++s)
@@ -289,8 +293,8 @@ ZB_FN uint32_t zd_back_read32(ZdBack* r, uint32_t n) /* n <= 32 */
 /* weights[0..n) (the last one already completed) -> single-symbol decoding table (RFC 8878 §4.2.1) */
 ZB_FN int zd_build_huf(ZdShared* sh, uint32_t n, uint32_t tlog)
 {
-    uint32_t rank_start[ZB_HUF_MAXBITS + 3u];
-    uint32_t cnt[ZB_HUF_MAXBITS + 3u];
+    uint32_t* rank_start = sh->rank_start;
+    uint32_t* cnt = sh->rank_cnt;
     if (tlog == 0u || tlog > ZB_HUF_MAXBITS + 1u)
         return 1;
     for (uint32_t w = 0; w <= tlog + 1u; ++w)
@@ -359,7 +363,7 @@ ZB_FN uint32_t zd_read_huf_tree(ZdShared* sh, const uint8_t* p, uint32_t size)
             const uint32_t hs = zd_read_ncount(p + 1, hb, sh->norm, &maxsym, 6u, &tl);
             if (hs == ZD_ERROR || hs >= hb)
                 return ZD_ERROR;
-            if (zd_build_fse(t, sh->norm, maxsym, tl))
+            if (zd_build_fse(t, sh->norm, maxsym, tl, sh->next))
                 return ZD_ERROR;
             if (zd_back_open(&br, p + 1u + hs, hb - hs))
                 return ZD_ERROR;
@@ -471,7 +475,7 @@ ZB_FN int zd_set_table(ZdShared* sh, int t, uint32_t mode, const uint8_t* p, uin
         const uint32_t nsym = zb_table_nsym(t);
         for (uint32_t s = 0; s < nsym; ++s)
             sh->norm[s] = (int16_t)zb_default_norm(t, s);
-        return zd_build_fse(f, sh->norm, nsym - 1u, zb_table_default_log(t));
+        return zd_build_fse(f, sh->norm, nsym - 1u, zb_table_default_log(t), sh->next);
     }
     if (mode == 1u)
     {
@@ -494,7 +498,7 @@ ZB_FN int zd_set_table(ZdShared* sh, int t, uint32_t mode, const uint8_t* p, uin
         if (hs == ZD_ERROR)
             return 1;
         *used = hs;
-        return zd_build_fse(f, sh->norm, maxsym, tl);
+        return zd_build_fse(f, sh->norm, maxsym, tl, sh->next);
     }
     return f->valid == 0u; /* Repeat_Mode needs a previous table */
 }
