@@ -10,6 +10,8 @@
 // settings ('ztd1'..'ztd5', longtail_zstd.c:12-22) select nothing here: there is one parse.
 #include "lthip_internal.h"
 
+#include <type_traits>
+
 #define ZB_LANES 64u
 #define ZB_FN __device__ __forceinline__ /* inlined so that LDS / global address spaces are known at every access */
 #define ZB_SYNC() __syncthreads() /* the encoder runs in one-wave workgroups */
@@ -515,7 +517,8 @@ struct ZPrep
     uint32_t log[3];    // table logs (0: an RLE table, one entry)
     uint32_t expect;    // bytes the piece has to produce
 };
-constexpr uint32_t ZT_ENTRIES = 512u; // per table and piece: u64 {new-state base:16 | state bits:8 | extra bits:8 | baseline:32}
+constexpr uint32_t ZT_ENTRIES = 512u; // per table and piece: u64 {BYTE OFFSET (within the piece's three tables) of the new state's base entry:16 |
+                                       // state bits:8 | extra bits:8 | baseline:32}
 
 // PIECES selects the item kind the launch works on: the mode of the decoder core is then a compile-time constant (with a run-time
 // mode the whole-payload path ran 4.6x slower per wave -- measured; the two flavours are launched back to back)
@@ -638,7 +641,8 @@ __global__ __launch_bounds__(64) void k_zstd_prepare(const uint8_t* __restrict__
                         ebits = sym & 31u;
                         ok = ok && sym <= 31u;
                     }
-                    tp[(uint32_t)t * ZT_ENTRIES + e] = (uint64_t)f->base[e] | ((uint64_t)f->nb[e] << 16) | ((uint64_t)ebits << 24) | ((uint64_t)baseline << 32);
+                    tp[(uint32_t)t * ZT_ENTRIES + e] = (uint64_t)(((uint32_t)t * ZT_ENTRIES + f->base[e]) * 8u) | ((uint64_t)f->nb[e] << 16) | ((uint64_t)ebits << 24) |
+                                                       ((uint64_t)baseline << 32);
                 }
             }
             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull)
@@ -831,9 +835,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const int lane = threadIdx.x;
     const ZBlock blk = blocks[it.payload];
     const uint32_t slot = i - item0;
-    const uint64_t* tl = tables + (uint64_t)slot * 3u * ZT_ENTRIES + ZT_LL * ZT_ENTRIES;
-    const uint64_t* to = tables + (uint64_t)slot * 3u * ZT_ENTRIES + ZT_OF * ZT_ENTRIES;
-    const uint64_t* tm = tables + (uint64_t)slot * 3u * ZT_ENTRIES + ZT_ML * ZT_ENTRIES;
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tables + (uint64_t)slot * 3u * ZT_ENTRIES); // states are byte offsets into this
     const uint8_t* lits = lit_scratch + (uint64_t)slot * (ZD_LIT_MAX + 64u);
     uint8_t* out = dst + blk.dst_off + it.out0;
 
@@ -881,9 +883,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         {
             br.load_window();
             br.normalize();
-            sl = br.take(pr.log[ZT_LL]);
-            so = br.take(pr.log[ZT_OF]);
-            sm = br.take(pr.log[ZT_ML]);
+            sl = (ZT_LL * ZT_ENTRIES + br.take(pr.log[ZT_LL])) * 8u;
+            so = (ZT_OF * ZT_ENTRIES + br.take(pr.log[ZT_OF])) * 8u;
+            sm = (ZT_ML * ZT_ENTRIES + br.take(pr.log[ZT_ML])) * 8u;
         }
     }
     uint32_t litpos = 0, produced = 0; // what the decoded sequences consume / produce (scalar bookkeeping of the checks)
@@ -892,43 +894,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint32_t cnt = pr.nbseq - s0 < 64u ? pr.nbseq - s0 : 64u;
         // ---- scalar unit: the next `cnt` sequences into lanes 0 .. cnt-1 ----
         uint32_t r_ll = 0, r_ml = 0, r_off = 0;
-        for (uint32_t k = 0; k < cnt; ++k)
-        {
-            const uint2 ql = *reinterpret_cast<const uint2*>(tl + sl), qo = *reinterpret_cast<const uint2*>(to + so),
-                        qm = *reinterpret_cast<const uint2*>(tm + sm);
-            const uint64_t el = ((uint64_t)zx_u(ql.y) << 32) | zx_u(ql.x), eo = ((uint64_t)zx_u(qo.y) << 32) | zx_u(qo.x),
-                           em = ((uint64_t)zx_u(qm.y) << 32) | zx_u(qm.x);
-            const uint32_t ob = (uint32_t)(eo >> 24) & 255u, mb = (uint32_t)(em >> 24) & 255u, lb = (uint32_t)(el >> 24) & 255u;
-            const bool more = s0 + k + 1u < pr.nbseq;
-            const uint32_t nbl = more ? (uint32_t)(el >> 16) & 255u : 0u, nbm = more ? (uint32_t)(em >> 16) & 255u : 0u,
-                           nbo = more ? (uint32_t)(eo >> 16) & 255u : 0u;
-            if (ob + mb + lb + nbl + nbm + nbo > br.pos)
-            {
-                bad = true; // the stream runs out: the serial decoder says how
-                break;
-            }
+        // one sequence: the three entries, the three extra-bit fields, (MORE) the three state updates, the record into lane k.
+        // GUARD: test that the stream still holds the bits (without it the caller has made sure of 89 bits per sequence).
+        auto one = [&](uint32_t k, auto more_c, auto guard_c) -> bool {
+            constexpr bool MORE = decltype(more_c)::value, GUARD = decltype(guard_c)::value;
+            const uint2 ql = *reinterpret_cast<const uint2*>(tb + sl), qo = *reinterpret_cast<const uint2*>(tb + so),
+                        qm = *reinterpret_cast<const uint2*>(tb + sm);
+            const uint32_t l0 = zx_u(ql.x), o0 = zx_u(qo.x), m0 = zx_u(qm.x);
+            const uint32_t ob = o0 >> 24, mb = m0 >> 24, lb = l0 >> 24;
+            const uint32_t nbl = (l0 >> 16) & 255u, nbm = (m0 >> 16) & 255u, nbo = (o0 >> 16) & 255u;
+            if (GUARD && ob + mb + lb + (MORE ? nbl + nbm + nbo : 0u) > br.pos)
+                return false; // the stream runs out: the serial decoder says how
             br.load_window();
             br.normalize();
-            const uint32_t ov = (uint32_t)(eo >> 32) + br.take(ob);
-            const uint32_t ml = (uint32_t)(em >> 32) + br.take(mb);
-            const uint32_t ll = (uint32_t)(el >> 32) + br.take(lb);
-            if (more)
+            const uint32_t ov = zx_u(qo.y) + br.take(ob);
+            const uint32_t ml = zx_u(qm.y) + br.take(mb);
+            const uint32_t ll = zx_u(ql.y) + br.take(lb);
+            if (MORE)
             {
                 br.normalize();
-                sl = ((uint32_t)el & 0xFFFFu) + br.take(nbl);
-                sm = ((uint32_t)em & 0xFFFFu) + br.take(nbm);
-                so = ((uint32_t)eo & 0xFFFFu) + br.take(nbo);
+                sl = (l0 & 0xFFFFu) + (br.take(nbl) << 3);
+                sm = (m0 & 0xFFFFu) + (br.take(nbm) << 3);
+                so = (o0 & 0xFFFFu) + (br.take(nbo) << 3);
             }
-            // (what the serial decoder checks per sequence is checked for the whole batch by the vector unit below)
-            {
-                // into lane k of the three record registers (gfx9 allows one SGPR per VOP3: the lane select goes through M0)
-                const uint32_t a = zx_u(ll), b = zx_u(ml), c = zx_u(ov), kk = zx_u(k);
-                uint32_t keep;
-                asm volatile("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %7\n\ts_nop 4\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\t"
-                             "v_writelane_b32 %2, %6, m0\n\ts_mov_b32 m0, %3"
-                             : "+v"(r_ll), "+v"(r_ml), "+v"(r_off), "=&s"(keep)
-                             : "s"(a), "s"(b), "s"(c), "s"(kk));
-            }
+            // into lane k of the three record registers (gfx9 allows one SGPR per VOP3: the lane select goes through M0);
+            // what the serial decoder checks per sequence is checked for the whole batch by the vector unit below
+            const uint32_t a = zx_u(ll), b = zx_u(ml), c = zx_u(ov), kk = zx_u(k);
+            uint32_t keep;
+            asm volatile("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %7\n\ts_nop 4\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\t"
+                         "v_writelane_b32 %2, %6, m0\n\ts_mov_b32 m0, %3"
+                         : "+v"(r_ll), "+v"(r_ml), "+v"(r_off), "=&s"(keep)
+                         : "s"(a), "s"(b), "s"(c), "s"(kk));
+            return true;
+        };
+        {
+            const bool last_batch = s0 + cnt == pr.nbseq;
+            const uint32_t with_more = last_batch ? cnt - 1u : cnt; // the block's very last sequence updates no state
+            bool ok = true;
+            if (br.pos >= 64u * 89u)
+                for (uint32_t k = 0; k < with_more; ++k)
+                    (void)one(k, std::true_type{}, std::false_type{});
+            else
+                for (uint32_t k = 0; k < with_more && ok; ++k)
+                    ok = one(k, std::true_type{}, std::true_type{});
+            if (ok && last_batch)
+                ok = one(cnt - 1u, std::false_type{}, std::true_type{});
+            if (!ok)
+                bad = true;
         }
         if (bad)
             break;
