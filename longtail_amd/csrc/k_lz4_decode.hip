@@ -1605,7 +1605,7 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
         void* hp = nullptr;
         LTHIP_CHECK(ctx, hipHostMalloc(&hp, 32 * (size_t)grid, hipHostMallocMapped));
         memset(hp, 0, 32 * (size_t)grid);
-        dbg = (volatile uint32_t*)hp; // leaked: debugging only
+        dbg = (volatile uint32_t*)hp; // host-visible progress words, freed below once the kernel is through
     }
     if (small)
         hipLaunchKernelGGL(k_lz4_pd_units<int32_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, (uint8_t*)d_dst, d_tiles,
@@ -1628,6 +1628,8 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
         }
     }
     PD_TRACE("units");
+    if (dbg)
+        (void)hipHostFree((void*)dbg); // (PD_TRACE synchronised the stream)
     hipLaunchKernelGGL(k_lz4_pd_finish, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, d_blocks, nb, d_state, d_out_sizes);
     LTHIP_LAUNCH_CHECK(ctx);
     if (stats)
