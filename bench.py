@@ -20,7 +20,8 @@ Workload (default = BASELINE.json configs[2]): a tree of 1 MiB random files, 64 
 N x 64 GiB) or in total (--scaling strong, configs[3]); the tree's jobs are assigned to ranks by lthip_partition_jobs
 (byte-balanced contiguous ranges by default: an asset's parts may straddle ranks, configs[4]); every rank synthesizes only its own
 parts.  value = bytes of the whole tree / max-over-ranks wall time of K steps (barrier + synchronize on both sides).
-The default run also measures, after the headline, the compressible variant and the north-star mixed-size tree ("secondary"),
+The default run also measures, after the headline, the compressible variant and the north-star mixed-size tree ("secondary";
+at N=1 also "restore": the device decoders' GB/s on 512 stored blocks of the compressible workload, round trip verified),
 and times the reference's bikeshed-threaded CPU path on a bounded sample ("cpu_baseline").
 """
 from __future__ import annotations
@@ -132,6 +133,37 @@ class Bench:
         if self.world > 1:
             self.dist.barrier()
             self.torch.cuda.synchronize(self.dev)
+
+    def restore_rates(self, gib=4.0, block_bytes=8 << 20):
+        """Restore side: `gib` of the compressible workload as stored blocks of `block_bytes`, compressed on the device,
+        then DEcoded on the device -- GB/s of output with every payload resident in HBM and in flight at once, round trip verified."""
+        torch, ctx = self.torch, self.ctx
+        FILE = 1 << 20
+        nfiles = int(gib * (1 << 30)) // FILE
+        n = nfiles * FILE
+        data = self.buf("data", n + 256)
+        ctx.synth_fill(data, np.arange(nfiles, dtype=np.uint64) * np.uint64(FILE), np.full(nfiles, FILE, np.uint64), asset_seeds(1, 0, nfiles), KINDS["mixed"])
+        nb = n // block_bytes
+        b_off = np.arange(nb, dtype=np.int64) * block_bytes
+        b_size = np.full(nb, block_bytes, np.int64)
+        out = {"workload": f"{nb} stored blocks of {block_bytes >> 20} MiB of the compressible workload, payloads in HBM", "unit": "GB/s of output"}
+        for name, comp, dec, bound in (("lz4", ctx.lz4_compress_blocks, ctx.lz4_decompress_blocks, b_size + b_size // 255 + 16),
+                                       ("zstd", ctx.zstd_compress_blocks, ctx.zstd_decompress_blocks, b_size + (b_size >> 8) + 64)):
+            d_offs = np.concatenate([[0], np.cumsum((bound + 63) // 64 * 64)[:-1]])
+            arena = self.buf("restore_arena", int(bound.sum()) + nb * 64 + 64)
+            back = self.buf("restore_back", n + 64)
+            sz = comp(data, b_off, b_size, arena, d_offs, bound).cpu().numpy().view(np.uint32).astype(np.int64)
+            ctx.sync()
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                got = dec(arena, d_offs, sz, back, b_off, b_size)
+                ctx.sync()
+                t = time.perf_counter() - t0
+                best = t if best is None or t < best else best
+            ok = bool((got.cpu().numpy().view(np.uint32) == b_size).all()) and bool(torch.equal(back[:n], data[:n]))
+            out[name] = {"value": round(n / best / 1e9, 1), "ms": round(best * 1e3, 2), "ratio": round(n / float(sz.sum()), 3), "round_trip": ok}
+        return out
 
     # ------------------------------------------------------------------------------------------------------------
     def run(self, cfg, steps, warmup):
@@ -337,6 +369,8 @@ def main():
             secondary[name] = {"value": round(r["value"], 3), "unit": "GB/s", "ms_per_step": round(r["ms_per_step"], 3),
                                "workload": r["workload"], "ratio": r["result"]["ratio"], "phase_ms": r["phase_ms"],
                                "dominant_kernel": r["roofline"] and {k: r["roofline"][k] for k in ("kernel", "achieved", "frac")}}
+        if b.world == 1:
+            secondary["restore"] = b.restore_rates()
     cpu_baseline = None
     if b.rank == 0 and b.world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(args)
