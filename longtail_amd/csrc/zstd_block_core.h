@@ -126,6 +126,8 @@ typedef struct ZbShared /* LDS on the GPU (about 9.5 KiB per wave) */
     uint8_t mode[4], table_log[4], rle_sym[4];
     uint32_t useq_base[ZB_MAX_UNITS + 1], ulit_base[ZB_MAX_UNITS + 1], carry[ZB_MAX_UNITS];
     uint32_t part2[4]; /* bits of the four literal streams */
+    uint32_t small[2][16]; /* scratch the serial builders index by data (code lengths, weights): a local array indexed that way is
+                            * private memory -- or a 16-way select chain -- on the GPU */
     uint32_t v[ZV_COUNT];
 } ZbShared;
 
@@ -629,7 +631,8 @@ ZB_FN void zb_huffman_build(ZbShared* sh)
     /* canonical codes as the decoder assigns them (huf_decompress.c HUF_readDTableX1 / RFC 8878 §4.2.1.3): the
      * longest codes get the smallest values, symbols of equal length in symbol order */
     {
-        uint32_t count[ZB_HUF_MAXBITS + 2u], start[ZB_HUF_MAXBITS + 2u];
+        uint32_t* count = sh->small[0];
+        uint32_t* start = sh->small[1];
         const uint32_t maxbits = sh->v[ZV_HUF_MAXBITS];
         for (uint32_t l = 0; l <= ZB_HUF_MAXBITS + 1u; ++l)
             count[l] = 0;
@@ -671,7 +674,7 @@ ZB_FN uint32_t zb_write_huf_tree(ZbShared* sh, uint8_t* dst)
     }
     /* FSE-compressed weights: table log <= 6, two interleaved states (fse_decompress.c:174-238) */
     {
-        uint32_t hist[16];
+        uint32_t* hist = sh->small[0];
         int16_t* norm = sh->norm[0];
         uint32_t distinct = 0;
         for (uint32_t w = 0; w < 16u; ++w)
