@@ -926,8 +926,23 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
                                     // measured SLOWER (155 vs 141 ms / 4 GiB).
                                     if (!glob)
                                     {
+                                        // four bytes per step where the offset allows it (unaligned LDS dwords; a step that would
+                                        // cross the end of the ring goes byte by byte): the loop is lane-divergent, every trip
+                                        // costs the wave its mask bookkeeping
+                                        typedef uint32_t u32_a1 __attribute__((aligned(1)));
                                         const uint32_t so = (uint32_t)opm - offl;
-                                        for (uint32_t k = 0; k < mll; ++k)
+                                        uint32_t k = 0;
+                                        if (offl >= 4u)
+                                            for (; k + 4u <= mll; k += 4u)
+                                            {
+                                                const uint32_t a = RING(so + k), b = RING((uint32_t)opm + k);
+                                                if (a <= DEC_RING - 4u && b <= DEC_RING - 4u)
+                                                    *reinterpret_cast<u32_a1*>(s_ring + b) = *reinterpret_cast<const u32_a1*>(s_ring + a);
+                                                else
+                                                    for (uint32_t j = 0; j < 4u; ++j)
+                                                        s_ring[RING((uint32_t)opm + k + j)] = s_ring[RING(so + k + j)];
+                                            }
+                                        for (; k < mll; ++k)
                                             s_ring[RING((uint32_t)opm + k)] = s_ring[RING(so + k)];
                                     }
                                     else

@@ -1018,8 +1018,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             {
                 const uint32_t li = zx.need_lit(lit_cur, t_ll + 1u) + (i_ll - a_ll);
                 if (in)
-                    for (uint32_t b = 0; b < ll; ++b)
+                {
+                    typedef uint32_t u32_a1 __attribute__((aligned(1)));
+                    uint32_t b = 0;
+                    for (; b + 4u <= ll; b += 4u) // four bytes per trip of this lane-divergent loop (unaligned LDS dwords)
+                    {
+                        const uint32_t r = zx.ring(o_l + b);
+                        const uint32_t v = *reinterpret_cast<const u32_a1*>(s_lit + li + b);
+                        if (r <= ZX_RING - 4u)
+                            *reinterpret_cast<u32_a1*>(s_ring + r) = v;
+                        else
+                            for (uint32_t j = 0; j < 4u; ++j)
+                                s_ring[zx.ring(o_l + b + j)] = (uint8_t)(v >> (8u * j));
+                    }
+                    for (; b < ll; ++b)
                         s_ring[zx.ring(o_l + b)] = s_lit[li + b];
+                }
             }
             // matches in dependency rounds: everything before the first pending sequence's match is final
             // a source the ring may lose while this run appends (it holds the 8 KiB below op + t_adv) was flushed long ago: from
@@ -1042,8 +1056,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 {
                     if (!glob)
                     {
+                        typedef uint32_t u32_a1 __attribute__((aligned(1)));
                         const uint32_t so2 = o_m - off;
-                        for (uint32_t b = 0; b < ml; ++b)
+                        uint32_t b = 0;
+                        if (off >= 4u)
+                            for (; b + 4u <= ml; b += 4u)
+                            {
+                                const uint32_t ra = zx.ring(so2 + b), rb = zx.ring(o_m + b);
+                                if (ra <= ZX_RING - 4u && rb <= ZX_RING - 4u)
+                                    *reinterpret_cast<u32_a1*>(s_ring + rb) = *reinterpret_cast<const u32_a1*>(s_ring + ra);
+                                else
+                                    for (uint32_t j = 0; j < 4u; ++j)
+                                        s_ring[zx.ring(o_m + b + j)] = s_ring[zx.ring(so2 + b + j)];
+                            }
+                        for (; b < ml; ++b)
                             s_ring[zx.ring(o_m + b)] = s_ring[zx.ring(so2 + b)];
                     }
                     else
