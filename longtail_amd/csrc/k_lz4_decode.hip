@@ -252,7 +252,8 @@ struct PdReader
 
 // One sequence at position ip, lengths only.  0: a sequence, `next` = the token after it, `out` = bytes it produces; 1: the last
 // sequence of the payload (literals up to its very end); 2: nothing a decoder accepts at any output position.
-__device__ __forceinline__ int pd_hop(PdReader& r, const int64_t ip, const uint64_t cap, int64_t& next, uint64_t& out)
+__device__ __forceinline__ int pd_hop(PdReader& r, const int64_t ip, const uint64_t cap, int64_t& next, uint64_t& out,
+                                      uint32_t* lit_pos = nullptr, uint32_t* lit_len = nullptr)
 {
     const int64_t n = r.n;
     if (ip >= n)
@@ -262,6 +263,11 @@ __device__ __forceinline__ int pd_hop(PdReader& r, const int64_t ip, const uint6
     uint64_t len = token >> 4;
     if (len == 15 && !r.more_len(p, len, n - 15, cap))
         return 2;
+    if (lit_pos)
+    {
+        *lit_pos = (uint32_t)p;
+        *lit_len = (uint32_t)len;
+    }
     if (p + (int64_t)len > n - 8)
     {
         out = len;
@@ -552,6 +558,42 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
         };
         // literals: payload [p, p + len) -> the ring at output position o
         auto copy_lits = [&](I p, I o, I len) {
+            // A long run (incompressible stretches; a whole block of random data is ONE run) does not have to pass through the ring:
+            // bring the ring to a flush boundary, copy the bulk payload -> output directly with 16-byte stores, and leave the last
+            // DEC_RING bytes of the run to the loop below, so that the ring holds what later matches may reach.
+            if (len >= (I)(3u * DEC_RING))
+            {
+                const uint32_t mis = ((uint32_t)o + g) & (DEC_FLUSH - 1u);
+                I pre = mis ? (I)(DEC_FLUSH - mis) : (I)0;
+                while (pre > 0) // (at most one flush granule, the loop below in small)
+                {
+                    const uint32_t i = need(p, 1);
+                    I avail = (I)DEC_IN - (I)i;
+                    const uint32_t c = (uint32_t)(pre < avail ? pre : avail);
+                    for (uint32_t j = lane; j < c; j += 64)
+                        s_ring[RING((uint32_t)o + j)] = s_in[i + j];
+                    p += (I)c;
+                    o += (I)c;
+                    len -= (I)c;
+                    pre -= (I)c;
+                }
+                flush(o + (I)g); // now flushed == o + g, a multiple of the flush granule
+                const I bulk = ((len - (I)DEC_RING) / (I)DEC_FLUSH) * (I)DEC_FLUSH;
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                typedef u32x4 u32x4_a1 __attribute__((aligned(1)));
+                for (I q = 16 * (I)lane; q < bulk; q += 1024)
+                {
+                    const u32x4 v = *reinterpret_cast<const u32x4_a1*>(in + (int64_t)(p + q)); // (the payload has any alignment)
+                    if constexpr (UNIT)
+                        __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, (int)(uint32_t)(o + (I)g + q), 0, 16);
+                    else
+                        *reinterpret_cast<u32x4*>(out_al + (int64_t)(o + (I)g + q)) = v;
+                }
+                p += bulk;
+                o += bulk;
+                len -= bulk;
+                flushed += bulk; // (drained stays behind: a far match waits for these stores like for any flush)
+            }
             while (len > 0)
             {
                 const uint32_t i = need(p, 1);
@@ -1186,9 +1228,14 @@ __global__ __launch_bounds__(64) void k_lz4_pd_first(const uint8_t* __restrict__
     r.init(src + blk.src_off, blk.size, s_in, threadIdx.x);
     int64_t next = 0;
     uint64_t out = 0;
-    const int kind = pd_hop(r, 0, blk.dst_cap, next, out);
+    uint32_t lp = 0, ll = 0;
+    const int kind = pd_hop(r, 0, blk.dst_cap, next, out, &lp, &ll);
     if (threadIdx.x == 0)
-        first_end[b] = kind == 2 ? 0u : (uint32_t)next;
+    {
+        first_end[3 * b] = kind == 2 ? 0u : (uint32_t)next;
+        first_end[3 * b + 1] = kind == 2 ? 0u : lp; // where its literals are in the payload ...
+        first_end[3 * b + 2] = kind == 2 ? 0u : ll; // ... and how many: a unit that lies inside them is a plain copy
+    }
 }
 
 __global__ __launch_bounds__(64) void k_lz4_pd_tiles(const uint8_t* __restrict__ src, const PdBlock* __restrict__ blocks, uint32_t nblocks,
@@ -1202,7 +1249,7 @@ __global__ __launch_bounds__(64) void k_lz4_pd_tiles(const uint8_t* __restrict__
     const uint32_t b = pd_block_of(blocks, nblocks, t, true);
     const PdBlock blk = blocks[b];
     const uint32_t j = t - blk.tile_base;
-    if (j > 0 && ((uint64_t)j + 1) * PD_TILE <= first_end[b]) // inside the block's first sequence: no token of the chain is here
+    if (j > 0 && ((uint64_t)j + 1) * PD_TILE <= first_end[3 * b]) // inside the block's first sequence: no token of the chain is here
     {
         if (threadIdx.x == 0)
             tiles[t] = PdTile{PD_NONE, 0u, 0u, 0u};
@@ -1379,7 +1426,7 @@ __global__ __launch_bounds__(64) void k_lz4_pd_units(const uint8_t* __restrict__
                                                      const PdTile* __restrict__ tiles, const uint32_t* __restrict__ tile_op,
                                                      const uint32_t* __restrict__ unit_tile, PdState* __restrict__ state,
                                                      uint32_t* __restrict__ done, uint32_t* __restrict__ counters, PdTickets tk,
-                                                     uint32_t dec_nobatch, volatile uint32_t* dbg)
+                                                     uint32_t dec_nobatch, volatile uint32_t* dbg, const uint32_t* __restrict__ first)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN];
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[DEC_RING];
@@ -1421,7 +1468,42 @@ __global__ __launch_bounds__(64) void k_lz4_pd_units(const uint8_t* __restrict__
         // the link pass ran in an earlier launch: its tables are plain global data here
         const PdState st = state[b];
         uint32_t result = DEC_UNIT_OK;
-        if (k < st.nunits)
+        const uint32_t f_pos = first[3 * b + 1], f_len = first[3 * b + 2];
+        if (k + 1u < st.nunits && (uint64_t)(k + 1u) * PD_UNIT <= f_len)
+        {
+            // The whole unit lies inside the literals of the block's first sequence (a block of incompressible data is one sequence):
+            // a plain copy, nothing to parse.  The sequence itself is checked by the unit in which it ends (never this one).
+            const uint8_t* from = src + blk.src_off + f_pos + (uint64_t)k * PD_UNIT;
+            uint8_t* to = dst + blk.dst_off + (uint64_t)k * PD_UNIT;
+            const uint32_t head = (uint32_t)((16u - ((uintptr_t)to & 15u)) & 15u); // bytes up to the first aligned vector
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)to, 0, (int)PD_UNIT, 0x00020000);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef u32x4 u32x4_a1 __attribute__((aligned(1)));
+            if ((uint32_t)lane < head)
+                __builtin_amdgcn_raw_buffer_store_b8(from[lane], rs, lane, 0, 16);
+            const uint32_t nvec = (PD_UNIT - head) >> 4;
+            for (uint32_t v0 = 0; v0 < nvec; v0 += 256u) // four loads in flight per lane
+            {
+                u32x4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const uint32_t v = v0 + (uint32_t)(u * 64 + lane);
+                    q[u] = *reinterpret_cast<const u32x4_a1*>(from + head + 16u * (v < nvec ? v : 0u));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const uint32_t v = v0 + (uint32_t)(u * 64 + lane);
+                    if (v < nvec)
+                        __builtin_amdgcn_raw_buffer_store_b128(q[u], rs, (int)(head + 16u * v), 0, 16);
+                }
+            }
+            const uint32_t done_b = head + (nvec << 4);
+            if ((uint32_t)lane < PD_UNIT - done_b)
+                __builtin_amdgcn_raw_buffer_store_b8(from[done_b + (uint32_t)lane], rs, (int)(done_b + (uint32_t)lane), 0, 16);
+        }
+        else if (k < st.nunits)
         {
             const uint32_t j = unit_tile[blk.unit_base + k];
             PdUnit un;
@@ -1543,10 +1625,10 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
         for (uint32_t k = 0; k < rows; ++k)
             row_base[(size_t)k + 1] = row_base[k] + count[k];
     }
-    // device tables: [PdTile x ntiles][tile_op x ntiles][unit_tile x nunits][state x nb][order x nb][row_base x rows+1][done x nunits][counters x 8][first_end x nb][alt PdTile x ntiles][claim x ntiles]
+    // device tables: [PdTile x ntiles][tile_op x ntiles][unit_tile x nunits][state x nb][order x nb][row_base x rows+1][done x nunits][counters x 8][first_end, first literals' position and count x nb][alt PdTile x ntiles][claim x ntiles]
     const size_t o_tiles = 0, o_top = o_tiles + sizeof(PdTile) * ntiles, o_ut = o_top + 4 * ntiles, o_state = o_ut + 4 * nunits,
                  o_order = o_state + sizeof(PdState) * nb, o_rows = o_order + 4 * (size_t)nb, o_done = o_rows + 4 * ((size_t)rows + 1),
-                 o_cnt = o_done + 4 * nunits, o_first = o_cnt + 32, o_alt = (o_first + 4 * (size_t)nb + 15) & ~(size_t)15, o_claim = o_alt + sizeof(PdTile) * ntiles,
+                 o_cnt = o_done + 4 * nunits, o_first = o_cnt + 32, o_alt = (o_first + 12 * (size_t)nb + 15) & ~(size_t)15, o_claim = o_alt + sizeof(PdTile) * ntiles,
                  o_end = o_claim + 4 * ntiles;
     void *tab, *blk;
     int err = lthip_scratch(ctx, S_LZ4_STREAM, o_end, &tab);
@@ -1624,10 +1706,10 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     }
     if (small)
         hipLaunchKernelGGL(k_lz4_pd_units<int32_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, (uint8_t*)d_dst, d_tiles,
-                           d_top, d_ut, d_state, d_done, d_cnt, tk, nobatch, dbg);
+                           d_top, d_ut, d_state, d_done, d_cnt, tk, nobatch, dbg, (const uint32_t*)d_first);
     else
         hipLaunchKernelGGL(k_lz4_pd_units<int64_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, (uint8_t*)d_dst, d_tiles,
-                           d_top, d_ut, d_state, d_done, d_cnt, tk, nobatch, dbg);
+                           d_top, d_ut, d_state, d_done, d_cnt, tk, nobatch, dbg, (const uint32_t*)d_first);
     LTHIP_LAUNCH_CHECK(ctx);
     if (trace)
     {
