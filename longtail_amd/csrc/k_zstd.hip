@@ -913,14 +913,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             br.load_window();
             br.normalize();
             const uint32_t ov = zx_u(qo.y) + br.take(ob);
-            const uint32_t ml = zx_u(qm.y) + br.take(mb);
-            const uint32_t ll = zx_u(ql.y) + br.take(lb);
+            const uint32_t t2 = br.take(mb + lb); // match-length and literal-length extra bits are adjacent (16 + 16 at most)
+            const uint32_t ml = zx_u(qm.y) + (t2 >> lb);
+            const uint32_t ll = zx_u(ql.y) + (t2 & ((1u << lb) - 1u));
             if (MORE)
             {
+                // the three state fields are adjacent (LL, ML, OF from the top; at most 26 bits): one take, split with 32-bit shifts
                 br.normalize();
-                sl = (l0 & 0xFFFFu) + (br.take(nbl) << 3);
-                sm = (m0 & 0xFFFFu) + (br.take(nbm) << 3);
-                so = (o0 & 0xFFFFu) + (br.take(nbo) << 3);
+                const uint32_t t3 = br.take(nbl + nbm + nbo);
+                sl = (l0 & 0xFFFFu) + ((t3 >> (nbm + nbo)) << 3);
+                sm = (m0 & 0xFFFFu) + (((t3 >> nbo) & ((1u << nbm) - 1u)) << 3);
+                so = (o0 & 0xFFFFu) + ((t3 & ((1u << nbo) - 1u)) << 3);
             }
             // into lane k of the three record registers (gfx9 allows one SGPR per VOP3: the lane select goes through M0);
             // what the serial decoder checks per sequence is checked for the whole batch by the vector unit below
