@@ -115,6 +115,15 @@ class Bench:
                 dist.init_process_group(self.backend)
         self.ctx = Context(dev_index)
         self.bufs = {}
+        # --collective c: the exchange's all-gathers through the C ABI (lthip_comm_allgather = ncclAllGather on the context's stream)
+        # instead of torch.distributed; the unique id travels through the process group the ranks were launched with
+        self.comm = None
+        if self.world > 1 and args.collective == "c" and self.backend == "nccl":
+            from longtail_amd.lib import Comm
+
+            box = [Comm.unique_id(self.lib) if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self.comm = Comm(self.ctx, self.world, self.rank, box[0])
 
     def buf(self, name, nbytes, dtype=None, pinned=False):
         """A named buffer of at least nbytes, kept across configurations."""
@@ -219,7 +228,7 @@ class Bench:
             t1 = time.perf_counter()
             if world > 1:
                 counts = out_first[1 : len(mine) + 1] - out_first[: len(mine)]
-                ex = exchange_chunks(part, counts, out_hash, out_lens, total, ctx)
+                ex = exchange_chunks(part, counts, out_hash, out_lens, total, ctx, comm=self.comm)
                 all_hash, all_lens, job_first = ex["hashes"], ex["lens"], ex["job_first"].astype(np.uint64)
                 my_jobs = mine
             else:
@@ -350,6 +359,8 @@ def main():
     ap.add_argument("--codec", choices=["lz4", "zstd"], default="lz4", help="block codec (BASELINE.json configs[4] uses zstd)")
     ap.add_argument("--no-compress", action="store_true", help="diagnostic: skip WriteContent (the line is then not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--collective", choices=["torch", "c"], default="torch",
+                    help="N > 1: the exchange's all-gathers by torch.distributed (RCCL backend) or by the C ABI's lthip_comm_allgather")
     ap.add_argument("--no-secondary", action="store_true", help="skip the compressible / mixed-size-tree measurements")
     ap.add_argument("--cpu-gib", type=float, default=8.0, help="sample size of the CPU baseline")
     args = ap.parse_args()

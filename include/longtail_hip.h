@@ -391,6 +391,19 @@ LTHIP_EXPORT int lthip_exchange_layout(uint64_t job_count, const uint32_t* job_r
                                        const uint32_t* gathered_counts, uint64_t count_stride, uint64_t chunk_stride,
                                        uint64_t* job_src, uint64_t* job_dst /* job_count + 1 */, uint32_t* job_chunks /* may be NULL */);
 
+/* The collective itself behind the C ABI (comm.hip): RCCL's all-gather on the context's stream, one process per GPU.  RCCL is
+ * bound at run time (dlopen): ENOSYS where it is missing.  Rank 0 makes the 128-byte id, the embedder carries it to the other
+ * processes (any side channel), every rank creates its communicator with it.  lthip_comm_allgather: every rank contributes
+ * `count` elements of `elem_bytes` from d_send; d_recv receives rank r's contribution at element r * count (the padded
+ * all-gathers lthip_exchange_layout describes).  Asynchronous on the context's stream like every other bulk call. */
+#define LTHIP_COMM_ID_BYTES 128
+typedef struct lthip_comm lthip_comm;
+LTHIP_EXPORT int lthip_comm_unique_id(void* id128);
+LTHIP_EXPORT int lthip_comm_create(lthip_ctx* ctx, int nranks, int rank, const void* id128, lthip_comm** out);
+LTHIP_EXPORT int lthip_comm_destroy(lthip_comm* comm);
+LTHIP_EXPORT int lthip_comm_allgather(lthip_ctx* ctx, lthip_comm* comm, const void* d_send, void* d_recv, uint64_t count,
+                                      uint32_t elem_bytes);
+
 /* ---- synthetic assets (include/longtail_synth.h), bench/test input generator ------------------------ */
 LTHIP_EXPORT int lthip_synth_fill(lthip_ctx* ctx, void* d_dst, uint32_t asset_count, const uint64_t* asset_offsets /*host*/,
                                   const uint64_t* asset_sizes /*host*/, const uint64_t* asset_seeds /*host*/, int kind);

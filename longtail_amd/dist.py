@@ -74,20 +74,27 @@ class JobPartition:
         return src, dst, cnt
 
 
-def _allgather(t: torch.Tensor, world: int, group=None) -> torch.Tensor:
+def _allgather(t: torch.Tensor, world: int, group=None, comm=None) -> torch.Tensor:
+    if comm is not None and t.device.type == "cuda":
+        # the collective through the C ABI (lthip_comm_allgather = ncclAllGather on the context's stream); the host reads what it
+        # gathered only after the context has been synchronised
+        out = comm.allgather(t)
+        comm.ctx.sync()
+        return out
     out = torch.empty(t.numel() * world, dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t.contiguous(), group=group)
     return out
 
 
 def exchange_chunks(part: JobPartition, job_counts: torch.Tensor, hashes: torch.Tensor, lens: torch.Tensor | None, total: int,
-                    ctx=None, group=None):
+                    ctx=None, group=None, comm=None):
     """job_counts: int32 tensor, chunk count of each of THIS rank's jobs (ascending job order); hashes (int64) / lens (int32):
     tensors whose first `total` entries are this rank's chunks in that order.  Returns a dict:
       hashes, lens   all ranks' chunks in JOB order (lens None when not given)
       job_first      int64 numpy [job_count + 1]: index of each job's first chunk (last entry = total chunks)
       mine           (job indices of this rank, ascending)
     On CUDA tensors with a context the reorder is one lthip_gather_ranges per array; CPU tensors (gloo tests) are indexed.
+    `comm` (longtail_amd.lib.Comm): run the three all-gathers through the C ABI's RCCL entry instead of torch.distributed.
     """
     world = part.world
     rank = dist.get_rank(group) if (dist.is_initialized() and world > 1) else 0
@@ -98,7 +105,7 @@ def exchange_chunks(part: JobPartition, job_counts: torch.Tensor, hashes: torch.
         np.cumsum(job_counts.cpu().numpy().astype(np.int64), out=first[1:])
         return dict(hashes=hashes[:total], lens=None if lens is None else lens[:total], job_first=first, mine=mine)
     out_dev = hashes.device
-    staged = out_dev.type == "cuda" and dist.get_backend(group) != "nccl"  # functional path for CPU-only backends on a GPU box
+    staged = comm is None and out_dev.type == "cuda" and dist.get_backend(group) != "nccl"  # functional path for CPU-only backends on a GPU box
     if staged:
         job_counts, hashes, lens = job_counts.cpu(), hashes[:total].cpu(), None if lens is None else lens[:total].cpu()
     dev = hashes.device
@@ -106,7 +113,7 @@ def exchange_chunks(part: JobPartition, job_counts: torch.Tensor, hashes: torch.
     count_stride = max(int(part.jobs_per_rank.max()), 1)
     send = torch.zeros(count_stride, dtype=torch.int32, device=dev)
     send[: len(mine)] = job_counts.to(torch.int32)
-    gathered_counts = _allgather(send, world, group).cpu().numpy().view(np.uint32)
+    gathered_counts = _allgather(send, world, group, comm).cpu().numpy().view(np.uint32)
     per_rank_total = gathered_counts.reshape(world, count_stride).astype(np.int64).sum(axis=1)
     assert int(per_rank_total[rank]) == total
     # (2) chunk arrays, padded to the largest rank
@@ -117,8 +124,8 @@ def exchange_chunks(part: JobPartition, job_counts: torch.Tensor, hashes: torch.
             return t[:chunk_stride]
         return torch.nn.functional.pad(t[:total], (0, chunk_stride - total))
 
-    g_hash = _allgather(padded(hashes), world, group)
-    g_lens = _allgather(padded(lens), world, group) if lens is not None else None
+    g_hash = _allgather(padded(hashes), world, group, comm)
+    g_lens = _allgather(padded(lens), world, group, comm) if lens is not None else None
     src, dst, cnt = part.layout(gathered_counts, count_stride, chunk_stride)
     n_all = int(dst[-1])
     if out_dev.type == "cuda" and ctx is not None and not staged:

@@ -136,6 +136,10 @@ class HipLib:
         sig("lthip_make_jobs", i32, [u32, vp, u32, u64, vp, vp, vp])
         sig("lthip_partition_jobs", i32, [u64, vp, u32, i32, vp, vp])
         sig("lthip_exchange_layout", i32, [u64, vp, u32, vp, u64, u64, vp, vp, vp])
+        sig("lthip_comm_unique_id", i32, [vp])
+        sig("lthip_comm_create", i32, [vp, i32, i32, vp, P(vp)])
+        sig("lthip_comm_destroy", i32, [vp])
+        sig("lthip_comm_allgather", i32, [vp, vp, vp, vp, u64, u32])
 
     def device_count(self) -> int:
         return int(self.dll.lthip_device_count())
@@ -391,6 +395,46 @@ class Context:
         self._check(self.lib.dll.lthip_dedup_first_seen(self.h, n, _ptr(hashes), _ptr(first), _ptr(uniq)),
                     "lthip_dedup_first_seen")
         return first[:n], uniq
+
+
+class Comm:
+    """RCCL communicator behind the C ABI (comm.hip): one process per GPU.  `unique_id()` on rank 0, carried to the other ranks by
+    the embedder (bench.py: the torch.distributed store), then `Comm(ctx, nranks, rank, id)` everywhere."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id(lib: Optional[HipLib] = None) -> bytes:
+        lib = lib or load()
+        buf = (C.c_ubyte * Comm.ID_BYTES)()
+        err = lib.dll.lthip_comm_unique_id(C.addressof(buf))
+        if err:
+            raise LongtailHipError(f"lthip_comm_unique_id: errno {err}")
+        return bytes(buf)
+
+    def __init__(self, ctx: "Context", nranks: int, rank: int, unique_id: bytes):
+        assert len(unique_id) == Comm.ID_BYTES
+        self.ctx, self.nranks, self.rank = ctx, nranks, rank
+        buf = (C.c_ubyte * Comm.ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        ctx._check(ctx.lib.dll.lthip_comm_create(ctx.h, nranks, rank, C.addressof(buf), C.byref(h)), "lthip_comm_create")
+        self.h = h
+
+    def allgather(self, send, recv=None):
+        """`send`: contiguous device tensor; returns `recv` = the ranks' tensors back to back (nranks * send.numel() elements)."""
+        import torch
+
+        send = send.contiguous()
+        if recv is None:
+            recv = torch.empty(send.numel() * self.nranks, dtype=send.dtype, device=send.device)
+        self.ctx._check(self.ctx.lib.dll.lthip_comm_allgather(self.ctx.h, self.h, _ptr(send), _ptr(recv), send.numel(), send.element_size()),
+                        "lthip_comm_allgather")
+        return recv
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.dll.lthip_comm_destroy(self.h)
+            self.h = None
 
 
 class IngestConfig(C.Structure):
