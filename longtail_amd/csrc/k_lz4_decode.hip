@@ -876,7 +876,7 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
                 if (d <= 40 && !dec_nobatch && (__builtin_amdgcn_readlane(w, (int)d) >> 4) != 15u)
                 {
                     constexpr uint32_t INLANE_MAX = 64u;                    // longest match a lane copies on its own
-                    constexpr uint32_t RING_SAFE = DEC_RING - 1280u;        // a batch writes up to 16 x (14 + 64) bytes ahead of `op`
+                    constexpr uint32_t RING_SAFE = DEC_RING - 1792u;        // a batch writes up to 21 x (14 + 64) bytes ahead of `op`
                     const uint32_t litl = w >> 4, mlcl = w & 15u;
                     const int e1 = lane + 1 + (int)litl;                    // where my offset would be
                     const bool one = mlcl == 15u;                           // one match-length byte behind the offset (19..273 bytes)
@@ -888,25 +888,19 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
                     // such a token is taken as the LAST of a batch
                     const bool coop = candidate && (mll > INLANE_MAX || (mll > 18u && offl > RING_SAFE));
                     const uint64_t okm = __builtin_amdgcn_ballot_w64(candidate && !coop), cpm = __builtin_amdgcn_ballot_w64(coop);
-                    uint64_t vis = 0ull;
-                    int cur = (int)d, ntok = 0;
-                    while (cur < 64 && ntok < 16)
+                    // the chain of real tokens from the current position: a bit walks up the mask of in-lane candidates (shifted out
+                    // of the word when the chain leaves the window); a wave-copied candidate where it stops is taken as the last one
+                    uint64_t vis = 0ull, bit = 1ull << d;
+                    uint32_t cur = (uint32_t)d;
+                    while (okm & bit)
                     {
-                        const uint64_t bit = 1ull << cur;
-                        if (okm & bit)
-                        {
-                            vis |= bit;
-                            cur += (int)__builtin_amdgcn_readlane(seqlen, cur);
-                            ++ntok;
-                            continue;
-                        }
-                        if (cpm & bit)
-                        {
-                            vis |= bit;
-                            ++ntok;
-                        }
-                        break;
+                        vis |= bit;
+                        const uint32_t step = __builtin_amdgcn_readlane(seqlen, (int)cur);
+                        cur += step;
+                        bit <<= step;
                     }
+                    vis |= cpm & bit;
+                    const int ntok = __builtin_popcountll(vis);
                     if (ntok >= 2)
                     {
                         const bool tv = (vis >> lane) & 1ull;
@@ -956,7 +950,7 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
                             while (pend)
                             {
                                 const int first = __builtin_ctzll(pend);
-                                // positions relative to `op` (a batch appends at most 1280 bytes): everything before the first pending
+                                // positions relative to `op` (a batch appends at most 1792 bytes): everything before the first pending
                                 // token's match is final
                                 const int32_t rel_m = (int32_t)(opm - op);
                                 const int32_t frontier = (int32_t)__builtin_amdgcn_readlane((uint32_t)rel_m, first);
