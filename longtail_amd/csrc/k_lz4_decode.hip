@@ -947,6 +947,25 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
                                 drained = flushed;
                             }
                             uint64_t pend = vis & ~cpm;
+                            // tokens whose source has left the ring (rare): from global memory, first -- that data is final, nothing in
+                            // the batch feeds it -- and in a branch of its own, so that its 18 addresses are not computed for every batch
+                            const uint64_t globm = __builtin_amdgcn_ballot_w64(glob);
+                            if (globm)
+                            {
+                                if (glob)
+                                {
+                                    const int64_t sp = (int64_t)opm - (int64_t)offl; // > RING_SAFE bytes back: cannot overlap the target
+                                    uint32_t bytes[18];
+#pragma unroll
+                                    for (uint32_t k = 0; k < 18u; ++k)
+                                        bytes[k] = k < mll ? out_byte(sp + k) : 0u;
+#pragma unroll
+                                    for (uint32_t k = 0; k < 18u; ++k)
+                                        if (k < mll)
+                                            s_ring[RING((uint32_t)opm + k)] = (uint8_t)bytes[k];
+                                }
+                                pend &= ~globm;
+                            }
                             while (pend)
                             {
                                 const int first = __builtin_ctzll(pend);
@@ -957,43 +976,25 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
                                 const bool ready = ((pend >> lane) & 1ull) && (lane == first || rel_m - (int32_t)offl + (int32_t)mll <= frontier);
                                 if (ready)
                                 {
-                                    // byte by byte in the lane; overlapping matches (offset < length) replicate their seed exactly
-                                    // because every byte is stored before the next is read.  "All reads first, then all stores" was
-                                    // measured SLOWER (155 vs 141 ms / 4 GiB).
-                                    if (!glob)
-                                    {
-                                        // four bytes per step where the offset allows it (unaligned LDS dwords; a step that would
-                                        // cross the end of the ring goes byte by byte): the loop is lane-divergent, every trip
-                                        // costs the wave its mask bookkeeping
-                                        typedef uint32_t u32_a1 __attribute__((aligned(1)));
-                                        const uint32_t so = (uint32_t)opm - offl;
-                                        uint32_t k = 0;
-                                        if (offl >= 4u)
-                                            for (; k + 4u <= mll; k += 4u)
-                                            {
-                                                const uint32_t a = RING(so + k), b = RING((uint32_t)opm + k);
-                                                if (a <= DEC_RING - 4u && b <= DEC_RING - 4u)
-                                                    *reinterpret_cast<u32_a1*>(s_ring + b) = *reinterpret_cast<const u32_a1*>(s_ring + a);
-                                                else
-                                                    for (uint32_t j = 0; j < 4u; ++j)
-                                                        s_ring[RING((uint32_t)opm + k + j)] = s_ring[RING(so + k + j)];
-                                            }
-                                        for (; k < mll; ++k)
-                                            s_ring[RING((uint32_t)opm + k)] = s_ring[RING(so + k)];
-                                    }
-                                    else
-                                    {
-                                        // from global memory the source lies > RING_SAFE bytes back: it cannot overlap the target
-                                        const int64_t sp = (int64_t)opm - (int64_t)offl;
-                                        uint32_t bytes[18];
-#pragma unroll
-                                        for (uint32_t k = 0; k < 18u; ++k)
-                                            bytes[k] = k < mll ? out_byte(sp + k) : 0u;
-#pragma unroll
-                                        for (uint32_t k = 0; k < 18u; ++k)
-                                            if (k < mll)
-                                                s_ring[RING((uint32_t)opm + k)] = (uint8_t)bytes[k];
-                                    }
+                                    // four bytes per step where the offset allows it (unaligned LDS dwords; a step that would cross the
+                                    // end of the ring goes byte by byte): the loop is lane-divergent, every trip costs the wave its mask
+                                    // bookkeeping.  Overlapping matches (offset < length) replicate their seed exactly because every
+                                    // byte is stored before the next is read.
+                                    typedef uint32_t u32_a1 __attribute__((aligned(1)));
+                                    const uint32_t so = (uint32_t)opm - offl;
+                                    uint32_t k = 0;
+                                    if (offl >= 4u)
+                                        for (; k + 4u <= mll; k += 4u)
+                                        {
+                                            const uint32_t a = RING(so + k), b = RING((uint32_t)opm + k);
+                                            if (a <= DEC_RING - 4u && b <= DEC_RING - 4u)
+                                                *reinterpret_cast<u32_a1*>(s_ring + b) = *reinterpret_cast<const u32_a1*>(s_ring + a);
+                                            else
+                                                for (uint32_t j = 0; j < 4u; ++j)
+                                                    s_ring[RING((uint32_t)opm + k + j)] = s_ring[RING(so + k + j)];
+                                        }
+                                    for (; k < mll; ++k)
+                                        s_ring[RING((uint32_t)opm + k)] = s_ring[RING(so + k)];
                                 }
                                 pend &= ~__builtin_amdgcn_ballot_w64(ready);
                             }
