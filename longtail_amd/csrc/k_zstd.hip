@@ -1054,6 +1054,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 zx.drained = zx.flushed;
             }
             uint64_t pend = __builtin_amdgcn_ballot_w64(in && ml != 0u);
+            // sources that have left the ring (rare): from global memory, first and in a branch of its own (that data is final, and
+            // the 18 addresses are not computed for every run)
+            const uint64_t globm = __builtin_amdgcn_ballot_w64(glob);
+            if (globm)
+            {
+                if (glob)
+                {
+                    uint32_t bytes[18];
+#pragma unroll
+                    for (uint32_t b = 0; b < 18u; ++b)
+                        bytes[b] = b < ml ? zx.out_al[o_m - off + b + zx.g] : 0u;
+#pragma unroll
+                    for (uint32_t b = 0; b < 18u; ++b)
+                        if (b < ml)
+                            s_ring[zx.ring(o_m + b)] = (uint8_t)bytes[b];
+                }
+                pend &= ~globm;
+            }
             while (pend)
             {
                 const int first = __builtin_ctzll(pend);
@@ -1062,35 +1080,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 const bool ready = ((pend >> lane) & 1ull) && (lane == first || rel_m - (int32_t)off + (int32_t)ml <= frontier);
                 if (ready)
                 {
-                    if (!glob)
-                    {
-                        typedef uint32_t u32_a1 __attribute__((aligned(1)));
-                        const uint32_t so2 = o_m - off;
-                        uint32_t b = 0;
-                        if (off >= 4u)
-                            for (; b + 4u <= ml; b += 4u)
-                            {
-                                const uint32_t ra = zx.ring(so2 + b), rb = zx.ring(o_m + b);
-                                if (ra <= ZX_RING - 4u && rb <= ZX_RING - 4u)
-                                    *reinterpret_cast<u32_a1*>(s_ring + rb) = *reinterpret_cast<const u32_a1*>(s_ring + ra);
-                                else
-                                    for (uint32_t j = 0; j < 4u; ++j)
-                                        s_ring[zx.ring(o_m + b + j)] = s_ring[zx.ring(so2 + b + j)];
-                            }
-                        for (; b < ml; ++b)
-                            s_ring[zx.ring(o_m + b)] = s_ring[zx.ring(so2 + b)];
-                    }
-                    else
-                    {
-                        uint32_t bytes[18];
-#pragma unroll
-                        for (uint32_t b = 0; b < 18u; ++b)
-                            bytes[b] = b < ml ? zx.out_al[o_m - off + b + zx.g] : 0u;
-#pragma unroll
-                        for (uint32_t b = 0; b < 18u; ++b)
-                            if (b < ml)
-                                s_ring[zx.ring(o_m + b)] = (uint8_t)bytes[b];
-                    }
+                    typedef uint32_t u32_a1 __attribute__((aligned(1)));
+                    const uint32_t so2 = o_m - off;
+                    uint32_t b = 0;
+                    if (off >= 4u)
+                        for (; b + 4u <= ml; b += 4u)
+                        {
+                            const uint32_t ra = zx.ring(so2 + b), rb = zx.ring(o_m + b);
+                            if (ra <= ZX_RING - 4u && rb <= ZX_RING - 4u)
+                                *reinterpret_cast<u32_a1*>(s_ring + rb) = *reinterpret_cast<const u32_a1*>(s_ring + ra);
+                            else
+                                for (uint32_t j = 0; j < 4u; ++j)
+                                    s_ring[zx.ring(o_m + b + j)] = s_ring[zx.ring(so2 + b + j)];
+                        }
+                    for (; b < ml; ++b)
+                        s_ring[zx.ring(o_m + b)] = s_ring[zx.ring(so2 + b)];
                 }
                 pend &= ~__builtin_amdgcn_ballot_w64(ready);
             }
