@@ -788,6 +788,7 @@ struct ZxBits
     uint64_t wbit0;        // arena bit of window bit 0
     uint64_t acc;          // the next bits to read, first one on top
     uint32_t pos;          // bits of the stream not consumed yet
+    uint32_t rel;          // window bit one past the next bit to read (= bits of the window still unread)
     __device__ __forceinline__ void load_window()
     {
         const uint64_t top = base + (uint64_t)pos; // arena bit one past the next bit to read
@@ -802,12 +803,18 @@ struct ZxBits
         lo = ((uint64_t)w.y << 32) | w.x;
         hi = ((uint64_t)w.w << 32) | w.z;
         wbit0 = d * 32ull;
+        rel = (uint32_t)(top - wbit0); // 97 .. 128 (less only at the very start of the arena)
+    }
+    // a sequence takes at most 89 bits: the window of the one before usually still holds them
+    __device__ __forceinline__ void ensure_window()
+    {
+        if (rel < 89u)
+            load_window();
     }
     // acc = the 64 bits below pos (zeros below the window's bit 0, which only happens where the stream has no bits either)
     __device__ __forceinline__ void normalize()
     {
-        const uint32_t r = (uint32_t)(base + (uint64_t)pos - wbit0); // window bit one past the next bit: 1 .. 128
-        const uint32_t s = 128u - r;                                  // shift the 128-bit window left by s, keep the upper half
+        const uint32_t s = 128u - rel; // shift the 128-bit window left by s, keep the upper half
         const uint64_t up = (hi << (s & 63u)) | ((s & 63u) ? lo >> (64u - (s & 63u)) : 0ull);
         acc = s < 64u ? up : lo << (s & 63u);
     }
@@ -816,6 +823,7 @@ struct ZxBits
         const uint32_t v = (uint32_t)((acc >> 1) >> (63u - n));
         acc <<= n;
         pos -= n;
+        rel -= n;
         return v;
     }
 };
@@ -879,6 +887,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     br.pos = pos;
     br.lo = br.hi = br.acc = 0;
     br.wbit0 = 0;
+    br.rel = 0;
     uint32_t sl = 0, so = 0, sm = 0;
     if (!bad)
     {
@@ -910,7 +919,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const uint32_t nbl = (l0 >> 16) & 255u, nbm = (m0 >> 16) & 255u, nbo = (o0 >> 16) & 255u;
             if (GUARD && ob + mb + lb + (MORE ? nbl + nbm + nbo : 0u) > br.pos)
                 return false; // the stream runs out: the serial decoder says how
-            br.load_window();
+            br.ensure_window();
             br.normalize();
             const uint32_t ov = zx_u(qo.y) + br.take(ob);
             const uint32_t t2 = br.take(mb + lb); // match-length and literal-length extra bits are adjacent (16 + 16 at most)
@@ -918,8 +927,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const uint32_t ll = zx_u(ql.y) + (t2 & ((1u << lb) - 1u));
             if (MORE)
             {
-                // the three state fields are adjacent (LL, ML, OF from the top; at most 26 bits): one take, split with 32-bit shifts
-                br.normalize();
+                // the three state fields are adjacent (LL, ML, OF from the top; at most 26 bits): one take, split with 32-bit shifts;
+                // the accumulator still holds them unless this sequence has taken more than 64 bits in all (rare)
+                if (ob + mb + lb + nbl + nbm + nbo > 64u)
+                    br.normalize();
                 const uint32_t t3 = br.take(nbl + nbm + nbo);
                 sl = (l0 & 0xFFFFu) + ((t3 >> (nbm + nbo)) << 3);
                 sm = (m0 & 0xFFFFu) + (((t3 >> nbo) & ((1u << nbm) - 1u)) << 3);
