@@ -786,8 +786,6 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
         DEC_T0();
         while (entered)
         {
-            PD_DBG(6, ip);
-            PD_DBG(7, op);
             if (UNIT && !un.last && op >= hi)
             {
                 flush(hi + (I)g);
