@@ -39,7 +39,7 @@ __device__ __forceinline__ uint32_t zb_scan_excl(uint32_t v, uint32_t* total)
     return incl - v;
 }
 #ifdef LTHIP_ZB_PROF /* debug build only: cycles per phase of zb_encode_block, summed over all pieces (lane 0) */
-__device__ unsigned long long g_zb_prof[16];
+__device__ unsigned long long g_zb_prof[24];
 __device__ unsigned long long g_zb_last[1 << 16];
 #define ZB_MARK(i)                                                                                     \
     do                                                                                                 \
@@ -399,10 +399,10 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
 #ifdef LTHIP_ZB_PROF
 extern "C" __attribute__((visibility("default"))) int lthip_zb_prof_dump(void)
 {
-    unsigned long long h[16];
+    unsigned long long h[24];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_zb_prof), sizeof(h)) != hipSuccess)
         return -1;
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < 24; ++i)
         if (h[i])
             fprintf(stderr, "zb phase ending at mark %2d: %.3f ms wave-time (100 MHz clock)\n", i, (double)h[i] / 1e5);
     memset(h, 0, sizeof(h));
@@ -595,10 +595,17 @@ __global__ __launch_bounds__(64) void k_zstd_prepare(const uint8_t* __restrict__
         uint8_t* lits = lit_scratch + (uint64_t)slot * (ZD_LIT_MAX + 64u);
         if (lane == 0)
             sh.v[ZDV_PREP] = 1;
+#ifdef LTHIP_ZB_PROF
+        if (lane == 0)
+            g_zb_last[blockIdx.x] = wall_clock64();
+#endif
         __syncthreads();
         const uint32_t content = out_sizes[it.payload] == ZD_ERROR ? 0u : out_sizes[it.payload]; // k_zstd_split stated it
         const uint32_t expect = content > it.out0 ? (content - it.out0 < ZB ? content - it.out0 : ZB) : 0u;
         const uint32_t n = zd_decode_payload_ex(src + it.src_off, it.size, dst + blk.dst_off, blk.dst_cap, lits, &sh, lane, it.out0);
+#ifdef LTHIP_ZB_PROF
+        ZB_MARK(13); /* prepare: 11 = up to the block, 12 = literals, 13 = sequence header + tables, 14 = export */
+#endif
         ZPrep pr;
         pr.bits_off = 0;
         pr.bits_size = pr.nbseq = pr.nlit = 0;
@@ -652,6 +659,9 @@ __global__ __launch_bounds__(64) void k_zstd_prepare(const uint8_t* __restrict__
             pr.status = ZP_DONE; // a raw or RLE block, or one without sequences: the core has written it
         if (lane == 0)
             prep[i] = pr;
+#ifdef LTHIP_ZB_PROF
+        ZB_MARK(14);
+#endif
         __syncthreads();
     }
 }

@@ -67,6 +67,8 @@ typedef struct ZdShared
     /* small tables the builders index dynamically: in shared memory, because a local array indexed by data is private memory on
      * the GPU (one memory round trip, or a 64-way select chain, per access -- the FSE builder alone cost 1.7 ms per block) */
     uint16_t next[64];
+    uint16_t cum[64 + 2]; /* zd_build_fse_par: first table cell (in spread order) of every symbol */
+    uint32_t tb_maxsym[3], tb_log[3], tb_build[3]; /* the sequence tables whose description was read and that are still to be built */
     uint32_t rank_start[ZB_HUF_MAXBITS + 3u];
     uint32_t rank_cnt[ZB_HUF_MAXBITS + 3u];
     uint32_t rep[3];
@@ -217,6 +219,114 @@ ZB_FN int zd_build_fse(ZdFse* t, const int16_t* norm, uint32_t maxsym, uint32_t 
 #define ZD_ABLATE 0u /* timing experiments of the kernel build */
 #endif
 
+/* The same table built by ALL lanes together (the three sequence tables of a block; the serial builder above spends ~250 cycles
+ * per cell on a chain of dependent shared-memory updates: 0.7 M cycles per block).  Called by every lane, outside ZB_SERIAL; the
+ * caller synchronises before and after.  Every step is a ZB_PAR_FOR:
+ *   1. per symbol: the low-probability symbols (-1) take the top cells, in symbol order from the top down;
+ *      cum[s] = number of cells of the symbols before s (counts > 0 only);
+ *   2. per step j of the spread walk (cell p = j * step mod size, cells above the threshold are skipped): its rank among the
+ *      cells that count is j minus the skipped cells met so far, each of which is met at step q * step^-1 mod size; the symbol
+ *      whose run [cum[s], cum[s + 1]) holds that rank gets the cell.
+ *      Steps 1 and 2 also set the cell's bit in the symbol's own occupancy mask (one bit per cell, 32 cells per word);
+ *   3. per symbol: running count of its cells before every 32-cell word;
+ *   4. per cell: its number among the symbol's cells IN CELL ORDER = that count + the mask bits below it; state bits and base
+ *      follow from the number as in the serial builder.
+ * masks: 64 * 16 words, pre: 64 * 16 halfwords of scratch.  Returns nonzero for what the serial builder rejects. */
+#define ZD_FSE_PAR_MASK_WORDS (64u * 16u)
+ZB_FN int zd_build_fse_par(ZdFse* t, const int16_t* norm, uint32_t maxsym, uint32_t tl, uint16_t* cum, uint32_t* masks, uint16_t* pre,
+                           uint32_t zl)
+{
+    const uint32_t size = 1u << tl, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
+    const uint32_t W = (size + 31u) >> 5; /* mask words per symbol */
+    uint32_t nlow = 0, total = 0, stepinv;
+    if (maxsym > 63u || tl > 9u || tl < 4u) /* (step is odd from 16 cells on; the format's tables have 32 or more) */
+        return 1;
+    for (uint32_t s = 0; s <= maxsym; ++s) /* (every lane: a few dozen reads of the same words) */
+    {
+        nlow += norm[s] == -1 ? 1u : 0u;
+        total += norm[s] > 0 ? (uint32_t)norm[s] : 0u;
+    }
+    if (total + nlow != size)
+        return 1; /* the counts do not fill the table exactly */
+    {
+        /* step is odd: its inverse modulo the power of two by Newton's iteration (3 bits -> 6 -> 12) */
+        uint32_t x = step; /* correct to 3 bits for every odd number */
+        x *= 2u - step * x;
+        x *= 2u - step * x;
+        stepinv = x & mask;
+    }
+    const uint32_t high = size - 1u - nlow;
+    ZB_PAR_FOR(i, (maxsym + 1u) * W) masks[i] = 0;
+    ZB_SYNC_LDS();
+    ZB_PAR_FOR(s, maxsym + 1u)
+    {
+        uint32_t before = 0, low_before = 0;
+        for (uint32_t q = 0; q < s; ++q)
+        {
+            before += norm[q] > 0 ? (uint32_t)norm[q] : 0u;
+            low_before += norm[q] == -1 ? 1u : 0u;
+        }
+        cum[s] = (uint16_t)before;
+        if (norm[s] == -1)
+        {
+            const uint32_t p = size - 1u - low_before;
+            t->sym[p] = (uint8_t)s;
+            zb_atomic_or(&masks[s * W + (p >> 5)], 1u << (p & 31u));
+        }
+        if (s == maxsym)
+            cum[s + 1u] = (uint16_t)(before + (norm[s] > 0 ? (uint32_t)norm[s] : 0u));
+    }
+    ZB_SYNC_LDS();
+    ZB_PAR_FOR(j, size)
+    {
+        const uint32_t p = (j * step) & mask;
+        if (p <= high)
+        {
+            uint32_t skipped = 0, lo = 0, hi = maxsym + 1u;
+            for (uint32_t q = high + 1u; q < size; ++q)
+                skipped += ((q * stepinv) & mask) < j ? 1u : 0u;
+            {
+                const uint32_t g = j - skipped; /* rank of this cell among the cells that count */
+                while (hi - lo > 1u) /* last symbol whose run starts at or before g (runs of absent symbols are empty: never them) */
+                {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (cum[mid] <= g)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+            }
+            t->sym[p] = (uint8_t)lo;
+            zb_atomic_or(&masks[lo * W + (p >> 5)], 1u << (p & 31u));
+        }
+    }
+    ZB_SYNC_LDS();
+    ZB_PAR_FOR(s, maxsym + 1u)
+    {
+        uint32_t running = norm[s] == -1 ? 1u : norm[s] > 0 ? (uint32_t)norm[s] : 0u; /* the first cell's number */
+        for (uint32_t w = 0; w < W; ++w)
+        {
+            pre[s * W + w] = (uint16_t)running;
+            running += (uint32_t)__builtin_popcount(masks[s * W + w]);
+        }
+    }
+    ZB_SYNC_LDS();
+    ZB_PAR_FOR(u, size)
+    {
+        const uint32_t k = (uint32_t)t->sym[u] * W + (u >> 5);
+        const uint32_t ns = pre[k] + (uint32_t)__builtin_popcount(masks[k] & ((1u << (u & 31u)) - 1u));
+        const uint32_t nb = tl - zb_highbit(ns);
+        t->nb[u] = (uint8_t)nb;
+        t->base[u] = (uint16_t)((ns << nb) - size);
+    }
+    ZB_SERIAL(zl)
+    {
+        t->log = tl;
+        t->valid = 1;
+    }
+    return 0;
+}
+
 /* ---- backward bit reader: the stream ends with a 1 bit followed by zero padding ---- */
 typedef struct ZdBack
 {
@@ -321,9 +431,10 @@ ZB_FN int zd_build_huf(ZdShared* sh, uint32_t n, uint32_t tlog)
         if (w)
         {
             const uint32_t len = 1u << (w - 1u), e = ((tlog + 1u - w) << 8) | s;
+            const uint32_t first = rank_start[w]; /* read once: the stores below may alias it as far as the compiler knows */
             for (uint32_t u = 0; u < len; ++u)
-                sh->huf[rank_start[w] + u] = (uint16_t)e;
-            rank_start[w] += len;
+                sh->huf[first + u] = (uint16_t)e;
+            rank_start[w] = first + len;
         }
     }
     sh->huf_log = tlog;
@@ -470,12 +581,18 @@ ZB_FN int zd_set_table(ZdShared* sh, int t, uint32_t mode, const uint8_t* p, uin
 {
     ZdFse* f = &sh->fse[t];
     *used = 0;
+    int16_t* const norm = sh->norm + 64 * t; /* one 64-entry slice per table: all three are built together after the descriptions */
+    sh->tb_build[t] = 0;
     if (mode == 0u)
     {
         const uint32_t nsym = zb_table_nsym(t);
         for (uint32_t s = 0; s < nsym; ++s)
-            sh->norm[s] = (int16_t)zb_default_norm(t, s);
-        return zd_build_fse(f, sh->norm, nsym - 1u, zb_table_default_log(t), sh->next);
+            norm[s] = (int16_t)zb_default_norm(t, s);
+        sh->tb_maxsym[t] = nsym - 1u;
+        sh->tb_log[t] = zb_table_default_log(t);
+        sh->tb_build[t] = 1;
+        f->valid = 0; /* until zd_build_fse_par has run */
+        return 0;
     }
     if (mode == 1u)
     {
@@ -494,11 +611,17 @@ ZB_FN int zd_set_table(ZdShared* sh, int t, uint32_t mode, const uint8_t* p, uin
     if (mode == 2u)
     {
         uint32_t maxsym = t == ZT_LL ? 35u : t == ZT_ML ? 52u : 31u, tl = 0;
-        const uint32_t hs = zd_read_ncount(p, size, sh->norm, &maxsym, zb_table_max_log(t), &tl);
+        const uint32_t hs = zd_read_ncount(p, size, norm, &maxsym, zb_table_max_log(t), &tl);
         if (hs == ZD_ERROR)
             return 1;
         *used = hs;
-        return zd_build_fse(f, sh->norm, maxsym, tl, sh->next);
+        if (maxsym > 63u || tl > 9u)
+            return 1;
+        sh->tb_maxsym[t] = maxsym;
+        sh->tb_log[t] = tl;
+        sh->tb_build[t] = 1;
+        f->valid = 0;
+        return 0;
     }
     return f->valid == 0u; /* Repeat_Mode needs a previous table */
 }
@@ -807,6 +930,7 @@ ZB_FN uint32_t zd_decode_payload_ex(const uint8_t* src, uint32_t src_size, uint8
                     else
                     {
                         /* tables (lane 0), then the sequence loop: lane 0 decodes one sequence, all lanes copy it */
+                        ZD_MARK(16);
                         ZB_SERIAL(zl)
                         {
                             uint32_t p = seq_pos;
@@ -831,6 +955,34 @@ ZB_FN uint32_t zd_decode_payload_ex(const uint8_t* src, uint32_t src_size, uint8
                         ZB_SYNC();
                         if (sh->v[ZDV_ERR])
                             return ZD_FAIL_AT(sh);
+                        ZD_MARK(17); /* 17: table descriptions (lane 0), 18: tables (all lanes) */
+                        if (piece) /* the tables described above; a piece is done with its Huffman table here: scratch for all lanes */
+                        {
+                            for (int t = 0; t < 3; ++t)
+                                if (sh->tb_build[t])
+                                {
+                                    if (zd_build_fse_par(&sh->fse[t], sh->norm + 64 * t, sh->tb_maxsym[t], sh->tb_log[t], sh->cum,
+                                                         (uint32_t*)sh->huf, sh->huf + 2u * ZD_FSE_PAR_MASK_WORDS, zl))
+                                        return ZD_FAIL_AT(sh);
+                                    ZB_SYNC_LDS();
+                                }
+                            sh->huf_valid = 0;
+                        }
+                        else /* a later block may still want the Huffman table (treeless literals) */
+                        {
+                            ZB_SERIAL(zl)
+                            {
+                                for (int t = 0; t < 3; ++t)
+                                    if (sh->tb_build[t] &&
+                                        zd_build_fse(&sh->fse[t], sh->norm + 64 * t, sh->tb_maxsym[t], sh->tb_log[t], sh->next))
+                                        ZD_SET_ERR(sh);
+                            }
+                            ZB_SYNC();
+                            if (sh->v[ZDV_ERR])
+                                return ZD_FAIL_AT(sh);
+                        }
+                        ZB_SYNC();
+                        ZD_MARK(18);
                         seq_pos = sh->v[ZDV_LEN];
                         if (seq_pos >= bsize)
                             return ZD_FAIL_AT(sh);

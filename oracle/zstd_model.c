@@ -197,3 +197,29 @@ int ltz_model_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap,
     *out_n = r;
     return 0;
 }
+
+/* Both FSE table builders of the decoder core on one normalised distribution (norm[0..maxsym], -1 = low probability): the serial
+ * one into a, the all-lanes one (run here with one lane) into b; each table as size * {sym, nb, base lo, base hi}.  Returns
+ * serial status | cooperative status << 1. */
+int ltz_model_fse_tables(const int16_t* norm, uint32_t maxsym, uint32_t tl, uint8_t* a, uint8_t* b)
+{
+    ZdFse* t = (ZdFse*)calloc(2, sizeof(ZdFse));
+    uint16_t next[64], cum[66], pre[ZD_FSE_PAR_MASK_WORDS];
+    uint32_t masks[ZD_FSE_PAR_MASK_WORDS];
+    const int ra = zd_build_fse(&t[0], norm, maxsym, tl, next);
+    const int rb = zd_build_fse_par(&t[1], norm, maxsym, tl, cum, masks, pre, 0);
+    for (int k = 0; k < 2; ++k)
+    {
+        uint8_t* o = k ? b : a;
+        if ((k ? rb : ra) == 0)
+            for (uint32_t u = 0; u < (1u << tl); ++u)
+            {
+                o[4 * u] = t[k].sym[u];
+                o[4 * u + 1] = t[k].nb[u];
+                o[4 * u + 2] = (uint8_t)t[k].base[u];
+                o[4 * u + 3] = (uint8_t)(t[k].base[u] >> 8);
+            }
+    }
+    free(t);
+    return ra | rb << 1;
+}

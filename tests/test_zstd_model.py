@@ -171,3 +171,38 @@ def test_decoder_never_accepts_what_the_reference_rejects(model):
                     assert e1 == 0 and len(o1) == len(o2) and (o1 == o2).all()
                     both += 1
     assert both > 100
+
+
+def test_cooperative_fse_table_builder_equals_serial(model):
+    """zd_build_fse_par (all lanes; the sequence tables of k_zstd_prepare / k_zstd_decode) against zd_build_fse (the construction of
+    zstd_decompress_block.c:484-603) on random normalised distributions with low-probability (-1) and absent symbols."""
+    d = model.dll
+    d.ltz_model_fse_tables.restype = C.c_int
+    d.ltz_model_fse_tables.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(77)
+    for it in range(600):
+        tl = int(rng.integers(5, 10))
+        size = 1 << tl
+        nsym = int(rng.integers(1, min(53, size) + 1))
+        nlow = int(rng.integers(0, min(nsym, 12))) if it % 3 else 0
+        npos = int(rng.integers(1, nsym - nlow + 1)) if nsym > nlow else 0
+        if npos == 0:
+            nlow, npos = nsym - 1, 1
+        rest = size - nlow
+        cuts = np.sort(rng.choice(np.arange(1, rest), npos - 1, replace=False)) if npos > 1 else np.zeros(0, np.int64)
+        counts = np.diff(np.concatenate(([0], cuts, [rest])))
+        vals = np.concatenate((counts, -np.ones(nlow, np.int64), np.zeros(nsym - nlow - npos, np.int64)))
+        rng.shuffle(vals)
+        if vals[-1] == 0:  # the last symbol is present by definition of maxsym
+            k = int(np.flatnonzero(vals)[0])
+            vals[-1], vals[k] = vals[k], 0
+        norm = vals.astype(np.int16)
+        a = np.zeros(4 * size, np.uint8)
+        b = np.ones(4 * size, np.uint8)
+        r = d.ltz_model_fse_tables(norm.ctypes.data, nsym - 1, tl, a.ctypes.data, b.ctypes.data)
+        assert r == 0, (it, tl, norm)
+        assert np.array_equal(a, b), (it, tl, norm)
+    # distributions that do not fill the table are rejected by both
+    norm = np.array([10, 10, 3], np.int16)
+    a = np.zeros(4 * 32, np.uint8)
+    assert d.ltz_model_fse_tables(norm.ctypes.data, 2, 5, a.ctypes.data, a.ctypes.data) == 3
