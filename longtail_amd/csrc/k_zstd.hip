@@ -101,10 +101,36 @@ __device__ __forceinline__ bool z_is_trailer(const uint8_t* d)
     return same;
 }
 
+// Frames whose pieces are runs of SUB-BLOCKS (zb_encode_piece_sub; one zstd block per 4 KiB unit, entropy tables sent once per piece)
+// end with a skippable frame that also carries a DIRECTORY: "LTP\2", then one u16 per 4 KiB unit of the content = the content size of
+// the unit's block (| 0x8000: a Raw_Block); 0xFFFF / 0xFFFE for every unit of a piece that is one Raw_Block / one RLE_Block.  With it
+// the decoder finds every block of the frame by prefix sums (and then checks each against its header) instead of walking 2 048
+// headers per 8 MiB one after the other.
+constexpr uint16_t ZDIR_RAW_PIECE = 0xFFFFu, ZDIR_RLE_PIECE = 0xFFFEu;
+__host__ __device__ __forceinline__ uint32_t z_units(uint64_t content) { return (uint32_t)((content + ZB_UNIT - 1u) / ZB_UNIT); }
+__host__ __device__ __forceinline__ uint32_t z_trailer2_size(uint64_t content) { return ZTRAILER + 2u * z_units(content); }
+__device__ __forceinline__ void z_write_trailer2_head(uint8_t* d, uint64_t content)
+{
+    const uint32_t n = 4u + 2u * z_units(content);
+    const uint8_t t[ZTRAILER] = {0x5D, 0x2A, 0x4D, 0x18, (uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24), 'L', 'T', 'P', 2};
+    for (uint32_t i = 0; i < ZTRAILER; ++i)
+        d[i] = t[i];
+}
+__device__ __forceinline__ bool z_is_trailer2_head(const uint8_t* d, uint64_t content)
+{
+    const uint32_t n = 4u + 2u * z_units(content);
+    const uint8_t t[ZTRAILER] = {0x5D, 0x2A, 0x4D, 0x18, (uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24), 'L', 'T', 'P', 2};
+    bool same = true;
+    for (uint32_t i = 0; i < ZTRAILER; ++i)
+        same &= d[i] == t[i];
+    return same;
+}
+
 // serial per stored block: destination offset of every piece, total size
 __global__ void k_zstd_scan(const ZBlock* __restrict__ blocks, uint32_t nblocks, const uint8_t* __restrict__ is_rle,
                             const uint32_t* __restrict__ enc_size, uint32_t* __restrict__ zb_dst,
-                            uint32_t* __restrict__ out_sizes, uint8_t* __restrict__ dst, uint32_t dbg)
+                            uint32_t* __restrict__ out_sizes, uint8_t* __restrict__ dst, uint32_t dbg, uint32_t sub,
+                            uint32_t* __restrict__ trailer_at)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks)
@@ -118,12 +144,21 @@ __global__ void k_zstd_scan(const ZBlock* __restrict__ blocks, uint32_t nblocks,
         const uint32_t len = blk.size - i * ZB < ZB ? blk.size - i * ZB : ZB;
         zb_dst[blk.zb_base + i] = (uint32_t)pos;
         const uint32_t enc = enc_size[blk.zb_base + i];
-        pos += 3u + ((is_rle[blk.zb_base + i] & 1u) ? 1u : enc ? enc : len);
+        // (a piece of sub-blocks brings its Block_Headers along)
+        pos += (is_rle[blk.zb_base + i] & 1u) ? 4u : enc ? ((is_rle[blk.zb_base + i] & 4u) ? enc : 3u + enc) : 3u + len;
     }
-    if (blk.nzb >= 2u && pos + ZTRAILER <= (uint64_t)blk.dst_cap && !(dbg & 2u))
+    trailer_at[b] = 0;
+    const uint32_t tsize = sub ? z_trailer2_size(blk.size) : ZTRAILER;
+    if (blk.nzb >= (sub ? 1u : 2u) && pos + tsize <= (uint64_t)blk.dst_cap && !(dbg & 2u))
     {
-        z_write_trailer(dst + blk.dst_off + pos);
-        pos += ZTRAILER;
+        if (sub)
+        {
+            z_write_trailer2_head(dst + blk.dst_off + pos, blk.size); // (the directory: k_zstd_emit, every piece its own entries)
+            trailer_at[b] = (uint32_t)pos;
+        }
+        else
+            z_write_trailer(dst + blk.dst_off + pos);
+        pos += tsize;
     }
     out_sizes[b] = pos <= (uint64_t)blk.dst_cap ? (uint32_t)pos : 0u;
 }
@@ -163,7 +198,8 @@ __global__ __launch_bounds__(ZT) void k_zstd_emit(const uint8_t* __restrict__ sr
                                                   uint32_t nblocks, const uint8_t* __restrict__ is_rle,
                                                   const uint32_t* __restrict__ enc_size, const uint8_t* __restrict__ enc,
                                                   const uint32_t* __restrict__ zb_dst, const uint32_t* __restrict__ out_sizes,
-                                                  uint8_t* __restrict__ dst)
+                                                  uint8_t* __restrict__ dst, const uint16_t* __restrict__ sub_sizes,
+                                                  const uint32_t* __restrict__ trailer_at)
 {
     const uint32_t zb = blockIdx.x;
     uint32_t lo = 0, hi = nblocks;
@@ -183,9 +219,32 @@ __global__ __launch_bounds__(ZT) void k_zstd_emit(const uint8_t* __restrict__ sr
     const uint32_t len = b.size - start < ZB ? b.size - start : ZB;
     const uint8_t* p = src + b.src_off + start;
     uint8_t* d = dst + b.dst_off + zb_dst[zb];
-    const uint32_t flags = is_rle[zb]; // 1 = RLE_Block, 2 = every unit without a sequence (bytes placed by the match finder)
+    const uint32_t flags = is_rle[zb]; // 1 = RLE_Block, 2 = every unit without a sequence (bytes placed by the match finder),
+                                       // 4 = a run of sub-blocks with their own headers
     const uint32_t rle = flags & 1u;
     const uint32_t csize = rle ? 0u : enc_size[zb];
+    const bool subs = csize && (flags & 4u);
+    const uint32_t nunits = (len + ZB_UNIT - 1u) / ZB_UNIT;
+    const uint16_t* my_sub = sub_sizes + (uint64_t)zb * ZB_MAX_UNITS;
+    if (trailer_at && trailer_at[lo] && threadIdx.x < nunits)
+    {
+        // this piece's entries of the frame's directory (unaligned: bytes)
+        uint8_t* e = dst + b.dst_off + trailer_at[lo] + ZTRAILER + 2u * ((uint64_t)i * ZB_MAX_UNITS + threadIdx.x);
+        const uint32_t v = subs ? my_sub[threadIdx.x] : rle ? ZDIR_RLE_PIECE : ZDIR_RAW_PIECE;
+        e[0] = (uint8_t)v;
+        e[1] = (uint8_t)(v >> 8);
+    }
+    if (subs)
+    {
+        wg_copy16(d, enc + (uint64_t)zb * ZB_OUT_BYTES, csize, threadIdx.x);
+        if (i + 1 == b.nzb)
+        {
+            __syncthreads();
+            if (threadIdx.x == 0) // Last_Block on the frame's very last block
+                d[csize - 3u - (my_sub[nunits - 1u] & 0x7FFFu)] |= 1u;
+        }
+        return;
+    }
     if (threadIdx.x == 0)
     {
         const uint32_t h = (i + 1 == b.nzb ? 1u : 0u) | ((csize ? 2u : rle) << 1) | ((csize ? csize : len) << 3);
@@ -207,7 +266,7 @@ __global__ __launch_bounds__(64, 4) void k_zstd_encode(const ZBlock* __restrict_
                                                     const ZbUnitMeta* __restrict__ unit_meta,
                                                     const uint8_t* __restrict__ unit_lits, const uint64_t* __restrict__ unit_recs,
                                                     uint8_t* __restrict__ work, uint8_t* __restrict__ enc,
-                                                    uint32_t* __restrict__ enc_size)
+                                                    uint32_t* __restrict__ enc_size, uint16_t* __restrict__ sub_sizes)
 {
     __shared__ ZbShared sh;
     ZbScratch sc;
@@ -244,7 +303,7 @@ __global__ __launch_bounds__(64, 4) void k_zstd_encode(const ZBlock* __restrict_
             const bool matchless = __builtin_amdgcn_ballot_w64(threadIdx.x < in.nunits && in.meta[threadIdx.x].nseq != 0u) == 0ull;
             if (threadIdx.x == 0)
             {
-                is_rle[zb] = (rle ? 1 : 0) | (matchless ? 2 : 0);
+                is_rle[zb] = (rle ? 1 : 0) | (matchless ? 2 : 0) | (sub_sizes ? 4 : 0);
                 if (rle)
                     enc_size[zb] = 0;
             }
@@ -256,7 +315,8 @@ __global__ __launch_bounds__(64, 4) void k_zstd_encode(const ZBlock* __restrict_
         if (threadIdx.x == 0)
             g_zb_last[blockIdx.x] = wall_clock64();
 #endif
-        const uint32_t n = zb_encode_block(&in, &sc, &sh, threadIdx.x);
+        const uint32_t n = sub_sizes ? zb_encode_piece_sub(&in, &sc, &sh, threadIdx.x, sub_sizes + (uint64_t)zb * ZB_MAX_UNITS)
+                                     : zb_encode_block(&in, &sc, &sh, threadIdx.x);
         if (threadIdx.x == 0)
             enc_size[zb] = n;
         __syncthreads();
@@ -359,9 +419,14 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const uint32_t nwg = (uint32_t)(nzb < (uint64_t)ncu * 16 ? nzb : (uint64_t)ncu * 16);
-    void *d_blocks, *d_rle, *d_zdst, *d_enc, *d_encsz, *d_work;
+    void *d_blocks, *d_rle, *d_zdst, *d_enc, *d_encsz, *d_work, *d_sub, *d_trail;
+    // sub-blocks (default): one zstd block per 4 KiB unit and a directory in the trailer; LTHIP_ZSTD_SUB=0: one block per 128 KiB piece
+    const bool sub = !(getenv("LTHIP_ZSTD_SUB") && atoi(getenv("LTHIP_ZSTD_SUB")) == 0);
     if ((err = lthip_scratch(ctx, S_LZ4_BLOCKS, sizeof(ZBlock) * (size_t)block_count, &d_blocks)))
         return err;
+    if ((err = lthip_scratch(ctx, S_Z_SUB, sizeof(uint16_t) * ZB_MAX_UNITS * ((size_t)nzb + 1) + 4 * ((size_t)block_count + 1), &d_sub)))
+        return err;
+    d_trail = (uint8_t*)d_sub + sizeof(uint16_t) * ZB_MAX_UNITS * ((size_t)nzb + 1);
     if ((err = lthip_scratch(ctx, S_TABLES2, (size_t)nzb + 16, &d_rle)))
         return err;
     if ((err = lthip_scratch(ctx, S_LZ4_SEGS, ((size_t)nzb + 4) * 4, &d_zdst)))
@@ -379,19 +444,21 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
         LaunchTimer t(ctx, LTHIP_K_ZSTD_ENC);
         hipLaunchKernelGGL(k_zstd_encode, dim3(nwg), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks, block_count, (uint32_t)nzb,
                            (const uint8_t*)d_src, (uint8_t*)d_rle, (const ZbUnitMeta*)d_meta, (const uint8_t*)d_lits, (const uint64_t*)d_recs,
-                           (uint8_t*)d_work, (uint8_t*)d_enc, (uint32_t*)d_encsz);
+                           (uint8_t*)d_work, (uint8_t*)d_enc, (uint32_t*)d_encsz, sub ? (uint16_t*)d_sub : (uint16_t*)nullptr);
         LTHIP_LAUNCH_CHECK(ctx);
     }
     LaunchTimer t(ctx, LTHIP_K_OTHER);
     hipLaunchKernelGGL(k_zstd_scan, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
                        block_count, (const uint8_t*)d_rle, (const uint32_t*)d_encsz, (uint32_t*)d_zdst, d_out_sizes, (uint8_t*)d_dst,
-                       (uint32_t)(getenv("LTHIP_ZSTD_DBG") ? atoi(getenv("LTHIP_ZSTD_DBG")) : 0)); // bit 1: no independence marker
+                       (uint32_t)(getenv("LTHIP_ZSTD_DBG") ? atoi(getenv("LTHIP_ZSTD_DBG")) : 0), // bit 1: no independence marker
+                       sub ? 1u : 0u, (uint32_t*)d_trail);
     hipLaunchKernelGGL(k_zstd_headers, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
                        block_count, (const uint32_t*)d_out_sizes, (uint8_t*)d_dst);
     if (nzb)
         hipLaunchKernelGGL(k_zstd_emit, dim3((uint32_t)nzb), dim3(ZT), 0, ctx->stream, (const uint8_t*)d_src,
                            (const ZBlock*)d_blocks, block_count, (const uint8_t*)d_rle, (const uint32_t*)d_encsz,
-                           (const uint8_t*)d_enc, (const uint32_t*)d_zdst, (const uint32_t*)d_out_sizes, (uint8_t*)d_dst);
+                           (const uint8_t*)d_enc, (const uint32_t*)d_zdst, (const uint32_t*)d_out_sizes, (uint8_t*)d_dst,
+                           (const uint16_t*)d_sub, (const uint32_t*)d_trail);
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
 }

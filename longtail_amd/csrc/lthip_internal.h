@@ -79,6 +79,7 @@ enum ScratchSlot
     S_Z_RECS,  // zstd: sequence records per unit
     S_Z_ENC,   // zstd: encoded 128 KiB pieces
     S_Z_WORK,  // zstd: per-encoder-wave work area
+    S_Z_SUB,   // zstd: content size of every unit's sub-block (u16 per 4 KiB unit) / decoder: sequence records
     S_LZ4_WORKLIST, // groups the stitch copy has to visit
     S_LZ4_LANE_RECS, // lane parser: {start, length, offset} records, 8 per lane and unit
     S_LZ4_CLASSIFY,  // two-pass match finder: list + flags of the groups with redundancy

@@ -1408,4 +1408,630 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     return sh->v[ZV_OUT_SIZE];
 }
 
+
+/* ============================================================================================================
+ * The same piece as a run of SUB-BLOCKS, one zstd block per match-finder unit (4 KiB of input).
+ *
+ * One FSE bit-stream per 128 KiB is one serial chain per piece, for the encoder (state chains) and for every decoder (one
+ * sequence after the other); the literals' four Huffman streams are four serial chains.  A wave has 64 lanes.  So the piece
+ * is written the way zstd's own target-block-size mode writes it (compress/zstd_compress_superblock.c): the entropy tables
+ * are built once, from the statistics of the whole piece, and go out with the FIRST sub-block that needs them; the others
+ * say Repeat_Mode / Treeless_Literals_Block (RFC 8878 3.1.1.3.1.1, 3.1.1.3.2.1.1) and carry only their own streams: up to 32
+ * sequence streams and 128 literal streams per piece, every one decodable by its own lane.  Any zstd decoder reads the
+ * result; the cost is about 20 bytes of headers per sub-block.
+ *
+ * Output: the sub-blocks back to back, each WITH its 3-byte Block_Header (Last_Block clear), and sub[u] = content size of
+ * unit u's block (| 0x8000 when it is a Raw_Block) for the frame's directory.  Returns the total size, 0 when that would
+ * not be smaller than one Raw_Block of the piece.
+ * ========================================================================================================== */
+typedef struct ZbSub /* per-unit values, over lit_hist (free once the Huffman code exists) */
+{
+    uint32_t seqbits[ZB_MAX_UNITS]; /* bits of the unit's sequence stream before the final states and the end mark */
+    uint32_t upos[ZB_MAX_UNITS + 1]; /* byte offset of the unit's Block_Header */
+    uint32_t litpos[ZB_MAX_UNITS];  /* ... of its first literal stream / raw literals / raw bytes */
+    uint32_t seqpos[ZB_MAX_UNITS];  /* ... of its sequence bit-stream */
+    uint16_t fstate[ZB_MAX_UNITS][4];
+    uint8_t lmode[ZB_MAX_UNITS]; /* 0 raw literals, 2 Huffman with the tree, 3 treeless, 4 the whole unit is a Raw_Block */
+    uint8_t nstr[ZB_MAX_UNITS];  /* Huffman streams: 1 or 4 */
+} ZbSub;
+#define ZB_SUB_RAW 0x8000u
+
+ZB_FN uint32_t zb_unit_byte(const ZbInput* in, uint32_t srcmask, uint32_t u, uint32_t idx, uint32_t n, uint32_t* cw, uint32_t* cwi)
+{
+    if ((idx >> 2) != *cwi)
+    {
+        *cwi = idx >> 2;
+        *cw = zb_unit_word(in, srcmask, u, idx >> 2, n);
+    }
+    return (*cw >> (8u * (idx & 3u))) & 255u;
+}
+
+ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbShared* sh, uint32_t zl, uint16_t* sub)
+{
+    uint8_t* const out8 = (uint8_t*)sc->out;
+    ZbSub* const sb = (ZbSub*)sh->lit_hist;
+    uint32_t* const strbits = sh->huf_w + 128; /* [ZB_MAX_UNITS][4] bits of every literal stream (past the FSE builders' spread area) */
+    const uint32_t nunits = in->nunits;
+
+    /* ---- phase 0: unit bases; zero the histograms ---- */
+    ZB_PAR_FOR(u, nunits)
+    {
+        const ZbUnitMeta m = in->meta[u];
+        sh->useq_base[u] = m.nseq;
+        sh->ulit_base[u] = m.nlit;
+    }
+    ZB_SYNC();
+    ZB_SERIAL(zl)
+    {
+        uint32_t nseq = 0, nlit = 0, srcmask = 0;
+        for (uint32_t u = 0; u < nunits; ++u)
+        {
+            const uint32_t un = sh->useq_base[u], ul = sh->ulit_base[u];
+            if (in->src && un == 0u)
+                srcmask |= 1u << u;
+            sh->useq_base[u] = nseq;
+            sh->ulit_base[u] = nlit;
+            nseq += un;
+            nlit += ul;
+        }
+        sh->useq_base[nunits] = nseq;
+        sh->ulit_base[nunits] = nlit;
+        sh->v[ZV_NBSEQ] = nseq;
+        sh->v[ZV_NLIT] = nlit;
+        sh->v[ZV_SRCMASK] = srcmask;
+    }
+    ZB_PAR_FOR(i, 256u) sh->lit_hist[i] = 0;
+    ZB_PAR_FOR(i, 3u * 64u) sh->sym_hist[i >> 6][i & 63u] = 0;
+    ZB_SYNC();
+    const uint32_t nbseq = sh->v[ZV_NBSEQ], nlit = sh->v[ZV_NLIT], srcmask = sh->v[ZV_SRCMASK];
+
+    ZB_MARK(1);
+    /* ---- phase 1: the sequences in block order (a unit's trailing literals stay with the unit: they are its block's last
+     * literals), the three symbol histograms, the literal histogram ---- */
+    ZB_PAR_FOR(i, nbseq)
+    {
+        uint32_t lo = 0, hi = nunits;
+        while (hi - lo > 1u)
+        {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (sh->useq_base[mid] <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        {
+            const uint64_t r = in->unit_recs[(uint64_t)lo * ZB_UNIT_SEQ_MAX + (i - sh->useq_base[lo])];
+            const uint32_t lit = (uint32_t)(r & 0xFFFFu), ml = (uint32_t)((r >> 16) & 0xFFFFu), off = (uint32_t)(r >> 32);
+            sc->seqs[i] = (uint64_t)lit | ((uint64_t)ml << 20) | ((uint64_t)off << 36);
+            zb_atomic_add(&sh->sym_hist[ZT_LL][zb_ll_code(lit)], 1u);
+            zb_atomic_add(&sh->sym_hist[ZT_ML][zb_ml_code(ml - 3u)], 1u);
+            zb_atomic_add(&sh->sym_hist[ZT_OF][zb_of_code(off)], 1u);
+        }
+    }
+    /* plainly noise?  (the sampled test of zb_encode_block) */
+    if (nlit >= 32768u && in->raw_size - nlit < 3u * nbseq + 32u && !(ZB_DBG & 8u))
+    {
+        for (uint32_t u = (nlit >> 12) & 7u; u < nunits; u += 8u)
+        {
+            const uint32_t n = sh->ulit_base[u + 1u] - sh->ulit_base[u];
+            ZB_PAR_FOR(j, n >> 2)
+            {
+                const uint32_t w = zb_unit_word(in, srcmask, u, j, n);
+                zb_atomic_add(&sh->lit_hist[w & 255u], 1u);
+                zb_atomic_add(&sh->lit_hist[(w >> 8) & 255u], 1u);
+                zb_atomic_add(&sh->lit_hist[(w >> 16) & 255u], 1u);
+                zb_atomic_add(&sh->lit_hist[w >> 24], 1u);
+            }
+        }
+        ZB_SYNC();
+        ZB_SERIAL(zl)
+        {
+            uint32_t largest = 0, ns = 0;
+            for (uint32_t s2 = 0; s2 < 256u; ++s2)
+            {
+                ns += sh->lit_hist[s2];
+                if (sh->lit_hist[s2] > largest)
+                    largest = sh->lit_hist[s2];
+            }
+            sh->v[ZV_SKIP] = (ns >= 2048u && largest <= (ns >> 7) + 4u) ? 1u : 0u;
+        }
+        ZB_SYNC();
+        if (sh->v[ZV_SKIP])
+            return 0;
+        ZB_PAR_FOR(i, 256u) sh->lit_hist[i] = 0;
+        ZB_SYNC();
+    }
+    for (uint32_t u = 0; u < nunits; ++u)
+    {
+        const uint32_t n = sh->ulit_base[u + 1u] - sh->ulit_base[u];
+        ZB_PAR_FOR(j, (n + 3u) >> 2)
+        {
+            const uint32_t w = zb_unit_word(in, srcmask, u, j, n);
+            const uint32_t k = n - 4u * j; /* valid bytes in this word, >= 1 */
+            zb_atomic_add(&sh->lit_hist[w & 255u], 1u);
+            if (k > 1u)
+                zb_atomic_add(&sh->lit_hist[(w >> 8) & 255u], 1u);
+            if (k > 2u)
+                zb_atomic_add(&sh->lit_hist[(w >> 16) & 255u], 1u);
+            if (k > 3u)
+                zb_atomic_add(&sh->lit_hist[w >> 24], 1u);
+        }
+    }
+    ZB_SYNC();
+
+    ZB_MARK(2);
+    /* ---- phase 2: Huffman code for the literals (lane 0), FSE tables for the three symbol types (lanes 0..2): as in
+     * zb_encode_block, from the statistics of the whole piece ---- */
+    ZB_SERIAL(zl)
+    {
+        uint32_t largest = 0;
+        for (uint32_t s2 = 0; s2 < 256u; ++s2)
+            if (sh->lit_hist[s2] > largest)
+                largest = sh->lit_hist[s2];
+        sh->v[ZV_HUF_OK] = 0;
+        sh->v[ZV_TREE_BYTES] = 0;
+        sh->v[ZV_HUF_NSYM] = 0;
+        sh->v[ZV_LIT_HDR] = (nlit >= 256u && !(ZB_DBG & 1u) && largest > (nlit >> 7) + 4u) ? 1u : 0u; /* try Huffman */
+        sh->v[ZV_SKIP] = (!sh->v[ZV_LIT_HDR] && in->raw_size - nlit < 3u * nbseq + 32u) ? 1u : 0u;
+    }
+    ZB_SYNC();
+    if (sh->v[ZV_SKIP])
+        return 0;
+    ZB_PAR_FOR(i, ZB_OUT_BYTES / 4u) sc->out[i] = 0;
+    if (sh->v[ZV_LIT_HDR])
+        zb_huffman_sort(sh, zl);
+    ZB_SYNC();
+    ZB_SERIAL(zl)
+    {
+        if (sh->v[ZV_LIT_HDR])
+            zb_huffman_build(sh);
+    }
+    ZB_SYNC();
+    ZB_SERIAL(zl)
+    {
+        if (sh->v[ZV_HUF_OK]) /* uses table slot 0 as work space: must precede the FSE tables below */
+        {
+            sh->v[ZV_TREE_BYTES] = zb_write_huf_tree(sh, sh->tree);
+            if (!sh->v[ZV_TREE_BYTES])
+                sh->v[ZV_HUF_OK] = 0;
+        }
+    }
+    ZB_PAR_FOR(i, 4u * ZB_MAX_UNITS) strbits[i] = 0;
+    ZB_SYNC();
+    ZB_MARK(9);
+    ZB_PAR_FOR(t, 3u)
+    {
+        if (nbseq)
+        {
+            const uint32_t nsym = zb_table_nsym((int)t);
+            uint32_t distinct = 0, only = 0, maxs = 0;
+            for (uint32_t s = 0; s < 64u; ++s)
+                if (sh->sym_hist[t][s])
+                {
+                    ++distinct;
+                    only = s;
+                    maxs = s;
+                }
+            if (distinct == 1u)
+            {
+                sh->mode[t] = 1; /* RLE_Mode */
+                sh->rle_sym[t] = (uint8_t)only;
+                sh->table_log[t] = 0;
+            }
+            else if (((nbseq < 64u && !(ZB_DBG & 2u)) || (ZB_DBG & 4u)) && maxs < nsym)
+            {
+                sh->mode[t] = 0; /* Predefined_Mode */
+                sh->table_log[t] = (uint8_t)zb_table_default_log((int)t);
+                for (uint32_t s = 0; s < 64u; ++s)
+                    sh->norm[t][s] = (int16_t)(s < nsym ? zb_default_norm((int)t, s) : 0);
+                zb_build_enc_table(sh->norm[t], nsym, sh->table_log[t], ZB_SPREAD(sh, t), sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
+            }
+            else
+            {
+                uint32_t tl = zb_highbit(nbseq) - 1u;
+                const uint32_t minlog = distinct > 32u ? 6u : 5u, maxlog = zb_table_max_log((int)t);
+                if (tl < minlog)
+                    tl = minlog;
+                if (tl > maxlog)
+                    tl = maxlog;
+                sh->mode[t] = 2; /* FSE_Compressed_Mode */
+                sh->table_log[t] = (uint8_t)tl;
+                zb_normalize(sh->sym_hist[t], maxs + 1u, nbseq, tl, sh->norm[t]);
+                zb_build_enc_table(sh->norm[t], maxs + 1u, tl, ZB_SPREAD(sh, t), sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
+                sh->rle_sym[t] = (uint8_t)maxs; /* highest present symbol, for the NCount writer */
+            }
+        }
+    }
+    /* the literal histogram is dead: its memory holds the per-unit values from here on */
+    ZB_SYNC();
+    ZB_PAR_FOR(u, ZB_MAX_UNITS)
+    {
+        sb->seqbits[u] = 0;
+        sb->lmode[u] = 0;
+        sb->nstr[u] = 0;
+    }
+    ZB_SYNC();
+
+    ZB_MARK(3);
+    /* ---- phase 3: bits of every literal stream: a unit's literals are one stream below 256 of them, else four (three of
+     * ceil(n / 4), the last takes the rest) ---- */
+    if (sh->v[ZV_HUF_OK])
+        for (uint32_t u = 0; u < nunits; ++u)
+        {
+            const uint32_t n = sh->ulit_base[u + 1u] - sh->ulit_base[u];
+            const uint32_t seg = n < 256u ? n : (n + 3u) >> 2;
+            ZB_PAR_FOR(j, (n + 3u) >> 2)
+            {
+                const uint32_t w = zb_unit_word(in, srcmask, u, j, n);
+                const uint32_t k = n - 4u * j < 4u ? n - 4u * j : 4u;
+                uint32_t q = (4u * j >= seg) + (4u * j >= 2u * seg) + (4u * j >= 3u * seg), bits = 0;
+                for (uint32_t b = 0; b < k; ++b)
+                {
+                    const uint32_t ib = 4u * j + b;
+                    const uint32_t qb = (ib >= seg) + (ib >= 2u * seg) + (ib >= 3u * seg);
+                    if (qb != q)
+                    {
+                        zb_atomic_add(&strbits[4u * u + q], bits);
+                        bits = 0;
+                        q = qb;
+                    }
+                    bits += sh->huf_len[(w >> (8u * b)) & 255u];
+                }
+                zb_atomic_add(&strbits[4u * u + q], bits);
+            }
+        }
+
+    ZB_MARK(4);
+    /* ---- phase 4: the FSE state chains, last sequence first.  A chain is serial: every unit's three chains run on the unit's
+     * own lane, interleaved (three independent LDS round trips per step instead of one), eight sequences loaded ahead of the
+     * eight steps.  The lane also adds up the sequences' extra bits. ---- */
+    ZB_PAR_FOR(u, nunits)
+    {
+        const uint32_t b0 = sh->useq_base[u], e0 = sh->useq_base[u + 1u];
+        if (e0 > b0)
+        {
+            const uint32_t tl_l = sh->table_log[ZT_LL], tl_o = sh->table_log[ZT_OF], tl_m = sh->table_log[ZT_ML];
+            const uint32_t c_l = sh->mode[ZT_LL] != 1u, c_o = sh->mode[ZT_OF] != 1u, c_m = sh->mode[ZT_ML] != 1u;
+            uint32_t x_l = 0, x_o = 0, x_m = 0, bits = 0, n = e0;
+            while (n > b0)
+            {
+                uint64_t q[8];
+                const uint32_t cnt = n - b0 < 8u ? n - b0 : 8u;
+                for (uint32_t j = 0; j < 8u; ++j)
+                    q[j] = j < cnt ? sc->seqs[n - 1u - j] : 0u;
+                for (uint32_t j = 0; j < 8u; ++j)
+                    if (j < cnt)
+                    {
+                        const uint32_t i = n - 1u - j;
+                        const uint32_t lc = zb_ll_code(ZB_SEQ_LIT(q[j])), mc = zb_ml_code(ZB_SEQ_ML(q[j]) - 3u), oc = zb_of_code(ZB_SEQ_OFF(q[j]));
+                        bits += zb_ll_bits(lc) + zb_ml_bits(mc) + oc;
+                        if (i == e0 - 1u) /* the block's last sequence: the states the decoder starts from */
+                        {
+                            x_l = (1u << tl_l) + (c_l ? sh->state_tab[ZT_LL][sh->sym_start[ZT_LL][lc]] : 0u);
+                            x_o = (1u << tl_o) + (c_o ? sh->state_tab[ZT_OF][sh->sym_start[ZT_OF][oc]] : 0u);
+                            x_m = (1u << tl_m) + (c_m ? sh->state_tab[ZT_ML][sh->sym_start[ZT_ML][mc]] : 0u);
+                        }
+                        else
+                        {
+                            if (c_l)
+                            {
+                                const uint32_t r = zb_fse_step(&x_l, lc, sh->norm[ZT_LL], sh->state_tab[ZT_LL], sh->sym_start[ZT_LL], tl_l);
+                                sc->sbits[(uint64_t)ZT_LL * ZB_SEQ_MAX + i] = (uint16_t)r;
+                                bits += r >> 10;
+                            }
+                            if (c_o)
+                            {
+                                const uint32_t r = zb_fse_step(&x_o, oc, sh->norm[ZT_OF], sh->state_tab[ZT_OF], sh->sym_start[ZT_OF], tl_o);
+                                sc->sbits[(uint64_t)ZT_OF * ZB_SEQ_MAX + i] = (uint16_t)r;
+                                bits += r >> 10;
+                            }
+                            if (c_m)
+                            {
+                                const uint32_t r = zb_fse_step(&x_m, mc, sh->norm[ZT_ML], sh->state_tab[ZT_ML], sh->sym_start[ZT_ML], tl_m);
+                                sc->sbits[(uint64_t)ZT_ML * ZB_SEQ_MAX + i] = (uint16_t)r;
+                                bits += r >> 10;
+                            }
+                        }
+                    }
+                n -= cnt;
+            }
+            sb->fstate[u][ZT_LL] = (uint16_t)(c_l ? x_l - (1u << tl_l) : 0u);
+            sb->fstate[u][ZT_OF] = (uint16_t)(c_o ? x_o - (1u << tl_o) : 0u);
+            sb->fstate[u][ZT_ML] = (uint16_t)(c_m ? x_m - (1u << tl_m) : 0u);
+            sb->seqbits[u] = bits;
+        }
+    }
+    ZB_SYNC();
+
+    ZB_MARK(5);
+    /* ---- phase 5 (lane 0): what every unit becomes, all headers, where its streams go ---- */
+    ZB_SERIAL(zl)
+    {
+        uint32_t pos = 0, tree_due = sh->v[ZV_HUF_OK], tables_due = 1;
+        const uint32_t tb = sh->v[ZV_TREE_BYTES];
+        for (uint32_t u = 0; u < nunits; ++u)
+        {
+            const uint32_t n = sh->ulit_base[u + 1u] - sh->ulit_base[u];
+            const uint32_t ns = sh->useq_base[u + 1u] - sh->useq_base[u];
+            const uint32_t ubytes = in->raw_size - u * ZB_UNIT < ZB_UNIT ? in->raw_size - u * ZB_UNIT : ZB_UNIT;
+            const uint32_t rawhdr = n < 32u ? 1u : n < 4096u ? 2u : 3u;
+            uint32_t lmode = 0, nstr = 0, lsize = rawhdr + n, lhdr = rawhdr, cs = 0;
+            if (sh->v[ZV_HUF_OK] && n)
+            {
+                nstr = n < 256u ? 1u : 4u;
+                for (uint32_t q = 0; q < nstr; ++q)
+                    cs += (strbits[4u * u + q] + 1u + 7u) >> 3; /* + end mark */
+                cs += (nstr == 4u ? 6u : 0u) + (tree_due ? tb : 0u);
+                {
+                    const uint32_t hdr = (n < 1024u && cs < 1024u) ? 3u : 4u;
+                    if (cs + hdr < lsize)
+                    {
+                        lmode = tree_due ? 2u : 3u;
+                        lsize = cs + hdr;
+                        lhdr = hdr;
+                    }
+                }
+            }
+            /* sequences section: count, modes and (first time) the table descriptions, the bit-stream */
+            uint32_t shdr = 1, sbytes = 0;
+            if (ns)
+            {
+                uint32_t bits = sb->seqbits[u] + 1u;
+                for (uint32_t t = 0; t < 3u; ++t)
+                    if (sh->mode[t] != 1u)
+                        bits += sh->table_log[t];
+                sbytes = (bits + 7u) >> 3;
+                shdr = (ns < 128u ? 1u : 2u) + 1u;
+            }
+            /* (the table descriptions are written in place below, their size is known only then: the test leaves them out) */
+            {
+                if (in->src && lsize + shdr + sbytes >= ubytes)
+                {
+                    /* does not pay: the unit's bytes as a Raw_Block (entropy tables live on across it) */
+                    const uint32_t h = (0u << 1) | (ubytes << 3);
+                    out8[pos] = (uint8_t)h;
+                    out8[pos + 1u] = (uint8_t)(h >> 8);
+                    out8[pos + 2u] = (uint8_t)(h >> 16);
+                    sb->upos[u] = pos;
+                    sb->litpos[u] = pos + 3u;
+                    sb->lmode[u] = 4;
+                    sub[u] = (uint16_t)(ubytes | ZB_SUB_RAW);
+                    pos += 3u + ubytes;
+                    continue;
+                }
+            }
+            sb->upos[u] = pos;
+            {
+                uint32_t p = pos + 3u;
+                if (lmode >= 2u)
+                {
+                    const uint32_t sf = nstr == 1u ? 0u : lhdr == 3u ? 1u : 2u;
+                    const uint32_t nb = lhdr == 3u ? 10u : 14u;
+                    const uint32_t h = lmode | (sf << 2) | (n << 4) | (cs << (4u + nb));
+                    for (uint32_t k = 0; k < lhdr; ++k)
+                        out8[p++] = (uint8_t)(h >> (8u * k));
+                    if (lmode == 2u)
+                    {
+                        for (uint32_t k = 0; k < tb; ++k)
+                            out8[p++] = sh->tree[k];
+                        tree_due = 0;
+                    }
+                    if (nstr == 4u)
+                        for (uint32_t q = 0; q < 3u; ++q)
+                        {
+                            const uint32_t by = (strbits[4u * u + q] + 1u + 7u) >> 3;
+                            out8[p++] = (uint8_t)by;
+                            out8[p++] = (uint8_t)(by >> 8);
+                        }
+                    sb->litpos[u] = p;
+                    p = pos + 3u + lsize;
+                }
+                else
+                {
+                    if (n < 32u)
+                        out8[p++] = (uint8_t)(n << 3);
+                    else if (n < 4096u)
+                    {
+                        const uint32_t h = 4u | (n << 4);
+                        out8[p++] = (uint8_t)h;
+                        out8[p++] = (uint8_t)(h >> 8);
+                    }
+                    else
+                    {
+                        const uint32_t h = 12u | (n << 4);
+                        out8[p++] = (uint8_t)h;
+                        out8[p++] = (uint8_t)(h >> 8);
+                        out8[p++] = (uint8_t)(h >> 16);
+                    }
+                    sb->litpos[u] = p;
+                    p += n;
+                }
+                if (ns == 0u)
+                    out8[p++] = 0;
+                else
+                {
+                    if (ns < 128u)
+                        out8[p++] = (uint8_t)ns;
+                    else
+                    {
+                        out8[p++] = (uint8_t)((ns >> 8) + 128u);
+                        out8[p++] = (uint8_t)ns;
+                    }
+                    if (tables_due)
+                    {
+                        out8[p++] = (uint8_t)((sh->mode[ZT_LL] << 6) | (sh->mode[ZT_OF] << 4) | (sh->mode[ZT_ML] << 2));
+                        for (uint32_t t = 0; t < 3u; ++t) /* LL, OF, ML in this order */
+                        {
+                            if (sh->mode[t] == 1u)
+                                out8[p++] = sh->rle_sym[t];
+                            else if (sh->mode[t] == 2u)
+                                p += zb_write_ncount(out8 + p, sh->norm[t], (uint32_t)sh->rle_sym[t] + 1u, sh->table_log[t]);
+                        }
+                        tables_due = 0;
+                    }
+                    else /* what the first one said: Predefined again, anything else by Repeat_Mode */
+                        out8[p++] = (uint8_t)(((sh->mode[ZT_LL] ? 3u : 0u) << 6) | ((sh->mode[ZT_OF] ? 3u : 0u) << 4) |
+                                              ((sh->mode[ZT_ML] ? 3u : 0u) << 2));
+                    sb->seqpos[u] = p;
+                    p += sbytes;
+                }
+                {
+                    const uint32_t content = p - (pos + 3u);
+                    const uint32_t h = (2u << 1) | (content << 3);
+                    out8[pos] = (uint8_t)h;
+                    out8[pos + 1u] = (uint8_t)(h >> 8);
+                    out8[pos + 2u] = (uint8_t)(h >> 16);
+                    sub[u] = (uint16_t)content;
+                }
+                sb->lmode[u] = (uint8_t)lmode;
+                sb->nstr[u] = (uint8_t)nstr;
+                pos = p;
+            }
+        }
+        sb->upos[nunits] = pos;
+        sh->v[ZV_OUT_SIZE] = pos < in->raw_size + 3u ? pos : 0u;
+    }
+    ZB_SYNC();
+    if (!sh->v[ZV_OUT_SIZE])
+        return 0;
+
+    ZB_MARK(6);
+    /* ---- phase 6: literals.  A Huffman stream is written from its LAST literal: per step every lane takes the next four
+     * literals (lane 0 the last four), a wave prefix sum of the bit counts places them (as in zb_encode_block). ---- */
+    for (uint32_t u = 0; u < nunits; ++u)
+    {
+        const uint32_t n = sh->ulit_base[u + 1u] - sh->ulit_base[u];
+        const uint32_t lmode = sb->lmode[u];
+        if (lmode == 2u || lmode == 3u)
+        {
+            const uint32_t nstr = sb->nstr[u], seg = nstr == 1u ? n : (n + 3u) >> 2;
+            uint32_t base = sb->litpos[u];
+            for (uint32_t st = 0; st < nstr; ++st)
+            {
+                const uint32_t s0 = st * seg, s1 = st + 1u == nstr ? n : s0 + seg;
+                uint32_t running = base * 8u, cw = 0, cwi = 0xFFFFFFFFu;
+                for (uint32_t done = 0; done < s1 - s0; done += 4u * ZB_LANES)
+                {
+                    uint64_t acc = 0;
+                    uint32_t nb = 0;
+                    for (uint32_t j = 0; j < 4u; ++j)
+                    {
+                        const uint32_t r = done + 4u * zl + j;
+                        if (r < s1 - s0)
+                        {
+                            const uint32_t sy = zb_unit_byte(in, srcmask, u, s1 - 1u - r, n, &cw, &cwi);
+                            acc |= (uint64_t)sh->huf_code[sy] << nb;
+                            nb += sh->huf_len[sy];
+                        }
+                    }
+                    {
+                        uint32_t total;
+                        const uint32_t off = zb_scan_excl(nb, &total);
+                        if (nb)
+                        {
+                            const uint32_t bp = running + off;
+                            const uint64_t v = acc << (bp & 31u); /* nb <= 44, shift <= 31: fits 75 bits -> three words */
+                            zb_atomic_or(sc->out + (bp >> 5), (uint32_t)v);
+                            if ((bp & 31u) + nb > 32u)
+                                zb_atomic_or(sc->out + (bp >> 5) + 1u, (uint32_t)(v >> 32));
+                            if ((bp & 31u) + nb > 64u)
+                                zb_atomic_or(sc->out + (bp >> 5) + 2u, (uint32_t)(acc >> (64u - (bp & 31u))));
+                        }
+                        running += total;
+                    }
+                }
+                ZB_SERIAL(zl) { zb_atomic_or(sc->out + (running >> 5), 1u << (running & 31u)); } /* end mark */
+                base += (strbits[4u * u + st] + 1u + 7u) >> 3;
+            }
+        }
+        else
+        {
+            /* raw literals, or the whole unit raw: bytes (the destination shares words with its neighbours: byte stores) */
+            const uint8_t* src = ((srcmask >> u) & 1u) || lmode == 4u ? in->src + (size_t)u * ZB_UNIT : in->unit_lits + (uint64_t)u * ZB_UNIT;
+            const uint32_t cnt = lmode == 4u ? (uint32_t)(sub[u] & 0x7FFFu) : n;
+            uint8_t* d2 = out8 + sb->litpos[u];
+            ZB_PAR_FOR(j, cnt) d2[j] = src[j];
+        }
+    }
+
+    ZB_MARK(7);
+    /* ---- phase 7: sequence bit-streams, last sequence first: one sequence per lane and step ---- */
+    for (uint32_t u = 0; u < nunits; ++u)
+    {
+        const uint32_t b0 = sh->useq_base[u], ns = sh->useq_base[u + 1u] - b0;
+        if (ns && sb->lmode[u] != 4u)
+        {
+            uint32_t running = sb->seqpos[u] * 8u;
+            for (uint32_t done = 0; done < ns; done += ZB_LANES)
+            {
+                const uint32_t r = done + zl;
+                uint32_t bits = 0, lit = 0, ml = 0, ofv = 4, lc = 0, mc = 0, oc = 2, lb = 0, mb = 0, so = 0, sm = 0, sl = 0;
+                if (r < ns)
+                {
+                    const uint32_t n = b0 + ns - 1u - r;
+                    const uint64_t q = sc->seqs[n];
+                    lit = ZB_SEQ_LIT(q);
+                    ml = ZB_SEQ_ML(q) - 3u;
+                    ofv = ZB_SEQ_OFF(q) + 3u;
+                    lc = zb_ll_code(lit);
+                    mc = zb_ml_code(ml);
+                    oc = zb_highbit(ofv);
+                    lb = zb_ll_bits(lc);
+                    mb = zb_ml_bits(mc);
+                    if (r) /* every sequence but the block's last one updates the states: OF, ML, LL (read back as LL, ML, OF) */
+                    {
+                        if (sh->mode[ZT_OF] != 1u)
+                            so = sc->sbits[(uint64_t)ZT_OF * ZB_SEQ_MAX + n];
+                        if (sh->mode[ZT_ML] != 1u)
+                            sm = sc->sbits[(uint64_t)ZT_ML * ZB_SEQ_MAX + n];
+                        if (sh->mode[ZT_LL] != 1u)
+                            sl = sc->sbits[(uint64_t)ZT_LL * ZB_SEQ_MAX + n];
+                    }
+                    bits = (so >> 10) + (sm >> 10) + (sl >> 10) + lb + mb + oc;
+                }
+                {
+                    uint32_t total;
+                    const uint32_t off = zb_scan_excl(bits, &total);
+                    if (bits)
+                    {
+                        ZbBits bw;
+                        zb_bits_open(&bw, sc->out, running + off);
+                        zb_bits_put(&bw, so & 1023u, so >> 10);
+                        zb_bits_put(&bw, sm & 1023u, sm >> 10);
+                        zb_bits_put(&bw, sl & 1023u, sl >> 10);
+                        zb_bits_put(&bw, lit - zb_ll_base(lc), lb);
+                        zb_bits_put(&bw, ml - zb_ml_base(mc), mb);
+                        zb_bits_put(&bw, ofv - (1u << oc), oc);
+                        zb_bits_close(&bw);
+                    }
+                    running += total;
+                }
+            }
+        }
+    }
+    ZB_SYNC();
+
+    ZB_MARK(8);
+    /* ---- phase 8: final states (ML, OF, LL: read back as LL, OF, ML) and the end mark of every stream ---- */
+    ZB_PAR_FOR(u, nunits)
+    {
+        if (sh->useq_base[u + 1u] > sh->useq_base[u] && sb->lmode[u] != 4u)
+        {
+            ZbBits bw;
+            zb_bits_open(&bw, sc->out, sb->seqpos[u] * 8u + sb->seqbits[u]);
+            if (sh->mode[ZT_ML] != 1u)
+                zb_bits_put(&bw, sb->fstate[u][ZT_ML], sh->table_log[ZT_ML]);
+            if (sh->mode[ZT_OF] != 1u)
+                zb_bits_put(&bw, sb->fstate[u][ZT_OF], sh->table_log[ZT_OF]);
+            if (sh->mode[ZT_LL] != 1u)
+                zb_bits_put(&bw, sb->fstate[u][ZT_LL], sh->table_log[ZT_LL]);
+            zb_bits_put(&bw, 1u, 1u);
+            zb_bits_close(&bw);
+        }
+    }
+    ZB_SYNC();
+    ZB_MARK(10);
+    return sh->v[ZV_OUT_SIZE];
+}
+
 #endif /* ZSTD_BLOCK_CORE_H */

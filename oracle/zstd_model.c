@@ -28,6 +28,10 @@ static uint32_t g_ltz_dbg;
 #define ZB_DBG g_ltz_dbg
 #include "../longtail_amd/csrc/zstd_decode_core.h" /* includes zstd_block_core.h */
 void ltz_model_debug(uint32_t flags) { g_ltz_dbg = flags; }
+static int g_ltz_sub; /* 1: pieces are written as runs of sub-blocks (zb_encode_piece_sub) */
+static uint16_t g_ltz_last_sub[ZB_MAX_UNITS];
+void ltz_model_sub_blocks(int on) { g_ltz_sub = on; }
+const uint16_t* ltz_model_last_sub(void) { return g_ltz_last_sub; }
 
 #include "oracle.h"
 
@@ -48,7 +52,7 @@ uint32_t ltz_model_encode_block_src(const void* meta, const uint8_t* unit_lits, 
     sc.seqs = (uint64_t*)malloc(sizeof(uint64_t) * ZB_SEQ_MAX);
     sc.sbits = (uint16_t*)malloc(sizeof(uint16_t) * 3 * ZB_SEQ_MAX);
     sc.out = (uint32_t*)malloc(ZB_OUT_BYTES);
-    n = zb_encode_block(&in, &sc, sh, 0);
+    n = g_ltz_sub ? zb_encode_piece_sub(&in, &sc, sh, 0, g_ltz_last_sub) : zb_encode_block(&in, &sc, sh, 0);
     if (n)
         memcpy(out, sc.out, n);
     free(sc.seqs);
@@ -160,6 +164,16 @@ int ltz_model_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, s
         }
         model_match_block(src, off, size, table, meta, unit_lits, unit_recs);
         csize = ltz_model_encode_block_src(meta, unit_lits, unit_recs, (size + ZB_UNIT - 1u) / ZB_UNIT, size, src + off, enc);
+        if (g_ltz_sub && csize)
+        {
+            /* the sub-blocks carry their own headers: only Last_Block is left to set */
+            const uint32_t lastu = (size + ZB_UNIT - 1u) / ZB_UNIT - 1u;
+            memcpy(dst + pos, enc, csize);
+            if (last)
+                dst[pos + csize - 3u - (g_ltz_last_sub[lastu] & 0x7FFFu)] |= 1u;
+            pos += csize;
+        }
+        else
         {
             const uint32_t h = last | ((csize ? 2u : 0u) << 1) | ((csize ? csize : size) << 3);
             dst[pos++] = (uint8_t)h;

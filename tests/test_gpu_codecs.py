@@ -116,6 +116,20 @@ def test_lz4_gpu_decoder_on_reference_payloads(gpu, oracle):
     assert (int(sizes[0]) == 0xFFFFFFFF) == (n < 0)
 
 
+@pytest.fixture(params=[1, 0], ids=["subblocks", "pieces"])
+def zmode(request, oracle, monkeypatch):
+    """Both layouts of the encoder's frames: a run of sub-blocks per 128 KiB piece with a directory (the default) and one block
+    per piece (LTHIP_ZSTD_SUB=0); the host model follows."""
+    import ctypes as C
+
+    oracle.dll.ltz_model_sub_blocks.argtypes = [C.c_int]
+    oracle.dll.ltz_model_sub_blocks.restype = None
+    monkeypatch.setenv("LTHIP_ZSTD_SUB", str(request.param))
+    oracle.dll.ltz_model_sub_blocks(request.param)
+    yield request.param
+    oracle.dll.ltz_model_sub_blocks(0)
+
+
 def gpu_zstd(gpu, blocks):
     dev, offs = to_device(blocks)
     caps = [len(b) + (len(b) >> 8) + 64 for b in blocks]
@@ -127,24 +141,55 @@ def gpu_zstd(gpu, blocks):
 
 
 def zstd_pieces(frame: np.ndarray):
-    """[(type, payload bytes)] of a single-segment frame with an 8-byte content size (the layout k_zstd.hip writes)."""
+    """[(type, payload bytes)] per 128 KiB piece of a single-segment frame with an 8-byte content size (the layouts k_zstd.hip
+    writes).  A piece is one block -- or, in frames that end with the "LTP\\2" directory, a run of sub-blocks (one per 4 KiB unit):
+    then type 2 and the payload is the run WITH its block headers, Last_Block cleared (what zb_encode_piece_sub returns)."""
     assert bytes(frame[:5]) == bytes([0x28, 0xB5, 0x2F, 0xFD, 0xE0])
-    pos, out = 13, []
+    content = int.from_bytes(bytes(frame[5:13]), "little")
+    nunits = (content + 4095) // 4096
+    pos, blocks = 13, []
     while True:
         h = int(frame[pos]) | int(frame[pos + 1]) << 8 | int(frame[pos + 2]) << 16
         last, typ, size = h & 1, (h >> 1) & 3, h >> 3
         n = 1 if typ == 1 else size
-        out.append((typ, frame[pos + 3 : pos + 3 + n]))
+        blocks.append((typ, pos, 3 + n))
         pos += 3 + n
         if last:
             break
+    tail = bytes(frame[pos:])
+    magic = bytes([0x5D, 0x2A, 0x4D, 0x18])
+    if tail[:4] == magic and tail[8:12] == b"LTP\x02":
+        # sub-block frames: skippable frame with the directory, one u16 per unit
+        assert len(tail) == 12 + 2 * nunits and int.from_bytes(tail[4:8], "little") == 4 + 2 * nunits
+        d = np.frombuffer(tail[12:], dtype="<u2")
+        out, k = [], 0
+        for u0 in range(0, nunits, 32):
+            nu = min(32, nunits - u0)
+            if d[u0] >= 0xFFFE:
+                assert (d[u0 : u0 + nu] == d[u0]).all()
+                typ, p0, n = blocks[k]
+                assert typ == (0 if d[u0] == 0xFFFF else 1)
+                out.append((typ, frame[p0 + 3 : p0 + n]))
+                k += 1
+            else:
+                p0 = blocks[k][1]
+                for u in range(nu):
+                    typ, _, n = blocks[k + u]
+                    assert n == 3 + (int(d[u0 + u]) & 0x7FFF) and typ == (0 if d[u0 + u] & 0x8000 else 2)
+                end = blocks[k + nu - 1][1] + blocks[k + nu - 1][2]
+                run = frame[p0:end].copy()
+                run[blocks[k + nu - 1][1] - p0] &= 0xFE
+                out.append((2, run))
+                k += nu
+        assert k == len(blocks)
+        return out
     # frames of two or more pieces end with the independence marker: a skippable frame (k_zstd.hip z_write_trailer)
-    if pos != len(frame):
-        assert len(out) >= 2 and bytes(frame[pos:]) == bytes([0x5D, 0x2A, 0x4D, 0x18, 4, 0, 0, 0]) + b"LTP\x01"
-    return out
+    if tail:
+        assert len(blocks) >= 2 and tail == magic + bytes([4, 0, 0, 0]) + b"LTP\x01"
+    return [(typ, frame[p0 + 3 : p0 + n]) for typ, p0, n in blocks]
 
 
-def test_zstd_frames_decode_with_reference(gpu, oracle, ref):
+def test_zstd_frames_decode_with_reference(gpu, oracle, ref, zmode):
     blocks = [oracle.synth(n, 40 + n, k) for k in (0, 1, 2, 11, 12, 13) for n in (0, 1, 100, 5000, 131071, 131072, 131073, 400000)]
     blocks.append(oracle.synth((8 << 20) + 12345, 7, 1))
     rng = np.random.default_rng(3)
@@ -157,10 +202,10 @@ def test_zstd_frames_decode_with_reference(gpu, oracle, ref):
         assert err == 0 and len(out) == len(b) and (out == b).all()
     # all-zero input collapses to RLE blocks
     z = [i for i, b in enumerate(blocks) if len(b) == 400000 and not b.any()]
-    assert z and len(frames[z[0]]) < 100
+    assert z and len(frames[z[0]]) < 100 + (12 + 2 * 98 if zmode else 0)  # (+ the directory: one u16 per 4 KiB unit)
 
 
-def test_zstd_compresses(gpu, oracle):
+def test_zstd_compresses(gpu, oracle, zmode):
     """Compressed_Blocks are really produced, and beat the LZ4 payload of the same parse on entropy-codable data."""
     blocks = [oracle.synth(2 << 20, 3, k) for k in (1, 11, 12, 13)]
     frames = gpu_zstd(gpu, blocks)
@@ -205,7 +250,7 @@ def _check_against_model(gpu, d, blocks, frames):
     return checked
 
 
-def test_zstd_entropy_stage_is_bit_exact_with_host_model(gpu, oracle):
+def test_zstd_entropy_stage_is_bit_exact_with_host_model(gpu, oracle, zmode):
     """k_zstd_encode and oracle/zstd_model.c compile the SAME zstd_block_core.h (64 lanes vs 1): fed with the GPU match
     finder's own output, the host model must reproduce every Compressed_Block byte for byte."""
     d = _model_src(oracle)
@@ -216,7 +261,7 @@ def test_zstd_entropy_stage_is_bit_exact_with_host_model(gpu, oracle):
     assert _check_against_model(gpu, d, blocks, frames) >= 10
 
 
-def test_zstd_unaligned_sources_and_literals_read_from_the_source(gpu, oracle, ref):
+def test_zstd_unaligned_sources_and_literals_read_from_the_source(gpu, oracle, ref, zmode):
     """Units without a sequence keep their literals in the source (no copy by the match finder), wherever the block lies:
     blocks at odd device offsets, with entropy-codable literals but no matches (Huffman from the source), noise (sampled
     early-out -> Raw, bytes placed by the match finder), and a mix, must equal the host model and decode with the reference."""
@@ -259,7 +304,7 @@ def gpu_zstd_decode(gpu, frames, caps):
     return [None if int(s) == 0xFFFFFFFF else host[o : o + int(s)].copy() for o, s in zip(d_offs, sizes)]
 
 
-def test_zstd_decoder_reads_reference_and_own_frames(gpu, oracle, ref):
+def test_zstd_decoder_reads_reference_and_own_frames(gpu, oracle, ref, zmode):
     """The HIP zstd decoder against frames from the REFERENCE encoder (all five longtail settings: levels 3, 3, 22, 8, 22)
     and from the HIP encoder: decoded bytes identical to the original."""
     rng = np.random.default_rng(8)
@@ -284,7 +329,7 @@ def test_zstd_decoder_reads_reference_and_own_frames(gpu, oracle, ref):
         assert o is not None and len(o) == len(r) and (o == r).all()
 
 
-def test_zstd_decoder_agrees_with_host_model_and_reference_on_damaged_frames(gpu, oracle, ref):
+def test_zstd_decoder_agrees_with_host_model_and_reference_on_damaged_frames(gpu, oracle, ref, zmode):
     """Same source on host and device (zstd_decode_core.h): identical verdict and bytes on mutated frames; whatever the
     decoder accepts the reference accepts with the same bytes (it is stricter than the reference's fast Huffman path,
     which does not check that a literal stream is consumed exactly, so the converse is not required)."""
@@ -335,6 +380,7 @@ def test_zstd_piece_decoder_is_the_serial_decoder_on_own_frames_and_strict_on_fa
         repeat offsets, repeated tables) with the marker appended -- is rejected or decoded exactly like the reference, never
         decoded differently."""
     rng = np.random.default_rng(12)
+    monkeypatch.setenv("LTHIP_ZSTD_SUB", "0")  # frames of one block per piece (the sub-block layout has its own test below)
     datas = [oracle.synth(n, 90 + n, k) for k, n in ((1, 131073), (1, 600000), (11, 400000), (12, 300000), (13, 262144), (0, 500000),
                                                     (2, 400000), (1, (8 << 20) + 5))]
     own = gpu_zstd(gpu, datas)
