@@ -493,20 +493,21 @@ struct ZItem
     uint32_t size;    // bytes of the item's source
     uint32_t out0;    // piece: first output byte inside the payload's destination; whole: unused
     uint32_t payload;
-    uint32_t kind;    // 0 nothing, 1 whole payload, 2 piece
+    uint32_t kind;    // 0 nothing, 1 whole payload, 2 piece (one block), 3 piece (a run of sub-blocks)
+    uint32_t aux;     // kind 3: offset (inside the payload) of the piece's first directory entry
+    uint32_t pad;
 };
 
-// one thread per payload: is it a marked frame of ours?  then list its pieces, else list the payload
+// Is the payload a marked frame of ours?  then list its pieces, else list the payload.  One wave per payload.
 // The list is DENSE (items are appended through a counter): with one slot per possible piece the whole-payload items of equal-sized
 // payloads sit a power of two apart and land on a handful of the persistent workgroups (measured: 128 payloads on 32 of 2048).
-__global__ void k_zstd_split(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t nblocks, ZItem* __restrict__ items,
-                             uint32_t* __restrict__ item_count, uint32_t* __restrict__ out_sizes, uint32_t dbg)
+//
+// Frames with the DIRECTORY (sub-block layout): every lane adds up the entries of one piece, a wave scan places the pieces; nothing
+// of the frame's 2 048 block headers is read here -- every piece checks its own headers against the directory when it is decoded,
+// and the sum of all sizes must land exactly on the trailer.
+// Frames with the plain marker (one block per piece): lane 0 walks the block headers.
+__device__ void z_split_walk(const uint8_t* p, const ZBlock blk, uint32_t b, ZItem* items, uint32_t* item_count, uint32_t* out_sizes, uint32_t dbg)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblocks)
-        return;
-    const ZBlock blk = blocks[b];
-    const uint8_t* p = src + blk.src_off;
     bool pieces = false;
     uint32_t np = 0;
     uint64_t content = 0;
@@ -557,6 +558,7 @@ __global__ void k_zstd_split(const uint8_t* __restrict__ src, const ZBlock* __re
             out[i].out0 = i * ZB;
             out[i].payload = b;
             out[i].kind = 2;
+            out[i].aux = out[i].pad = 0;
             ip += 3u + body;
         }
         out_sizes[b] = (uint32_t)content; // a piece that fails replaces it by ZD_ERROR
@@ -569,6 +571,143 @@ __global__ void k_zstd_split(const uint8_t* __restrict__ src, const ZBlock* __re
         it->out0 = 0;
         it->payload = b;
         it->kind = 1;
+        it->aux = it->pad = 0;
+    }
+}
+
+__device__ __forceinline__ uint32_t z_wave_scan_excl(uint32_t v, int lane, uint32_t* total)
+{
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const uint32_t x = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d)
+            incl += x;
+    }
+    *total = (uint32_t)__shfl((int)incl, 63, 64);
+    return incl - v;
+}
+
+__global__ __launch_bounds__(64) void k_zstd_split(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t nblocks,
+                                                   ZItem* __restrict__ items, uint32_t* __restrict__ item_count,
+                                                   uint32_t* __restrict__ out_sizes, uint32_t dbg)
+{
+    const uint32_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const ZBlock blk = blocks[b];
+    const uint8_t* p = src + blk.src_off;
+    uint64_t content = 0;
+    bool dir = false;
+    if (!(dbg & 1u) && blk.size >= ZHDR + 3u + ZTRAILER && p[0] == 0x28 && p[1] == 0xB5 && p[2] == 0x2F && p[3] == 0xFD && p[4] == 0xE0)
+    {
+        for (int i = 0; i < 8; ++i)
+            content |= (uint64_t)p[5 + i] << (8 * i);
+        const uint64_t want = (content + ZB - 1u) / ZB;
+        if (content != 0 && content <= (uint64_t)blk.dst_cap && want <= (uint64_t)blk.nzb &&
+            (uint64_t)blk.size >= (uint64_t)ZHDR + 3u + z_trailer2_size(content))
+            dir = z_is_trailer2_head(p + blk.size - z_trailer2_size(content), content);
+    }
+    if (!dir)
+    {
+        if (lane == 0)
+            z_split_walk(p, blk, b, items, item_count, out_sizes, dbg);
+        return;
+    }
+    const uint32_t tsize = z_trailer2_size(content);
+    const uint8_t* d = p + blk.size - tsize + ZTRAILER; // u16 entries, any alignment
+    const uint32_t np = (uint32_t)((content + ZB - 1u) / ZB);
+    // pass 1: do the sizes add up?  pass 2: the items
+    uint32_t base = 0;
+    ZItem* out = nullptr;
+    for (int pass = 0; pass < 2; ++pass)
+    {
+        uint32_t pos = ZHDR;
+        bool ok = true;
+        for (uint32_t i0 = 0; i0 < np; i0 += 64u)
+        {
+            const uint32_t i = i0 + (uint32_t)lane;
+            uint32_t size = 0, kind = 0, rle = 0;
+            if (i < np)
+            {
+                const uint32_t len = (uint32_t)(content - (uint64_t)i * ZB < ZB ? content - (uint64_t)i * ZB : ZB);
+                const uint32_t nu = (len + ZB_UNIT - 1u) / ZB_UNIT;
+                const uint8_t* e = d + 2u * (uint64_t)i * ZB_MAX_UNITS;
+                const uint32_t e0 = (uint32_t)e[0] | ((uint32_t)e[1] << 8);
+                if (e0 == ZDIR_RAW_PIECE || e0 == ZDIR_RLE_PIECE)
+                {
+                    size = e0 == ZDIR_RAW_PIECE ? 3u + len : 4u;
+                    rle = e0 == ZDIR_RLE_PIECE ? 1u : 0u;
+                    kind = 2;
+                    for (uint32_t u = 1; u < nu; ++u)
+                        ok = ok && ((uint32_t)e[2u * u] | ((uint32_t)e[2u * u + 1u] << 8)) == e0;
+                }
+                else
+                {
+                    kind = 3;
+                    for (uint32_t u = 0; u < nu; ++u)
+                    {
+                        const uint32_t eu = (uint32_t)e[2u * u] | ((uint32_t)e[2u * u + 1u] << 8);
+                        ok = ok && eu < ZDIR_RLE_PIECE;
+                        size += 3u + (eu & 0x7FFFu);
+                    }
+                }
+            }
+            uint32_t total;
+            const uint32_t off = z_wave_scan_excl(size, lane, &total);
+            if (pass == 0 && kind == 2u) // a piece of one Raw_Block / RLE_Block: its header is checked here (runs of sub-blocks: by their decoder)
+            {
+                const uint64_t at = (uint64_t)pos + off;
+                if (at + size > (uint64_t)blk.size - tsize)
+                    ok = false;
+                else
+                {
+                    const uint32_t len = (uint32_t)(content - (uint64_t)i * ZB < ZB ? content - (uint64_t)i * ZB : ZB);
+                    const uint32_t bh = (uint32_t)p[at] | ((uint32_t)p[at + 1] << 8) | ((uint32_t)p[at + 2] << 16);
+                    ok = ok && bh == ((i + 1u == np ? 1u : 0u) | (rle << 1) | (len << 3));
+                }
+            }
+            if (pass == 1 && i < np)
+            {
+                ZItem it;
+                it.src_off = blk.src_off + pos + off;
+                it.size = size;
+                it.out0 = i * ZB;
+                it.payload = b;
+                it.kind = kind;
+                it.aux = (uint32_t)(d - p) + 2u * i * ZB_MAX_UNITS;
+                it.pad = 0;
+                out[i] = it;
+            }
+            if ((uint64_t)pos + total > (uint64_t)blk.size)
+                ok = false;
+            pos += total;
+        }
+        ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull && pos == blk.size - tsize;
+        if (pass == 0)
+        {
+            if (!ok)
+            {
+                if (lane == 0) // not what the directory promises: the serial decoder says what the payload is
+                {
+                    ZItem* it = items + atomicAdd(item_count, 1u);
+                    it->src_off = blk.src_off;
+                    it->size = blk.size;
+                    it->out0 = 0;
+                    it->payload = b;
+                    it->kind = 1;
+                    it->aux = it->pad = 0;
+                }
+                return;
+            }
+            if (lane == 0)
+            {
+                base = atomicAdd(item_count, np);
+                out_sizes[b] = (uint32_t)content; // a piece that fails replaces it
+            }
+            base = (uint32_t)__builtin_amdgcn_readfirstlane(base);
+            out = items + base;
+        }
     }
 }
 
@@ -584,6 +723,7 @@ struct ZPrep
     uint32_t log[3];    // table logs (0: an RLE table, one entry)
     uint32_t expect;    // bytes the piece has to produce
 };
+constexpr uint32_t ZREC_MAX = ZB_MAX_UNITS * ZB_UNIT_SEQ_MAX; // sequence records per piece of sub-blocks
 constexpr uint32_t ZT_ENTRIES = 512u; // per table and piece: u64 {BYTE OFFSET (within the piece's three tables) of the new state's base entry:16 |
                                        // state bits:8 | extra bits:8 | baseline:32}
 
@@ -729,6 +869,481 @@ __global__ __launch_bounds__(64) void k_zstd_prepare(const uint8_t* __restrict__
 #ifdef LTHIP_ZB_PROF
         ZB_MARK(14);
 #endif
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pieces that are runs of SUB-BLOCKS (kind 3): k_zstd_sub_entropy + k_zstd_execute<true>.
+// One wave per piece.  Lane u owns unit u's block: it finds it through the frame's directory, checks the Block_Header against the
+// directory, parses the literals and sequences section headers.  The Huffman tree and the three FSE tables come with the first
+// block that needs them (everything else is treeless / Predefined or Repeat_Mode) and are built once, by the decoder core's
+// own readers.  Then every lane decodes streams of its own: the up to 128 Huffman streams of the piece's literals (into the piece's
+// literal buffer, back to back in block order), and the up to 32 sequence bit-streams (lane u the sequences of block u, as records
+// {literal length, match length, offset value} into the piece's record array).  A block's literals after its last sequence join
+// the literal length of the next sequence of the piece, so what k_zstd_execute<true> sees is ONE run of sequences over ONE run of
+// literals, exactly what it executes for a one-block piece.
+// STRICT like the one-block piece decoder: a block may not use repeat offsets; more than that, anything that is not what
+// zb_encode_piece_sub writes (a second tree, tables sent twice, a block that does not regenerate exactly its unit, a header that
+// disagrees with the directory) sends the whole payload to the serial decoder (retry[payload]), which accepts and rejects what it
+// always did.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t zs_bits(const uint8_t* base, uint32_t bitpos, uint32_t n) // bits [bitpos, bitpos + n), n <= 32
+{
+    const uint32_t b1 = (bitpos + n + 7u) >> 3; // the 8 bytes that END with the byte holding the field's top bit: never past the stream
+    uint64_t w;
+    __builtin_memcpy(&w, base + (int64_t)b1 - 8, 8);
+    return (uint32_t)(w >> (bitpos + 64u - 8u * b1)) & (uint32_t)((1ull << n) - 1ull);
+}
+
+__global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, const ZItem* __restrict__ items,
+                                                         const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
+                                                         uint8_t* __restrict__ lit_scratch, uint64_t* __restrict__ rec_scratch,
+                                                         ZPrep* __restrict__ prep, const uint32_t* __restrict__ out_sizes,
+                                                         uint32_t* __restrict__ retry)
+{
+    __shared__ ZdShared sh;
+    __shared__ uint4 s_streams[4 * ZB_MAX_UNITS]; // {source offset inside the piece, bytes, literal offset, symbols}
+    const uint32_t nitems = *item_count < item1 ? *item_count : item1;
+    const int lane = threadIdx.x;
+    uint64_t* const pk_ll = reinterpret_cast<uint64_t*>(sh.huf); // packed tables {base:16 | state bits:8 | extra bits:8 | baseline:32},
+    uint64_t* const pk_ml = pk_ll + 512;                         // over the Huffman table (done with by then) ...
+    uint64_t* const pk_of = reinterpret_cast<uint64_t*>(&sh.wtab); // ... and the weights' table
+    static_assert(sizeof(sh.huf) >= 2 * 512 * 8 && sizeof(sh.wtab) >= 256 * 8, "room for the packed tables");
+    for (uint32_t i = item0 + blockIdx.x; i < nitems; i += gridDim.x)
+    {
+        const ZItem it = items[i];
+        if (it.kind != 3u)
+            continue;
+        __syncthreads();
+        const ZBlock blk = blocks[it.payload];
+        const uint32_t slot = i - item0;
+        uint8_t* lits = lit_scratch + (uint64_t)slot * (ZD_LIT_MAX + 64u);
+        uint64_t* recs = rec_scratch + (uint64_t)slot * ZREC_MAX;
+        const uint8_t* p = src + it.src_off;
+        const uint8_t* dir = src + blk.src_off + it.aux;
+        const uint32_t content = out_sizes[it.payload] == ZD_ERROR ? 0u : out_sizes[it.payload];
+        const uint32_t expect = content > it.out0 ? (content - it.out0 < ZB ? content - it.out0 : ZB) : 0u;
+        const uint32_t nunits = (expect + ZB_UNIT - 1u) / ZB_UNIT;
+        const bool mine = (uint32_t)lane < nunits;
+        bool bad = expect == 0u;
+        if (lane == 0)
+        {
+            sh.v[ZDV_ERR] = 0;
+            sh.v[ZDV_PREP] = 0;
+            sh.huf_valid = 0;
+        }
+        // ---- my block: where, what ----
+        uint32_t e = 0;
+        if (mine)
+            e = (uint32_t)dir[2 * lane] | ((uint32_t)dir[2 * lane + 1] << 8);
+        const uint32_t raw = e >> 15, csz = e & 0x7FFFu;
+        uint32_t total;
+        const uint32_t off = z_wave_scan_excl(mine ? 3u + csz : 0u, lane, &total);
+        bad = bad || total != it.size;
+        const uint32_t ubytes = mine ? ((uint32_t)lane + 1u == nunits ? expect - (uint32_t)lane * ZB_UNIT : ZB_UNIT) : 0u;
+        const uint8_t* c = p + off + 3u; // my block's content
+        uint32_t lmode = 0, nlit = 0, lhdr = 0, lcs = 0, nstr = 0, nbseq = 0, shdr = 0, modes = 0;
+        if (mine && !bad)
+        {
+            const uint32_t h = (uint32_t)p[off] | ((uint32_t)p[off + 1u] << 8) | ((uint32_t)p[off + 2u] << 16);
+            const uint32_t is_last = (it.out0 + expect == content && (uint32_t)lane + 1u == nunits) ? 1u : 0u;
+            if ((h & 1u) != is_last || ((h >> 1) & 3u) != (raw ? 0u : 2u) || (h >> 3) != csz || (raw && csz != ubytes))
+                bad = true;
+            else if (raw)
+                nlit = ubytes; // the unit's bytes are its literals
+            else if (csz < 2u)
+                bad = true;
+            else
+            {
+                const uint32_t b0 = c[0], sf = (b0 >> 2) & 3u;
+                lmode = b0 & 3u;
+                if (lmode < 2u)
+                {
+                    lhdr = (sf & 1u) == 0u ? 1u : sf == 1u ? 2u : 3u;
+                    if (lhdr > csz)
+                        bad = true;
+                    else
+                    {
+                        nlit = lhdr == 1u ? b0 >> 3 : lhdr == 2u ? ((uint32_t)c[0] | ((uint32_t)c[1] << 8)) >> 4
+                                                                : ((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16)) >> 4;
+                        lcs = lmode == 0u ? nlit : 1u;
+                    }
+                }
+                else
+                {
+                    lhdr = sf < 2u ? 3u : sf == 2u ? 4u : 5u;
+                    if (lhdr > csz)
+                        bad = true;
+                    else if (lhdr == 3u)
+                    {
+                        const uint32_t hh = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+                        nlit = (hh >> 4) & 0x3FFu;
+                        lcs = hh >> 14;
+                    }
+                    else if (lhdr == 4u)
+                    {
+                        const uint32_t hh = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
+                        nlit = (hh >> 4) & 0x3FFFu;
+                        lcs = hh >> 18;
+                    }
+                    else
+                    {
+                        const uint32_t hh = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
+                        nlit = (hh >> 4) & 0x3FFFFu;
+                        lcs = (hh >> 22) | ((uint32_t)c[4] << 10);
+                    }
+                    nstr = sf == 0u ? 1u : 4u;
+                }
+                if (!bad && (nlit > ubytes || lcs >= csz - lhdr)) // (at least one byte of sequences section follows)
+                    bad = true;
+                if (!bad)
+                {
+                    const uint32_t sp = lhdr + lcs;
+                    const uint32_t n0 = c[sp];
+                    if (n0 == 0u)
+                    {
+                        shdr = 1;
+                        bad = sp + 1u != csz;
+                    }
+                    else
+                    {
+                        if (n0 < 128u)
+                        {
+                            nbseq = n0;
+                            shdr = 1;
+                        }
+                        else if (n0 < 255u)
+                        {
+                            bad = sp + 2u > csz;
+                            nbseq = bad ? 0u : ((n0 - 128u) << 8) + c[sp + 1u];
+                            shdr = 2;
+                        }
+                        else
+                            bad = true; // 0x7F00 sequences and more: not in a 4 KiB unit
+                        if (!bad && (sp + shdr + 1u >= csz || nbseq > ZB_UNIT_SEQ_MAX || nbseq == 0u))
+                            bad = true;
+                        if (!bad)
+                        {
+                            modes = c[sp + shdr];
+                            shdr += 1u;
+                            bad = (modes & 3u) != 0u;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- who brings the tree, who the tables; is everybody else consistent with them? ----
+        const uint64_t treem = __builtin_amdgcn_ballot_w64(mine && !raw && lmode == 2u);
+        const uint64_t lessm = __builtin_amdgcn_ballot_w64(mine && !raw && lmode == 3u);
+        const uint64_t seqm = __builtin_amdgcn_ballot_w64(mine && nbseq != 0u);
+        const int tree_lane = treem ? __builtin_ctzll(treem) : -1;
+        const int tab_lane = seqm ? __builtin_ctzll(seqm) : -1;
+        if (treem & (treem - 1ull))
+            bad = true; // a second tree
+        if (lessm && (tree_lane < 0 || (lessm & ((1ull << tree_lane) - 1ull))))
+            bad = true; // treeless before the tree
+        const uint32_t modes0 = tab_lane >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)modes, tab_lane) : 0u;
+        {
+            uint32_t want = 0;
+            for (int t = 0; t < 3; ++t)
+            {
+                const uint32_t m = (modes0 >> (6 - 2 * t)) & 3u;
+                if (m == 3u)
+                    bad = true; // nothing to repeat at the head of a piece
+                want |= (m ? 3u : 0u) << (6 - 2 * t);
+            }
+            if (mine && nbseq != 0u && lane != tab_lane && modes != want)
+                bad = true;
+        }
+        if (__builtin_amdgcn_ballot_w64(bad))
+            bad = true;
+        // ---- the table descriptions (lane 0), the tables (all lanes; their scratch lies over the Huffman table, so:), THEN the tree
+        // (lane 0), all by the decoder core's own readers ----
+        uint32_t tree_bytes = 0, desc_bytes = 0;
+        if (!bad)
+        {
+            const uint32_t t_off = tree_lane >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)(off + 3u + lhdr), tree_lane) : 0u;
+            const uint32_t t_size = tree_lane >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)lcs, tree_lane) : 0u;
+            const uint32_t d_off = tab_lane >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)(off + 3u + lhdr + lcs + shdr), tab_lane) : 0u;
+            const uint32_t d_end = tab_lane >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)(off + 3u + csz), tab_lane) : 0u;
+            if (lane == 0)
+            {
+                sh.v[ZDV_LEN] = 0;
+                sh.v[ZDV_LL] = 0;
+                if (tab_lane >= 0)
+                {
+                    uint32_t q = d_off;
+                    for (int t = 0; t < 3 && !sh.v[ZDV_ERR]; ++t) // LL, OF, ML
+                    {
+                        uint32_t used = 0;
+                        if (zd_set_table(&sh, t, (modes0 >> (6 - 2 * t)) & 3u, p + q, d_end - q, &used))
+                            sh.v[ZDV_ERR] = 1;
+                        q += used;
+                    }
+                    sh.v[ZDV_LL] = q - d_off;
+                    if (q >= d_end)
+                        sh.v[ZDV_ERR] = 1;
+                }
+            }
+            __syncthreads();
+            bad = sh.v[ZDV_ERR] != 0u;
+            desc_bytes = sh.v[ZDV_LL];
+            if (!bad && tab_lane >= 0)
+            {
+                for (int t = 0; t < 3; ++t)
+                    if (sh.tb_build[t])
+                    {
+                        if (zd_build_fse_par(&sh.fse[t], sh.norm + 64 * t, sh.tb_maxsym[t], sh.tb_log[t], sh.cum, (uint32_t*)sh.huf,
+                                             sh.huf + 2u * ZD_FSE_PAR_MASK_WORDS, (uint32_t)lane))
+                            bad = true;
+                        ZB_SYNC_LDS();
+                    }
+            }
+            __syncthreads();
+            if (lane == 0 && !bad && tree_lane >= 0)
+            {
+                const uint32_t tr = zd_read_huf_tree(&sh, p + t_off, t_size);
+                if (tr == ZD_ERROR)
+                    sh.v[ZDV_ERR] = 1;
+                else
+                    sh.v[ZDV_LEN] = tr;
+            }
+            __syncthreads();
+            bad = bad || sh.v[ZDV_ERR] != 0u;
+            tree_bytes = sh.v[ZDV_LEN];
+        }
+        // ---- literals: offsets, the stream list, raw runs ----
+        uint32_t nlit_total, nstr_total, nseq_total;
+        const uint32_t lo = z_wave_scan_excl(mine ? nlit : 0u, lane, &nlit_total);
+        const bool huf = mine && !raw && lmode >= 2u;
+        const uint32_t st0 = z_wave_scan_excl(huf ? nstr : 0u, lane, &nstr_total);
+        const uint32_t rec0 = z_wave_scan_excl(mine ? nbseq : 0u, lane, &nseq_total);
+        bad = bad || nlit_total > ZD_LIT_MAX || nlit_total > expect;
+        if (!bad && huf)
+        {
+            const uint32_t tb = lane == tree_lane ? tree_bytes : 0u;
+            const uint32_t at = off + 3u + lhdr + tb;
+            if (lcs < tb)
+                bad = true;
+            else if (nstr == 1u)
+                s_streams[st0] = make_uint4(at, lcs - tb, lo, nlit);
+            else if (lcs - tb < 10u)
+                bad = true;
+            else
+            {
+                const uint8_t* j = p + at;
+                const uint32_t s1 = (uint32_t)j[0] | ((uint32_t)j[1] << 8), s2 = (uint32_t)j[2] | ((uint32_t)j[3] << 8),
+                               s3 = (uint32_t)j[4] | ((uint32_t)j[5] << 8);
+                const uint32_t body = lcs - tb - 6u, seg = (nlit + 3u) >> 2;
+                if (s1 + s2 + s3 >= body || 3u * seg > nlit)
+                    bad = true;
+                else
+                {
+                    s_streams[st0] = make_uint4(at + 6u, s1, lo, seg);
+                    s_streams[st0 + 1u] = make_uint4(at + 6u + s1, s2, lo + seg, seg);
+                    s_streams[st0 + 2u] = make_uint4(at + 6u + s1 + s2, s3, lo + 2u * seg, seg);
+                    s_streams[st0 + 3u] = make_uint4(at + 6u + s1 + s2 + s3, body - s1 - s2 - s3, lo + 3u * seg, nlit - 3u * seg);
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(bad))
+            bad = true;
+        __syncthreads();
+        if (!bad)
+        {
+            // raw / RLE literals and raw blocks: all lanes, unit after unit
+            uint64_t plain = __builtin_amdgcn_ballot_w64(mine && nlit != 0u && (raw || lmode < 2u));
+            while (plain)
+            {
+                const int u = __builtin_ctzll(plain);
+                plain &= plain - 1ull;
+                const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)nlit, u);
+                const uint32_t from = (uint32_t)__builtin_amdgcn_readlane((int)(off + 3u + lhdr), u);
+                const uint32_t to = (uint32_t)__builtin_amdgcn_readlane((int)lo, u);
+                const uint32_t rle = (uint32_t)__builtin_amdgcn_readlane((int)((!raw && lmode == 1u) ? 1u : 0u), u);
+                for (uint32_t k = lane; k < n; k += 64)
+                    lits[to + k] = p[from + (rle ? 0u : k)];
+            }
+            // Huffman streams: one per lane
+            for (uint32_t k = lane; k < nstr_total; k += 64)
+            {
+                const uint4 st = s_streams[k];
+                if (st.w == 0u || zd_huf_stream(&sh, p + st.x, st.y, lits + st.z, st.w))
+                    bad = true;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(bad))
+            bad = true;
+        __syncthreads();
+        // ---- the tables, packed: one 8-byte read per state ----
+        uint32_t log_l = 0, log_o = 0, log_m = 0;
+        if (!bad && tab_lane >= 0)
+        {
+            for (int t = 0; t < 3; ++t)
+            {
+                const ZdFse* f = &sh.fse[t];
+                uint64_t* pk = t == ZT_LL ? pk_ll : t == ZT_ML ? pk_ml : pk_of;
+                const uint32_t size = f->valid == 2u ? 1u : f->valid == 1u ? 1u << f->log : 0u;
+                if (size == 0u || size > (t == ZT_OF ? 256u : 512u))
+                    bad = true;
+                const uint32_t lg = f->valid == 2u ? 0u : f->log;
+                if (t == ZT_LL)
+                    log_l = lg;
+                else if (t == ZT_OF)
+                    log_o = lg;
+                else
+                    log_m = lg;
+                for (uint32_t x = lane; x < size && !bad; x += 64)
+                {
+                    const uint32_t sym = f->sym[x];
+                    uint32_t baseline, ebits;
+                    if (t == ZT_LL)
+                    {
+                        baseline = zb_ll_base(sym & 63u);
+                        ebits = zb_ll_bits(sym & 63u);
+                        bad = sym > 35u;
+                    }
+                    else if (t == ZT_ML)
+                    {
+                        baseline = zb_ml_base(sym & 63u) + 3u;
+                        ebits = zb_ml_bits(sym & 63u);
+                        bad = sym > 52u;
+                    }
+                    else
+                    {
+                        baseline = 1u << (sym & 31u);
+                        ebits = sym & 31u;
+                        bad = sym > 23u; // (an offset of 2^24 and more cannot lie inside a piece)
+                    }
+                    // the table's own fields are read before its packed form lands on them?  No: the packed tables lie over the
+                    // Huffman table and the weights' table, never over sh.fse
+                    pk[x] = (uint64_t)(f->valid == 2u ? 0u : f->base[x]) | ((uint64_t)(f->valid == 2u ? 0u : f->nb[x]) << 16) | ((uint64_t)ebits << 24) |
+                            ((uint64_t)baseline << 32);
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(bad))
+            bad = true;
+        __syncthreads();
+        // ---- sequences: lane u the bit-stream of block u ----
+        uint32_t sum_ll = 0, sum_ml = 0;
+        if (!bad && mine && nbseq != 0u)
+        {
+            const uint32_t at = off + 3u + lhdr + lcs + shdr + (lane == tab_lane ? desc_bytes : 0u);
+            const uint32_t end = off + 3u + csz;
+            if (at >= end || p[end - 1u] == 0u)
+                bad = true;
+            else
+            {
+                const uint8_t* bs = p + at;
+                uint32_t pos = (end - at - 1u) * 8u + (31u - (uint32_t)__builtin_clz((uint32_t)p[end - 1u]));
+                uint32_t sl = 0, so = 0, sm = 0;
+                if (log_l + log_o + log_m > pos)
+                    bad = true;
+                else
+                {
+                    pos -= log_l;
+                    sl = zs_bits(bs, pos, log_l);
+                    pos -= log_o;
+                    so = zs_bits(bs, pos, log_o);
+                    pos -= log_m;
+                    sm = zs_bits(bs, pos, log_m);
+                }
+                for (uint32_t k = 0; k < nbseq && !bad; ++k)
+                {
+                    const uint64_t el = pk_ll[sl], eo = pk_of[so], em = pk_ml[sm];
+                    const uint32_t l0 = (uint32_t)el, o0 = (uint32_t)eo, m0 = (uint32_t)em;
+                    const uint32_t ob = o0 >> 24, mb = m0 >> 24, lb = l0 >> 24;
+                    const uint32_t nbl = (l0 >> 16) & 255u, nbm = (m0 >> 16) & 255u, nbo = (o0 >> 16) & 255u;
+                    const bool more = k + 1u < nbseq;
+                    if (ob + mb + lb + (more ? nbl + nbm + nbo : 0u) > pos)
+                    {
+                        bad = true;
+                        break;
+                    }
+                    pos -= ob;
+                    const uint32_t ov = (uint32_t)(eo >> 32) + zs_bits(bs, pos, ob);
+                    pos -= mb + lb;
+                    const uint32_t t2 = zs_bits(bs, pos, mb + lb); // match-length and literal-length extra bits are adjacent
+                    const uint32_t ml = (uint32_t)(em >> 32) + (t2 >> lb);
+                    const uint32_t ll = (uint32_t)(el >> 32) + (t2 & ((1u << lb) - 1u));
+                    if (more)
+                    {
+                        pos -= nbl + nbm + nbo;
+                        const uint32_t t3 = zs_bits(bs, pos, nbl + nbm + nbo); // LL, ML, OF from the top
+                        sl = (l0 & 0xFFFFu) + (t3 >> (nbm + nbo));
+                        sm = (m0 & 0xFFFFu) + ((t3 >> nbo) & ((1u << nbm) - 1u));
+                        so = (o0 & 0xFFFFu) + (t3 & ((1u << nbo) - 1u));
+                    }
+                    if (ov <= 3u || ov >= (1u << 24)) // repeat offsets need the block before
+                        bad = true;
+                    sum_ll += ll;
+                    sum_ml += ml;
+                    recs[rec0 + k] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)ov << 40);
+                }
+                if (pos != 0u)
+                    bad = true; // the bit-stream must be consumed exactly
+            }
+            // the block must regenerate exactly its unit
+            if (!bad && (sum_ll > nlit || nlit + sum_ml != ubytes))
+                bad = true;
+        }
+        else if (!bad && mine && nlit != ubytes)
+            bad = true; // no sequences: all literals
+        if (__builtin_amdgcn_ballot_w64(bad))
+            bad = true;
+        // ---- a block's last literals go with the next sequence of the piece ----
+        if (!bad)
+        {
+            const uint32_t tail = mine ? nlit - sum_ll : 0u;
+            uint32_t run = 0, carry = 0;
+            for (uint32_t u = 0; u < nunits; ++u)
+            {
+                const uint32_t tu = (uint32_t)__builtin_amdgcn_readlane((int)tail, (int)u);
+                const bool has = (seqm >> u) & 1ull;
+                if ((uint32_t)lane == u)
+                    carry = run;
+                run = has ? tu : run + tu;
+            }
+            if (mine && nbseq != 0u && carry != 0u)
+                recs[rec0] += carry; // (20 bits hold a whole piece of literals)
+        }
+        ZPrep pr;
+        pr.bits_off = 0;
+        pr.bits_size = 0;
+        pr.nbseq = nseq_total;
+        pr.nlit = nlit_total;
+        pr.log[0] = pr.log[1] = pr.log[2] = 0;
+        pr.expect = expect;
+        pr.status = bad ? ZP_SERIAL : ZP_READY;
+        if (lane == 0)
+        {
+            prep[i] = pr;
+            if (bad)
+                retry[it.payload] = 1u;
+        }
+    }
+}
+
+// payloads the sub-block decoder gave back: the whole payload, serially (the plain decoder's verdict and bytes)
+__global__ __launch_bounds__(64) void k_zstd_decode_retry(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t nblocks,
+                                                          const uint32_t* __restrict__ retry, uint8_t* __restrict__ dst,
+                                                          uint8_t* __restrict__ lit_scratch, uint32_t* __restrict__ out_sizes)
+{
+    __shared__ ZdShared sh;
+    uint8_t* lits = lit_scratch + (uint64_t)blockIdx.x * (ZD_LIT_MAX + 64u);
+    if (threadIdx.x == 0)
+        sh.v[ZDV_PREP] = 0;
+    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x)
+    {
+        if (!retry[b])
+            continue;
+        const ZBlock blk = blocks[b];
+        __syncthreads();
+        const uint32_t n = zd_decode_payload_ex(src + blk.src_off, blk.size, dst + blk.dst_off, blk.dst_cap, lits, &sh, threadIdx.x, ZD_WHOLE);
+        if (threadIdx.x == 0)
+            out_sizes[b] = n;
         __syncthreads();
     }
 }
@@ -905,11 +1520,14 @@ struct ZxBits
     }
 };
 
+// RECS: the sequences come as records {literal length:20 | match length:20 | offset value:24} from k_zstd_sub_entropy (`tables` is
+// then the record array, ZREC_MAX per slot) instead of from the bit-stream; everything after that is the same.
+template <bool RECS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_zstd_execute(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, const ZItem* __restrict__ items,
                                                      const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
                                                      uint8_t* __restrict__ dst, const uint8_t* __restrict__ lit_scratch,
                                                      const uint64_t* __restrict__ tables, const ZPrep* __restrict__ prep,
-                                                     uint32_t* __restrict__ status_out)
+                                                     uint32_t* __restrict__ status_out, uint32_t* __restrict__ retry)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZX_RING];
     __shared__ __attribute__((aligned(16))) uint8_t s_lit[ZX_LIT];
@@ -917,7 +1535,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (i >= item1 || i >= *item_count)
         return;
     const ZItem it = items[i];
-    if (it.kind != 2u)
+    if (it.kind != (RECS ? 3u : 2u))
         return;
     const ZPrep pr = prep[i];
     if (pr.status != ZP_READY)
@@ -926,6 +1544,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const ZBlock blk = blocks[it.payload];
     const uint32_t slot = i - item0;
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(tables + (uint64_t)slot * 3u * ZT_ENTRIES); // states are byte offsets into this
+    const uint64_t* recs = tables + (uint64_t)slot * ZREC_MAX;
     const uint8_t* lits = lit_scratch + (uint64_t)slot * (ZD_LIT_MAX + 64u);
     uint8_t* out = dst + blk.dst_off + it.out0;
 
@@ -950,6 +1569,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const uint64_t skew_bits = 8ull * ((uintptr_t)src & 3u);
     bool bad = false;
     uint32_t pos = 0; // bits of the stream not consumed yet
+    if (!RECS)
     {
         const uint32_t last = src[pr.bits_off + pr.bits_size - 1u];
         if (last == 0u)
@@ -966,7 +1586,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     br.wbit0 = 0;
     br.rel = 0;
     uint32_t sl = 0, so = 0, sm = 0;
-    if (!bad)
+    if (!bad && !RECS)
     {
         if (pr.log[ZT_LL] + pr.log[ZT_OF] + pr.log[ZT_ML] > br.pos)
             bad = true;
@@ -1023,6 +1643,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                          : "s"(a), "s"(b), "s"(c), "s"(kk));
             return true;
         };
+        if (RECS)
+        {
+            const uint64_t r = (uint32_t)lane < cnt ? recs[s0 + (uint32_t)lane] : 0ull;
+            r_ll = (uint32_t)r & 0xFFFFFu;
+            r_ml = (uint32_t)(r >> 20) & 0xFFFFFu;
+            r_off = (uint32_t)(r >> 40);
+        }
+        else
         {
             const bool last_batch = s0 + cnt == pr.nbseq;
             const uint32_t with_more = last_batch ? cnt - 1u : cnt; // the block's very last sequence updates no state
@@ -1040,7 +1668,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         if (bad)
             break;
-        if (s0 + cnt == pr.nbseq && br.pos != 0u)
+        if (!RECS && s0 + cnt == pr.nbseq && br.pos != 0u)
         {
             bad = true; // the bit-stream must be consumed exactly
             break;
@@ -1205,7 +1833,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
     }
     if (bad && lane == 0)
+    {
         status_out[(size_t)i * (sizeof(ZPrep) / 4u)] = ZP_SERIAL; // = prep[i].status (a second view: `prep` itself is read-only here)
+        if (RECS)
+            retry[it.payload] = 1u; // a run of sub-blocks has no serial piece decoder: the whole payload, serially
+    }
 }
 
 } // namespace
@@ -1246,10 +1878,11 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
         return err;
     if ((err = lthip_scratch(ctx, S_Z_WORK, (size_t)(ZD_LIT_MAX + 64u) * nwg, &d_lits)))
         return err;
-    if ((err = lthip_scratch(ctx, S_Z_ENC, sizeof(ZItem) * (size_t)nitems + 16, &d_items)))
+    if ((err = lthip_scratch(ctx, S_Z_ENC, sizeof(ZItem) * (size_t)nitems + 16 + 4 * (size_t)block_count, &d_items)))
         return err;
     uint32_t* d_count = (uint32_t*)((uint8_t*)d_items + sizeof(ZItem) * (size_t)nitems);
-    LTHIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 4, ctx->stream));
+    uint32_t* d_retry = d_count + 4; // per payload: the sub-block decoder gives it back to the serial one
+    LTHIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 16 + 4 * (size_t)block_count, ctx->stream));
     if ((err = lthip_stage_upload(ctx, d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, ctx->stream)))
         return err;
     const uint32_t dbg = (uint32_t)(getenv("LTHIP_ZSTD_DBG") ? atoi(getenv("LTHIP_ZSTD_DBG")) : 0); // 1: never decode by pieces
@@ -1259,42 +1892,60 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
         LTHIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_zd_ablate), &a, sizeof(a)));
     }
     LaunchTimer t(ctx, LTHIP_K_OTHER);
-    hipLaunchKernelGGL(k_zstd_split, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
+    hipLaunchKernelGGL(k_zstd_split, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                        block_count, (ZItem*)d_items, d_count, d_out_sizes, dbg);
     hipLaunchKernelGGL(k_zstd_decode<false>, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                        (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes, (const ZPrep*)nullptr);
     LTHIP_LAUNCH_CHECK(ctx);
-    // pieces: two stages (k_zstd_prepare / k_zstd_execute) in rounds of ZROUND pieces, whose literals and tables live in scratch;
-    // what they leave (ZP_SERIAL) goes to the serial piece decoder.  LTHIP_ZSTD_DBG & 4: the serial piece decoder for everything.
+    // pieces, in rounds of ZROUND whose literals and tables / sequence records live in scratch:
+    //   one block per piece (kind 2):        k_zstd_prepare + k_zstd_execute<false>; what they leave (ZP_SERIAL) goes to the serial piece decoder
+    //   a run of sub-blocks per piece (3):   k_zstd_sub_entropy + k_zstd_execute<true>; what they leave goes, payload-wise, to the serial decoder
+    // LTHIP_ZSTD_DBG & 4: the serial piece decoder for every one-block piece.
     ZPrep* d_prep = nullptr;
-    if (!(dbg & 4u)) // (pieces exist only in marked frames; the kernels look at the item list)
     {
-        constexpr uint32_t ZROUND = 16384u;
+        constexpr uint32_t ZROUND = 8192u;
         const uint32_t per_round = nitems < ZROUND ? (uint32_t)nitems : ZROUND;
-        void *d_plits, *d_tabs, *d_pr;
+        void *d_plits, *d_tabs, *d_pr, *d_recs;
         if ((err = lthip_scratch(ctx, S_Z_LITS, (size_t)(ZD_LIT_MAX + 64u) * per_round + 4096, &d_plits)))
             return err;
         if ((err = lthip_scratch(ctx, S_Z_RECS, (size_t)3u * ZT_ENTRIES * 8u * per_round, &d_tabs)))
             return err;
+        if ((err = lthip_scratch(ctx, S_Z_SUB, (size_t)ZREC_MAX * 8u * per_round, &d_recs)))
+            return err;
         if ((err = lthip_scratch(ctx, S_LZ4_META, sizeof(ZPrep) * (size_t)nitems, &d_pr)))
             return err;
         d_prep = (ZPrep*)d_pr;
+        LTHIP_CHECK(ctx, hipMemsetAsync(d_pr, 0xFF, sizeof(ZPrep) * (size_t)nitems, ctx->stream)); // (status of items nobody prepares: none of the three)
         for (uint64_t i0 = 0; i0 < nitems; i0 += per_round)
         {
             const uint32_t i1 = (uint32_t)(i0 + per_round < nitems ? i0 + per_round : nitems);
             const uint32_t n = i1 - (uint32_t)i0;
-            hipLaunchKernelGGL(k_zstd_prepare, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
-                               (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, (uint8_t*)d_plits,
-                               (uint64_t*)d_tabs, d_prep, (const uint32_t*)d_out_sizes);
+            if (!(dbg & 4u))
+            {
+                hipLaunchKernelGGL(k_zstd_prepare, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
+                                   (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, (uint8_t*)d_plits,
+                                   (uint64_t*)d_tabs, d_prep, (const uint32_t*)d_out_sizes);
+                LTHIP_LAUNCH_CHECK(ctx);
+                hipLaunchKernelGGL(k_zstd_execute<false>, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
+                                   (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, (const uint8_t*)d_plits,
+                                   (const uint64_t*)d_tabs, (const ZPrep*)d_prep, &d_prep->status, d_retry);
+                LTHIP_LAUNCH_CHECK(ctx);
+            }
+            hipLaunchKernelGGL(k_zstd_sub_entropy, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
+                               (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_plits, (uint64_t*)d_recs, d_prep,
+                               (const uint32_t*)d_out_sizes, d_retry);
             LTHIP_LAUNCH_CHECK(ctx);
-            hipLaunchKernelGGL(k_zstd_execute, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
+            hipLaunchKernelGGL(k_zstd_execute<true>, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                                (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, (const uint8_t*)d_plits,
-                               (const uint64_t*)d_tabs, (const ZPrep*)d_prep, &d_prep->status);
+                               (const uint64_t*)d_recs, (const ZPrep*)d_prep, &d_prep->status, d_retry);
             LTHIP_LAUNCH_CHECK(ctx);
         }
     }
     hipLaunchKernelGGL(k_zstd_decode<true>, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
-                       (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes, (const ZPrep*)d_prep);
+                       (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes,
+                       (dbg & 4u) ? (const ZPrep*)nullptr : (const ZPrep*)d_prep);
+    hipLaunchKernelGGL(k_zstd_decode_retry, dim3(block_count < nwg ? block_count : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src,
+                       (const ZBlock*)d_blocks, block_count, (const uint32_t*)d_retry, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes);
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -420,6 +420,84 @@ def test_zstd_piece_decoder_is_the_serial_decoder_on_own_frames_and_strict_on_fa
         assert o is None or (len(o) == len(r) and (o == r).all())
 
 
+def test_zstd_sub_block_decoder_is_the_serial_decoder_and_strict(gpu, oracle, ref, monkeypatch):
+    """Frames in the sub-block layout (one zstd block per 4 KiB unit, directory in the trailer) are decoded with one lane per block
+    (k_zstd_sub_entropy + k_zstd_execute<true>).
+    (1) the encoder's own frames: same bytes as the serial decoder (LTHIP_ZSTD_DBG=1) and the reference;
+    (2) damaged frames -- bit flips anywhere (blocks, headers, directory), truncations with the trailer kept, directory entries
+        swapped: never accepted where the serial decoder rejects, and identical bytes where accepted;
+    (3) a directory that describes the blocks correctly on a frame that does not keep the layout's promises (the reference
+        encoder's frames: repeat offsets, matches across blocks) is given back to the serial decoder: decoded like the reference."""
+    rng = np.random.default_rng(21)
+    monkeypatch.setenv("LTHIP_ZSTD_SUB", "1")
+    datas = [oracle.synth(n, 190 + n, k) for k, n in ((1, 131073), (1, 600000), (11, 400000), (12, 300000), (13, 262144), (0, 500000),
+                                                     (2, 400000), (1, 4097), (12, 100), (1, (8 << 20) + 5))]
+    half = np.concatenate([rng.integers(0, 256, 70000, dtype=np.uint8), oracle.synth(200000, 4, 1), rng.integers(0, 256, 9000, dtype=np.uint8)])
+    datas.append(half)  # raw sub-blocks inside compressed pieces, raw pieces
+    own = gpu_zstd(gpu, datas)
+    for f, d in zip(own, datas):
+        nu = (len(d) + 4095) // 4096
+        assert bytes(f[-(12 + 2 * nu) :][8:12]) == b"LTP\x02"
+    frames, caps = list(own), [len(d) for d in datas]
+    for f, d in zip(own[:7] + own[10:], datas[:7] + datas[10:]):
+        nu = (len(d) + 4095) // 4096
+        tl = 12 + 2 * nu
+        for _ in range(30):
+            x = f.copy()
+            k = rng.integers(0, 5)
+            if k == 0:
+                x = np.concatenate([x[: rng.integers(13, len(x) - tl)], x[-tl:]])  # truncated, trailer kept
+            elif k == 1 and nu >= 2:
+                a, b = rng.integers(0, nu, 2)
+                e = x[-2 * nu :].view("<u2")
+                e[a], e[b] = e[b], e[a]  # directory entries swapped
+            elif k == 2:
+                x[len(x) - 2 * nu + rng.integers(0, 2 * nu)] ^= np.uint8(1 << rng.integers(0, 8))  # a directory bit
+            else:
+                for _ in range(int(rng.integers(1, 4))):
+                    x[rng.integers(0, len(x) - tl)] ^= np.uint8(1 << rng.integers(0, 8))  # bit flips before the trailer
+            frames.append(x)
+            caps.append(len(d))
+    fast = gpu_zstd_decode(gpu, frames, caps)
+    monkeypatch.setenv("LTHIP_ZSTD_DBG", "1")
+    serial = gpu_zstd_decode(gpu, frames, caps)
+    monkeypatch.delenv("LTHIP_ZSTD_DBG")
+    for i, (f, cap, p_out, s_out) in enumerate(zip(frames, caps, fast, serial)):
+        if i < len(own):
+            assert p_out is not None and (p_out == datas[i]).all() and s_out is not None and (s_out == datas[i]).all()
+            err, r_out = ref.decompress(1, f, cap)
+            assert err == 0 and (r_out == datas[i]).all()
+        assert (p_out is None) == (s_out is None), i
+        if p_out is not None:
+            assert len(p_out) == len(s_out) and (p_out == s_out).all(), i
+    assert sum(o is None for o in fast[len(own):]) > 20  # the damage is really detected
+    # (3) a truthful directory over a block of another encoder: the reference's single block of a 4 KiB input (repeat-offset codes,
+    # its own choice of table modes) under this library's frame header, directory = [its size]
+    lying, raws = [], []
+    for d in datas[:7]:
+        d = d[:4096]
+        for w in (0, 2, 3):
+            f = ref.compress(1, ref.dll.refh_zstd_type(w), d)
+            fhd = int(f[4])
+            pos = 5 + (0 if fhd & 0x20 else 1) + (0, 1, 2, 4)[fhd & 3] + ((1, 2, 4, 8)[fhd >> 6] if (fhd >> 6) or (fhd & 0x20) else 0)
+            h = int(f[pos]) | int(f[pos + 1]) << 8 | int(f[pos + 2]) << 16
+            if not (h & 1):
+                continue  # (more than one block: not a layout the directory can describe)
+            n = 1 if (h >> 1) & 3 == 1 else h >> 3
+            typ = (h >> 1) & 3
+            e = np.array([0xFFFF if typ == 0 else 0xFFFE if typ == 1 else n], "<u2")
+            t = bytes([0x5D, 0x2A, 0x4D, 0x18]) + (4 + 2).to_bytes(4, "little") + b"LTP\x02" + e.tobytes()
+            head = bytes([0x28, 0xB5, 0x2F, 0xFD, 0xE0]) + len(d).to_bytes(8, "little")
+            lying.append(np.frombuffer(head + bytes(f[pos : pos + 3 + n]) + t, np.uint8).copy())
+            raws.append(d)
+    assert len(lying) >= 10
+    outs = gpu_zstd_decode(gpu, lying, [len(r) for r in raws])
+    for f, r, o in zip(lying, raws, outs):
+        err, r_out = ref.decompress(1, f, len(r))
+        assert err == 0 and (r_out == r).all()  # the reference skips the trailer and decodes the frame
+        assert o is not None and len(o) == len(r) and (o == r).all()
+
+
 def test_lz4_gpu_decoder_differential_fuzz(gpu, oracle):
     """Damaged payloads: the HIP decoder accepts exactly what the oracle's strict LZ4_decompress_safe restatement accepts
     (lz4.c:2215-2435), with the same size and bytes -- truncations, bit flips, zeroed tails, wrong capacities."""

@@ -27,7 +27,17 @@ def model():
     d.ltz_model_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     d.ltz_model_debug.restype = None
     d.ltz_model_debug.argtypes = [C.c_uint32]
+    d.ltz_model_sub_blocks.restype = None
+    d.ltz_model_sub_blocks.argtypes = [C.c_int]
     return o
+
+
+@pytest.fixture(params=[0, 1], ids=["pieces", "subblocks"], autouse=True)
+def layout(request, model):
+    """both layouts of a 128 KiB piece: one block (zb_encode_block) / one block per 4 KiB unit (zb_encode_piece_sub)"""
+    model.dll.ltz_model_sub_blocks(request.param)
+    yield request.param
+    model.dll.ltz_model_sub_blocks(0)
 
 
 def compress(o, b: np.ndarray) -> np.ndarray:
@@ -88,8 +98,8 @@ def test_every_table_mode(model, flags):
         model.dll.ltz_model_debug(0)
 
 
-def test_encode_block_from_records_maximum_sequence_count(model):
-    """32 units x 1024 sequences of 4 bytes (the 3-byte Number_of_Sequences form, >= 0x7F00)."""
+def test_encode_block_from_records_maximum_sequence_count(model, layout):
+    """32 units x 1024 sequences of 4 bytes (one block: the 3-byte Number_of_Sequences form, >= 0x7F00; sub-blocks: 1024 each)."""
     nunits = 32
     meta = np.zeros((nunits, 4), np.uint32)
     lits = np.zeros((nunits, 4096), np.uint8)
@@ -106,8 +116,14 @@ def test_encode_block_from_records_maximum_sequence_count(model):
     n = model.dll.ltz_model_encode_block(meta.ctypes.data, lits.ctypes.data, recs.ctypes.data, nunits, 131072, out.ctypes.data)
     assert 0 < n < 131072
     raw = np.tile(pat, 32768)
-    frame = np.concatenate([np.frombuffer(bytes([0x28, 0xB5, 0x2F, 0xFD, 0xE0]) + (131072).to_bytes(8, "little"), np.uint8),
-                            np.frombuffer((1 | 2 << 1 | n << 3).to_bytes(3, "little"), np.uint8), out[:n]])
+    head = np.frombuffer(bytes([0x28, 0xB5, 0x2F, 0xFD, 0xE0]) + (131072).to_bytes(8, "little"), np.uint8)
+    if layout:  # the sub-blocks bring their headers; Last_Block goes on the last one
+        model.dll.ltz_model_last_sub.restype = C.POINTER(C.c_uint16)
+        sub = model.dll.ltz_model_last_sub()
+        out[n - 3 - (sub[nunits - 1] & 0x7FFF)] |= 1
+        frame = np.concatenate([head, out[:n]])
+    else:
+        frame = np.concatenate([head, np.frombuffer((1 | 2 << 1 | n << 3).to_bytes(3, "little"), np.uint8), out[:n]])
     err, dec = get_ref().decompress(CODEC_ZSTD, frame, len(raw))
     assert err == 0 and (dec == raw).all()
 
