@@ -39,7 +39,7 @@ __device__ __forceinline__ uint32_t zb_scan_excl(uint32_t v, uint32_t* total)
     return incl - v;
 }
 #ifdef LTHIP_ZB_PROF /* debug build only: cycles per phase of zb_encode_block, summed over all pieces (lane 0) */
-__device__ unsigned long long g_zb_prof[24];
+__device__ unsigned long long g_zb_prof[32];
 __device__ unsigned long long g_zb_last[1 << 16];
 #define ZB_MARK(i)                                                                                     \
     do                                                                                                 \
@@ -466,10 +466,10 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
 #ifdef LTHIP_ZB_PROF
 extern "C" __attribute__((visibility("default"))) int lthip_zb_prof_dump(void)
 {
-    unsigned long long h[24];
+    unsigned long long h[32];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_zb_prof), sizeof(h)) != hipSuccess)
         return -1;
-    for (int i = 0; i < 24; ++i)
+    for (int i = 0; i < 32; ++i)
         if (h[i])
             fprintf(stderr, "zb phase ending at mark %2d: %.3f ms wave-time (100 MHz clock)\n", i, (double)h[i] / 1e5);
     memset(h, 0, sizeof(h));
@@ -916,6 +916,10 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
         if (it.kind != 3u)
             continue;
         __syncthreads();
+#ifdef LTHIP_ZB_PROF
+        if (lane == 0)
+            g_zb_last[blockIdx.x] = wall_clock64();
+#endif
         const ZBlock blk = blocks[it.payload];
         const uint32_t slot = i - item0;
         uint8_t* lits = lit_scratch + (uint64_t)slot * (ZD_LIT_MAX + 64u);
@@ -1033,6 +1037,9 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
                 }
             }
         }
+#ifdef LTHIP_ZB_PROF
+        ZB_MARK(19);
+#endif
         // ---- who brings the tree, who the tables; is everybody else consistent with them? ----
         const uint64_t treem = __builtin_amdgcn_ballot_w64(mine && !raw && lmode == 2u);
         const uint64_t lessm = __builtin_amdgcn_ballot_w64(mine && !raw && lmode == 3u);
@@ -1113,6 +1120,9 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
             bad = bad || sh.v[ZDV_ERR] != 0u;
             tree_bytes = sh.v[ZDV_LEN];
         }
+#ifdef LTHIP_ZB_PROF
+        ZB_MARK(20);
+#endif
         // ---- literals: offsets, the stream list, raw runs ----
         uint32_t nlit_total, nstr_total, nseq_total;
         const uint32_t lo = z_wave_scan_excl(mine ? nlit : 0u, lane, &nlit_total);
@@ -1176,6 +1186,9 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
         if (__builtin_amdgcn_ballot_w64(bad))
             bad = true;
         __syncthreads();
+#ifdef LTHIP_ZB_PROF
+        ZB_MARK(21);
+#endif
         // ---- the tables, packed: one 8-byte read per state ----
         uint32_t log_l = 0, log_o = 0, log_m = 0;
         if (!bad && tab_lane >= 0)
@@ -1226,6 +1239,9 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
         if (__builtin_amdgcn_ballot_w64(bad))
             bad = true;
         __syncthreads();
+#ifdef LTHIP_ZB_PROF
+        ZB_MARK(22);
+#endif
         // ---- sequences: lane u the bit-stream of block u ----
         uint32_t sum_ll = 0, sum_ml = 0;
         if (!bad && mine && nbseq != 0u)
@@ -1293,6 +1309,9 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
             bad = true; // no sequences: all literals
         if (__builtin_amdgcn_ballot_w64(bad))
             bad = true;
+#ifdef LTHIP_ZB_PROF
+        ZB_MARK(23);
+#endif
         // ---- a block's last literals go with the next sequence of the piece ----
         if (!bad)
         {
@@ -1349,8 +1368,10 @@ __global__ __launch_bounds__(64) void k_zstd_decode_retry(const uint8_t* __restr
 }
 
 constexpr uint32_t ZX_RING = 8192u, ZX_FLUSH = 2048u, ZX_LIT = 2048u;
-constexpr uint32_t ZX_LL_LANE = 16u, ZX_ML_LANE = 64u;       // what a sequence's own lane copies
+constexpr uint32_t ZX_ML_LANE = 64u;                         // the longest match a sequence's own lane copies
 constexpr uint32_t ZX_RING_SAFE = ZX_RING - 64u * 80u - 64u; // a run appends at most 64 x (16 + 64) bytes ahead of `op`
+constexpr uint32_t ZX_BATCH_ADV = 64u * 80u, ZX_BATCH_LL = 1100u; // a batch of 64 sequences executed in one pass: at most as much as a run
+constexpr uint32_t ZX_LL_OWN = 32u;                              // ... literal runs up to this by the sequence's own lane
 
 // output of one piece: LDS ring + flush, literal stream through an LDS window (piece-local 32-bit positions)
 struct ZxOut
@@ -1600,6 +1621,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
     }
     uint32_t litpos = 0, produced = 0; // what the decoded sequences consume / produce (scalar bookkeeping of the checks)
+#ifdef LTHIP_ZB_PROF
+    unsigned long long t_prof = wall_clock64();
+#endif
     for (uint32_t s0 = 0; s0 < pr.nbseq && !bad; s0 += 64u)
     {
         const uint32_t cnt = pr.nbseq - s0 < 64u ? pr.nbseq - s0 : 64u;
@@ -1676,8 +1700,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // ---- vector unit: the serial decoder's checks for all of them at once, then execution ----
         const uint32_t ll = (uint32_t)lane < cnt ? r_ll : 0u, ml = (uint32_t)lane < cnt ? r_ml : 0u, off = r_off - 3u;
         uint32_t batch_ll, batch_adv;
+        uint32_t i_l = ll, i_a = ll + ml; // inclusive prefix sums: literals / output up to and including my sequence
         {
-            uint32_t i_l = ll, i_a = ll + ml; // inclusive prefix sums: literals / output up to and including my sequence
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1)
             {
@@ -1699,70 +1723,85 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 break;
             }
         }
-        const bool small = ll <= ZX_LL_LANE && ml <= ZX_ML_LANE && !(ml > 18u && off > ZX_RING_SAFE);
-        const uint64_t smallm = __builtin_amdgcn_ballot_w64(small && (uint32_t)lane < cnt);
-        uint32_t start = 0;
-        static_assert(ZX_RING_SAFE > 2048u, "ring too small for a run");
-        uint32_t lit_cur = litpos; // literal position of sequence `start`
-        litpos += batch_ll;
-        produced += batch_adv;
+#ifdef LTHIP_ZB_PROF
+        unsigned long long t_mark = wall_clock64();
+        if (lane == 0)
+        {
+            atomicAdd(&g_zb_prof[24], t_mark - t_prof); // 24: records + checks
+            atomicAdd(&g_zb_prof[30], (unsigned long long)cnt);
+        }
+        t_prof = t_mark;
+#endif
+        // ---- execution: as many sequences as fit the ring's margins in ONE pass (usually the whole batch): the prefix sums of the
+        // checks place everything; ALL literals first (they depend on nothing), then the matches in dependency rounds -- short ones
+        // by their own lanes, a long one by the whole wave when its turn comes.  A sequence too big for a pass (a raw unit's 4 KiB
+        // of literals) goes through the whole wave alone. ----
+        uint32_t start = 0, base_l = 0, base_a = 0; // literals / output of the batch's sequences before `start`
         while (start < cnt)
         {
-            if (!((smallm >> start) & 1ull))
+            const bool fit = (uint32_t)lane >= start && (uint32_t)lane < cnt && i_a - base_a <= ZX_BATCH_ADV && i_l - base_l <= ZX_BATCH_LL;
+            const uint64_t fm = __builtin_amdgcn_ballot_w64(fit) >> start; // (the sums grow: the bits are a run from bit 0)
+            const uint32_t k = fm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fm);
+            if (k == 0u)
             {
-                // one sequence by the whole wave
                 const uint32_t gl = zx_u((uint32_t)__builtin_amdgcn_readlane(r_ll, (int)start)), gm = zx_u((uint32_t)__builtin_amdgcn_readlane(r_ml, (int)start)),
                                go = zx_u((uint32_t)__builtin_amdgcn_readlane(r_off, (int)start)) - 3u;
-                zx.copy_lits(lit_cur, gl);
-                lit_cur += gl;
+                zx.copy_lits(litpos + base_l, gl);
                 zx.copy_match(go, gm);
+                base_l += gl;
+                base_a += gl + gm;
                 ++start;
+#ifdef LTHIP_ZB_PROF
+                t_mark = wall_clock64();
+                if (lane == 0)
+                    atomicAdd(&g_zb_prof[26], t_mark - t_prof); // 26: sequences by the whole wave
+                t_prof = t_mark;
+#endif
                 continue;
             }
-            // a run of small sequences: lanes [start, start + k)
-            uint64_t runm = smallm >> start;
-            const uint32_t k = runm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~runm);
             const bool in = (uint32_t)lane >= start && (uint32_t)lane < start + k;
-            const uint32_t a_ll = in ? ll : 0u, a_adv = in ? ll + ml : 0u;
-            uint32_t i_ll = a_ll, i_adv = a_adv; // inclusive prefix sums
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1)
+            const uint32_t t_ll = zx_u((uint32_t)__builtin_amdgcn_readlane((int)i_l, (int)(start + k - 1u))) - base_l,
+                           t_adv = zx_u((uint32_t)__builtin_amdgcn_readlane((int)i_a, (int)(start + k - 1u))) - base_a;
+            const uint32_t o_l = zx.op + (i_a - ll - ml - base_a); // where my literals go
+            const uint32_t o_m = o_l + ll;                          // where my match goes
+            const uint32_t li = zx.need_lit(litpos + base_l, t_ll + 1u) + (i_l - ll - base_l);
+            typedef uint32_t u32_a1 __attribute__((aligned(1)));
+            if (in && ll <= ZX_LL_OWN)
             {
-                const uint32_t x = (uint32_t)__shfl_up((int)i_ll, d, 64), y = (uint32_t)__shfl_up((int)i_adv, d, 64);
-                if (lane >= d)
+                uint32_t b = 0;
+                for (; b + 4u <= ll; b += 4u) // four bytes per trip of this lane-divergent loop (unaligned LDS dwords)
                 {
-                    i_ll += x;
-                    i_adv += y;
+                    const uint32_t r = zx.ring(o_l + b);
+                    const uint32_t v = *reinterpret_cast<const u32_a1*>(s_lit + li + b);
+                    if (r <= ZX_RING - 4u)
+                        *reinterpret_cast<u32_a1*>(s_ring + r) = v;
+                    else
+                        for (uint32_t j = 0; j < 4u; ++j)
+                            s_ring[zx.ring(o_l + b + j)] = (uint8_t)(v >> (8u * j));
+                }
+                for (; b < ll; ++b)
+                    s_ring[zx.ring(o_l + b)] = s_lit[li + b];
+            }
+            for (uint64_t big = __builtin_amdgcn_ballot_w64(in && ll > ZX_LL_OWN); big; big &= big - 1ull)
+            {
+                const int u = __builtin_ctzll(big);
+                const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)ll, u), from = (uint32_t)__builtin_amdgcn_readlane((int)li, u),
+                               to = (uint32_t)__builtin_amdgcn_readlane((int)o_l, u);
+                for (uint32_t j = 4u * (uint32_t)lane; j < n; j += 256u)
+                {
+                    const uint32_t r = zx.ring(to + j);
+                    if (j + 4u <= n && r <= ZX_RING - 4u)
+                        *reinterpret_cast<u32_a1*>(s_ring + r) = *reinterpret_cast<const u32_a1*>(s_lit + from + j);
+                    else
+                        for (uint32_t q = 0; q < 4u && j + q < n; ++q)
+                            s_ring[zx.ring(to + j + q)] = s_lit[from + j + q];
                 }
             }
-            const uint32_t t_ll = (uint32_t)__shfl((int)i_ll, 63, 64), t_adv = (uint32_t)__shfl((int)i_adv, 63, 64);
-            const uint32_t o_l = zx.op + i_adv - a_adv; // where my literals go
-            const uint32_t o_m = o_l + ll;              // where my match goes
-            // literals: each sequence's own lane, from the LDS window
-            {
-                const uint32_t li = zx.need_lit(lit_cur, t_ll + 1u) + (i_ll - a_ll);
-                if (in)
-                {
-                    typedef uint32_t u32_a1 __attribute__((aligned(1)));
-                    uint32_t b = 0;
-                    for (; b + 4u <= ll; b += 4u) // four bytes per trip of this lane-divergent loop (unaligned LDS dwords)
-                    {
-                        const uint32_t r = zx.ring(o_l + b);
-                        const uint32_t v = *reinterpret_cast<const u32_a1*>(s_lit + li + b);
-                        if (r <= ZX_RING - 4u)
-                            *reinterpret_cast<u32_a1*>(s_ring + r) = v;
-                        else
-                            for (uint32_t j = 0; j < 4u; ++j)
-                                s_ring[zx.ring(o_l + b + j)] = (uint8_t)(v >> (8u * j));
-                    }
-                    for (; b < ll; ++b)
-                        s_ring[zx.ring(o_l + b)] = s_lit[li + b];
-                }
-            }
-            // matches in dependency rounds: everything before the first pending sequence's match is final
-            // a source the ring may lose while this run appends (it holds the 8 KiB below op + t_adv) was flushed long ago: from
-            // global memory then; only offsets above ZX_RING_SAFE can be that far back, and those come with at most 18 bytes
-            const bool glob = in && o_m - off + ZX_RING < zx.op + t_adv;
+            const uint32_t end = zx.op + t_adv;
+            const bool own = in && ml <= ZX_ML_LANE && !(ml > 20u && off > ZX_RING_SAFE); // my lane copies my match
+            const uint64_t ownm = __builtin_amdgcn_ballot_w64(own);
+            // a source the ring loses while this pass appends (it holds the 8 KiB below `end`) was flushed long ago: from global memory
+            const bool glob = in && ml != 0u && o_m - off + ZX_RING < end;
             if (__builtin_amdgcn_ballot_w64(glob && o_m - off + ml + zx.g > zx.drained))
             {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1770,33 +1809,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 zx.drained = zx.flushed;
             }
             uint64_t pend = __builtin_amdgcn_ballot_w64(in && ml != 0u);
-            // sources that have left the ring (rare): from global memory, first and in a branch of its own (that data is final, and
-            // the 18 addresses are not computed for every run)
-            const uint64_t globm = __builtin_amdgcn_ballot_w64(glob);
+            const uint64_t globm = __builtin_amdgcn_ballot_w64(glob && own);
             if (globm)
             {
-                if (glob)
+                if (glob && own) // at most 20 bytes, final data: five dwords
                 {
-                    uint32_t bytes[18];
+                    uint32_t w[5];
 #pragma unroll
-                    for (uint32_t b = 0; b < 18u; ++b)
-                        bytes[b] = b < ml ? zx.out_al[o_m - off + b + zx.g] : 0u;
+                    for (uint32_t b = 0; b < 5u; ++b)
+                        w[b] = 4u * b < ml ? *reinterpret_cast<const u32_a1*>(zx.out_al + (o_m - off + 4u * b + zx.g)) : 0u;
 #pragma unroll
-                    for (uint32_t b = 0; b < 18u; ++b)
+                    for (uint32_t b = 0; b < 20u; ++b)
                         if (b < ml)
-                            s_ring[zx.ring(o_m + b)] = (uint8_t)bytes[b];
+                            s_ring[zx.ring(o_m + b)] = (uint8_t)(w[b >> 2] >> (8u * (b & 3u)));
                 }
                 pend &= ~globm;
             }
             while (pend)
             {
                 const int first = __builtin_ctzll(pend);
+                if (!((ownm >> first) & 1ull))
+                {
+                    // a long match (or a far source with more than 20 bytes): the whole wave
+                    const uint32_t gm = (uint32_t)__builtin_amdgcn_readlane((int)ml, first), go = (uint32_t)__builtin_amdgcn_readlane((int)off, first),
+                                   gd = (uint32_t)__builtin_amdgcn_readlane((int)o_m, first);
+                    if (go >= 64u)
+                        for (uint32_t j = lane; j < gm; j += 64)
+                        {
+                            // a source byte the ring has lost by the end of this pass was flushed long ago (it lies more than 3 KiB
+                            // below `op`); everything younger -- unflushed bytes, this very match's own output -- is in the ring
+                            const uint32_t sp = gd - go + j;
+                            s_ring[zx.ring(gd + j)] = sp + ZX_RING >= end ? s_ring[zx.ring(sp)] : zx.out_al[sp + zx.g];
+                        }
+                    else
+                        for (uint32_t j0 = 0; j0 < gm; j0 += 64) // byte j = seed byte j mod off
+                        {
+                            const uint32_t j = j0 + (uint32_t)lane;
+                            if (j < gm)
+                                s_ring[zx.ring(gd + j)] = s_ring[zx.ring(gd - go + j % go)];
+                        }
+                    pend &= ~(1ull << first);
+                    continue;
+                }
                 const int32_t rel_m = (int32_t)(o_m - zx.op);
                 const int32_t frontier = (int32_t)__builtin_amdgcn_readlane((uint32_t)rel_m, first);
-                const bool ready = ((pend >> lane) & 1ull) && (lane == first || rel_m - (int32_t)off + (int32_t)ml <= frontier);
+                const bool ready = ((pend >> lane) & 1ull) && own && (lane == first || rel_m - (int32_t)off + (int32_t)ml <= frontier);
                 if (ready)
                 {
-                    typedef uint32_t u32_a1 __attribute__((aligned(1)));
                     const uint32_t so2 = o_m - off;
                     uint32_t b = 0;
                     if (off >= 4u)
@@ -1814,11 +1873,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
                 pend &= ~__builtin_amdgcn_ballot_w64(ready);
             }
-            zx.op += t_adv;
-            lit_cur += t_ll;
+            zx.op = end;
             zx.maybe_flush();
+            base_l += t_ll;
+            base_a += t_adv;
             start += k;
+#ifdef LTHIP_ZB_PROF
+            t_mark = wall_clock64();
+            if (lane == 0)
+            {
+                atomicAdd(&g_zb_prof[25], t_mark - t_prof); // 25: passes
+                atomicAdd(&g_zb_prof[29], 1ull);
+                atomicAdd(&g_zb_prof[28], (unsigned long long)__builtin_popcountll(globm));
+            }
+            t_prof = t_mark;
+#endif
         }
+        litpos += batch_ll;
+        produced += batch_adv;
     }
     if (!bad)
     {
