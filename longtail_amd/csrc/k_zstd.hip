@@ -896,6 +896,56 @@ __device__ __forceinline__ uint32_t zs_bits(const uint8_t* base, uint32_t bitpos
     return (uint32_t)(w >> (bitpos + 64u - 8u * b1)) & (uint32_t)((1ull << n) - 1ull);
 }
 
+// A lane's backward bit reader with the stream ahead of it in registers: 128 bits [top - 128, top) plus the 64 below them already
+// on their way, so that no load sits on the chain state -> bits -> next state (one 8-byte load per 64 bits consumed, issued a
+// window ahead).  Loads may reach up to 24 bytes below the stream: `reach` = how many bytes below it are readable (what lies
+// there is never used).
+struct ZsWin
+{
+    const uint8_t* base;
+    uint64_t hi, lo, nx;
+    int32_t top;   // bit index (relative to base) one past the window
+    int32_t reach; // lowest readable byte offset relative to base (<= 0)
+    __device__ __forceinline__ uint64_t load(int32_t byte_off) const
+    {
+        uint64_t w;
+        const int32_t o = byte_off < reach ? reach : byte_off;
+        __builtin_memcpy(&w, base + o, 8);
+        return w;
+    }
+    __device__ __forceinline__ void open(const uint8_t* b, uint32_t size, uint32_t below)
+    {
+        base = b;
+        reach = -(int32_t)below;
+        top = (int32_t)(8u * size);
+        hi = load((int32_t)size - 8);
+        lo = load((int32_t)size - 16);
+        nx = load((int32_t)size - 24);
+    }
+    // make bits [pos - need, pos) part of the window (need <= 64; pos <= top)
+    __device__ __forceinline__ void ensure(uint32_t pos, uint32_t need)
+    {
+        if ((int32_t)pos - (int32_t)need < top - 128)
+        {
+            hi = lo;
+            lo = nx;
+            top -= 64;
+            nx = load((top >> 3) - 24);
+        }
+    }
+    __device__ __forceinline__ uint64_t get64(uint32_t bitpos) const // bits [bitpos, bitpos + 64), inside the window
+    {
+        const uint32_t s = (uint32_t)((int32_t)bitpos - (top - 128)); // 0 .. 64
+        return s >= 64u ? hi : (s ? (lo >> s) | (hi << (64u - s)) : lo);
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t bitpos, uint32_t n) const // bits [bitpos, bitpos + n), n <= 32, inside the window
+    {
+        const uint32_t s = (uint32_t)((int32_t)bitpos - (top - 128)); // 0 .. 127
+        const uint64_t v = s >= 64u ? hi >> (s - 64u) : (s ? (lo >> s) | (hi << (64u - s)) : lo);
+        return (uint32_t)v & (uint32_t)((1ull << n) - 1ull);
+    }
+};
+
 __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, const ZItem* __restrict__ items,
                                                          const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
                                                          uint8_t* __restrict__ lit_scratch, uint64_t* __restrict__ rec_scratch,
@@ -1172,14 +1222,102 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
                 const uint32_t from = (uint32_t)__builtin_amdgcn_readlane((int)(off + 3u + lhdr), u);
                 const uint32_t to = (uint32_t)__builtin_amdgcn_readlane((int)lo, u);
                 const uint32_t rle = (uint32_t)__builtin_amdgcn_readlane((int)((!raw && lmode == 1u) ? 1u : 0u), u);
-                for (uint32_t k = lane; k < n; k += 64)
-                    lits[to + k] = p[from + (rle ? 0u : k)];
+                if (rle)
+                    for (uint32_t k = lane; k < n; k += 64)
+                        lits[to + k] = p[from];
+                else
+                {
+                    typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+                    const uint32_t nv = n >> 4; // 16 bytes per lane and trip, any alignment on both sides
+                    for (uint32_t k = lane; k < nv; k += 64)
+                        *reinterpret_cast<u32x4_a1*>(lits + to + 16u * k) = *reinterpret_cast<const u32x4_a1*>(p + from + 16u * k);
+                    for (uint32_t k = 16u * nv + (uint32_t)lane; k < n; k += 64)
+                        lits[to + k] = p[from + k];
+                }
             }
-            // Huffman streams: one per lane
-            for (uint32_t k = lane; k < nstr_total; k += 64)
+            // Huffman streams: TWO per lane, interleaved (a stream is a chain of dependent table reads: two chains hide half of
+            // the latency), each with its next 128 bits in registers (ZsWin: no load on the chain).  Four symbols per step while a
+            // stream has 64 bits and four symbols left; the core's careful loop finishes it and gives the verdict.
+            const uint32_t tl = sh.huf_log;
+            for (uint32_t k0 = 0; k0 < nstr_total; k0 += 128u)
             {
-                const uint4 st = s_streams[k];
-                if (st.w == 0u || zd_huf_stream(&sh, p + st.x, st.y, lits + st.z, st.w))
+                const uint32_t ka = k0 + (uint32_t)lane, kb = ka + 64u;
+                const bool has_a = ka < nstr_total, has_b = kb < nstr_total;
+                const uint4 sa = has_a ? s_streams[ka] : make_uint4(0, 0, 0, 0), sb2 = has_b ? s_streams[kb] : make_uint4(0, 0, 0, 0);
+                uint32_t pa = 0, pb = 0, ia = 0, ib = 0;
+                ZsWin wa, wb;
+                bool go_a = false, go_b = false;
+                if (has_a)
+                {
+                    const uint32_t last = sa.y ? p[sa.x + sa.y - 1u] : 0u;
+                    if (sa.w == 0u || last == 0u)
+                        bad = true;
+                    else
+                    {
+                        pa = (sa.y - 1u) * 8u + (31u - (uint32_t)__builtin_clz(last));
+                        wa.open(p + sa.x, sa.y, (uint32_t)(it.src_off + sa.x > 64u ? 64u : it.src_off + sa.x));
+                        go_a = true;
+                    }
+                }
+                if (has_b)
+                {
+                    const uint32_t last = sb2.y ? p[sb2.x + sb2.y - 1u] : 0u;
+                    if (sb2.w == 0u || last == 0u)
+                        bad = true;
+                    else
+                    {
+                        pb = (sb2.y - 1u) * 8u + (31u - (uint32_t)__builtin_clz(last));
+                        wb.open(p + sb2.x, sb2.y, (uint32_t)(it.src_off + sb2.x > 64u ? 64u : it.src_off + sb2.x));
+                        go_b = true;
+                    }
+                }
+                uint8_t* const oa = lits + sa.z;
+                uint8_t* const ob2 = lits + sb2.z;
+                for (;;)
+                {
+                    const bool fa = go_a && sa.w - ia >= 4u && pa >= 64u, fb = go_b && sb2.w - ib >= 4u && pb >= 64u;
+                    if (!__builtin_amdgcn_ballot_w64(fa || fb))
+                        break;
+                    uint64_t ta = 0, tb2 = 0;
+                    if (fa)
+                    {
+                        wa.ensure(pa, 64u);
+                        ta = wa.get64(pa - 64u);
+                    }
+                    if (fb)
+                    {
+                        wb.ensure(pb, 64u);
+                        tb2 = wb.get64(pb - 64u);
+                    }
+                    uint32_t ua = 0, ub = 0, qa = 0, qb = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j)
+                    {
+                        const uint32_t ea = sh.huf[(uint32_t)(ta >> (64u - tl))], eb = sh.huf[(uint32_t)(tb2 >> (64u - tl))];
+                        const uint32_t na = ea >> 8, nb2 = eb >> 8;
+                        ta <<= na;
+                        tb2 <<= nb2;
+                        ua += na;
+                        ub += nb2;
+                        qa |= (ea & 255u) << (8u * j);
+                        qb |= (eb & 255u) << (8u * j);
+                    }
+                    if (fa)
+                    {
+                        __builtin_memcpy(oa + ia, &qa, 4);
+                        pa -= ua;
+                        ia += 4u;
+                    }
+                    if (fb)
+                    {
+                        __builtin_memcpy(ob2 + ib, &qb, 4);
+                        pb -= ub;
+                        ib += 4u;
+                    }
+                }
+                if (go_a && zd_huf_stream_from(&sh, p + sa.x, sa.y, oa, sa.w, pa, ia))
+                    bad = true;
+                if (go_b && zd_huf_stream_from(&sh, p + sb2.x, sb2.y, ob2, sb2.w, pb, ib))
                     bad = true;
             }
         }
@@ -1255,16 +1393,18 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
                 const uint8_t* bs = p + at;
                 uint32_t pos = (end - at - 1u) * 8u + (31u - (uint32_t)__builtin_clz((uint32_t)p[end - 1u]));
                 uint32_t sl = 0, so = 0, sm = 0;
+                ZsWin w;
+                w.open(bs, end - at, (uint32_t)(it.src_off + at > 64u ? 64u : it.src_off + at));
                 if (log_l + log_o + log_m > pos)
                     bad = true;
                 else
                 {
                     pos -= log_l;
-                    sl = zs_bits(bs, pos, log_l);
+                    sl = w.get(pos, log_l);
                     pos -= log_o;
-                    so = zs_bits(bs, pos, log_o);
+                    so = w.get(pos, log_o);
                     pos -= log_m;
-                    sm = zs_bits(bs, pos, log_m);
+                    sm = w.get(pos, log_m);
                 }
                 for (uint32_t k = 0; k < nbseq && !bad; ++k)
                 {
@@ -1278,16 +1418,18 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
                         bad = true;
                         break;
                     }
+                    w.ensure(pos, 64u); // offset + lengths: at most 31 + 32 bits
                     pos -= ob;
-                    const uint32_t ov = (uint32_t)(eo >> 32) + zs_bits(bs, pos, ob);
+                    const uint32_t ov = (uint32_t)(eo >> 32) + w.get(pos, ob);
                     pos -= mb + lb;
-                    const uint32_t t2 = zs_bits(bs, pos, mb + lb); // match-length and literal-length extra bits are adjacent
+                    const uint32_t t2 = w.get(pos, mb + lb); // match-length and literal-length extra bits are adjacent
                     const uint32_t ml = (uint32_t)(em >> 32) + (t2 >> lb);
                     const uint32_t ll = (uint32_t)(el >> 32) + (t2 & ((1u << lb) - 1u));
                     if (more)
                     {
+                        w.ensure(pos, 32u); // the three state fields: at most 26 bits
                         pos -= nbl + nbm + nbo;
-                        const uint32_t t3 = zs_bits(bs, pos, nbl + nbm + nbo); // LL, ML, OF from the top
+                        const uint32_t t3 = w.get(pos, nbl + nbm + nbo); // LL, ML, OF from the top
                         sl = (l0 & 0xFFFFu) + (t3 >> (nbm + nbo));
                         sm = (m0 & 0xFFFFu) + ((t3 >> nbo) & ((1u << nbm) - 1u));
                         so = (o0 & 0xFFFFu) + (t3 & ((1u << nbo) - 1u));

@@ -526,14 +526,16 @@ ZB_FN uint32_t zd_read_huf_tree(ZdShared* sh, const uint8_t* p, uint32_t size)
     return used;
 }
 
-/* one Huffman stream of `count` symbols into out[] (serial) */
-ZB_FN int zd_huf_stream(const ZdShared* sh, const uint8_t* p, uint32_t size, uint8_t* out, uint32_t count)
+/* one Huffman stream of `count` symbols into out[] (serial); zd_huf_stream_from: the first i0 symbols are there already and pos0
+ * bits of the stream are left (a caller that decodes the bulk its own way: k_zstd_sub_entropy, two streams per lane) */
+ZB_FN int zd_huf_stream_from(const ZdShared* sh, const uint8_t* p, uint32_t size, uint8_t* out, uint32_t count, uint32_t pos0, uint32_t i0)
 {
     ZdBack br;
     const uint32_t tl = sh->huf_log;
-    uint32_t i = 0;
-    if (zd_back_open(&br, p, size))
+    uint32_t i = i0;
+    if (zd_back_open(&br, p, size) || pos0 > br.pos)
         return 1;
+    br.pos = pos0;
     /* Four symbols per refill while at least 64 bits are left (4 x huf_log <= 44 of the >= 57 bits of one 8-byte load, so no
      * symbol of a group can run out of bits and nothing has to be checked inside it); the careful loop below finishes the
      * stream and reports every malformation exactly as before. */
@@ -574,6 +576,12 @@ ZB_FN int zd_huf_stream(const ZdShared* sh, const uint8_t* p, uint32_t size, uin
         }
     }
     return br.pos != 0u; /* the stream must be consumed exactly */
+}
+ZB_FN int zd_huf_stream(const ZdShared* sh, const uint8_t* p, uint32_t size, uint8_t* out, uint32_t count)
+{
+    if (size == 0u || p[size - 1u] == 0u)
+        return 1;
+    return zd_huf_stream_from(sh, p, size, out, count, (size - 1u) * 8u + zb_highbit(p[size - 1u]), 0);
 }
 
 /* ---- sequences ---- */
