@@ -950,7 +950,7 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
                                                          const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
                                                          uint8_t* __restrict__ lit_scratch, uint64_t* __restrict__ rec_scratch,
                                                          ZPrep* __restrict__ prep, const uint32_t* __restrict__ out_sizes,
-                                                         uint32_t* __restrict__ retry)
+                                                         uint32_t* __restrict__ retry, uint32_t* __restrict__ ticket)
 {
     __shared__ ZdShared sh;
     __shared__ uint4 s_streams[4 * ZB_MAX_UNITS]; // {source offset inside the piece, bytes, literal offset, symbols}
@@ -960,8 +960,16 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
     uint64_t* const pk_ml = pk_ll + 512;                         // over the Huffman table (done with by then) ...
     uint64_t* const pk_of = reinterpret_cast<uint64_t*>(&sh.wtab); // ... and the weights' table
     static_assert(sizeof(sh.huf) >= 2 * 512 * 8 && sizeof(sh.wtab) >= 256 * 8, "room for the packed tables");
-    for (uint32_t i = item0 + blockIdx.x; i < nitems; i += gridDim.x)
+    for (;;)
     {
+        // Pieces cost very different amounts (raw units next to units full of sequences): the persistent waves draw them from a
+        // counter.  (Every lane takes part in the draw -- lane 0 adds one, the others zero -- see k_lz4_pd_units for why.)
+        __builtin_amdgcn_wave_barrier();
+        uint32_t t = atomicAdd(ticket, lane == 0 ? 1u : 0u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        const uint32_t i = item0 + t;
+        if (i >= nitems)
+            break;
         const ZItem it = items[i];
         if (it.kind != 3u)
             continue;
@@ -2092,11 +2100,14 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
         return err;
     if ((err = lthip_scratch(ctx, S_Z_WORK, (size_t)(ZD_LIT_MAX + 64u) * nwg, &d_lits)))
         return err;
-    if ((err = lthip_scratch(ctx, S_Z_ENC, sizeof(ZItem) * (size_t)nitems + 16 + 4 * (size_t)block_count, &d_items)))
+    if ((err = lthip_scratch(ctx, S_Z_ENC, sizeof(ZItem) * (size_t)nitems + 16 + 4 * (size_t)block_count + 4 * (size_t)(nitems / 8192u + 2u), &d_items)))
         return err;
     uint32_t* d_count = (uint32_t*)((uint8_t*)d_items + sizeof(ZItem) * (size_t)nitems);
     uint32_t* d_retry = d_count + 4; // per payload: the sub-block decoder gives it back to the serial one
-    LTHIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 16 + 4 * (size_t)block_count, ctx->stream));
+    constexpr uint32_t ZROUND = 8192u;
+    const size_t nrounds = (size_t)((nitems + ZROUND - 1) / ZROUND);
+    uint32_t* d_tickets = d_retry + block_count; // one work counter per round
+    LTHIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 16 + 4 * ((size_t)block_count + nrounds), ctx->stream));
     if ((err = lthip_stage_upload(ctx, d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, ctx->stream)))
         return err;
     const uint32_t dbg = (uint32_t)(getenv("LTHIP_ZSTD_DBG") ? atoi(getenv("LTHIP_ZSTD_DBG")) : 0); // 1: never decode by pieces
@@ -2117,7 +2128,6 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     // LTHIP_ZSTD_DBG & 4: the serial piece decoder for every one-block piece.
     ZPrep* d_prep = nullptr;
     {
-        constexpr uint32_t ZROUND = 8192u;
         const uint32_t per_round = nitems < ZROUND ? (uint32_t)nitems : ZROUND;
         void *d_plits, *d_tabs, *d_pr, *d_recs;
         if ((err = lthip_scratch(ctx, S_Z_LITS, (size_t)(ZD_LIT_MAX + 64u) * per_round + 4096, &d_plits)))
@@ -2147,7 +2157,7 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
             }
             hipLaunchKernelGGL(k_zstd_sub_entropy, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                                (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_plits, (uint64_t*)d_recs, d_prep,
-                               (const uint32_t*)d_out_sizes, d_retry);
+                               (const uint32_t*)d_out_sizes, d_retry, d_tickets + (size_t)(i0 / per_round));
             LTHIP_LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(k_zstd_execute<true>, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                                (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, (const uint8_t*)d_plits,
