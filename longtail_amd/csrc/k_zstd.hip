@@ -795,7 +795,7 @@ __global__ __launch_bounds__(64) void k_zstd_prepare(const uint8_t* __restrict__
     for (uint32_t i = item0 + blockIdx.x; i < nitems; i += gridDim.x)
     {
         const ZItem it = items[i];
-        if (it.kind != 2u)
+        if (it.kind != 2u || it.aux != 0u) // (aux != 0: one Raw / RLE block of a directory frame -- k_zstd_plain_pieces)
             continue;
         const ZBlock blk = blocks[it.payload];
         const uint32_t slot = i - item0;
@@ -1495,6 +1495,45 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
     }
 }
 
+// Pieces of directory frames that are ONE Raw_Block or RLE_Block (kind 2 with aux != 0: k_zstd_split has checked the header against
+// the directory): a copy / a fill, 256 threads per piece -- no reason to send them through the decoder core.
+__global__ __launch_bounds__(256) void k_zstd_plain_pieces(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, const ZItem* __restrict__ items,
+                                                           const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
+                                                           uint8_t* __restrict__ dst, ZPrep* __restrict__ prep)
+{
+    const uint32_t i = item0 + blockIdx.x;
+    if (i >= item1 || i >= *item_count)
+        return;
+    const ZItem it = items[i];
+    if (it.kind != 2u || it.aux == 0u)
+        return;
+    const ZBlock blk = blocks[it.payload];
+    const uint8_t* p = src + it.src_off;
+    const uint32_t bh = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    const uint32_t len = bh >> 3;
+    uint8_t* out = dst + blk.dst_off + it.out0;
+    if ((uint64_t)it.out0 + len > (uint64_t)blk.dst_cap)
+        return; // (cannot happen: the content size fits the capacity; the piece then stays for the serial piece decoder)
+    if (((bh >> 1) & 3u) == 1u)
+    {
+        const uint8_t b = p[3];
+        for (uint32_t k = threadIdx.x; k < len; k += 256)
+            out[k] = b;
+    }
+    else
+        wg_copy16(out, p + 3, len, threadIdx.x);
+    if (threadIdx.x == 0)
+    {
+        ZPrep pr;
+        pr.bits_off = 0;
+        pr.bits_size = pr.nbseq = pr.nlit = 0;
+        pr.log[0] = pr.log[1] = pr.log[2] = 0;
+        pr.expect = len;
+        pr.status = ZP_DONE;
+        prep[i] = pr;
+    }
+}
+
 // payloads the sub-block decoder gave back: the whole payload, serially (the plain decoder's verdict and bytes)
 __global__ __launch_bounds__(64) void k_zstd_decode_retry(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t nblocks,
                                                           const uint32_t* __restrict__ retry, uint8_t* __restrict__ dst,
@@ -2144,6 +2183,9 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
         {
             const uint32_t i1 = (uint32_t)(i0 + per_round < nitems ? i0 + per_round : nitems);
             const uint32_t n = i1 - (uint32_t)i0;
+            hipLaunchKernelGGL(k_zstd_plain_pieces, dim3(n), dim3(256), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
+                               (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, d_prep);
+            LTHIP_LAUNCH_CHECK(ctx);
             if (!(dbg & 4u))
             {
                 hipLaunchKernelGGL(k_zstd_prepare, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
