@@ -954,6 +954,8 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
 {
     __shared__ ZdShared sh;
     __shared__ uint4 s_streams[4 * ZB_MAX_UNITS]; // {source offset inside the piece, bytes, literal offset, symbols}
+    __shared__ __attribute__((aligned(16))) uint8_t s_desc[512 + 256]; // the table descriptions and the tree description, staged: lane 0 parses
+                                                                      // them bit by bit, and a byte from global memory costs it a round trip
     const uint32_t nitems = *item_count < item1 ? *item_count : item1;
     const int lane = threadIdx.x;
     uint64_t* const pk_ll = reinterpret_cast<uint64_t*>(sh.huf); // packed tables {base:16 | state bits:8 | extra bits:8 | baseline:32},
@@ -1132,22 +1134,28 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
             const uint32_t t_size = tree_lane >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)lcs, tree_lane) : 0u;
             const uint32_t d_off = tab_lane >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)(off + 3u + lhdr + lcs + shdr), tab_lane) : 0u;
             const uint32_t d_end = tab_lane >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)(off + 3u + csz), tab_lane) : 0u;
+            const uint32_t d_staged = d_end - d_off < 512u ? d_end - d_off : 512u, t_staged = t_size < 256u ? t_size : 256u;
+            for (uint32_t k = lane; k < d_staged; k += 64)
+                s_desc[k] = p[d_off + k];
+            for (uint32_t k = lane; k < t_staged; k += 64)
+                s_desc[512u + k] = p[t_off + k];
+            __syncthreads();
             if (lane == 0)
             {
                 sh.v[ZDV_LEN] = 0;
                 sh.v[ZDV_LL] = 0;
                 if (tab_lane >= 0)
                 {
-                    uint32_t q = d_off;
+                    uint32_t q = 0; // (a description that ran past the staged bytes fails the readers' bounds checks: the serial decoder then)
                     for (int t = 0; t < 3 && !sh.v[ZDV_ERR]; ++t) // LL, OF, ML
                     {
                         uint32_t used = 0;
-                        if (zd_set_table(&sh, t, (modes0 >> (6 - 2 * t)) & 3u, p + q, d_end - q, &used))
+                        if (zd_set_table(&sh, t, (modes0 >> (6 - 2 * t)) & 3u, s_desc + q, d_staged - q, &used))
                             sh.v[ZDV_ERR] = 1;
                         q += used;
                     }
-                    sh.v[ZDV_LL] = q - d_off;
-                    if (q >= d_end)
+                    sh.v[ZDV_LL] = q;
+                    if (d_off + q >= d_end)
                         sh.v[ZDV_ERR] = 1;
                 }
             }
@@ -1168,7 +1176,7 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
             __syncthreads();
             if (lane == 0 && !bad && tree_lane >= 0)
             {
-                const uint32_t tr = zd_read_huf_tree(&sh, p + t_off, t_size);
+                const uint32_t tr = zd_read_huf_tree(&sh, s_desc + 512, t_staged);
                 if (tr == ZD_ERROR)
                     sh.v[ZDV_ERR] = 1;
                 else
