@@ -211,7 +211,10 @@ LTHIP_EXPORT int lthip_gather_ranges(lthip_ctx* ctx, const void* d_src, uint64_t
 
 /* ZStd (ZStdCompressionAPI_Compress, lib/zstd/longtail_zstd.c:105-142): one zstd frame per block, 128 KiB pieces
  * stored as RLE / Compressed (LZ sequences + Huffman literals + FSE) / Raw blocks; decodable by the reference's
- * ZSTD_decompressDCtx.  Same calling convention as lthip_lz4_compress_blocks. */
+ * ZSTD_decompressDCtx.  A compressed piece is a run of small zstd blocks (one per 4 KiB of content, one set of entropy
+ * tables per piece) and the frame ends with a skippable frame holding the directory of block sizes, which lets
+ * lthip_zstd_decompress_blocks decode every block on a lane of its own (LTHIP_ZSTD_SUB=0: one block per
+ * piece).  Same calling convention as lthip_lz4_compress_blocks. */
 LTHIP_EXPORT size_t lthip_zstd_bound(size_t size); /* ZSTD_COMPRESSBOUND, lib/zstd/ext/zstd.h:232 */
 LTHIP_EXPORT int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count,
                                             const uint64_t* src_offsets, const uint32_t* src_sizes, void* d_dst,

@@ -2,10 +2,16 @@
 // (RFC 8878 §3.1.1: magic 0xFD2FB528 | FHD 0xE0 = single segment, 8-byte content size, no checksum, no dictionary |
 // u64 content size | blocks, each with a 3-byte header {last:1, type:2, size:21}) whose 128 KiB pieces are
 //   RLE_Block         all bytes equal (per-unit flags from the match finder, checked in k_zstd_encode)
-//   Compressed_Block  LZ sequences from the LZ4 match finder run with sequence output (k_lz4.hip, FMT 1), literals
-//                     Huffman-coded in 4 streams, the three symbol streams FSE-coded (predefined / RLE / described
-//                     tables) -- zstd_block_core.h, one wavefront per piece (k_zstd_encode)
+//   Compressed        LZ sequences from the LZ4 match finder run with sequence output (k_lz4.hip, FMT 1), literals
+//                     Huffman-coded, the three symbol streams FSE-coded (predefined / RLE / described tables) --
+//                     zstd_block_core.h, one wavefront per piece (k_zstd_encode).  By default a RUN OF SUB-BLOCKS, one
+//                     Compressed_Block per 4 KiB match-finder unit sharing the piece's entropy tables (first block: tree and
+//                     table descriptions, the others Treeless / Repeat_Mode; zb_encode_piece_sub), so that encoder and
+//                     decoder have 32 sequence streams and up to 128 literal streams per piece, one per lane, instead of
+//                     1 and 4; LTHIP_ZSTD_SUB=0: one Compressed_Block per piece (zb_encode_block)
 //   Raw_Block         whenever that would not be smaller.
+// A skippable frame at the end carries the directory of block sizes (sub-block layout) or just says that the pieces are
+// independent of each other (one block per piece): see z_write_trailer / z_write_trailer2_head.
 // The reference's ZSTD_decompressDCtx (lib/zstd/longtail_zstd.c:144-177) decodes these like any other frame; the
 // settings ('ztd1'..'ztd5', longtail_zstd.c:12-22) select nothing here: there is one parse.
 #include "lthip_internal.h"
@@ -450,7 +456,7 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
     LaunchTimer t(ctx, LTHIP_K_OTHER);
     hipLaunchKernelGGL(k_zstd_scan, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
                        block_count, (const uint8_t*)d_rle, (const uint32_t*)d_encsz, (uint32_t*)d_zdst, d_out_sizes, (uint8_t*)d_dst,
-                       (uint32_t)(getenv("LTHIP_ZSTD_DBG") ? atoi(getenv("LTHIP_ZSTD_DBG")) : 0), // bit 1: no independence marker
+                       (uint32_t)(getenv("LTHIP_ZSTD_DBG") ? atoi(getenv("LTHIP_ZSTD_DBG")) : 0), // bit 1: no trailer
                        sub ? 1u : 0u, (uint32_t*)d_trail);
     hipLaunchKernelGGL(k_zstd_headers, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
                        block_count, (const uint32_t*)d_out_sizes, (uint8_t*)d_dst);
@@ -480,10 +486,11 @@ extern "C" __attribute__((visibility("default"))) int lthip_zb_prof_dump(void)
 
 // ---------------------------------------------------------------------------------------------------
 // decoder (zstd_decode_core.h): one wavefront per WORK ITEM, persistent over the items.  A payload is one item -- decoded serially,
-// frame by frame, block by block -- unless it is a frame of this library's own encoder that carries the independence marker
-// (z_write_trailer): then every 128 KiB piece is an item of its own (k_zstd_split lists them), and a stored block of 8 MiB is
-// decoded by 64 waves instead of one.  Anything about a marked payload that is not exactly what the encoder writes (header form,
-// block count, sizes) sends it down the serial path, which accepts and rejects what it always did.
+// frame by frame, block by block -- unless it is a frame of this library's own encoder that says so in its trailer: then every
+// 128 KiB piece is an item of its own (k_zstd_split lists them), and a stored block of 8 MiB is decoded by 64 waves instead of
+// one -- with the directory (sub-block layout) every lane of such a wave has a block of its own (k_zstd_sub_entropy, further
+// down).  Anything about such a payload that is not exactly what the encoder writes (header form, block count, sizes) sends it
+// down the serial path, which accepts and rejects what it always did.
 // ---------------------------------------------------------------------------------------------------
 namespace
 {
