@@ -64,4 +64,61 @@ for rnd in range(12):
             else:
                 assert int(ds[i]) == n and (bh[b_offs[i]: b_offs[i] + n] == out[:n]).all(), ("lz4 sliding window", i, int(ds[i]), n)
         tot += len(comps)
+    # the zstd decoders on damaged frames of this encoder (sub-block layout with its directory, and one block per piece): the
+    # lane-parallel decoders must give the serial decoder's verdict and bytes (LTHIP_ZSTD_DBG=1: one wave per payload)
+    import os
+    for sub in ("1", "0"):
+        os.environ["LTHIP_ZSTD_SUB"] = sub
+        src = [b for b in blocks if len(b) >= 3000][:60]
+        if not src:
+            continue
+        sdev, soffs = to_device(src)
+        ssz = [len(b) for b in src]
+        caps = [n + (n >> 8) + 64 for n in ssz]
+        d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
+        dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+        cs = u32(ctx.zstd_compress_blocks(sdev, soffs, ssz, dst, d_offs, caps)).astype(np.int64)
+        host = dst.cpu().numpy()
+        frames, fcaps = [], []
+        for i, b in enumerate(src):
+            f = host[d_offs[i]: d_offs[i] + int(cs[i])].copy()
+            nu = (len(b) + 4095) // 4096
+            tl = 12 + 2 * nu if sub == "1" else 12
+            for _ in range(6):
+                x = f.copy()
+                kind = int(rng.integers(0, 6))
+                if kind == 0 and len(x) > tl + 20:
+                    x = np.concatenate([x[: int(rng.integers(13, len(x) - tl))], x[-tl:]])
+                elif kind == 1:
+                    x = x[: int(rng.integers(1, len(x)))]
+                elif kind == 2 and sub == "1":
+                    x[len(x) - 2 * nu + int(rng.integers(0, 2 * nu))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+                elif kind == 3:
+                    a = int(rng.integers(0, len(x))); x[a: a + int(rng.integers(1, 64))] = int(rng.integers(0, 256))
+                else:
+                    for _ in range(int(rng.integers(1, 5))):
+                        x[int(rng.integers(0, len(x)))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+                frames.append(x)
+                fcaps.append(len(b) if rng.integers(0, 8) else max(1, len(b) + int(rng.integers(-5000, 5000))))
+        fdev, foffs = to_device(frames)
+        b_offs, btot = layout([np.zeros(c, np.uint8) for c in fcaps])
+        outs = []
+        for dbg in (None, "1"):
+            if dbg:
+                os.environ["LTHIP_ZSTD_DBG"] = dbg
+            back = torch.zeros(btot + 64, dtype=torch.uint8, device="cuda")
+            ds = u32(ctx.zstd_decompress_blocks(fdev, foffs, [len(f) for f in frames], back, b_offs, fcaps))
+            outs.append((ds.copy(), back.cpu().numpy()))
+            os.environ.pop("LTHIP_ZSTD_DBG", None)
+        (fs, fb), (ss, sb) = outs
+        for i in range(len(frames)):
+            # sub-block frames the lane-parallel decoder declines go to the serial one: same verdict.  One-block pieces are decoded
+            # strictly (a damaged offset that reaches into the piece before is an error there): it may reject more, never accept more
+            if sub == "1" or int(fs[i]) != 0xFFFFFFFF:
+                assert int(fs[i]) == int(ss[i]), ("zstd verdict", sub, i, int(fs[i]), int(ss[i]))
+            if int(fs[i]) != 0xFFFFFFFF:
+                n = int(fs[i])
+                assert (fb[b_offs[i]: b_offs[i] + n] == sb[b_offs[i]: b_offs[i] + n]).all(), ("zstd bytes", sub, i)
+        tot += len(frames)
+    os.environ.pop("LTHIP_ZSTD_SUB", None)
 print("ok", tot, "payloads")
