@@ -940,10 +940,15 @@ struct ZsWin
             nx = load((top >> 3) - 24);
         }
     }
-    __device__ __forceinline__ uint64_t get64(uint32_t bitpos) const // bits [bitpos, bitpos + 64), inside the window
+    __device__ __forceinline__ uint64_t get64(uint32_t bitpos) const // bits [bitpos, bitpos + 64) (zeros above the window's top)
     {
-        const uint32_t s = (uint32_t)((int32_t)bitpos - (top - 128)); // 0 .. 64
-        return s >= 64u ? hi : (s ? (lo >> s) | (hi << (64u - s)) : lo);
+        const uint32_t s = (uint32_t)((int32_t)bitpos - (top - 128)); // 0 .. 127
+        return s >= 64u ? hi >> (s - 64u) : (s ? (lo >> s) | (hi << (64u - s)) : lo);
+    }
+    // the 64 bits below `pos`, the next bit to read on top (fewer than 64 bits left: zeros below them)
+    __device__ __forceinline__ uint64_t below(uint32_t pos) const
+    {
+        return pos >= 64u ? get64(pos - 64u) : (pos ? get64(0u) << (64u - pos) : 0ull);
     }
     __device__ __forceinline__ uint32_t get(uint32_t bitpos, uint32_t n) const // bits [bitpos, bitpos + n), n <= 32, inside the window
     {
@@ -1405,72 +1410,95 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
 #endif
         // ---- sequences: lane u the bit-stream of block u ----
         uint32_t sum_ll = 0, sum_ml = 0;
-        if (!bad && mine && nbseq != 0u)
         {
+            // One loop for the wave, a lane takes part while its stream has sequences left (no lane leaves early: a lane that
+            // finds an error only stops decoding).  Per sequence: the three entries, ONE 64-bit view of the bits below the
+            // position (a second one only when offset + lengths + states exceed 64 bits), the fields shifted off its top.
+            bool act = !bad && mine && nbseq != 0u;
             const uint32_t at = off + 3u + lhdr + lcs + shdr + (lane == tab_lane ? desc_bytes : 0u);
             const uint32_t end = off + 3u + csz;
-            if (at >= end || p[end - 1u] == 0u)
-                bad = true;
-            else
+            uint32_t pos = 0, sl = 0, so = 0, sm = 0;
+            ZsWin w;
+            w.base = p;
+            w.hi = w.lo = w.nx = 0;
+            w.top = 0;
+            w.reach = 0;
+            if (act)
             {
-                const uint8_t* bs = p + at;
-                uint32_t pos = (end - at - 1u) * 8u + (31u - (uint32_t)__builtin_clz((uint32_t)p[end - 1u]));
-                uint32_t sl = 0, so = 0, sm = 0;
-                ZsWin w;
-                w.open(bs, end - at, (uint32_t)(it.src_off + at > 64u ? 64u : it.src_off + at));
-                if (log_l + log_o + log_m > pos)
+                if (at >= end || p[end - 1u] == 0u)
                     bad = true;
                 else
                 {
-                    pos -= log_l;
-                    sl = w.get(pos, log_l);
-                    pos -= log_o;
-                    so = w.get(pos, log_o);
-                    pos -= log_m;
-                    sm = w.get(pos, log_m);
+                    pos = (end - at - 1u) * 8u + (31u - (uint32_t)__builtin_clz((uint32_t)p[end - 1u]));
+                    w.open(p + at, end - at, (uint32_t)(it.src_off + at > 64u ? 64u : it.src_off + at));
+                    if (log_l + log_o + log_m > pos)
+                        bad = true;
+                    else
+                    {
+                        pos -= log_l;
+                        sl = w.get(pos, log_l);
+                        pos -= log_o;
+                        so = w.get(pos, log_o);
+                        pos -= log_m;
+                        sm = w.get(pos, log_m);
+                    }
                 }
-                for (uint32_t k = 0; k < nbseq && !bad; ++k)
+                act = !bad;
+            }
+            const bool had = act;
+            for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(act && k < nbseq) != 0ull; ++k)
+            {
+                if (act && k < nbseq)
                 {
                     const uint64_t el = pk_ll[sl], eo = pk_of[so], em = pk_ml[sm];
                     const uint32_t l0 = (uint32_t)el, o0 = (uint32_t)eo, m0 = (uint32_t)em;
                     const uint32_t ob = o0 >> 24, mb = m0 >> 24, lb = l0 >> 24;
                     const uint32_t nbl = (l0 >> 16) & 255u, nbm = (m0 >> 16) & 255u, nbo = (o0 >> 16) & 255u;
                     const bool more = k + 1u < nbseq;
-                    if (ob + mb + lb + (more ? nbl + nbm + nbo : 0u) > pos)
+                    const uint32_t n1 = ob + mb + lb, n2 = more ? nbl + nbm + nbo : 0u; // <= 55, <= 26
+                    if (n1 + n2 > pos)
                     {
                         bad = true;
-                        break;
+                        act = false;
                     }
-                    w.ensure(pos, 64u); // offset + lengths: at most 31 + 32 bits
-                    pos -= ob;
-                    const uint32_t ov = (uint32_t)(eo >> 32) + w.get(pos, ob);
-                    pos -= mb + lb;
-                    const uint32_t t2 = w.get(pos, mb + lb); // match-length and literal-length extra bits are adjacent
-                    const uint32_t ml = (uint32_t)(em >> 32) + (t2 >> lb);
-                    const uint32_t ll = (uint32_t)(el >> 32) + (t2 & ((1u << lb) - 1u));
-                    if (more)
+                    else
                     {
-                        w.ensure(pos, 32u); // the three state fields: at most 26 bits
-                        pos -= nbl + nbm + nbo;
-                        const uint32_t t3 = w.get(pos, nbl + nbm + nbo); // LL, ML, OF from the top
-                        sl = (l0 & 0xFFFFu) + (t3 >> (nbm + nbo));
-                        sm = (m0 & 0xFFFFu) + ((t3 >> nbo) & ((1u << nbm) - 1u));
-                        so = (o0 & 0xFFFFu) + (t3 & ((1u << nbo) - 1u));
+                        w.ensure(pos, 64u);
+                        uint64_t acc = w.below(pos);
+                        const uint32_t ov = (uint32_t)(eo >> 32) + (uint32_t)((acc >> 1) >> (63u - ob));
+                        acc <<= ob;
+                        const uint32_t t2 = (uint32_t)((acc >> 1) >> (63u - (mb + lb))); // match-length and literal-length bits are adjacent
+                        acc <<= mb + lb;
+                        const uint32_t ml = (uint32_t)(em >> 32) + (t2 >> lb);
+                        const uint32_t ll = (uint32_t)(el >> 32) + (t2 & ((1u << lb) - 1u));
+                        if (n1 + n2 > 64u) // (rare: the view does not reach the state fields)
+                        {
+                            w.ensure(pos - n1, 32u);
+                            acc = w.below(pos - n1);
+                        }
+                        if (more)
+                        {
+                            const uint32_t t3 = (uint32_t)((acc >> 1) >> (63u - n2)); // LL, ML, OF from the top
+                            sl = (l0 & 0xFFFFu) + (t3 >> (nbm + nbo));
+                            sm = (m0 & 0xFFFFu) + ((t3 >> nbo) & ((1u << nbm) - 1u));
+                            so = (o0 & 0xFFFFu) + (t3 & ((1u << nbo) - 1u));
+                        }
+                        pos -= n1 + n2;
+                        if (ov <= 3u || ov >= (1u << 24)) // repeat offsets need the block before
+                            bad = true;
+                        sum_ll += ll;
+                        sum_ml += ml;
+                        recs[rec0 + k] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)ov << 40);
                     }
-                    if (ov <= 3u || ov >= (1u << 24)) // repeat offsets need the block before
-                        bad = true;
-                    sum_ll += ll;
-                    sum_ml += ml;
-                    recs[rec0 + k] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)ov << 40);
                 }
-                if (pos != 0u)
-                    bad = true; // the bit-stream must be consumed exactly
             }
+            if (had && !bad && pos != 0u)
+                bad = true; // the bit-stream must be consumed exactly
             // the block must regenerate exactly its unit
-            if (!bad && (sum_ll > nlit || nlit + sum_ml != ubytes))
+            if (had && !bad && (sum_ll > nlit || nlit + sum_ml != ubytes))
                 bad = true;
         }
-        else if (!bad && mine && nlit != ubytes)
+        if (!bad && mine && nbseq == 0u && nlit != ubytes)
             bad = true; // no sequences: all literals
         if (__builtin_amdgcn_ballot_w64(bad))
             bad = true;
