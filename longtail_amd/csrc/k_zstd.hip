@@ -1721,6 +1721,19 @@ struct ZxOut
 
 __device__ __forceinline__ uint32_t zx_u(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// inclusive prefix sum over the 64 lanes with DPP moves (row shifts inside the rows of 16, then the two row broadcasts): twelve
+// VALU instructions, nothing through the LDS crossbar (__shfl_up is a ds_bpermute per step, each a round trip on the chain)
+__device__ __forceinline__ uint32_t zx_scan_incl(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // The sequences' bit-stream, read backwards, on the scalar unit.  Per sequence ONE aligned 16-byte load that ends with the dword holding
 // the next bit (a sequence takes at most 89 bits: offset 31, lengths 16 + 16, states 9 + 9 + 8), then two 64-bit accumulators with
 // the next bits on top -- the three extra-bit fields (<= 63 bits) come out of the first, the three state fields out of the second --
@@ -1932,20 +1945,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // ---- vector unit: the serial decoder's checks for all of them at once, then execution ----
         const uint32_t ll = (uint32_t)lane < cnt ? r_ll : 0u, ml = (uint32_t)lane < cnt ? r_ml : 0u, off = r_off - 3u;
         uint32_t batch_ll, batch_adv;
-        uint32_t i_l = ll, i_a = ll + ml; // inclusive prefix sums: literals / output up to and including my sequence
+        uint32_t i_l = zx_scan_incl(ll), i_a = zx_scan_incl(ll + ml); // inclusive prefix sums: literals / output up to and including my sequence
         {
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1)
-            {
-                const uint32_t x = (uint32_t)__shfl_up((int)i_l, d, 64), y = (uint32_t)__shfl_up((int)i_a, d, 64);
-                if (lane >= d)
-                {
-                    i_l += x;
-                    i_a += y;
-                }
-            }
-            batch_ll = (uint32_t)__shfl((int)i_l, 63, 64);
-            batch_adv = (uint32_t)__shfl((int)i_a, 63, 64);
+            batch_ll = (uint32_t)__builtin_amdgcn_readlane((int)i_l, 63);
+            batch_adv = (uint32_t)__builtin_amdgcn_readlane((int)i_a, 63);
             // a piece may not use repeat offsets (ov <= 3); literals and output must fit; an offset may not reach below the piece
             const bool wrong = (uint32_t)lane < cnt && (r_off <= 3u || ll > 131072u || ml > 131075u || litpos + i_l > pr.nlit ||
                                                          produced + i_a > pr.expect || off > produced + i_a - ml);
