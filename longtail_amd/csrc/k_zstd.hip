@@ -596,9 +596,91 @@ __device__ __forceinline__ uint32_t z_wave_scan_excl(uint32_t v, int lane, uint3
     return incl - v;
 }
 
+// Frames of OTHER encoders (the reference's: blocks that depend on each other through the window, repeat offsets, repeated tables):
+// one frame that fills the payload, content size stated, no dictionary.  Its blocks are listed at FIXED places (slot zb_base + k of
+// `fitems`): k_zstd_blk_entropy decodes the streams of every block on a wave of its own (literals and sequence records to scratch),
+// k_zstd_execute<2> executes a payload's blocks one after the other.  Frame header: RFC 8878 3.1.1.1.
+struct ZFrameHdr
+{
+    uint32_t size;      // bytes of the frame header
+    uint64_t content;   // Frame_Content_Size
+    uint32_t checksum;  // a 4-byte content checksum follows the last block
+    bool ok;
+};
+__device__ __forceinline__ ZFrameHdr z_frame_header(const uint8_t* p, uint32_t avail)
+{
+    ZFrameHdr h;
+    h.size = 0;
+    h.content = 0;
+    h.checksum = 0;
+    h.ok = false;
+    if (avail < 6u || p[0] != 0x28 || p[1] != 0xB5 || p[2] != 0x2F || p[3] != 0xFD)
+        return h;
+    const uint32_t fhd = p[4];
+    const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1u;
+    if ((fhd & 8u) || (fhd & 3u)) // reserved bit; a dictionary
+        return h;
+    uint32_t pos = 5u + (single ? 0u : 1u);
+    const uint32_t fcs = fcs_flag == 0u ? (single ? 1u : 0u) : fcs_flag == 1u ? 2u : fcs_flag == 2u ? 4u : 8u;
+    if (fcs == 0u || pos + fcs > avail)
+        return h;
+    uint64_t c = 0;
+    for (uint32_t i = 0; i < fcs; ++i)
+        c |= (uint64_t)p[pos + i] << (8u * i);
+    if (fcs == 2u)
+        c += 256u;
+    h.size = pos + fcs;
+    h.content = c;
+    h.checksum = (fhd >> 2) & 1u;
+    h.ok = true;
+    return h;
+}
+__device__ bool z_split_foreign(const uint8_t* p, const ZBlock blk, uint32_t b, ZItem* fitems, uint32_t* f_nblocks, uint32_t* out_sizes, uint32_t* totals)
+{
+    const ZFrameHdr h = z_frame_header(p, blk.size);
+    if (!h.ok || h.content == 0u || h.content > (uint64_t)blk.dst_cap || h.content > 0x7F000000ull)
+        return false;
+    uint32_t pos = h.size, k = 0;
+    bool last = false;
+    while (!last)
+    {
+        if (k >= blk.nzb || blk.size - pos < 3u)
+            return false;
+        const uint32_t bh = (uint32_t)p[pos] | ((uint32_t)p[pos + 1] << 8) | ((uint32_t)p[pos + 2] << 16);
+        const uint32_t type = (bh >> 1) & 3u, bsize = bh >> 3;
+        last = (bh & 1u) != 0u;
+        const uint32_t body = type == 1u ? 1u : bsize;
+        if (type == 3u || bsize > ZB || body > blk.size - pos - 3u)
+            return false;
+        ZItem it;
+        it.src_off = blk.src_off;
+        it.size = blk.size;
+        it.out0 = 0;
+        it.payload = b;
+        it.kind = 4;
+        it.aux = k;
+        it.pad = pos;
+        fitems[blk.zb_base + k] = it;
+        pos += 3u + body;
+        ++k;
+    }
+    if (pos + 4u * h.checksum != blk.size)
+    {
+        for (uint32_t j = 0; j < k; ++j)
+            fitems[blk.zb_base + j].kind = 0;
+        return false; // more frames behind this one: the serial decoder
+    }
+    f_nblocks[b] = k;
+    out_sizes[b] = (uint32_t)h.content; // (replaced when the payload goes back to the serial decoder)
+    atomicAdd(&totals[0], k);                                          // blocks listed this way, and the bytes they regenerate:
+    atomicAdd((unsigned long long*)&totals[2], (unsigned long long)h.content); // the host sizes the literal and record arenas from these
+    return true;
+}
+
 __global__ __launch_bounds__(64) void k_zstd_split(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t nblocks,
                                                    ZItem* __restrict__ items, uint32_t* __restrict__ item_count,
-                                                   uint32_t* __restrict__ out_sizes, uint32_t dbg)
+                                                   uint32_t* __restrict__ out_sizes, uint32_t dbg, ZItem* __restrict__ fitems,
+                                                   uint32_t* __restrict__ f_nblocks)
 {
     const uint32_t b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -618,7 +700,11 @@ __global__ __launch_bounds__(64) void k_zstd_split(const uint8_t* __restrict__ s
     if (!dir)
     {
         if (lane == 0)
-            z_split_walk(p, blk, b, items, item_count, out_sizes, dbg);
+        {
+            const bool marked = blk.size >= ZHDR + 3u + ZTRAILER && z_is_trailer(p + blk.size - ZTRAILER);
+            if (marked || (dbg & 9u) || !z_split_foreign(p, blk, b, fitems, f_nblocks, out_sizes, item_count + 4)) // (dbg 8: no block-parallel path for foreign frames)
+                z_split_walk(p, blk, b, items, item_count, out_sizes, dbg);
+        }
         return;
     }
     const uint32_t tsize = z_trailer2_size(content);
@@ -957,6 +1043,96 @@ struct ZsWin
         return (uint32_t)v & (uint32_t)((1ull << n) - 1ull);
     }
 };
+
+// The sequence lanes: every lane with `act` decodes ONE bit-stream of nbseq sequences (tables packed in shared memory, one 8-byte
+// entry per state) into records {literal length:20 | match length:20 | offset value:24}.  One loop for the wave, a lane takes part
+// while its stream has sequences left (no lane leaves early: a lane that finds an error only stops decoding).  Per sequence: the
+// three entries, ONE 64-bit view of the bits below the position (a second one only when offset + lengths + states exceed 64 bits),
+// the fields shifted off its top.  STRICT: offset values 1..3 (repeat offsets) are errors; otherwise they stay in the record for
+// whoever executes it in order.
+template <bool STRICT>
+__device__ __forceinline__ void zs_seq_lanes(bool act, const uint8_t* stream, uint32_t ssize, uint32_t below, uint32_t nbseq, uint32_t log_l,
+                                             uint32_t log_o, uint32_t log_m, const uint64_t* pk_ll, const uint64_t* pk_of, const uint64_t* pk_ml,
+                                             uint64_t* recs, bool& bad, uint32_t& sum_ll, uint32_t& sum_ml)
+{
+    uint32_t pos = 0, sl = 0, so = 0, sm = 0;
+    ZsWin w;
+    w.base = stream;
+    w.hi = w.lo = w.nx = 0;
+    w.top = 0;
+    w.reach = 0;
+    if (act)
+    {
+        if (ssize == 0u || stream[ssize - 1u] == 0u)
+            bad = true;
+        else
+        {
+            pos = (ssize - 1u) * 8u + (31u - (uint32_t)__builtin_clz((uint32_t)stream[ssize - 1u]));
+            w.open(stream, ssize, below);
+            if (log_l + log_o + log_m > pos)
+                bad = true;
+            else
+            {
+                pos -= log_l;
+                sl = w.get(pos, log_l);
+                pos -= log_o;
+                so = w.get(pos, log_o);
+                pos -= log_m;
+                sm = w.get(pos, log_m);
+            }
+        }
+        act = !bad;
+    }
+    const bool had = act;
+    for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(act && k < nbseq) != 0ull; ++k)
+    {
+        if (act && k < nbseq)
+        {
+            const uint64_t el = pk_ll[sl], eo = pk_of[so], em = pk_ml[sm];
+            const uint32_t l0 = (uint32_t)el, o0 = (uint32_t)eo, m0 = (uint32_t)em;
+            const uint32_t ob = o0 >> 24, mb = m0 >> 24, lb = l0 >> 24;
+            const uint32_t nbl = (l0 >> 16) & 255u, nbm = (m0 >> 16) & 255u, nbo = (o0 >> 16) & 255u;
+            const bool more = k + 1u < nbseq;
+            const uint32_t n1 = ob + mb + lb, n2 = more ? nbl + nbm + nbo : 0u; // <= 55, <= 26
+            if (n1 + n2 > pos)
+            {
+                bad = true;
+                act = false;
+            }
+            else
+            {
+                w.ensure(pos, 64u);
+                uint64_t acc = w.below(pos);
+                const uint32_t ov = (uint32_t)(eo >> 32) + (uint32_t)((acc >> 1) >> (63u - ob));
+                acc <<= ob;
+                const uint32_t t2 = (uint32_t)((acc >> 1) >> (63u - (mb + lb))); // match-length and literal-length bits are adjacent
+                acc <<= mb + lb;
+                const uint32_t ml = (uint32_t)(em >> 32) + (t2 >> lb);
+                const uint32_t ll = (uint32_t)(el >> 32) + (t2 & ((1u << lb) - 1u));
+                if (n1 + n2 > 64u) // (rare: the view does not reach the state fields)
+                {
+                    w.ensure(pos - n1, 32u);
+                    acc = w.below(pos - n1);
+                }
+                if (more)
+                {
+                    const uint32_t t3 = (uint32_t)((acc >> 1) >> (63u - n2)); // LL, ML, OF from the top
+                    sl = (l0 & 0xFFFFu) + (t3 >> (nbm + nbo));
+                    sm = (m0 & 0xFFFFu) + ((t3 >> nbo) & ((1u << nbm) - 1u));
+                    so = (o0 & 0xFFFFu) + (t3 & ((1u << nbo) - 1u));
+                }
+                pos -= n1 + n2;
+                if ((STRICT && ov <= 3u) || ov >= (1u << 24)) // repeat offsets need the block before
+                    bad = true;
+                sum_ll += ll;
+                sum_ml += ml;
+                recs[k] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)ov << 40);
+            }
+        }
+    }
+    if (had && !bad && pos != 0u)
+        bad = true; // the bit-stream must be consumed exactly
+}
 
 __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, const ZItem* __restrict__ items,
                                                          const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
@@ -1411,89 +1587,11 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
         // ---- sequences: lane u the bit-stream of block u ----
         uint32_t sum_ll = 0, sum_ml = 0;
         {
-            // One loop for the wave, a lane takes part while its stream has sequences left (no lane leaves early: a lane that
-            // finds an error only stops decoding).  Per sequence: the three entries, ONE 64-bit view of the bits below the
-            // position (a second one only when offset + lengths + states exceed 64 bits), the fields shifted off its top.
-            bool act = !bad && mine && nbseq != 0u;
             const uint32_t at = off + 3u + lhdr + lcs + shdr + (lane == tab_lane ? desc_bytes : 0u);
             const uint32_t end = off + 3u + csz;
-            uint32_t pos = 0, sl = 0, so = 0, sm = 0;
-            ZsWin w;
-            w.base = p;
-            w.hi = w.lo = w.nx = 0;
-            w.top = 0;
-            w.reach = 0;
-            if (act)
-            {
-                if (at >= end || p[end - 1u] == 0u)
-                    bad = true;
-                else
-                {
-                    pos = (end - at - 1u) * 8u + (31u - (uint32_t)__builtin_clz((uint32_t)p[end - 1u]));
-                    w.open(p + at, end - at, (uint32_t)(it.src_off + at > 64u ? 64u : it.src_off + at));
-                    if (log_l + log_o + log_m > pos)
-                        bad = true;
-                    else
-                    {
-                        pos -= log_l;
-                        sl = w.get(pos, log_l);
-                        pos -= log_o;
-                        so = w.get(pos, log_o);
-                        pos -= log_m;
-                        sm = w.get(pos, log_m);
-                    }
-                }
-                act = !bad;
-            }
-            const bool had = act;
-            for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(act && k < nbseq) != 0ull; ++k)
-            {
-                if (act && k < nbseq)
-                {
-                    const uint64_t el = pk_ll[sl], eo = pk_of[so], em = pk_ml[sm];
-                    const uint32_t l0 = (uint32_t)el, o0 = (uint32_t)eo, m0 = (uint32_t)em;
-                    const uint32_t ob = o0 >> 24, mb = m0 >> 24, lb = l0 >> 24;
-                    const uint32_t nbl = (l0 >> 16) & 255u, nbm = (m0 >> 16) & 255u, nbo = (o0 >> 16) & 255u;
-                    const bool more = k + 1u < nbseq;
-                    const uint32_t n1 = ob + mb + lb, n2 = more ? nbl + nbm + nbo : 0u; // <= 55, <= 26
-                    if (n1 + n2 > pos)
-                    {
-                        bad = true;
-                        act = false;
-                    }
-                    else
-                    {
-                        w.ensure(pos, 64u);
-                        uint64_t acc = w.below(pos);
-                        const uint32_t ov = (uint32_t)(eo >> 32) + (uint32_t)((acc >> 1) >> (63u - ob));
-                        acc <<= ob;
-                        const uint32_t t2 = (uint32_t)((acc >> 1) >> (63u - (mb + lb))); // match-length and literal-length bits are adjacent
-                        acc <<= mb + lb;
-                        const uint32_t ml = (uint32_t)(em >> 32) + (t2 >> lb);
-                        const uint32_t ll = (uint32_t)(el >> 32) + (t2 & ((1u << lb) - 1u));
-                        if (n1 + n2 > 64u) // (rare: the view does not reach the state fields)
-                        {
-                            w.ensure(pos - n1, 32u);
-                            acc = w.below(pos - n1);
-                        }
-                        if (more)
-                        {
-                            const uint32_t t3 = (uint32_t)((acc >> 1) >> (63u - n2)); // LL, ML, OF from the top
-                            sl = (l0 & 0xFFFFu) + (t3 >> (nbm + nbo));
-                            sm = (m0 & 0xFFFFu) + ((t3 >> nbo) & ((1u << nbm) - 1u));
-                            so = (o0 & 0xFFFFu) + (t3 & ((1u << nbo) - 1u));
-                        }
-                        pos -= n1 + n2;
-                        if (ov <= 3u || ov >= (1u << 24)) // repeat offsets need the block before
-                            bad = true;
-                        sum_ll += ll;
-                        sum_ml += ml;
-                        recs[rec0 + k] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)ov << 40);
-                    }
-                }
-            }
-            if (had && !bad && pos != 0u)
-                bad = true; // the bit-stream must be consumed exactly
+            const bool had = !bad && mine && nbseq != 0u;
+            zs_seq_lanes<true>(had, p + at, at < end ? end - at : 0u, (uint32_t)(it.src_off + at > 64u ? 64u : it.src_off + at), nbseq, log_l, log_o,
+                               log_m, pk_ll, pk_of, pk_ml, recs + rec0, bad, sum_ll, sum_ml);
             // the block must regenerate exactly its unit
             if (had && !bad && (sum_ll > nlit || nlit + sum_ml != ubytes))
                 bad = true;
@@ -1532,6 +1630,531 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
         if (lane == 0)
         {
             prep[i] = pr;
+            if (bad)
+                retry[it.payload] = 1u;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Frames of other encoders, block-parallel (fitems, kind 4): k_zstd_blk_entropy, one wave per BLOCK.
+// A block's streams need nothing from the blocks before it except their entropy tables (Treeless literals, Repeat_Mode), and those
+// are found without decoding anything: the wave walks the headers of the blocks before its own (section headers only), notes which
+// block last SET the Huffman tree and each of the three FSE tables, and builds them from there with the decoder core's readers.
+// Then it decodes its own block's literal streams (two per lane) into the block's literal buffer and its sequence bit-stream (one
+// lane) into records -- offset values 1..3 (repeat offsets) stay in the records; k_zstd_execute<2> resolves them when it executes
+// the payload's blocks in order.  Whatever is unusual gives the payload back to the serial decoder.
+// ---------------------------------------------------------------------------------------------------
+struct ZfBlk
+{
+    uint32_t lmode, nlit, lhdr, lcs, nstr, nbseq, shdr, modes;
+    bool ok;
+};
+// section headers of a Compressed_Block's content c[0 .. csz)
+__device__ __forceinline__ ZfBlk zf_parse(const uint8_t* c, uint32_t csz)
+{
+    ZfBlk f;
+    f.lmode = f.nlit = f.lhdr = f.lcs = f.nstr = f.nbseq = f.shdr = f.modes = 0;
+    f.ok = false;
+    if (csz < 2u)
+        return f;
+    const uint32_t b0 = c[0], sf = (b0 >> 2) & 3u;
+    f.lmode = b0 & 3u;
+    if (f.lmode < 2u)
+    {
+        f.lhdr = (sf & 1u) == 0u ? 1u : sf == 1u ? 2u : 3u;
+        if (f.lhdr > csz)
+            return f;
+        f.nlit = f.lhdr == 1u ? b0 >> 3 : f.lhdr == 2u ? ((uint32_t)c[0] | ((uint32_t)c[1] << 8)) >> 4
+                                                       : ((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16)) >> 4;
+        f.lcs = f.lmode == 0u ? f.nlit : 1u;
+    }
+    else
+    {
+        f.lhdr = sf < 2u ? 3u : sf == 2u ? 4u : 5u;
+        if (f.lhdr > csz)
+            return f;
+        if (f.lhdr == 3u)
+        {
+            const uint32_t hh = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+            f.nlit = (hh >> 4) & 0x3FFu;
+            f.lcs = hh >> 14;
+        }
+        else if (f.lhdr == 4u)
+        {
+            const uint32_t hh = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
+            f.nlit = (hh >> 4) & 0x3FFFu;
+            f.lcs = hh >> 18;
+        }
+        else
+        {
+            const uint32_t hh = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
+            f.nlit = (hh >> 4) & 0x3FFFFu;
+            f.lcs = (hh >> 22) | ((uint32_t)c[4] << 10);
+        }
+        f.nstr = sf == 0u ? 1u : 4u;
+    }
+    if (f.nlit > ZD_LIT_MAX || f.lcs >= csz - f.lhdr) // (at least one byte of sequences section follows)
+        return f;
+    const uint32_t sp = f.lhdr + f.lcs;
+    const uint32_t n0 = c[sp];
+    if (n0 == 0u)
+    {
+        f.shdr = 1;
+        f.ok = sp + 1u == csz;
+        return f;
+    }
+    if (n0 < 128u)
+    {
+        f.nbseq = n0;
+        f.shdr = 1;
+    }
+    else if (n0 < 255u)
+    {
+        if (sp + 2u > csz)
+            return f;
+        f.nbseq = ((n0 - 128u) << 8) + c[sp + 1u];
+        f.shdr = 2;
+    }
+    else
+    {
+        if (sp + 3u > csz)
+            return f;
+        f.nbseq = (uint32_t)c[sp + 1u] + ((uint32_t)c[sp + 2u] << 8) + 0x7F00u;
+        f.shdr = 3;
+    }
+    if (sp + f.shdr + 1u >= csz || f.nbseq == 0u)
+        return f;
+    f.modes = c[sp + f.shdr];
+    f.shdr += 1u;
+    f.ok = (f.modes & 3u) == 0u;
+    return f;
+}
+
+__global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restrict__ src, const ZItem* __restrict__ fitems, uint32_t slot0, uint32_t slot1,
+                                                         uint8_t* __restrict__ lit_scratch, uint64_t* __restrict__ rec_scratch,
+                                                         ZPrep* __restrict__ fprep, uint32_t* __restrict__ retry, uint32_t* __restrict__ ticket,
+                                                         unsigned long long* __restrict__ bump, uint64_t lit_cap, uint64_t rec_cap)
+{
+    __shared__ ZdShared sh;
+    __shared__ uint4 s_streams[4];
+    __shared__ __attribute__((aligned(16))) uint8_t s_desc[512 + 256];
+    const int lane = threadIdx.x;
+    uint64_t* const pk_ll = reinterpret_cast<uint64_t*>(sh.huf);
+    uint64_t* const pk_ml = pk_ll + 512;
+    uint64_t* const pk_of = reinterpret_cast<uint64_t*>(&sh.wtab);
+    for (;;)
+    {
+        __builtin_amdgcn_wave_barrier();
+        uint32_t tk = atomicAdd(ticket, lane == 0 ? 1u : 0u);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        const uint32_t i = slot0 + tk;
+        if (i >= slot1)
+            break;
+        const ZItem it = fitems[i];
+        if (it.kind != 4u)
+            continue;
+        __syncthreads();
+        const uint8_t* p = src + it.src_off; // the payload
+        ZPrep pr;
+        pr.bits_off = 0;
+        pr.bits_size = pr.nbseq = pr.nlit = 0;
+        pr.log[0] = pr.log[1] = pr.log[2] = 0;
+        pr.expect = 0;
+        pr.status = ZP_SERIAL;
+        bool bad = false;
+        if (lane == 0)
+        {
+            sh.v[ZDV_ERR] = 0;
+            sh.v[ZDV_PREP] = 0;
+            sh.huf_valid = 0;
+        }
+        const uint32_t bh = (uint32_t)p[it.pad] | ((uint32_t)p[it.pad + 1u] << 8) | ((uint32_t)p[it.pad + 2u] << 16);
+        const uint32_t type = (bh >> 1) & 3u, bsize = bh >> 3;
+        if (type != 2u)
+        {
+            // Raw_Block / RLE_Block: where the bytes are (the executor copies / fills)
+            pr.log[0] = type == 0u ? 1u : 2u;
+            pr.bits_off = it.src_off + it.pad + 3u;
+            pr.expect = bsize;
+            pr.status = ZP_DONE;
+            if (lane == 0)
+                fprep[i] = pr;
+            continue;
+        }
+        const uint32_t c0 = it.pad + 3u; // my block's content inside the payload
+        const ZfBlk me = zf_parse(p + c0, bsize);
+        bad = !me.ok;
+        // room for my literals and my records in the two arenas (a wave-uniform draw; an arena that is full sends the payload to the
+        // serial decoder: the host sizes them for a record per six bytes of output)
+        unsigned long long lit_at = 0, rec_at = 0;
+        if (!bad)
+        {
+            const unsigned long long want_l = ((unsigned long long)me.nlit + 79ull) & ~15ull;
+            lit_at = atomicAdd(&bump[0], lane == 0 ? want_l : 0ull);
+            rec_at = atomicAdd(&bump[1], lane == 0 ? (unsigned long long)me.nbseq : 0ull);
+            lit_at = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(lit_at >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)lit_at);
+            rec_at = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(rec_at >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)rec_at);
+            if (lit_at + want_l > lit_cap || rec_at + me.nbseq > rec_cap)
+                bad = true;
+        }
+        uint8_t* lits = lit_scratch + lit_at;
+        uint64_t* recs = rec_scratch + rec_at;
+        // ---- who set the tree / the tables last?  (the section headers of the blocks up to mine) ----
+        uint32_t tree_at = 0, tree_size = 0, tab_at[3] = {0, 0, 0}, tab_end[3] = {0, 0, 0}, tab_modes[3] = {0, 0, 0};
+        bool have_tree = false, have_tab[3] = {false, false, false};
+        if (!bad)
+        {
+            const ZFrameHdr fh = z_frame_header(p, it.size);
+            uint32_t q = fh.size;
+            for (uint32_t j = 0; j <= it.aux && !bad; ++j)
+            {
+                const uint32_t h = (uint32_t)p[q] | ((uint32_t)p[q + 1u] << 8) | ((uint32_t)p[q + 2u] << 16);
+                const uint32_t ty = (h >> 1) & 3u, sz = h >> 3;
+                if (ty == 2u)
+                {
+                    const ZfBlk f = j == it.aux ? me : zf_parse(p + q + 3u, sz);
+                    if (!f.ok)
+                        bad = true;
+                    else
+                    {
+                        if (f.lmode == 2u)
+                        {
+                            have_tree = true;
+                            tree_at = q + 3u + f.lhdr;
+                            tree_size = f.lcs;
+                        }
+                        if (f.nbseq)
+                            for (int t = 0; t < 3; ++t)
+                                if (((f.modes >> (6 - 2 * t)) & 3u) != 3u)
+                                {
+                                    have_tab[t] = true;
+                                    tab_at[t] = q + 3u + f.lhdr + f.lcs + f.shdr; // the first description of that block
+                                    tab_end[t] = q + 3u + sz;
+                                    tab_modes[t] = f.modes;
+                                }
+                    }
+                }
+                q += 3u + (ty == 1u ? 1u : sz);
+            }
+            if ((me.lmode == 3u && !have_tree) || (me.nbseq && !(have_tab[0] && have_tab[1] && have_tab[2])))
+                bad = true; // nothing to repeat: the serial decoder says so
+        }
+        // ---- the three tables (descriptions by lane 0 from staged bytes, tables by all lanes), then the tree ----
+        if (!bad && me.nbseq)
+        {
+            for (int t = 0; t < 3 && !bad; ++t)
+            {
+                const uint32_t staged = tab_end[t] - tab_at[t] < 512u ? tab_end[t] - tab_at[t] : 512u;
+                __syncthreads();
+                for (uint32_t k = lane; k < staged; k += 64)
+                    s_desc[k] = p[tab_at[t] + k];
+                __syncthreads();
+                if (lane == 0)
+                {
+                    // the descriptions of a block lie one behind the other (LL, OF, ML): skip the ones before mine
+                    uint32_t q = 0;
+                    for (int tt = 0; tt <= t && !sh.v[ZDV_ERR]; ++tt)
+                    {
+                        const uint32_t m = (tab_modes[t] >> (6 - 2 * tt)) & 3u;
+                        uint32_t used = 0;
+                        if (tt == t)
+                        {
+                            if (zd_set_table(&sh, t, m, s_desc + q, staged - q, &used))
+                                sh.v[ZDV_ERR] = 1;
+                        }
+                        else if (m == 1u)
+                            used = 1;
+                        else if (m == 2u)
+                        {
+                            uint32_t maxsym = tt == ZT_LL ? 35u : tt == ZT_ML ? 52u : 31u, tl = 0;
+                            used = q < staged ? zd_read_ncount(s_desc + q, staged - q, sh.norm + 192, &maxsym, zb_table_max_log(tt), &tl) : ZD_ERROR;
+                            if (used == ZD_ERROR)
+                            {
+                                sh.v[ZDV_ERR] = 1;
+                                used = 0;
+                            }
+                        }
+                        q += used;
+                        if (q > staged)
+                            sh.v[ZDV_ERR] = 1;
+                    }
+                }
+                __syncthreads();
+                bad = sh.v[ZDV_ERR] != 0u;
+                if (!bad && sh.tb_build[t])
+                {
+                    if (zd_build_fse_par(&sh.fse[t], sh.norm + 64 * t, sh.tb_maxsym[t], sh.tb_log[t], sh.cum, (uint32_t*)sh.huf,
+                                         sh.huf + 2u * ZD_FSE_PAR_MASK_WORDS, (uint32_t)lane))
+                        bad = true;
+                    ZB_SYNC_LDS();
+                }
+            }
+            __syncthreads();
+        }
+        uint32_t tree_bytes = 0;
+        if (!bad && me.lmode >= 2u)
+        {
+            const uint32_t staged = tree_size < 256u ? tree_size : 256u;
+            for (uint32_t k = lane; k < staged; k += 64)
+                s_desc[512u + k] = p[tree_at + k];
+            __syncthreads();
+            if (lane == 0)
+            {
+                const uint32_t tr = zd_read_huf_tree(&sh, s_desc + 512, staged);
+                if (tr == ZD_ERROR)
+                    sh.v[ZDV_ERR] = 1;
+                else
+                    sh.v[ZDV_LEN] = tr;
+            }
+            __syncthreads();
+            bad = sh.v[ZDV_ERR] != 0u;
+            tree_bytes = me.lmode == 2u ? sh.v[ZDV_LEN] : 0u;
+        }
+        // ---- literals ----
+        uint32_t nstr_total = 0;
+        if (!bad)
+        {
+            const uint32_t at0 = c0 + me.lhdr;
+            if (me.lmode == 0u)
+            {
+                typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+                const uint32_t nv = me.nlit >> 4;
+                for (uint32_t k = lane; k < nv; k += 64)
+                    *reinterpret_cast<u32x4_a1*>(lits + 16u * k) = *reinterpret_cast<const u32x4_a1*>(p + at0 + 16u * k);
+                for (uint32_t k = 16u * nv + (uint32_t)lane; k < me.nlit; k += 64)
+                    lits[k] = p[at0 + k];
+            }
+            else if (me.lmode == 1u)
+                for (uint32_t k = lane; k < me.nlit; k += 64)
+                    lits[k] = p[at0];
+            else
+            {
+                const uint32_t at = at0 + tree_bytes;
+                if (me.lcs < tree_bytes)
+                    bad = true;
+                else if (me.nstr == 1u)
+                {
+                    if (lane == 0)
+                        s_streams[0] = make_uint4(at, me.lcs - tree_bytes, 0u, me.nlit);
+                    nstr_total = 1;
+                }
+                else if (me.lcs - tree_bytes < 10u)
+                    bad = true;
+                else
+                {
+                    const uint8_t* j = p + at;
+                    const uint32_t s1 = (uint32_t)j[0] | ((uint32_t)j[1] << 8), s2 = (uint32_t)j[2] | ((uint32_t)j[3] << 8),
+                                   s3 = (uint32_t)j[4] | ((uint32_t)j[5] << 8);
+                    const uint32_t body = me.lcs - tree_bytes - 6u, seg = (me.nlit + 3u) >> 2;
+                    if (s1 + s2 + s3 >= body || 3u * seg > me.nlit)
+                        bad = true;
+                    else
+                    {
+                        if (lane == 0)
+                        {
+                            s_streams[0] = make_uint4(at + 6u, s1, 0u, seg);
+                            s_streams[1] = make_uint4(at + 6u + s1, s2, seg, seg);
+                            s_streams[2] = make_uint4(at + 6u + s1 + s2, s3, 2u * seg, seg);
+                            s_streams[3] = make_uint4(at + 6u + s1 + s2 + s3, body - s1 - s2 - s3, 3u * seg, me.nlit - 3u * seg);
+                        }
+                        nstr_total = 4;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (!bad && nstr_total)
+        {
+            // the streams: lanes 0 and 1, two each (as in k_zstd_sub_entropy)
+            const uint32_t tl = sh.huf_log;
+            const uint32_t ka = (uint32_t)lane, kb = ka + 2u;
+            const bool has_a = ka < nstr_total && ka < 2u, has_b = kb < nstr_total && ka < 2u;
+            const uint4 sa = has_a ? s_streams[ka] : make_uint4(0, 0, 0, 0), sb2 = has_b ? s_streams[kb] : make_uint4(0, 0, 0, 0);
+            uint32_t pa = 0, pb = 0, ia = 0, ib = 0;
+            ZsWin wa, wb;
+            wa.base = wb.base = p;
+            wa.hi = wa.lo = wa.nx = wb.hi = wb.lo = wb.nx = 0;
+            wa.top = wb.top = 0;
+            wa.reach = wb.reach = 0;
+            bool go_a = false, go_b = false;
+            if (has_a)
+            {
+                const uint32_t last = sa.y ? p[sa.x + sa.y - 1u] : 0u;
+                if (sa.w == 0u || last == 0u)
+                    bad = true;
+                else
+                {
+                    pa = (sa.y - 1u) * 8u + (31u - (uint32_t)__builtin_clz(last));
+                    wa.open(p + sa.x, sa.y, (uint32_t)(it.src_off + sa.x > 64u ? 64u : it.src_off + sa.x));
+                    go_a = true;
+                }
+            }
+            if (has_b)
+            {
+                const uint32_t last = sb2.y ? p[sb2.x + sb2.y - 1u] : 0u;
+                if (sb2.w == 0u || last == 0u)
+                    bad = true;
+                else
+                {
+                    pb = (sb2.y - 1u) * 8u + (31u - (uint32_t)__builtin_clz(last));
+                    wb.open(p + sb2.x, sb2.y, (uint32_t)(it.src_off + sb2.x > 64u ? 64u : it.src_off + sb2.x));
+                    go_b = true;
+                }
+            }
+            uint8_t* const oa = lits + sa.z;
+            uint8_t* const ob2 = lits + sb2.z;
+            for (;;)
+            {
+                const bool fa = go_a && sa.w - ia >= 4u && pa >= 64u, fb = go_b && sb2.w - ib >= 4u && pb >= 64u;
+                if (!__builtin_amdgcn_ballot_w64(fa || fb))
+                    break;
+                uint64_t ta = 0, tb2 = 0;
+                if (fa)
+                {
+                    wa.ensure(pa, 64u);
+                    ta = wa.get64(pa - 64u);
+                }
+                if (fb)
+                {
+                    wb.ensure(pb, 64u);
+                    tb2 = wb.get64(pb - 64u);
+                }
+                uint32_t ua = 0, ub = 0, qa = 0, qb = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j)
+                {
+                    const uint32_t ea = sh.huf[(uint32_t)(ta >> (64u - tl))], eb = sh.huf[(uint32_t)(tb2 >> (64u - tl))];
+                    const uint32_t na = ea >> 8, nb2 = eb >> 8;
+                    ta <<= na;
+                    tb2 <<= nb2;
+                    ua += na;
+                    ub += nb2;
+                    qa |= (ea & 255u) << (8u * j);
+                    qb |= (eb & 255u) << (8u * j);
+                }
+                if (fa)
+                {
+                    __builtin_memcpy(oa + ia, &qa, 4);
+                    pa -= ua;
+                    ia += 4u;
+                }
+                if (fb)
+                {
+                    __builtin_memcpy(ob2 + ib, &qb, 4);
+                    pb -= ub;
+                    ib += 4u;
+                }
+            }
+            if (go_a && zd_huf_stream_from(&sh, p + sa.x, sa.y, oa, sa.w, pa, ia))
+                bad = true;
+            if (go_b && zd_huf_stream_from(&sh, p + sb2.x, sb2.y, ob2, sb2.w, pb, ib))
+                bad = true;
+        }
+        if (__builtin_amdgcn_ballot_w64(bad))
+            bad = true;
+        __syncthreads();
+        // ---- the tables, packed; the sequences (lane 0) ----
+        uint32_t log_l = 0, log_o = 0, log_m = 0, sum_ll = 0, sum_ml = 0;
+        if (!bad && me.nbseq)
+        {
+            for (int t = 0; t < 3; ++t)
+            {
+                const ZdFse* f = &sh.fse[t];
+                uint64_t* pk = t == ZT_LL ? pk_ll : t == ZT_ML ? pk_ml : pk_of;
+                const uint32_t size = f->valid == 2u ? 1u : f->valid == 1u ? 1u << f->log : 0u;
+                if (size == 0u || size > (t == ZT_OF ? 256u : 512u))
+                    bad = true;
+                const uint32_t lg = f->valid == 2u ? 0u : f->log;
+                if (t == ZT_LL)
+                    log_l = lg;
+                else if (t == ZT_OF)
+                    log_o = lg;
+                else
+                    log_m = lg;
+                for (uint32_t x = lane; x < size && !bad; x += 64)
+                {
+                    const uint32_t sym = f->sym[x];
+                    uint32_t baseline, ebits;
+                    if (t == ZT_LL)
+                    {
+                        baseline = zb_ll_base(sym & 63u);
+                        ebits = zb_ll_bits(sym & 63u);
+                        bad = sym > 35u;
+                    }
+                    else if (t == ZT_ML)
+                    {
+                        baseline = zb_ml_base(sym & 63u) + 3u;
+                        ebits = zb_ml_bits(sym & 63u);
+                        bad = sym > 52u;
+                    }
+                    else
+                    {
+                        baseline = 1u << (sym & 31u);
+                        ebits = sym & 31u;
+                        bad = sym > 23u; // (an offset of 2^24 and more: not with windows of 8 MiB; the serial decoder takes those)
+                    }
+                    pk[x] = (uint64_t)(f->valid == 2u ? 0u : f->base[x]) | ((uint64_t)(f->valid == 2u ? 0u : f->nb[x]) << 16) | ((uint64_t)ebits << 24) |
+                            ((uint64_t)baseline << 32);
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(bad))
+                bad = true;
+            __syncthreads();
+            const uint32_t at = c0 + me.lhdr + me.lcs + me.shdr + (uint32_t)0;
+            // my own block's descriptions precede the bit-stream: their size = the bytes its non-repeated tables took
+            uint32_t skip = 0;
+            if (!bad)
+            {
+                if (lane == 0)
+                {
+                    uint32_t q = 0;
+                    const uint32_t avail = c0 + bsize - at;
+                    for (int tt = 0; tt < 3 && !sh.v[ZDV_ERR]; ++tt)
+                    {
+                        const uint32_t m = (me.modes >> (6 - 2 * tt)) & 3u;
+                        if (m == 1u)
+                            q += 1u;
+                        else if (m == 2u)
+                        {
+                            uint32_t maxsym = tt == ZT_LL ? 35u : tt == ZT_ML ? 52u : 31u, tl2 = 0;
+                            const uint32_t used = q < avail ? zd_read_ncount(p + at + q, avail - q, sh.norm + 192, &maxsym, zb_table_max_log(tt), &tl2) : ZD_ERROR;
+                            if (used == ZD_ERROR)
+                                sh.v[ZDV_ERR] = 1;
+                            else
+                                q += used;
+                        }
+                    }
+                    sh.v[ZDV_LL] = q;
+                    if (q >= avail)
+                        sh.v[ZDV_ERR] = 1;
+                }
+                __syncthreads();
+                bad = sh.v[ZDV_ERR] != 0u;
+                skip = sh.v[ZDV_LL];
+            }
+            const uint32_t sat = at + skip, send = c0 + bsize;
+            zs_seq_lanes<false>(!bad && lane == 0, p + sat, sat < send ? send - sat : 0u, (uint32_t)(it.src_off + sat > 64u ? 64u : it.src_off + sat),
+                                me.nbseq, log_l, log_o, log_m, pk_ll, pk_of, pk_ml, recs, bad, sum_ll, sum_ml);
+            sum_ll = (uint32_t)__builtin_amdgcn_readfirstlane(sum_ll);
+            sum_ml = (uint32_t)__builtin_amdgcn_readfirstlane(sum_ml);
+            if (__builtin_amdgcn_ballot_w64(bad))
+                bad = true;
+            if (!bad && (sum_ll > me.nlit || me.nlit + sum_ml > ZB))
+                bad = true;
+        }
+        else if (!bad && me.nlit > ZB)
+            bad = true;
+        pr.nbseq = me.nbseq;
+        pr.nlit = me.nlit;
+        pr.expect = me.nlit + sum_ml; // what the block regenerates
+        pr.bits_off = lit_at;          // where its literals are ...
+        pr.log[1] = (uint32_t)rec_at;  // ... and its records
+        pr.log[2] = (uint32_t)(rec_at >> 32);
+        pr.status = bad ? ZP_SERIAL : ZP_READY;
+        if (lane == 0)
+        {
+            fprep[i] = pr;
             if (bad)
                 retry[it.payload] = 1u;
         }
@@ -1786,6 +2409,174 @@ struct ZxBits
     }
 };
 
+// One batch of up to 64 sequences, one per lane (r_ll, r_ml, r_off = offset + 3 in lanes 0 .. cnt-1): the serial decoder's checks for
+// all of them at once, then their execution through the ring.  litpos / produced: literals consumed / bytes produced so far in the
+// literal buffer / the output the ring belongs to (updated); nlit_total / out_limit: how many there are / may be.
+__device__ __forceinline__ void zx_batch(ZxOut& zx, uint8_t* s_ring, uint8_t* s_lit, const int lane, const uint32_t cnt, const uint32_t r_ll,
+                                         const uint32_t r_ml, const uint32_t r_off, uint32_t& litpos, uint32_t& produced, const uint32_t nlit_total,
+                                         const uint32_t out_limit, bool& bad)
+{
+    // ---- vector unit: the serial decoder's checks for all of them at once, then execution ----
+    const uint32_t ll = (uint32_t)lane < cnt ? r_ll : 0u, ml = (uint32_t)lane < cnt ? r_ml : 0u, off = r_off - 3u;
+    uint32_t batch_ll, batch_adv;
+    uint32_t i_l = zx_scan_incl(ll), i_a = zx_scan_incl(ll + ml); // inclusive prefix sums: literals / output up to and including my sequence
+    {
+        batch_ll = (uint32_t)__builtin_amdgcn_readlane((int)i_l, 63);
+        batch_adv = (uint32_t)__builtin_amdgcn_readlane((int)i_a, 63);
+        // a piece may not use repeat offsets (ov <= 3); literals and output must fit; an offset may not reach below the piece
+        const bool wrong = (uint32_t)lane < cnt && (r_off <= 3u || ll > 131072u || ml > 131075u || litpos + i_l > nlit_total ||
+                                                     produced + i_a > out_limit || off > produced + i_a - ml);
+        if (__builtin_amdgcn_ballot_w64(wrong))
+        {
+            bad = true;
+            return;
+        }
+    }
+    // ---- execution: as many sequences as fit the ring's margins in ONE pass (usually the whole batch): the prefix sums of the
+    // checks place everything; ALL literals first (they depend on nothing), then the matches in dependency rounds -- short ones
+    // by their own lanes, a long one by the whole wave when its turn comes.  A sequence too big for a pass (a raw unit's 4 KiB
+    // of literals) goes through the whole wave alone. ----
+    uint32_t start = 0, base_l = 0, base_a = 0; // literals / output of the batch's sequences before `start`
+    while (start < cnt)
+    {
+        const bool fit = (uint32_t)lane >= start && (uint32_t)lane < cnt && i_a - base_a <= ZX_BATCH_ADV && i_l - base_l <= ZX_BATCH_LL;
+        const uint64_t fm = __builtin_amdgcn_ballot_w64(fit) >> start; // (the sums grow: the bits are a run from bit 0)
+        const uint32_t k = fm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fm);
+        if (k == 0u)
+        {
+            const uint32_t gl = zx_u((uint32_t)__builtin_amdgcn_readlane(r_ll, (int)start)), gm = zx_u((uint32_t)__builtin_amdgcn_readlane(r_ml, (int)start)),
+                           go = zx_u((uint32_t)__builtin_amdgcn_readlane(r_off, (int)start)) - 3u;
+            zx.copy_lits(litpos + base_l, gl);
+            zx.copy_match(go, gm);
+            base_l += gl;
+            base_a += gl + gm;
+            ++start;
+            continue;
+        }
+        const bool in = (uint32_t)lane >= start && (uint32_t)lane < start + k;
+        const uint32_t t_ll = zx_u((uint32_t)__builtin_amdgcn_readlane((int)i_l, (int)(start + k - 1u))) - base_l,
+                       t_adv = zx_u((uint32_t)__builtin_amdgcn_readlane((int)i_a, (int)(start + k - 1u))) - base_a;
+        const uint32_t o_l = zx.op + (i_a - ll - ml - base_a); // where my literals go
+        const uint32_t o_m = o_l + ll;                          // where my match goes
+        const uint32_t li = zx.need_lit(litpos + base_l, t_ll + 1u) + (i_l - ll - base_l);
+        typedef uint32_t u32_a1 __attribute__((aligned(1)));
+        if (in && ll <= ZX_LL_OWN)
+        {
+            uint32_t b = 0;
+            for (; b + 4u <= ll; b += 4u) // four bytes per trip of this lane-divergent loop (unaligned LDS dwords)
+            {
+                const uint32_t r = zx.ring(o_l + b);
+                const uint32_t v = *reinterpret_cast<const u32_a1*>(s_lit + li + b);
+                if (r <= ZX_RING - 4u)
+                    *reinterpret_cast<u32_a1*>(s_ring + r) = v;
+                else
+                    for (uint32_t j = 0; j < 4u; ++j)
+                        s_ring[zx.ring(o_l + b + j)] = (uint8_t)(v >> (8u * j));
+            }
+            for (; b < ll; ++b)
+                s_ring[zx.ring(o_l + b)] = s_lit[li + b];
+        }
+        for (uint64_t big = __builtin_amdgcn_ballot_w64(in && ll > ZX_LL_OWN); big; big &= big - 1ull)
+        {
+            const int u = __builtin_ctzll(big);
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)ll, u), from = (uint32_t)__builtin_amdgcn_readlane((int)li, u),
+                           to = (uint32_t)__builtin_amdgcn_readlane((int)o_l, u);
+            for (uint32_t j = 4u * (uint32_t)lane; j < n; j += 256u)
+            {
+                const uint32_t r = zx.ring(to + j);
+                if (j + 4u <= n && r <= ZX_RING - 4u)
+                    *reinterpret_cast<u32_a1*>(s_ring + r) = *reinterpret_cast<const u32_a1*>(s_lit + from + j);
+                else
+                    for (uint32_t q = 0; q < 4u && j + q < n; ++q)
+                        s_ring[zx.ring(to + j + q)] = s_lit[from + j + q];
+            }
+        }
+        const uint32_t end = zx.op + t_adv;
+        const bool own = in && ml <= ZX_ML_LANE && !(ml > 20u && off > ZX_RING_SAFE); // my lane copies my match
+        const uint64_t ownm = __builtin_amdgcn_ballot_w64(own);
+        // a source the ring loses while this pass appends (it holds the 8 KiB below `end`) was flushed long ago: from global memory
+        const bool glob = in && ml != 0u && o_m - off + ZX_RING < end;
+        if (__builtin_amdgcn_ballot_w64(glob && o_m - off + ml + zx.g > zx.drained))
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            zx.drained = zx.flushed;
+        }
+        uint64_t pend = __builtin_amdgcn_ballot_w64(in && ml != 0u);
+        const uint64_t globm = __builtin_amdgcn_ballot_w64(glob && own);
+        if (globm)
+        {
+            if (glob && own) // at most 20 bytes, final data: five dwords
+            {
+                uint32_t w[5];
+#pragma unroll
+                for (uint32_t b = 0; b < 5u; ++b)
+                    w[b] = 4u * b < ml ? *reinterpret_cast<const u32_a1*>(zx.out_al + (o_m - off + 4u * b + zx.g)) : 0u;
+#pragma unroll
+                for (uint32_t b = 0; b < 20u; ++b)
+                    if (b < ml)
+                        s_ring[zx.ring(o_m + b)] = (uint8_t)(w[b >> 2] >> (8u * (b & 3u)));
+            }
+            pend &= ~globm;
+        }
+        while (pend)
+        {
+            const int first = __builtin_ctzll(pend);
+            if (!((ownm >> first) & 1ull))
+            {
+                // a long match (or a far source with more than 20 bytes): the whole wave
+                const uint32_t gm = (uint32_t)__builtin_amdgcn_readlane((int)ml, first), go = (uint32_t)__builtin_amdgcn_readlane((int)off, first),
+                               gd = (uint32_t)__builtin_amdgcn_readlane((int)o_m, first);
+                if (go >= 64u)
+                    for (uint32_t j = lane; j < gm; j += 64)
+                    {
+                        // a source byte the ring has lost by the end of this pass was flushed long ago (it lies more than 3 KiB
+                        // below `op`); everything younger -- unflushed bytes, this very match's own output -- is in the ring
+                        const uint32_t sp = gd - go + j;
+                        s_ring[zx.ring(gd + j)] = sp + ZX_RING >= end ? s_ring[zx.ring(sp)] : zx.out_al[sp + zx.g];
+                    }
+                else
+                    for (uint32_t j0 = 0; j0 < gm; j0 += 64) // byte j = seed byte j mod off
+                    {
+                        const uint32_t j = j0 + (uint32_t)lane;
+                        if (j < gm)
+                            s_ring[zx.ring(gd + j)] = s_ring[zx.ring(gd - go + j % go)];
+                    }
+                pend &= ~(1ull << first);
+                continue;
+            }
+            const int32_t rel_m = (int32_t)(o_m - zx.op);
+            const int32_t frontier = (int32_t)__builtin_amdgcn_readlane((uint32_t)rel_m, first);
+            const bool ready = ((pend >> lane) & 1ull) && own && (lane == first || rel_m - (int32_t)off + (int32_t)ml <= frontier);
+            if (ready)
+            {
+                const uint32_t so2 = o_m - off;
+                uint32_t b = 0;
+                if (off >= 4u)
+                    for (; b + 4u <= ml; b += 4u)
+                    {
+                        const uint32_t ra = zx.ring(so2 + b), rb = zx.ring(o_m + b);
+                        if (ra <= ZX_RING - 4u && rb <= ZX_RING - 4u)
+                            *reinterpret_cast<u32_a1*>(s_ring + rb) = *reinterpret_cast<const u32_a1*>(s_ring + ra);
+                        else
+                            for (uint32_t j = 0; j < 4u; ++j)
+                                s_ring[zx.ring(o_m + b + j)] = s_ring[zx.ring(so2 + b + j)];
+                    }
+                for (; b < ml; ++b)
+                    s_ring[zx.ring(o_m + b)] = s_ring[zx.ring(so2 + b)];
+            }
+            pend &= ~__builtin_amdgcn_ballot_w64(ready);
+        }
+        zx.op = end;
+        zx.maybe_flush();
+        base_l += t_ll;
+        base_a += t_adv;
+        start += k;
+    }
+    litpos += batch_ll;
+    produced += batch_adv;
+}
+
 // RECS: the sequences come as records {literal length:20 | match length:20 | offset value:24} from k_zstd_sub_entropy (`tables` is
 // then the record array, ZREC_MAX per slot) instead of from the bit-stream; everything after that is the same.
 template <bool RECS>
@@ -1942,190 +2733,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             bad = true; // the bit-stream must be consumed exactly
             break;
         }
-        // ---- vector unit: the serial decoder's checks for all of them at once, then execution ----
-        const uint32_t ll = (uint32_t)lane < cnt ? r_ll : 0u, ml = (uint32_t)lane < cnt ? r_ml : 0u, off = r_off - 3u;
-        uint32_t batch_ll, batch_adv;
-        uint32_t i_l = zx_scan_incl(ll), i_a = zx_scan_incl(ll + ml); // inclusive prefix sums: literals / output up to and including my sequence
-        {
-            batch_ll = (uint32_t)__builtin_amdgcn_readlane((int)i_l, 63);
-            batch_adv = (uint32_t)__builtin_amdgcn_readlane((int)i_a, 63);
-            // a piece may not use repeat offsets (ov <= 3); literals and output must fit; an offset may not reach below the piece
-            const bool wrong = (uint32_t)lane < cnt && (r_off <= 3u || ll > 131072u || ml > 131075u || litpos + i_l > pr.nlit ||
-                                                         produced + i_a > pr.expect || off > produced + i_a - ml);
-            if (__builtin_amdgcn_ballot_w64(wrong))
-            {
-                bad = true;
-                break;
-            }
-        }
-#ifdef LTHIP_ZB_PROF
-        unsigned long long t_mark = wall_clock64();
-        if (lane == 0)
-        {
-            atomicAdd(&g_zb_prof[24], t_mark - t_prof); // 24: records + checks
-            atomicAdd(&g_zb_prof[30], (unsigned long long)cnt);
-        }
-        t_prof = t_mark;
-#endif
-        // ---- execution: as many sequences as fit the ring's margins in ONE pass (usually the whole batch): the prefix sums of the
-        // checks place everything; ALL literals first (they depend on nothing), then the matches in dependency rounds -- short ones
-        // by their own lanes, a long one by the whole wave when its turn comes.  A sequence too big for a pass (a raw unit's 4 KiB
-        // of literals) goes through the whole wave alone. ----
-        uint32_t start = 0, base_l = 0, base_a = 0; // literals / output of the batch's sequences before `start`
-        while (start < cnt)
-        {
-            const bool fit = (uint32_t)lane >= start && (uint32_t)lane < cnt && i_a - base_a <= ZX_BATCH_ADV && i_l - base_l <= ZX_BATCH_LL;
-            const uint64_t fm = __builtin_amdgcn_ballot_w64(fit) >> start; // (the sums grow: the bits are a run from bit 0)
-            const uint32_t k = fm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fm);
-            if (k == 0u)
-            {
-                const uint32_t gl = zx_u((uint32_t)__builtin_amdgcn_readlane(r_ll, (int)start)), gm = zx_u((uint32_t)__builtin_amdgcn_readlane(r_ml, (int)start)),
-                               go = zx_u((uint32_t)__builtin_amdgcn_readlane(r_off, (int)start)) - 3u;
-                zx.copy_lits(litpos + base_l, gl);
-                zx.copy_match(go, gm);
-                base_l += gl;
-                base_a += gl + gm;
-                ++start;
-#ifdef LTHIP_ZB_PROF
-                t_mark = wall_clock64();
-                if (lane == 0)
-                    atomicAdd(&g_zb_prof[26], t_mark - t_prof); // 26: sequences by the whole wave
-                t_prof = t_mark;
-#endif
-                continue;
-            }
-            const bool in = (uint32_t)lane >= start && (uint32_t)lane < start + k;
-            const uint32_t t_ll = zx_u((uint32_t)__builtin_amdgcn_readlane((int)i_l, (int)(start + k - 1u))) - base_l,
-                           t_adv = zx_u((uint32_t)__builtin_amdgcn_readlane((int)i_a, (int)(start + k - 1u))) - base_a;
-            const uint32_t o_l = zx.op + (i_a - ll - ml - base_a); // where my literals go
-            const uint32_t o_m = o_l + ll;                          // where my match goes
-            const uint32_t li = zx.need_lit(litpos + base_l, t_ll + 1u) + (i_l - ll - base_l);
-            typedef uint32_t u32_a1 __attribute__((aligned(1)));
-            if (in && ll <= ZX_LL_OWN)
-            {
-                uint32_t b = 0;
-                for (; b + 4u <= ll; b += 4u) // four bytes per trip of this lane-divergent loop (unaligned LDS dwords)
-                {
-                    const uint32_t r = zx.ring(o_l + b);
-                    const uint32_t v = *reinterpret_cast<const u32_a1*>(s_lit + li + b);
-                    if (r <= ZX_RING - 4u)
-                        *reinterpret_cast<u32_a1*>(s_ring + r) = v;
-                    else
-                        for (uint32_t j = 0; j < 4u; ++j)
-                            s_ring[zx.ring(o_l + b + j)] = (uint8_t)(v >> (8u * j));
-                }
-                for (; b < ll; ++b)
-                    s_ring[zx.ring(o_l + b)] = s_lit[li + b];
-            }
-            for (uint64_t big = __builtin_amdgcn_ballot_w64(in && ll > ZX_LL_OWN); big; big &= big - 1ull)
-            {
-                const int u = __builtin_ctzll(big);
-                const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)ll, u), from = (uint32_t)__builtin_amdgcn_readlane((int)li, u),
-                               to = (uint32_t)__builtin_amdgcn_readlane((int)o_l, u);
-                for (uint32_t j = 4u * (uint32_t)lane; j < n; j += 256u)
-                {
-                    const uint32_t r = zx.ring(to + j);
-                    if (j + 4u <= n && r <= ZX_RING - 4u)
-                        *reinterpret_cast<u32_a1*>(s_ring + r) = *reinterpret_cast<const u32_a1*>(s_lit + from + j);
-                    else
-                        for (uint32_t q = 0; q < 4u && j + q < n; ++q)
-                            s_ring[zx.ring(to + j + q)] = s_lit[from + j + q];
-                }
-            }
-            const uint32_t end = zx.op + t_adv;
-            const bool own = in && ml <= ZX_ML_LANE && !(ml > 20u && off > ZX_RING_SAFE); // my lane copies my match
-            const uint64_t ownm = __builtin_amdgcn_ballot_w64(own);
-            // a source the ring loses while this pass appends (it holds the 8 KiB below `end`) was flushed long ago: from global memory
-            const bool glob = in && ml != 0u && o_m - off + ZX_RING < end;
-            if (__builtin_amdgcn_ballot_w64(glob && o_m - off + ml + zx.g > zx.drained))
-            {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_s_waitcnt(0);
-                zx.drained = zx.flushed;
-            }
-            uint64_t pend = __builtin_amdgcn_ballot_w64(in && ml != 0u);
-            const uint64_t globm = __builtin_amdgcn_ballot_w64(glob && own);
-            if (globm)
-            {
-                if (glob && own) // at most 20 bytes, final data: five dwords
-                {
-                    uint32_t w[5];
-#pragma unroll
-                    for (uint32_t b = 0; b < 5u; ++b)
-                        w[b] = 4u * b < ml ? *reinterpret_cast<const u32_a1*>(zx.out_al + (o_m - off + 4u * b + zx.g)) : 0u;
-#pragma unroll
-                    for (uint32_t b = 0; b < 20u; ++b)
-                        if (b < ml)
-                            s_ring[zx.ring(o_m + b)] = (uint8_t)(w[b >> 2] >> (8u * (b & 3u)));
-                }
-                pend &= ~globm;
-            }
-            while (pend)
-            {
-                const int first = __builtin_ctzll(pend);
-                if (!((ownm >> first) & 1ull))
-                {
-                    // a long match (or a far source with more than 20 bytes): the whole wave
-                    const uint32_t gm = (uint32_t)__builtin_amdgcn_readlane((int)ml, first), go = (uint32_t)__builtin_amdgcn_readlane((int)off, first),
-                                   gd = (uint32_t)__builtin_amdgcn_readlane((int)o_m, first);
-                    if (go >= 64u)
-                        for (uint32_t j = lane; j < gm; j += 64)
-                        {
-                            // a source byte the ring has lost by the end of this pass was flushed long ago (it lies more than 3 KiB
-                            // below `op`); everything younger -- unflushed bytes, this very match's own output -- is in the ring
-                            const uint32_t sp = gd - go + j;
-                            s_ring[zx.ring(gd + j)] = sp + ZX_RING >= end ? s_ring[zx.ring(sp)] : zx.out_al[sp + zx.g];
-                        }
-                    else
-                        for (uint32_t j0 = 0; j0 < gm; j0 += 64) // byte j = seed byte j mod off
-                        {
-                            const uint32_t j = j0 + (uint32_t)lane;
-                            if (j < gm)
-                                s_ring[zx.ring(gd + j)] = s_ring[zx.ring(gd - go + j % go)];
-                        }
-                    pend &= ~(1ull << first);
-                    continue;
-                }
-                const int32_t rel_m = (int32_t)(o_m - zx.op);
-                const int32_t frontier = (int32_t)__builtin_amdgcn_readlane((uint32_t)rel_m, first);
-                const bool ready = ((pend >> lane) & 1ull) && own && (lane == first || rel_m - (int32_t)off + (int32_t)ml <= frontier);
-                if (ready)
-                {
-                    const uint32_t so2 = o_m - off;
-                    uint32_t b = 0;
-                    if (off >= 4u)
-                        for (; b + 4u <= ml; b += 4u)
-                        {
-                            const uint32_t ra = zx.ring(so2 + b), rb = zx.ring(o_m + b);
-                            if (ra <= ZX_RING - 4u && rb <= ZX_RING - 4u)
-                                *reinterpret_cast<u32_a1*>(s_ring + rb) = *reinterpret_cast<const u32_a1*>(s_ring + ra);
-                            else
-                                for (uint32_t j = 0; j < 4u; ++j)
-                                    s_ring[zx.ring(o_m + b + j)] = s_ring[zx.ring(so2 + b + j)];
-                        }
-                    for (; b < ml; ++b)
-                        s_ring[zx.ring(o_m + b)] = s_ring[zx.ring(so2 + b)];
-                }
-                pend &= ~__builtin_amdgcn_ballot_w64(ready);
-            }
-            zx.op = end;
-            zx.maybe_flush();
-            base_l += t_ll;
-            base_a += t_adv;
-            start += k;
-#ifdef LTHIP_ZB_PROF
-            t_mark = wall_clock64();
-            if (lane == 0)
-            {
-                atomicAdd(&g_zb_prof[25], t_mark - t_prof); // 25: passes
-                atomicAdd(&g_zb_prof[29], 1ull);
-                atomicAdd(&g_zb_prof[28], (unsigned long long)__builtin_popcountll(globm));
-            }
-            t_prof = t_mark;
-#endif
-        }
-        litpos += batch_ll;
-        produced += batch_adv;
+        zx_batch(zx, s_ring, s_lit, lane, cnt, r_ll, r_ml, r_off, litpos, produced, pr.nlit, pr.expect, bad);
+        if (bad)
+            break;
     }
     if (!bad)
     {
@@ -2145,6 +2755,198 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (RECS)
             retry[it.payload] = 1u; // a run of sub-blocks has no serial piece decoder: the whole payload, serially
     }
+}
+
+// A payload of another encoder, its blocks one after the other (k_zstd_blk_entropy has decoded their streams): one wave per payload.
+// Raw and RLE blocks go through the ring like literals; a Compressed_Block's records are executed 64 at a time by zx_batch, after
+// their offset values have been turned into offsets IN ORDER (repeat offsets: RFC 8878 3.1.1.5, the history lives in three scalars).
+// Positions are relative to the frame's start, the ring and its flush state carry on from block to block; matches reach as far
+// back as the frame allows (sources that have left the ring are read from the output, as in the piece decoders).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_zstd_execute_payload(
+    const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t pb0, uint32_t pb1, const uint32_t* __restrict__ f_nblocks,
+    uint8_t* __restrict__ dst, const uint8_t* __restrict__ lit_scratch, const uint64_t* __restrict__ rec_scratch,
+    const ZPrep* __restrict__ fprep, uint32_t* __restrict__ retry)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZX_RING];
+    __shared__ __attribute__((aligned(16))) uint8_t s_lit[ZX_LIT];
+    const uint32_t b = pb0 + blockIdx.x;
+    if (b >= pb1)
+        return;
+    const uint32_t nb = f_nblocks[b];
+    if (nb == 0u || retry[b])
+        return;
+    const int lane = threadIdx.x;
+    const ZBlock blk = blocks[b];
+    const ZFrameHdr fh = z_frame_header(src + blk.src_off, blk.size);
+    const uint32_t content = (uint32_t)fh.content;
+    uint8_t* out = dst + blk.dst_off;
+    ZxOut zx;
+    zx.s_ring = s_ring;
+    zx.s_lit = s_lit;
+    zx.g = (uint32_t)((uintptr_t)out & 15u);
+    zx.out_al = out - zx.g;
+    zx.lh = 0;
+    zx.lit_al = src;
+    zx.nlit = 0;
+    zx.cap = content;
+    zx.lane = lane;
+    zx.op = 0;
+    zx.flushed = zx.drained = 0;
+    zx.lwa = -(int32_t)ZX_LIT;
+    bool bad = !fh.ok;
+    uint32_t produced = 0;
+    uint32_t rep0 = 1, rep1 = 4, rep2 = 8; // Repeated_Offsets at the start of a frame
+    for (uint32_t k = 0; k < nb && !bad; ++k)
+    {
+        const uint32_t fi = blk.zb_base + k;
+        const ZPrep pr = fprep[fi];
+        if (pr.status == ZP_SERIAL || pr.expect > content - produced || pr.expect > ZB)
+        {
+            bad = true;
+            break;
+        }
+        if (pr.log[0] == 2u)
+        {
+            // RLE_Block
+            const uint8_t v = src[pr.bits_off];
+            uint32_t left = pr.expect;
+            while (left)
+            {
+                const uint32_t c = left < ZX_FLUSH ? left : ZX_FLUSH;
+                for (uint32_t j = lane; j < c; j += 64)
+                    s_ring[zx.ring(zx.op + j)] = v;
+                zx.op += c;
+                left -= c;
+                zx.maybe_flush();
+            }
+            produced += pr.expect;
+            continue;
+        }
+        // the block's literal source: its literal buffer, or (Raw_Block) the block's own bytes
+        const uint8_t* lits = pr.log[0] == 1u ? src + pr.bits_off : lit_scratch + pr.bits_off;
+        zx.lh = (uint32_t)((uintptr_t)lits & 15u);
+        zx.lit_al = lits - zx.lh;
+        zx.nlit = pr.log[0] == 1u ? pr.expect : pr.nlit;
+        zx.lwa = -(int32_t)ZX_LIT - 64; // (nothing of the window is valid for this source)
+        if (pr.log[0] == 1u)
+        {
+            // Raw_Block: from the payload into the ring, 16 bytes per lane and trip, never reading past the block
+            typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+            typedef uint32_t u32_a1 __attribute__((aligned(1)));
+            const uint8_t* from = src + pr.bits_off;
+            uint32_t left = pr.expect;
+            while (left)
+            {
+                const uint32_t c = left < ZX_FLUSH ? left : ZX_FLUSH;
+                for (uint32_t j = 16u * (uint32_t)lane; j < c; j += 1024u)
+                {
+                    const uint32_t r0 = zx.ring(zx.op + j);
+                    if (j + 16u <= c && r0 <= ZX_RING - 16u)
+                    {
+                        const u32x4_a1 v = *reinterpret_cast<const u32x4_a1*>(from + j);
+                        *reinterpret_cast<u32_a1*>(s_ring + r0) = v.x;
+                        *reinterpret_cast<u32_a1*>(s_ring + r0 + 4u) = v.y;
+                        *reinterpret_cast<u32_a1*>(s_ring + r0 + 8u) = v.z;
+                        *reinterpret_cast<u32_a1*>(s_ring + r0 + 12u) = v.w;
+                    }
+                    else
+                        for (uint32_t q = 0; q < 16u && j + q < c; ++q)
+                            s_ring[zx.ring(zx.op + j + q)] = from[j + q];
+                }
+                from += c;
+                zx.op += c;
+                left -= c;
+                zx.maybe_flush();
+            }
+            produced += pr.expect;
+            continue;
+        }
+        const uint64_t* recs = rec_scratch + (((uint64_t)pr.log[2] << 32) | pr.log[1]);
+        const uint32_t block_start = produced;
+        uint32_t litpos = 0;
+        for (uint32_t s0 = 0; s0 < pr.nbseq && !bad; s0 += 64u)
+        {
+            const uint32_t cnt = pr.nbseq - s0 < 64u ? pr.nbseq - s0 : 64u;
+            const uint64_t r = (uint32_t)lane < cnt ? recs[s0 + (uint32_t)lane] : 0ull;
+            const uint32_t r_ll = (uint32_t)r & 0xFFFFFu, r_ml = (uint32_t)(r >> 20) & 0xFFFFFu;
+            uint32_t r_off = (uint32_t)(r >> 40); // Offset_Value: 1..3 = repeat offsets
+            const uint64_t repm = __builtin_amdgcn_ballot_w64((uint32_t)lane < cnt && r_off <= 3u);
+            if (repm == 0ull)
+            {
+                // no repeat offset in the batch: the history is simply its last three offsets
+                const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)r_off, (int)(cnt - 1u)) - 3u;
+                if (cnt >= 3u)
+                {
+                    rep2 = (uint32_t)__builtin_amdgcn_readlane((int)r_off, (int)(cnt - 3u)) - 3u;
+                    rep1 = (uint32_t)__builtin_amdgcn_readlane((int)r_off, (int)(cnt - 2u)) - 3u;
+                }
+                else if (cnt == 2u)
+                {
+                    rep2 = rep0;
+                    rep1 = (uint32_t)__builtin_amdgcn_readlane((int)r_off, 0) - 3u;
+                }
+                else
+                {
+                    rep2 = rep1;
+                    rep1 = rep0;
+                }
+                rep0 = o1;
+            }
+            else
+            {
+                for (uint32_t q = 0; q < cnt; ++q)
+                {
+                    const uint32_t ov = (uint32_t)__builtin_amdgcn_readlane((int)r_off, (int)q);
+                    uint32_t o;
+                    if (ov > 3u)
+                    {
+                        o = ov - 3u;
+                        rep2 = rep1;
+                        rep1 = rep0;
+                        rep0 = o;
+                    }
+                    else
+                    {
+                        const uint32_t idx = ov + ((uint32_t)__builtin_amdgcn_readlane((int)r_ll, (int)q) == 0u ? 1u : 0u); // 1..4
+                        if (idx == 1u)
+                            o = rep0;
+                        else
+                        {
+                            o = idx == 4u ? rep0 - 1u : idx == 2u ? rep1 : rep2;
+                            if (idx >= 3u)
+                                rep2 = rep1;
+                            rep1 = rep0;
+                            rep0 = o;
+                        }
+                        if ((uint32_t)lane == q)
+                            r_off = o + 3u; // (0 becomes 3: zx_batch rejects it like the serial decoder does)
+                    }
+                }
+                rep0 = zx_u(rep0);
+                rep1 = zx_u(rep1);
+                rep2 = zx_u(rep2);
+            }
+            zx_batch(zx, s_ring, s_lit, lane, cnt, r_ll, r_ml, r_off, litpos, produced, pr.nlit, content, bad);
+        }
+        if (!bad)
+        {
+            // the block's last literals; it must have regenerated what k_zstd_blk_entropy counted
+            const uint32_t rest = pr.nlit - litpos;
+            if (produced - block_start + rest != pr.expect)
+                bad = true;
+            else
+            {
+                zx.copy_lits(litpos, rest);
+                produced += rest;
+            }
+        }
+    }
+    if (!bad && produced != content)
+        bad = true;
+    if (!bad)
+        zx.flush(zx.op + zx.g);
+    if (bad && lane == 0)
+        retry[b] = 1u; // the serial decoder gives the verdict (and the bytes)
 }
 
 } // namespace
@@ -2185,14 +2987,22 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
         return err;
     if ((err = lthip_scratch(ctx, S_Z_WORK, (size_t)(ZD_LIT_MAX + 64u) * nwg, &d_lits)))
         return err;
-    if ((err = lthip_scratch(ctx, S_Z_ENC, sizeof(ZItem) * (size_t)nitems + 16 + 4 * (size_t)block_count + 4 * (size_t)(nitems / 8192u + 2u), &d_items)))
-        return err;
-    uint32_t* d_count = (uint32_t*)((uint8_t*)d_items + sizeof(ZItem) * (size_t)nitems);
-    uint32_t* d_retry = d_count + 4; // per payload: the sub-block decoder gives it back to the serial one
+    // frames of other encoders, block-parallel: their blocks sit at FIXED slots (zb_base + k) of a second item list
     constexpr uint32_t ZROUND = 8192u;
     const size_t nrounds = (size_t)((nitems + ZROUND - 1) / ZROUND);
-    uint32_t* d_tickets = d_retry + block_count; // one work counter per round
-    LTHIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 16 + 4 * ((size_t)block_count + nrounds), ctx->stream));
+    const size_t ncounters = 8 + (size_t)block_count * 2 + nrounds + 8; // item count, totals | retry | f_nblocks | tickets | foreign ticket, arenas
+    if ((err = lthip_scratch(ctx, S_Z_ENC, sizeof(ZItem) * (size_t)nitems * 2 + sizeof(ZPrep) * (size_t)nitems + 4 * ncounters + 64, &d_items)))
+        return err;
+    ZItem* d_fitems = (ZItem*)d_items + nitems;
+    ZPrep* d_fprep = (ZPrep*)(d_fitems + nitems);
+    uint32_t* d_count = (uint32_t*)(d_fprep + nitems);
+    uint32_t* d_retry = d_count + 8; // per payload: the lane-parallel decoders give it back to the serial one
+    uint32_t* d_fnb = d_retry + block_count; // per payload: blocks of a frame of another encoder (0: not decoded that way)
+    uint32_t* d_tickets = d_fnb + block_count; // one work counter per round
+    uint32_t* d_ftickets = d_tickets + nrounds + (((nrounds + (size_t)block_count * 2) & 1) ? 1 : 0); // (8-byte aligned: the arena counters follow)
+    unsigned long long* d_bump = (unsigned long long*)(d_ftickets + 2);
+    LTHIP_CHECK(ctx, hipMemsetAsync(d_fitems, 0, sizeof(ZItem) * (size_t)nitems, ctx->stream));
+    LTHIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 4 * ncounters, ctx->stream));
     if ((err = lthip_stage_upload(ctx, d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, ctx->stream)))
         return err;
     const uint32_t dbg = (uint32_t)(getenv("LTHIP_ZSTD_DBG") ? atoi(getenv("LTHIP_ZSTD_DBG")) : 0); // 1: never decode by pieces
@@ -2203,7 +3013,7 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     }
     LaunchTimer t(ctx, LTHIP_K_OTHER);
     hipLaunchKernelGGL(k_zstd_split, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
-                       block_count, (ZItem*)d_items, d_count, d_out_sizes, dbg);
+                       block_count, (ZItem*)d_items, d_count, d_out_sizes, dbg, d_fitems, d_fnb);
     hipLaunchKernelGGL(k_zstd_decode<false>, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                        (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes, (const ZPrep*)nullptr);
     LTHIP_LAUNCH_CHECK(ctx);
@@ -2214,12 +3024,13 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     ZPrep* d_prep = nullptr;
     {
         const uint32_t per_round = nitems < ZROUND ? (uint32_t)nitems : ZROUND;
+        const uint32_t slots = per_round;
         void *d_plits, *d_tabs, *d_pr, *d_recs;
-        if ((err = lthip_scratch(ctx, S_Z_LITS, (size_t)(ZD_LIT_MAX + 64u) * per_round + 4096, &d_plits)))
+        if ((err = lthip_scratch(ctx, S_Z_LITS, (size_t)(ZD_LIT_MAX + 64u) * slots + 4096, &d_plits)))
             return err;
         if ((err = lthip_scratch(ctx, S_Z_RECS, (size_t)3u * ZT_ENTRIES * 8u * per_round, &d_tabs)))
             return err;
-        if ((err = lthip_scratch(ctx, S_Z_SUB, (size_t)ZREC_MAX * 8u * per_round, &d_recs)))
+        if ((err = lthip_scratch(ctx, S_Z_SUB, (size_t)ZREC_MAX * 8u * slots, &d_recs)))
             return err;
         if ((err = lthip_scratch(ctx, S_LZ4_META, sizeof(ZPrep) * (size_t)nitems, &d_pr)))
             return err;
@@ -2250,6 +3061,33 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
             hipLaunchKernelGGL(k_zstd_execute<true>, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                                (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, (const uint8_t*)d_plits,
                                (const uint64_t*)d_recs, (const ZPrep*)d_prep, &d_prep->status, d_retry);
+            LTHIP_LAUNCH_CHECK(ctx);
+        }
+    }
+    // frames of other encoders: the streams of every block on a wave of its own, then a payload's blocks in order on one wave -- all
+    // payloads at once (a payload is ONE chain of dependent copies: only many of them fill the machine).  How many there are, and how
+    // large the literal and record arenas must be, is known after k_zstd_split: the one place where this call waits for the device.
+    if (!(dbg & 9u))
+    {
+        uint32_t totals[4] = {0, 0, 0, 0};
+        LTHIP_CHECK(ctx, hipMemcpyAsync(totals, d_count + 4, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
+        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        const uint64_t f_blocks = totals[0], f_bytes = ((uint64_t)totals[3] << 32) | totals[2];
+        if (f_blocks)
+        {
+            const uint64_t lit_cap = f_bytes + 96ull * f_blocks + 4096ull, rec_cap = f_bytes / 6ull + 64ull * f_blocks + 4096ull;
+            void *d_flits, *d_frecs;
+            if ((err = lthip_scratch(ctx, S_Z_LITS, (size_t)lit_cap + 4096, &d_flits)))
+                return err;
+            if ((err = lthip_scratch(ctx, S_Z_SUB, (size_t)rec_cap * 8u, &d_frecs)))
+                return err;
+            const uint32_t n = (uint32_t)nitems;
+            hipLaunchKernelGGL(k_zstd_blk_entropy, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZItem*)d_fitems, 0u, n,
+                               (uint8_t*)d_flits, (uint64_t*)d_frecs, d_fprep, d_retry, d_ftickets, d_bump, lit_cap, rec_cap);
+            LTHIP_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL(k_zstd_execute_payload, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks, 0u,
+                               block_count, (const uint32_t*)d_fnb, (uint8_t*)d_dst, (const uint8_t*)d_flits, (const uint64_t*)d_frecs,
+                               (const ZPrep*)d_fprep, d_retry);
             LTHIP_LAUNCH_CHECK(ctx);
         }
     }

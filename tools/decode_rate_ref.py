@@ -24,3 +24,20 @@ for rep in range(2):
     t = time.perf_counter() - t0
 ok = (u32(out) == BLOCK).all() and all((back[i * BLOCK:(i + 1) * BLOCK].cpu().numpy() == raws[i]).all() for i in range(0, nb, max(1, nb // 4)))
 print(f"lz4 (sliding-window payloads): {nb} blocks of 8 MiB, ratio {nb * BLOCK / sum(len(c) for c in comps):.3f}, decode {t * 1e3:.1f} ms = {nb * BLOCK / t / 1e9:.2f} GB/s, {'ok' if ok else 'MISMATCH'}")
+
+# the same for zstd frames written by the REFERENCE encoder (longtail's default setting): blocks that depend on each other (window =
+# the frame, repeat offsets, repeated tables) -- one wave per payload, the serial core
+try:
+    from tests._libs import ref as get_ref
+    r = get_ref()
+    zc = [r.compress(1, r.zstd_default, x) for x in raws]
+    zdev, zoffs = to_device(zc)
+    for rep in range(2):
+        t0 = time.perf_counter()
+        out = ctx.zstd_decompress_blocks(zdev, zoffs, [len(c) for c in zc], back, b_off, [BLOCK] * nb)
+        ctx.sync()
+        t = time.perf_counter() - t0
+    ok = (u32(out) == BLOCK).all() and all((back[i * BLOCK:(i + 1) * BLOCK].cpu().numpy() == raws[i]).all() for i in range(0, nb, max(1, nb // 4)))
+    print(f"zstd (reference encoder's frames): {nb} blocks of 8 MiB, ratio {nb * BLOCK / sum(len(c) for c in zc):.3f}, decode {t * 1e3:.1f} ms = {nb * BLOCK / t / 1e9:.2f} GB/s, {'ok' if ok else 'MISMATCH'}")
+except Exception as e:  # oracle/_ref not built
+    print("zstd reference frames: skipped:", e)
