@@ -815,6 +815,12 @@ struct ZPrep
     uint32_t status;    // ZP_READY: literals + tables exported; ZP_DONE: nothing left to do; ZP_SERIAL: the serial piece decoder takes it
     uint32_t log[3];    // table logs (0: an RLE table, one entry)
     uint32_t expect;    // bytes the piece has to produce
+    // blocks of other encoders' frames (k_zstd_blk_entropy -> k_zstd_blk_sequences -> k_zstd_execute_payload): bits_off = where the
+    // block's literals are in the literal arena (Raw / RLE blocks: where its bytes are in the source), log[0] = 0 compressed | 1 raw |
+    // 2 RLE, log[1] = the three table logs (LL | OF << 8 | ML << 16), and:
+    uint64_t rec_at;    // first record of the block in the record arena
+    uint32_t seq_off;   // the sequences' bit-stream: offset inside the payload ...
+    uint32_t seq_size;  // ... and bytes
 };
 constexpr uint32_t ZREC_MAX = ZB_MAX_UNITS * ZB_UNIT_SEQ_MAX; // sequence records per piece of sub-blocks
 constexpr uint32_t ZT_ENTRIES = 512u; // per table and piece: u64 {BYTE OFFSET (within the piece's three tables) of the new state's base entry:16 |
@@ -1734,7 +1740,8 @@ __device__ __forceinline__ ZfBlk zf_parse(const uint8_t* c, uint32_t csz)
 __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restrict__ src, const ZItem* __restrict__ fitems, uint32_t slot0, uint32_t slot1,
                                                          uint8_t* __restrict__ lit_scratch, uint64_t* __restrict__ rec_scratch,
                                                          ZPrep* __restrict__ fprep, uint32_t* __restrict__ retry, uint32_t* __restrict__ ticket,
-                                                         unsigned long long* __restrict__ bump, uint64_t lit_cap, uint64_t rec_cap)
+                                                         unsigned long long* __restrict__ bump, uint64_t lit_cap, uint64_t rec_cap,
+                                                         uint64_t* __restrict__ tabs)
 {
     __shared__ ZdShared sh;
     __shared__ uint4 s_streams[4];
@@ -1755,6 +1762,10 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
         if (it.kind != 4u)
             continue;
         __syncthreads();
+#ifdef LTHIP_ZB_PROF
+        if (lane == 0)
+            g_zb_last[blockIdx.x] = wall_clock64();
+#endif
         const uint8_t* p = src + it.src_off; // the payload
         ZPrep pr;
         pr.bits_off = 0;
@@ -1762,6 +1773,8 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
         pr.log[0] = pr.log[1] = pr.log[2] = 0;
         pr.expect = 0;
         pr.status = ZP_SERIAL;
+        pr.rec_at = 0;
+        pr.seq_off = pr.seq_size = 0;
         bool bad = false;
         if (lane == 0)
         {
@@ -1799,7 +1812,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
                 bad = true;
         }
         uint8_t* lits = lit_scratch + lit_at;
-        uint64_t* recs = rec_scratch + rec_at;
+        (void)rec_scratch; // (the records are k_zstd_blk_sequences': only their place is drawn here)
         // ---- who set the tree / the tables last?  (the section headers of the blocks up to mine) ----
         uint32_t tree_at = 0, tree_size = 0, tab_at[3] = {0, 0, 0}, tab_end[3] = {0, 0, 0}, tab_modes[3] = {0, 0, 0};
         bool have_tree = false, have_tab[3] = {false, false, false};
@@ -1840,6 +1853,9 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
             if ((me.lmode == 3u && !have_tree) || (me.nbseq && !(have_tab[0] && have_tab[1] && have_tab[2])))
                 bad = true; // nothing to repeat: the serial decoder says so
         }
+#ifdef LTHIP_ZB_PROF
+        ZB_MARK(19);
+#endif
         // ---- the three tables (descriptions by lane 0 from staged bytes, tables by all lanes), then the tree ----
         if (!bad && me.nbseq)
         {
@@ -1911,6 +1927,9 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
             bad = sh.v[ZDV_ERR] != 0u;
             tree_bytes = me.lmode == 2u ? sh.v[ZDV_LEN] : 0u;
         }
+#ifdef LTHIP_ZB_PROF
+        ZB_MARK(20);
+#endif
         // ---- literals ----
         uint32_t nstr_total = 0;
         if (!bad)
@@ -1966,10 +1985,11 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
         __syncthreads();
         if (!bad && nstr_total)
         {
-            // the streams: lanes 0 and 1, two each (as in k_zstd_sub_entropy)
+            // the streams: one per lane (a block has at most four; the loop is k_zstd_sub_entropy's, its second stream unused: this
+            // wave has lanes to spare, and a lane alone with one chain finishes it sooner than two lanes with two chains each)
             const uint32_t tl = sh.huf_log;
-            const uint32_t ka = (uint32_t)lane, kb = ka + 2u;
-            const bool has_a = ka < nstr_total && ka < 2u, has_b = kb < nstr_total && ka < 2u;
+            const uint32_t ka = (uint32_t)lane, kb = ka + 64u;
+            const bool has_a = ka < nstr_total, has_b = kb < nstr_total;
             const uint4 sa = has_a ? s_streams[ka] : make_uint4(0, 0, 0, 0), sb2 = has_b ? s_streams[kb] : make_uint4(0, 0, 0, 0);
             uint32_t pa = 0, pb = 0, ia = 0, ib = 0;
             ZsWin wa, wb;
@@ -2054,8 +2074,11 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
         if (__builtin_amdgcn_ballot_w64(bad))
             bad = true;
         __syncthreads();
+#ifdef LTHIP_ZB_PROF
+        ZB_MARK(21);
+#endif
         // ---- the tables, packed; the sequences (lane 0) ----
-        uint32_t log_l = 0, log_o = 0, log_m = 0, sum_ll = 0, sum_ml = 0;
+        uint32_t log_l = 0, log_o = 0, log_m = 0;
         if (!bad && me.nbseq)
         {
             for (int t = 0; t < 3; ++t)
@@ -2134,23 +2157,33 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
                 skip = sh.v[ZDV_LL];
             }
             const uint32_t sat = at + skip, send = c0 + bsize;
-            zs_seq_lanes<false>(!bad && lane == 0, p + sat, sat < send ? send - sat : 0u, (uint32_t)(it.src_off + sat > 64u ? 64u : it.src_off + sat),
-                                me.nbseq, log_l, log_o, log_m, pk_ll, pk_of, pk_ml, recs, bad, sum_ll, sum_ml);
-            sum_ll = (uint32_t)__builtin_amdgcn_readfirstlane(sum_ll);
-            sum_ml = (uint32_t)__builtin_amdgcn_readfirstlane(sum_ml);
-            if (__builtin_amdgcn_ballot_w64(bad))
-                bad = true;
-            if (!bad && (sum_ll > me.nlit || me.nlit + sum_ml > ZB))
-                bad = true;
+            // the packed tables go to the block's place in the table arena: k_zstd_blk_sequences decodes the bit-streams of 64 blocks
+            // per wave, a lane each, reading its states' entries from there (ONE lane of this wave would take 2.3 ms per block)
+            if (!bad)
+            {
+                uint64_t* tp = tabs + (uint64_t)i * 1280u;
+                for (uint32_t x = lane; x < 512u; x += 64)
+                {
+                    tp[x] = pk_ll[x];
+                    tp[512u + x] = pk_ml[x];
+                }
+                for (uint32_t x = lane; x < 256u; x += 64)
+                    tp[1024u + x] = pk_of[x];
+                pr.seq_off = sat;
+                pr.seq_size = sat < send ? send - sat : 0u;
+                pr.log[1] = log_l | (log_o << 8) | (log_m << 16);
+            }
         }
         else if (!bad && me.nlit > ZB)
             bad = true;
+#ifdef LTHIP_ZB_PROF
+        ZB_MARK(23);
+#endif
         pr.nbseq = me.nbseq;
         pr.nlit = me.nlit;
-        pr.expect = me.nlit + sum_ml; // what the block regenerates
-        pr.bits_off = lit_at;          // where its literals are ...
-        pr.log[1] = (uint32_t)rec_at;  // ... and its records
-        pr.log[2] = (uint32_t)(rec_at >> 32);
+        pr.expect = me.nlit; // (+ the match lengths: k_zstd_blk_sequences)
+        pr.bits_off = lit_at;
+        pr.rec_at = rec_at;
         pr.status = bad ? ZP_SERIAL : ZP_READY;
         if (lane == 0)
         {
@@ -2158,6 +2191,49 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
             if (bad)
                 retry[it.payload] = 1u;
         }
+    }
+}
+
+// The sequence bit-streams of other encoders' blocks: 64 blocks per wave, a lane each (zs_seq_lanes), every lane reading the entries of
+// ITS block's tables from the table arena (three 8-byte gathers per sequence: the machine has the lanes and the L2 for them; one lane
+// with its tables in shared memory, the other 63 idle, is what made k_zstd_blk_entropy take 2.3 ms per block).
+__global__ __launch_bounds__(64) void k_zstd_blk_sequences(const uint8_t* __restrict__ src, const ZItem* __restrict__ fitems, uint32_t nslots,
+                                                          const uint64_t* __restrict__ tabs, uint64_t* __restrict__ rec_scratch,
+                                                          ZPrep* __restrict__ fprep, uint32_t* __restrict__ retry)
+{
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    ZItem it;
+    it.kind = 0;
+    it.src_off = 0;
+    it.payload = 0;
+    if (i < nslots)
+        it = fitems[i];
+    ZPrep pr;
+    pr.status = ZP_SERIAL;
+    pr.nbseq = pr.nlit = pr.seq_off = pr.seq_size = 0;
+    pr.log[0] = 1;
+    pr.log[1] = 0;
+    pr.rec_at = 0;
+    if (it.kind == 4u)
+        pr = fprep[i];
+    const bool act = it.kind == 4u && pr.status == ZP_READY && pr.log[0] == 0u && pr.nbseq != 0u;
+    const uint64_t* tp = tabs + (uint64_t)i * 1280u;
+    bool bad = false;
+    uint32_t sum_ll = 0, sum_ml = 0;
+    const uint64_t at = it.src_off + pr.seq_off;
+    zs_seq_lanes<false>(act, src + at, pr.seq_size, (uint32_t)(at > 64u ? 64u : at), pr.nbseq, pr.log[1] & 255u, (pr.log[1] >> 8) & 255u,
+                        (pr.log[1] >> 16) & 255u, tp, tp + 1024, tp + 512, rec_scratch + pr.rec_at, bad, sum_ll, sum_ml);
+    if (act)
+    {
+        if (!bad && (sum_ll > pr.nlit || pr.nlit + sum_ml > ZB))
+            bad = true;
+        if (bad)
+        {
+            fprep[i].status = ZP_SERIAL;
+            retry[it.payload] = 1u;
+        }
+        else
+            fprep[i].expect = pr.nlit + sum_ml; // what the block regenerates
     }
 }
 
@@ -2659,6 +2735,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     uint32_t litpos = 0, produced = 0; // what the decoded sequences consume / produce (scalar bookkeeping of the checks)
 #ifdef LTHIP_ZB_PROF
     unsigned long long t_prof = wall_clock64();
+    (void)t_prof;
 #endif
     for (uint32_t s0 = 0; s0 < pr.nbseq && !bad; s0 += 64u)
     {
@@ -2795,6 +2872,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     zx.lwa = -(int32_t)ZX_LIT;
     bool bad = !fh.ok;
     uint32_t produced = 0;
+#ifdef LTHIP_ZB_PROF
+    unsigned long long acc_rep = 0, acc_bat = 0; // 100 MHz ticks: records + repeat offsets / zx_batch
+#endif
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8; // Repeated_Offsets at the start of a frame
     for (uint32_t k = 0; k < nb && !bad; ++k)
     {
@@ -2861,13 +2941,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             produced += pr.expect;
             continue;
         }
-        const uint64_t* recs = rec_scratch + (((uint64_t)pr.log[2] << 32) | pr.log[1]);
+        const uint64_t* recs = rec_scratch + pr.rec_at;
         const uint32_t block_start = produced;
         uint32_t litpos = 0;
+        uint64_t r_next = (uint32_t)lane < pr.nbseq ? recs[lane] : 0ull; // (a lone wave: the next batch's records are loaded a batch ahead)
+#ifdef LTHIP_ZB_PROF
+        unsigned long long t0 = wall_clock64();
+#endif
         for (uint32_t s0 = 0; s0 < pr.nbseq && !bad; s0 += 64u)
         {
             const uint32_t cnt = pr.nbseq - s0 < 64u ? pr.nbseq - s0 : 64u;
-            const uint64_t r = (uint32_t)lane < cnt ? recs[s0 + (uint32_t)lane] : 0ull;
+            const uint64_t r = r_next;
+            r_next = s0 + 64u + (uint32_t)lane < pr.nbseq ? recs[s0 + 64u + (uint32_t)lane] : 0ull;
             const uint32_t r_ll = (uint32_t)r & 0xFFFFFu, r_ml = (uint32_t)(r >> 20) & 0xFFFFFu;
             uint32_t r_off = (uint32_t)(r >> 40); // Offset_Value: 1..3 = repeat offsets
             const uint64_t repm = __builtin_amdgcn_ballot_w64((uint32_t)lane < cnt && r_off <= 3u);
@@ -2926,7 +3011,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 rep1 = zx_u(rep1);
                 rep2 = zx_u(rep2);
             }
+#ifdef LTHIP_ZB_PROF
+            const unsigned long long t1 = wall_clock64();
+#endif
             zx_batch(zx, s_ring, s_lit, lane, cnt, r_ll, r_ml, r_off, litpos, produced, pr.nlit, content, bad);
+#ifdef LTHIP_ZB_PROF
+            const unsigned long long t2 = wall_clock64();
+            acc_rep += t1 - t0;
+            acc_bat += t2 - t1;
+            t0 = t2;
+#endif
         }
         if (!bad)
         {
@@ -2947,6 +3041,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         zx.flush(zx.op + zx.g);
     if (bad && lane == 0)
         retry[b] = 1u; // the serial decoder gives the verdict (and the bytes)
+#ifdef LTHIP_ZB_PROF
+    if (lane == 0)
+    {
+        atomicAdd(&g_zb_prof[24], acc_rep);
+        atomicAdd(&g_zb_prof[25], acc_bat);
+    }
+#endif
 }
 
 } // namespace
@@ -3082,8 +3183,14 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
             if ((err = lthip_scratch(ctx, S_Z_SUB, (size_t)rec_cap * 8u, &d_frecs)))
                 return err;
             const uint32_t n = (uint32_t)nitems;
+            void* d_ftabs;
+            if ((err = lthip_scratch(ctx, S_Z_RECS, (size_t)n * 1280u * 8u, &d_ftabs))) // (10 KiB of packed tables per block slot)
+                return err;
             hipLaunchKernelGGL(k_zstd_blk_entropy, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZItem*)d_fitems, 0u, n,
-                               (uint8_t*)d_flits, (uint64_t*)d_frecs, d_fprep, d_retry, d_ftickets, d_bump, lit_cap, rec_cap);
+                               (uint8_t*)d_flits, (uint64_t*)d_frecs, d_fprep, d_retry, d_ftickets, d_bump, lit_cap, rec_cap, (uint64_t*)d_ftabs);
+            LTHIP_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL(k_zstd_blk_sequences, dim3((n + 63u) / 64u), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZItem*)d_fitems, n,
+                               (const uint64_t*)d_ftabs, (uint64_t*)d_frecs, d_fprep, d_retry);
             LTHIP_LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(k_zstd_execute_payload, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks, 0u,
                                block_count, (const uint32_t*)d_fnb, (uint8_t*)d_dst, (const uint8_t*)d_flits, (const uint64_t*)d_frecs,
