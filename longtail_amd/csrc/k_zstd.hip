@@ -600,6 +600,7 @@ __device__ __forceinline__ uint32_t z_wave_scan_excl(uint32_t v, int lane, uint3
 // one frame that fills the payload, content size stated, no dictionary.  Its blocks are listed at FIXED places (slot zb_base + k of
 // `fitems`): k_zstd_blk_entropy decodes the streams of every block on a wave of its own (literals and sequence records to scratch),
 // k_zstd_execute<2> executes a payload's blocks one after the other.  Frame header: RFC 8878 3.1.1.1.
+constexpr uint32_t ZF_SLOTS = 8u; // block slots of a payload of another encoder per 128 KiB of its capacity
 struct ZFrameHdr
 {
     uint32_t size;      // bytes of the frame header
@@ -635,7 +636,8 @@ __device__ __forceinline__ ZFrameHdr z_frame_header(const uint8_t* p, uint32_t a
     h.ok = true;
     return h;
 }
-__device__ bool z_split_foreign(const uint8_t* p, const ZBlock blk, uint32_t b, ZItem* fitems, uint32_t* f_nblocks, uint32_t* out_sizes, uint32_t* totals)
+__device__ bool z_split_foreign(const uint8_t* p, const ZBlock blk, uint32_t b, ZItem* fitems, uint32_t* f_nblocks, uint32_t* out_sizes, uint32_t* totals,
+                                uint32_t* flist)
 {
     const ZFrameHdr h = z_frame_header(p, blk.size);
     if (!h.ok || h.content == 0u || h.content > (uint64_t)blk.dst_cap || h.content > 0x7F000000ull)
@@ -644,7 +646,7 @@ __device__ bool z_split_foreign(const uint8_t* p, const ZBlock blk, uint32_t b, 
     bool last = false;
     while (!last)
     {
-        if (k >= blk.nzb || blk.size - pos < 3u)
+        if (k >= ZF_SLOTS * blk.nzb || blk.size - pos < 3u) // (blocks of 16 KiB on average still fit: the block splitter of the high levels)
             return false;
         const uint32_t bh = (uint32_t)p[pos] | ((uint32_t)p[pos + 1] << 8) | ((uint32_t)p[pos + 2] << 16);
         const uint32_t type = (bh >> 1) & 3u, bsize = bh >> 3;
@@ -660,18 +662,21 @@ __device__ bool z_split_foreign(const uint8_t* p, const ZBlock blk, uint32_t b, 
         it.kind = 4;
         it.aux = k;
         it.pad = pos;
-        fitems[blk.zb_base + k] = it;
+        fitems[blk.pad + k] = it;
         pos += 3u + body;
         ++k;
     }
     if (pos + 4u * h.checksum != blk.size)
     {
-        for (uint32_t j = 0; j < k; ++j)
-            fitems[blk.zb_base + j].kind = 0;
-        return false; // more frames behind this one: the serial decoder
+        return false; // more frames behind this one: the serial decoder (nothing is listed yet)
     }
     f_nblocks[b] = k;
     out_sizes[b] = (uint32_t)h.content; // (replaced when the payload goes back to the serial decoder)
+    {
+        const uint32_t at = atomicAdd(&totals[1], k); // the work list of k_zstd_blk_entropy
+        for (uint32_t j = 0; j < k; ++j)
+            flist[at + j] = blk.pad + j;
+    }
     atomicAdd(&totals[0], k);                                          // blocks listed this way, and the bytes they regenerate:
     atomicAdd((unsigned long long*)&totals[2], (unsigned long long)h.content); // the host sizes the literal and record arenas from these
     return true;
@@ -680,7 +685,7 @@ __device__ bool z_split_foreign(const uint8_t* p, const ZBlock blk, uint32_t b, 
 __global__ __launch_bounds__(64) void k_zstd_split(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t nblocks,
                                                    ZItem* __restrict__ items, uint32_t* __restrict__ item_count,
                                                    uint32_t* __restrict__ out_sizes, uint32_t dbg, ZItem* __restrict__ fitems,
-                                                   uint32_t* __restrict__ f_nblocks)
+                                                   uint32_t* __restrict__ f_nblocks, uint32_t* __restrict__ flist)
 {
     const uint32_t b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(64) void k_zstd_split(const uint8_t* __restrict__ s
         if (lane == 0)
         {
             const bool marked = blk.size >= ZHDR + 3u + ZTRAILER && z_is_trailer(p + blk.size - ZTRAILER);
-            if (marked || (dbg & 9u) || !z_split_foreign(p, blk, b, fitems, f_nblocks, out_sizes, item_count + 4)) // (dbg 8: no block-parallel path for foreign frames)
+            if (marked || (dbg & 9u) || !z_split_foreign(p, blk, b, fitems, f_nblocks, out_sizes, item_count + 4, flist)) // (dbg 8: no block-parallel path for foreign frames)
                 z_split_walk(p, blk, b, items, item_count, out_sizes, dbg);
         }
         return;
@@ -1099,7 +1104,7 @@ __device__ __forceinline__ void zs_seq_lanes(bool act, const uint8_t* stream, ui
             const uint32_t ob = o0 >> 24, mb = m0 >> 24, lb = l0 >> 24;
             const uint32_t nbl = (l0 >> 16) & 255u, nbm = (m0 >> 16) & 255u, nbo = (o0 >> 16) & 255u;
             const bool more = k + 1u < nbseq;
-            const uint32_t n1 = ob + mb + lb, n2 = more ? nbl + nbm + nbo : 0u; // <= 55, <= 26
+            const uint32_t n1 = ob + mb + lb, n2 = more ? nbl + nbm + nbo : 0u; // <= 63, <= 26
             if (n1 + n2 > pos)
             {
                 bad = true;
@@ -1575,7 +1580,7 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
                     {
                         baseline = 1u << (sym & 31u);
                         ebits = sym & 31u;
-                        bad = sym > 23u; // (an offset of 2^24 and more cannot lie inside a piece)
+                        bad = sym > 31u; // (codes above 23 may sit in a table -- the predefined one has 29 --: a sequence that USES one is stopped in zs_seq_lanes)
                     }
                     // the table's own fields are read before its packed form lands on them?  No: the packed tables lie over the
                     // Huffman table and the weights' table, never over sh.fse
@@ -1737,7 +1742,8 @@ __device__ __forceinline__ ZfBlk zf_parse(const uint8_t* c, uint32_t csz)
     return f;
 }
 
-__global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restrict__ src, const ZItem* __restrict__ fitems, uint32_t slot0, uint32_t slot1,
+__global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restrict__ src, const ZItem* __restrict__ fitems, const uint32_t* __restrict__ flist,
+                                                         uint32_t nlist, uint32_t* __restrict__ slist, uint32_t* __restrict__ scount,
                                                          uint8_t* __restrict__ lit_scratch, uint64_t* __restrict__ rec_scratch,
                                                          ZPrep* __restrict__ fprep, uint32_t* __restrict__ retry, uint32_t* __restrict__ ticket,
                                                          unsigned long long* __restrict__ bump, uint64_t lit_cap, uint64_t rec_cap,
@@ -1755,9 +1761,9 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
         __builtin_amdgcn_wave_barrier();
         uint32_t tk = atomicAdd(ticket, lane == 0 ? 1u : 0u);
         tk = __builtin_amdgcn_readfirstlane(tk);
-        const uint32_t i = slot0 + tk;
-        if (i >= slot1)
+        if (tk >= nlist)
             break;
+        const uint32_t i = flist[tk];
         const ZItem it = fitems[i];
         if (it.kind != 4u)
             continue;
@@ -1775,6 +1781,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
         pr.status = ZP_SERIAL;
         pr.rec_at = 0;
         pr.seq_off = pr.seq_size = 0;
+        uint32_t why = 0;
         bool bad = false;
         if (lane == 0)
         {
@@ -1809,7 +1816,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
             lit_at = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(lit_at >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)lit_at);
             rec_at = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(rec_at >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)rec_at);
             if (lit_at + want_l > lit_cap || rec_at + me.nbseq > rec_cap)
-                bad = true;
+                { bad = true; why = __LINE__; }
         }
         uint8_t* lits = lit_scratch + lit_at;
         (void)rec_scratch; // (the records are k_zstd_blk_sequences': only their place is drawn here)
@@ -1828,7 +1835,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
                 {
                     const ZfBlk f = j == it.aux ? me : zf_parse(p + q + 3u, sz);
                     if (!f.ok)
-                        bad = true;
+                        { bad = true; why = __LINE__; }
                     else
                     {
                         if (f.lmode == 2u)
@@ -1851,7 +1858,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
                 q += 3u + (ty == 1u ? 1u : sz);
             }
             if ((me.lmode == 3u && !have_tree) || (me.nbseq && !(have_tab[0] && have_tab[1] && have_tab[2])))
-                bad = true; // nothing to repeat: the serial decoder says so
+                { bad = true; why = __LINE__; } // nothing to repeat: the serial decoder says so
         }
 #ifdef LTHIP_ZB_PROF
         ZB_MARK(19);
@@ -1902,7 +1909,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
                 {
                     if (zd_build_fse_par(&sh.fse[t], sh.norm + 64 * t, sh.tb_maxsym[t], sh.tb_log[t], sh.cum, (uint32_t*)sh.huf,
                                          sh.huf + 2u * ZD_FSE_PAR_MASK_WORDS, (uint32_t)lane))
-                        bad = true;
+                        { bad = true; why = __LINE__; }
                     ZB_SYNC_LDS();
                 }
             }
@@ -1951,7 +1958,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
             {
                 const uint32_t at = at0 + tree_bytes;
                 if (me.lcs < tree_bytes)
-                    bad = true;
+                    { bad = true; why = __LINE__; }
                 else if (me.nstr == 1u)
                 {
                     if (lane == 0)
@@ -1959,7 +1966,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
                     nstr_total = 1;
                 }
                 else if (me.lcs - tree_bytes < 10u)
-                    bad = true;
+                    { bad = true; why = __LINE__; }
                 else
                 {
                     const uint8_t* j = p + at;
@@ -1967,7 +1974,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
                                    s3 = (uint32_t)j[4] | ((uint32_t)j[5] << 8);
                     const uint32_t body = me.lcs - tree_bytes - 6u, seg = (me.nlit + 3u) >> 2;
                     if (s1 + s2 + s3 >= body || 3u * seg > me.nlit)
-                        bad = true;
+                        { bad = true; why = __LINE__; }
                     else
                     {
                         if (lane == 0)
@@ -2002,7 +2009,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
             {
                 const uint32_t last = sa.y ? p[sa.x + sa.y - 1u] : 0u;
                 if (sa.w == 0u || last == 0u)
-                    bad = true;
+                    { bad = true; why = __LINE__; }
                 else
                 {
                     pa = (sa.y - 1u) * 8u + (31u - (uint32_t)__builtin_clz(last));
@@ -2014,7 +2021,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
             {
                 const uint32_t last = sb2.y ? p[sb2.x + sb2.y - 1u] : 0u;
                 if (sb2.w == 0u || last == 0u)
-                    bad = true;
+                    { bad = true; why = __LINE__; }
                 else
                 {
                     pb = (sb2.y - 1u) * 8u + (31u - (uint32_t)__builtin_clz(last));
@@ -2067,12 +2074,12 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
                 }
             }
             if (go_a && zd_huf_stream_from(&sh, p + sa.x, sa.y, oa, sa.w, pa, ia))
-                bad = true;
+                { bad = true; why = __LINE__; }
             if (go_b && zd_huf_stream_from(&sh, p + sb2.x, sb2.y, ob2, sb2.w, pb, ib))
-                bad = true;
+                { bad = true; why = __LINE__; }
         }
         if (__builtin_amdgcn_ballot_w64(bad))
-            bad = true;
+            { bad = true; why = __LINE__; }
         __syncthreads();
 #ifdef LTHIP_ZB_PROF
         ZB_MARK(21);
@@ -2087,7 +2094,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
                 uint64_t* pk = t == ZT_LL ? pk_ll : t == ZT_ML ? pk_ml : pk_of;
                 const uint32_t size = f->valid == 2u ? 1u : f->valid == 1u ? 1u << f->log : 0u;
                 if (size == 0u || size > (t == ZT_OF ? 256u : 512u))
-                    bad = true;
+                    { bad = true; why = __LINE__; }
                 const uint32_t lg = f->valid == 2u ? 0u : f->log;
                 if (t == ZT_LL)
                     log_l = lg;
@@ -2115,14 +2122,14 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
                     {
                         baseline = 1u << (sym & 31u);
                         ebits = sym & 31u;
-                        bad = sym > 23u; // (an offset of 2^24 and more: not with windows of 8 MiB; the serial decoder takes those)
+                        bad = sym > 31u; // (codes above 23 may sit in a table -- the predefined one has 29 --: a sequence that USES one is stopped in zs_seq_lanes)
                     }
                     pk[x] = (uint64_t)(f->valid == 2u ? 0u : f->base[x]) | ((uint64_t)(f->valid == 2u ? 0u : f->nb[x]) << 16) | ((uint64_t)ebits << 24) |
                             ((uint64_t)baseline << 32);
                 }
             }
             if (__builtin_amdgcn_ballot_w64(bad))
-                bad = true;
+                { bad = true; why = __LINE__; }
             __syncthreads();
             const uint32_t at = c0 + me.lhdr + me.lcs + me.shdr + (uint32_t)0;
             // my own block's descriptions precede the bit-stream: their size = the bytes its non-repeated tables took
@@ -2161,7 +2168,12 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
             // per wave, a lane each, reading its states' entries from there (ONE lane of this wave would take 2.3 ms per block)
             if (!bad)
             {
-                uint64_t* tp = tabs + (uint64_t)i * 1280u;
+                // (its place in the table arena = its place in the list of blocks k_zstd_blk_sequences has to visit)
+                uint32_t si = atomicAdd(scount, lane == 0 ? 1u : 0u);
+                si = __builtin_amdgcn_readfirstlane(si);
+                if (lane == 0)
+                    slist[si] = i;
+                uint64_t* tp = tabs + (uint64_t)si * 1280u;
                 for (uint32_t x = lane; x < 512u; x += 64)
                 {
                     tp[x] = pk_ll[x];
@@ -2175,7 +2187,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
             }
         }
         else if (!bad && me.nlit > ZB)
-            bad = true;
+            { bad = true; why = __LINE__; }
 #ifdef LTHIP_ZB_PROF
         ZB_MARK(23);
 #endif
@@ -2189,7 +2201,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
         {
             fprep[i] = pr;
             if (bad)
-                retry[it.payload] = 1u;
+                retry[it.payload] = why ? why : __LINE__;
         }
     }
 }
@@ -2197,17 +2209,24 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
 // The sequence bit-streams of other encoders' blocks: 64 blocks per wave, a lane each (zs_seq_lanes), every lane reading the entries of
 // ITS block's tables from the table arena (three 8-byte gathers per sequence: the machine has the lanes and the L2 for them; one lane
 // with its tables in shared memory, the other 63 idle, is what made k_zstd_blk_entropy take 2.3 ms per block).
-__global__ __launch_bounds__(64) void k_zstd_blk_sequences(const uint8_t* __restrict__ src, const ZItem* __restrict__ fitems, uint32_t nslots,
+__global__ __launch_bounds__(64) void k_zstd_blk_sequences(const uint8_t* __restrict__ src, const ZItem* __restrict__ fitems, const uint32_t* __restrict__ slist,
+                                                          const uint32_t* __restrict__ scount,
                                                           const uint64_t* __restrict__ tabs, uint64_t* __restrict__ rec_scratch,
                                                           ZPrep* __restrict__ fprep, uint32_t* __restrict__ retry)
 {
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+    if (blockIdx.x * 64u >= *scount)
+        return;
     ZItem it;
     it.kind = 0;
     it.src_off = 0;
     it.payload = 0;
-    if (i < nslots)
+    uint32_t i = 0;
+    if (g < *scount)
+    {
+        i = slist[g];
         it = fitems[i];
+    }
     ZPrep pr;
     pr.status = ZP_SERIAL;
     pr.nbseq = pr.nlit = pr.seq_off = pr.seq_size = 0;
@@ -2217,7 +2236,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_sequences(const uint8_t* __rest
     if (it.kind == 4u)
         pr = fprep[i];
     const bool act = it.kind == 4u && pr.status == ZP_READY && pr.log[0] == 0u && pr.nbseq != 0u;
-    const uint64_t* tp = tabs + (uint64_t)i * 1280u;
+    const uint64_t* tp = tabs + (uint64_t)g * 1280u;
     bool bad = false;
     uint32_t sum_ll = 0, sum_ml = 0;
     const uint64_t at = it.src_off + pr.seq_off;
@@ -2230,7 +2249,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_sequences(const uint8_t* __rest
         if (bad)
         {
             fprep[i].status = ZP_SERIAL;
-            retry[it.payload] = 1u;
+            retry[it.payload] = __LINE__;
         }
         else
             fprep[i].expect = pr.nlit + sum_ml; // what the block regenerates
@@ -2870,6 +2889,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     zx.op = 0;
     zx.flushed = zx.drained = 0;
     zx.lwa = -(int32_t)ZX_LIT;
+    uint32_t why = 0;
     bool bad = !fh.ok;
     uint32_t produced = 0;
 #ifdef LTHIP_ZB_PROF
@@ -2878,11 +2898,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8; // Repeated_Offsets at the start of a frame
     for (uint32_t k = 0; k < nb && !bad; ++k)
     {
-        const uint32_t fi = blk.zb_base + k;
+        const uint32_t fi = blk.pad + k;
         const ZPrep pr = fprep[fi];
         if (pr.status == ZP_SERIAL || pr.expect > content - produced || pr.expect > ZB)
         {
-            bad = true;
+            { bad = true; why = __LINE__; }
             break;
         }
         if (pr.log[0] == 2u)
@@ -3027,7 +3047,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             // the block's last literals; it must have regenerated what k_zstd_blk_entropy counted
             const uint32_t rest = pr.nlit - litpos;
             if (produced - block_start + rest != pr.expect)
-                bad = true;
+                { bad = true; why = __LINE__; }
             else
             {
                 zx.copy_lits(litpos, rest);
@@ -3036,11 +3056,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
     }
     if (!bad && produced != content)
-        bad = true;
+        { bad = true; why = __LINE__; }
     if (!bad)
         zx.flush(zx.op + zx.g);
     if (bad && lane == 0)
-        retry[b] = 1u; // the serial decoder gives the verdict (and the bytes)
+        retry[b] = why ? why : 1u; // the serial decoder gives the verdict (and the bytes); the value says where it was sent from
 #ifdef LTHIP_ZB_PROF
     if (lane == 0)
     {
@@ -3051,6 +3071,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 }
 
 } // namespace
+
+// what the last lthip_zstd_decompress_blocks call did (diagnostics for the tests: which decoder the payloads went to)
+static const uint32_t* g_last_retry;
+static uint32_t g_last_payloads, g_last_foreign_blocks;
+extern "C" int lthip_zstd_last_decode_stats(lthip_ctx* ctx, uint32_t out[4])
+{
+    if (!ctx || !out)
+        return EINVAL;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> r(g_last_payloads);
+    if (g_last_payloads)
+        LTHIP_CHECK(ctx, hipMemcpy(r.data(), g_last_retry, 4 * (size_t)g_last_payloads, hipMemcpyDeviceToHost));
+    uint32_t back = 0, first = 0;
+    for (uint32_t v : r)
+    {
+        back += v ? 1u : 0u;
+        first = first ? first : v;
+    }
+    out[3] = first; // (where the first of them was sent back: a source line of k_zstd.hip, 1 = not recorded)
+    out[0] = g_last_payloads;       // payloads of the call
+    out[1] = g_last_foreign_blocks; // blocks of other encoders' frames listed for the block-parallel path
+    out[2] = back;                  // payloads a lane-parallel decoder gave back to the serial one
+    return 0;
+}
 
 extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                                             const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
@@ -3071,10 +3116,11 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
         hb[b].dst_cap = dst_caps[b];
         hb[b].zb_base = (uint32_t)nitems; // item slots of the payload: one per 128 KiB of destination, at least one
         hb[b].nzb = dst_caps[b] ? (uint32_t)(((uint64_t)dst_caps[b] + ZB - 1u) / ZB) : 1u;
-        hb[b].unit_base = hb[b].pad = 0;
+        hb[b].unit_base = 0;
+        hb[b].pad = ZF_SLOTS * (uint32_t)nitems; // first block slot of the payload should it be another encoder's frame
         nitems += hb[b].nzb;
     }
-    if (nitems > 0x7FFFFFF0ull)
+    if (nitems > 0x7FFFFFF0ull / ZF_SLOTS)
         return lthip_fail(ctx, EINVAL, "zstd decode", "too many pieces in one call");
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -3091,18 +3137,25 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     // frames of other encoders, block-parallel: their blocks sit at FIXED slots (zb_base + k) of a second item list
     constexpr uint32_t ZROUND = 8192u;
     const size_t nrounds = (size_t)((nitems + ZROUND - 1) / ZROUND);
-    const size_t ncounters = 8 + (size_t)block_count * 2 + nrounds + 8; // item count, totals | retry | f_nblocks | tickets | foreign ticket, arenas
-    if ((err = lthip_scratch(ctx, S_Z_ENC, sizeof(ZItem) * (size_t)nitems * 2 + sizeof(ZPrep) * (size_t)nitems + 4 * ncounters + 64, &d_items)))
+    const size_t nfslots = (size_t)ZF_SLOTS * nitems;
+    const size_t ncounters = 8 + (size_t)block_count * 2 + nrounds + 10; // item count, totals | retry | f_nblocks | tickets | foreign ticket, list count, arenas
+    if ((err = lthip_scratch(ctx, S_Z_ENC, sizeof(ZItem) * ((size_t)nitems + nfslots) + sizeof(ZPrep) * nfslots + 8 * nfslots + 4 * ncounters + 64, &d_items)))
         return err;
     ZItem* d_fitems = (ZItem*)d_items + nitems;
-    ZPrep* d_fprep = (ZPrep*)(d_fitems + nitems);
-    uint32_t* d_count = (uint32_t*)(d_fprep + nitems);
+    ZPrep* d_fprep = (ZPrep*)(d_fitems + nfslots);
+    uint32_t* d_flist = (uint32_t*)(d_fprep + nfslots); // blocks of other encoders' frames (slots), in no order
+    uint32_t* d_slist = d_flist + nfslots;              // those of them that have sequences
+    uint32_t* d_count = d_slist + nfslots;
     uint32_t* d_retry = d_count + 8; // per payload: the lane-parallel decoders give it back to the serial one
     uint32_t* d_fnb = d_retry + block_count; // per payload: blocks of a frame of another encoder (0: not decoded that way)
     uint32_t* d_tickets = d_fnb + block_count; // one work counter per round
     uint32_t* d_ftickets = d_tickets + nrounds + (((nrounds + (size_t)block_count * 2) & 1) ? 1 : 0); // (8-byte aligned: the arena counters follow)
+    uint32_t* d_scount = d_ftickets + 1;
     unsigned long long* d_bump = (unsigned long long*)(d_ftickets + 2);
-    LTHIP_CHECK(ctx, hipMemsetAsync(d_fitems, 0, sizeof(ZItem) * (size_t)nitems, ctx->stream));
+    g_last_retry = d_retry;
+    g_last_payloads = block_count;
+    g_last_foreign_blocks = 0;
+    LTHIP_CHECK(ctx, hipMemsetAsync(d_fitems, 0, sizeof(ZItem) * nfslots, ctx->stream));
     LTHIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 4 * ncounters, ctx->stream));
     if ((err = lthip_stage_upload(ctx, d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, ctx->stream)))
         return err;
@@ -3114,7 +3167,7 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     }
     LaunchTimer t(ctx, LTHIP_K_OTHER);
     hipLaunchKernelGGL(k_zstd_split, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
-                       block_count, (ZItem*)d_items, d_count, d_out_sizes, dbg, d_fitems, d_fnb);
+                       block_count, (ZItem*)d_items, d_count, d_out_sizes, dbg, d_fitems, d_fnb, d_flist);
     hipLaunchKernelGGL(k_zstd_decode<false>, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                        (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes, (const ZPrep*)nullptr);
     LTHIP_LAUNCH_CHECK(ctx);
@@ -3174,6 +3227,7 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
         LTHIP_CHECK(ctx, hipMemcpyAsync(totals, d_count + 4, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
         LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         const uint64_t f_blocks = totals[0], f_bytes = ((uint64_t)totals[3] << 32) | totals[2];
+        g_last_foreign_blocks = totals[0];
         if (f_blocks)
         {
             const uint64_t lit_cap = f_bytes + 96ull * f_blocks + 4096ull, rec_cap = f_bytes / 6ull + 64ull * f_blocks + 4096ull;
@@ -3182,15 +3236,16 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
                 return err;
             if ((err = lthip_scratch(ctx, S_Z_SUB, (size_t)rec_cap * 8u, &d_frecs)))
                 return err;
-            const uint32_t n = (uint32_t)nitems;
+            const uint32_t n = (uint32_t)f_blocks;
             void* d_ftabs;
-            if ((err = lthip_scratch(ctx, S_Z_RECS, (size_t)n * 1280u * 8u, &d_ftabs))) // (10 KiB of packed tables per block slot)
+            if ((err = lthip_scratch(ctx, S_Z_RECS, (size_t)n * 1280u * 8u, &d_ftabs))) // (10 KiB of packed tables per block)
                 return err;
-            hipLaunchKernelGGL(k_zstd_blk_entropy, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZItem*)d_fitems, 0u, n,
-                               (uint8_t*)d_flits, (uint64_t*)d_frecs, d_fprep, d_retry, d_ftickets, d_bump, lit_cap, rec_cap, (uint64_t*)d_ftabs);
+            hipLaunchKernelGGL(k_zstd_blk_entropy, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZItem*)d_fitems,
+                               (const uint32_t*)d_flist, n, d_slist, d_scount, (uint8_t*)d_flits, (uint64_t*)d_frecs, d_fprep, d_retry, d_ftickets, d_bump,
+                               lit_cap, rec_cap, (uint64_t*)d_ftabs);
             LTHIP_LAUNCH_CHECK(ctx);
-            hipLaunchKernelGGL(k_zstd_blk_sequences, dim3((n + 63u) / 64u), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZItem*)d_fitems, n,
-                               (const uint64_t*)d_ftabs, (uint64_t*)d_frecs, d_fprep, d_retry);
+            hipLaunchKernelGGL(k_zstd_blk_sequences, dim3((n + 63u) / 64u), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZItem*)d_fitems,
+                               (const uint32_t*)d_slist, (const uint32_t*)d_scount, (const uint64_t*)d_ftabs, (uint64_t*)d_frecs, d_fprep, d_retry);
             LTHIP_LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(k_zstd_execute_payload, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks, 0u,
                                block_count, (const uint32_t*)d_fnb, (uint8_t*)d_dst, (const uint8_t*)d_flits, (const uint64_t*)d_frecs,

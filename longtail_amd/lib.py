@@ -112,6 +112,7 @@ class HipLib:
         sig("lthip_zstd_compress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_zstd_decompress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_zstd_debug_units", i32, [vp, u64, u64, vp, vp, vp])
+        sig("lthip_zstd_last_decode_stats", i32, [vp, vp])
         sig("lthip_stored_block_header_size", sz, [u32])
         sig("lthip_write_stored_block_headers", i32, [vp, u32, vp, vp, vp, u32, u32, vp, vp, vp, vp])
         sig("lthip_create_missing_content", i32, [vp, u64, vp, u64, vp, vp, vp, u32, u32, u32, vp, sz, vp])
@@ -305,6 +306,13 @@ class Context:
     def zstd_decompress_blocks(self, src, src_offsets, src_sizes, dst, dst_offsets, dst_caps):
         return self._codec(self.lib.dll.lthip_zstd_decompress_blocks, src, src_offsets, src_sizes, dst, dst_offsets,
                            dst_caps)
+
+    def zstd_last_decode_stats(self):
+        """(payloads, blocks of other encoders' frames listed for the block-parallel decoder, payloads given back to the serial
+        decoder) of the last zstd_decompress_blocks call."""
+        out = np.zeros(4, np.uint32)
+        self._check(self.lib.dll.lthip_zstd_last_decode_stats(self.h, out.ctypes.data), "lthip_zstd_last_decode_stats")
+        return tuple(int(v) for v in out)
 
     def zstd_debug_units(self, first: int, count: int):
         """Match-finder output of the last zstd_compress_blocks call: (meta[count,4] u32, lits[count,4096] u8,

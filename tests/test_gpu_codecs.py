@@ -498,6 +498,57 @@ def test_zstd_sub_block_decoder_is_the_serial_decoder_and_strict(gpu, oracle, re
         assert o is not None and len(o) == len(r) and (o == r).all()
 
 
+def test_zstd_reference_frames_block_parallel_is_the_serial_decoder(gpu, oracle, ref, monkeypatch):
+    """Frames of the REFERENCE encoder (blocks that depend on each other: window = the frame, repeat offsets, repeated tables,
+    treeless literals) are decoded block-parallel: every block's streams on a wave / lane of its own (k_zstd_blk_entropy,
+    k_zstd_blk_sequences), then a payload's blocks in order on one wave (k_zstd_execute_payload); whatever that path declines goes to
+    the serial decoder.  All five longtail settings, sizes from a few KiB to 8 MiB + 5, raw and RLE blocks inside frames; and 300
+    damaged frames: same verdict and bytes as the serial decoder (LTHIP_ZSTD_DBG=1), undamaged ones equal to the data."""
+    rng = np.random.default_rng(33)
+    datas = [oracle.synth(n, 290 + n, k) for k, n in ((1, 131073), (1, 600000), (11, 400000), (12, 300000), (13, 262144), (2, 400000),
+                                                     (1, 5000), (12, (8 << 20) + 5))]
+    datas.append(np.concatenate([rng.integers(0, 256, 200000, dtype=np.uint8), oracle.synth(300000, 4, 1), np.zeros(150000, np.uint8)]))
+    frames, caps, truth = [], [], []
+    for i, d in enumerate(datas):
+        for w in range(5):
+            if len(d) > (1 << 20) and w not in (0, 3):
+                continue  # (the slow settings only on the smaller inputs)
+            frames.append(ref.compress(1, ref.dll.refh_zstd_type(w), d))
+            caps.append(len(d))
+            truth.append(d)
+    clean = len(frames)
+    for f, d in list(zip(frames[:clean], truth[:clean]))[:30]:
+        for _ in range(10):
+            x = f.copy()
+            k = rng.integers(0, 4)
+            if k == 0:
+                x = x[: rng.integers(1, len(x))]
+            elif k == 1:
+                a = int(rng.integers(0, len(x)))
+                x[a : a + int(rng.integers(1, 40))] = int(rng.integers(0, 256))
+            else:
+                for _ in range(int(rng.integers(1, 4))):
+                    x[rng.integers(0, len(x))] ^= np.uint8(1 << rng.integers(0, 8))
+            frames.append(x)
+            caps.append(len(d))
+            truth.append(None)
+    clean_out = gpu_zstd_decode(gpu, frames[:clean], caps[:clean])
+    n_pay, n_blocks, n_back, _ = gpu.zstd_last_decode_stats()
+    assert n_pay == clean and n_back == 0 and n_blocks >= sum((len(t) + 131071) // 131072 for t in truth[:clean])  # none went the serial way
+    assert all(o is not None and (o == t).all() for o, t in zip(clean_out, truth[:clean]))
+    fast = gpu_zstd_decode(gpu, frames, caps)
+    monkeypatch.setenv("LTHIP_ZSTD_DBG", "1")
+    serial = gpu_zstd_decode(gpu, frames, caps)
+    monkeypatch.delenv("LTHIP_ZSTD_DBG")
+    for i, (f_out, s_out, t) in enumerate(zip(fast, serial, truth)):
+        if t is not None:
+            assert f_out is not None and len(f_out) == len(t) and (f_out == t).all(), i
+        assert (f_out is None) == (s_out is None), i
+        if f_out is not None:
+            assert len(f_out) == len(s_out) and (f_out == s_out).all(), i
+    assert sum(o is None for o in fast[clean:]) > 50  # the damage is really detected
+
+
 def test_lz4_gpu_decoder_differential_fuzz(gpu, oracle):
     """Damaged payloads: the HIP decoder accepts exactly what the oracle's strict LZ4_decompress_safe restatement accepts
     (lz4.c:2215-2435), with the same size and bytes -- truncations, bit flips, zeroed tails, wrong capacities."""

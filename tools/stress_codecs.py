@@ -67,23 +67,38 @@ for rnd in range(12):
     # the zstd decoders on damaged frames of this encoder (sub-block layout with its directory, and one block per piece): the
     # lane-parallel decoders must give the serial decoder's verdict and bytes (LTHIP_ZSTD_DBG=1: one wave per payload)
     import os
-    for sub in ("1", "0"):
-        os.environ["LTHIP_ZSTD_SUB"] = sub
+    for sub in ("1", "0", "ref"):
+        if sub != "ref":
+            os.environ["LTHIP_ZSTD_SUB"] = sub
         src = [b for b in blocks if len(b) >= 3000][:60]
         if not src:
             continue
-        sdev, soffs = to_device(src)
-        ssz = [len(b) for b in src]
-        caps = [n + (n >> 8) + 64 for n in ssz]
-        d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
-        dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
-        cs = u32(ctx.zstd_compress_blocks(sdev, soffs, ssz, dst, d_offs, caps)).astype(np.int64)
-        host = dst.cpu().numpy()
+        if sub == "ref":
+            # frames of the REFERENCE encoder (any of longtail's five settings): decoded block-parallel (k_zstd_blk_entropy / _sequences /
+            # k_zstd_execute_payload), anything it declines by the serial decoder
+            src = src[:24]
+            ssz = [len(b) for b in src]
+            made = [r.compress(1, r.dll.refh_zstd_type(int(rng.integers(0, 5))), b) for b in src]
+            cs = np.array([len(m) for m in made], np.int64)
+            d_offs, total = layout(made)
+            host = np.zeros(total + 64, np.uint8)
+            for o_, m in zip(d_offs, made):
+                host[o_: o_ + len(m)] = m
+        else:
+            sdev, soffs = to_device(src)
+            ssz = [len(b) for b in src]
+            caps = [n + (n >> 8) + 64 for n in ssz]
+            d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
+            dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+            cs = u32(ctx.zstd_compress_blocks(sdev, soffs, ssz, dst, d_offs, caps)).astype(np.int64)
+            host = dst.cpu().numpy()
         frames, fcaps = [], []
         for i, b in enumerate(src):
             f = host[d_offs[i]: d_offs[i] + int(cs[i])].copy()
             nu = (len(b) + 4095) // 4096
-            tl = 12 + 2 * nu if sub == "1" else 12
+            tl = 12 + 2 * nu if sub == "1" else 12 if sub == "0" else 0
+            frames.append(f)  # (the undamaged frame too)
+            fcaps.append(len(b))
             for _ in range(6):
                 x = f.copy()
                 kind = int(rng.integers(0, 6))
@@ -114,7 +129,7 @@ for rnd in range(12):
         for i in range(len(frames)):
             # sub-block frames the lane-parallel decoder declines go to the serial one: same verdict.  One-block pieces are decoded
             # strictly (a damaged offset that reaches into the piece before is an error there): it may reject more, never accept more
-            if sub == "1" or int(fs[i]) != 0xFFFFFFFF:
+            if sub != "0" or int(fs[i]) != 0xFFFFFFFF:
                 assert int(fs[i]) == int(ss[i]), ("zstd verdict", sub, i, int(fs[i]), int(ss[i]))
             if int(fs[i]) != 0xFFFFFFFF:
                 n = int(fs[i])
