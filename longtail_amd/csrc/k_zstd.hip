@@ -1747,7 +1747,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
                                                          uint8_t* __restrict__ lit_scratch, uint64_t* __restrict__ rec_scratch,
                                                          ZPrep* __restrict__ fprep, uint32_t* __restrict__ retry, uint32_t* __restrict__ ticket,
                                                          unsigned long long* __restrict__ bump, uint64_t lit_cap, uint64_t rec_cap,
-                                                         uint64_t* __restrict__ tabs)
+                                                         uint64_t* __restrict__ tabs, uint32_t inline_seqs)
 {
     __shared__ ZdShared sh;
     __shared__ uint4 s_streams[4];
@@ -1819,7 +1819,6 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
                 { bad = true; why = __LINE__; }
         }
         uint8_t* lits = lit_scratch + lit_at;
-        (void)rec_scratch; // (the records are k_zstd_blk_sequences': only their place is drawn here)
         // ---- who set the tree / the tables last?  (the section headers of the blocks up to mine) ----
         uint32_t tree_at = 0, tree_size = 0, tab_at[3] = {0, 0, 0}, tab_end[3] = {0, 0, 0}, tab_modes[3] = {0, 0, 0};
         bool have_tree = false, have_tab[3] = {false, false, false};
@@ -2085,7 +2084,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
         ZB_MARK(21);
 #endif
         // ---- the tables, packed; the sequences (lane 0) ----
-        uint32_t log_l = 0, log_o = 0, log_m = 0;
+        uint32_t log_l = 0, log_o = 0, log_m = 0, seq_ml = 0;
         if (!bad && me.nbseq)
         {
             for (int t = 0; t < 3; ++t)
@@ -2165,8 +2164,23 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
             }
             const uint32_t sat = at + skip, send = c0 + bsize;
             // the packed tables go to the block's place in the table arena: k_zstd_blk_sequences decodes the bit-streams of 64 blocks
-            // per wave, a lane each, reading its states' entries from there (ONE lane of this wave would take 2.3 ms per block)
-            if (!bad)
+            // per wave, a lane each, reading its states' entries from there.  ONE lane of this wave takes 2.3 ms per block with the
+            // tables in shared memory -- which is the faster way as long as the call has no more blocks than the machine has waves for
+            // (a lane of k_zstd_blk_sequences takes 14 ms for its block, however few there are): inline_seqs.
+            if (!bad && inline_seqs)
+            {
+                uint32_t sum_ll = 0, sum_ml = 0;
+                zs_seq_lanes<false>(lane == 0, p + sat, sat < send ? send - sat : 0u, (uint32_t)(it.src_off + sat > 64u ? 64u : it.src_off + sat),
+                                    me.nbseq, log_l, log_o, log_m, pk_ll, pk_of, pk_ml, rec_scratch + rec_at, bad, sum_ll, sum_ml);
+                sum_ll = (uint32_t)__builtin_amdgcn_readfirstlane(sum_ll);
+                sum_ml = (uint32_t)__builtin_amdgcn_readfirstlane(sum_ml);
+                if (__builtin_amdgcn_ballot_w64(bad))
+                    bad = true;
+                if (!bad && (sum_ll > me.nlit || me.nlit + sum_ml > ZB))
+                    bad = true;
+                seq_ml = sum_ml;
+            }
+            else if (!bad)
             {
                 // (its place in the table arena = its place in the list of blocks k_zstd_blk_sequences has to visit)
                 uint32_t si = atomicAdd(scount, lane == 0 ? 1u : 0u);
@@ -2193,7 +2207,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
 #endif
         pr.nbseq = me.nbseq;
         pr.nlit = me.nlit;
-        pr.expect = me.nlit; // (+ the match lengths: k_zstd_blk_sequences)
+        pr.expect = me.nlit + seq_ml; // (k_zstd_blk_sequences adds the match lengths when the sequences are its)
         pr.bits_off = lit_at;
         pr.rec_at = rec_at;
         pr.status = bad ? ZP_SERIAL : ZP_READY;
@@ -3237,13 +3251,15 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
             if ((err = lthip_scratch(ctx, S_Z_SUB, (size_t)rec_cap * 8u, &d_frecs)))
                 return err;
             const uint32_t n = (uint32_t)f_blocks;
+            const uint32_t inline_seqs = n <= 4u * nwg ? 1u : 0u; // (few blocks: their sequences on the block's own wave)
             void* d_ftabs;
             if ((err = lthip_scratch(ctx, S_Z_RECS, (size_t)n * 1280u * 8u, &d_ftabs))) // (10 KiB of packed tables per block)
                 return err;
             hipLaunchKernelGGL(k_zstd_blk_entropy, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZItem*)d_fitems,
                                (const uint32_t*)d_flist, n, d_slist, d_scount, (uint8_t*)d_flits, (uint64_t*)d_frecs, d_fprep, d_retry, d_ftickets, d_bump,
-                               lit_cap, rec_cap, (uint64_t*)d_ftabs);
+                               lit_cap, rec_cap, (uint64_t*)d_ftabs, inline_seqs);
             LTHIP_LAUNCH_CHECK(ctx);
+            if (!inline_seqs)
             hipLaunchKernelGGL(k_zstd_blk_sequences, dim3((n + 63u) / 64u), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZItem*)d_fitems,
                                (const uint32_t*)d_slist, (const uint32_t*)d_scount, (const uint64_t*)d_ftabs, (uint64_t*)d_frecs, d_fprep, d_retry);
             LTHIP_LAUNCH_CHECK(ctx);
