@@ -1543,18 +1543,27 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
     }
     for (uint32_t u = 0; u < nunits; ++u)
     {
+        /* four words per lane and trip, loaded before the first counter is touched: the loop is bound by the round trips to
+         * memory, and this way four of them are in flight */
         const uint32_t n = sh->ulit_base[u + 1u] - sh->ulit_base[u];
-        ZB_PAR_FOR(j, (n + 3u) >> 2)
+        const uint32_t nw = (n + 3u) >> 2;
+        ZB_PAR_FOR(j4, (nw + 3u) >> 2)
         {
-            const uint32_t w = zb_unit_word(in, srcmask, u, j, n);
-            const uint32_t k = n - 4u * j; /* valid bytes in this word, >= 1 */
-            zb_atomic_add(&sh->lit_hist[w & 255u], 1u);
-            if (k > 1u)
-                zb_atomic_add(&sh->lit_hist[(w >> 8) & 255u], 1u);
-            if (k > 2u)
-                zb_atomic_add(&sh->lit_hist[(w >> 16) & 255u], 1u);
-            if (k > 3u)
-                zb_atomic_add(&sh->lit_hist[w >> 24], 1u);
+            uint32_t w[4];
+            for (uint32_t q = 0; q < 4u; ++q)
+                w[q] = 4u * j4 + q < nw ? zb_unit_word(in, srcmask, u, 4u * j4 + q, n) : 0u;
+            for (uint32_t q = 0; q < 4u; ++q)
+                if (4u * j4 + q < nw)
+                {
+                    const uint32_t k = n - 4u * (4u * j4 + q); /* valid bytes in this word, >= 1 */
+                    zb_atomic_add(&sh->lit_hist[w[q] & 255u], 1u);
+                    if (k > 1u)
+                        zb_atomic_add(&sh->lit_hist[(w[q] >> 8) & 255u], 1u);
+                    if (k > 2u)
+                        zb_atomic_add(&sh->lit_hist[(w[q] >> 16) & 255u], 1u);
+                    if (k > 3u)
+                        zb_atomic_add(&sh->lit_hist[w[q] >> 24], 1u);
+                }
         }
     }
     ZB_SYNC();
