@@ -2572,6 +2572,27 @@ __device__ __forceinline__ void zx_batch(ZxOut& zx, uint8_t* s_ring, uint8_t* s_
         if (in && ll <= ZX_LL_OWN)
         {
             uint32_t b = 0;
+            {
+                const uint32_t rl0 = zx.ring(o_l);
+                if (rl0 + ll <= ZX_RING) // (no wrap: plain pointers)
+                {
+                    uint8_t* dp = s_ring + rl0;
+                    const uint8_t* sp = s_lit + li;
+                    for (; b + 16u <= ll; b += 16u)
+                    {
+                        const uint32_t v0 = *reinterpret_cast<const u32_a1*>(sp + b), v1 = *reinterpret_cast<const u32_a1*>(sp + b + 4u),
+                                       v2 = *reinterpret_cast<const u32_a1*>(sp + b + 8u), v3 = *reinterpret_cast<const u32_a1*>(sp + b + 12u);
+                        *reinterpret_cast<u32_a1*>(dp + b) = v0;
+                        *reinterpret_cast<u32_a1*>(dp + b + 4u) = v1;
+                        *reinterpret_cast<u32_a1*>(dp + b + 8u) = v2;
+                        *reinterpret_cast<u32_a1*>(dp + b + 12u) = v3;
+                    }
+                    for (; b + 4u <= ll; b += 4u)
+                        *reinterpret_cast<u32_a1*>(dp + b) = *reinterpret_cast<const u32_a1*>(sp + b);
+                    for (; b < ll; ++b)
+                        dp[b] = sp[b];
+                }
+            }
             for (; b + 4u <= ll; b += 4u) // four bytes per trip of this lane-divergent loop (unaligned LDS dwords)
             {
                 const uint32_t r = zx.ring(o_l + b);
@@ -2661,6 +2682,30 @@ __device__ __forceinline__ void zx_batch(ZxOut& zx, uint8_t* s_ring, uint8_t* s_
             {
                 const uint32_t so2 = o_m - off;
                 uint32_t b = 0;
+                {
+                    // neither range wraps around the ring's end (all but one copy in a hundred): plain pointers, no index arithmetic
+                    // and no wrap tests per dword
+                    const uint32_t ra0 = zx.ring(so2), rb0 = zx.ring(o_m);
+                    if (off >= 4u && ra0 + ml <= ZX_RING && rb0 + ml <= ZX_RING)
+                    {
+                        const uint8_t* sp = s_ring + ra0;
+                        uint8_t* dp = s_ring + rb0;
+                        if (off >= 16u) // sixteen bytes read, then written: one wait per sixteen instead of one per four
+                            for (; b + 16u <= ml; b += 16u)
+                            {
+                                const uint32_t v0 = *reinterpret_cast<const u32_a1*>(sp + b), v1 = *reinterpret_cast<const u32_a1*>(sp + b + 4u),
+                                               v2 = *reinterpret_cast<const u32_a1*>(sp + b + 8u), v3 = *reinterpret_cast<const u32_a1*>(sp + b + 12u);
+                                *reinterpret_cast<u32_a1*>(dp + b) = v0;
+                                *reinterpret_cast<u32_a1*>(dp + b + 4u) = v1;
+                                *reinterpret_cast<u32_a1*>(dp + b + 8u) = v2;
+                                *reinterpret_cast<u32_a1*>(dp + b + 12u) = v3;
+                            }
+                        for (; b + 4u <= ml; b += 4u)
+                            *reinterpret_cast<u32_a1*>(dp + b) = *reinterpret_cast<const u32_a1*>(sp + b);
+                        for (; b < ml; ++b)
+                            dp[b] = sp[b];
+                    }
+                }
                 if (off >= 4u)
                     for (; b + 4u <= ml; b += 4u)
                     {
