@@ -20,3 +20,13 @@ t0 = time.perf_counter()
 out = int(ctx.lz4_decompress_blocks(arena, [0], [sz], back, [0], [n]).cpu().numpy().view(np.uint32)[0])
 ctx.sync()
 print(f"block {n} bytes -> {sz}; decoded {out} in {(time.perf_counter() - t0) * 1e3:.1f} ms;", "ok" if out == n and torch.equal(back[:n], data[:n]) else "MISMATCH")
+# the same block through the zstd codec (8 488 pieces in one frame: more than one round of the piece decoders)
+zb = n + (n >> 8) + 64
+arena = None
+arena = torch.empty(zb + 64, dtype=torch.uint8, device="cuda")
+sz = int(ctx.zstd_compress_blocks(data, [0], [n], arena, [0], [zb]).cpu().numpy().view(np.uint32)[0])
+back.zero_()
+t0 = time.perf_counter()
+out = int(ctx.zstd_decompress_blocks(arena, [0], [sz], back, [0], [n]).cpu().numpy().view(np.uint32)[0])
+ctx.sync()
+print(f"zstd: block {n} bytes -> {sz}; decoded {out} in {(time.perf_counter() - t0) * 1e3:.1f} ms;", "ok" if out == n and torch.equal(back[:n], data[:n]) else "MISMATCH", ctx.zstd_last_decode_stats())
