@@ -20,6 +20,9 @@
 //   K3 compact            : scan of per-part counts, gather into dense (offset,len) arrays.
 #include "lthip_internal.h"
 
+#include <stdlib.h>
+#include <type_traits>
+
 namespace
 {
 
@@ -43,6 +46,26 @@ __device__ __forceinline__ uint32_t lds_load_u32(uint32_t byte_addr)
 #else
     (void)byte_addr;
     return 0u;
+#endif
+}
+
+__device__ __forceinline__ uint32_t lds_load_u8(uint32_t byte_addr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(3))) uint8_t*)byte_addr;
+#else
+    (void)byte_addr;
+    return 0u;
+#endif
+}
+
+__device__ __forceinline__ uint4 lds_load_u128(uint32_t byte_addr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(3))) uint4*)byte_addr;
+#else
+    (void)byte_addr;
+    return make_uint4(0, 0, 0, 0);
 #endif
 }
 
@@ -281,6 +304,435 @@ __global__ __launch_bounds__(K1_THREADS, 1) void k_buzhash_candidates(const uint
         pd = npd;
         span = next_span;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1, prefix-XOR formulation (round 3; the default).
+//
+// In the de-rotated frame U[q] = rotr(T[b_q], q mod 32) the window hash of hpcdcchunker.c:266-306 is
+//     H(p) = rotl( XOR_{q=p-48}^{p-1} U[q], (p-1) mod 32 )
+// (rotl(U[p-1-j], p-1) = rotl(T[b_{p-1-j}], j)), so a lane that owns the 64-byte aligned run [q0, q0+64) needs ONE table
+// look-up per byte and no 48-byte warm-up: with the suffix XORs S[k] = XOR_{i>=k} U[q0+i] (S[64] = 0) of its own run,
+//     k >= 47:  W = S[k-47] ^ S[k+1]                                  (window inside the run)
+//     k <  47:  W = S[0] ^ S[k+1] ^ S'[k+17]                          (S' = the suffix XORs of the run before = lane-1:
+//                                                                      one v_xor_b32_dpp wave_ror:1)
+//     H(q0+k+1) = rotl(W, k mod 32)                                   (compile-time rotate: q0 is a multiple of 64)
+// Lane 0's predecessor is the halo row: its 47 suffix XORs are made by the whole wave (one byte per lane, wave scan),
+// parked in LDS, and loaded into LANE 63's registers S[17..63] once that lane has used them itself -- the steps run from
+// k = 63 down, so a register's own use (step j-1) precedes its use by the neighbour (step j-17) -- where wave_ror:1
+// hands them to lane 0.  The cut test is accumulated: y = H*inv + inv (<= qodd iff the odd part of d divides H+1) of
+// eight steps goes through v_min3_u32, one compare and one scalar branch per eight bytes; the exact test only in the
+// rare branch.  ~8.4 VALU instructions per byte and lane instead of 11.5, 64 + 16 live values instead of 112 + 28.
+// ---------------------------------------------------------------------------------------------------
+constexpr int HALO_DW = 64; // per wave: suffix XORs of the halo row, dword j = S'[j]
+
+struct PrefixConsts
+{
+    uint32_t lane4;     // lane * 4: low byte of a look-up address
+    uint32_t hj;        // the halo byte this lane looks up (63 - lane)
+    uint32_t halo_byte; // LDS byte address of the wave's halo[] array
+    uint32_t thr;       // y <= thr is necessary for a cut
+    uint32_t exact_add; // H*inv + addc = y + exact_add
+};
+
+// One wave-tile: win[] = the lane's own 64-byte run, hb = the lane's halo byte (byte 63 - lane of the 64 bytes before the
+// tile; lanes >= 47 are ignored).  Returns the 64 candidate bits of the run, bit k <=> cut position q0 + k + 1.
+template <int MODE>
+__device__ __forceinline__ uint64_t prefix_tile(const uint32_t (&win)[16], uint32_t hb, const PrefixConsts& pc, const DivTest& dv,
+                                                int lane, uint32_t* __restrict__ halo)
+{
+    // ---- halo: S'[j] for j = 17..63 by a wave scan, to LDS ----
+    {
+        uint32_t x = lds_load_u32((hb << 8) | pc.lane4);
+        x = rotr32(x, pc.hj);
+        if (lane >= 47)
+            x = 0u;
+        // inclusive XOR scan over the lanes: lane i gets the bytes 63-i .. 63 = S'[63 - i]
+        x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); // row_shr:1
+        x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false); // row_shr:2
+        x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false); // row_shr:4
+        x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false); // row_shr:8
+        x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // row_bcast:15
+        x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31
+        halo[pc.hj] = x;
+    }
+
+    // ---- pass A: suffix XORs of the lane's own run ----
+    uint32_t S[65];
+#define LT_LOOKUP(j) S[j] = lds_load_u32(__builtin_amdgcn_perm(win[(j) >> 2], pc.lane4, 0x0c0c0400u | ((uint32_t)((j) & 3) << 8)))
+#pragma unroll
+    for (int j = 63; j >= 0; --j)
+        LT_LOOKUP(j);
+#undef LT_LOOKUP
+    __builtin_amdgcn_sched_barrier(0);
+    S[64] = 0u;
+#pragma unroll
+    for (int j = 63; j >= 0; --j)
+        S[j] = S[j + 1] ^ ((j & 31) ? rotr32(S[j], (uint32_t)(j & 31)) : S[j]);
+    __builtin_amdgcn_wave_barrier(); // halo[] written by all lanes, read by lane 63 below
+
+    // ---- pass B: eight steps per group, from the top ----
+    uint32_t mlo = 0, mhi = 0;
+    auto group = [&](auto G) __attribute__((always_inline))
+    {
+        constexpr int g = decltype(G)::value;
+        uint32_t y[8];
+#pragma unroll
+        for (int i = 7; i >= 0; --i)
+        {
+            const int k = 8 * g + i;
+            uint32_t w;
+            if (k >= 47)
+                w = S[k - 47] ^ S[k + 1];
+            else
+                w = (S[0] ^ S[k + 1]) ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S[(k + 17) & 63], 0x13C, 0xf, 0xf, false); // wave_ror:1
+            const uint32_t h = (k & 31) ? rotl32(w, (uint32_t)(k & 31)) : w;
+            y[i] = MODE == 1 ? (~h & (dv.d - 1u)) : h * dv.inv + dv.inv;
+        }
+        const uint32_t m = min(min(min(y[0], y[1]), y[2]), min(min(min(y[3], y[4]), y[5]), min(y[6], y[7])));
+        if (__builtin_amdgcn_ballot_w64(m <= pc.thr) != 0ull) // wave-uniform, one group in ~6
+        {
+            asm volatile("");
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+            {
+                const int k = 8 * g + i;
+                if (__builtin_amdgcn_ballot_w64(y[i] <= pc.thr) != 0ull)
+                {
+                    asm volatile("");
+                    const bool hit = MODE == 1 ? y[i] == 0u : rotr32(y[i] + pc.exact_add, dv.k2) <= dv.qlim; // h % d == d-1
+                    uint32_t hbit;
+                    asm volatile("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(hbit) : "s"(__builtin_amdgcn_ballot_w64(hit)));
+                    if (k < 32)
+                        mlo |= hbit << k;
+                    else
+                        mhi |= hbit << (k - 32);
+                }
+            }
+        }
+        // Lane 63 has used S[8g+1 .. 8g+8] for the last time; the neighbour steps that read them (k = j - 17) belong
+        // to group g-2: lane 63 now takes the halo's suffixes there, and wave_ror:1 delivers them to lane 0.  Written
+        // as exec-masked loads by hand: the compiler's version of `if (lane == 63) S[j] = halo[j]` waits for the LDS
+        // right behind the branch; here the wait sits behind group g-1, in front of group g-2.
+        if constexpr (g >= 2)
+        {
+            constexpr int J = 8 * g + 1; // g = 7: S[57..63] (S[64] is the constant 0), else eight registers
+            constexpr int J7 = g == 7 ? 0 : J + 7;
+            uint64_t save;
+            if constexpr (g == 7)
+                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[msk]\n\t"
+                             "ds_read_b32 %[r0], %[ad] offset:%[o0]\n\tds_read_b32 %[r1], %[ad] offset:%[o0]+4\n\t"
+                             "ds_read_b32 %[r2], %[ad] offset:%[o0]+8\n\tds_read_b32 %[r3], %[ad] offset:%[o0]+12\n\t"
+                             "ds_read_b32 %[r4], %[ad] offset:%[o0]+16\n\tds_read_b32 %[r5], %[ad] offset:%[o0]+20\n\t"
+                             "ds_read_b32 %[r6], %[ad] offset:%[o0]+24\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sv] "=&s"(save), [r0] "+v"(S[J]), [r1] "+v"(S[J + 1]), [r2] "+v"(S[J + 2]), [r3] "+v"(S[J + 3]),
+                               [r4] "+v"(S[J + 4]), [r5] "+v"(S[J + 5]), [r6] "+v"(S[J + 6])
+                             : [ad] "v"(pc.halo_byte), [msk] "s"(0x8000000000000000ull), [o0] "i"(4 * J));
+            else
+                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[msk]\n\t"
+                             "ds_read_b32 %[r0], %[ad] offset:%[o0]\n\tds_read_b32 %[r1], %[ad] offset:%[o0]+4\n\t"
+                             "ds_read_b32 %[r2], %[ad] offset:%[o0]+8\n\tds_read_b32 %[r3], %[ad] offset:%[o0]+12\n\t"
+                             "ds_read_b32 %[r4], %[ad] offset:%[o0]+16\n\tds_read_b32 %[r5], %[ad] offset:%[o0]+20\n\t"
+                             "ds_read_b32 %[r6], %[ad] offset:%[o0]+24\n\tds_read_b32 %[r7], %[ad] offset:%[o0]+28\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sv] "=&s"(save), [r0] "+v"(S[J]), [r1] "+v"(S[J + 1]), [r2] "+v"(S[J + 2]), [r3] "+v"(S[J + 3]),
+                               [r4] "+v"(S[J + 4]), [r5] "+v"(S[J + 5]), [r6] "+v"(S[J + 6]), [r7] "+v"(S[J7])
+                             : [ad] "v"(pc.halo_byte), [msk] "s"(0x8000000000000000ull), [o0] "i"(4 * J));
+        }
+        // what was issued behind group g+1 is read by group g-1: it has had a whole group to land; the eight loads just
+        // issued stay in flight (LDS operations complete in order)
+        if constexpr (g >= 1 && g <= 6)
+        {
+            constexpr int J = 8 * (g + 1) + 1;
+            constexpr int J7 = g == 6 ? 0 : J + 7; // group 7 loaded seven registers; S[0] only fills the operand list
+            if constexpr (g == 1)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(S[J]), "+v"(S[J + 1]), "+v"(S[J + 2]), "+v"(S[J + 3]), "+v"(S[J + 4]), "+v"(S[J + 5]),
+                               "+v"(S[J + 6]), "+v"(S[J7]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(8)"
+                             : "+v"(S[J]), "+v"(S[J + 1]), "+v"(S[J + 2]), "+v"(S[J + 3]), "+v"(S[J + 4]), "+v"(S[J + 5]),
+                               "+v"(S[J + 6]), "+v"(S[J7]));
+        }
+    };
+    group(std::integral_constant<int, 7>{});
+    group(std::integral_constant<int, 6>{});
+    group(std::integral_constant<int, 5>{});
+    group(std::integral_constant<int, 4>{});
+    group(std::integral_constant<int, 3>{});
+    group(std::integral_constant<int, 2>{});
+    group(std::integral_constant<int, 1>{});
+    group(std::integral_constant<int, 0>{});
+    return ((uint64_t)mhi << 32) | mlo;
+}
+
+// candidate bits of a run -> the legal ones (cuts p with 48 <= p <= size), 0 for runs beyond the part
+__device__ __forceinline__ uint64_t prefix_legal(uint64_t m, uint64_t q0, uint64_t size)
+{
+    if (q0 >= size)
+        return 0ull;
+    if (q0 < 47)
+        m &= ~0ull << (47 - q0);
+    const uint64_t remain = size - q0; // >= 1
+    if (remain < 64)
+        m &= (1ull << remain) - 1ull;
+    return m;
+}
+
+__device__ __forceinline__ void prefix_table_init(uint32_t* tab, int tid, int nthreads)
+{
+    for (int v = tid; v < 256; v += nthreads)
+    {
+        const uint32_t tv = c_buztab[v];
+        uint4 q = make_uint4(tv, tv, tv, tv);
+        uint4* dst = reinterpret_cast<uint4*>(tab + v * TAB_REP);
+#pragma unroll
+        for (int j = 0; j < TAB_REP / 4; ++j)
+            dst[j] = q;
+    }
+    __syncthreads(); // the only barrier: table visible to every wave
+    if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)tab != 0u)
+        __builtin_trap(); // a look-up address is the v_perm result itself (see k_buzhash_candidates)
+}
+
+// Flavour 1: wave-tiles staged through registers into padded rows (the round-1/2 loader).
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_buzhash_prefix(const uint8_t* __restrict__ data,
+                                                                   const PartDev* __restrict__ parts,
+                                                                   const uint32_t* __restrict__ tile_part,
+                                                                   uint32_t ntiles, DivTest dv,
+                                                                   uint64_t* __restrict__ bm0,
+                                                                   uint64_t* __restrict__ bm1)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t* rows = smem + 256 * TAB_REP + wave * (WROWS * ROW_DW + HALO_DW); // this wave's [WROWS][ROW_DW] + halo suffixes
+    uint32_t* halo = rows + WROWS * ROW_DW;
+    prefix_table_init(smem, tid, 64 * WAVES);
+
+    const uint32_t rows_byte = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)rows;
+    PrefixConsts pc;
+    pc.lane4 = (uint32_t)lane * 4u;
+    pc.hj = 63u - (uint32_t)lane;
+    pc.halo_byte = rows_byte + WROWS * ROW_DW * 4u;
+    pc.thr = MODE == 1 ? 0u : 0xFFFFFFFFu / (dv.d >> dv.k2);
+    pc.exact_add = dv.addc - dv.inv;
+
+    const uint64_t nwt = (uint64_t)ntiles * 4u;
+    const uint64_t wstride = (uint64_t)gridDim.x * (uint64_t)WAVES;
+    uint64_t wt = (uint64_t)blockIdx.x * (uint64_t)WAVES + (uint64_t)wave;
+    if (wt >= nwt)
+        return;
+    PartDev pd = parts[tile_part[wt >> 2]];
+    uint64_t span = ((wt >> 2) - pd.tile_base) * (uint64_t)TILE + (wt & 3u) * (uint64_t)WTILE; // part-relative
+    TileRegs regs;
+    tile_load(regs, data, pd, span, lane);
+
+    for (;;)
+    {
+        __builtin_amdgcn_wave_barrier();
+        tile_store(regs, rows, lane);
+        __builtin_amdgcn_wave_barrier();
+
+        const uint64_t next = wt + wstride;
+        PartDev npd = pd;
+        uint64_t next_span = 0;
+        if (next < nwt)
+        {
+            npd = parts[tile_part[next >> 2]];
+            next_span = ((next >> 2) - npd.tile_base) * (uint64_t)TILE + (next & 3u) * (uint64_t)WTILE;
+            tile_load(regs, data, npd, next_span, lane);
+        }
+
+        uint32_t win[16];
+        const uint32_t* own = rows + (lane + 1) * ROW_DW;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            win[i] = own[i];
+        const uint32_t hb = lds_load_u8(rows_byte + pc.hj); // row 0 = the halo row
+        const uint64_t m = prefix_legal(prefix_tile<MODE>(win, hb, pc, dv, lane, halo), span + (uint64_t)lane * RUN, pd.size);
+
+        const uint64_t summary = __builtin_amdgcn_ballot_w64(m != 0ull);
+        if (m != 0ull)
+            bm0[pd.bm0_base + (span >> 6) + (uint64_t)lane] = m; // one word per 64-byte run
+        if (lane == 0)
+            bm1[pd.bm1_base + (span >> 12)] = summary;            // one word per 4 KiB
+
+        if (next >= nwt)
+            break;
+        wt = next;
+        pd = npd;
+        span = next_span;
+    }
+}
+
+// Flavour 2 (default): the wave-tile comes straight from global memory into LDS (global_load_lds_dwordx4, 1 KiB per
+// instruction, no staging registers and no ds_write pass).  The LDS image of an LDS-DMA is lane-linear (base + instruction
+// offset + lane * 16), so the rows cannot be padded; the bank spread comes from the SOURCE side instead: the wave's buffer holds
+// 65 rows x 4 vectors of 16 bytes (row 0 = the 64 bytes before the tile), and slot (r, c') receives data vector
+// c = c' ^ ((r >> 2) & 3) of row r -- lane L then reads its row r = L + 1 with four ds_read_b128 at slots c ^ ((r >> 2) & 3),
+// which puts the sixteen lanes of every ds_read_b128 service group on sixteen different 16-byte slots (checked for all four
+// groups).  ONE buffer per wave: the run is in registers after the four reads, so the next tile's DMA is issued right behind
+// them and has the whole hashing of this tile to land; the results of a tile are stored at the start of the NEXT iteration,
+// in front of that issue, so that the vmcnt(0) which retires the DMA never waits for a store just issued.
+constexpr int DMA_BUF_B = WROWS * 64; // 4160 bytes, linear
+
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_buzhash_prefix_dma(const uint8_t* __restrict__ data,
+                                                                       const PartDev* __restrict__ parts,
+                                                                       const uint32_t* __restrict__ tile_part,
+                                                                       uint32_t ntiles, DivTest dv,
+                                                                       uint64_t* __restrict__ bm0,
+                                                                       uint64_t* __restrict__ bm1)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t* buf = smem + 256 * TAB_REP + wave * ((DMA_BUF_B >> 2) + HALO_DW);
+    uint32_t* halo = buf + (DMA_BUF_B >> 2);
+    prefix_table_init(smem, tid, 64 * WAVES);
+
+    const uint32_t buf_byte = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)buf);
+    PrefixConsts pc;
+    pc.lane4 = (uint32_t)lane * 4u;
+    pc.hj = 63u - (uint32_t)lane;
+    pc.halo_byte = buf_byte + DMA_BUF_B;
+    pc.thr = MODE == 1 ? 0u : 0xFFFFFFFFu / (dv.d >> dv.k2);
+    pc.exact_add = dv.addc - dv.inv;
+
+    // DMA instruction u moves vector V = 64 u + lane = slot (r = V >> 2, c' = V & 3); (r >> 2) & 3 = (lane >> 4) & 3 for every u
+    const uint32_t src_vec = 4u * ((uint32_t)lane >> 2) + (((uint32_t)lane & 3u) ^ (((uint32_t)lane >> 4) & 3u));
+    const uint32_t src_off = 16u * src_vec; // byte offset of the lane's source vector inside a 1 KiB piece
+    // own row r = lane + 1: data vector c sits at slot c ^ f, f = (r >> 2) & 3
+    const uint32_t own_f = (((uint32_t)lane + 1u) >> 2) & 3u;
+    const uint32_t own_row = buf_byte + 64u * ((uint32_t)lane + 1u);
+
+    const uint64_t nwt = (uint64_t)ntiles * 4u;
+    const uint64_t wstride = (uint64_t)gridDim.x * (uint64_t)WAVES;
+    uint64_t wt = (uint64_t)blockIdx.x * (uint64_t)WAVES + (uint64_t)wave;
+    if (wt >= nwt)
+        return;
+
+    // issue the DMA of the wave-tile at part-relative `sp` of part `p` into the wave's buffer
+    auto issue = [&](const PartDev& p, uint64_t sp) __attribute__((always_inline))
+    {
+        const uint8_t* base = data + p.off + sp - 64; // row 0 of the image (may point before the part when sp == 0: never dereferenced then)
+        uint32_t keep;
+        if (sp >= 64 && sp + (uint64_t)WTILE <= p.size) // every vector inside the part: the common case
+        {
+            asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %[v], %[b] offset:0\n\t"
+                         "global_load_lds_dwordx4 %[v], %[b] offset:1024\n\t"
+                         "global_load_lds_dwordx4 %[v], %[b] offset:2048\n\t"
+                         "global_load_lds_dwordx4 %[v], %[b] offset:3072\n\t"
+                         "s_mov_b32 m0, %[k]"
+                         : [k] "=&s"(keep)
+                         : [v] "v"(src_off), [l] "s"(buf_byte), [b] "s"(base)
+                         : "memory");
+            if (lane < 4) // vectors 256..259: row 64
+                asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %[v], %[b] offset:0\n\t"
+                             "s_mov_b32 m0, %[k]"
+                             : [k] "=&s"(keep)
+                             : [v] "v"(src_off + 4096u), [l] "s"(buf_byte + 4096u), [b] "s"(base)
+                             : "memory");
+        }
+        else
+        {
+            // a tile at an end of its part: vectors outside the part are not loaded (the slot keeps stale bytes; every
+            // position they could influence is masked by prefix_legal), the vector that straddles the end is assembled
+            // from byte loads and stored by its lane
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+            {
+                const int64_t g = (int64_t)sp - 64 + 1024 * u + (int64_t)src_off;
+                const bool lane_on = u < 4 || lane < 4;
+                const bool whole = lane_on && g >= 0 && (uint64_t)g + 16 <= p.size;
+                const bool part = lane_on && g >= 0 && (uint64_t)g < p.size && (uint64_t)g + 16 > p.size;
+                if (whole)
+                    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+                                 "global_load_lds_dwordx4 %[v], %[b] offset:0\n\t"
+                                 "s_mov_b32 m0, %[k]"
+                                 : [k] "=&s"(keep)
+                                 : [v] "v"(src_off + 1024u * u), [l] "s"(buf_byte + 1024u * u), [b] "s"(base)
+                                 : "memory");
+                if (part)
+                {
+                    const uint8_t* src = data + p.off;
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    const uint32_t n = (uint32_t)(p.size - (uint64_t)g);
+                    for (uint32_t bb = 0; bb < n; ++bb)
+                        w[bb >> 2] |= (uint32_t)src[g + bb] << (8 * (bb & 3));
+                    uint32_t* d = buf + 256 * u + 4 * lane;
+                    d[0] = w[0];
+                    d[1] = w[1];
+                    d[2] = w[2];
+                    d[3] = w[3];
+                }
+            }
+        }
+    };
+
+    PartDev pd = parts[tile_part[wt >> 2]];
+    uint64_t span = ((wt >> 2) - pd.tile_base) * (uint64_t)TILE + (wt & 3u) * (uint64_t)WTILE; // part-relative
+    issue(pd, span);
+
+    uint64_t pend_m = 0, pend_summary = 0, pend_i0 = 0, pend_i1 = 0; // results of the tile before, stored one iteration late
+    bool pend = false;
+    for (;;)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the tile has landed (and the stores of two tiles ago are done)
+        uint32_t win[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+        {
+            const uint4 q = lds_load_u128(own_row + 16u * ((uint32_t)c ^ own_f));
+            win[4 * c + 0] = q.x;
+            win[4 * c + 1] = q.y;
+            win[4 * c + 2] = q.z;
+            win[4 * c + 3] = q.w;
+        }
+        const uint32_t hb = lds_load_u8(buf_byte + pc.hj); // row 0 = the halo row, f(0) = 0
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the buffer is free
+
+        if (pend)
+        {
+            if (pend_m != 0ull)
+                bm0[pend_i0 + (uint64_t)lane] = pend_m; // one word per 64-byte run
+            if (lane == 0)
+                bm1[pend_i1] = pend_summary;            // one word per 4 KiB
+        }
+
+        const uint64_t next = wt + wstride;
+        PartDev npd = pd;
+        uint64_t next_span = 0;
+        if (next < nwt)
+        {
+            npd = parts[tile_part[next >> 2]];
+            next_span = ((next >> 2) - npd.tile_base) * (uint64_t)TILE + (next & 3u) * (uint64_t)WTILE;
+            issue(npd, next_span);
+        }
+
+        pend_m = prefix_legal(prefix_tile<MODE>(win, hb, pc, dv, lane, halo), span + (uint64_t)lane * RUN, pd.size);
+        pend_summary = __builtin_amdgcn_ballot_w64(pend_m != 0ull);
+        pend_i0 = pd.bm0_base + (span >> 6);
+        pend_i1 = pd.bm1_base + (span >> 12);
+        pend = true;
+
+        if (next >= nwt)
+            break;
+        wt = next;
+        pd = npd;
+        span = next_span;
+    }
+    if (pend_m != 0ull)
+        bm0[pend_i0 + (uint64_t)lane] = pend_m;
+    if (lane == 0)
+        bm1[pend_i1] = pend_summary;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -584,10 +1036,60 @@ int lthip_launch_tile_table(lthip_ctx* ctx, lthip_plan* plan)
     return 0;
 }
 
+template <int WAVES, bool DMA>
+static int launch_buzhash_prefix(lthip_ctx* ctx, const lthip_plan* plan, const uint8_t* d_data, uint64_t* bm0, uint64_t* bm1)
+{
+    constexpr size_t per_wave = DMA ? (DMA_BUF_B >> 2) + HALO_DW : WROWS * ROW_DW + HALO_DW;
+    static_assert(sizeof(uint32_t) * (256 * TAB_REP + WAVES * per_wave) <= 160 * 1024, "LDS budget: one workgroup per CU");
+    const size_t lds = sizeof(uint32_t) * (256 * TAB_REP + WAVES * per_wave);
+    auto k0 = DMA ? &k_buzhash_prefix_dma<0, WAVES> : &k_buzhash_prefix<0, WAVES>;
+    auto k1 = DMA ? &k_buzhash_prefix_dma<1, WAVES> : &k_buzhash_prefix<1, WAVES>;
+    static bool granted[64] = {}; // per device: more than 64 KiB of dynamic LDS has to be granted explicitly
+    if (ctx->device < 0 || ctx->device >= 64 || !granted[ctx->device])
+    {
+        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (ctx->device >= 0 && ctx->device < 64)
+            granted[ctx->device] = true;
+    }
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    uint32_t grid = (uint32_t)ncu;
+    if ((uint64_t)grid * WAVES > plan->ntiles * 4u)
+        grid = (uint32_t)div_up_u64(plan->ntiles * 4u, WAVES);
+    LaunchTimer t(ctx, LTHIP_K_BUZHASH);
+    hipLaunchKernelGGL(plan->div.pow2 ? k1 : k0, dim3(grid), dim3(64 * WAVES), lds, ctx->stream, d_data, plan->d_parts,
+                       plan->d_tile_part, (uint32_t)plan->ntiles, plan->div, bm0, bm1);
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// LTHIP_K1: "dma16" (default) / "dma12" = the prefix-XOR kernel fed by LDS-DMA, 16 / 12 waves per CU; "prefix16" / "prefix12" =
+// the same with register staging; "roll" = the rolling-window kernel of rounds 1-2 (ablations)
+static int k1_flavour()
+{
+    static int f = -1;
+    if (f < 0)
+    {
+        const char* e = getenv("LTHIP_K1");
+        f = !e ? 0 : !strcmp(e, "roll") ? 4 : !strcmp(e, "prefix12") ? 3 : !strcmp(e, "prefix16") ? 2 : !strcmp(e, "dma12") ? 1 : 0;
+    }
+    return f;
+}
+
 int lthip_launch_buzhash(lthip_ctx* ctx, const lthip_plan* plan, const uint8_t* d_data, uint64_t* bm0, uint64_t* bm1)
 {
     if (plan->ntiles == 0)
         return 0;
+    const int flavour = k1_flavour();
+    if (flavour == 0)
+        return launch_buzhash_prefix<16, true>(ctx, plan, d_data, bm0, bm1);
+    if (flavour == 1)
+        return launch_buzhash_prefix<12, true>(ctx, plan, d_data, bm0, bm1);
+    if (flavour == 2)
+        return launch_buzhash_prefix<16, false>(ctx, plan, d_data, bm0, bm1);
+    if (flavour == 3)
+        return launch_buzhash_prefix<12, false>(ctx, plan, d_data, bm0, bm1);
     static_assert(sizeof(uint32_t) * (256 * TAB_REP + K1_WAVES * WROWS * ROW_DW) <= 160 * 1024, "LDS budget: one workgroup per CU");
     const size_t lds = sizeof(uint32_t) * (256 * TAB_REP + K1_WAVES * WROWS * ROW_DW);
     if (!ctx->k1_lds_enabled) // per context = per device: more than 64 KiB of dynamic LDS has to be granted explicitly
