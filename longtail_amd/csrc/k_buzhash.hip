@@ -59,10 +59,12 @@ __device__ __forceinline__ uint32_t lds_load_u8(uint32_t byte_addr)
 #endif
 }
 
-__device__ __forceinline__ uint4 lds_load_u128(uint32_t byte_addr)
+__device__ __forceinline__ uint4 lds_load_u128(uint32_t byte_addr) // 16-byte aligned: ONE ds_read_b128
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return *(const __attribute__((address_space(3))) uint4*)byte_addr;
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const v4 q = *(const __attribute__((address_space(3))) v4*)byte_addr;
+    return make_uint4(q.x, q.y, q.z, q.w);
 #else
     (void)byte_addr;
     return make_uint4(0, 0, 0, 0);
@@ -324,6 +326,9 @@ __global__ __launch_bounds__(K1_THREADS, 1) void k_buzhash_candidates(const uint
 // eight steps goes through v_min3_u32, one compare and one scalar branch per eight bytes; the exact test only in the
 // rare branch.  ~8.4 VALU instructions per byte and lane instead of 11.5, 64 + 16 live values instead of 112 + 28.
 // ---------------------------------------------------------------------------------------------------
+#ifndef K1_MAD64
+#define K1_MAD64 0 // measured: 5.88 against 5.76 ms per 16 GiB -- not kept
+#endif
 constexpr int HALO_DW = 64; // per wave: suffix XORs of the halo row, dword j = S'[j]
 
 struct PrefixConsts
@@ -372,22 +377,103 @@ __device__ __forceinline__ uint64_t prefix_tile(const uint32_t (&win)[16], uint3
     __builtin_amdgcn_wave_barrier(); // halo[] written by all lanes, read by lane 63 below
 
     // ---- pass B: eight steps per group, from the top ----
+    // Lane 63 hands the halo's suffixes to lane 0 (wave_ror:1): once the steps down to k = 4n are done, lane 63 has used
+    // S[4n+4 .. 4n+7] for the last time (own use of S[j]: step j - 1), and the neighbour steps that read them (k = j - 17 =
+    // 4n-13 .. 4n-10) lie two to three half-groups ahead: lane 63 takes the halo's values there with one exec-masked
+    // ds_read_b128 per half-group, written by hand -- the compiler's version of `if (lane == 63) S[j] = halo[j]` waits for
+    // the LDS right behind the branch; here the wait (lgkmcnt counts: LDS operations complete in order) sits in front of the
+    // half-group that reads them, with the two younger loads still in flight.
     uint32_t mlo = 0, mhi = 0;
+    uint32_t inv_v; // the addend in a VGPR: v_add_u32 with two VGPR sources issues at the double rate, with an SGPR source it does not
+    asm volatile("v_mov_b32 %0, %1" : "=v"(inv_v) : "s"(dv.inv));
+#if K1_MAD64
+    const uint64_t inv64 = (uint64_t)inv_v;
+#endif
+    // A register that an asm load is still writing must not be touched by anything the compiler generates (a copy made
+    // between the load and its wait reads the OLD value whenever the data has not landed: a rare, timing-dependent wrong
+    // hand-off -- seen with the tuple taken apart right behind the load).  So a quad stays ONE 128-bit value from the load
+    // statement to the wait statement, both tie it in and out, and it is taken apart only behind the wait.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 Q[16];
+    auto halo_quad = [&](auto QI) __attribute__((always_inline)) // lane 63: quad q = halo[4q .. 4q+3], issued
+    {
+        constexpr int q = decltype(QI)::value;
+        if constexpr (q >= 4 && q <= 15)
+        {
+            u32x4 v = {S[4 * q], S[4 * q + 1], S[4 * q + 2], S[4 * q + 3]};
+            uint64_t save;
+            asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[msk]\n\t"
+                         "ds_read_b128 %[r], %[ad] offset:%[o]\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [sv] "=&s"(save), [r] "+v"(v)
+                         : [ad] "v"(pc.halo_byte), [msk] "s"(0x8000000000000000ull), [o] "i"(16 * q)
+                         : "memory"); // reads halo[]: the store above may not sink below it
+            Q[q] = v;
+        }
+    };
+    auto halo_wait = [&](auto QI) __attribute__((always_inline)) // in front of the first half-group that reads quad q through the DPP
+    {
+        constexpr int q = decltype(QI)::value;
+        if constexpr (q >= 4 && q <= 15)
+        {
+            // younger loads still in flight: those of the (at most two) half-groups executed since quad q was issued
+            u32x4 v = Q[q];
+            if constexpr (q >= 6)
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(v));
+            else if constexpr (q == 5)
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(v));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
+            S[4 * q] = v.x;
+            S[4 * q + 1] = v.y;
+            S[4 * q + 2] = v.z;
+            S[4 * q + 3] = v.w;
+        }
+    };
     auto group = [&](auto G) __attribute__((always_inline))
     {
         constexpr int g = decltype(G)::value;
         uint32_t y[8];
 #pragma unroll
-        for (int i = 7; i >= 0; --i)
+        for (int half = 1; half >= 0; --half)
         {
-            const int k = 8 * g + i;
-            uint32_t w;
-            if (k >= 47)
-                w = S[k - 47] ^ S[k + 1];
+            // steps 8g + 4 half + 3 .. 8g + 4 half =: 4n + 3 .. 4n read, through the DPP, S[4n+17 .. 4n+20]: quads n+4 and n+5
+            // (S[4n+20], the first register of quad n+5, was waited for by half-group n+1, which ran before this one)
+            if (half == 1)
+                halo_wait(std::integral_constant<int, 2 * g + 1 + 4>{});
             else
-                w = (S[0] ^ S[k + 1]) ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S[(k + 17) & 63], 0x13C, 0xf, 0xf, false); // wave_ror:1
-            const uint32_t h = (k & 31) ? rotl32(w, (uint32_t)(k & 31)) : w;
-            y[i] = MODE == 1 ? (~h & (dv.d - 1u)) : h * dv.inv + dv.inv;
+                halo_wait(std::integral_constant<int, 2 * g + 4>{});
+#pragma unroll
+            for (int ii = 3; ii >= 0; --ii)
+            {
+                const int i = 4 * half + ii;
+                const int k = 8 * g + i;
+                uint32_t w;
+                if (k >= 47)
+                    w = S[k - 47] ^ S[k + 1];
+                else
+                    w = (S[0] ^ S[k + 1]) ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S[(k + 17) & 63], 0x13C, 0xf, 0xf, false); // wave_ror:1
+                const uint32_t h = (k & 31) ? rotl32(w, (uint32_t)(k & 31)) : w;
+                if (MODE == 1)
+                    y[i] = ~h & (dv.d - 1u);
+                else
+                {
+#if K1_MAD64
+                    // h * inv + inv in ONE instruction (measured 5.3 cycles against 4.2 + 2.8 for v_mul_lo_u32 + v_add_u32); the
+                    // upper half of the 64-bit result and the carry are not used
+                    uint64_t t, carry;
+                    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t), "=s"(carry) : "v"(h), "s"(dv.inv), "v"(inv64));
+                    y[i] = (uint32_t)t;
+#else
+                    y[i] = h * dv.inv + inv_v;
+#endif
+                }
+            }
+            // steps down to 4n are done: quad n + 1
+            if (half == 1)
+                halo_quad(std::integral_constant<int, 2 * g + 2>{});
+            else
+                halo_quad(std::integral_constant<int, 2 * g + 1>{});
         }
         const uint32_t m = min(min(min(y[0], y[1]), y[2]), min(min(min(y[3], y[4]), y[5]), min(y[6], y[7])));
         if (__builtin_amdgcn_ballot_w64(m <= pc.thr) != 0ull) // wave-uniform, one group in ~6
@@ -409,51 +495,6 @@ __device__ __forceinline__ uint64_t prefix_tile(const uint32_t (&win)[16], uint3
                         mhi |= hbit << (k - 32);
                 }
             }
-        }
-        // Lane 63 has used S[8g+1 .. 8g+8] for the last time; the neighbour steps that read them (k = j - 17) belong
-        // to group g-2: lane 63 now takes the halo's suffixes there, and wave_ror:1 delivers them to lane 0.  Written
-        // as exec-masked loads by hand: the compiler's version of `if (lane == 63) S[j] = halo[j]` waits for the LDS
-        // right behind the branch; here the wait sits behind group g-1, in front of group g-2.
-        if constexpr (g >= 2)
-        {
-            constexpr int J = 8 * g + 1; // g = 7: S[57..63] (S[64] is the constant 0), else eight registers
-            constexpr int J7 = g == 7 ? 0 : J + 7;
-            uint64_t save;
-            if constexpr (g == 7)
-                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[msk]\n\t"
-                             "ds_read_b32 %[r0], %[ad] offset:%[o0]\n\tds_read_b32 %[r1], %[ad] offset:%[o0]+4\n\t"
-                             "ds_read_b32 %[r2], %[ad] offset:%[o0]+8\n\tds_read_b32 %[r3], %[ad] offset:%[o0]+12\n\t"
-                             "ds_read_b32 %[r4], %[ad] offset:%[o0]+16\n\tds_read_b32 %[r5], %[ad] offset:%[o0]+20\n\t"
-                             "ds_read_b32 %[r6], %[ad] offset:%[o0]+24\n\t"
-                             "s_mov_b64 exec, %[sv]"
-                             : [sv] "=&s"(save), [r0] "+v"(S[J]), [r1] "+v"(S[J + 1]), [r2] "+v"(S[J + 2]), [r3] "+v"(S[J + 3]),
-                               [r4] "+v"(S[J + 4]), [r5] "+v"(S[J + 5]), [r6] "+v"(S[J + 6])
-                             : [ad] "v"(pc.halo_byte), [msk] "s"(0x8000000000000000ull), [o0] "i"(4 * J));
-            else
-                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[msk]\n\t"
-                             "ds_read_b32 %[r0], %[ad] offset:%[o0]\n\tds_read_b32 %[r1], %[ad] offset:%[o0]+4\n\t"
-                             "ds_read_b32 %[r2], %[ad] offset:%[o0]+8\n\tds_read_b32 %[r3], %[ad] offset:%[o0]+12\n\t"
-                             "ds_read_b32 %[r4], %[ad] offset:%[o0]+16\n\tds_read_b32 %[r5], %[ad] offset:%[o0]+20\n\t"
-                             "ds_read_b32 %[r6], %[ad] offset:%[o0]+24\n\tds_read_b32 %[r7], %[ad] offset:%[o0]+28\n\t"
-                             "s_mov_b64 exec, %[sv]"
-                             : [sv] "=&s"(save), [r0] "+v"(S[J]), [r1] "+v"(S[J + 1]), [r2] "+v"(S[J + 2]), [r3] "+v"(S[J + 3]),
-                               [r4] "+v"(S[J + 4]), [r5] "+v"(S[J + 5]), [r6] "+v"(S[J + 6]), [r7] "+v"(S[J7])
-                             : [ad] "v"(pc.halo_byte), [msk] "s"(0x8000000000000000ull), [o0] "i"(4 * J));
-        }
-        // what was issued behind group g+1 is read by group g-1: it has had a whole group to land; the eight loads just
-        // issued stay in flight (LDS operations complete in order)
-        if constexpr (g >= 1 && g <= 6)
-        {
-            constexpr int J = 8 * (g + 1) + 1;
-            constexpr int J7 = g == 6 ? 0 : J + 7; // group 7 loaded seven registers; S[0] only fills the operand list
-            if constexpr (g == 1)
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(S[J]), "+v"(S[J + 1]), "+v"(S[J + 2]), "+v"(S[J + 3]), "+v"(S[J + 4]), "+v"(S[J + 5]),
-                               "+v"(S[J + 6]), "+v"(S[J7]));
-            else
-                asm volatile("s_waitcnt lgkmcnt(8)"
-                             : "+v"(S[J]), "+v"(S[J + 1]), "+v"(S[J + 2]), "+v"(S[J + 3]), "+v"(S[J + 4]), "+v"(S[J + 5]),
-                               "+v"(S[J + 6]), "+v"(S[J7]));
         }
     };
     group(std::integral_constant<int, 7>{});
@@ -617,49 +658,50 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_buzhash_prefix_dma(const uint
     if (wt >= nwt)
         return;
 
-    // issue the DMA of the wave-tile at part-relative `sp` of part `p` into the wave's buffer
+    // issue the DMA of the wave-tile at part-relative `sp` of part `p` into the wave's buffer.  M0 (the LDS base of an LDS-DMA)
+    // points at the MIDDLE of the buffer for the whole kernel, the five pieces are told apart by the instruction offset
+    // (13 bits, signed: -2048 .. +2048), which the hardware adds to the LDS address and to the global address alike.
+    const uint32_t buf_mid = buf_byte + 2048u;
+    auto piece = [&](auto U, const uint8_t* mid_src) __attribute__((always_inline))
+    {
+        constexpr int u = decltype(U)::value;
+        const uint32_t so = src_off, bm = buf_mid; // (named here: asm operands alone do not capture in a generic lambda)
+        asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[v], %[b] offset:%[o]"
+                     :
+                     : [v] "v"(so), [l] "s"(bm), [b] "s"(mid_src), [o] "i"(1024 * u - 2048)
+                     : "memory");
+    };
     auto issue = [&](const PartDev& p, uint64_t sp) __attribute__((always_inline))
     {
-        const uint8_t* base = data + p.off + sp - 64; // row 0 of the image (may point before the part when sp == 0: never dereferenced then)
-        uint32_t keep;
+        const uint8_t* mid_src = data + p.off + sp - 64 + 2048; // the source of the buffer's middle (sp == 0: row 0 lies before the part and is not loaded)
         if (sp >= 64 && sp + (uint64_t)WTILE <= p.size) // every vector inside the part: the common case
         {
-            asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+            asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %[v], %[b] offset:-2048\n\t"
+                         "global_load_lds_dwordx4 %[v], %[b] offset:-1024\n\t"
                          "global_load_lds_dwordx4 %[v], %[b] offset:0\n\t"
-                         "global_load_lds_dwordx4 %[v], %[b] offset:1024\n\t"
-                         "global_load_lds_dwordx4 %[v], %[b] offset:2048\n\t"
-                         "global_load_lds_dwordx4 %[v], %[b] offset:3072\n\t"
-                         "s_mov_b32 m0, %[k]"
-                         : [k] "=&s"(keep)
-                         : [v] "v"(src_off), [l] "s"(buf_byte), [b] "s"(base)
+                         "global_load_lds_dwordx4 %[v], %[b] offset:1024"
+                         :
+                         : [v] "v"(src_off), [l] "s"(buf_mid), [b] "s"(mid_src)
                          : "memory");
-            if (lane < 4) // vectors 256..259: row 64
-                asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
-                             "global_load_lds_dwordx4 %[v], %[b] offset:0\n\t"
-                             "s_mov_b32 m0, %[k]"
-                             : [k] "=&s"(keep)
-                             : [v] "v"(src_off + 4096u), [l] "s"(buf_byte + 4096u), [b] "s"(base)
-                             : "memory");
+            if (lane < 4) // vectors 256..259: row 64 (src_off = 16 * lane for these lanes)
+                piece(std::integral_constant<int, 4>{}, mid_src);
         }
         else
         {
             // a tile at an end of its part: vectors outside the part are not loaded (the slot keeps stale bytes; every
             // position they could influence is masked by prefix_legal), the vector that straddles the end is assembled
             // from byte loads and stored by its lane
-#pragma unroll
-            for (int u = 0; u < 5; ++u)
+            auto edge = [&](auto U) __attribute__((always_inline))
             {
+                constexpr int u = decltype(U)::value;
                 const int64_t g = (int64_t)sp - 64 + 1024 * u + (int64_t)src_off;
                 const bool lane_on = u < 4 || lane < 4;
                 const bool whole = lane_on && g >= 0 && (uint64_t)g + 16 <= p.size;
                 const bool part = lane_on && g >= 0 && (uint64_t)g < p.size && (uint64_t)g + 16 > p.size;
                 if (whole)
-                    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
-                                 "global_load_lds_dwordx4 %[v], %[b] offset:0\n\t"
-                                 "s_mov_b32 m0, %[k]"
-                                 : [k] "=&s"(keep)
-                                 : [v] "v"(src_off + 1024u * u), [l] "s"(buf_byte + 1024u * u), [b] "s"(base)
-                                 : "memory");
+                    piece(U, mid_src);
                 if (part)
                 {
                     const uint8_t* src = data + p.off;
@@ -673,7 +715,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_buzhash_prefix_dma(const uint
                     d[2] = w[2];
                     d[3] = w[3];
                 }
-            }
+            };
+            edge(std::integral_constant<int, 0>{});
+            edge(std::integral_constant<int, 1>{});
+            edge(std::integral_constant<int, 2>{});
+            edge(std::integral_constant<int, 3>{});
+            edge(std::integral_constant<int, 4>{});
         }
     };
 

@@ -1880,6 +1880,11 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
                     {
                         const uint32_t m = (tab_modes[t] >> (6 - 2 * tt)) & 3u;
                         uint32_t used = 0;
+                        if ((m == 1u || m == 2u) && q >= staged) // a description past what was staged (also the one-byte RLE form):
+                        {                                        // `staged - q` must never wrap -- the payload goes to the serial decoder
+                            sh.v[ZDV_ERR] = 1;
+                            break;
+                        }
                         if (tt == t)
                         {
                             if (zd_set_table(&sh, t, m, s_desc + q, staged - q, &used))
@@ -3132,17 +3137,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 } // namespace
 
 // what the last lthip_zstd_decompress_blocks call did (diagnostics for the tests: which decoder the payloads went to)
-static const uint32_t* g_last_retry;
-static uint32_t g_last_payloads, g_last_foreign_blocks;
+// (kept in the context: one context per calling thread, so concurrent callers do not share them)
+static int env_u32_cached(const char* name, int& cache) // environment switches are read once per process, not per call
+{
+    if (cache == -2)
+    {
+        const char* e = getenv(name);
+        cache = e ? atoi(e) : -1;
+    }
+    return cache;
+}
 extern "C" int lthip_zstd_last_decode_stats(lthip_ctx* ctx, uint32_t out[4])
 {
     if (!ctx || !out)
         return EINVAL;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<uint32_t> r(g_last_payloads);
-    if (g_last_payloads)
-        LTHIP_CHECK(ctx, hipMemcpy(r.data(), g_last_retry, 4 * (size_t)g_last_payloads, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> r(ctx->z_last_payloads);
+    if (ctx->z_last_payloads)
+        LTHIP_CHECK(ctx, hipMemcpy(r.data(), ctx->z_last_retry, 4 * (size_t)ctx->z_last_payloads, hipMemcpyDeviceToHost));
     uint32_t back = 0, first = 0;
     for (uint32_t v : r)
     {
@@ -3150,8 +3163,8 @@ extern "C" int lthip_zstd_last_decode_stats(lthip_ctx* ctx, uint32_t out[4])
         first = first ? first : v;
     }
     out[3] = first; // (where the first of them was sent back: a source line of k_zstd.hip, 1 = not recorded)
-    out[0] = g_last_payloads;       // payloads of the call
-    out[1] = g_last_foreign_blocks; // blocks of other encoders' frames listed for the block-parallel path
+    out[0] = ctx->z_last_payloads;       // payloads of the call
+    out[1] = ctx->z_last_foreign_blocks; // blocks of other encoders' frames listed for the block-parallel path
     out[2] = back;                  // payloads a lane-parallel decoder gave back to the serial one
     return 0;
 }
@@ -3185,8 +3198,9 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
     // 8 single-wave workgroups per CU (12 would be resident at 143 VGPRs, measured slower: 190 vs 160 ms for 512 blocks)
     uint32_t nwg = nitems < (uint64_t)ncu * 8u ? (uint32_t)nitems : (uint32_t)ncu * 8u;
-    if (getenv("LTHIP_ZSTD_NWG"))
-        nwg = (uint32_t)atoi(getenv("LTHIP_ZSTD_NWG"));
+    static int env_nwg = -2, env_dbg = -2, env_ablate = -2;
+    if (env_u32_cached("LTHIP_ZSTD_NWG", env_nwg) >= 0)
+        nwg = (uint32_t)env_nwg;
     void *d_blocks, *d_lits, *d_items;
     int err;
     if ((err = lthip_scratch(ctx, S_LZ4_BLOCKS, sizeof(ZBlock) * (size_t)block_count, &d_blocks)))
@@ -3211,17 +3225,17 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     uint32_t* d_ftickets = d_tickets + nrounds + (((nrounds + (size_t)block_count * 2) & 1) ? 1 : 0); // (8-byte aligned: the arena counters follow)
     uint32_t* d_scount = d_ftickets + 1;
     unsigned long long* d_bump = (unsigned long long*)(d_ftickets + 2);
-    g_last_retry = d_retry;
-    g_last_payloads = block_count;
-    g_last_foreign_blocks = 0;
+    ctx->z_last_retry = d_retry;
+    ctx->z_last_payloads = block_count;
+    ctx->z_last_foreign_blocks = 0;
     LTHIP_CHECK(ctx, hipMemsetAsync(d_fitems, 0, sizeof(ZItem) * nfslots, ctx->stream));
     LTHIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 4 * ncounters, ctx->stream));
     if ((err = lthip_stage_upload(ctx, d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, ctx->stream)))
         return err;
-    const uint32_t dbg = (uint32_t)(getenv("LTHIP_ZSTD_DBG") ? atoi(getenv("LTHIP_ZSTD_DBG")) : 0); // 1: never decode by pieces
-    if (getenv("LTHIP_ZSTD_ABLATE"))
+    const uint32_t dbg = env_u32_cached("LTHIP_ZSTD_DBG", env_dbg) > 0 ? (uint32_t)env_dbg : 0u; // 1: never decode by pieces
+    if (env_u32_cached("LTHIP_ZSTD_ABLATE", env_ablate) >= 0)
     {
-        const uint32_t a = (uint32_t)atoi(getenv("LTHIP_ZSTD_ABLATE"));
+        const uint32_t a = (uint32_t)env_ablate;
         LTHIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_zd_ablate), &a, sizeof(a)));
     }
     LaunchTimer t(ctx, LTHIP_K_OTHER);
@@ -3286,7 +3300,7 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
         LTHIP_CHECK(ctx, hipMemcpyAsync(totals, d_count + 4, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
         LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         const uint64_t f_blocks = totals[0], f_bytes = ((uint64_t)totals[3] << 32) | totals[2];
-        g_last_foreign_blocks = totals[0];
+        ctx->z_last_foreign_blocks = totals[0];
         if (f_blocks)
         {
             const uint64_t lit_cap = f_bytes + 96ull * f_blocks + 4096ull, rec_cap = f_bytes / 6ull + 64ull * f_blocks + 4096ull;

@@ -69,6 +69,9 @@ extern "C" int lthip_ctx_create(int device, void* hip_stream, lthip_ctx** out_ct
     memset(ctx->stage, 0, sizeof ctx->stage);
     ctx->stage_next = 0;
     ctx->k1_lds_enabled = false;
+    ctx->z_last_retry = nullptr;
+    ctx->z_last_payloads = 0;
+    ctx->z_last_foreign_blocks = 0;
     ctx->k5_lds_enabled = false;
     memset(ctx->scratch_cap, 0, sizeof ctx->scratch_cap);
     memset(ctx->total_ms, 0, sizeof ctx->total_ms);

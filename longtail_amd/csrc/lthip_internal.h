@@ -117,6 +117,8 @@ struct lthip_ctx
     bool timing;
     std::vector<TimingRec> pending;
     std::vector<hipEvent_t> free_events;
+    const uint32_t* z_last_retry; // what the last lthip_zstd_decompress_blocks call of THIS context did (lthip_zstd_last_decode_stats)
+    uint32_t z_last_payloads, z_last_foreign_blocks;
     double total_ms[LTHIP_K_COUNT];
     uint64_t launches[LTHIP_K_COUNT];
 };

@@ -130,6 +130,8 @@ int lthip_partition_jobs(uint64_t job_count, const uint64_t* job_sizes, uint32_t
     }
     else if (policy == LTHIP_PARTITION_LPT)
     {
+        if (job_count > (uint64_t)(SIZE_MAX / sizeof(struct lpt_job)))
+            return EOVERFLOW;
         struct lpt_job* jobs = (struct lpt_job*)ltp_alloc("lthip_partition_jobs", sizeof(struct lpt_job) * (size_t)(job_count ? job_count : 1));
         struct lpt_rank* heap = (struct lpt_rank*)ltp_alloc("lthip_partition_jobs", sizeof(struct lpt_rank) * rank_count);
         if (!jobs || !heap)
@@ -169,7 +171,8 @@ int lthip_partition_jobs(uint64_t job_count, const uint64_t* job_sizes, uint32_t
 int lthip_exchange_layout(uint64_t job_count, const uint32_t* job_rank, uint32_t rank_count, const uint32_t* gathered_counts,
                           uint64_t count_stride, uint64_t chunk_stride, uint64_t* job_src, uint64_t* job_dst, uint32_t* job_chunks)
 {
-    if (!rank_count || (job_count && (!job_rank || !gathered_counts || !job_src || !job_dst)))
+    /* job_dst always receives job_count + 1 entries (the total at the end): it may never be NULL */
+    if (!rank_count || !job_dst || (job_count && (!job_rank || !gathered_counts || !job_src)))
         return EINVAL;
     uint64_t* next_job = (uint64_t*)ltp_alloc("lthip_exchange_layout", sizeof(uint64_t) * 2 * rank_count);
     if (!next_job)

@@ -2,6 +2,8 @@
  * the HIP ChunkerAPI / HashAPI / CompressionAPI objects.  Plain C99 over the lthip_* C ABI. */
 #include "plugin_common.h"
 
+#include <stdatomic.h>
+
 #include <stdio.h>
 
 /* ---------------------------------------------------------------------------------------------------
@@ -156,6 +158,12 @@ static pthread_rwlock_t g_win_lock = PTHREAD_RWLOCK_INITIALIZER;
 static struct ltp_window g_windows[LTP_MAX_WINDOWS];
 static unsigned char g_window_used[LTP_MAX_WINDOWS];
 static int g_window_high; /* highest used slot + 1 */
+/* per-slot sequence number: odd while a writer (always under g_win_lock) is changing the slot, bumped twice per change.  The
+ * lock-free look-up of a thread's own window (below) is valid only while the number it noted at ltp_window_set_current stands. */
+static _Atomic uint64_t g_window_seq[LTP_MAX_WINDOWS];
+
+static void slot_write_begin(int slot) { atomic_fetch_add_explicit(&g_window_seq[slot], 1, memory_order_acq_rel); }
+static void slot_write_end(int slot) { atomic_fetch_add_explicit(&g_window_seq[slot], 1, memory_order_release); }
 
 int ltp_window_register(void)
 {
@@ -165,8 +173,10 @@ int ltp_window_register(void)
     {
         if (!g_window_used[i])
         {
+            slot_write_begin(i);
             g_window_used[i] = 1;
             memset(&g_windows[i], 0, sizeof g_windows[i]);
+            slot_write_end(i);
             if (i + 1 > g_window_high)
                 g_window_high = i + 1;
             slot = i;
@@ -182,7 +192,9 @@ void ltp_window_publish(int slot, const struct ltp_window* w)
     if (slot < 0)
         return;
     pthread_rwlock_wrlock(&g_win_lock);
+    slot_write_begin(slot);
     g_windows[slot] = *w;
+    slot_write_end(slot);
     pthread_rwlock_unlock(&g_win_lock);
 }
 
@@ -191,18 +203,27 @@ void ltp_window_unregister(int slot)
     if (slot < 0)
         return;
     pthread_rwlock_wrlock(&g_win_lock);
+    slot_write_begin(slot);
     g_window_used[slot] = 0;
     memset(&g_windows[slot], 0, sizeof g_windows[slot]);
+    slot_write_end(slot);
     while (g_window_high > 0 && !g_window_used[g_window_high - 1])
         --g_window_high;
     pthread_rwlock_unlock(&g_win_lock);
 }
 
-/* points into g_windows (static storage): a stale pointer can at worst see another chunker's published window, whose digests are
- * correct for the memory they describe */
-static __thread const struct ltp_window* t_current_window;
+/* The calling thread's own window: slot + the slot's sequence number when the chunker published it.  Any later change of the slot
+ * (the chunker's next window, its disposal by another thread, reuse by another chunker) changes the number, and the look-up
+ * falls back to the locked scan: a thread never reads a slot that is being written and never trusts one that has changed. */
+static __thread int t_current_slot = -1;
+static __thread uint64_t t_current_seq;
 
-void ltp_window_set_current(int slot) { t_current_window = slot >= 0 ? &g_windows[slot] : 0; }
+void ltp_window_set_current(int slot)
+{
+    t_current_slot = slot;
+    if (slot >= 0)
+        t_current_seq = atomic_load_explicit(&g_window_seq[slot], memory_order_acquire);
+}
 
 static int window_find(const struct ltp_window* w, const uint8_t* p, uint32_t len, uint64_t* out_hash)
 {
@@ -228,9 +249,25 @@ int ltp_window_lookup(const void* data, uint32_t len, uint64_t* out_hash)
 {
     const uint8_t* p = (const uint8_t*)data;
     /* the calling thread's own chunker first: no lock, no scan (the common case by far, src/longtail.c:2231-2296) */
-    const struct ltp_window* cur = t_current_window;
-    if (cur && cur->base && p >= cur->base && p < cur->base + cur->size)
-        return window_find(cur, p, len, out_hash);
+    const int slot = t_current_slot;
+    if (slot >= 0 && !(t_current_seq & 1u) && atomic_load_explicit(&g_window_seq[slot], memory_order_acquire) == t_current_seq)
+    {
+        const struct ltp_window cur = g_windows[slot]; /* a copy taken between two reads of an unchanged sequence number */
+        atomic_thread_fence(memory_order_acquire);
+        if (atomic_load_explicit(&g_window_seq[slot], memory_order_relaxed) == t_current_seq && cur.base && p >= cur.base &&
+            p < cur.base + cur.size)
+        {
+            uint64_t h = 0;
+            const int hit = window_find(&cur, p, len, &h);
+            atomic_thread_fence(memory_order_acquire);
+            if (atomic_load_explicit(&g_window_seq[slot], memory_order_relaxed) == t_current_seq) /* the tables stood while read */
+            {
+                if (hit)
+                    *out_hash = h;
+                return hit;
+            }
+        }
+    }
     int found = 0;
     pthread_rwlock_rdlock(&g_win_lock);
     for (int i = 0; i < g_window_high && !found; ++i)

@@ -12,6 +12,7 @@
 #include "index_kernels.h"
 
 #include <algorithm>
+#include <unordered_set>
 
 namespace
 {
@@ -622,15 +623,15 @@ extern "C" int lthip_get_existing_store_index(lthip_ctx* ctx, const void* store_
     // (5): the taken blocks in walk order; a block hash that occurs twice in the store is taken once (block_to_index_lookup, :7246)
     std::vector<uint32_t> found;
     {
-        std::vector<uint64_t> seen;
+        std::unordered_set<uint64_t> seen; // one hash look-up per taken block, like the reference's table (:7246)
+        seen.reserve(nb);
         for (uint32_t b : order)
             if (taken[b])
             {
                 uint64_t bh;
                 memcpy(&bh, p_bhash + (size_t)b * 8, 8);
-                if (std::find(seen.begin(), seen.end(), bh) != seen.end())
+                if (!seen.insert(bh).second)
                     continue;
-                seen.push_back(bh);
                 found.push_back(b);
             }
     }

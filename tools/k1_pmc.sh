@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC of K1 per flavour: instruction counts and busy cycles (8 GiB, one step)
-for f in prefix12 roll; do
+for f in dma16 roll; do
   echo "== LTHIP_K1=$f"
   export LTHIP_K1=$f
   tools/pmc_all.sh pmc_k1_${f}_a "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" --gib 8 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary | grep buzhash
