@@ -16,6 +16,8 @@
 //                 last merge; writes output words 0,1 as the u64 digest.
 #include "lthip_internal.h"
 
+#include <stdlib.h>
+
 namespace
 {
 
@@ -441,7 +443,8 @@ int lthip_launch_blake3(lthip_ctx* ctx, const uint8_t* d_data, const uint64_t* d
         return err;
     {
         LaunchTimer t(ctx, LTHIP_K_B3_LEAF);
-        hipLaunchKernelGGL(k_blake3_leaves, dim3((uint32_t)div_up_u64(leaf_bound, 256)), dim3(256), 0, ctx->stream, d_data,
+        static const int pad_lds = getenv("LTHIP_B3_PAD_LDS") ? atoi(getenv("LTHIP_B3_PAD_LDS")) : 0; // experiment: unused LDS limits the waves per CU
+        hipLaunchKernelGGL(k_blake3_leaves, dim3((uint32_t)div_up_u64(leaf_bound, 256)), dim3(256), (size_t)pad_lds, ctx->stream, d_data,
                            d_offsets, d_lens, (const uint32_t*)lp, count_bound, d_count, (uint32_t*)cv, (uint32_t*)wf);
         LTHIP_LAUNCH_CHECK(ctx);
     }

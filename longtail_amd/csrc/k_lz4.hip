@@ -32,6 +32,8 @@
 //   decode           k_lz4_decode.hip
 #include "lthip_internal.h"
 
+#include <string>
+
 #include <stdlib.h>
 
 namespace
@@ -302,6 +304,27 @@ constexpr int LZ4_TAB_LANES = 2560;
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t LZ4_LANE_MAXREC = 8; // sequences a lane may record (tools/lz4_lane_model.c: 8 costs nothing, 6 does)
 
+#ifdef LTHIP_K5_PROF /* debug build only (make prof, tools/k5_prof.sh): shader-clock cycles per phase of the lane parser, summed over all waves */
+__device__ unsigned long long g_k5_prof[32];
+struct K5Prof
+{
+    unsigned long long last, acc[16];
+};
+#define K5P_DECL K5Prof k5p; k5p.last = __builtin_readcyclecounter(); for (int i__ = 0; i__ < 16; ++i__) k5p.acc[i__] = 0;
+#define K5P_ARG , K5Prof& k5p
+#define K5P_PASS , k5p
+#define K5P(i) do { const unsigned long long n__ = __builtin_readcyclecounter(); k5p.acc[i] += n__ - k5p.last; k5p.last = n__; } while (0)
+#define K5P_COUNT(i, n) do { k5p.acc[i] += (n); } while (0)
+#define K5P_FLUSH do { if ((threadIdx.x & 63) == 0) for (int i__ = 0; i__ < 16; ++i__) atomicAdd(&g_k5_prof[i__], k5p.acc[i__]); } while (0)
+#else
+#define K5P_DECL
+#define K5P_ARG
+#define K5P_PASS
+#define K5P(i) do { } while (0)
+#define K5P_COUNT(i, n) do { } while (0)
+#define K5P_FLUSH do { } while (0)
+#endif
+
 // value held by the lane that owns sub-unit `s` (s outside 0..63: `ident`)
 __device__ __forceinline__ uint32_t sub_shfl(uint32_t x, int s, bool rev, uint32_t ident)
 {
@@ -313,7 +336,7 @@ __device__ __forceinline__ uint32_t sub_shfl(uint32_t x, int s, bool rev, uint32
 template <int TAB, int FMT>
 __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t head, uint16_t* tab, int lane, uint32_t my_start,
                                                uint32_t my_len, int32_t start_limit, uint32_t end_limit, uint32_t sub, uint8_t* __restrict__ out,
-                                               uint64_t* __restrict__ zrecs, uint64_t* __restrict__ lrecs, Lz4Seq& st, uint32_t dbg)
+                                               uint64_t* __restrict__ zrecs, uint64_t* __restrict__ lrecs, Lz4Seq& st, uint32_t dbg K5P_ARG)
 {
     const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(sdata);
     const bool rev = !(dbg & 128u);
@@ -332,7 +355,8 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
     // cheap, so hits are measured in bulk.
     const uint32_t wait_for = (dbg >> 20) & 63u ? (dbg >> 20) & 63u : 16u;
     bool pend = false;
-    uint32_t cand = LZ4_EMPTY;
+    uint32_t cand = 0u;
+    // (the lane parser's tables hold 0 for "nothing here": a candidate 0 is position 0 of the window, verified like any other)
     for (;;)
     {
         const bool act = !pend && p < lend && (int32_t)p <= start_limit && nrec < LZ4_LANE_MAXREC && !(dbg & 2048u);
@@ -341,7 +365,7 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
             break;
         if (am)
         {
-            uint32_t v = 0, h = 0, c = LZ4_EMPTY;
+            uint32_t v = 0, h = 0, c = 0u;
             if (act)
             {
                 v = lds_read32(sdata, p + head);
@@ -364,7 +388,7 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
                 }
             }
             bool hit = false;
-            if (act && c != LZ4_EMPTY && c < p)
+            if (act && c < p)
                 hit = lds_read32(sdata, c + head) == v;
             if (hit)
             {
@@ -377,6 +401,8 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
                 ++nmiss;
             }
         }
+        K5P(3);
+        K5P_COUNT(10, 1);
         const uint64_t pm = __builtin_amdgcn_ballot_w64(pend);
         if (pm == 0ull)
             continue;
@@ -386,6 +412,8 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
         const bool ok0 = pend;
         bool ok = ok0;
         pend = false;
+        K5P_COUNT(11, 1);
+        K5P_COUNT(12, (unsigned)__builtin_popcountll(pm));
         // ---- forwards, every hit lane for itself: 16 bytes per LDS round trip, at most 36 bytes ----
         uint32_t mlen = ok ? 4u : 0u;
         bool grow = ok;
@@ -434,8 +462,10 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
         // such a match covers give up what they hold (it would be dropped below anyway) and continue behind it ----
         uint64_t longs = __builtin_amdgcn_ballot_w64(grow);
         bool covered = false;
+        K5P(4);
         while (longs)
         {
+            K5P_COUNT(13, 1);
             const int f = rev ? 63 - __builtin_clzll(longs) : __builtin_ctzll(longs);
             longs &= ~(1ull << f);
             const uint32_t pf = __builtin_amdgcn_readlane(p, f), cf = __builtin_amdgcn_readlane(cand, f);
@@ -488,6 +518,7 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
             // (cannot happen: a waiting hit is either recorded or covered) -- step on so that the loop always advances
             p += 1u;
         }
+        K5P(5);
     }
 
     // ---- what earlier sub-units' matches cover is dropped: exclusive prefix maximum of the match ends, in sub-unit order ----
@@ -543,6 +574,7 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
     uint32_t q_pos = FMT == 1 ? c_incl - cnt : 0u;
     const uint32_t last_kept_end = sub_shfl(kincl, 63, rev, 0u);
 
+    K5P(6);
     // ---- emission: every lane writes its own sequences; literal runs above 16 bytes are copied by the whole wave ----
     {
         uint32_t prev = prev0;
@@ -617,6 +649,7 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
             }
         }
     }
+    K5P(7);
     // ---- the unit's result, as the batch parser leaves it ----
     const uint64_t hm = __builtin_amdgcn_ballot_w64(have);
     st.have_first = hm != 0ull;
@@ -667,6 +700,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     // while the current one is parsed -- without that the memory pipe idles during every parse and the ALUs during every load.
     uint4 pre[5];
     bool have_pre = false;
+    K5P_DECL
     // with a worklist (MODE 1 behind the classification pass) the loop runs over its entries: worklist[0] = count, then group ids
     const bool listed = MODE == 1 && worklist != nullptr;
     const uint32_t grp_end = listed ? worklist[0] : (MODE == 1 ? grp0 + ngroups : grp0 + blockIdx.x + 1u);
@@ -724,7 +758,8 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             }
         }
         uint4* tv = reinterpret_cast<uint4*>(tab);
-        const uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        const uint32_t e1 = MODE == 1 ? 0u : 0xFFFFFFFFu; // lane parser: 0 = empty, so that tables merge by a packed maximum
+        const uint4 e = make_uint4(e1, e1, e1, e1);
 #pragma unroll
         for (uint32_t v = 0; v < (TAB * 2 / 16 + 63) / 64; ++v) // TAB * 2 bytes, 64 lanes x 16 bytes per step
             if (v * 64 + lane < TAB * 2 / 16)
@@ -733,6 +768,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             *flag = 0u;
     }
     __syncthreads();
+    K5P(0);
     if constexpr (MODE == 1)
     {
         // the next group of this workgroup: its loads are in flight during the parse below
@@ -767,6 +803,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         }
     }
 
+    K5P(1);
     // ---- my unit, positions relative to the group start ----
     const uint32_t my_start = (uint32_t)wave * sub_bytes;
     const bool have_unit = my_start < glen;
@@ -802,46 +839,103 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         const uint32_t sub = (dbg & 256u) ? ((sub_bytes >> 6) | 4u) : sub_bytes >> 6;
         // every group this kernel sees holds redundancy (the classification pass listed it; LTHIP_LZ4_DBG bit 14 sends ALL groups
         // here, an ablation): no probe, no rendezvous -- the waves of the group only share the window
+        //
+        // History (round 3).  A unit's table has to start with the positions of the units before it.  Rounds 1-2 let every wave
+        // insert all of that itself: sum over w of w * 1024 inserts per group, LDS-write bound, and wave 15 worked while wave 0
+        // waited at the group's barrier (21 % of the kernel's wave time).  Now every wave inserts only ITS OWN unit (every 4th
+        // position, the aligned dwords of the window) into its table, and the tables are combined by a prefix "sum" over the
+        // waves whose operator is the packed 16-bit maximum -- a later unit's position is the larger one, 0 = empty --: four
+        // Hillis-Steele rounds, each one conflict-free ds_read_b128 sweep of another wave's table (5 KiB) + 20 v_pk_max_u16 +
+        // a sweep back.  Table k then holds units 0..k: wave k parses with table k-1 (wave 0 with a cleared one).  Same work for
+        // every wave, 16 inserts per lane instead of up to 108, and the far history is complete instead of every 16th position.
+        uint16_t* ptab = tab; // the table this wave parses with
+        if (!(dbg & 1u))
         {
+            typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+            static_assert((TAB * 2) % (16 * 64) == 0, "a table is a whole number of 1 KiB sweeps");
+            constexpr int NV = TAB * 2 / (16 * 64);
             if (have_unit)
             {
-                if (wave != 0 && !(dbg & 1u))
+                const uint4* s128 = reinterpret_cast<const uint4*>(sdata);
+                const uint32_t l0 = (my_start + head) >> 4, l1 = (my_start + my_len + head + 15u) >> 4; // 16-byte lines that hold my unit
+                for (uint32_t j0 = l0; j0 < l1; j0 += 256)
                 {
-                    // Every 4th position of the history, oldest first -- the positions whose four bytes are an ALIGNED dword of the
-                    // window (position + head = 0 mod 4), so that one 16-byte LDS read delivers four of them: per 1024 inserts 4
-                    // reads instead of 16.  History older than 16 KiB is inserted every 16th position only (LTHIP_LZ4_DBG bit 15
-                    // inserts all of it: the far history hardly pays, tools/lz4_lane_model.c).
-                    const uint4* s128 = reinterpret_cast<const uint4*>(sdata);
-                    const uint32_t nlines = (my_start + head + 15u) >> 4; // 16-byte lines of the window that hold history
-                    const uint32_t near0 = (dbg & 32768u) || my_start <= 16384u ? 0u : ((my_start - 16384u + head) >> 4);
-                    for (uint32_t j0 = 0; j0 < nlines; j0 += 256)
+                    uint4 w[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
                     {
-                        uint4 w[4];
+                        const uint32_t j = j0 + u * 64 + (uint32_t)lane;
+                        w[u] = j < l1 ? s128[j] : make_uint4(0, 0, 0, 0);
+                    }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < 4; ++u)
+                    {
+                        const uint32_t j = j0 + u * 64 + (uint32_t)lane;
+                        const uint32_t q = 16u * j - head; // position of the line's first byte (may be "negative" in line 0)
+                        const uint32_t g4[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
                         {
-                            const uint32_t j = j0 + u * 64 + (uint32_t)lane;
-                            w[u] = j < nlines ? s128[j] : make_uint4(0, 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                        {
-                            const uint32_t j = j0 + u * 64 + (uint32_t)lane;
-                            const uint32_t q = 16u * j - head; // position of the line's first byte (may be "negative" in line 0)
-                            const uint32_t g[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
-                            const bool far = j < near0;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                            {
-                                const uint32_t pk = q + 4u * k;
-                                if (j < nlines && pk < my_start && (!far || k == 0)) // pk wraps above my_start when negative
-                                    tab[__umulhi(g[k] * 2654435761u, (uint32_t)TAB)] = (uint16_t)pk;
-                            }
+                            const uint32_t pk = q + 4u * k;
+                            if (j < l1 && pk >= my_start && pk < my_start + my_len) // (a wrapped "negative" position is above the unit)
+                                tab[__umulhi(g4[k] * 2654435761u, (uint32_t)TAB)] = (uint16_t)pk;
                         }
                     }
                 }
-                lz4_lane_parse<TAB, FMT>(sdata, head, tab, lane, my_start, my_len, start_limit, end_limit, sub, out, recs,
-                                         lane_recs + (uint64_t)unit * (64u * LZ4_LANE_MAXREC), st, dbg);
+            }
+            __syncthreads();
+            uint4* own = reinterpret_cast<uint4*>(tab);
+            uint4 mine[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                mine[v] = own[v * 64 + lane];
+#pragma unroll
+            for (int d = 1; d < G; d <<= 1)
+            {
+                uint4 other[NV];
+                if (wave >= d)
+                {
+                    const uint4* src_tab = reinterpret_cast<const uint4*>(tab - (size_t)d * TAB);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v)
+                        other[v] = src_tab[v * 64 + lane];
+                }
+                __syncthreads(); // every wave has read the round's input before anybody overwrites it
+                if (wave >= d)
+                {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v)
+                    {
+                        uint32_t a4[4] = {mine[v].x, mine[v].y, mine[v].z, mine[v].w};
+                        const uint32_t b4[4] = {other[v].x, other[v].y, other[v].z, other[v].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                        {
+                            const u16x2 x = __builtin_bit_cast(u16x2, a4[k]), y = __builtin_bit_cast(u16x2, b4[k]);
+                            a4[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(x, y));
+                        }
+                        mine[v] = make_uint4(a4[0], a4[1], a4[2], a4[3]);
+                        own[v * 64 + lane] = mine[v];
+                    }
+                }
+                __syncthreads();
+            }
+            // table k = units 0..k; mine is the one before (wave 0 takes the last one, which nobody needs, and clears it)
+            ptab = (wave == 0 ? tab + (size_t)(G - 1) * TAB : tab - (size_t)TAB);
+            if (wave == 0)
+            {
+                uint4* tv = reinterpret_cast<uint4*>(ptab);
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    tv[v * 64 + lane] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        {
+            if (have_unit)
+            {
+                K5P(2);
+                lz4_lane_parse<TAB, FMT>(sdata, head, ptab, lane, my_start, my_len, start_limit, end_limit, sub, out, recs,
+                                         lane_recs + (uint64_t)unit * (64u * LZ4_LANE_MAXREC), st, dbg K5P_PASS);
             }
         }
     }
@@ -1250,9 +1344,13 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         meta[unit] = m;
     }
     } // FMT 0
+    K5P(8);
     if constexpr (MODE == 1)
         __syncthreads(); // every wave is done with the window before the next group overwrites it
+    K5P(9);
     } // groups of this workgroup
+    if constexpr (MODE == 1)
+        K5P_FLUSH;
 }
 
 __device__ __forceinline__ void wg_emit_header(uint8_t* dst, uint32_t lits, uint32_t match_nibble, int tid, int nthreads)
@@ -1562,6 +1660,28 @@ static int upload_blocks(lthip_ctx* ctx, uint32_t block_count, const uint64_t* s
 // The parser of the match finder: "lanes" (default, MODE 1: 16 x 4 KiB units share a 64 KiB window, every lane parses its own
 // 64-byte sub-unit; 144 KiB of LDS, one workgroup of 16 waves per CU) or "batch" (LTHIP_LZ4_PARSER=batch, MODE 0: the round-1
 // parser, 8 x 4 KiB units per 32 KiB window, 52 KiB of LDS, 24 waves per CU).
+#ifdef LTHIP_K5_PROF
+extern "C" __attribute__((visibility("default"))) int lthip_k5_prof_dump(int reset)
+{
+    unsigned long long h[32];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_k5_prof), sizeof(h)) != hipSuccess)
+        return -1;
+    static const char* names[16] = {"stage+clear+barrier", "prefetch issue", "pre-seed", "loop: probe", "loop: extend fwd/back", "loop: long+record",
+                                    "cover scans", "emission", "unit end", "group barrier", "#probe iterations", "#extension rounds", "#hits", "#long matches", "", ""};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 10; ++i)
+        tot += h[i];
+    for (int i = 0; i < 14; ++i)
+        printf("k5prof %-24s %14llu%s\n", names[i], h[i], i < 10 ? (std::string("  ") + std::to_string(100.0 * (double)h[i] / (double)(tot ? tot : 1)).substr(0, 5) + " %").c_str() : "");
+    if (reset)
+    {
+        memset(h, 0, sizeof(h));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k5_prof), h, sizeof(h));
+    }
+    return 0;
+}
+#endif
+
 static bool lz4_lane_parser()
 {
     static const bool v = [] {
