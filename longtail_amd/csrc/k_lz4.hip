@@ -347,7 +347,7 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
     uint32_t p = s0, anchor = s0, nrec = 0, last_end = 0;
     uint32_t nmiss = 0; // consecutive misses of this lane: it steps 1 + nmiss / 4 bytes (the reference accelerates the same way,
                         // lz4.c:1044-1053, only 16 times slower; tools/lz4_lane_model.c: half the iterations for 0.3 % of the ratio)
-    const uint32_t ashift = (dbg >> 16) & 7u ? (dbg >> 16) & 7u : 2u;
+    const uint32_t ashift = (dbg >> 16) & 7u; // 0: dense, then aligned (the default); n: step 1 + misses >> n
     uint64_t* myrecs = lrecs + (uint32_t)sidx * LZ4_LANE_MAXREC;
 
     // A verified hit WAITS (the lane keeps its position and candidate, `pend`) until at least `wait_for` lanes hold one or nobody can
@@ -397,7 +397,15 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
             }
             else if (act)
             {
-                p += 1u + (nmiss >> ashift);
+                // Four misses step one byte each (all byte phases of a dword get their probe); after that only the positions whose
+                // four bytes are an address-aligned dword are probed -- the ones the history was inserted at, so that where the
+                // lane lands does not depend on where its sub-unit began.  (Rounds 1-2 stepped 1 + misses / 4 bytes: on data whose
+                // structures do not start on the sub-unit grid the lanes skipped the keys of the history -- "tokens" 1.69 -> 1.49,
+                // "mixed" 1.92 -> 1.81 at odd block offsets; tools/lz4_lane_model.c.  LTHIP_LZ4_DBG bits 16-18 = n keeps that rule.)
+                if (ashift)
+                    p += 1u + (nmiss >> ashift);
+                else
+                    p = nmiss < 4u ? p + 1u : (((p + head) | 3u) + 1u - head);
                 ++nmiss;
             }
         }

@@ -16,12 +16,13 @@ gib = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
 dbgs = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0").split(",")]
 kinds = (sys.argv[3] if len(sys.argv) > 3 else "mixed,records,tokens,lines,random").split(",")
 codec = sys.argv[4] if len(sys.argv) > 4 else "lz4"
+shift = int(sys.argv[5]) if len(sys.argv) > 5 else 0  # blocks start `shift` bytes into the data (phase experiments)
 ctx = Context(0)
 BLOCK = 8 << 20
 n = int(gib * (1 << 30)) // BLOCK * BLOCK
-data = torch.empty(n + 256, dtype=torch.uint8, device="cuda")
+data = torch.empty(n + BLOCK + 256, dtype=torch.uint8, device="cuda")
 nb = n // BLOCK
-b_off = np.arange(nb, dtype=np.int64) * BLOCK
+b_off = np.arange(nb, dtype=np.int64) * BLOCK + shift
 b_size = np.full(nb, BLOCK, np.int64)
 bound = b_size + b_size // 255 + 16 if codec == "lz4" else b_size + (b_size >> 8) + 64
 d_offs = np.concatenate([[0], np.cumsum((bound + 63) // 64 * 64)[:-1]])
@@ -29,7 +30,7 @@ arena = torch.empty(int(bound.sum()) + nb * 64 + 64, dtype=torch.uint8, device="
 back = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
 print(f"parser={os.environ.get('LTHIP_LZ4_PARSER', 'lanes')} {gib} GiB, {codec}")
 for kind in kinds:
-    nfiles = n // (1 << 20)
+    nfiles = (n + BLOCK) // (1 << 20)
     ctx.synth_fill(data, np.arange(nfiles, dtype=np.uint64) * np.uint64(1 << 20), np.full(nfiles, 1 << 20, np.uint64), asset_seeds(0xBEEF, 0, nfiles), KINDS[kind])
     ctx.sync()
     for dbg in dbgs:
@@ -44,8 +45,8 @@ for kind in kinds:
         t = ctx.timing_get()
         ctx.timing(False)
         dec = ctx.lz4_decompress_blocks if codec == "lz4" else ctx.zstd_decompress_blocks
-        out = dec(arena, d_offs, sz, back, b_off, b_size)
-        good = bool((out.cpu().numpy().view(np.uint32) == b_size).all()) and torch.equal(back[:n], data[:n])
+        out = dec(arena, d_offs, sz, back, b_off - shift, b_size)
+        good = bool((out.cpu().numpy().view(np.uint32) == b_size).all()) and all(torch.equal(back[int(o) - shift:int(o) - shift + BLOCK], data[int(o):int(o) + BLOCK]) for o in b_off[:4])
         k5 = t["lz4_segments"][0]
         rest = {k: round(v[0], 2) for k, v in t.items() if v[1] and k != "lz4_segments"}
         print(f"{kind:8s} dbg={dbg:<5d} ratio {n / sz.sum():7.4f}  K5 {k5:8.2f} ms = {n / k5 / 1e6:7.1f} GB/s  roundtrip={'ok' if good else 'FAIL'}  {rest}")
