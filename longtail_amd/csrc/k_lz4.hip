@@ -815,6 +815,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     // ---- my unit, positions relative to the group start ----
     const uint32_t my_start = (uint32_t)wave * sub_bytes;
     const bool have_unit = my_start < glen;
+    bool emit_unit = have_unit; // (the lane kernel leaves the units of a half-group alone that the classification pass has already written)
     const uint32_t my_len = have_unit ? (glen - my_start < sub_bytes ? glen - my_start : sub_bytes) : 0u;
     const uint32_t unit = blk.seg_base + gi * G + (uint32_t)wave;
     // parsing limits (lz4.c:963-964: mflimit / matchlimit, applied at the BLOCK end)
@@ -857,6 +858,10 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         // a sweep back.  Table k then holds units 0..k: wave k parses with table k-1 (wave 0 with a cleared one).  Same work for
         // every wave, 16 inserts per lane instead of up to 108, and the far history is complete instead of every 16th position.
         uint16_t* ptab = tab; // the table this wave parses with
+        // a half of the group (8 units) in which the classification pass saw no redundancy was skimmed and written there: its
+        // units only lend their bytes to the others' history here (LTHIP_LZ4_DBG bit 19: parse them again, the round-2 behaviour)
+        if (listed && !(dbg & 524288u) && !((worklist[1u + ngroups + grp] >> ((uint32_t)wave / (uint32_t)(G / 2))) & 1u))
+            emit_unit = false;
         if (!(dbg & 1u))
         {
             typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
@@ -939,7 +944,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             }
         }
         {
-            if (have_unit)
+            if (emit_unit)
             {
                 K5P(2);
                 lz4_lane_parse<TAB, FMT>(sdata, head, ptab, lane, my_start, my_len, start_limit, end_limit, sub, out, recs,
@@ -966,7 +971,9 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
                     if (tid == 0)
                     {
                         const uint32_t g16 = blk.grp_base + gi / (uint32_t)(LZ4_G_LANES / LZ4_G_BATCH);
-                        if (atomicExch(&worklist[1u + ngroups + g16], 1u) == 0u)
+                        // (bit h of the group's word: its half h holds redundancy; a half WITHOUT it is skimmed by this pass, and the
+                        // lane kernel only takes its bytes as history)
+                        if (atomicOr(&worklist[1u + ngroups + g16], 1u << (gi & 1u)) == 0u)
                             worklist[1u + atomicAdd(&worklist[0], 1u)] = g16;
                     }
                     return;
@@ -1285,13 +1292,13 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     if constexpr (FMT == 1)
     {
         // the unit's trailing literals complete its literal buffer; meta = ZbUnitMeta {nseq, nlit, tail, 0}
-        const uint32_t tail = have_unit ? my_start + my_len - st.anchor : 0u;
+        const uint32_t tail = emit_unit ? my_start + my_len - st.anchor : 0u;
         if (st.nseq != 0u)
         {
             for (uint32_t j = lane; j < tail; j += 64)
                 out[st.op + j] = sbytes[st.anchor + j + head];
         }
-        else if (have_unit && spec_dst)
+        else if (emit_unit && spec_dst)
         {
             // A unit without a sequence has no literal buffer (the entropy stage reads its bytes from the source,
             // ZbInput.src).  If its whole 128 KiB piece is like that the piece will most likely be a Raw_Block, and if the
@@ -1305,7 +1312,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         }
         // is the unit one repeated byte?  (zstd stores a 128 KiB piece made of such units as an RLE_Block)
         uint32_t uniform = 0;
-        if (have_unit)
+        if (emit_unit)
         {
             const uint32_t b0 = sbytes[my_start + head];
             const uint32_t rep = b0 * 0x01010101u;
@@ -1326,7 +1333,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             }
             uniform = __builtin_amdgcn_ballot_w64(diff != 0u) == 0ull ? (0x100u | b0) : 0u;
         }
-        if (have_unit && lane == 0)
+        if (emit_unit && lane == 0)
             reinterpret_cast<uint4*>(meta)[unit] = make_uint4(st.nseq, st.op + tail, tail, uniform);
     }
     else
@@ -1336,13 +1343,13 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     // bytes, and this unit's bytes belong at  header + its offset in the block.  They are still in LDS, so they are put
     // there now, speculatively; the stitch then only writes the header for such blocks instead of reading and writing
     // them again (a block that does have matches is laid out by the stitch as usual, overwriting these bytes).
-    if (FMT == 0 && spec_dst && have_unit && !st.have_first)
+    if (FMT == 0 && spec_dst && emit_unit && !st.have_first)
     {
         const uint64_t o = (uint64_t)(1u + lz4_len_bytes(blk.size)) + group_start + my_start;
         if (o + my_len <= (uint64_t)blk.dst_cap)
             wave_copy_lds_to_global(spec_dst + blk.dst_off + o, sdata, my_start + head, my_len, lane);
     }
-    if (have_unit && lane == 0)
+    if (emit_unit && lane == 0)
     {
         Lz4Meta m;
         m.seq_bytes = st.op;
