@@ -77,6 +77,11 @@ LTHIP_EXPORT int Longtail_Hip_GetLastError(void);
  * about 0.5 + 2 GiB (and as much HBM) however many chunkers longtail's job system keeps alive; a thread that needs a window beyond
  * the cap waits for one to be released.  The reference pools 4 * max_chunk bytes per chunker (hpcdcchunker.c:148-171). */
 LTHIP_EXPORT uint64_t Longtail_Hip_PinnedBytes(void);
+/* Diagnostics of the small-window batcher (plugin_batch.c): GPU submissions made and windows carried by them since the library
+ * was loaded; windows / batches = how many chunkers shared a submission on average. */
+LTHIP_EXPORT void Longtail_Hip_BatchStats(uint64_t* out_batches, uint64_t* out_windows);
+/* ... and of its content-hash memo: digest arrays remembered, HashBuffer calls answered from them */
+LTHIP_EXPORT void Longtail_Hip_MemoStats(uint64_t* out_puts, uint64_t* out_hits);
 
 /* =====================================================================================================
  * B. bulk device API
@@ -136,6 +141,11 @@ LTHIP_EXPORT int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const ui
 /* A plan of ONE part (created with part_count 1, offset 0, size = capacity) aimed at `size` <= capacity bytes: no allocation, no
  * kernel, no synchronisation -- the plugin chunker keeps one plan per window and re-aims it at every refill. */
 LTHIP_EXPORT int lthip_plan_resize_single(lthip_ctx* ctx, lthip_plan* plan, uint64_t size);
+/* The plan aimed at ANOTHER set of parts: at most as many as it was created with, and no more 16 KiB tiles in total; no
+ * allocation, no synchronisation (the tables are rewritten on the context's stream).  The plugin layer's batcher keeps one plan of
+ * N window slots and aims it at the windows of every submission. */
+LTHIP_EXPORT int lthip_plan_reaim(lthip_ctx* ctx, lthip_plan* plan, uint32_t part_count, const uint64_t* part_offsets /*host*/,
+                                  const uint64_t* part_sizes /*host*/);
 /* ctx may be NULL (e.g. the creating thread's context is gone): the device is synchronised instead of the stream */
 LTHIP_EXPORT void lthip_plan_destroy(lthip_ctx* ctx, lthip_plan* plan);
 /* upper bound on the number of chunks the plan can produce (size the output arrays with it) */
@@ -168,6 +178,16 @@ LTHIP_EXPORT int lthip_divtest_eval(uint32_t discriminator, uint32_t hash);
 LTHIP_EXPORT int lthip_hash_ranges(lthip_ctx* ctx, const void* d_data, uint64_t range_count, const uint64_t* d_offsets,
                                    const uint32_t* d_lens, uint32_t max_len /*upper bound of d_lens[], 0 = unknown*/,
                                    uint64_t* d_hashes);
+
+/* BLAKE3-64 of ONE input of at most 64 KiB in one launch, read where it lies and answered where `out` points: both must be device
+ * accessible (pinned host memory from lthip_malloc_pinned, or device memory).  What the plugin layer's HashBuffer uses for path
+ * strings and hash arrays.  Asynchronous on the context's stream; EINVAL above 64 KiB. */
+LTHIP_EXPORT int lthip_hash_one(lthip_ctx* ctx, const void* in, uint32_t len, uint64_t* out);
+
+/* BLAKE3-64 of runs of 64-bit values: d_out[i] = blake3(bytes of d_values[d_first[i] .. d_first[i+1])), i < run_count.  Over the
+ * chunk hashes and the part table of lthip_chunk_hash: every part's content hash (src/longtail.c:2518-2537 for a one-part asset). */
+LTHIP_EXPORT int lthip_hash_runs_u64(lthip_ctx* ctx, const uint64_t* d_values, const uint32_t* d_first, uint32_t run_count,
+                                     uint64_t* d_out);
 
 /* ---- phase 2: per-block compression ----------------------------------------------------------------
  * One call compresses a batch of stored blocks (the unit of CompressBlock, compressblockstore.c:67-141).

@@ -244,6 +244,52 @@ __global__ __launch_bounds__(256) void k_blake3_parents_small(const uint32_t* __
     hashes[c] = (uint64_t)base[0] | ((uint64_t)base[1] << 32);
 }
 
+// ONE small input (<= 64 KiB) in ONE launch, read where it lies -- pinned host memory, over the bus -- and answered into pinned host
+// memory: the plugin layer's HashBuffer of a path string, a chunk-hash array or a block's hash array (src/longtail.c:1272, 2522,
+// 3757), which used to cost two uploads, seven launches (counts, scan, leaves, parents) and a download per call.  Lane l hashes leaf
+// l byte by byte (speed is irrelevant here: the call is a bus round trip), lane 0 reduces the tree.
+__global__ __launch_bounds__(64) void k_blake3_one(const uint8_t* __restrict__ in, uint32_t len, uint64_t* __restrict__ out)
+{
+    __shared__ uint32_t s_cv[64 * 8];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t nleaf = leaves_of(len);
+    if (lane < nleaf)
+    {
+        const uint32_t llen = len - (lane << 10) < 1024u ? len - (lane << 10) : 1024u;
+        const uint8_t* p = in + ((size_t)lane << 10);
+        const uint32_t nblocks = llen ? (llen + 63u) >> 6 : 1u;
+        uint32_t cv[8] = {B3_IV0, B3_IV1, B3_IV2, B3_IV3, B3_IV4, B3_IV5, B3_IV6, B3_IV7};
+        for (uint32_t b = 0; b < nblocks; ++b)
+        {
+            const uint32_t bl = llen - b * 64u < 64u ? llen - b * 64u : 64u;
+            uint32_t m[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                m[i] = 0u;
+            for (uint32_t j = 0; j < bl; ++j)
+                m[j >> 2] |= (uint32_t)p[b * 64u + j] << (8u * (j & 3u));
+            uint32_t fl = b == 0 ? (uint32_t)F_CHUNK_START : 0u;
+            if (b + 1 == nblocks)
+                fl |= (uint32_t)F_CHUNK_END | (nleaf == 1u ? (uint32_t)F_ROOT : 0u);
+            b3_compress(cv, m, lane, bl, fl);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            s_cv[lane * 8 + i] = cv[i];
+    }
+    __syncthreads();
+    if (lane == 0)
+    {
+        for (uint32_t stride = 1; stride < nleaf; stride <<= 1)
+        {
+            const uint32_t last = (stride << 1) >= nleaf;
+            for (uint32_t k = 0; k + stride < nleaf; k += stride << 1)
+                b3_parent(s_cv + k * 8u, s_cv + (k + stride) * 8u, (uint32_t)F_PARENT | (last ? (uint32_t)F_ROOT : 0u));
+        }
+        *out = (uint64_t)s_cv[0] | ((uint64_t)s_cv[1] << 32);
+    }
+}
+
 // small trees, lane-dense: a workgroup owns the ranges whose first leaf slot lies in its window of PW slots, keeps their
 // chaining values in LDS and reduces ALL of them level by level -- the merges of one level (any range, any position) are
 // compacted into a list so that every lane of every wave has one, instead of one thread walking one tree serially with
@@ -472,5 +518,17 @@ int lthip_launch_blake3(lthip_ctx* ctx, const uint8_t* d_data, const uint64_t* d
                            (const uint32_t*)lp, host_count, (const uint32_t*)cv, d_hashes);
         LTHIP_LAUNCH_CHECK(ctx);
     }
+    return 0;
+}
+
+// BLAKE3-64 of one input of at most 64 KiB that the device can read where it is (pinned host memory or device memory), result
+// written to `out` (pinned host or device): one launch on the context's stream
+int lthip_launch_blake3_one(lthip_ctx* ctx, const void* in, uint32_t len, uint64_t* out)
+{
+    if (len > 65536u)
+        return lthip_fail(ctx, EINVAL, "blake3_one", "input above 64 KiB");
+    LaunchTimer t(ctx, LTHIP_K_B3_LEAF);
+    hipLaunchKernelGGL(k_blake3_one, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t*)in, len, out);
+    LTHIP_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -536,6 +536,8 @@ extern "C" int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const uint
     plan->total_bytes = bytes;
     plan->leaf_cap = leaves;
     plan->capacity_bytes = bytes;
+    plan->cap_parts = part_count ? part_count : 1;
+    plan->cap_tiles = tiles ? tiles : 1;
 
     hipError_t e = hipMalloc((void**)&plan->d_parts, sizeof(PartDev) * (part_count ? part_count : 1));
     if (e == hipSuccess)
@@ -583,6 +585,58 @@ extern "C" int lthip_plan_resize_single(lthip_ctx* ctx, lthip_plan* plan, uint64
     plan->total_bytes = size;
     plan->leaf_cap = div_up_u64(size, 1024) + cap;
     return lthip_stage_upload(ctx, plan->d_parts, &pd, sizeof pd, ctx->stream);
+}
+
+// A plan re-aimed at ANOTHER set of parts (any count up to the one it was created with, any layout whose tiles fit the tile
+// table it was created with): no allocation and no synchronisation -- the part table goes through the pinned staging ring, the
+// tile -> part table is rebuilt by its kernel on the stream.  What the plugin layer's batcher needs: one plan, a different set of
+// windows in every submission (plugin_batch.c).
+extern "C" int lthip_plan_reaim(lthip_ctx* ctx, lthip_plan* plan, uint32_t part_count, const uint64_t* part_offsets,
+                                const uint64_t* part_sizes)
+{
+    if (!ctx || !plan || (part_count && (!part_offsets || !part_sizes)))
+        return EINVAL;
+    if (part_count == 0 || part_count > plan->cap_parts)
+        return lthip_fail(ctx, EINVAL, "lthip_plan_reaim", "part count outside 1 .. the count the plan was created with");
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::vector<PartDev> parts(part_count);
+    uint64_t tiles = 0, bm0 = 0, bm1 = 0, region = 0, bytes = 0, leaves = 0;
+    for (uint32_t p = 0; p < part_count; ++p)
+    {
+        const uint64_t sz = part_sizes[p];
+        if ((part_offsets[p] & 15u) != 0 || sz > 0xFFFFFFFFull)
+            return lthip_fail(ctx, EINVAL, "lthip_plan_reaim", "part offsets must be 16-byte aligned, sizes < 4 GiB");
+        PartDev& pd = parts[p];
+        memset(&pd, 0, sizeof pd);
+        pd.off = part_offsets[p];
+        pd.size = sz;
+        pd.bm0_base = bm0;
+        pd.bm1_base = bm1;
+        pd.region_base = region;
+        pd.tile_base = (uint32_t)tiles;
+        const uint64_t cap = sz ? sz / plan->min_chunk + 1 : 0;
+        pd.region_cap = (uint32_t)cap;
+        const uint64_t t = div_up_u64(sz, 16384);
+        tiles += t;
+        bm0 += t * 256;
+        bm1 += t * 4;
+        region += cap;
+        bytes += sz;
+        leaves += div_up_u64(sz, 1024) + cap;
+    }
+    if (tiles > plan->cap_tiles)
+        return lthip_fail(ctx, EINVAL, "lthip_plan_reaim", "more 16 KiB tiles than the plan was created with");
+    plan->nparts = part_count;
+    plan->ntiles = tiles;
+    plan->bm0_words = bm0;
+    plan->bm1_words = bm1;
+    plan->chunk_cap = region;
+    plan->total_bytes = bytes;
+    plan->leaf_cap = leaves;
+    int err = lthip_stage_upload(ctx, plan->d_parts, parts.data(), sizeof(PartDev) * part_count, ctx->stream);
+    if (err)
+        return err;
+    return lthip_launch_tile_table(ctx, plan);
 }
 
 extern "C" void lthip_plan_destroy(lthip_ctx* ctx, lthip_plan* plan)
@@ -682,6 +736,49 @@ extern "C" int lthip_chunk_from_buffer(lthip_ctx* ctx, const void* d_data, uint6
     LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *out_len = len;
     return 0;
+}
+
+// BLAKE3-64 of runs of 64-bit values: d_out[i] = blake3(the bytes of d_values[d_first[i] .. d_first[i + 1])).  With d_values = the
+// chunk hashes of lthip_chunk_hash and d_first = its part table this is every part's CONTENT hash as ChunkAssets computes it for a
+// one-part asset (src/longtail.c:2518-2537): the plugin layer's batcher keeps it so that the core's later HashBuffer over the same
+// digests is answered from memory (plugin_batch.c).
+__global__ void k_runs_to_ranges(const uint32_t* __restrict__ first, uint32_t n, uint64_t* __restrict__ offs, uint32_t* __restrict__ lens)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+    {
+        offs[i] = 8ull * first[i];
+        lens[i] = 8u * (first[i + 1] - first[i]);
+    }
+}
+
+extern "C" int lthip_hash_runs_u64(lthip_ctx* ctx, const uint64_t* d_values, const uint32_t* d_first, uint32_t run_count,
+                                   uint64_t* d_out)
+{
+    if (!ctx || !d_values || !d_first || !d_out)
+        return EINVAL;
+    if (run_count == 0)
+        return 0;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    void* tab;
+    int err = lthip_scratch(ctx, S_TABLES, (size_t)run_count * 16, &tab);
+    if (err)
+        return err;
+    uint64_t* offs = (uint64_t*)tab;
+    uint32_t* lens = (uint32_t*)(offs + run_count);
+    hipLaunchKernelGGL(k_runs_to_ranges, dim3((run_count + 255u) / 256u), dim3(256), 0, ctx->stream, d_first, run_count, offs, lens);
+    LTHIP_LAUNCH_CHECK(ctx);
+    return lthip_launch_blake3(ctx, (const uint8_t*)d_values, offs, lens, nullptr, run_count, 0, 0, d_out);
+}
+
+// One small input where it lies (see k_blake3_one): `in` and `out` must be readable / writable by the device -- pinned host memory
+// (lthip_malloc_pinned) or device memory.  Asynchronous on the context's stream.
+extern "C" int lthip_hash_one(lthip_ctx* ctx, const void* in, uint32_t len, uint64_t* out)
+{
+    if (!ctx || !out || (len && !in))
+        return EINVAL;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return lthip_launch_blake3_one(ctx, in, len, out);
 }
 
 extern "C" int lthip_hash_ranges(lthip_ctx* ctx, const void* d_data, uint64_t range_count, const uint64_t* d_offsets,

@@ -51,6 +51,8 @@ struct lthip_plan
     uint64_t bm1_words;
     uint64_t leaf_cap;
     uint64_t capacity_bytes; // bytes the plan was created for (lthip_plan_resize_single may aim it at fewer)
+    uint32_t cap_parts;      // parts / tiles the device tables were allocated for (lthip_plan_reaim)
+    uint64_t cap_tiles;
     PartDev* d_parts;
     uint32_t* d_tile_part;
 };
@@ -179,6 +181,8 @@ int lthip_exclusive_scan_u32(lthip_ctx* ctx, const uint32_t* d_in, uint32_t* d_o
 int lthip_launch_blake3(lthip_ctx* ctx, const uint8_t* d_data, const uint64_t* d_offsets, const uint32_t* d_lens,
                         const uint32_t* d_count, uint64_t count_bound, uint64_t leaf_bound, uint64_t max_len,
                         uint64_t* d_hashes);
+
+int lthip_launch_blake3_one(lthip_ctx* ctx, const void* in, uint32_t len, uint64_t* out);
 
 int lthip_launch_from_buffer(lthip_ctx* ctx, const uint8_t* d_data, uint32_t n, uint32_t min_chunk, const DivTest& dv,
                              uint64_t* d_out);

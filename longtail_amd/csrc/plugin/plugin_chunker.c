@@ -72,6 +72,18 @@ static void chunker_free(struct HipChunker* c)
     ltp_free(c);
 }
 
+/* LONGTAIL_HIP_BATCH=0 keeps every window on its thread's own stream (the round-1/2 behaviour; ablation) */
+static int batching_enabled(void)
+{
+    static int v = -1;
+    if (v < 0)
+    {
+        const char* e = getenv("LONGTAIL_HIP_BATCH");
+        v = !(e && e[0] == '0');
+    }
+    return v;
+}
+
 /* fill the window from the feeder and run the GPU over it */
 static int chunker_refill(struct HipChunker* c, Longtail_Chunker_Feeder feeder, void* feeder_context, int* feeder_failed)
 {
@@ -129,21 +141,33 @@ static int chunker_refill(struct HipChunker* c, Longtail_Chunker_Feeder feeder, 
         return 0;
 
     uint64_t total = 0;
-    err = lthip_plan_resize_single(ctx, w->plan, c->have);
-    if (!err)
-        err = lthip_copy_h2d(ctx, w->d_win, w->h_win, (size_t)c->have);
-    if (!err)
-        err = lthip_chunk_hash(ctx, w->plan, w->d_win, w->d_off, w->d_len, w->d_hash, w->d_first, &total);
-    if (err)
-        return err;
-    if (total > w->ccap)
-        return EIO;
-    err = lthip_copy_d2h(ctx, w->h_off, w->d_off, (size_t)total * 8);
-    if (!err) err = lthip_copy_d2h(ctx, w->h_len, w->d_len, (size_t)total * 4);
-    if (!err) err = lthip_copy_d2h(ctx, w->h_hash, w->d_hash, (size_t)total * 8);
-    if (!err) err = lthip_ctx_sync(ctx);
-    if (err)
-        return err;
+    if (w->cls == 0 && c->have <= LTP_WINDOW_SMALL && batching_enabled())
+    {
+        /* a small window: submitted together with the other threads' (plugin_batch.c) */
+        err = ltp_batch_chunk_hash(w, c->have, c->min, c->avg, c->max, &total);
+        if (err)
+            return err;
+        if (total > w->ccap)
+            return EIO;
+    }
+    else
+    {
+        err = lthip_plan_resize_single(ctx, w->plan, c->have);
+        if (!err)
+            err = lthip_copy_h2d(ctx, w->d_win, w->h_win, (size_t)c->have);
+        if (!err)
+            err = lthip_chunk_hash(ctx, w->plan, w->d_win, w->d_off, w->d_len, w->d_hash, w->d_first, &total);
+        if (err)
+            return err;
+        if (total > w->ccap)
+            return EIO;
+        err = lthip_copy_d2h(ctx, w->h_off, w->d_off, (size_t)total * 8);
+        if (!err) err = lthip_copy_d2h(ctx, w->h_len, w->d_len, (size_t)total * 4);
+        if (!err) err = lthip_copy_d2h(ctx, w->h_hash, w->d_hash, (size_t)total * 8);
+        if (!err) err = lthip_ctx_sync(ctx);
+        if (err)
+            return err;
+    }
     c->ntotal = (uint32_t)total;
     if (c->eof)
         c->nfinal = c->ntotal;
@@ -183,7 +207,10 @@ static void HipChunker_Dispose(struct Longtail_API* base_api)
     pthread_mutex_destroy(&api->lock);
     ltp_free(api);
     if (__atomic_sub_fetch(&g_api_count, 1, __ATOMIC_ACQ_REL) == 0)
+    {
+        ltp_batch_shutdown();
         ltp_window_pool_trim();
+    }
 }
 
 static int HipChunker_GetMinChunkSize(struct Longtail_ChunkerAPI* chunker_api, uint32_t* out_min_chunk_size)

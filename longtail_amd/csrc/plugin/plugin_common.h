@@ -89,6 +89,14 @@ void ltp_window_release(struct ltp_chunk_window* w);
 void ltp_window_pool_trim(void); /* frees the idle windows (called when the last HIP ChunkerAPI is disposed) */
 uint64_t ltp_window_pool_pinned_bytes(void);
 
+/* ---- plugin_batch.c: chunk + hash of a SMALL window (have <= LTP_WINDOW_SMALL bytes in w->h_win) through the dispatcher thread,
+ * together with whatever other threads have queued; fills w->h_off / h_len / h_hash like the direct path and blocks until done ---- */
+int ltp_batch_chunk_hash(struct ltp_chunk_window* w, uint64_t have, uint32_t min_chunk, uint32_t avg_chunk, uint32_t max_chunk,
+                         uint64_t* out_total);
+void ltp_batch_shutdown(void);
+/* content-hash memo of the batcher: 1 + the digest when `data` is byte for byte a digest array whose BLAKE3 the GPU has computed */
+int ltp_memo_get(const void* data, uint32_t length, uint64_t* out_hash);
+
 /* ---- error latch: void / value-returning entry points of the plugin structs (HashAPI.Hash, EndContext) cannot report failure;
  * the first errno of such a call on a thread is kept until read.  Exported as Longtail_Hip_GetLastError(). ---- */
 void ltp_latch_error(int err);

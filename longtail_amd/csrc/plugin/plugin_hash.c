@@ -29,12 +29,34 @@ struct HipHashContext
     int err; /* first failure of a Hash() call on this context: EndContext reports it through the error latch */
 };
 
+#define LTP_HASH_ONE_MAX 65536u
+
 static int gpu_hash(const void* data, uint32_t length, uint64_t* out_hash)
 {
     struct ltp_thread_state* ts = ltp_thread_state_get();
     if (!ts)
         return ENODEV;
     lthip_ctx* ctx = ts->ctx;
+    if (length <= LTP_HASH_ONE_MAX)
+    {
+        /* small inputs (paths, hash arrays): copied into the thread's pinned block, hashed from there by ONE launch that also
+         * writes the digest back into it -- no upload, no download, one synchronisation */
+        const size_t data_bytes = ((size_t)length + 15u) & ~(size_t)15u;
+        int err = ltp_pin_reserve(ctx, &ts->h_pin, data_bytes + 64);
+        if (err)
+            return err;
+        uint8_t* h = (uint8_t*)ts->h_pin.p;
+        if (length)
+            memcpy(h, data, length);
+        uint64_t* res = (uint64_t*)(h + data_bytes);
+        err = lthip_hash_one(ctx, h, length, res);
+        if (!err)
+            err = lthip_ctx_sync(ctx);
+        if (err)
+            return err;
+        *out_hash = *res;
+        return 0;
+    }
     /* layout of d_in: [data, padded to 16][u64 offset][u32 len][pad][u64 hash] */
     const size_t data_bytes = ((size_t)length + 15u) & ~(size_t)15u;
     int err = ltp_dev_reserve(ctx, &ts->d_in, data_bytes + 64);
@@ -46,12 +68,11 @@ static int gpu_hash(const void* data, uint32_t length, uint64_t* out_hash)
     uint64_t* h_tab = (uint64_t*)ts->h_pin.p;
     h_tab[0] = 0;                  /* offset */
     ((uint32_t*)h_tab)[2] = length; /* len at byte 8 */
-    if (length)
-        err = lthip_copy_h2d(ctx, d, data, length);
+    err = lthip_copy_h2d(ctx, d, data, length);
     if (!err)
         err = lthip_copy_h2d(ctx, d + data_bytes, h_tab, 16);
     if (!err)
-        err = lthip_hash_ranges(ctx, d, 1, (const uint64_t*)(d + data_bytes), (const uint32_t*)(d + data_bytes + 8), length ? length : 1,
+        err = lthip_hash_ranges(ctx, d, 1, (const uint64_t*)(d + data_bytes), (const uint32_t*)(d + data_bytes + 8), length,
                                 (uint64_t*)(d + data_bytes + 16));
     if (!err)
         err = lthip_copy_d2h(ctx, &h_tab[4], d + data_bytes + 16, 8);
@@ -137,6 +158,8 @@ static int HipHash_HashBuffer(struct Longtail_HashAPI* hash_api, uint32_t length
     if (!hash_api || !data || !out_hash)
         return EINVAL; /* longtail_blake3.c:94-96 */
     if (length && ltp_window_lookup(data, length, out_hash))
+        return 0;
+    if (ltp_memo_get(data, length, out_hash)) /* an asset's digest array the batcher has hashed on the GPU already */
         return 0;
     return gpu_hash(data, length, out_hash);
 }

@@ -16,10 +16,13 @@ struct lthip_ctx
 {
     int dummy;
 };
+#define MOCK_MAX_PARTS 64
 struct lthip_plan
 {
-    uint64_t capacity, size;
+    uint64_t capacity, size; /* single-part view (part 0) */
     uint32_t min, avg, max;
+    uint32_t nparts, cap_parts;
+    uint64_t offs[MOCK_MAX_PARTS], sizes[MOCK_MAX_PARTS], cap_bytes;
 };
 
 static int g_fail_alloc_after = -1; /* fault injection: the n-th allocation from now fails */
@@ -83,7 +86,7 @@ int lthip_plan_create(lthip_ctx* c, uint32_t parts, const uint64_t* offs, const 
                       lthip_plan** out)
 {
     (void)c;
-    if (parts != 1 || offs[0] != 0 || mn < 48 || mn > av || av > mx)
+    if (parts < 1 || parts > MOCK_MAX_PARTS || offs[0] != 0 || mn < 48 || mn > av || av > mx)
         return EINVAL;
     if (alloc_fails())
         return ENOMEM;
@@ -91,6 +94,13 @@ int lthip_plan_create(lthip_ctx* c, uint32_t parts, const uint64_t* offs, const 
     if (!p)
         return ENOMEM;
     p->capacity = p->size = sizes[0];
+    p->nparts = p->cap_parts = parts;
+    for (uint32_t i = 0; i < parts; ++i)
+    {
+        p->offs[i] = offs[i];
+        p->sizes[i] = sizes[i];
+        p->cap_bytes += sizes[i];
+    }
     p->min = mn;
     p->avg = av;
     p->max = mx;
@@ -103,6 +113,27 @@ int lthip_plan_resize_single(lthip_ctx* c, lthip_plan* p, uint64_t size)
     if (size > p->capacity)
         return EINVAL;
     p->size = size;
+    p->sizes[0] = size;
+    return 0;
+}
+int lthip_plan_reaim(lthip_ctx* c, lthip_plan* p, uint32_t parts, const uint64_t* offs, const uint64_t* sizes)
+{
+    (void)c;
+    uint64_t bytes = 0;
+    if (parts < 1 || parts > p->cap_parts)
+        return EINVAL;
+    for (uint32_t i = 0; i < parts; ++i)
+    {
+        if (offs[i] & 15u)
+            return EINVAL;
+        p->offs[i] = offs[i];
+        p->sizes[i] = sizes[i];
+        bytes += sizes[i];
+    }
+    if (bytes > p->cap_bytes)
+        return EINVAL;
+    p->nparts = parts;
+    p->size = sizes[0];
     return 0;
 }
 void lthip_plan_destroy(lthip_ctx* c, lthip_plan* p)
@@ -110,31 +141,69 @@ void lthip_plan_destroy(lthip_ctx* c, lthip_plan* p)
     (void)c;
     free(p);
 }
-uint64_t lthip_plan_chunk_capacity(const lthip_plan* p) { return p->size / p->min + 1; }
+uint64_t lthip_plan_chunk_capacity(const lthip_plan* p)
+{
+    uint64_t cap = 0;
+    for (uint32_t i = 0; i < p->nparts; ++i)
+        cap += p->sizes[i] ? p->sizes[i] / p->min + 1 : 0;
+    return cap ? cap : 1;
+}
 int lthip_chunk_hash(lthip_ctx* c, const lthip_plan* p, const void* d, uint64_t* offs, uint32_t* lens, uint64_t* hashes, uint32_t* first,
                      uint64_t* out_total)
 {
     (void)c;
-    const uint64_t cap = p->size / p->min + 2;
-    const uint64_t n = lto_hpcdc_chunk_stream((const uint8_t*)d, p->size, p->min, p->avg, p->max, lens, cap);
-    uint64_t o = 0;
-    for (uint64_t i = 0; i < n; ++i)
+    uint64_t n_all = 0;
+    for (uint32_t part = 0; part < p->nparts; ++part)
     {
-        offs[i] = o;
-        o += lens[i];
+        const uint64_t size = p->sizes[part];
+        const uint8_t* base = (const uint8_t*)d + p->offs[part];
+        const uint64_t cap = size / p->min + 2;
+        uint32_t* tmp = (uint32_t*)malloc(sizeof(uint32_t) * cap);
+        if (!tmp)
+            return ENOMEM;
+        const uint64_t n = size ? lto_hpcdc_chunk_stream(base, size, p->min, p->avg, p->max, tmp, cap) : 0;
+        uint64_t o = (uint64_t)(base - (const uint8_t*)d);
+        first[part] = (uint32_t)n_all;
+        for (uint64_t i = 0; i < n; ++i)
+        {
+            offs[n_all + i] = o;
+            lens[n_all + i] = tmp[i];
+            o += tmp[i];
+        }
+        free(tmp);
+        if (hashes)
+            lto_blake3_u64_many((const uint8_t*)d, offs + n_all, lens + n_all, n, hashes + n_all);
+        n_all += n;
     }
-    if (hashes)
-        lto_blake3_u64_many((const uint8_t*)d, offs, lens, n, hashes);
-    first[0] = 0;
-    first[1] = (uint32_t)n;
+    first[p->nparts] = (uint32_t)n_all;
     if (out_total)
-        *out_total = n;
+        *out_total = n_all;
     return 0;
 }
 int lthip_chunk_from_buffer(lthip_ctx* c, const void* d, uint64_t size, uint32_t mn, uint32_t av, uint32_t mx, uint64_t* out_len)
 {
     (void)c;
     *out_len = lto_hpcdc_next_from_buffer((const uint8_t*)d, size, mn, av, mx);
+    return 0;
+}
+int lthip_hash_runs_u64(lthip_ctx* c, const uint64_t* v, const uint32_t* first, uint32_t n, uint64_t* out)
+{
+    (void)c;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        const uint64_t off = 8ull * first[i];
+        const uint32_t len = 8u * (first[i + 1] - first[i]);
+        lto_blake3_u64_many((const uint8_t*)v, &off, &len, 1, out + i);
+    }
+    return 0;
+}
+int lthip_hash_one(lthip_ctx* c, const void* in, uint32_t len, uint64_t* out)
+{
+    (void)c;
+    const uint64_t off = 0;
+    if (len > 65536u)
+        return EINVAL;
+    lto_blake3_u64_many((const uint8_t*)in, &off, &len, 1, out);
     return 0;
 }
 int lthip_hash_ranges(lthip_ctx* c, const void* d, uint64_t n, const uint64_t* offs, const uint32_t* lens, uint32_t max_len, uint64_t* out)

@@ -40,6 +40,11 @@ for rep in range(2):
 assert vi_hip == vi_cpu
 print(f"CreateVersionIndex {total / 2**30:.1f} GiB: HIP plugins {total / t_hip / 1e9:.2f} GB/s, reference CPU plugins {total / t_cpu / 1e9:.2f} GB/s "
       f"(VersionIndex identical); pinned window memory held by the HIP chunkers: {d.Longtail_Hip_PinnedBytes() / 2**20:.0f} MiB")
+bs = (C.c_uint64 * 4)()
+d.Longtail_Hip_BatchStats(C.byref(bs, 0), C.byref(bs, 8))
+d.Longtail_Hip_MemoStats(C.byref(bs, 16), C.byref(bs, 24))
+if bs[0]:
+    print(f"small-window batcher: {bs[1]} windows in {bs[0]} submissions ({bs[1] / bs[0]:.1f} per submission); content-hash memo: {bs[2]} digest arrays kept, {bs[3]} HashBuffer calls answered")
 for rep in range(2):
     res_h = r.ingest_roundtrip(files, 65536, 8 << 20, 1024, tag, workers, chunker, hasher, codec_api)
     res_c = r.ingest_roundtrip(files, 65536, 8 << 20, 1024, tag, workers)
