@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """PCIe-inclusive rate of the DROP-IN path: the unmodified reference core (oracle/_ref) driving the HIP
 ChunkerAPI + HashAPI (+ LZ4 / ZStd CompressionAPI) through host buffers, next to the reference's own CPU plugins, same tree,
-same worker count.  usage: tools/plugin_rate.py [files] [file_mib] [workers] [kind] [codec] [tmpfs]"""
+same worker count.  usage: tools/plugin_rate.py [files] [file_mib] [workers] [kind] [codec] [tmpfs|mem] [index]
+(`index`: CreateVersionIndex only, one repetition after a warm-up on the first 1024 files -- the 64 GiB headline tree)"""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -34,9 +35,15 @@ assert chunker and hasher and codec_api
 files = [(f"d{i % 8}/f{i:04d}.bin", o.synth(mib << 20, 500 + i, KINDS[kind])) for i in range(nfiles)]
 total = sum(len(b) for _, b in files)
 print(f"{nfiles} x {mib} MiB {kind} files, {workers} bikeshed workers, {codec}, source tree in {storage}")
-for rep in range(2):
+index_only = len(sys.argv) > 7 and sys.argv[7] == "index"
+if index_only:
+    r.version_index(files[:1024], 65536, workers, 0, chunker, hasher)  # warm-up: contexts, window pool, dispatcher
     vi_hip, t_hip = r.version_index(files, 65536, workers, 0, chunker, hasher)
     vi_cpu, t_cpu = r.version_index(files, 65536, workers, 0)
+else:
+    for rep in range(2):
+        vi_hip, t_hip = r.version_index(files, 65536, workers, 0, chunker, hasher)
+        vi_cpu, t_cpu = r.version_index(files, 65536, workers, 0)
 assert vi_hip == vi_cpu
 print(f"CreateVersionIndex {total / 2**30:.1f} GiB: HIP plugins {total / t_hip / 1e9:.2f} GB/s, reference CPU plugins {total / t_cpu / 1e9:.2f} GB/s "
       f"(VersionIndex identical); pinned window memory held by the HIP chunkers: {d.Longtail_Hip_PinnedBytes() / 2**20:.0f} MiB")
@@ -45,6 +52,8 @@ d.Longtail_Hip_BatchStats(C.byref(bs, 0), C.byref(bs, 8))
 d.Longtail_Hip_MemoStats(C.byref(bs, 16), C.byref(bs, 24))
 if bs[0]:
     print(f"small-window batcher: {bs[1]} windows in {bs[0]} submissions ({bs[1] / bs[0]:.1f} per submission); content-hash memo: {bs[2]} digest arrays kept, {bs[3]} HashBuffer calls answered")
+if index_only:
+    sys.exit(0)
 for rep in range(2):
     res_h = r.ingest_roundtrip(files, 65536, 8 << 20, 1024, tag, workers, chunker, hasher, codec_api)
     res_c = r.ingest_roundtrip(files, 65536, 8 << 20, 1024, tag, workers)
