@@ -184,6 +184,17 @@ LTHIP_EXPORT int lthip_hash_ranges(lthip_ctx* ctx, const void* d_data, uint64_t 
  * strings and hash arrays.  Asynchronous on the context's stream; EINVAL above 64 KiB. */
 LTHIP_EXPORT int lthip_hash_one(lthip_ctx* ctx, const void* in, uint32_t len, uint64_t* out);
 
+/* Streaming BLAKE3-64 with O(1) state (Blake3Hash_BeginContext/_Hash/_EndContext, longtail_blake3.c:24-79): the caller cuts the
+ * stream into batches of LTHIP_B3_STREAM_BATCH bytes (device memory, 16-byte aligned), calls lthip_b3_stream_batch for the batches
+ * in order -- a batch only when at least one byte follows it -- and lthip_b3_stream_final with the rest (1 .. one batch of bytes, or
+ * 0 bytes after 0 batches: the empty stream).  d_stack: LTHIP_B3_STREAM_STACK_BYTES of device memory per stream; d_out: device or
+ * pinned host memory.  Asynchronous on the context's stream.  Streams below 4 TiB. */
+#define LTHIP_B3_STREAM_BATCH (1u << 20)
+#define LTHIP_B3_STREAM_STACK_BYTES 2048u
+LTHIP_EXPORT int lthip_b3_stream_batch(lthip_ctx* ctx, const void* d_data, uint64_t batch_index, void* d_stack);
+LTHIP_EXPORT int lthip_b3_stream_final(lthip_ctx* ctx, const void* d_tail, uint32_t tail_len, uint64_t batch_count, const void* d_stack,
+                                       uint64_t* d_out);
+
 /* BLAKE3-64 of runs of 64-bit values: d_out[i] = blake3(bytes of d_values[d_first[i] .. d_first[i+1])), i < run_count.  Over the
  * chunk hashes and the part table of lthip_chunk_hash: every part's content hash (src/longtail.c:2518-2537 for a one-part asset). */
 LTHIP_EXPORT int lthip_hash_runs_u64(lthip_ctx* ctx, const uint64_t* d_values, const uint32_t* d_first, uint32_t run_count,

@@ -290,6 +290,134 @@ __global__ __launch_bounds__(64) void k_blake3_one(const uint8_t* __restrict__ i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Streaming (Blake3Hash_BeginContext / _Hash / _EndContext, lib/blake3/longtail_blake3.c:24-79; ext/blake3.c:462-618).
+// The reference keeps O(1) state: a partial 1 KiB chunk and a stack of subtree chaining values (one per set bit of the chunk
+// count).  Same here, with the stack in device memory and the unit of work a BATCH of 1024 full leaves (1 MiB):
+//   k_blake3_stream_batch  leaves leaf0 .. leaf0 + 1023 of the stream -> their complete subtree's chaining value (1024 threads, ten
+//                          merge levels in LDS) -> pushed onto the stack, followed by `merges` = trailing-zeros(batch count) parent
+//                          compressions (equal-sized neighbours merge: blake3.c:add_chunk_chaining_value restated per batch)
+//   k_blake3_stream_final  the rest of the stream (0 .. 1 MiB, never empty unless the whole stream is): its leaves in parallel, then
+//                          one thread pushes them the same way and folds the stack from the top, ROOT on the last compression
+//                          (blake3.c:576-618); the empty stream is the one empty ROOT leaf.
+// A batch is only hashed once a byte beyond it has arrived (the host holds it back), so the final kernel always has the last leaf.
+// ---------------------------------------------------------------------------------------------------
+constexpr int B3S_LEAVES = 1024;
+
+__global__ __launch_bounds__(B3S_LEAVES) void k_blake3_stream_batch(const uint8_t* __restrict__ data, uint32_t leaf0,
+                                                                      uint32_t* __restrict__ stack, uint32_t depth_in, uint32_t merges)
+{
+    __shared__ uint32_t s_cv[B3S_LEAVES * 8];
+    const uint32_t t = threadIdx.x;
+    {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(data) + (size_t)t * 256u; // 16-byte aligned device buffer
+        uint32_t cv[8] = {B3_IV0, B3_IV1, B3_IV2, B3_IV3, B3_IV4, B3_IV5, B3_IV6, B3_IV7};
+        for (uint32_t b = 0; b < 16u; ++b)
+        {
+            uint32_t m[16];
+            const uint4* q = reinterpret_cast<const uint4*>(p + b * 16u);
+            const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+            m[0] = v0.x; m[1] = v0.y; m[2] = v0.z; m[3] = v0.w; m[4] = v1.x; m[5] = v1.y; m[6] = v1.z; m[7] = v1.w;
+            m[8] = v2.x; m[9] = v2.y; m[10] = v2.z; m[11] = v2.w; m[12] = v3.x; m[13] = v3.y; m[14] = v3.z; m[15] = v3.w;
+            b3_compress(cv, m, leaf0 + t, 64u, (b == 0 ? (uint32_t)F_CHUNK_START : 0u) | (b == 15u ? (uint32_t)F_CHUNK_END : 0u));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            s_cv[t * 8 + i] = cv[i];
+    }
+    __syncthreads();
+    for (uint32_t stride = 1; stride < (uint32_t)B3S_LEAVES; stride <<= 1)
+    {
+        if ((t & (2u * stride - 1u)) == 0u)
+            b3_parent(s_cv + t * 8u, s_cv + (t + stride) * 8u, (uint32_t)F_PARENT);
+        __syncthreads();
+    }
+    if (t == 0)
+    {
+        uint32_t depth = depth_in;
+        for (int i = 0; i < 8; ++i)
+            stack[depth * 8u + i] = s_cv[i];
+        ++depth;
+        for (uint32_t m = 0; m < merges; ++m)
+        {
+            b3_parent(stack + (depth - 2u) * 8u, stack + (depth - 1u) * 8u, (uint32_t)F_PARENT);
+            --depth;
+        }
+    }
+}
+
+__global__ __launch_bounds__(B3S_LEAVES) void k_blake3_stream_final(const uint8_t* __restrict__ tail, uint32_t tail_len, uint32_t leaf0,
+                                                                      const uint32_t* __restrict__ stack, uint32_t depth_in,
+                                                                      uint64_t* __restrict__ out)
+{
+    __shared__ uint32_t s_cv[B3S_LEAVES * 8];
+    __shared__ uint32_t s_stack[64 * 8];
+    const uint32_t t = threadIdx.x;
+    const uint32_t nleaf = tail_len ? (tail_len + 1023u) >> 10 : (leaf0 == 0u ? 1u : 0u);
+    const bool single = leaf0 == 0u && nleaf == 1u; // the whole stream is one leaf: it carries ROOT itself
+    if (t < nleaf)
+    {
+        const uint32_t llen = tail_len - (t << 10) < 1024u ? tail_len - (t << 10) : 1024u;
+        const uint8_t* p = tail + ((size_t)t << 10);
+        const uint32_t nblocks = llen ? (llen + 63u) >> 6 : 1u;
+        uint32_t cv[8] = {B3_IV0, B3_IV1, B3_IV2, B3_IV3, B3_IV4, B3_IV5, B3_IV6, B3_IV7};
+        for (uint32_t b = 0; b < nblocks; ++b)
+        {
+            const uint32_t bl = llen - b * 64u < 64u ? llen - b * 64u : 64u;
+            uint32_t m[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                m[i] = 0u;
+            for (uint32_t j = 0; j < bl; ++j)
+                m[j >> 2] |= (uint32_t)p[b * 64u + j] << (8u * (j & 3u));
+            uint32_t fl = b == 0 ? (uint32_t)F_CHUNK_START : 0u;
+            if (b + 1 == nblocks)
+                fl |= (uint32_t)F_CHUNK_END | (single ? (uint32_t)F_ROOT : 0u);
+            b3_compress(cv, m, leaf0 + t, bl, fl);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            s_cv[t * 8 + i] = cv[i];
+    }
+    for (uint32_t i = t; i < depth_in * 8u; i += (uint32_t)B3S_LEAVES)
+        s_stack[i] = stack[i];
+    __syncthreads();
+    if (t != 0)
+        return;
+    if (single)
+    {
+        *out = (uint64_t)s_cv[0] | ((uint64_t)s_cv[1] << 32);
+        return;
+    }
+    // every leaf but the last is pushed and merged eagerly: after leaf number g (0-based) the stack holds one subtree per set bit of
+    // g + 1.  The stack counts BATCHES below the tail (leaf0 is a multiple of 1024, so its entries are the set bits of leaf0 >> 10
+    // and sit below anything the tail pushes).
+    uint32_t depth = depth_in;
+    for (uint32_t j = 0; j + 1 < nleaf; ++j)
+    {
+        for (int i = 0; i < 8; ++i)
+            s_stack[depth * 8u + i] = s_cv[j * 8u + i];
+        ++depth;
+        uint32_t cnt = leaf0 + j + 1u; // chunks so far
+        while ((cnt & 1u) == 0u)      // equal-sized neighbours merge
+        {
+            b3_parent(s_stack + (depth - 2u) * 8u, s_stack + (depth - 1u) * 8u, (uint32_t)F_PARENT);
+            --depth;
+            cnt >>= 1;
+        }
+    }
+    // the last leaf's value, folded with the stack from the top; ROOT on the final compression
+    uint32_t* cur = s_cv + (nleaf - 1u) * 8u;
+    while (depth > 0u)
+    {
+        uint32_t* left = s_stack + (depth - 1u) * 8u;
+        b3_parent(left, cur, (uint32_t)F_PARENT | (depth == 1u ? (uint32_t)F_ROOT : 0u));
+        cur = left;
+        --depth;
+    }
+    *out = (uint64_t)cur[0] | ((uint64_t)cur[1] << 32);
+}
+
 // small trees, lane-dense: a workgroup owns the ranges whose first leaf slot lies in its window of PW slots, keeps their
 // chaining values in LDS and reduces ALL of them level by level -- the merges of one level (any range, any position) are
 // compacted into a list so that every lane of every wave has one, instead of one thread walking one tree serially with
@@ -529,6 +657,24 @@ int lthip_launch_blake3_one(lthip_ctx* ctx, const void* in, uint32_t len, uint64
         return lthip_fail(ctx, EINVAL, "blake3_one", "input above 64 KiB");
     LaunchTimer t(ctx, LTHIP_K_B3_LEAF);
     hipLaunchKernelGGL(k_blake3_one, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t*)in, len, out);
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int lthip_launch_blake3_stream_batch(lthip_ctx* ctx, const void* d_data, uint32_t leaf0, uint32_t* d_stack, uint32_t depth_in, uint32_t merges)
+{
+    LaunchTimer t(ctx, LTHIP_K_B3_LEAF);
+    hipLaunchKernelGGL(k_blake3_stream_batch, dim3(1), dim3(B3S_LEAVES), 0, ctx->stream, (const uint8_t*)d_data, leaf0, d_stack, depth_in, merges);
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int lthip_launch_blake3_stream_final(lthip_ctx* ctx, const void* d_tail, uint32_t tail_len, uint32_t leaf0, const uint32_t* d_stack,
+                                     uint32_t depth, uint64_t* d_out)
+{
+    LaunchTimer t(ctx, LTHIP_K_B3_PARENT);
+    hipLaunchKernelGGL(k_blake3_stream_final, dim3(1), dim3(B3S_LEAVES), 0, ctx->stream, (const uint8_t*)d_tail, tail_len, leaf0, d_stack, depth,
+                       d_out);
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
 }

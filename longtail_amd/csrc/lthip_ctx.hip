@@ -771,6 +771,31 @@ extern "C" int lthip_hash_runs_u64(lthip_ctx* ctx, const uint64_t* d_values, con
     return lthip_launch_blake3(ctx, (const uint8_t*)d_values, offs, lens, nullptr, run_count, 0, 0, d_out);
 }
 
+// Streaming BLAKE3 (k_blake3.hip): a batch of LTHIP_B3_STREAM_BATCH bytes = 1024 full leaves, the `batch_index`-th of its stream, is
+// reduced to its subtree's chaining value and pushed onto the stream's stack (d_stack: LTHIP_B3_STREAM_STACK_BYTES of device memory
+// owned by the caller, no initialisation needed); lthip_b3_stream_final hashes the rest (tail_len <= one batch; 0 only for an empty
+// stream) and folds the stack.  The caller passes how many batches came before: the stack depth and the merges follow from that
+// number alone (one entry per set bit).  The low 32 bits of the BLAKE3 chunk counter are used: streams below 4 TiB.
+extern "C" int lthip_b3_stream_batch(lthip_ctx* ctx, const void* d_data, uint64_t batch_index, void* d_stack)
+{
+    if (!ctx || !d_data || !d_stack || batch_index >= (1ull << 22))
+        return EINVAL;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t depth_in = (uint32_t)__builtin_popcountll(batch_index);
+    const uint32_t merges = (uint32_t)__builtin_ctzll(batch_index + 1ull);
+    return lthip_launch_blake3_stream_batch(ctx, d_data, (uint32_t)(batch_index << 10), (uint32_t*)d_stack, depth_in, merges);
+}
+
+extern "C" int lthip_b3_stream_final(lthip_ctx* ctx, const void* d_tail, uint32_t tail_len, uint64_t batch_count, const void* d_stack,
+                                     uint64_t* d_out)
+{
+    if (!ctx || !d_out || (tail_len && !d_tail) || tail_len > (1u << 20) || batch_count > (1ull << 22) || (batch_count && (!tail_len || !d_stack)))
+        return EINVAL;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return lthip_launch_blake3_stream_final(ctx, d_tail, tail_len, (uint32_t)(batch_count << 10), (const uint32_t*)d_stack,
+                                            (uint32_t)__builtin_popcountll(batch_count), d_out);
+}
+
 // One small input where it lies (see k_blake3_one): `in` and `out` must be readable / writable by the device -- pinned host memory
 // (lthip_malloc_pinned) or device memory.  Asynchronous on the context's stream.
 extern "C" int lthip_hash_one(lthip_ctx* ctx, const void* in, uint32_t len, uint64_t* out)

@@ -21,11 +21,17 @@ struct HipHashAPI
     struct Longtail_HashAPI api;
 };
 
+/* Streaming context: O(1) host memory whatever the stream's length (the reference's blake3_hasher is 1 912 bytes; round 2 buffered the
+ * WHOLE stream on the host and stopped at 4 GiB).  One batch of LTHIP_B3_STREAM_BATCH bytes is collected on the host; when it is full
+ * AND another byte arrives it goes to the device, is reduced to its subtree's chaining value and merged into the stream's stack,
+ * which lives in device memory (lthip_b3_stream_batch).  EndContext sends what is left and folds the stack (lthip_b3_stream_final). */
 struct HipHashContext
 {
-    uint8_t* data;
-    uint64_t size;
-    uint64_t cap;
+    uint8_t* buf;      /* LTHIP_B3_STREAM_BATCH bytes, allocated with the first Hash() call */
+    uint32_t have;     /* bytes in buf */
+    uint64_t batches;  /* batches already on the device */
+    void* d_stack;     /* device: the stream's subtree stack, allocated with the first batch */
+    void* d_batch;     /* device: one batch */
     int err; /* first failure of a Hash() call on this context: EndContext reports it through the error latch */
 };
 
@@ -102,34 +108,68 @@ static int HipHash_BeginContext(struct Longtail_HashAPI* hash_api, Longtail_Hash
     return 0;
 }
 
+static int stream_flush_batch(struct HipHashContext* c, lthip_ctx* ctx)
+{
+    int err = 0;
+    if (!c->d_batch)
+        err = lthip_malloc_device(ctx, LTHIP_B3_STREAM_BATCH, &c->d_batch);
+    if (!err && !c->d_stack)
+        err = lthip_malloc_device(ctx, LTHIP_B3_STREAM_STACK_BYTES, &c->d_stack);
+    if (!err)
+        err = lthip_copy_h2d(ctx, c->d_batch, c->buf, LTHIP_B3_STREAM_BATCH);
+    if (!err)
+        err = lthip_b3_stream_batch(ctx, c->d_batch, c->batches, c->d_stack);
+    if (!err)
+        err = lthip_ctx_sync(ctx); /* the host buffer is refilled next, and the next call may come from another thread */
+    if (!err)
+    {
+        c->batches += 1;
+        c->have = 0;
+    }
+    return err;
+}
+
 static void HipHash_Hash(struct Longtail_HashAPI* hash_api, Longtail_HashAPI_HContext context, uint32_t length,
                          const void* data)
 {
     struct HipHashContext* c = (struct HipHashContext*)context;
     if (!hash_api || !c || !length || !data || c->err)
         return;
-    if (c->size + length > c->cap)
+    /* a void function in the ABI (src/longtail.h:205): a failure is remembered and surfaces at EndContext, which then returns 0
+     * and latches the errno (Longtail_Hip_GetLastError) instead of the digest of a truncated stream */
+    if (!c->buf)
     {
-        uint64_t cap = c->cap ? c->cap * 2 : 4096;
-        while (cap < c->size + length)
-            cap *= 2;
-        uint8_t* n = (uint8_t*)ltp_alloc("HipHash_Hash", (size_t)cap);
-        if (!n)
+        c->buf = (uint8_t*)ltp_alloc("HipHash_Hash", LTHIP_B3_STREAM_BATCH);
+        if (!c->buf)
         {
-            /* a void function in the ABI (src/longtail.h:205): the failure is remembered and surfaces at EndContext, which then
-             * returns 0 and latches ENOMEM (Longtail_Hip_GetLastError) instead of the digest of a truncated stream */
             c->err = ENOMEM;
             ltp_latch_error(ENOMEM);
             return;
         }
-        if (c->size)
-            memcpy(n, c->data, (size_t)c->size);
-        ltp_free(c->data);
-        c->data = n;
-        c->cap = cap;
     }
-    memcpy(c->data + c->size, data, length);
-    c->size += length;
+    const uint8_t* p = (const uint8_t*)data;
+    while (length)
+    {
+        if (c->have == LTHIP_B3_STREAM_BATCH)
+        {
+            /* the batch is full and more follows: it is not the end of the stream */
+            lthip_ctx* ctx = ltp_thread_ctx();
+            const int err = ctx ? stream_flush_batch(c, ctx) : ENODEV;
+            if (err)
+            {
+                c->err = err;
+                ltp_latch_error(err);
+                return;
+            }
+        }
+        uint32_t n = LTHIP_B3_STREAM_BATCH - c->have;
+        if (n > length)
+            n = length;
+        memcpy(c->buf + c->have, p, n);
+        c->have += n;
+        p += n;
+        length -= n;
+    }
 }
 
 static uint64_t HipHash_EndContext(struct Longtail_HashAPI* hash_api, Longtail_HashAPI_HContext context)
@@ -139,16 +179,46 @@ static uint64_t HipHash_EndContext(struct Longtail_HashAPI* hash_api, Longtail_H
     if (!hash_api || !c)
         return 0;
     int err = c->err;
-    if (!err && c->size > 0xFFFFFFFFull)
-        err = EFBIG; /* one BLAKE3 input of the kernels is below 4 GiB (HashBuffer's length is a uint32_t as well, src/longtail.h:207) */
+    lthip_ctx* ctx = 0;
     if (!err)
-        err = gpu_hash(c->data, (uint32_t)c->size, &h);
+    {
+        struct ltp_thread_state* ts = ltp_thread_state_get();
+        ctx = ts ? ts->ctx : 0;
+        if (!ctx)
+            err = ENODEV;
+        else if (c->batches == 0 && c->have <= LTP_HASH_ONE_MAX)
+            err = gpu_hash(c->buf ? c->buf : (const uint8_t*)"", c->have, &h); /* a short stream is a HashBuffer */
+        else
+        {
+            /* the rest of the stream (1 .. one batch of bytes) and the fold of the stack, digest into the thread's pinned block */
+            if (!c->d_batch)
+                err = lthip_malloc_device(ctx, LTHIP_B3_STREAM_BATCH, &c->d_batch);
+            if (!err)
+                err = ltp_pin_reserve(ctx, &ts->h_pin, 64);
+            if (!err)
+                err = lthip_copy_h2d(ctx, c->d_batch, c->buf, c->have);
+            if (!err)
+                err = lthip_b3_stream_final(ctx, c->d_batch, c->have, c->batches, c->d_stack, (uint64_t*)ts->h_pin.p);
+            if (!err)
+                err = lthip_ctx_sync(ctx);
+            if (!err)
+                h = *(const uint64_t*)ts->h_pin.p;
+        }
+    }
     if (err)
     {
+        /* never a plausible digest for a stream that could not be hashed: 0 + the errno in the latch */
         ltp_latch_error(err);
         h = 0;
     }
-    ltp_free(c->data);
+    if (!ctx)
+        ctx = ltp_thread_ctx();
+    if (ctx)
+    {
+        lthip_free_device(ctx, c->d_batch);
+        lthip_free_device(ctx, c->d_stack);
+    }
+    ltp_free(c->buf);
     ltp_free(c);
     return h;
 }

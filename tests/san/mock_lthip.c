@@ -186,6 +186,73 @@ int lthip_chunk_from_buffer(lthip_ctx* c, const void* d, uint64_t size, uint32_t
     *out_len = lto_hpcdc_next_from_buffer((const uint8_t*)d, size, mn, av, mx);
     return 0;
 }
+/* streaming: the "device" stack block holds a pointer to everything the stream has sent so far; the accumulators stay reachable from a
+ * global list so that an abandoned stream (an injected failure) is not a leak report */
+struct mock_stream
+{
+    uint64_t magic;
+    uint8_t* acc;
+    size_t len, cap;
+};
+static uint8_t* g_stream_accs[256];
+static int g_stream_acc_count;
+int lthip_b3_stream_batch(lthip_ctx* c, const void* d, uint64_t batch_index, void* d_stack)
+{
+    (void)c;
+    struct mock_stream* st = (struct mock_stream*)d_stack;
+    if (batch_index == 0)
+    {
+        memset(st, 0, sizeof *st);
+        st->magic = 0x53545245414dull;
+    }
+    if (st->magic != 0x53545245414dull || st->len != (size_t)batch_index << 20)
+        return EINVAL;
+    if (st->len + (1u << 20) > st->cap)
+    {
+        const size_t cap = st->cap ? st->cap * 2 : (4u << 20);
+        uint8_t* n = (uint8_t*)realloc(st->acc, cap);
+        if (!n)
+            return ENOMEM;
+        for (int i = 0; i < g_stream_acc_count; ++i)
+            if (g_stream_accs[i] == st->acc)
+                g_stream_accs[i] = n;
+        if (!st->acc && g_stream_acc_count < 256)
+            g_stream_accs[g_stream_acc_count++] = n;
+        st->acc = n;
+        st->cap = cap;
+    }
+    memcpy(st->acc + st->len, d, 1u << 20);
+    st->len += 1u << 20;
+    return 0;
+}
+int lthip_b3_stream_final(lthip_ctx* c, const void* d_tail, uint32_t tail_len, uint64_t batch_count, const void* d_stack, uint64_t* out)
+{
+    (void)c;
+    if (batch_count == 0)
+    {
+        const uint64_t off = 0;
+        lto_blake3_u64_many((const uint8_t*)(tail_len ? d_tail : (const void*)""), &off, &tail_len, 1, out);
+        return 0;
+    }
+    struct mock_stream* st = (struct mock_stream*)d_stack;
+    if (st->magic != 0x53545245414dull || st->len != (size_t)batch_count << 20 || !tail_len)
+        return EINVAL;
+    uint8_t* all = (uint8_t*)malloc(st->len + tail_len);
+    if (!all)
+        return ENOMEM;
+    memcpy(all, st->acc, st->len);
+    memcpy(all + st->len, d_tail, tail_len);
+    const uint64_t off = 0;
+    const uint32_t len = (uint32_t)(st->len + tail_len);
+    lto_blake3_u64_many(all, &off, &len, 1, out);
+    free(all);
+    for (int i = 0; i < g_stream_acc_count; ++i)
+        if (g_stream_accs[i] == st->acc)
+            g_stream_accs[i] = g_stream_accs[--g_stream_acc_count];
+    free(st->acc);
+    st->acc = 0;
+    return 0;
+}
 int lthip_hash_runs_u64(lthip_ctx* c, const uint64_t* v, const uint32_t* first, uint32_t n, uint64_t* out)
 {
     (void)c;

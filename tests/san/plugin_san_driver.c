@@ -192,6 +192,26 @@ int main(void)
         g_hash->Hash(g_hash, hc, 299000, d + 1001);
         CHECK(g_hash->EndContext(g_hash, hc) == lto_blake3_u64(d, 300001));
         CHECK(Longtail_Hip_GetLastError() == 0);
+        {
+            /* a stream of several batches (1 MiB each) in pieces that straddle them, ending exactly on a batch boundary and not */
+            for (int round = 0; round < 2; ++round)
+            {
+                const size_t n = round ? (3u << 20) : (3u << 20) + 12345u;
+                uint8_t* s = (uint8_t*)malloc(n);
+                lto_synth_fill(s, n, 77 + round, 0, 1);
+                CHECK(g_hash->BeginContext(g_hash, &hc) == 0);
+                size_t o = 0, step = 700001;
+                while (o < n)
+                {
+                    const size_t k = n - o < step ? n - o : step;
+                    g_hash->Hash(g_hash, hc, (uint32_t)k, s + o);
+                    o += k;
+                }
+                CHECK(g_hash->EndContext(g_hash, hc) == lto_blake3_u64(s, (uint32_t)n));
+                CHECK(Longtail_Hip_GetLastError() == 0);
+                free(s);
+            }
+        }
         CHECK(g_hash->BeginContext(g_hash, &hc) == 0);
         g_hash->Hash(g_hash, hc, 100, d);
         mock_fail_alloc_after(0); /* the device buffer of the final hash cannot be had */

@@ -242,3 +242,61 @@ def test_plugins_do_not_leak_under_the_reference_memtracer():
     line = [l for l in out.stdout.splitlines() if l.startswith("outstanding")][-1].split()
     assert int(line[1]) == 0, line
     assert int(line[-1]) >= 4  # the objects were really counted while alive
+
+
+def _stream(api_ptr, pieces):
+    """BeginContext / Hash... / EndContext over an iterable of numpy byte arrays, as longtail_blake3.c:24-79 is driven."""
+    h = HashAPIStruct.from_address(api_ptr)
+    ctx = C.c_void_p()
+    assert h.BeginContext(api_ptr, C.byref(ctx)) == 0
+    for p in pieces:
+        if len(p):
+            h.Hash(api_ptr, ctx, len(p), p.ctypes.data)
+    return h.EndContext(api_ptr, ctx)
+
+
+def _cut(data, step):
+    return [data[o : o + step] for o in range(0, len(data), step)] if len(data) else []
+
+
+def test_streaming_context_matches_the_reference_hasher(plugins, ref, oracle, hiplib):
+    """The streaming trio with O(1) state (round 3: batches of 1 MiB reduced on the device, the subtree stack in device memory) against
+    the reference's own Blake3Hash_BeginContext/_Hash/_EndContext: every size around the leaf, the one-launch limit and the batch."""
+    ref.dll.Longtail_CreateBlake3HashAPI.restype = C.c_void_p
+    cpu = ref.dll.Longtail_CreateBlake3HashAPI()
+    assert cpu
+    try:
+        data = oracle.synth((17 << 20) + 1, 4242, 1)
+        mib = 1 << 20
+        for n in (0, 1, 63, 64, 1023, 1024, 1025, 65535, 65536, 65537, mib - 1, mib, mib + 1, 2 * mib - 1, 2 * mib, 2 * mib + 1, 3 * mib + 5,
+                  4 * mib, 8 * mib + 1023, 16 * mib, 17 * mib + 1):
+            for step in (n or 1, 700001, 4096 + 17):
+                if step > 100000 or n <= 3 * mib + 5:
+                    got = _stream(plugins["hash"], _cut(data[:n], step))
+                    want = _stream(cpu, _cut(data[:n], step))
+                    assert got == want == oracle.blake3(data[:n]), (n, step)
+        assert hiplib.dll.Longtail_Hip_GetLastError() == 0
+    finally:
+        HashAPIStruct.from_address(cpu).Dispose(cpu)
+
+
+def test_streaming_context_5_gib(plugins, ref, oracle, hiplib):
+    """More than 4 GiB through one context (round 2 stopped there with EFBIG and buffered the whole stream on the host): 5 GiB + 3 bytes
+    fed in 64 MiB pieces, against the reference's hasher fed the same pieces."""
+    ref.dll.Longtail_CreateBlake3HashAPI.restype = C.c_void_p
+    cpu = ref.dll.Longtail_CreateBlake3HashAPI()
+    assert cpu
+    try:
+        base = oracle.synth(64 << 20, 99, 0)
+
+        def pieces():
+            for i in range(80):  # 80 x 64 MiB = 5 GiB, every piece different (rotated)
+                yield np.roll(base, i * 4099)
+            yield base[:3]
+
+        got = _stream(plugins["hash"], pieces())
+        want = _stream(cpu, pieces())
+        assert got == want and got != 0
+        assert hiplib.dll.Longtail_Hip_GetLastError() == 0
+    finally:
+        HashAPIStruct.from_address(cpu).Dispose(cpu)
