@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 KINDS = {"random": 0, "mixed": 1, "zero": 2, "records": 11, "tokens": 12, "lines": 13}
 # wave-instructions per 4 KiB of input (one wave: 64 lanes x 64 bytes), from the ISA dumps / SQ_INSTS_VALU, priced at
 # one VALU instruction per SIMD per 4 cycles at the nominal 2.4 GHz on 256 CUs x 4 SIMDs: the integer-issue roof of K1 / K3
-VALU_INSTR_PER_4KIB = {"buzhash": 735, "blake3_leaf": 695}
+VALU_INSTR_PER_4KIB = {"buzhash": 537, "blake3_leaf": 695}  # K1: SQ_INSTS_VALU / wave-tiles, profiles/r03a_pmc_k1.txt (round 2: 735)
 VALU_ISSUE_PER_S = 256 * 4 * 2.4e9 / 4.0
 
 
@@ -296,27 +296,46 @@ class Bench:
                 roofline["valu"] = {"instr_per_4KiB_wave_tile": VALU_INSTR_PER_4KIB[dom], "issue_roof_GBps": round(roof, 1),
                                     "valu_frac": round(achieved / roof, 4),
                                     "note": "integer-issue roof: one VALU instruction per SIMD per 4 cycles at 2.4 GHz, 1024 SIMDs"}
-            # HBM traffic from the PMC counters: collected offline (rocprofv3 cannot wrap itself), tools/pmc_traffic.sh ->
-            # profiles/*pmc_traffic*.json; per input byte, scaled to this run's launch size
+            # HBM traffic from the PMC counters: collected offline (rocprofv3 cannot wrap itself).  Round 3: tools/pmc_exact_traffic.sh
+            # -> profiles/*xtraffic*.json, bytes from the L2's request-SIZE counters (128 * RDREQ_128B + 64 * RDREQ_64B + 32 * RDREQ_32B,
+            # 64 / 32 per write request): exact for any access pattern, where 2 * FETCH_SIZE is only right for wide coalesced reads.
+            # Per input byte, scaled to this run's launch size.
+            pipeline_traffic = None
             try:
-                tfiles = sorted((ROOT / "profiles").glob("*pmc_traffic*.json"))
+                tfiles = sorted((ROOT / "profiles").glob("*xtraffic*.json"))
                 tj = json.load(open(tfiles[-1]))
-                names = {"buzhash": "k_buzhash_candidates<0>", "blake3_leaf": "k_blake3_leaves", "lz4_segments": "k_lz4_segments<"}
+                prefix = {"buzhash": "k_buzhash", "blake3_leaf": "k_blake3_leaves", "lz4_segments": "k_lz4_segments<", "zstd_encode": "k_zstd_encode"}
 
                 def fmt_of(k):  # k_lz4_segments<G, TAB, FMT, MODE, CLS>: the LZ4 flavours have FMT 0
                     args = k[k.index("<") + 1 : k.rindex(">")].split(",")
                     return int(args[2]) if len(args) >= 3 else int(args[-1])
 
                 want_fmt = 0 if cfg["codec"] == "lz4" else 1
-                keys = [k for k in tj["kernels"] if k.startswith(names[dom]) and (dom != "lz4_segments" or fmt_of(k) == want_fmt)]
+
+                def per_byte(k):
+                    return tj["kernels"][k]["read_per_input_byte"] + tj["kernels"][k]["write_per_input_byte"]
+
+                keys = [k for k in tj["kernels"] if k.startswith(prefix[dom]) and (dom != "lz4_segments" or fmt_of(k) == want_fmt)]
                 if not keys:
                     raise KeyError(dom)
                 # the match finder is two kernels (classification pass + lane parser) under one timer: their traffic adds up
-                ratio = round(sum(tj["kernels"][k]["corrected_per_input_byte"] for k in keys), 4)
+                ratio = round(sum(per_byte(k) for k in keys), 4)
                 roofline["traffic"] = int(ratio * my_bytes / launches)
-                roofline["traffic_source"] = f"profiles/{tfiles[-1].name}: {ratio} HBM bytes per input byte (2*FETCH_SIZE+WRITE_SIZE)"
+                roofline["traffic_source"] = (f"profiles/{tfiles[-1].name}: {ratio} memory-side bytes per input byte (L2 request-size counters, "
+                                              f"reads + writes), measured on {tj.get('workload', 'the default workload at 8 GiB')}")
+                pipeline_traffic = round(sum(per_byte(k) for k in tj["kernels"] if not k.startswith("k_synth")), 4)
             except Exception:
                 pass
+            # the whole step against the same roof: algorithmic bytes = N read once + N_out written once (SURVEY.md §8d "combined minimal")
+            step_s = elapsed / steps
+            alg_pipeline = my_bytes + int(res.compressed_bytes)
+            roofline["pipeline"] = {"algorithmic_bytes": alg_pipeline, "ms": round(step_s * 1e3, 3),
+                                    "achieved": round(alg_pipeline / step_s / 1e9, 1), "frac": round(alg_pipeline / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                                    "frac_over_input_only": round(my_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                                    "traffic_per_input_byte": pipeline_traffic,
+                                    "traffic_over_algorithmic": None if pipeline_traffic is None else round(pipeline_traffic * my_bytes / alg_pipeline, 3),
+                                    "note": "all kernels of one step (three serial passes over the input: scan, hash, codec); traffic = sum of the kernels' "
+                                            "memory-side bytes from the same PMC file"}
         label = {"files": f"{cfg['gib']:g} GiB tree of {cfg['file_mib']:g} MiB {cfg['kind']} files",
                  "mixed-sizes": f"{cfg['gib']:g} GiB tree of {cfg['kind']} files, 4 KiB..4 GiB log-uniform (north-star tree)"}[cfg["tree"]]
         per = "per GPU" if cfg["scaling"] == "weak" else "in total"

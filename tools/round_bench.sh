@@ -16,6 +16,6 @@ cp gpurun_out/${tag}_prof/p_kernel_stats.csv gpurun_out/${tag}_bench64g_kernel_s
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_mixed -o p -- python bench.py --steps 2 --warmup 1 --kind mixed --no-cpu-baseline > gpurun_out/${tag}_prof_mixed.log 2>&1
 cp gpurun_out/${tag}_prof_mixed/p_kernel_stats.csv gpurun_out/${tag}_bench64g_mixed_kernel_stats.csv 2>/dev/null
 rm -f gpurun_out/${tag}_prof*/p_kernel_trace.csv
-bash tools/pmc_traffic.sh --gib 8 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > gpurun_out/${tag}_pmc_traffic.log 2>&1
-python tools/pmc_traffic_json.py $((8 << 30)) gpurun_out/${tag}_pmc_traffic_8g.json >> gpurun_out/${tag}_pmc_traffic.log 2>&1
+bash tools/pmc_exact_traffic.sh gpurun_out/${tag}_xtraffic_8g.json $((8 << 30)) --gib 8 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > gpurun_out/${tag}_pmc_traffic.log 2>&1; bash tools/pmc_exact_traffic.sh gpurun_out/${tag}_xtraffic_8g_mixed.json $((8 << 30)) --gib 8 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --kind mixed >> gpurun_out/${tag}_pmc_traffic.log 2>&1
+
 tail -c 400 gpurun_out/${tag}_bench64g_default.json; echo; head -8 gpurun_out/${tag}_bench64g_kernel_stats.csv; tail -12 gpurun_out/${tag}_pmc_traffic.log
