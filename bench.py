@@ -178,7 +178,7 @@ class Bench:
     def run(self, cfg, steps, warmup):
         """cfg: dict(tree, kind, codec, gib, file_mib, scaling, partition).  Returns the measurements of this configuration."""
         torch, args, ctx, world, rank = self.torch, self.args, self.ctx, self.world, self.rank
-        from longtail_amd.dist import JobPartition, exchange_chunks
+        from longtail_amd.dist import JobPartition, exchange_chunks, sharded_first_seen
         from longtail_amd.lib import Ingest, chunker_params
 
         mn, av, mx = chunker_params(args.target_chunk_size)
@@ -231,6 +231,10 @@ class Bench:
                 ex = exchange_chunks(part, counts, out_hash, out_lens, total, ctx, comm=self.comm)
                 all_hash, all_lens, job_first = ex["hashes"], ex["lens"], ex["job_first"].astype(np.uint64)
                 my_jobs = mine
+                if args.dedup == "sharded":
+                    # the first-seen table sharded by hash: this rank inserts its 1/N of the hash space, not every rank's chunks
+                    first_all, uniq_all = sharded_first_seen(part, ex, out_hash, total, ctx)
+                    ing.set_first_seen(first_all, uniq_all)
             else:
                 all_hash, all_lens = out_hash, out_lens
                 job_first = out_first[: len(mine) + 1].cpu().numpy().view(np.uint32).astype(np.uint64)
@@ -378,11 +382,18 @@ def main():
     ap.add_argument("--codec", choices=["lz4", "zstd"], default="lz4", help="block codec (BASELINE.json configs[4] uses zstd)")
     ap.add_argument("--no-compress", action="store_true", help="diagnostic: skip WriteContent (the line is then not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dedup", choices=["sharded", "replicated"], default="sharded",
+                    help="N > 1: first-seen table sharded by hash (all-to-all, every rank inserts 1/N of the chunks) or rebuilt on every rank")
     ap.add_argument("--collective", choices=["torch", "c"], default="torch",
                     help="N > 1: the exchange's all-gathers by torch.distributed (RCCL backend) or by the C ABI's lthip_comm_allgather")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: print how the tree's (asset, part) jobs fall onto --gpus ranks and what the exchange moves")
     ap.add_argument("--no-secondary", action="store_true", help="skip the compressible / mixed-size-tree measurements")
     ap.add_argument("--cpu-gib", type=float, default=8.0, help="sample size of the CPU baseline")
     args = ap.parse_args()
+    if args.dry_run:
+        print(json.dumps(dry_run(args)))
+        return
 
     b = Bench(args)
     cfg = dict(tree=args.tree, kind=args.kind, codec=args.codec, gib=args.gib, file_mib=args.file_mib, scaling=args.scaling,
@@ -439,6 +450,40 @@ def main():
         print(json.dumps(line))
     if b.world > 1:
         b.dist.destroy_process_group()
+
+
+def dry_run(args):
+    """What a --gpus N run WOULD do, computed on the host alone (the partitioner is plain C in liblongtail_hip.so and needs no GPU):
+    the jobs of the tree exactly as ChunkAssets lists them (src/longtail.c:2399-2457), their assignment, the balance, and the bytes
+    the exchange carries -- for BASELINE.json configs[3] (default tree, --scaling strong) and configs[4] (--file-mib 16384)."""
+    from longtail_amd.dist import JobPartition
+
+    world = args.gpus
+    per_gpu = int(args.gib * (1 << 30))
+    total = per_gpu * (world if args.scaling == "weak" else 1)
+    file_bytes = int(args.file_mib * (1 << 20))
+    tree = make_tree(args.tree, total, file_bytes)
+    part = JobPartition(tree["sizes"], args.target_chunk_size, world, args.partition)
+    rb = part.rank_bytes.astype(np.int64)
+    mean_chunk = 32.1 * 1024 * args.target_chunk_size / 65536  # observed mean on random data (SURVEY.md §8)
+    chunks_rank = rb / mean_chunk
+    chunks_all = float(chunks_rank.sum())
+    count_stride = int(part.jobs_per_rank.max())
+    straddle = int(sum(1 for a in range(len(tree["sizes"])) if len(set(part.job_rank[part.job_asset == a].tolist())) > 1)) if len(tree["sizes"]) <= 4096 else None
+    return {
+        "dry_run": True, "n_gpus": world, "scaling": args.scaling, "partition": args.partition, "tree_bytes": int(tree["sizes"].sum()),
+        "files": int(tree["nfiles"]), "jobs": int(part.job_count), "jobs_per_rank": [int(x) for x in part.jobs_per_rank],
+        "bytes_per_rank": [int(x) for x in rb], "imbalance_max_over_mean": round(float(rb.max() / max(rb.mean(), 1)), 4),
+        "assets_whose_parts_straddle_ranks": straddle, "rank_major_is_job_order": part.is_rank_major(),
+        "expected_chunks_total": int(chunks_all), "expected_chunks_largest_rank": int(chunks_rank.max()),
+        "exchange_bytes_received_per_rank": {
+            "allgather_job_counts": 4 * count_stride * world,
+            "allgather_hashes_and_lengths": int(12 * chunks_rank.max() * world),
+            "sharded_first_seen (all-to-all of hash + ordinal, reply, all-gather of the first ordinals)": int(12 * chunks_rank.max() + 4 * chunks_rank.max() + 4 * chunks_all),
+        },
+        "first_seen_table_inserts_per_rank": {"replicated": int(chunks_all), "sharded": int(chunks_all / world)},
+        "note": "expected_* assume the 32.1 KiB mean chunk of random data at target 65536; the all-gathers are padded to the largest rank",
+    }
 
 
 def run_cpu_baseline(args):

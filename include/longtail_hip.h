@@ -281,6 +281,13 @@ LTHIP_EXPORT int lthip_dedup_first_seen(lthip_ctx* ctx, uint64_t count, const ui
 LTHIP_EXPORT int lthip_dedup_first_seen_range(lthip_ctx* ctx, uint64_t count, const uint64_t* d_hashes, uint64_t lookup_first,
                                               uint64_t lookup_count, uint32_t* d_first_index, uint64_t* d_unique_count);
 
+/* Hash-range-sharded form of the first-seen pass (multi-GPU): this rank holds an arbitrary subset of the tree's chunk hashes, each
+ * with its global chunk position; d_first_ordinal[j] = smallest position among the subset's items with the hash of item j.  The
+ * ranks route every chunk to the owner of its hash (longtail_amd/dist.py: sharded_first_seen), so a rank inserts 1/N of the tree's
+ * chunks instead of all of them. */
+LTHIP_EXPORT int lthip_dedup_min_ordinal(lthip_ctx* ctx, uint64_t count, const uint64_t* d_hashes, const uint32_t* d_ordinals,
+                                         uint32_t* d_first_ordinal, uint64_t* d_unique_count);
+
 /* ---- bulk Longtail_CreateVersionIndex tail (src/longtail.c:2808-3017, layout :2551-2584, :2709-2806) ---
  * From the device-resident chunk lists of lthip_chunk_hash -- all assets' chunks concatenated in (asset, part, chunk) order,
  * asset a owning asset_chunk_counts[a] of them -- to the SERIALIZED VersionIndex (the bytes Longtail_WriteVersionIndexToBuffer
@@ -392,6 +399,10 @@ LTHIP_EXPORT int lthip_ingest_index(lthip_ingest* ingest, const lthip_ingest_tre
                                     const uint32_t* d_all_lens, uint64_t all_chunks, const uint64_t* d_local_offsets,
                                     const uint32_t* d_local_part_first, uint64_t local_chunks, void* h_version_index,
                                     size_t version_index_capacity);
+/* Multi-GPU with the hash-range-sharded first-seen table: d_first_index[i] = position of the first chunk (job order, all ranks) with
+ * the hash of chunk i, for all `all_chunks` chunks of the NEXT lthip_ingest_index call, and the tree's number of distinct hashes; that
+ * call then skips its own table pass (every rank inserting every rank's hashes).  The array must stay valid until the call returns. */
+LTHIP_EXPORT int lthip_ingest_set_first_seen(lthip_ingest* ingest, const uint32_t* d_first_index, uint64_t unique_chunks);
 LTHIP_EXPORT int lthip_ingest_write(lthip_ingest* ingest, const void* d_data, void* d_arena, uint64_t arena_bytes);
 LTHIP_EXPORT int lthip_ingest_finish(lthip_ingest* ingest, void* h_store_index, size_t store_index_capacity,
                                      lthip_ingest_result* out_result);

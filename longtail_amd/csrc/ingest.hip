@@ -155,6 +155,10 @@ struct lthip_ingest
     DBuf d_bhash, d_boff, d_blen, d_comp, d_sum;
     DBuf d_gather, d_gsrc, d_glen, d_gdst, d_bfirst, d_braw, d_bimg, d_btag, d_tmpsz;
     hipEvent_t ev_counts, ev_lens, ev_index;
+    // the first-seen index of every chunk computed elsewhere (the sharded table of the multi-GPU path): consumed by the next
+    // lthip_ingest_index instead of its own table pass
+    const uint32_t* ext_first;
+    uint64_t ext_unique;
     // host state between the phases
     uint64_t n_all, n_local, unique_all, n_mine;
     std::vector<uint64_t> b_first;   // nb + 1 chunk indices into the owned-unique list
@@ -233,6 +237,15 @@ extern "C" void lthip_ingest_destroy(lthip_ingest* g)
 // ---------------------------------------------------------------------------------------------------------------------
 // phase 2: the tail of CreateVersionIndex + CreateMissingContent
 // ---------------------------------------------------------------------------------------------------------------------
+extern "C" int lthip_ingest_set_first_seen(lthip_ingest* g, const uint32_t* d_first_index, uint64_t unique_chunks)
+{
+    if (!g)
+        return EINVAL;
+    g->ext_first = d_first_index;
+    g->ext_unique = unique_chunks;
+    return 0;
+}
+
 extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, const uint64_t* d_all_hashes, const uint32_t* d_all_lens,
                                   uint64_t all_chunks, const uint64_t* d_local_offsets, const uint32_t* d_local_part_first,
                                   uint64_t local_chunks, void* h_version_index, size_t version_index_capacity)
@@ -309,7 +322,16 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
     volatile uint64_t* h_counts = (volatile uint64_t*)g->h_counts.p;
 
     // ---- first-seen pass over ALL chunks (:2951-2970), unique index of every asset chunk ----
-    if ((err = lthip_dedup_first_seen(ctx, n, d_all_hashes, (uint32_t*)g->d_first.p, d_counts)))
+    if (g->ext_first)
+    {
+        // computed by the ranks together (lthip_dedup_min_ordinal on every rank's share of the hash space): nothing to insert here
+        const uint64_t u = g->ext_unique;
+        LTHIP_CHECK(ctx, hipMemcpyAsync(g->d_first.p, g->ext_first, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        if ((err = lthip_stage_upload(ctx, d_counts, &u, 8, s)))
+            return err;
+        g->ext_first = nullptr;
+    }
+    else if ((err = lthip_dedup_first_seen(ctx, n, d_all_hashes, (uint32_t*)g->d_first.p, d_counts)))
         return err;
     if ((err = lthip_stage_upload(ctx, g->d_starts.p, starts.data(), ((size_t)na + 1) * 4, s)))
         return err;

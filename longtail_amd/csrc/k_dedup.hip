@@ -34,16 +34,21 @@ __global__ void k_dedup_clear(uint64_t* __restrict__ keys, uint32_t* __restrict_
     }
 }
 
+// `ordinals` (may be null): the value kept per hash is the MINIMUM of ordinals[i] instead of the minimum position i -- the
+// hash-range-sharded first-seen table of the multi-GPU path, where a rank holds an arbitrary subset of the chunks and each comes
+// with its global position (lthip_dedup_min_ordinal)
 __global__ void k_dedup_insert(const uint64_t* __restrict__ hashes, uint64_t n, uint64_t* __restrict__ keys,
-                               uint32_t* __restrict__ idx, uint64_t mask, uint32_t* special, unsigned long long* distinct)
+                               uint32_t* __restrict__ idx, uint64_t mask, uint32_t* special, unsigned long long* distinct,
+                               const uint32_t* __restrict__ ordinals)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
+    const uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= n)
         return;
-    const uint64_t h = hashes[i];
+    const uint64_t h = hashes[pos];
+    const uint32_t i = ordinals ? ordinals[pos] : (uint32_t)pos;
     if (h == EMPTY_KEY)
     {
-        if (atomicMin(special, (uint32_t)i) == 0xFFFFFFFFu && distinct)
+        if (atomicMin(special, i) == 0xFFFFFFFFu && distinct)
             atomicAdd(distinct, 1ull);
         return;
     }
@@ -54,7 +59,7 @@ __global__ void k_dedup_insert(const uint64_t* __restrict__ hashes, uint64_t n, 
             atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]), (unsigned long long)EMPTY_KEY, (unsigned long long)h);
         if (prev == EMPTY_KEY || prev == h)
         {
-            atomicMin(&idx[slot], (uint32_t)i);
+            atomicMin(&idx[slot], i);
             if (distinct && prev == EMPTY_KEY)
                 atomicAdd(distinct, 1ull); // this insert claimed the slot: one more distinct hash
             return;
@@ -120,7 +125,7 @@ extern "C" int lthip_dedup_first_seen_range(lthip_ctx* ctx, uint64_t count, cons
                        (unsigned long long*)d_unique_count);
     if (count)
         hipLaunchKernelGGL(k_dedup_insert, dim3((uint32_t)div_up_u64(count, 256)), dim3(256), 0, ctx->stream, d_hashes, count,
-                           (uint64_t*)keys, (uint32_t*)idx, slots - 1, special, (unsigned long long*)d_unique_count);
+                           (uint64_t*)keys, (uint32_t*)idx, slots - 1, special, (unsigned long long*)d_unique_count, (const uint32_t*)nullptr);
     if (lookup_count)
         hipLaunchKernelGGL(k_dedup_lookup, dim3((uint32_t)div_up_u64(lookup_count, 256)), dim3(256), 0, ctx->stream, d_hashes,
                            lookup_first, lookup_count, (const uint64_t*)keys, (const uint32_t*)idx, slots - 1, (const uint32_t*)special,
@@ -135,4 +140,42 @@ extern "C" int lthip_dedup_first_seen(lthip_ctx* ctx, uint64_t count, const uint
     if (count && !d_first_index)
         return EINVAL;
     return lthip_dedup_first_seen_range(ctx, count, d_hashes, 0, count, d_first_index, d_unique_count);
+}
+
+// The sharded form: THIS rank owns an arbitrary subset of all chunks' hashes (those of its hash range), each with its global
+// position; d_first_ordinal[j] = the smallest position among the items with the hash of item j -- what the owner answers to the
+// rank that sent item j.  *d_unique_count = distinct hashes of the subset (summed over the owners: the tree's unique chunks).
+extern "C" int lthip_dedup_min_ordinal(lthip_ctx* ctx, uint64_t count, const uint64_t* d_hashes, const uint32_t* d_ordinals,
+                                       uint32_t* d_first_ordinal, uint64_t* d_unique_count)
+{
+    if (!ctx || !d_unique_count || (count && (!d_hashes || !d_ordinals || !d_first_ordinal)))
+        return EINVAL;
+    if (count > 0x7FFFFFFFull)
+        return lthip_fail(ctx, EINVAL, "dedup", "too many hashes");
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    uint64_t slots = 1024;
+    while (slots < count * 2)
+        slots <<= 1;
+    void *keys, *idx, *misc;
+    int err;
+    if ((err = lthip_scratch(ctx, S_TABLES, slots * 8, &keys)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_TABLES2, slots * 4, &idx)))
+        return err;
+    if ((err = lthip_scratch(ctx, S_MISC, 64, &misc)))
+        return err;
+    uint32_t* special = (uint32_t*)misc;
+    LaunchTimer t(ctx, LTHIP_K_OTHER);
+    hipLaunchKernelGGL(k_dedup_clear, dim3(2048), dim3(256), 0, ctx->stream, (uint64_t*)keys, (uint32_t*)idx, slots, special,
+                       (unsigned long long*)d_unique_count);
+    if (count)
+    {
+        hipLaunchKernelGGL(k_dedup_insert, dim3((uint32_t)div_up_u64(count, 256)), dim3(256), 0, ctx->stream, d_hashes, count,
+                           (uint64_t*)keys, (uint32_t*)idx, slots - 1, special, (unsigned long long*)d_unique_count, d_ordinals);
+        hipLaunchKernelGGL(k_dedup_lookup, dim3((uint32_t)div_up_u64(count, 256)), dim3(256), 0, ctx->stream, d_hashes, (uint64_t)0, count,
+                           (const uint64_t*)keys, (const uint32_t*)idx, slots - 1, (const uint32_t*)special, d_first_ordinal,
+                           (unsigned long long*)nullptr);
+    }
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
 }

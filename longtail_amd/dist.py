@@ -144,7 +144,83 @@ def exchange_chunks(part: JobPartition, job_counts: torch.Tensor, hashes: torch.
         idx = torch.from_numpy(perm).to(dev)
         o_hash = g_hash[idx].to(out_dev)
         o_lens = g_lens[idx].to(out_dev) if g_lens is not None else None
-    return dict(hashes=o_hash, lens=o_lens, job_first=dst.astype(np.int64), mine=mine)
+    return dict(hashes=o_hash, lens=o_lens, job_first=dst.astype(np.int64), mine=mine,
+                layout=dict(src=src, dst=dst, cnt=cnt, chunk_stride=chunk_stride, staged=staged))
+
+
+def _min_ordinal(h: torch.Tensor, o: torch.Tensor, ctx=None):
+    """first[j] = smallest ordinal among the items with the hash of item j; number of distinct hashes.  Device tensors go through
+    lthip_dedup_min_ordinal (open addressing, atomicMin); CPU tensors (the gloo tests) through numpy."""
+    if h.device.type == "cuda" and ctx is not None:
+        return ctx.dedup_min_ordinal(h, o)
+    hn, on = h.cpu().numpy().view(np.uint64), o.cpu().numpy().astype(np.int64)
+    if len(hn) == 0:
+        return torch.zeros(0, dtype=torch.int32, device=h.device), 0
+    uniq, inv = np.unique(hn, return_inverse=True)
+    m = np.full(len(uniq), np.iinfo(np.int64).max, np.int64)
+    np.minimum.at(m, inv, on)
+    return torch.from_numpy(m[inv].astype(np.int32)).to(h.device), int(len(uniq))
+
+
+def sharded_first_seen(part: JobPartition, ex: dict, my_hashes: torch.Tensor, total: int, ctx=None, group=None):
+    """The first-seen pass (src/longtail.c:2951-2970) with the table SHARDED by hash instead of replicated: every rank routes each of
+    its chunks (hash, global position in job order) to the owner of the hash (all-to-all), the owner keeps the minimum position per
+    hash (lthip_dedup_min_ordinal) and answers, and one all-gather spreads the answers: a rank inserts ~1/N of the tree's chunks instead
+    of all N shares (round 2 rebuilt the whole table on every rank).  `ex` = the result of exchange_chunks (job layout).
+    Returns (first: int32 tensor [all chunks] in job order -- the position of the first chunk with the same hash --, unique count).
+    The result does not depend on the number of ranks: it is the minimum position per hash."""
+    world = part.world
+    job_first, mine = ex["job_first"], ex["mine"]
+    n_all = int(job_first[-1])
+    if n_all >= 1 << 31:
+        raise ValueError("more than 2^31 chunks")
+    dev = my_hashes.device
+    if world == 1:
+        first, uniq = _min_ordinal(my_hashes[:total], torch.arange(total, dtype=torch.int32, device=dev), ctx)
+        return first, uniq
+    rank = dist.get_rank(group)
+    staged = ex["layout"]["staged"]
+    if staged:
+        my_hashes = my_hashes[:total].cpu()
+    wdev = my_hashes.device
+    # global positions of my chunks: job j's run starts at job_first[j]
+    cnt = (job_first[mine + 1] - job_first[mine]).astype(np.int64)
+    assert int(cnt.sum()) == total
+    starts = np.repeat(job_first[mine] - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt)
+    ordinals = torch.from_numpy((starts + np.arange(total, dtype=np.int64)).astype(np.int32)).to(wdev)
+    h = my_hashes[:total]
+    owner = ((h >> 40) & 0xFFFFFF) % world  # 24 bits from the middle of the digest
+    order = torch.argsort(owner, stable=True)
+    send_h, send_o = h[order].contiguous(), ordinals[order].contiguous()
+    send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+    recv_counts = torch.empty(world, dtype=torch.int64, device=wdev)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    sc, rc = [int(x) for x in send_counts.cpu().tolist()], [int(x) for x in recv_counts.cpu().tolist()]
+    recv_h = torch.empty(sum(rc), dtype=torch.int64, device=wdev)
+    recv_o = torch.empty(sum(rc), dtype=torch.int32, device=wdev)
+    dist.all_to_all_single(recv_h, send_h, rc, sc, group=group)
+    dist.all_to_all_single(recv_o, send_o, rc, sc, group=group)
+    if staged and ctx is not None:
+        d = torch.device("cuda", torch.cuda.current_device())
+        f, uniq = _min_ordinal(recv_h.to(d), recv_o.to(d), ctx)
+        f = f.cpu()
+    else:
+        f, uniq = _min_ordinal(recv_h, recv_o, ctx)
+    back = torch.empty(total, dtype=torch.int32, device=wdev)
+    dist.all_to_all_single(back, f.contiguous(), sc, rc, group=group)
+    my_first = torch.empty(total, dtype=torch.int32, device=wdev)
+    my_first[order] = back
+    u = torch.tensor([uniq], dtype=torch.int64, device=wdev)
+    dist.all_reduce(u, group=group)
+    # every rank's answers, in job order (the padded all-gather + reorder of exchange_chunks)
+    lay = ex["layout"]
+    chunk_stride = lay["chunk_stride"]
+    send = my_first if total >= chunk_stride else torch.nn.functional.pad(my_first, (0, chunk_stride - total))
+    g = _allgather(send[:chunk_stride].contiguous(), world, group, None)
+    c64 = lay["cnt"].astype(np.int64)
+    perm = np.repeat(lay["src"].astype(np.int64) - lay["dst"][:-1].astype(np.int64), c64) + np.arange(n_all, dtype=np.int64)
+    first = g[torch.from_numpy(perm).to(wdev)]
+    return first.to(dev), int(u.item())
 
 
 def allgather_hashes(local_hashes: torch.Tensor, total: int, group=None):

@@ -82,6 +82,8 @@ class HipLib:
         sig("Longtail_Hip_SetDevice", i32, [i32])
         sig("Longtail_Hip_GetLastError", i32, [])
         sig("Longtail_Hip_PinnedBytes", u64, [])
+        sig("Longtail_Hip_BatchStats", None, [vp, vp])
+        sig("Longtail_Hip_MemoStats", None, [vp, vp])
         # --- bulk API ---
         sig("lthip_ctx_create", i32, [i32, vp, P(vp)])
         sig("lthip_ctx_destroy", None, [vp])
@@ -120,6 +122,13 @@ class HipLib:
         sig("lthip_version_index_size", sz, [u32, u64, u64, u32])
         sig("lthip_build_version_index", i32, [vp, u32, vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, u32, u32, vp, sz, vp])
         sig("lthip_dedup_first_seen", i32, [vp, u64, vp, vp, vp])
+        sig("lthip_dedup_min_ordinal", i32, [vp, u64, vp, vp, vp, vp])
+        sig("lthip_ingest_set_first_seen", i32, [vp, vp, u64])
+        sig("lthip_plan_reaim", i32, [vp, vp, u32, vp, vp])
+        sig("lthip_hash_one", i32, [vp, vp, u32, vp])
+        sig("lthip_hash_runs_u64", i32, [vp, vp, vp, u32, vp])
+        sig("lthip_b3_stream_batch", i32, [vp, vp, u64, vp])
+        sig("lthip_b3_stream_final", i32, [vp, vp, u32, u64, vp, vp])
         sig("lthip_dedup_first_seen_range", i32, [vp, u64, vp, u64, u64, vp, vp])
         sig("lthip_gather_ranges", i32, [vp, vp, u64, vp, vp, vp, vp])
         sig("lthip_pack_blocks", i32, [u64, vp, u32, u32, vp, u64, P(u64)])
@@ -404,6 +413,18 @@ class Context:
                     "lthip_dedup_first_seen")
         return first[:n], uniq
 
+    def dedup_min_ordinal(self, hashes, ordinals):
+        """The owner's side of the sharded first-seen table: first[j] = smallest ordinal among the items with the hash of item j
+        (int32 tensor), number of distinct hashes (int, after a synchronisation)."""
+        torch = self.torch
+        n = int(hashes.numel())
+        first = torch.empty(max(1, n), dtype=torch.int32, device=self._dev())
+        uniq = torch.zeros(1, dtype=torch.int64, device=self._dev())
+        self._check(self.lib.dll.lthip_dedup_min_ordinal(self.h, n, _ptr(hashes.contiguous()), _ptr(ordinals.contiguous()), _ptr(first), _ptr(uniq)),
+                    "lthip_dedup_min_ordinal")
+        self.sync()
+        return first[:n], int(uniq.item())
+
 
 class Comm:
     """RCCL communicator behind the C ABI (comm.hip): one process per GPU.  `unique_id()` on rank 0, carried to the other ranks by
@@ -514,6 +535,12 @@ class Ingest:
         err = self.ctx.lib.dll.lthip_ingest_index(self.h, C.byref(tree), _ptr(all_hashes), _ptr(all_lens), all_chunks, _ptr(local_offsets),
                                                   _ptr(local_part_first), local_chunks, _ptr(version_index_out) or None, cap)
         self.ctx._check(err, "lthip_ingest_index")
+
+    def set_first_seen(self, first_index, unique_chunks: int):
+        """first-seen index of every chunk from the sharded table (longtail_amd.dist.sharded_first_seen): the next index() uses it."""
+        self._first_keep = first_index  # must stay alive until index() has returned
+        self.ctx._check(self.ctx.lib.dll.lthip_ingest_set_first_seen(self.h, _ptr(first_index), C.c_uint64(int(unique_chunks))),
+                        "lthip_ingest_set_first_seen")
 
     def write(self, data, arena):
         self.ctx._check(self.ctx.lib.dll.lthip_ingest_write(self.h, _ptr(data), _ptr(arena), int(arena.numel())), "lthip_ingest_write")

@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from longtail_amd.dist import JobPartition, allgather_hashes, exchange_chunks, shard_range
+from longtail_amd.dist import JobPartition, allgather_hashes, exchange_chunks, shard_range, sharded_first_seen
 
 TARGET = 256  # part = 256 KiB, chunks 48 / 128 / 512 bytes: multi-part assets stay small enough for the CPU
 PARAMS = (48, 128, 512)
@@ -75,8 +75,11 @@ def _worker(rank, world, port, out, policy):
         lens[:total] = torch.from_numpy(np.concatenate([l for _, l in lists]))
     res = exchange_chunks(part, counts, hashes, lens, total)
     first, uniq = _first_seen(res["hashes"].numpy())
+    # the hash-range-sharded table (round 3): all-to-all of (hash, position) to the hash's owner, minimum per hash, answers spread
+    s_first, s_uniq = sharded_first_seen(part, res, hashes, total)
     torch.save({"hashes": res["hashes"], "lens": res["lens"], "job_first": res["job_first"], "mine": res["mine"], "first": first,
-                "uniq": uniq, "job_rank": part.job_rank, "rank_bytes": part.rank_bytes}, f"{out}/r{rank}.pt")
+                "uniq": uniq, "job_rank": part.job_rank, "rank_bytes": part.rank_bytes, "sharded_first": s_first.numpy().astype(np.int64),
+                "sharded_uniq": s_uniq}, f"{out}/r{rank}.pt")
     dist.destroy_process_group()
 
 
@@ -100,6 +103,9 @@ def test_exchange_reproduces_job_order_and_first_seen(tmp_path, world, policy):
         assert (res[r]["hashes"].numpy() == s_hash).all() and (res[r]["lens"].numpy() == s_lens).all()
         assert (res[r]["job_first"] == s_first).all()
         assert (res[r]["first"] == exp_first).all() and res[r]["uniq"] == exp_uniq
+        # ... and the sharded table gives every rank the same first-seen index as the serial pass (:2951-2970): the VersionIndex
+        # built from it is the single-rank one
+        assert (res[r]["sharded_first"] == exp_first).all() and res[r]["sharded_uniq"] == exp_uniq
         assert (res[r]["job_rank"] == job_rank).all()  # every rank computed the same assignment
     # every job has exactly one owner, every unique chunk exactly one first-seen owner
     owners = np.zeros(part1.job_count, np.int64)
@@ -190,3 +196,21 @@ def test_shard_range_covers_everything():
             r = [shard_range(n, w, k) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_dry_run_reports_the_partition_without_a_gpu():
+    """bench.py --gpus 8 --dry-run: partition balance and exchange volume for BASELINE.json configs[3] / configs[4], host only."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    for extra, jobs in (([], 65536), (["--file-mib", "16384", "--codec", "zstd"], 1028)):
+        out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8", "--dry-run", "--scaling", "strong"] + extra,
+                             capture_output=True, text=True, timeout=300, cwd=root)
+        assert out.returncode == 0, out.stderr[-800:]
+        j = json.loads(out.stdout.strip().splitlines()[-1])
+        assert j["dry_run"] and j["jobs"] == jobs and sum(j["bytes_per_rank"]) == 64 << 30
+        assert j["imbalance_max_over_mean"] < 1.01 and len(j["jobs_per_rank"]) == 8
+        assert j["first_seen_table_inserts_per_rank"]["sharded"] * 8 <= j["first_seen_table_inserts_per_rank"]["replicated"] + 8

@@ -198,3 +198,30 @@ def test_ingest_sessions_of_r_ranks_partition_the_reference_result(gpu, oracle, 
         assert s["si"] == ref_missing_content(ref, others, uh, us, ut, max_block, max_chunks), f"rank {r} StoreIndex"
         assert s["res"].unique_all == len(uh) and s["res"].unique_local == len(owned[r])
         check_images(gpu, ref, s, 0, tag, max_block)
+
+
+def test_sharded_first_seen_table_feeds_the_ingest_session(gpu, oracle):
+    """lthip_dedup_min_ordinal (the owner's side of the hash-range-sharded first-seen table) against the serial pass, and a session that
+    is GIVEN the first-seen index (lthip_ingest_set_first_seen) against one that builds its own table: same serialized VersionIndex."""
+    rng = np.random.default_rng(7)
+    n = 200_000
+    pool = rng.integers(1, 2**63 - 1, size=60_000, dtype=np.int64)
+    h = pool[rng.integers(0, len(pool), size=n)]
+    h[1234] = -1  # the table's empty-key value is a legal hash
+    h[99_999] = -1
+    order = rng.permutation(n).astype(np.int32)  # an owner sees its items in any order, each with its global position
+    first, uniq = gpu.dedup_min_ordinal(torch.from_numpy(h[order]).cuda(), torch.from_numpy(order).cuda())
+    seen, exp = {}, np.zeros(n, np.int64)
+    for i, x in enumerate(h.tolist()):
+        exp[i] = seen.setdefault(x, i)
+    assert uniq == len(seen)
+    assert (first.cpu().numpy().astype(np.int64) == exp[order]).all()
+    # two subsets (two "owners") partition the hashes: minima per owner == global minima, distinct counts add up
+    own = (h >> 40) & 1
+    tot = 0
+    for o in (0, 1):
+        idx = np.flatnonzero(own == o).astype(np.int32)
+        f, u = gpu.dedup_min_ordinal(torch.from_numpy(h[idx]).cuda(), torch.from_numpy(idx).cuda())
+        assert (f.cpu().numpy().astype(np.int64) == exp[idx]).all()
+        tot += u
+    assert tot == len(seen)
