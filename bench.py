@@ -107,7 +107,10 @@ class Bench:
         dev_index = local_rank % torch.cuda.device_count() if self.backend != "nccl" else local_rank
         torch.cuda.set_device(dev_index)
         self.dev = torch.device("cuda", dev_index)
-        if self.world > 1:
+        # LONGTAIL_LAUNCH=plain (tools/run8.sh): N processes started by a shell loop, no torch.distributed at all -- the collectives
+        # are the C ABI's (lthip_comm_* = RCCL, comm.hip), the communicator id travels through a file
+        self.plain = self.world > 1 and os.environ.get("LONGTAIL_LAUNCH") == "plain"
+        if self.world > 1 and not self.plain:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=self.dev)
@@ -118,12 +121,42 @@ class Bench:
         # --collective c: the exchange's all-gathers through the C ABI (lthip_comm_allgather = ncclAllGather on the context's stream)
         # instead of torch.distributed; the unique id travels through the process group the ranks were launched with
         self.comm = None
-        if self.world > 1 and args.collective == "c" and self.backend == "nccl":
+        if self.plain:
+            from longtail_amd.lib import Comm
+
+            idfile = os.environ.get("LTHIP_COMM_ID_FILE", "/tmp/lthip_comm_id")
+            if self.rank == 0:
+                with open(idfile + ".tmp", "wb") as f:
+                    f.write(Comm.unique_id(self.lib))
+                os.replace(idfile + ".tmp", idfile)
+            t0 = time.time()
+            while not os.path.exists(idfile):
+                if time.time() - t0 > 120:
+                    raise SystemExit(f"rank {self.rank}: no communicator id in {idfile} after 120 s")
+                time.sleep(0.01)
+            self.comm = Comm(self.ctx, self.world, self.rank, open(idfile, "rb").read())
+            args.dedup = "replicated"  # the sharded table's all-to-all is a torch.distributed collective
+        elif self.world > 1 and args.collective == "c" and self.backend == "nccl":
             from longtail_amd.lib import Comm
 
             box = [Comm.unique_id(self.lib) if self.rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             self.comm = Comm(self.ctx, self.world, self.rank, box[0])
+
+    def reduce(self, values, op="sum"):
+        """All-reduce of a few host numbers over the ranks (max of the wall time, sums of the result counters)."""
+        torch = self.torch
+        if self.world == 1:
+            return list(values)
+        if self.plain:
+            t = torch.tensor(list(values), dtype=torch.float64, device=self.dev)
+            g = self.comm.allgather(t).view(self.world, -1)
+            self.ctx.sync()
+            return (g.max(dim=0).values if op == "max" else g.sum(dim=0)).cpu().tolist()
+        on = self.dev if self.backend == "nccl" else "cpu"
+        t = torch.tensor(list(values), dtype=torch.float64, device=on)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return t.cpu().tolist()
 
     def buf(self, name, nbytes, dtype=None, pinned=False):
         """A named buffer of at least nbytes, kept across configurations."""
@@ -140,7 +173,10 @@ class Bench:
     def barrier(self):
         self.torch.cuda.synchronize(self.dev)
         if self.world > 1:
-            self.dist.barrier()
+            if self.plain:
+                self.reduce([0.0])  # an all-gather every rank has to join
+            else:
+                self.dist.barrier()
             self.torch.cuda.synchronize(self.dev)
 
     def restore_rates(self, gib=4.0, block_bytes=8 << 20):
@@ -228,7 +264,7 @@ class Bench:
             t1 = time.perf_counter()
             if world > 1:
                 counts = out_first[1 : len(mine) + 1] - out_first[: len(mine)]
-                ex = exchange_chunks(part, counts, out_hash, out_lens, total, ctx, comm=self.comm)
+                ex = exchange_chunks(part, counts, out_hash, out_lens, total, ctx, comm=self.comm, rank=rank)
                 all_hash, all_lens, job_first = ex["hashes"], ex["lens"], ex["job_first"].astype(np.uint64)
                 my_jobs = mine
                 if args.dedup == "sharded":
@@ -267,13 +303,8 @@ class Bench:
         res = stats["res"]
         comp, blocks, raw = res.compressed_bytes, res.blocks, res.raw_bytes
         if world > 1:
-            on = self.dev if self.backend == "nccl" else "cpu"
-            t = torch.tensor([elapsed], dtype=torch.float64, device=on)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-            s = torch.tensor([comp, blocks, raw], dtype=torch.int64, device=on)
-            self.dist.all_reduce(s)
-            comp, blocks, raw = (int(x) for x in s.tolist())
+            elapsed = float(self.reduce([elapsed], "max")[0])
+            comp, blocks, raw = (int(round(x)) for x in self.reduce([comp, blocks, raw]))
         sizes = ing.compressed_sizes(res.blocks)
         ing.close()
 
@@ -448,7 +479,7 @@ def main():
             "result": main_res["result"],
         }
         print(json.dumps(line))
-    if b.world > 1:
+    if b.world > 1 and not b.plain:
         b.dist.destroy_process_group()
 
 

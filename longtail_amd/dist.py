@@ -87,7 +87,7 @@ def _allgather(t: torch.Tensor, world: int, group=None, comm=None) -> torch.Tens
 
 
 def exchange_chunks(part: JobPartition, job_counts: torch.Tensor, hashes: torch.Tensor, lens: torch.Tensor | None, total: int,
-                    ctx=None, group=None, comm=None):
+                    ctx=None, group=None, comm=None, rank: int | None = None):
     """job_counts: int32 tensor, chunk count of each of THIS rank's jobs (ascending job order); hashes (int64) / lens (int32):
     tensors whose first `total` entries are this rank's chunks in that order.  Returns a dict:
       hashes, lens   all ranks' chunks in JOB order (lens None when not given)
@@ -97,7 +97,8 @@ def exchange_chunks(part: JobPartition, job_counts: torch.Tensor, hashes: torch.
     `comm` (longtail_amd.lib.Comm): run the three all-gathers through the C ABI's RCCL entry instead of torch.distributed.
     """
     world = part.world
-    rank = dist.get_rank(group) if (dist.is_initialized() and world > 1) else 0
+    if rank is None:  # (given by a launcher that does not use torch.distributed: tools/run8.sh, `comm` carries the collectives)
+        rank = dist.get_rank(group) if (dist.is_initialized() and world > 1) else 0
     mine = part.jobs_of(rank)
     assert job_counts.numel() == len(mine), "one chunk count per own job"
     if world == 1:
@@ -105,7 +106,7 @@ def exchange_chunks(part: JobPartition, job_counts: torch.Tensor, hashes: torch.
         np.cumsum(job_counts.cpu().numpy().astype(np.int64), out=first[1:])
         return dict(hashes=hashes[:total], lens=None if lens is None else lens[:total], job_first=first, mine=mine)
     out_dev = hashes.device
-    staged = comm is None and out_dev.type == "cuda" and dist.get_backend(group) != "nccl"  # functional path for CPU-only backends on a GPU box
+    staged = comm is None and out_dev.type == "cuda" and dist.is_initialized() and dist.get_backend(group) != "nccl"  # functional path for CPU-only backends on a GPU box
     if staged:
         job_counts, hashes, lens = job_counts.cpu(), hashes[:total].cpu(), None if lens is None else lens[:total].cpu()
     dev = hashes.device
