@@ -20,7 +20,7 @@ C_OBJ   := $(patsubst $(CSRC)/plugin/%.c,$(OBJDIR)/%.o,$(C_SRC))
 GENDIR  := build/gen
 # header dependencies come from the compilers (-MMD -MP -> build/obj/*.d), never from a hand-written list: a header edit
 # rebuilds exactly the objects that include it
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -Iinclude -MMD -MP
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -Iinclude -MMD -MP $(EXTRA_HIPFLAGS)
 CFLAGS   := -O2 -std=c99 -D_POSIX_C_SOURCE=200809L -fPIC -fvisibility=hidden -Wall -Wextra -pthread -Iinclude -I$(GENDIR) -MMD -MP
 
 # identity of the source tree (tools/build_id.py), refreshed on every make run; the stamp only changes when a source does

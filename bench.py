@@ -337,8 +337,10 @@ class Bench:
             # Per input byte, scaled to this run's launch size.
             pipeline_traffic = None
             try:
-                tfiles = sorted((ROOT / "profiles").glob("*xtraffic*.json"))
-                tj = json.load(open(tfiles[-1]))
+                tj, tsrc = getattr(self, "traffic", None), "measured in this run (rocprofv3 --kernel-trace --pmc, 8 GiB of the same workload)"
+                if tj is None or cfg["kind"] != self.traffic_cfg["kind"] or cfg["codec"] != self.traffic_cfg["codec"] or cfg["tree"] != self.traffic_cfg["tree"]:
+                    tfiles = sorted((ROOT / "profiles").glob("*xtraffic*.json"))
+                    tj, tsrc = json.load(open(tfiles[-1])), f"profiles/{tfiles[-1].name} (committed measurement)"
                 prefix = {"buzhash": "k_buzhash", "blake3_leaf": "k_blake3_leaves", "lz4_segments": "k_lz4_segments<", "zstd_encode": "k_zstd_encode"}
 
                 def fmt_of(k):  # k_lz4_segments<G, TAB, FMT, MODE, CLS>: the LZ4 flavours have FMT 0
@@ -356,8 +358,8 @@ class Bench:
                 # the match finder is two kernels (classification pass + lane parser) under one timer: their traffic adds up
                 ratio = round(sum(per_byte(k) for k in keys), 4)
                 roofline["traffic"] = int(ratio * my_bytes / launches)
-                roofline["traffic_source"] = (f"profiles/{tfiles[-1].name}: {ratio} memory-side bytes per input byte (L2 request-size counters, "
-                                              f"reads + writes), measured on {tj.get('workload', 'the default workload at 8 GiB')}")
+                roofline["traffic_source"] = (f"{tsrc}: {ratio} memory-side bytes per input byte (L2 request-size counters, reads + writes), "
+                                              f"workload {tj.get('workload', 'the default workload at 8 GiB')}")
                 pipeline_traffic = round(sum(per_byte(k) for k in tj["kernels"] if not k.startswith("k_synth")), 4)
             except Exception:
                 pass
@@ -417,6 +419,8 @@ def main():
                     help="N > 1: first-seen table sharded by hash (all-to-all, every rank inserts 1/N of the chunks) or rebuilt on every rank")
     ap.add_argument("--collective", choices=["torch", "c"], default="torch",
                     help="N > 1: the exchange's all-gathers by torch.distributed (RCCL backend) or by the C ABI's lthip_comm_allgather")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the newest profiles/*xtraffic*.json instead of a live rocprofv3 --pmc run of this script on 8 GiB")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: print how the tree's (asset, part) jobs fall onto --gpus ranks and what the exchange moves")
     ap.add_argument("--no-secondary", action="store_true", help="skip the compressible / mixed-size-tree measurements")
@@ -426,7 +430,17 @@ def main():
         print(json.dumps(dry_run(args)))
         return
 
+    # the traffic leg runs FIRST, in a child process under rocprofv3 (a profiler cannot wrap the process it runs in), rank 0 of a
+    # single-GPU run only; --no-live-traffic (and the child itself) take the committed measurement instead
+    traffic = None
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    plain_default = (args.tree == "files" and args.kind == "random" and args.codec == "lz4" and not args.no_compress and not args.no_secondary
+                     and not args.no_cpu_baseline)  # the driver's command; every tool / test / profiler run passes one of these flags
+    under_profiler = any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ)
+    if world_env == 1 and not args.no_live_traffic and plain_default and not under_profiler:
+        traffic = live_traffic(args)
     b = Bench(args)
+    b.traffic, b.traffic_cfg = traffic, dict(kind=args.kind, codec=args.codec, tree=args.tree)
     cfg = dict(tree=args.tree, kind=args.kind, codec=args.codec, gib=args.gib, file_mib=args.file_mib, scaling=args.scaling,
                partition=args.partition)
     main_res = b.run(cfg, args.steps, args.warmup)
@@ -481,6 +495,51 @@ def main():
         print(json.dumps(line))
     if b.world > 1 and not b.plain:
         b.dist.destroy_process_group()
+
+
+def live_traffic(args, timeout_s=150):
+    """Memory-side traffic per kernel, measured NOW: this script again on 8 GiB under `rocprofv3 --kernel-trace --pmc <L2 request-size
+    counters>` (two passes: reads, writes; counters and arithmetic of tools/pmc_exact_traffic.sh).  Returns the same structure as
+    profiles/*xtraffic*.json or None (no rocprofv3, a failure, a timeout): the caller then falls back to the committed file."""
+    import collections
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+
+    if not shutil.which("rocprofv3"):
+        return None
+    inp = 8 << 30
+    base = [sys.executable, str(ROOT / "bench.py"), "--gib", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary",
+            "--no-live-traffic", "--kind", args.kind, "--codec", args.codec, "--tree", args.tree, "--file-mib", str(min(args.file_mib, 1024.0)),
+            "--target-chunk-size", str(args.target_chunk_size)]
+    passes = (["TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_32B_sum"], ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"])
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.Counter()
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for i, ctrs in enumerate(passes):
+            with tempfile.TemporaryDirectory(dir="/tmp") as d:
+                r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", d, "-o", "p", "--", *base],
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+                files = list(Path(d).rglob("p_counter_collection.csv"))
+                if r.returncode != 0 or not files:
+                    return None
+                for row in csv.DictReader(open(files[0])):
+                    k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+                    agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                    if i == 0 and row["Counter_Name"] == ctrs[0]:
+                        launches[k] += 1
+    except Exception:
+        return None
+    out = {"_about": "measured by this run: bench.py --gib 8 --steps 1 under rocprofv3 --kernel-trace --pmc (L2 request-size counters)",
+           "input_bytes": inp, "workload": f"8 GiB, kind {args.kind}, codec {args.codec}, tree {args.tree}", "kernels": {}}
+    for k, v in agg.items():
+        rd = 128 * v["TCC_EA0_RDREQ_128B_sum"] + 64 * v["TCC_EA0_RDREQ_64B_sum"] + 32 * v["TCC_EA0_RDREQ_32B_sum"]
+        wr = 64 * v["TCC_EA0_WRREQ_64B_sum"] + 32 * (v["TCC_EA0_WRREQ_sum"] - v["TCC_EA0_WRREQ_64B_sum"])
+        if rd + wr >= 0.005 * inp:
+            out["kernels"][k] = {"launches": launches[k], "read_per_input_byte": round(rd / inp, 4), "write_per_input_byte": round(wr / inp, 4)}
+    return out if out["kernels"] else None
 
 
 def dry_run(args):
