@@ -677,6 +677,7 @@ __device__ bool z_split_foreign(const uint8_t* p, const ZBlock blk, uint32_t b, 
         for (uint32_t j = 0; j < k; ++j)
             flist[at + j] = blk.pad + j;
     }
+    atomicMax(totals - 3, k);                                          // (item_count[1]: the most blocks any such frame has)
     atomicAdd(&totals[0], k);                                          // blocks listed this way, and the bytes they regenerate:
     atomicAdd((unsigned long long*)&totals[2], (unsigned long long)h.content); // the host sizes the literal and record arenas from these
     return true;
@@ -3134,6 +3135,417 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Frames of other encoders, EXECUTED block-parallel (round 3).  A frame is one chain of dependent copies -- a block's matches reach
+// into the blocks before it, and through them into everything older -- so executing VALUES in parallel would have every block wait
+// for the end of the one before.  What CAN run in parallel is the execution of ORIGINS: where does every byte of a block come from?
+//   k_zstd_fr_reps     one wave per block: repeat offsets turned into offsets, with the history at the block's start SYMBOLIC
+//                      (offset values 1..3 in the records it rewrites then mean "entry 0..2 of the history this block starts with",
+//                      minus the two bits above the match length); leaves the block's final history, entries symbolic or not
+//   k_zstd_fr_chain    one lane per frame: composes the histories block by block, adds up where every block starts
+//   k_zstd_fr_trace    one wave per block, all blocks of all frames at once: the block's sequences executed on 32-bit origins
+//                      instead of bytes -- a literal's origin is its index in the block's literal buffer, a match copies the origins
+//                      of its source, and a source byte that lies in an EARLIER block is recorded as that frame position.  Chains
+//                      inside the block collapse as it goes; what is left per byte is "literal i" or "byte p of an earlier block"
+//   k_zstd_fr_gather   launch k fills block k of every frame: out[q] = literal or out[p]; blocks below k are final by then.
+// Same checks as the serial decoder (RFC 8878 3.1.1.3-5); whatever fails sends the payload there (retry).
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t ZO_FLAG = 0x80000000u; // origins: an earlier block's byte (frame position below) / histories: a symbolic entry
+struct ZFr
+{
+    uint32_t in[3];  // the repeat offsets the block starts with
+    uint32_t start;  // frame position of the block's first byte
+    uint32_t out[3]; // ... and ends with: offsets, or ZO_FLAG | slot << 24 | d = entry `slot` of in[] minus d
+    uint32_t pad;
+};
+__device__ __forceinline__ uint32_t zo_minus1(uint32_t v) { return (v & ZO_FLAG) ? v + 1u : (v ? v - 1u : 0u); }
+__device__ __forceinline__ uint32_t zo_bind(uint32_t v, const uint32_t in0, const uint32_t in1, const uint32_t in2)
+{
+    if (!(v & ZO_FLAG))
+        return v;
+    const uint32_t slot = (v >> 24) & 3u, d = v & 0xFFFFFFu;
+    const uint32_t e = slot == 0u ? in0 : slot == 1u ? in1 : in2;
+    return e > d ? e - d : 0u; // (0: not an offset; whoever uses it is stopped)
+}
+// stores of this wave's lanes -> loads of this wave's lanes, through memory: the stores have to have left the wave (vmcnt), the
+// CU's vector cache is written through and shared by whoever runs on the CU (agent scope would write the L2 back, per round)
+__device__ __forceinline__ void zo_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ __launch_bounds__(64) void k_zstd_fr_reps(const uint32_t* __restrict__ flist, uint32_t n, uint64_t* __restrict__ rec_scratch,
+                                                    const ZPrep* __restrict__ fprep, ZFr* __restrict__ fr, const ZItem* __restrict__ fitems,
+                                                    uint32_t* __restrict__ retry)
+{
+    if (blockIdx.x >= n)
+        return;
+    const uint32_t fi = flist[blockIdx.x];
+    const ZPrep pr = fprep[fi];
+    const int lane = threadIdx.x;
+    uint32_t rep0 = ZO_FLAG, rep1 = ZO_FLAG | (1u << 24), rep2 = ZO_FLAG | (2u << 24);
+    bool bad = false;
+    if (pr.status == ZP_READY && pr.log[0] == 0u && pr.nbseq != 0u)
+    {
+        uint64_t* recs = rec_scratch + pr.rec_at;
+        uint64_t r_next = (uint32_t)lane < pr.nbseq ? recs[lane] : 0ull;
+        for (uint32_t s0 = 0; s0 < pr.nbseq; s0 += 64u)
+        {
+            const uint32_t cnt = pr.nbseq - s0 < 64u ? pr.nbseq - s0 : 64u;
+            const uint64_t r = r_next;
+            r_next = s0 + 64u + (uint32_t)lane < pr.nbseq ? recs[s0 + 64u + (uint32_t)lane] : 0ull;
+            const uint32_t r_ll = (uint32_t)r & 0xFFFFFu;
+            const uint32_t r_off = (uint32_t)(r >> 40); // Offset_Value: 1..3 = repeat offsets
+            const uint64_t repm = __builtin_amdgcn_ballot_w64((uint32_t)lane < cnt && r_off <= 3u);
+            if (repm == 0ull)
+            {
+                // no repeat offset in the batch: the history is simply its last three offsets
+                const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)r_off, (int)(cnt - 1u)) - 3u;
+                if (cnt >= 3u)
+                {
+                    rep2 = (uint32_t)__builtin_amdgcn_readlane((int)r_off, (int)(cnt - 3u)) - 3u;
+                    rep1 = (uint32_t)__builtin_amdgcn_readlane((int)r_off, (int)(cnt - 2u)) - 3u;
+                }
+                else if (cnt == 2u)
+                {
+                    rep2 = rep0;
+                    rep1 = (uint32_t)__builtin_amdgcn_readlane((int)r_off, 0) - 3u;
+                }
+                else
+                {
+                    rep2 = rep1;
+                    rep1 = rep0;
+                }
+                rep0 = o1;
+                continue;
+            }
+            uint32_t mine = 0; // what my sequence's repeat code stands for
+            for (uint32_t q = 0; q < cnt; ++q)
+            {
+                const uint32_t ov = (uint32_t)__builtin_amdgcn_readlane((int)r_off, (int)q);
+                if (ov > 3u)
+                {
+                    rep2 = rep1;
+                    rep1 = rep0;
+                    rep0 = ov - 3u;
+                    continue;
+                }
+                const uint32_t idx = ov + ((uint32_t)__builtin_amdgcn_readlane((int)r_ll, (int)q) == 0u ? 1u : 0u); // 1..4 (0: not a value)
+                uint32_t o = rep0;
+                if (idx != 1u)
+                {
+                    o = idx == 4u ? zo_minus1(rep0) : idx == 2u ? rep1 : rep2;
+                    if (idx >= 3u)
+                        rep2 = rep1;
+                    rep1 = rep0;
+                    rep0 = o;
+                }
+                if (ov == 0u)
+                    o = 0u;
+                if ((uint32_t)lane == q)
+                    mine = o;
+            }
+            rep0 = zx_u(rep0);
+            rep1 = zx_u(rep1);
+            rep2 = zx_u(rep2);
+            if ((repm >> lane) & 1ull)
+            {
+                // an offset: value offset + 3 (0: none -- the trace stops there); symbolic: value 1 + slot, the decrement above the match length
+                uint32_t ov = 0, dd = 0;
+                if (mine & ZO_FLAG)
+                {
+                    ov = 1u + ((mine >> 24) & 3u);
+                    dd = mine & 0xFFFFFFu;
+                    if (dd > 3u)
+                        bad = true; // (four "repeat offset 1 minus one" in a row on a history nobody has seen yet: the serial decoder)
+                }
+                else if (mine != 0u && mine < 0xFFFFFCu)
+                    ov = mine + 3u;
+                recs[s0 + (uint32_t)lane] = (r & 0x0000003FFFFFFFFFull) | ((uint64_t)(dd & 3u) << 38) | ((uint64_t)ov << 40);
+            }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) && lane == 0)
+        retry[fitems[fi].payload] = __LINE__;
+    if (lane == 0)
+    {
+        fr[fi].out[0] = rep0;
+        fr[fi].out[1] = rep1;
+        fr[fi].out[2] = rep2;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_zstd_fr_chain(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t nblocks,
+                                                     const uint32_t* __restrict__ f_nblocks, const ZPrep* __restrict__ fprep, ZFr* __restrict__ fr,
+                                                     uint32_t* __restrict__ retry)
+{
+    const uint32_t b = blockIdx.x * 64u + threadIdx.x;
+    if (b >= nblocks)
+        return;
+    const uint32_t nb = f_nblocks[b];
+    if (nb == 0u || retry[b])
+        return;
+    const ZBlock blk = blocks[b];
+    const ZFrameHdr fh = z_frame_header(src + blk.src_off, blk.size);
+    if (!fh.ok)
+    {
+        retry[b] = __LINE__;
+        return;
+    }
+    const uint32_t content = (uint32_t)fh.content;
+    uint32_t h0 = 1, h1 = 4, h2 = 8, produced = 0; // Repeated_Offsets at the start of a frame
+    for (uint32_t k = 0; k < nb; ++k)
+    {
+        const uint32_t fi = blk.pad + k;
+        const ZPrep pr = fprep[fi];
+        if (pr.status == ZP_SERIAL || pr.expect > content - produced || pr.expect > ZB)
+        {
+            retry[b] = __LINE__;
+            return;
+        }
+        ZFr f = fr[fi];
+        f.in[0] = h0;
+        f.in[1] = h1;
+        f.in[2] = h2;
+        f.start = produced;
+        fr[fi] = f;
+        const uint32_t n0 = zo_bind(f.out[0], h0, h1, h2), n1 = zo_bind(f.out[1], h0, h1, h2), n2 = zo_bind(f.out[2], h0, h1, h2);
+        h0 = n0;
+        h1 = n1;
+        h2 = n2;
+        produced += pr.expect;
+    }
+    if (produced != content)
+        retry[b] = __LINE__;
+}
+
+// (one wave per block slot [slot0, slot0 + gridDim.x); origins of payload b at org + (zb_base(b) - item0) * ZB, one u32 per byte)
+__global__ __launch_bounds__(64) void k_zstd_fr_trace(const ZBlock* __restrict__ blocks, const ZItem* __restrict__ fitems, uint32_t slot0,
+                                                     const uint32_t* __restrict__ f_nblocks, const uint64_t* __restrict__ rec_scratch,
+                                                     const ZPrep* __restrict__ fprep, const ZFr* __restrict__ fr, uint32_t* __restrict__ org_arena,
+                                                     uint32_t item0, uint32_t* __restrict__ retry)
+{
+    __shared__ uint32_t s_ia[64], s_om[64];
+    const uint32_t fi = slot0 + blockIdx.x;
+    const ZItem it = fitems[fi];
+    if (it.kind != 4u)
+        return;
+    const uint32_t b = it.payload;
+    if (f_nblocks[b] == 0u || retry[b])
+        return;
+    const ZPrep pr = fprep[fi];
+    if (pr.log[0] != 0u)
+        return; // Raw_Block / RLE_Block: the gather copies / fills
+    const int lane = threadIdx.x;
+    const ZFr f = fr[fi];
+    const uint32_t start = f.start;
+    uint32_t* org = org_arena + (uint64_t)(blocks[b].zb_base - item0) * ZB + start; // origin of the block's byte q: org[q]
+    const uint64_t* recs = rec_scratch + pr.rec_at;
+    uint32_t litpos = 0, produced = 0;
+    bool bad = false;
+    uint32_t why = 0;
+    uint64_t r_next = (uint32_t)lane < pr.nbseq ? recs[lane] : 0ull;
+    for (uint32_t s0 = 0; s0 < pr.nbseq && !bad; s0 += 64u)
+    {
+        const uint32_t cnt = pr.nbseq - s0 < 64u ? pr.nbseq - s0 : 64u;
+        const uint64_t r = r_next;
+        r_next = s0 + 64u + (uint32_t)lane < pr.nbseq ? recs[s0 + 64u + (uint32_t)lane] : 0ull;
+        const bool act = (uint32_t)lane < cnt;
+        const uint32_t ll = act ? (uint32_t)r & 0xFFFFFu : 0u, ml = act ? (uint32_t)(r >> 20) & 0x3FFFFu : 0u, dd = (uint32_t)(r >> 38) & 3u;
+        const uint32_t ov = (uint32_t)(r >> 40);
+        uint32_t off;
+        if (ov > 3u)
+            off = ov - 3u;
+        else if (ov == 0u)
+            off = 0u;
+        else
+        {
+            const uint32_t e = ov == 1u ? f.in[0] : ov == 2u ? f.in[1] : f.in[2];
+            off = e > dd ? e - dd : 0u;
+        }
+        const uint32_t i_l = zx_scan_incl(ll), i_a = zx_scan_incl(ll + ml);
+        const uint32_t batch_ll = (uint32_t)__builtin_amdgcn_readlane((int)i_l, 63), batch_adv = (uint32_t)__builtin_amdgcn_readlane((int)i_a, 63);
+        const uint32_t o_l = produced + (i_a - ll - ml), o_m = o_l + ll; // where my literals / my match go (block positions)
+        {
+            const bool wrong = act && (off == 0u || ll > 131072u || ml > 131075u || ml < 3u || litpos + i_l > pr.nlit || produced + i_a > pr.expect ||
+                                       off > start + o_m);
+            if (__builtin_amdgcn_ballot_w64(wrong))
+            {
+                bad = true;
+                why = __LINE__;
+                break;
+            }
+        }
+        // ---- literals: their origin is their index ----
+        const uint32_t li = litpos + (i_l - ll);
+        if (ll <= 32u)
+            for (uint32_t j = 0; j < ll; ++j)
+                org[o_l + j] = li + j;
+        for (uint64_t big = __builtin_amdgcn_ballot_w64(ll > 32u); big; big &= big - 1ull)
+        {
+            const int u = __builtin_ctzll(big);
+            const uint32_t nn = (uint32_t)__builtin_amdgcn_readlane((int)ll, u), from = (uint32_t)__builtin_amdgcn_readlane((int)li, u),
+                           to = (uint32_t)__builtin_amdgcn_readlane((int)o_l, u);
+            for (uint32_t j = lane; j < nn; j += 64)
+                org[to + j] = from + j;
+        }
+        // ---- matches.  Which matches of THIS batch does mine read from?  those of the sequences that hold my first and my last
+        // source byte and everything between (sequence of a position: binary search in the prefix sums) ----
+        const int32_t a = (int32_t)o_m - (int32_t)off;          // first source byte (block position; below 0: an earlier block)
+        const uint32_t span = ml < off ? ml : off;              // distinct source bytes (off < ml: byte j = source byte j mod off)
+        uint64_t dep = 0;
+        s_ia[lane] = produced + i_a;
+        s_om[lane] = o_m;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (act && a + (int32_t)span > (int32_t)produced)
+        {
+            const uint32_t xa = a > (int32_t)produced ? (uint32_t)a : produced, xb = (uint32_t)(a + (int32_t)span) - 1u;
+            uint32_t ja = 0, jb = 0; // smallest j with s_ia[j] > x
+#pragma unroll
+            for (int st = 32; st; st >>= 1)
+            {
+                if (s_ia[ja + st - 1] <= xa)
+                    ja += st;
+                if (s_ia[jb + st - 1] <= xb)
+                    jb += st;
+            }
+            if (jb > (uint32_t)lane)
+                jb = (uint32_t)lane; // (cannot be: a source ends where its match begins)
+            int32_t hi = (int32_t)jb;
+            if (jb == (uint32_t)lane || xb < s_om[jb])
+                hi -= 1; // my own sequence / only the literals of that one
+            if (hi >= (int32_t)ja)
+                dep = ((hi >= 63 ? 0ull : (1ull << (hi + 1))) - 1ull) & ~((1ull << ja) - 1ull);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool own = act && ml <= 64u;
+        const uint64_t ownm = __builtin_amdgcn_ballot_w64(own);
+        uint64_t pend = __builtin_amdgcn_ballot_w64(act);
+        zo_sync(); // (the literals)
+        while (pend)
+        {
+            const bool ready = own && ((pend >> lane) & 1ull) && !(pend & dep);
+            if (ready)
+            {
+                if (off >= ml)
+                {
+                    uint32_t j = 0;
+                    for (; j + 4u <= ml; j += 4u)
+                    {
+                        uint32_t v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                        {
+                            const int32_t sp = a + (int32_t)j + q;
+                            v[q] = sp < 0 ? ZO_FLAG | (uint32_t)((int32_t)start + sp) : org[sp];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            org[o_m + j + q] = v[q];
+                    }
+                    for (; j < ml; ++j)
+                    {
+                        const int32_t sp = a + (int32_t)j;
+                        org[o_m + j] = sp < 0 ? ZO_FLAG | (uint32_t)((int32_t)start + sp) : org[sp];
+                    }
+                }
+                else
+                {
+                    uint32_t m = 0;
+                    for (uint32_t j = 0; j < ml; ++j)
+                    {
+                        const int32_t sp = a + (int32_t)m;
+                        org[o_m + j] = sp < 0 ? ZO_FLAG | (uint32_t)((int32_t)start + sp) : org[sp];
+                        m = m + 1u == off ? 0u : m + 1u;
+                    }
+                }
+            }
+            const uint64_t readym = __builtin_amdgcn_ballot_w64(ready);
+            const int first = __builtin_ctzll(pend);
+            if (!((ownm >> first) & 1ull))
+            {
+                // a long match whose turn has come (nothing pending below it): the whole wave
+                const uint32_t gm = (uint32_t)__builtin_amdgcn_readlane((int)ml, first), go = (uint32_t)__builtin_amdgcn_readlane((int)off, first),
+                               gd = (uint32_t)__builtin_amdgcn_readlane((int)o_m, first);
+                const int32_t ga = (int32_t)gd - (int32_t)go;
+                for (uint32_t j = lane; j < gm; j += 64)
+                {
+                    const int32_t sp = ga + (int32_t)(go < gm ? j % go : j);
+                    org[gd + j] = sp < 0 ? ZO_FLAG | (uint32_t)((int32_t)start + sp) : org[sp];
+                }
+                pend &= ~(1ull << first);
+            }
+            pend &= ~readym;
+            zo_sync();
+        }
+        litpos += batch_ll;
+        produced += batch_adv;
+    }
+    if (!bad)
+    {
+        // the block's last literals; it must regenerate what k_zstd_blk_entropy counted
+        const uint32_t rest = pr.nlit - litpos;
+        if (produced + rest != pr.expect)
+        {
+            bad = true;
+            why = __LINE__;
+        }
+        else
+            for (uint32_t j = lane; j < rest; j += 64)
+                org[produced + j] = litpos + j;
+    }
+    if (bad && lane == 0)
+        retry[b] = why ? why : 1u;
+}
+
+// block k of the payloads [pb0, pb0 + gridDim.y): 256 threads x 4 bytes per workgroup
+__global__ __launch_bounds__(256) void k_zstd_fr_gather(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t pb0, uint32_t k,
+                                                       const uint32_t* __restrict__ f_nblocks, uint8_t* __restrict__ dst,
+                                                       const uint8_t* __restrict__ lit_scratch, const ZPrep* __restrict__ fprep,
+                                                       const ZFr* __restrict__ fr, const uint32_t* __restrict__ org_arena, uint32_t item0,
+                                                       const uint32_t* __restrict__ retry)
+{
+    const uint32_t b = pb0 + blockIdx.y;
+    if (k >= f_nblocks[b] || retry[b])
+        return;
+    const ZBlock blk = blocks[b];
+    const uint32_t fi = blk.pad + k;
+    const ZPrep pr = fprep[fi];
+    const uint32_t q = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (q >= pr.expect)
+        return;
+    const uint32_t n = pr.expect - q < 4u ? pr.expect - q : 4u;
+    const uint32_t start = fr[fi].start;
+    uint8_t* out = dst + blk.dst_off;
+    uint8_t v[4] = {0, 0, 0, 0};
+    if (pr.log[0] == 2u)
+    {
+        const uint8_t x = src[pr.bits_off];
+        v[0] = v[1] = v[2] = v[3] = x;
+    }
+    else if (pr.log[0] == 1u)
+    {
+        for (uint32_t i = 0; i < n; ++i)
+            v[i] = src[pr.bits_off + q + i];
+    }
+    else
+    {
+        const uint32_t* org = org_arena + (uint64_t)(blk.zb_base - item0) * ZB + start + q;
+        const uint8_t* lits = lit_scratch + pr.bits_off;
+        uint32_t o[4];
+        for (uint32_t i = 0; i < 4u; ++i)
+            o[i] = i < n ? org[i] : 0u;
+        for (uint32_t i = 0; i < 4u; ++i)
+            v[i] = (o[i] & ZO_FLAG) ? out[o[i] & ~ZO_FLAG] : lits[o[i]];
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        out[start + q + i] = v[i];
+}
+
 } // namespace
 
 // what the last lthip_zstd_decompress_blocks call did (diagnostics for the tests: which decoder the payloads went to)
@@ -3296,9 +3708,11 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     // large the literal and record arenas must be, is known after k_zstd_split: the one place where this call waits for the device.
     if (!(dbg & 9u))
     {
-        uint32_t totals[4] = {0, 0, 0, 0};
-        LTHIP_CHECK(ctx, hipMemcpyAsync(totals, d_count + 4, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
+        uint32_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        LTHIP_CHECK(ctx, hipMemcpyAsync(counters, d_count, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
         LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        const uint32_t* totals = counters + 4;
+        const uint32_t f_most = counters[1]; // the most blocks a frame of another encoder has
         const uint64_t f_blocks = totals[0], f_bytes = ((uint64_t)totals[3] << 32) | totals[2];
         ctx->z_last_foreign_blocks = totals[0];
         if (f_blocks)
@@ -3322,10 +3736,58 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
             hipLaunchKernelGGL(k_zstd_blk_sequences, dim3((n + 63u) / 64u), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZItem*)d_fitems,
                                (const uint32_t*)d_slist, (const uint32_t*)d_scount, (const uint64_t*)d_ftabs, (uint64_t*)d_frecs, d_fprep, d_retry);
             LTHIP_LAUNCH_CHECK(ctx);
-            hipLaunchKernelGGL(k_zstd_execute_payload, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks, 0u,
-                               block_count, (const uint32_t*)d_fnb, (uint8_t*)d_dst, (const uint8_t*)d_flits, (const uint64_t*)d_frecs,
-                               (const ZPrep*)d_fprep, d_retry);
-            LTHIP_LAUNCH_CHECK(ctx);
+            if (dbg & 16u) // (round 2's way: a payload's blocks one after the other on ONE wave)
+            {
+                hipLaunchKernelGGL(k_zstd_execute_payload, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks, 0u,
+                                   block_count, (const uint32_t*)d_fnb, (uint8_t*)d_dst, (const uint8_t*)d_flits, (const uint64_t*)d_frecs,
+                                   (const ZPrep*)d_fprep, d_retry);
+                LTHIP_LAUNCH_CHECK(ctx);
+            }
+            else
+            {
+                // execution on origins, all blocks at once; the origins (4 bytes per byte of output) of as many payloads at a time as
+                // the arena's budget allows (LTHIP_ZSTD_ORG_MIB, default 4096)
+                void *d_fr, *d_org;
+                if ((err = lthip_scratch(ctx, S_Z_FR, sizeof(ZFr) * nfslots, &d_fr)))
+                    return err;
+                static int env_org = -2;
+                const int org_mib = env_u32_cached("LTHIP_ZSTD_ORG_MIB", env_org);
+                const uint64_t budget_items = ((uint64_t)(org_mib > 0 ? org_mib : 4096) << 20) / ((uint64_t)ZB * 4u);
+                uint64_t most = 0;
+                for (uint32_t p0 = 0; p0 < block_count;)
+                {
+                    uint64_t items = hb[p0].nzb;
+                    uint32_t p1 = p0 + 1;
+                    while (p1 < block_count && items + hb[p1].nzb <= budget_items)
+                        items += hb[p1++].nzb;
+                    most = items > most ? items : most;
+                    p0 = p1;
+                }
+                if ((err = lthip_scratch(ctx, S_Z_ORG, (size_t)most * ZB * 4u + 256, &d_org)))
+                    return err;
+                hipLaunchKernelGGL(k_zstd_fr_reps, dim3(n), dim3(64), 0, ctx->stream, (const uint32_t*)d_flist, n, (uint64_t*)d_frecs,
+                                   (const ZPrep*)d_fprep, (ZFr*)d_fr, (const ZItem*)d_fitems, d_retry);
+                hipLaunchKernelGGL(k_zstd_fr_chain, dim3((block_count + 63u) / 64u), dim3(64), 0, ctx->stream, (const uint8_t*)d_src,
+                                   (const ZBlock*)d_blocks, block_count, (const uint32_t*)d_fnb, (const ZPrep*)d_fprep, (ZFr*)d_fr, d_retry);
+                LTHIP_LAUNCH_CHECK(ctx);
+                for (uint32_t p0 = 0; p0 < block_count;)
+                {
+                    uint64_t items = hb[p0].nzb;
+                    uint32_t p1 = p0 + 1;
+                    while (p1 < block_count && items + hb[p1].nzb <= budget_items)
+                        items += hb[p1++].nzb;
+                    hipLaunchKernelGGL(k_zstd_fr_trace, dim3((uint32_t)(items * ZF_SLOTS)), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
+                                       (const ZItem*)d_fitems, hb[p0].pad, (const uint32_t*)d_fnb, (const uint64_t*)d_frecs, (const ZPrep*)d_fprep,
+                                       (const ZFr*)d_fr, (uint32_t*)d_org, hb[p0].zb_base, d_retry);
+                    LTHIP_LAUNCH_CHECK(ctx);
+                    for (uint32_t k = 0; k < f_most; ++k)
+                        hipLaunchKernelGGL(k_zstd_fr_gather, dim3(ZB / 1024u, p1 - p0), dim3(256), 0, ctx->stream, (const uint8_t*)d_src,
+                                           (const ZBlock*)d_blocks, p0, k, (const uint32_t*)d_fnb, (uint8_t*)d_dst, (const uint8_t*)d_flits,
+                                           (const ZPrep*)d_fprep, (const ZFr*)d_fr, (const uint32_t*)d_org, hb[p0].zb_base, (const uint32_t*)d_retry);
+                    LTHIP_LAUNCH_CHECK(ctx);
+                    p0 = p1;
+                }
+            }
         }
     }
     hipLaunchKernelGGL(k_zstd_decode<true>, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,

@@ -86,6 +86,8 @@ enum ScratchSlot
     S_LZ4_LANE_RECS, // lane parser: {start, length, offset} records, 8 per lane and unit
     S_LZ4_CLASSIFY,  // two-pass match finder: list + flags of the groups with redundancy
     S_B3_WINDOWS,   // first range of every window of leaf slots (parents kernel)
+    S_Z_FR,         // zstd decoder, frames of other encoders: per block {history in, start, history out}
+    S_Z_ORG,        // ... and the origins (u32 per byte of output) of the payloads in flight
     S_COUNT
 };
 
