@@ -1,5 +1,6 @@
 // k_lz4_decode.hip -- LZ4 block decoders on gfx950 (LZ4_decompress_safe rules, lib/lz4/ext/lz4.c:2215-2435).
 #include "lthip_internal.h"
+#include "origin_exec.h"
 
 #include <stdlib.h>
 #include <time.h>
@@ -419,11 +420,12 @@ struct PdUnit
     int64_t ip0, op0;
     bool last;                // the unit that runs to the end of the payload (hi is not a limit for it)
     const uint32_t* prev_done; // completion flag of the unit before this one (sources below lo live there)
+    bool defer;                // a source below lo: do not wait for that unit, give the unit up (it is then executed on origins)
     uint32_t* timeout;         // set when a wait gave up (the block is reported as damaged)
     volatile uint32_t* dbg;    // LTHIP_LZ4_PD_TRACE: host-visible progress words of this workgroup (else nullptr)
 };
 #define PD_DBG(i, v) do { if (UNIT && un.dbg && lane == 0) un.dbg[i] = (uint32_t)(v); } while (0)
-enum : uint32_t { DEC_ERROR = 0xFFFFFFFFu, DEC_UNIT_OK = 0u, DEC_UNIT_END = 1u };
+enum : uint32_t { DEC_ERROR = 0xFFFFFFFFu, DEC_UNIT_OK = 0u, DEC_UNIT_END = 1u, DEC_UNIT_DEFER = 2u };
 
 // One payload (UNIT = false; returns the decoded size or DEC_ERROR) or one unit of it (UNIT = true; returns DEC_UNIT_OK, DEC_UNIT_END
 // when it reached the valid end of the payload, or DEC_ERROR).
@@ -479,7 +481,7 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
         [[maybe_unused]] __amdgpu_buffer_rsrc_t orsrc;
         if constexpr (UNIT)
             orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out_al, 0, (int)((uint32_t)cap + g), 0x00020000);
-        [[maybe_unused]] bool prev_ready = false, gave_up = false;
+        [[maybe_unused]] bool prev_ready = false, gave_up = false, deferred = false;
         // sources below lo were written by the unit before this one (an offset is below 64 KiB = one unit): wait for its flag once
         auto wait_prev = [&]() {
             if constexpr (UNIT)
@@ -625,6 +627,12 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
                     // overlap what is written here) comes from global memory once that unit has published its bytes
                     const I gap = lo - (op - (I)off);
                     seg = (I)seg < gap ? seg : (uint32_t)gap;
+                    if (un.defer)
+                    {
+                        deferred = true; // (whatever else the caller does with this unit is thrown away)
+                        op += ml;
+                        return;
+                    }
                     wait_prev();
                     for (uint32_t j = lane; j < seg; j += 64)
                         s_ring[RING((uint32_t)op + j)] = out_byte((int64_t)op - off + j);
@@ -786,6 +794,8 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
         DEC_T0();
         while (entered)
         {
+            if (UNIT && deferred)
+                break;
             if (UNIT && !un.last && op >= hi)
             {
                 flush(hi + (I)g);
@@ -1140,6 +1150,8 @@ __device__ __forceinline__ uint32_t lz4_decode_one(const uint8_t* __restrict__ i
         DEC_ACC(0);
         if (gave_up)
             result = DEC_ERROR;
+        if (UNIT && deferred)
+            result = DEC_UNIT_DEFER;
 #undef RING
     }
     return result;
@@ -1419,7 +1431,8 @@ __global__ __launch_bounds__(64) void k_lz4_pd_units(const uint8_t* __restrict__
                                                      const PdTile* __restrict__ tiles, const uint32_t* __restrict__ tile_op,
                                                      const uint32_t* __restrict__ unit_tile, PdState* __restrict__ state,
                                                      uint32_t* __restrict__ done, uint32_t* __restrict__ counters, PdTickets tk,
-                                                     uint32_t dec_nobatch, volatile uint32_t* dbg, const uint32_t* __restrict__ first)
+                                                     uint32_t dec_nobatch, volatile uint32_t* dbg, const uint32_t* __restrict__ first,
+                                                     uint32_t* __restrict__ unit_mode)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN];
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[DEC_RING];
@@ -1506,6 +1519,7 @@ __global__ __launch_bounds__(64) void k_lz4_pd_units(const uint8_t* __restrict__
             un.ip0 = k == 0 ? 0 : (int64_t)tiles[blk.tile_base + j].entry;
             un.op0 = k == 0 ? 0 : (int64_t)tile_op[blk.tile_base + j];
             un.prev_done = k ? flag - 1 : nullptr;
+            un.defer = unit_mode != nullptr;
             un.timeout = &counters[1];
             un.dbg = dbg ? dbg + blockIdx.x * 8 : nullptr;
             if (dbg && lane == 0)
@@ -1523,6 +1537,11 @@ __global__ __launch_bounds__(64) void k_lz4_pd_units(const uint8_t* __restrict__
                     atomicOr(&state[b].err, 1u);
                 else if (result == DEC_UNIT_END)
                     atomicOr(&state[b].end_ok, 1u);
+                else if (result == DEC_UNIT_DEFER)
+                {
+                    unit_mode[blk.unit_base + k] = 1u; // a match reaches into the unit before: executed on origins (k_lz4_po_trace)
+                    atomicAdd(&counters[2], 1u);
+                }
             }
         }
         // publish: every store of this wave has landed (they were write-through), then the flag
@@ -1534,6 +1553,183 @@ __global__ __launch_bounds__(64) void k_lz4_pd_units(const uint8_t* __restrict__
         if (dbg && lane == 0)
             dbg[blockIdx.x * 8 + 6] = 0xCCCCu;
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Units given up by k_lz4_pd_units because a match reaches into the unit before (a payload with a sliding window: the reference's
+// parse), executed on ORIGINS (origin_exec.h): k_lz4_po_trace, one wave per such unit, all of them at once -- the unit's sequences
+// from the one that covers its first byte, clipped to [lo, hi), 64 at a time: a literal's origin is its position in the payload, a
+// source byte below lo becomes its output position -- then k_lz4_po_gather, launch k for unit k of every block.  The checks are
+// the serial decoder's (lz4.c:1979-2250), made with the true positions by the unit that holds the sequence's end, as in
+// lz4_decode_one<UNIT>.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_lz4_po_trace(const uint8_t* __restrict__ src, const PdBlock* __restrict__ blocks, uint32_t nblocks,
+                                                    uint32_t unit0, const PdTile* __restrict__ tiles, const uint32_t* __restrict__ tile_op,
+                                                    const uint32_t* __restrict__ unit_tile, PdState* __restrict__ state,
+                                                    uint32_t* __restrict__ unit_mode, uint32_t* __restrict__ org_arena)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN];
+    __shared__ uint32_t s_ia[64], s_om[64];
+    const uint32_t u = unit0 + blockIdx.x;
+    if (unit_mode[u] != 1u)
+        return;
+    const int lane = threadIdx.x;
+    const uint32_t b = pd_block_of(blocks, nblocks, u, false);
+    const PdBlock blk = blocks[b];
+    const PdState st = state[b];
+    const uint32_t k = u - blk.unit_base;
+    const bool last = k + 1u == st.nunits;
+    const int64_t cap = blk.dst_cap;
+    const int64_t lo = (int64_t)k * PD_UNIT, hi = last ? cap : lo + (int64_t)PD_UNIT;
+    uint32_t* org = org_arena + (uint64_t)blockIdx.x * PD_UNIT; // origin of output byte lo + q: org[q]
+    const uint32_t j0 = unit_tile[u];
+    int64_t ip = k == 0u ? 0 : (int64_t)tiles[blk.tile_base + j0].entry;
+    int64_t op = k == 0u ? 0 : (int64_t)tile_op[blk.tile_base + j0];
+    PdReader r;
+    r.init(src + blk.src_off, blk.size, s_in, lane);
+    bool bad = false, ended = false;
+    while (!bad && !ended && op < hi)
+    {
+        // ---- up to 64 sequences into the lanes, clipped to [lo, hi) ----
+        uint32_t ll = 0, li = 0, ml = 0, off = 1, cnt = 0;
+        const uint32_t pos = (uint32_t)((op > lo ? op : lo) - lo);
+        while (cnt < 64u && !bad && !ended && op < hi)
+        {
+            int64_t next = 0;
+            uint64_t out = 0;
+            uint32_t lp = 0, len = 0;
+            const int kind = pd_hop(r, ip, (uint64_t)cap, next, out, &lp, &len);
+            if (kind == 2)
+            {
+                bad = true;
+                break;
+            }
+            const int64_t lit_end = op + (int64_t)len;
+            if (kind == 1 || lit_end > cap - 12)
+            {
+                // the last sequence of the payload: literals up to its very end (or damage)
+                if (kind != 1 || lit_end > cap || lit_end < lo || (!last && lit_end < hi))
+                {
+                    bad = true;
+                    break;
+                }
+                ended = true;
+            }
+            const int64_t m = ended ? 0 : (int64_t)out - (int64_t)len; // match length
+            if (!ended && lit_end + m <= lo)
+            {
+                op = lit_end + m; // ends at or before lo: an earlier unit's (which also checks it)
+                ip = next;
+                continue;
+            }
+            uint32_t o = 1;
+            if (!ended)
+            {
+                o = r.byte_at((int64_t)lp + len) | (r.byte_at((int64_t)lp + len + 1) << 8);
+                if (o == 0u || (int64_t)o > lit_end || lit_end + m > cap - 5)
+                {
+                    bad = true;
+                    break;
+                }
+            }
+            const int64_t a0 = op > lo ? op : lo, a1 = lit_end < hi ? lit_end : hi; // my literals inside the unit
+            const int64_t m0 = lit_end > lo ? lit_end : lo, m1 = lit_end + m < hi ? lit_end + m : hi;
+            const uint32_t c_ll = a1 > a0 ? (uint32_t)(a1 - a0) : 0u, c_ml = m1 > m0 ? (uint32_t)(m1 - m0) : 0u;
+            const uint32_t c_li = lp + (uint32_t)(a0 - op);
+            if ((uint32_t)lane == cnt)
+            {
+                ll = c_ll;
+                li = c_li;
+                ml = c_ml;
+                off = o;
+            }
+            ++cnt;
+            op = lit_end + m;
+            ip = next;
+        }
+        if (bad)
+            break;
+        const bool act = (uint32_t)lane < cnt;
+        const uint32_t i_a = zo_scan_incl(act ? ll + ml : 0u);
+        zo_batch(org, (uint32_t)lo, lane, act, act ? ll : 0u, li, act ? ml : 0u, off, i_a, pos, s_ia, s_om);
+    }
+    if (!bad && !ended && !last && op < hi)
+        bad = true;
+    if (lane == 0)
+    {
+        if (bad)
+        {
+            atomicOr(&state[b].err, 1u);
+            unit_mode[u] = 2u; // (nothing to gather)
+        }
+        else if (ended && last)
+            atomicOr(&state[b].end_ok, 1u);
+    }
+}
+
+// unit k of the blocks [g0, g0 + gridDim.y): 256 threads x 16 bytes per workgroup
+__global__ __launch_bounds__(256) void k_lz4_po_gather(const uint8_t* __restrict__ src, const PdBlock* __restrict__ blocks, uint32_t g0, uint32_t k,
+                                                      uint32_t unit0, const PdState* __restrict__ state, const uint32_t* __restrict__ unit_mode,
+                                                      const uint32_t* __restrict__ org_arena, uint8_t* __restrict__ dst)
+{
+    const uint32_t b = g0 + blockIdx.y;
+    const PdBlock blk = blocks[b];
+    const PdState st = state[b];
+    if (k >= st.nunits || k >= blk.nunits_cap)
+        return;
+    const uint32_t u = blk.unit_base + k;
+    if (unit_mode[u] != 1u)
+        return;
+    const uint32_t lo = k * PD_UNIT;
+    const uint32_t len = st.total > lo ? (st.total - lo < PD_UNIT ? st.total - lo : PD_UNIT) : 0u;
+    const uint32_t q = (blockIdx.x * 256u + threadIdx.x) * 16u;
+    if (q >= len)
+        return;
+    const uint32_t nq = len - q < 16u ? len - q : 16u;
+    const uint32_t* org = org_arena + (uint64_t)(u - unit0) * PD_UNIT + q;
+    const uint8_t* lits = src + blk.src_off;
+    uint8_t* out = dst + blk.dst_off;
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    uint32_t o[16], w[4] = {0, 0, 0, 0};
+    if (nq == 16u)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(org + 4 * i);
+            o[4 * i] = v.x;
+            o[4 * i + 1] = v.y;
+            o[4 * i + 2] = v.z;
+            o[4 * i + 3] = v.w;
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i)
+            o[i] = i < nq ? org[i] : 0u;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < 16u; ++i)
+    {
+        const uint32_t x = (o[i] & ZO_FLAG) ? out[o[i] & ~ZO_FLAG] : lits[o[i]];
+        w[i >> 2] |= x << (8u * (i & 3u));
+    }
+    uint8_t* to = out + lo + q;
+    if (nq == 16u)
+    {
+        typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+        u32x4_a1 v;
+        v.x = w[0];
+        v.y = w[1];
+        v.z = w[2];
+        v.w = w[3];
+        *reinterpret_cast<u32x4_a1*>(to) = v;
+    }
+    else
+        for (uint32_t i = 0; i < nq; ++i)
+            to[i] = (uint8_t)(w[i >> 2] >> (8u * (i & 3u)));
 }
 
 __global__ void k_lz4_pd_finish(const PdBlock* __restrict__ blocks, uint32_t nblocks, const PdState* __restrict__ state,
@@ -1622,7 +1818,7 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     const size_t o_tiles = 0, o_top = o_tiles + sizeof(PdTile) * ntiles, o_ut = o_top + 4 * ntiles, o_state = o_ut + 4 * nunits,
                  o_order = o_state + sizeof(PdState) * nb, o_rows = o_order + 4 * (size_t)nb, o_done = o_rows + 4 * ((size_t)rows + 1),
                  o_cnt = o_done + 4 * nunits, o_first = o_cnt + 32, o_alt = (o_first + 12 * (size_t)nb + 15) & ~(size_t)15, o_claim = o_alt + sizeof(PdTile) * ntiles,
-                 o_end = o_claim + 4 * ntiles;
+                 o_mode = o_claim + 4 * ntiles, o_end = o_mode + 4 * nunits;
     void *tab, *blk;
     int err = lthip_scratch(ctx, S_LZ4_STREAM, o_end, &tab);
     if (!err)
@@ -1640,7 +1836,7 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     uint8_t* t8 = (uint8_t*)tab;
     LTHIP_CHECK(ctx, hipMemsetAsync(t8 + o_done, 0, o_first - o_done, ctx->stream));
     LTHIP_CHECK(ctx, hipMemsetAsync(t8 + o_alt, 0xFF, sizeof(PdTile) * ntiles, ctx->stream)); // entry = PD_NONE
-    LTHIP_CHECK(ctx, hipMemsetAsync(t8 + o_claim, 0, 4 * ntiles, ctx->stream)); // flags and counters: zero before every launch
+    LTHIP_CHECK(ctx, hipMemsetAsync(t8 + o_claim, 0, 4 * ntiles + 4 * nunits, ctx->stream)); // flags and counters: zero before every launch
     const PdBlock* d_blocks = (const PdBlock*)blk;
     PdTile* d_tiles = (PdTile*)(t8 + o_tiles);
     uint32_t* d_top = (uint32_t*)(t8 + o_top);
@@ -1697,13 +1893,64 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
         memset(hp, 0, 32 * (size_t)grid);
         dbg = (volatile uint32_t*)hp; // host-visible progress words, freed below once the kernel is through
     }
+    // LTHIP_LZ4_PD_WAIT=1: round 2's way -- a unit whose matches reach into the unit before WAITS for it (a chain of units)
+    static const bool wait_mode = [] { const char* e = getenv("LTHIP_LZ4_PD_WAIT"); return e && atoi(e) != 0; }();
+    uint32_t* d_mode = wait_mode ? nullptr : (uint32_t*)(t8 + o_mode);
     if (small)
         hipLaunchKernelGGL(k_lz4_pd_units<int32_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, (uint8_t*)d_dst, d_tiles,
-                           d_top, d_ut, d_state, d_done, d_cnt, tk, nobatch, dbg, (const uint32_t*)d_first);
+                           d_top, d_ut, d_state, d_done, d_cnt, tk, nobatch, dbg, (const uint32_t*)d_first, d_mode);
     else
         hipLaunchKernelGGL(k_lz4_pd_units<int64_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, (uint8_t*)d_dst, d_tiles,
-                           d_top, d_ut, d_state, d_done, d_cnt, tk, nobatch, dbg, (const uint32_t*)d_first);
+                           d_top, d_ut, d_state, d_done, d_cnt, tk, nobatch, dbg, (const uint32_t*)d_first, d_mode);
     LTHIP_LAUNCH_CHECK(ctx);
+    if (d_mode)
+    {
+        // units that were given up (a payload with a sliding window): on origins, as many blocks at a time as the arena's budget
+        // allows (4 bytes per byte of output; LTHIP_LZ4_ORG_MIB, default 4096).  The one place where this call waits for the device.
+        uint32_t given_up = 0;
+        LTHIP_CHECK(ctx, hipMemcpyAsync(&given_up, d_cnt + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (given_up)
+        {
+            static const uint64_t budget_units = [] {
+                const char* e = getenv("LTHIP_LZ4_ORG_MIB");
+                const int v = e ? atoi(e) : 0;
+                return ((uint64_t)(v > 0 ? v : 4096) << 20) / ((uint64_t)PD_UNIT * 4u);
+            }();
+            uint64_t most = 0;
+            for (uint32_t g0 = 0; g0 < nb;)
+            {
+                uint64_t units = hb[g0].nunits_cap;
+                uint32_t g1 = g0 + 1;
+                while (g1 < nb && units + hb[g1].nunits_cap <= budget_units)
+                    units += hb[g1++].nunits_cap;
+                most = units > most ? units : most;
+                g0 = g1;
+            }
+            void* d_org;
+            if ((err = lthip_scratch(ctx, S_Z_ORG, (size_t)most * PD_UNIT * 4u + 256, &d_org)))
+                return err;
+            for (uint32_t g0 = 0; g0 < nb;)
+            {
+                uint64_t units = hb[g0].nunits_cap;
+                uint32_t g1 = g0 + 1, rows_g = hb[g0].nunits_cap;
+                while (g1 < nb && units + hb[g1].nunits_cap <= budget_units)
+                {
+                    rows_g = hb[g1].nunits_cap > rows_g ? hb[g1].nunits_cap : rows_g;
+                    units += hb[g1++].nunits_cap;
+                }
+                hipLaunchKernelGGL(k_lz4_po_trace, dim3((uint32_t)units), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, nb, hb[g0].unit_base,
+                                   (const PdTile*)d_tiles, (const uint32_t*)d_top, (const uint32_t*)d_ut, d_state, d_mode, (uint32_t*)d_org);
+                LTHIP_LAUNCH_CHECK(ctx);
+                for (uint32_t k = 1; k < rows_g; ++k) // (unit 0 has nothing before it)
+                    hipLaunchKernelGGL(k_lz4_po_gather, dim3(PD_UNIT / 4096u, g1 - g0), dim3(256), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, g0, k,
+                                       hb[g0].unit_base, (const PdState*)d_state, (const uint32_t*)d_mode, (const uint32_t*)d_org, (uint8_t*)d_dst);
+                LTHIP_LAUNCH_CHECK(ctx);
+                g0 = g1;
+            }
+            PD_TRACE("origins");
+        }
+    }
     if (trace)
     {
         for (int sec = 0; sec < 5 && hipStreamQuery(ctx->stream) == hipErrorNotReady; ++sec)

@@ -62,6 +62,7 @@ __device__ unsigned long long g_zb_last[1 << 16];
 __device__ uint32_t g_zd_ablate; /* timing experiments only (LTHIP_ZSTD_ABLATE): 1 = no sequence execution, 2 = no Huffman decode */
 #define ZD_ABLATE g_zd_ablate
 #include "zstd_decode_core.h" /* includes zstd_block_core.h */
+#include "origin_exec.h"
 
 namespace
 {
@@ -3151,7 +3152,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 //   k_zstd_fr_gather   launch k fills block k of every frame: out[q] = literal or out[p]; blocks below k are final by then.
 // Same checks as the serial decoder (RFC 8878 3.1.1.3-5); whatever fails sends the payload there (retry).
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t ZO_FLAG = 0x80000000u; // origins: an earlier block's byte (frame position below) / histories: a symbolic entry
+// (histories: ZO_FLAG marks a symbolic entry)
 struct ZFr
 {
     uint32_t in[3];  // the repeat offsets the block starts with
@@ -3168,15 +3169,6 @@ __device__ __forceinline__ uint32_t zo_bind(uint32_t v, const uint32_t in0, cons
     const uint32_t e = slot == 0u ? in0 : slot == 1u ? in1 : in2;
     return e > d ? e - d : 0u; // (0: not an offset; whoever uses it is stopped)
 }
-// stores of this wave's lanes -> loads of this wave's lanes, through memory: the stores have to have left the wave (vmcnt), the
-// CU's vector cache is written through and shared by whoever runs on the CU (agent scope would write the L2 back, per round)
-__device__ __forceinline__ void zo_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
 __global__ __launch_bounds__(64) void k_zstd_fr_reps(const uint32_t* __restrict__ flist, uint32_t n, uint64_t* __restrict__ rec_scratch,
                                                     const ZPrep* __restrict__ fprep, ZFr* __restrict__ fr, const ZItem* __restrict__ fitems,
                                                     uint32_t* __restrict__ retry)
@@ -3379,109 +3371,7 @@ __global__ __launch_bounds__(64) void k_zstd_fr_trace(const ZBlock* __restrict__
                 break;
             }
         }
-        // ---- literals: their origin is their index ----
-        const uint32_t li = litpos + (i_l - ll);
-        if (ll <= 32u)
-            for (uint32_t j = 0; j < ll; ++j)
-                org[o_l + j] = li + j;
-        for (uint64_t big = __builtin_amdgcn_ballot_w64(ll > 32u); big; big &= big - 1ull)
-        {
-            const int u = __builtin_ctzll(big);
-            const uint32_t nn = (uint32_t)__builtin_amdgcn_readlane((int)ll, u), from = (uint32_t)__builtin_amdgcn_readlane((int)li, u),
-                           to = (uint32_t)__builtin_amdgcn_readlane((int)o_l, u);
-            for (uint32_t j = lane; j < nn; j += 64)
-                org[to + j] = from + j;
-        }
-        // ---- matches.  Which matches of THIS batch does mine read from?  those of the sequences that hold my first and my last
-        // source byte and everything between (sequence of a position: binary search in the prefix sums) ----
-        const int32_t a = (int32_t)o_m - (int32_t)off;          // first source byte (block position; below 0: an earlier block)
-        const uint32_t span = ml < off ? ml : off;              // distinct source bytes (off < ml: byte j = source byte j mod off)
-        uint64_t dep = 0;
-        s_ia[lane] = produced + i_a;
-        s_om[lane] = o_m;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (act && a + (int32_t)span > (int32_t)produced)
-        {
-            const uint32_t xa = a > (int32_t)produced ? (uint32_t)a : produced, xb = (uint32_t)(a + (int32_t)span) - 1u;
-            uint32_t ja = 0, jb = 0; // smallest j with s_ia[j] > x
-#pragma unroll
-            for (int st = 32; st; st >>= 1)
-            {
-                if (s_ia[ja + st - 1] <= xa)
-                    ja += st;
-                if (s_ia[jb + st - 1] <= xb)
-                    jb += st;
-            }
-            if (jb > (uint32_t)lane)
-                jb = (uint32_t)lane; // (cannot be: a source ends where its match begins)
-            int32_t hi = (int32_t)jb;
-            if (jb == (uint32_t)lane || xb < s_om[jb])
-                hi -= 1; // my own sequence / only the literals of that one
-            if (hi >= (int32_t)ja)
-                dep = ((hi >= 63 ? 0ull : (1ull << (hi + 1))) - 1ull) & ~((1ull << ja) - 1ull);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const bool own = act && ml <= 64u;
-        const uint64_t ownm = __builtin_amdgcn_ballot_w64(own);
-        uint64_t pend = __builtin_amdgcn_ballot_w64(act);
-        zo_sync(); // (the literals)
-        while (pend)
-        {
-            const bool ready = own && ((pend >> lane) & 1ull) && !(pend & dep);
-            if (ready)
-            {
-                if (off >= ml)
-                {
-                    uint32_t j = 0;
-                    for (; j + 4u <= ml; j += 4u)
-                    {
-                        uint32_t v[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                        {
-                            const int32_t sp = a + (int32_t)j + q;
-                            v[q] = sp < 0 ? ZO_FLAG | (uint32_t)((int32_t)start + sp) : org[sp];
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            org[o_m + j + q] = v[q];
-                    }
-                    for (; j < ml; ++j)
-                    {
-                        const int32_t sp = a + (int32_t)j;
-                        org[o_m + j] = sp < 0 ? ZO_FLAG | (uint32_t)((int32_t)start + sp) : org[sp];
-                    }
-                }
-                else
-                {
-                    uint32_t m = 0;
-                    for (uint32_t j = 0; j < ml; ++j)
-                    {
-                        const int32_t sp = a + (int32_t)m;
-                        org[o_m + j] = sp < 0 ? ZO_FLAG | (uint32_t)((int32_t)start + sp) : org[sp];
-                        m = m + 1u == off ? 0u : m + 1u;
-                    }
-                }
-            }
-            const uint64_t readym = __builtin_amdgcn_ballot_w64(ready);
-            const int first = __builtin_ctzll(pend);
-            if (!((ownm >> first) & 1ull))
-            {
-                // a long match whose turn has come (nothing pending below it): the whole wave
-                const uint32_t gm = (uint32_t)__builtin_amdgcn_readlane((int)ml, first), go = (uint32_t)__builtin_amdgcn_readlane((int)off, first),
-                               gd = (uint32_t)__builtin_amdgcn_readlane((int)o_m, first);
-                const int32_t ga = (int32_t)gd - (int32_t)go;
-                for (uint32_t j = lane; j < gm; j += 64)
-                {
-                    const int32_t sp = ga + (int32_t)(go < gm ? j % go : j);
-                    org[gd + j] = sp < 0 ? ZO_FLAG | (uint32_t)((int32_t)start + sp) : org[sp];
-                }
-                pend &= ~(1ull << first);
-            }
-            pend &= ~readym;
-            zo_sync();
-        }
+        zo_batch(org, start, lane, act, ll, litpos + (i_l - ll), ml, off, i_a, produced, s_ia, s_om);
         litpos += batch_ll;
         produced += batch_adv;
     }
@@ -3502,7 +3392,7 @@ __global__ __launch_bounds__(64) void k_zstd_fr_trace(const ZBlock* __restrict__
         retry[b] = why ? why : 1u;
 }
 
-// block k of the payloads [pb0, pb0 + gridDim.y): 256 threads x 4 bytes per workgroup
+// block k of the payloads [pb0, pb0 + gridDim.y): 256 threads x 16 bytes per workgroup
 __global__ __launch_bounds__(256) void k_zstd_fr_gather(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t pb0, uint32_t k,
                                                        const uint32_t* __restrict__ f_nblocks, uint8_t* __restrict__ dst,
                                                        const uint8_t* __restrict__ lit_scratch, const ZPrep* __restrict__ fprep,
@@ -3515,37 +3405,70 @@ __global__ __launch_bounds__(256) void k_zstd_fr_gather(const uint8_t* __restric
     const ZBlock blk = blocks[b];
     const uint32_t fi = blk.pad + k;
     const ZPrep pr = fprep[fi];
-    const uint32_t q = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    const uint32_t q = (blockIdx.x * 256u + threadIdx.x) * 16u;
     if (q >= pr.expect)
         return;
-    const uint32_t n = pr.expect - q < 4u ? pr.expect - q : 4u;
+    const uint32_t n = pr.expect - q < 16u ? pr.expect - q : 16u;
     const uint32_t start = fr[fi].start;
     uint8_t* out = dst + blk.dst_off;
-    uint8_t v[4] = {0, 0, 0, 0};
+    uint32_t w[4] = {0, 0, 0, 0}; // the sixteen bytes
     if (pr.log[0] == 2u)
     {
-        const uint8_t x = src[pr.bits_off];
-        v[0] = v[1] = v[2] = v[3] = x;
+        const uint32_t x = src[pr.bits_off];
+        w[0] = w[1] = w[2] = w[3] = x * 0x01010101u;
     }
     else if (pr.log[0] == 1u)
     {
+        const uint8_t* from = src + pr.bits_off + q;
         for (uint32_t i = 0; i < n; ++i)
-            v[i] = src[pr.bits_off + q + i];
+            w[i >> 2] |= (uint32_t)from[i] << (8u * (i & 3u));
     }
     else
     {
+        typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
         const uint32_t* org = org_arena + (uint64_t)(blk.zb_base - item0) * ZB + start + q;
         const uint8_t* lits = lit_scratch + pr.bits_off;
-        uint32_t o[4];
-        for (uint32_t i = 0; i < 4u; ++i)
-            o[i] = i < n ? org[i] : 0u;
-        for (uint32_t i = 0; i < 4u; ++i)
-            v[i] = (o[i] & ZO_FLAG) ? out[o[i] & ~ZO_FLAG] : lits[o[i]];
+        uint32_t o[16];
+        if (n == 16u)
+        {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(org + 4 * i);
+                o[4 * i] = v.x;
+                o[4 * i + 1] = v.y;
+                o[4 * i + 2] = v.z;
+                o[4 * i + 3] = v.w;
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (uint32_t i = 0; i < 16u; ++i)
+                o[i] = i < n ? org[i] : 0u;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i)
+        {
+            const uint32_t x = (o[i] & ZO_FLAG) ? out[o[i] & ~ZO_FLAG] : lits[o[i]];
+            w[i >> 2] |= x << (8u * (i & 3u));
+        }
     }
-    for (uint32_t i = 0; i < n; ++i)
-        out[start + q + i] = v[i];
+    uint8_t* to = out + start + q;
+    if (n == 16u)
+    {
+        typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+        u32x4_a1 v;
+        v.x = w[0];
+        v.y = w[1];
+        v.z = w[2];
+        v.w = w[3];
+        *reinterpret_cast<u32x4_a1*>(to) = v;
+    }
+    else
+        for (uint32_t i = 0; i < n; ++i)
+            to[i] = (uint8_t)(w[i >> 2] >> (8u * (i & 3u)));
 }
-
 } // namespace
 
 // what the last lthip_zstd_decompress_blocks call did (diagnostics for the tests: which decoder the payloads went to)
@@ -3781,7 +3704,7 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
                                        (const ZFr*)d_fr, (uint32_t*)d_org, hb[p0].zb_base, d_retry);
                     LTHIP_LAUNCH_CHECK(ctx);
                     for (uint32_t k = 0; k < f_most; ++k)
-                        hipLaunchKernelGGL(k_zstd_fr_gather, dim3(ZB / 1024u, p1 - p0), dim3(256), 0, ctx->stream, (const uint8_t*)d_src,
+                        hipLaunchKernelGGL(k_zstd_fr_gather, dim3(ZB / 4096u, p1 - p0), dim3(256), 0, ctx->stream, (const uint8_t*)d_src,
                                            (const ZBlock*)d_blocks, p0, k, (const uint32_t*)d_fnb, (uint8_t*)d_dst, (const uint8_t*)d_flits,
                                            (const ZPrep*)d_fprep, (const ZFr*)d_fr, (const uint32_t*)d_org, hb[p0].zb_base, (const uint32_t*)d_retry);
                     LTHIP_LAUNCH_CHECK(ctx);
