@@ -1571,6 +1571,7 @@ __global__ __launch_bounds__(64) void k_lz4_po_trace(const uint8_t* __restrict__
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN];
     __shared__ uint32_t s_ia[64], s_om[64];
+    __shared__ uint32_t s_ll[96], s_lp[96], s_ml[96], s_off[96], s_op[96]; // the batch being collected
     const uint32_t u = unit0 + blockIdx.x;
     if (unit_mode[u] != 1u)
         return;
@@ -1580,6 +1581,7 @@ __global__ __launch_bounds__(64) void k_lz4_po_trace(const uint8_t* __restrict__
     const PdState st = state[b];
     const uint32_t k = u - blk.unit_base;
     const bool last = k + 1u == st.nunits;
+    const int32_t n = (int32_t)blk.size;
     const int64_t cap = blk.dst_cap;
     const int64_t lo = (int64_t)k * PD_UNIT, hi = last ? cap : lo + (int64_t)PD_UNIT;
     uint32_t* org = org_arena + (uint64_t)blockIdx.x * PD_UNIT; // origin of output byte lo + q: org[q]
@@ -1589,12 +1591,113 @@ __global__ __launch_bounds__(64) void k_lz4_po_trace(const uint8_t* __restrict__
     PdReader r;
     r.init(src + blk.src_off, blk.size, s_in, lane);
     bool bad = false, ended = false;
+    if (lo > 0)
+    {
+        // positions only, up to the sequence that covers lo (what ends at or before lo is an earlier unit's, which also checks it)
+        const PdPos at = pd_walk<true>(r, ip, (uint64_t)op, INT64_MAX, (uint64_t)lo, (uint64_t)cap);
+        ip = at.ip;
+        op = (int64_t)at.op;
+    }
+    uint32_t cnt = 0; // sequences collected
+    // the batch: every lane clips its sequence to [lo, hi); the origins of all of them in one go
+    auto run_batch = [&]() {
+        const bool act = (uint32_t)lane < cnt;
+        const int64_t sop = act ? (int64_t)s_op[lane] + (lo & ~0xFFFFFFFFll) : hi; // (positions are kept as their low 32 bits)
+        const uint32_t lit = act ? s_ll[lane] : 0u, mlen = act ? s_ml[lane] : 0u;
+        const int64_t lit_end = sop + (int64_t)lit;
+        const int64_t a0 = sop > lo ? sop : lo, a1 = lit_end < hi ? lit_end : hi;
+        const int64_t m0 = lit_end > lo ? lit_end : lo, m1 = lit_end + (int64_t)mlen < hi ? lit_end + (int64_t)mlen : hi;
+        const uint32_t c_ll = act && a1 > a0 ? (uint32_t)(a1 - a0) : 0u, c_ml = act && m1 > m0 ? (uint32_t)(m1 - m0) : 0u;
+        const uint32_t c_li = (act ? s_lp[lane] : 0u) + (uint32_t)(a0 - sop);
+        const uint32_t offv = act ? s_off[lane] : 1u;
+        const int64_t first = (int64_t)s_op[0] + (lo & ~0xFFFFFFFFll);
+        const uint32_t pos = (uint32_t)((first > lo ? first : lo) - lo);
+        const uint32_t i_a = zo_scan_incl(c_ll + c_ml);
+        __builtin_amdgcn_wave_barrier();
+        zo_batch(org, (uint32_t)lo, lane, act, c_ll, c_li, c_ml, offv, i_a, pos, s_ia, s_om);
+        cnt = 0;
+    };
     while (!bad && !ended && op < hi)
     {
-        // ---- up to 64 sequences into the lanes, clipped to [lo, hi) ----
-        uint32_t ll = 0, li = 0, ml = 0, off = 1, cnt = 0;
-        const uint32_t pos = (uint32_t)((op > lo ? op : lo) - lo);
-        while (cnt < 64u && !bad && !ended && op < hi)
+        if (cnt > 42u) // (a window holds at most 21 sequences, the slow path adds one)
+            run_batch();
+        if (ip >= n)
+        {
+            bad = true;
+            break;
+        }
+        // ---- 64 positions at a time (pd_walk's scheme, with offsets): every lane reads its byte of the window as a token; a sequence
+        // without length bytes (or with ONE match-length byte below 255) that lies inside the window is "simple" ----
+        if (r.w0 != ip)
+        {
+            r.w0 = ip - 64; // force a reseed at exactly ip
+            (void)r.byte_at(ip);
+        }
+        const uint32_t w = r.w;
+        const uint32_t litl = w >> 4, mlcl = w & 15u;
+        const int32_t pl = (int32_t)ip + lane;
+        const bool big = litl == 15u;
+        const uint32_t after = (uint32_t)__shfl((int)w, (lane + 1) & 63, 64);
+        const uint32_t lit = big ? 15u + after : litl, hdr = big ? 2u : 1u;
+        const uint32_t e = (uint32_t)lane + hdr + lit + 2u; // where a match-length byte would be, relative to the window
+        const uint32_t ext = (uint32_t)__shfl((int)w, (int)(e & 63u), 64);
+        const uint32_t offv = (uint32_t)__shfl((int)w, (int)((e - 2u) & 63u), 64) | ((uint32_t)__shfl((int)w, (int)((e - 1u) & 63u), 64) << 8);
+        const bool one = mlcl == 15u;
+        bool simple = pl + (int32_t)(hdr + lit) <= n - 8 && e <= 64u; // "ip + len > n - 8" ends the payload; the offset inside the window
+        if (big) // its length byte: "ip >= n - 15" before it, "ip > n - 15" after it
+            simple = simple && lane < 63 && after != 255u && pl + 2 <= n - 15;
+        if (one)
+            simple = simple && e < 64u && pl + (int32_t)(hdr + lit) + 2 < n - 4 && ext != 255u;
+        const uint32_t mlen = mlcl + 4u + (one ? ext : 0u);
+        const uint32_t outv = lit + mlen, nxtv = e + (one ? 1u : 0u);
+        const uint64_t ok = __builtin_amdgcn_ballot_w64(simple);
+        uint64_t chain = 0;
+        uint32_t cur = 0;
+        while (cur < 64u && ((ok >> cur) & 1ull))
+        {
+            chain |= 1ull << cur;
+            cur = __builtin_amdgcn_readlane(nxtv, (int)cur);
+        }
+        if (chain)
+        {
+            // where each of them starts, and the checks that need it ("op + len > cap - 12", the offset, "op + ml > cap - 5"); the first
+            // one that fails them (or starts at or past hi) ends the chain: the slow path below says what it is
+            const bool inch = (chain >> lane) & 1ull;
+            const uint32_t pre = zo_scan_incl(inch ? outv : 0u);
+            const int64_t sop = op + (int64_t)(pre - (inch ? outv : 0u)), lit_end = sop + (int64_t)lit;
+            const bool good = inch && sop < hi && lit_end <= cap - 12 && lit_end + (int64_t)mlen <= cap - 5 && offv != 0u && (int64_t)offv <= lit_end;
+            const uint64_t failed = chain & ~__builtin_amdgcn_ballot_w64(good);
+            const uint64_t kept = failed ? chain & ((1ull << __builtin_ctzll(failed)) - 1ull) : chain;
+            if ((kept >> lane) & 1ull)
+            {
+                const uint32_t at = cnt + (uint32_t)__builtin_popcountll(kept & ((1ull << lane) - 1ull));
+                s_ll[at] = lit;
+                s_lp[at] = (uint32_t)pl + hdr;
+                s_ml[at] = mlen;
+                s_off[at] = offv;
+                s_op[at] = (uint32_t)sop;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            cnt += (uint32_t)__builtin_popcountll(kept);
+            if (failed)
+            {
+                const int fb = __builtin_ctzll(failed);
+                op = op + (int64_t)((uint32_t)__builtin_amdgcn_readlane((int)(pre - outv), fb)); // where that one starts
+                ip += fb;
+                if (op >= hi)
+                    break;
+            }
+            else
+            {
+                op += (int64_t)((uint32_t)__builtin_amdgcn_readlane((int)pre, 63));
+                ip += cur;
+                continue;
+            }
+        }
+        else if (cur == 0u && (ok & 1ull) == 0ull)
+            ; // the token at ip is not a simple one
+        // ---- one sequence the careful way (length bytes, the end of the payload, damage) ----
         {
             int64_t next = 0;
             uint64_t out = 0;
@@ -1617,12 +1720,6 @@ __global__ __launch_bounds__(64) void k_lz4_po_trace(const uint8_t* __restrict__
                 ended = true;
             }
             const int64_t m = ended ? 0 : (int64_t)out - (int64_t)len; // match length
-            if (!ended && lit_end + m <= lo)
-            {
-                op = lit_end + m; // ends at or before lo: an earlier unit's (which also checks it)
-                ip = next;
-                continue;
-            }
             uint32_t o = 1;
             if (!ended)
             {
@@ -1633,29 +1730,23 @@ __global__ __launch_bounds__(64) void k_lz4_po_trace(const uint8_t* __restrict__
                     break;
                 }
             }
-            const int64_t a0 = op > lo ? op : lo, a1 = lit_end < hi ? lit_end : hi; // my literals inside the unit
-            const int64_t m0 = lit_end > lo ? lit_end : lo, m1 = lit_end + m < hi ? lit_end + m : hi;
-            const uint32_t c_ll = a1 > a0 ? (uint32_t)(a1 - a0) : 0u, c_ml = m1 > m0 ? (uint32_t)(m1 - m0) : 0u;
-            const uint32_t c_li = lp + (uint32_t)(a0 - op);
-            if ((uint32_t)lane == cnt)
+            if (lane == 0)
             {
-                ll = c_ll;
-                li = c_li;
-                ml = c_ml;
-                off = o;
+                s_ll[cnt] = len;
+                s_lp[cnt] = lp;
+                s_ml[cnt] = (uint32_t)m;
+                s_off[cnt] = o;
+                s_op[cnt] = (uint32_t)op;
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             ++cnt;
             op = lit_end + m;
             ip = next;
         }
-        if (bad)
-            break;
-        const bool act = (uint32_t)lane < cnt;
-        const uint32_t i_a = zo_scan_incl(act ? ll + ml : 0u);
-        zo_batch(org, (uint32_t)lo, lane, act, act ? ll : 0u, li, act ? ml : 0u, off, i_a, pos, s_ia, s_om);
     }
-    if (!bad && !ended && !last && op < hi)
-        bad = true;
+    if (!bad && cnt)
+        run_batch();
     if (lane == 0)
     {
         if (bad)
