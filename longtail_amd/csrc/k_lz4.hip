@@ -285,6 +285,7 @@ constexpr uint32_t Z_PIECE = 128u << 10; // zstd Block_Maximum_Size (ZB_BLOCK_MA
 constexpr int LZ4_TAB_LZ4 = 1024 + 256;
 constexpr int LZ4_TAB_ZSTD = 1024 + 256;
 constexpr int LZ4_TAB_LANES = 2560;
+constexpr int LZ4_TAB_SHARED = 1536, LZ4_SH_LOG2 = 13; // lane parser with the group's shared table: 64 + 48 + 32 KiB of LDS
 
 // ---------------------------------------------------------------------------------------------------
 // K5, lane-sequential parse (MODE 1).  The batch parser above looks at 64 CONSECUTIVE positions per step and then has to choose
@@ -333,8 +334,8 @@ __device__ __forceinline__ uint32_t sub_shfl(uint32_t x, int s, bool rev, uint32
     return (s < 0 || s > 63) ? ident : v;
 }
 
-template <int TAB, int FMT>
-__device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t head, uint16_t* tab, int lane, uint32_t my_start,
+template <int TAB, int FMT, int SH>
+__device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t head, uint16_t* tab, const uint32_t* shr, int lane, uint32_t my_start,
                                                uint32_t my_len, int32_t start_limit, uint32_t end_limit, uint32_t sub, uint8_t* __restrict__ out,
                                                uint64_t* __restrict__ zrecs, uint64_t* __restrict__ lrecs, Lz4Seq& st, uint32_t dbg K5P_ARG)
 {
@@ -366,11 +367,15 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
         if (am)
         {
             uint32_t v = 0, h = 0, c = 0u;
+            [[maybe_unused]] uint32_t c2 = 0xFFFFFFFFu; // SH: the group's earliest aligned occurrence of these four bytes
             if (act)
             {
                 v = lds_read32(sdata, p + head);
-                h = __umulhi(v * 2654435761u, (uint32_t)TAB);
+                const uint32_t prod = v * 2654435761u;
+                h = __umulhi(prod, (uint32_t)TAB);
                 c = tab[h];
+                if constexpr (SH != 0)
+                    c2 = shr[prod >> (32 - SH)];
             }
             if (act)
             {
@@ -388,7 +393,15 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
                 }
             }
             bool hit = false;
-            if (act && c < p)
+            if constexpr (SH != 0)
+            {
+                // both candidates' bytes in one round trip; the private table's (the nearer one) first
+                const uint32_t x1 = act && c < p ? lds_read32(sdata, c + head) : ~v;
+                const uint32_t x2 = act && c2 < p ? lds_read32(sdata, c2 + head) : ~v;
+                hit = x1 == v || x2 == v;
+                c = x1 == v ? c : c2;
+            }
+            else if (act && c < p)
                 hit = lds_read32(sdata, c + head) == v;
             if (hit)
             {
@@ -686,7 +699,7 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
 // CLS (MODE 0 only) = classification pass of the two-pass scheme: groups without redundancy are skimmed here and now (the fast
 // geometry: 24 waves per CU), groups with redundancy are only NOTED -- the 16-unit group they belong to goes onto `worklist` --
 // and left to the lane parser, which then runs over that list.
-template <int G, int TAB, int FMT, int MODE, int CLS = 0>
+template <int G, int TAB, int FMT, int MODE, int CLS = 0, int SH = 0>
 __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
                                                              uint32_t nblocks, uint32_t grp0, uint32_t sub_bytes,
                                                              uint8_t* __restrict__ streams, Lz4Meta* __restrict__ meta,
@@ -702,6 +715,8 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint16_t* tab = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u) + (size_t)wave * TAB;
+    // SH (lane parser, round 3): a table of 2^SH 32-bit slots behind the private ones, shared by the group's waves
+    [[maybe_unused]] uint32_t* shr = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u + (size_t)G * TAB * 2);
 
     // MODE 0: one window group per workgroup.  MODE 1: the workgroup is alone on its CU (144 KiB of LDS), so it is PERSISTENT over
     // the groups grp0 + blockIdx.x, + gridDim.x, ... and the next group's bytes are fetched into registers (80 bytes per thread)
@@ -772,6 +787,13 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         for (uint32_t v = 0; v < (TAB * 2 / 16 + 63) / 64; ++v) // TAB * 2 bytes, 64 lanes x 16 bytes per step
             if (v * 64 + lane < TAB * 2 / 16)
                 tv[v * 64 + lane] = e;
+        if constexpr (SH != 0)
+        {
+            uint4* hv = reinterpret_cast<uint4*>(shr);
+            const uint4 none = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            for (uint32_t v = tid; v < (4u << SH) / 16u; v += 64 * G)
+                hv[v] = none;
+        }
         if (tid == 0)
             *flag = 0u;
     }
@@ -862,7 +884,47 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         // units only lend their bytes to the others' history here (LTHIP_LZ4_DBG bit 19: parse them again, the round-2 behaviour)
         if (listed && !(dbg & 524288u) && !((worklist[1u + ngroups + grp] >> ((uint32_t)wave / (uint32_t)(G / 2))) & 1u))
             emit_unit = false;
-        if (!(dbg & 1u))
+        if constexpr (SH != 0)
+        {
+            // History, second take (round 3): ONE table for the group that keeps the EARLIEST position of every aligned dword's hash
+            // (LDS atomic minimum, every wave inserts its own unit: 16 per lane) -- whatever a lane probes, every occurrence but the
+            // group's first finds the first one, in whichever unit it lies; the private tables (1536 entries now) hold only what the
+            // wave's own parse inserts and give the nearer candidate when they have one.  Against the prefix maximum over the
+            // waves' tables above: no sweeps, the far history no longer competes for 2560 slots with the near one ("tokens": a
+            // vocabulary of 2 x 1024 keys lost 40 % of its entries), tools/lz4_lane_model.c: mixed 1.89 -> 2.02 (reference 1.94),
+            // tokens 1.64 -> 2.13 (1.98), records 2.45 -> 2.53 (2.56) with 17 % fewer probe steps.
+            if (have_unit)
+            {
+                const uint4* s128 = reinterpret_cast<const uint4*>(sdata);
+                const uint32_t l0 = (my_start + head) >> 4, l1 = (my_start + my_len + head + 15u) >> 4; // 16-byte lines that hold my unit
+                for (uint32_t j0 = l0; j0 < l1; j0 += 256)
+                {
+                    uint4 w[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                    {
+                        const uint32_t j = j0 + u * 64 + (uint32_t)lane;
+                        w[u] = j < l1 ? s128[j] : make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                    {
+                        const uint32_t j = j0 + u * 64 + (uint32_t)lane;
+                        const uint32_t q = 16u * j - head; // position of the line's first byte (may be "negative" in line 0)
+                        const uint32_t g4[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                        {
+                            const uint32_t pk = q + 4u * k;
+                            if (j < l1 && pk >= my_start && pk < my_start + my_len) // (a wrapped "negative" position is above the unit)
+                                (void)__hip_atomic_fetch_min(&shr[(g4[k] * 2654435761u) >> (32 - SH)], pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        else if (!(dbg & 1u))
         {
             typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
             static_assert((TAB * 2) % (16 * 64) == 0, "a table is a whole number of 1 KiB sweeps");
@@ -947,7 +1009,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             if (emit_unit)
             {
                 K5P(2);
-                lz4_lane_parse<TAB, FMT>(sdata, head, ptab, lane, my_start, my_len, start_limit, end_limit, sub, out, recs,
+                lz4_lane_parse<TAB, FMT, SH>(sdata, head, ptab, shr, lane, my_start, my_len, start_limit, end_limit, sub, out, recs,
                                          lane_recs + (uint64_t)unit * (64u * LZ4_LANE_MAXREC), st, dbg K5P_PASS);
             }
         }
@@ -1706,14 +1768,18 @@ static bool lz4_lane_parser()
     return v;
 }
 
-template <int G, int TAB, int FMT, int MODE, int CLS = 0>
+template <int G, int TAB, int FMT, int MODE, int CLS = 0, int SH = 0>
 static int launch_segments(lthip_ctx* ctx, uint32_t groups, uint32_t SEG, const void* d_src, const Lz4Block* d_blocks, uint32_t block_count,
                            uint32_t g0, uint8_t* streams, Lz4Meta* meta, uint64_t* zrecs, uint8_t* spec_dst, uint32_t dbg, uint64_t* lane_recs,
                            uint32_t ngroups, uint32_t* worklist)
 {
-    const size_t lds = (size_t)G * SEG + 64 + 16 + (size_t)G * TAB * 2;
+    const size_t lds = (size_t)G * SEG + 64 + 16 + (size_t)G * TAB * 2 + (SH ? (size_t)4 << SH : 0);
     if (lds > 64u * 1024u && !ctx->k5_lds_enabled)
     {
+        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_SHARED, 0, 1, 0, LZ4_SH_LOG2>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_SHARED, 1, 1, 0, LZ4_SH_LOG2>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_LANES, 0, 1>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_LANES, 1, 1>),
@@ -1727,7 +1793,7 @@ static int launch_segments(lthip_ctx* ctx, uint32_t groups, uint32_t SEG, const 
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
         grid = groups < (uint32_t)ncu ? groups : (uint32_t)ncu; // one persistent workgroup per CU
     }
-    hipLaunchKernelGGL((k_lz4_segments<G, TAB, FMT, MODE, CLS>), dim3(grid), dim3(64 * G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
+    hipLaunchKernelGGL((k_lz4_segments<G, TAB, FMT, MODE, CLS, SH>), dim3(grid), dim3(64 * G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
                        block_count, g0, SEG, streams, meta, zrecs, spec_dst, dbg, lane_recs, ngroups, worklist);
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
@@ -1745,9 +1811,13 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
     if (!lanes)
         return launch_segments<LZ4_G_BATCH, FMT == 1 ? LZ4_TAB_ZSTD : LZ4_TAB_LZ4, FMT, 0>(ctx, g1 - g0, SEG, d_src, d_blocks, block_count, g0, streams,
                                                                                             meta, zrecs, spec_dst, dbg, nullptr, 0, nullptr);
+    // LTHIP_LZ4_SHARED=0: round 2/3a's history (prefix maximum over the waves' 2560-entry tables) instead of the shared table
+    static const bool shared = [] { const char* e = getenv("LTHIP_LZ4_SHARED"); return !(e && atoi(e) == 0); }();
     if (dbg & 16384u) // ablation: the lane kernel alone, with its own probe
-        return launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, FMT, 1>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta, zrecs,
-                                                                   spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr);
+        return shared ? launch_segments<LZ4_G_LANES, LZ4_TAB_SHARED, FMT, 1, 0, LZ4_SH_LOG2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams,
+                                                                                            meta, zrecs, spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr)
+                      : launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, FMT, 1>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta, zrecs,
+                                                                           spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr);
     void* wl;
     int err = lthip_scratch(ctx, S_LZ4_CLASSIFY, 4 * (2 * (size_t)ngrp + 2), &wl);
     if (err)
@@ -1757,6 +1827,9 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
                                                                                              streams, meta, zrecs, spec_dst, dbg, nullptr,
                                                                                              (uint32_t)ngrp, (uint32_t*)wl)))
         return err;
+    if (shared)
+        return launch_segments<LZ4_G_LANES, LZ4_TAB_SHARED, FMT, 1, 0, LZ4_SH_LOG2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta,
+                                                                                   zrecs, spec_dst, dbg, lane_recs, (uint32_t)ngrp, (uint32_t*)wl);
     return launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, FMT, 1>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta, zrecs,
                                                                spec_dst, dbg, lane_recs, (uint32_t)ngrp, (uint32_t*)wl);
 }

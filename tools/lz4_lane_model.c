@@ -37,6 +37,7 @@ struct params
     int far_stride;     /* 0 = the far history is not inserted at all */
     int accel;          /* a lane steps 1 + (consecutive misses >> accel) bytes after a miss (0 = always 1) */
     int raw;            /* 1: the table is read again AFTER the step's writes: the surviving entry of a write conflict is a candidate at once */
+    uint32_t shared;    /* > 0: slots of a table shared by the group's waves that keeps the EARLIEST aligned occurrence of a key (looked at when the private table has nothing) */
 };
 
 static uint32_t rd32(const uint8_t* p)
@@ -62,6 +63,7 @@ static uint64_t model_block(const uint8_t* src, uint32_t n, const struct params*
     uint64_t ns = 0, iters = 0;
     uint32_t* tab = (uint32_t*)malloc(sizeof(uint32_t) * P->tab * 2);
     const uint32_t NB = P->tab / (uint32_t)P->ways; /* buckets */
+    uint32_t* shared = (uint32_t*)malloc(4 * (P->shared + 1));
     uint32_t* p = (uint32_t*)malloc(4 * L);
     uint32_t* lane_end = (uint32_t*)malloc(4 * L);
     uint32_t* lane_anchor = (uint32_t*)malloc(4 * L);
@@ -72,6 +74,17 @@ static uint64_t model_block(const uint8_t* src, uint32_t n, const struct params*
     {
         const uint32_t glen = n - g0 < gbytes ? n - g0 : gbytes;
         const uint32_t hist0 = g0 >= (uint32_t)P->history_groups * gbytes ? g0 - (uint32_t)P->history_groups * gbytes : 0;
+        if (P->shared)
+        {
+            for (uint32_t i = 0; i < P->shared; ++i)
+                shared[i] = EMPTY;
+            for (uint32_t q = g0; q + 4 <= g0 + glen; q += 4)
+            {
+                const uint32_t hs = hidx(rd32(src + q) ^ 0x9E3779B9u, P->shared);
+                if (shared[hs] == EMPTY)
+                    shared[hs] = q;
+            }
+        }
         for (uint32_t w = 0; w * U < glen; ++w)
         {
             const uint32_t ustart = g0 + w * U;
@@ -167,6 +180,8 @@ static uint64_t model_block(const uint8_t* src, uint32_t n, const struct params*
                     }
                     if (!(c != EMPTY && c < p[l] && p[l] - c <= 65535 && rd32(src + c) == vv[l]))
                         c = cand2[l];
+                    if (P->shared && !(c != EMPTY && c < p[l] && p[l] - c <= 65535 && rd32(src + c) == vv[l]))
+                        c = shared[hidx(vv[l] ^ 0x9E3779B9u, P->shared)];
                     if (c != EMPTY && c < p[l] && p[l] - c <= 65535 && rd32(src + c) == vv[l])
                     {
                         uint32_t s = p[l], cs = c, ml = 4;
@@ -239,6 +254,7 @@ static uint64_t model_block(const uint8_t* src, uint32_t n, const struct params*
     *iters_out += iters;
     free(seqs);
     free(tab);
+    free(shared);
     free(p);
     free(lane_end);
     free(lane_anchor);
@@ -258,14 +274,12 @@ int main(int argc, char** argv)
     uint8_t* dst = (uint8_t*)malloc(lto_lz4_bound(block));
     struct params variants[] = {
         /* unit group tab lanes cross seed inm back hist trim ways policy maxrec near far accel raw */
-        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1},
-        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 8, 2, 1},
-        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 8192, 8, 2, 1},
-        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 16, 2, 1},
-        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 32768, 0, 2, 1},
-        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 0, 2, 1},
-        {4096, 16, 2560, 64, 1, 8, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1},
-        {4096, 16, 2560, 64, 1, 6, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1},
+        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 16, 2, 1, 0},
+        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 16, 2, 1, 8192},
+        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 16, 2, 1, 16384},
+        {4096, 16, 1536, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 8192},
+        {4096, 16, 1536, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 16384},
+        {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 16, 2, 1, 8192},
     };
     printf("%-58s", "variant (unit group tab lanes cross seed inm back hist trim)");
     for (int k = 0; k < 4; ++k)
@@ -294,7 +308,7 @@ int main(int argc, char** argv)
         char label[128];
         snprintf(label, sizeof label, "%5u %3u %5u %3u   %d    %d    %d    %d    %d    %d  w%d p%d", P->unit, P->group, P->tab, P->lanes, P->cross, P->seed_stride,
                  P->insert_in_match, P->back, P->history_groups, P->trim, P->ways, P->policy);
-        snprintf(label + strlen(label), sizeof label - strlen(label), " m%d n%u f%d a%d", P->maxrec, P->near_bytes, P->far_stride, P->accel);
+        snprintf(label + strlen(label), sizeof label - strlen(label), " m%d n%u f%d a%d s%u", P->maxrec, P->near_bytes, P->far_stride, P->accel, P->shared);
         printf("%-58s", label);
         double it_mixed = 0;
         for (int k = 0; k < 4; ++k)
