@@ -280,6 +280,10 @@ int main(int argc, char** argv)
         {4096, 16, 1536, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 8192},
         {4096, 16, 1536, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 16384},
         {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 16, 2, 1, 8192},
+        {4096, 16, 8, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 8192},
+        {4096, 16, 8, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 16384},
+        {4096, 16, 512, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 16384},
+        {4096, 16, 1536, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 0, 8192},
     };
     printf("%-58s", "variant (unit group tab lanes cross seed inm back hist trim)");
     for (int k = 0; k < 4; ++k)
