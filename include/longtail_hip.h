@@ -262,6 +262,9 @@ LTHIP_EXPORT int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src,
  * other encoders' frames that were listed for the block-parallel decoder, out[2] payloads a lane-parallel decoder gave back to the
  * serial one, out[3] where the first of those was sent back (a source line of k_zstd.hip).  Waits for the context's stream. */
 LTHIP_EXPORT int lthip_zstd_last_decode_stats(lthip_ctx* ctx, uint32_t out[4]);
+/* Tests only: the library caches its environment switches (LTHIP_ZSTD_DBG, LTHIP_LZ4_PD_WAIT, LTHIP_LZ4_SHARED, ...) per process; after
+ * this call they are read again, so that one process can run a path and its ablation. */
+LTHIP_EXPORT void lthip_debug_reload_env(void);
 /* Diagnostics (parity tests): match-finder output of the last lthip_zstd_compress_blocks call (its last internal batch:
  * calls above LTHIP_BATCH_BYTES = 8 GiB of input are processed in several) on this context for the
  * 4 KiB units [first, first + count) -- 16 bytes of meta {nseq, nlit, tail, 0}, 4096 literal bytes and 1024 u64

@@ -1812,7 +1812,8 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
         return launch_segments<LZ4_G_BATCH, FMT == 1 ? LZ4_TAB_ZSTD : LZ4_TAB_LZ4, FMT, 0>(ctx, g1 - g0, SEG, d_src, d_blocks, block_count, g0, streams,
                                                                                             meta, zrecs, spec_dst, dbg, nullptr, 0, nullptr);
     // LTHIP_LZ4_SHARED=0: round 2/3a's history (prefix maximum over the waves' 2560-entry tables) instead of the shared table
-    static const bool shared = [] { const char* e = getenv("LTHIP_LZ4_SHARED"); return !(e && atoi(e) == 0); }();
+    static LthipEnvInt env_shared{"LTHIP_LZ4_SHARED"};
+    const bool shared = env_shared.get() != 0;
     if (dbg & 16384u) // ablation: the lane kernel alone, with its own probe
         return shared ? launch_segments<LZ4_G_LANES, LZ4_TAB_SHARED, FMT, 1, 0, LZ4_SH_LOG2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams,
                                                                                             meta, zrecs, spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr)

@@ -1985,7 +1985,8 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
         dbg = (volatile uint32_t*)hp; // host-visible progress words, freed below once the kernel is through
     }
     // LTHIP_LZ4_PD_WAIT=1: round 2's way -- a unit whose matches reach into the unit before WAITS for it (a chain of units)
-    static const bool wait_mode = [] { const char* e = getenv("LTHIP_LZ4_PD_WAIT"); return e && atoi(e) != 0; }();
+    static LthipEnvInt env_wait{"LTHIP_LZ4_PD_WAIT"};
+    const bool wait_mode = env_wait.get() > 0;
     uint32_t* d_mode = wait_mode ? nullptr : (uint32_t*)(t8 + o_mode);
     if (small)
         hipLaunchKernelGGL(k_lz4_pd_units<int32_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, (uint8_t*)d_dst, d_tiles,

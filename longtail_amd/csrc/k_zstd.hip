@@ -3473,15 +3473,6 @@ __global__ __launch_bounds__(256) void k_zstd_fr_gather(const uint8_t* __restric
 
 // what the last lthip_zstd_decompress_blocks call did (diagnostics for the tests: which decoder the payloads went to)
 // (kept in the context: one context per calling thread, so concurrent callers do not share them)
-static int env_u32_cached(const char* name, int& cache) // environment switches are read once per process, not per call
-{
-    if (cache == -2)
-    {
-        const char* e = getenv(name);
-        cache = e ? atoi(e) : -1;
-    }
-    return cache;
-}
 extern "C" int lthip_zstd_last_decode_stats(lthip_ctx* ctx, uint32_t out[4])
 {
     if (!ctx || !out)
@@ -3533,9 +3524,9 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
     // 8 single-wave workgroups per CU (12 would be resident at 143 VGPRs, measured slower: 190 vs 160 ms for 512 blocks)
     uint32_t nwg = nitems < (uint64_t)ncu * 8u ? (uint32_t)nitems : (uint32_t)ncu * 8u;
-    static int env_nwg = -2, env_dbg = -2, env_ablate = -2;
-    if (env_u32_cached("LTHIP_ZSTD_NWG", env_nwg) >= 0)
-        nwg = (uint32_t)env_nwg;
+    static LthipEnvInt env_nwg{"LTHIP_ZSTD_NWG"}, env_dbg{"LTHIP_ZSTD_DBG"}, env_ablate{"LTHIP_ZSTD_ABLATE"};
+    if (env_nwg.get() >= 0)
+        nwg = (uint32_t)env_nwg.get();
     void *d_blocks, *d_lits, *d_items;
     int err;
     if ((err = lthip_scratch(ctx, S_LZ4_BLOCKS, sizeof(ZBlock) * (size_t)block_count, &d_blocks)))
@@ -3567,10 +3558,10 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     LTHIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 4 * ncounters, ctx->stream));
     if ((err = lthip_stage_upload(ctx, d_blocks, hb.data(), sizeof(ZBlock) * (size_t)block_count, ctx->stream)))
         return err;
-    const uint32_t dbg = env_u32_cached("LTHIP_ZSTD_DBG", env_dbg) > 0 ? (uint32_t)env_dbg : 0u; // 1: never decode by pieces
-    if (env_u32_cached("LTHIP_ZSTD_ABLATE", env_ablate) >= 0)
+    const uint32_t dbg = env_dbg.get() > 0 ? (uint32_t)env_dbg.get() : 0u; // 1: never decode by pieces
+    if (env_ablate.get() >= 0)
     {
-        const uint32_t a = (uint32_t)env_ablate;
+        const uint32_t a = (uint32_t)env_ablate.get();
         LTHIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_zd_ablate), &a, sizeof(a)));
     }
     LaunchTimer t(ctx, LTHIP_K_OTHER);
@@ -3673,8 +3664,8 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
                 void *d_fr, *d_org;
                 if ((err = lthip_scratch(ctx, S_Z_FR, sizeof(ZFr) * nfslots, &d_fr)))
                     return err;
-                static int env_org = -2;
-                const int org_mib = env_u32_cached("LTHIP_ZSTD_ORG_MIB", env_org);
+                static LthipEnvInt env_org{"LTHIP_ZSTD_ORG_MIB"};
+                const int org_mib = env_org.get();
                 const uint64_t budget_items = ((uint64_t)(org_mib > 0 ? org_mib : 4096) << 20) / ((uint64_t)ZB * 4u);
                 uint64_t most = 0;
                 for (uint32_t p0 = 0; p0 < block_count;)

@@ -36,6 +36,9 @@ int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out)
     return 0;
 }
 
+volatile uint32_t g_lthip_env_gen = 1;
+extern "C" void lthip_debug_reload_env(void) { g_lthip_env_gen = g_lthip_env_gen + 1u; }
+
 // ---------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------

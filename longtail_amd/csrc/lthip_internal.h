@@ -6,6 +6,7 @@
 #include <errno.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -128,6 +129,27 @@ struct lthip_ctx
 };
 
 int lthip_fail(lthip_ctx* ctx, int code, const char* what, const char* detail);
+
+// Environment switches (ablations, debug paths) are read once per process and cached -- not per call: the plugins call from up to 256
+// threads.  lthip_debug_reload_env() (tests: one process tries a path and its ablation) bumps the generation; a cache re-reads then.
+extern volatile uint32_t g_lthip_env_gen;
+struct LthipEnvInt
+{
+    const char* name;
+    int value;     // atoi of the variable; -1 when it is not set
+    uint32_t seen; // generation the value was read at (0: never)
+    int get()
+    {
+        const uint32_t gen = g_lthip_env_gen;
+        if (seen != gen)
+        {
+            const char* e = getenv(name);
+            value = e ? atoi(e) : -1;
+            seen = gen;
+        }
+        return value;
+    }
+};
 int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out);
 // A second in-order queue of the context for work that should overlap the main stream (callers order the two with
 // events from lthip_sync_event and must make the main stream wait for the side stream before they return).

@@ -68,3 +68,14 @@ def gpu(hiplib):
     ctx = Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(autouse=True)
+def _library_rereads_its_switches(request):
+    """The library caches its environment switches per process; a test that sets one (monkeypatch) must not leak the cached value
+    into the next test: read them again after every GPU test."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        from longtail_amd.lib import load
+
+        load().dll.lthip_debug_reload_env()

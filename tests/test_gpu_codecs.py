@@ -399,8 +399,10 @@ def test_zstd_piece_decoder_is_the_serial_decoder_on_own_frames_and_strict_on_fa
             caps.append(len(d))
     pieces = gpu_zstd_decode(gpu, frames, caps)
     monkeypatch.setenv("LTHIP_ZSTD_DBG", "1")
+    gpu.lib.dll.lthip_debug_reload_env()  # (the library caches its switches)
     serial = gpu_zstd_decode(gpu, frames, caps)
     monkeypatch.delenv("LTHIP_ZSTD_DBG")
+    gpu.lib.dll.lthip_debug_reload_env()
     for i, (f, cap, p_out, s_out) in enumerate(zip(frames, caps, pieces, serial)):
         if i < len(own):
             assert p_out is not None and (p_out == datas[i]).all() and (s_out == datas[i]).all()
@@ -460,8 +462,10 @@ def test_zstd_sub_block_decoder_is_the_serial_decoder_and_strict(gpu, oracle, re
             caps.append(len(d))
     fast = gpu_zstd_decode(gpu, frames, caps)
     monkeypatch.setenv("LTHIP_ZSTD_DBG", "1")
+    gpu.lib.dll.lthip_debug_reload_env()  # (the library caches its switches)
     serial = gpu_zstd_decode(gpu, frames, caps)
     monkeypatch.delenv("LTHIP_ZSTD_DBG")
+    gpu.lib.dll.lthip_debug_reload_env()
     for i, (f, cap, p_out, s_out) in enumerate(zip(frames, caps, fast, serial)):
         if i < len(own):
             assert p_out is not None and (p_out == datas[i]).all() and s_out is not None and (s_out == datas[i]).all()
@@ -538,8 +542,10 @@ def test_zstd_reference_frames_block_parallel_is_the_serial_decoder(gpu, oracle,
     assert all(o is not None and (o == t).all() for o, t in zip(clean_out, truth[:clean]))
     fast = gpu_zstd_decode(gpu, frames, caps)
     monkeypatch.setenv("LTHIP_ZSTD_DBG", "1")
+    gpu.lib.dll.lthip_debug_reload_env()  # (the library caches its switches)
     serial = gpu_zstd_decode(gpu, frames, caps)
     monkeypatch.delenv("LTHIP_ZSTD_DBG")
+    gpu.lib.dll.lthip_debug_reload_env()
     for i, (f_out, s_out, t) in enumerate(zip(fast, serial, truth)):
         if t is not None:
             assert f_out is not None and len(f_out) == len(t) and (f_out == t).all(), i
@@ -709,3 +715,46 @@ def test_lz4_block_parallel_decoder_differential_fuzz(gpu, oracle):
             assert (host[o : o + n] == out[:n]).all(), i
             accepted += 1
     assert 10 <= accepted < len(cases)
+
+
+@pytest.mark.gpu
+def test_origin_execution_is_the_chained_execution(gpu, oracle, ref, monkeypatch):
+    """Payloads whose matches cross the pieces they are decoded in -- LZ4 blocks with a sliding window (the reference's parse), zstd
+    frames of the reference encoder -- are executed on ORIGINS (origin_exec.h: k_lz4_po_trace/_gather, k_zstd_fr_reps/_chain/_trace/
+    _gather).  Chain-heavy data (every token / record / line repeats an earlier one: the closure of what depends on the piece before
+    is the whole piece), a block of 8 MiB + 5, repeat offsets at block starts, raw and RLE blocks inside frames, two arena budgets
+    (several groups per call).  Same sizes and bytes as round 2's execution (a unit waits for the unit before: LTHIP_LZ4_PD_WAIT=1;
+    a frame's blocks one after the other on one wave: LTHIP_ZSTD_DBG=16) and as the data."""
+    rng = np.random.default_rng(77)
+    raws = [oracle.synth(n, 500 + k, k) for k, n in ((12, (8 << 20) + 5), (11, 3 << 20), (13, 2 << 20), (1, 5 << 20), (12, 131073), (2, 1 << 20))]
+    raws.append(np.concatenate([oracle.synth(300000, 9, 12), rng.integers(0, 256, 200000, dtype=np.uint8), oracle.synth(300000, 9, 12),
+                                np.zeros(200000, np.uint8), oracle.synth(300000, 9, 12)]))
+    lz = [oracle.lz4_compress(r) for r in raws]
+    zs = [ref.compress(1, ref.zstd_default, r) for r in raws]
+    caps = [len(r) for r in raws]
+
+    def run_lz4():
+        dev, offs = to_device(lz)
+        d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
+        dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+        sizes = u32(gpu.lz4_decompress_blocks(dev, offs, [len(c) for c in lz], dst, d_offs, caps))
+        host = dst.cpu().numpy()
+        return [host[o : o + int(s)].copy() for o, s in zip(d_offs, sizes)]
+
+    results = {}
+    for budget in ("1", "4096"):  # MiB of origins in flight: one block per group / all of them
+        monkeypatch.setenv("LTHIP_LZ4_ORG_MIB", budget)
+        monkeypatch.setenv("LTHIP_ZSTD_ORG_MIB", budget)
+        gpu.lib.dll.lthip_debug_reload_env()
+        results["lz4", budget] = run_lz4()
+        results["zstd", budget] = gpu_zstd_decode(gpu, zs, caps)
+        n_pay, n_blocks, n_back, _ = gpu.zstd_last_decode_stats()
+        assert n_pay == len(zs) and n_back == 0 and n_blocks >= sum((c + 131071) // 131072 for c in caps)
+    monkeypatch.setenv("LTHIP_LZ4_PD_WAIT", "1")
+    monkeypatch.setenv("LTHIP_ZSTD_DBG", "16")
+    gpu.lib.dll.lthip_debug_reload_env()
+    results["lz4", "chained"] = run_lz4()
+    results["zstd", "chained"] = gpu_zstd_decode(gpu, zs, caps)
+    for key, outs in results.items():
+        for i, (o, r) in enumerate(zip(outs, raws)):
+            assert o is not None and len(o) == len(r) and (o == r).all(), (key, i)
