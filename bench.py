@@ -278,12 +278,18 @@ class Bench:
             n_all = int(job_first[-1])
             t2 = time.perf_counter()
             tr, keep = Ingest.tree(tree["sizes"], tree["path_offsets"], tree["perms"], tree["path_data"], part.job_asset, job_first, my_jobs)
+            t2b = time.perf_counter()
             ing.index(tr, all_hash, all_lens, n_all, out_offs, out_first, total, h_vi)
             t3 = time.perf_counter()
+            if os.environ.get("LTHIP_BENCH_TRACE"):
+                print(f"step: chunk_hash {1e3*(t1-t0):.2f} first {1e3*(t2-t1):.2f} tree {1e3*(t2b-t2):.2f} index {1e3*(t3-t2b):.2f} ms", file=sys.stderr)
             if not args.no_compress:
                 ing.write(data, arena)
+            t3b = time.perf_counter()
             res = ing.finish(h_si)
             t4 = time.perf_counter()
+            if os.environ.get("LTHIP_BENCH_TRACE"):
+                print(f"step: write (host) {1e3*(t3b-t3):.2f} finish {1e3*(t4-t3b):.2f} ms", file=sys.stderr)
             stats.update(res=res, t=(t1 - t0, t2 - t1, t3 - t2, t4 - t3))
 
         for _ in range(warmup):
