@@ -335,7 +335,8 @@ __device__ __forceinline__ uint32_t sub_shfl(uint32_t x, int s, bool rev, uint32
 }
 
 template <int TAB, int FMT, int SH>
-__device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t head, uint16_t* tab, const uint32_t* shr, int lane, uint32_t my_start,
+__device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t head, uint16_t* tab, const uint32_t* shr, uint32_t sh_base, int lane,
+                                               uint32_t my_start,
                                                uint32_t my_len, int32_t start_limit, uint32_t end_limit, uint32_t sub, uint8_t* __restrict__ out,
                                                uint64_t* __restrict__ zrecs, uint64_t* __restrict__ lrecs, Lz4Seq& st, uint32_t dbg K5P_ARG)
 {
@@ -375,7 +376,7 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
                 h = __umulhi(prod, (uint32_t)TAB);
                 c = tab[h];
                 if constexpr (SH != 0)
-                    c2 = shr[prod >> (32 - SH)];
+                    c2 = shr[prod >> (32 - SH)] - sh_base; // (another group's entry: far above any position)
             }
             if (act)
             {
@@ -728,8 +729,24 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     const bool listed = MODE == 1 && worklist != nullptr;
     const uint32_t grp_end = listed ? worklist[0] : (MODE == 1 ? grp0 + ngroups : grp0 + blockIdx.x + 1u);
     const uint32_t grp_step = MODE == 1 ? gridDim.x : 1u;
+    [[maybe_unused]] uint32_t sh_gen = 0; // SH: tag of the group's entries in the shared table (upper 16 bits), counting down
     for (uint32_t gidx = blockIdx.x + (listed ? 0u : grp0); gidx < grp_end; gidx += grp_step)
     {
+    if constexpr (SH != 0)
+    {
+        if (sh_gen == 0u)
+        {
+            // (first group of this workgroup, and again after 65535 of them: everything "older than any group")
+            uint4* hv = reinterpret_cast<uint4*>(shr);
+            const uint4 none = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            for (uint32_t v = tid; v < (4u << SH) / 16u; v += 64 * G)
+                hv[v] = none;
+            __syncthreads();
+            sh_gen = 0xFFFFu;
+        }
+        --sh_gen;
+    }
+    [[maybe_unused]] const uint32_t sh_base = sh_gen << 16;
     const uint32_t grp = listed ? worklist[1u + gidx] : gidx;
     uint32_t lo = 0, hi = nblocks;
     while (hi - lo > 1)
@@ -752,6 +769,24 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         const uint4* gv = reinterpret_cast<const uint4*>(g - head);
         const uint32_t nvec = (head + glen + 15u) >> 4;
         uint4* sv = reinterpret_cast<uint4*>(sdata);
+        // SH: the aligned dwords of the group enter the shared table straight from the registers that stage them (whoever holds a
+        // line inserts it: the minimum does not care); entries carry the group's tag in their upper half -- it counts DOWN, so a
+        // newer group's entry is smaller than any older one and the table is never cleared between groups
+        [[maybe_unused]] auto seed_line = [&](const uint4& line, uint32_t v) {
+            if constexpr (SH != 0)
+            {
+                const uint32_t q = 16u * v - head; // position of the line's first byte (line 0: "negative" = above the group)
+                const uint32_t g4[4] = {line.x, line.y, line.z, line.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                {
+                    const uint32_t pk = q + 4u * k;
+                    if (pk < glen)
+                        (void)__hip_atomic_fetch_min(&shr[(g4[k] * 2654435761u) >> (32 - SH)], sh_base | pk, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        };
         if (MODE == 1 && have_pre)
         {
 #pragma unroll
@@ -759,7 +794,10 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             {
                 const uint32_t v = u * 64 * G + tid;
                 if (v < nvec)
+                {
                     sv[v] = pre[u];
+                    seed_line(pre[u], v);
+                }
             }
         }
         else
@@ -777,7 +815,11 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             {
                 const uint32_t v = v0 + u * 64 * G + tid;
                 if (v < nvec)
+                {
                     sv[v] = q[u];
+                    if (MODE == 1)
+                        seed_line(q[u], v);
+                }
             }
         }
         uint4* tv = reinterpret_cast<uint4*>(tab);
@@ -787,13 +829,6 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         for (uint32_t v = 0; v < (TAB * 2 / 16 + 63) / 64; ++v) // TAB * 2 bytes, 64 lanes x 16 bytes per step
             if (v * 64 + lane < TAB * 2 / 16)
                 tv[v * 64 + lane] = e;
-        if constexpr (SH != 0)
-        {
-            uint4* hv = reinterpret_cast<uint4*>(shr);
-            const uint4 none = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            for (uint32_t v = tid; v < (4u << SH) / 16u; v += 64 * G)
-                hv[v] = none;
-        }
         if (tid == 0)
             *flag = 0u;
     }
@@ -893,36 +928,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             // waves' tables above: no sweeps, the far history no longer competes for 2560 slots with the near one ("tokens": a
             // vocabulary of 2 x 1024 keys lost 40 % of its entries), tools/lz4_lane_model.c: mixed 1.89 -> 2.02 (reference 1.94),
             // tokens 1.64 -> 2.13 (1.98), records 2.45 -> 2.53 (2.56) with 17 % fewer probe steps.
-            if (have_unit)
-            {
-                const uint4* s128 = reinterpret_cast<const uint4*>(sdata);
-                const uint32_t l0 = (my_start + head) >> 4, l1 = (my_start + my_len + head + 15u) >> 4; // 16-byte lines that hold my unit
-                for (uint32_t j0 = l0; j0 < l1; j0 += 256)
-                {
-                    uint4 w[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                    {
-                        const uint32_t j = j0 + u * 64 + (uint32_t)lane;
-                        w[u] = j < l1 ? s128[j] : make_uint4(0, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                    {
-                        const uint32_t j = j0 + u * 64 + (uint32_t)lane;
-                        const uint32_t q = 16u * j - head; // position of the line's first byte (may be "negative" in line 0)
-                        const uint32_t g4[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                        {
-                            const uint32_t pk = q + 4u * k;
-                            if (j < l1 && pk >= my_start && pk < my_start + my_len) // (a wrapped "negative" position is above the unit)
-                                (void)__hip_atomic_fetch_min(&shr[(g4[k] * 2654435761u) >> (32 - SH)], pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
-                }
-            }
-            __syncthreads();
+            // (inserted while the group was staged, see seed_line; the barrier behind the staging covers it)
         }
         else if (!(dbg & 1u))
         {
@@ -1009,7 +1015,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             if (emit_unit)
             {
                 K5P(2);
-                lz4_lane_parse<TAB, FMT, SH>(sdata, head, ptab, shr, lane, my_start, my_len, start_limit, end_limit, sub, out, recs,
+                lz4_lane_parse<TAB, FMT, SH>(sdata, head, ptab, shr, sh_base, lane, my_start, my_len, start_limit, end_limit, sub, out, recs,
                                          lane_recs + (uint64_t)unit * (64u * LZ4_LANE_MAXREC), st, dbg K5P_PASS);
             }
         }
