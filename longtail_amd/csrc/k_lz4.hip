@@ -929,6 +929,41 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             // vocabulary of 2 x 1024 keys lost 40 % of its entries), tools/lz4_lane_model.c: mixed 1.89 -> 2.02 (reference 1.94),
             // tokens 1.64 -> 2.13 (1.98), records 2.45 -> 2.53 (2.56) with 17 % fewer probe steps.
             // (inserted while the group was staged, see seed_line; the barrier behind the staging covers it)
+            //
+            // The private table starts with the aligned dwords of the unit BEFORE mine (16 stores per lane, my own table: no barrier): the
+            // shared table answers with the group's EARLIEST occurrence, up to 64 KiB back, and a decoder pays for far offsets -- its
+            // LDS ring holds 8 KiB, sources beyond it are fetched from memory one match at a time (own "records" payloads decoded at
+            // 104 GB/s instead of 155 when half of their offsets were far; the model: 51 % -> 25 % above 6400 at the same ratio).
+            if (have_unit && wave > 0 && !(dbg & 1u))
+            {
+                const uint4* s128 = reinterpret_cast<const uint4*>(sdata);
+                const uint32_t p0 = my_start - sub_bytes;
+                const uint32_t l0 = (p0 + head) >> 4, l1 = (my_start + head + 15u) >> 4; // 16-byte lines that hold the unit before mine
+                for (uint32_t j0 = l0; j0 < l1; j0 += 256)
+                {
+                    uint4 w[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                    {
+                        const uint32_t j = j0 + u * 64 + (uint32_t)lane;
+                        w[u] = j < l1 ? s128[j] : make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                    {
+                        const uint32_t j = j0 + u * 64 + (uint32_t)lane;
+                        const uint32_t q = 16u * j - head; // position of the line's first byte (may be "negative" in line 0)
+                        const uint32_t g4[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                        {
+                            const uint32_t pk = q + 4u * k;
+                            if (j < l1 && pk >= p0 && pk < my_start) // (a wrapped "negative" position is above the unit)
+                                tab[__umulhi(g4[k] * 2654435761u, (uint32_t)TAB)] = (uint16_t)pk;
+                        }
+                    }
+                }
+            }
         }
         else if (!(dbg & 1u))
         {

@@ -55,6 +55,7 @@ struct seq
 };
 
 /* returns the LZ4 block size of `n` bytes at `src` compressed by the modelled parse */
+static uint64_t g_far;
 static uint64_t model_block(const uint8_t* src, uint32_t n, const struct params* P, uint64_t* nseq_out, uint64_t* iters_out)
 {
     const uint32_t U = P->unit, G = P->group, L = P->lanes, sub = U / L;
@@ -247,6 +248,8 @@ static uint64_t model_block(const uint8_t* src, uint32_t n, const struct params*
     {
         const uint32_t lit = seqs[i].start - anchor;
         out += 1 + lenbytes(lit) + lit + 2 + lenbytes(seqs[i].len - 4);
+        if (seqs[i].off > 6400)
+            ++g_far;
         anchor = seqs[i].start + seqs[i].len;
     }
     out += 1 + lenbytes(n - anchor) + (n - anchor);
@@ -280,7 +283,9 @@ int main(int argc, char** argv)
         {4096, 16, 1536, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 8192},
         {4096, 16, 1536, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 16384},
         {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 16, 2, 1, 8192},
-        {4096, 16, 8, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 8192},
+        {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 8192},
+        {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 8192, 0, 2, 1, 8192},
+        {4096, 16, 2048, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 4096},
         {4096, 16, 8, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 16384},
         {4096, 16, 512, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 16384},
         {4096, 16, 1536, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 0, 8192},
@@ -318,6 +323,7 @@ int main(int argc, char** argv)
         for (int k = 0; k < 4; ++k)
         {
             uint64_t in = 0, out = 0, nseq = 0, iters = 0;
+            g_far = 0;
             for (int b = 0; b < nblocks; ++b)
             {
                 for (uint64_t w = 0; w < block / 8; ++w)
@@ -331,7 +337,7 @@ int main(int argc, char** argv)
             printf(" %8.4f", (double)in / (double)out);
             if (k == 0)
                 it_mixed = (double)iters / ((double)in / P->unit);
-            printf("(%4.1f)", (double)iters / ((double)in / P->unit));
+            printf("(%4.1f,%2.0f%%)", (double)iters / ((double)in / P->unit), 100.0 * (double)g_far / (double)(nseq ? nseq : 1));
         }
         printf("\n");
         (void)it_mixed;
