@@ -70,7 +70,8 @@ extern "C" int lthip_ctx_create(int device, void* hip_stream, lthip_ctx** out_ct
     ctx->timing = false;
     memset(ctx->scratch, 0, sizeof ctx->scratch);
     memset(ctx->stage, 0, sizeof ctx->stage);
-    ctx->stage_next = 0;
+    memset(ctx->stage_small, 0, sizeof ctx->stage_small);
+    ctx->stage_next = ctx->stage_small_next = 0;
     ctx->k1_lds_enabled = false;
     ctx->z_last_retry = nullptr;
     ctx->z_last_payloads = 0;
@@ -121,6 +122,13 @@ extern "C" void lthip_ctx_destroy(lthip_ctx* ctx)
         if (ctx->scratch[i])
             (void)hipFree(ctx->scratch[i]);
     for (auto& st : ctx->stage)
+    {
+        if (st.done)
+            (void)hipEventDestroy(st.done);
+        if (st.p)
+            (void)hipHostFree(st.p);
+    }
+    for (auto& st : ctx->stage_small)
     {
         if (st.done)
             (void)hipEventDestroy(st.done);
@@ -248,16 +256,20 @@ int lthip_stage_upload(lthip_ctx* ctx, void* d_dst, const void* h_src, size_t by
 {
     if (bytes == 0)
         return 0;
-    lthip_ctx::Stage& st = ctx->stage[ctx->stage_next++ % (sizeof(ctx->stage) / sizeof(ctx->stage[0]))];
+    const bool small = bytes <= LTHIP_STAGE_SMALL;
+    static LthipEnvInt env_slots{"LTHIP_STAGE_SLOTS"}; // (experiment: 8 = the ring of rounds 1-2)
+    const size_t nsmall = env_slots.get() > 0 && env_slots.get() < 64 ? (size_t)env_slots.get() : sizeof(ctx->stage_small) / sizeof(ctx->stage_small[0]);
+    lthip_ctx::Stage& st = small ? ctx->stage_small[ctx->stage_small_next++ % nsmall]
+                                 : ctx->stage[ctx->stage_next++ % (sizeof(ctx->stage) / sizeof(ctx->stage[0]))];
     if (st.used)
-        LTHIP_CHECK(ctx, hipEventSynchronize(st.done)); // eight uploads ago: long finished in steady state
+        LTHIP_CHECK(ctx, hipEventSynchronize(st.done)); // a ring ago: long finished in steady state
     if (st.cap < bytes)
     {
         if (st.p)
             LTHIP_CHECK(ctx, hipHostFree(st.p));
         st.p = nullptr;
         st.cap = 0;
-        const size_t want = bytes + bytes / 2 + 4096;
+        const size_t want = small ? LTHIP_STAGE_SMALL : bytes + bytes / 2 + 4096;
         LTHIP_CHECK(ctx, hipHostMalloc(&st.p, want, hipHostMallocDefault));
         st.cap = want;
     }

@@ -113,7 +113,12 @@ struct lthip_ctx
         size_t cap;
         hipEvent_t done;
         bool used;
-    } stage[8];
+    };
+    // two rings: uploads of up to LTHIP_STAGE_SMALL bytes (the per-batch tables of the codec phase: with one ring of 8 slots
+    // lthip_ingest_write waited for the codec batch after batch) rotate through 64 slots of that size, larger ones (plans, the
+    // tree's tables) through 8 slots that grow to what they have to hold
+    Stage stage[8], stage_small[64];
+    size_t stage_small_next;
     size_t stage_next;
     bool k1_lds_enabled; // hipFuncAttributeMaxDynamicSharedMemorySize set for K1 on this context's device
     bool k5_lds_enabled; // ... and for the lane-parser flavours of K5
@@ -159,6 +164,7 @@ uint64_t lthip_codec_batch_bytes(); // input bytes per internal codec batch (LTH
 // Host table -> device without stalling the caller: the bytes are copied into one of a ring of pinned staging buffers and
 // queued on `stream`; `h_src` may be freed on return, and the host does not wait for earlier work of the stream (a
 // pageable hipMemcpyAsync + hipStreamSynchronize would wait for every kernel queued before it).
+constexpr size_t LTHIP_STAGE_SMALL = 64u << 10;
 int lthip_stage_upload(lthip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hipStream_t stream);
 
 #define LTHIP_CHECK(ctx, expr)                                                          \
