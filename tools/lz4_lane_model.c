@@ -37,6 +37,7 @@ struct params
     int far_stride;     /* 0 = the far history is not inserted at all */
     int accel;          /* a lane steps 1 + (consecutive misses >> accel) bytes after a miss (0 = always 1) */
     int raw;            /* 1: the table is read again AFTER the step's writes: the surviving entry of a write conflict is a candidate at once */
+    int best2;          /* 1: when the private AND the shared candidate verify, the one with the longer match is taken (a deeper search) */
     uint32_t shared;    /* > 0: slots of a table shared by the group's waves that keeps the EARLIEST aligned occurrence of a key (looked at when the private table has nothing) */
 };
 
@@ -183,6 +184,20 @@ static uint64_t model_block(const uint8_t* src, uint32_t n, const struct params*
                         c = cand2[l];
                     if (P->shared && !(c != EMPTY && c < p[l] && p[l] - c <= 65535 && rd32(src + c) == vv[l]))
                         c = shared[hidx(vv[l] ^ 0x9E3779B9u, P->shared)];
+                    else if (P->shared && P->best2)
+                    {
+                        const uint32_t c2 = shared[hidx(vv[l] ^ 0x9E3779B9u, P->shared)];
+                        if (c2 != EMPTY && c2 < p[l] && c2 != c && rd32(src + c2) == vv[l])
+                        {
+                            uint32_t m1 = 4, m2 = 4;
+                            while (p[l] + m1 < end_limit && src[p[l] + m1] == src[c + m1])
+                                ++m1;
+                            while (p[l] + m2 < end_limit && src[p[l] + m2] == src[c2 + m2])
+                                ++m2;
+                            if (m2 > m1)
+                                c = c2;
+                        }
+                    }
                     if (c != EMPTY && c < p[l] && p[l] - c <= 65535 && rd32(src + c) == vv[l])
                     {
                         uint32_t s = p[l], cs = c, ml = 4;
@@ -276,19 +291,12 @@ int main(int argc, char** argv)
     uint8_t* buf = (uint8_t*)malloc(block);
     uint8_t* dst = (uint8_t*)malloc(lto_lz4_bound(block));
     struct params variants[] = {
-        /* unit group tab lanes cross seed inm back hist trim ways policy maxrec near far accel raw */
-        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 16, 2, 1, 0},
-        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 16, 2, 1, 8192},
-        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 16, 2, 1, 16384},
-        {4096, 16, 1536, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 8192},
-        {4096, 16, 1536, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 16384},
-        {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 16, 2, 1, 8192},
-        {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 8192},
-        {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 8192, 0, 2, 1, 8192},
-        {4096, 16, 2048, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 4096},
-        {4096, 16, 8, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 16384},
-        {4096, 16, 512, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 16384},
-        {4096, 16, 1536, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 0, 8192},
+        /* unit group tab lanes cross seed inm back hist trim ways policy maxrec near far accel raw best2 shared */
+        {4096, 16, 2560, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 16384, 16, 2, 1, 0, 0},
+        {4096, 16, 1536, 64, 1, 0, 0, 1, 0, 0, 1, 1, 8, 0, 0, 2, 1, 0, 8192},
+        {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 0, 8192},
+        {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 1, 8192},
+        {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 2, 1, 8, 4096, 0, 2, 1, 1, 8192},
     };
     printf("%-58s", "variant (unit group tab lanes cross seed inm back hist trim)");
     for (int k = 0; k < 4; ++k)
