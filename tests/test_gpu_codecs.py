@@ -758,3 +758,20 @@ def test_origin_execution_is_the_chained_execution(gpu, oracle, ref, monkeypatch
     for key, outs in results.items():
         for i, (o, r) in enumerate(zip(outs, raws)):
             assert o is not None and len(o) == len(r) and (o == r).all(), (key, i)
+
+
+@pytest.mark.gpu
+def test_lane_parser_shared_table_tag_runs_out(gpu, oracle, monkeypatch):
+    """The lane parser's shared history table is never cleared between the groups of a workgroup: entries carry a group tag that
+    counts down from 0xFFFF and the table is cleared when it runs out (after 65535 groups = 4 GiB per workgroup).  LTHIP_LZ4_DBG bit 26
+    makes it run out every third group: same bytes as without, and they decode."""
+    # (one persistent workgroup per CU: more than 3 x 256 groups of 64 KiB with redundancy, so that every workgroup sees a fourth group)
+    raws = [oracle.synth(24 << 20, 70 + k, k) for k in (1, 11, 12)] + [oracle.synth((8 << 20) + 12345, 9, 11)]
+    plain, _ = gpu_lz4(gpu, raws)
+    monkeypatch.setenv("LTHIP_LZ4_DBG", str(1 << 26))
+    short, _ = gpu_lz4(gpu, raws)
+    monkeypatch.delenv("LTHIP_LZ4_DBG")
+    for a, b, r in zip(plain, short, raws):
+        assert len(a) == len(b) and (a == b).all()
+        n, out = oracle.lz4_decompress(b, len(r))
+        assert n == len(r) and (out[:n] == r).all()
