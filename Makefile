@@ -13,7 +13,7 @@ LIB     := longtail_amd/liblongtail_hip.so
 HIP_SRC := $(CSRC)/lthip_ctx.hip $(CSRC)/k_buzhash.hip $(CSRC)/k_blake3.hip $(CSRC)/k_lz4.hip $(CSRC)/k_lz4_decode.hip $(CSRC)/k_zstd.hip \
            $(CSRC)/k_dedup.hip $(CSRC)/k_gather.hip $(CSRC)/k_synth.hip $(CSRC)/version_index.hip $(CSRC)/ingest.hip $(CSRC)/comm.hip
 C_SRC   := $(CSRC)/plugin/plugin_common.c $(CSRC)/plugin/plugin_chunker.c $(CSRC)/plugin/plugin_hash.c \
-           $(CSRC)/plugin/plugin_codec.c $(CSRC)/plugin/plugin_batch.c $(CSRC)/plugin/build_id.c $(CSRC)/plugin/partition.c
+           $(CSRC)/plugin/plugin_codec.c $(CSRC)/plugin/plugin_codec_batch.c $(CSRC)/plugin/plugin_batch.c $(CSRC)/plugin/build_id.c $(CSRC)/plugin/partition.c
 HIP_OBJ := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(HIP_SRC))
 C_OBJ   := $(patsubst $(CSRC)/plugin/%.c,$(OBJDIR)/%.o,$(C_SRC))
 

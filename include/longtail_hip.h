@@ -80,6 +80,8 @@ LTHIP_EXPORT uint64_t Longtail_Hip_PinnedBytes(void);
 /* Diagnostics of the small-window batcher (plugin_batch.c): GPU submissions made and windows carried by them since the library
  * was loaded; windows / batches = how many chunkers shared a submission on average. */
 LTHIP_EXPORT void Longtail_Hip_BatchStats(uint64_t* out_batches, uint64_t* out_windows);
+/* ... and of the codec objects: submissions of the dispatcher that runs concurrent Compress / Decompress calls together, blocks in them */
+LTHIP_EXPORT void Longtail_Hip_CodecBatchStats(uint64_t* out_submissions, uint64_t* out_blocks);
 /* ... and of its content-hash memo: digest arrays remembered, HashBuffer calls answered from them */
 LTHIP_EXPORT void Longtail_Hip_MemoStats(uint64_t* out_puts, uint64_t* out_hits);
 

@@ -25,13 +25,62 @@ struct HipCodecAPI
     int codec;
 };
 
-static void HipCodec_Dispose(struct Longtail_API* api) { ltp_free(api); }
+static pthread_mutex_t g_codec_lock = PTHREAD_MUTEX_INITIALIZER;
+static int g_codec_live;
+
+static void HipCodec_Dispose(struct Longtail_API* api)
+{
+    ltp_free(api);
+    pthread_mutex_lock(&g_codec_lock);
+    const int last = --g_codec_live == 0;
+    pthread_mutex_unlock(&g_codec_lock);
+    if (last)
+        ltp_codec_batch_shutdown(); /* the dispatcher thread and its context go with the last CompressionAPI */
+}
 
 static size_t HipCodec_GetMaxCompressedSize(struct Longtail_CompressionAPI* compression_api, uint32_t settings_id, size_t size)
 {
     (void)settings_id;
     struct HipCodecAPI* a = (struct HipCodecAPI*)compression_api;
     return a->codec == CODEC_LZ4 ? lthip_lz4_bound(size) : lthip_zstd_bound(size);
+}
+
+static int codec_batching(void)
+{
+    static int v = -1;
+    if (v < 0)
+    {
+        const char* e = getenv("LONGTAIL_HIP_CODEC_BATCH");
+        v = !(e && e[0] == '0');
+    }
+    return v;
+}
+
+/* what the codec reported for my block -> the reference wrappers' error codes, the payload into the caller's buffer */
+static int fetch_payload(struct ltp_thread_state* ts, int codec, int decompress, uint32_t produced, char* dst, size_t cap, size_t* out_n)
+{
+    if (decompress)
+    {
+        if (produced == 0xFFFFFFFFu)
+            return codec == CODEC_ZSTD ? EINVAL : EBADF; /* longtail_lz4.c:95-99; longtail_zstd.c:168-172 */
+    }
+    else if (produced == 0)
+        return ENOMEM; /* longtail_lz4.c:70-74 */
+    if (produced > cap)
+        return EIO;
+    int err = 0;
+    if (produced)
+    {
+        uint8_t* stage = (uint8_t*)ts->h_pin.p + 64;
+        err = lthip_copy_d2h(ts->ctx, stage, ts->d_out.p, produced);
+        if (!err)
+            err = lthip_ctx_sync(ts->ctx);
+        if (!err)
+            memcpy(dst, stage, produced);
+    }
+    if (!err)
+        *out_n = produced;
+    return err;
 }
 
 /* One block through the bulk API: host -> pinned staging -> device -> kernels -> pinned staging -> host.  The caller's buffers
@@ -66,6 +115,18 @@ static int run_block(int codec, int decompress, const char* src, char* dst, size
     }
     const uint64_t zero = 0;
     const uint32_t sz = (uint32_t)n, dcap = (uint32_t)cap;
+    if (codec_batching())
+    {
+        /* my block is on the device (my stream, synchronised): through the codec together with the other threads' blocks */
+        uint32_t produced = 0;
+        if (n)
+            err = lthip_ctx_sync(ctx);
+        if (!err)
+            err = ltp_codec_batch(codec, decompress, ts->d_in.p, sz, ts->d_out.p, dcap, &produced);
+        if (err)
+            return err;
+        return fetch_payload(ts, codec, decompress, produced, dst, cap, out_n);
+    }
     if (decompress && codec == CODEC_ZSTD)
         err = lthip_zstd_decompress_blocks(ctx, ts->d_in.p, 1, &zero, &sz, ts->d_out.p, &zero, &dcap, (uint32_t*)ts->d_aux.p);
     else if (decompress)
@@ -81,27 +142,7 @@ static int run_block(int codec, int decompress, const char* src, char* dst, size
         err = lthip_ctx_sync(ctx); /* the input staging is free again from here on */
     if (err)
         return err;
-    const uint32_t produced = *h_size;
-    if (decompress)
-    {
-        if (produced == 0xFFFFFFFFu)
-            return codec == CODEC_ZSTD ? EINVAL : EBADF; /* longtail_lz4.c:95-99; longtail_zstd.c:168-172 */
-    }
-    else if (produced == 0)
-        return ENOMEM; /* longtail_lz4.c:70-74 */
-    if (produced > cap)
-        return EIO;
-    if (produced)
-    {
-        err = lthip_copy_d2h(ctx, stage, ts->d_out.p, produced);
-        if (!err)
-            err = lthip_ctx_sync(ctx);
-        if (!err)
-            memcpy(dst, stage, produced);
-    }
-    if (!err)
-        *out_n = produced;
-    return err;
+    return fetch_payload(ts, codec, decompress, *h_size, dst, cap, out_n);
 }
 
 static int HipCodec_Compress(struct Longtail_CompressionAPI* compression_api, uint32_t settings_id, const char* uncompressed,
@@ -139,6 +180,9 @@ static struct Longtail_CompressionAPI* make_codec(int codec)
     a->api.Compress = HipCodec_Compress;
     a->api.Decompress = HipCodec_Decompress;
     a->codec = codec;
+    pthread_mutex_lock(&g_codec_lock);
+    ++g_codec_live;
+    pthread_mutex_unlock(&g_codec_lock);
     return &a->api;
 }
 

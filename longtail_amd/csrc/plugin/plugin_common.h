@@ -97,6 +97,11 @@ void ltp_batch_shutdown(void);
 /* content-hash memo of the batcher: 1 + the digest when `data` is byte for byte a digest array whose BLAKE3 the GPU has computed */
 int ltp_memo_get(const void* data, uint32_t length, uint64_t* out_hash);
 
+/* ---- plugin_codec_batch.c: one block (on the device, in the calling thread's buffers) through codec (0 LZ4, 1 zstd) together with the
+ * blocks other threads have queued; *produced as the bulk entry points report it ---- */
+int ltp_codec_batch(int codec, int decompress, const void* d_in, uint32_t n, void* d_out, uint32_t cap, uint32_t* produced);
+void ltp_codec_batch_shutdown(void);
+
 /* ---- error latch: void / value-returning entry points of the plugin structs (HashAPI.Hash, EndContext) cannot report failure;
  * the first errno of such a call on a thread is kept until read.  Exported as Longtail_Hip_GetLastError(). ---- */
 void ltp_latch_error(int err);

@@ -57,6 +57,10 @@ if index_only:
 for rep in range(2):
     res_h = r.ingest_roundtrip(files, 65536, 8 << 20, 1024, tag, workers, chunker, hasher, codec_api)
     res_c = r.ingest_roundtrip(files, 65536, 8 << 20, 1024, tag, workers)
+cb = (C.c_uint64 * 2)()
+d.Longtail_Hip_CodecBatchStats(C.byref(cb, 0), C.byref(cb, 8))
+if cb[0]:
+    print(f"codec dispatcher: {cb[1]} blocks in {cb[0]} submissions ({cb[1] / cb[0]:.1f} per submission)")
 for name, res in (("HIP plugins", res_h), ("reference CPU plugins", res_c)):
     s = res["seconds_index"] + res["seconds_write"]
     print(f"UpSync (index + WriteContent, restore verified) {name}: err {res['err']}, index {res['seconds_index']:.2f} s, write {res['seconds_write']:.2f} s "
