@@ -922,9 +922,9 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         if constexpr (SH != 0)
         {
             // History, second take (round 3): ONE table for the group that keeps the EARLIEST position of every aligned dword's hash
-            // (LDS atomic minimum, every wave inserts its own unit: 16 per lane) -- whatever a lane probes, every occurrence but the
-            // group's first finds the first one, in whichever unit it lies; the private tables (1536 entries now) hold only what the
-            // wave's own parse inserts and give the nearer candidate when they have one.  Against the prefix maximum over the
+            // (LDS atomic minimum; the dwords are inserted by whoever stages them, see seed_line) -- whatever a lane probes, every occurrence but the
+            // group's first finds the first one, in whichever unit it lies; the private tables (1536 entries now) hold the unit before
+            // (below) and what the wave's own parse inserts, and give the nearer candidate when they have one.  Against the prefix maximum over the
             // waves' tables above: no sweeps, the far history no longer competes for 2560 slots with the near one ("tokens": a
             // vocabulary of 2 x 1024 keys lost 40 % of its entries), tools/lz4_lane_model.c: mixed 1.89 -> 2.02 (reference 1.94),
             // tokens 1.64 -> 2.13 (1.98), records 2.45 -> 2.53 (2.56) with 17 % fewer probe steps.
