@@ -121,10 +121,12 @@ for rnd in range(12):
         for dbg in (None, "1"):
             if dbg:
                 os.environ["LTHIP_ZSTD_DBG"] = dbg
+            ctx.lib.dll.lthip_debug_reload_env()  # (the library caches its switches)
             back = torch.zeros(btot + 64, dtype=torch.uint8, device="cuda")
             ds = u32(ctx.zstd_decompress_blocks(fdev, foffs, [len(f) for f in frames], back, b_offs, fcaps))
             outs.append((ds.copy(), back.cpu().numpy()))
             os.environ.pop("LTHIP_ZSTD_DBG", None)
+        ctx.lib.dll.lthip_debug_reload_env()
         (fs, fb), (ss, sb) = outs
         for i in range(len(frames)):
             # sub-block frames the lane-parallel decoder declines go to the serial one: same verdict.  One-block pieces are decoded
