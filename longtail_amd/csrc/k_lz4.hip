@@ -384,7 +384,10 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
                 // everyone has written: when several lanes insert the same slot in this step the entry that survives (the lowest
                 // position: lanes are mapped to sub-units in reverse) is a candidate for the others at once
                 tab[h] = (uint16_t)p;
-                if (!(dbg & 512u))
+                // (with the group's shared table behind it -- which holds every aligned position, this unit's too -- the second read
+                // finds next to nothing the first candidates do not: off there unless LTHIP_LZ4_DBG bit 28 asks for it; mixed 2.0976 ->
+                // 2.0960, lines 19.86 -> 19.33, 2-8 % of the kernel's time)
+                if (SH != 0 ? (dbg & (1u << 28)) != 0u : !(dbg & 512u))
                 {
                     uint32_t hr = h;
                     asm volatile("" : "+v"(hr)); // the compiler must not know that this is the slot just written (it would forward the store)
