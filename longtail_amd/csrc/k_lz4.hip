@@ -350,6 +350,11 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
     uint32_t nmiss = 0; // consecutive misses of this lane: it steps 1 + nmiss / 4 bytes (the reference accelerates the same way,
                         // lz4.c:1044-1053, only 16 times slower; tools/lz4_lane_model.c: half the iterations for 0.3 % of the ratio)
     const uint32_t ashift = (dbg >> 16) & 7u; // 0: dense, then aligned (the default); n: step 1 + misses >> n
+    const uint32_t dense = 4u >> ((dbg >> 29) & 3u); // one-byte steps before the aligned ones (LTHIP_LZ4_DBG bits 29-30: 4, 2, 1, 0)
+    // (The four one-byte steps are there for repeats whose distance is not a multiple of 4.  On data made of aligned structures they
+    // are wasted -- 0 instead of 4: 8-12 % of the kernel's time on the synthetic kinds -- and on text (tools/text_ratio_probe.py: words of
+    // 3..11 bytes) 0 costs 5 % of the ratio.  A rule that drops to one step while a wave's hits all have distances that are multiples
+    // of 4 was built: text unchanged, records / tokens 5 % faster, the mixed tree of bench.py 0.2 %: not kept.)
     uint64_t* myrecs = lrecs + (uint32_t)sidx * LZ4_LANE_MAXREC;
 
     // A verified hit WAITS (the lane keeps its position and candidate, `pend`) until at least `wait_for` lanes hold one or nobody can
@@ -422,7 +427,7 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
                 if (ashift)
                     p += 1u + (nmiss >> ashift);
                 else
-                    p = nmiss < 4u ? p + 1u : (((p + head) | 3u) + 1u - head);
+                    p = nmiss < dense ? p + 1u : (((p + head) | 3u) + 1u - head);
                 ++nmiss;
             }
         }
