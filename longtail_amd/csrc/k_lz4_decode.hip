@@ -1564,27 +1564,59 @@ __global__ __launch_bounds__(64) void k_lz4_pd_units(const uint8_t* __restrict__
 // the serial decoder's (lz4.c:1979-2250), made with the true positions by the unit that holds the sequence's end, as in
 // lz4_decode_one<UNIT>.
 // ---------------------------------------------------------------------------------------------------
+// BYTES (round 3, last part): the same walk for EVERY unit, executing bytes (zo_batch_bytes) straight into the block's output -- the
+// unit decoder of the block-parallel path since then (k_lz4_pd_units / lz4_decode_one<UNIT> stays as LTHIP_LZ4_PX=0): a unit that meets
+// a source below its start stops and is marked for the origin pass, which is this kernel with BYTES = false.
+template <bool BYTES>
 __global__ __launch_bounds__(64) void k_lz4_po_trace(const uint8_t* __restrict__ src, const PdBlock* __restrict__ blocks, uint32_t nblocks,
                                                     uint32_t unit0, const PdTile* __restrict__ tiles, const uint32_t* __restrict__ tile_op,
                                                     const uint32_t* __restrict__ unit_tile, PdState* __restrict__ state,
-                                                    uint32_t* __restrict__ unit_mode, uint32_t* __restrict__ org_arena)
+                                                    uint32_t* __restrict__ unit_mode, uint32_t* __restrict__ org_arena, uint8_t* __restrict__ dst,
+                                                    const uint32_t* __restrict__ first, uint32_t* __restrict__ counters)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN];
     __shared__ uint32_t s_ia[64], s_om[64];
     __shared__ uint32_t s_ll[96], s_lp[96], s_ml[96], s_off[96], s_op[96]; // the batch being collected
     const uint32_t u = unit0 + blockIdx.x;
-    if (unit_mode[u] != 1u)
+    if (!BYTES && unit_mode[u] != 1u)
         return;
     const int lane = threadIdx.x;
     const uint32_t b = pd_block_of(blocks, nblocks, u, false);
     const PdBlock blk = blocks[b];
     const PdState st = state[b];
     const uint32_t k = u - blk.unit_base;
+    if (BYTES && k >= st.nunits)
+        return;
+    if constexpr (BYTES)
+    {
+        const uint32_t f_pos = first[3 * b + 1], f_len = first[3 * b + 2];
+        if (k + 1u < st.nunits && (uint64_t)(k + 1u) * PD_UNIT <= f_len)
+        {
+            // the whole unit lies inside the literals of the block's first sequence (incompressible data is ONE sequence): a plain copy;
+            // the sequence itself is checked by the unit in which it ends
+            typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+            const uint8_t* from = src + blk.src_off + f_pos + (uint64_t)k * PD_UNIT;
+            uint8_t* to = dst + blk.dst_off + (uint64_t)k * PD_UNIT;
+            for (uint32_t v0 = 0; v0 < PD_UNIT / 16u; v0 += 256u)
+            {
+                u32x4_a1 q[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    q[w] = *reinterpret_cast<const u32x4_a1*>(from + 16u * (v0 + (uint32_t)(w * 64 + lane)));
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    *reinterpret_cast<u32x4_a1*>(to + 16u * (v0 + (uint32_t)(w * 64 + lane))) = q[w];
+            }
+            return;
+        }
+    }
     const bool last = k + 1u == st.nunits;
     const int32_t n = (int32_t)blk.size;
     const int64_t cap = blk.dst_cap;
     const int64_t lo = (int64_t)k * PD_UNIT, hi = last ? cap : lo + (int64_t)PD_UNIT;
-    uint32_t* org = org_arena + (uint64_t)blockIdx.x * PD_UNIT; // origin of output byte lo + q: org[q]
+    uint32_t* org = BYTES ? nullptr : org_arena + (uint64_t)blockIdx.x * PD_UNIT; // origin of output byte lo + q: org[q]
+    uint8_t* out = BYTES ? dst + blk.dst_off + lo : nullptr;                      // ... or the byte itself
+    bool given_up = false; // BYTES: a source below lo
     const uint32_t j0 = unit_tile[u];
     int64_t ip = k == 0u ? 0 : (int64_t)tiles[blk.tile_base + j0].entry;
     int64_t op = k == 0u ? 0 : (int64_t)tile_op[blk.tile_base + j0];
@@ -1614,13 +1646,21 @@ __global__ __launch_bounds__(64) void k_lz4_po_trace(const uint8_t* __restrict__
         const uint32_t pos = (uint32_t)((first > lo ? first : lo) - lo);
         const uint32_t i_a = zo_scan_incl(c_ll + c_ml);
         __builtin_amdgcn_wave_barrier();
-        zo_batch(org, (uint32_t)lo, lane, act, c_ll, c_li, c_ml, offv, i_a, pos, s_ia, s_om);
+        if constexpr (BYTES)
+        {
+            if (!zo_batch_bytes(out, src + blk.src_off, lane, act, c_ll, c_li, c_ml, offv, i_a, pos, s_ia, s_om))
+                given_up = true;
+        }
+        else
+            zo_batch(org, (uint32_t)lo, lane, act, c_ll, c_li, c_ml, offv, i_a, pos, s_ia, s_om);
         cnt = 0;
     };
-    while (!bad && !ended && op < hi)
+    while (!bad && !ended && op < hi && !given_up)
     {
         if (cnt > 42u) // (a window holds at most 21 sequences, the slow path adds one)
             run_batch();
+        if (given_up)
+            break;
         if (ip >= n)
         {
             bad = true;
@@ -1745,11 +1785,16 @@ __global__ __launch_bounds__(64) void k_lz4_po_trace(const uint8_t* __restrict__
             ip = next;
         }
     }
-    if (!bad && cnt)
+    if (!bad && cnt && !given_up)
         run_batch();
     if (lane == 0)
     {
-        if (bad)
+        if (BYTES && given_up)
+        {
+            unit_mode[u] = 1u; // a match reaches into the unit before: executed on origins (this kernel again, BYTES = false)
+            atomicAdd(&counters[2], 1u);
+        }
+        else if (bad)
         {
             atomicOr(&state[b].err, 1u);
             unit_mode[u] = 2u; // (nothing to gather)
@@ -1988,7 +2033,13 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     static LthipEnvInt env_wait{"LTHIP_LZ4_PD_WAIT"};
     const bool wait_mode = env_wait.get() > 0;
     uint32_t* d_mode = wait_mode ? nullptr : (uint32_t*)(t8 + o_mode);
-    if (small)
+    static LthipEnvInt env_px{"LTHIP_LZ4_PX"}; // 0: the unit decoder of round 2 (lz4_decode_one<UNIT> through an LDS ring)
+    const bool px = d_mode && env_px.get() != 0;
+    if (px)
+        hipLaunchKernelGGL(k_lz4_po_trace<true>, dim3((uint32_t)nunits), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, nb, 0u,
+                           (const PdTile*)d_tiles, (const uint32_t*)d_top, (const uint32_t*)d_ut, d_state, d_mode, (uint32_t*)nullptr,
+                           (uint8_t*)d_dst, (const uint32_t*)d_first, d_cnt);
+    else if (small)
         hipLaunchKernelGGL(k_lz4_pd_units<int32_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, (uint8_t*)d_dst, d_tiles,
                            d_top, d_ut, d_state, d_done, d_cnt, tk, nobatch, dbg, (const uint32_t*)d_first, d_mode);
     else
@@ -2031,8 +2082,9 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
                     rows_g = hb[g1].nunits_cap > rows_g ? hb[g1].nunits_cap : rows_g;
                     units += hb[g1++].nunits_cap;
                 }
-                hipLaunchKernelGGL(k_lz4_po_trace, dim3((uint32_t)units), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, nb, hb[g0].unit_base,
-                                   (const PdTile*)d_tiles, (const uint32_t*)d_top, (const uint32_t*)d_ut, d_state, d_mode, (uint32_t*)d_org);
+                hipLaunchKernelGGL(k_lz4_po_trace<false>, dim3((uint32_t)units), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, nb, hb[g0].unit_base,
+                                   (const PdTile*)d_tiles, (const uint32_t*)d_top, (const uint32_t*)d_ut, d_state, d_mode, (uint32_t*)d_org,
+                                   (uint8_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
                 LTHIP_LAUNCH_CHECK(ctx);
                 for (uint32_t k = 1; k < rows_g; ++k) // (unit 0 has nothing before it)
                     hipLaunchKernelGGL(k_lz4_po_gather, dim3(PD_UNIT / 4096u, g1 - g0), dim3(256), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, g0, k,

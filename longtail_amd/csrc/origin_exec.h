@@ -165,4 +165,128 @@ __device__ __forceinline__ void zo_batch(uint32_t* __restrict__ org, const uint3
     }
 }
 
+// The same batch executed on BYTES (a piece none of whose matches reaches below its start: payloads of this library's LZ4 encoder, whose
+// matches stay inside 64 KiB groups; units of other payloads that happen not to): out[q] = byte q of the piece, literals copied from
+// `lits` (literal number i = lits[i]), matches from out[] itself -- through memory, like the origins.  Returns false, having written
+// nothing but literals, when a match of the batch reads below 0: the caller gives the piece up (it is then executed on origins).
+__device__ __forceinline__ bool zo_batch_bytes(uint8_t* __restrict__ out, const uint8_t* __restrict__ lits, const int lane, const bool act,
+                                               const uint32_t ll, const uint32_t li, const uint32_t ml, const uint32_t off, const uint32_t i_a,
+                                               const uint32_t pos, uint32_t* s_ia, uint32_t* s_om)
+{
+    typedef uint32_t u32_a1 __attribute__((aligned(1)));
+    typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+    const uint32_t o_l = pos + (i_a - ll - ml), o_m = o_l + ll; // where my literals / my match go
+    const bool has = act && ml != 0u;
+    const int32_t a = (int32_t)o_m - (int32_t)off; // first source byte
+    if (__builtin_amdgcn_ballot_w64(has && a < 0))
+        return false;
+    // ---- literals ----
+    if (act && ll <= 32u)
+    {
+        uint32_t j = 0;
+        for (; j + 4u <= ll; j += 4u)
+            *reinterpret_cast<u32_a1*>(out + o_l + j) = *reinterpret_cast<const u32_a1*>(lits + li + j);
+        for (; j < ll; ++j)
+            out[o_l + j] = lits[li + j];
+    }
+    for (uint64_t big = __builtin_amdgcn_ballot_w64(act && ll > 32u); big; big &= big - 1ull)
+    {
+        const int u = __builtin_ctzll(big);
+        const uint32_t nn = (uint32_t)__builtin_amdgcn_readlane((int)ll, u), from = (uint32_t)__builtin_amdgcn_readlane((int)li, u),
+                       to = (uint32_t)__builtin_amdgcn_readlane((int)o_l, u);
+        uint32_t j = 16u * (uint32_t)lane;
+        for (; j + 16u <= nn; j += 1024u)
+            *reinterpret_cast<u32x4_a1*>(out + to + j) = *reinterpret_cast<const u32x4_a1*>(lits + from + j);
+        if (j < nn) // (the run's last vector: byte by byte)
+            for (uint32_t k = j; k < nn && k < j + 16u; ++k)
+                out[to + k] = lits[from + k];
+    }
+    // ---- matches: the rounds of zo_batch ----
+    const uint32_t span = ml < off ? ml : off;
+    uint64_t dep = 0;
+    s_ia[lane] = pos + i_a;
+    s_om[lane] = o_m;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (has && a + (int32_t)span > (int32_t)pos)
+    {
+        const uint32_t xa = a > (int32_t)pos ? (uint32_t)a : pos, xb = (uint32_t)(a + (int32_t)span) - 1u;
+        uint32_t ja = 0, jb = 0; // smallest j with s_ia[j] > x
+#pragma unroll
+        for (int st = 32; st; st >>= 1)
+        {
+            if (s_ia[ja + st - 1] <= xa)
+                ja += st;
+            if (s_ia[jb + st - 1] <= xb)
+                jb += st;
+        }
+        if (jb > (uint32_t)lane)
+            jb = (uint32_t)lane;
+        int32_t hi = (int32_t)jb;
+        if (jb == (uint32_t)lane || xb < s_om[jb])
+            hi -= 1; // my own sequence / only the literals of that one
+        if (hi >= (int32_t)ja)
+            dep = ((hi >= 63 ? 0ull : (1ull << (hi + 1))) - 1ull) & ~((1ull << ja) - 1ull);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool own = has && ml <= 64u;
+    const uint64_t ownm = __builtin_amdgcn_ballot_w64(own);
+    uint64_t pend = __builtin_amdgcn_ballot_w64(has);
+    zo_sync(); // (the literals)
+    while (pend)
+    {
+        const bool ready = own && ((pend >> lane) & 1ull) && !(pend & dep);
+        if (ready)
+        {
+            const uint8_t* sp = out + a;
+            uint8_t* dp = out + o_m;
+            uint32_t j = 0;
+            if (off >= ml)
+            {
+                for (; j + 16u <= ml; j += 16u)
+                    *reinterpret_cast<u32x4_a1*>(dp + j) = *reinterpret_cast<const u32x4_a1*>(sp + j);
+                for (; j + 4u <= ml; j += 4u)
+                    *reinterpret_cast<u32_a1*>(dp + j) = *reinterpret_cast<const u32_a1*>(sp + j);
+                for (; j < ml; ++j)
+                    dp[j] = sp[j];
+            }
+            else
+            {
+                // overlapping: byte j = seed byte j mod off (the seed lies before the match: final)
+                uint32_t m = 0;
+                for (; j < ml; ++j)
+                {
+                    dp[j] = sp[m];
+                    m = m + 1u == off ? 0u : m + 1u;
+                }
+            }
+        }
+        const uint64_t readym = __builtin_amdgcn_ballot_w64(ready);
+        const int first = __builtin_ctzll(pend);
+        if (!((ownm >> first) & 1ull))
+        {
+            // a long match whose turn has come (nothing pending below it): the whole wave
+            const uint32_t gm = (uint32_t)__builtin_amdgcn_readlane((int)ml, first), go = (uint32_t)__builtin_amdgcn_readlane((int)off, first),
+                           gd = (uint32_t)__builtin_amdgcn_readlane((int)o_m, first);
+            const uint8_t* sp = out + (gd - go);
+            if (go >= gm)
+            {
+                uint32_t j = 16u * (uint32_t)lane;
+                for (; j + 16u <= gm; j += 1024u)
+                    *reinterpret_cast<u32x4_a1*>(out + gd + j) = *reinterpret_cast<const u32x4_a1*>(sp + j);
+                if (j < gm)
+                    for (uint32_t k = j; k < gm && k < j + 16u; ++k)
+                        out[gd + k] = sp[k];
+            }
+            else
+                for (uint32_t j = lane; j < gm; j += 64)
+                    out[gd + j] = sp[j % go];
+            pend &= ~(1ull << first);
+        }
+        pend &= ~readym;
+        zo_sync();
+    }
+    return true;
+}
+
 #endif
