@@ -2745,10 +2745,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                      const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
                                                      uint8_t* __restrict__ dst, const uint8_t* __restrict__ lit_scratch,
                                                      const uint64_t* __restrict__ tables, const ZPrep* __restrict__ prep,
-                                                     uint32_t* __restrict__ status_out, uint32_t* __restrict__ retry)
+                                                     uint32_t* __restrict__ status_out, uint32_t* __restrict__ retry, uint32_t px)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZX_RING];
     __shared__ __attribute__((aligned(16))) uint8_t s_lit[ZX_LIT];
+    __shared__ uint32_t s_ia[64], s_om[64]; // (px: the batch's prefix sums, zo_batch_bytes)
     const uint32_t i = item0 + blockIdx.x;
     if (i >= item1 || i >= *item_count)
         return;
@@ -2822,6 +2823,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     unsigned long long t_prof = wall_clock64();
     (void)t_prof;
 #endif
+    if (RECS && px == 1u)
+    {
+        // Which executor?  The ring (zx_batch) copies a match of more than 20 bytes whose source has left its 8 KiB with the whole wave,
+        // one such match at a time; bytes through memory (zo_batch_bytes) do not care where a source lies but pay a memory round trip
+        // per dependency round.  A piece with many such matches (records: the group's first occurrence of a 24-byte field, up to
+        // 64 KiB back) goes through memory -- 502 against 295 GB/s --, the others through the ring (lines 565 against 328, tokens 223
+        // against 195): one pass over the records decides.
+        uint32_t far_long = 0;
+        for (uint32_t s0 = (uint32_t)lane; s0 < pr.nbseq; s0 += 64u)
+        {
+            const uint64_t r = recs[s0];
+            far_long += ((uint32_t)(r >> 40) > ZX_RING_SAFE + 3u && ((uint32_t)(r >> 20) & 0xFFFFFu) > 20u) ? 1u : 0u;
+        }
+        far_long = zx_scan_incl(far_long);
+        far_long = (uint32_t)__builtin_amdgcn_readlane((int)far_long, 63);
+        px = far_long * 8u > pr.nbseq ? 2u : 0u;
+    }
     for (uint32_t s0 = 0; s0 < pr.nbseq && !bad; s0 += 64u)
     {
         const uint32_t cnt = pr.nbseq - s0 < 64u ? pr.nbseq - s0 : 64u;
@@ -2895,7 +2913,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             bad = true; // the bit-stream must be consumed exactly
             break;
         }
-        zx_batch(zx, s_ring, s_lit, lane, cnt, r_ll, r_ml, r_off, litpos, produced, pr.nlit, pr.expect, bad);
+        if (RECS && px)
+        {
+            // executed on bytes through memory (origin_exec.h) instead of through the LDS ring: the serial decoder's checks for the 64
+            // sequences at once, then literals and matches in dependency rounds straight into the piece's output
+            const bool act = (uint32_t)lane < cnt;
+            const uint32_t ll = act ? r_ll : 0u, ml = act ? r_ml : 0u, off = r_off - 3u;
+            const uint32_t i_l = zx_scan_incl(ll), i_a = zx_scan_incl(ll + ml);
+            const uint32_t batch_ll = (uint32_t)__builtin_amdgcn_readlane((int)i_l, 63), batch_adv = (uint32_t)__builtin_amdgcn_readlane((int)i_a, 63);
+            const bool wrong = act && (r_off <= 3u || ll > 131072u || ml > 131075u || litpos + i_l > pr.nlit || produced + i_a > pr.expect ||
+                                       off > produced + i_a - ml);
+            if (__builtin_amdgcn_ballot_w64(wrong) ||
+                !zo_batch_bytes(out, lits, lane, act, ll, litpos + (i_l - ll), ml, off, i_a, produced, s_ia, s_om))
+            {
+                bad = true;
+                break;
+            }
+            litpos += batch_ll;
+            produced += batch_adv;
+        }
+        else
+            zx_batch(zx, s_ring, s_lit, lane, cnt, r_ll, r_ml, r_off, litpos, produced, pr.nlit, pr.expect, bad);
         if (bad)
             break;
     }
@@ -2905,6 +2943,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint32_t rest = pr.nlit - litpos;
         if (rest != pr.expect - produced)
             bad = true;
+        else if (RECS && px)
+        {
+            typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+            uint32_t j = 16u * (uint32_t)lane;
+            for (; j + 16u <= rest; j += 1024u)
+                *reinterpret_cast<u32x4_a1*>(out + produced + j) = *reinterpret_cast<const u32x4_a1*>(lits + litpos + j);
+            if (j < rest)
+                for (uint32_t k = j; k < rest && k < j + 16u; ++k)
+                    out[produced + k] = lits[litpos + k];
+        }
         else
         {
             zx.copy_lits(litpos, rest);
@@ -3524,7 +3572,10 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
     // 8 single-wave workgroups per CU (12 would be resident at 143 VGPRs, measured slower: 190 vs 160 ms for 512 blocks)
     uint32_t nwg = nitems < (uint64_t)ncu * 8u ? (uint32_t)nitems : (uint32_t)ncu * 8u;
-    static LthipEnvInt env_nwg{"LTHIP_ZSTD_NWG"}, env_dbg{"LTHIP_ZSTD_DBG"}, env_ablate{"LTHIP_ZSTD_ABLATE"};
+    static LthipEnvInt env_nwg{"LTHIP_ZSTD_NWG"}, env_dbg{"LTHIP_ZSTD_DBG"}, env_ablate{"LTHIP_ZSTD_ABLATE"}, env_zpx{"LTHIP_ZSTD_PX"};
+    // the sub-block pieces' sequences: 1 (default) = the kernel chooses per piece between the LDS ring (zx_batch) and bytes through memory
+    // (zo_batch_bytes), 0 = always the ring (round 2), 2 = always through memory
+    const uint32_t zpx = env_zpx.get() < 0 ? 1u : (uint32_t)env_zpx.get();
     if (env_nwg.get() >= 0)
         nwg = (uint32_t)env_nwg.get();
     void *d_blocks, *d_lits, *d_items;
@@ -3604,7 +3655,7 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
                 LTHIP_LAUNCH_CHECK(ctx);
                 hipLaunchKernelGGL(k_zstd_execute<false>, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                                    (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, (const uint8_t*)d_plits,
-                                   (const uint64_t*)d_tabs, (const ZPrep*)d_prep, &d_prep->status, d_retry);
+                                   (const uint64_t*)d_tabs, (const ZPrep*)d_prep, &d_prep->status, d_retry, 0u);
                 LTHIP_LAUNCH_CHECK(ctx);
             }
             hipLaunchKernelGGL(k_zstd_sub_entropy, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
@@ -3613,7 +3664,7 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
             LTHIP_LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(k_zstd_execute<true>, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                                (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, (const uint8_t*)d_plits,
-                               (const uint64_t*)d_recs, (const ZPrep*)d_prep, &d_prep->status, d_retry);
+                               (const uint64_t*)d_recs, (const ZPrep*)d_prep, &d_prep->status, d_retry, zpx);
             LTHIP_LAUNCH_CHECK(ctx);
         }
     }

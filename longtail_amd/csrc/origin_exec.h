@@ -102,7 +102,6 @@ __device__ __forceinline__ void zo_batch(uint32_t* __restrict__ org, const uint3
     }
     __builtin_amdgcn_wave_barrier();
     const bool own = has && ml <= 64u;
-    const uint64_t ownm = __builtin_amdgcn_ballot_w64(own);
     uint64_t pend = __builtin_amdgcn_ballot_w64(has);
     zo_sync(); // (the literals)
     while (pend)
@@ -146,21 +145,21 @@ __device__ __forceinline__ void zo_batch(uint32_t* __restrict__ org, const uint3
             }
         }
         const uint64_t readym = __builtin_amdgcn_ballot_w64(ready);
-        const int first = __builtin_ctzll(pend);
-        if (!((ownm >> first) & 1ull))
+        // long matches that read from nothing pending: the whole wave, one after the other (the lowest pending one always qualifies)
+        const uint64_t longm = __builtin_amdgcn_ballot_w64(has && !own && ((pend >> lane) & 1ull) && !(pend & dep));
+        for (uint64_t todo = longm; todo; todo &= todo - 1ull)
         {
-            // a long match whose turn has come (nothing pending below it): the whole wave
-            const uint32_t gm = (uint32_t)__builtin_amdgcn_readlane((int)ml, first), go = (uint32_t)__builtin_amdgcn_readlane((int)off, first),
-                           gd = (uint32_t)__builtin_amdgcn_readlane((int)o_m, first);
+            const int f = __builtin_ctzll(todo);
+            const uint32_t gm = (uint32_t)__builtin_amdgcn_readlane((int)ml, f), go = (uint32_t)__builtin_amdgcn_readlane((int)off, f),
+                           gd = (uint32_t)__builtin_amdgcn_readlane((int)o_m, f);
             const int32_t ga = (int32_t)gd - (int32_t)go;
             for (uint32_t j = lane; j < gm; j += 64)
             {
                 const int32_t sp = ga + (int32_t)(go < gm ? j % go : j);
                 org[gd + j] = sp < 0 ? ZO_FLAG | (uint32_t)((int32_t)start + sp) : org[sp];
             }
-            pend &= ~(1ull << first);
         }
-        pend &= ~readym;
+        pend &= ~(readym | longm);
         zo_sync();
     }
 }
@@ -230,7 +229,6 @@ __device__ __forceinline__ bool zo_batch_bytes(uint8_t* __restrict__ out, const 
     }
     __builtin_amdgcn_wave_barrier();
     const bool own = has && ml <= 64u;
-    const uint64_t ownm = __builtin_amdgcn_ballot_w64(own);
     uint64_t pend = __builtin_amdgcn_ballot_w64(has);
     zo_sync(); // (the literals)
     while (pend)
@@ -262,12 +260,13 @@ __device__ __forceinline__ bool zo_batch_bytes(uint8_t* __restrict__ out, const 
             }
         }
         const uint64_t readym = __builtin_amdgcn_ballot_w64(ready);
-        const int first = __builtin_ctzll(pend);
-        if (!((ownm >> first) & 1ull))
+        // long matches that read from nothing pending: the whole wave, one after the other (the lowest pending one always qualifies)
+        const uint64_t longm = __builtin_amdgcn_ballot_w64(has && !own && ((pend >> lane) & 1ull) && !(pend & dep));
+        for (uint64_t todo = longm; todo; todo &= todo - 1ull)
         {
-            // a long match whose turn has come (nothing pending below it): the whole wave
-            const uint32_t gm = (uint32_t)__builtin_amdgcn_readlane((int)ml, first), go = (uint32_t)__builtin_amdgcn_readlane((int)off, first),
-                           gd = (uint32_t)__builtin_amdgcn_readlane((int)o_m, first);
+            const int f = __builtin_ctzll(todo);
+            const uint32_t gm = (uint32_t)__builtin_amdgcn_readlane((int)ml, f), go = (uint32_t)__builtin_amdgcn_readlane((int)off, f),
+                           gd = (uint32_t)__builtin_amdgcn_readlane((int)o_m, f);
             const uint8_t* sp = out + (gd - go);
             if (go >= gm)
             {
@@ -281,9 +280,8 @@ __device__ __forceinline__ bool zo_batch_bytes(uint8_t* __restrict__ out, const 
             else
                 for (uint32_t j = lane; j < gm; j += 64)
                     out[gd + j] = sp[j % go];
-            pend &= ~(1ull << first);
         }
-        pend &= ~readym;
+        pend &= ~(readym | longm);
         zo_sync();
     }
     return true;
