@@ -192,7 +192,7 @@ class Bench:
         b_off = np.arange(nb, dtype=np.int64) * block_bytes
         b_size = np.full(nb, block_bytes, np.int64)
         out = {"workload": f"{nb} stored blocks of {block_bytes >> 20} MiB of the compressible workload, payloads in HBM", "unit": "GB/s of output",
-               "note": "payloads of this library's encoders; stores written by the reference's: profiles/r03c_decode_rate_ref.txt"}
+               "note": "payloads of this library's encoders; stores written by the reference's: profiles/r03d_decode_rate.txt"}
         for name, comp, dec, bound in (("lz4", ctx.lz4_compress_blocks, ctx.lz4_decompress_blocks, b_size + b_size // 255 + 16),
                                        ("zstd", ctx.zstd_compress_blocks, ctx.zstd_decompress_blocks, b_size + (b_size >> 8) + 64)):
             d_offs = np.concatenate([[0], np.cumsum((bound + 63) // 64 * 64)[:-1]])
