@@ -1568,7 +1568,7 @@ __global__ __launch_bounds__(64) void k_lz4_pd_units(const uint8_t* __restrict__
 // unit decoder of the block-parallel path since then (k_lz4_pd_units / lz4_decode_one<UNIT> stays as LTHIP_LZ4_PX=0): a unit that meets
 // a source below its start stops and is marked for the origin pass, which is this kernel with BYTES = false.
 template <bool BYTES>
-__global__ __launch_bounds__(64) void k_lz4_po_trace(const uint8_t* __restrict__ src, const PdBlock* __restrict__ blocks, uint32_t nblocks,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lz4_po_trace(const uint8_t* __restrict__ src, const PdBlock* __restrict__ blocks, uint32_t nblocks,
                                                     uint32_t unit0, const PdTile* __restrict__ tiles, const uint32_t* __restrict__ tile_op,
                                                     const uint32_t* __restrict__ unit_tile, PdState* __restrict__ state,
                                                     uint32_t* __restrict__ unit_mode, uint32_t* __restrict__ org_arena, uint8_t* __restrict__ dst,
