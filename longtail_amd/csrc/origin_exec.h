@@ -103,10 +103,15 @@ __device__ __forceinline__ void zo_batch(uint32_t* __restrict__ org, const uint3
     __builtin_amdgcn_wave_barrier();
     const bool own = has && ml <= 64u;
     uint64_t pend = __builtin_amdgcn_ballot_w64(has);
-    zo_sync(); // (the literals)
-    while (pend)
+    // Round 0 needs no wait: it takes the matches whose source lies entirely before the batch (final since the last batch's wait) next
+    // to the literal stores; the wait behind it covers both.  A batch without a match that reads from the batch itself -- most of
+    // them -- is one memory round trip, not two.
+    const bool early = has && a + (int32_t)span <= (int32_t)pos;
+    bool round0 = true;
+    do
     {
-        const bool ready = own && ((pend >> lane) & 1ull) && !(pend & dep);
+        const bool free_now = round0 ? early : !(pend & dep);
+        const bool ready = own && ((pend >> lane) & 1ull) && free_now;
         if (ready)
         {
             if (off >= ml)
@@ -146,7 +151,7 @@ __device__ __forceinline__ void zo_batch(uint32_t* __restrict__ org, const uint3
         }
         const uint64_t readym = __builtin_amdgcn_ballot_w64(ready);
         // long matches that read from nothing pending: the whole wave, one after the other (the lowest pending one always qualifies)
-        const uint64_t longm = __builtin_amdgcn_ballot_w64(has && !own && ((pend >> lane) & 1ull) && !(pend & dep));
+        const uint64_t longm = __builtin_amdgcn_ballot_w64(has && !own && ((pend >> lane) & 1ull) && free_now);
         for (uint64_t todo = longm; todo; todo &= todo - 1ull)
         {
             const int f = __builtin_ctzll(todo);
@@ -161,7 +166,8 @@ __device__ __forceinline__ void zo_batch(uint32_t* __restrict__ org, const uint3
         }
         pend &= ~(readym | longm);
         zo_sync();
-    }
+        round0 = false;
+    } while (pend);
 }
 
 // The same batch executed on BYTES (a piece none of whose matches reaches below its start: payloads of this library's LZ4 encoder, whose
@@ -230,10 +236,15 @@ __device__ __forceinline__ bool zo_batch_bytes(uint8_t* __restrict__ out, const 
     __builtin_amdgcn_wave_barrier();
     const bool own = has && ml <= 64u;
     uint64_t pend = __builtin_amdgcn_ballot_w64(has);
-    zo_sync(); // (the literals)
-    while (pend)
+    // Round 0 needs no wait: it takes the matches whose source lies entirely before the batch (final since the last batch's wait) next
+    // to the literal stores; the wait behind it covers both.  A batch without a match that reads from the batch itself -- most of
+    // them -- is one memory round trip, not two.
+    const bool early = has && a + (int32_t)span <= (int32_t)pos;
+    bool round0 = true;
+    do
     {
-        const bool ready = own && ((pend >> lane) & 1ull) && !(pend & dep);
+        const bool free_now = round0 ? early : !(pend & dep);
+        const bool ready = own && ((pend >> lane) & 1ull) && free_now;
         if (ready)
         {
             const uint8_t* sp = out + a;
@@ -261,7 +272,7 @@ __device__ __forceinline__ bool zo_batch_bytes(uint8_t* __restrict__ out, const 
         }
         const uint64_t readym = __builtin_amdgcn_ballot_w64(ready);
         // long matches that read from nothing pending: the whole wave, one after the other (the lowest pending one always qualifies)
-        const uint64_t longm = __builtin_amdgcn_ballot_w64(has && !own && ((pend >> lane) & 1ull) && !(pend & dep));
+        const uint64_t longm = __builtin_amdgcn_ballot_w64(has && !own && ((pend >> lane) & 1ull) && free_now);
         for (uint64_t todo = longm; todo; todo &= todo - 1ull)
         {
             const int f = __builtin_ctzll(todo);
@@ -283,7 +294,8 @@ __device__ __forceinline__ bool zo_batch_bytes(uint8_t* __restrict__ out, const 
         }
         pend &= ~(readym | longm);
         zo_sync();
-    }
+        round0 = false;
+    } while (pend);
     return true;
 }
 
