@@ -21,6 +21,7 @@
 #include "index_kernels.h"
 
 #include <algorithm>
+#include <thread>
 
 namespace
 {
@@ -393,93 +394,117 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
     if (nm)
         LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_mu_hash.p, g->d_mu_hash.p, (size_t)nm * 8, hipMemcpyDeviceToHost, s)); // StoreIndex, read in finish
 
-    // ---- ... then the VersionIndex sections, which the GPU works on while the host packs ----
+    // ---- ... then the VersionIndex sections: the GPU works on them while the host packs -- and so does a second host thread: the
+    // tables of 65 536 assets and the tag column of 2.1 M chunks are 1.2-2.4 ms of host work on the 64 GiB tree, the packing loop
+    // below as much, and neither needs the other (LTHIP_INGEST_VI_THREAD=0: one after the other, rounds 1-2).  The helper is the only
+    // one that touches the context until it is joined. ----
     g->vi_size = 0;
+    int vi_err = 0;
+    std::thread vi_thread;
     if (want_vi)
     {
         const size_t size = lthip_version_index_size(na, unique, n, t->path_data_size);
         g->vi_size = size;
         if (version_index_capacity < size)
             return lthip_fail(ctx, ENOMEM, "lthip_ingest_index", "version index buffer too small");
-        // content hash of every asset = BLAKE3 of its chunk-hash array (:2518-2537); path hashes (:1269-1300)
-        std::vector<uint64_t> h_off(na);
-        std::vector<uint32_t> h_len(na);
-        uint32_t max_len = 0;
-        for (uint32_t a = 0; a < na; ++a)
-        {
-            if ((uint64_t)counts[a] * 8u > 0xFFFFFFFFull)
-                return lthip_fail(ctx, EINVAL, "lthip_ingest_index", "asset with more than 2^29 chunks");
-            h_off[a] = (uint64_t)starts[a] * 8u;
-            h_len[a] = counts[a] * 8u;
-            max_len = std::max(max_len, h_len[a]);
-        }
-        if (na)
-        {
-            if ((err = lthip_stage_upload(ctx, g->d_aoff.p, h_off.data(), (size_t)na * 8, s)) ||
-                (err = lthip_stage_upload(ctx, g->d_alen.p, h_len.data(), (size_t)na * 4, s)))
-                return err;
-            if ((err = lthip_hash_ranges(ctx, n ? (const void*)d_all_hashes : g->d_paths.p, na, (const uint64_t*)g->d_aoff.p,
-                                         (const uint32_t*)g->d_alen.p, max_len, (uint64_t*)g->d_ch.p)))
-                return err;
-            max_len = 0;
+        auto emit_vi = [&]() -> int {
+            LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+            // content hash of every asset = BLAKE3 of its chunk-hash array (:2518-2537); path hashes (:1269-1300)
+            std::vector<uint64_t> h_off(na);
+            std::vector<uint32_t> h_len(na);
+            uint32_t max_len = 0;
             for (uint32_t a = 0; a < na; ++a)
             {
-                if (t->path_start_offsets[a] >= t->path_data_size)
-                    return lthip_fail(ctx, EINVAL, "lthip_ingest_index", "path offset outside the path data");
-                h_off[a] = t->path_start_offsets[a];
-                h_len[a] = (uint32_t)strnlen(t->path_data + t->path_start_offsets[a], t->path_data_size - t->path_start_offsets[a]);
+                if ((uint64_t)counts[a] * 8u > 0xFFFFFFFFull)
+                    return lthip_fail(ctx, EINVAL, "lthip_ingest_index", "asset with more than 2^29 chunks");
+                h_off[a] = (uint64_t)starts[a] * 8u;
+                h_len[a] = counts[a] * 8u;
                 max_len = std::max(max_len, h_len[a]);
             }
-            // the staging ring holds 8 uploads: the offset / length tables of the content hashes were consumed by a kernel
-            // queued before these, and the uploads are ordered on the stream, so reusing d_aoff / d_alen is safe
-            if ((err = lthip_stage_upload(ctx, g->d_paths.p, t->path_data, t->path_data_size, s)) ||
-                (err = lthip_stage_upload(ctx, g->d_aoff.p, h_off.data(), (size_t)na * 8, s)) ||
-                (err = lthip_stage_upload(ctx, g->d_alen.p, h_len.data(), (size_t)na * 4, s)))
-                return err;
-            if ((err = lthip_hash_ranges(ctx, g->d_paths.p, na, (const uint64_t*)g->d_aoff.p, (const uint32_t*)g->d_alen.p, max_len,
-                                         (uint64_t*)g->d_ph.p)))
-                return err;
-        }
-        // serialized layout (Longtail_BuildVersionIndex :2757-2806 over InitVersionIndexFromData's section order)
-        uint8_t* w = (uint8_t*)h_version_index;
-        const uint32_t head[6] = {2u /* LONGTAIL_VERSION_INDEX_VERSION_0_0_2, :16-22 */, g->cfg.hash_identifier, g->cfg.target_chunk_size, na,
-                                  (uint32_t)unique, n};
-        memcpy(w, head, sizeof head);
-        w += sizeof head;
-#define LT_D2H(SRC, BYTES)                                                                    \
-    do                                                                                        \
-    {                                                                                         \
-        if (BYTES)                                                                            \
-            LTHIP_CHECK(ctx, hipMemcpyAsync(w, (SRC), (BYTES), hipMemcpyDeviceToHost, s));    \
-        w += (BYTES);                                                                         \
-    } while (0)
-        LT_D2H(g->d_ph.p, (size_t)na * 8);             // m_PathHashes
-        LT_D2H(g->d_ch.p, (size_t)na * 8);             // m_ContentHashes
-        memcpy(w, t->asset_sizes, (size_t)na * 8);     // m_AssetSizes
-        w += (size_t)na * 8;
-        memcpy(w, counts.data(), (size_t)na * 4);      // m_AssetChunkCounts
-        w += (size_t)na * 4;
-        memcpy(w, starts.data(), (size_t)na * 4);      // m_AssetChunkIndexStarts
-        w += (size_t)na * 4;
-        LT_D2H(g->d_idx.p, (size_t)n * 4);             // m_AssetChunkIndexes
-        LT_D2H(g->d_uh.p, (size_t)unique * 8);         // m_ChunkHashes
-        LT_D2H(g->d_us.p, (size_t)unique * 4);         // m_ChunkSizes
-        if (g->has_tags)
-            LT_D2H(g->d_ut.p, (size_t)unique * 4);     // m_ChunkTags
-        else
-        {
-            uint32_t* tg = (uint32_t*)w;               // one tag for the whole tree (what UpSync passes, cmd/main.c:1038-1046)
-            for (uint64_t i = 0; i < unique; ++i)
-                tg[i] = g->cfg.compression_type;
-            w += (size_t)unique * 4;
-        }
-#undef LT_D2H
-        memcpy(w, t->path_start_offsets, (size_t)na * 4); // m_NameOffsets
-        w += (size_t)na * 4;
-        memcpy(w, t->permissions, (size_t)na * 2);        // m_Permissions
-        w += (size_t)na * 2;
-        memcpy(w, t->path_data, t->path_data_size);       // m_NameData
+            if (na)
+            {
+                if ((err = lthip_stage_upload(ctx, g->d_aoff.p, h_off.data(), (size_t)na * 8, s)) ||
+                    (err = lthip_stage_upload(ctx, g->d_alen.p, h_len.data(), (size_t)na * 4, s)))
+                    return err;
+                if ((err = lthip_hash_ranges(ctx, n ? (const void*)d_all_hashes : g->d_paths.p, na, (const uint64_t*)g->d_aoff.p,
+                                             (const uint32_t*)g->d_alen.p, max_len, (uint64_t*)g->d_ch.p)))
+                    return err;
+                max_len = 0;
+                for (uint32_t a = 0; a < na; ++a)
+                {
+                    if (t->path_start_offsets[a] >= t->path_data_size)
+                        return lthip_fail(ctx, EINVAL, "lthip_ingest_index", "path offset outside the path data");
+                    h_off[a] = t->path_start_offsets[a];
+                    h_len[a] = (uint32_t)strnlen(t->path_data + t->path_start_offsets[a], t->path_data_size - t->path_start_offsets[a]);
+                    max_len = std::max(max_len, h_len[a]);
+                }
+                // the staging ring holds 8 uploads: the offset / length tables of the content hashes were consumed by a kernel
+                // queued before these, and the uploads are ordered on the stream, so reusing d_aoff / d_alen is safe
+                if ((err = lthip_stage_upload(ctx, g->d_paths.p, t->path_data, t->path_data_size, s)) ||
+                    (err = lthip_stage_upload(ctx, g->d_aoff.p, h_off.data(), (size_t)na * 8, s)) ||
+                    (err = lthip_stage_upload(ctx, g->d_alen.p, h_len.data(), (size_t)na * 4, s)))
+                    return err;
+                if ((err = lthip_hash_ranges(ctx, g->d_paths.p, na, (const uint64_t*)g->d_aoff.p, (const uint32_t*)g->d_alen.p, max_len,
+                                             (uint64_t*)g->d_ph.p)))
+                    return err;
+            }
+            // serialized layout (Longtail_BuildVersionIndex :2757-2806 over InitVersionIndexFromData's section order)
+            uint8_t* w = (uint8_t*)h_version_index;
+            const uint32_t head[6] = {2u /* LONGTAIL_VERSION_INDEX_VERSION_0_0_2, :16-22 */, g->cfg.hash_identifier, g->cfg.target_chunk_size, na,
+                                      (uint32_t)unique, n};
+            memcpy(w, head, sizeof head);
+            w += sizeof head;
+    #define LT_D2H(SRC, BYTES)                                                                    \
+        do                                                                                        \
+        {                                                                                         \
+            if (BYTES)                                                                            \
+                LTHIP_CHECK(ctx, hipMemcpyAsync(w, (SRC), (BYTES), hipMemcpyDeviceToHost, s));    \
+            w += (BYTES);                                                                         \
+        } while (0)
+            LT_D2H(g->d_ph.p, (size_t)na * 8);             // m_PathHashes
+            LT_D2H(g->d_ch.p, (size_t)na * 8);             // m_ContentHashes
+            memcpy(w, t->asset_sizes, (size_t)na * 8);     // m_AssetSizes
+            w += (size_t)na * 8;
+            memcpy(w, counts.data(), (size_t)na * 4);      // m_AssetChunkCounts
+            w += (size_t)na * 4;
+            memcpy(w, starts.data(), (size_t)na * 4);      // m_AssetChunkIndexStarts
+            w += (size_t)na * 4;
+            LT_D2H(g->d_idx.p, (size_t)n * 4);             // m_AssetChunkIndexes
+            LT_D2H(g->d_uh.p, (size_t)unique * 8);         // m_ChunkHashes
+            LT_D2H(g->d_us.p, (size_t)unique * 4);         // m_ChunkSizes
+            if (g->has_tags)
+                LT_D2H(g->d_ut.p, (size_t)unique * 4);     // m_ChunkTags
+            else
+            {
+                uint32_t* tg = (uint32_t*)w;               // one tag for the whole tree (what UpSync passes, cmd/main.c:1038-1046)
+                for (uint64_t i = 0; i < unique; ++i)
+                    tg[i] = g->cfg.compression_type;
+                w += (size_t)unique * 4;
+            }
+    #undef LT_D2H
+            memcpy(w, t->path_start_offsets, (size_t)na * 4); // m_NameOffsets
+            w += (size_t)na * 4;
+            memcpy(w, t->permissions, (size_t)na * 2);        // m_Permissions
+            w += (size_t)na * 2;
+            memcpy(w, t->path_data, t->path_data_size);       // m_NameData
+
+            return 0;
+        };
+        static LthipEnvInt env_vit{"LTHIP_INGEST_VI_THREAD"};
+        if (env_vit.get() != 0)
+            vi_thread = std::thread([&vi_err, emit_vi] { vi_err = emit_vi(); }); // (a copy: the lambda's own scope ends below; what it refers to lives on)
+        else if ((vi_err = emit_vi()))
+            return vi_err;
     }
+    struct Joiner // (every return below has to collect the helper first)
+    {
+        std::thread& t;
+        ~Joiner()
+        {
+            if (t.joinable())
+                t.join();
+        }
+    } vi_join{vi_thread};
 
     // ---- greedy packing of the owned chunks (Longtail_CreateStoreIndex :6801-6860), serial like the reference's ----
     LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_lens));
@@ -513,6 +538,10 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
         i = j;
     }
     g->b_first.push_back(nm);
+    if (vi_thread.joinable())
+        vi_thread.join(); // (the context is this thread's again)
+    if (vi_err)
+        return vi_err;
     const size_t nb = g->b_size.size();
     g->res.chunks_all = n;
     g->res.unique_all = unique;
