@@ -132,6 +132,14 @@ __global__ void k_ing_compact(const uint32_t* __restrict__ owned, const uint32_t
     }
 }
 
+// brk[i] = chunk i does not continue the byte range of chunk i - 1 (what the packing loop needs of the offsets: a byte instead of 8)
+__global__ void k_ing_breaks(const uint64_t* __restrict__ off, const uint32_t* __restrict__ len, uint32_t n, uint8_t* __restrict__ brk)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        brk[i] = i != 0u && off[i] != off[i - 1u] + len[i - 1u] ? 1 : 0;
+}
+
 __global__ void k_ing_sum_u32(const uint32_t* __restrict__ v, uint32_t n, unsigned long long* __restrict__ out)
 {
     unsigned long long acc = 0;
@@ -152,10 +160,11 @@ struct lthip_ingest
     // ---- index phase ----
     DBuf d_first, d_isfirst, d_rank, d_idx, d_uh, d_us, d_ut, d_starts, d_tags, d_counts, d_paths, d_aoff, d_alen, d_ph, d_ch;
     DBuf d_gfirst, d_owned, d_orank, d_l2g, d_mu_hash, d_mu_len, d_mu_off, d_mu_tag;
-    HBuf h_counts, h_mu_len, h_mu_off, h_mu_hash, h_mu_tag, h_bhash, h_comp;
+    HBuf h_counts, h_mu_len, h_mu_off, h_mu_hash, h_mu_tag, h_bhash, h_comp, h_brk;
+    DBuf d_brk;
     DBuf d_bhash, d_boff, d_blen, d_comp, d_sum;
     DBuf d_gather, d_gsrc, d_glen, d_gdst, d_bfirst, d_braw, d_bimg, d_btag, d_tmpsz;
-    hipEvent_t ev_counts, ev_lens, ev_index;
+    hipEvent_t ev_counts, ev_lens, ev_offs, ev_index;
     // the first-seen index of every chunk computed elsewhere (the sharded table of the multi-GPU path): consumed by the next
     // lthip_ingest_index instead of its own table pass
     const uint32_t* ext_first;
@@ -197,9 +206,10 @@ extern "C" int lthip_ingest_create(lthip_ctx* ctx, const lthip_ingest_config* cf
     if (g->cfg.batch_bytes == 0)
         g->cfg.batch_bytes = 8ull << 30;
     g->indexed = g->written = false;
-    g->ev_counts = g->ev_lens = g->ev_index = nullptr;
+    g->ev_counts = g->ev_lens = g->ev_index = g->ev_offs = nullptr;
     if (hipEventCreateWithFlags(&g->ev_counts, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g->ev_lens, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_offs, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g->ev_index, hipEventDisableTiming) != hipSuccess)
     {
         lthip_ingest_destroy(g);
@@ -218,11 +228,11 @@ extern "C" void lthip_ingest_destroy(lthip_ingest* g)
     DBuf* dev[] = {&g->d_first, &g->d_isfirst, &g->d_rank, &g->d_idx, &g->d_uh, &g->d_us, &g->d_ut, &g->d_starts, &g->d_tags, &g->d_counts,
                    &g->d_paths, &g->d_aoff, &g->d_alen, &g->d_ph, &g->d_ch, &g->d_gfirst, &g->d_owned, &g->d_orank, &g->d_l2g, &g->d_mu_hash,
                    &g->d_mu_len, &g->d_mu_off, &g->d_mu_tag, &g->d_bhash, &g->d_boff, &g->d_blen, &g->d_comp, &g->d_sum, &g->d_gather,
-                   &g->d_gsrc, &g->d_glen, &g->d_gdst, &g->d_bfirst, &g->d_braw, &g->d_bimg, &g->d_btag, &g->d_tmpsz};
+                   &g->d_gsrc, &g->d_glen, &g->d_gdst, &g->d_bfirst, &g->d_braw, &g->d_bimg, &g->d_btag, &g->d_tmpsz, &g->d_brk};
     for (DBuf* b : dev)
         if (b->p)
             (void)hipFree(b->p);
-    HBuf* pin[] = {&g->h_counts, &g->h_mu_len, &g->h_mu_off, &g->h_mu_hash, &g->h_mu_tag, &g->h_bhash, &g->h_comp};
+    HBuf* pin[] = {&g->h_counts, &g->h_mu_len, &g->h_mu_off, &g->h_mu_hash, &g->h_mu_tag, &g->h_bhash, &g->h_comp, &g->h_brk};
     for (HBuf* b : pin)
         if (b->p)
             (void)hipHostFree(b->p);
@@ -230,6 +240,8 @@ extern "C" void lthip_ingest_destroy(lthip_ingest* g)
         (void)hipEventDestroy(g->ev_counts);
     if (g->ev_lens)
         (void)hipEventDestroy(g->ev_lens);
+    if (g->ev_offs)
+        (void)hipEventDestroy(g->ev_offs);
     if (g->ev_index)
         (void)hipEventDestroy(g->ev_index);
     delete g;
@@ -317,6 +329,7 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
         (err = reserve_dev(ctx, g->d_mu_len, (size_t)nl * 4)) || (err = reserve_dev(ctx, g->d_mu_off, (size_t)nl * 8)) ||
         (err = reserve_dev(ctx, g->d_mu_tag, (size_t)nl * 4)) || (err = reserve_pinned(ctx, g->h_counts, 64)) ||
         (err = reserve_pinned(ctx, g->h_mu_len, (size_t)nl * 4)) || (err = reserve_pinned(ctx, g->h_mu_off, (size_t)nl * 8)) ||
+        (err = reserve_pinned(ctx, g->h_brk, (size_t)nl + 16)) || (err = reserve_dev(ctx, g->d_brk, (size_t)nl + 16)) ||
         (err = reserve_pinned(ctx, g->h_mu_hash, (size_t)nl * 8)) || (err = reserve_pinned(ctx, g->h_mu_tag, (size_t)nl * 4)))
         return err;
     uint64_t* d_counts = (uint64_t*)g->d_counts.p; // [0] distinct hashes of all ranks, [1] chunks this rank writes (u32 in the low half)
@@ -383,14 +396,23 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
     g->n_mine = nm;
 
     // ---- the host needs the owned chunks' lengths and offsets (and tags) for the packing: queue those copies first ----
+    // (the packing loop reads the lengths and, of the offsets, only whether a chunk continues the range of the one before: a byte per
+    // chunk from k_ing_breaks instead of the 8-byte offsets -- 10.5 instead of 25 MB on the 64 GiB tree before the loop can start; the
+    // offsets themselves follow for lthip_ingest_write)
     if (nm)
     {
+        hipLaunchKernelGGL(k_ing_breaks, dim3((uint32_t)div_up_u64(nm, 256)), dim3(256), 0, s, (const uint64_t*)g->d_mu_off.p,
+                           (const uint32_t*)g->d_mu_len.p, nm, (uint8_t*)g->d_brk.p);
+        LTHIP_LAUNCH_CHECK(ctx);
         LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_mu_len.p, g->d_mu_len.p, (size_t)nm * 4, hipMemcpyDeviceToHost, s));
-        LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_mu_off.p, g->d_mu_off.p, (size_t)nm * 8, hipMemcpyDeviceToHost, s));
+        LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_brk.p, g->d_brk.p, (size_t)nm, hipMemcpyDeviceToHost, s));
         if (g->has_tags)
             LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_mu_tag.p, g->d_mu_tag.p, (size_t)nm * 4, hipMemcpyDeviceToHost, s));
     }
     LTHIP_CHECK(ctx, hipEventRecord(g->ev_lens, s));
+    if (nm)
+        LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_mu_off.p, g->d_mu_off.p, (size_t)nm * 8, hipMemcpyDeviceToHost, s));
+    LTHIP_CHECK(ctx, hipEventRecord(g->ev_offs, s));
     if (nm)
         LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_mu_hash.p, g->d_mu_hash.p, (size_t)nm * 8, hipMemcpyDeviceToHost, s)); // StoreIndex, read in finish
 
@@ -509,7 +531,7 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
     // ---- greedy packing of the owned chunks (Longtail_CreateStoreIndex :6801-6860), serial like the reference's ----
     LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_lens));
     const uint32_t* lens = (const uint32_t*)g->h_mu_len.p;
-    const uint64_t* offs = (const uint64_t*)g->h_mu_off.p;
+    const uint8_t* brk = (const uint8_t*)g->h_brk.p;
     const uint32_t* tags = g->has_tags ? (const uint32_t*)g->h_mu_tag.p : nullptr;
     g->b_first.clear();
     g->b_size.clear();
@@ -526,7 +548,7 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
         const uint32_t tag = tags ? tags[i] : g->cfg.compression_type;
         while (j < nm && j - i < max_chunks && (!tags || tags[j] == tag) && size + lens[j] <= limit)
         {
-            range &= offs[j] == offs[j - 1] + lens[j - 1];
+            range &= brk[j] == 0;
             size += lens[j];
             ++j;
         }
@@ -590,6 +612,7 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const size_t nb = g->b_size.size();
+    LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_offs)); // (the owned chunks' offsets: queued behind what the packing needed)
     const uint32_t* lens = (const uint32_t*)g->h_mu_len.p;
     const uint64_t* offs = (const uint64_t*)g->h_mu_off.p;
     int err;
