@@ -100,6 +100,37 @@ static void* worker(void* arg)
     return 0;
 }
 
+struct codec_job
+{
+    struct Longtail_CompressionAPI* api;
+    uint32_t tag;
+    uint64_t seed;
+    size_t size;
+    int rounds, failed;
+};
+
+static void* codec_worker(void* arg)
+{
+    struct codec_job* j = (struct codec_job*)arg;
+    uint8_t* d = (uint8_t*)malloc(j->size);
+    const size_t cap = j->api->GetMaxCompressedSize(j->api, j->tag, j->size);
+    uint8_t* out = (uint8_t*)malloc(cap + 8);
+    uint8_t* back = (uint8_t*)malloc(j->size + 8);
+    for (int r = 0; r < j->rounds; ++r)
+    {
+        lto_synth_fill(d, j->size, j->seed + (uint64_t)r, 0, 1);
+        size_t got = 0, got2 = 0;
+        if (j->api->Compress(j->api, j->tag, (const char*)d, (char*)out + 4, j->size, cap, &got) != 0 || got == 0 ||
+            j->api->Decompress(j->api, (const char*)out + 4, (char*)back + 4, got, j->size, &got2) != 0 || got2 != j->size ||
+            memcmp(back + 4, d, j->size) != 0)
+            j->failed = 1;
+    }
+    free(d);
+    free(out);
+    free(back);
+    return 0;
+}
+
 int main(void)
 {
     g_chunker = Longtail_CreateHipChunkerAPI();
@@ -252,6 +283,31 @@ int main(void)
         uint8_t small[64];
         CHECK(lz4->Compress(lz4, tags[0], (const char*)d, (char*)small, 50000, 60, &got) == ENOMEM); /* longtail_lz4.c:70-74 */
         free(d);
+    }
+    /* 7. many threads in Compress / Decompress of both codecs at once: their blocks go through the codec dispatcher together
+     * (plugin_codec_batch.c: offsets relative to the lowest queued address, mixed operations sorted into submissions) */
+    {
+        enum { T = 10 };
+        pthread_t th[T];
+        struct codec_job jobs[T];
+        for (int i = 0; i < T; ++i)
+        {
+            jobs[i].api = i % 2 ? zstd : lz4;
+            jobs[i].tag = i % 2 ? 0x7a746432u : 0x6c7a3432u;
+            jobs[i].seed = 300 + (uint64_t)i;
+            jobs[i].size = 50000u + 77777u * (size_t)i;
+            jobs[i].rounds = 4;
+            jobs[i].failed = 0;
+            CHECK(pthread_create(&th[i], 0, codec_worker, &jobs[i]) == 0);
+        }
+        for (int i = 0; i < T; ++i)
+        {
+            pthread_join(th[i], 0);
+            CHECK(jobs[i].failed == 0);
+        }
+        uint64_t subs = 0, blocks = 0;
+        Longtail_Hip_CodecBatchStats(&subs, &blocks);
+        CHECK(blocks >= (uint64_t)T * 4u * 2u && subs >= 1 && subs <= blocks);
     }
     lz4->m_API.Dispose(&lz4->m_API);
     zstd->m_API.Dispose(&zstd->m_API);
