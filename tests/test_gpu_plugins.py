@@ -300,3 +300,51 @@ def test_streaming_context_5_gib(plugins, ref, oracle, hiplib):
         assert hiplib.dll.Longtail_Hip_GetLastError() == 0
     finally:
         HashAPIStruct.from_address(cpu).Dispose(cpu)
+
+
+def test_codec_plugins_many_threads_at_once(plugins, ref, oracle, hiplib):
+    """Compress / Decompress of both HIP codec objects from sixteen threads at once: the calls meet in the codec dispatcher
+    (plugin_codec_batch.c: one bulk submission for whatever is queued, offsets relative to the lowest queued address).  Every payload
+    decodes with the reference decoder and through the plugin itself; reference-made payloads (matches across the pieces: the origin
+    passes) come back too."""
+    import threading
+
+    jobs = []
+    for i in range(16):
+        codec = "zstd" if i % 2 else "lz4"
+        n = 200000 + 300007 * i
+        jobs.append((codec, oracle.synth(n, 900 + i, (1, 11, 12)[i % 3])))
+    errors = []
+
+    def work(codec, d):
+        try:
+            ptr = plugins[codec]
+            api = CompressionAPIStruct.from_address(ptr)
+            tag = ref.zstd_default if codec == "zstd" else ref.lz4_type
+            n = len(d)
+            cap = api.GetMaxCompressedSize(ptr, tag, n)
+            for rnd in range(3):
+                out = np.zeros(cap + 8, np.uint8)
+                got = C.c_size_t(0)
+                assert api.Compress(ptr, tag, d.ctypes.data, out.ctypes.data + 4, n, cap, C.byref(got)) == 0
+                own = out[4 : 4 + got.value].copy()
+                err, back = ref.decompress(1 if codec == "zstd" else 0, own, n)
+                assert err == 0 and len(back) == n and (back == d).all()
+                theirs = ref.compress(1, tag, d) if codec == "zstd" else oracle.lz4_compress(d)
+                for f in (own, theirs):
+                    res = np.zeros(n + 8, np.uint8)
+                    m = C.c_size_t(0)
+                    assert api.Decompress(ptr, f.ctypes.data, res.ctypes.data + 4, len(f), n, C.byref(m)) == 0
+                    assert m.value == n and (res[4 : 4 + n] == d).all()
+        except BaseException as e:  # noqa: BLE001 (collected for the main thread)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    subs, blocks = C.c_uint64(0), C.c_uint64(0)
+    hiplib.dll.Longtail_Hip_CodecBatchStats(C.byref(subs), C.byref(blocks))
+    assert blocks.value >= 16 * 3 * 3 and 1 <= subs.value <= blocks.value
