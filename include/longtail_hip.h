@@ -358,7 +358,10 @@ LTHIP_EXPORT int lthip_get_existing_store_index(lthip_ctx* ctx, const void* stor
  * chunks in job order (see lthip_exchange_layout) and tree->my_jobs lists this rank's jobs; a rank writes the chunks that are
  * first-seen and lie in its own jobs, i.e. Longtail_CreateMissingContent against a store that already holds the other ranks'
  * chunks.  h_version_index (may be NULL: this rank does not serialize the index) and h_store_index should be pinned memory so
- * the copies overlap the kernels.  asset_tags NULL = every asset carries cfg.compression_type (what UpSync passes). */
+ * the copies overlap the kernels.  asset_tags NULL = every asset carries cfg.compression_type (what UpSync passes).
+ * What lthip_ingest_index is given -- the tree's arrays, the device arrays, the VersionIndex buffer -- must stay valid, and the buffer
+ * unread, until lthip_ingest_finish has returned: the index is serialized by a helper thread next to lthip_ingest_write, and the
+ * packing into blocks is finished there too (the result's block count comes from lthip_ingest_finish). */
 enum lthip_codec
 {
     LTHIP_CODEC_NONE = 0,

@@ -178,7 +178,23 @@ struct lthip_ingest
     bool has_tags;
     size_t vi_size;
     bool indexed, written;
+    // the packing runs in slices (ingest_pack): lthip_ingest_index packs what the first codec batch takes, lthip_ingest_write the rest
+    // once that batch is queued
+    uint32_t pack_next;   // first owned chunk that is in no block yet
+    uint32_t pack_avail;  // owned chunks whose lengths / break flags / tags / offsets are on the host
+    uint64_t pack_raw;    // raw bytes of the blocks so far
+    bool blocks_done;     // all blocks packed and hashed, their hashes on the way to the host (ev_index)
+    hipEvent_t ev_hashes; // the owned chunks' hashes are on the host (side stream)
     lthip_ingest_result res;
+    // the VersionIndex sections are put together by a helper thread on a context of its own (stream, staging ring, BLAKE3 scratch), so
+    // that the calling thread keeps the session's context to itself and does not wait for it before lthip_ingest_finish
+    lthip_ctx* vi_ctx;
+    std::thread vi_thread;
+    int vi_err;
+    lthip_ingest_tree vi_tree; // (a copy: the arrays it points to are the caller's and must stay valid until lthip_ingest_finish)
+    std::vector<uint32_t> vi_starts, vi_counts;
+    const uint64_t* vi_hashes;
+    void* vi_out;
 };
 
 static size_t codec_bound(const lthip_ingest* g, size_t n)
@@ -206,11 +222,15 @@ extern "C" int lthip_ingest_create(lthip_ctx* ctx, const lthip_ingest_config* cf
     if (g->cfg.batch_bytes == 0)
         g->cfg.batch_bytes = 8ull << 30;
     g->indexed = g->written = false;
-    g->ev_counts = g->ev_lens = g->ev_index = g->ev_offs = nullptr;
+    g->vi_ctx = nullptr;
+    g->vi_err = 0;
+    g->ev_counts = g->ev_lens = g->ev_index = g->ev_offs = g->ev_hashes = nullptr;
+    g->blocks_done = false;
     if (hipEventCreateWithFlags(&g->ev_counts, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g->ev_lens, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g->ev_offs, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&g->ev_index, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&g->ev_index, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_hashes, hipEventDisableTiming) != hipSuccess)
     {
         lthip_ingest_destroy(g);
         return lthip_fail(ctx, EIO, "lthip_ingest_create", "hipEventCreate");
@@ -219,11 +239,16 @@ extern "C" int lthip_ingest_create(lthip_ctx* ctx, const lthip_ingest_config* cf
     return 0;
 }
 
+static int ingest_vi_join(lthip_ingest* g);
+
 extern "C" void lthip_ingest_destroy(lthip_ingest* g)
 {
     if (!g)
         return;
     (void)hipSetDevice(g->ctx->device);
+    (void)ingest_vi_join(g);
+    if (g->vi_ctx)
+        lthip_ctx_destroy(g->vi_ctx);
     (void)hipStreamSynchronize(g->ctx->stream);
     DBuf* dev[] = {&g->d_first, &g->d_isfirst, &g->d_rank, &g->d_idx, &g->d_uh, &g->d_us, &g->d_ut, &g->d_starts, &g->d_tags, &g->d_counts,
                    &g->d_paths, &g->d_aoff, &g->d_alen, &g->d_ph, &g->d_ch, &g->d_gfirst, &g->d_owned, &g->d_orank, &g->d_l2g, &g->d_mu_hash,
@@ -244,6 +269,11 @@ extern "C" void lthip_ingest_destroy(lthip_ingest* g)
         (void)hipEventDestroy(g->ev_offs);
     if (g->ev_index)
         (void)hipEventDestroy(g->ev_index);
+    if (g->ev_hashes)
+    {
+        (void)hipEventSynchronize(g->ev_hashes);
+        (void)hipEventDestroy(g->ev_hashes);
+    }
     delete g;
 }
 
@@ -257,6 +287,200 @@ extern "C" int lthip_ingest_set_first_seen(lthip_ingest* g, const uint32_t* d_fi
     g->ext_first = d_first_index;
     g->ext_unique = unique_chunks;
     return 0;
+}
+
+// Greedy packing of the owned chunks into blocks (Longtail_CreateStoreIndex :6801-6860), serial like the reference's, continued from
+// where it stopped: until the new blocks hold `raw_budget` bytes or the chunks on the host (pack_avail) run out.  A block is only
+// closed when the chunk that does not fit any more has been seen (or there is none).
+static void ingest_pack(lthip_ingest* g, uint64_t raw_budget)
+{
+    const uint32_t nm = (uint32_t)g->n_mine, avail = g->pack_avail;
+    const uint32_t* lens = (const uint32_t*)g->h_mu_len.p;
+    const uint8_t* brk = (const uint8_t*)g->h_brk.p;
+    const uint32_t* tags = g->has_tags ? (const uint32_t*)g->h_mu_tag.p : nullptr;
+    const uint64_t limit = (uint64_t)g->cfg.max_block_size + g->cfg.max_block_size / 10;
+    const uint32_t max_chunks = g->cfg.max_chunks_per_block;
+    uint64_t added = 0;
+    uint32_t i = g->pack_next;
+    while (i < avail && added < raw_budget)
+    {
+        uint64_t size = lens[i];
+        uint32_t j = i + 1;
+        bool range = true;
+        const uint32_t tag = tags ? tags[i] : g->cfg.compression_type;
+        while (j < avail && j - i < max_chunks && (!tags || tags[j] == tag) && size + lens[j] <= limit)
+        {
+            range &= brk[j] == 0;
+            size += lens[j];
+            ++j;
+        }
+        if (j == avail && avail < nm && j - i < max_chunks)
+            break; // the next chunk may still belong to this block
+        g->b_size.push_back(size);
+        g->b_first.push_back(j); // (b_first[b + 1]: where block b ends)
+        g->b_is_range.push_back(range ? 1 : 0);
+        g->b_tag.push_back(tag);
+        added += size;
+        i = j;
+    }
+    g->pack_next = i;
+    g->pack_raw += added;
+}
+
+// The rest of the packing, then the block hashes = BLAKE3 of each block's chunk-hash array (:3753-3757) on their way to the host.
+// lthip_ingest_write calls this behind the launches of its first batch (the codec runs while the host packs), lthip_ingest_finish when
+// nothing was written.
+static int ingest_blocks_done(lthip_ingest* g)
+{
+    if (g->blocks_done)
+        return 0;
+    lthip_ctx* ctx = g->ctx;
+    hipStream_t s = ctx->stream;
+    int err;
+    if (g->pack_avail < g->n_mine)
+    {
+        LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_offs));
+        g->pack_avail = (uint32_t)g->n_mine;
+    }
+    ingest_pack(g, ~0ull);
+    const size_t nb = g->b_size.size();
+    g->res.blocks = nb;
+    g->res.raw_bytes = g->pack_raw;
+    if ((err = reserve_pinned(ctx, g->h_bhash, nb * 8)) || (err = reserve_pinned(ctx, g->h_comp, nb * 4 + 8)))
+        return err;
+    if (nb)
+    {
+        std::vector<uint64_t> o(nb);
+        std::vector<uint32_t> l(nb);
+        uint32_t max_len = 0;
+        for (size_t b = 0; b < nb; ++b)
+        {
+            o[b] = g->b_first[b] * 8u;
+            l[b] = (uint32_t)(g->b_first[b + 1] - g->b_first[b]) * 8u;
+            max_len = std::max(max_len, l[b]);
+        }
+        if ((err = lthip_stage_upload(ctx, g->d_boff.p, o.data(), nb * 8, s)) || (err = lthip_stage_upload(ctx, g->d_blen.p, l.data(), nb * 4, s)))
+            return err;
+        if ((err = lthip_hash_ranges(ctx, g->d_mu_hash.p, nb, (const uint64_t*)g->d_boff.p, (const uint32_t*)g->d_blen.p, max_len,
+                                     (uint64_t*)g->d_bhash.p)))
+            return err;
+        LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_bhash.p, g->d_bhash.p, nb * 8, hipMemcpyDeviceToHost, s));
+    }
+    LTHIP_CHECK(ctx, hipEventRecord(g->ev_index, s));
+    g->blocks_done = true;
+    return 0;
+}
+
+// The serialized VersionIndex (Longtail_BuildVersionIndex :2757-2806 over InitVersionIndexFromData's section order) into the caller's
+// buffer: content hash of every asset = BLAKE3 of its chunk-hash array (:2518-2537), path hashes (:1269-1300), the sections copied or
+// written.  `ctx`: the context whose stream, staging ring and scratch it may use -- the helper thread's own, or the session's.
+static int ingest_vi_work(lthip_ingest* g, lthip_ctx* ctx)
+{
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const lthip_ingest_tree* t = &g->vi_tree;
+    const std::vector<uint32_t>&starts = g->vi_starts, &counts = g->vi_counts;
+    const uint32_t n = (uint32_t)g->n_all, na = t->asset_count;
+    const uint64_t unique = g->unique_all;
+    const uint64_t* d_all_hashes = g->vi_hashes;
+    void* h_version_index = g->vi_out;
+    int err = 0;
+    if (ctx != g->ctx)
+        LTHIP_CHECK(ctx, hipStreamWaitEvent(s, g->ev_lens, 0)); // (recorded behind the first-seen pass on the session's stream)
+    // content hash of every asset = BLAKE3 of its chunk-hash array (:2518-2537); path hashes (:1269-1300)
+    std::vector<uint64_t> h_off(na);
+    std::vector<uint32_t> h_len(na);
+    uint32_t max_len = 0;
+    for (uint32_t a = 0; a < na; ++a)
+    {
+        if ((uint64_t)counts[a] * 8u > 0xFFFFFFFFull)
+            return lthip_fail(ctx, EINVAL, "lthip_ingest_index", "asset with more than 2^29 chunks");
+        h_off[a] = (uint64_t)starts[a] * 8u;
+        h_len[a] = counts[a] * 8u;
+        max_len = std::max(max_len, h_len[a]);
+    }
+    if (na)
+    {
+        if ((err = lthip_stage_upload(ctx, g->d_aoff.p, h_off.data(), (size_t)na * 8, s)) ||
+            (err = lthip_stage_upload(ctx, g->d_alen.p, h_len.data(), (size_t)na * 4, s)))
+            return err;
+        if ((err = lthip_hash_ranges(ctx, n ? (const void*)d_all_hashes : g->d_paths.p, na, (const uint64_t*)g->d_aoff.p,
+                                     (const uint32_t*)g->d_alen.p, max_len, (uint64_t*)g->d_ch.p)))
+            return err;
+        max_len = 0;
+        for (uint32_t a = 0; a < na; ++a)
+        {
+            if (t->path_start_offsets[a] >= t->path_data_size)
+                return lthip_fail(ctx, EINVAL, "lthip_ingest_index", "path offset outside the path data");
+            h_off[a] = t->path_start_offsets[a];
+            h_len[a] = (uint32_t)strnlen(t->path_data + t->path_start_offsets[a], t->path_data_size - t->path_start_offsets[a]);
+            max_len = std::max(max_len, h_len[a]);
+        }
+        // the staging ring holds 8 uploads: the offset / length tables of the content hashes were consumed by a kernel
+        // queued before these, and the uploads are ordered on the stream, so reusing d_aoff / d_alen is safe
+        if ((err = lthip_stage_upload(ctx, g->d_paths.p, t->path_data, t->path_data_size, s)) ||
+            (err = lthip_stage_upload(ctx, g->d_aoff.p, h_off.data(), (size_t)na * 8, s)) ||
+            (err = lthip_stage_upload(ctx, g->d_alen.p, h_len.data(), (size_t)na * 4, s)))
+            return err;
+        if ((err = lthip_hash_ranges(ctx, g->d_paths.p, na, (const uint64_t*)g->d_aoff.p, (const uint32_t*)g->d_alen.p, max_len,
+                                     (uint64_t*)g->d_ph.p)))
+            return err;
+    }
+    // serialized layout (Longtail_BuildVersionIndex :2757-2806 over InitVersionIndexFromData's section order)
+    uint8_t* w = (uint8_t*)h_version_index;
+    const uint32_t head[6] = {2u /* LONGTAIL_VERSION_INDEX_VERSION_0_0_2, :16-22 */, g->cfg.hash_identifier, g->cfg.target_chunk_size, na,
+                              (uint32_t)unique, n};
+    memcpy(w, head, sizeof head);
+    w += sizeof head;
+    #define LT_D2H(SRC, BYTES)                                                                    \
+do                                                                                        \
+{                                                                                         \
+    if (BYTES)                                                                            \
+        LTHIP_CHECK(ctx, hipMemcpyAsync(w, (SRC), (BYTES), hipMemcpyDeviceToHost, s));    \
+    w += (BYTES);                                                                         \
+} while (0)
+    LT_D2H(g->d_ph.p, (size_t)na * 8);             // m_PathHashes
+    LT_D2H(g->d_ch.p, (size_t)na * 8);             // m_ContentHashes
+    memcpy(w, t->asset_sizes, (size_t)na * 8);     // m_AssetSizes
+    w += (size_t)na * 8;
+    memcpy(w, counts.data(), (size_t)na * 4);      // m_AssetChunkCounts
+    w += (size_t)na * 4;
+    memcpy(w, starts.data(), (size_t)na * 4);      // m_AssetChunkIndexStarts
+    w += (size_t)na * 4;
+    LT_D2H(g->d_idx.p, (size_t)n * 4);             // m_AssetChunkIndexes
+    LT_D2H(g->d_uh.p, (size_t)unique * 8);         // m_ChunkHashes
+    LT_D2H(g->d_us.p, (size_t)unique * 4);         // m_ChunkSizes
+    if (g->has_tags)
+        LT_D2H(g->d_ut.p, (size_t)unique * 4);     // m_ChunkTags
+    else
+    {
+        uint32_t* tg = (uint32_t*)w;               // one tag for the whole tree (what UpSync passes, cmd/main.c:1038-1046)
+        for (uint64_t i = 0; i < unique; ++i)
+            tg[i] = g->cfg.compression_type;
+        w += (size_t)unique * 4;
+    }
+    #undef LT_D2H
+    memcpy(w, t->path_start_offsets, (size_t)na * 4); // m_NameOffsets
+    w += (size_t)na * 4;
+    memcpy(w, t->permissions, (size_t)na * 2);        // m_Permissions
+    w += (size_t)na * 2;
+    memcpy(w, t->path_data, t->path_data_size);       // m_NameData
+
+    return 0;
+}
+
+// collects the helper (and what it queued): its error, if any
+static int ingest_vi_join(lthip_ingest* g)
+{
+    if (g->vi_thread.joinable())
+    {
+        g->vi_thread.join();
+        if (g->vi_ctx)
+            (void)hipStreamSynchronize(g->vi_ctx->stream);
+    }
+    const int e = g->vi_err;
+    g->vi_err = 0;
+    return e;
 }
 
 extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, const uint64_t* d_all_hashes, const uint32_t* d_all_lens,
@@ -273,6 +497,8 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
     if (t->job_count && t->job_first[t->job_count] != all_chunks)
         return lthip_fail(ctx, EINVAL, "lthip_ingest_index", "job_first[job_count] must be the number of chunks");
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    (void)ingest_vi_join(g); // (an index that was never finished: its helper reads what this call is about to replace ...
+    (void)hipEventSynchronize(g->ev_hashes); // ... and so does the side stream)
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t)all_chunks, nl = (uint32_t)local_chunks, na = t->asset_count;
     const bool all_mine = t->my_jobs == nullptr;
@@ -330,7 +556,12 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
         (err = reserve_dev(ctx, g->d_mu_tag, (size_t)nl * 4)) || (err = reserve_pinned(ctx, g->h_counts, 64)) ||
         (err = reserve_pinned(ctx, g->h_mu_len, (size_t)nl * 4)) || (err = reserve_pinned(ctx, g->h_mu_off, (size_t)nl * 8)) ||
         (err = reserve_pinned(ctx, g->h_brk, (size_t)nl + 16)) || (err = reserve_dev(ctx, g->d_brk, (size_t)nl + 16)) ||
-        (err = reserve_pinned(ctx, g->h_mu_hash, (size_t)nl * 8)) || (err = reserve_pinned(ctx, g->h_mu_tag, (size_t)nl * 4)))
+        (err = reserve_pinned(ctx, g->h_mu_hash, (size_t)nl * 8)) || (err = reserve_pinned(ctx, g->h_mu_tag, (size_t)nl * 4)) ||
+        // (per block; the number of blocks is known when the packing ends, which is after the first codec batch was queued: a block
+        // holds at least one chunk)
+        (err = reserve_dev(ctx, g->d_bhash, (size_t)nl * 8)) || (err = reserve_dev(ctx, g->d_boff, (size_t)nl * 8)) ||
+        (err = reserve_dev(ctx, g->d_blen, (size_t)nl * 4)) || (err = reserve_dev(ctx, g->d_comp, (size_t)nl * 4)) ||
+        (err = reserve_dev(ctx, g->d_sum, 8)))
         return err;
     uint64_t* d_counts = (uint64_t*)g->d_counts.p; // [0] distinct hashes of all ranks, [1] chunks this rank writes (u32 in the low half)
     volatile uint64_t* h_counts = (volatile uint64_t*)g->h_counts.p;
@@ -395,208 +626,111 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
     g->unique_all = unique;
     g->n_mine = nm;
 
-    // ---- the host needs the owned chunks' lengths and offsets (and tags) for the packing: queue those copies first ----
-    // (the packing loop reads the lengths and, of the offsets, only whether a chunk continues the range of the one before: a byte per
-    // chunk from k_ing_breaks instead of the 8-byte offsets -- 10.5 instead of 25 MB on the 64 GiB tree before the loop can start; the
-    // offsets themselves follow for lthip_ingest_write)
+    // ---- the host needs the owned chunks' lengths, offsets (and tags) for the packing and the codec calls.  Of the offsets the packing
+    // loop reads only whether a chunk continues the range of the one before: a byte per chunk from k_ing_breaks.  The copies are 44 MB on
+    // the 64 GiB tree (0.8 ms of the link), and the first codec batch needs the head of the lists only: the chunks of about that batch
+    // are copied on the session's stream (ev_lens), the rest -- and the chunk hashes, which lthip_ingest_finish reads -- by the side
+    // stream next to the codec kernels (ev_offs, ev_hashes)
+    uint32_t head = nm;
+    {
+        static LthipEnvInt env_slices{"LTHIP_INGEST_PACK_SLICES"};
+        uint64_t tree_bytes = 0;
+        for (uint32_t a = 0; a < na; ++a)
+            tree_bytes += t->asset_sizes[a];
+        if (env_slices.get() != 0 && n && tree_bytes > 2 * g->cfg.batch_bytes)
+        {
+            // chunks of one batch at the tree's mean chunk size, a quarter more, and the chunks of one more block
+            const double per_byte = (double)n / (double)tree_bytes;
+            const double want = 1.25 * per_byte * (double)g->cfg.batch_bytes + 2.0 * g->cfg.max_chunks_per_block + 4096.0;
+            if (want < (double)nm)
+                head = (uint32_t)want;
+        }
+    }
+    g->pack_avail = head;
+    hipStream_t s2 = s;
+    if (head < nm && (err = lthip_second_stream(ctx, &s2)))
+        return err;
+    auto d2h_lists = [&](uint32_t c0, uint32_t c1, hipStream_t st) -> int {
+        const size_t k = (size_t)c1 - c0;
+        if (!k)
+            return 0;
+        LTHIP_CHECK(ctx, hipMemcpyAsync((uint32_t*)g->h_mu_len.p + c0, (const uint32_t*)g->d_mu_len.p + c0, k * 4, hipMemcpyDeviceToHost, st));
+        LTHIP_CHECK(ctx, hipMemcpyAsync((uint8_t*)g->h_brk.p + c0, (const uint8_t*)g->d_brk.p + c0, k, hipMemcpyDeviceToHost, st));
+        if (g->has_tags)
+            LTHIP_CHECK(ctx, hipMemcpyAsync((uint32_t*)g->h_mu_tag.p + c0, (const uint32_t*)g->d_mu_tag.p + c0, k * 4, hipMemcpyDeviceToHost, st));
+        LTHIP_CHECK(ctx, hipMemcpyAsync((uint64_t*)g->h_mu_off.p + c0, (const uint64_t*)g->d_mu_off.p + c0, k * 8, hipMemcpyDeviceToHost, st));
+        return 0;
+    };
     if (nm)
     {
         hipLaunchKernelGGL(k_ing_breaks, dim3((uint32_t)div_up_u64(nm, 256)), dim3(256), 0, s, (const uint64_t*)g->d_mu_off.p,
                            (const uint32_t*)g->d_mu_len.p, nm, (uint8_t*)g->d_brk.p);
         LTHIP_LAUNCH_CHECK(ctx);
-        LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_mu_len.p, g->d_mu_len.p, (size_t)nm * 4, hipMemcpyDeviceToHost, s));
-        LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_brk.p, g->d_brk.p, (size_t)nm, hipMemcpyDeviceToHost, s));
-        if (g->has_tags)
-            LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_mu_tag.p, g->d_mu_tag.p, (size_t)nm * 4, hipMemcpyDeviceToHost, s));
+        if ((err = d2h_lists(0, head, s)))
+            return err;
     }
     LTHIP_CHECK(ctx, hipEventRecord(g->ev_lens, s));
+    if (s2 != s)
+        LTHIP_CHECK(ctx, hipStreamWaitEvent(s2, g->ev_lens, 0));
+    if ((err = d2h_lists(head, nm, s2)))
+        return err;
+    LTHIP_CHECK(ctx, hipEventRecord(g->ev_offs, s2));
     if (nm)
-        LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_mu_off.p, g->d_mu_off.p, (size_t)nm * 8, hipMemcpyDeviceToHost, s));
-    LTHIP_CHECK(ctx, hipEventRecord(g->ev_offs, s));
-    if (nm)
-        LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_mu_hash.p, g->d_mu_hash.p, (size_t)nm * 8, hipMemcpyDeviceToHost, s)); // StoreIndex, read in finish
+        LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_mu_hash.p, g->d_mu_hash.p, (size_t)nm * 8, hipMemcpyDeviceToHost, s2)); // StoreIndex, read in finish
+    LTHIP_CHECK(ctx, hipEventRecord(g->ev_hashes, s2));
 
-    // ---- ... then the VersionIndex sections: the GPU works on them while the host packs -- and so does a second host thread: the
-    // tables of 65 536 assets and the tag column of 2.1 M chunks are 1.2-2.4 ms of host work on the 64 GiB tree, the packing loop
-    // below as much, and neither needs the other (LTHIP_INGEST_VI_THREAD=0: one after the other, rounds 1-2).  The helper is the only
-    // one that touches the context until it is joined. ----
+    // ---- ... then the VersionIndex sections: 1.2-2.4 ms of host work on the 64 GiB tree (the tables of 65 536 assets, the tag column
+    // of 2.1 M chunks) plus copies and two small hash launches, none of which the rest of the session waits for: a helper thread with a
+    // context of its own does them (LTHIP_INGEST_VI_THREAD=0: here and now, on the session's context); lthip_ingest_finish collects it.
     g->vi_size = 0;
-    int vi_err = 0;
-    std::thread vi_thread;
     if (want_vi)
     {
         const size_t size = lthip_version_index_size(na, unique, n, t->path_data_size);
         g->vi_size = size;
         if (version_index_capacity < size)
             return lthip_fail(ctx, ENOMEM, "lthip_ingest_index", "version index buffer too small");
-        auto emit_vi = [&]() -> int {
-            LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
-            // content hash of every asset = BLAKE3 of its chunk-hash array (:2518-2537); path hashes (:1269-1300)
-            std::vector<uint64_t> h_off(na);
-            std::vector<uint32_t> h_len(na);
-            uint32_t max_len = 0;
-            for (uint32_t a = 0; a < na; ++a)
-            {
-                if ((uint64_t)counts[a] * 8u > 0xFFFFFFFFull)
-                    return lthip_fail(ctx, EINVAL, "lthip_ingest_index", "asset with more than 2^29 chunks");
-                h_off[a] = (uint64_t)starts[a] * 8u;
-                h_len[a] = counts[a] * 8u;
-                max_len = std::max(max_len, h_len[a]);
-            }
-            if (na)
-            {
-                if ((err = lthip_stage_upload(ctx, g->d_aoff.p, h_off.data(), (size_t)na * 8, s)) ||
-                    (err = lthip_stage_upload(ctx, g->d_alen.p, h_len.data(), (size_t)na * 4, s)))
-                    return err;
-                if ((err = lthip_hash_ranges(ctx, n ? (const void*)d_all_hashes : g->d_paths.p, na, (const uint64_t*)g->d_aoff.p,
-                                             (const uint32_t*)g->d_alen.p, max_len, (uint64_t*)g->d_ch.p)))
-                    return err;
-                max_len = 0;
-                for (uint32_t a = 0; a < na; ++a)
-                {
-                    if (t->path_start_offsets[a] >= t->path_data_size)
-                        return lthip_fail(ctx, EINVAL, "lthip_ingest_index", "path offset outside the path data");
-                    h_off[a] = t->path_start_offsets[a];
-                    h_len[a] = (uint32_t)strnlen(t->path_data + t->path_start_offsets[a], t->path_data_size - t->path_start_offsets[a]);
-                    max_len = std::max(max_len, h_len[a]);
-                }
-                // the staging ring holds 8 uploads: the offset / length tables of the content hashes were consumed by a kernel
-                // queued before these, and the uploads are ordered on the stream, so reusing d_aoff / d_alen is safe
-                if ((err = lthip_stage_upload(ctx, g->d_paths.p, t->path_data, t->path_data_size, s)) ||
-                    (err = lthip_stage_upload(ctx, g->d_aoff.p, h_off.data(), (size_t)na * 8, s)) ||
-                    (err = lthip_stage_upload(ctx, g->d_alen.p, h_len.data(), (size_t)na * 4, s)))
-                    return err;
-                if ((err = lthip_hash_ranges(ctx, g->d_paths.p, na, (const uint64_t*)g->d_aoff.p, (const uint32_t*)g->d_alen.p, max_len,
-                                             (uint64_t*)g->d_ph.p)))
-                    return err;
-            }
-            // serialized layout (Longtail_BuildVersionIndex :2757-2806 over InitVersionIndexFromData's section order)
-            uint8_t* w = (uint8_t*)h_version_index;
-            const uint32_t head[6] = {2u /* LONGTAIL_VERSION_INDEX_VERSION_0_0_2, :16-22 */, g->cfg.hash_identifier, g->cfg.target_chunk_size, na,
-                                      (uint32_t)unique, n};
-            memcpy(w, head, sizeof head);
-            w += sizeof head;
-    #define LT_D2H(SRC, BYTES)                                                                    \
-        do                                                                                        \
-        {                                                                                         \
-            if (BYTES)                                                                            \
-                LTHIP_CHECK(ctx, hipMemcpyAsync(w, (SRC), (BYTES), hipMemcpyDeviceToHost, s));    \
-            w += (BYTES);                                                                         \
-        } while (0)
-            LT_D2H(g->d_ph.p, (size_t)na * 8);             // m_PathHashes
-            LT_D2H(g->d_ch.p, (size_t)na * 8);             // m_ContentHashes
-            memcpy(w, t->asset_sizes, (size_t)na * 8);     // m_AssetSizes
-            w += (size_t)na * 8;
-            memcpy(w, counts.data(), (size_t)na * 4);      // m_AssetChunkCounts
-            w += (size_t)na * 4;
-            memcpy(w, starts.data(), (size_t)na * 4);      // m_AssetChunkIndexStarts
-            w += (size_t)na * 4;
-            LT_D2H(g->d_idx.p, (size_t)n * 4);             // m_AssetChunkIndexes
-            LT_D2H(g->d_uh.p, (size_t)unique * 8);         // m_ChunkHashes
-            LT_D2H(g->d_us.p, (size_t)unique * 4);         // m_ChunkSizes
-            if (g->has_tags)
-                LT_D2H(g->d_ut.p, (size_t)unique * 4);     // m_ChunkTags
-            else
-            {
-                uint32_t* tg = (uint32_t*)w;               // one tag for the whole tree (what UpSync passes, cmd/main.c:1038-1046)
-                for (uint64_t i = 0; i < unique; ++i)
-                    tg[i] = g->cfg.compression_type;
-                w += (size_t)unique * 4;
-            }
-    #undef LT_D2H
-            memcpy(w, t->path_start_offsets, (size_t)na * 4); // m_NameOffsets
-            w += (size_t)na * 4;
-            memcpy(w, t->permissions, (size_t)na * 2);        // m_Permissions
-            w += (size_t)na * 2;
-            memcpy(w, t->path_data, t->path_data_size);       // m_NameData
-
-            return 0;
-        };
+        for (uint32_t a = 0; a < na; ++a)
+        {
+            if ((uint64_t)counts[a] * 8u > 0xFFFFFFFFull)
+                return lthip_fail(ctx, EINVAL, "lthip_ingest_index", "asset with more than 2^29 chunks");
+            if (t->path_start_offsets[a] >= t->path_data_size)
+                return lthip_fail(ctx, EINVAL, "lthip_ingest_index", "path offset outside the path data");
+        }
+        g->vi_tree = *t;
+        g->vi_starts.swap(starts);
+        g->vi_counts.swap(counts);
+        g->vi_hashes = d_all_hashes;
+        g->vi_out = h_version_index;
         static LthipEnvInt env_vit{"LTHIP_INGEST_VI_THREAD"};
         if (env_vit.get() != 0)
-            vi_thread = std::thread([&vi_err, emit_vi] { vi_err = emit_vi(); }); // (a copy: the lambda's own scope ends below; what it refers to lives on)
-        else if ((vi_err = emit_vi()))
-            return vi_err;
-    }
-    struct Joiner // (every return below has to collect the helper first)
-    {
-        std::thread& t;
-        ~Joiner()
         {
-            if (t.joinable())
-                t.join();
+            if (!g->vi_ctx && lthip_ctx_create(ctx->device, LTHIP_STREAM_PRIVATE, &g->vi_ctx) != 0)
+                return lthip_fail(ctx, ENOMEM, "lthip_ingest_index", "no context for the VersionIndex helper");
+            g->vi_thread = std::thread([g] { g->vi_err = ingest_vi_work(g, g->vi_ctx); });
         }
-    } vi_join{vi_thread};
+        else if ((err = ingest_vi_work(g, ctx)))
+            return err;
+    }
 
-    // ---- greedy packing of the owned chunks (Longtail_CreateStoreIndex :6801-6860), serial like the reference's ----
+    // ---- greedy packing of the owned chunks (Longtail_CreateStoreIndex :6801-6860): here the blocks of the first codec batch ----
     LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_lens));
-    const uint32_t* lens = (const uint32_t*)g->h_mu_len.p;
-    const uint8_t* brk = (const uint8_t*)g->h_brk.p;
-    const uint32_t* tags = g->has_tags ? (const uint32_t*)g->h_mu_tag.p : nullptr;
     g->b_first.clear();
     g->b_size.clear();
     g->b_is_range.clear();
     g->b_tag.clear();
-    const uint64_t limit = (uint64_t)g->cfg.max_block_size + g->cfg.max_block_size / 10;
-    const uint32_t max_chunks = g->cfg.max_chunks_per_block;
-    uint64_t raw_total = 0;
-    for (uint32_t i = 0; i < nm;)
-    {
-        uint64_t size = lens[i];
-        uint32_t j = i + 1;
-        bool range = true;
-        const uint32_t tag = tags ? tags[i] : g->cfg.compression_type;
-        while (j < nm && j - i < max_chunks && (!tags || tags[j] == tag) && size + lens[j] <= limit)
-        {
-            range &= brk[j] == 0;
-            size += lens[j];
-            ++j;
-        }
-        g->b_first.push_back(i);
-        g->b_size.push_back(size);
-        g->b_is_range.push_back(range ? 1 : 0);
-        g->b_tag.push_back(tag);
-        raw_total += size;
-        i = j;
-    }
-    g->b_first.push_back(nm);
-    if (vi_thread.joinable())
-        vi_thread.join(); // (the context is this thread's again)
-    if (vi_err)
-        return vi_err;
-    const size_t nb = g->b_size.size();
+    g->b_first.push_back(0);
+    g->pack_next = 0;
+    g->pack_raw = 0;
+    g->blocks_done = false;
+    g->written = false;
+    ingest_pack(g, g->cfg.batch_bytes + 2ull * g->cfg.max_block_size);
     g->res.chunks_all = n;
     g->res.unique_all = unique;
     g->res.chunks_local = nl;
     g->res.unique_local = nm;
-    g->res.blocks = nb;
-    g->res.raw_bytes = raw_total;
+    g->res.blocks = 0; // (ingest_blocks_done)
+    g->res.raw_bytes = 0;
     g->res.version_index_size = g->vi_size;
-
-    // ---- block hashes = BLAKE3 of each block's chunk-hash array (:3753-3757) ----
-    if ((err = reserve_dev(ctx, g->d_bhash, nb * 8)) || (err = reserve_dev(ctx, g->d_boff, nb * 8)) || (err = reserve_dev(ctx, g->d_blen, nb * 4)) ||
-        (err = reserve_dev(ctx, g->d_comp, nb * 4)) || (err = reserve_dev(ctx, g->d_sum, 8)) || (err = reserve_pinned(ctx, g->h_bhash, nb * 8)) ||
-        (err = reserve_pinned(ctx, g->h_comp, nb * 4 + 8)))
-        return err;
-    if (nb)
-    {
-        std::vector<uint64_t> o(nb);
-        std::vector<uint32_t> l(nb);
-        uint32_t max_len = 0;
-        for (size_t b = 0; b < nb; ++b)
-        {
-            o[b] = g->b_first[b] * 8u;
-            l[b] = (uint32_t)(g->b_first[b + 1] - g->b_first[b]) * 8u;
-            max_len = std::max(max_len, l[b]);
-        }
-        if ((err = lthip_stage_upload(ctx, g->d_boff.p, o.data(), nb * 8, s)) || (err = lthip_stage_upload(ctx, g->d_blen.p, l.data(), nb * 4, s)))
-            return err;
-        if ((err = lthip_hash_ranges(ctx, g->d_mu_hash.p, nb, (const uint64_t*)g->d_boff.p, (const uint32_t*)g->d_blen.p, max_len,
-                                     (uint64_t*)g->d_bhash.p)))
-            return err;
-        LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_bhash.p, g->d_bhash.p, nb * 8, hipMemcpyDeviceToHost, s));
-    }
-    LTHIP_CHECK(ctx, hipEventRecord(g->ev_index, s));
     g->indexed = true;
     return 0;
 }
@@ -606,26 +740,41 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_arena, uint64_t arena_bytes)
 {
-    if (!g || !g->indexed || (g->res.raw_bytes && (!d_data || !d_arena)))
+    if (!g || !g->indexed || (g->n_mine && (!d_data || !d_arena)))
         return EINVAL;
     lthip_ctx* ctx = g->ctx;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const size_t nb = g->b_size.size();
-    LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_offs)); // (the owned chunks' offsets: queued behind what the packing needed)
     const uint32_t* lens = (const uint32_t*)g->h_mu_len.p;
     const uint64_t* offs = (const uint64_t*)g->h_mu_off.p;
     int err;
     uint64_t gathered_blocks = 0;
     std::vector<uint64_t> src_off, dst_off, img_off, g_src, g_dst, bfirst;
     std::vector<uint32_t> src_size, dst_cap, g_len, braw;
-    for (size_t b0 = 0; b0 < nb;)
+    // more blocks, when the batch being put together has taken all there are and chunks are left
+    auto more_blocks = [&](size_t have) -> int {
+        while (g->b_size.size() == have && g->pack_next < g->n_mine)
+        {
+            if (g->pack_next + 2ull * g->cfg.max_chunks_per_block >= g->pack_avail && g->pack_avail < g->n_mine)
+            {
+                LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_offs));
+                g->pack_avail = (uint32_t)g->n_mine;
+            }
+            ingest_pack(g, 1ull << 30);
+        }
+        return 0;
+    };
+    for (size_t b0 = 0;;)
     {
+        if ((err = more_blocks(b0)))
+            return err;
+        if (b0 == g->b_size.size())
+            break;
         // ---- one batch: as many blocks as the arena and the codec's batch size hold (always at least one) ----
         size_t b1 = b0;
         uint64_t arena = 0, bytes = 0, gather_chunks = 0;
         img_off.clear();
-        while (b1 < nb)
+        while ((err = more_blocks(b1)) == 0 && b1 < g->b_size.size())
         {
             const uint32_t nchunks = (uint32_t)(g->b_first[b1 + 1] - g->b_first[b1]);
             const uint64_t need = ((uint64_t)lthip_stored_block_header_size(nchunks) + codec_bound(g, g->b_size[b1]) + 63u) & ~(uint64_t)63u;
@@ -640,6 +789,8 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
                 gather_chunks += nchunks;
             ++b1;
         }
+        if (err)
+            return err;
         const size_t cnt = b1 - b0;
         // ---- block assembly (WriteContentBlockJob, :4640-4721) only for blocks that are not one byte range of the data ----
         if (gather_chunks)
@@ -747,6 +898,9 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
             if (pass == 1)
                 gathered_blocks += k;
         }
+        // ---- (first batch: the codec has work now; the rest of the packing and all block hashes) ----
+        if ((err = ingest_blocks_done(g)))
+            return err;
         // ---- BlockIndex + [raw][compressed] around the payloads (:4111-4150; compressblockstore.c:103-139) ----
         if ((err = reserve_dev(ctx, g->d_bfirst, (cnt + 1) * 4)) || (err = reserve_dev(ctx, g->d_braw, cnt * 4)) ||
             (err = reserve_dev(ctx, g->d_bimg, cnt * 8)) || (err = reserve_dev(ctx, g->d_btag, cnt * 4)))
@@ -778,6 +932,9 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
         }
         b0 = b1;
     }
+    if ((err = ingest_blocks_done(g))) // (nothing to write)
+        return err;
+    const size_t nb = g->b_size.size();
     // compressed sizes of all blocks: total on the device, list to the host for the caller's statistics
     LTHIP_CHECK(ctx, hipMemsetAsync(g->d_sum.p, 0, 8, s));
     if (nb)
@@ -802,6 +959,11 @@ extern "C" int lthip_ingest_finish(lthip_ingest* g, void* h_store_index, size_t 
         return EINVAL;
     lthip_ctx* ctx = g->ctx;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    {
+        const int err = ingest_blocks_done(g); // (an index without lthip_ingest_write)
+        if (err)
+            return err;
+    }
     const size_t nb = g->b_size.size(), m = (size_t)g->n_mine;
     const size_t size = 16 + nb * 8 + m * 8 + nb * 12 + m * 4; // Longtail_GetStoreIndexDataSize
     g->res.store_index_size = size;
@@ -812,7 +974,8 @@ extern "C" int lthip_ingest_finish(lthip_ingest* g, void* h_store_index, size_t 
             rc = ENOMEM;
         else
         {
-            LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_index)); // block hashes and the owned chunks' hashes are on the host
+            LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_index));  // block hashes ...
+            LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_hashes)); // ... and the owned chunks' hashes are on the host
             uint8_t* w = (uint8_t*)h_store_index;
             const uint32_t head[4] = {(1u << 24) /* LONGTAIL_STORE_INDEX_VERSION_1_0_0, :19-23 */, g->cfg.hash_identifier, (uint32_t)nb, (uint32_t)m};
             memcpy(w, head, 16);
@@ -833,6 +996,12 @@ extern "C" int lthip_ingest_finish(lthip_ingest* g, void* h_store_index, size_t 
         }
     }
     LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_hashes)); // (the side stream's copies)
+    {
+        const int vi_err = ingest_vi_join(g); // the VersionIndex is in the caller's buffer (or could not be made)
+        if (vi_err)
+            return lthip_fail(ctx, vi_err, "lthip_ingest_finish: VersionIndex", g->vi_ctx ? g->vi_ctx->err : "");
+    }
     g->res.compressed_bytes = g->written ? *(const uint64_t*)g->h_comp.p : 0;
     if (out)
         *out = g->res;

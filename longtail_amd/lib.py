@@ -527,7 +527,9 @@ class Ingest:
         t = IngestTree(len(a_sz), a_sz.ctypes.data, a_off.ctypes.data, a_perm.ctypes.data, path_data, len(path_data),
                        tags.ctypes.data if tags is not None else None, len(j_as), j_as.ctypes.data, j_first.ctypes.data,
                        len(mine) if mine is not None else 0, mine.ctypes.data if mine is not None else None)
-        return t, [a_sz, a_off, a_perm, path_data, j_as, j_first, mine, tags]
+        keep = [a_sz, a_off, a_perm, path_data, j_as, j_first, mine, tags]
+        t._keep = keep  # the arrays are read until finish() (the library's helper thread serializes the VersionIndex)
+        return t, keep
 
     def index(self, tree: IngestTree, all_hashes, all_lens, all_chunks: int, local_offsets, local_part_first, local_chunks: int,
               version_index_out=None):
@@ -535,6 +537,7 @@ class Ingest:
         cap = 0 if version_index_out is None else (version_index_out.numel() if hasattr(version_index_out, "numel") else len(version_index_out))
         err = self.ctx.lib.dll.lthip_ingest_index(self.h, C.byref(tree), _ptr(all_hashes), _ptr(all_lens), all_chunks, _ptr(local_offsets),
                                                   _ptr(local_part_first), local_chunks, _ptr(version_index_out) or None, cap)
+        self._index_keep = (tree, all_hashes, all_lens, local_offsets, local_part_first, version_index_out)  # until finish()
         self.ctx._check(err, "lthip_ingest_index")
 
     def set_first_seen(self, first_index, unique_chunks: int):
@@ -551,6 +554,7 @@ class Ingest:
         res = IngestResult()
         err = self.ctx.lib.dll.lthip_ingest_finish(self.h, _ptr(store_index_out) or None, cap, C.byref(res))
         self.ctx._check(err, "lthip_ingest_finish")
+        self._index_keep = None
         return res
 
     def compressed_sizes(self, nblocks: int) -> np.ndarray:

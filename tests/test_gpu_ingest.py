@@ -37,7 +37,8 @@ def make_files(oracle, target):
     return files
 
 
-def rank_session(gpu, ref, files, target, world, rank, policy, codec, max_block, max_chunks, tag, all_lists=None, arena_bytes=None):
+def rank_session(gpu, ref, files, target, world, rank, policy, codec, max_block, max_chunks, tag, all_lists=None, arena_bytes=None,
+                 batch_bytes=0):
     """Chunk + hash the rank's jobs on the GPU; with all_lists (job -> (hashes, lens) of every job) run the session."""
     by_name = {n: d for n, d in files}
     paths, sizes, offs, perms, path_data = ref.tree_file_infos(files)
@@ -63,7 +64,7 @@ def rank_session(gpu, ref, files, target, world, rank, policy, codec, max_block,
     all_lens = torch.cat([all_lists[j][1] for j in range(part.job_count)]) if part.job_count else torch.zeros(0, dtype=torch.int32, device="cuda")
     job_first = np.concatenate([[0], np.cumsum([int(all_lists[j][0].numel()) for j in range(part.job_count)])]).astype(np.uint64)
     n_all = int(job_first[-1])
-    ing = Ingest(gpu, target, max_block, max_chunks, codec, compression_type=tag)
+    ing = Ingest(gpu, target, max_block, max_chunks, codec, compression_type=tag, batch_bytes=batch_bytes)
     tree, keep = Ingest.tree(sizes, offs, perms, path_data, part.job_asset, job_first, my_jobs=None if world == 1 else mine)
     vi = torch.zeros(gpu.lib.dll.lthip_version_index_size(len(sizes), n_all, n_all, len(path_data)) + 64, dtype=torch.uint8).pin_memory()
     ing.index(tree, all_hash, all_lens, n_all, d_off, d_first, total, vi if rank == 0 else None)
@@ -166,6 +167,27 @@ def test_ingest_session_single_rank_matches_reference(gpu, oracle, ref, target, 
     assert res.raw_bytes == int(us.astype(np.int64).sum()) and 0 < res.compressed_bytes == int(sess["comp"].astype(np.int64).sum())
     assert res.gathered_blocks > 0  # the duplicate / zero files leave holes: some blocks are not one byte range
     check_images(gpu, ref, sess, 0 if codec == "lz4" else 1, tag, max_block)
+
+
+@pytest.mark.parametrize("target,codec,max_block,max_chunks,batch", [(1024, "lz4", 262144, 16, 1 << 20), (4096, "zstd", 1 << 20, 64, 3 << 20),
+                                                                       (1024, "lz4", 65536, 1024, 1 << 18)])
+def test_ingest_session_packing_in_slices_is_the_packing_at_once(gpu, oracle, ref, target, codec, max_block, max_chunks, batch):
+    """A tree of more than two codec batches: lthip_ingest_index packs the blocks of the first batch from the head of the owned chunks'
+    lists (the rest of the lists arrives by the side stream), lthip_ingest_write the rest behind its first batch; the VersionIndex is
+    serialized by the helper thread meanwhile.  Same VersionIndex, StoreIndex and compressed sizes as the one-batch session."""
+    files = make_files(oracle, target)
+    tag = ref.lz4_type if codec == "lz4" else ref.zstd_default
+    probe = rank_session(gpu, ref, files, target, 1, 0, "range", codec, max_block, max_chunks, tag)
+    lists = {int(j): (probe["d_hash"][int(probe["first"][m]) : int(probe["first"][m + 1])], probe["d_len"][int(probe["first"][m]) : int(probe["first"][m + 1])])
+             for m, j in enumerate(probe["mine"])}
+    once = rank_session(gpu, ref, files, target, 1, 0, "range", codec, max_block, max_chunks, tag, lists, arena_bytes=96 << 20)
+    for arena in (96 << 20, 3 * max_block):  # batches bounded by the codec's batch size / by a small arena
+        sliced = rank_session(gpu, ref, files, target, 1, 0, "range", codec, max_block, max_chunks, tag, lists, arena_bytes=arena,
+                              batch_bytes=batch)
+        assert sliced["vi"] == once["vi"] and sliced["si"] == once["si"]
+        assert sliced["res"].blocks == once["res"].blocks and sliced["res"].raw_bytes == once["res"].raw_bytes
+        assert sliced["res"].compressed_bytes == once["res"].compressed_bytes and (sliced["comp"] == once["comp"]).all()
+        assert sliced["res"].gathered_blocks == once["res"].gathered_blocks
 
 
 @pytest.mark.parametrize("world,policy", [(2, "range"), (3, "lpt"), (4, "range"), (4, "mod")])
