@@ -21,6 +21,7 @@
 #include "index_kernels.h"
 
 #include <algorithm>
+#include <chrono>
 #include <thread>
 
 namespace
@@ -197,6 +198,37 @@ struct lthip_ingest
     void* vi_out;
 };
 
+// LTHIP_INGEST_TRACE=1: host time between the marks of lthip_ingest_index / _write, to stderr
+struct IngTrace
+{
+    bool on;
+    const char* what;
+    std::chrono::steady_clock::time_point t0, last;
+    char line[512];
+    size_t len;
+    explicit IngTrace(const char* w) : what(w), len(0)
+    {
+        static LthipEnvInt env{"LTHIP_INGEST_TRACE"};
+        on = env.get() > 0;
+        if (on)
+            t0 = last = std::chrono::steady_clock::now();
+    }
+    void mark(const char* name)
+    {
+        if (!on)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        if (len < sizeof line - 48)
+            len += (size_t)snprintf(line + len, sizeof line - len, " %s %.0f", name, std::chrono::duration<double, std::micro>(now - last).count());
+        last = now;
+    }
+    ~IngTrace()
+    {
+        if (on)
+            fprintf(stderr, "%s (us):%s | total %.0f\n", what, line, std::chrono::duration<double, std::micro>(last - t0).count());
+    }
+};
+
 static size_t codec_bound(const lthip_ingest* g, size_t n)
 {
     if (g->cfg.codec == LTHIP_CODEC_LZ4)
@@ -353,16 +385,19 @@ static int ingest_blocks_done(lthip_ingest* g)
         std::vector<uint64_t> o(nb);
         std::vector<uint32_t> l(nb);
         uint32_t max_len = 0;
+        uint64_t leaves = 0; // (1 KiB leaves of the hash arrays: known here, so the hash launcher reads nothing back -- the stream holds
+                             // the first codec batch by now)
         for (size_t b = 0; b < nb; ++b)
         {
             o[b] = g->b_first[b] * 8u;
             l[b] = (uint32_t)(g->b_first[b + 1] - g->b_first[b]) * 8u;
             max_len = std::max(max_len, l[b]);
+            leaves += l[b] ? (l[b] + 1023u) >> 10 : 1u;
         }
         if ((err = lthip_stage_upload(ctx, g->d_boff.p, o.data(), nb * 8, s)) || (err = lthip_stage_upload(ctx, g->d_blen.p, l.data(), nb * 4, s)))
             return err;
-        if ((err = lthip_hash_ranges(ctx, g->d_mu_hash.p, nb, (const uint64_t*)g->d_boff.p, (const uint32_t*)g->d_blen.p, max_len,
-                                     (uint64_t*)g->d_bhash.p)))
+        if ((err = lthip_hash_ranges_known(ctx, g->d_mu_hash.p, nb, (const uint64_t*)g->d_boff.p, (const uint32_t*)g->d_blen.p, max_len, leaves,
+                                           (uint64_t*)g->d_bhash.p)))
             return err;
         LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_bhash.p, g->d_bhash.p, nb * 8, hipMemcpyDeviceToHost, s));
     }
@@ -499,6 +534,7 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     (void)ingest_vi_join(g); // (an index that was never finished: its helper reads what this call is about to replace ...
     (void)hipEventSynchronize(g->ev_hashes); // ... and so does the side stream)
+    IngTrace tr("lthip_ingest_index");
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t)all_chunks, nl = (uint32_t)local_chunks, na = t->asset_count;
     const bool all_mine = t->my_jobs == nullptr;
@@ -541,6 +577,7 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
     else if (nl != n)
         return lthip_fail(ctx, EINVAL, "lthip_ingest_index", "without my_jobs the local arrays are the global ones");
 
+    tr.mark("checks");
     int err;
     if ((err = reserve_dev(ctx, g->d_first, (size_t)n * 4)) || (err = reserve_dev(ctx, g->d_isfirst, (size_t)n * 4)) ||
         (err = reserve_dev(ctx, g->d_rank, ((size_t)n + 1) * 4)) || (err = reserve_dev(ctx, g->d_idx, (size_t)n * 4)) ||
@@ -563,6 +600,7 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
         (err = reserve_dev(ctx, g->d_blen, (size_t)nl * 4)) || (err = reserve_dev(ctx, g->d_comp, (size_t)nl * 4)) ||
         (err = reserve_dev(ctx, g->d_sum, 8)))
         return err;
+    tr.mark("reserve");
     uint64_t* d_counts = (uint64_t*)g->d_counts.p; // [0] distinct hashes of all ranks, [1] chunks this rank writes (u32 in the low half)
     volatile uint64_t* h_counts = (volatile uint64_t*)g->h_counts.p;
 
@@ -619,8 +657,10 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
         LTHIP_CHECK(ctx, hipMemcpyAsync((void*)(h_counts + 3), (const uint32_t*)g->d_owned.p + (nl - 1), 4, hipMemcpyDeviceToHost, s));
     }
     LTHIP_CHECK(ctx, hipMemcpyAsync((void*)h_counts, d_counts, 8, hipMemcpyDeviceToHost, s));
+    tr.mark("queued");
     LTHIP_CHECK(ctx, hipEventRecord(g->ev_counts, s));
     LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_counts));
+    tr.mark("counts");
     const uint64_t unique = h_counts[0];
     const uint32_t nm = nl ? (uint32_t)(h_counts[2] & 0xFFFFFFFFu) + (uint32_t)(h_counts[3] & 0xFFFFFFFFu) : 0u;
     g->unique_all = unique;
@@ -679,6 +719,7 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
         LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_mu_hash.p, g->d_mu_hash.p, (size_t)nm * 8, hipMemcpyDeviceToHost, s2)); // StoreIndex, read in finish
     LTHIP_CHECK(ctx, hipEventRecord(g->ev_hashes, s2));
 
+    tr.mark("lists");
     // ---- ... then the VersionIndex sections: 1.2-2.4 ms of host work on the 64 GiB tree (the tables of 65 536 assets, the tag column
     // of 2.1 M chunks) plus copies and two small hash launches, none of which the rest of the session waits for: a helper thread with a
     // context of its own does them (LTHIP_INGEST_VI_THREAD=0: here and now, on the session's context); lthip_ingest_finish collects it.
@@ -712,6 +753,7 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
             return err;
     }
 
+    tr.mark("helper");
     // ---- greedy packing of the owned chunks (Longtail_CreateStoreIndex :6801-6860): here the blocks of the first codec batch ----
     LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_lens));
     g->b_first.clear();
@@ -724,6 +766,7 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
     g->blocks_done = false;
     g->written = false;
     ingest_pack(g, g->cfg.batch_bytes + 2ull * g->cfg.max_block_size);
+    tr.mark("pack");
     g->res.chunks_all = n;
     g->res.unique_all = unique;
     g->res.chunks_local = nl;
@@ -742,6 +785,7 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
 {
     if (!g || !g->indexed || (g->n_mine && (!d_data || !d_arena)))
         return EINVAL;
+    IngTrace tr("lthip_ingest_write");
     lthip_ctx* ctx = g->ctx;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -791,6 +835,7 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
         }
         if (err)
             return err;
+        tr.mark("batch");
         const size_t cnt = b1 - b0;
         // ---- block assembly (WriteContentBlockJob, :4640-4721) only for blocks that are not one byte range of the data ----
         if (gather_chunks)
@@ -898,9 +943,11 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
             if (pass == 1)
                 gathered_blocks += k;
         }
+        tr.mark("codec");
         // ---- (first batch: the codec has work now; the rest of the packing and all block hashes) ----
         if ((err = ingest_blocks_done(g)))
             return err;
+        tr.mark("blocks");
         // ---- BlockIndex + [raw][compressed] around the payloads (:4111-4150; compressblockstore.c:103-139) ----
         if ((err = reserve_dev(ctx, g->d_bfirst, (cnt + 1) * 4)) || (err = reserve_dev(ctx, g->d_braw, cnt * 4)) ||
             (err = reserve_dev(ctx, g->d_bimg, cnt * 8)) || (err = reserve_dev(ctx, g->d_btag, cnt * 4)))

@@ -834,3 +834,17 @@ extern "C" int lthip_hash_ranges(lthip_ctx* ctx, const void* d_data, uint64_t ra
     // leaf bound unknown without reading the lengths: 0 => the launcher sizes the grid from the scanned total
     return lthip_launch_blake3(ctx, (const uint8_t*)d_data, d_offsets, d_lens, nullptr, range_count, 0, max_len, d_hashes);
 }
+
+// ... for a caller that has the lengths on the host: `leaf_total` = sum over the ranges of max(1, ceil(len / 1024)).  With ranges of
+// at most 256 KiB nothing is read back and the stream is not waited for (lthip_hash_ranges stalls the caller until everything queued
+// before it has run).
+int lthip_hash_ranges_known(lthip_ctx* ctx, const void* d_data, uint64_t range_count, const uint64_t* d_offsets, const uint32_t* d_lens,
+                            uint32_t max_len, uint64_t leaf_total, uint64_t* d_hashes)
+{
+    if (!ctx || (range_count && (!d_offsets || !d_lens || !d_hashes)) || range_count > 0xFFFFFFF0ull)
+        return EINVAL;
+    if (range_count == 0)
+        return 0;
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return lthip_launch_blake3(ctx, (const uint8_t*)d_data, d_offsets, d_lens, nullptr, range_count, leaf_total, max_len, d_hashes);
+}

@@ -212,6 +212,9 @@ int lthip_launch_blake3(lthip_ctx* ctx, const uint8_t* d_data, const uint64_t* d
                         const uint32_t* d_count, uint64_t count_bound, uint64_t leaf_bound, uint64_t max_len,
                         uint64_t* d_hashes);
 
+int lthip_hash_ranges_known(lthip_ctx* ctx, const void* d_data, uint64_t range_count, const uint64_t* d_offsets, const uint32_t* d_lens,
+                            uint32_t max_len, uint64_t leaf_total, uint64_t* d_hashes); // lthip_hash_ranges without its read-back
+
 int lthip_launch_blake3_stream_batch(lthip_ctx* ctx, const void* d_data, uint32_t leaf0, uint32_t* d_stack, uint32_t depth_in, uint32_t merges);
 int lthip_launch_blake3_stream_final(lthip_ctx* ctx, const void* d_tail, uint32_t tail_len, uint32_t leaf0, const uint32_t* d_stack,
                                      uint32_t depth, uint64_t* d_out);

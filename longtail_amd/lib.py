@@ -578,6 +578,16 @@ class Plan:
         self.capacity = int(ctx.lib.dll.lthip_plan_chunk_capacity(h))
         self.total_bytes = int(s.sum()) if len(s) else 0
 
+    def reaim(self, part_offsets, part_sizes):
+        """The plan aimed at another set of parts (lthip_plan_reaim): no more parts / 16 KiB tiles than it was created with; the part
+        tables are recomputed and rewritten on the context's stream, nothing is allocated or waited for."""
+        o, s = _u64arr(part_offsets), _u64arr(part_sizes)
+        assert len(o) == len(s)
+        self.ctx._check(self.ctx.lib.dll.lthip_plan_reaim(self.ctx.h, self.h, len(o), o.ctypes.data, s.ctypes.data), "lthip_plan_reaim")
+        self.nparts = len(o)
+        self.capacity = int(self.ctx.lib.dll.lthip_plan_chunk_capacity(self.h))
+        self.total_bytes = int(s.sum()) if len(s) else 0
+
     def close(self):
         if getattr(self, "h", None) and getattr(self.ctx, "h", None):
             self.ctx.lib.dll.lthip_plan_destroy(self.ctx.h, self.h)
