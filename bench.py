@@ -256,6 +256,7 @@ class Bench:
         out_lens = self.buf("lens", cap * 4, torch.int32)
         out_hash = self.buf("hash", cap * 8, torch.int64)
         out_first = self.buf("first", (len(mine) + 1) * 4, torch.int32)
+        h_first = self.buf("first_host", (len(mine) + 1) * 4, torch.int32, pinned=True)
         batch_bytes = int(args.batch_gib * (1 << 30))
         limit = args.block_size + args.block_size // 10
         arena_bytes = batch_bytes + batch_bytes // 128 + (batch_bytes // args.block_size + 4) * (16384 + 64) + 2 * (limit + limit // 128 + 16384)
@@ -274,7 +275,13 @@ class Bench:
             else:
                 plan.reaim(p_off, p_size)
                 step_plan = plan
-            total, _, _, _, _ = ctx.chunk_hash(step_plan, data, outputs=(out_offs, out_lens, out_hash, out_first), sync=True)
+            # (the part -> first chunk table is what the host builds the tree's job table from: its copy to pinned memory is queued
+            # behind the kernels, so that the step's one wait after chunk + hash delivers it together with the chunk count)
+            ctx.chunk_hash(step_plan, data, outputs=(out_offs, out_lens, out_hash, out_first), sync=False)
+            ctx._check(self.lib.dll.lthip_copy_d2h(ctx.h, h_first.data_ptr(), out_first.data_ptr(), (len(mine) + 1) * 4), "lthip_copy_d2h")
+            ctx.sync()
+            first_host = h_first.numpy()[: len(mine) + 1].view(np.uint32)
+            total = int(first_host[len(mine)]) if len(mine) else 0
             if new_plan:
                 step_plan.close()
             t1 = time.perf_counter()
@@ -289,7 +296,7 @@ class Bench:
                     ing.set_first_seen(first_all, uniq_all)
             else:
                 all_hash, all_lens = out_hash, out_lens
-                job_first = out_first[: len(mine) + 1].cpu().numpy().view(np.uint32).astype(np.uint64)
+                job_first = first_host.astype(np.uint64)
                 my_jobs = None
             n_all = int(job_first[-1])
             t2 = time.perf_counter()
