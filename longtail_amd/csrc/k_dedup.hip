@@ -42,30 +42,35 @@ __global__ void k_dedup_insert(const uint64_t* __restrict__ hashes, uint64_t n, 
                                const uint32_t* __restrict__ ordinals)
 {
     const uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= n)
-        return;
-    const uint64_t h = hashes[pos];
-    const uint32_t i = ordinals ? ordinals[pos] : (uint32_t)pos;
-    if (h == EMPTY_KEY)
+    bool claimed = false; // this insert claimed a slot: one more distinct hash
+    if (pos < n)
     {
-        if (atomicMin(special, i) == 0xFFFFFFFFu && distinct)
-            atomicAdd(distinct, 1ull);
-        return;
-    }
-    uint64_t slot = mix64(h) & mask;
-    for (;;)
-    {
-        const unsigned long long prev =
-            atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]), (unsigned long long)EMPTY_KEY, (unsigned long long)h);
-        if (prev == EMPTY_KEY || prev == h)
+        const uint64_t h = hashes[pos];
+        const uint32_t i = ordinals ? ordinals[pos] : (uint32_t)pos;
+        if (h == EMPTY_KEY)
+            claimed = atomicMin(special, i) == 0xFFFFFFFFu;
+        else
         {
-            atomicMin(&idx[slot], i);
-            if (distinct && prev == EMPTY_KEY)
-                atomicAdd(distinct, 1ull); // this insert claimed the slot: one more distinct hash
-            return;
+            uint64_t slot = mix64(h) & mask;
+            for (;;)
+            {
+                const unsigned long long prev =
+                    atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]), (unsigned long long)EMPTY_KEY, (unsigned long long)h);
+                if (prev == EMPTY_KEY || prev == h)
+                {
+                    atomicMin(&idx[slot], i);
+                    claimed = prev == EMPTY_KEY;
+                    break;
+                }
+                slot = (slot + 1) & mask;
+            }
         }
-        slot = (slot + 1) & mask;
     }
+    // one add per wave (measured: not what the kernel's time is -- 0.45 ms for 2.15 M hashes either way: the CAS and the minimum are
+    // 4.3 M device-scope atomics on random slots)
+    const uint64_t b = __builtin_amdgcn_ballot_w64(claimed);
+    if (distinct && b && (threadIdx.x & 63) == 0)
+        atomicAdd(distinct, (unsigned long long)__builtin_popcountll(b));
 }
 
 __global__ void k_dedup_lookup(const uint64_t* __restrict__ hashes, uint64_t i0, uint64_t n, const uint64_t* __restrict__ keys,
