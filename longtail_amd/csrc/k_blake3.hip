@@ -107,9 +107,19 @@ __global__ void k_leaf_counts(const uint32_t* __restrict__ lens, uint64_t bound,
 // ---------------------------------------------------------------------------------------------------
 // leaves
 // ---------------------------------------------------------------------------------------------------
-constexpr int PW = 1024;     // parents kernel: window of leaf slots per workgroup
+#ifndef LTHIP_B3_PW
+#define LTHIP_B3_PW 1024
+#endif
+constexpr int PW = LTHIP_B3_PW; // parents kernel: window of leaf slots per workgroup (a power of two)
 constexpr int PW_MAXN = 256; // leaves of the largest range (small trees: <= 256 KiB)
 constexpr int PW_SLOTS = PW + PW_MAXN;
+#ifndef LTHIP_B3_PW_THREADS
+#define LTHIP_B3_PW_THREADS 512
+#endif
+constexpr int PW_THREADS = LTHIP_B3_PW_THREADS; // threads of a parents workgroup (a power of two).  Measured on the 64 GiB tree (same box,
+// builds side by side through LTHIP_LIB_PATH): windows of 256 / 512 / 1024 / 2048 slots with 256 threads 4.19 / 3.54 / 3.12 / 5.55 ms
+// (2048: two workgroups per CU); 1024 slots with 256 / 512 / 1024 threads 3.12 / 2.80 / 3.19 ms -- 512 threads have one merge each
+// on the first level and three workgroups of them are 24 waves per CU.
 
 __global__ __launch_bounds__(256) void k_blake3_leaves(const uint8_t* __restrict__ data,
                                                        const uint64_t* __restrict__ offsets,
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(B3S_LEAVES) void k_blake3_stream_final(const uint8_
 // compacted into a list so that every lane of every wave has one, instead of one thread walking one tree serially with
 // its 2 x 32-byte loads uncoalesced (k_blake3_parents_small).  Left-heavy tree as above: the node of leaves [k, k + 2 st)
 // lives at slot k; a level's merges read slots (k, k + st) and write slot k, so they are independent.
-__global__ __launch_bounds__(256) void k_blake3_parents_window(const uint32_t* __restrict__ leaf_prefix, uint64_t count_bound,
+__global__ __launch_bounds__(PW_THREADS) void k_blake3_parents_window(const uint32_t* __restrict__ leaf_prefix, uint64_t count_bound,
                                                                const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ cvs,
                                                                const uint32_t* __restrict__ win_first, uint64_t* __restrict__ hashes)
 {
@@ -454,14 +464,14 @@ __global__ __launch_bounds__(256) void k_blake3_parents_window(const uint32_t* _
     }
     {
         const uint4* g = reinterpret_cast<const uint4*>(cvs) + (uint64_t)wbase * 2u;
-        for (uint32_t v = tid; v < nslots * 2u; v += 256)
+        for (uint32_t v = tid; v < nslots * 2u; v += PW_THREADS)
             s_cv[v] = g[v];
     }
     __syncthreads();
     if (nch * 8u < nslots)
     {
         // few large ranges: a wave per range
-        for (uint32_t j = tid >> 6; j < nch; j += 4)
+        for (uint32_t j = tid >> 6; j < nch; j += PW_THREADS / 64)
         {
             const uint32_t p0 = leaf_prefix[c_lo + j], n = leaf_prefix[c_lo + j + 1] - p0;
             for (uint32_t k = lane; k < n; k += 64)
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(256) void k_blake3_parents_window(const uint32_t* _
     }
     else
     {
-        for (uint32_t j = tid; j < nch; j += 256)
+        for (uint32_t j = tid; j < nch; j += PW_THREADS)
         {
             const uint32_t p0 = leaf_prefix[c_lo + j], n = leaf_prefix[c_lo + j + 1] - p0;
             for (uint32_t k = 0; k < n; ++k)
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(256) void k_blake3_parents_window(const uint32_t* _
     uint32_t rot = blockIdx.x; // which wave takes the first 64 merges of a level: rotates, or the SIMD of wave 0 does all the thin levels
     for (uint32_t st = 1; st < maxn; st <<= 1, ++rot)
     {
-        for (uint32_t s0 = 0; s0 < nslots; s0 += 256)
+        for (uint32_t s0 = 0; s0 < nslots; s0 += PW_THREADS)
         {
             const uint32_t sl = s0 + (uint32_t)tid;
             const uint32_t info = sl < nslots ? s_info[sl] : 0u;
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(256) void k_blake3_parents_window(const uint32_t* _
         }
         __syncthreads();
         const uint32_t nm = s_cnt;
-        for (uint32_t mi = ((uint32_t)tid + 64u * rot) & 255u; mi < nm; mi += 256)
+        for (uint32_t mi = ((uint32_t)tid + 64u * rot) & (uint32_t)(PW_THREADS - 1); mi < nm; mi += PW_THREADS)
         {
             const uint32_t sl = s_list[mi];
             const uint32_t n = s_info[sl] >> 16;
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(256) void k_blake3_parents_window(const uint32_t* _
             s_cnt = 0;
         __syncthreads();
     }
-    for (uint32_t j = tid; j < nch; j += 256)
+    for (uint32_t j = tid; j < nch; j += PW_THREADS)
     {
         const uint4 r = s_cv[2u * (leaf_prefix[c_lo + j] - wbase)];
         hashes[c_lo + j] = (uint64_t)r.x | ((uint64_t)r.y << 32);
@@ -630,7 +640,7 @@ int lthip_launch_blake3(lthip_ctx* ctx, const uint8_t* d_data, const uint64_t* d
             hipLaunchKernelGGL(k_blake3_parents_small, dim3((uint32_t)div_up_u64(count_bound, 256)), dim3(256), 0, ctx->stream,
                                d_lens, (const uint32_t*)lp, count_bound, d_count, (uint32_t*)cv, d_hashes);
         else
-            hipLaunchKernelGGL(k_blake3_parents_window, dim3((uint32_t)div_up_u64(leaf_bound, PW)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_blake3_parents_window, dim3((uint32_t)div_up_u64(leaf_bound, PW)), dim3(PW_THREADS), 0, ctx->stream,
                                (const uint32_t*)lp, count_bound, d_count, (const uint32_t*)cv, (const uint32_t*)wf, d_hashes);
         LTHIP_LAUNCH_CHECK(ctx);
     }

@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-_LIB_PATH = Path(__file__).resolve().parent / "liblongtail_hip.so"
+# (LTHIP_LIB_PATH: another build of the same sources next to the in-tree one, for same-box A/B runs of compile-time constants)
+_LIB_PATH = Path(os.environ["LTHIP_LIB_PATH"]) if os.environ.get("LTHIP_LIB_PATH") else Path(__file__).resolve().parent / "liblongtail_hip.so"
 
 KERNEL_IDS = {
     "buzhash": 0,
