@@ -1667,6 +1667,9 @@ __device__ __forceinline__ void wg_copy(uint8_t* __restrict__ dst, const uint8_t
 constexpr int K6_THREADS = 256;
 
 // one workgroup per window group: its (up to gunits) units are moved into place one after the other
+#ifdef LTHIP_K6_WAVES
+__attribute__((amdgpu_waves_per_eu(LTHIP_K6_WAVES, LTHIP_K6_WAVES)))
+#endif
 __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* __restrict__ src,
                                                                  const Lz4Block* __restrict__ blocks, uint32_t nblocks,
                                                                  uint32_t SEG, const uint8_t* __restrict__ streams,
@@ -1984,7 +1987,15 @@ static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_
         return err;
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const uint32_t copy_grid = (uint32_t)ncu * 8u; // persistent over the work list
+    // The stitch copy is persistent over the work list with a fixed stride, so its grid has to be RESIDENT at once: a multiple of what
+    // the kernel's registers let a CU hold (72 VGPRs: 7 workgroups of 4 waves, not 8 -- with 8 per CU the eighth ran its share of the list
+    // after the others were through: 23.9 instead of 18.1 ms on the compressible 64 GiB tree; twice that many, half the share each, evens
+    // the tail: 17.8).  LTHIP_LZ4_STITCH_WGS = workgroups per CU.
+    static LthipEnvInt env_swg{"LTHIP_LZ4_STITCH_WGS"};
+    int stitch_wgs = 7;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&stitch_wgs, k_lz4_stitch_copy, K6_THREADS, 0) != hipSuccess || stitch_wgs < 1)
+        stitch_wgs = 7;
+    const uint32_t copy_grid = (uint32_t)ncu * (env_swg.get() > 0 ? (uint32_t)env_swg.get() : 2u * (uint32_t)stitch_wgs);
     hipStream_t s2 = ctx->stream;
     if (overlap)
     {
