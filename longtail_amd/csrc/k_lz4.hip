@@ -738,7 +738,13 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     const uint32_t grp_end = listed ? worklist[0] : (MODE == 1 ? grp0 + ngroups : grp0 + blockIdx.x + 1u);
     const uint32_t grp_step = MODE == 1 ? gridDim.x : 1u;
     [[maybe_unused]] uint32_t sh_gen = 0; // SH: tag of the group's entries in the shared table (upper 16 bits), counting down
-    for (uint32_t gidx = blockIdx.x + (listed ? 0u : grp0); gidx < grp_end; gidx += grp_step)
+    // The listed groups differ in what they cost (the classes of the data: a group of "lines" takes a third of a group of "tokens"), so
+    // the workgroups DRAW the entries of the list -- the first gridDim.x by their index, then a ticket each (the word behind the
+    // flags, zero at launch), drawn one group ahead because the next group's bytes are fetched during the parse.  With the fixed stride
+    // the slowest of 256 workgroups set the time of every launch (LTHIP_LZ4_DBG bit 27 keeps the stride).
+    const bool ticketed = listed && !(dbg & (1u << 27));
+    uint32_t next_gidx = 0;
+    for (uint32_t gidx = blockIdx.x + (listed ? 0u : grp0); gidx < grp_end; gidx = ticketed ? next_gidx : gidx + grp_step)
     {
     if constexpr (SH != 0)
     {
@@ -838,14 +844,19 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             if (v * 64 + lane < TAB * 2 / 16)
                 tv[v * 64 + lane] = e;
         if (tid == 0)
+        {
             *flag = 0u;
+            if (MODE == 1 && ticketed)
+                flag[1] = gridDim.x + atomicAdd(worklist + 2u * ngroups + 1u, 1u);
+        }
     }
     __syncthreads();
     K5P(0);
     if constexpr (MODE == 1)
     {
         // the next group of this workgroup: its loads are in flight during the parse below
-        const uint32_t nidx = gidx + grp_step;
+        const uint32_t nidx = ticketed ? flag[1] : gidx + grp_step;
+        next_gidx = nidx;
         have_pre = false;
         if (nidx < grp_end && !(dbg & 4096u))
         {
@@ -1120,7 +1131,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
 #undef LT_REPLAY
             }
             else if (*flag == 0u && more && !(dbg & 16u))
-                nfail += (dbg >> 8) ? (dbg >> 8) : 24u; // nobody in the 32 KiB group matched anything in its probe batches: one twin round skims the rest
+                nfail += 24u; // nobody in the 32 KiB group matched anything in its probe batches: one twin round skims the rest
             met = true;
         }
         if (!more)

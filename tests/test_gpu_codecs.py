@@ -775,3 +775,21 @@ def test_lane_parser_shared_table_tag_runs_out(gpu, oracle, monkeypatch):
         assert len(a) == len(b) and (a == b).all()
         n, out = oracle.lz4_decompress(b, len(r))
         assert n == len(r) and (out[:n] == r).all()
+
+
+def test_lane_parser_tickets_give_the_payloads_of_the_fixed_stride(gpu, oracle, monkeypatch):
+    """The lane parser's workgroups DRAW the listed groups (a ticket each, one group ahead) instead of striding over the list; a
+    payload is a function of its block, whoever parsed its groups and in which order: blocks that are no multiples of the 64 KiB
+    groups, the block list forwards and backwards, tickets and LTHIP_LZ4_DBG bit 27 (the fixed stride) -- the same bytes."""
+    raws = [oracle.synth((6 << 20) - 4099 * k - 1, 30 + k, (1, 11, 12, 13)[k % 4]) for k in range(12)]
+    drawn, _ = gpu_lz4(gpu, raws)
+    back, _ = gpu_lz4(gpu, raws[::-1])
+    monkeypatch.setenv("LTHIP_LZ4_DBG", str(1 << 27))
+    gpu.lib.dll.lthip_debug_reload_env()
+    strided, _ = gpu_lz4(gpu, raws)
+    monkeypatch.delenv("LTHIP_LZ4_DBG")
+    gpu.lib.dll.lthip_debug_reload_env()
+    for a, b, c, r in zip(drawn, back[::-1], strided, raws):
+        assert len(a) == len(b) == len(c) and (a == b).all() and (a == c).all()
+        n, out = oracle.lz4_decompress(a, len(r))
+        assert n == len(r) and (out[:n] == r).all()
