@@ -273,14 +273,26 @@ __global__ __launch_bounds__(64, 4) void k_zstd_encode(const ZBlock* __restrict_
                                                     const ZbUnitMeta* __restrict__ unit_meta,
                                                     const uint8_t* __restrict__ unit_lits, const uint64_t* __restrict__ unit_recs,
                                                     uint8_t* __restrict__ work, uint8_t* __restrict__ enc,
-                                                    uint32_t* __restrict__ enc_size, uint16_t* __restrict__ sub_sizes)
+                                                    uint32_t* __restrict__ enc_size, uint16_t* __restrict__ sub_sizes,
+                                                    uint32_t* __restrict__ ticket)
 {
     __shared__ ZbShared sh;
     ZbScratch sc;
     uint8_t* w = work + (uint64_t)blockIdx.x * Z_WORK_STRIDE;
     sc.seqs = reinterpret_cast<uint64_t*>(w);
     sc.sbits = reinterpret_cast<uint16_t*>(w + Z_WORK_SEQS);
-    for (uint32_t zb = blockIdx.x; zb < npieces; zb += gridDim.x)
+    // The pieces differ in what they cost (raw and RLE pieces next to nothing, pieces full of short matches the most) and a wave gets
+    // only ~16 of them per launch: the waves DRAW their pieces (`ticket`, zero at launch; the first gridDim.x by index) -- with a fixed
+    // stride the unluckiest of 4096 waves set the launch's time.  ticket == nullptr (LTHIP_ZSTD_TICKETS=0): the stride.
+    auto next_piece = [&](uint32_t zb) -> uint32_t {
+        if (!ticket)
+            return zb + gridDim.x;
+        uint32_t t = 0;
+        if (threadIdx.x == 0)
+            t = atomicAdd(ticket, 1u);
+        return gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    };
+    for (uint32_t zb = blockIdx.x; zb < npieces; zb = next_piece(zb))
     {
         uint32_t lo = 0, hi = nblocks;
         while (hi - lo > 1)
@@ -448,10 +460,14 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
         return err;
     if (nzb)
     {
+        static LthipEnvInt env_tickets{"LTHIP_ZSTD_TICKETS"};
+        uint32_t* d_ticket = env_tickets.get() == 0 ? nullptr : (uint32_t*)d_encsz + nzb + 1; // (the size list has four spare words)
+        if (d_ticket)
+            LTHIP_CHECK(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
         LaunchTimer t(ctx, LTHIP_K_ZSTD_ENC);
         hipLaunchKernelGGL(k_zstd_encode, dim3(nwg), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks, block_count, (uint32_t)nzb,
                            (const uint8_t*)d_src, (uint8_t*)d_rle, (const ZbUnitMeta*)d_meta, (const uint8_t*)d_lits, (const uint64_t*)d_recs,
-                           (uint8_t*)d_work, (uint8_t*)d_enc, (uint32_t*)d_encsz, sub ? (uint16_t*)d_sub : (uint16_t*)nullptr);
+                           (uint8_t*)d_work, (uint8_t*)d_enc, (uint32_t*)d_encsz, sub ? (uint16_t*)d_sub : (uint16_t*)nullptr, d_ticket);
         LTHIP_LAUNCH_CHECK(ctx);
     }
     LaunchTimer t(ctx, LTHIP_K_OTHER);
