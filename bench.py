@@ -83,6 +83,121 @@ def make_tree(kind_of_tree: str, total_bytes: int, file_bytes: int):
     return dict(sizes=sizes, path_data=path_data, path_offsets=path_offsets, perms=np.full(n, 0o644, np.uint16), nfiles=n)
 
 
+def plain_comm(lib, ctx, rank, world, idfile=None, timeout_s=120):
+    """The torch-free handshake (tools/run8.sh, --launch plain): rank 0 makes the communicator id (lthip_comm_unique_id) and publishes
+    it by an atomic rename, the others wait for the file, every rank creates its communicator with it (lthip_comm_create returns
+    when all ranks are there).  `ctx` None: the shared-memory transport with host pointers (tests without a GPU)."""
+    from longtail_amd.lib import Comm
+
+    idfile = idfile or os.environ.get("LTHIP_COMM_ID_FILE", "/tmp/lthip_comm_id")
+    if rank == 0:
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(Comm.unique_id(lib))
+        os.replace(idfile + ".tmp", idfile)
+    t0 = time.time()
+    while not os.path.exists(idfile):
+        if time.time() - t0 > timeout_s:
+            raise SystemExit(f"rank {rank}: no communicator id in {idfile} after {timeout_s} s")
+        time.sleep(0.01)
+    return Comm(ctx, world, rank, open(idfile, "rb").read(), lib=lib)
+
+
+def handshake_only(args):
+    """--handshake-only: everything a plain launch does BEFORE the first kernel -- the id file, lthip_comm_create, a barrier, the
+    reductions bench.py makes (max / sum through an all-gather) and one all-to-all -- and a JSON line from rank 0.  With
+    LTHIP_COMM_TRANSPORT=shm it needs no GPU (tests/test_comm_shm.py); on an N-GPU node it is the 10-second check that RCCL sees N
+    ranks before a lease is spent on the measurement."""
+    import torch
+
+    from longtail_amd.lib import Context, load
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    lib = load()
+    shm = os.environ.get("LTHIP_COMM_TRANSPORT") == "shm"
+    ctx = None
+    if torch.cuda.is_available() and lib.device_count() > 0:
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        dev = local % torch.cuda.device_count() if shm else local
+        torch.cuda.set_device(dev)
+        ctx = Context(dev)
+    elif not shm:
+        raise SystemExit("no GPU: the handshake needs RCCL's devices (LTHIP_COMM_TRANSPORT=shm is the stand-in)")
+    device = "cuda" if ctx is not None else "cpu"
+    comm = plain_comm(lib, ctx, rank, world)
+    info = comm.info()
+    vals = torch.tensor([float(rank + 1), 10.0 * (rank + 1)], dtype=torch.float64, device=device)
+    g = comm.allgather(vals).view(world, -1)
+    comm.sync()
+    ok = bool(g[:, 0].max().item() == world and g[:, 1].sum().item() == 10.0 * world * (world + 1) / 2)
+    # all-to-all: rank r sends (r + 1) * (p + 1) copies of the value 1000 * r + p to rank p
+    sc = [(rank + 1) * (p + 1) for p in range(world)]
+    rc = [(p + 1) * (rank + 1) for p in range(world)]
+    send = torch.cat([torch.full((sc[p],), 1000 * rank + p, dtype=torch.int64, device=device) for p in range(world)])
+    recv = comm.alltoallv(send, sc, rc)
+    comm.sync()
+    want = torch.cat([torch.full((rc[p],), 1000 * p + rank, dtype=torch.int64, device=device) for p in range(world)])
+    ok = ok and bool(torch.equal(recv, want))
+    oks = comm.allgather(torch.tensor([1 if ok else 0], dtype=torch.int32, device=device))
+    comm.sync()
+    all_ok = bool(oks.min().item() == 1)
+    comm.close()
+    if rank == 0:
+        print(json.dumps({"handshake": all_ok, "n_gpus": world, "comm": info, "device": device}))
+    if not all_ok:
+        raise SystemExit(1)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here.  --launch torch (default) gives them the
+    environment torch.distributed.run would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; collectives = RCCL through
+    torch.distributed), --launch plain the one of tools/run8.sh (no torch.distributed; every collective through the C ABI's
+    lthip_comm_*).  Rank 0's stdout is this process's; any rank failing stops the others and fails the run -- a line is printed by
+    N ranks or not at all."""
+    import socket
+    import subprocess
+    import tempfile
+
+    n = args.gpus
+    env = dict(os.environ, WORLD_SIZE=str(n), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    idfile = None
+    if args.launch == "plain":
+        idfile = tempfile.mktemp(prefix="lthip_comm_id.", dir="/tmp")
+        env.update(LONGTAIL_LAUNCH="plain", LTHIP_COMM_ID_FILE=idfile)
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n))
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), *sys.argv[1:]], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, pending = 0, set(range(n))
+    try:
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()  # exactly the processes started above
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        if idfile and os.path.exists(idfile):
+            os.unlink(idfile)
+    return rc
+
+
 class Bench:
     """Device buffers shared by the configurations measured in one process."""
 
@@ -96,20 +211,27 @@ class Bench:
         self.rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        if self.world != args.gpus and self.world > 1:
+        if self.world != args.gpus:
+            # (main() starts the ranks itself when WORLD_SIZE is unset; a line whose n_gpus is not --gpus is never printed)
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
         self.lib = load()
         if not torch.cuda.is_available() or self.lib.device_count() == 0:
             raise SystemExit("bench.py needs a GPU and liblongtail_hip.so: there is no CPU fallback")
         # LONGTAIL_DIST_BACKEND=gloo runs the multi-rank flow with all ranks on the GPUs that exist (rank % device_count) and the
-        # exchange staged through host memory: a functional check of the N>1 path on a 1-GPU box, not a measurement
+        # exchange staged through host memory: a functional check of the N>1 path on a 1-GPU box, not a measurement.  The same for
+        # the torch-free launch: LTHIP_COMM_TRANSPORT=shm (the C ABI's shared-memory stand-in for RCCL, comm.hip)
         self.backend = os.environ.get("LONGTAIL_DIST_BACKEND", "nccl")
-        dev_index = local_rank % torch.cuda.device_count() if self.backend != "nccl" else local_rank
+        self.plain = self.world > 1 and os.environ.get("LONGTAIL_LAUNCH") == "plain"
+        stand_in = self.backend != "nccl" or (self.plain and os.environ.get("LTHIP_COMM_TRANSPORT") == "shm")
+        if self.world > 1 and not stand_in and torch.cuda.device_count() < self.world:
+            raise SystemExit(f"--gpus {self.world} but this node has {torch.cuda.device_count()} GPU(s): one process per GPU "
+                             "(functional stand-ins on fewer GPUs: LONGTAIL_DIST_BACKEND=gloo, or LONGTAIL_LAUNCH=plain LTHIP_COMM_TRANSPORT=shm)")
+        dev_index = local_rank % torch.cuda.device_count() if stand_in else local_rank
         torch.cuda.set_device(dev_index)
         self.dev = torch.device("cuda", dev_index)
-        # LONGTAIL_LAUNCH=plain (tools/run8.sh): N processes started by a shell loop, no torch.distributed at all -- the collectives
-        # are the C ABI's (lthip_comm_* = RCCL, comm.hip), the communicator id travels through a file
-        self.plain = self.world > 1 and os.environ.get("LONGTAIL_LAUNCH") == "plain"
+        # LONGTAIL_LAUNCH=plain (tools/run8.sh, or bench.py's own self-launch with --launch plain): N processes, no torch.distributed
+        # at all -- every collective is the C ABI's (lthip_comm_allgather / lthip_comm_alltoallv = RCCL, comm.hip), the communicator
+        # id travels through a file
         if self.world > 1 and not self.plain:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if self.backend == "nccl":
@@ -118,30 +240,24 @@ class Bench:
                 dist.init_process_group(self.backend)
         self.ctx = Context(dev_index)
         self.bufs = {}
-        # --collective c: the exchange's all-gathers through the C ABI (lthip_comm_allgather = ncclAllGather on the context's stream)
-        # instead of torch.distributed; the unique id travels through the process group the ranks were launched with
+        # --collective c: the exchange's collectives through the C ABI instead of torch.distributed; the unique id travels through the
+        # process group the ranks were launched with
         self.comm = None
         if self.plain:
-            from longtail_amd.lib import Comm
-
-            idfile = os.environ.get("LTHIP_COMM_ID_FILE", "/tmp/lthip_comm_id")
-            if self.rank == 0:
-                with open(idfile + ".tmp", "wb") as f:
-                    f.write(Comm.unique_id(self.lib))
-                os.replace(idfile + ".tmp", idfile)
-            t0 = time.time()
-            while not os.path.exists(idfile):
-                if time.time() - t0 > 120:
-                    raise SystemExit(f"rank {self.rank}: no communicator id in {idfile} after 120 s")
-                time.sleep(0.01)
-            self.comm = Comm(self.ctx, self.world, self.rank, open(idfile, "rb").read())
-            args.dedup = "replicated"  # the sharded table's all-to-all is a torch.distributed collective
+            self.comm = plain_comm(self.lib, self.ctx, self.rank, self.world)
         elif self.world > 1 and args.collective == "c" and self.backend == "nccl":
             from longtail_amd.lib import Comm
 
             box = [Comm.unique_id(self.lib) if self.rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             self.comm = Comm(self.ctx, self.world, self.rank, box[0])
+        self.comm_info = None
+        if self.comm is not None:
+            self.comm_info = self.comm.info()  # what the TRANSPORT says (ncclCommCount), not what it was asked for
+            if self.comm_info["nranks"] != self.world:
+                raise SystemExit(f"rank {self.rank}: the communicator has {self.comm_info['nranks']} ranks, expected {self.world}")
+        elif self.world > 1:
+            self.comm_info = {"nranks": dist.get_world_size(), "rank": dist.get_rank(), "transport": f"torch.distributed/{dist.get_backend()}"}
 
     def reduce(self, values, op="sum"):
         """All-reduce of a few host numbers over the ranks (max of the wall time, sums of the result counters)."""
@@ -292,7 +408,7 @@ class Bench:
                 my_jobs = mine
                 if args.dedup == "sharded":
                     # the first-seen table sharded by hash: this rank inserts its 1/N of the hash space, not every rank's chunks
-                    first_all, uniq_all = sharded_first_seen(part, ex, out_hash, total, ctx)
+                    first_all, uniq_all = sharded_first_seen(part, ex, out_hash, total, ctx, comm=self.comm, rank=rank)
                     ing.set_first_seen(first_all, uniq_all)
             else:
                 all_hash, all_lens = out_hash, out_lens
@@ -454,10 +570,23 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: print how the tree's (asset, part) jobs fall onto --gpus ranks and what the exchange moves")
     ap.add_argument("--no-secondary", action="store_true", help="skip the compressible / mixed-size-tree measurements")
+    ap.add_argument("--launch", choices=["torch", "plain"], default="torch",
+                    help="--gpus N > 1 started without a launcher (WORLD_SIZE unset): how this process starts its N ranks -- 'torch': the "
+                         "environment of torch.distributed.run (collectives by torch.distributed = RCCL), 'plain': no torch.distributed, "
+                         "every collective through the C ABI (lthip_comm_*), the id through a file (what tools/run8.sh does)")
+    ap.add_argument("--handshake-only", action="store_true",
+                    help="plain launch only: id file + lthip_comm_create + barrier + reductions + one all-to-all, then a JSON line; no kernels")
     ap.add_argument("--cpu-gib", type=float, default=8.0, help="sample size of the CPU baseline")
     args = ap.parse_args()
     if args.dry_run:
         print(json.dumps(dry_run(args)))
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.handshake_only:
+            args.launch = "plain"  # (the handshake IS the plain launch's)
+        raise SystemExit(self_launch(args))
+    if args.handshake_only:
+        handshake_only(args)
         return
 
     # the traffic leg runs FIRST, in a child process under rocprofv3 (a profiler cannot wrap the process it runs in), rank 0 of a
@@ -512,6 +641,7 @@ def main():
                 "device_block_assembly": main_res["result"]["gathered_blocks_rank0"] > 0,
                 "sharding": (f"(asset, part) jobs over {b.world} ranks by lthip_partition_jobs('{args.partition}'), RCCL all-gather of "
                              "per-job chunk counts + hashes + lengths") if b.world > 1 else "single GPU",
+                "comm": b.comm_info, "dedup_table": (args.dedup if b.world > 1 else "single rank"),
                 "metric_definition": "wall time of CreateVersionIndex + CreateMissingContent + WriteContent equivalents (SURVEY.md §8d), "
                                      "serialized VersionIndex and StoreIndex delivered to host memory, stored-block images to a null sink",
             },

@@ -452,14 +452,33 @@ LTHIP_EXPORT int lthip_exchange_layout(uint64_t job_count, const uint32_t* job_r
  * bound at run time (dlopen): ENOSYS where it is missing.  Rank 0 makes the 128-byte id, the embedder carries it to the other
  * processes (any side channel), every rank creates its communicator with it.  lthip_comm_allgather: every rank contributes
  * `count` elements of `elem_bytes` from d_send; d_recv receives rank r's contribution at element r * count (the padded
- * all-gathers lthip_exchange_layout describes).  Asynchronous on the context's stream like every other bulk call. */
+ * all-gathers lthip_exchange_layout describes).  Asynchronous on the context's stream like every other bulk call.
+ *
+ * lthip_comm_alltoallv: the exchange of the SHARDED first-seen table (the serial pass of src/longtail.c:2951-2970 restated as "minimum
+ * position per hash", the table split by hash over the ranks): rank r sends send_counts[p] elements starting at element
+ * send_displs[p] of d_send to every rank p and receives recv_counts[p] elements from it at element recv_displs[p] of d_recv
+ * (host arrays of nranks entries; recv_counts[p] must equal rank p's send_counts[r] -- the ranks learn them by an all-gather of
+ * their send counts).  RCCL: one group of ncclSend / ncclRecv pairs on the context's stream -- point to point, the natural shape on
+ * xGMI.  lthip_comm_info: the communicator's size AS THE TRANSPORT REPORTS IT (ncclCommCount), this process's rank, the transport.
+ *
+ * Transports.  LTHIP_COMM_RCCL is the product path.  LTHIP_COMM_SHM is a stand-in for boxes without N GPUs: lthip_comm_unique_id
+ * makes a shared-memory id when LTHIP_COMM_TRANSPORT=shm is set in the environment of the process that makes the id, and every
+ * lthip_comm_create that receives such an id attaches to the segment /dev/shm/lthip_comm_<id>; the same entry points then move the
+ * bytes through host memory, synchronously (with ctx == NULL the pointers are host pointers: the CPU tests).  It exists so that the
+ * torch-free launch, the id hand-over and the exchange can be exercised with N processes on one GPU; it is never a measured path. */
 #define LTHIP_COMM_ID_BYTES 128
+#define LTHIP_COMM_RCCL 1
+#define LTHIP_COMM_SHM 2
 typedef struct lthip_comm lthip_comm;
 LTHIP_EXPORT int lthip_comm_unique_id(void* id128);
 LTHIP_EXPORT int lthip_comm_create(lthip_ctx* ctx, int nranks, int rank, const void* id128, lthip_comm** out);
 LTHIP_EXPORT int lthip_comm_destroy(lthip_comm* comm);
+LTHIP_EXPORT int lthip_comm_info(const lthip_comm* comm, int* out_nranks, int* out_rank, int* out_transport);
 LTHIP_EXPORT int lthip_comm_allgather(lthip_ctx* ctx, lthip_comm* comm, const void* d_send, void* d_recv, uint64_t count,
                                       uint32_t elem_bytes);
+LTHIP_EXPORT int lthip_comm_alltoallv(lthip_ctx* ctx, lthip_comm* comm, const void* d_send, const uint64_t* send_counts /*host*/,
+                                      const uint64_t* send_displs /*host*/, void* d_recv, const uint64_t* recv_counts /*host*/,
+                                      const uint64_t* recv_displs /*host*/, uint32_t elem_bytes);
 
 /* ---- synthetic assets (include/longtail_synth.h), bench/test input generator ------------------------ */
 LTHIP_EXPORT int lthip_synth_fill(lthip_ctx* ctx, void* d_dst, uint32_t asset_count, const uint64_t* asset_offsets /*host*/,

@@ -6,7 +6,9 @@ lthip_partition_jobs -- contiguous byte-balanced ranges, LPT or job mod R; deter
 chunks + hashes its own jobs in ascending job order; `exchange_chunks` all-gathers the per-job chunk counts and the chunk
 hash / length arrays and puts the runs back into JOB order (lthip_exchange_layout), which is the order the serial
 first-seen pass (:2951-2970) and the VersionIndex layout depend on.  backend "nccl" is RCCL on ROCm; the same code runs on
-CPU tensors with "gloo" (tests/test_dist_gloo.py).  These two all-gathers are the only collectives on the path.
+CPU tensors with "gloo" (tests/test_dist_gloo.py).  `sharded_first_seen` adds the all-to-all of the first-seen table sharded by
+hash.  Every collective runs either through torch.distributed or, with `comm=` (longtail_amd.lib.Comm), through the C ABI's
+lthip_comm_allgather / lthip_comm_alltoallv (comm.hip) -- the torch-free launch of tools/run8.sh and bench.py's self-launch.
 """
 from __future__ import annotations
 
@@ -75,11 +77,13 @@ class JobPartition:
 
 
 def _allgather(t: torch.Tensor, world: int, group=None, comm=None) -> torch.Tensor:
-    if comm is not None and t.device.type == "cuda":
+    if comm is not None:
         # the collective through the C ABI (lthip_comm_allgather = ncclAllGather on the context's stream); the host reads what it
-        # gathered only after the context has been synchronised
+        # gathered only after the context has been synchronised.  (A communicator without a context -- the shared-memory stand-in in
+        # the CPU tests -- takes CPU tensors.)
+        assert (t.device.type == "cuda") == (comm.ctx is not None), "tensors must live where the communicator's pointers do"
         out = comm.allgather(t)
-        comm.ctx.sync()
+        comm.sync()
         return out
     out = torch.empty(t.numel() * world, dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t.contiguous(), group=group)
@@ -163,7 +167,27 @@ def _min_ordinal(h: torch.Tensor, o: torch.Tensor, ctx=None):
     return torch.from_numpy(m[inv].astype(np.int32)).to(h.device), int(len(uniq))
 
 
-def sharded_first_seen(part: JobPartition, ex: dict, my_hashes: torch.Tensor, total: int, ctx=None, group=None):
+def _a2a_counts(send_counts: torch.Tensor, world: int, group=None, comm=None) -> list:
+    """recv_counts[p] = what rank p holds for me: row `me` of the all-gathered send-count matrix (comm) or an all-to-all of it."""
+    if comm is not None:
+        g = comm.allgather(send_counts.to(torch.int64))
+        comm.sync()
+        return [int(x) for x in g.view(world, world)[:, comm.rank].cpu().tolist()]
+    recv_counts = torch.empty(world, dtype=torch.int64, device=send_counts.device)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    return [int(x) for x in recv_counts.cpu().tolist()]
+
+
+def _a2a(send: torch.Tensor, sc: list, rc: list, group=None, comm=None) -> torch.Tensor:
+    if comm is not None:
+        return comm.alltoallv(send, sc, rc)  # lthip_comm_alltoallv: grouped ncclSend / ncclRecv on the context's stream
+    recv = torch.empty(sum(rc), dtype=send.dtype, device=send.device)
+    dist.all_to_all_single(recv, send, rc, sc, group=group)
+    return recv
+
+
+def sharded_first_seen(part: JobPartition, ex: dict, my_hashes: torch.Tensor, total: int, ctx=None, group=None, comm=None,
+                       rank: int | None = None):
     """The first-seen pass (src/longtail.c:2951-2970) with the table SHARDED by hash instead of replicated: every rank routes each of
     its chunks (hash, global position in job order) to the owner of the hash (all-to-all), the owner keeps the minimum position per
     hash (lthip_dedup_min_ordinal) and answers, and one all-gather spreads the answers: a rank inserts ~1/N of the tree's chunks instead
@@ -179,7 +203,8 @@ def sharded_first_seen(part: JobPartition, ex: dict, my_hashes: torch.Tensor, to
     if world == 1:
         first, uniq = _min_ordinal(my_hashes[:total], torch.arange(total, dtype=torch.int32, device=dev), ctx)
         return first, uniq
-    rank = dist.get_rank(group)
+    if rank is None:
+        rank = comm.rank if comm is not None else dist.get_rank(group)
     staged = ex["layout"]["staged"]
     if staged:
         my_hashes = my_hashes[:total].cpu()
@@ -194,30 +219,31 @@ def sharded_first_seen(part: JobPartition, ex: dict, my_hashes: torch.Tensor, to
     order = torch.argsort(owner, stable=True)
     send_h, send_o = h[order].contiguous(), ordinals[order].contiguous()
     send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
-    recv_counts = torch.empty(world, dtype=torch.int64, device=wdev)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
-    sc, rc = [int(x) for x in send_counts.cpu().tolist()], [int(x) for x in recv_counts.cpu().tolist()]
-    recv_h = torch.empty(sum(rc), dtype=torch.int64, device=wdev)
-    recv_o = torch.empty(sum(rc), dtype=torch.int32, device=wdev)
-    dist.all_to_all_single(recv_h, send_h, rc, sc, group=group)
-    dist.all_to_all_single(recv_o, send_o, rc, sc, group=group)
+    rc = _a2a_counts(send_counts, world, group, comm)
+    sc = [int(x) for x in send_counts.cpu().tolist()]
+    recv_h = _a2a(send_h, sc, rc, group, comm)
+    recv_o = _a2a(send_o, sc, rc, group, comm)
     if staged and ctx is not None:
         d = torch.device("cuda", torch.cuda.current_device())
         f, uniq = _min_ordinal(recv_h.to(d), recv_o.to(d), ctx)
         f = f.cpu()
     else:
-        f, uniq = _min_ordinal(recv_h, recv_o, ctx)
-    back = torch.empty(total, dtype=torch.int32, device=wdev)
-    dist.all_to_all_single(back, f.contiguous(), sc, rc, group=group)
+        f, uniq = _min_ordinal(recv_h, recv_o, ctx if wdev.type == "cuda" else None)
+    back = _a2a(f.contiguous(), rc, sc, group, comm)
     my_first = torch.empty(total, dtype=torch.int32, device=wdev)
     my_first[order] = back
     u = torch.tensor([uniq], dtype=torch.int64, device=wdev)
-    dist.all_reduce(u, group=group)
+    if comm is not None:
+        u = comm.allgather(u)
+        comm.sync()
+        u = u.sum()
+    else:
+        dist.all_reduce(u, group=group)
     # every rank's answers, in job order (the padded all-gather + reorder of exchange_chunks)
     lay = ex["layout"]
     chunk_stride = lay["chunk_stride"]
     send = my_first if total >= chunk_stride else torch.nn.functional.pad(my_first, (0, chunk_stride - total))
-    g = _allgather(send[:chunk_stride].contiguous(), world, group, None)
+    g = _allgather(send[:chunk_stride].contiguous(), world, group, comm)
     c64 = lay["cnt"].astype(np.int64)
     perm = np.repeat(lay["src"].astype(np.int64) - lay["dst"][:-1].astype(np.int64), c64) + np.arange(n_all, dtype=np.int64)
     first = g[torch.from_numpy(perm).to(wdev)]

@@ -152,6 +152,8 @@ class HipLib:
         sig("lthip_comm_create", i32, [vp, i32, i32, vp, P(vp)])
         sig("lthip_comm_destroy", i32, [vp])
         sig("lthip_comm_allgather", i32, [vp, vp, vp, vp, u64, u32])
+        sig("lthip_comm_alltoallv", i32, [vp, vp, vp, vp, vp, vp, vp, vp, u32])
+        sig("lthip_comm_info", i32, [vp, P(i32), P(i32), P(i32)])
 
     def device_count(self) -> int:
         return int(self.dll.lthip_device_count())
@@ -429,10 +431,13 @@ class Context:
 
 
 class Comm:
-    """RCCL communicator behind the C ABI (comm.hip): one process per GPU.  `unique_id()` on rank 0, carried to the other ranks by
-    the embedder (bench.py: the torch.distributed store), then `Comm(ctx, nranks, rank, id)` everywhere."""
+    """Communicator behind the C ABI (comm.hip), one process per GPU: RCCL, or -- when the id was made under
+    LTHIP_COMM_TRANSPORT=shm -- the shared-memory stand-in for boxes without N GPUs.  `unique_id()` on rank 0, carried to the other
+    ranks by the embedder (bench.py: a file, or the torch.distributed store), then `Comm(ctx, nranks, rank, id)` everywhere.
+    `ctx=None` (shared-memory transport only): the tensors are CPU tensors (the tests without a GPU)."""
 
     ID_BYTES = 128
+    TRANSPORTS = {1: "rccl", 2: "host-shm"}
 
     @staticmethod
     def unique_id(lib: Optional[HipLib] = None) -> bytes:
@@ -440,31 +445,71 @@ class Comm:
         buf = (C.c_ubyte * Comm.ID_BYTES)()
         err = lib.dll.lthip_comm_unique_id(C.addressof(buf))
         if err:
-            raise LongtailHipError(f"lthip_comm_unique_id: errno {err}")
+            raise LongtailHipError(err, "lthip_comm_unique_id")
         return bytes(buf)
 
-    def __init__(self, ctx: "Context", nranks: int, rank: int, unique_id: bytes):
+    def __init__(self, ctx: "Optional[Context]", nranks: int, rank: int, unique_id: bytes, lib: Optional[HipLib] = None):
         assert len(unique_id) == Comm.ID_BYTES
         self.ctx, self.nranks, self.rank = ctx, nranks, rank
+        self.lib = ctx.lib if ctx is not None else (lib or load())
         buf = (C.c_ubyte * Comm.ID_BYTES).from_buffer_copy(unique_id)
         h = C.c_void_p()
-        ctx._check(ctx.lib.dll.lthip_comm_create(ctx.h, nranks, rank, C.addressof(buf), C.byref(h)), "lthip_comm_create")
+        self._check(self.lib.dll.lthip_comm_create(self._ctx_h(), nranks, rank, C.addressof(buf), C.byref(h)), "lthip_comm_create")
         self.h = h
 
+    def _ctx_h(self):
+        return self.ctx.h if self.ctx is not None else None
+
+    def _check(self, err, what):
+        if self.ctx is not None:
+            self.ctx._check(err, what)
+        elif err:
+            raise LongtailHipError(err, what)
+
+    def sync(self):
+        if self.ctx is not None:
+            self.ctx.sync()
+
+    def info(self) -> dict:
+        """Size of the communicator as the TRANSPORT reports it (ncclCommCount), this rank, the transport's name."""
+        n, r, t = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.lib.dll.lthip_comm_info(self.h, C.byref(n), C.byref(r), C.byref(t)), "lthip_comm_info")
+        return {"nranks": int(n.value), "rank": int(r.value), "transport": Comm.TRANSPORTS.get(int(t.value), str(t.value))}
+
     def allgather(self, send, recv=None):
-        """`send`: contiguous device tensor; returns `recv` = the ranks' tensors back to back (nranks * send.numel() elements)."""
+        """`send`: contiguous tensor; returns `recv` = the ranks' tensors back to back (nranks * send.numel() elements)."""
         import torch
 
         send = send.contiguous()
         if recv is None:
             recv = torch.empty(send.numel() * self.nranks, dtype=send.dtype, device=send.device)
-        self.ctx._check(self.ctx.lib.dll.lthip_comm_allgather(self.ctx.h, self.h, _ptr(send), _ptr(recv), send.numel(), send.element_size()),
-                        "lthip_comm_allgather")
+        self._check(self.lib.dll.lthip_comm_allgather(self._ctx_h(), self.h, _ptr(send), _ptr(recv), send.numel(), send.element_size()),
+                    "lthip_comm_allgather")
+        return recv
+
+    def alltoallv(self, send, send_counts, recv_counts, recv=None):
+        """`send`: this rank's elements grouped by destination rank (send_counts[p] of them for rank p, back to back); returns the
+        elements received, grouped by source rank (recv_counts[p] from rank p).  Counts are host integers."""
+        import torch
+
+        send = send.contiguous()
+        sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.uint64)
+        assert len(sc) == self.nranks and len(rc) == self.nranks and int(sc.sum()) == send.numel()
+        sd = np.zeros(self.nranks, np.uint64)
+        rd = np.zeros(self.nranks, np.uint64)
+        np.cumsum(sc[:-1], out=sd[1:])
+        np.cumsum(rc[:-1], out=rd[1:])
+        if recv is None:
+            recv = torch.empty(int(rc.sum()), dtype=send.dtype, device=send.device)
+        self._check(self.lib.dll.lthip_comm_alltoallv(self._ctx_h(), self.h, _ptr(send) if send.numel() else None, sc.ctypes.data, sd.ctypes.data,
+                                                      _ptr(recv) if recv.numel() else None, rc.ctypes.data, rd.ctypes.data, send.element_size()),
+                    "lthip_comm_alltoallv")
         return recv
 
     def close(self):
         if self.h:
-            self.ctx.lib.dll.lthip_comm_destroy(self.h)
+            self.lib.dll.lthip_comm_destroy(self.h)
             self.h = None
 
 
