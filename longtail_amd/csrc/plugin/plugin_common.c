@@ -2,6 +2,7 @@
  * the HIP ChunkerAPI / HashAPI / CompressionAPI objects.  Plain C99 over the lthip_* C ABI. */
 #include "plugin_common.h"
 
+#include <sched.h>
 #include <stdatomic.h>
 
 #include <stdio.h>
@@ -159,10 +160,30 @@ static struct ltp_window g_windows[LTP_MAX_WINDOWS];
 static unsigned char g_window_used[LTP_MAX_WINDOWS];
 static int g_window_high; /* highest used slot + 1 */
 /* per-slot sequence number: odd while a writer (always under g_win_lock) is changing the slot, bumped twice per change.  The
- * lock-free look-up of a thread's own window (below) is valid only while the number it noted at ltp_window_set_current stands. */
+ * lock-free look-up of a thread's own window (below) is valid only while the number it noted at ltp_window_set_current stands.
+ *
+ * A sequence number protects against torn VALUES, not against unmapped MEMORY: the slot holds pointers to a window's pinned tables,
+ * and whoever changes the slot (the chunker's next window, DisposeChunker -- possibly from another thread --, the pool's trim) goes
+ * on to recycle or free those tables.  So the fast path also COUNTS itself in (g_window_readers[slot]) before it looks at the
+ * sequence number, and a writer, having made the number odd, waits for the count to drain before it touches the slot: a reader that
+ * saw the old number is finished with the tables before they can go away, a reader that comes later sees the odd / new number and
+ * takes the locked path.  Both counters are sequentially consistent (store-buffering pattern: reader = count++ then load seq, writer
+ * = seq++ then load count -- at least one of them sees the other).  The count's cache line is the slot's own: the thread that owns
+ * the chunker is the only regular visitor, so the two atomic RMWs cost a few nanoseconds, not a contended lock. */
 static _Atomic uint64_t g_window_seq[LTP_MAX_WINDOWS];
+static struct
+{
+    _Atomic uint32_t n;
+    char pad[60];
+} g_window_readers[LTP_MAX_WINDOWS];
 
-static void slot_write_begin(int slot) { atomic_fetch_add_explicit(&g_window_seq[slot], 1, memory_order_acq_rel); }
+static void slot_write_begin(int slot)
+{
+    atomic_fetch_add_explicit(&g_window_seq[slot], 1, memory_order_seq_cst);
+    for (unsigned spins = 0; atomic_load_explicit(&g_window_readers[slot].n, memory_order_seq_cst) != 0; ++spins)
+        if (spins > 64)
+            sched_yield(); /* a reader is inside one binary search: nanoseconds */
+}
 static void slot_write_end(int slot) { atomic_fetch_add_explicit(&g_window_seq[slot], 1, memory_order_release); }
 
 int ltp_window_register(void)
@@ -250,23 +271,28 @@ int ltp_window_lookup(const void* data, uint32_t len, uint64_t* out_hash)
     const uint8_t* p = (const uint8_t*)data;
     /* the calling thread's own chunker first: no lock, no scan (the common case by far, src/longtail.c:2231-2296) */
     const int slot = t_current_slot;
-    if (slot >= 0 && !(t_current_seq & 1u) && atomic_load_explicit(&g_window_seq[slot], memory_order_acquire) == t_current_seq)
+    if (slot >= 0 && !(t_current_seq & 1u))
     {
-        const struct ltp_window cur = g_windows[slot]; /* a copy taken between two reads of an unchanged sequence number */
-        atomic_thread_fence(memory_order_acquire);
-        if (atomic_load_explicit(&g_window_seq[slot], memory_order_relaxed) == t_current_seq && cur.base && p >= cur.base &&
-            p < cur.base + cur.size)
+        atomic_fetch_add_explicit(&g_window_readers[slot].n, 1, memory_order_seq_cst);
+        if (atomic_load_explicit(&g_window_seq[slot], memory_order_seq_cst) == t_current_seq)
         {
+            /* no writer has begun on this slot, and none can get past slot_write_begin while the count stands: the slot and the
+             * tables it points to are stable until the decrement below */
+            const struct ltp_window* cur = &g_windows[slot];
+            int hit = -1;
             uint64_t h = 0;
-            const int hit = window_find(&cur, p, len, &h);
-            atomic_thread_fence(memory_order_acquire);
-            if (atomic_load_explicit(&g_window_seq[slot], memory_order_relaxed) == t_current_seq) /* the tables stood while read */
+            if (cur->base && p >= cur->base && p < cur->base + cur->size)
+                hit = window_find(cur, p, len, &h);
+            atomic_fetch_sub_explicit(&g_window_readers[slot].n, 1, memory_order_release);
+            if (hit >= 0)
             {
                 if (hit)
                     *out_hash = h;
                 return hit;
             }
         }
+        else
+            atomic_fetch_sub_explicit(&g_window_readers[slot].n, 1, memory_order_release);
     }
     int found = 0;
     pthread_rwlock_rdlock(&g_win_lock);

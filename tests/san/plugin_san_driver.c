@@ -131,6 +131,84 @@ static void* codec_worker(void* arg)
     return 0;
 }
 
+/* 8. a chunker DISPOSED FROM ANOTHER THREAD while the thread that drew its last chunk keeps calling HashBuffer (on memory of its
+ * own: the chunk's bytes died with the chunker, reading them would be the caller's bug).  The hasher's lock-free look-up of "my
+ * thread's window" (plugin_common.c ltp_window_lookup) must not read the slot -- or the pinned tables it points to -- while the
+ * disposer recycles or frees them.  Run under ASan and, `make run-tsan`, under ThreadSanitizer. */
+struct handoff
+{
+    pthread_mutex_t m;
+    pthread_cond_t cv;
+    Longtail_ChunkerAPI_HChunker pending[4];
+    int n, done;
+};
+
+static void* disposer(void* arg)
+{
+    struct handoff* h = (struct handoff*)arg;
+    for (;;)
+    {
+        pthread_mutex_lock(&h->m);
+        while (h->n == 0 && !h->done)
+            pthread_cond_wait(&h->cv, &h->m);
+        if (h->n == 0 && h->done)
+        {
+            pthread_mutex_unlock(&h->m);
+            return 0;
+        }
+        Longtail_ChunkerAPI_HChunker c = h->pending[--h->n];
+        pthread_cond_broadcast(&h->cv);
+        pthread_mutex_unlock(&h->m);
+        CHECK(g_chunker->DisposeChunker(g_chunker, c) == 0);
+    }
+}
+
+static void dispose_from_another_thread(void)
+{
+    struct handoff h;
+    pthread_mutex_init(&h.m, 0);
+    pthread_cond_init(&h.cv, 0);
+    h.n = 0;
+    h.done = 0;
+    pthread_t th;
+    CHECK(pthread_create(&th, 0, disposer, &h) == 0);
+    const uint64_t size = 400000;
+    uint8_t* d = (uint8_t*)malloc(size);
+    uint8_t* mine = (uint8_t*)malloc(131072);
+    lto_synth_fill(d, size, 4242, 0, 1);
+    for (int round = 0; round < 200; ++round)
+    {
+        Longtail_ChunkerAPI_HChunker c = 0;
+        CHECK(g_chunker->CreateChunker(g_chunker, 8192, 32768, 131072, &c) == 0);
+        struct feed f = {d, size, 0, 0, 0};
+        struct Longtail_Chunker_ChunkRange r;
+        CHECK(g_chunker->NextChunk(g_chunker, c, feeder, &f, &r) == 0 && r.len > 0);
+        uint64_t want = 0, got = 0;
+        CHECK(g_hash->HashBuffer(g_hash, r.len, r.buf, &want) == 0); /* from the window's tables */
+        const uint32_t len = r.len;
+        memcpy(mine, r.buf, len);
+        pthread_mutex_lock(&h.m);
+        while (h.n == 4)
+            pthread_cond_wait(&h.cv, &h.m);
+        h.pending[h.n++] = c; /* the other thread disposes it ... */
+        pthread_cond_broadcast(&h.cv);
+        pthread_mutex_unlock(&h.m);
+        for (int k = 0; k < 3; ++k) /* ... while this one goes on hashing: its "current window" is being torn down */
+        {
+            CHECK(g_hash->HashBuffer(g_hash, len, mine, &got) == 0 && got == want);
+        }
+    }
+    pthread_mutex_lock(&h.m);
+    h.done = 1;
+    pthread_cond_broadcast(&h.cv);
+    pthread_mutex_unlock(&h.m);
+    pthread_join(th, 0);
+    free(d);
+    free(mine);
+    pthread_mutex_destroy(&h.m);
+    pthread_cond_destroy(&h.cv);
+}
+
 int main(void)
 {
     g_chunker = Longtail_CreateHipChunkerAPI();
@@ -309,6 +387,7 @@ int main(void)
         Longtail_Hip_CodecBatchStats(&subs, &blocks);
         CHECK(blocks >= (uint64_t)T * 4u * 2u && subs >= 1 && subs <= blocks);
     }
+    dispose_from_another_thread();
     lz4->m_API.Dispose(&lz4->m_API);
     zstd->m_API.Dispose(&zstd->m_API);
     g_hash->m_API.Dispose(&g_hash->m_API);

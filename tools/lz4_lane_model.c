@@ -297,6 +297,19 @@ int main(int argc, char** argv)
         {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 0, 8192},
         {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 1, 8192},
         {4096, 16, 1536, 64, 1, 4, 0, 1, 0, 0, 2, 1, 8, 4096, 0, 2, 1, 1, 8192},
+        /* round 4: geometries that put 32 waves on a CU (two workgroups of 72 KiB) */
+        {2048, 16, 768, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 2048, 0, 2, 1, 0, 4096},
+        {2048, 16, 768, 64, 1, 4, 0, 1, 0, 0, 1, 1, 4, 2048, 0, 2, 1, 0, 4096},
+        {2048, 16, 1024, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 2048, 0, 2, 1, 0, 4096},
+        {4096, 8, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 0, 4096},
+        {2048, 16, 768, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 2048, 0, 2, 1, 0, 8192},
+        {2048, 32, 768, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 2048, 0, 2, 1, 0, 8192},
+        {4096, 12, 512, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 0, 4096},
+        {4096, 12, 768, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 0, 4096},
+        {4096, 12, 1536, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 0, 8192},
+        {4096, 16, 512, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 0, 8192},
+        {4096, 16, 512, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 0, 4096},
+        {4096, 16, 256, 64, 1, 4, 0, 1, 0, 0, 1, 1, 8, 4096, 0, 2, 1, 0, 2048},
     };
     printf("%-58s", "variant (unit group tab lanes cross seed inm back hist trim)");
     for (int k = 0; k < 4; ++k)
