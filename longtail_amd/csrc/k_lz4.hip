@@ -97,16 +97,66 @@ __device__ __forceinline__ uint32_t lds_read32(const uint32_t* sdata, uint32_t b
     return __builtin_amdgcn_alignbyte(sdata[w + 1], sdata[w], byte_idx & 3u);
 }
 
+// PADDED window (the second formulation of the lane parser, PV 2).  Lanes own consecutive 64-byte sub-units, so whatever the lanes of a
+// wave read "at their own position" lies 16 dwords apart: two of the 32 LDS banks serve a 32-lane group, a 16-way conflict on every
+// such read while the lanes run in phase (any data made of aligned structures; SQ_LDS_BANK_CONFLICT was 62 % of the LDS-array cycles on
+// "tokens", and half of that went away with an odd sub-unit pitch -- which costs ratio and lanes).  Here the window keeps its 64-byte
+// sub-units and is stored in ROWS of 32 dwords (128 bytes) at a pitch of 35: two neighbouring sub-units share a row, rows shift by
+// three banks each -- the 32 lanes of a group land on 32 different banks (3 j + 16 b mod 32, j < 16, b < 2: all distinct).  The three
+// extra dwords of a row REPEAT the first three dwords of the next row, so that a run of up to four dwords starting anywhere in a row is
+// contiguous in LDS: one address computation (x + 12 (x >> 7): two instructions) and ds_read2_b32 with constant offsets, no matter
+// where the row ends.
+constexpr uint32_t LZ4_ROW_DUP = 3; // repeated dwords per 32-dword row
+template <bool PAD>
+__device__ __forceinline__ uint32_t lds_pidx(uint32_t D)
+{
+    return PAD ? D + LZ4_ROW_DUP * (D >> 5) : D;
+}
+template <bool PAD>
+__device__ __forceinline__ uint32_t lds_dw(const uint32_t* sdata, uint32_t D)
+{
+    return sdata[lds_pidx<PAD>(D)];
+}
+// N <= 4 consecutive dwords of the window from dword D
+template <bool PAD, int N>
+__device__ __forceinline__ void lds_run(const uint32_t* sdata, uint32_t D, uint32_t* out)
+{
+    static_assert(N >= 1 && N <= 1 + (int)LZ4_ROW_DUP, "a run is contiguous up to 1 + LZ4_ROW_DUP dwords");
+    const uint32_t* q = sdata + lds_pidx<PAD>(D);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        out[k] = q[k];
+}
+template <bool PAD>
+__device__ __forceinline__ uint32_t lds_byte(const uint32_t* sdata, uint32_t x)
+{
+    return reinterpret_cast<const uint8_t*>(sdata)[PAD ? x + 4u * LZ4_ROW_DUP * (x >> 7) : x];
+}
+template <bool PAD>
+__device__ __forceinline__ uint32_t lds_read32x(const uint32_t* sdata, uint32_t byte_idx)
+{
+    if constexpr (!PAD)
+        return lds_read32(sdata, byte_idx);
+    uint32_t d[2];
+    lds_run<true, 2>(sdata, byte_idx >> 2, d);
+    return __builtin_amdgcn_alignbyte(d[1], d[0], byte_idx & 3u);
+}
+// bytes of LDS a window of n data bytes occupies
+__host__ __device__ constexpr uint32_t lz4_window_lds_bytes(uint32_t n, bool pad)
+{
+    return pad ? ((((n + 127u) >> 7) * (128u + 4u * LZ4_ROW_DUP) + 16u + 15u) & ~15u) : n;
+}
+
 // n bytes of the LDS window (from byte `sbyte`) to global memory, one wave, 16-byte stores on the aligned part
+template <bool PAD = false>
 __device__ __forceinline__ void wave_copy_lds_to_global(uint8_t* __restrict__ dst, const uint32_t* sdata, uint32_t sbyte, uint32_t n,
                                                         int lane)
 {
-    const uint8_t* sb = reinterpret_cast<const uint8_t*>(sdata);
     uint32_t headb = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
     if (headb > n)
         headb = n;
     if ((uint32_t)lane < headb)
-        dst[lane] = sb[sbyte + (uint32_t)lane];
+        dst[lane] = (uint8_t)lds_byte<PAD>(sdata, sbyte + (uint32_t)lane);
     dst += headb;
     sbyte += headb;
     n -= headb;
@@ -115,15 +165,29 @@ __device__ __forceinline__ void wave_copy_lds_to_global(uint8_t* __restrict__ ds
     {
         const uint32_t b = sbyte + 16u * v;
         uint4 o;
-        o.x = lds_read32(sdata, b);
-        o.y = lds_read32(sdata, b + 4u);
-        o.z = lds_read32(sdata, b + 8u);
-        o.w = lds_read32(sdata, b + 12u);
+        if constexpr (PAD)
+        {
+            const uint32_t w = b >> 2, sh = b & 3u;
+            uint32_t d[4];
+            lds_run<true, 4>(sdata, w, d);
+            const uint32_t d4 = lds_dw<true>(sdata, w + 4u);
+            o.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+            o.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+            o.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+            o.w = __builtin_amdgcn_alignbyte(d4, d[3], sh);
+        }
+        else
+        {
+            o.x = lds_read32(sdata, b);
+            o.y = lds_read32(sdata, b + 4u);
+            o.z = lds_read32(sdata, b + 8u);
+            o.w = lds_read32(sdata, b + 12u);
+        }
         *reinterpret_cast<uint4*>(dst + (uint64_t)v * 16u) = o;
     }
     const uint32_t done = nvec << 4;
     if ((uint32_t)lane < n - done)
-        dst[done + (uint32_t)lane] = sb[sbyte + done + (uint32_t)lane];
+        dst[done + (uint32_t)lane] = (uint8_t)lds_byte<PAD>(sdata, sbyte + done + (uint32_t)lane);
 }
 
 // wave-cooperative emission of a length (already reduced by 15) as 255,255,...,rem
@@ -702,13 +766,433 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K5, lane-sequential parse, second formulation (round 4; PV = 2 of k_lz4_segments).  The parse is the one above -- same probe rule,
+// same candidates, same extension limits, same cover rule: the payloads are byte-identical -- restated around what the per-phase
+// cycle counters said it costs (profiles/r04_k5_prof.txt: a probe step took 1500 cycles for ~100 instructions):
+//   * PROBE in two LDS round trips instead of four.  The lane's next bytes live in a three-dword REGISTER window that slides with p
+//     (one exec-masked dword read ahead per crossing, consumed a step later), so the four bytes at p cost no round trip; the private
+//     and the shared candidate's bytes are read by ONE pair of unconditional reads (an invalid candidate reads the lane's own position
+//     and is masked) -- the compiler had serialised the two predicated reads, each with its own s_waitcnt.
+//   * EXTENSION in one round trip: the 28 bytes p-8 .. p+20 of both sides are eight aligned dwords each (the window is staged 16
+//     bytes into LDS so that "8 bytes before position 0" is a legal address), read together; the backward count and the first 16
+//     forward bytes come out of the same registers.  Matches of 20 bytes and more take a second 16-byte round, then the wave.
+//   * RECORDS in registers (8 x {start | length << 16, offset}) instead of a global scratch area of 4 KiB per unit that the cover
+//     scans, the size pass and the emission each read back through the memory system (1 B/B written and read on "tokens").
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t LZ4_LPAD = 16; // PV 2: LDS byte offset of the staged window
+
+// equal leading bytes (0..16) of the 16 bytes at LDS byte addresses qa and qb (any alignment): five aligned dwords per side
+template <bool PAD>
+__device__ __forceinline__ uint32_t lds_cmp16(const uint32_t* sdata, uint32_t qa, uint32_t qb)
+{
+    const uint32_t wa = qa >> 2, wb = qb >> 2, da = qa & 3u, db = qb & 3u;
+    uint32_t ra[4], rb[4];
+    lds_run<PAD, 4>(sdata, wa, ra);
+    lds_run<PAD, 4>(sdata, wb, rb);
+    const uint32_t a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3], a4 = lds_dw<PAD>(sdata, wa + 4u);
+    const uint32_t b0 = rb[0], b1 = rb[1], b2 = rb[2], b3 = rb[3], b4 = lds_dw<PAD>(sdata, wb + 4u);
+    const uint32_t x0 = __builtin_amdgcn_alignbyte(a1, a0, da) ^ __builtin_amdgcn_alignbyte(b1, b0, db);
+    const uint32_t x1 = __builtin_amdgcn_alignbyte(a2, a1, da) ^ __builtin_amdgcn_alignbyte(b2, b1, db);
+    const uint32_t x2 = __builtin_amdgcn_alignbyte(a3, a2, da) ^ __builtin_amdgcn_alignbyte(b3, b2, db);
+    const uint32_t x3 = __builtin_amdgcn_alignbyte(a4, a3, da) ^ __builtin_amdgcn_alignbyte(b4, b3, db);
+    uint32_t n = 16u;
+    if (x0)
+        n = (uint32_t)__builtin_ctz(x0) >> 3;
+    else if (x1)
+        n = 4u + ((uint32_t)__builtin_ctz(x1) >> 3);
+    else if (x2)
+        n = 8u + ((uint32_t)__builtin_ctz(x2) >> 3);
+    else if (x3)
+        n = 12u + ((uint32_t)__builtin_ctz(x3) >> 3);
+    return n;
+}
+
+template <int TAB, int FMT, int SH>
+__device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t head /* incl. LZ4_LPAD */, uint16_t* tab, const uint32_t* shr,
+                                                uint32_t sh_base, int lane, uint32_t my_start, uint32_t my_len, int32_t start_limit,
+                                                uint32_t end_limit, uint32_t sub, uint8_t* __restrict__ out, uint64_t* __restrict__ zrecs,
+                                                Lz4Seq& st, uint32_t dbg K5P_ARG)
+{
+    static_assert(SH != 0, "the second formulation is the shared-table parser's");
+    static_assert(LZ4_LANE_MAXREC == 8, "records are eight register pairs");
+    constexpr bool PAD = true; // the window is the padded one (lds_dw)
+    constexpr bool rev = true;
+    const int sidx = 63 - lane; // my sub-unit (reverse mapping: the lowest position survives a same-instruction write conflict)
+    const uint32_t unit_end = my_start + my_len;
+    const uint32_t s0 = my_start + (uint32_t)sidx * sub;
+    const uint32_t lend = s0 + sub < unit_end ? s0 + sub : unit_end;
+    uint32_t p = s0, anchor = s0, nrec = 0, last_end = 0, nmiss = 0;
+    const uint32_t dense = 4u >> ((dbg >> 29) & 3u);
+    const uint32_t wait_for = (dbg >> 20) & 63u ? (dbg >> 20) & 63u : 8u;
+    uint32_t rsl[8], roff[8]; // records: start | length << 16, offset
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        rsl[k] = roff[k] = 0u;
+    bool pend = false, stale = true;
+    uint32_t cand = 0u;
+    uint32_t w0 = 0, w1 = 0, w2 = 0, W = 0; // the dwords W, W + 1, W + 2 of the window: the lane's next 9..12 bytes
+    for (;;)
+    {
+        const bool act = !pend && p < lend && (int32_t)p <= start_limit && nrec < LZ4_LANE_MAXREC && !(dbg & 2048u);
+        const uint64_t am = __builtin_amdgcn_ballot_w64(act);
+        if (am == 0ull && __builtin_amdgcn_ballot_w64(pend) == 0ull)
+            break;
+        if (am)
+        {
+            if (__builtin_amdgcn_ballot_w64(act && stale))
+            {
+                if (act && stale)
+                {
+                    W = (p + head) >> 2;
+                    uint32_t r3[3];
+                    lds_run<PAD, 3>(sdata, W, r3);
+                    w0 = r3[0];
+                    w1 = r3[1];
+                    w2 = r3[2];
+                    stale = false;
+                }
+            }
+            if (act)
+            {
+                const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, (p + head) & 3u);
+                const uint32_t prod = v * 2654435761u;
+                const uint32_t h = __umulhi(prod, (uint32_t)TAB);
+                uint32_t c = tab[h];
+                const uint32_t c2 = shr[prod >> (32 - SH)] - sh_base; // (another group's entry: far above any position)
+                tab[h] = (uint16_t)p;
+                if (dbg & (1u << 28))
+                {
+                    uint32_t hr = h;
+                    asm volatile("" : "+v"(hr));
+                    const uint32_t fresh = tab[hr];
+                    if (fresh < p)
+                        c = fresh;
+                }
+                // both candidates' bytes in one round trip (an invalid one reads my own position and is masked)
+                const bool v1 = c < p, v2 = c2 < p;
+                const uint32_t r1 = lds_read32x<PAD>(sdata, (v1 ? c : p) + head);
+                const uint32_t r2 = lds_read32x<PAD>(sdata, (v2 ? c2 : p) + head);
+                const bool h1 = v1 && r1 == v, h2 = v2 && r2 == v;
+                if (h1 || h2)
+                {
+                    pend = true;
+                    cand = h1 ? c : c2; // the private table's (the nearer one) first
+                }
+                else
+                {
+                    const uint32_t np = nmiss < dense ? p + 1u : (((p + head) | 3u) + 1u - head);
+                    if (((np + head) >> 2) != W) // at most one dword further
+                    {
+                        w0 = w1;
+                        w1 = w2;
+                        W += 1u;
+                        w2 = lds_dw<PAD>(sdata, W + 2u); // consumed at the next crossing at the earliest
+                    }
+                    p = np;
+                    ++nmiss;
+                }
+            }
+        }
+        K5P(3);
+        K5P_COUNT(10, 1);
+        const uint64_t pm = __builtin_amdgcn_ballot_w64(pend);
+        if (pm == 0ull)
+            continue;
+        if ((uint32_t)__builtin_popcountll(pm) < wait_for &&
+            __builtin_amdgcn_ballot_w64(!pend && p < lend && (int32_t)p <= start_limit && nrec < LZ4_LANE_MAXREC) != 0ull)
+            continue; // somebody can still probe: let the hits pile up
+        const bool ok0 = pend;
+        bool ok = ok0;
+        pend = false;
+        K5P_COUNT(11, 1);
+        K5P_COUNT(12, (unsigned)__builtin_popcountll(pm));
+        // ---- one round trip: 8 bytes backwards and the first 16 bytes forwards of every hit ----
+        uint32_t mlen = 0, nbk = 0;
+        bool grow = false;
+        const uint32_t maxlen = ok ? end_limit - p : 0u; // p <= start_limit: at least 4
+        if (ok)
+        {
+            const uint32_t qo = p + head - 8u, qc = cand + head - 8u;
+            const uint32_t bo = qo >> 2, bc = qc >> 2, dlo = qo & 3u, dlc = qc & 3u;
+            uint32_t Do[8], Dc[8];
+            lds_run<PAD, 4>(sdata, bo, Do);
+            lds_run<PAD, 4>(sdata, bo + 4u, Do + 4);
+            lds_run<PAD, 4>(sdata, bc, Dc);
+            lds_run<PAD, 4>(sdata, bc + 4u, Dc + 4);
+            uint32_t X[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                X[k] = __builtin_amdgcn_alignbyte(Do[k + 1], Do[k], dlo) ^ __builtin_amdgcn_alignbyte(Dc[k + 1], Dc[k], dlc);
+            uint32_t add = 16u; // bytes p + 4 .. p + 20
+            if (X[3])
+                add = (uint32_t)__builtin_ctz(X[3]) >> 3;
+            else if (X[4])
+                add = 4u + ((uint32_t)__builtin_ctz(X[4]) >> 3);
+            else if (X[5])
+                add = 8u + ((uint32_t)__builtin_ctz(X[5]) >> 3);
+            else if (X[6])
+                add = 12u + ((uint32_t)__builtin_ctz(X[6]) >> 3);
+            mlen = 4u + add;
+            grow = add == 16u;
+            if (mlen >= maxlen)
+            {
+                mlen = maxlen;
+                grow = false;
+            }
+            if (cand >= 8u && p - anchor != 0u)
+            {
+                nbk = X[1] ? (uint32_t)__builtin_clz(X[1]) >> 3 : (X[0] ? 4u + ((uint32_t)__builtin_clz(X[0]) >> 3) : 8u);
+                nbk = nbk < p - anchor ? nbk : p - anchor;
+            }
+        }
+        // ---- matches of 20 bytes and more: one more 16-byte round of their own (at most 36 bytes), then the whole wave ----
+        if (__builtin_amdgcn_ballot_w64(grow))
+        {
+            if (grow)
+            {
+                const uint32_t add = lds_cmp16<PAD>(sdata, p + mlen + head, cand + mlen + head);
+                mlen += add;
+                if (add != 16u)
+                    grow = false;
+                if (mlen >= maxlen)
+                {
+                    mlen = maxlen;
+                    grow = false;
+                }
+            }
+        }
+        uint64_t longs = __builtin_amdgcn_ballot_w64(grow);
+        bool covered = false;
+        K5P(4);
+        while (longs)
+        {
+            K5P_COUNT(13, 1);
+            const int f = rev ? 63 - __builtin_clzll(longs) : __builtin_ctzll(longs);
+            longs &= ~(1ull << f);
+            const uint32_t pf = __builtin_amdgcn_readlane(p, f), cf = __builtin_amdgcn_readlane(cand, f);
+            uint32_t ml = __builtin_amdgcn_readlane(mlen, f);
+            for (;;)
+            {
+                const uint32_t i = pf + ml + 4u * (uint32_t)lane;
+                uint32_t cnt = 0; // equal bytes of my four, as far as the unit goes
+                if (i < end_limit)
+                {
+                    const uint32_t x = lds_read32x<PAD>(sdata, i + head) ^ lds_read32x<PAD>(sdata, cf + ml + 4u * (uint32_t)lane + head);
+                    const uint32_t lim = end_limit - i < 4u ? end_limit - i : 4u;
+                    cnt = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+                    cnt = cnt < lim ? cnt : lim;
+                }
+                const uint64_t diff = __builtin_amdgcn_ballot_w64(cnt < 4u);
+                if (diff)
+                {
+                    const int g = __builtin_ctzll(diff);
+                    ml += 4u * (uint32_t)g + __builtin_amdgcn_readlane(cnt, g);
+                    break;
+                }
+                ml += 256u;
+            }
+            if (lane == f)
+                mlen = ml;
+            const uint32_t cov = pf + ml;
+            const bool cv = lane != f && p > pf && p < cov;
+            if (cv)
+            {
+                p = cov;
+                anchor = anchor > cov ? anchor : cov;
+                ok = false;
+                covered = true;
+                stale = true;
+            }
+            longs &= ~__builtin_amdgcn_ballot_w64(cv);
+        }
+        if (ok)
+        {
+            const uint32_t s = p - nbk, len = mlen + nbk;
+            const uint32_t sl = s | (len << 16), of = p - cand;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (nrec == (uint32_t)k)
+                {
+                    rsl[k] = sl;
+                    roff[k] = of;
+                }
+            ++nrec;
+            p = s + len;
+            anchor = p;
+            last_end = p;
+            nmiss = 0;
+            stale = true;
+        }
+        else if (ok0 && !covered)
+            p += 1u; // (cannot happen: a waiting hit is either recorded or covered)
+        K5P(5);
+    }
+
+    // ---- what earlier sub-units' matches cover is dropped: exclusive prefix maximum of the match ends, in sub-unit order ----
+    uint32_t incl = last_end;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const uint32_t o = sub_shfl(incl, sidx - d, rev, 0u);
+        incl = incl > o ? incl : o;
+    }
+    const uint32_t cover = sub_shfl(incl, sidx - 1, rev, 0u);
+    uint32_t k0 = 0; // my first record that starts at or after the cover (starts ascend)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        k0 += ((uint32_t)k < nrec && (rsl[k] & 0xFFFFu) < cover) ? 1u : 0u;
+    const bool have = k0 < nrec;
+    uint32_t first_start_v = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if ((uint32_t)k == k0)
+            first_start_v = rsl[k] & 0xFFFFu;
+    if (!have)
+        first_start_v = 0u;
+    // previous kept end = where the literals of my first kept sequence begin
+    uint32_t kincl = have ? last_end : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const uint32_t o = sub_shfl(kincl, sidx - d, rev, 0u);
+        kincl = kincl > o ? kincl : o;
+    }
+    uint32_t prev0 = sub_shfl(kincl, sidx - 1, rev, 0u);
+    prev0 = prev0 > my_start ? prev0 : my_start;
+    // sizes
+    uint32_t bytes = 0, nlit = 0;
+    {
+        uint32_t prev = prev0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+        {
+            const bool on = (uint32_t)k >= k0 && (uint32_t)k < nrec;
+            const uint32_t s = rsl[k] & 0xFFFFu, len = rsl[k] >> 16;
+            const uint32_t lit = s - prev;
+            if (on)
+            {
+                bytes += 1u + lz4_len_bytes(lit) + lit + 2u + lz4_len_bytes(len - 4u);
+                nlit += lit;
+                prev = s + len;
+            }
+        }
+    }
+    const uint32_t cnt = have ? nrec - k0 : 0u;
+    uint32_t a_incl = FMT == 1 ? nlit : bytes, c_incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        a_incl += sub_shfl(a_incl, sidx - d, rev, 0u);
+        if constexpr (FMT == 1)
+            c_incl += sub_shfl(c_incl, sidx - d, rev, 0u);
+    }
+    const uint32_t a_total = sub_shfl(a_incl, 63, rev, 0u);
+    uint32_t o_pos = a_incl - (FMT == 1 ? nlit : bytes);
+    uint32_t q_pos = FMT == 1 ? c_incl - cnt : 0u;
+    const uint32_t last_kept_end = sub_shfl(kincl, 63, rev, 0u);
+
+    K5P(6);
+    // ---- emission: every lane writes its own sequences; literal runs above 16 bytes are copied by the whole wave ----
+    if (!(dbg & 1024u))
+    {
+        uint32_t prev = prev0;
+        const uint64_t anyrec = __builtin_amdgcn_ballot_w64(cnt != 0u);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+        {
+            const bool on = (uint32_t)k >= k0 && (uint32_t)k < nrec;
+            if (anyrec == 0ull || __builtin_amdgcn_ballot_w64(on) == 0ull)
+                continue;
+            uint32_t lit = 0, lit_src = 0, lit_dst = 0;
+            if (on)
+            {
+                const uint32_t s = rsl[k] & 0xFFFFu, len = rsl[k] >> 16, off = roff[k];
+                lit = s - prev;
+                lit_src = prev;
+                if constexpr (FMT == 1)
+                {
+                    lit_dst = o_pos;
+                    zrecs[q_pos] = (uint64_t)lit | ((uint64_t)len << 16) | ((uint64_t)off << 32);
+                    ++q_pos;
+                    o_pos += lit;
+                }
+                else
+                {
+                    uint8_t* o = out + o_pos;
+                    const uint32_t mcode = len - 4u;
+                    o[0] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
+                    uint32_t idx = 1u;
+                    if (lit >= 15u)
+                    {
+                        uint32_t rem = lit - 15u;
+                        for (; rem >= 255u; rem -= 255u)
+                            o[idx++] = 255;
+                        o[idx++] = (uint8_t)rem;
+                    }
+                    lit_dst = o_pos + idx;
+                    idx += lit;
+                    o[idx] = (uint8_t)off;
+                    o[idx + 1u] = (uint8_t)(off >> 8);
+                    idx += 2u;
+                    if (mcode >= 15u)
+                    {
+                        uint32_t rem = mcode - 15u;
+                        for (; rem >= 255u; rem -= 255u)
+                            o[idx++] = 255;
+                        o[idx++] = (uint8_t)rem;
+                    }
+                    o_pos += idx;
+                }
+                prev = s + len;
+                if (lit <= 16u)
+                {
+                    uint8_t* o = out + lit_dst;
+                    for (uint32_t j = 0; j < lit; ++j)
+                        o[j] = (uint8_t)lds_byte<PAD>(sdata, lit_src + j + head);
+                }
+            }
+            uint64_t big = __builtin_amdgcn_ballot_w64(on && lit > 16u);
+            while (big)
+            {
+                const int f = __builtin_ctzll(big);
+                big &= big - 1ull;
+                wave_copy_lds_to_global<PAD>(out + __builtin_amdgcn_readlane(lit_dst, f), sdata, __builtin_amdgcn_readlane(lit_src, f) + head,
+                                        __builtin_amdgcn_readlane(lit, f), lane);
+            }
+        }
+    }
+    K5P(7);
+    // ---- the unit's result, as the batch parser leaves it ----
+    const uint64_t hm = __builtin_amdgcn_ballot_w64(have);
+    st.have_first = hm != 0ull;
+    st.anchor = hm ? last_kept_end : my_start;
+    if constexpr (FMT == 1)
+    {
+        st.op = a_total; // literal bytes so far
+        st.nseq = sub_shfl(c_incl, 63, rev, 0u);
+    }
+    else
+    {
+        st.op = a_total;
+        if (hm)
+        {
+            const int f = 63 - __builtin_clzll(hm); // the lane of the first sub-unit with a sequence
+            const uint32_t first_start = __builtin_amdgcn_readlane(first_start_v, f);
+            st.first_lit = first_start - my_start;
+            st.first_hdr = 1u + lz4_len_bytes(st.first_lit);
+        }
+    }
+}
+
 // TAB = entries of a wave's private table (any multiple of 8: the index is mulhi(hash, TAB), not a mask); G = units per window
 // group = waves per workgroup; MODE 0 = batch parser, 1 = lane parser for groups whose probe finds redundancy (incompressible
 // groups are skimmed by the batch parser's miss mode either way)
 // CLS (MODE 0 only) = classification pass of the two-pass scheme: groups without redundancy are skimmed here and now (the fast
 // geometry: 24 waves per CU), groups with redundancy are only NOTED -- the 16-unit group they belong to goes onto `worklist` --
 // and left to the lane parser, which then runs over that list.
-template <int G, int TAB, int FMT, int MODE, int CLS = 0, int SH = 0>
+// PV (lane parser only) = formulation of the parse: 0 lz4_lane_parse, 2 lz4_lane_parse2 (same payloads)
+template <int G, int TAB, int FMT, int MODE, int CLS = 0, int SH = 0, int PV = 0>
 __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
                                                              uint32_t nblocks, uint32_t grp0, uint32_t sub_bytes,
                                                              uint8_t* __restrict__ streams, Lz4Meta* __restrict__ meta,
@@ -716,7 +1200,8 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
                                                              uint64_t* __restrict__ lane_recs, uint32_t ngroups, uint32_t* __restrict__ worklist)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t data_bytes = G * sub_bytes + 64u;
+    constexpr bool PAD = PV == 2; // the window is the padded one (lds_dw / lz4_window_lds_bytes)
+    const uint32_t data_bytes = lz4_window_lds_bytes(G * sub_bytes + 64u + (PAD ? LZ4_LPAD : 0u), PAD);
     uint32_t* sdata = smem;
     const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(sdata);
     uint32_t* flag = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes); // 16 bytes
@@ -778,18 +1263,43 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     const uint8_t* g = src + blk.src_off + group_start;
 
     // ---- stage the whole group with every wave (16-byte loads from the aligned-down address), clear my table ----
-    const uint32_t head = (uint32_t)((uintptr_t)g & 15u);
+    const uint32_t head_src = (uint32_t)((uintptr_t)g & 15u);
+    // LDS byte address of position 0 of the group: the source's misalignment (the window is staged in aligned 16-byte lines) and, for
+    // the second formulation of the lane parser, one line of padding in front (its extension reads 8 bytes below a position)
+    const uint32_t head = head_src + (PV == 2 ? LZ4_LPAD : 0u);
     {
-        const uint4* gv = reinterpret_cast<const uint4*>(g - head);
-        const uint32_t nvec = (head + glen + 15u) >> 4;
+        const uint4* gv = reinterpret_cast<const uint4*>(g - head_src);
+        const uint32_t nvec = (head_src + glen + 15u) >> 4;
         uint4* sv = reinterpret_cast<uint4*>(sdata);
+        // line v of the source goes to window bytes 16 v (+ the pad line of PV 2); in the padded window a line stays whole (16 | 128) but
+        // is only dword aligned
+        [[maybe_unused]] auto put_line = [&](uint32_t v, const uint4& x) {
+            if constexpr (PAD)
+            {
+                const uint32_t D = 4u * (v + LZ4_LPAD / 16u);
+                uint32_t* q = sdata + lds_pidx<true>(D);
+                q[0] = x.x;
+                q[1] = x.y;
+                q[2] = x.z;
+                q[3] = x.w;
+                if ((D & 31u) == 0u && D != 0u) // the first line of a row: its first dwords are repeated behind the row before
+                {
+                    static_assert(LZ4_ROW_DUP == 3, "three repeated dwords");
+                    q[-3] = x.x;
+                    q[-2] = x.y;
+                    q[-1] = x.z;
+                }
+            }
+            else
+                sv[v] = x;
+        };
         // SH: the aligned dwords of the group enter the shared table straight from the registers that stage them (whoever holds a
         // line inserts it: the minimum does not care); entries carry the group's tag in their upper half -- it counts DOWN, so a
         // newer group's entry is smaller than any older one and the table is never cleared between groups
         [[maybe_unused]] auto seed_line = [&](const uint4& line, uint32_t v) {
             if constexpr (SH != 0)
             {
-                const uint32_t q = 16u * v - head; // position of the line's first byte (line 0: "negative" = above the group)
+                const uint32_t q = 16u * v - head_src; // position of the line's first byte (line 0: "negative" = above the group)
                 const uint32_t g4[4] = {line.x, line.y, line.z, line.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -801,7 +1311,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
                 }
             }
         };
-        if (MODE == 1 && have_pre)
+        if (MODE == 1 && PV != 2 && have_pre)
         {
 #pragma unroll
             for (int u = 0; u < 5; ++u)
@@ -809,7 +1319,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
                 const uint32_t v = u * 64 * G + tid;
                 if (v < nvec)
                 {
-                    sv[v] = pre[u];
+                    put_line(v, pre[u]);
                     seed_line(pre[u], v);
                 }
             }
@@ -830,7 +1340,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
                 const uint32_t v = v0 + u * 64 * G + tid;
                 if (v < nvec)
                 {
-                    sv[v] = q[u];
+                    put_line(v, q[u]);
                     if (MODE == 1)
                         seed_line(q[u], v);
                 }
@@ -858,7 +1368,10 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         const uint32_t nidx = ticketed ? flag[1] : gidx + grp_step;
         next_gidx = nidx;
         have_pre = false;
-        if (nidx < grp_end && !(dbg & 4096u))
+        // (PV 2 does without the register prefetch: its 20 VGPRs are the parser's records and window now, and with the prefetch off --
+        // LTHIP_LZ4_DBG bit 12 -- the round-3 kernel measured the same time: the staging loads of one workgroup hide behind the parse of
+        // nothing, but they are 5 % of the group's time)
+        if (PV != 2 && nidx < grp_end && !(dbg & 4096u))
         {
             const uint32_t nxt = listed ? worklist[1u + nidx] : nidx;
             uint32_t lo2 = 0, hi2 = nblocks;
@@ -965,6 +1478,12 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
                     for (int u = 0; u < 4; ++u)
                     {
                         const uint32_t j = j0 + u * 64 + (uint32_t)lane;
+                        if constexpr (PAD)
+                        {
+                            const uint32_t* q = sdata + lds_pidx<true>(4u * j);
+                            w[u] = j < l1 ? make_uint4(q[0], q[1], q[2], q[3]) : make_uint4(0, 0, 0, 0);
+                        }
+                        else
                         w[u] = j < l1 ? s128[j] : make_uint4(0, 0, 0, 0);
                     }
 #pragma unroll
@@ -1069,8 +1588,12 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             if (emit_unit)
             {
                 K5P(2);
-                lz4_lane_parse<TAB, FMT, SH>(sdata, head, ptab, shr, sh_base, lane, my_start, my_len, start_limit, end_limit, sub, out, recs,
-                                         lane_recs + (uint64_t)unit * (64u * LZ4_LANE_MAXREC), st, dbg K5P_PASS);
+                if constexpr (PV == 2)
+                    lz4_lane_parse2<TAB, FMT, SH>(sdata, head, ptab, shr, sh_base, lane, my_start, my_len, start_limit, end_limit, sub, out, recs, st,
+                                                  dbg K5P_PASS);
+                else
+                    lz4_lane_parse<TAB, FMT, SH>(sdata, head, ptab, shr, sh_base, lane, my_start, my_len, start_limit, end_limit, sub, out, recs,
+                                                 lane_recs + (uint64_t)unit * (64u * LZ4_LANE_MAXREC), st, dbg K5P_PASS);
             }
         }
     }
@@ -1418,7 +1941,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         if (st.nseq != 0u)
         {
             for (uint32_t j = lane; j < tail; j += 64)
-                out[st.op + j] = sbytes[st.anchor + j + head];
+                out[st.op + j] = (uint8_t)lds_byte<PAD>(sdata, st.anchor + j + head);
         }
         else if (emit_unit && spec_dst)
         {
@@ -1430,28 +1953,28 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             const uint32_t pos = group_start + my_start;
             const uint64_t o = 13u + (uint64_t)(pos / Z_PIECE) * (Z_PIECE + 3u) + 3u + pos % Z_PIECE;
             if (o + my_len <= (uint64_t)blk.dst_cap)
-                wave_copy_lds_to_global(spec_dst + blk.dst_off + o, sdata, my_start + head, my_len, lane);
+                wave_copy_lds_to_global<PAD>(spec_dst + blk.dst_off + o, sdata, my_start + head, my_len, lane);
         }
         // is the unit one repeated byte?  (zstd stores a 128 KiB piece made of such units as an RLE_Block)
         uint32_t uniform = 0;
         if (emit_unit)
         {
-            const uint32_t b0 = sbytes[my_start + head];
+            const uint32_t b0 = lds_byte<PAD>(sdata, my_start + head);
             const uint32_t rep = b0 * 0x01010101u;
             uint32_t diff = 0;
             // almost always settled by the first dword of every lane's 64 bytes
             if (64u * (uint32_t)lane + 4u <= my_len)
-                diff = lds_read32(sdata, my_start + 64u * (uint32_t)lane + head) ^ rep;
+                diff = lds_read32x<PAD>(sdata, my_start + 64u * (uint32_t)lane + head) ^ rep;
             if (__builtin_amdgcn_ballot_w64(diff != 0u) == 0ull)
 #pragma unroll 4
             for (uint32_t j = 0; j < 16u; ++j)
             {
                 const uint32_t o = 64u * (uint32_t)lane + 4u * j;
                 if (o + 4u <= my_len)
-                    diff |= lds_read32(sdata, my_start + o + head) ^ rep;
+                    diff |= lds_read32x<PAD>(sdata, my_start + o + head) ^ rep;
                 else if (o < my_len)
                     for (uint32_t k = o; k < my_len; ++k)
-                        diff |= (uint32_t)sbytes[my_start + k + head] ^ b0;
+                        diff |= lds_byte<PAD>(sdata, my_start + k + head) ^ b0;
             }
             uniform = __builtin_amdgcn_ballot_w64(diff != 0u) == 0ull ? (0x100u | b0) : 0u;
         }
@@ -1469,7 +1992,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     {
         const uint64_t o = (uint64_t)(1u + lz4_len_bytes(blk.size)) + group_start + my_start;
         if (o + my_len <= (uint64_t)blk.dst_cap)
-            wave_copy_lds_to_global(spec_dst + blk.dst_off + o, sdata, my_start + head, my_len, lane);
+            wave_copy_lds_to_global<PAD>(spec_dst + blk.dst_off + o, sdata, my_start + head, my_len, lane);
     }
     if (emit_unit && lane == 0)
     {
@@ -1831,14 +2354,18 @@ static bool lz4_lane_parser()
     return v;
 }
 
-template <int G, int TAB, int FMT, int MODE, int CLS = 0, int SH = 0>
+template <int G, int TAB, int FMT, int MODE, int CLS = 0, int SH = 0, int PV = 0>
 static int launch_segments(lthip_ctx* ctx, uint32_t groups, uint32_t SEG, const void* d_src, const Lz4Block* d_blocks, uint32_t block_count,
                            uint32_t g0, uint8_t* streams, Lz4Meta* meta, uint64_t* zrecs, uint8_t* spec_dst, uint32_t dbg, uint64_t* lane_recs,
                            uint32_t ngroups, uint32_t* worklist)
 {
-    const size_t lds = (size_t)G * SEG + 64 + 16 + (size_t)G * TAB * 2 + (SH ? (size_t)4 << SH : 0);
+    const size_t lds = (size_t)lz4_window_lds_bytes(G * SEG + 64u + (PV == 2 ? LZ4_LPAD : 0u), PV == 2) + 16 + (size_t)G * TAB * 2 + (SH ? (size_t)4 << SH : 0);
     if (lds > 64u * 1024u && !ctx->k5_lds_enabled)
     {
+        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_SHARED, 0, 1, 0, LZ4_SH_LOG2, 2>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_SHARED, 1, 1, 0, LZ4_SH_LOG2, 2>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_SHARED, 0, 1, 0, LZ4_SH_LOG2>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_SHARED, 1, 1, 0, LZ4_SH_LOG2>),
@@ -1856,7 +2383,7 @@ static int launch_segments(lthip_ctx* ctx, uint32_t groups, uint32_t SEG, const 
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
         grid = groups < (uint32_t)ncu ? groups : (uint32_t)ncu; // one persistent workgroup per CU
     }
-    hipLaunchKernelGGL((k_lz4_segments<G, TAB, FMT, MODE, CLS, SH>), dim3(grid), dim3(64 * G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
+    hipLaunchKernelGGL((k_lz4_segments<G, TAB, FMT, MODE, CLS, SH, PV>), dim3(grid), dim3(64 * G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
                        block_count, g0, SEG, streams, meta, zrecs, spec_dst, dbg, lane_recs, ngroups, worklist);
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
@@ -1877,6 +2404,11 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
     // LTHIP_LZ4_SHARED=0: round 2/3a's history (prefix maximum over the waves' 2560-entry tables) instead of the shared table
     static LthipEnvInt env_shared{"LTHIP_LZ4_SHARED"};
     const bool shared = env_shared.get() != 0;
+    static LthipEnvInt env_pv{"LTHIP_LZ4_PV"}; // 0: the round-3 formulation of the lane parse (lz4_lane_parse), default: the round-4 one
+    const bool pv2 = shared && env_pv.get() != 0;
+    if (pv2 && (dbg & 16384u))
+        return launch_segments<LZ4_G_LANES, LZ4_TAB_SHARED, FMT, 1, 0, LZ4_SH_LOG2, 2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta,
+                                                                                      zrecs, spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr);
     if (dbg & 16384u) // ablation: the lane kernel alone, with its own probe
         return shared ? launch_segments<LZ4_G_LANES, LZ4_TAB_SHARED, FMT, 1, 0, LZ4_SH_LOG2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams,
                                                                                             meta, zrecs, spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr)
@@ -1891,6 +2423,9 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
                                                                                              streams, meta, zrecs, spec_dst, dbg, nullptr,
                                                                                              (uint32_t)ngrp, (uint32_t*)wl)))
         return err;
+    if (pv2)
+        return launch_segments<LZ4_G_LANES, LZ4_TAB_SHARED, FMT, 1, 0, LZ4_SH_LOG2, 2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta,
+                                                                                      zrecs, spec_dst, dbg, lane_recs, (uint32_t)ngrp, (uint32_t*)wl);
     if (shared)
         return launch_segments<LZ4_G_LANES, LZ4_TAB_SHARED, FMT, 1, 0, LZ4_SH_LOG2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta,
                                                                                    zrecs, spec_dst, dbg, lane_recs, (uint32_t)ngrp, (uint32_t*)wl);

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <vector>
 
 #include "../../include/longtail_hip.h"
@@ -140,19 +141,22 @@ int lthip_fail(lthip_ctx* ctx, int code, const char* what, const char* detail);
 extern volatile uint32_t g_lthip_env_gen;
 struct LthipEnvInt
 {
+    // (function-local statics shared by every host thread of the plugin layer: the value is published before the generation it
+    // belongs to, so a reader that sees the generation sees the value)
     const char* name;
-    int value;     // atoi of the variable; -1 when it is not set
-    uint32_t seen; // generation the value was read at (0: never)
+    std::atomic<int> value{-1};     // atoi of the variable; -1 when it is not set
+    std::atomic<uint32_t> seen{0};  // generation the value was read at (0: never)
+    explicit LthipEnvInt(const char* n) : name(n) {}
     int get()
     {
         const uint32_t gen = g_lthip_env_gen;
-        if (seen != gen)
+        if (seen.load(std::memory_order_acquire) != gen)
         {
             const char* e = getenv(name);
-            value = e ? atoi(e) : -1;
-            seen = gen;
+            value.store(e ? atoi(e) : -1, std::memory_order_relaxed);
+            seen.store(gen, std::memory_order_release);
         }
-        return value;
+        return value.load(std::memory_order_relaxed);
     }
 };
 int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out);
