@@ -112,17 +112,26 @@ __device__ __forceinline__ uint32_t lds_pidx(uint32_t D)
 {
     return PAD ? D + LZ4_ROW_DUP * (D >> 5) : D;
 }
+// the dword that holds window byte x, as a pointer: x + 12 (x >> 7) in bytes -- a shift and one v_mad_u32_u24 (a 32-bit multiply is
+// a quarter-rate instruction), the runs then use the LDS instructions' immediate offsets
+template <bool PAD>
+__device__ __forceinline__ const uint32_t* lds_ptr(const uint32_t* sdata, uint32_t x)
+{
+    const uint32_t xa = x & ~3u;
+    const uint32_t a = PAD ? __umul24(xa >> 7, 4u * LZ4_ROW_DUP) + xa : xa;
+    return reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(sdata) + a);
+}
 template <bool PAD>
 __device__ __forceinline__ uint32_t lds_dw(const uint32_t* sdata, uint32_t D)
 {
-    return sdata[lds_pidx<PAD>(D)];
+    return *lds_ptr<PAD>(sdata, D << 2);
 }
 // N <= 4 consecutive dwords of the window from dword D
 template <bool PAD, int N>
 __device__ __forceinline__ void lds_run(const uint32_t* sdata, uint32_t D, uint32_t* out)
 {
     static_assert(N >= 1 && N <= 1 + (int)LZ4_ROW_DUP, "a run is contiguous up to 1 + LZ4_ROW_DUP dwords");
-    const uint32_t* q = sdata + lds_pidx<PAD>(D);
+    const uint32_t* q = lds_ptr<PAD>(sdata, D << 2);
 #pragma unroll
     for (int k = 0; k < N; ++k)
         out[k] = q[k];
@@ -130,7 +139,7 @@ __device__ __forceinline__ void lds_run(const uint32_t* sdata, uint32_t D, uint3
 template <bool PAD>
 __device__ __forceinline__ uint32_t lds_byte(const uint32_t* sdata, uint32_t x)
 {
-    return reinterpret_cast<const uint8_t*>(sdata)[PAD ? x + 4u * LZ4_ROW_DUP * (x >> 7) : x];
+    return reinterpret_cast<const uint8_t*>(sdata)[PAD ? x + __umul24(x >> 7, 4u * LZ4_ROW_DUP) : x];
 }
 template <bool PAD>
 __device__ __forceinline__ uint32_t lds_read32x(const uint32_t* sdata, uint32_t byte_idx)
@@ -782,6 +791,18 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t LZ4_LPAD = 16; // PV 2: LDS byte offset of the staged window
 
+// slot of a private table of TAB entries for the (multiplied) hash `prod`.  PV 0: mulhi(prod, TAB), a quarter-rate 32-bit multiply;
+// PV 2: the upper 16 bits of prod times TAB, a 24-bit multiply and a shift (TAB < 2^16) -- another function of the same bits, so the two
+// formulations fill their tables differently (ratios agree to the fourth digit)
+template <int TAB, int PV>
+__device__ __forceinline__ uint32_t lz4_tab_slot(uint32_t prod)
+{
+    if constexpr (PV == 2)
+        return __umul24(prod >> 16, (uint32_t)TAB) >> 16;
+    else
+        return __umulhi(prod, (uint32_t)TAB);
+}
+
 // equal leading bytes (0..16) of the 16 bytes at LDS byte addresses qa and qb (any alignment): five aligned dwords per side
 template <bool PAD>
 __device__ __forceinline__ uint32_t lds_cmp16(const uint32_t* sdata, uint32_t qa, uint32_t qb)
@@ -857,7 +878,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
             {
                 const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, (p + head) & 3u);
                 const uint32_t prod = v * 2654435761u;
-                const uint32_t h = __umulhi(prod, (uint32_t)TAB);
+                const uint32_t h = lz4_tab_slot<TAB, 2>(prod);
                 uint32_t c = tab[h];
                 const uint32_t c2 = shr[prod >> (32 - SH)] - sh_base; // (another group's entry: far above any position)
                 tab[h] = (uint16_t)p;
@@ -1497,7 +1518,7 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
                         {
                             const uint32_t pk = q + 4u * k;
                             if (j < l1 && pk >= p0 && pk < my_start) // (a wrapped "negative" position is above the unit)
-                                tab[__umulhi(g4[k] * 2654435761u, (uint32_t)TAB)] = (uint16_t)pk;
+                                tab[lz4_tab_slot<TAB, PV>(g4[k] * 2654435761u)] = (uint16_t)pk;
                         }
                     }
                 }
