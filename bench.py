@@ -60,8 +60,12 @@ def asset_seeds(tree_seed: int, first: int, count: int) -> np.ndarray:
         return synth_mix(np.uint64(tree_seed) + np.uint64(0x9E3779B97F4A7C15) * idx)
 
 
-def make_tree(kind_of_tree: str, total_bytes: int, file_bytes: int):
-    """The tree as a struct Longtail_FileInfos taken apart (src/longtail.h:1684-1692): sizes, path data, offsets, permissions."""
+def make_tree(kind_of_tree: str, total_bytes: int, file_bytes: int, dups: bool = False):
+    """The tree as a struct Longtail_FileInfos taken apart (src/longtail.h:1684-1692): sizes, path data, offsets, permissions.
+    dups: a quarter of the files repeat earlier ones (SURVEY.md §8d "dedup (duplicate files)") -- file i with i % 8 == 5 is file i - 3
+    again, byte for byte; file i with i % 8 == 7 is file i - 5 SHIFTED: the same byte stream entered 20 KiB + 16 (i % 64) bytes later,
+    so its first chunks are new, the cuts then fall back into step (content-defined chunking) and the rest of its chunks are known
+    ones -- blocks whose unique chunks are not one byte range of the data (device block assembly, src/longtail.c:4640-4721)."""
     if kind_of_tree == "files":
         n = max(1, total_bytes // file_bytes)
         sizes = np.full(n, file_bytes, dtype=np.uint64)
@@ -80,7 +84,18 @@ def make_tree(kind_of_tree: str, total_bytes: int, file_bytes: int):
     path_offsets = np.zeros(n, np.uint32)
     np.cumsum(lens[:-1], out=path_offsets[1:])
     path_data = ("\0".join(names) + "\0").encode()
-    return dict(sizes=sizes, path_data=path_data, path_offsets=path_offsets, perms=np.full(n, 0o644, np.uint16), nfiles=n)
+    seed_of, shift = np.arange(n, dtype=np.int64), np.zeros(n, np.uint64)
+    if dups:
+        idx = np.arange(n, dtype=np.int64)
+        whole = (idx % 8 == 5) & (idx >= 3)
+        moved = (idx % 8 == 7) & (idx >= 5)
+        seed_of[whole] = idx[whole] - 3
+        seed_of[moved] = idx[moved] - 5
+        shift[moved] = (20480 + 16 * (idx[moved] % 64)).astype(np.uint64)
+        if kind_of_tree != "files":  # a copy is as long as its original is: the generator's stream has no end, the tree's sizes stay
+            pass
+    return dict(sizes=sizes, path_data=path_data, path_offsets=path_offsets, perms=np.full(n, 0o644, np.uint16), nfiles=n,
+                seed_of=seed_of, shift=shift, dups=bool(dups))
 
 
 def plain_comm(lib, ctx, rank, world, idfile=None, timeout_s=120):
@@ -259,6 +274,32 @@ class Bench:
         elif self.world > 1:
             self.comm_info = {"nranks": dist.get_world_size(), "rank": dist.get_rank(), "transport": f"torch.distributed/{dist.get_backend()}"}
 
+    def measure_peak(self, gib=4):
+        """What this box's memory system delivers to plain streaming kernels (tools/hbm_peak.py, SURVEY.md §8d "use the measured peak
+        as denominator too"): device copy (read + write) and read-only reduction, GB/s, best of 3 on `gib` GiB."""
+        torch = self.torch
+        n = int(gib) << 30
+        a = self.buf("data", n + 256)[:n]
+        b = self.buf("arena", n)[:n]
+
+        def best(f):
+            f()
+            torch.cuda.synchronize(self.dev)
+            t = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                f()
+                torch.cuda.synchronize(self.dev)
+                dt = time.perf_counter() - t0
+                t = dt if t is None or dt < t else t
+            return t
+
+        c = best(lambda: b.copy_(a))
+        r = best(lambda: a.view(torch.int64).sum())
+        self.peak_measured = {"copy_GBps": round(2 * n / c / 1e9, 1), "read_GBps": round(n / r / 1e9, 1),
+                              "how": f"torch device copy / int64 sum over {gib} GiB, best of 3 (tools/hbm_peak.py)"}
+        return self.peak_measured
+
     def reduce(self, values, op="sum"):
         """All-reduce of a few host numbers over the ranks (max of the wall time, sums of the result counters)."""
         torch = self.torch
@@ -346,7 +387,7 @@ class Bench:
         total_bytes = int(cfg["gib"] * (1 << 30)) * (world if cfg["scaling"] == "weak" else 1)
         file_bytes = int(cfg["file_mib"] * (1 << 20))
         file_bytes -= file_bytes % 16
-        tree = make_tree(cfg["tree"], total_bytes, file_bytes)
+        tree = make_tree(cfg["tree"], total_bytes, file_bytes, dups=cfg.get("dups", False))
         tree_bytes = int(tree["sizes"].sum())
         part = JobPartition(tree["sizes"], args.target_chunk_size, world, cfg["partition"], self.lib)
         mine = part.jobs_of(rank)
@@ -358,8 +399,9 @@ class Bench:
         my_bytes = int(p_size.sum())
         arena_in = int(p_off[-1] + p_size[-1]) if len(mine) else 0
         data = self.buf("data", arena_in + 256)
-        seeds = asset_seeds(0x10C0FFEE, 0, tree["nfiles"])
-        ctx.synth_fill(data, p_off, p_size, seeds[part.job_asset[mine]], KINDS[cfg["kind"]], skips=part.job_offset[mine])
+        seeds = asset_seeds(0x10C0FFEE, 0, tree["nfiles"])[tree["seed_of"]]  # (a repeated file has the seed of its original)
+        ctx.synth_fill(data, p_off, p_size, seeds[part.job_asset[mine]], KINDS[cfg["kind"]],
+                       skips=part.job_offset[mine] + tree["shift"][part.job_asset[mine]])
         ctx.sync()
 
         # ---- output arrays and arenas (allocated once; nothing is allocated in steady state) ----
@@ -455,7 +497,12 @@ class Bench:
         plan.close()
 
         # ---- per-kernel rates: ALGORITHMIC bytes per launch / average launch duration (HIP events on the stream) ----
-        alg_bytes = {"buzhash": my_bytes, "blake3_leaf": my_bytes, "lz4_segments": my_bytes, "zstd_encode": my_bytes + res.compressed_bytes}
+        # phase 1 = N read per kernel; LZ4 match finder / zstd entropy stage = N read + N_out written, N = the bytes
+        # this rank WRITES (unique chunks: what reaches the codec), N_out its payload bytes
+        codec_in = int(res.raw_bytes)
+        alg_bytes = {"buzhash": my_bytes, "blake3_leaf": my_bytes, "lz4_segments": codec_in + int(res.compressed_bytes),
+                     "zstd_encode": codec_in + int(res.compressed_bytes)}
+        alg_input_only = {"buzhash": my_bytes, "blake3_leaf": my_bytes, "lz4_segments": codec_in, "zstd_encode": codec_in}
         kern = {}
         for name, (ms, n) in ktimes.items():
             if n:
@@ -471,7 +518,15 @@ class Bench:
             achieved = alg_bytes[dom] / launches / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                        "algorithmic_bytes_per_launch": int(alg_bytes[dom] / launches), "avg_launch_ms": round(avg_ms, 3)}
+                        "algorithmic_bytes_per_launch": int(alg_bytes[dom] / launches), "avg_launch_ms": round(avg_ms, 3),
+                        "algorithmic_bytes": "SURVEY.md §8(d): N read per phase-1 kernel; N read + N_out written for the codec kernels",
+                        "frac_over_input_only": round(alg_input_only[dom] / launches / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            pm = getattr(self, "peak_measured", None)
+            if pm:
+                # the box's own memory system beside the nominal figure: a device copy for kernels that read and write (the codec),
+                # a read-only reduction for the ones that only read (scan, hash)
+                ref = pm["copy_GBps"] if dom in ("lz4_segments", "zstd_encode") else pm["read_GBps"]
+                roofline["peak_measured"] = dict(pm, frac=round(achieved / ref, 4), against="copy" if dom in ("lz4_segments", "zstd_encode") else "read")
             if dom in VALU_INSTR_PER_4KIB:
                 roof = VALU_ISSUE_PER_S / VALU_INSTR_PER_4KIB[dom] * 4096 / 1e9
                 roofline["valu"] = {"instr_per_4KiB_wave_tile": VALU_INSTR_PER_4KIB[dom], "issue_roof_GBps": round(roof, 1),
@@ -519,7 +574,8 @@ class Bench:
                                     "traffic_over_algorithmic": None if pipeline_traffic is None else round(pipeline_traffic * my_bytes / alg_pipeline, 3),
                                     "note": "all kernels of one step (three serial passes over the input: scan, hash, codec); traffic = sum of the kernels' "
                                             "memory-side bytes from the same PMC file"}
-        label = {"files": f"{cfg['gib']:g} GiB tree of {cfg['file_mib']:g} MiB {cfg['kind']} files",
+        dup_note = ", a quarter of the files repeated (whole and shifted)" if cfg.get("dups") else ""
+        label = {"files": f"{cfg['gib']:g} GiB tree of {cfg['file_mib']:g} MiB {cfg['kind']} files{dup_note}",
                  "mixed-sizes": f"{cfg['gib']:g} GiB tree of {cfg['kind']} files, 4 KiB..4 GiB log-uniform (north-star tree)"}[cfg["tree"]]
         per = "per GPU" if cfg["scaling"] == "weak" else "in total"
         which = ""
@@ -539,6 +595,9 @@ class Bench:
             "result": {"chunks": int(res.chunks_all), "unique_chunks": int(res.unique_all), "blocks": int(blocks),
                        "raw_bytes_written": int(raw), "compressed_bytes": int(comp),
                        "ratio": round(raw / comp, 4) if comp else None, "gathered_blocks_rank0": int(res.gathered_blocks),
+                       "gathered_bytes_rank0": int(res.gathered_bytes),
+                       "gather_GBps_rank0": (round(res.gathered_bytes / (kern["gather"]["ms_per_step"] * 1e-3) / 1e9, 1)
+                                             if res.gathered_bytes and "gather" in kern else None),
                        "version_index_bytes": int(res.version_index_size), "store_index_bytes_rank0": int(res.store_index_size)},
         }
 
@@ -570,6 +629,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: print how the tree's (asset, part) jobs fall onto --gpus ranks and what the exchange moves")
     ap.add_argument("--no-secondary", action="store_true", help="skip the compressible / mixed-size-tree measurements")
+    ap.add_argument("--dups", action="store_true", help="a quarter of the tree's files repeat earlier ones (whole-file and shifted duplicates)")
     ap.add_argument("--launch", choices=["torch", "plain"], default="torch",
                     help="--gpus N > 1 started without a launcher (WORLD_SIZE unset): how this process starts its N ranks -- 'torch': the "
                          "environment of torch.distributed.run (collectives by torch.distributed = RCCL), 'plain': no torch.distributed, "
@@ -601,19 +661,27 @@ def main():
     b = Bench(args)
     b.traffic, b.traffic_cfg = traffic, dict(kind=args.kind, codec=args.codec, tree=args.tree)
     cfg = dict(tree=args.tree, kind=args.kind, codec=args.codec, gib=args.gib, file_mib=args.file_mib, scaling=args.scaling,
-               partition=args.partition)
+               partition=args.partition, dups=args.dups)
+    if b.world == 1 and not under_profiler:
+        b.measure_peak(4 if args.gib >= 8 else 1)
     main_res = b.run(cfg, args.steps, args.warmup)
     secondary = None
     default_headline = args.tree == "files" and args.kind == "random" and args.codec == "lz4" and not args.no_compress
     if not args.no_secondary and default_headline:
         # "report both" -- the compressible variant (match path + a real ratio) and the north-star tree
         secondary = {}
-        for name, over in (("compressible", dict(kind="mixed")), ("north_star_tree", dict(tree="mixed-sizes")),
+        for name, over in (("compressible", dict(kind="mixed")), ("dedup", dict(kind="mixed", dups=True)),
+                           ("north_star_tree", dict(tree="mixed-sizes")),
                            ("north_star_tree_compressible", dict(tree="mixed-sizes", kind="mixed"))):
             r = b.run(dict(cfg, **over), max(1, min(args.steps, 2)), 1)
             secondary[name] = {"value": round(r["value"], 3), "unit": "GB/s", "ms_per_step": round(r["ms_per_step"], 3),
                                "workload": r["workload"], "ratio": r["result"]["ratio"], "phase_ms": r["phase_ms"],
                                "dominant_kernel": r["roofline"] and {k: r["roofline"][k] for k in ("kernel", "achieved", "frac")}}
+            if over.get("dups"):
+                # first-seen hits, CreateMissingContent with chunks to drop, blocks assembled from non-contiguous unique chunks
+                secondary[name].update({k: r["result"][k] for k in ("chunks", "unique_chunks", "blocks", "raw_bytes_written",
+                                                                    "gathered_blocks_rank0", "gathered_bytes_rank0", "gather_GBps_rank0")})
+                secondary[name]["dedup_table"] = args.dedup if b.world > 1 else "single rank"
         if b.world == 1:
             secondary["restore"] = b.restore_rates()
     cpu_baseline = None

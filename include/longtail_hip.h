@@ -126,7 +126,8 @@ enum lthip_kernel_id
     LTHIP_K_LZ4_STITCH = 6,/* LZ4 stitch scan + compaction copy */
     LTHIP_K_OTHER = 7,
     LTHIP_K_ZSTD_ENC = 8, /* zstd entropy stage (Huffman literals, FSE sequences), one wave per 128 KiB piece */
-    LTHIP_K_COUNT = 9
+    LTHIP_K_GATHER = 9,   /* device block assembly: chunk ranges -> contiguous block images (src/longtail.c:4640-4721) */
+    LTHIP_K_COUNT = 10
 };
 LTHIP_EXPORT int lthip_timing_enable(lthip_ctx* ctx, int on);
 LTHIP_EXPORT int lthip_timing_reset(lthip_ctx* ctx);
@@ -400,6 +401,7 @@ typedef struct lthip_ingest_result
     uint64_t chunks_local, unique_local;  /* chunks of this rank's jobs / those of them this rank writes */
     uint64_t blocks, raw_bytes, compressed_bytes, gathered_blocks;
     uint64_t version_index_size, store_index_size;
+    uint64_t gathered_bytes;              /* bytes of the blocks that went through the device block assembly */
 } lthip_ingest_result;
 LTHIP_EXPORT int lthip_ingest_create(lthip_ctx* ctx, const lthip_ingest_config* config, lthip_ingest** out);
 LTHIP_EXPORT void lthip_ingest_destroy(lthip_ingest* ingest);

@@ -809,7 +809,7 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
     const uint32_t* lens = (const uint32_t*)g->h_mu_len.p;
     const uint64_t* offs = (const uint64_t*)g->h_mu_off.p;
     int err;
-    uint64_t gathered_blocks = 0;
+    uint64_t gathered_blocks = 0, gathered_bytes = 0;
     std::vector<uint64_t> src_off, dst_off, img_off, g_src, g_dst, bfirst;
     std::vector<uint32_t> src_size, dst_cap, g_len, braw;
     // more blocks, when the batch being put together has taken all there are and chunks are left
@@ -958,7 +958,11 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
                     return err;
             }
             if (pass == 1)
+            {
                 gathered_blocks += k;
+                for (uint32_t i = 0; i < k; ++i)
+                    gathered_bytes += src_size[i];
+            }
         }
         tr.mark("codec");
         // ---- (first batch: the codec has work now; the rest of the packing and all block hashes) ----
@@ -1009,6 +1013,7 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
     }
     LTHIP_CHECK(ctx, hipMemcpyAsync(g->h_comp.p, g->d_sum.p, 8, hipMemcpyDeviceToHost, s));
     g->res.gathered_blocks = gathered_blocks;
+    g->res.gathered_bytes = gathered_bytes;
     g->written = true;
     return 0;
 }

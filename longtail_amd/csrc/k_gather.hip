@@ -63,7 +63,7 @@ extern "C" int lthip_gather_ranges(lthip_ctx* ctx, const void* d_src, uint64_t r
     if (range_count > 0x7FFFFFFFull)
         return lthip_fail(ctx, EINVAL, "gather", "too many ranges");
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
-    LaunchTimer t(ctx, LTHIP_K_OTHER);
+    LaunchTimer t(ctx, LTHIP_K_GATHER);
     hipLaunchKernelGGL(k_gather_ranges, dim3((uint32_t)range_count), dim3(GT), 0, ctx->stream, (const uint8_t*)d_src,
                        d_src_offsets, d_lens, d_dst_offsets, range_count, (uint8_t*)d_dst);
     LTHIP_LAUNCH_CHECK(ctx);

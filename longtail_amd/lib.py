@@ -26,6 +26,7 @@ KERNEL_IDS = {
     "lz4_stitch": 6,
     "other": 7,
     "zstd_encode": 8,
+    "gather": 9,
 }
 
 
@@ -528,7 +529,7 @@ class IngestTree(C.Structure):
 
 class IngestResult(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("chunks_all", "unique_all", "chunks_local", "unique_local", "blocks", "raw_bytes",
-                                          "compressed_bytes", "gathered_blocks", "version_index_size", "store_index_size")]
+                                          "compressed_bytes", "gathered_blocks", "version_index_size", "store_index_size", "gathered_bytes")]
 
 
 CODECS = {"none": 0, "lz4": 1, "zstd": 2}

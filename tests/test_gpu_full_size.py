@@ -180,3 +180,86 @@ def test_one_gigabyte_part_through_one_chunker(gpu, oracle, target):
     assert total == len(e_len)
     assert (d_len[:total].cpu().numpy().view(np.uint32) == e_len).all()
     assert (d_hash[:total].cpu().numpy().view(np.uint64) == e_hash).all()
+
+
+def vi_asset_chunks(blob):
+    """Per-asset chunk lists of a serialized VersionIndex (layout src/longtail.c:2551-2584): (asset sizes, chunk counts per asset,
+    chunk hashes in (asset, chunk) order, chunk sizes in that order)."""
+    h = np.frombuffer(blob[:24], np.uint32)
+    na, nu, ni = int(h[3]), int(h[4]), int(h[5])
+    o = 24 + na * 16
+    sizes = np.frombuffer(blob[o : o + na * 8], np.uint64); o += na * 8
+    counts = np.frombuffer(blob[o : o + na * 4], np.uint32); o += na * 4
+    starts = np.frombuffer(blob[o : o + na * 4], np.uint32); o += na * 4
+    idx = np.frombuffer(blob[o : o + ni * 4], np.uint32); o += ni * 4
+    hashes = np.frombuffer(blob[o : o + nu * 8], np.uint64); o += nu * 8
+    csz = np.frombuffer(blob[o : o + nu * 4], np.uint32)
+    assert (starts.astype(np.int64) == np.concatenate([[0], np.cumsum(counts.astype(np.int64))[:-1]])).all()
+    return sizes, counts, hashes[idx], csz[idx]
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs the reference build (oracle/_ref)")
+def test_every_chunk_of_the_full_tree_against_the_reference_itself(gpu, tree):
+    """ALL chunks of BASELINE.json configs[2], not a sample: the tree leaves the device in slices of 8 GiB, the reference's own
+    Longtail_CreateVersionIndex (reference hpcdc chunker + BLAKE3, bikeshed W = 32; lib/hpcdcchunker/longtail_hpcdcchunker.c:266-306,
+    src/longtail.c:2343-2550) runs on every slice, and each file's (length, hash) list must equal the device's, pair for pair."""
+    n = tree["nfiles"]
+    total, d_off, d_len, d_hash, d_first = run_plan(gpu, tree, 0, n)
+    first = d_first.cpu().numpy().view(np.uint32).astype(np.int64)
+    len_h, hash_h = d_len.cpu().numpy().view(np.uint32), d_hash.cpu().numpy().view(np.uint64)
+    r = get_ref()
+    per = (8 << 30) // FILE
+    workers = min(32, os.cpu_count() or 1)
+    checked = 0
+    secs = 0.0
+    for lo in range(0, n, per):
+        hi = min(n, lo + per)
+        host = tree["data"][lo * FILE : hi * FILE].cpu().numpy()
+        files = [(f"f{lo + i:06d}.bin", host[i * FILE : (i + 1) * FILE]) for i in range(hi - lo)]
+        blob, s = r.version_index(files, TARGET, workers=workers)
+        secs += s
+        sizes, counts, hashes, csz = vi_asset_chunks(blob)
+        assert len(sizes) == hi - lo and (sizes == FILE).all()
+        a, b = int(first[lo]), int(first[hi])
+        assert (counts.astype(np.int64) == np.diff(first[lo : hi + 1])).all(), "chunk counts per file differ from the reference"
+        assert (csz == len_h[a:b]).all(), "chunk lengths differ from the reference"
+        assert (hashes == hash_h[a:b]).all(), "chunk hashes differ from the reference"
+        checked += b - a
+    assert checked == total
+    print(f"full-size parity: {checked} (length, hash) pairs of {n} files equal to Longtail_CreateVersionIndex's ({secs:.1f} s of reference time at W={workers})")
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs the reference build (oracle/_ref)")
+def test_large_files_against_the_reference_itself(gpu):
+    """The configs[4] shape (few huge assets, many parts each) at 15.5 GiB: 8 files of 31 x 64 MiB (32 jobs each, the last one empty:
+    an exact multiple of the part size, src/longtail.c:2402), every chunk against the reference.  (Files stay below 2 GiB: the
+    reference's in-memory storage, which the harness feeds it from, does not take larger ones.)"""
+    part = TARGET * 1024
+    nf = 8 if GIB >= 16 else 2
+    fsz = 31 * part
+    # parts back to back: consecutive parts of one file are contiguous, files at 16-byte aligned offsets
+    p_off, p_size, seeds, skips = [], [], [], []
+    s4 = asset_seeds(0xC0FFEE4, 0, nf)
+    for f in range(nf):
+        for k in range(1 + fsz // part):
+            p_off.append(f * fsz + k * part)
+            p_size.append(min(part, fsz - k * part))
+            seeds.append(int(s4[f]))
+            skips.append(k * part)
+    data = torch.empty(nf * fsz + 256, dtype=torch.uint8, device="cuda")
+    gpu.synth_fill(data, np.array(p_off, np.uint64), np.array(p_size, np.uint64), np.array(seeds, np.uint64), 1, skips=np.array(skips, np.uint64))
+    mn, av, mx = chunker_params(TARGET)
+    plan = gpu.make_plan(p_off, p_size, mn, av, mx)
+    total, d_off, d_len, d_hash, d_first = gpu.chunk_hash(plan, data)
+    plan.close()
+    first = d_first.cpu().numpy().view(np.uint32).astype(np.int64)
+    len_h, hash_h = d_len[:total].cpu().numpy().view(np.uint32), d_hash[:total].cpu().numpy().view(np.uint64)
+    r = get_ref()
+    jobs_per_file = 1 + fsz // part
+    for f in range(nf):
+        host = data[f * fsz : (f + 1) * fsz].cpu().numpy()
+        blob, _ = r.version_index([(f"big{f}.pak", host)], TARGET, workers=min(32, os.cpu_count() or 1))
+        sizes, counts, hashes, csz = vi_asset_chunks(blob)
+        a, b = int(first[f * jobs_per_file]), int(first[(f + 1) * jobs_per_file])
+        assert int(sizes[0]) == fsz and int(counts[0]) == b - a
+        assert (csz == len_h[a:b]).all() and (hashes == hash_h[a:b]).all()

@@ -247,3 +247,44 @@ def test_sharded_first_seen_table_feeds_the_ingest_session(gpu, oracle):
         assert (f.cpu().numpy().astype(np.int64) == exp[idx]).all()
         tot += u
     assert tot == len(seen)
+
+
+def test_duplicate_bearing_tree_at_8_gib_matches_reference(gpu, ref):
+    """bench.py's `secondary.dedup` workload (compressible 1 MiB files, a quarter of them repeated: whole-file copies and copies entered
+    20 KiB later, whose chunking falls back into step) at 8 GiB: first-seen hits (src/longtail.c:2951-2970), CreateMissingContent with
+    chunks to drop (:6801-6860), blocks assembled from non-contiguous unique chunks (:4640-4721).  Serialized VersionIndex and StoreIndex
+    byte-identical with the reference's."""
+    import os
+
+    from bench import KINDS, asset_seeds, make_tree
+
+    gib = float(os.environ.get("LONGTAIL_DEDUP_GIB", "8"))
+    FILE = 1 << 20
+    tree = make_tree("files", int(gib * (1 << 30)), FILE, dups=True)
+    n = tree["nfiles"]
+    data = torch.empty(n * FILE + 256, dtype=torch.uint8, device="cuda")
+    seeds = asset_seeds(0x10C0FFEE, 0, n)[tree["seed_of"]]
+    gpu.synth_fill(data, np.arange(n, dtype=np.uint64) * np.uint64(FILE), np.full(n, FILE, np.uint64), seeds, KINDS["mixed"], skips=tree["shift"])
+    gpu.sync()
+    host = data[: n * FILE].cpu().numpy()
+    del data
+    names = tree["path_data"].decode().split("\0")[:n]
+    files = [(names[i], host[i * FILE : (i + 1) * FILE]) for i in range(n)]
+    assert (files[5][1] == files[2][1]).all() and not (files[7][1] == files[2][1]).all()  # whole copy / shifted copy
+    target, max_block, max_chunks, tag = 65536, 8 << 20, 1024, ref.lz4_type
+    probe = rank_session(gpu, ref, files, target, 1, 0, "range", "lz4", max_block, max_chunks, tag)
+    lists = {int(j): (probe["d_hash"][int(probe["first"][m]) : int(probe["first"][m + 1])], probe["d_len"][int(probe["first"][m]) : int(probe["first"][m + 1])])
+             for m, j in enumerate(probe["mine"])}
+    del probe
+    batch = 2 << 30
+    limit = max_block + max_block // 10
+    arena_bytes = batch + batch // 128 + (batch // max_block + 4) * (16384 + 64) + 2 * (limit + limit // 128 + 16384)
+    sess = rank_session(gpu, ref, files, target, 1, 0, "range", "lz4", max_block, max_chunks, tag, lists, arena_bytes=arena_bytes, batch_bytes=batch)
+    expect_vi, _ = ref.version_index(files, target, min(32, os.cpu_count() or 1), tag)
+    assert sess["vi"] == expect_vi, "VersionIndex differs from Longtail_CreateVersionIndex"
+    uh, us, ut = version_unique_lists(expect_vi)
+    expect_si = ref_missing_content(ref, np.zeros(0, np.uint64), uh, us, ut, max_block, max_chunks)
+    assert sess["si"] == expect_si, "StoreIndex differs from Longtail_CreateMissingContent"
+    res = sess["res"]
+    assert res.unique_all == len(uh) and 0.70 * res.chunks_all < res.unique_all < 0.80 * res.chunks_all  # a quarter of the files repeat
+    assert res.gathered_blocks > 0 and res.gathered_bytes > 0 and res.raw_bytes == int(us.astype(np.int64).sum())
