@@ -200,6 +200,10 @@ LTHIP_EXPORT int lthip_b3_stream_final(lthip_ctx* ctx, const void* d_tail, uint3
 
 /* BLAKE3-64 of runs of 64-bit values: d_out[i] = blake3(bytes of d_values[d_first[i] .. d_first[i+1])), i < run_count.  Over the
  * chunk hashes and the part table of lthip_chunk_hash: every part's content hash (src/longtail.c:2518-2537 for a one-part asset). */
+/* ..._bounded: the caller knows upper bounds of d_first[run_count] - d_first[0] (all values) and of the longest run: with runs of at
+ * most 32768 values the call then never waits for the device (no read-back of the counts).  0 = unknown. */
+LTHIP_EXPORT int lthip_hash_runs_u64_bounded(lthip_ctx* ctx, const uint64_t* d_values, const uint32_t* d_first, uint32_t run_count,
+                                             uint64_t total_values_bound, uint64_t run_values_bound, uint64_t* d_out);
 LTHIP_EXPORT int lthip_hash_runs_u64(lthip_ctx* ctx, const uint64_t* d_values, const uint32_t* d_first, uint32_t run_count,
                                      uint64_t* d_out);
 
@@ -360,9 +364,11 @@ LTHIP_EXPORT int lthip_get_existing_store_index(lthip_ctx* ctx, const void* stor
  * first-seen and lie in its own jobs, i.e. Longtail_CreateMissingContent against a store that already holds the other ranks'
  * chunks.  h_version_index (may be NULL: this rank does not serialize the index) and h_store_index should be pinned memory so
  * the copies overlap the kernels.  asset_tags NULL = every asset carries cfg.compression_type (what UpSync passes).
- * What lthip_ingest_index is given -- the tree's arrays, the device arrays, the VersionIndex buffer -- must stay valid, and the buffer
- * unread, until lthip_ingest_finish has returned: the index is serialized by a helper thread next to lthip_ingest_write, and the
- * packing into blocks is finished there too (the result's block count comes from lthip_ingest_finish). */
+ * Lifetimes.  The host arrays of `tree` (sizes, paths, permissions, tags, job tables) may be freed or reused as soon as
+ * lthip_ingest_index has returned (the session keeps its own copy of what it reads later: round 4; round 3 read the caller's arrays from
+ * a helper thread until lthip_ingest_finish).  The DEVICE arrays (d_all_hashes, d_all_lens, d_local_*) and the VersionIndex buffer must
+ * stay valid, and the buffer unread, until lthip_ingest_finish has returned: the index is serialized by a helper thread next to
+ * lthip_ingest_write, and the packing into blocks is finished there too (the result's block count comes from lthip_ingest_finish). */
 enum lthip_codec
 {
     LTHIP_CODEC_NONE = 0,

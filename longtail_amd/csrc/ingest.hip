@@ -193,7 +193,14 @@ struct lthip_ingest
     std::thread vi_thread;
     int vi_err;
     bool vi_pending; // prepared by lthip_ingest_index, not started yet
-    lthip_ingest_tree vi_tree; // (a copy: the arrays it points to are the caller's and must stay valid until lthip_ingest_finish)
+    // what the VersionIndex helper reads of the caller's tree AFTER lthip_ingest_index has returned: a deep copy (O(assets): sizes, path
+    // offsets, permissions, path data), so that a caller may free or reuse its lthip_ingest_tree arrays as soon as the call returns --
+    // the contract of round 2.  Only the device arrays and the output buffer live until lthip_ingest_finish (include/longtail_hip.h).
+    lthip_ingest_tree vi_tree;
+    std::vector<uint64_t> vi_asset_sizes;
+    std::vector<uint32_t> vi_path_offsets;
+    std::vector<uint16_t> vi_permissions;
+    std::vector<char> vi_path_data;
     std::vector<uint32_t> vi_starts, vi_counts;
     const uint64_t* vi_hashes;
     void* vi_out;
@@ -776,6 +783,18 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
                 return lthip_fail(ctx, EINVAL, "lthip_ingest_index", "path offset outside the path data");
         }
         g->vi_tree = *t;
+        g->vi_asset_sizes.assign(t->asset_sizes, t->asset_sizes + na);
+        g->vi_path_offsets.assign(t->path_start_offsets, t->path_start_offsets + na);
+        g->vi_permissions.assign(t->permissions, t->permissions + na);
+        g->vi_path_data.assign(t->path_data, t->path_data + t->path_data_size);
+        g->vi_tree.asset_sizes = g->vi_asset_sizes.data();
+        g->vi_tree.path_start_offsets = g->vi_path_offsets.data();
+        g->vi_tree.permissions = g->vi_permissions.data();
+        g->vi_tree.path_data = g->vi_path_data.data();
+        g->vi_tree.asset_tags = nullptr; // (not read after the call)
+        g->vi_tree.job_asset = nullptr;
+        g->vi_tree.job_first = nullptr;
+        g->vi_tree.my_jobs = nullptr;
         g->vi_starts.swap(starts);
         g->vi_counts.swap(counts);
         g->vi_hashes = d_all_hashes;

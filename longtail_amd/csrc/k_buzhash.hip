@@ -1115,13 +1115,18 @@ static int launch_buzhash_prefix(lthip_ctx* ctx, const lthip_plan* plan, const u
 // the same with register staging; "roll" = the rolling-window kernel of rounds 1-2 (ablations)
 static int k1_flavour()
 {
-    static int f = -1;
-    if (f < 0)
+    // (read again after lthip_debug_reload_env: tools/k1_stress_tib.py runs two flavours against each other in one process)
+    static std::atomic<int> f{-1};
+    static std::atomic<uint32_t> seen{0};
+    const uint32_t gen = g_lthip_env_gen;
+    if (seen.load(std::memory_order_acquire) != gen)
     {
         const char* e = getenv("LTHIP_K1");
-        f = !e ? 0 : !strcmp(e, "roll") ? 4 : !strcmp(e, "prefix12") ? 3 : !strcmp(e, "prefix16") ? 2 : !strcmp(e, "dma12") ? 1 : 0;
+        f.store(!e ? 0 : !strcmp(e, "roll") ? 4 : !strcmp(e, "prefix12") ? 3 : !strcmp(e, "prefix16") ? 2 : !strcmp(e, "dma12") ? 1 : 0,
+                std::memory_order_relaxed);
+        seen.store(gen, std::memory_order_release);
     }
-    return f;
+    return f.load(std::memory_order_relaxed);
 }
 
 int lthip_launch_buzhash(lthip_ctx* ctx, const lthip_plan* plan, const uint8_t* d_data, uint64_t* bm0, uint64_t* bm1)

@@ -770,6 +770,12 @@ __global__ void k_runs_to_ranges(const uint32_t* __restrict__ first, uint32_t n,
 extern "C" int lthip_hash_runs_u64(lthip_ctx* ctx, const uint64_t* d_values, const uint32_t* d_first, uint32_t run_count,
                                    uint64_t* d_out)
 {
+    return lthip_hash_runs_u64_bounded(ctx, d_values, d_first, run_count, 0, 0, d_out);
+}
+
+extern "C" int lthip_hash_runs_u64_bounded(lthip_ctx* ctx, const uint64_t* d_values, const uint32_t* d_first, uint32_t run_count,
+                                           uint64_t total_values_bound, uint64_t run_values_bound, uint64_t* d_out)
+{
     if (!ctx || !d_values || !d_first || !d_out)
         return EINVAL;
     if (run_count == 0)
@@ -783,7 +789,10 @@ extern "C" int lthip_hash_runs_u64(lthip_ctx* ctx, const uint64_t* d_values, con
     uint32_t* lens = (uint32_t*)(offs + run_count);
     hipLaunchKernelGGL(k_runs_to_ranges, dim3((run_count + 255u) / 256u), dim3(256), 0, ctx->stream, d_first, run_count, offs, lens);
     LTHIP_LAUNCH_CHECK(ctx);
-    return lthip_launch_blake3(ctx, (const uint8_t*)d_values, offs, lens, nullptr, run_count, 0, 0, d_out);
+    // with the caller's bounds the launch needs nothing back from the device (no read-back, no stream synchronisation): leaves <= one per
+    // KiB of values + one per run
+    const uint64_t leaf_bound = total_values_bound ? total_values_bound * 8u / 1024u + run_count : 0u;
+    return lthip_launch_blake3(ctx, (const uint8_t*)d_values, offs, lens, nullptr, run_count, leaf_bound, run_values_bound * 8u, d_out);
 }
 
 // Streaming BLAKE3 (k_blake3.hip): a batch of LTHIP_B3_STREAM_BATCH bytes = 1024 full leaves, the `batch_index`-th of its stream, is
@@ -804,7 +813,7 @@ extern "C" int lthip_b3_stream_batch(lthip_ctx* ctx, const void* d_data, uint64_
 extern "C" int lthip_b3_stream_final(lthip_ctx* ctx, const void* d_tail, uint32_t tail_len, uint64_t batch_count, const void* d_stack,
                                      uint64_t* d_out)
 {
-    if (!ctx || !d_out || (tail_len && !d_tail) || tail_len > (1u << 20) || batch_count > (1ull << 22) || (batch_count && (!tail_len || !d_stack)))
+    if (!ctx || !d_out || (tail_len && !d_tail) || tail_len > (1u << 20) || batch_count >= (1ull << 22) || (batch_count && (!tail_len || !d_stack)))
         return EINVAL;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     return lthip_launch_blake3_stream_final(ctx, d_tail, tail_len, (uint32_t)(batch_count << 10), (const uint32_t*)d_stack,

@@ -114,6 +114,19 @@ static int run_batch(struct ltb_state* st, struct ltb_req** reqs, uint32_t n)
     if (err)
         return err;
     const uint64_t cap = lthip_plan_chunk_capacity(st->plan);
+    /* what THIS submission can produce at most: a window of `have` bytes has at most have / min + 1 chunks.  The downloads and the
+     * content-hash launch are sized by it, not by the plan's capacity for 64 full windows (a single window at a small target chunk
+     * size paid tens of MB of D2H per submission) */
+    uint64_t ub = 0, run_ub = 0;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        const uint64_t c = sizes[i] / reqs[0]->min_chunk + 2u;
+        ub += c;
+        if (c > run_ub)
+            run_ub = c;
+    }
+    if (ub > cap)
+        ub = cap;
     if (!err) err = ltp_dev_reserve(ctx, &st->d_off, (size_t)cap * 8);
     if (!err) err = ltp_dev_reserve(ctx, &st->d_len, (size_t)cap * 4);
     if (!err) err = ltp_dev_reserve(ctx, &st->d_hash, (size_t)cap * 8);
@@ -128,13 +141,14 @@ static int run_batch(struct ltb_state* st, struct ltb_req** reqs, uint32_t n)
         err = lthip_chunk_hash(ctx, st->plan, g_arena, (uint64_t*)st->d_off.p, (uint32_t*)st->d_len.p, (uint64_t*)st->d_hash.p,
                                (uint32_t*)st->d_first.p, 0);
     if (!err) /* every window's digest array hashed as ChunkAssets will hash it (the content-hash memo below) */
-        err = lthip_hash_runs_u64(ctx, (const uint64_t*)st->d_hash.p, (const uint32_t*)st->d_first.p, n, (uint64_t*)st->d_content.p);
+        err = lthip_hash_runs_u64_bounded(ctx, (const uint64_t*)st->d_hash.p, (const uint32_t*)st->d_first.p, n, ub, run_ub,
+                                          (uint64_t*)st->d_content.p);
     uint8_t* h = (uint8_t*)st->h_res.p;
     if (!err) err = lthip_copy_d2h(ctx, h, st->d_first.p, (size_t)(n + 1) * 4);
     if (!err) err = lthip_copy_d2h(ctx, h + 512, st->d_content.p, (size_t)n * 8);
-    if (!err) err = lthip_copy_d2h(ctx, h + o_off, st->d_off.p, (size_t)cap * 8);
-    if (!err) err = lthip_copy_d2h(ctx, h + o_hash, st->d_hash.p, (size_t)cap * 8);
-    if (!err) err = lthip_copy_d2h(ctx, h + o_len, st->d_len.p, (size_t)cap * 4);
+    if (!err) err = lthip_copy_d2h(ctx, h + o_off, st->d_off.p, (size_t)ub * 8);
+    if (!err) err = lthip_copy_d2h(ctx, h + o_hash, st->d_hash.p, (size_t)ub * 8);
+    if (!err) err = lthip_copy_d2h(ctx, h + o_len, st->d_len.p, (size_t)ub * 4);
     if (!err) err = lthip_ctx_sync(ctx);
     if (err)
         return err;
@@ -146,7 +160,7 @@ static int run_batch(struct ltb_state* st, struct ltb_req** reqs, uint32_t n)
     {
         struct ltb_req* r = reqs[i];
         const uint32_t a = first[i], b = first[i + 1];
-        if (b < a || b > cap || (uint64_t)(b - a) > r->w->ccap)
+        if (b < a || b > ub || (uint64_t)(b - a) > r->w->ccap)
         {
             r->err = EIO;
             continue;

@@ -126,14 +126,27 @@ static void* dispatcher(void* arg)
         g_tail = keep_tail;
         pthread_mutex_unlock(&g_lock);
 
+        int errs[LTC_MAX];
+        uint32_t submissions = 1;
         const int err = init_err ? init_err : run_batch(ctx, d_sizes, (uint32_t*)h_sizes, reqs, n);
+        for (uint32_t i = 0; i < n; ++i)
+            errs[i] = err;
+        if (err && !init_err && n > 1)
+        {
+            /* A library-level failure of a shared submission (scratch ENOMEM, an EINVAL one request's arguments caused) is not every
+             * caller's failure: the up to 64 requests are unrelated blocks of unrelated threads.  Run them again one at a time, so
+             * that only the offending request reports the error (a transient ENOMEM may well pass at a 64th of the size). */
+            for (uint32_t i = 0; i < n; ++i)
+                errs[i] = run_batch(ctx, d_sizes, (uint32_t*)h_sizes, reqs + i, 1);
+            submissions += n;
+        }
 
         pthread_mutex_lock(&g_lock);
-        g_stat_batches += 1;
+        g_stat_batches += submissions;
         g_stat_blocks += n;
         for (uint32_t i = 0; i < n; ++i)
         {
-            reqs[i]->err = err;
+            reqs[i]->err = errs[i];
             reqs[i]->done = 1;
         }
         pthread_cond_broadcast(&g_done);

@@ -130,6 +130,7 @@ class HipLib:
         sig("lthip_plan_reaim", i32, [vp, vp, u32, vp, vp])
         sig("lthip_hash_one", i32, [vp, vp, u32, vp])
         sig("lthip_hash_runs_u64", i32, [vp, vp, vp, u32, vp])
+        sig("lthip_hash_runs_u64_bounded", i32, [vp, vp, vp, u32, u64, u64, vp])
         sig("lthip_b3_stream_batch", i32, [vp, vp, u64, vp])
         sig("lthip_b3_stream_final", i32, [vp, vp, u32, u64, vp, vp])
         sig("lthip_dedup_first_seen_range", i32, [vp, u64, vp, u64, u64, vp, vp])
@@ -575,7 +576,7 @@ class Ingest:
                        tags.ctypes.data if tags is not None else None, len(j_as), j_as.ctypes.data, j_first.ctypes.data,
                        len(mine) if mine is not None else 0, mine.ctypes.data if mine is not None else None)
         keep = [a_sz, a_off, a_perm, path_data, j_as, j_first, mine, tags]
-        t._keep = keep  # the arrays are read until finish() (the library's helper thread serializes the VersionIndex)
+        t._keep = keep  # the arrays are read during index() only (the session copies what its helper thread needs later)
         return t, keep
 
     def index(self, tree: IngestTree, all_hashes, all_lens, all_chunks: int, local_offsets, local_part_first, local_chunks: int,

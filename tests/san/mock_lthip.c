@@ -264,6 +264,17 @@ int lthip_hash_runs_u64(lthip_ctx* c, const uint64_t* v, const uint32_t* first, 
     }
     return 0;
 }
+int lthip_hash_runs_u64_bounded(lthip_ctx* c, const uint64_t* v, const uint32_t* first, uint32_t n, uint64_t total_bound, uint64_t run_bound,
+                                uint64_t* out)
+{
+    /* the bounds the caller states must hold (the device launch is sized by them) */
+    if (n && total_bound && (first[n] - first[0] > total_bound))
+        return EINVAL;
+    for (uint32_t i = 0; i < n; ++i)
+        if (run_bound && first[i + 1] - first[i] > run_bound)
+            return EINVAL;
+    return lthip_hash_runs_u64(c, v, first, n, out);
+}
 int lthip_hash_one(lthip_ctx* c, const void* in, uint32_t len, uint64_t* out)
 {
     (void)c;

@@ -62,6 +62,37 @@ def test_cancel_gives_ecanceled_and_no_index(plugins, ref, oracle, workers, afte
     assert cpu == hip
 
 
+@pytest.mark.parametrize("workers,after", [(2, 3), (4, 5), (4, 40)])
+def test_cancel_in_flight_is_always_ecanceled_on_a_large_tree(plugins, ref, oracle, workers, after):
+    """The cancellation semantics of the BATCHED path, deterministically: 600 jobs on 2-4 workers -- a worker blocks in its submission, so
+    at most `workers` jobs can be in flight when the progress callback cancels after `after` completions, and hundreds are left: the
+    call must return ECANCELED and no index (test/test.cpp:4733-4837), whatever the batcher had queued."""
+    files = [(f"d{i % 7}/f{i:03d}.bin", oracle.synth(120000 + 11 * i, 5000 + i, i % 3)) for i in range(600)]
+    err, is_null, calls = ref.version_index_cancel(files, 16384, workers, after, plugins["chunker"], plugins["hash"])
+    assert err == errno.ECANCELED and is_null and calls >= after
+    sample = files[:40]
+    cpu, _ = ref.version_index(sample, 16384, workers=workers)
+    hip, _ = ref.version_index(sample, 16384, workers=workers, chunker_api=plugins["chunker"], hash_api=plugins["hash"])
+    assert cpu == hip
+
+
+def test_cancel_semantics_without_the_batcher():
+    """The same two cancel tests with LONGTAIL_HIP_BATCH=0 (every window on its thread's own stream; the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    if os.environ.get("LONGTAIL_HIP_BATCH") == "0":
+        pytest.skip("already the unbatched run")
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, "-m", "pytest", str(Path(__file__).resolve()), "-q", "-x", "-m", "gpu", "-k",
+                          "test_cancel_in_flight or test_cancel_gives"], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, LONGTAIL_HIP_BATCH="0", PYTHONPATH=str(root)), cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
+
+
 @pytest.mark.parametrize("workers", [0, 4])
 def test_configs1_256mib_file_is_bit_exact(plugins, ref, oracle, workers):
     """BASELINE.json configs[1]."""

@@ -65,9 +65,15 @@ def rank_session(gpu, ref, files, target, world, rank, policy, codec, max_block,
     job_first = np.concatenate([[0], np.cumsum([int(all_lists[j][0].numel()) for j in range(part.job_count)])]).astype(np.uint64)
     n_all = int(job_first[-1])
     ing = Ingest(gpu, target, max_block, max_chunks, codec, compression_type=tag, batch_bytes=batch_bytes)
-    tree, keep = Ingest.tree(sizes, offs, perms, path_data, part.job_asset, job_first, my_jobs=None if world == 1 else mine)
+    tree, keep = Ingest.tree(sizes.copy(), offs.copy(), perms.copy(), path_data, part.job_asset.copy(), job_first.copy(),
+                             my_jobs=None if world == 1 else mine.copy())
     vi = torch.zeros(gpu.lib.dll.lthip_version_index_size(len(sizes), n_all, n_all, len(path_data)) + 64, dtype=torch.uint8).pin_memory()
     ing.index(tree, all_hash, all_lens, n_all, d_off, d_first, total, vi if rank == 0 else None)
+    # the host arrays of the tree belong to the caller again once index() has returned (the helper thread that serializes the
+    # VersionIndex reads the session's own copy): scribble over them
+    for a in keep:
+        if isinstance(a, np.ndarray):
+            a.fill(0xEE)
     arena = torch.zeros(arena_bytes or (64 << 20), dtype=torch.uint8, device="cuda")
     ing.write(dev, arena)
     si = torch.zeros(16 + 32 * max(total, 1) + 64, dtype=torch.uint8).pin_memory()
