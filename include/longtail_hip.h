@@ -258,6 +258,22 @@ LTHIP_EXPORT int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, u
                                             const uint64_t* src_offsets, const uint32_t* src_sizes, void* d_dst,
                                             const uint64_t* dst_offsets, const uint32_t* dst_caps,
                                             uint32_t* d_out_sizes);
+/* The same with the parse the reference's settings ids stand for (lib/zstd/longtail_zstd.c:11-28, 43-60: 'ztd1' -> level 0 = the
+ * default 3, 'ztd2' -> 3, 'ztd4' -> 8, 'ztd3' -> 22, 'ztd5' -> its own type id, which zstd clamps to 22; any other id -> 0 = the
+ * default, it is NOT rejected there and is not here):
+ *   LTHIP_ZSTD_Q_DEFAULT  'ztd1', 'ztd2', unknown ids: the lane parser's greedy parse (what lthip_zstd_compress_blocks runs)
+ *   LTHIP_ZSTD_Q_HIGH     'ztd4': every byte position is probed (no skipping to address-aligned positions after misses) and of the
+ *                         two candidates of a probe the one with the longer match is taken
+ *   LTHIP_ZSTD_Q_MAX      'ztd3', 'ztd5': Q_HIGH, and the wave's table is read again after the step's inserts (what the lanes beside
+ *                         this one have just put there is a candidate at once)
+ * Every quality writes the same frame format (sub-blocks with block-local repeat-offset codes). */
+#define LTHIP_ZSTD_Q_DEFAULT 0
+#define LTHIP_ZSTD_Q_HIGH 1
+#define LTHIP_ZSTD_Q_MAX 2
+LTHIP_EXPORT int lthip_zstd_compress_blocks_q(lthip_ctx* ctx, const void* d_src, uint32_t block_count,
+                                              const uint64_t* src_offsets, const uint32_t* src_sizes, void* d_dst,
+                                              const uint64_t* dst_offsets, const uint32_t* dst_caps,
+                                              uint32_t* d_out_sizes, int quality);
 /* ZStdCompressionAPI_Decompress (longtail_zstd.c:144-177): every payload is one or more zstd frames (any encoder's: Huffman /
  * FSE / repeat modes / repeat offsets / skippable frames; no dictionaries; a content checksum is skipped, not verified).
  * d_out_sizes[b] = decoded size, or 0xFFFFFFFF when the payload is malformed or does not fit dst_caps[b]. */

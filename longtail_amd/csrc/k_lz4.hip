@@ -790,6 +790,7 @@ __device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t h
 //     scans, the size pass and the emission each read back through the memory system (1 B/B written and read on "tokens").
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t LZ4_LPAD = 16; // PV 2: LDS byte offset of the staged window
+constexpr uint32_t LZ4_DBG_Q_HIGH = 1u << 15, LZ4_DBG_Q_MAX = 1u << 31; // quality bits of `dbg` (zstd settings, lthip_launch_lz_sequences)
 
 // slot of a private table of TAB entries for the (multiplied) hash `prod`.  PV 0: mulhi(prod, TAB), a quarter-rate 32-bit multiply;
 // PV 2: the upper 16 bits of prod times TAB, a 24-bit multiply and a shift (TAB < 2^16) -- another function of the same bits, so the two
@@ -844,9 +845,11 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
     const uint32_t s0 = my_start + (uint32_t)sidx * sub;
     const uint32_t lend = s0 + sub < unit_end ? s0 + sub : unit_end;
     uint32_t p = s0, anchor = s0, nrec = 0, last_end = 0, nmiss = 0;
-    const uint32_t dense = 4u >> ((dbg >> 29) & 3u);
+    const bool q_high = (dbg & LZ4_DBG_Q_HIGH) != 0u, q_max = (dbg & LZ4_DBG_Q_MAX) != 0u;
+    const uint32_t dense = q_high ? 0xFFFFu : 4u >> ((dbg >> 29) & 3u); // "high": every byte position is probed
     const uint32_t wait_for = (dbg >> 20) & 63u ? (dbg >> 20) & 63u : 8u;
     uint32_t rsl[8], roff[8]; // records: start | length << 16, offset
+    uint32_t cand2 = 0xFFFFFFFFu; // "high": the other verified candidate of the probe (0xFFFFFFFF: none)
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         rsl[k] = roff[k] = 0u;
@@ -882,7 +885,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 uint32_t c = tab[h];
                 const uint32_t c2 = shr[prod >> (32 - SH)] - sh_base; // (another group's entry: far above any position)
                 tab[h] = (uint16_t)p;
-                if (dbg & (1u << 28))
+                if ((dbg & (1u << 28)) || q_max) // "max": the slot is read again after the step's inserts (entries of lanes in phase)
                 {
                     uint32_t hr = h;
                     asm volatile("" : "+v"(hr));
@@ -899,6 +902,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 {
                     pend = true;
                     cand = h1 ? c : c2; // the private table's (the nearer one) first
+                    cand2 = (q_high && h1 && h2 && c != c2) ? c2 : 0xFFFFFFFFu;
                 }
                 else
                 {
@@ -965,6 +969,36 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
             {
                 nbk = X[1] ? (uint32_t)__builtin_clz(X[1]) >> 3 : (X[0] ? 4u + ((uint32_t)__builtin_clz(X[0]) >> 3) : 8u);
                 nbk = nbk < p - anchor ? nbk : p - anchor;
+            }
+        }
+        // ---- "high": where the probe verified BOTH candidates, the other one's first 16 bytes too; the longer match wins (the nearer on a
+        // tie).  One more round trip for the lanes concerned. ----
+        if (q_high && __builtin_amdgcn_ballot_w64(ok && cand2 != 0xFFFFFFFFu))
+        {
+            if (ok && cand2 != 0xFFFFFFFFu)
+            {
+                uint32_t a2 = 4u + lds_cmp16<PAD>(sdata, p + 4u + head, cand2 + 4u + head);
+                bool g2 = a2 == 20u;
+                if (a2 >= maxlen)
+                {
+                    a2 = maxlen;
+                    g2 = false;
+                }
+                if (a2 > mlen)
+                {
+                    // the backward count belongs to the candidate: redo it for the new one
+                    nbk = 0;
+                    if (cand2 >= 8u && p - anchor != 0u)
+                    {
+                        const uint32_t x1 = lds_read32x<PAD>(sdata, p - 4u + head) ^ lds_read32x<PAD>(sdata, cand2 - 4u + head);
+                        const uint32_t x0 = lds_read32x<PAD>(sdata, p - 8u + head) ^ lds_read32x<PAD>(sdata, cand2 - 8u + head);
+                        nbk = x1 ? (uint32_t)__builtin_clz(x1) >> 3 : (x0 ? 4u + ((uint32_t)__builtin_clz(x0) >> 3) : 8u);
+                        nbk = nbk < p - anchor ? nbk : p - anchor;
+                    }
+                    cand = cand2;
+                    mlen = a2;
+                    grow = g2;
+                }
             }
         }
         // ---- matches of 20 bytes and more: one more 16-byte round of their own (at most 36 bytes), then the whole wave ----
@@ -2615,7 +2649,7 @@ static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_
 
 int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                               const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets, const uint32_t* dst_caps,
-                              uint8_t** d_lits, uint64_t** d_recs, void** d_meta, uint32_t* unit_base, uint64_t* total_units)
+                              uint8_t** d_lits, uint64_t** d_recs, void** d_meta, uint32_t* unit_base, uint64_t* total_units, int quality)
 {
     const uint32_t SEG = 4096u; // ZB_UNIT
     Lz4Block* d_blocks = nullptr;
@@ -2646,7 +2680,13 @@ int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_
     if (nseg)
     {
         LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
-        const uint32_t dbg = (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0);
+        uint32_t dbg = (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0);
+        // the parse the zstd setting asks for (LTHIP_ZSTD_Q_*): bit 15 = "high" (dense probing, the longer of the two candidates),
+        // bit 31 = "max" (high + one lazy step); lz4_lane_parse2 reads them
+        if (quality >= 1)
+            dbg |= LZ4_DBG_Q_HIGH;
+        if (quality >= 2)
+            dbg |= LZ4_DBG_Q_MAX;
         if ((err = launch_match_finder<1>(ctx, lanes, SEG, d_src, d_blocks, block_count, 0u, (uint32_t)ngrp64, ngrp64, ncgrp64, (uint8_t*)lits,
                                           (Lz4Meta*)meta, (uint64_t*)recs, (uint8_t*)d_dst, dbg, (uint64_t*)lrecs)))
             return err;

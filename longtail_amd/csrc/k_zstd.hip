@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64, 4) void k_zstd_encode(const ZBlock* __restrict_
                                                     const uint8_t* __restrict__ unit_lits, const uint64_t* __restrict__ unit_recs,
                                                     uint8_t* __restrict__ work, uint8_t* __restrict__ enc,
                                                     uint32_t* __restrict__ enc_size, uint16_t* __restrict__ sub_sizes,
-                                                    uint32_t* __restrict__ ticket)
+                                                    uint32_t* __restrict__ ticket, uint32_t zflags)
 {
     __shared__ ZbShared sh;
     ZbScratch sc;
@@ -314,6 +314,7 @@ __global__ __launch_bounds__(64, 4) void k_zstd_encode(const ZBlock* __restrict_
         in.nunits = (len + ZB_UNIT - 1u) / ZB_UNIT;
         in.raw_size = len;
         in.src = src + b.src_off + (uint64_t)i * ZB;
+        in.flags = zflags;
         {
             // RLE_Block: every unit of the piece is one repeated byte (flagged by the match finder) and it is the same one
             const uint32_t f = threadIdx.x < in.nunits ? in.meta[threadIdx.x].uniform : in.meta[0].uniform;
@@ -379,13 +380,22 @@ extern "C" size_t lthip_zstd_bound(size_t n)
 
 static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                                const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets, const uint32_t* dst_caps,
-                               uint32_t* d_out_sizes);
+                               uint32_t* d_out_sizes, int quality);
 
 extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                                           const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
                                           const uint32_t* dst_caps, uint32_t* d_out_sizes)
 {
-    if (!ctx || !d_out_sizes || (block_count && (!src_offsets || !src_sizes || !dst_offsets || !dst_caps || !d_dst)))
+    return lthip_zstd_compress_blocks_q(ctx, d_src, block_count, src_offsets, src_sizes, d_dst, dst_offsets, dst_caps, d_out_sizes,
+                                        LTHIP_ZSTD_Q_DEFAULT);
+}
+
+extern "C" int lthip_zstd_compress_blocks_q(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
+                                            const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
+                                            const uint32_t* dst_caps, uint32_t* d_out_sizes, int quality)
+{
+    if (!ctx || !d_out_sizes || (block_count && (!src_offsets || !src_sizes || !dst_offsets || !dst_caps || !d_dst)) ||
+        quality < LTHIP_ZSTD_Q_DEFAULT || quality > LTHIP_ZSTD_Q_MAX)
         return EINVAL;
     const uint64_t budget = lthip_codec_batch_bytes(); // scratch (unit literals + records + piece slots): about three times that
     for (uint32_t b0 = 0; b0 < block_count;)
@@ -395,7 +405,7 @@ extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uin
         while (b1 < block_count && bytes + src_sizes[b1] <= budget)
             bytes += src_sizes[b1++];
         const int err = zstd_compress_batch(ctx, d_src, b1 - b0, src_offsets + b0, src_sizes + b0, d_dst, dst_offsets + b0, dst_caps + b0,
-                                            d_out_sizes + b0);
+                                            d_out_sizes + b0, quality);
         if (err)
             return err;
         b0 = b1;
@@ -405,7 +415,7 @@ extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uin
 
 static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                                const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets, const uint32_t* dst_caps,
-                               uint32_t* d_out_sizes)
+                               uint32_t* d_out_sizes, int quality)
 {
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     std::vector<ZBlock> hb(block_count);
@@ -431,7 +441,7 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
     uint64_t nunits = 0;
     int err;
     if ((err = lthip_launch_lz_sequences(ctx, d_src, block_count, src_offsets, src_sizes, d_dst, dst_offsets, dst_caps, &d_lits, &d_recs,
-                                         &d_meta, unit_base.data(), &nunits)))
+                                         &d_meta, unit_base.data(), &nunits, quality)))
         return err;
     for (uint32_t b = 0; b < block_count; ++b)
         hb[b].unit_base = unit_base[b];
@@ -461,13 +471,15 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
     if (nzb)
     {
         static LthipEnvInt env_tickets{"LTHIP_ZSTD_TICKETS"};
+        static LthipEnvInt env_rep{"LTHIP_ZSTD_REP"}; // 0: no repeat-offset codes (the frames of rounds 2-3)
         uint32_t* d_ticket = env_tickets.get() == 0 ? nullptr : (uint32_t*)d_encsz + nzb + 1; // (the size list has four spare words)
         if (d_ticket)
             LTHIP_CHECK(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
         LaunchTimer t(ctx, LTHIP_K_ZSTD_ENC);
         hipLaunchKernelGGL(k_zstd_encode, dim3(nwg), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks, block_count, (uint32_t)nzb,
                            (const uint8_t*)d_src, (uint8_t*)d_rle, (const ZbUnitMeta*)d_meta, (const uint8_t*)d_lits, (const uint64_t*)d_recs,
-                           (uint8_t*)d_work, (uint8_t*)d_enc, (uint32_t*)d_encsz, sub ? (uint16_t*)d_sub : (uint16_t*)nullptr, d_ticket);
+                           (uint8_t*)d_work, (uint8_t*)d_enc, (uint32_t*)d_encsz, sub ? (uint16_t*)d_sub : (uint16_t*)nullptr, d_ticket,
+                           env_rep.get() == 0 ? 0u : (uint32_t)ZB_F_REPCODES);
         LTHIP_LAUNCH_CHECK(ctx);
     }
     LaunchTimer t(ctx, LTHIP_K_OTHER);
@@ -1085,6 +1097,7 @@ __device__ __forceinline__ void zs_seq_lanes(bool act, const uint8_t* stream, ui
                                              uint64_t* recs, bool& bad, uint32_t& sum_ll, uint32_t& sum_ml)
 {
     uint32_t pos = 0, sl = 0, so = 0, sm = 0;
+    [[maybe_unused]] uint32_t r1 = 0, r2 = 0, r3 = 0; // STRICT: the block's own offset history, 0 = unknown
     ZsWin w;
     w.base = stream;
     w.hi = w.lo = w.nx = 0;
@@ -1151,11 +1164,38 @@ __device__ __forceinline__ void zs_seq_lanes(bool act, const uint8_t* stream, ui
                     so = (o0 & 0xFFFFu) + (t3 & ((1u << nbo) - 1u));
                 }
                 pos -= n1 + n2;
-                if ((STRICT && ov <= 3u) || ov >= (1u << 24)) // repeat offsets need the block before
+                uint32_t ovr = ov;
+                if constexpr (STRICT)
+                {
+                    // Repeat offsets, resolved here: this library's encoder only refers to history entries that the block's own
+                    // sequences have set (zb_encode_piece_sub, ZB_F_REPCODES), so the lane starts with an unknown history (0) and a
+                    // code that would read an unknown entry is what "needs the block before" now means.
+                    const uint32_t used = ov > 3u ? 0u : (ll != 0u ? ov : ov + 1u); // entry 1..3, 4 = entry 1 minus one, 0 = a new offset
+                    uint32_t off = ov - 3u;
+                    if (used)
+                    {
+                        off = used == 1u ? r1 : used == 2u ? r2 : used == 3u ? r3 : r1 - 1u;
+                        if (off == 0u || (used == 4u && r1 == 0u))
+                            bad = true;
+                    }
+                    if (used == 2u)
+                    {
+                        r2 = r1;
+                        r1 = off;
+                    }
+                    else if (used != 1u)
+                    {
+                        r3 = r2;
+                        r2 = r1;
+                        r1 = off;
+                    }
+                    ovr = off + 3u;
+                }
+                if (ovr >= (1u << 24))
                     bad = true;
                 sum_ll += ll;
                 sum_ml += ml;
-                recs[k] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)ov << 40);
+                recs[k] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)ovr << 40);
             }
         }
     }

@@ -230,8 +230,9 @@ int lthip_launch_from_buffer(lthip_ctx* ctx, const uint8_t* d_data, uint32_t n, 
 // zstd front end (k_lz4.hip): the LZ4 match finder run with sequence output.  Per 4 KiB unit u of the batch (units
 // are numbered block after block, `unit_base[b]` first): literals at d_lits + u*4096, records at d_recs + u*1024,
 // ZbUnitMeta at d_meta + u (zstd_block_core.h).
+// quality: LTHIP_ZSTD_Q_* (the parse the zstd settings select)
 int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                               const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets, const uint32_t* dst_caps,
-                              uint8_t** d_lits, uint64_t** d_recs, void** d_meta, uint32_t* unit_base, uint64_t* total_units);
+                              uint8_t** d_lits, uint64_t** d_recs, void** d_meta, uint32_t* unit_base, uint64_t* total_units, int quality);
 
 static inline uint64_t div_up_u64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }

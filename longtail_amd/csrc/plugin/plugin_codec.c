@@ -88,7 +88,7 @@ static int fetch_payload(struct ltp_thread_state* ts, int codec, int decompress,
  * calling thread's own pinned buffers keeps the DMA engine at full rate and lets the 32..256 bikeshed workers that call Compress
  * concurrently (one context + stream each) overlap their copies and kernels.  Two synchronisations per call: the payload size
  * has to be known before the payload is fetched. */
-static int run_block(int codec, int decompress, const char* src, char* dst, size_t n, size_t cap, size_t* out_n)
+static int run_block(int codec, int decompress, int quality, const char* src, char* dst, size_t n, size_t cap, size_t* out_n)
 {
     struct ltp_thread_state* ts = ltp_thread_state_get();
     if (!ts)
@@ -122,7 +122,7 @@ static int run_block(int codec, int decompress, const char* src, char* dst, size
         if (n)
             err = lthip_ctx_sync(ctx);
         if (!err)
-            err = ltp_codec_batch(codec, decompress, ts->d_in.p, sz, ts->d_out.p, dcap, &produced);
+            err = ltp_codec_batch(codec, decompress, quality, ts->d_in.p, sz, ts->d_out.p, dcap, &produced);
         if (err)
             return err;
         return fetch_payload(ts, codec, decompress, produced, dst, cap, out_n);
@@ -134,7 +134,7 @@ static int run_block(int codec, int decompress, const char* src, char* dst, size
     else if (codec == CODEC_LZ4)
         err = lthip_lz4_compress_blocks(ctx, ts->d_in.p, 1, &zero, &sz, ts->d_out.p, &zero, &dcap, (uint32_t*)ts->d_aux.p, 0);
     else
-        err = lthip_zstd_compress_blocks(ctx, ts->d_in.p, 1, &zero, &sz, ts->d_out.p, &zero, &dcap, (uint32_t*)ts->d_aux.p);
+        err = lthip_zstd_compress_blocks_q(ctx, ts->d_in.p, 1, &zero, &sz, ts->d_out.p, &zero, &dcap, (uint32_t*)ts->d_aux.p, quality);
     uint32_t* h_size = (uint32_t*)ts->h_pin.p;
     if (!err)
         err = lthip_copy_d2h(ctx, h_size, ts->d_aux.p, 4);
@@ -156,7 +156,17 @@ static int HipCodec_Compress(struct Longtail_CompressionAPI* compression_api, ui
         return EINVAL; /* longtail_lz4.c:33 */
     if (a->codec == CODEC_ZSTD && (settings_id & 0xffffff00u) != LTP_ZSTD_TYPE)
         return EINVAL;
-    return run_block(a->codec, 0, uncompressed, compressed, uncompressed_size, max_compressed_size, out_compressed_size);
+    /* SettingsIDToCompressionSetting (lib/zstd/longtail_zstd.c:43-60): 'ztd1' -> level 0 (= zstd's default, 3), 'ztd2' -> 3, 'ztd3' ->
+     * 22, 'ztd4' -> 8, 'ztd5' -> the LOW type id itself (the macro shadows the constant, :12 vs :22), which zstd clamps to 22; any
+     * other id -> 0, the default -- the reference does not reject it, neither does this.  Levels 3 / 8 / 22 become the three parses
+     * of lthip_zstd_compress_blocks_q. */
+    int quality = LTHIP_ZSTD_Q_DEFAULT;
+    if (a->codec == CODEC_ZSTD)
+    {
+        const uint32_t low = settings_id & 0xffu;
+        quality = low == '4' ? LTHIP_ZSTD_Q_HIGH : (low == '3' || low == '5') ? LTHIP_ZSTD_Q_MAX : LTHIP_ZSTD_Q_DEFAULT;
+    }
+    return run_block(a->codec, 0, quality, uncompressed, compressed, uncompressed_size, max_compressed_size, out_compressed_size);
 }
 
 static int HipCodec_Decompress(struct Longtail_CompressionAPI* compression_api, const char* compressed, char* uncompressed,
@@ -165,7 +175,7 @@ static int HipCodec_Decompress(struct Longtail_CompressionAPI* compression_api, 
     if (!compression_api || !compressed || !out_uncompressed_size || (max_uncompressed_size && !uncompressed))
         return EINVAL;
     struct HipCodecAPI* a = (struct HipCodecAPI*)compression_api;
-    return run_block(a->codec, 1, compressed, uncompressed, compressed_size, max_uncompressed_size, out_uncompressed_size);
+    return run_block(a->codec, 1, 0, compressed, uncompressed, compressed_size, max_uncompressed_size, out_uncompressed_size);
 }
 
 static struct Longtail_CompressionAPI* make_codec(int codec)

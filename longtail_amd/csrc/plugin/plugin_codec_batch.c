@@ -62,7 +62,10 @@ static int run_batch(lthip_ctx* ctx, void* d_sizes, uint32_t* h_sizes, struct lt
         err = lthip_lz4_decompress_blocks(ctx, (const void*)s_base, n, s_off, s_size, (void*)d_base, d_off, d_cap, (uint32_t*)d_sizes);
         break;
     case 2:
-        err = lthip_zstd_compress_blocks(ctx, (const void*)s_base, n, s_off, s_size, (void*)d_base, d_off, d_cap, (uint32_t*)d_sizes);
+    case 4:
+    case 5:
+        err = lthip_zstd_compress_blocks_q(ctx, (const void*)s_base, n, s_off, s_size, (void*)d_base, d_off, d_cap, (uint32_t*)d_sizes,
+                                           reqs[0]->kind == 2 ? 0 : reqs[0]->kind - 3);
         break;
     default:
         err = lthip_zstd_decompress_blocks(ctx, (const void*)s_base, n, s_off, s_size, (void*)d_base, d_off, d_cap, (uint32_t*)d_sizes);
@@ -163,11 +166,13 @@ static void* dispatcher(void* arg)
 
 /* The block at d_in (n bytes, uploaded and synchronised by the caller) through the codec into d_out (cap bytes), together with
  * whatever the other threads have queued; blocks until done.  *produced as the bulk entry points report it. */
-int ltp_codec_batch(int codec, int decompress, const void* d_in, uint32_t n, void* d_out, uint32_t cap, uint32_t* produced)
+int ltp_codec_batch(int codec, int decompress, int quality, const void* d_in, uint32_t n, void* d_out, uint32_t cap, uint32_t* produced)
 {
     struct ltc_req r;
     memset(&r, 0, sizeof r);
-    r.kind = codec * 2 + (decompress ? 1 : 0);
+    r.kind = codec * 2 + (decompress ? 1 : 0); /* 0 lz4 compress, 1 lz4 decompress, 2 zstd compress, 3 zstd decompress ... */
+    if (codec == 1 && !decompress && quality > 0)
+        r.kind = 3 + quality; /* ... 4 / 5 zstd compress at LTHIP_ZSTD_Q_HIGH / _MAX: a submission carries one kind */
     r.d_in = d_in;
     r.d_out = d_out;
     r.n = n;

@@ -99,7 +99,7 @@ int ltp_memo_get(const void* data, uint32_t length, uint64_t* out_hash);
 
 /* ---- plugin_codec_batch.c: one block (on the device, in the calling thread's buffers) through codec (0 LZ4, 1 zstd) together with the
  * blocks other threads have queued; *produced as the bulk entry points report it ---- */
-int ltp_codec_batch(int codec, int decompress, const void* d_in, uint32_t n, void* d_out, uint32_t cap, uint32_t* produced);
+int ltp_codec_batch(int codec, int decompress, int quality, const void* d_in, uint32_t n, void* d_out, uint32_t cap, uint32_t* produced);
 void ltp_codec_batch_shutdown(void);
 
 /* ---- error latch: void / value-returning entry points of the plugin structs (HashAPI.Hash, EndContext) cannot report failure;

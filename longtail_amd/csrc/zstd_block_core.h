@@ -57,6 +57,9 @@
 #define ZB_SEQ_LIT(s) ((uint32_t)((s) & 0xFFFFFu))
 #define ZB_SEQ_ML(s) ((uint32_t)(((s) >> 20) & 0xFFFFu))
 #define ZB_SEQ_OFF(s) ((uint32_t)((s) >> 36))
+/* sub-block layout: the offset field holds either the offset (Offset_Value = offset + 3) or, with bit 27 set, a repeat code 1..3 */
+#define ZB_OFF_REP 0x8000000u
+#define ZB_SEQ_OFV(s) ((ZB_SEQ_OFF(s) & ZB_OFF_REP) ? (ZB_SEQ_OFF(s) & 3u) : ZB_SEQ_OFF(s) + 3u)
 
 typedef struct ZbUnitMeta
 {
@@ -76,7 +79,9 @@ typedef struct ZbInput
     const uint8_t* src; /* the block's raw bytes (any alignment) or NULL.  When given, a unit WITHOUT a sequence has no
                          * literal buffer: its literals are its own bytes, src + u * ZB_UNIT (the match finder does not
                          * copy what nobody may ever need) */
+    uint32_t flags;     /* ZB_F_* */
 } ZbInput;
+#define ZB_F_REPCODES 1u /* sub-block layout: repeat-offset codes whose history entry was SET INSIDE THE BLOCK (see zb_rep_pass) */
 
 typedef struct ZbScratch /* global memory owned by the lanes of one block encoder */
 {
@@ -1505,7 +1510,52 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
             sc->seqs[i] = (uint64_t)lit | ((uint64_t)ml << 20) | ((uint64_t)off << 36);
             zb_atomic_add(&sh->sym_hist[ZT_LL][zb_ll_code(lit)], 1u);
             zb_atomic_add(&sh->sym_hist[ZT_ML][zb_ml_code(ml - 3u)], 1u);
-            zb_atomic_add(&sh->sym_hist[ZT_OF][zb_of_code(off)], 1u);
+            if (!(in->flags & ZB_F_REPCODES))
+                zb_atomic_add(&sh->sym_hist[ZT_OF][zb_of_code(off)], 1u);
+        }
+    }
+    if (in->flags & ZB_F_REPCODES)
+    {
+        /* ---- repeat-offset codes (zstd_compression_format.md "Repeat Offsets"; ZSTD_updateRep / ZSTD_storeSeq of the reference,
+         * compress/zstd_compress_internal.h).  A zstd block starts with the three-entry offset history its predecessor left behind --
+         * which is exactly what a decoder that gives every block a lane of its own does not have.  So a block here only ever refers to
+         * history entries that were SET BY ITS OWN SEQUENCES: the history starts "unknown" in every block, an entry becomes known when
+         * a sequence of the block writes it, and a repeat code is used only for a known entry.  Any zstd decoder reads such a block (it
+         * simply never looks at what it inherited); the lane-parallel one needs nothing from the block before.  One lane per block, in
+         * sequence order (the chain is serial by nature); the offset-code histogram is built here. */
+        ZB_SYNC();
+        ZB_PAR_FOR(u, nunits)
+        {
+            const uint32_t b0 = sh->useq_base[u], e0 = sh->useq_base[u + 1u];
+            uint32_t r1 = 0, r2 = 0, r3 = 0; /* 0 = unknown (an offset is never 0) */
+            for (uint32_t i = b0; i < e0; ++i)
+            {
+                const uint64_t q = sc->seqs[i];
+                const uint32_t lit = ZB_SEQ_LIT(q), off = ZB_SEQ_OFF(q);
+                uint32_t code = 0; /* 0: the offset itself */
+                if (lit != 0u)
+                    code = off == r1 ? 1u : off == r2 ? 2u : off == r3 ? 3u : 0u;
+                else
+                    code = off == r2 ? 1u : off == r3 ? 2u : (r1 > 1u && off == r1 - 1u) ? 3u : 0u;
+                /* which history entry was used (with literals: the code; without: one further, code 3 = r1 - 1 counts as "new") */
+                const uint32_t used = code == 0u ? 0u : (lit != 0u ? code : code + 1u);
+                if (used == 2u)
+                {
+                    const uint32_t t = r2;
+                    r2 = r1;
+                    r1 = t;
+                }
+                else if (used != 1u) /* a new offset, entry 3, or r1 - 1: pushed in front */
+                {
+                    const uint32_t v = used == 3u ? r3 : off;
+                    r3 = r2;
+                    r2 = r1;
+                    r1 = v;
+                }
+                if (code)
+                    sc->seqs[i] = (q & 0xFFFFFFFFFull) | ((uint64_t)(ZB_OFF_REP | code) << 36);
+                zb_atomic_add(&sh->sym_hist[ZT_OF][zb_highbit(code ? code : off + 3u)], 1u);
+            }
         }
     }
     /* plainly noise?  (the sampled test of zb_encode_block) */
@@ -1712,7 +1762,7 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
                     if (j < cnt)
                     {
                         const uint32_t i = n - 1u - j;
-                        const uint32_t lc = zb_ll_code(ZB_SEQ_LIT(q[j])), mc = zb_ml_code(ZB_SEQ_ML(q[j]) - 3u), oc = zb_of_code(ZB_SEQ_OFF(q[j]));
+                        const uint32_t lc = zb_ll_code(ZB_SEQ_LIT(q[j])), mc = zb_ml_code(ZB_SEQ_ML(q[j]) - 3u), oc = zb_highbit(ZB_SEQ_OFV(q[j]));
                         bits += zb_ll_bits(lc) + zb_ml_bits(mc) + oc;
                         if (i == e0 - 1u) /* the block's last sequence: the states the decoder starts from */
                         {
@@ -1981,7 +2031,7 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
                     const uint64_t q = sc->seqs[n];
                     lit = ZB_SEQ_LIT(q);
                     ml = ZB_SEQ_ML(q) - 3u;
-                    ofv = ZB_SEQ_OFF(q) + 3u;
+                    ofv = ZB_SEQ_OFV(q);
                     lc = zb_ll_code(lit);
                     mc = zb_ml_code(ml);
                     oc = zb_highbit(ofv);

@@ -114,6 +114,7 @@ class HipLib:
         sig("lthip_lz4_decompress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_zstd_bound", sz, [sz])
         sig("lthip_zstd_compress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
+        sig("lthip_zstd_compress_blocks_q", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp, i32])
         sig("lthip_zstd_decompress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_zstd_debug_units", i32, [vp, u64, u64, vp, vp, vp])
         sig("lthip_zstd_last_decode_stats", i32, [vp, vp])
@@ -314,9 +315,10 @@ class Context:
         return self._codec(self.lib.dll.lthip_lz4_decompress_blocks, src, src_offsets, src_sizes, dst, dst_offsets,
                            dst_caps)
 
-    def zstd_compress_blocks(self, src, src_offsets, src_sizes, dst, dst_offsets, dst_caps):
-        return self._codec(self.lib.dll.lthip_zstd_compress_blocks, src, src_offsets, src_sizes, dst, dst_offsets,
-                           dst_caps)
+    def zstd_compress_blocks(self, src, src_offsets, src_sizes, dst, dst_offsets, dst_caps, quality: int = 0):
+        """quality: 0 default ('ztd1', 'ztd2'), 1 high ('ztd4'), 2 max ('ztd3', 'ztd5') -- LTHIP_ZSTD_Q_*"""
+        return self._codec(self.lib.dll.lthip_zstd_compress_blocks_q, src, src_offsets, src_sizes, dst, dst_offsets,
+                           dst_caps, (int(quality),))
 
     def zstd_decompress_blocks(self, src, src_offsets, src_sizes, dst, dst_offsets, dst_caps):
         return self._codec(self.lib.dll.lthip_zstd_decompress_blocks, src, src_offsets, src_sizes, dst, dst_offsets,

@@ -29,6 +29,8 @@ static uint32_t g_ltz_dbg;
 #include "../longtail_amd/csrc/zstd_decode_core.h" /* includes zstd_block_core.h */
 void ltz_model_debug(uint32_t flags) { g_ltz_dbg = flags; }
 static int g_ltz_sub; /* 1: pieces are written as runs of sub-blocks (zb_encode_piece_sub) */
+static uint32_t g_ltz_flags = ZB_F_REPCODES; /* ZbInput.flags of the next encodes (the kernel's default) */
+void ltz_model_flags(uint32_t flags) { g_ltz_flags = flags; }
 static uint16_t g_ltz_last_sub[ZB_MAX_UNITS];
 void ltz_model_sub_blocks(int on) { g_ltz_sub = on; }
 const uint16_t* ltz_model_last_sub(void) { return g_ltz_last_sub; }
@@ -49,6 +51,7 @@ uint32_t ltz_model_encode_block_src(const void* meta, const uint8_t* unit_lits, 
     in.nunits = nunits;
     in.raw_size = raw_size;
     in.src = src;
+    in.flags = g_ltz_flags;
     sc.seqs = (uint64_t*)malloc(sizeof(uint64_t) * ZB_SEQ_MAX);
     sc.sbits = (uint16_t*)malloc(sizeof(uint16_t) * 3 * ZB_SEQ_MAX);
     sc.out = (uint32_t*)malloc(ZB_OUT_BYTES);

@@ -317,6 +317,15 @@ int lthip_lz4_decompress_blocks(lthip_ctx* c, const void* s, uint32_t nb, const 
     return 0;
 }
 int lthip_zstd_compress_blocks(lthip_ctx* c, const void* s, uint32_t nb, const uint64_t* so, const uint32_t* ss, void* d, const uint64_t* dof,
+                               const uint32_t* dc, uint32_t* out);
+int lthip_zstd_compress_blocks_q(lthip_ctx* c, const void* s, uint32_t nb, const uint64_t* so, const uint32_t* ss, void* d, const uint64_t* dof,
+                                 const uint32_t* dc, uint32_t* out, int quality)
+{
+    if (quality < 0 || quality > 2)
+        return EINVAL;
+    return lthip_zstd_compress_blocks(c, s, nb, so, ss, d, dof, dc, out); /* (the model has one parse) */
+}
+int lthip_zstd_compress_blocks(lthip_ctx* c, const void* s, uint32_t nb, const uint64_t* so, const uint32_t* ss, void* d, const uint64_t* dof,
                                const uint32_t* dc, uint32_t* out)
 {
     (void)c;

@@ -222,3 +222,86 @@ def test_cooperative_fse_table_builder_equals_serial(model):
     norm = np.array([10, 10, 3], np.int16)
     a = np.zeros(4 * 32, np.uint8)
     assert d.ltz_model_fse_tables(norm.ctypes.data, 2, 5, a.ctypes.data, a.ctypes.data) == 3
+
+
+def _rep_piece(seed, nunits=8):
+    """Sequences whose offsets repeat in every way the format has a code for -- the last, the one before, the third, the last minus
+    one, with and without literals in front -- executed into the raw bytes they describe; per 4 KiB unit as the match finder delivers
+    them (records {literals | match length << 16 | offset << 32}, the unit's literal bytes, meta {nseq, nlit, tail, 0})."""
+    rng = np.random.default_rng(seed)
+    raw = np.zeros(nunits * 4096, np.uint8)
+    meta = np.zeros((nunits, 4), np.uint32)
+    lits = np.zeros((nunits, 4096), np.uint8)
+    recs = np.zeros((nunits, 1024), np.uint64)
+    pos = 0
+    for u in range(nunits):
+        end, nlit, nseq, hist = (u + 1) * 4096, 0, 0, []
+        while True:
+            lit = int(rng.choice([0, 0, 0, 1, 2, 5, 17]))
+            ml = int(rng.integers(3, 40))
+            if pos + lit + ml > end - 8 or nseq == 1024:
+                break
+            raw[pos : pos + lit] = rng.integers(0, 256, lit)
+            lits[u, nlit : nlit + lit] = raw[pos : pos + lit]
+            pos += lit
+            nlit += lit
+            pick = int(rng.integers(0, 6))
+            off = None
+            if hist and pick < 5:
+                off = [hist[-1], hist[-2] if len(hist) > 1 else hist[-1], hist[-3] if len(hist) > 2 else hist[-1], hist[-1] - 1, hist[-1]][pick]
+            if not off or off < 1 or off > pos:
+                off = int(rng.integers(1, pos + 1)) if pos else None
+            if off is None:  # nothing to copy from yet: literals only
+                raw[pos : pos + ml] = rng.integers(0, 256, ml)
+                lits[u, nlit : nlit + ml] = raw[pos : pos + ml]
+                pos += ml
+                nlit += ml
+                continue
+            for k in range(ml):
+                raw[pos + k] = raw[pos + k - off]
+            pos += ml
+            # the literals in front of this match are all the literal bytes since the last match
+            recs[u, nseq] = (nlit - int(sum(int(r & 0xFFFF) for r in recs[u, :nseq]))) | (ml << 16) | (off << 32)
+            nseq += 1
+            hist.append(off)
+        tail = end - pos
+        raw[pos:end] = rng.integers(0, 256, tail)
+        lits[u, nlit : nlit + tail] = raw[pos:end]
+        nlit += tail
+        pos = end
+        meta[u] = (nseq, nlit, tail, 0)
+    return raw, meta, lits, recs
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_block_local_repeat_offset_codes(model, layout, seed):
+    """Sub-block layout: repeat-offset codes for history entries set inside the block (zb_encode_piece_sub, ZB_F_REPCODES).  The
+    reference decoder (which carries the real history across blocks) regenerates the bytes, and the codes pay: the piece is smaller
+    than with plain offsets."""
+    if not layout:
+        pytest.skip("the one-block-per-piece layout writes plain offsets")
+    d = model.dll
+    d.ltz_model_flags.restype = None
+    d.ltz_model_flags.argtypes = [C.c_uint32]
+    raw, meta, lits, recs = _rep_piece(seed)
+    nunits = len(meta)
+    head = np.frombuffer(bytes([0x28, 0xB5, 0x2F, 0xFD, 0xE0]) + (len(raw)).to_bytes(8, "little"), np.uint8)
+    sizes = {}
+    try:
+        for flags in (1, 0):
+            d.ltz_model_flags(flags)
+            out = np.zeros(140000, np.uint8)
+            n = d.ltz_model_encode_block(meta.ctypes.data, lits.ctypes.data, recs.ctypes.data, nunits, len(raw), out.ctypes.data)
+            assert 0 < n < len(raw)
+            d.ltz_model_last_sub.restype = C.POINTER(C.c_uint16)
+            sub = d.ltz_model_last_sub()
+            out[n - 3 - (sub[nunits - 1] & 0x7FFF)] |= 1
+            frame = np.concatenate([head, out[:n]])
+            err, dec = get_ref().decompress(CODEC_ZSTD, frame, len(raw))
+            assert err == 0 and len(dec) == len(raw) and (dec == raw).all(), flags
+            err2, got = model_decode(model, frame, len(raw))  # the decoder core of this library (serial instantiation)
+            assert err2 == 0 and len(got) == len(raw) and (got == raw).all()
+            sizes[flags] = n
+    finally:
+        d.ltz_model_flags(1)
+    assert sizes[1] < sizes[0], sizes
