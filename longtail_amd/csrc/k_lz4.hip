@@ -834,8 +834,11 @@ template <int TAB, int FMT, int SH>
 __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t head /* incl. LZ4_LPAD */, uint16_t* tab, const uint32_t* shr,
                                                 uint32_t sh_base, int lane, uint32_t my_start, uint32_t my_len, int32_t start_limit,
                                                 uint32_t end_limit, uint32_t sub, uint8_t* __restrict__ out, uint64_t* __restrict__ zrecs,
-                                                Lz4Seq& st, uint32_t dbg K5P_ARG)
+                                                Lz4Seq& st, uint32_t dbg K5P_ARG, uint32_t lo_bound = 0u, uint32_t sh_shift = 32u - (uint32_t)SH,
+                                                uint32_t sh_off = 0u)
 {
+    // lo_bound: candidates below this window position are not this unit's history (two unrelated half-groups share the window, see
+    // k_lz4_lanes2); sh_shift / sh_off: the part of the shared table that is this half's
     static_assert(SH != 0, "the second formulation is the shared-table parser's");
     static_assert(LZ4_LANE_MAXREC == 8, "records are eight register pairs");
     constexpr bool PAD = true; // the window is the padded one (lds_dw)
@@ -883,7 +886,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 const uint32_t prod = v * 2654435761u;
                 const uint32_t h = lz4_tab_slot<TAB, 2>(prod);
                 uint32_t c = tab[h];
-                const uint32_t c2 = shr[prod >> (32 - SH)] - sh_base; // (another group's entry: far above any position)
+                const uint32_t c2 = shr[(prod >> sh_shift) + sh_off] - sh_base; // (another group's entry: far above any position)
                 tab[h] = (uint16_t)p;
                 if ((dbg & (1u << 28)) || q_max) // "max": the slot is read again after the step's inserts (entries of lanes in phase)
                 {
@@ -894,7 +897,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                         c = fresh;
                 }
                 // both candidates' bytes in one round trip (an invalid one reads my own position and is masked)
-                const bool v1 = c < p, v2 = c2 < p;
+                const bool v1 = c < p && c >= lo_bound, v2 = c2 < p && c2 >= lo_bound;
                 const uint32_t r1 = lds_read32x<PAD>(sdata, (v1 ? c : p) + head);
                 const uint32_t r2 = lds_read32x<PAD>(sdata, (v2 ? c2 : p) + head);
                 const bool h1 = v1 && r1 == v, h2 = v2 && r2 == v;
@@ -965,7 +968,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 mlen = maxlen;
                 grow = false;
             }
-            if (cand >= 8u && p - anchor != 0u)
+            if (cand >= lo_bound + 8u && p - anchor != 0u)
             {
                 nbk = X[1] ? (uint32_t)__builtin_clz(X[1]) >> 3 : (X[0] ? 4u + ((uint32_t)__builtin_clz(X[0]) >> 3) : 8u);
                 nbk = nbk < p - anchor ? nbk : p - anchor;
@@ -988,7 +991,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 {
                     // the backward count belongs to the candidate: redo it for the new one
                     nbk = 0;
-                    if (cand2 >= 8u && p - anchor != 0u)
+                    if (cand2 >= lo_bound + 8u && p - anchor != 0u)
                     {
                         const uint32_t x1 = lds_read32x<PAD>(sdata, p - 4u + head) ^ lds_read32x<PAD>(sdata, cand2 - 4u + head);
                         const uint32_t x0 = lds_read32x<PAD>(sdata, p - 8u + head) ^ lds_read32x<PAD>(sdata, cand2 - 8u + head);
@@ -2068,6 +2071,295 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
         K5P_FLUSH;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K5 lane parser, round 4: HALF-GROUPS as the unit of work.  The classification pass flags redundancy per 32 KiB half of a 64 KiB
+// group; a group with one redundant and one incompressible half (37 % of the listed groups of bench.py's compressible tree: regions
+// of four kinds, a quarter of them random, at arbitrary offsets against the groups) kept eight of the workgroup's sixteen waves idle
+// for the whole group.  Now the list is turned into ITEMS of two halves: the two halves of a group that is redundant throughout
+// (linked: one contiguous 64 KiB window, as before), or two LONE halves of different groups, which share nothing but the workgroup --
+// each has its own 32 KiB of the window (candidates below a half's start are refused), its own half of the shared table, its own
+// source alignment.  What a half compresses to does not depend on its partner.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t LZ4_HALF_NONE = 0xFFFFFFFFu;
+// worklist layout behind the classification pass (ngroups = groups of the batch): [0] listed groups, [1 .. ngroups] their ids,
+// [1 + ngroups ..) per-group half bits, [2 ngroups + 1] ticket, [2 ngroups + 2] items, [2 ngroups + 3] lone halves,
+// [2 ngroups + 4 ..) items (two half ids each), [4 ngroups + 4 ..) lone halves
+__global__ void k_lz4_pair_halves(uint32_t* __restrict__ wl, uint32_t ngroups, uint32_t phase)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t* items = wl + 2u * ngroups + 4u;
+    uint32_t* lone = wl + 4u * ngroups + 4u;
+    if (phase == 0u)
+    {
+        if (i >= wl[0])
+            return;
+        const uint32_t g = wl[1u + i], bits = wl[1u + ngroups + g] & 3u;
+        if (bits == 3u)
+        {
+            const uint32_t k = atomicAdd(&wl[2u * ngroups + 2u], 1u);
+            items[2u * k] = 2u * g;
+            items[2u * k + 1u] = 2u * g + 1u;
+        }
+        else if (bits)
+            lone[atomicAdd(&wl[2u * ngroups + 3u], 1u)] = 2u * g + (bits >> 1);
+    }
+    else
+    {
+        const uint32_t nl = wl[2u * ngroups + 3u];
+        if (2u * i >= nl)
+            return;
+        const uint32_t k = atomicAdd(&wl[2u * ngroups + 2u], 1u);
+        items[2u * k] = lone[2u * i];
+        items[2u * k + 1u] = 2u * i + 1u < nl ? lone[2u * i + 1u] : LZ4_HALF_NONE;
+    }
+}
+
+template <int FMT>
+__global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks, uint32_t nblocks,
+                                                       uint32_t sub_bytes, uint8_t* __restrict__ streams, Lz4Meta* __restrict__ meta,
+                                                       uint64_t* __restrict__ zrecs, uint8_t* __restrict__ spec_dst, uint32_t dbg,
+                                                       uint32_t ngroups, uint32_t* __restrict__ worklist)
+{
+    constexpr int G = LZ4_G_LANES, TAB = LZ4_TAB_SHARED, SH = LZ4_SH_LOG2;
+    constexpr bool PAD = true;
+    constexpr uint32_t GAP = 32u; // LDS bytes between the windows of two unlinked halves
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t data_bytes = lz4_window_lds_bytes(G * sub_bytes + 64u + LZ4_LPAD + GAP, true);
+    uint32_t* sdata = smem;
+    uint32_t* flag = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes); // 16 bytes
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t hsel = (uint32_t)wave >> 3, wih = (uint32_t)wave & 7u; // my half of the item, my unit in the half
+    uint16_t* tab = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u) + (size_t)wave * TAB;
+    uint32_t* shr = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u + (size_t)G * TAB * 2);
+    const uint32_t* items = worklist + 2u * ngroups + 4u;
+    const uint32_t nitems = worklist[2u * ngroups + 2u];
+    const uint32_t half_bytes = (uint32_t)(G / 2) * sub_bytes;
+    K5P_DECL
+    uint32_t sh_gen = 0;
+    uint32_t next_idx = 0;
+    for (uint32_t idx = blockIdx.x; idx < nitems; idx = next_idx)
+    {
+        if (sh_gen == 0u)
+        {
+            uint4* hv = reinterpret_cast<uint4*>(shr);
+            const uint4 none = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            for (uint32_t v = tid; v < (4u << SH) / 16u; v += 64 * G)
+                hv[v] = none;
+            __syncthreads();
+            sh_gen = (dbg & (1u << 26)) ? 3u : 0xFFFFu;
+        }
+        --sh_gen;
+        const uint32_t sh_base = sh_gen << 16;
+        const uint32_t ha = items[2u * idx], hb = items[2u * idx + 1u];
+        const bool linked = hb == ha + 1u && !(ha & 1u);
+        const uint32_t hid = hsel ? hb : ha;
+        const bool valid = hid != LZ4_HALF_NONE;
+        const uint32_t grp = valid ? hid >> 1 : ha >> 1, hh = valid ? hid & 1u : 0u;
+        uint32_t lo = 0, hi = nblocks;
+        while (hi - lo > 1)
+        {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (blocks[mid].grp_base <= grp)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const Lz4Block blk = blocks[lo];
+        const uint32_t gi = grp - blk.grp_base;
+        const uint32_t half_start = (gi * (uint32_t)G + hh * (uint32_t)(G / 2)) * sub_bytes; // block relative
+        const uint32_t hlen = valid && half_start < blk.size ? (blk.size - half_start < half_bytes ? blk.size - half_start : half_bytes) : 0u;
+        const uint8_t* g = src + blk.src_off + half_start;
+        const uint32_t head_src = (uint32_t)((uintptr_t)g & 15u);
+        const uint32_t wbase = hsel * half_bytes;                       // window position of my half's first byte
+        const uint32_t extra = hsel && !linked ? GAP : 0u;              // its LDS displacement
+        const uint32_t head = head_src + LZ4_LPAD + extra;              // LDS byte address of window position x: x + head
+        const uint32_t lo_bound = hsel && !linked ? half_bytes : 0u;
+        const uint32_t sh_shift = linked ? 32u - (uint32_t)SH : 33u - (uint32_t)SH;
+        const uint32_t sh_off = linked ? 0u : hsel << (SH - 1);
+
+        // ---- every half is staged by its own eight waves (16-byte loads from the aligned-down address); the aligned dwords enter the
+        // half's part of the shared table from the registers that stage them ----
+        {
+            const uint4* gv = reinterpret_cast<const uint4*>(g - head_src);
+            const uint32_t nvec = hlen ? (head_src + hlen + 15u) >> 4 : 0u;
+            const uint32_t line0 = (wbase + extra + LZ4_LPAD) >> 4; // LDS line (unpadded numbering) of my half's source line 0
+            const uint32_t th = (uint32_t)tid & 511u;
+            for (uint32_t v0 = 0; v0 < nvec; v0 += 512u * 4u)
+            {
+                uint4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const uint32_t v = v0 + (uint32_t)u * 512u + th;
+                    q[u] = v < nvec ? gv[v] : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const uint32_t v = v0 + (uint32_t)u * 512u + th;
+                    if (v < nvec)
+                    {
+                        const uint32_t D = 4u * (line0 + v);
+                        uint32_t* w = sdata + lds_pidx<true>(D);
+                        w[0] = q[u].x;
+                        w[1] = q[u].y;
+                        w[2] = q[u].z;
+                        w[3] = q[u].w;
+                        if ((D & 31u) == 0u && D != 0u) // the first line of a row: repeated behind the row before
+                        {
+                            w[-3] = q[u].x;
+                            w[-2] = q[u].y;
+                            w[-1] = q[u].z;
+                        }
+                        const uint32_t pq = wbase + 16u * v - head_src; // window position of the line's first byte
+                        const uint32_t g4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                        {
+                            const uint32_t pk = pq + 4u * (uint32_t)k;
+                            if (pk >= wbase && pk < wbase + hlen) // (line 0 may begin before the half: a wrapped value is above it)
+                                (void)__hip_atomic_fetch_min(&shr[((g4[k] * 2654435761u) >> sh_shift) + sh_off], sh_base | pk, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+            }
+            uint4* tv = reinterpret_cast<uint4*>(tab);
+            const uint4 e = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (uint32_t v = 0; v < (TAB * 2 / 16 + 63) / 64; ++v)
+                if (v * 64 + lane < TAB * 2 / 16)
+                    tv[v * 64 + lane] = e;
+            if (tid == 0)
+                flag[1] = gridDim.x + atomicAdd(worklist + 2u * ngroups + 1u, 1u);
+        }
+        __syncthreads();
+        K5P(0);
+        next_idx = flag[1];
+        K5P(1);
+        // ---- my unit, positions relative to the window ----
+        const uint32_t my_start = (uint32_t)wave * sub_bytes;
+        const bool have_unit = wih * sub_bytes < hlen;
+        const uint32_t my_len = have_unit ? (hlen - wih * sub_bytes < sub_bytes ? hlen - wih * sub_bytes : sub_bytes) : 0u;
+        const uint32_t unit = blk.seg_base + gi * (uint32_t)G + hh * (uint32_t)(G / 2) + wih;
+        const int64_t blk_left = (int64_t)blk.size - (int64_t)half_start - (int64_t)(wih * sub_bytes); // unit start .. block end
+        int64_t sl = (int64_t)my_len - 4;
+        if (sl > blk_left - 12)
+            sl = blk_left - 12;
+        const int32_t start_limit = have_unit ? (int32_t)((int64_t)my_start + sl) : -1;
+        const int64_t el = (int64_t)my_len < blk_left - 5 ? (int64_t)my_len : (blk_left - 5 > 0 ? blk_left - 5 : 0);
+        const uint32_t end_limit = my_start + (uint32_t)el;
+        uint8_t* out = streams + (uint64_t)unit * (FMT == 1 ? sub_bytes : lz4_stream_stride(sub_bytes));
+        uint64_t* recs = FMT == 1 ? zrecs + (uint64_t)unit * (sub_bytes >> 2) : nullptr;
+        Lz4Seq st;
+        st.op = 0;
+        st.nseq = 0;
+        st.anchor = my_start;
+        st.first_lit = st.first_hdr = 0;
+        st.have_first = false;
+        // the private table starts with the aligned dwords of the unit before mine (my half's, or -- linked -- the other half's last)
+        if (have_unit && (wih > 0u || (hsel && linked)) && !(dbg & 1u))
+        {
+            const uint32_t p0 = my_start - sub_bytes;
+            const uint32_t l0 = (p0 + head) >> 4, l1 = (my_start + head + 15u) >> 4;
+            for (uint32_t j0 = l0; j0 < l1; j0 += 256)
+            {
+                uint4 w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const uint32_t j = j0 + (uint32_t)u * 64u + (uint32_t)lane;
+                    const uint32_t* q = sdata + lds_pidx<true>(4u * j);
+                    w[u] = j < l1 ? make_uint4(q[0], q[1], q[2], q[3]) : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const uint32_t j = j0 + (uint32_t)u * 64u + (uint32_t)lane;
+                    const uint32_t q = 16u * j - head;
+                    const uint32_t g4[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        const uint32_t pk = q + 4u * (uint32_t)k;
+                        if (j < l1 && pk >= p0 && pk < my_start)
+                            tab[lz4_tab_slot<TAB, 2>(g4[k] * 2654435761u)] = (uint16_t)pk;
+                    }
+                }
+            }
+        }
+        if (have_unit)
+        {
+            K5P(2);
+            lz4_lane_parse2<TAB, FMT, SH>(sdata, head, tab, shr, sh_base, lane, my_start, my_len, start_limit, end_limit, sub_bytes >> 6, out, recs, st,
+                                          dbg K5P_PASS, lo_bound, sh_shift, sh_off);
+        }
+        if constexpr (FMT == 1)
+        {
+            const uint32_t tail = have_unit ? my_start + my_len - st.anchor : 0u;
+            if (st.nseq != 0u)
+            {
+                for (uint32_t j = lane; j < tail; j += 64)
+                    out[st.op + j] = (uint8_t)lds_byte<PAD>(sdata, st.anchor + j + head);
+            }
+            else if (have_unit && spec_dst)
+            {
+                const uint32_t pos = half_start + wih * sub_bytes;
+                const uint64_t o = 13u + (uint64_t)(pos / Z_PIECE) * (Z_PIECE + 3u) + 3u + pos % Z_PIECE;
+                if (o + my_len <= (uint64_t)blk.dst_cap)
+                    wave_copy_lds_to_global<PAD>(spec_dst + blk.dst_off + o, sdata, my_start + head, my_len, lane);
+            }
+            uint32_t uniform = 0;
+            if (have_unit)
+            {
+                const uint32_t b0 = lds_byte<PAD>(sdata, my_start + head);
+                const uint32_t rep = b0 * 0x01010101u;
+                uint32_t diff = 0;
+                if (64u * (uint32_t)lane + 4u <= my_len)
+                    diff = lds_read32x<PAD>(sdata, my_start + 64u * (uint32_t)lane + head) ^ rep;
+                if (__builtin_amdgcn_ballot_w64(diff != 0u) == 0ull)
+#pragma unroll 4
+                    for (uint32_t j = 0; j < 16u; ++j)
+                    {
+                        const uint32_t o = 64u * (uint32_t)lane + 4u * j;
+                        if (o + 4u <= my_len)
+                            diff |= lds_read32x<PAD>(sdata, my_start + o + head) ^ rep;
+                        else if (o < my_len)
+                            for (uint32_t k = o; k < my_len; ++k)
+                                diff |= lds_byte<PAD>(sdata, my_start + k + head) ^ b0;
+                    }
+                uniform = __builtin_amdgcn_ballot_w64(diff != 0u) == 0ull ? (0x100u | b0) : 0u;
+            }
+            if (have_unit && lane == 0)
+                reinterpret_cast<uint4*>(meta)[unit] = make_uint4(st.nseq, st.op + tail, tail, uniform);
+        }
+        else
+        {
+            if (spec_dst && have_unit && !st.have_first)
+            {
+                const uint64_t o = (uint64_t)(1u + lz4_len_bytes(blk.size)) + half_start + wih * sub_bytes;
+                if (o + my_len <= (uint64_t)blk.dst_cap)
+                    wave_copy_lds_to_global<PAD>(spec_dst + blk.dst_off + o, sdata, my_start + head, my_len, lane);
+            }
+            if (have_unit && lane == 0)
+            {
+                Lz4Meta m;
+                m.seq_bytes = st.op;
+                m.tail_lits = my_start + my_len - st.anchor;
+                m.first_lit_len = st.first_lit;
+                m.first_hdr_bytes = st.first_hdr;
+                meta[unit] = m;
+            }
+        }
+        K5P(8);
+        __syncthreads(); // every wave is done with the window before the next item overwrites it
+        K5P(9);
+    }
+    K5P_FLUSH;
+}
+
 __device__ __forceinline__ void wg_emit_header(uint8_t* dst, uint32_t lits, uint32_t match_nibble, int tid, int nthreads)
 {
     if (tid == 0)
@@ -2470,14 +2762,36 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
                       : launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, FMT, 1>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta, zrecs,
                                                                            spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr);
     void* wl;
-    int err = lthip_scratch(ctx, S_LZ4_CLASSIFY, 4 * (2 * (size_t)ngrp + 2), &wl);
+    int err = lthip_scratch(ctx, S_LZ4_CLASSIFY, 4 * (5 * (size_t)ngrp + 8), &wl);
     if (err)
         return err;
-    LTHIP_CHECK(ctx, hipMemsetAsync(wl, 0, 4 * (2 * (size_t)ngrp + 2), ctx->stream));
+    LTHIP_CHECK(ctx, hipMemsetAsync(wl, 0, 4 * (2 * (size_t)ngrp + 4), ctx->stream));
     if ((err = launch_segments<LZ4_G_BATCH, FMT == 1 ? LZ4_TAB_ZSTD : LZ4_TAB_LZ4, FMT, 0, 1>(ctx, (uint32_t)ncgrp, SEG, d_src, d_blocks, block_count, 0,
                                                                                              streams, meta, zrecs, spec_dst, dbg, nullptr,
                                                                                              (uint32_t)ngrp, (uint32_t*)wl)))
         return err;
+    static LthipEnvInt env_halves{"LTHIP_LZ4_HALVES"}; // 0: whole groups as the unit of work (a group's incompressible half idles eight waves)
+    if (pv2 && env_halves.get() != 0)
+    {
+        // the list of groups -> items of two half-groups (k_lz4_pair_halves), then the lane kernel over the items
+        const uint32_t nthreads = 256, ng = (uint32_t)ngrp;
+        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng + nthreads - 1) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 0u);
+        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng / 2 + nthreads) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 1u);
+        LTHIP_LAUNCH_CHECK(ctx);
+        const size_t lds = (size_t)lz4_window_lds_bytes(LZ4_G_LANES * SEG + 64u + LZ4_LPAD + 32u, true) + 16 + (size_t)LZ4_G_LANES * LZ4_TAB_SHARED * 2 +
+                           ((size_t)4 << LZ4_SH_LOG2);
+        if (!ctx->k5h_lds_enabled[FMT])
+        {
+            LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_lanes2<FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ctx->k5h_lds_enabled[FMT] = true;
+        }
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        hipLaunchKernelGGL((k_lz4_lanes2<FMT>), dim3((uint32_t)ncu), dim3(64 * LZ4_G_LANES), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
+                           block_count, SEG, streams, meta, zrecs, spec_dst, dbg, ng, (uint32_t*)wl);
+        LTHIP_LAUNCH_CHECK(ctx);
+        return 0;
+    }
     if (pv2)
         return launch_segments<LZ4_G_LANES, LZ4_TAB_SHARED, FMT, 1, 0, LZ4_SH_LOG2, 2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta,
                                                                                       zrecs, spec_dst, dbg, lane_recs, (uint32_t)ngrp, (uint32_t*)wl);

@@ -123,6 +123,7 @@ struct lthip_ctx
     size_t stage_next;
     bool k1_lds_enabled; // hipFuncAttributeMaxDynamicSharedMemorySize set for K1 on this context's device
     bool k5_lds_enabled; // ... and for the lane-parser flavours of K5
+    bool k5h_lds_enabled[2]; // ... and for k_lz4_lanes2<FMT>
     void* scratch[S_COUNT];
     size_t scratch_cap[S_COUNT];
     bool timing;
