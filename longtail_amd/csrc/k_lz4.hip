@@ -835,8 +835,11 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                                                 uint32_t sh_base, int lane, uint32_t my_start, uint32_t my_len, int32_t start_limit,
                                                 uint32_t end_limit, uint32_t sub, uint8_t* __restrict__ out, uint64_t* __restrict__ zrecs,
                                                 Lz4Seq& st, uint32_t dbg K5P_ARG, uint32_t lo_bound = 0u, uint32_t sh_shift = 32u - (uint32_t)SH,
-                                                uint32_t sh_off = 0u)
+                                                uint32_t sh_off = 0u, uint32_t not_private = 0xFFFFFFFFu)
 {
+    // not_private: a position the PRIVATE table never offers (an unlinked half's first position: in the window's lower half that is
+    // position 0, which the table cannot tell from "empty", so the upper half must not have it either -- what a half compresses to must
+    // not depend on which slot of the window it was given)
     // lo_bound: candidates below this window position are not this unit's history (two unrelated half-groups share the window, see
     // k_lz4_lanes2); sh_shift / sh_off: the part of the shared table that is this half's
     static_assert(SH != 0, "the second formulation is the shared-table parser's");
@@ -897,7 +900,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                         c = fresh;
                 }
                 // both candidates' bytes in one round trip (an invalid one reads my own position and is masked)
-                const bool v1 = c < p && c >= lo_bound, v2 = c2 < p && c2 >= lo_bound;
+                const bool v1 = c < p && c >= lo_bound && c != not_private, v2 = c2 < p && c2 >= lo_bound;
                 const uint32_t r1 = lds_read32x<PAD>(sdata, (v1 ? c : p) + head);
                 const uint32_t r2 = lds_read32x<PAD>(sdata, (v2 ? c2 : p) + head);
                 const bool h1 = v1 && r1 == v, h2 = v2 && r2 == v;
@@ -2294,7 +2297,7 @@ __global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restric
         {
             K5P(2);
             lz4_lane_parse2<TAB, FMT, SH>(sdata, head, tab, shr, sh_base, lane, my_start, my_len, start_limit, end_limit, sub_bytes >> 6, out, recs, st,
-                                          dbg K5P_PASS, lo_bound, sh_shift, sh_off);
+                                          dbg K5P_PASS, lo_bound, sh_shift, sh_off, linked ? 0xFFFFFFFFu : wbase);
         }
         if constexpr (FMT == 1)
         {
