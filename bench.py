@@ -540,11 +540,15 @@ class Bench:
             try:
                 tj, tsrc = getattr(self, "traffic", None), "measured in this run (rocprofv3 --kernel-trace --pmc, 8 GiB of the same workload)"
                 if tj is None or cfg["kind"] != self.traffic_cfg["kind"] or cfg["codec"] != self.traffic_cfg["codec"] or cfg["tree"] != self.traffic_cfg["tree"]:
-                    tfiles = sorted((ROOT / "profiles").glob("*xtraffic*.json"))
+                    # the newest committed measurement OF THIS WORKLOAD: ..._xtraffic_8g[_zstd][_mixed].json
+                    want = "_xtraffic_8g" + ("_zstd" if cfg["codec"] == "zstd" else "") + ("_mixed" if cfg["kind"] != "random" else "") + ".json"
+                    tfiles = sorted(f for f in (ROOT / "profiles").glob("*xtraffic*.json") if f.name.endswith(want) and
+                                    ("zstd" in f.name) == (cfg["codec"] == "zstd") and ("mixed" in f.name) == (cfg["kind"] != "random"))
                     tj, tsrc = json.load(open(tfiles[-1])), f"profiles/{tfiles[-1].name} (committed measurement)"
-                prefix = {"buzhash": "k_buzhash", "blake3_leaf": "k_blake3_leaves", "lz4_segments": "k_lz4_segments<", "zstd_encode": "k_zstd_encode"}
+                prefix = {"buzhash": ("k_buzhash",), "blake3_leaf": ("k_blake3_leaves",), "lz4_segments": ("k_lz4_segments<", "k_lz4_lanes2<"),
+                          "zstd_encode": ("k_zstd_encode",)}
 
-                def fmt_of(k):  # k_lz4_segments<G, TAB, FMT, MODE, CLS>: the LZ4 flavours have FMT 0
+                def fmt_of(k):  # k_lz4_segments<G, TAB, FMT, MODE, CLS, ...> / k_lz4_lanes2<FMT>: the LZ4 flavours have FMT 0
                     args = k[k.index("<") + 1 : k.rindex(">")].split(",")
                     return int(args[2]) if len(args) >= 3 else int(args[-1])
 
@@ -554,6 +558,8 @@ class Bench:
                     return tj["kernels"][k]["read_per_input_byte"] + tj["kernels"][k]["write_per_input_byte"]
 
                 keys = [k for k in tj["kernels"] if k.startswith(prefix[dom]) and (dom != "lz4_segments" or fmt_of(k) == want_fmt)]
+                if dom == "zstd_encode":  # (its match finder runs under the lz4_segments timer; the entropy stage is what dominates)
+                    keys = [k for k in tj["kernels"] if k.startswith("k_zstd_encode")]
                 if not keys:
                     raise KeyError(dom)
                 # the match finder is two kernels (classification pass + lane parser) under one timer: their traffic adds up
