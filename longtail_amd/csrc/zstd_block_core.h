@@ -81,7 +81,7 @@ typedef struct ZbInput
                          * copy what nobody may ever need) */
     uint32_t flags;     /* ZB_F_* */
 } ZbInput;
-#define ZB_F_REPCODES 1u /* sub-block layout: repeat-offset codes whose history entry was SET INSIDE THE BLOCK (see zb_rep_pass) */
+#define ZB_F_REPCODES 1u /* sub-block layout: repeat-offset codes whose history entry was SET INSIDE THE BLOCK (zb_encode_piece_sub, phase 1) */
 
 typedef struct ZbScratch /* global memory owned by the lanes of one block encoder */
 {
@@ -1493,68 +1493,81 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
     ZB_MARK(1);
     /* ---- phase 1: the sequences in block order (a unit's trailing literals stay with the unit: they are its block's last
      * literals), the three symbol histograms, the literal histogram ---- */
-    ZB_PAR_FOR(i, nbseq)
+    if (!(in->flags & ZB_F_REPCODES))
     {
-        uint32_t lo = 0, hi = nunits;
-        while (hi - lo > 1u)
+        ZB_PAR_FOR(i, nbseq)
         {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (sh->useq_base[mid] <= i)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        {
-            const uint64_t r = in->unit_recs[(uint64_t)lo * ZB_UNIT_SEQ_MAX + (i - sh->useq_base[lo])];
-            const uint32_t lit = (uint32_t)(r & 0xFFFFu), ml = (uint32_t)((r >> 16) & 0xFFFFu), off = (uint32_t)(r >> 32);
-            sc->seqs[i] = (uint64_t)lit | ((uint64_t)ml << 20) | ((uint64_t)off << 36);
-            zb_atomic_add(&sh->sym_hist[ZT_LL][zb_ll_code(lit)], 1u);
-            zb_atomic_add(&sh->sym_hist[ZT_ML][zb_ml_code(ml - 3u)], 1u);
-            if (!(in->flags & ZB_F_REPCODES))
+            uint32_t lo = 0, hi = nunits;
+            while (hi - lo > 1u)
+            {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (sh->useq_base[mid] <= i)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            {
+                const uint64_t r = in->unit_recs[(uint64_t)lo * ZB_UNIT_SEQ_MAX + (i - sh->useq_base[lo])];
+                const uint32_t lit = (uint32_t)(r & 0xFFFFu), ml = (uint32_t)((r >> 16) & 0xFFFFu), off = (uint32_t)(r >> 32);
+                sc->seqs[i] = (uint64_t)lit | ((uint64_t)ml << 20) | ((uint64_t)off << 36);
+                zb_atomic_add(&sh->sym_hist[ZT_LL][zb_ll_code(lit)], 1u);
+                zb_atomic_add(&sh->sym_hist[ZT_ML][zb_ml_code(ml - 3u)], 1u);
                 zb_atomic_add(&sh->sym_hist[ZT_OF][zb_of_code(off)], 1u);
+            }
         }
     }
-    if (in->flags & ZB_F_REPCODES)
+    else
     {
-        /* ---- repeat-offset codes (zstd_compression_format.md "Repeat Offsets"; ZSTD_updateRep / ZSTD_storeSeq of the reference,
+        /* ---- with repeat-offset codes (zstd_compression_format.md "Repeat Offsets"; ZSTD_updateRep / ZSTD_storeSeq of the reference,
          * compress/zstd_compress_internal.h).  A zstd block starts with the three-entry offset history its predecessor left behind --
          * which is exactly what a decoder that gives every block a lane of its own does not have.  So a block here only ever refers to
          * history entries that were SET BY ITS OWN SEQUENCES: the history starts "unknown" in every block, an entry becomes known when
          * a sequence of the block writes it, and a repeat code is used only for a known entry.  Any zstd decoder reads such a block (it
          * simply never looks at what it inherited); the lane-parallel one needs nothing from the block before.  One lane per block, in
-         * sequence order (the chain is serial by nature); the offset-code histogram is built here. */
-        ZB_SYNC();
+         * sequence order (the chain is serial by nature): the lane reads its unit's records eight at a time (the loads do not depend on
+         * the history; one at a time the lane waited a memory round trip per sequence), writes the merged list and counts all three
+         * code histograms. */
         ZB_PAR_FOR(u, nunits)
         {
             const uint32_t b0 = sh->useq_base[u], e0 = sh->useq_base[u + 1u];
+            const uint64_t* recs = in->unit_recs + (uint64_t)u * ZB_UNIT_SEQ_MAX;
             uint32_t r1 = 0, r2 = 0, r3 = 0; /* 0 = unknown (an offset is never 0) */
-            for (uint32_t i = b0; i < e0; ++i)
+            for (uint32_t i0 = b0; i0 < e0; i0 += 8u)
             {
-                const uint64_t q = sc->seqs[i];
-                const uint32_t lit = ZB_SEQ_LIT(q), off = ZB_SEQ_OFF(q);
-                uint32_t code = 0; /* 0: the offset itself */
-                if (lit != 0u)
-                    code = off == r1 ? 1u : off == r2 ? 2u : off == r3 ? 3u : 0u;
-                else
-                    code = off == r2 ? 1u : off == r3 ? 2u : (r1 > 1u && off == r1 - 1u) ? 3u : 0u;
-                /* which history entry was used (with literals: the code; without: one further, code 3 = r1 - 1 counts as "new") */
-                const uint32_t used = code == 0u ? 0u : (lit != 0u ? code : code + 1u);
-                if (used == 2u)
-                {
-                    const uint32_t t = r2;
-                    r2 = r1;
-                    r1 = t;
-                }
-                else if (used != 1u) /* a new offset, entry 3, or r1 - 1: pushed in front */
-                {
-                    const uint32_t v = used == 3u ? r3 : off;
-                    r3 = r2;
-                    r2 = r1;
-                    r1 = v;
-                }
-                if (code)
-                    sc->seqs[i] = (q & 0xFFFFFFFFFull) | ((uint64_t)(ZB_OFF_REP | code) << 36);
-                zb_atomic_add(&sh->sym_hist[ZT_OF][zb_highbit(code ? code : off + 3u)], 1u);
+                uint64_t q8[8];
+                const uint32_t cnt = e0 - i0 < 8u ? e0 - i0 : 8u;
+                for (uint32_t j = 0; j < 8u; ++j)
+                    q8[j] = j < cnt ? recs[i0 - b0 + j] : 0u;
+                for (uint32_t j = 0; j < 8u; ++j)
+                    if (j < cnt)
+                    {
+                        const uint64_t r = q8[j];
+                        const uint32_t lit = (uint32_t)(r & 0xFFFFu), ml = (uint32_t)((r >> 16) & 0xFFFFu), off = (uint32_t)(r >> 32);
+                        uint32_t code = 0; /* 0: the offset itself */
+                        if (lit != 0u)
+                            code = off == r1 ? 1u : off == r2 ? 2u : off == r3 ? 3u : 0u;
+                        else
+                            code = off == r2 ? 1u : off == r3 ? 2u : (r1 > 1u && off == r1 - 1u) ? 3u : 0u;
+                        /* which history entry was used (with literals: the code; without: one further, code 3 = r1 - 1 counts as "new") */
+                        const uint32_t used = code == 0u ? 0u : (lit != 0u ? code : code + 1u);
+                        if (used == 2u)
+                        {
+                            const uint32_t t = r2;
+                            r2 = r1;
+                            r1 = t;
+                        }
+                        else if (used != 1u) /* a new offset, entry 3, or r1 - 1: pushed in front */
+                        {
+                            const uint32_t v = used == 3u ? r3 : off;
+                            r3 = r2;
+                            r2 = r1;
+                            r1 = v;
+                        }
+                        sc->seqs[i0 + j] = (uint64_t)lit | ((uint64_t)ml << 20) | ((uint64_t)(code ? (ZB_OFF_REP | code) : off) << 36);
+                        zb_atomic_add(&sh->sym_hist[ZT_LL][zb_ll_code(lit)], 1u);
+                        zb_atomic_add(&sh->sym_hist[ZT_ML][zb_ml_code(ml - 3u)], 1u);
+                        zb_atomic_add(&sh->sym_hist[ZT_OF][zb_highbit(code ? code : off + 3u)], 1u);
+                    }
             }
         }
     }
