@@ -2086,12 +2086,26 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
 constexpr uint32_t LZ4_HALF_NONE = 0xFFFFFFFFu;
 // worklist layout behind the classification pass (ngroups = groups of the batch): [0] listed groups, [1 .. ngroups] their ids,
 // [1 + ngroups ..) per-group half bits, [2 ngroups + 1] ticket, [2 ngroups + 2] items, [2 ngroups + 3] lone halves,
-// [2 ngroups + 4 ..) items (two half ids each), [4 ngroups + 4 ..) lone halves
-__global__ void k_lz4_pair_halves(uint32_t* __restrict__ wl, uint32_t ngroups, uint32_t phase)
+// [2 ngroups + 4 ..) items of four words {half a, half b, block of a, block of b}, [6 ngroups + 4 ..) lone halves
+__host__ __device__ constexpr uint32_t lz4_items_off(uint32_t ngroups) { return (2u * ngroups + 4u + 3u) & ~3u; } // (16-byte aligned: items are read as uint4)
+__device__ __forceinline__ uint32_t lz4_block_of_group(const Lz4Block* __restrict__ blocks, uint32_t nblocks, uint32_t grp)
+{
+    uint32_t lo = 0, hi = nblocks;
+    while (hi - lo > 1)
+    {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (blocks[mid].grp_base <= grp)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+__global__ void k_lz4_pair_halves(uint32_t* __restrict__ wl, uint32_t ngroups, uint32_t phase, const Lz4Block* __restrict__ blocks, uint32_t nblocks)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t* items = wl + 2u * ngroups + 4u;
-    uint32_t* lone = wl + 4u * ngroups + 4u;
+    uint32_t* items = wl + lz4_items_off(ngroups);
+    uint32_t* lone = items + 4u * ngroups;
     if (phase == 0u)
     {
         if (i >= wl[0])
@@ -2100,8 +2114,11 @@ __global__ void k_lz4_pair_halves(uint32_t* __restrict__ wl, uint32_t ngroups, u
         if (bits == 3u)
         {
             const uint32_t k = atomicAdd(&wl[2u * ngroups + 2u], 1u);
-            items[2u * k] = 2u * g;
-            items[2u * k + 1u] = 2u * g + 1u;
+            const uint32_t b = lz4_block_of_group(blocks, nblocks, g); // (the ten dependent loads of the search happen here, once, in parallel)
+            items[4u * k] = 2u * g;
+            items[4u * k + 1u] = 2u * g + 1u;
+            items[4u * k + 2u] = b;
+            items[4u * k + 3u] = b;
         }
         else if (bits)
             lone[atomicAdd(&wl[2u * ngroups + 3u], 1u)] = 2u * g + (bits >> 1);
@@ -2112,8 +2129,11 @@ __global__ void k_lz4_pair_halves(uint32_t* __restrict__ wl, uint32_t ngroups, u
         if (2u * i >= nl)
             return;
         const uint32_t k = atomicAdd(&wl[2u * ngroups + 2u], 1u);
-        items[2u * k] = lone[2u * i];
-        items[2u * k + 1u] = 2u * i + 1u < nl ? lone[2u * i + 1u] : LZ4_HALF_NONE;
+        const uint32_t a = lone[2u * i], b = 2u * i + 1u < nl ? lone[2u * i + 1u] : LZ4_HALF_NONE;
+        items[4u * k] = a;
+        items[4u * k + 1u] = b;
+        items[4u * k + 2u] = lz4_block_of_group(blocks, nblocks, a >> 1);
+        items[4u * k + 3u] = b != LZ4_HALF_NONE ? lz4_block_of_group(blocks, nblocks, b >> 1) : 0u;
     }
 }
 
@@ -2136,12 +2156,15 @@ __global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restric
     const uint32_t hsel = (uint32_t)wave >> 3, wih = (uint32_t)wave & 7u; // my half of the item, my unit in the half
     uint16_t* tab = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u) + (size_t)wave * TAB;
     uint32_t* shr = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u + (size_t)G * TAB * 2);
-    const uint32_t* items = worklist + 2u * ngroups + 4u;
+    const uint32_t* items = worklist + lz4_items_off(ngroups);
     const uint32_t nitems = worklist[2u * ngroups + 2u];
     const uint32_t half_bytes = (uint32_t)(G / 2) * sub_bytes;
     K5P_DECL
     uint32_t sh_gen = 0;
     uint32_t next_idx = 0;
+    // (Fetching the next item's lines into registers during the parse -- 16 VGPRs -- was built and measured in round 4 as in round 3:
+    // no difference, 4.24 / 4.08 / 6.03 ms with it against 4.23 / 4.06 / 6.00 without on mixed / records / tokens.  An item's fixed
+    // cost is LDS work -- 16 K ds_min_u32, the table clears and preloads -- and two barriers, not the latency of its loads.)
     for (uint32_t idx = blockIdx.x; idx < nitems; idx = next_idx)
     {
         if (sh_gen == 0u)
@@ -2155,21 +2178,13 @@ __global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restric
         }
         --sh_gen;
         const uint32_t sh_base = sh_gen << 16;
-        const uint32_t ha = items[2u * idx], hb = items[2u * idx + 1u];
+        const uint4 item = reinterpret_cast<const uint4*>(items)[idx];
+        const uint32_t ha = item.x, hb = item.y;
         const bool linked = hb == ha + 1u && !(ha & 1u);
         const uint32_t hid = hsel ? hb : ha;
         const bool valid = hid != LZ4_HALF_NONE;
         const uint32_t grp = valid ? hid >> 1 : ha >> 1, hh = valid ? hid & 1u : 0u;
-        uint32_t lo = 0, hi = nblocks;
-        while (hi - lo > 1)
-        {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (blocks[mid].grp_base <= grp)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const Lz4Block blk = blocks[lo];
+        const Lz4Block blk = blocks[valid && hsel ? item.w : item.z];
         const uint32_t gi = grp - blk.grp_base;
         const uint32_t half_start = (gi * (uint32_t)G + hh * (uint32_t)(G / 2)) * sub_bytes; // block relative
         const uint32_t hlen = valid && half_start < blk.size ? (blk.size - half_start < half_bytes ? blk.size - half_start : half_bytes) : 0u;
@@ -2765,7 +2780,7 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
                       : launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, FMT, 1>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta, zrecs,
                                                                            spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr);
     void* wl;
-    int err = lthip_scratch(ctx, S_LZ4_CLASSIFY, 4 * (5 * (size_t)ngrp + 8), &wl);
+    int err = lthip_scratch(ctx, S_LZ4_CLASSIFY, 4 * (7 * (size_t)ngrp + 16), &wl);
     if (err)
         return err;
     LTHIP_CHECK(ctx, hipMemsetAsync(wl, 0, 4 * (2 * (size_t)ngrp + 4), ctx->stream));
@@ -2778,8 +2793,8 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
     {
         // the list of groups -> items of two half-groups (k_lz4_pair_halves), then the lane kernel over the items
         const uint32_t nthreads = 256, ng = (uint32_t)ngrp;
-        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng + nthreads - 1) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 0u);
-        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng / 2 + nthreads) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 1u);
+        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng + nthreads - 1) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 0u, d_blocks, block_count);
+        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng / 2 + nthreads) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 1u, d_blocks, block_count);
         LTHIP_LAUNCH_CHECK(ctx);
         const size_t lds = (size_t)lz4_window_lds_bytes(LZ4_G_LANES * SEG + 64u + LZ4_LPAD + 32u, true) + 16 + (size_t)LZ4_G_LANES * LZ4_TAB_SHARED * 2 +
                            ((size_t)4 << LZ4_SH_LOG2);
