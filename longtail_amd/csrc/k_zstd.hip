@@ -116,21 +116,26 @@ __device__ __forceinline__ bool z_is_trailer(const uint8_t* d)
 constexpr uint16_t ZDIR_RAW_PIECE = 0xFFFFu, ZDIR_RLE_PIECE = 0xFFFEu;
 __host__ __device__ __forceinline__ uint32_t z_units(uint64_t content) { return (uint32_t)((content + ZB_UNIT - 1u) / ZB_UNIT); }
 __host__ __device__ __forceinline__ uint32_t z_trailer2_size(uint64_t content) { return ZTRAILER + 2u * z_units(content); }
-__device__ __forceinline__ void z_write_trailer2_head(uint8_t* d, uint64_t content)
+// version 2: plain offsets only; version 3 (round 4, LTHIP_ZSTD_REP=1): blocks may use repeat-offset codes for history entries set inside
+// the block (zb_encode_piece_sub, ZB_F_REPCODES) -- the lane decoder then carries a block-local history (zs_seq_lanes<2>), which costs it
+// 5-9 % (321 -> 294 GB/s on "mixed"): frames say which they are so that the others keep the cheaper loop
+__device__ __forceinline__ void z_write_trailer2_head(uint8_t* d, uint64_t content, uint32_t version)
 {
     const uint32_t n = 4u + 2u * z_units(content);
-    const uint8_t t[ZTRAILER] = {0x5D, 0x2A, 0x4D, 0x18, (uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24), 'L', 'T', 'P', 2};
+    const uint8_t t[ZTRAILER] = {0x5D, 0x2A, 0x4D, 0x18, (uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24), 'L', 'T', 'P', (uint8_t)version};
     for (uint32_t i = 0; i < ZTRAILER; ++i)
         d[i] = t[i];
 }
-__device__ __forceinline__ bool z_is_trailer2_head(const uint8_t* d, uint64_t content)
+// 0: not a directory trailer; else its version (2 or 3)
+__device__ __forceinline__ uint32_t z_is_trailer2_head(const uint8_t* d, uint64_t content)
 {
     const uint32_t n = 4u + 2u * z_units(content);
     const uint8_t t[ZTRAILER] = {0x5D, 0x2A, 0x4D, 0x18, (uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24), 'L', 'T', 'P', 2};
     bool same = true;
-    for (uint32_t i = 0; i < ZTRAILER; ++i)
+    for (uint32_t i = 0; i + 1u < ZTRAILER; ++i)
         same &= d[i] == t[i];
-    return same;
+    const uint32_t ver = d[ZTRAILER - 1u];
+    return same && (ver == 2u || ver == 3u) ? ver : 0u;
 }
 
 // serial per stored block: destination offset of every piece, total size
@@ -160,7 +165,7 @@ __global__ void k_zstd_scan(const ZBlock* __restrict__ blocks, uint32_t nblocks,
     {
         if (sub)
         {
-            z_write_trailer2_head(dst + blk.dst_off + pos, blk.size); // (the directory: k_zstd_emit, every piece its own entries)
+            z_write_trailer2_head(dst + blk.dst_off + pos, blk.size, sub == 2u ? 3u : 2u); // (the directory: k_zstd_emit, every piece its own entries)
             trailer_at[b] = (uint32_t)pos;
         }
         else
@@ -451,6 +456,11 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
     void *d_blocks, *d_rle, *d_zdst, *d_enc, *d_encsz, *d_work, *d_sub, *d_trail;
     // sub-blocks (default): one zstd block per 4 KiB unit and a directory in the trailer; LTHIP_ZSTD_SUB=0: one block per 128 KiB piece
     const bool sub = !(getenv("LTHIP_ZSTD_SUB") && atoi(getenv("LTHIP_ZSTD_SUB")) == 0);
+    // LTHIP_ZSTD_REP=1: block-local repeat-offset codes (sub-block layout only; the trailer says so: version 3).  Off by default -- on
+    // every kind measured they are worth < 0.1 % of the compressed size (offsets rarely repeat inside a 4 KiB block:
+    // profiles/r04_zstd_ratio_table*.txt) and cost the encoder 4 % and the lane decoder 5-9 %
+    static LthipEnvInt env_rep{"LTHIP_ZSTD_REP"};
+    const bool rep = sub && env_rep.get() == 1;
     if ((err = lthip_scratch(ctx, S_LZ4_BLOCKS, sizeof(ZBlock) * (size_t)block_count, &d_blocks)))
         return err;
     if ((err = lthip_scratch(ctx, S_Z_SUB, sizeof(uint16_t) * ZB_MAX_UNITS * ((size_t)nzb + 1) + 4 * ((size_t)block_count + 1), &d_sub)))
@@ -471,7 +481,7 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
     if (nzb)
     {
         static LthipEnvInt env_tickets{"LTHIP_ZSTD_TICKETS"};
-        static LthipEnvInt env_rep{"LTHIP_ZSTD_REP"}; // 0: no repeat-offset codes (the frames of rounds 2-3)
+
         uint32_t* d_ticket = env_tickets.get() == 0 ? nullptr : (uint32_t*)d_encsz + nzb + 1; // (the size list has four spare words)
         if (d_ticket)
             LTHIP_CHECK(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
@@ -479,14 +489,14 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
         hipLaunchKernelGGL(k_zstd_encode, dim3(nwg), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks, block_count, (uint32_t)nzb,
                            (const uint8_t*)d_src, (uint8_t*)d_rle, (const ZbUnitMeta*)d_meta, (const uint8_t*)d_lits, (const uint64_t*)d_recs,
                            (uint8_t*)d_work, (uint8_t*)d_enc, (uint32_t*)d_encsz, sub ? (uint16_t*)d_sub : (uint16_t*)nullptr, d_ticket,
-                           env_rep.get() == 0 ? 0u : (uint32_t)ZB_F_REPCODES);
+                           rep ? (uint32_t)ZB_F_REPCODES : 0u);
         LTHIP_LAUNCH_CHECK(ctx);
     }
     LaunchTimer t(ctx, LTHIP_K_OTHER);
     hipLaunchKernelGGL(k_zstd_scan, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
                        block_count, (const uint8_t*)d_rle, (const uint32_t*)d_encsz, (uint32_t*)d_zdst, d_out_sizes, (uint8_t*)d_dst,
                        (uint32_t)(getenv("LTHIP_ZSTD_DBG") ? atoi(getenv("LTHIP_ZSTD_DBG")) : 0), // bit 1: no trailer
-                       sub ? 1u : 0u, (uint32_t*)d_trail);
+                       sub ? (rep ? 2u : 1u) : 0u, (uint32_t*)d_trail);
     hipLaunchKernelGGL(k_zstd_headers, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
                        block_count, (const uint32_t*)d_out_sizes, (uint8_t*)d_dst);
     if (nzb)
@@ -722,7 +732,7 @@ __global__ __launch_bounds__(64) void k_zstd_split(const uint8_t* __restrict__ s
     const ZBlock blk = blocks[b];
     const uint8_t* p = src + blk.src_off;
     uint64_t content = 0;
-    bool dir = false;
+    uint32_t dir = 0; // the directory trailer's version, 0 = none
     if (!(dbg & 1u) && blk.size >= ZHDR + 3u + ZTRAILER && p[0] == 0x28 && p[1] == 0xB5 && p[2] == 0x2F && p[3] == 0xFD && p[4] == 0xE0)
     {
         for (int i = 0; i < 8; ++i)
@@ -804,7 +814,7 @@ __global__ __launch_bounds__(64) void k_zstd_split(const uint8_t* __restrict__ s
                 it.payload = b;
                 it.kind = kind;
                 it.aux = (uint32_t)(d - p) + 2u * i * ZB_MAX_UNITS;
-                it.pad = 0;
+                it.pad = dir == 3u ? 1u : 0u; // kind 3: the frame's blocks may use block-local repeat-offset codes
                 out[i] = it;
             }
             if ((uint64_t)pos + total > (uint64_t)blk.size)
@@ -1091,7 +1101,8 @@ struct ZsWin
 // three entries, ONE 64-bit view of the bits below the position (a second one only when offset + lengths + states exceed 64 bits),
 // the fields shifted off its top.  STRICT: offset values 1..3 (repeat offsets) are errors; otherwise they stay in the record for
 // whoever executes it in order.
-template <bool STRICT>
+// STRICT 0: offset values 1..3 stay in the record; 1: they are errors; 2: resolved with a block-local history (version-3 frames)
+template <int STRICT>
 __device__ __forceinline__ void zs_seq_lanes(bool act, const uint8_t* stream, uint32_t ssize, uint32_t below, uint32_t nbseq, uint32_t log_l,
                                              uint32_t log_o, uint32_t log_m, const uint64_t* pk_ll, const uint64_t* pk_of, const uint64_t* pk_ml,
                                              uint64_t* recs, bool& bad, uint32_t& sum_ll, uint32_t& sum_ml)
@@ -1165,7 +1176,12 @@ __device__ __forceinline__ void zs_seq_lanes(bool act, const uint8_t* stream, ui
                 }
                 pos -= n1 + n2;
                 uint32_t ovr = ov;
-                if constexpr (STRICT)
+                if constexpr (STRICT == 1)
+                {
+                    if (ov <= 3u)
+                        bad = true; // (a version-2 frame writes plain offsets only)
+                }
+                if constexpr (STRICT == 2)
                 {
                     // Repeat offsets, resolved here: this library's encoder only refers to history entries that the block's own
                     // sequences have set (zb_encode_piece_sub, ZB_F_REPCODES), so the lane starts with an unknown history (0) and a
@@ -1659,8 +1675,12 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
             const uint32_t at = off + 3u + lhdr + lcs + shdr + (lane == tab_lane ? desc_bytes : 0u);
             const uint32_t end = off + 3u + csz;
             const bool had = !bad && mine && nbseq != 0u;
-            zs_seq_lanes<true>(had, p + at, at < end ? end - at : 0u, (uint32_t)(it.src_off + at > 64u ? 64u : it.src_off + at), nbseq, log_l, log_o,
-                               log_m, pk_ll, pk_of, pk_ml, recs + rec0, bad, sum_ll, sum_ml);
+            if (it.pad) // (wave-uniform: the frame's trailer version)
+                zs_seq_lanes<2>(had, p + at, at < end ? end - at : 0u, (uint32_t)(it.src_off + at > 64u ? 64u : it.src_off + at), nbseq, log_l, log_o,
+                                log_m, pk_ll, pk_of, pk_ml, recs + rec0, bad, sum_ll, sum_ml);
+            else
+                zs_seq_lanes<1>(had, p + at, at < end ? end - at : 0u, (uint32_t)(it.src_off + at > 64u ? 64u : it.src_off + at), nbseq, log_l, log_o,
+                                log_m, pk_ll, pk_of, pk_ml, recs + rec0, bad, sum_ll, sum_ml);
             // the block must regenerate exactly its unit
             if (had && !bad && (sum_ll > nlit || nlit + sum_ml != ubytes))
                 bad = true;
@@ -2233,7 +2253,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_entropy(const uint8_t* __restri
             if (!bad && inline_seqs)
             {
                 uint32_t sum_ll = 0, sum_ml = 0;
-                zs_seq_lanes<false>(lane == 0, p + sat, sat < send ? send - sat : 0u, (uint32_t)(it.src_off + sat > 64u ? 64u : it.src_off + sat),
+                zs_seq_lanes<0>(lane == 0, p + sat, sat < send ? send - sat : 0u, (uint32_t)(it.src_off + sat > 64u ? 64u : it.src_off + sat),
                                     me.nbseq, log_l, log_o, log_m, pk_ll, pk_of, pk_ml, rec_scratch + rec_at, bad, sum_ll, sum_ml);
                 sum_ll = (uint32_t)__builtin_amdgcn_readfirstlane(sum_ll);
                 sum_ml = (uint32_t)__builtin_amdgcn_readfirstlane(sum_ml);
@@ -2317,7 +2337,7 @@ __global__ __launch_bounds__(64) void k_zstd_blk_sequences(const uint8_t* __rest
     bool bad = false;
     uint32_t sum_ll = 0, sum_ml = 0;
     const uint64_t at = it.src_off + pr.seq_off;
-    zs_seq_lanes<false>(act, src + at, pr.seq_size, (uint32_t)(at > 64u ? 64u : at), pr.nbseq, pr.log[1] & 255u, (pr.log[1] >> 8) & 255u,
+    zs_seq_lanes<0>(act, src + at, pr.seq_size, (uint32_t)(at > 64u ? 64u : at), pr.nbseq, pr.log[1] & 255u, (pr.log[1] >> 8) & 255u,
                         (pr.log[1] >> 16) & 255u, tp, tp + 1024, tp + 512, rec_scratch + pr.rec_at, bad, sum_ll, sum_ml);
     if (act)
     {

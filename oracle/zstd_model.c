@@ -29,7 +29,7 @@ static uint32_t g_ltz_dbg;
 #include "../longtail_amd/csrc/zstd_decode_core.h" /* includes zstd_block_core.h */
 void ltz_model_debug(uint32_t flags) { g_ltz_dbg = flags; }
 static int g_ltz_sub; /* 1: pieces are written as runs of sub-blocks (zb_encode_piece_sub) */
-static uint32_t g_ltz_flags = ZB_F_REPCODES; /* ZbInput.flags of the next encodes (the kernel's default) */
+static uint32_t g_ltz_flags = 0; /* ZbInput.flags of the next encodes (the kernel's default: plain offsets; ZB_F_REPCODES = LTHIP_ZSTD_REP=1) */
 void ltz_model_flags(uint32_t flags) { g_ltz_flags = flags; }
 static uint16_t g_ltz_last_sub[ZB_MAX_UNITS];
 void ltz_model_sub_blocks(int on) { g_ltz_sub = on; }

@@ -116,18 +116,29 @@ def test_lz4_gpu_decoder_on_reference_payloads(gpu, oracle):
     assert (int(sizes[0]) == 0xFFFFFFFF) == (n < 0)
 
 
-@pytest.fixture(params=[1, 0], ids=["subblocks", "pieces"])
+@pytest.fixture(params=[1, 2, 0], ids=["subblocks", "subblocks+repcodes", "pieces"])
 def zmode(request, oracle, monkeypatch):
-    """Both layouts of the encoder's frames: a run of sub-blocks per 128 KiB piece with a directory (the default) and one block
-    per piece (LTHIP_ZSTD_SUB=0); the host model follows."""
+    """The layouts of the encoder's frames: a run of sub-blocks per 128 KiB piece with a directory (the default), the same with
+    block-local repeat-offset codes (LTHIP_ZSTD_REP=1: version-3 trailer, the lane decoder carries a block-local history) and one
+    block per piece (LTHIP_ZSTD_SUB=0); the host model follows."""
     import ctypes as C
+
+    from longtail_amd.lib import load
 
     oracle.dll.ltz_model_sub_blocks.argtypes = [C.c_int]
     oracle.dll.ltz_model_sub_blocks.restype = None
-    monkeypatch.setenv("LTHIP_ZSTD_SUB", str(request.param))
-    oracle.dll.ltz_model_sub_blocks(request.param)
+    oracle.dll.ltz_model_flags.argtypes = [C.c_uint32]
+    oracle.dll.ltz_model_flags.restype = None
+    monkeypatch.setenv("LTHIP_ZSTD_SUB", "1" if request.param else "0")
+    monkeypatch.setenv("LTHIP_ZSTD_REP", "1" if request.param == 2 else "0")
+    load().dll.lthip_debug_reload_env()
+    oracle.dll.ltz_model_sub_blocks(1 if request.param else 0)
+    oracle.dll.ltz_model_flags(1 if request.param == 2 else 0)
     yield request.param
     oracle.dll.ltz_model_sub_blocks(0)
+    oracle.dll.ltz_model_flags(0)
+    monkeypatch.delenv("LTHIP_ZSTD_REP")
+    load().dll.lthip_debug_reload_env()
 
 
 def gpu_zstd(gpu, blocks):
@@ -158,7 +169,7 @@ def zstd_pieces(frame: np.ndarray):
             break
     tail = bytes(frame[pos:])
     magic = bytes([0x5D, 0x2A, 0x4D, 0x18])
-    if tail[:4] == magic and tail[8:12] == b"LTP\x02":
+    if tail[:4] == magic and tail[8:12] in (b"LTP\x02", b"LTP\x03"):
         # sub-block frames: skippable frame with the directory, one u16 per unit
         assert len(tail) == 12 + 2 * nunits and int.from_bytes(tail[4:8], "little") == 4 + 2 * nunits
         d = np.frombuffer(tail[12:], dtype="<u2")
@@ -793,3 +804,34 @@ def test_lane_parser_tickets_give_the_payloads_of_the_fixed_stride(gpu, oracle, 
         assert len(a) == len(b) == len(c) and (a == b).all() and (a == c).all()
         n, out = oracle.lz4_decompress(a, len(r))
         assert n == len(r) and (out[:n] == r).all()
+
+
+def test_zstd_repcode_frames_stay_on_the_lane_decoder(gpu, oracle, ref, monkeypatch):
+    """LTHIP_ZSTD_REP=1: the frames say so in their trailer (version 3), their blocks use repeat-offset codes only for history entries
+    the block itself has set, the reference decodes them, and this library's lane-per-block decoder resolves the codes itself --
+    none of the payloads is handed back to the serial decoder.  Smaller than the same frames with plain offsets."""
+    monkeypatch.setenv("LTHIP_ZSTD_SUB", "1")
+    blocks = [oracle.synth(1 << 20, 5, k) for k in (1, 11, 12, 13)]
+    rng = np.random.default_rng(12)
+    rec = rng.integers(0, 256, (64, 40)).astype(np.uint8)  # 40-byte records from a small dictionary, one field varying: offsets repeat
+    rows = rec[rng.integers(0, 64, 20000)].copy()
+    rows[:, 7] = rng.integers(0, 256, 20000)
+    blocks.append(rows.reshape(-1))
+    sizes = {}
+    for rep in ("0", "1"):
+        monkeypatch.setenv("LTHIP_ZSTD_REP", rep)
+        gpu.lib.dll.lthip_debug_reload_env()
+        frames = gpu_zstd(gpu, blocks)
+        for b, f in zip(blocks, frames):
+            nu = (len(b) + 4095) // 4096
+            assert bytes(f[-(12 + 2 * nu) :][8:12]) == (b"LTP\x03" if rep == "1" else b"LTP\x02")
+            err, out = ref.decompress(1, f, len(b))
+            assert err == 0 and len(out) == len(b) and (out == b).all()
+        got = gpu_zstd_decode(gpu, frames, [len(b) for b in blocks])
+        assert all(g is not None and (g == b).all() for g, b in zip(got, blocks))
+        stats = gpu.zstd_last_decode_stats()
+        assert stats[0] == len(blocks) and stats[2] == 0, stats  # nothing went back to the serial decoder
+        sizes[rep] = [len(f) for f in frames]
+    monkeypatch.delenv("LTHIP_ZSTD_REP")
+    gpu.lib.dll.lthip_debug_reload_env()
+    assert sizes["1"][-1] < sizes["0"][-1] and sum(sizes["1"]) <= sum(sizes["0"])

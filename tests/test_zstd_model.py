@@ -303,5 +303,5 @@ def test_block_local_repeat_offset_codes(model, layout, seed):
             assert err2 == 0 and len(got) == len(raw) and (got == raw).all()
             sizes[flags] = n
     finally:
-        d.ltz_model_flags(1)
+        d.ltz_model_flags(0)
     assert sizes[1] < sizes[0], sizes
