@@ -853,7 +853,9 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
     uint32_t p = s0, anchor = s0, nrec = 0, last_end = 0, nmiss = 0;
     const bool q_high = (dbg & LZ4_DBG_Q_HIGH) != 0u, q_max = (dbg & LZ4_DBG_Q_MAX) != 0u;
     const uint32_t dense = q_high ? 0xFFFFu : 4u >> ((dbg >> 29) & 3u); // "high": every byte position is probed
-    const uint32_t wait_for = (dbg >> 20) & 63u ? (dbg >> 20) & 63u : 8u;
+    // lanes that must hold a hit before the wave turns to the extension: 4 (round 4, VALU bound: 2 GiB mixed 4.25 ms at 8, 4.12 at 4,
+    // 4.16 / 4.37 / 4.76 at 16 / 32 / 48; tokens 5.97 / 5.93 / 6.03 / 6.80 / 7.78 -- waiting lanes are idle lanes)
+    const uint32_t wait_for = (dbg >> 20) & 63u ? (dbg >> 20) & 63u : 4u;
     uint32_t rsl[8], roff[8]; // records: start | length << 16, offset
     uint32_t cand2 = 0xFFFFFFFFu; // "high": the other verified candidate of the probe (0xFFFFFFFF: none)
 #pragma unroll
@@ -1208,8 +1210,14 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 prev = s + len;
                 if (lit <= 16u)
                 {
+                    // four bytes per store where four are left (the destination has any alignment: global memory takes unaligned
+                    // dwords), single bytes for the rest -- never a byte beyond the run: the next byte is another lane's
+                    typedef uint32_t u32_a1 __attribute__((aligned(1)));
                     uint8_t* o = out + lit_dst;
-                    for (uint32_t j = 0; j < lit; ++j)
+                    uint32_t j = 0;
+                    for (; j + 4u <= lit; j += 4u)
+                        *reinterpret_cast<u32_a1*>(o + j) = lds_read32x<PAD>(sdata, lit_src + j + head);
+                    for (; j < lit; ++j)
                         o[j] = (uint8_t)lds_byte<PAD>(sdata, lit_src + j + head);
                 }
             }
