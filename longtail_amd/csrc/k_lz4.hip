@@ -2241,11 +2241,23 @@ __global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restric
                         }
                         const uint32_t pq = wbase + 16u * v - head_src; // window position of the line's first byte
                         const uint32_t g4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                        // a dword that an EARLIER dword of the same line repeats cannot lower its slot (the table keeps the minimum):
+                        // data of a short period (runs, 8-byte patterns) would otherwise send every lane's four updates to one or two
+                        // slots, which the LDS serialises (21 % of the kernel on "lines")
+                        // ... and the same for the dword at the same place of the line before (the lane before holds it): zero pages
+                        // and other runs leave one update per wave
+                        const bool nb = lane != 0 && pq >= wbase + 16u;
+                        bool dup[4] = {false, g4[1] == g4[0], g4[2] == g4[0] || g4[2] == g4[1], g4[3] == g4[1] || g4[3] == g4[2] || g4[3] == g4[0]};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            dup[k] = dup[k] || (nb && (uint32_t)__builtin_amdgcn_update_dpp((int)~g4[k], (int)g4[k], 0x138 /* wave_shr:1 */, 0xf, 0xf, false) == g4[k]);
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                         {
                             const uint32_t pk = pq + 4u * (uint32_t)k;
-                            if (pk >= wbase && pk < wbase + hlen) // (line 0 may begin before the half: a wrapped value is above it)
+                            // (line 0 may begin before the half: a wrapped value is above it -- and then dword k may be the half's first
+                            // occurrence although an earlier dword of the line equals it: line 0 takes no shortcut)
+                            if (pk >= wbase && pk < wbase + hlen && (!dup[k] || v == 0u))
                                 (void)__hip_atomic_fetch_min(&shr[((g4[k] * 2654435761u) >> sh_shift) + sh_off], sh_base | pk, __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
