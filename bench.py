@@ -423,7 +423,11 @@ class Bench:
         vi_cap = int(self.lib.dll.lthip_version_index_size(tree["nfiles"], est_chunks, est_chunks, len(tree["path_data"]))) + 64
         h_vi = self.buf("vi", vi_cap, pinned=True) if rank == 0 else None
         h_si = self.buf("si", 16 + 32 * cap + 64, pinned=True)
-        ing = Ingest(ctx, args.target_chunk_size, args.block_size, args.max_chunks_per_block, cfg["codec"], batch_bytes=batch_bytes)
+        ctype = None
+        if cfg["codec"] == "zstd" and args.zstd_settings != 2:
+            ctype = 0x7A746430 + args.zstd_settings  # 'ztd3' / 'ztd4' (lib/zstd/longtail_zstd.c:11-28): the max / high parse
+        ing = Ingest(ctx, args.target_chunk_size, args.block_size, args.max_chunks_per_block, cfg["codec"], compression_type=ctype,
+                     batch_bytes=batch_bytes)
         stats = {}
 
         def step():
@@ -585,6 +589,7 @@ class Bench:
                  "mixed-sizes": f"{cfg['gib']:g} GiB tree of {cfg['kind']} files, 4 KiB..4 GiB log-uniform (north-star tree)"}[cfg["tree"]]
         per = "per GPU" if cfg["scaling"] == "weak" else "in total"
         which = ""
+        zset = f" 'ztd{args.zstd_settings}'" if cfg["codec"] == "zstd" and args.zstd_settings != 2 else ""
         if cfg["tree"] == "files" and cfg["kind"] == "random" and cfg["codec"] == "lz4" and abs(cfg["file_mib"] - 1.0) < 1e-9:
             which = " (BASELINE.json configs[2])" if world == 1 else " (BASELINE.json configs[3])"
         elif cfg["tree"] == "files" and cfg["codec"] == "zstd" and cfg["file_mib"] >= 16384:
@@ -592,7 +597,7 @@ class Bench:
         return {
             "value": tree_bytes * steps / elapsed / 1e9,
             "ms_per_step": elapsed / steps * 1e3,
-            "workload": f"{label} {per}, CreateVersionIndex + CreateMissingContent + WriteContent, chunk+BLAKE3+{cfg['codec'].upper()}{which}",
+            "workload": f"{label} {per}, CreateVersionIndex + CreateMissingContent + WriteContent, chunk+BLAKE3+{cfg['codec'].upper()}{zset}{which}",
             "tree_bytes": tree_bytes, "bytes_this_rank": my_bytes, "files": tree["nfiles"], "jobs": int(part.job_count),
             "jobs_this_rank": int(len(mine)), "min_avg_max": [mn, av, mx],
             "roofline": roofline, "kernels": kern,
@@ -624,6 +629,8 @@ def main():
     ap.add_argument("--max-chunks-per-block", type=int, default=1024)
     ap.add_argument("--batch-gib", "--lz4-batch-gib", dest="batch_gib", type=float, default=8.0)
     ap.add_argument("--codec", choices=["lz4", "zstd"], default="lz4", help="block codec (BASELINE.json configs[4] uses zstd)")
+    ap.add_argument("--zstd-settings", type=int, choices=[2, 3, 4], default=2,
+                    help="the reference's zstd settings id 'ztd2' (default) / 'ztd3' (max) / 'ztd4' (high): the parse the session runs")
     ap.add_argument("--no-compress", action="store_true", help="diagnostic: skip WriteContent (the line is then not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dedup", choices=["sharded", "replicated"], default="sharded",

@@ -261,15 +261,21 @@ LTHIP_EXPORT int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, u
 /* The same with the parse the reference's settings ids stand for (lib/zstd/longtail_zstd.c:11-28, 43-60: 'ztd1' -> level 0 = the
  * default 3, 'ztd2' -> 3, 'ztd4' -> 8, 'ztd3' -> 22, 'ztd5' -> its own type id, which zstd clamps to 22; any other id -> 0 = the
  * default, it is NOT rejected there and is not here):
- *   LTHIP_ZSTD_Q_DEFAULT  'ztd1', 'ztd2', unknown ids: the lane parser's greedy parse (what lthip_zstd_compress_blocks runs)
- *   LTHIP_ZSTD_Q_HIGH     'ztd4': every byte position is probed (no skipping to address-aligned positions after misses) and of the
- *                         two candidates of a probe the one with the longer match is taken
+ *   LTHIP_ZSTD_Q_DEFAULT  'ztd1', 'ztd2', unknown ids: the lane parser's greedy parse (what lthip_zstd_compress_blocks runs); a match
+ *                         of four bytes must start within 1 KiB, one of five within 4 KiB (the offset's bits are written out: a short
+ *                         match from far away costs more than the literals it replaces)
+ *   LTHIP_ZSTD_Q_HIGH     'ztd4': every redundant 32 KiB half of a 128 KiB piece but the piece's first is parsed with the 32 KiB in
+ *                         front of it as HISTORY (matches reach 32 .. 64 KiB back wherever the half lies; by default a half only sees
+ *                         what its 64 KiB group holds in front of it).  About half the match finder's throughput.
  *   LTHIP_ZSTD_Q_MAX      'ztd3', 'ztd5': Q_HIGH, and the wave's table is read again after the step's inserts (what the lanes beside
  *                         this one have just put there is a candidate at once)
- * Every quality writes the same frame format (sub-blocks with block-local repeat-offset codes). */
+ * Every quality writes the same frame format (sub-blocks; the pieces of a frame stay independent of each other), and each is smaller
+ * than the one before on the synthetic kinds (profiles/r04_zstd_ratio_table.txt).
+ * lthip_zstd_quality_of_settings: the quality a settings id ('ztd?' as a big-endian u32, the value blocks carry) stands for. */
 #define LTHIP_ZSTD_Q_DEFAULT 0
 #define LTHIP_ZSTD_Q_HIGH 1
 #define LTHIP_ZSTD_Q_MAX 2
+LTHIP_EXPORT int lthip_zstd_quality_of_settings(uint32_t settings_id);
 LTHIP_EXPORT int lthip_zstd_compress_blocks_q(lthip_ctx* ctx, const void* d_src, uint32_t block_count,
                                               const uint64_t* src_offsets, const uint32_t* src_sizes, void* d_dst,
                                               const uint64_t* dst_offsets, const uint32_t* dst_caps,

@@ -950,7 +950,8 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
             if (g->cfg.codec == LTHIP_CODEC_LZ4)
                 err = lthip_lz4_compress_blocks(ctx, src, k, src_off.data(), src_size.data(), d_arena, dst_off.data(), dst_cap.data(), d_sizes, 0);
             else if (g->cfg.codec == LTHIP_CODEC_ZSTD)
-                err = lthip_zstd_compress_blocks(ctx, src, k, src_off.data(), src_size.data(), d_arena, dst_off.data(), dst_cap.data(), d_sizes);
+                err = lthip_zstd_compress_blocks_q(ctx, src, k, src_off.data(), src_size.data(), d_arena, dst_off.data(), dst_cap.data(), d_sizes,
+                                                   lthip_zstd_quality_of_settings(g->cfg.compression_type)); // ('ztd4': high, 'ztd3' / 'ztd5': max)
             else
                 err = lthip_fail(ctx, EINVAL, "lthip_ingest_write", "codec 0 (store raw) is not implemented");
             if (err)

@@ -835,8 +835,13 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                                                 uint32_t sh_base, int lane, uint32_t my_start, uint32_t my_len, int32_t start_limit,
                                                 uint32_t end_limit, uint32_t sub, uint8_t* __restrict__ out, uint64_t* __restrict__ zrecs,
                                                 Lz4Seq& st, uint32_t dbg K5P_ARG, uint32_t lo_bound = 0u, uint32_t sh_shift = 32u - (uint32_t)SH,
-                                                uint32_t sh_off = 0u, uint32_t not_private = 0xFFFFFFFFu)
+                                                uint32_t sh_off = 0u, uint32_t not_private = 0xFFFFFFFFu, uint32_t far1 = 0xFFFFFFFFu,
+                                                uint32_t far2 = 0xFFFFFFFFu, uint32_t hist = 0u, uint32_t far3 = 4u)
 {
+    // hist != 0: the window below position `hist` is HISTORY (k_lz4_pair_halves): the shared table's lower half holds, per key, its LATEST
+    // position there (stored inverted, so that the table's minimum is the nearest one) -- a third candidate, asked last; a match into the
+    // history must have far3 bytes
+
     // not_private: a position the PRIVATE table never offers (an unlinked half's first position: in the window's lower half that is
     // position 0, which the table cannot tell from "empty", so the upper half must not have it either -- what a half compresses to must
     // not depend on which slot of the window it was given)
@@ -851,8 +856,10 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
     const uint32_t s0 = my_start + (uint32_t)sidx * sub;
     const uint32_t lend = s0 + sub < unit_end ? s0 + sub : unit_end;
     uint32_t p = s0, anchor = s0, nrec = 0, last_end = 0, nmiss = 0;
-    const bool q_high = (dbg & LZ4_DBG_Q_HIGH) != 0u, q_max = (dbg & LZ4_DBG_Q_MAX) != 0u;
-    const uint32_t dense = q_high ? 0xFFFFu : 4u >> ((dbg >> 29) & 3u); // "high": every byte position is probed
+    // LTHIP_LZ4_DBG bit 13, "deep": every byte position is probed and, where both tables' candidates verify, the longer match wins --
+    // round 4's first "high" setting; with the history halves it measures WORSE than without on every synthetic kind (and a third slower)
+    const bool q_high = (dbg & 8192u) != 0u, q_max = (dbg & LZ4_DBG_Q_MAX) != 0u;
+    const uint32_t dense = q_high ? 0xFFFFu : 4u >> ((dbg >> 29) & 3u);
     // lanes that must hold a hit before the wave turns to the extension: 4 (round 4, VALU bound: 2 GiB mixed 4.25 ms at 8, 4.12 at 4,
     // 4.16 / 4.37 / 4.76 at 16 / 32 / 48; tokens 5.97 / 5.93 / 6.03 / 6.80 / 7.78 -- waiting lanes are idle lanes)
     const uint32_t wait_for = (dbg >> 20) & 63u ? (dbg >> 20) & 63u : 4u;
@@ -906,10 +913,19 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 const uint32_t r1 = lds_read32x<PAD>(sdata, (v1 ? c : p) + head);
                 const uint32_t r2 = lds_read32x<PAD>(sdata, (v2 ? c2 : p) + head);
                 const bool h1 = v1 && r1 == v, h2 = v2 && r2 == v;
-                if (h1 || h2)
+                bool h3 = false;
+                uint32_t c3 = 0u;
+                if (hist)
+                {
+                    const uint32_t e3 = shr[prod >> sh_shift] - sh_base; // (another item's entry: above 0xFFFF)
+                    c3 = 0xFFFFu - e3;
+                    const bool v3 = e3 <= 0xFFFFu;
+                    h3 = v3 && lds_read32x<PAD>(sdata, (v3 ? c3 : p) + head) == v;
+                }
+                if (h1 || h2 || h3)
                 {
                     pend = true;
-                    cand = h1 ? c : c2; // the private table's (the nearer one) first
+                    cand = h1 ? c : (h2 ? c2 : c3); // the private table's (the nearest one) first, the history's last
                     cand2 = (q_high && h1 && h2 && c != c2) ? c2 : 0xFFFFFFFFu;
                 }
                 else
@@ -1069,7 +1085,16 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
             }
             longs &= ~__builtin_amdgcn_ballot_w64(cv);
         }
-        if (ok)
+        // the zstd flavour prices a match by its distance (the offset's bits are written out): four or five bytes from far away cost more
+        // than the literals they replace -- such a hit counts as a miss (T1, T2: LTHIP_LZ4_FAR, measured in profiles/r04_zstd_ratio_table.txt)
+        if (FMT == 1 && ok && mlen + nbk < (cand < hist ? far3 : 4u + (p - cand >= far1 ? 1u : 0u) + (p - cand >= far2 ? 1u : 0u)))
+        {
+            ok = false;
+            p += 1u;
+            ++nmiss;
+            stale = true;
+        }
+        else if (ok)
         {
             const uint32_t s = p - nbk, len = mlen + nbk;
             const uint32_t sl = s | (len << 16), of = p - cand;
@@ -2092,9 +2117,10 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
 // source alignment.  What a half compresses to does not depend on its partner.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t LZ4_HALF_NONE = 0xFFFFFFFFu;
+constexpr uint32_t LZ4_HALF_HIST = 0x40000000u; // on an item's first half: staged as HISTORY of the second, not parsed (k_lz4_pair_halves, hist)
 // worklist layout behind the classification pass (ngroups = groups of the batch): [0] listed groups, [1 .. ngroups] their ids,
 // [1 + ngroups ..) per-group half bits, [2 ngroups + 1] ticket, [2 ngroups + 2] items, [2 ngroups + 3] lone halves,
-// [2 ngroups + 4 ..) items of four words {half a, half b, block of a, block of b}, [6 ngroups + 4 ..) lone halves
+// [2 ngroups + 4 ..) items of four words {half a, half b, block of a, block of b} (up to two per group), [10 ngroups + 4 ..) lone halves
 __host__ __device__ constexpr uint32_t lz4_items_off(uint32_t ngroups) { return (2u * ngroups + 4u + 3u) & ~3u; } // (16-byte aligned: items are read as uint4)
 __device__ __forceinline__ uint32_t lz4_block_of_group(const Lz4Block* __restrict__ blocks, uint32_t nblocks, uint32_t grp)
 {
@@ -2109,17 +2135,43 @@ __device__ __forceinline__ uint32_t lz4_block_of_group(const Lz4Block* __restric
     }
     return lo;
 }
-__global__ void k_lz4_pair_halves(uint32_t* __restrict__ wl, uint32_t ngroups, uint32_t phase, const Lz4Block* __restrict__ blocks, uint32_t nblocks)
+// hist (the zstd flavour's "high" and "max" settings): every flagged half becomes an item of its own whose OTHER half is the 32 KiB in
+// front of it, staged as history and not parsed -- a half's matches then reach 32 .. 64 KiB back wherever the half lies in its group
+// (a lower half has no history otherwise, and an upper half only when the lower one is flagged too), at the price of eight idle waves
+// per item.  The first half of every 128 KiB PIECE takes no history: the frame's pieces stay independent (k_zstd.hip decodes them
+// with a wave each).
+__global__ void k_lz4_pair_halves(uint32_t* __restrict__ wl, uint32_t ngroups, uint32_t phase, const Lz4Block* __restrict__ blocks, uint32_t nblocks,
+                                  uint32_t hist)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t* items = wl + lz4_items_off(ngroups);
-    uint32_t* lone = items + 4u * ngroups;
+    uint32_t* lone = items + 8u * ngroups;
     if (phase == 0u)
     {
         if (i >= wl[0])
             return;
         const uint32_t g = wl[1u + i], bits = wl[1u + ngroups + g] & 3u;
-        if (bits == 3u)
+        if (hist)
+        {
+            const uint32_t b = lz4_block_of_group(blocks, nblocks, g);
+            const bool piece_first = ((g - blocks[b].grp_base) & 1u) == 0u; // (a piece = two groups)
+            for (uint32_t hh = 0; hh < 2u; ++hh)
+                if ((bits >> hh) & 1u)
+                {
+                    const uint32_t h = 2u * g + hh;
+                    if (hh == 0u && piece_first)
+                        lone[atomicAdd(&wl[2u * ngroups + 3u], 1u)] = h;
+                    else
+                    {
+                        const uint32_t k = atomicAdd(&wl[2u * ngroups + 2u], 1u);
+                        items[4u * k] = (h - 1u) | LZ4_HALF_HIST;
+                        items[4u * k + 1u] = h;
+                        items[4u * k + 2u] = b;
+                        items[4u * k + 3u] = b;
+                    }
+                }
+        }
+        else if (bits == 3u)
         {
             const uint32_t k = atomicAdd(&wl[2u * ngroups + 2u], 1u);
             const uint32_t b = lz4_block_of_group(blocks, nblocks, g); // (the ten dependent loads of the search happen here, once, in parallel)
@@ -2149,9 +2201,10 @@ template <int FMT>
 __global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks, uint32_t nblocks,
                                                        uint32_t sub_bytes, uint8_t* __restrict__ streams, Lz4Meta* __restrict__ meta,
                                                        uint64_t* __restrict__ zrecs, uint8_t* __restrict__ spec_dst, uint32_t dbg,
-                                                       uint32_t ngroups, uint32_t* __restrict__ worklist)
+                                                       uint32_t ngroups, uint32_t* __restrict__ worklist, uint32_t farlog)
 {
     constexpr int G = LZ4_G_LANES, TAB = LZ4_TAB_SHARED, SH = LZ4_SH_LOG2;
+    const uint32_t far1 = 1u << (farlog & 31u), far2 = 1u << ((farlog >> 8) & 31u), far3 = (farlog >> 16) & 255u; // (zstd flavour: lz4_lane_parse2; far3 = bytes a match into the history half must have)
     constexpr bool PAD = true;
     constexpr uint32_t GAP = 32u; // LDS bytes between the windows of two unlinked halves
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -2187,8 +2240,9 @@ __global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restric
         --sh_gen;
         const uint32_t sh_base = sh_gen << 16;
         const uint4 item = reinterpret_cast<const uint4*>(items)[idx];
-        const uint32_t ha = item.x, hb = item.y;
-        const bool linked = hb == ha + 1u && !(ha & 1u);
+        const bool hist = (item.x & LZ4_HALF_HIST) != 0u; // (a first half is never LZ4_HALF_NONE)
+        const uint32_t ha = item.x & ~LZ4_HALF_HIST, hb = item.y;
+        const bool linked = hist || (hb == ha + 1u && !(ha & 1u)); // one contiguous 64 KiB window
         const uint32_t hid = hsel ? hb : ha;
         const bool valid = hid != LZ4_HALF_NONE;
         const uint32_t grp = valid ? hid >> 1 : ha >> 1, hh = valid ? hid & 1u : 0u;
@@ -2202,8 +2256,10 @@ __global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restric
         const uint32_t extra = hsel && !linked ? GAP : 0u;              // its LDS displacement
         const uint32_t head = head_src + LZ4_LPAD + extra;              // LDS byte address of window position x: x + head
         const uint32_t lo_bound = hsel && !linked ? half_bytes : 0u;
-        const uint32_t sh_shift = linked ? 32u - (uint32_t)SH : 33u - (uint32_t)SH;
-        const uint32_t sh_off = linked ? 0u : hsel << (SH - 1);
+        const bool split = !linked || hist; // every half has its own half of the shared table
+        const uint32_t sh_shift = split ? 33u - (uint32_t)SH : 32u - (uint32_t)SH;
+        const uint32_t sh_off = split ? hsel << (SH - 1) : 0u;
+        const uint32_t sh_inv = hist && hsel == 0u ? 0xFFFFu : 0u; // a history half keeps its LATEST occurrences: positions stored inverted
 
         // ---- every half is staged by its own eight waves (16-byte loads from the aligned-down address); the aligned dwords enter the
         // half's part of the shared table from the registers that stage them ----
@@ -2257,8 +2313,8 @@ __global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restric
                             const uint32_t pk = pq + 4u * (uint32_t)k;
                             // (line 0 may begin before the half: a wrapped value is above it -- and then dword k may be the half's first
                             // occurrence although an earlier dword of the line equals it: line 0 takes no shortcut)
-                            if (pk >= wbase && pk < wbase + hlen && (!dup[k] || v == 0u))
-                                (void)__hip_atomic_fetch_min(&shr[((g4[k] * 2654435761u) >> sh_shift) + sh_off], sh_base | pk, __ATOMIC_RELAXED,
+                            if (pk >= wbase && pk < wbase + hlen && (!dup[k] || v == 0u || sh_inv != 0u)) // (a history half keeps the LATEST: no shortcut)
+                                (void)__hip_atomic_fetch_min(&shr[((g4[k] * 2654435761u) >> sh_shift) + sh_off], sh_base | (pk ^ sh_inv), __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
@@ -2279,7 +2335,7 @@ __global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restric
         K5P(1);
         // ---- my unit, positions relative to the window ----
         const uint32_t my_start = (uint32_t)wave * sub_bytes;
-        const bool have_unit = wih * sub_bytes < hlen;
+        const bool have_unit = wih * sub_bytes < hlen && !(hist && hsel == 0u); // (a history half is staged and seeded, not parsed)
         const uint32_t my_len = have_unit ? (hlen - wih * sub_bytes < sub_bytes ? hlen - wih * sub_bytes : sub_bytes) : 0u;
         const uint32_t unit = blk.seg_base + gi * (uint32_t)G + hh * (uint32_t)(G / 2) + wih;
         const int64_t blk_left = (int64_t)blk.size - (int64_t)half_start - (int64_t)(wih * sub_bytes); // unit start .. block end
@@ -2332,7 +2388,7 @@ __global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restric
         {
             K5P(2);
             lz4_lane_parse2<TAB, FMT, SH>(sdata, head, tab, shr, sh_base, lane, my_start, my_len, start_limit, end_limit, sub_bytes >> 6, out, recs, st,
-                                          dbg K5P_PASS, lo_bound, sh_shift, sh_off, linked ? 0xFFFFFFFFu : wbase);
+                                          dbg K5P_PASS, lo_bound, sh_shift, sh_off, linked ? 0xFFFFFFFFu : wbase, far1, far2, hist ? half_bytes : 0u, far3);
         }
         if constexpr (FMT == 1)
         {
@@ -2800,7 +2856,7 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
                       : launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, FMT, 1>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta, zrecs,
                                                                            spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr);
     void* wl;
-    int err = lthip_scratch(ctx, S_LZ4_CLASSIFY, 4 * (7 * (size_t)ngrp + 16), &wl);
+    int err = lthip_scratch(ctx, S_LZ4_CLASSIFY, 4 * (11 * (size_t)ngrp + 16), &wl);
     if (err)
         return err;
     LTHIP_CHECK(ctx, hipMemsetAsync(wl, 0, 4 * (2 * (size_t)ngrp + 4), ctx->stream));
@@ -2813,8 +2869,10 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
     {
         // the list of groups -> items of two half-groups (k_lz4_pair_halves), then the lane kernel over the items
         const uint32_t nthreads = 256, ng = (uint32_t)ngrp;
-        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng + nthreads - 1) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 0u, d_blocks, block_count);
-        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng / 2 + nthreads) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 1u, d_blocks, block_count);
+        // history halves: the zstd flavour at its "high" and "max" settings
+        const uint32_t hist = (FMT == 1 && (dbg & (LZ4_DBG_Q_HIGH | LZ4_DBG_Q_MAX))) ? 1u : 0u;
+        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng + nthreads - 1) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 0u, d_blocks, block_count, hist);
+        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng / 2 + nthreads) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 1u, d_blocks, block_count, hist);
         LTHIP_LAUNCH_CHECK(ctx);
         const size_t lds = (size_t)lz4_window_lds_bytes(LZ4_G_LANES * SEG + 64u + LZ4_LPAD + 32u, true) + 16 + (size_t)LZ4_G_LANES * LZ4_TAB_SHARED * 2 +
                            ((size_t)4 << LZ4_SH_LOG2);
@@ -2825,8 +2883,12 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
         }
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        // zstd flavour: a match must be one byte longer from 2^a bytes away and two from 2^b, and c bytes long when it reaches into a
+        // history half (LTHIP_LZ4_FAR = a + 256 b + 65536 c; default 10, 12, 8; a = b = 31 and c = 4: no rule)
+        static LthipEnvInt env_far{"LTHIP_LZ4_FAR"};
+        const uint32_t farlog = env_far.get() >= 0 ? (uint32_t)env_far.get() : (10u | (12u << 8) | (8u << 16));
         hipLaunchKernelGGL((k_lz4_lanes2<FMT>), dim3((uint32_t)ncu), dim3(64 * LZ4_G_LANES), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
-                           block_count, SEG, streams, meta, zrecs, spec_dst, dbg, ng, (uint32_t*)wl);
+                           block_count, SEG, streams, meta, zrecs, spec_dst, dbg, ng, (uint32_t*)wl, farlog);
         LTHIP_LAUNCH_CHECK(ctx);
         return 0;
     }
@@ -3033,8 +3095,8 @@ int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_
     {
         LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
         uint32_t dbg = (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0);
-        // the parse the zstd setting asks for (LTHIP_ZSTD_Q_*): bit 15 = "high" (dense probing, the longer of the two candidates),
-        // bit 31 = "max" (high + one lazy step); lz4_lane_parse2 reads them
+        // the parse the zstd setting asks for (LTHIP_ZSTD_Q_*): bit 15 = "high" (history halves: k_lz4_pair_halves), bit 31 = "max" (high +
+        // the private table read again after the step's inserts); launch_match_finder and lz4_lane_parse2 read them
         if (quality >= 1)
             dbg |= LZ4_DBG_Q_HIGH;
         if (quality >= 2)

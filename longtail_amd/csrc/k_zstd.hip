@@ -387,6 +387,16 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
                                const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets, const uint32_t* dst_caps,
                                uint32_t* d_out_sizes, int quality);
 
+extern "C" int lthip_zstd_quality_of_settings(uint32_t settings_id)
+{
+    // lib/zstd/longtail_zstd.c:11-28, 43-60: the id's last character picks the level ('1' -> 0 = default 3, '2' -> 3, '3' -> 22, '4' -> 8,
+    // '5' -> its own id, clamped to 22); anything else compresses at the default there, and does here
+    const uint32_t low = settings_id & 0xFFu;
+    if ((settings_id >> 8) != (((uint32_t)'z' << 16) | ((uint32_t)'t' << 8) | (uint32_t)'d'))
+        return LTHIP_ZSTD_Q_DEFAULT;
+    return low == '4' ? LTHIP_ZSTD_Q_HIGH : (low == '3' || low == '5') ? LTHIP_ZSTD_Q_MAX : LTHIP_ZSTD_Q_DEFAULT;
+}
+
 extern "C" int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                                           const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
                                           const uint32_t* dst_caps, uint32_t* d_out_sizes)

@@ -162,10 +162,7 @@ static int HipCodec_Compress(struct Longtail_CompressionAPI* compression_api, ui
      * of lthip_zstd_compress_blocks_q. */
     int quality = LTHIP_ZSTD_Q_DEFAULT;
     if (a->codec == CODEC_ZSTD)
-    {
-        const uint32_t low = settings_id & 0xffu;
-        quality = low == '4' ? LTHIP_ZSTD_Q_HIGH : (low == '3' || low == '5') ? LTHIP_ZSTD_Q_MAX : LTHIP_ZSTD_Q_DEFAULT;
-    }
+        quality = lthip_zstd_quality_of_settings(settings_id);
     return run_block(a->codec, 0, quality, uncompressed, compressed, uncompressed_size, max_compressed_size, out_compressed_size);
 }
 

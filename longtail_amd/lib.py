@@ -115,6 +115,7 @@ class HipLib:
         sig("lthip_zstd_bound", sz, [sz])
         sig("lthip_zstd_compress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_zstd_compress_blocks_q", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp, i32])
+        sig("lthip_zstd_quality_of_settings", i32, [u32])
         sig("lthip_zstd_decompress_blocks", i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp])
         sig("lthip_zstd_debug_units", i32, [vp, u64, u64, vp, vp, vp])
         sig("lthip_zstd_last_decode_stats", i32, [vp, vp])

@@ -356,3 +356,9 @@ int lthip_zstd_decompress_blocks(lthip_ctx* c, const void* s, uint32_t nb, const
     }
     return 0;
 }
+
+int lthip_zstd_quality_of_settings(uint32_t settings_id)
+{
+    const uint32_t low = settings_id & 0xFFu;
+    return low == '4' ? 1 : (low == '3' || low == '5') ? 2 : 0;
+}

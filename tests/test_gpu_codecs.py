@@ -141,12 +141,12 @@ def zmode(request, oracle, monkeypatch):
     load().dll.lthip_debug_reload_env()
 
 
-def gpu_zstd(gpu, blocks):
+def gpu_zstd(gpu, blocks, quality=0):
     dev, offs = to_device(blocks)
     caps = [len(b) + (len(b) >> 8) + 64 for b in blocks]
     d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
     dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
-    sizes = u32(gpu.zstd_compress_blocks(dev, offs, [len(b) for b in blocks], dst, d_offs, caps))
+    sizes = u32(gpu.zstd_compress_blocks(dev, offs, [len(b) for b in blocks], dst, d_offs, caps, quality=quality))
     host = dst.cpu().numpy()
     return [host[o : o + int(s)].copy() for o, s in zip(d_offs, sizes)]
 
@@ -835,3 +835,32 @@ def test_zstd_repcode_frames_stay_on_the_lane_decoder(gpu, oracle, ref, monkeypa
     monkeypatch.delenv("LTHIP_ZSTD_REP")
     gpu.lib.dll.lthip_debug_reload_env()
     assert sizes["1"][-1] < sizes["0"][-1] and sum(sizes["1"]) <= sum(sizes["0"])
+
+
+def test_zstd_settings_are_three_parses(gpu, oracle, ref, monkeypatch):
+    """LTHIP_ZSTD_Q_DEFAULT / _HIGH / _MAX ('ztd1'/'ztd2', 'ztd4', 'ztd3'/'ztd5' of lib/zstd/longtail_zstd.c:11-28): "high" gives every
+    redundant 32 KiB half of a piece the half in front of it as history (k_lz4_pair_halves), "max" also reads the private table again
+    after a step's inserts.  Both are smaller than the default on every synthetic kind with structure, all three decode with the
+    reference, and with this library's lane-per-block decoder WITHOUT a payload going back to the serial one: the history never
+    leaves the 128 KiB piece, so the pieces stay independent."""
+    monkeypatch.setenv("LTHIP_ZSTD_SUB", "1")
+    gpu.lib.dll.lthip_debug_reload_env()
+    blocks = [oracle.synth((2 << 20) + 4097 * k, 70 + k, k) for k in (1, 11, 12, 13)]
+    blocks.append(oracle.synth(300000, 5, 12))
+    blocks.append(oracle.synth(1 << 20, 6, 0))  # incompressible: the same at every setting
+    sizes = []
+    for q in (0, 1, 2):
+        frames = gpu_zstd(gpu, blocks, quality=q)
+        for b, f in zip(blocks, frames):
+            err, out = ref.decompress(1, f, len(b))
+            assert err == 0 and len(out) == len(b) and (out == b).all()
+        got = gpu_zstd_decode(gpu, frames, [len(b) for b in blocks])
+        assert all(g is not None and (g == b).all() for g, b in zip(got, blocks))
+        stats = gpu.zstd_last_decode_stats()
+        assert stats[0] == len(blocks) and stats[2] == 0, stats
+        sizes.append([len(f) for f in frames])
+    for i in range(5):
+        assert sizes[1][i] < sizes[0][i] and sizes[2][i] < sizes[0][i], (i, [s[i] for s in sizes])
+    assert sizes[0][5] == sizes[1][5] == sizes[2][5]
+    # "tokens": the vocabulary's first occurrences inside a half are what the history buys -- more than 8 %
+    assert sizes[1][2] < 0.92 * sizes[0][2]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Is the LZ4 / zstd payload of a block a function of the block alone?  Compresses the same blocks several times (alone, in another
 order of the call's block list, with tickets and with the fixed stride) and compares the payload bytes.
-python tools/k5_determinism.py [gib] [codec]"""
+python tools/k5_determinism.py [gib] [codec] [ragged|-] [zstd quality 0..2]"""
 import os
 import sys
 from pathlib import Path
@@ -30,7 +30,8 @@ if ragged:
 full = np.full(nb, BLOCK, np.int64)
 bound = full + full // 255 + 16 if codec == "lz4" else full + (full >> 8) + 64  # (of a whole block: the lists are permuted)
 d_offs = np.concatenate([[0], np.cumsum((bound + 63) // 64 * 64)[:-1]])
-fn = ctx.lz4_compress_blocks if codec == "lz4" else ctx.zstd_compress_blocks
+quality = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+fn = ctx.lz4_compress_blocks if codec == "lz4" else (lambda *a: ctx.zstd_compress_blocks(*a, quality=quality))
 
 
 def run(order, dbg):
@@ -51,4 +52,4 @@ for name, order, dbg in [("again", ident, 0), ("reversed block list", ident[::-1
                          ("fixed stride, reversed", ident[::-1], 1 << 27), ("first half only", ident[: nb // 2], 0)]:
     other = run(order, dbg)
     diff = [b for b in other if other[b] != base[b]]
-    print(f"{codec}{' ragged' if ragged else ''} {name}: {len(diff)} of {len(other)} payloads differ" + (f" (first: block {diff[0]}, {len(base[diff[0]])} vs {len(other[diff[0]])} bytes)" if diff else ""))
+    print(f"{codec}{' q' + str(quality) if quality else ''}{' ragged' if ragged else ''} {name}: {len(diff)} of {len(other)} payloads differ" + (f" (first: block {diff[0]}, {len(base[diff[0]])} vs {len(other[diff[0]])} bytes)" if diff else ""))
