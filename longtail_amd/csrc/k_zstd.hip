@@ -81,7 +81,7 @@ struct ZBlock
 
 constexpr uint32_t ZB = ZB_BLOCK_MAX;
 static_assert(ZB_BLOCK_MAX == (128u << 10) && ZB_UNIT == 4096u, "k_lz4.hip's Z_PIECE and unit size");
-constexpr size_t Z_WORK_SEQS = sizeof(uint64_t) * ZB_SEQ_MAX, Z_WORK_SBITS = sizeof(uint16_t) * 3 * ZB_SEQ_MAX;
+constexpr size_t Z_WORK_SEQS = sizeof(uint64_t) * ZB_SEQ_MAX, Z_WORK_SBITS = sizeof(uint16_t) * 4 * ZB_SEQ_MAX;
 constexpr size_t Z_WORK_STRIDE = Z_WORK_SEQS + Z_WORK_SBITS;
 constexpr uint32_t ZHDR = 13u;
 constexpr int ZT = 256;

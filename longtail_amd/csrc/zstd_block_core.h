@@ -86,7 +86,8 @@ typedef struct ZbInput
 typedef struct ZbScratch /* global memory owned by the lanes of one block encoder */
 {
     uint64_t* seqs;  /* [ZB_SEQ_MAX]        merged sequences */
-    uint16_t* sbits; /* [3 * ZB_SEQ_MAX]    FSE state-transition bits per sequence: nbBits << 10 | bits */
+    uint16_t* sbits; /* [4 * ZB_SEQ_MAX]    FSE state-transition bits per sequence: nbBits << 10 | bits -- three planes (zb_encode_block),
+                      * or one 64-bit word per sequence: LL | OF << 16 | ML << 32 (zb_encode_piece_sub) */
     uint32_t* out;   /* [ZB_OUT_BYTES / 4]  the encoded block */
 } ZbScratch;
 
@@ -1451,10 +1452,123 @@ ZB_FN uint32_t zb_unit_byte(const ZbInput* in, uint32_t srcmask, uint32_t u, uin
     return (*cw >> (8u * (idx & 3u))) & 255u;
 }
 
+/* ---- the sub-block encoder's merged sequence list: a sequence's three CODES and its extra bits, computed once (phase 1) ----
+ * bits 0-5 LL code, 6-11 ML code, 12-16 OF code, 17-29 LL extra bits' value (a unit's literal run: <= 12 bits), 30-45 ML extra bits'
+ * value, 46-61 OF extra bits' value (offset value < 2^17: <= 16 bits) */
+#define ZP_LC(q) ((uint32_t)(q) & 63u)
+#define ZP_MC(q) ((uint32_t)((q) >> 6) & 63u)
+#define ZP_OC(q) ((uint32_t)((q) >> 12) & 31u)
+#define ZP_LLX(q) ((uint32_t)((q) >> 17) & 0x1FFFu)
+#define ZP_MLX(q) ((uint32_t)((q) >> 30) & 0xFFFFu)
+#define ZP_OFX(q) ((uint32_t)((q) >> 46) & 0xFFFFu)
+ZB_FN uint64_t zb_pack_seq(uint32_t lit, uint32_t ml, uint32_t ofv, uint32_t* lc_out, uint32_t* mc_out, uint32_t* oc_out, uint32_t* xbits)
+{
+    const uint32_t lc = zb_ll_code(lit), mc = zb_ml_code(ml - 3u), oc = zb_highbit(ofv);
+    *lc_out = lc;
+    *mc_out = mc;
+    *oc_out = oc;
+    *xbits = zb_ll_bits(lc) + zb_ml_bits(mc) + oc;
+    return (uint64_t)lc | ((uint64_t)mc << 6) | ((uint64_t)oc << 12) | ((uint64_t)(lit - zb_ll_base(lc)) << 17) |
+           ((uint64_t)(ml - 3u - zb_ml_base(mc)) << 30) | ((uint64_t)(ofv - (1u << oc)) << 46);
+}
+/* The same from tables in shared memory (zb_encode_piece_sub builds them in phase 0; the compare chains of zb_ll_code / zb_ml_code and
+ * their bit counts and baselines are ~110 instructions a sequence): lcode[64] / mcode[128] the codes of small values, lbits / mbits
+ * and lbase / mbase per code. */
+typedef struct ZbCodeTabs
+{
+    uint32_t lbase[36], mbase[53];
+    uint8_t lcode[64], mcode[128], lbits[36], mbits[53];
+} ZbCodeTabs; /* 637 bytes, over huf_w until the Huffman code is built */
+ZB_FN uint64_t zb_pack_seq_t(const ZbCodeTabs* ct, uint32_t lit, uint32_t ml, uint32_t ofv, uint32_t* lc_out, uint32_t* mc_out, uint32_t* oc_out,
+                             uint32_t* xbits)
+{
+    const uint32_t m = ml - 3u;
+    const uint32_t lc = lit < 64u ? ct->lcode[lit] : zb_highbit(lit) + 19u, mc = m < 128u ? ct->mcode[m] : zb_highbit(m) + 36u, oc = zb_highbit(ofv);
+    *lc_out = lc;
+    *mc_out = mc;
+    *oc_out = oc;
+    *xbits = (uint32_t)ct->lbits[lc] + (uint32_t)ct->mbits[mc] + oc;
+    return (uint64_t)lc | ((uint64_t)mc << 6) | ((uint64_t)oc << 12) | ((uint64_t)(lit - ct->lbase[lc]) << 17) | ((uint64_t)(m - ct->mbase[mc]) << 30) |
+           ((uint64_t)(ofv - (1u << oc)) << 46);
+}
+/* One encoding step from the per-symbol entry nb_hi << 22 | (count << nb_hi) << 11 | (sym_start - count + 512) (built once per table,
+ * zb_encode_piece_sub phase 2): the same step as zb_fse_step without the symbol's count, its logarithm and sym_start being looked up
+ * and derived again for every sequence. */
+ZB_FN uint32_t zb_fse_step_tt(uint32_t* x, uint32_t e, const uint16_t* state_tab, uint32_t tl)
+{
+    const uint32_t nb = (e >> 22) - (*x < ((e >> 11) & 0x7FFu) ? 1u : 0u);
+    const uint32_t bits = *x & ((1u << nb) - 1u);
+    *x = (1u << tl) + state_tab[(*x >> nb) + (e & 0x7FFu) - 512u];
+    return (nb << 10) | bits;
+}
+
+/* n bytes from src (any alignment) to dst (any alignment; the words at its two ends are shared with neighbours: bytes there), the
+ * words in between four bytes at a time -- all lanes */
+typedef uint32_t zb_u32_a1 __attribute__((aligned(1)));
+ZB_FN void zb_copy_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t zl)
+{
+    const uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u);
+    const uint32_t h = head < n ? head : n, nw = (n - h) >> 2, t0 = h + 4u * nw;
+    ZB_PAR_FOR(j, h) dst[j] = src[j];
+    ZB_PAR_FOR(w, nw) *(uint32_t*)(dst + h + 4u * w) = *(const zb_u32_a1*)(src + h + 4u * w);
+    ZB_PAR_FOR(j, n - t0) dst[t0 + j] = src[t0 + j];
+}
+
+/* ---- staged bit output (zb_encode_piece_sub, phases 6 and 7) ----
+ * The lanes of a step write one contiguous run of bits.  OR-ing every lane's two or three words into the output in global memory is
+ * an atomic per word and lane (8 x 10^8 of them per 2 GiB of "tokens": as long as everything else the kernel does); here the lanes
+ * OR into a tile in shared memory (`stg`, >= 152 words), and the run's whole words leave with plain stores, one lane a word.  The
+ * word a run ends in stays in stg[0] for the next step; a stream's first word (it may hold the bytes in front of the stream) and
+ * its last one (the bytes behind it) go out with an atomic OR.
+ *   zb_stage_open: before a stream's first step.  zb_stage_begin / zb_stage_end around every step (`total` bits from bit position
+ *   `running` of `out`); the lanes write at tile bit (running & 31) + their offset in between.  zb_stage_close: after the last step. */
+ZB_FN void zb_stage_open(uint32_t* stg, uint32_t zl)
+{
+    ZB_SERIAL(zl) { stg[0] = 0; }
+}
+ZB_FN void zb_stage_begin(uint32_t* stg, uint32_t running, uint32_t total, uint32_t zl)
+{
+    const uint32_t nw = (((running & 31u) + total) >> 5) + 1u; /* (the word the run ends in, even when it ends on its boundary) */
+    ZB_PAR_FOR(w, nw)
+    {
+        if (w)
+            stg[w] = 0;
+    }
+    ZB_SYNC_LDS();
+}
+ZB_FN void zb_stage_end(uint32_t* stg, uint32_t* out, uint32_t running, uint32_t total, uint32_t first_bit, uint32_t zl)
+{
+    const uint32_t nfull = ((running & 31u) + total) >> 5, w0 = running >> 5;
+    uint32_t tail;
+    ZB_SYNC_LDS();
+    tail = stg[nfull];
+    ZB_PAR_FOR(w, nfull)
+    {
+        if (w0 + w == (first_bit >> 5) && (first_bit & 31u))
+            zb_atomic_or(out + w0 + w, stg[w]);
+        else
+            out[w0 + w] = stg[w];
+    }
+    ZB_SYNC_LDS();
+    ZB_SERIAL(zl) { stg[0] = tail; }
+    ZB_SYNC_LDS();
+}
+ZB_FN void zb_stage_close(uint32_t* stg, uint32_t* out, uint32_t running, uint32_t zl)
+{
+    ZB_SERIAL(zl)
+    {
+        if (stg[0])
+            zb_atomic_or(out + (running >> 5), stg[0]);
+    }
+    ZB_SYNC_LDS();
+}
+
 ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbShared* sh, uint32_t zl, uint16_t* sub)
 {
     uint8_t* const out8 = (uint8_t*)sc->out;
     ZbSub* const sb = (ZbSub*)sh->lit_hist;
+    ZbCodeTabs* const ct = (ZbCodeTabs*)sh->huf_w; /* phase 1's code tables (the Huffman build takes the memory afterwards) */
+    uint32_t* const stg = sh->sort_key; /* the staged bit output's tile (free once the FSE tables are built) */
     uint32_t* const strbits = sh->huf_w + 128; /* [ZB_MAX_UNITS][4] bits of every literal stream (past the FSE builders' spread area) */
     const uint32_t nunits = in->nunits;
 
@@ -1464,6 +1578,7 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
         const ZbUnitMeta m = in->meta[u];
         sh->useq_base[u] = m.nseq;
         sh->ulit_base[u] = m.nlit;
+        sh->carry[u] = 0; /* the unit's extra bits (phase 1 adds them up) */
     }
     ZB_SYNC();
     ZB_SERIAL(zl)
@@ -1487,6 +1602,22 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
     }
     ZB_PAR_FOR(i, 256u) sh->lit_hist[i] = 0;
     ZB_PAR_FOR(i, 3u * 64u) sh->sym_hist[i >> 6][i & 63u] = 0;
+    ZB_PAR_FOR(i, 128u)
+    {
+        ct->mcode[i] = (uint8_t)zb_ml_code(i);
+        if (i < 64u)
+            ct->lcode[i] = (uint8_t)zb_ll_code(i);
+        if (i < 36u)
+        {
+            ct->lbits[i] = (uint8_t)zb_ll_bits(i);
+            ct->lbase[i] = zb_ll_base(i);
+        }
+        if (i < 53u)
+        {
+            ct->mbits[i] = (uint8_t)zb_ml_bits(i);
+            ct->mbase[i] = zb_ml_base(i);
+        }
+    }
     ZB_SYNC();
     const uint32_t nbseq = sh->v[ZV_NBSEQ], nlit = sh->v[ZV_NLIT], srcmask = sh->v[ZV_SRCMASK];
 
@@ -1509,10 +1640,12 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
             {
                 const uint64_t r = in->unit_recs[(uint64_t)lo * ZB_UNIT_SEQ_MAX + (i - sh->useq_base[lo])];
                 const uint32_t lit = (uint32_t)(r & 0xFFFFu), ml = (uint32_t)((r >> 16) & 0xFFFFu), off = (uint32_t)(r >> 32);
-                sc->seqs[i] = (uint64_t)lit | ((uint64_t)ml << 20) | ((uint64_t)off << 36);
-                zb_atomic_add(&sh->sym_hist[ZT_LL][zb_ll_code(lit)], 1u);
-                zb_atomic_add(&sh->sym_hist[ZT_ML][zb_ml_code(ml - 3u)], 1u);
-                zb_atomic_add(&sh->sym_hist[ZT_OF][zb_of_code(off)], 1u);
+                uint32_t lc, mc, oc, xb;
+                sc->seqs[i] = zb_pack_seq_t(ct, lit, ml, off + 3u, &lc, &mc, &oc, &xb);
+                zb_atomic_add(&sh->sym_hist[ZT_LL][lc], 1u);
+                zb_atomic_add(&sh->sym_hist[ZT_ML][mc], 1u);
+                zb_atomic_add(&sh->sym_hist[ZT_OF][oc], 1u);
+                zb_atomic_add(&sh->carry[lo], xb);
             }
         }
     }
@@ -1563,10 +1696,14 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
                             r2 = r1;
                             r1 = v;
                         }
-                        sc->seqs[i0 + j] = (uint64_t)lit | ((uint64_t)ml << 20) | ((uint64_t)(code ? (ZB_OFF_REP | code) : off) << 36);
-                        zb_atomic_add(&sh->sym_hist[ZT_LL][zb_ll_code(lit)], 1u);
-                        zb_atomic_add(&sh->sym_hist[ZT_ML][zb_ml_code(ml - 3u)], 1u);
-                        zb_atomic_add(&sh->sym_hist[ZT_OF][zb_highbit(code ? code : off + 3u)], 1u);
+                        {
+                            uint32_t lc, mc, oc, xb;
+                            sc->seqs[i0 + j] = zb_pack_seq_t(ct, lit, ml, code ? code : off + 3u, &lc, &mc, &oc, &xb);
+                            zb_atomic_add(&sh->sym_hist[ZT_LL][lc], 1u);
+                            zb_atomic_add(&sh->sym_hist[ZT_ML][mc], 1u);
+                            zb_atomic_add(&sh->sym_hist[ZT_OF][oc], 1u);
+                            zb_atomic_add(&sh->carry[u], xb);
+                        }
                     }
             }
         }
@@ -1716,6 +1853,25 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
     }
     /* the literal histogram is dead: its memory holds the per-unit values from here on */
     ZB_SYNC();
+    /* ... and so are the code histograms: per symbol, what an encoding step needs of it (zb_fse_step_tt); the work arrays of the
+     * table builds become the extra-bit counts of the LL and ML codes */
+    ZB_PAR_FOR(i, 3u * 64u)
+    {
+        const uint32_t t = i >> 6, s2 = i & 63u;
+        const int16_t nv = sh->norm[t][s2];
+        uint32_t e = 0;
+        if (sh->mode[t] != 1u && nv != 0)
+        {
+            const uint32_t c = (uint32_t)(nv < 0 ? 1 : nv), nbh = (uint32_t)sh->table_log[t] - zb_highbit(c);
+            e = (nbh << 22) | ((c << nbh) << 11) | ((uint32_t)sh->sym_start[t][s2] + 512u - c);
+        }
+        sh->sym_hist[t][s2] = e;
+    }
+    ZB_PAR_FOR(i, 64u)
+    {
+        ((uint8_t*)sh->cursor[0])[i] = (uint8_t)(i < 36u ? zb_ll_bits(i) : 0u);
+        ((uint8_t*)sh->cursor[1])[i] = (uint8_t)(i < 53u ? zb_ml_bits(i) : 0u);
+    }
     ZB_PAR_FOR(u, ZB_MAX_UNITS)
     {
         sb->seqbits[u] = 0;
@@ -1764,19 +1920,21 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
         {
             const uint32_t tl_l = sh->table_log[ZT_LL], tl_o = sh->table_log[ZT_OF], tl_m = sh->table_log[ZT_ML];
             const uint32_t c_l = sh->mode[ZT_LL] != 1u, c_o = sh->mode[ZT_OF] != 1u, c_m = sh->mode[ZT_ML] != 1u;
-            uint32_t x_l = 0, x_o = 0, x_m = 0, bits = 0, n = e0;
+            uint32_t x_l = 0, x_o = 0, x_m = 0, bits = sh->carry[u], n = e0; /* (the extra bits were added up in phase 1) */
             while (n > b0)
             {
-                uint64_t q[8];
+                uint64_t q[8], tr[8]; /* the steps' transition bits: stored eight at a time, one 64-byte run per lane (three 2-byte
+                                       * stores per step and lane were 96 partial cache lines per wave and step: half of "tokens"' time) */
                 const uint32_t cnt = n - b0 < 8u ? n - b0 : 8u;
                 for (uint32_t j = 0; j < 8u; ++j)
                     q[j] = j < cnt ? sc->seqs[n - 1u - j] : 0u;
                 for (uint32_t j = 0; j < 8u; ++j)
+                {
+                    tr[j] = 0;
                     if (j < cnt)
                     {
                         const uint32_t i = n - 1u - j;
-                        const uint32_t lc = zb_ll_code(ZB_SEQ_LIT(q[j])), mc = zb_ml_code(ZB_SEQ_ML(q[j]) - 3u), oc = zb_highbit(ZB_SEQ_OFV(q[j]));
-                        bits += zb_ll_bits(lc) + zb_ml_bits(mc) + oc;
+                        const uint32_t lc = ZP_LC(q[j]), mc = ZP_MC(q[j]), oc = ZP_OC(q[j]);
                         if (i == e0 - 1u) /* the block's last sequence: the states the decoder starts from */
                         {
                             x_l = (1u << tl_l) + (c_l ? sh->state_tab[ZT_LL][sh->sym_start[ZT_LL][lc]] : 0u);
@@ -1785,26 +1943,23 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
                         }
                         else
                         {
+                            /* the three entries first: they depend on the codes alone, the steps on the states */
+                            const uint32_t e_l = sh->sym_hist[ZT_LL][lc], e_o = sh->sym_hist[ZT_OF][oc], e_m = sh->sym_hist[ZT_ML][mc];
+                            uint32_t r_l = 0, r_o = 0, r_m = 0;
                             if (c_l)
-                            {
-                                const uint32_t r = zb_fse_step(&x_l, lc, sh->norm[ZT_LL], sh->state_tab[ZT_LL], sh->sym_start[ZT_LL], tl_l);
-                                sc->sbits[(uint64_t)ZT_LL * ZB_SEQ_MAX + i] = (uint16_t)r;
-                                bits += r >> 10;
-                            }
+                                r_l = zb_fse_step_tt(&x_l, e_l, sh->state_tab[ZT_LL], tl_l);
                             if (c_o)
-                            {
-                                const uint32_t r = zb_fse_step(&x_o, oc, sh->norm[ZT_OF], sh->state_tab[ZT_OF], sh->sym_start[ZT_OF], tl_o);
-                                sc->sbits[(uint64_t)ZT_OF * ZB_SEQ_MAX + i] = (uint16_t)r;
-                                bits += r >> 10;
-                            }
+                                r_o = zb_fse_step_tt(&x_o, e_o, sh->state_tab[ZT_OF], tl_o);
                             if (c_m)
-                            {
-                                const uint32_t r = zb_fse_step(&x_m, mc, sh->norm[ZT_ML], sh->state_tab[ZT_ML], sh->sym_start[ZT_ML], tl_m);
-                                sc->sbits[(uint64_t)ZT_ML * ZB_SEQ_MAX + i] = (uint16_t)r;
-                                bits += r >> 10;
-                            }
+                                r_m = zb_fse_step_tt(&x_m, e_m, sh->state_tab[ZT_ML], tl_m);
+                            bits += (r_l >> 10) + (r_o >> 10) + (r_m >> 10);
+                            tr[j] = (uint64_t)r_l | ((uint64_t)r_o << 16) | ((uint64_t)r_m << 32);
                         }
                     }
+                }
+                for (uint32_t j = 0; j < 8u; ++j)
+                    if (j < cnt)
+                        ((uint64_t*)sc->sbits)[n - 1u - j] = tr[j];
                 n -= cnt;
             }
             sb->fstate[u][ZT_LL] = (uint16_t)(c_l ? x_l - (1u << tl_l) : 0u);
@@ -1981,7 +2136,9 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
             for (uint32_t st = 0; st < nstr; ++st)
             {
                 const uint32_t s0 = st * seg, s1 = st + 1u == nstr ? n : s0 + seg;
-                uint32_t running = base * 8u, cw = 0, cwi = 0xFFFFFFFFu;
+                const uint32_t first_bit = base * 8u;
+                uint32_t running = first_bit, cw = 0, cwi = 0xFFFFFFFFu;
+                zb_stage_open(stg, zl);
                 for (uint32_t done = 0; done < s1 - s0; done += 4u * ZB_LANES)
                 {
                     uint64_t acc = 0;
@@ -1999,19 +2156,22 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
                     {
                         uint32_t total;
                         const uint32_t off = zb_scan_excl(nb, &total);
+                        zb_stage_begin(stg, running, total, zl);
                         if (nb)
                         {
-                            const uint32_t bp = running + off;
+                            const uint32_t bp = (running & 31u) + off;
                             const uint64_t v = acc << (bp & 31u); /* nb <= 44, shift <= 31: fits 75 bits -> three words */
-                            zb_atomic_or(sc->out + (bp >> 5), (uint32_t)v);
+                            zb_atomic_or(stg + (bp >> 5), (uint32_t)v);
                             if ((bp & 31u) + nb > 32u)
-                                zb_atomic_or(sc->out + (bp >> 5) + 1u, (uint32_t)(v >> 32));
+                                zb_atomic_or(stg + (bp >> 5) + 1u, (uint32_t)(v >> 32));
                             if ((bp & 31u) + nb > 64u)
-                                zb_atomic_or(sc->out + (bp >> 5) + 2u, (uint32_t)(acc >> (64u - (bp & 31u))));
+                                zb_atomic_or(stg + (bp >> 5) + 2u, (uint32_t)(acc >> (64u - (bp & 31u))));
                         }
+                        zb_stage_end(stg, sc->out, running, total, first_bit, zl);
                         running += total;
                     }
                 }
+                zb_stage_close(stg, sc->out, running, zl);
                 ZB_SERIAL(zl) { zb_atomic_or(sc->out + (running >> 5), 1u << (running & 31u)); } /* end mark */
                 base += (strbits[4u * u + st] + 1u + 7u) >> 3;
             }
@@ -2021,8 +2181,7 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
             /* raw literals, or the whole unit raw: bytes (the destination shares words with its neighbours: byte stores) */
             const uint8_t* src = ((srcmask >> u) & 1u) || lmode == 4u ? in->src + (size_t)u * ZB_UNIT : in->unit_lits + (uint64_t)u * ZB_UNIT;
             const uint32_t cnt = lmode == 4u ? (uint32_t)(sub[u] & 0x7FFFu) : n;
-            uint8_t* d2 = out8 + sb->litpos[u];
-            ZB_PAR_FOR(j, cnt) d2[j] = src[j];
+            zb_copy_bytes(out8 + sb->litpos[u], src, cnt, zl);
         }
     }
 
@@ -2033,52 +2192,53 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
         const uint32_t b0 = sh->useq_base[u], ns = sh->useq_base[u + 1u] - b0;
         if (ns && sb->lmode[u] != 4u)
         {
-            uint32_t running = sb->seqpos[u] * 8u;
+            const uint32_t first_bit = sb->seqpos[u] * 8u;
+            uint32_t running = first_bit;
+            zb_stage_open(stg, zl);
             for (uint32_t done = 0; done < ns; done += ZB_LANES)
             {
                 const uint32_t r = done + zl;
-                uint32_t bits = 0, lit = 0, ml = 0, ofv = 4, lc = 0, mc = 0, oc = 2, lb = 0, mb = 0, so = 0, sm = 0, sl = 0;
+                uint32_t bits = 0, llx = 0, mlx = 0, ofx = 0, oc = 0, lb = 0, mb = 0, so = 0, sm = 0, sl = 0;
                 if (r < ns)
                 {
                     const uint32_t n = b0 + ns - 1u - r;
                     const uint64_t q = sc->seqs[n];
-                    lit = ZB_SEQ_LIT(q);
-                    ml = ZB_SEQ_ML(q) - 3u;
-                    ofv = ZB_SEQ_OFV(q);
-                    lc = zb_ll_code(lit);
-                    mc = zb_ml_code(ml);
-                    oc = zb_highbit(ofv);
-                    lb = zb_ll_bits(lc);
-                    mb = zb_ml_bits(mc);
+                    llx = ZP_LLX(q);
+                    mlx = ZP_MLX(q);
+                    ofx = ZP_OFX(q);
+                    oc = ZP_OC(q);
+                    lb = ((const uint8_t*)sh->cursor[0])[ZP_LC(q)];
+                    mb = ((const uint8_t*)sh->cursor[1])[ZP_MC(q)];
                     if (r) /* every sequence but the block's last one updates the states: OF, ML, LL (read back as LL, ML, OF) */
                     {
-                        if (sh->mode[ZT_OF] != 1u)
-                            so = sc->sbits[(uint64_t)ZT_OF * ZB_SEQ_MAX + n];
-                        if (sh->mode[ZT_ML] != 1u)
-                            sm = sc->sbits[(uint64_t)ZT_ML * ZB_SEQ_MAX + n];
-                        if (sh->mode[ZT_LL] != 1u)
-                            sl = sc->sbits[(uint64_t)ZT_LL * ZB_SEQ_MAX + n];
+                        const uint64_t tr = ((const uint64_t*)sc->sbits)[n]; /* (zero for a table in RLE mode) */
+                        sl = (uint32_t)tr & 0xFFFFu;
+                        so = (uint32_t)(tr >> 16) & 0xFFFFu;
+                        sm = (uint32_t)(tr >> 32) & 0xFFFFu;
                     }
                     bits = (so >> 10) + (sm >> 10) + (sl >> 10) + lb + mb + oc;
                 }
                 {
                     uint32_t total;
                     const uint32_t off = zb_scan_excl(bits, &total);
+                    zb_stage_begin(stg, running, total, zl);
                     if (bits)
                     {
                         ZbBits bw;
-                        zb_bits_open(&bw, sc->out, running + off);
-                        zb_bits_put(&bw, so & 1023u, so >> 10);
-                        zb_bits_put(&bw, sm & 1023u, sm >> 10);
-                        zb_bits_put(&bw, sl & 1023u, sl >> 10);
-                        zb_bits_put(&bw, lit - zb_ll_base(lc), lb);
-                        zb_bits_put(&bw, ml - zb_ml_base(mc), mb);
-                        zb_bits_put(&bw, ofv - (1u << oc), oc);
+                        /* three puts instead of six: the transition bits of the three states (<= 27 bits), the two lengths' extra
+                         * bits (a unit's lengths: <= 12 + 12), the offset's */
+                        const uint32_t no = so >> 10, nm = sm >> 10, nl = sl >> 10;
+                        zb_bits_open(&bw, stg, (running & 31u) + off);
+                        zb_bits_put(&bw, (so & 1023u) | ((sm & 1023u) << no) | ((sl & 1023u) << (no + nm)), no + nm + nl);
+                        zb_bits_put(&bw, llx | (mlx << lb), lb + mb);
+                        zb_bits_put(&bw, ofx, oc);
                         zb_bits_close(&bw);
                     }
+                    zb_stage_end(stg, sc->out, running, total, first_bit, zl);
                     running += total;
                 }
             }
+            zb_stage_close(stg, sc->out, running, zl);
         }
     }
     ZB_SYNC();
