@@ -9,6 +9,7 @@ python bench.py > gpurun_out/${tag}_bench64g_default.json 2> gpurun_out/${tag}_b
 python bench.py --kind mixed --no-cpu-baseline --no-secondary > gpurun_out/${tag}_bench64g_mixed.json 2> gpurun_out/${tag}_bench64g_mixed.err
 python bench.py --kind mixed --dups --no-cpu-baseline --no-secondary > gpurun_out/${tag}_bench64g_dedup.json 2> gpurun_out/${tag}_bench64g_dedup.err
 python bench.py --codec zstd --kind mixed --no-cpu-baseline --no-secondary > gpurun_out/${tag}_bench64g_zstd_mixed.json 2> gpurun_out/${tag}_bench64g_zstd_mixed.err
+python bench.py --codec zstd --zstd-settings 4 --kind mixed --no-cpu-baseline --no-secondary > gpurun_out/${tag}_bench64g_zstd4_mixed.json 2> gpurun_out/${tag}_bench64g_zstd4_mixed.err
 python bench.py --codec zstd --file-mib 16384 --no-cpu-baseline --no-secondary > gpurun_out/${tag}_bench64g_zstd_4x16g.json 2> gpurun_out/${tag}_bench64g_zstd_4x16g.err
 here=$(pwd); cd /tmp && export TMPDIR=/tmp; cd $here
 for leg in "default:" "mixed:--kind mixed" "zstd_mixed:--codec zstd --kind mixed"; do
