@@ -155,10 +155,16 @@ def check_images(gpu, ref, sess, codec_id, tag, max_block):
         assert got.value == raw and (out[:raw] == expect).all(), b
 
 
-@pytest.mark.parametrize("target,codec,max_block,max_chunks", [(65536, "lz4", 8 << 20, 1024), (4096, "zstd", 1 << 20, 64), (1024, "lz4", 262144, 16)])
+@pytest.mark.parametrize("target,codec,max_block,max_chunks", [(65536, "lz4", 8 << 20, 1024), (4096, "zstd", 1 << 20, 64), (1024, "lz4", 262144, 16),
+                                                               (4096, "zstd:ztd4", 1 << 20, 64)])
 def test_ingest_session_single_rank_matches_reference(gpu, oracle, ref, target, codec, max_block, max_chunks):
     files = make_files(oracle, target)
     tag = ref.lz4_type if codec == "lz4" else ref.zstd_default
+    if codec == "zstd:ztd4":  # the settings id is the block tag AND selects the parse (lthip_zstd_quality_of_settings): "high"
+        codec, tag = "zstd", int(ref.dll.refh_zstd_type(3))
+        assert tag == 0x7A746434 and gpu.lib.dll.lthip_zstd_quality_of_settings(tag) == 1
+        assert [gpu.lib.dll.lthip_zstd_quality_of_settings(0x7A746430 + k) for k in range(7)] == [0, 0, 0, 2, 1, 2, 0]
+        assert gpu.lib.dll.lthip_zstd_quality_of_settings(ref.lz4_type) == 0
     probe = rank_session(gpu, ref, files, target, 1, 0, "range", codec, max_block, max_chunks, tag)
     lists = {int(j): (probe["d_hash"][int(probe["first"][m]) : int(probe["first"][m + 1])], probe["d_len"][int(probe["first"][m]) : int(probe["first"][m + 1])])
              for m, j in enumerate(probe["mine"])}

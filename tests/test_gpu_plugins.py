@@ -174,6 +174,30 @@ def test_zstd_plugin_compress_decodes_with_reference(plugins, ref, oracle):
         assert err == 0 and len(back) == n and (back == d).all()
 
 
+def test_zstd_plugin_settings_select_the_parse(plugins, ref, oracle):
+    """'ztd4' and 'ztd3' through Longtail_CompressionAPI::Compress: smaller than 'ztd2' on data with redundancy beyond a half's own
+    32 KiB (a vocabulary of tokens), decoded by the reference; an unknown 'ztd?' id compresses like the default (longtail_zstd.c:43-60:
+    `default: return 0`)."""
+    api = CompressionAPIStruct.from_address(plugins["zstd"])
+    d = oracle.synth(3 << 20, 21, 12)
+    sizes = {}
+    for w, name in ((1, "ztd2"), (3, "ztd4"), (2, "ztd3")):
+        tag = int(ref.dll.refh_zstd_type(w))
+        cap = api.GetMaxCompressedSize(plugins["zstd"], tag, len(d))
+        out = np.zeros(cap + 8, np.uint8)
+        got = C.c_size_t(0)
+        assert api.Compress(plugins["zstd"], tag, d.ctypes.data, out.ctypes.data, len(d), cap, C.byref(got)) == 0
+        err, back = ref.decompress(1, out[: got.value].copy(), len(d))
+        assert err == 0 and (back == d).all()
+        sizes[name] = got.value
+    assert sizes["ztd4"] < 0.95 * sizes["ztd2"] and sizes["ztd3"] <= sizes["ztd4"], sizes
+    tag = 0x7A746439  # 'ztd9'
+    out = np.zeros(len(d) + (len(d) >> 8) + 72, np.uint8)
+    got = C.c_size_t(0)
+    assert api.Compress(plugins["zstd"], tag, d.ctypes.data, out.ctypes.data, len(d), len(out) - 8, C.byref(got)) == 0
+    assert got.value == sizes["ztd2"]
+
+
 def test_zstd_plugin_decompress_reads_reference_frames(plugins, ref, oracle):
     """ZStdCompressionAPI_Decompress on the GPU: frames written by the REFERENCE encoder at every longtail setting
     ('ztd1'..'ztd5', lib/zstd/longtail_zstd.c:12-22) and frames written by the HIP encoder itself; malformed -> EINVAL."""
