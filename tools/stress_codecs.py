@@ -22,7 +22,8 @@ for rnd in range(12):
         caps = [s + s // 255 + 16 if codec == "lz4" else s + (s >> 8) + 64 for s in sizes]
         d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
         dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
-        fn = ctx.lz4_compress_blocks if codec == "lz4" else ctx.zstd_compress_blocks
+        zq = rnd % 3  # the zstd setting's parse: default / high (history halves) / max, round by round
+        fn = ctx.lz4_compress_blocks if codec == "lz4" else (lambda *a: ctx.zstd_compress_blocks(*a, quality=zq))
         cs = u32(fn(dev, offs, sizes, dst, d_offs, caps)).astype(np.int64)
         assert (cs > 0).all(), codec
         b_offs, btot = layout([np.zeros(s, np.uint8) for s in sizes])
@@ -90,7 +91,7 @@ for rnd in range(12):
             caps = [n + (n >> 8) + 64 for n in ssz]
             d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
             dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
-            cs = u32(ctx.zstd_compress_blocks(sdev, soffs, ssz, dst, d_offs, caps)).astype(np.int64)
+            cs = u32(ctx.zstd_compress_blocks(sdev, soffs, ssz, dst, d_offs, caps, quality=(rnd + 1) % 3)).astype(np.int64)
             host = dst.cpu().numpy()
         frames, fcaps = [], []
         for i, b in enumerate(src):
