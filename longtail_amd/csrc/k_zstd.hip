@@ -44,6 +44,19 @@ __device__ __forceinline__ uint32_t zb_scan_excl(uint32_t v, uint32_t* total)
     *total = __shfl(incl, 63, 64);
     return incl - v;
 }
+__device__ __forceinline__ uint64_t zb_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+// v of lane `lane` (any lane, also one that sits out a branch: every lane of the wave executes the call)
+__device__ __forceinline__ uint32_t zb_shfl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lane << 2), (int)v); }
+__device__ __forceinline__ uint32_t zb_reduce_max(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+    {
+        const uint32_t o = __shfl_xor(v, d, 64);
+        v = v > o ? v : o;
+    }
+    return v;
+}
 #ifdef LTHIP_ZB_PROF /* debug build only: cycles per phase of zb_encode_block, summed over all pieces (lane 0) */
 __device__ unsigned long long g_zb_prof[32];
 __device__ unsigned long long g_zb_last[1 << 16];

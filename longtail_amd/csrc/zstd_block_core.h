@@ -20,6 +20,10 @@
  *   zb_atomic_add(p,v) / zb_atomic_or(p,v)   32-bit atomics on shared / global words
  *   zb_scan_excl(v, &total)                  exclusive prefix sum of v over the lanes (lane 0 first) and its total;
  *                                            called by all lanes together (with one lane: 0 and v)
+ *   with ZB_LANES > 1 also: zb_ballot(pred) (64-bit mask of the lanes with pred), zb_shfl(v, lane) (v of another lane; all
+ *                                            lanes call), zb_reduce_max(v) -- the table builders below have an all-lanes form
+ *                                            (zb_normalize_par, zb_build_enc_table_par) that produces the SAME tables as the
+ *                                            serial form the one-lane build runs: the tables are functions of the counts alone
  * Every phase is either `ZB_SERIAL(zl)` (lane 0), or a `ZB_PAR_FOR` whose iterations only interact through those
  * commutative atomics, so the bytes produced do not depend on ZB_LANES: the one-lane host build (zstd_model.c in the test
  * infrastructure) is a bit-exact model of the kernel (k_zstd.hip), and runs here without a GPU against the
@@ -478,6 +482,129 @@ ZB_FN void zb_build_enc_table(const int16_t* norm, uint32_t nsym, uint32_t tl, u
     }
 }
 
+#if ZB_LANES > 1
+/* zb_normalize by all lanes: lane s owns symbol s (nsym <= 64 <= ZB_LANES); (hist << tl) fits 32 bits (hist <= ZB_SEQ_MAX = 2^15,
+ * tl <= 9).  One division per LANE instead of one per symbol on one lane; the correction loop (usually one round) finds the
+ * first largest count with a wave maximum and a ballot. */
+ZB_FN void zb_normalize_par(const uint32_t* hist, uint32_t nsym, uint32_t total, uint32_t tl, int16_t* norm, uint32_t zl)
+{
+    const uint32_t size = 1u << tl;
+    const uint32_t h = zl < nsym ? hist[zl] : 0u;
+    uint32_t v = 0, sum;
+    if (h)
+    {
+        v = (h << tl) / total;
+        if (v == 0u)
+            v = 1u;
+    }
+    (void)zb_scan_excl(v, &sum);
+    while (sum != size)
+    {
+        const uint32_t mx = zb_reduce_max(v);
+        const uint32_t best = (uint32_t)__builtin_ctzll(zb_ballot(v == mx));
+        if (sum < size)
+        {
+            if (zl == best)
+                v += size - sum;
+            sum = size;
+        }
+        else
+        {
+            uint32_t take = sum - size;
+            if (take > mx - 1u)
+                take = mx - 1u;
+            if (zl == best)
+                v -= take;
+            sum -= take;
+        }
+    }
+    if (zl < 64u)
+        norm[zl] = (int16_t)v;
+    ZB_SYNC_LDS();
+}
+
+/* zb_build_enc_table by all lanes (norm[0..63] in shared memory, 0 beyond nsym).  The serial walk -- symbol occurrence i goes to
+ * the i-th cell of the walk 0, step, 2 step, ... (mod size) that is not one of the top cells the "less than one" symbols took --
+ * is inverted per cell: cell u <= high is visit k(u) = u * step^-1 (mod size) of the walk, the top cells visited before it
+ * (at most a handful: one per -1 symbol) are counted off, and the occurrence index that is left is looked up in the running
+ * sums of the counts (incl[], 64 x u16 of scratch).  The cells of a symbol are then numbered in state order: lane s keeps how
+ * many cells of symbol s the chunks of 64 cells before this one held, the cells of a chunk rank themselves among the equal
+ * symbols of lower lanes with one ballot per DISTINCT symbol of the chunk. */
+ZB_FN void zb_build_enc_table_par(const int16_t* norm, uint32_t nsym, uint32_t tl, uint16_t* state_tab, uint16_t* sym_start,
+                                  uint16_t* incl, uint32_t zl)
+{
+    const uint32_t size = 1u << tl, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
+    const int nv = zl < nsym ? norm[zl] : 0;
+    const uint32_t cnt = nv < 0 ? 1u : (uint32_t)nv, pcnt = nv > 0 ? (uint32_t)nv : 0u;
+    uint32_t tot, inv = step, count_s = 0;
+    const uint32_t start = zb_scan_excl(cnt, &tot);
+    const uint32_t pex = zb_scan_excl(pcnt, &tot);
+    const uint64_t low = zb_ballot(nv == -1);
+    const uint32_t nlow = (uint32_t)__builtin_popcountll(low), high = size - 1u - nlow;
+    for (int it = 0; it < 4; ++it) /* step^-1 mod 2^32 (Newton; step is odd: 3 correct bits to start with) */
+        inv *= 2u - step * inv;
+    if (zl < 64u)
+    {
+        sym_start[zl] = (uint16_t)start;
+        incl[zl] = (uint16_t)(pex + pcnt);
+    }
+    ZB_SYNC_LDS();
+    for (uint32_t u0 = 0; u0 < size; u0 += 64u)
+    {
+        const uint32_t u = u0 + zl;
+        const int act = zl < 64u && u < size;
+        uint32_t sym = 0, within = 0;
+        if (act)
+        {
+            if (u > high)
+            {
+                /* the -1 symbols took the top cells in symbol order, the first one the last cell */
+                uint64_t m = low;
+                for (uint32_t j = size - 1u - u; j; --j)
+                    m &= m - 1u;
+                sym = (uint32_t)__builtin_ctzll(m);
+            }
+            else
+            {
+                const uint32_t k = (u * inv) & mask;
+                uint32_t skipped = 0, lo = 0, hi = 64u;
+                for (uint32_t j = 0; j < nlow; ++j)
+                    skipped += (((size - 1u - j) * inv) & mask) < k ? 1u : 0u;
+                {
+                    const uint32_t i = k - skipped;
+                    while (lo < hi) /* the first symbol whose running sum exceeds i */
+                    {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((uint32_t)incl[mid] <= i)
+                            lo = mid + 1u;
+                        else
+                            hi = mid;
+                    }
+                }
+                sym = lo;
+            }
+        }
+        {
+            const uint32_t before = zb_shfl(count_s, sym), base = zb_shfl(start, sym);
+            uint64_t rem = zb_ballot(act);
+            while (rem)
+            {
+                const uint32_t s0 = zb_shfl(sym, (uint32_t)__builtin_ctzll(rem));
+                const uint64_t m = zb_ballot(act && sym == s0);
+                if (act && sym == s0)
+                    within = (uint32_t)__builtin_popcountll(m & ((1ull << zl) - 1ull));
+                if (zl == s0)
+                    count_s += (uint32_t)__builtin_popcountll(m);
+                rem &= ~m;
+            }
+            if (act)
+                state_tab[base + before + within] = (uint16_t)u;
+        }
+    }
+    ZB_SYNC_LDS();
+}
+#endif
+
 ZB_FN uint32_t zb_sym_count(const int16_t* norm, uint32_t s) { return (uint32_t)(norm[s] < 0 ? 1 : norm[s]); }
 
 /* One encoding step; returns nbBits << 10 | bits and updates *x. */
@@ -834,6 +961,105 @@ ZB_FN uint32_t zb_lit_get(ZbLitReader* r, uint32_t k) /* k < total literals */
 
 ZB_FN uint32_t zb_of_code(uint32_t off) { return zb_highbit(off + 3u); }
 
+/* Mode, table log, normalised counts and encoding table of the three sequence-symbol types from sh->sym_hist (both block layouts).
+ * One lane per table in the one-lane form; with a wave every table is built by all lanes, one table after the other (the serial
+ * builders were 28 % of the entropy kernel's wave time: a division per symbol, then ~4 dependent LDS accesses per table cell, on
+ * one lane). */
+ZB_FN void zb_build_seq_tables(ZbShared* sh, uint32_t nbseq, uint32_t zl)
+{
+#if ZB_LANES > 1
+    for (uint32_t t = 0; t < 3u && nbseq; ++t)
+    {
+        const uint32_t nsym = zb_table_nsym((int)t);
+        const uint64_t present = zb_ballot(zl < 64u && sh->sym_hist[t][zl & 63u] != 0u);
+        const uint32_t distinct = (uint32_t)__builtin_popcountll(present), maxs = 63u - (uint32_t)__builtin_clzll(present | 1ull);
+        if (distinct == 1u)
+        {
+            ZB_SERIAL(zl)
+            {
+                sh->mode[t] = 1; /* RLE_Mode */
+                sh->rle_sym[t] = (uint8_t)maxs;
+                sh->table_log[t] = 0;
+            }
+        }
+        else if (((nbseq < 64u && !(ZB_DBG & 2u)) || (ZB_DBG & 4u)) && maxs < nsym)
+        {
+            const uint32_t tl = zb_table_default_log((int)t);
+            ZB_SERIAL(zl)
+            {
+                sh->mode[t] = 0; /* Predefined_Mode */
+                sh->table_log[t] = (uint8_t)tl;
+            }
+            if (zl < 64u)
+                sh->norm[t][zl] = (int16_t)(zl < nsym ? zb_default_norm((int)t, zl) : 0);
+            ZB_SYNC_LDS();
+            zb_build_enc_table_par(sh->norm[t], nsym, tl, sh->state_tab[t], sh->sym_start[t], sh->cursor[t], zl);
+        }
+        else
+        {
+            uint32_t tl = zb_highbit(nbseq) - 1u;
+            const uint32_t minlog = distinct > 32u ? 6u : 5u, maxlog = zb_table_max_log((int)t);
+            if (tl < minlog)
+                tl = minlog;
+            if (tl > maxlog)
+                tl = maxlog;
+            ZB_SERIAL(zl)
+            {
+                sh->mode[t] = 2; /* FSE_Compressed_Mode */
+                sh->table_log[t] = (uint8_t)tl;
+                sh->rle_sym[t] = (uint8_t)maxs; /* highest present symbol, for the NCount writer */
+            }
+            zb_normalize_par(sh->sym_hist[t], maxs + 1u, nbseq, tl, sh->norm[t], zl);
+            zb_build_enc_table_par(sh->norm[t], maxs + 1u, tl, sh->state_tab[t], sh->sym_start[t], sh->cursor[t], zl);
+        }
+    }
+#else
+    ZB_PAR_FOR(t, 3u)
+    {
+        if (nbseq)
+        {
+            const uint32_t nsym = zb_table_nsym((int)t);
+            uint32_t distinct = 0, only = 0, maxs = 0;
+            for (uint32_t s = 0; s < 64u; ++s)
+                if (sh->sym_hist[t][s])
+                {
+                    ++distinct;
+                    only = s;
+                    maxs = s;
+                }
+            if (distinct == 1u)
+            {
+                sh->mode[t] = 1; /* RLE_Mode */
+                sh->rle_sym[t] = (uint8_t)only;
+                sh->table_log[t] = 0;
+            }
+            else if (((nbseq < 64u && !(ZB_DBG & 2u)) || (ZB_DBG & 4u)) && maxs < nsym)
+            {
+                sh->mode[t] = 0; /* Predefined_Mode */
+                sh->table_log[t] = (uint8_t)zb_table_default_log((int)t);
+                for (uint32_t s = 0; s < 64u; ++s)
+                    sh->norm[t][s] = (int16_t)(s < nsym ? zb_default_norm((int)t, s) : 0);
+                zb_build_enc_table(sh->norm[t], nsym, sh->table_log[t], ZB_SPREAD(sh, t), sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
+            }
+            else
+            {
+                uint32_t tl = zb_highbit(nbseq) - 1u;
+                const uint32_t minlog = distinct > 32u ? 6u : 5u, maxlog = zb_table_max_log((int)t);
+                if (tl < minlog)
+                    tl = minlog;
+                if (tl > maxlog)
+                    tl = maxlog;
+                sh->mode[t] = 2; /* FSE_Compressed_Mode */
+                sh->table_log[t] = (uint8_t)tl;
+                zb_normalize(sh->sym_hist[t], maxs + 1u, nbseq, tl, sh->norm[t]);
+                zb_build_enc_table(sh->norm[t], maxs + 1u, tl, ZB_SPREAD(sh, t), sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
+                sh->rle_sym[t] = (uint8_t)maxs; /* highest present symbol, for the NCount writer */
+            }
+        }
+    }
+#endif
+}
+
 /* Encodes one block.  Returns the size of the Compressed_Block content in sc->out, or 0 when it would not be
  * smaller than the raw bytes (the caller then stores a Raw_Block). */
 ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared* sh, uint32_t zl)
@@ -1043,49 +1269,7 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     }
     ZB_SYNC();
     ZB_MARK(9);
-    ZB_PAR_FOR(t, 3u)
-    {
-        if (nbseq)
-        {
-            const uint32_t nsym = zb_table_nsym((int)t);
-            uint32_t distinct = 0, only = 0, maxs = 0;
-            for (uint32_t s = 0; s < 64u; ++s)
-                if (sh->sym_hist[t][s])
-                {
-                    ++distinct;
-                    only = s;
-                    maxs = s;
-                }
-            if (distinct == 1u)
-            {
-                sh->mode[t] = 1; /* RLE_Mode */
-                sh->rle_sym[t] = (uint8_t)only;
-                sh->table_log[t] = 0;
-            }
-            else if (((nbseq < 64u && !(ZB_DBG & 2u)) || (ZB_DBG & 4u)) && maxs < nsym)
-            {
-                sh->mode[t] = 0; /* Predefined_Mode */
-                sh->table_log[t] = (uint8_t)zb_table_default_log((int)t);
-                for (uint32_t s = 0; s < 64u; ++s)
-                    sh->norm[t][s] = (int16_t)(s < nsym ? zb_default_norm((int)t, s) : 0);
-                zb_build_enc_table(sh->norm[t], nsym, sh->table_log[t], ZB_SPREAD(sh, t), sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
-            }
-            else
-            {
-                uint32_t tl = zb_highbit(nbseq) - 1u;
-                const uint32_t minlog = distinct > 32u ? 6u : 5u, maxlog = zb_table_max_log((int)t);
-                if (tl < minlog)
-                    tl = minlog;
-                if (tl > maxlog)
-                    tl = maxlog;
-                sh->mode[t] = 2; /* FSE_Compressed_Mode */
-                sh->table_log[t] = (uint8_t)tl;
-                zb_normalize(sh->sym_hist[t], maxs + 1u, nbseq, tl, sh->norm[t]);
-                zb_build_enc_table(sh->norm[t], maxs + 1u, tl, ZB_SPREAD(sh, t), sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
-                sh->rle_sym[t] = (uint8_t)maxs; /* highest present symbol, for the NCount writer */
-            }
-        }
-    }
+    zb_build_seq_tables(sh, nbseq, zl);
     ZB_SYNC();
 
     ZB_MARK(3);
@@ -1808,49 +1992,7 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
     ZB_PAR_FOR(i, 4u * ZB_MAX_UNITS) strbits[i] = 0;
     ZB_SYNC();
     ZB_MARK(9);
-    ZB_PAR_FOR(t, 3u)
-    {
-        if (nbseq)
-        {
-            const uint32_t nsym = zb_table_nsym((int)t);
-            uint32_t distinct = 0, only = 0, maxs = 0;
-            for (uint32_t s = 0; s < 64u; ++s)
-                if (sh->sym_hist[t][s])
-                {
-                    ++distinct;
-                    only = s;
-                    maxs = s;
-                }
-            if (distinct == 1u)
-            {
-                sh->mode[t] = 1; /* RLE_Mode */
-                sh->rle_sym[t] = (uint8_t)only;
-                sh->table_log[t] = 0;
-            }
-            else if (((nbseq < 64u && !(ZB_DBG & 2u)) || (ZB_DBG & 4u)) && maxs < nsym)
-            {
-                sh->mode[t] = 0; /* Predefined_Mode */
-                sh->table_log[t] = (uint8_t)zb_table_default_log((int)t);
-                for (uint32_t s = 0; s < 64u; ++s)
-                    sh->norm[t][s] = (int16_t)(s < nsym ? zb_default_norm((int)t, s) : 0);
-                zb_build_enc_table(sh->norm[t], nsym, sh->table_log[t], ZB_SPREAD(sh, t), sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
-            }
-            else
-            {
-                uint32_t tl = zb_highbit(nbseq) - 1u;
-                const uint32_t minlog = distinct > 32u ? 6u : 5u, maxlog = zb_table_max_log((int)t);
-                if (tl < minlog)
-                    tl = minlog;
-                if (tl > maxlog)
-                    tl = maxlog;
-                sh->mode[t] = 2; /* FSE_Compressed_Mode */
-                sh->table_log[t] = (uint8_t)tl;
-                zb_normalize(sh->sym_hist[t], maxs + 1u, nbseq, tl, sh->norm[t]);
-                zb_build_enc_table(sh->norm[t], maxs + 1u, tl, ZB_SPREAD(sh, t), sh->state_tab[t], sh->sym_start[t], sh->cursor[t]);
-                sh->rle_sym[t] = (uint8_t)maxs; /* highest present symbol, for the NCount writer */
-            }
-        }
-    }
+    zb_build_seq_tables(sh, nbseq, zl);
     /* the literal histogram is dead: its memory holds the per-unit values from here on */
     ZB_SYNC();
     /* ... and so are the code histograms: per symbol, what an encoding step needs of it (zb_fse_step_tt); the work arrays of the
