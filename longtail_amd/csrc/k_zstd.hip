@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #define ZB_LANES 64u
+#define ZB_UNROLL _Pragma("unroll")
 #define ZB_FN __device__ __forceinline__ /* inlined so that LDS / global address spaces are known at every access */
 #define ZB_SYNC() __syncthreads() /* the encoder runs in one-wave workgroups */
 /* LDS traffic of ONE wave is executed in program order: only the compiler has to be kept from moving it */

@@ -44,6 +44,13 @@
 #define ZB_MARK(i) ((void)0) /* profiling hook of the kernel build (phase boundaries) */
 #endif
 #define ZB_PAR_FOR(i, n) for (uint32_t i = zl; i < (uint32_t)(n); i += ZB_LANES)
+/* n items handled K per lane and trip, lanes next to each other in every one of the K accesses: trip t covers the items
+ * [t K LANES, (t + 1) K LANES), lane zl takes t K LANES + q LANES + zl for q < K (each to be checked against n); every lane makes
+ * every trip */
+#define ZB_PAR_FOR_K(t, n, K) for (uint32_t t = 0; t * (K) * ZB_LANES < (uint32_t)(n); ++t)
+#ifndef ZB_UNROLL
+#define ZB_UNROLL /* the kernel build: _Pragma("unroll") -- arrays indexed by such a loop's counter must stay in registers */
+#endif
 #define ZB_SERIAL(zl) if ((zl) == 0)
 
 #define ZB_BLOCK_MAX (128u * 1024u) /* Block_Maximum_Size, zstd.h:142-143 */
@@ -1747,6 +1754,20 @@ ZB_FN void zb_stage_close(uint32_t* stg, uint32_t* out, uint32_t running, uint32
     ZB_SYNC_LDS();
 }
 
+/* The output is NOT cleared as a whole (133 KiB per piece were: one byte written per byte of input, a fifth of the kernel's memory
+ * instructions): every byte of a block is written by exactly one party -- the headers and raw bytes with byte stores, a bit-stream's
+ * whole words with plain stores (zb_stage_end) -- except the words a stream shares with its neighbours and the ones its last bits are
+ * OR-ed into (stream end, end mark, final states).  The stream's own bytes of THOSE words are cleared here, before the streams are
+ * written: [s, e) = the stream's bytes, endbit = the bit (relative to the output) its staged bits end at. */
+ZB_FN void zb_zero_edges(uint8_t* out8, uint32_t s, uint32_t e, uint32_t endbit)
+{
+    const uint32_t a = (s + 3u) & ~3u, z0 = (endbit >> 5) << 2;
+    for (uint32_t j = s; j < a && j < e; ++j)
+        out8[j] = 0;
+    for (uint32_t j = z0 > s ? z0 : s; j < e; ++j)
+        out8[j] = 0;
+}
+
 ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbShared* sh, uint32_t zl, uint16_t* sub)
 {
     uint8_t* const out8 = (uint8_t*)sc->out;
@@ -1810,26 +1831,40 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
      * literals), the three symbol histograms, the literal histogram ---- */
     if (!(in->flags & ZB_F_REPCODES))
     {
-        ZB_PAR_FOR(i, nbseq)
+        /* four sequences per lane and trip, their records loaded before the first is packed: the loop is bound by the round trips
+         * to memory (one wave per piece), and this way four of them are in flight */
+        ZB_PAR_FOR_K(t4, nbseq, 4u)
         {
-            uint32_t lo = 0, hi = nunits;
-            while (hi - lo > 1u)
+            const uint32_t ibase = t4 * 4u * ZB_LANES + zl;
+            uint64_t r4[4];
+            uint32_t u4[4];
+            ZB_UNROLL
+            for (uint32_t q = 0; q < 4u; ++q)
             {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (sh->useq_base[mid] <= i)
-                    lo = mid;
-                else
-                    hi = mid;
+                const uint32_t i = ibase + q * ZB_LANES;
+                uint32_t lo = 0;
+                ZB_UNROLL
+                for (uint32_t st = ZB_MAX_UNITS / 2u; st; st >>= 1) /* the last unit whose first sequence is at or before i */
+                    if (lo + st < nunits && sh->useq_base[lo + st] <= i)
+                        lo += st;
+                u4[q] = lo;
+                r4[q] = i < nbseq ? in->unit_recs[(uint64_t)lo * ZB_UNIT_SEQ_MAX + (i - sh->useq_base[lo])] : 0u;
             }
+            ZB_UNROLL
+            for (uint32_t q = 0; q < 4u; ++q)
             {
-                const uint64_t r = in->unit_recs[(uint64_t)lo * ZB_UNIT_SEQ_MAX + (i - sh->useq_base[lo])];
-                const uint32_t lit = (uint32_t)(r & 0xFFFFu), ml = (uint32_t)((r >> 16) & 0xFFFFu), off = (uint32_t)(r >> 32);
-                uint32_t lc, mc, oc, xb;
-                sc->seqs[i] = zb_pack_seq_t(ct, lit, ml, off + 3u, &lc, &mc, &oc, &xb);
-                zb_atomic_add(&sh->sym_hist[ZT_LL][lc], 1u);
-                zb_atomic_add(&sh->sym_hist[ZT_ML][mc], 1u);
-                zb_atomic_add(&sh->sym_hist[ZT_OF][oc], 1u);
-                zb_atomic_add(&sh->carry[lo], xb);
+                const uint32_t i = ibase + q * ZB_LANES;
+                if (i < nbseq)
+                {
+                    const uint64_t r = r4[q];
+                    const uint32_t lit = (uint32_t)(r & 0xFFFFu), ml = (uint32_t)((r >> 16) & 0xFFFFu), off = (uint32_t)(r >> 32);
+                    uint32_t lc, mc, oc, xb;
+                    sc->seqs[i] = zb_pack_seq_t(ct, lit, ml, off + 3u, &lc, &mc, &oc, &xb);
+                    zb_atomic_add(&sh->sym_hist[ZT_LL][lc], 1u);
+                    zb_atomic_add(&sh->sym_hist[ZT_ML][mc], 1u);
+                    zb_atomic_add(&sh->sym_hist[ZT_OF][oc], 1u);
+                    zb_atomic_add(&sh->carry[u4[q]], xb);
+                }
             }
         }
     }
@@ -1892,6 +1927,7 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
             }
         }
     }
+    ZB_MARK(11);
     /* plainly noise?  (the sampled test of zb_encode_block) */
     if (nlit >= 32768u && in->raw_size - nlit < 3u * nbseq + 32u && !(ZB_DBG & 8u))
     {
@@ -1925,29 +1961,66 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
         ZB_PAR_FOR(i, 256u) sh->lit_hist[i] = 0;
         ZB_SYNC();
     }
-    for (uint32_t u = 0; u < nunits; ++u)
     {
-        /* four words per lane and trip, loaded before the first counter is touched: the loop is bound by the round trips to
-         * memory, and this way four of them are in flight */
-        const uint32_t n = sh->ulit_base[u + 1u] - sh->ulit_base[u];
-        const uint32_t nw = (n + 3u) >> 2;
-        ZB_PAR_FOR(j4, (nw + 3u) >> 2)
+        /* The literal QUADS (four words, 16 bytes) of all units as one list (qbase[u] = quads of the units before u; a unit's last
+         * quad may be partial): two quads per lane and trip, loaded before the first counter is touched.  The loop is bound by the
+         * round trips to memory: unit by unit a piece took 64 of them one after the other (15 % of the kernel's time). */
+        uint16_t* const qbase = sh->cursor[0]; /* [nunits + 1] <= 33 entries, <= 8192 (free until the table builds) */
+        ZB_SERIAL(zl)
         {
-            uint32_t w[4];
-            for (uint32_t q = 0; q < 4u; ++q)
-                w[q] = 4u * j4 + q < nw ? zb_unit_word(in, srcmask, u, 4u * j4 + q, n) : 0u;
-            for (uint32_t q = 0; q < 4u; ++q)
-                if (4u * j4 + q < nw)
+            uint32_t acc = 0;
+            for (uint32_t u = 0; u < nunits; ++u)
+            {
+                qbase[u] = (uint16_t)acc;
+                acc += (sh->ulit_base[u + 1u] - sh->ulit_base[u] + 15u) >> 4;
+            }
+            qbase[nunits] = (uint16_t)acc;
+        }
+        ZB_SYNC_LDS();
+        const uint32_t nquads = qbase[nunits];
+        ZB_PAR_FOR_K(t2, nquads, 2u)
+        {
+            uint32_t w[2][4], nb[2];
+            ZB_UNROLL
+            for (uint32_t q = 0; q < 2u; ++q)
+            {
+                const uint32_t g = t2 * 2u * ZB_LANES + q * ZB_LANES + zl;
+                uint32_t lo = 0;
+                ZB_UNROLL
+                for (uint32_t st = ZB_MAX_UNITS / 2u; st; st >>= 1) /* the last unit whose first quad is at or before g */
+                    if (lo + st < nunits && (uint32_t)qbase[lo + st] <= g)
+                        lo += st;
+                nb[q] = 0;
+                ZB_UNROLL
+                for (uint32_t k = 0; k < 4u; ++k)
+                    w[q][k] = 0;
+                if (g < nquads)
                 {
-                    const uint32_t k = n - 4u * (4u * j4 + q); /* valid bytes in this word, >= 1 */
-                    zb_atomic_add(&sh->lit_hist[w[q] & 255u], 1u);
-                    if (k > 1u)
-                        zb_atomic_add(&sh->lit_hist[(w[q] >> 8) & 255u], 1u);
-                    if (k > 2u)
-                        zb_atomic_add(&sh->lit_hist[(w[q] >> 16) & 255u], 1u);
-                    if (k > 3u)
-                        zb_atomic_add(&sh->lit_hist[w[q] >> 24], 1u);
+                    const uint32_t n = sh->ulit_base[lo + 1u] - sh->ulit_base[lo], w0 = 4u * (g - qbase[lo]);
+                    nb[q] = n - 4u * w0; /* valid bytes from this quad's first word on, >= 1 */
+                    ZB_UNROLL
+                    for (uint32_t k = 0; k < 4u; ++k)
+                        if (4u * k < nb[q])
+                            w[q][k] = zb_unit_word(in, srcmask, lo, w0 + k, n);
                 }
+            }
+            ZB_UNROLL
+            for (uint32_t q = 0; q < 2u; ++q)
+            {
+                ZB_UNROLL
+                for (uint32_t k = 0; k < 4u; ++k)
+                {
+                    const uint32_t v = w[q][k], left = nb[q] > 4u * k ? nb[q] - 4u * k : 0u; /* valid bytes in this word */
+                    if (left > 0u)
+                        zb_atomic_add(&sh->lit_hist[v & 255u], 1u);
+                    if (left > 1u)
+                        zb_atomic_add(&sh->lit_hist[(v >> 8) & 255u], 1u);
+                    if (left > 2u)
+                        zb_atomic_add(&sh->lit_hist[(v >> 16) & 255u], 1u);
+                    if (left > 3u)
+                        zb_atomic_add(&sh->lit_hist[v >> 24], 1u);
+                }
+            }
         }
     }
     ZB_SYNC();
@@ -1970,16 +2043,18 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
     ZB_SYNC();
     if (sh->v[ZV_SKIP])
         return 0;
-    ZB_PAR_FOR(i, ZB_OUT_BYTES / 4u) sc->out[i] = 0;
+    ZB_MARK(12);
     if (sh->v[ZV_LIT_HDR])
         zb_huffman_sort(sh, zl);
     ZB_SYNC();
+    ZB_MARK(13);
     ZB_SERIAL(zl)
     {
         if (sh->v[ZV_LIT_HDR])
             zb_huffman_build(sh);
     }
     ZB_SYNC();
+    ZB_MARK(14);
     ZB_SERIAL(zl)
     {
         if (sh->v[ZV_HUF_OK]) /* uses table slot 0 as work space: must precede the FSE tables below */
@@ -2263,6 +2338,29 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
     ZB_SYNC();
     if (!sh->v[ZV_OUT_SIZE])
         return 0;
+    ZB_PAR_FOR(u, nunits)
+    {
+        const uint32_t lmode = sb->lmode[u];
+        if (lmode == 2u || lmode == 3u)
+        {
+            uint32_t s0 = sb->litpos[u];
+            for (uint32_t q = 0; q < sb->nstr[u]; ++q)
+            {
+                const uint32_t bits = strbits[4u * u + q], by = (bits + 1u + 7u) >> 3;
+                zb_zero_edges(out8, s0, s0 + by, s0 * 8u + bits);
+                s0 += by;
+            }
+        }
+        if (sh->useq_base[u + 1u] > sh->useq_base[u] && lmode != 4u)
+        {
+            uint32_t bits = sb->seqbits[u] + 1u;
+            for (uint32_t t = 0; t < 3u; ++t)
+                if (sh->mode[t] != 1u)
+                    bits += sh->table_log[t];
+            zb_zero_edges(out8, sb->seqpos[u], sb->seqpos[u] + ((bits + 7u) >> 3), sb->seqpos[u] * 8u + sb->seqbits[u]);
+        }
+    }
+    ZB_SYNC();
 
     ZB_MARK(6);
     /* ---- phase 6: literals.  A Huffman stream is written from its LAST literal: per step every lane takes the next four

@@ -55,6 +55,7 @@ uint32_t ltz_model_encode_block_src(const void* meta, const uint8_t* unit_lits, 
     sc.seqs = (uint64_t*)malloc(sizeof(uint64_t) * ZB_SEQ_MAX);
     sc.sbits = (uint16_t*)malloc(sizeof(uint16_t) * 4 * ZB_SEQ_MAX);
     sc.out = (uint32_t*)malloc(ZB_OUT_BYTES);
+    memset(sc.out, 0xA5, ZB_OUT_BYTES); /* the encoders must not rely on a cleared output (the kernel's work area is reused) */
     n = g_ltz_sub ? zb_encode_piece_sub(&in, &sc, sh, 0, g_ltz_last_sub) : zb_encode_block(&in, &sc, sh, 0);
     if (n)
         memcpy(out, sc.out, n);
