@@ -2426,36 +2426,71 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
     }
 
     ZB_MARK(7);
-    /* ---- phase 7: sequence bit-streams, last sequence first: one sequence per lane and step ---- */
-    for (uint32_t u = 0; u < nunits; ++u)
+    /* ---- phase 7: sequence bit-streams, last sequence first: one sequence per lane and step.  The steps of ALL units form one list
+     * and the records of the step after the current one are loaded before the current one is worked on: a step is a round trip to
+     * memory, and with one wave per piece nothing else hides it (17 % of the kernel's wave time were these loads, one step at a
+     * time). ---- */
     {
-        const uint32_t b0 = sh->useq_base[u], ns = sh->useq_base[u + 1u] - b0;
-        if (ns && sb->lmode[u] != 4u)
+        uint32_t nu = 0, ndone = 0; /* the step whose records are on their way */
+        uint64_t nq = 0, ntr = 0;
+        uint32_t first_bit = 0, running = 0;
+        while (nu < nunits && !(sh->useq_base[nu + 1u] > sh->useq_base[nu] && sb->lmode[nu] != 4u))
+            ++nu;
+        if (nu < nunits)
         {
-            const uint32_t first_bit = sb->seqpos[u] * 8u;
-            uint32_t running = first_bit;
-            zb_stage_open(stg, zl);
-            for (uint32_t done = 0; done < ns; done += ZB_LANES)
+            const uint32_t b0 = sh->useq_base[nu], ns = sh->useq_base[nu + 1u] - b0;
+            if (zl < ns)
+            {
+                nq = sc->seqs[b0 + ns - 1u - zl];
+                ntr = zl ? ((const uint64_t*)sc->sbits)[b0 + ns - 1u - zl] : 0u;
+            }
+        }
+        while (nu < nunits)
+        {
+            const uint32_t u = nu, done = ndone;
+            const uint32_t b0 = sh->useq_base[u], ns = sh->useq_base[u + 1u] - b0;
+            const uint64_t q = nq, tr = ntr;
+            /* the next step: of this unit, or the first of the next unit that has a sequence stream */
+            ndone += ZB_LANES;
+            if (ndone >= ns)
+            {
+                ndone = 0;
+                ++nu;
+                while (nu < nunits && !(sh->useq_base[nu + 1u] > sh->useq_base[nu] && sb->lmode[nu] != 4u))
+                    ++nu;
+            }
+            nq = 0;
+            ntr = 0;
+            if (nu < nunits)
+            {
+                const uint32_t nb0 = sh->useq_base[nu], nns = sh->useq_base[nu + 1u] - nb0, nr = ndone + zl;
+                if (nr < nns)
+                {
+                    nq = sc->seqs[nb0 + nns - 1u - nr];
+                    ntr = nr ? ((const uint64_t*)sc->sbits)[nb0 + nns - 1u - nr] : 0u; /* (zero for a table in RLE mode) */
+                }
+            }
+            if (done == 0u)
+            {
+                first_bit = sb->seqpos[u] * 8u;
+                running = first_bit;
+                zb_stage_open(stg, zl);
+            }
             {
                 const uint32_t r = done + zl;
                 uint32_t bits = 0, llx = 0, mlx = 0, ofx = 0, oc = 0, lb = 0, mb = 0, so = 0, sm = 0, sl = 0;
                 if (r < ns)
                 {
-                    const uint32_t n = b0 + ns - 1u - r;
-                    const uint64_t q = sc->seqs[n];
                     llx = ZP_LLX(q);
                     mlx = ZP_MLX(q);
                     ofx = ZP_OFX(q);
                     oc = ZP_OC(q);
                     lb = ((const uint8_t*)sh->cursor[0])[ZP_LC(q)];
                     mb = ((const uint8_t*)sh->cursor[1])[ZP_MC(q)];
-                    if (r) /* every sequence but the block's last one updates the states: OF, ML, LL (read back as LL, ML, OF) */
-                    {
-                        const uint64_t tr = ((const uint64_t*)sc->sbits)[n]; /* (zero for a table in RLE mode) */
-                        sl = (uint32_t)tr & 0xFFFFu;
-                        so = (uint32_t)(tr >> 16) & 0xFFFFu;
-                        sm = (uint32_t)(tr >> 32) & 0xFFFFu;
-                    }
+                    /* every sequence but the block's last one updates the states: OF, ML, LL (read back as LL, ML, OF) */
+                    sl = (uint32_t)tr & 0xFFFFu;
+                    so = (uint32_t)(tr >> 16) & 0xFFFFu;
+                    sm = (uint32_t)(tr >> 32) & 0xFFFFu;
                     bits = (so >> 10) + (sm >> 10) + (sl >> 10) + lb + mb + oc;
                 }
                 {
@@ -2478,7 +2513,8 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
                     running += total;
                 }
             }
-            zb_stage_close(stg, sc->out, running, zl);
+            if (done + ZB_LANES >= ns)
+                zb_stage_close(stg, sc->out, running, zl);
         }
     }
     ZB_SYNC();
