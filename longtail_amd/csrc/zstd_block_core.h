@@ -2101,30 +2101,83 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
     /* ---- phase 3: bits of every literal stream: a unit's literals are one stream below 256 of them, else four (three of
      * ceil(n / 4), the last takes the rest) ---- */
     if (sh->v[ZV_HUF_OK])
-        for (uint32_t u = 0; u < nunits; ++u)
+    {
+        /* the literal quads of all units as one list, two quads per lane and trip (as in the histogram of phase 1: word by word and
+         * unit by unit a piece made 224 round trips to memory here, one after the other) */
+        uint16_t* const qbase = (uint16_t*)sh->small; /* [nunits + 1] <= 33 of the 64 entries (the serial builders' scratch) */
+        ZB_SERIAL(zl)
         {
-            const uint32_t n = sh->ulit_base[u + 1u] - sh->ulit_base[u];
-            const uint32_t seg = n < 256u ? n : (n + 3u) >> 2;
-            ZB_PAR_FOR(j, (n + 3u) >> 2)
+            uint32_t acc = 0;
+            for (uint32_t u = 0; u < nunits; ++u)
             {
-                const uint32_t w = zb_unit_word(in, srcmask, u, j, n);
-                const uint32_t k = n - 4u * j < 4u ? n - 4u * j : 4u;
-                uint32_t q = (4u * j >= seg) + (4u * j >= 2u * seg) + (4u * j >= 3u * seg), bits = 0;
-                for (uint32_t b = 0; b < k; ++b)
+                qbase[u] = (uint16_t)acc;
+                acc += (sh->ulit_base[u + 1u] - sh->ulit_base[u] + 15u) >> 4;
+            }
+            qbase[nunits] = (uint16_t)acc;
+        }
+        ZB_SYNC_LDS();
+        const uint32_t nquads = qbase[nunits];
+        ZB_PAR_FOR_K(t2, nquads, 2u)
+        {
+            uint32_t w[2][4], un[2], uu[2], w0s[2];
+            ZB_UNROLL
+            for (uint32_t qd = 0; qd < 2u; ++qd)
+            {
+                const uint32_t g = t2 * 2u * ZB_LANES + qd * ZB_LANES + zl;
+                uint32_t lo = 0;
+                ZB_UNROLL
+                for (uint32_t st = ZB_MAX_UNITS / 2u; st; st >>= 1)
+                    if (lo + st < nunits && (uint32_t)qbase[lo + st] <= g)
+                        lo += st;
+                un[qd] = 0;
+                uu[qd] = lo;
+                w0s[qd] = 0;
+                ZB_UNROLL
+                for (uint32_t k = 0; k < 4u; ++k)
+                    w[qd][k] = 0;
+                if (g < nquads)
                 {
-                    const uint32_t ib = 4u * j + b;
-                    const uint32_t qb = (ib >= seg) + (ib >= 2u * seg) + (ib >= 3u * seg);
-                    if (qb != q)
-                    {
-                        zb_atomic_add(&strbits[4u * u + q], bits);
-                        bits = 0;
-                        q = qb;
-                    }
-                    bits += sh->huf_len[(w >> (8u * b)) & 255u];
+                    const uint32_t n = sh->ulit_base[lo + 1u] - sh->ulit_base[lo], w0 = 4u * (g - qbase[lo]);
+                    un[qd] = n;
+                    w0s[qd] = w0;
+                    ZB_UNROLL
+                    for (uint32_t k = 0; k < 4u; ++k)
+                        if (4u * (w0 + k) < n)
+                            w[qd][k] = zb_unit_word(in, srcmask, lo, w0 + k, n);
                 }
-                zb_atomic_add(&strbits[4u * u + q], bits);
+            }
+            ZB_UNROLL
+            for (uint32_t qd = 0; qd < 2u; ++qd)
+            {
+                const uint32_t n = un[qd], u = uu[qd];
+                const uint32_t seg = n < 256u ? n : (n + 3u) >> 2;
+                ZB_UNROLL
+                for (uint32_t kw = 0; kw < 4u; ++kw)
+                {
+                    const uint32_t j = w0s[qd] + kw;
+                    if (4u * j < n)
+                    {
+                        const uint32_t wv = w[qd][kw];
+                        const uint32_t k = n - 4u * j < 4u ? n - 4u * j : 4u;
+                        uint32_t q = (4u * j >= seg) + (4u * j >= 2u * seg) + (4u * j >= 3u * seg), bits = 0;
+                        for (uint32_t b = 0; b < k; ++b)
+                        {
+                            const uint32_t ib = 4u * j + b;
+                            const uint32_t qb = (ib >= seg) + (ib >= 2u * seg) + (ib >= 3u * seg);
+                            if (qb != q)
+                            {
+                                zb_atomic_add(&strbits[4u * u + q], bits);
+                                bits = 0;
+                                q = qb;
+                            }
+                            bits += sh->huf_len[(wv >> (8u * b)) & 255u];
+                        }
+                        zb_atomic_add(&strbits[4u * u + q], bits);
+                    }
+                }
             }
         }
+    }
 
     ZB_MARK(4);
     /* ---- phase 4: the FSE state chains, last sequence first.  A chain is serial: every unit's three chains run on the unit's
@@ -2138,13 +2191,23 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
             const uint32_t tl_l = sh->table_log[ZT_LL], tl_o = sh->table_log[ZT_OF], tl_m = sh->table_log[ZT_ML];
             const uint32_t c_l = sh->mode[ZT_LL] != 1u, c_o = sh->mode[ZT_OF] != 1u, c_m = sh->mode[ZT_ML] != 1u;
             uint32_t x_l = 0, x_o = 0, x_m = 0, bits = sh->carry[u], n = e0; /* (the extra bits were added up in phase 1) */
+            uint64_t qn[8]; /* the eight sequences after the ones being worked on: loaded a batch ahead (the lane waited a round trip
+                             * to memory per batch) */
+            ZB_UNROLL
+            for (uint32_t j = 0; j < 8u; ++j)
+                qn[j] = j < n - b0 ? sc->seqs[n - 1u - j] : 0u;
             while (n > b0)
             {
                 uint64_t q[8], tr[8]; /* the steps' transition bits: stored eight at a time, one 64-byte run per lane (three 2-byte
                                        * stores per step and lane were 96 partial cache lines per wave and step: half of "tokens"' time) */
                 const uint32_t cnt = n - b0 < 8u ? n - b0 : 8u;
+                ZB_UNROLL
                 for (uint32_t j = 0; j < 8u; ++j)
-                    q[j] = j < cnt ? sc->seqs[n - 1u - j] : 0u;
+                    q[j] = qn[j];
+                ZB_UNROLL
+                for (uint32_t j = 0; j < 8u; ++j)
+                    qn[j] = cnt + j < n - b0 ? sc->seqs[n - cnt - 1u - j] : 0u;
+                ZB_UNROLL
                 for (uint32_t j = 0; j < 8u; ++j)
                 {
                     tr[j] = 0;
