@@ -272,6 +272,45 @@ def test_zstd_entropy_stage_is_bit_exact_with_host_model(gpu, oracle, zmode):
     assert _check_against_model(gpu, d, blocks, frames) >= 10
 
 
+def test_zstd_table_builders_all_lanes_equal_the_serial_ones(gpu, oracle, ref, zmode):
+    """The kernel builds the Huffman code and the three FSE tables with all lanes (zb_huffman_build_par, zb_normalize_par,
+    zb_build_enc_table_par), the one-lane host model with the serial builders: literal and sequence statistics that reach the
+    builders' corners -- two literal symbols, all 256 equally often, geometric counts (depths far above 11: the length limit and
+    the FSE-compressed tree description), a single literal value with rare others; sequences with one code only (RLE tables),
+    with a few (predefined tables: the "less than one" cells), and with many distinct lengths and offsets -- must give the same
+    bytes as the model and decode with the reference."""
+    d = _model_src(oracle)
+    rng = np.random.default_rng(77)
+    n = 262144 + 4096 + 37
+    two = rng.integers(0, 2, n).astype(np.uint8) * 200 + 7
+    flat = rng.permutation(np.arange(n, dtype=np.int64) % 256).astype(np.uint8)
+    geo = np.minimum(rng.geometric(0.5, n) - 1, 60).astype(np.uint8) * 3 + 1  # P(k) ~ 2^-k: Huffman depths up to ~18
+    geo_hi = (255 - np.minimum(rng.geometric(0.35, n) - 1, 200)).astype(np.uint8)  # > 128 weights: FSE-compressed tree
+    rare = np.full(n, 65, np.uint8)
+    rare[rng.integers(0, n, 300)] = rng.integers(0, 256, 300).astype(np.uint8)
+    # sequences: a 16-byte record repeated with one random byte in between (one match length, one literal length: RLE tables);
+    # a handful of sequences per piece (predefined tables); matches of many lengths at many distances
+    rec = rng.integers(0, 256, 16).astype(np.uint8)
+    same = np.concatenate([np.concatenate([rec, rng.integers(0, 256, 1).astype(np.uint8)]) for _ in range(n // 17)])
+    few = rng.integers(0, 256, n).astype(np.uint8)
+    for k in range(0, n - 70000, 65536):
+        few[k + 5000 : k + 5040] = few[k + 100 : k + 140]
+    varied = rng.integers(0, 256, n).astype(np.uint8)
+    pos = 3000
+    while pos + 400 < n:
+        ln = int(rng.integers(4, 300))
+        src = int(rng.integers(max(0, pos - 60000), pos - ln)) if pos - ln > 0 else 0
+        varied[pos : pos + ln] = varied[src : src + ln]
+        pos += ln + int(rng.integers(1, 40))
+    blocks = [two, flat, geo, geo_hi, rare, same, few, varied]
+    frames = gpu_zstd(gpu, blocks)
+    assert _check_against_model(gpu, d, blocks, frames) >= 12
+    for b, f in zip(blocks, frames):
+        err, out = ref.decompress(1, f, len(b))
+        assert err == 0 and (out == b).all()
+    assert len(frames[0]) < n // 2 and len(frames[4]) < n // 20  # (two symbols; one symbol with rare others)
+
+
 def test_zstd_unaligned_sources_and_literals_read_from_the_source(gpu, oracle, ref, zmode):
     """Units without a sequence keep their literals in the source (no copy by the match finder), wherever the block lies:
     blocks at odd device offsets, with entropy-codable literals but no matches (Huffman from the source), noise (sampled
