@@ -2255,6 +2255,19 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
             ZB_UNROLL
             for (uint32_t q = 0; q < 2u; ++q)
             {
+                if (nb[q] >= 16u) /* a whole quad (all but a unit's last one): no byte is questioned */
+                {
+                    ZB_UNROLL
+                    for (uint32_t k = 0; k < 4u; ++k)
+                    {
+                        const uint32_t v = w[q][k];
+                        zb_atomic_add(&sh->lit_hist[v & 255u], 1u);
+                        zb_atomic_add(&sh->lit_hist[(v >> 8) & 255u], 1u);
+                        zb_atomic_add(&sh->lit_hist[(v >> 16) & 255u], 1u);
+                        zb_atomic_add(&sh->lit_hist[v >> 24], 1u);
+                    }
+                    continue;
+                }
                 ZB_UNROLL
                 for (uint32_t k = 0; k < 4u; ++k)
                 {
@@ -2404,6 +2417,23 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
             {
                 const uint32_t n = un[qd], u = uu[qd];
                 const uint32_t seg = n < 256u ? n : (n + 3u) >> 2;
+                {
+                    /* a whole quad inside ONE stream (nearly all of them): sixteen code lengths, one addition to the stream's total */
+                    const uint32_t b0 = 4u * w0s[qd], b1 = b0 + 15u;
+                    const uint32_t q0 = (b0 >= seg) + (b0 >= 2u * seg) + (b0 >= 3u * seg), q1 = (b1 >= seg) + (b1 >= 2u * seg) + (b1 >= 3u * seg);
+                    if (b1 < n && q0 == q1)
+                    {
+                        uint32_t bits = 0;
+                        ZB_UNROLL
+                        for (uint32_t kw = 0; kw < 4u; ++kw)
+                        {
+                            const uint32_t wv = w[qd][kw];
+                            bits += (uint32_t)sh->huf_len[wv & 255u] + sh->huf_len[(wv >> 8) & 255u] + sh->huf_len[(wv >> 16) & 255u] + sh->huf_len[wv >> 24];
+                        }
+                        zb_atomic_add(&strbits[4u * u + q0], bits);
+                        continue;
+                    }
+                }
                 ZB_UNROLL
                 for (uint32_t kw = 0; kw < 4u; ++kw)
                 {
