@@ -2723,21 +2723,30 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
             {
                 const uint32_t s0 = st * seg, s1 = st + 1u == nstr ? n : s0 + seg;
                 const uint32_t first_bit = base * 8u;
-                uint32_t running = first_bit, cw = 0, cwi = 0xFFFFFFFFu;
+                uint32_t running = first_bit;
                 zb_stage_open(stg, zl);
                 for (uint32_t done = 0; done < s1 - s0; done += 4u * ZB_LANES)
                 {
                     uint64_t acc = 0;
                     uint32_t nb = 0;
-                    for (uint32_t j = 0; j < 4u; ++j)
+                    const uint32_t r0 = done + 4u * zl;
+                    if (r0 < s1 - s0)
                     {
-                        const uint32_t r = done + 4u * zl + j;
-                        if (r < s1 - s0)
-                        {
-                            const uint32_t sy = zb_unit_byte(in, srcmask, u, s1 - 1u - r, n, &cw, &cwi);
-                            acc |= (uint64_t)sh->huf_code[sy] << nb;
-                            nb += sh->huf_len[sy];
-                        }
+                        /* my (up to) four literals, the highest index first: they lie in one or two words, both loaded at once (a
+                         * load per byte that leaves the cached word made two dependent round trips of them) */
+                        const uint32_t k4 = s1 - s0 - r0 < 4u ? s1 - s0 - r0 : 4u;
+                        const uint32_t hi_idx = s1 - 1u - r0, lo_idx = hi_idx + 1u - k4;
+                        const uint32_t whi = zb_unit_word(in, srcmask, u, hi_idx >> 2, n);
+                        const uint32_t wlo = (lo_idx >> 2) != (hi_idx >> 2) ? zb_unit_word(in, srcmask, u, lo_idx >> 2, n) : whi;
+                        ZB_UNROLL
+                        for (uint32_t j = 0; j < 4u; ++j)
+                            if (j < k4)
+                            {
+                                const uint32_t idx = hi_idx - j;
+                                const uint32_t sy = (((idx >> 2) == (hi_idx >> 2) ? whi : wlo) >> (8u * (idx & 3u))) & 255u;
+                                acc |= (uint64_t)sh->huf_code[sy] << nb;
+                                nb += sh->huf_len[sy];
+                            }
                     }
                     {
                         uint32_t total;
