@@ -13,7 +13,8 @@
 // A skippable frame at the end carries the directory of block sizes (sub-block layout) or just says that the pieces are
 // independent of each other (one block per piece): see z_write_trailer / z_write_trailer2_head.
 // The reference's ZSTD_decompressDCtx (lib/zstd/longtail_zstd.c:144-177) decodes these like any other frame; the
-// settings ('ztd1'..'ztd5', longtail_zstd.c:12-22) select nothing here: there is one parse.
+// settings ('ztd1'..'ztd5', longtail_zstd.c:12-22) select one of three parses of the match finder (k_lz4.hip: default, history
+// halves, + re-read after inserts; lthip_zstd_quality_of_settings) -- the entropy stage below is the same for all of them.
 #include "lthip_internal.h"
 
 #include <type_traits>

@@ -1461,7 +1461,7 @@ ZB_FN uint32_t zb_encode_block(const ZbInput* in, const ZbScratch* sc, ZbShared*
     ZB_SYNC();
 
     ZB_MARK(2);
-    /* ---- phase 2: Huffman code for the literals (lane 0), FSE tables for the three symbol types (lanes 0..2) ---- */
+    /* ---- phase 2: Huffman code for the literals, FSE tables for the three symbol types (with a wave: by all lanes) ---- */
     ZB_SERIAL(zl)
     {
         /* Is it worth going on?  Literals whose most frequent byte is as rare as in noise stay raw (the test zstd's
@@ -2287,8 +2287,9 @@ ZB_FN uint32_t zb_encode_piece_sub(const ZbInput* in, const ZbScratch* sc, ZbSha
     ZB_SYNC();
 
     ZB_MARK(2);
-    /* ---- phase 2: Huffman code for the literals (lane 0), FSE tables for the three symbol types (lanes 0..2): as in
-     * zb_encode_block, from the statistics of the whole piece ---- */
+    /* ---- phase 2: Huffman code for the literals, FSE tables for the three symbol types: as in zb_encode_block, from the statistics
+     * of the whole piece (with a wave: by all lanes -- zb_huffman_build_par, zb_build_seq_tables; the one-lane build runs the serial
+     * builders and must produce the same tables) ---- */
     ZB_SERIAL(zl)
     {
         uint32_t largest = 0;
