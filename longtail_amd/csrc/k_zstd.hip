@@ -2839,6 +2839,134 @@ __device__ __forceinline__ void zx_batch(ZxOut& zx, uint8_t* s_ring, uint8_t* s_
     produced += batch_adv;
 }
 
+// The sequence bit-stream of ONE block of another encoder's frame on the SCALAR unit (a wave per block): what k_zstd_blk_sequences does
+// with a lane per block -- same tables (the block's packed tables in the table arena), same records, same verdicts -- for calls with so
+// few blocks that a block's chain of sequences IS the call's time: ONE reference-made 8 MiB frame has 64 blocks of up to 16 000
+// sequences each; a lane walks them at 0.42 us a sequence (~150 dependent vector instructions), the scalar unit at about half of that
+// (the state machine of k_zstd_execute<false>: entries by s_load from the scalar cache, two 64-bit accumulators, every sequence dropped
+// into its lane with v_writelane, the records leave 64 at a time).  Worth it while a CU's scalar pipe serves one or two such waves.
+__global__ __launch_bounds__(64) void k_zstd_blk_seq_scalar(const uint8_t* __restrict__ src, const ZItem* __restrict__ fitems, const uint32_t* __restrict__ slist,
+                                                           const uint32_t* __restrict__ scount, const uint64_t* __restrict__ tabs,
+                                                           uint64_t* __restrict__ rec_scratch, ZPrep* __restrict__ fprep, uint32_t* __restrict__ retry)
+{
+    const uint32_t g = blockIdx.x;
+    if (g >= *scount)
+        return;
+    const uint32_t i = slist[g];
+    const ZItem it = fitems[i];
+    if (it.kind != 4u)
+        return;
+    const ZPrep pr = fprep[i];
+    if (!(pr.status == ZP_READY && pr.log[0] == 0u && pr.nbseq != 0u))
+        return;
+    const int lane = threadIdx.x;
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tabs + (uint64_t)g * 1280u); // LL at 0, ML at 512, OF at 1024 entries of 8 bytes
+    const uint64_t at = it.src_off + pr.seq_off;
+    const uint32_t ssize = zx_u(pr.seq_size), nbseq = zx_u(pr.nbseq);
+    const uint32_t log_l = zx_u(pr.log[1] & 255u), log_o = zx_u((pr.log[1] >> 8) & 255u), log_m = zx_u((pr.log[1] >> 16) & 255u);
+    uint64_t* recs = rec_scratch + pr.rec_at;
+    bool bad = false;
+    uint32_t sum_ll = 0, sum_ml = 0;
+    ZxBits br;
+    br.arena = reinterpret_cast<const uint32_t*>(src - ((uintptr_t)src & 3u));
+    br.base = at * 8ull + 8ull * ((uintptr_t)src & 3u);
+    br.pos = 0;
+    br.lo = br.hi = br.acc = 0;
+    br.wbit0 = 0;
+    br.rel = 0;
+    if (ssize == 0u)
+        bad = true;
+    else
+    {
+        const uint32_t last = zx_u((uint32_t)src[at + ssize - 1u]);
+        if (last == 0u)
+            bad = true;
+        else
+            br.pos = (ssize - 1u) * 8u + (31u - (uint32_t)__builtin_clz(last));
+    }
+    uint32_t sl = 0, so = 0, sm = 0; // byte offsets into tb
+    if (!bad)
+    {
+        if (log_l + log_o + log_m > br.pos)
+            bad = true;
+        else
+        {
+            br.load_window();
+            br.normalize();
+            sl = br.take(log_l) * 8u;
+            so = (1024u + br.take(log_o)) * 8u;
+            sm = (512u + br.take(log_m)) * 8u;
+        }
+    }
+    for (uint32_t s0 = 0; s0 < nbseq && !bad; s0 += 64u)
+    {
+        const uint32_t cnt = nbseq - s0 < 64u ? nbseq - s0 : 64u;
+        uint32_t r_ll = 0, r_ml = 0, r_off = 0;
+        for (uint32_t k = 0; k < cnt; ++k)
+        {
+            const uint2 ql = *reinterpret_cast<const uint2*>(tb + sl), qo = *reinterpret_cast<const uint2*>(tb + so),
+                        qm = *reinterpret_cast<const uint2*>(tb + sm);
+            const uint32_t l0 = zx_u(ql.x), o0 = zx_u(qo.x), m0 = zx_u(qm.x);
+            const uint32_t ob = o0 >> 24, mb = m0 >> 24, lb = l0 >> 24;
+            const uint32_t nbl = (l0 >> 16) & 255u, nbm = (m0 >> 16) & 255u, nbo = (o0 >> 16) & 255u;
+            const bool more = s0 + k + 1u < nbseq;
+            const uint32_t n1 = ob + mb + lb, n2 = more ? nbl + nbm + nbo : 0u; // <= 63, <= 26
+            if (n1 + n2 > br.pos)
+            {
+                bad = true; // the stream runs out
+                break;
+            }
+            br.ensure_window();
+            br.normalize();
+            const uint32_t ov = zx_u(qo.y) + br.take(ob);
+            const uint32_t t2 = br.take(mb + lb); // match-length and literal-length extra bits are adjacent
+            const uint32_t ml = zx_u(qm.y) + (t2 >> lb);
+            const uint32_t ll = zx_u(ql.y) + (t2 & ((1u << lb) - 1u));
+            if (more)
+            {
+                if (n1 + n2 > 64u)
+                    br.normalize();
+                const uint32_t t3 = br.take(n2); // LL, ML, OF from the top
+                sl = ((l0 & 0xFFFFu) + (t3 >> (nbm + nbo))) * 8u;
+                sm = (512u + (m0 & 0xFFFFu) + ((t3 >> nbo) & ((1u << nbm) - 1u))) * 8u;
+                so = (1024u + (o0 & 0xFFFFu) + (t3 & ((1u << nbo) - 1u))) * 8u;
+            }
+            sum_ll += ll;
+            sum_ml += ml;
+            {
+                const uint32_t a = zx_u(ll), b = zx_u(ml), c = zx_u(ov), kk = zx_u(k);
+                uint32_t keep;
+                asm volatile("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %7\n\ts_nop 4\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\t"
+                             "v_writelane_b32 %2, %6, m0\n\ts_mov_b32 m0, %3"
+                             : "+v"(r_ll), "+v"(r_ml), "+v"(r_off), "=&s"(keep)
+                             : "s"(a), "s"(b), "s"(c), "s"(kk));
+            }
+        }
+        if (!bad)
+        {
+            const bool mine = (uint32_t)lane < cnt;
+            if (__builtin_amdgcn_ballot_w64(mine && r_off >= (1u << 24)))
+                bad = true; // (as zs_seq_lanes: an offset value the record cannot hold)
+            if (mine)
+                recs[s0 + (uint32_t)lane] = (uint64_t)r_ll | ((uint64_t)r_ml << 20) | ((uint64_t)r_off << 40);
+        }
+    }
+    if (!bad && br.pos != 0u)
+        bad = true; // the bit-stream must be consumed exactly
+    if (!bad && (sum_ll > pr.nlit || pr.nlit + sum_ml > ZB))
+        bad = true;
+    if (lane == 0)
+    {
+        if (bad)
+        {
+            fprep[i].status = ZP_SERIAL;
+            retry[it.payload] = __LINE__;
+        }
+        else
+            fprep[i].expect = pr.nlit + sum_ml; // what the block regenerates
+    }
+}
+
 // RECS: the sequences come as records {literal length:20 | match length:20 | offset value:24} from k_zstd_sub_entropy (`tables` is
 // then the record array, ZREC_MAX per slot) instead of from the bit-stream; everything after that is the same.
 template <bool RECS>
@@ -3790,7 +3918,13 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
             if ((err = lthip_scratch(ctx, S_Z_SUB, (size_t)rec_cap * 8u, &d_frecs)))
                 return err;
             const uint32_t n = (uint32_t)f_blocks;
-            const uint32_t inline_seqs = n <= 4u * nwg ? 1u : 0u; // (few blocks: their sequences on the block's own wave)
+            // few blocks: their sequences on the block's own wave; VERY few (a wave or two per CU: one to eight frames of 8 MiB): on the
+            // scalar unit of a wave of their own, which walks a block's chain of sequences twice as fast as a lane (LTHIP_ZSTD_SEQ_SCALAR=0: off)
+            static LthipEnvInt env_scal{"LTHIP_ZSTD_SEQ_SCALAR"};
+            int ncu = 256;
+            (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+            const bool scalar_seqs = env_scal.get() != 0 && (n <= 2u * (uint32_t)ncu || env_scal.get() == 2); // (2: always -- tests)
+            const uint32_t inline_seqs = !scalar_seqs && n <= 4u * nwg ? 1u : 0u;
             void* d_ftabs;
             if ((err = lthip_scratch(ctx, S_Z_RECS, (size_t)n * 1280u * 8u, &d_ftabs))) // (10 KiB of packed tables per block)
                 return err;
@@ -3798,7 +3932,10 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
                                (const uint32_t*)d_flist, n, d_slist, d_scount, (uint8_t*)d_flits, (uint64_t*)d_frecs, d_fprep, d_retry, d_ftickets, d_bump,
                                lit_cap, rec_cap, (uint64_t*)d_ftabs, inline_seqs);
             LTHIP_LAUNCH_CHECK(ctx);
-            if (!inline_seqs)
+            if (scalar_seqs)
+                hipLaunchKernelGGL(k_zstd_blk_seq_scalar, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZItem*)d_fitems,
+                                   (const uint32_t*)d_slist, (const uint32_t*)d_scount, (const uint64_t*)d_ftabs, (uint64_t*)d_frecs, d_fprep, d_retry);
+            else if (!inline_seqs)
             hipLaunchKernelGGL(k_zstd_blk_sequences, dim3((n + 63u) / 64u), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZItem*)d_fitems,
                                (const uint32_t*)d_slist, (const uint32_t*)d_scount, (const uint64_t*)d_ftabs, (uint64_t*)d_frecs, d_fprep, d_retry);
             LTHIP_LAUNCH_CHECK(ctx);

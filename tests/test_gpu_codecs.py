@@ -591,17 +591,27 @@ def test_zstd_reference_frames_block_parallel_is_the_serial_decoder(gpu, oracle,
     assert n_pay == clean and n_back == 0 and n_blocks >= sum((len(t) + 131071) // 131072 for t in truth[:clean])  # none went the serial way
     assert all(o is not None and (o == t).all() for o, t in zip(clean_out, truth[:clean]))
     fast = gpu_zstd_decode(gpu, frames, caps)
-    monkeypatch.setenv("LTHIP_ZSTD_DBG", "1")
+    # the sequences of a call with few blocks are walked by the scalar unit (k_zstd_blk_seq_scalar): forced here for all of them, and
+    # switched off, so that both ways see the damaged frames too
+    monkeypatch.setenv("LTHIP_ZSTD_SEQ_SCALAR", "2")
     gpu.lib.dll.lthip_debug_reload_env()  # (the library caches its switches)
+    scalar = gpu_zstd_decode(gpu, frames, caps)
+    monkeypatch.setenv("LTHIP_ZSTD_SEQ_SCALAR", "0")
+    gpu.lib.dll.lthip_debug_reload_env()
+    lanes = gpu_zstd_decode(gpu, frames, caps)
+    monkeypatch.delenv("LTHIP_ZSTD_SEQ_SCALAR")
+    monkeypatch.setenv("LTHIP_ZSTD_DBG", "1")
+    gpu.lib.dll.lthip_debug_reload_env()
     serial = gpu_zstd_decode(gpu, frames, caps)
     monkeypatch.delenv("LTHIP_ZSTD_DBG")
     gpu.lib.dll.lthip_debug_reload_env()
-    for i, (f_out, s_out, t) in enumerate(zip(fast, serial, truth)):
-        if t is not None:
-            assert f_out is not None and len(f_out) == len(t) and (f_out == t).all(), i
-        assert (f_out is None) == (s_out is None), i
-        if f_out is not None:
-            assert len(f_out) == len(s_out) and (f_out == s_out).all(), i
+    for way in (fast, scalar, lanes):
+        for i, (f_out, s_out, t) in enumerate(zip(way, serial, truth)):
+            if t is not None:
+                assert f_out is not None and len(f_out) == len(t) and (f_out == t).all(), i
+            assert (f_out is None) == (s_out is None), i
+            if f_out is not None:
+                assert len(f_out) == len(s_out) and (f_out == s_out).all(), i
     assert sum(o is None for o in fast[clean:]) > 50  # the damage is really detected
 
 
