@@ -2918,6 +2918,26 @@ uint64_t lthip_codec_batch_bytes()
     return v;
 }
 
+// Budget (MiB) of the arena the restore paths execute dependent payloads on ORIGINS in (4 bytes per byte of output of the payloads in
+// flight; k_lz4_decode.hip, k_zstd.hip).  The payloads of a call go through it in rounds, one small launch per unit row and round: 512
+// sliding-window LZ4 blocks of 8 MiB take 25.2 ms with 4 GiB (four rounds), 21.7 with 8, 20.1 with 16 (one round).  An explicit
+// setting (LTHIP_LZ4_ORG_MIB / LTHIP_ZSTD_ORG_MIB) wins; otherwise a quarter of what the device has free when the question is first
+// asked, between 4 and 16 GiB.
+uint64_t lthip_origin_budget_mib(int explicit_mib)
+{
+    if (explicit_mib > 0)
+        return (uint64_t)explicit_mib;
+    static const uint64_t v = [] {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+            return (uint64_t)4096;
+        uint64_t mib = (uint64_t)(free_b >> 20) / 4u;
+        mib = mib < 4096u ? 4096u : mib > 16384u ? 16384u : mib;
+        return mib;
+    }();
+    return v;
+}
+
 extern "C" int lthip_lz4_compress_blocks(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
                                          const uint32_t* src_sizes, void* d_dst, const uint64_t* dst_offsets,
                                          const uint32_t* dst_caps, uint32_t* d_out_sizes, int segment_log2)

@@ -2049,17 +2049,14 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     if (d_mode)
     {
         // units that were given up (a payload with a sliding window): on origins, as many blocks at a time as the arena's budget
-        // allows (4 bytes per byte of output; LTHIP_LZ4_ORG_MIB, default 4096).  The one place where this call waits for the device.
+        // allows (4 bytes per byte of output; LTHIP_LZ4_ORG_MIB, default: lthip_origin_budget_mib).  The one place where this call waits for the device.
         uint32_t given_up = 0;
         LTHIP_CHECK(ctx, hipMemcpyAsync(&given_up, d_cnt + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
         LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (given_up)
         {
-            static const uint64_t budget_units = [] {
-                const char* e = getenv("LTHIP_LZ4_ORG_MIB");
-                const int v = e ? atoi(e) : 0;
-                return ((uint64_t)(v > 0 ? v : 4096) << 20) / ((uint64_t)PD_UNIT * 4u);
-            }();
+            static LthipEnvInt env_org{"LTHIP_LZ4_ORG_MIB"};
+            const uint64_t budget_units = (lthip_origin_budget_mib(env_org.get()) << 20) / ((uint64_t)PD_UNIT * 4u);
             uint64_t most = 0;
             for (uint32_t g0 = 0; g0 < nb;)
             {

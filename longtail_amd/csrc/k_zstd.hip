@@ -3949,13 +3949,13 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
             else
             {
                 // execution on origins, all blocks at once; the origins (4 bytes per byte of output) of as many payloads at a time as
-                // the arena's budget allows (LTHIP_ZSTD_ORG_MIB, default 4096)
+                // the arena's budget allows (LTHIP_ZSTD_ORG_MIB, default: lthip_origin_budget_mib)
                 void *d_fr, *d_org;
                 if ((err = lthip_scratch(ctx, S_Z_FR, sizeof(ZFr) * nfslots, &d_fr)))
                     return err;
                 static LthipEnvInt env_org{"LTHIP_ZSTD_ORG_MIB"};
                 const int org_mib = env_org.get();
-                const uint64_t budget_items = ((uint64_t)(org_mib > 0 ? org_mib : 4096) << 20) / ((uint64_t)ZB * 4u);
+                const uint64_t budget_items = (lthip_origin_budget_mib(org_mib) << 20) / ((uint64_t)ZB * 4u);
                 uint64_t most = 0;
                 for (uint32_t p0 = 0; p0 < block_count;)
                 {

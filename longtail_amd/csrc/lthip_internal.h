@@ -166,6 +166,7 @@ int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out);
 int lthip_second_stream(lthip_ctx* ctx, hipStream_t* out);
 hipEvent_t lthip_sync_event(lthip_ctx* ctx);
 uint64_t lthip_codec_batch_bytes(); // input bytes per internal codec batch (LTHIP_BATCH_BYTES, default 8 GiB)
+uint64_t lthip_origin_budget_mib(int explicit_mib); // arena of the restore paths' execution on origins (k_lz4.hip)
 // Host table -> device without stalling the caller: the bytes are copied into one of a ring of pinned staging buffers and
 // queued on `stream`; `h_src` may be freed on return, and the host does not wait for earlier work of the stream (a
 // pageable hipMemcpyAsync + hipStreamSynchronize would wait for every kernel queued before it).
