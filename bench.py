@@ -429,8 +429,12 @@ class Bench:
         ing = Ingest(ctx, args.target_chunk_size, args.block_size, args.max_chunks_per_block, cfg["codec"], compression_type=ctype,
                      batch_bytes=batch_bytes)
         stats = {}
+        from longtail_amd.dist import StepProfile
+
+        xprof = {"host": 0.0, "device": 0.0, "transport": 0.0, "detail": {}, "steps": 0}
 
         def step():
+            prof = StepProfile(ctx) if (args.exchange_profile and world > 1) else None
             t0 = time.perf_counter()
             if new_plan:
                 step_plan = ctx.make_plan(p_off, p_size, mn, av, mx)
@@ -448,13 +452,15 @@ class Bench:
                 step_plan.close()
             t1 = time.perf_counter()
             if world > 1:
+                if prof:
+                    prof.start()
                 counts = out_first[1 : len(mine) + 1] - out_first[: len(mine)]
-                ex = exchange_chunks(part, counts, out_hash, out_lens, total, ctx, comm=self.comm, rank=rank)
+                ex = exchange_chunks(part, counts, out_hash, out_lens, total, ctx, comm=self.comm, rank=rank, prof=prof)
                 all_hash, all_lens, job_first = ex["hashes"], ex["lens"], ex["job_first"].astype(np.uint64)
                 my_jobs = mine
                 if args.dedup == "sharded":
                     # the first-seen table sharded by hash: this rank inserts its 1/N of the hash space, not every rank's chunks
-                    first_all, uniq_all = sharded_first_seen(part, ex, out_hash, total, ctx, comm=self.comm, rank=rank)
+                    first_all, uniq_all = sharded_first_seen(part, ex, out_hash, total, ctx, comm=self.comm, rank=rank, prof=prof)
                     ing.set_first_seen(first_all, uniq_all)
             else:
                 all_hash, all_lens = out_hash, out_lens
@@ -464,8 +470,17 @@ class Bench:
             t2 = time.perf_counter()
             tr, keep = Ingest.tree(tree["sizes"], tree["path_offsets"], tree["perms"], tree["path_data"], part.job_asset, job_first, my_jobs)
             t2b = time.perf_counter()
+            if prof:
+                prof.mark("host", "index: job / asset tables of the tree (O(jobs))")
             ing.index(tr, all_hash, all_lens, n_all, out_offs, out_first, total, h_vi)
             t3 = time.perf_counter()
+            if prof:
+                prof.mark("device", "index: lthip_ingest_index (first-seen compaction, ownership, packing of the first batch)")
+                for k in ("host", "device", "transport"):
+                    xprof[k] += prof.ms[k]
+                for k, v in prof.detail.items():
+                    xprof["detail"][k] = xprof["detail"].get(k, 0.0) + v
+                xprof["steps"] += 1
             if os.environ.get("LTHIP_BENCH_TRACE"):
                 print(f"step: chunk_hash {1e3*(t1-t0):.2f} first {1e3*(t2-t1):.2f} tree {1e3*(t2b-t2):.2f} index {1e3*(t3-t2b):.2f} ms", file=sys.stderr)
             if not args.no_compress:
@@ -482,10 +497,14 @@ class Bench:
         ctx.timing(True)
         ctx.timing_reset()
         phase = np.zeros(4)
+        xprof.update(host=0.0, device=0.0, transport=0.0, detail={}, steps=0)
+        step_ms = []
         self.barrier()
         t_start = time.perf_counter()
         for _ in range(steps):
-            step()
+            ts = time.perf_counter()
+            step()  # (ends with lthip_ingest_finish: the session's full synchronisation)
+            step_ms.append((time.perf_counter() - ts) * 1e3)
             phase += stats["t"]
         self.barrier()
         elapsed = time.perf_counter() - t_start
@@ -594,9 +613,21 @@ class Bench:
             which = " (BASELINE.json configs[2])" if world == 1 else " (BASELINE.json configs[3])"
         elif cfg["tree"] == "files" and cfg["codec"] == "zstd" and cfg["file_mib"] >= 16384:
             which = " (BASELINE.json configs[4] shape)"
+        exchange_profile = None
+        if xprof["steps"]:
+            k = xprof["steps"]
+            mx = self.reduce([xprof["host"] / k, xprof["device"] / k, xprof["transport"] / k], "max")
+            exchange_profile = {"what": "phase_ms.exchange + index of a PROFILED step (the device is waited for at every mark: a breakdown, slower "
+                                        "than the plain step), per step; max over ranks, and rank 0's items",
+                                "host_ms": round(mx[0], 3), "device_ms": round(mx[1], 3), "transport_ms": round(mx[2], 3),
+                                "rank0_detail_ms": {a: round(b / k, 3) for a, b in xprof["detail"].items()}}
+        sm = sorted(step_ms)
         return {
             "value": tree_bytes * steps / elapsed / 1e9,
             "ms_per_step": elapsed / steps * 1e3,
+            "ms_per_step_spread": {"min": round(sm[0], 3), "median": round(sm[len(sm) // 2], 3), "max": round(sm[-1], 3),
+                                   "note": "this rank's wall time of each timed step"},
+            "exchange_profile": exchange_profile,
             "workload": f"{label} {per}, CreateVersionIndex + CreateMissingContent + WriteContent, chunk+BLAKE3+{cfg['codec'].upper()}{zset}{which}",
             "tree_bytes": tree_bytes, "bytes_this_rank": my_bytes, "files": tree["nfiles"], "jobs": int(part.job_count),
             "jobs_this_rank": int(len(mine)), "min_avg_max": [mn, av, mx],
@@ -650,6 +681,9 @@ def main():
     ap.add_argument("--handshake-only", action="store_true",
                     help="plain launch only: id file + lthip_comm_create + barrier + reductions + one all-to-all, then a JSON line; no kernels")
     ap.add_argument("--cpu-gib", type=float, default=8.0, help="sample size of the CPU baseline")
+    ap.add_argument("--exchange-profile", action="store_true",
+                    help="N > 1: split the exchange + index phases of every step into host / device / transport time (waits for the device at "
+                         "every mark: a breakdown, not the metric; tools/exchange_cost.py)")
     args = ap.parse_args()
     if args.dry_run:
         print(json.dumps(dry_run(args)))
@@ -709,6 +743,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(main_res["ms_per_step"], 3),
+            "ms_per_step_spread": main_res["ms_per_step_spread"],
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -733,6 +768,8 @@ def main():
             "phase_ms": main_res["phase_ms"],
             "result": main_res["result"],
         }
+        if main_res.get("exchange_profile"):
+            line["exchange_profile"] = main_res["exchange_profile"]
         print(json.dumps(line))
     if b.world > 1 and not b.plain:
         b.dist.destroy_process_group()

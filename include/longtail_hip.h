@@ -52,8 +52,9 @@ LTHIP_EXPORT struct Longtail_CompressionAPI* Longtail_CompressionRegistry_Create
 LTHIP_EXPORT uint32_t Longtail_GetHipLZ4DefaultQuality(void);
 
 /* Replaces Longtail_CreateZStdCompressionAPI() / Longtail_CompressionRegistry_CreateForZstd()
- * (lib/zstd/longtail_zstd.h:10-16, longtail_zstd.c:30-41,72-177).  Type ids 'ztd1'..'ztd5' (one parse whatever the
- * setting).  Compress: one zstd frame per block -- RLE / Compressed (LZ sequences, Huffman literals, FSE sequences) / Raw
+ * (lib/zstd/longtail_zstd.h:10-16, longtail_zstd.c:30-41,72-177).  Type ids 'ztd1'..'ztd5'; the setting selects one of three
+ * parses (lthip_zstd_quality_of_settings: 'ztd1' / 'ztd2' default, 'ztd4' high, 'ztd3' / 'ztd5' max; unknown ids -> default, exactly
+ * like longtail_zstd.c:43-60).  Compress: one zstd frame per block -- RLE / Compressed (LZ sequences, Huffman literals, FSE sequences) / Raw
  * blocks -- that ZSTD_decompressDCtx decodes.  Decompress: any zstd frame(s) without a dictionary, e.g. the reference
  * encoder's; malformed input -> EINVAL (longtail_zstd.c:168-172). */
 LTHIP_EXPORT struct Longtail_CompressionAPI* Longtail_CreateHipZStdCompressionAPI(void);
@@ -104,6 +105,13 @@ LTHIP_EXPORT int lthip_device_count(void);
 /* Identity of the sources the library was built from: the first 16 hex digits of the sha256 tools/build_id.py computes over
  * longtail_amd/csrc/ and include/.  A test recomputes it from the tree, so a stale binary cannot pass for HEAD. */
 LTHIP_EXPORT const char* lthip_build_id(void);
+/* Version of the BINARY interface of section B: bumped whenever a struct of this header grows or changes layout, an enum value
+ * moves, or an entry point changes its signature (new entry points alone do not bump it).  An embedder built against this header
+ * checks  lthip_abi_version() == LTHIP_ABI_VERSION  once after loading the library.
+ *   1  rounds 1-3      2  round 4: lthip_ingest_result.gathered_bytes appended, LTHIP_K_COUNT 9 -> 10
+ *   3  round 5: lthip_ingest_result starts with struct_size (set by the caller; the library writes no more than that) */
+#define LTHIP_ABI_VERSION 3
+LTHIP_EXPORT int lthip_abi_version(void);
 
 /* Memory helpers so that plain-C callers (the plugin layer) need no HIP headers.  Copies are
  * asynchronous on the context's stream: lthip_ctx_sync() before reading a d2h destination. */
@@ -425,6 +433,7 @@ typedef struct lthip_ingest_tree
 } lthip_ingest_tree;
 typedef struct lthip_ingest_result
 {
+    uint64_t struct_size;                 /* IN: sizeof(lthip_ingest_result) of the caller's header; the library fills at most that */
     uint64_t chunks_all, unique_all;      /* chunks / distinct chunks of the whole tree */
     uint64_t chunks_local, unique_local;  /* chunks of this rank's jobs / those of them this rank writes */
     uint64_t blocks, raw_bytes, compressed_bytes, gathered_blocks;
@@ -477,6 +486,23 @@ LTHIP_EXPORT int lthip_partition_jobs(uint64_t job_count, const uint64_t* job_si
 LTHIP_EXPORT int lthip_exchange_layout(uint64_t job_count, const uint32_t* job_rank, uint32_t rank_count,
                                        const uint32_t* gathered_counts, uint64_t count_stride, uint64_t chunk_stride,
                                        uint64_t* job_src, uint64_t* job_dst /* job_count + 1 */, uint32_t* job_chunks /* may be NULL */);
+/* The layout as the device reorder wants it: runs of jobs that are contiguous on both sides merged (range policy: one run per rank),
+ * then cut into pieces of at most max_piece elements (a workgroup per piece).  Returns the number of pieces; out arrays NULL or
+ * capacity too small: count only.  Host function, O(jobs). */
+LTHIP_EXPORT uint64_t lthip_exchange_ranges(uint64_t job_count, const uint64_t* job_src, const uint64_t* job_dst,
+                                            const uint32_t* job_chunks, uint64_t max_piece, uint64_t capacity, uint64_t* out_src,
+                                            uint64_t* out_dst, uint32_t* out_cnt);
+/* Applies it on the device: d_out[range_dst[i] ..) = d_gathered[range_src[i] .. + range_cnt[i]) in elements of elem_bytes (host
+ * tables, staged through the context's pinned ring; asynchronous on the context's stream).  Every array of the exchange -- hashes,
+ * lengths, the first-seen answers -- goes through the same tables. */
+LTHIP_EXPORT int lthip_exchange_reorder(lthip_ctx* ctx, const void* d_gathered, void* d_out, uint32_t elem_bytes,
+                                        uint64_t range_count, const uint64_t* range_src, const uint64_t* range_dst,
+                                        const uint32_t* range_cnt);
+/* Positions of this rank's chunks in job order (what the sharded first-seen table is keyed with): d_out[k] = global_first[m] +
+ * (k - local_first[m]) for the own job m that holds local chunk k; local_first / global_first: host arrays of my_job_count entries,
+ * index of each own job's first chunk in the rank's own lists / in the tree's job-ordered lists. */
+LTHIP_EXPORT int lthip_job_ordinals(lthip_ctx* ctx, uint64_t my_job_count, const uint32_t* local_first, const uint32_t* global_first,
+                                    uint64_t local_chunks, uint32_t* d_out);
 
 /* The collective itself behind the C ABI (comm.hip): RCCL's all-gather on the context's stream, one process per GPU.  RCCL is
  * bound at run time (dlopen): ENOSYS where it is missing.  Rank 0 makes the 128-byte id, the embedder carries it to the other

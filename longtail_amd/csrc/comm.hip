@@ -75,7 +75,8 @@ struct ShmHeader
     std::atomic<uint32_t> arrived;    // barrier: ranks that reached it
     std::atomic<uint32_t> generation; // barrier: incremented by the last one to arrive
     std::atomic<uint32_t> attached;   // ranks that mapped the segment (the last one to leave unlinks it)
-    uint32_t pad[9];
+    std::atomic<uint32_t> broken;     // sticky: the errno of the first rank that timed out or failed locally; every later collective fails
+    uint32_t pad[8];
 };
 static_assert(sizeof(ShmHeader) == 64, "header is one cache line");
 // per rank: a table of 2 * nranks u64 (what an all-to-all sender tells its receivers) followed by the data slot
@@ -105,9 +106,21 @@ int shm_timeout_s()
     return v > 0 ? v : 300;
 }
 
+// A rank that cannot go on (a local copy failed, a peer never came) marks the communicator broken BEFORE it would have arrived at the
+// next barrier: the peers waiting there leave with the error in the same round instead of waiting out the timeout, and nobody is ever
+// released by fewer than nranks real arrivals (a timed-out rank's increment used to stay behind).  Sticky: the communicator is done.
+void shm_break(Shm& s, int err)
+{
+    uint32_t none = 0;
+    s.h->broken.compare_exchange_strong(none, (uint32_t)(err ? err : EIO), std::memory_order_acq_rel);
+}
+int shm_broken(const Shm& s) { return (int)s.h->broken.load(std::memory_order_acquire); }
+
 // every rank of the communicator calls this the same number of times
 int shm_barrier(Shm& s)
 {
+    if (shm_broken(s))
+        return EPIPE;
     const uint32_t gen = s.h->generation.load(std::memory_order_acquire);
     if (s.h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == s.h->nranks)
     {
@@ -119,13 +132,18 @@ int shm_barrier(Shm& s)
     const int limit = shm_timeout_s();
     for (uint32_t spins = 0; s.h->generation.load(std::memory_order_acquire) == gen; ++spins)
     {
+        if (shm_broken(s))
+            return EPIPE; // a peer gave up (its errno is in the header)
         if (spins < 2000)
             sched_yield();
         else
         {
             usleep(50);
             if ((spins & 1023) == 0 && now_s() - t0 > limit)
-                return ETIMEDOUT; // a peer died or never came
+            {
+                shm_break(s, ETIMEDOUT); // a peer died or never came: nobody may be released by this rank's stale arrival later
+                return ETIMEDOUT;
+            }
         }
     }
     return 0;
@@ -173,13 +191,17 @@ int shm_allgather(lthip_ctx* ctx, lthip_comm* c, const void* send, void* recv, s
         int e = xfer(ctx, s.slot(c->rank), (const uint8_t*)send + off, n, true);
         if (!e)
             e = xfer_wait(ctx);
-        const int b = shm_barrier(s); // (reached also after a local failure: the peers must not wait for ever)
+        if (e)
+            shm_break(s, e); // (published before the barrier: the peers leave in this round, not after the timeout)
+        const int b = shm_barrier(s);
         if (e || b)
             return e ? e : b;
         for (int r = 0; r < c->nranks && !e; ++r)
             e = xfer(ctx, (uint8_t*)recv + (size_t)r * bytes + off, s.slot(r), n, false);
         if (!e)
             e = xfer_wait(ctx);
+        if (e)
+            shm_break(s, e);
         const int b2 = shm_barrier(s);
         if (e || b2)
             return e ? e : b2;
@@ -240,6 +262,8 @@ int shm_alltoallv(lthip_ctx* ctx, lthip_comm* c, const void* send, const uint64_
             if (!e)
                 e = xfer_wait(ctx);
         }
+        if (e)
+            shm_break(s, e);
         b = shm_barrier(s);
         if (e || b)
             return e ? e : b;
@@ -253,6 +277,8 @@ int shm_alltoallv(lthip_ctx* ctx, lthip_comm* c, const void* send, const uint64_
         }
         if (!e)
             e = xfer_wait(ctx);
+        if (e)
+            shm_break(s, e);
         b = shm_barrier(s);
         if (e || b)
             return e ? e : b;
@@ -341,14 +367,32 @@ static int shm_create(lthip_ctx* ctx, int nranks, int rank, const uint8_t* id, l
         }
     }
     // (a peer maps what rank 0 has sized: wait for the size, then for the header)
+    // (rank 0 made the name: whatever goes wrong on rank 0 from here on, the name goes away with it -- the peers that did attach wait
+    // out their barrier and fail, and nothing stays behind in /dev/shm)
+    auto fail = [&](int e, void* mapped) {
+        if (mapped)
+            munmap(mapped, k->shm.map_bytes);
+        if (rank == 0)
+            unlink(k->shm.path);
+        delete k;
+        return e;
+    };
     struct stat st;
-    while (fstat(fd, &st) == 0 && st.st_size < 64)
+    memset(&st, 0, sizeof st);
+    for (;;)
     {
+        if (fstat(fd, &st) != 0)
+        {
+            const int e = errno ? errno : EIO;
+            close(fd);
+            return fail(e, nullptr);
+        }
+        if (st.st_size >= 64)
+            break;
         if (now_s() - t0 > limit)
         {
             close(fd);
-            delete k;
-            return ETIMEDOUT;
+            return fail(ETIMEDOUT, nullptr);
         }
         usleep(1000);
     }
@@ -356,10 +400,7 @@ static int shm_create(lthip_ctx* ctx, int nranks, int rank, const uint8_t* id, l
     void* p = mmap(nullptr, k->shm.map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (p == MAP_FAILED)
-    {
-        delete k;
-        return ENOMEM;
-    }
+        return fail(ENOMEM, nullptr);
     k->shm.base = (uint8_t*)p;
     k->shm.h = (ShmHeader*)p;
     if (rank == 0)
@@ -369,33 +410,25 @@ static int shm_create(lthip_ctx* ctx, int nranks, int rank, const uint8_t* id, l
         k->shm.h->arrived.store(0);
         k->shm.h->generation.store(0);
         k->shm.h->attached.store(0);
+        k->shm.h->broken.store(0);
         k->shm.h->ready.store(1, std::memory_order_release);
     }
     else
         while (!k->shm.h->ready.load(std::memory_order_acquire))
         {
             if (now_s() - t0 > limit)
-            {
-                munmap(p, k->shm.map_bytes);
-                delete k;
-                return ETIMEDOUT;
-            }
+                return fail(ETIMEDOUT, p);
             usleep(1000);
         }
     if (k->shm.h->nranks != (uint32_t)nranks || k->shm.map_bytes < 64 + (size_t)nranks * (shm_table_bytes(nranks) + k->shm.h->slot_bytes))
     {
-        munmap(p, k->shm.map_bytes);
-        delete k;
-        return EINVAL; // the ranks disagree about the size of the communicator
+        shm_break(k->shm, EINVAL); // (the ranks that agree with each other leave their create barrier now, not after the timeout)
+        return fail(EINVAL, p);    // the ranks disagree about the size of the communicator
     }
     k->shm.h->attached.fetch_add(1);
     const int b = shm_barrier(k->shm); // like ncclCommInitRank: returns once every rank is there
     if (b)
-    {
-        munmap(p, k->shm.map_bytes);
-        delete k;
-        return b;
-    }
+        return fail(b, p);
     *out = k;
     return 0;
 }

@@ -1095,7 +1095,14 @@ extern "C" int lthip_ingest_finish(lthip_ingest* g, void* h_store_index, size_t 
     }
     g->res.compressed_bytes = g->written ? *(const uint64_t*)g->h_comp.p : 0;
     if (out)
-        *out = g->res;
+    {
+        // (the caller says how large ITS struct is: a header older or newer than this library's never gets written past its end)
+        const uint64_t have = out->struct_size;
+        if (have < 16 || have > 4096)
+            return lthip_fail(ctx, EINVAL, "lthip_ingest_finish", "out_result->struct_size must be set to sizeof(lthip_ingest_result)");
+        g->res.struct_size = have < sizeof g->res ? have : sizeof g->res;
+        memcpy(out, &g->res, (size_t)g->res.struct_size);
+    }
     return rc;
 }
 

@@ -51,7 +51,103 @@ __global__ __launch_bounds__(GT) void k_gather_ranges(const uint8_t* __restrict_
         d[done + tid] = s[done + tid];
 }
 
+// positions of a rank's chunks in job order (the multi-GPU exchange): chunk k of the rank lies in its own job m with
+// part_first[m] <= k < part_first[m + 1] (lthip_chunk_hash's part table: one part per own job, ascending) and is the tree's chunk
+// job_gfirst[m] + (k - part_first[m])
+__global__ void k_job_ordinals(const uint32_t* __restrict__ part_first, uint32_t nparts, const uint32_t* __restrict__ job_gfirst,
+                               uint32_t nlocal, uint32_t* __restrict__ out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nlocal)
+        return;
+    uint32_t lo = 0, hi = nparts; // (empty parts: the last one that starts at or before k)
+    while (hi - lo > 1)
+    {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (part_first[mid] <= k)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    out[k] = job_gfirst[lo] + (k - part_first[lo]);
+}
+
+// element ranges -> byte ranges of k_gather_ranges
+__global__ void k_scale_ranges(const uint64_t* __restrict__ src, const uint64_t* __restrict__ dst, const uint32_t* __restrict__ cnt,
+                               uint64_t count, uint32_t elem_bytes, uint64_t* __restrict__ src_b, uint64_t* __restrict__ dst_b,
+                               uint32_t* __restrict__ len_b)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count)
+        return;
+    src_b[i] = src[i] * elem_bytes;
+    dst_b[i] = dst[i] * elem_bytes;
+    len_b[i] = cnt[i] * elem_bytes;
+}
+
 } // namespace
+
+extern "C" int lthip_exchange_reorder(lthip_ctx* ctx, const void* d_gathered, void* d_out, uint32_t elem_bytes, uint64_t range_count,
+                                      const uint64_t* range_src, const uint64_t* range_dst, const uint32_t* range_cnt)
+{
+    if (!ctx || !elem_bytes || (range_count && (!d_gathered || !d_out || !range_src || !range_dst || !range_cnt)))
+        return EINVAL;
+    if (range_count == 0)
+        return 0;
+    if (range_count > 0x7FFFFFFFull)
+        return lthip_fail(ctx, EINVAL, "lthip_exchange_reorder", "too many ranges");
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // tables: {src, dst} u64 + cnt u32 in elements, then the same in bytes
+    const size_t n = (size_t)range_count, n8 = (n + 1) & ~(size_t)1;
+    void* tab = nullptr;
+    int err = lthip_scratch(ctx, S_XCHG, n8 * 40 + 64, &tab);
+    if (err)
+        return err;
+    uint64_t* d_src = (uint64_t*)tab;
+    uint64_t* d_dst = d_src + n8;
+    uint64_t* d_src_b = d_dst + n8;
+    uint64_t* d_dst_b = d_src_b + n8;
+    uint32_t* d_cnt = (uint32_t*)(d_dst_b + n8);
+    uint32_t* d_len_b = d_cnt + n8;
+    hipStream_t s = ctx->stream;
+    if ((err = lthip_stage_upload(ctx, d_src, range_src, n * 8, s)) || (err = lthip_stage_upload(ctx, d_dst, range_dst, n * 8, s)) ||
+        (err = lthip_stage_upload(ctx, d_cnt, range_cnt, n * 4, s)))
+        return err;
+    LaunchTimer t(ctx, LTHIP_K_GATHER);
+    hipLaunchKernelGGL(k_scale_ranges, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_src, d_dst, d_cnt, (uint64_t)n, elem_bytes,
+                       d_src_b, d_dst_b, d_len_b);
+    hipLaunchKernelGGL(k_gather_ranges, dim3((uint32_t)n), dim3(GT), 0, s, (const uint8_t*)d_gathered, d_src_b, d_len_b, d_dst_b,
+                       (uint64_t)n, (uint8_t*)d_out);
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+extern "C" int lthip_job_ordinals(lthip_ctx* ctx, uint64_t my_job_count, const uint32_t* local_first, const uint32_t* global_first,
+                                  uint64_t local_chunks, uint32_t* d_out)
+{
+    if (!ctx || (local_chunks && (!my_job_count || !local_first || !global_first || !d_out)))
+        return EINVAL;
+    if (local_chunks == 0)
+        return 0;
+    if (local_chunks > 0x7FFFFFF0ull || my_job_count > 0x7FFFFFF0ull)
+        return lthip_fail(ctx, EINVAL, "lthip_job_ordinals", "counts out of range");
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t m = (size_t)my_job_count;
+    void* tab = nullptr;
+    int err = lthip_scratch(ctx, S_XCHG2, m * 8 + 64, &tab);
+    if (err)
+        return err;
+    uint32_t* d_lf = (uint32_t*)tab;
+    uint32_t* d_gf = d_lf + m;
+    hipStream_t s = ctx->stream;
+    if ((err = lthip_stage_upload(ctx, d_lf, local_first, m * 4, s)) || (err = lthip_stage_upload(ctx, d_gf, global_first, m * 4, s)))
+        return err;
+    LaunchTimer t(ctx, LTHIP_K_OTHER);
+    hipLaunchKernelGGL(k_job_ordinals, dim3((uint32_t)((local_chunks + 255) / 256)), dim3(256), 0, s, d_lf, (uint32_t)m, d_gf,
+                       (uint32_t)local_chunks, d_out);
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
+}
 
 extern "C" int lthip_gather_ranges(lthip_ctx* ctx, const void* d_src, uint64_t range_count, const uint64_t* d_src_offsets,
                                    const uint32_t* d_lens, void* d_dst, const uint64_t* d_dst_offsets)

@@ -90,6 +90,8 @@ enum ScratchSlot
     S_B3_WINDOWS,   // first range of every window of leaf slots (parents kernel)
     S_Z_FR,         // zstd decoder, frames of other encoders: per block {history in, start, history out}
     S_Z_ORG,        // ... and the origins (u32 per byte of output) of the payloads in flight
+    S_XCHG,         // multi-GPU exchange: range tables of lthip_exchange_reorder
+    S_XCHG2,        // ... and the job tables of lthip_job_ordinals
     S_COUNT
 };
 

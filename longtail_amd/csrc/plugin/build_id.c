@@ -5,3 +5,5 @@
 #include "build_id.h"
 
 LTHIP_EXPORT const char* lthip_build_id(void) { return LTHIP_BUILD_ID; }
+
+LTHIP_EXPORT int lthip_abi_version(void) { return LTHIP_ABI_VERSION; }

@@ -207,3 +207,48 @@ int lthip_exchange_layout(uint64_t job_count, const uint32_t* job_rank, uint32_t
     ltp_free(next_job);
     return err;
 }
+
+/* The per-job runs of lthip_exchange_layout as the device reorder wants them: runs that are contiguous on both sides are merged
+ * (range policy: one per rank; the other policies: one per maximal run of jobs of one rank) and cut into pieces of at most max_piece
+ * elements -- lthip_exchange_reorder gives every piece a workgroup, so neither 500 000 ranges of 33 elements nor 8 ranges of 17 MB.
+ * Returns the number of pieces (out arrays may be NULL: count only); more than `capacity` = the arrays were too small. */
+uint64_t lthip_exchange_ranges(uint64_t job_count, const uint64_t* job_src, const uint64_t* job_dst, const uint32_t* job_chunks,
+                               uint64_t max_piece, uint64_t capacity, uint64_t* out_src, uint64_t* out_dst, uint32_t* out_cnt)
+{
+    if (!max_piece || max_piece > 0x7FFFFFFFu || (job_count && (!job_src || !job_dst || !job_chunks)))
+        return 0;
+    uint64_t n = 0;
+    uint64_t j = 0;
+    while (j < job_count)
+    {
+        if (!job_chunks[j])
+        {
+            ++j;
+            continue;
+        }
+        uint64_t src = job_src[j], dst = job_dst[j], len = job_chunks[j];
+        for (++j; j < job_count; ++j)
+        {
+            if (!job_chunks[j])
+                continue;
+            if (job_src[j] != src + len || job_dst[j] != dst + len)
+                break;
+            len += job_chunks[j];
+        }
+        while (len)
+        {
+            const uint64_t k = len < max_piece ? len : max_piece;
+            if (out_src && out_dst && out_cnt && n < capacity)
+            {
+                out_src[n] = src;
+                out_dst[n] = dst;
+                out_cnt[n] = (uint32_t)k;
+            }
+            ++n;
+            src += k;
+            dst += k;
+            len -= k;
+        }
+    }
+    return n;
+}

@@ -19,6 +19,43 @@ import torch
 import torch.distributed as dist
 
 POLICIES = {"range": 0, "lpt": 1, "mod": 2}
+REORDER_PIECE = 1 << 15  # elements per workgroup of lthip_exchange_reorder (256 KiB of hashes)
+
+
+class StepProfile:
+    """Where an N-rank step's exchange time goes (tools/exchange_cost.py): wall time between marks, booked to "host" (numpy / C tables,
+    Python), "device" (kernels and torch ops, waited for) or "transport" (collectives, waited for).  Marks synchronise the device, so a
+    profiled step is slower than a plain one: it is a breakdown, not a measurement of the step."""
+
+    def __init__(self, ctx=None):
+        import time
+
+        self.ctx, self.ms, self._now = ctx, {"host": 0.0, "device": 0.0, "transport": 0.0}, time.perf_counter
+        self.detail = {}
+        self.t = self._now()
+
+    def start(self):
+        self._wait()
+        self.t = self._now()
+
+    def _wait(self):
+        if self.ctx is not None:
+            self.ctx.sync()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+
+    def mark(self, kind: str, what: str):
+        self._wait()
+        t = self._now()
+        d = (t - self.t) * 1e3
+        self.ms[kind] += d
+        self.detail[what] = self.detail.get(what, 0.0) + d
+        self.t = t
+
+
+def _mark(prof, kind, what):
+    if prof is not None:
+        prof.mark(kind, what)
 
 
 def shard_range(n_items: int, world: int, rank: int):
@@ -56,10 +93,14 @@ class JobPartition:
             raise RuntimeError(f"lthip_partition_jobs: errno {err}")
         self.job_count = n
         self.jobs_per_rank = np.bincount(self.job_rank, minlength=world).astype(np.int64)
+        self._jobs_of = {}
 
     def jobs_of(self, rank: int) -> np.ndarray:
         """Indices of the rank's jobs, ascending (= the order it must process them in)."""
-        return np.flatnonzero(self.job_rank == rank)
+        got = self._jobs_of.get(rank)
+        if got is None:
+            got = self._jobs_of[rank] = np.flatnonzero(self.job_rank == rank)
+        return got
 
     def is_rank_major(self) -> bool:
         """True when the rank-major concatenation of the ranks' job lists is already job order."""
@@ -74,6 +115,17 @@ class JobPartition:
         if err:
             raise RuntimeError(f"lthip_exchange_layout: errno {err} (per-job counts do not match the assignment)")
         return src, dst, cnt
+
+    def ranges(self, src, dst, cnt, max_piece: int = REORDER_PIECE):
+        """The layout merged into maximal runs and cut into pieces of at most max_piece elements (lthip_exchange_ranges): what
+        Context.exchange_reorder takes.  Range policy: world runs; O(jobs) in C."""
+        f = self.lib.dll.lthip_exchange_ranges
+        n = self.job_count
+        k = int(f(n, src.ctypes.data, dst.ctypes.data, cnt.ctypes.data, max_piece, 0, None, None, None))
+        r_src, r_dst, r_cnt = np.zeros(k, np.uint64), np.zeros(k, np.uint64), np.zeros(k, np.uint32)
+        got = int(f(n, src.ctypes.data, dst.ctypes.data, cnt.ctypes.data, max_piece, k, r_src.ctypes.data, r_dst.ctypes.data, r_cnt.ctypes.data))
+        assert got == k
+        return r_src, r_dst, r_cnt
 
 
 def _allgather(t: torch.Tensor, world: int, group=None, comm=None) -> torch.Tensor:
@@ -91,13 +143,14 @@ def _allgather(t: torch.Tensor, world: int, group=None, comm=None) -> torch.Tens
 
 
 def exchange_chunks(part: JobPartition, job_counts: torch.Tensor, hashes: torch.Tensor, lens: torch.Tensor | None, total: int,
-                    ctx=None, group=None, comm=None, rank: int | None = None):
+                    ctx=None, group=None, comm=None, rank: int | None = None, prof: StepProfile | None = None):
     """job_counts: int32 tensor, chunk count of each of THIS rank's jobs (ascending job order); hashes (int64) / lens (int32):
     tensors whose first `total` entries are this rank's chunks in that order.  Returns a dict:
       hashes, lens   all ranks' chunks in JOB order (lens None when not given)
       job_first      int64 numpy [job_count + 1]: index of each job's first chunk (last entry = total chunks)
       mine           (job indices of this rank, ascending)
-    On CUDA tensors with a context the reorder is one lthip_gather_ranges per array; CPU tensors (gloo tests) are indexed.
+    On CUDA tensors with a context the reorder is one lthip_exchange_reorder per array over the merged runs of the layout (nothing
+    per chunk happens on the host: the host sees the count matrix and O(jobs) tables only); CPU tensors (gloo tests) are indexed.
     `comm` (longtail_amd.lib.Comm): run the three all-gathers through the C ABI's RCCL entry instead of torch.distributed.
     """
     world = part.world
@@ -118,7 +171,9 @@ def exchange_chunks(part: JobPartition, job_counts: torch.Tensor, hashes: torch.
     count_stride = max(int(part.jobs_per_rank.max()), 1)
     send = torch.zeros(count_stride, dtype=torch.int32, device=dev)
     send[: len(mine)] = job_counts.to(torch.int32)
+    _mark(prof, "device", "counts: pad")
     gathered_counts = _allgather(send, world, group, comm).cpu().numpy().view(np.uint32)
+    _mark(prof, "transport", "counts: all-gather + D2H")
     per_rank_total = gathered_counts.reshape(world, count_stride).astype(np.int64).sum(axis=1)
     assert int(per_rank_total[rank]) == total
     # (2) chunk arrays, padded to the largest rank
@@ -129,20 +184,25 @@ def exchange_chunks(part: JobPartition, job_counts: torch.Tensor, hashes: torch.
             return t[:chunk_stride]
         return torch.nn.functional.pad(t[:total], (0, chunk_stride - total))
 
-    g_hash = _allgather(padded(hashes), world, group, comm)
-    g_lens = _allgather(padded(lens), world, group, comm) if lens is not None else None
+    p_hash = padded(hashes)
+    p_lens = padded(lens) if lens is not None else None
+    _mark(prof, "device", "chunks: pad")
+    g_hash = _allgather(p_hash, world, group, comm)
+    g_lens = _allgather(p_lens, world, group, comm) if lens is not None else None
+    _mark(prof, "transport", "chunks: all-gather")
     src, dst, cnt = part.layout(gathered_counts, count_stride, chunk_stride)
     n_all = int(dst[-1])
+    ranges = None
     if out_dev.type == "cuda" and ctx is not None and not staged:
-        d_src = torch.from_numpy(src.view(np.int64)).to(out_dev)
-        d_dst = torch.from_numpy(dst[:-1].view(np.int64).copy()).to(out_dev)
-        d_cnt = torch.from_numpy(cnt.view(np.int32)).to(out_dev)
+        ranges = part.ranges(src, dst, cnt)
+        _mark(prof, "host", "layout + ranges (O(jobs), C)")
         o_hash = torch.empty(n_all, dtype=torch.int64, device=out_dev)
-        ctx.gather_ranges(g_hash.view(torch.uint8), d_src * 8, d_cnt * 8, o_hash.view(torch.uint8), d_dst * 8)
+        ctx.exchange_reorder(g_hash, o_hash, ranges)
         o_lens = None
         if g_lens is not None:
             o_lens = torch.empty(n_all, dtype=torch.int32, device=out_dev)
-            ctx.gather_ranges(g_lens.view(torch.uint8), d_src * 4, d_cnt * 4, o_lens.view(torch.uint8), d_dst * 4)
+            ctx.exchange_reorder(g_lens, o_lens, ranges)
+        _mark(prof, "device", "chunks: reorder to job order")
     else:
         c64 = cnt.astype(np.int64)
         perm = np.repeat(src.astype(np.int64) - dst[:-1].astype(np.int64), c64) + np.arange(n_all, dtype=np.int64)
@@ -150,7 +210,7 @@ def exchange_chunks(part: JobPartition, job_counts: torch.Tensor, hashes: torch.
         o_hash = g_hash[idx].to(out_dev)
         o_lens = g_lens[idx].to(out_dev) if g_lens is not None else None
     return dict(hashes=o_hash, lens=o_lens, job_first=dst.astype(np.int64), mine=mine,
-                layout=dict(src=src, dst=dst, cnt=cnt, chunk_stride=chunk_stride, staged=staged))
+                layout=dict(src=src, dst=dst, cnt=cnt, chunk_stride=chunk_stride, staged=staged, ranges=ranges))
 
 
 def _min_ordinal(h: torch.Tensor, o: torch.Tensor, ctx=None):
@@ -180,20 +240,27 @@ def _a2a_counts(send_counts: torch.Tensor, world: int, group=None, comm=None) ->
 
 def _a2a(send: torch.Tensor, sc: list, rc: list, group=None, comm=None) -> torch.Tensor:
     if comm is not None:
-        return comm.alltoallv(send, sc, rc)  # lthip_comm_alltoallv: grouped ncclSend / ncclRecv on the context's stream
+        # lthip_comm_alltoallv: grouped ncclSend / ncclRecv on the context's stream; the caller synchronises the communicator after its
+        # group of exchanges, before torch ops (which may run on another stream) read what was received
+        return comm.alltoallv(send, sc, rc)
     recv = torch.empty(sum(rc), dtype=send.dtype, device=send.device)
     dist.all_to_all_single(recv, send, rc, sc, group=group)
     return recv
 
 
 def sharded_first_seen(part: JobPartition, ex: dict, my_hashes: torch.Tensor, total: int, ctx=None, group=None, comm=None,
-                       rank: int | None = None):
+                       rank: int | None = None, prof: StepProfile | None = None):
     """The first-seen pass (src/longtail.c:2951-2970) with the table SHARDED by hash instead of replicated: every rank routes each of
     its chunks (hash, global position in job order) to the owner of the hash (all-to-all), the owner keeps the minimum position per
     hash (lthip_dedup_min_ordinal) and answers, and one all-gather spreads the answers: a rank inserts ~1/N of the tree's chunks instead
     of all N shares (round 2 rebuilt the whole table on every rank).  `ex` = the result of exchange_chunks (job layout).
     Returns (first: int32 tensor [all chunks] in job order -- the position of the first chunk with the same hash --, unique count).
-    The result does not depend on the number of ranks: it is the minimum position per hash."""
+    The result does not depend on the number of ranks: it is the minimum position per hash.
+
+    Device tensors + a context: nothing per chunk happens on the host (round 5; round 4 built two permutations of all chunks in numpy
+    and uploaded them from pageable memory every step).  The positions come from lthip_job_ordinals (O(own jobs) host tables), the
+    answers go back into job order through the merged runs exchange_chunks already made (lthip_exchange_reorder); the host reads the
+    N x N count matrix between the collectives and the distinct count at the end, nothing else."""
     world = part.world
     job_first, mine = ex["job_first"], ex["mine"]
     n_all = int(job_first[-1])
@@ -205,49 +272,77 @@ def sharded_first_seen(part: JobPartition, ex: dict, my_hashes: torch.Tensor, to
         return first, uniq
     if rank is None:
         rank = comm.rank if comm is not None else dist.get_rank(group)
-    staged = ex["layout"]["staged"]
+    lay = ex["layout"]
+    staged = lay["staged"]
     if staged:
         my_hashes = my_hashes[:total].cpu()
     wdev = my_hashes.device
+    on_device = wdev.type == "cuda" and ctx is not None and lay.get("ranges") is not None
     # global positions of my chunks: job j's run starts at job_first[j]
     cnt = (job_first[mine + 1] - job_first[mine]).astype(np.int64)
     assert int(cnt.sum()) == total
-    starts = np.repeat(job_first[mine] - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt)
-    ordinals = torch.from_numpy((starts + np.arange(total, dtype=np.int64)).astype(np.int32)).to(wdev)
+    local_first = np.concatenate([[0], np.cumsum(cnt)[:-1]]) if len(mine) else np.zeros(0, np.int64)
+    if on_device:
+        ordinals = ctx.job_ordinals(local_first.astype(np.uint32), job_first[mine].astype(np.uint32), total)
+        _mark(prof, "host", "positions: job tables (O(own jobs))")
+    else:
+        starts = np.repeat(job_first[mine] - local_first, cnt)
+        ordinals = torch.from_numpy((starts + np.arange(total, dtype=np.int64)).astype(np.int32)).to(wdev)
     h = my_hashes[:total]
     owner = ((h >> 40) & 0xFFFFFF) % world  # 24 bits from the middle of the digest
     order = torch.argsort(owner, stable=True)
     send_h, send_o = h[order].contiguous(), ordinals[order].contiguous()
     send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+    _mark(prof, "device", "route: positions, owner, sort, counts")
     rc = _a2a_counts(send_counts, world, group, comm)
     sc = [int(x) for x in send_counts.cpu().tolist()]
+    _mark(prof, "transport", "route: count matrix")
     recv_h = _a2a(send_h, sc, rc, group, comm)
     recv_o = _a2a(send_o, sc, rc, group, comm)
+    if comm is not None:
+        comm.sync()  # (the receives were queued on the context's stream: torch's ops below may run on another one)
+    _mark(prof, "transport", "route: all-to-all (hash, position)")
     if staged and ctx is not None:
         d = torch.device("cuda", torch.cuda.current_device())
         f, uniq = _min_ordinal(recv_h.to(d), recv_o.to(d), ctx)
         f = f.cpu()
+    elif on_device:
+        f, uniq = ctx.dedup_min_ordinal(recv_h, recv_o, sync=False)  # (the count stays on the device until the end)
     else:
         f, uniq = _min_ordinal(recv_h, recv_o, ctx if wdev.type == "cuda" else None)
+    _mark(prof, "device", "owner: minimum position per hash")
     back = _a2a(f.contiguous(), rc, sc, group, comm)
+    if comm is not None:
+        comm.sync()
+    _mark(prof, "transport", "answer: all-to-all")
     my_first = torch.empty(total, dtype=torch.int32, device=wdev)
     my_first[order] = back
-    u = torch.tensor([uniq], dtype=torch.int64, device=wdev)
+    u = uniq.to(torch.int64).reshape(1) if torch.is_tensor(uniq) else torch.tensor([uniq], dtype=torch.int64, device=wdev)
+    # every rank's answers, in job order (the padded all-gather + reorder of exchange_chunks)
+    chunk_stride = lay["chunk_stride"]
+    send = my_first if total >= chunk_stride else torch.nn.functional.pad(my_first, (0, chunk_stride - total))
+    send = send[:chunk_stride].contiguous()
+    _mark(prof, "device", "answer: scatter + pad")
     if comm is not None:
         u = comm.allgather(u)
+        g = comm.allgather(send)
         comm.sync()
         u = u.sum()
     else:
         dist.all_reduce(u, group=group)
-    # every rank's answers, in job order (the padded all-gather + reorder of exchange_chunks)
-    lay = ex["layout"]
-    chunk_stride = lay["chunk_stride"]
-    send = my_first if total >= chunk_stride else torch.nn.functional.pad(my_first, (0, chunk_stride - total))
-    g = _allgather(send[:chunk_stride].contiguous(), world, group, comm)
-    c64 = lay["cnt"].astype(np.int64)
-    perm = np.repeat(lay["src"].astype(np.int64) - lay["dst"][:-1].astype(np.int64), c64) + np.arange(n_all, dtype=np.int64)
-    first = g[torch.from_numpy(perm).to(wdev)]
-    return first.to(dev), int(u.item())
+        g = _allgather(send, world, group, None)
+    _mark(prof, "transport", "answer: all-gather")
+    if on_device:
+        first = torch.empty(n_all, dtype=torch.int32, device=wdev)
+        ctx.exchange_reorder(g, first, lay["ranges"])
+        _mark(prof, "device", "answer: reorder to job order")
+    else:
+        c64 = lay["cnt"].astype(np.int64)
+        perm = np.repeat(lay["src"].astype(np.int64) - lay["dst"][:-1].astype(np.int64), c64) + np.arange(n_all, dtype=np.int64)
+        first = g[torch.from_numpy(perm).to(wdev)]
+    uniq_all = int(u.item())
+    _mark(prof, "transport", "distinct count: D2H")
+    return first.to(dev), uniq_all
 
 
 def allgather_hashes(local_hashes: torch.Tensor, total: int, group=None):

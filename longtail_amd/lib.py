@@ -44,6 +44,9 @@ def _u32arr(a: Sequence[int]) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a, dtype=np.uint32))
 
 
+ABI_VERSION = 3  # include/longtail_hip.h LTHIP_ABI_VERSION
+
+
 class HipLib:
     """The loaded shared library with argtypes/restypes set."""
 
@@ -93,6 +96,10 @@ class HipLib:
         sig("lthip_ctx_error", C.c_char_p, [vp])
         sig("lthip_device_count", i32, [])
         sig("lthip_build_id", C.c_char_p, [])
+        sig("lthip_abi_version", i32, [])
+        if d.lthip_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{p}: binary interface version {d.lthip_abi_version()}, this binding was written for {ABI_VERSION} "
+                               "(include/longtail_hip.h LTHIP_ABI_VERSION): rebuild the library")
         sig("lthip_malloc_device", i32, [vp, sz, P(vp)])
         sig("lthip_free_device", None, [vp, vp])
         sig("lthip_malloc_pinned", i32, [vp, sz, P(vp)])
@@ -152,6 +159,9 @@ class HipLib:
         sig("lthip_make_jobs", i32, [u32, vp, u32, u64, vp, vp, vp])
         sig("lthip_partition_jobs", i32, [u64, vp, u32, i32, vp, vp])
         sig("lthip_exchange_layout", i32, [u64, vp, u32, vp, u64, u64, vp, vp, vp])
+        sig("lthip_exchange_ranges", u64, [u64, vp, vp, vp, u64, u64, vp, vp, vp])
+        sig("lthip_exchange_reorder", i32, [vp, vp, vp, u32, u64, vp, vp, vp])
+        sig("lthip_job_ordinals", i32, [vp, u64, vp, vp, u64, vp])
         sig("lthip_comm_unique_id", i32, [vp])
         sig("lthip_comm_create", i32, [vp, i32, i32, vp, P(vp)])
         sig("lthip_comm_destroy", i32, [vp])
@@ -402,6 +412,22 @@ class Context:
         self._check(self.lib.dll.lthip_gather_ranges(self.h, _ptr(src), n, _ptr(src_offsets), _ptr(lens), _ptr(dst),
                                                      _ptr(dst_offsets)), "lthip_gather_ranges")
 
+    def exchange_reorder(self, gathered, out, ranges):
+        """out[dst ..) = gathered[src .. + cnt) for the (src, dst, cnt) element ranges of JobPartition.ranges (host arrays)."""
+        r_src, r_dst, r_cnt = ranges
+        assert gathered.dtype == out.dtype and gathered.is_contiguous() and out.is_contiguous()
+        self._check(self.lib.dll.lthip_exchange_reorder(self.h, _ptr(gathered), _ptr(out), gathered.element_size(), len(r_src),
+                                                        r_src.ctypes.data, r_dst.ctypes.data, r_cnt.ctypes.data), "lthip_exchange_reorder")
+
+    def job_ordinals(self, local_first: np.ndarray, global_first: np.ndarray, local_chunks: int):
+        """int32 tensor [local_chunks]: position in job order of every chunk of this rank (own job m: local_first[m] -> global_first[m])."""
+        lf, gf = _u32arr(local_first), _u32arr(global_first)
+        assert len(lf) == len(gf)
+        out = self.torch.empty(max(1, local_chunks), dtype=self.torch.int32, device=self._dev())
+        self._check(self.lib.dll.lthip_job_ordinals(self.h, len(lf), lf.ctypes.data, gf.ctypes.data, local_chunks, _ptr(out)),
+                    "lthip_job_ordinals")
+        return out[:local_chunks]
+
     # -- dedup --
     def dedup_first_seen_range(self, hashes, first: int, count: int):
         """All hashes inserted, first-occurrence (global) indices returned for [first, first+count) only; + distinct count."""
@@ -422,15 +448,17 @@ class Context:
                     "lthip_dedup_first_seen")
         return first[:n], uniq
 
-    def dedup_min_ordinal(self, hashes, ordinals):
+    def dedup_min_ordinal(self, hashes, ordinals, sync: bool = True):
         """The owner's side of the sharded first-seen table: first[j] = smallest ordinal among the items with the hash of item j
-        (int32 tensor), number of distinct hashes (int, after a synchronisation)."""
+        (int32 tensor), number of distinct hashes (int, after a synchronisation; sync=False: a one-element int64 device tensor)."""
         torch = self.torch
         n = int(hashes.numel())
         first = torch.empty(max(1, n), dtype=torch.int32, device=self._dev())
         uniq = torch.zeros(1, dtype=torch.int64, device=self._dev())
         self._check(self.lib.dll.lthip_dedup_min_ordinal(self.h, n, _ptr(hashes.contiguous()), _ptr(ordinals.contiguous()), _ptr(first), _ptr(uniq)),
                     "lthip_dedup_min_ordinal")
+        if not sync:
+            return first[:n], uniq
         self.sync()
         return first[:n], int(uniq.item())
 
@@ -532,7 +560,7 @@ class IngestTree(C.Structure):
 
 
 class IngestResult(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("chunks_all", "unique_all", "chunks_local", "unique_local", "blocks", "raw_bytes",
+    _fields_ = [(n, C.c_uint64) for n in ("struct_size", "chunks_all", "unique_all", "chunks_local", "unique_local", "blocks", "raw_bytes",
                                           "compressed_bytes", "gathered_blocks", "version_index_size", "store_index_size", "gathered_bytes")]
 
 
@@ -603,6 +631,7 @@ class Ingest:
     def finish(self, store_index_out=None) -> IngestResult:
         cap = 0 if store_index_out is None else (store_index_out.numel() if hasattr(store_index_out, "numel") else len(store_index_out))
         res = IngestResult()
+        res.struct_size = C.sizeof(IngestResult)
         err = self.ctx.lib.dll.lthip_ingest_finish(self.h, _ptr(store_index_out) or None, cap, C.byref(res))
         self.ctx._check(err, "lthip_ingest_finish")
         self._index_keep = None

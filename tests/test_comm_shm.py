@@ -23,7 +23,7 @@ ROOT = Path(__file__).resolve().parent.parent
 def _comm(rank, world, idfile, slot):
     os.environ["LTHIP_COMM_TRANSPORT"] = "shm"
     os.environ["LTHIP_COMM_SHM_SLOT"] = str(slot)
-    os.environ["LTHIP_COMM_TIMEOUT_S"] = "60"
+    os.environ["LTHIP_COMM_TIMEOUT_S"] = os.environ.get("LTHIP_COMM_TIMEOUT_S_OVERRIDE", "60")
     sys.path.insert(0, str(ROOT))
     import bench
     from longtail_amd.lib import load
@@ -60,6 +60,44 @@ def _worker_collectives(rank, world, idfile, slot, out):
         res["mismatch"] = str(e)
     comm.close()
     torch.save(res, f"{out}/c{rank}.pt")
+
+
+def _worker_absent_peer(rank, world, idfile, out):
+    import time
+
+    os.environ["LTHIP_COMM_TIMEOUT_S_OVERRIDE"] = "2"
+    comm = _comm(rank, world, idfile, 4096)
+    from longtail_amd.lib import LongtailHipError
+
+    res = {"first": None, "second": None, "second_s": None}
+    comm.allgather(torch.arange(4, dtype=torch.int64))  # everybody is here for this one
+    if rank != world - 1:  # the last rank stops taking part (without leaving: its mapping keeps the segment alive)
+        for key in ("first", "second"):
+            t0 = time.time()
+            try:
+                comm.allgather(torch.arange(4, dtype=torch.int64))
+                res[key] = "returned"
+            except LongtailHipError as e:
+                res[key] = str(e)
+            res[key + "_s"] = time.time() - t0
+    else:
+        time.sleep(6)
+    torch.save(res, f"{out}/b{rank}.pt")
+    comm.close()
+
+
+def test_a_timed_out_barrier_breaks_the_communicator_for_good(tmp_path):
+    """a rank that timed out in the barrier used to leave its arrival behind, so the NEXT barrier could release with
+    n - 1 real arrivals and hand out slots nobody had written.  Now the first timeout marks the communicator broken: the ranks still
+    waiting leave at once, and every later collective fails immediately instead of waiting or -- worse -- succeeding."""
+    world = 3
+    idfile = str(tmp_path / "id")
+    mp.spawn(_worker_absent_peer, args=(world, idfile, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"b{r}.pt", weights_only=False) for r in range(world)]
+    for r in range(world - 1):
+        assert res[r]["first"] != "returned" and ("errno 110" in res[r]["first"] or "errno 32" in res[r]["first"]), res[r]
+        assert "errno 32" in res[r]["second"] and res[r]["second_s"] < 1.0, res[r]  # EPIPE at once: sticky
+    assert any("errno 110" in res[r]["first"] for r in range(world - 1))  # somebody saw the timeout itself
 
 
 @pytest.mark.parametrize("world,slot", [(2, 4096), (4, 1024), (3, 16 << 20)])

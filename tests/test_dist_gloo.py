@@ -214,3 +214,36 @@ def test_dry_run_reports_the_partition_without_a_gpu():
         assert j["dry_run"] and j["jobs"] == jobs and sum(j["bytes_per_rank"]) == 64 << 30
         assert j["imbalance_max_over_mean"] < 1.01 and len(j["jobs_per_rank"]) == 8
         assert j["first_seen_table_inserts_per_rank"]["sharded"] * 8 <= j["first_seen_table_inserts_per_rank"]["replicated"] + 8
+
+
+@pytest.mark.parametrize("world,policy", [(1, "range"), (3, "range"), (4, "lpt"), (8, "mod")])
+def test_exchange_ranges_is_the_layout_merged_and_cut(world, policy):
+    """lthip_exchange_ranges (what the device reorder takes): applying its pieces is the permutation the per-job layout describes; the
+    range policy collapses to one run per rank; no piece is longer than asked."""
+    rng = np.random.default_rng(7)
+    sizes = rng.integers(0, 300 << 20, size=40).astype(np.uint64)
+    sizes[5] = 0
+    part = JobPartition(sizes, 65536, world, policy)
+    counts = rng.integers(0, 50, size=part.job_count).astype(np.uint32)
+    counts[rng.integers(0, part.job_count, size=5)] = 0
+    count_stride = int(part.jobs_per_rank.max())
+    g = np.zeros((world, count_stride), np.uint32)
+    totals = np.zeros(world, np.int64)
+    for r in range(world):
+        mine = part.jobs_of(r)
+        g[r, : len(mine)] = counts[mine]
+        totals[r] = counts[mine].sum()
+    chunk_stride = max(int(totals.max()), 1)
+    src, dst, cnt = part.layout(g.reshape(-1), count_stride, chunk_stride)
+    n_all = int(dst[-1])
+    gathered = rng.integers(0, 1 << 62, size=world * chunk_stride).astype(np.int64)
+    want = np.concatenate([gathered[int(s) : int(s) + int(c)] for s, c in zip(src, cnt)]) if n_all else np.zeros(0, np.int64)
+    for piece in (7, 1 << 15):
+        r_src, r_dst, r_cnt = part.ranges(src, dst, cnt, max_piece=piece)
+        assert (r_cnt <= piece).all() and (r_cnt > 0).all()
+        got = np.full(n_all, -1, np.int64)
+        for s, d, c in zip(r_src, r_dst, r_cnt):
+            got[int(d) : int(d) + int(c)] = gathered[int(s) : int(s) + int(c)]
+        assert np.array_equal(got, want)
+        if policy == "range" and piece == 1 << 15:
+            assert len(r_src) <= world  # (rank-major order is job order: one run per rank that has chunks)

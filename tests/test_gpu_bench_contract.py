@@ -76,33 +76,34 @@ def test_bench_multi_rank_flow_on_one_gpu(world, scaling, partition):
     assert single["result"]["blocks"] <= multi["result"]["blocks"] <= single["result"]["blocks"] + 4 * world
 
 
-@pytest.mark.parametrize("launch", ["torch", "plain", "run8.sh"])
+@pytest.mark.parametrize("launch", ["torch", "plain", "run8.sh", "plain-lpt3"])
 def test_bench_starts_its_own_ranks(launch):
     """`python bench.py --gpus 2` as the driver types it (no launcher, WORLD_SIZE unset) starts two ranks itself, and the line says
     n_gpus 2 -- with torch.distributed (gloo standing in for RCCL on this 1-GPU box) and with the plain launch, where every collective
     -- the three all-gathers AND the sharded first-seen table's all-to-all -- goes through the C ABI (lthip_comm_*, the shared-memory
     transport standing in for RCCL).  Same tree-wide results as the single-rank run."""
     gib = 0.25
+    world = 3 if launch == "plain-lpt3" else 2  # (LPT: rank-major order is NOT job order -- the device reorder has many runs)
     args = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--gib", str(gib), "--tree", "mixed-sizes", "--kind", "mixed",
-            "--partition", "range", "--dedup", "sharded"]
+            "--partition", "lpt" if launch == "plain-lpt3" else "range", "--dedup", "sharded"]
     env = dict(os.environ, PYTHONPATH=str(ROOT))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     if launch == "torch":
         env["LONGTAIL_DIST_BACKEND"] = "gloo"
         cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", *args]
-    elif launch == "plain":
+    elif launch in ("plain", "plain-lpt3"):
         env["LTHIP_COMM_TRANSPORT"] = "shm"
-        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--launch", "plain", *args]
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--launch", "plain", *args]
     else:
         env["LTHIP_COMM_TRANSPORT"] = "shm"
         cmd = ["bash", str(ROOT / "tools" / "run8.sh"), "2", *args]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     multi = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert multi["n_gpus"] == 2 and multi["config"]["comm"]["nranks"] == 2 and multi["config"]["dedup_table"] == "sharded"
+    assert multi["n_gpus"] == world and multi["config"]["comm"]["nranks"] == world and multi["config"]["dedup_table"] == "sharded"
     assert multi["config"]["comm"]["transport"] == ("torch.distributed/gloo" if launch == "torch" else "host-shm")
-    single = run_bench("--gib", str(2 * gib), "--tree", "mixed-sizes", "--kind", "mixed")
+    single = run_bench("--gib", str(world * gib), "--tree", "mixed-sizes", "--kind", "mixed")
     assert multi["config"]["tree_bytes"] == single["config"]["tree_bytes"]
     for key in ("chunks", "unique_chunks", "raw_bytes_written", "version_index_bytes"):
         assert multi["result"][key] == single["result"][key], key

@@ -40,3 +40,58 @@ def test_single_rank_communicator_allgather(gpu):
         assert torch.equal(ex["hashes"], hashes) and int(ex["job_first"][-1]) == total
     finally:
         comm.close()
+
+
+def test_exchange_reorder_and_job_ordinals_against_numpy(gpu):
+    """The device side of the N-rank exchange (round 5: nothing per chunk on the host): lthip_exchange_reorder applies the merged runs
+    of the layout, lthip_job_ordinals gives every local chunk its position in job order -- both equal to the numpy permutations the
+    CPU path of longtail_amd.dist builds."""
+    from longtail_amd.dist import JobPartition
+
+    rng = np.random.default_rng(11)
+    sizes = rng.integers(0, 200 << 20, size=300).astype(np.uint64)
+    for world, policy in ((4, "lpt"), (8, "range"), (3, "mod")):
+        part = JobPartition(sizes, 65536, world, policy)
+        counts = rng.integers(0, 40, size=part.job_count).astype(np.uint32)
+        count_stride = int(part.jobs_per_rank.max())
+        g = np.zeros((world, count_stride), np.uint32)
+        totals = np.zeros(world, np.int64)
+        for r in range(world):
+            mine = part.jobs_of(r)
+            g[r, : len(mine)] = counts[mine]
+            totals[r] = counts[mine].sum()
+        chunk_stride = int(totals.max())
+        src, dst, cnt = part.layout(g.reshape(-1), count_stride, chunk_stride)
+        n_all = int(dst[-1])
+        perm = np.repeat(src.astype(np.int64) - dst[:-1].astype(np.int64), cnt.astype(np.int64)) + np.arange(n_all, dtype=np.int64)
+        for piece in (5, 1 << 15):
+            ranges = part.ranges(src, dst, cnt, max_piece=piece)
+            for dt in (torch.int64, torch.int32, torch.uint8):
+                gathered = torch.randint(0, 127, (world * chunk_stride,), device="cuda").to(dt)
+                out = torch.zeros(n_all, dtype=dt, device="cuda")
+                gpu.exchange_reorder(gathered, out, ranges)
+                gpu.sync()
+                assert torch.equal(out.cpu(), gathered.cpu()[torch.from_numpy(perm)]), (world, policy, piece, dt)
+        job_first = dst.astype(np.int64)
+        for r in range(world):
+            mine = part.jobs_of(r)
+            c = counts[mine].astype(np.int64)
+            total = int(c.sum())
+            local_first = np.concatenate([[0], np.cumsum(c)[:-1]]) if len(mine) else np.zeros(0, np.int64)
+            got = gpu.job_ordinals(local_first.astype(np.uint32), job_first[mine].astype(np.uint32), total)
+            gpu.sync()
+            want = np.repeat(job_first[mine] - local_first, c) + np.arange(total, dtype=np.int64)
+            assert np.array_equal(got.cpu().numpy().astype(np.int64), want), (world, policy, r)
+
+
+def test_abi_version_and_result_struct_size(gpu):
+    """include/longtail_hip.h LTHIP_ABI_VERSION: the library says which binary interface it implements, and lthip_ingest_finish never
+    writes past the struct size its caller states (the struct grew without a version)."""
+    import ctypes as C
+    import re
+    from pathlib import Path
+
+    from longtail_amd.lib import ABI_VERSION, load
+
+    text = (Path(__file__).resolve().parents[1] / "include" / "longtail_hip.h").read_text()
+    assert int(re.search(r"#define LTHIP_ABI_VERSION (\d+)", text).group(1)) == ABI_VERSION == load().dll.lthip_abi_version()
