@@ -323,7 +323,7 @@ class Bench:
         t = self.bufs.get(name)
         if t is None or t.numel() < n or t.dtype != dtype:
             self.bufs[name] = None
-            t = torch.empty(max(n, 16), dtype=dtype).pin_memory() if pinned else torch.empty(max(n, 16), dtype=dtype, device=self.dev)
+            t = torch.empty(max(n, 16), dtype=dtype, pin_memory=True) if pinned else torch.empty(max(n, 16), dtype=dtype, device=self.dev)
             self.bufs[name] = t
         return t
 
@@ -374,6 +374,163 @@ class Bench:
                 one = t if one is None or t < one else one
             out[name] = {"value": round(n / best / 1e9, 1), "ms": round(best * 1e3, 2), "one_block_ms": round(one * 1e3, 2),
                          "ratio": round(n / float(sz.sum()), 3), "round_trip": ok}
+        # ONE stored block written by the REFERENCE's encoders (what a restore that asks block by block sees on an existing store,
+        # lib/compressblockstore/longtail_compressblockstore.c:271-338), on the GPU and on one host core with the reference decoder
+        try:
+            from tests._libs import have_ref, ref
+
+            if have_ref():
+                r = ref()
+                raw = data[:block_bytes].cpu().numpy()
+                back = self.buf("restore_back", n + 64)
+                single = {"what": f"one {block_bytes >> 20} MiB block of the compressible workload compressed by the reference encoder: decode latency, best of 5"}
+                for name, codec, settings, dec in (("lz4", 0, r.lz4_type, ctx.lz4_decompress_blocks), ("zstd", 1, r.zstd_default, ctx.zstd_decompress_blocks)):
+                    comp = r.compress(codec, settings, raw)
+                    dev = torch.from_numpy(comp).to(self.dev)
+                    cpu_best = gpu_best = None
+                    for _ in range(5):
+                        t0 = time.perf_counter()
+                        err, dec_out = r.decompress(codec, comp, block_bytes)
+                        t = time.perf_counter() - t0
+                        cpu_best = t if cpu_best is None or t < cpu_best else cpu_best
+                    for _ in range(5):
+                        t0 = time.perf_counter()
+                        got = dec(dev, np.zeros(1, np.int64), np.array([len(comp)], np.int64), back, np.zeros(1, np.int64), np.array([block_bytes], np.int64))
+                        ctx.sync()
+                        t = time.perf_counter() - t0
+                        gpu_best = t if gpu_best is None or t < gpu_best else gpu_best
+                    ok1 = err == 0 and int(got.cpu().numpy().view(np.uint32)[0]) == block_bytes and bool((back[:block_bytes].cpu().numpy() == raw).all())
+                    single[name] = {"gpu_ms": round(gpu_best * 1e3, 2), "one_host_core_ms": round(cpu_best * 1e3, 2), "ratio": round(block_bytes / len(comp), 3), "round_trip": ok1}
+                single["note"] = ("a reference zstd frame is one chain of dependent sequences per 128 KiB block: the GPU's floor for it is a host core's time "
+                                  "(DESIGN.md §9 lead 6, INTEGRATION.md: batch the blocks of a restore -- 512 blocks in one call decode at the rates above)")
+                out["one_reference_made_block"] = single
+        except Exception as e:
+            out["one_reference_made_block"] = {"error": repr(e)}
+        return out
+
+    def host_fed_rates(self, kinds=("random", "mixed"), slices=2, slice_gib=8.0, rounds=3):
+        """secondary.host_fed -- the ingest path fed from HOST memory (what the reference's path starts from: StorageAPI.Read,
+        src/longtail.c:1923-1960; block assembly :4640-4721), as the double-buffered loop INTEGRATION.md recommends to an embedder:
+        pinned slice k+1 -> H2D on a copy stream | lthip_chunk_hash + lthip_ingest_index / _write / _finish of slice k on the compute
+        stream | stored-block images of slice k-1 packed (lthip_gather_ranges over lthip_ingest_images) -> D2H on a second copy stream.
+        Every slice is a session of its own (its VersionIndex / StoreIndex land in pinned memory as in the headline); `slices` distinct
+        slices of the headline tree live in pinned host memory and are streamed `rounds` times.  PCIe is the ceiling here: the value
+        is reported next to the box's measured H2D / D2H rates."""
+        torch, ctx, args = self.torch, self.ctx, self.args
+        from longtail_amd.lib import Ingest, chunker_params
+
+        FILE = 1 << 20
+        nfiles = int(slice_gib * (1 << 30)) // FILE
+        n = nfiles * FILE
+        mn, av, mx = chunker_params(args.target_chunk_size)
+        tree = make_tree("files", n, FILE)
+        p_off = np.arange(nfiles, dtype=np.uint64) * np.uint64(FILE)
+        p_size = np.full(nfiles, FILE, np.uint64)
+        limit = args.block_size + args.block_size // 10
+        arena_bytes = n + n // 128 + (n // args.block_size + 4) * (16384 + 64) + 2 * (limit + limit // 128 + 16384)
+        t0 = time.perf_counter()
+        host_in = [self.buf(f"hf_in{i}", n, pinned=True) for i in range(slices)]
+        host_out = [self.buf(f"hf_out{i}", arena_bytes, pinned=True) for i in range(2)]
+        pin_s = time.perf_counter() - t0
+        data = [self.buf("data", n + 256), self.buf("hf_data1", n + 256)]
+        arena = [self.buf("arena", arena_bytes), self.buf("hf_arena1", arena_bytes)]
+        packed = [self.buf("hf_packed0", arena_bytes), self.buf("hf_packed1", arena_bytes)]
+        plan = ctx.make_plan(p_off, p_size, mn, av, mx)
+        cap = max(1, plan.capacity)
+        out_offs, out_lens, out_hash = self.buf("offs", cap * 8, torch.int64), self.buf("lens", cap * 4, torch.int32), self.buf("hash", cap * 8, torch.int64)
+        out_first = self.buf("first", (nfiles + 1) * 4, torch.int32)
+        h_first = self.buf("first_host", (nfiles + 1) * 4, torch.int32, pinned=True)
+        vi_cap = int(self.lib.dll.lthip_version_index_size(nfiles, cap, cap, len(tree["path_data"]))) + 64
+        h_vi, h_si = self.buf("vi", vi_cap, pinned=True), self.buf("si", 16 + 32 * cap + 64, pinned=True)
+        job_asset = np.arange(nfiles, dtype=np.uint32)
+        h2d, d2h = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        cur = torch.cuda.current_stream(self.dev)
+
+        def link_rate(dst, src):
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize(self.dev)
+                t0 = time.perf_counter()
+                dst[:n].copy_(src[:n], non_blocking=True)
+                torch.cuda.synchronize(self.dev)
+                t = time.perf_counter() - t0
+                best = t if best is None or t < best else best
+            return n / best / 1e9
+
+        out = {"workload": f"{slices} x {slice_gib:g} GiB slices of the headline tree in pinned host memory, streamed {rounds} x: H2D | chunk+hash+index+write | "
+                           "stored-block images D2H, double buffered on three streams; a session (VersionIndex + StoreIndex + images) per slice",
+               "unit": "GB/s of input", "pinned_alloc_s": round(pin_s, 2)}
+        for kind in kinds:
+            for i in range(slices):
+                ctx.synth_fill(data[0], p_off, p_size, asset_seeds(0x10C0FFEE, i * nfiles, nfiles), KINDS[kind])
+                ctx.sync()
+                host_in[i][:n].copy_(data[0][:n])
+            torch.cuda.synchronize(self.dev)
+            if "h2d_GBps" not in out:
+                out["h2d_GBps"] = round(link_rate(data[0], host_in[0]), 2)
+                out["d2h_GBps"] = round(link_rate(host_out[0], data[0]), 2)
+            ing = Ingest(ctx, args.target_chunk_size, args.block_size, args.max_chunks_per_block, "lz4", batch_bytes=n)
+            ev_in = [torch.cuda.Event() for _ in range(2)]
+            ev_done = [torch.cuda.Event() for _ in range(2)]
+            ev_out = [torch.cuda.Event() for _ in range(2)]
+            total_slices = slices * rounds
+            image_bytes = 0
+            res = None
+
+            def upload(k):
+                b = k % 2
+                h2d.wait_event(ev_done[b])  # (the session of slice k - 2 has read data[b] to the end)
+                with torch.cuda.stream(h2d):
+                    data[b][:n].copy_(host_in[k % slices][:n], non_blocking=True)
+                    ev_in[b].record(h2d)
+
+            def one_pass(count):
+                nonlocal image_bytes, res
+                image_bytes = 0
+                upload(0)
+                for k in range(count):
+                    b = k % 2
+                    if k + 1 < count:
+                        upload(k + 1)
+                    cur.wait_event(ev_in[b])
+                    cur.wait_event(ev_out[b])  # (packed[b] has left for the host)
+                    plan.reaim(p_off, p_size)
+                    ctx.chunk_hash(plan, data[b], outputs=(out_offs, out_lens, out_hash, out_first), sync=False)
+                    ctx._check(self.lib.dll.lthip_copy_d2h(ctx.h, h_first.data_ptr(), out_first.data_ptr(), (nfiles + 1) * 4), "lthip_copy_d2h")
+                    ctx.sync()
+                    first_host = h_first.numpy()[: nfiles + 1].view(np.uint32)
+                    total = int(first_host[nfiles])
+                    tr, keep = Ingest.tree(tree["sizes"], tree["path_offsets"], tree["perms"], tree["path_data"], job_asset, first_host.astype(np.uint64), None)
+                    ing.index(tr, out_hash, out_lens, total, out_offs, out_first, total, h_vi)
+                    ing.write(data[b], arena[b])
+                    res = ing.finish(h_si)
+                    _, offs, sizes = ing.images()
+                    assert len(offs) == res.blocks, "a slice must fit one codec batch"
+                    dst = np.zeros(len(offs) + 1, np.int64)
+                    np.cumsum((sizes.astype(np.int64) + 7) // 8 * 8, out=dst[1:])
+                    tot = int(dst[-1])
+                    ctx.gather_ranges(arena[b], torch.from_numpy(offs.view(np.int64)).to(self.dev), torch.from_numpy(sizes.view(np.int32)).to(self.dev),
+                                      packed[b], torch.from_numpy(dst[:-1].copy()).to(self.dev))
+                    ev_done[b].record(cur)
+                    d2h.wait_event(ev_done[b])
+                    with torch.cuda.stream(d2h):
+                        host_out[b][:tot].copy_(packed[b][:tot], non_blocking=True)
+                        ev_out[b].record(d2h)
+                    image_bytes += tot
+                torch.cuda.synchronize(self.dev)
+
+            one_pass(2)  # warm-up: allocations of the session, the plan, the streams
+            t0 = time.perf_counter()
+            one_pass(total_slices)
+            dt = time.perf_counter() - t0
+            ing.close()
+            gbps = total_slices * n / dt / 1e9
+            out[kind] = {"value": round(gbps, 2), "ms_per_slice": round(dt / total_slices * 1e3, 2), "ratio": round(res.raw_bytes / max(1, res.compressed_bytes), 3),
+                         "image_bytes_per_input_byte": round(image_bytes / (total_slices * n), 4),
+                         "frac_of_h2d": round(gbps / out["h2d_GBps"], 3)}
+        plan.close()
+        for k in [k for k in self.bufs if k.startswith("hf_")]:
+            self.bufs[k] = None
         return out
 
     # ------------------------------------------------------------------------------------------------------------
@@ -731,9 +888,14 @@ def main():
                 secondary[name]["dedup_table"] = args.dedup if b.world > 1 else "single rank"
         if b.world == 1:
             secondary["restore"] = b.restore_rates()
+            secondary["host_fed"] = b.host_fed_rates()
     cpu_baseline = None
     if b.rank == 0 and b.world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(args)
+        if cpu_baseline and cpu_baseline.get("drop_in") is not None:
+            if secondary is None:
+                secondary = {}
+            secondary["drop_in"] = cpu_baseline.pop("drop_in")
     if b.rank == 0:
         line = {
             "metric": "ingest GB/s (chunk+hash+compress)",
@@ -898,8 +1060,8 @@ def run_cpu_baseline(args):
     sweep = sorted({1, min(32, ncpu), physical, ncpu})
     reps = 3
 
-    def measure(files, workers):
-        res = r.ingest_sweep(files, args.target_chunk_size, args.block_size, args.max_chunks_per_block, tag, workers, reps)
+    def measure(files, workers, apis=(None, None, None)):
+        res = r.ingest_sweep(files, args.target_chunk_size, args.block_size, args.max_chunks_per_block, tag, workers, reps, *apis)
         if res["err"]:
             return None
         nbytes = sum(len(d) for _, d in files)
@@ -920,6 +1082,34 @@ def run_cpu_baseline(args):
     one = measure(files[:n_small], [1])
     if one:
         by_w["1"] = dict(one["1"], sample_files=n_small)
+    # ---- secondary.drop_in: the SAME sample, harness and worker count with this library's plugin objects in the unmodified core --
+    # what a longtail embedder gets by switching the three constructors and nothing else (host buffers in, host buffers out: PCIe,
+    # the pull-style per-chunk API and the core's own file reads are all inside)
+    drop_in = None
+    w_drop = min(32, ncpu)
+    if str(w_drop) in by_w:
+        try:
+            from longtail_amd.lib import load
+
+            d = load().dll
+            chunker, hasher = d.Longtail_CreateHipChunkerAPI(), d.Longtail_CreateHipBlake3HashAPI()
+            codec_api = d.Longtail_CreateHipLZ4CompressionAPI() if args.codec == "lz4" else d.Longtail_CreateHipZStdCompressionAPI()
+            r.version_index(files[: min(1024, len(files))], args.target_chunk_size, w_drop, 0, chunker, hasher)  # warm-up: contexts, window pool
+            hip = measure(files, [w_drop], (chunker, hasher, codec_api))
+            if hip:
+                h, c = hip[str(w_drop)], by_w[str(w_drop)]
+                nbytes = sum(len(x) for _, x in files)
+                drop_in = {"what": "the unmodified reference core (oracle/_ref) with Longtail_CreateHipChunkerAPI + HipBlake3HashAPI + Hip"
+                                   f"{args.codec.upper()}CompressionAPI against its own CPU plugins: same files, same storage, same bikeshed worker count, median of {reps}",
+                           "workers": w_drop, "sample_files": len(files),
+                           "upsync_GBps": {"hip_plugins": h["GBps"], "cpu_plugins": c["GBps"], "ratio": round(h["GBps"] / c["GBps"], 3)},
+                           "create_version_index_GBps": {"hip_plugins": round(nbytes / h["index_s"] / 1e9, 3), "cpu_plugins": round(nbytes / c["index_s"] / 1e9, 3),
+                                                         "ratio": round(c["index_s"] / h["index_s"], 3)},
+                           "write_content_GBps": {"hip_plugins": round(nbytes / h["write_s"] / 1e9, 3), "cpu_plugins": round(nbytes / c["write_s"] / 1e9, 3),
+                                                  "ratio": round(c["write_s"] / h["write_s"], 3)},
+                           "seconds": {"hip_plugins": h, "cpu_plugins": c}}
+        except Exception as e:  # (the baseline itself must not fail with it)
+            drop_in = {"error": repr(e)}
     del files
     cfg0 = measure(make_files(1, 268_435_456, first=1), [w for w in sweep if w > 1][:1] + [ncpu])  # BASELINE.json configs[0]
     if not by_w:
@@ -930,7 +1120,8 @@ def run_cpu_baseline(args):
                       f"Longtail_CreateMissingContent + Longtail_WriteContent, reference hpcdc+BLAKE3+{args.codec.upper()}, bikeshed W workers, "
                       f"{storage}, null block sink; median of {reps}; value = best W",
             "by_workers": by_w, "physical_cores": physical, "host_cpus": ncpu,
-            "configs0_one_256MiB_file": cfg0}
+            "configs0_one_256MiB_file": cfg0, "drop_in": drop_in,
+            "sample_fraction_of_tree": round(n_big * file_bytes / float(int(args.gib * (1 << 30))), 4)}
 
 
 if __name__ == "__main__":

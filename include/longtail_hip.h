@@ -453,6 +453,14 @@ LTHIP_EXPORT int lthip_ingest_set_first_seen(lthip_ingest* ingest, const uint32_
 LTHIP_EXPORT int lthip_ingest_write(lthip_ingest* ingest, const void* d_data, void* d_arena, uint64_t arena_bytes);
 LTHIP_EXPORT int lthip_ingest_finish(lthip_ingest* ingest, void* h_store_index, size_t store_index_capacity,
                                      lthip_ingest_result* out_result);
+/* The stored-block images of the LAST codec batch of lthip_ingest_write (host tables owned by the session, valid after
+ * lthip_ingest_finish until the next lthip_ingest_index): blocks *out_first_block .. + *out_count of the session; image i lies at
+ * d_arena + offsets[i] and is sizes[i] bytes long -- BlockIndex, [raw size][compressed size], payload: exactly what
+ * Longtail_WriteStoredBlockToBuffer produces and PutStoredBlock receives (src/longtail.c:4111-4150, 4722-4757).  A session whose
+ * write fit ONE batch (raw bytes <= cfg.batch_bytes, and the arena) has all of its images there: the host-fed loop of INTEGRATION.md
+ * (pinned slice -> H2D -> lthip_chunk_hash -> session -> images D2H) downloads them through this table. */
+LTHIP_EXPORT int lthip_ingest_images(const lthip_ingest* ingest, uint64_t* out_first_block, uint64_t* out_count,
+                                     const uint64_t** out_offsets, const uint32_t** out_sizes);
 /* per-block compressed sizes of the last lthip_ingest_write (host, valid after lthip_ingest_finish) */
 LTHIP_EXPORT const uint32_t* lthip_ingest_compressed_sizes(const lthip_ingest* ingest);
 

@@ -204,6 +204,11 @@ struct lthip_ingest
     std::vector<uint32_t> vi_starts, vi_counts;
     const uint64_t* vi_hashes;
     void* vi_out;
+    // the stored-block images of the last codec batch (lthip_ingest_images): first block, offsets in the arena, header sizes; the image
+    // sizes are completed by lthip_ingest_finish (they need the compressed sizes)
+    uint64_t img_first;
+    std::vector<uint64_t> img_offsets;
+    std::vector<uint32_t> img_sizes;
 };
 
 // LTHIP_INGEST_TRACE=1: host time between the marks of lthip_ingest_index / _write, to stderr
@@ -829,6 +834,9 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
     const uint64_t* offs = (const uint64_t*)g->h_mu_off.p;
     int err;
     uint64_t gathered_blocks = 0, gathered_bytes = 0;
+    g->img_first = 0;
+    g->img_offsets.clear();
+    g->img_sizes.clear();
     std::vector<uint64_t> src_off, dst_off, img_off, g_src, g_dst, bfirst;
     std::vector<uint32_t> src_size, dst_cap, g_len, braw;
     // more blocks, when the batch being put together has taken all there are and chunks are left
@@ -1018,6 +1026,11 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
                                (const uint32_t*)g->d_comp.p + b0, (const uint64_t*)g->d_bimg.p, (uint8_t*)d_arena);
             LTHIP_LAUNCH_CHECK(ctx);
         }
+        g->img_first = b0;
+        g->img_offsets.assign(img_off.begin(), img_off.end());
+        g->img_sizes.resize(cnt);
+        for (size_t b = b0; b < b1; ++b)
+            g->img_sizes[b - b0] = (uint32_t)lthip_stored_block_header_size((uint32_t)(g->b_first[b + 1] - g->b_first[b]));
         b0 = b1;
     }
     if ((err = ingest_vi_start(g)) || (err = ingest_blocks_done(g))) // (nothing to write)
@@ -1094,6 +1107,12 @@ extern "C" int lthip_ingest_finish(lthip_ingest* g, void* h_store_index, size_t 
             return lthip_fail(ctx, vi_err, "lthip_ingest_finish: VersionIndex", g->vi_ctx ? g->vi_ctx->err : "");
     }
     g->res.compressed_bytes = g->written ? *(const uint64_t*)g->h_comp.p : 0;
+    if (g->written)
+    {
+        const uint32_t* comp = (const uint32_t*)((const uint8_t*)g->h_comp.p + 8);
+        for (size_t i = 0; i < g->img_sizes.size(); ++i)
+            g->img_sizes[i] += comp[g->img_first + i]; // header (BlockIndex + [raw][compressed]) + payload
+    }
     if (out)
     {
         // (the caller says how large ITS struct is: a header older or newer than this library's never gets written past its end)
@@ -1104,6 +1123,22 @@ extern "C" int lthip_ingest_finish(lthip_ingest* g, void* h_store_index, size_t 
         memcpy(out, &g->res, (size_t)g->res.struct_size);
     }
     return rc;
+}
+
+extern "C" int lthip_ingest_images(const lthip_ingest* g, uint64_t* out_first_block, uint64_t* out_count, const uint64_t** out_offsets,
+                                   const uint32_t** out_sizes)
+{
+    if (!g || !g->written)
+        return EINVAL;
+    if (out_first_block)
+        *out_first_block = g->img_first;
+    if (out_count)
+        *out_count = g->img_offsets.size();
+    if (out_offsets)
+        *out_offsets = g->img_offsets.data();
+    if (out_sizes)
+        *out_sizes = g->img_sizes.data();
+    return 0;
 }
 
 extern "C" const uint32_t* lthip_ingest_compressed_sizes(const lthip_ingest* g) { return g && g->written ? (const uint32_t*)((const uint8_t*)g->h_comp.p + 8) : nullptr; }

@@ -154,6 +154,7 @@ class HipLib:
         sig("lthip_ingest_write", i32, [vp, vp, vp, u64])
         sig("lthip_ingest_finish", i32, [vp, vp, sz, vp])
         sig("lthip_ingest_compressed_sizes", vp, [vp])
+        sig("lthip_ingest_images", i32, [vp, P(u64), P(u64), P(vp), P(vp)])
         sig("lthip_divtest_eval", i32, [u32, u32])
         sig("lthip_job_count", u64, [u32, vp, u32])
         sig("lthip_make_jobs", i32, [u32, vp, u32, u64, vp, vp, vp])
@@ -636,6 +637,17 @@ class Ingest:
         self.ctx._check(err, "lthip_ingest_finish")
         self._index_keep = None
         return res
+
+    def images(self):
+        """(first block, offsets into the arena [u64], image sizes [u32]) of the last codec batch: the stored-block images a host-fed
+        embedder downloads (lthip_ingest_images; valid after finish())."""
+        first, count, po, ps = C.c_uint64(), C.c_uint64(), C.c_void_p(), C.c_void_p()
+        self.ctx._check(self.ctx.lib.dll.lthip_ingest_images(self.h, C.byref(first), C.byref(count), C.byref(po), C.byref(ps)), "lthip_ingest_images")
+        n = int(count.value)
+        if n == 0:
+            return int(first.value), np.zeros(0, np.uint64), np.zeros(0, np.uint32)
+        return (int(first.value), np.ctypeslib.as_array((C.c_uint64 * n).from_address(po.value)).copy(),
+                np.ctypeslib.as_array((C.c_uint32 * n).from_address(ps.value)).copy())
 
     def compressed_sizes(self, nblocks: int) -> np.ndarray:
         p = self.ctx.lib.dll.lthip_ingest_compressed_sizes(self.h)

@@ -963,17 +963,19 @@ int refh_ingest_time(uint32_t tag, uint32_t nfiles, const char* const* names, co
  *     -> Longtail_WriteContent (compressblockstore over a null block sink)
  * with the reference's plugins and Longtail_CreateBikeshedJobAPI(W, 0).  out_seconds[(w * reps + r) * 3 + {0,1,2}] = seconds of
  * the three calls. */
-int refh_ingest_sweep(uint32_t tag, uint32_t nfiles, const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
-                      uint32_t target_chunk_size, uint32_t max_block_size, uint32_t max_chunks_per_block, uint32_t n_workers,
-                      const int* workers, uint32_t reps, double* out_seconds, uint64_t* out_chunk_count, uint64_t* out_block_count,
-                      uint64_t* out_stored_bytes)
+static int ingest_sweep_impl(struct Longtail_ChunkerAPI* foreign_chunker, struct Longtail_HashAPI* foreign_hash,
+                             struct Longtail_CompressionAPI* foreign_codec, uint32_t tag, uint32_t nfiles, const char* const* names,
+                             const uint8_t* const* datas, const uint64_t* sizes, uint32_t target_chunk_size, uint32_t max_block_size,
+                             uint32_t max_chunks_per_block, uint32_t n_workers, const int* workers, uint32_t reps, double* out_seconds,
+                             uint64_t* out_chunk_count, uint64_t* out_block_count, uint64_t* out_stored_bytes)
 {
     struct refh_tree t;
     int err = tree_make(&t, nfiles, names, datas, sizes, 1, tag);
     if (err)
         return err;
-    struct Longtail_ChunkerAPI* chunker_api = Longtail_CreateHPCDCChunkerAPI();
-    struct Longtail_HashAPI* hash_api = Longtail_CreateBlake3HashAPI();
+    /* a plugin object handed in (the embedder's: liblongtail_hip.so's constructors) replaces the reference's; it stays the caller's */
+    struct Longtail_ChunkerAPI* chunker_api = foreign_chunker ? foreign_chunker : Longtail_CreateHPCDCChunkerAPI();
+    struct Longtail_HashAPI* hash_api = foreign_hash ? foreign_hash : Longtail_CreateBlake3HashAPI();
     for (uint32_t w = 0; w < n_workers && !err; ++w)
     {
         struct Longtail_JobAPI* jobs = Longtail_CreateBikeshedJobAPI((uint32_t)workers[w], 0);
@@ -982,7 +984,7 @@ int refh_ingest_sweep(uint32_t tag, uint32_t nfiles, const char* const* names, c
             struct Longtail_VersionIndex* vi = 0;
             struct Longtail_StoreIndex* existing = 0;
             struct Longtail_StoreIndex* missing = 0;
-            struct Longtail_CompressionRegistryAPI* reg = make_registry(0, tag);
+            struct Longtail_CompressionRegistryAPI* reg = make_registry(foreign_codec, tag);
             struct Longtail_BlockStoreAPI* sink = make_null_store();
             struct Longtail_BlockStoreAPI* cbs = Longtail_CreateCompressBlockStoreAPI(sink, reg);
             double* secs = out_seconds + ((size_t)w * reps + r) * 3;
@@ -1029,10 +1031,34 @@ int refh_ingest_sweep(uint32_t tag, uint32_t nfiles, const char* const* names, c
         }
         SAFE_DISPOSE_API(jobs);
     }
-    SAFE_DISPOSE_API(chunker_api);
-    SAFE_DISPOSE_API(hash_api);
+    if (!foreign_chunker)
+        SAFE_DISPOSE_API(chunker_api);
+    if (!foreign_hash)
+        SAFE_DISPOSE_API(hash_api);
     tree_free(&t);
     return err;
+}
+
+int refh_ingest_sweep(uint32_t tag, uint32_t nfiles, const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
+                      uint32_t target_chunk_size, uint32_t max_block_size, uint32_t max_chunks_per_block, uint32_t n_workers,
+                      const int* workers, uint32_t reps, double* out_seconds, uint64_t* out_chunk_count, uint64_t* out_block_count,
+                      uint64_t* out_stored_bytes)
+{
+    return ingest_sweep_impl(0, 0, 0, tag, nfiles, names, datas, sizes, target_chunk_size, max_block_size, max_chunks_per_block, n_workers,
+                             workers, reps, out_seconds, out_chunk_count, out_block_count, out_stored_bytes);
+}
+
+/* The same measurement with the EMBEDDER'S plugin objects in the unmodified core (any of them 0 = the reference's): what a longtail
+ * user gets by switching constructors and nothing else (bench.py secondary.drop_in). */
+int refh_ingest_sweep_apis(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_HashAPI* hash_api,
+                           struct Longtail_CompressionAPI* codec_api, uint32_t tag, uint32_t nfiles, const char* const* names,
+                           const uint8_t* const* datas, const uint64_t* sizes, uint32_t target_chunk_size, uint32_t max_block_size,
+                           uint32_t max_chunks_per_block, uint32_t n_workers, const int* workers, uint32_t reps, double* out_seconds,
+                           uint64_t* out_chunk_count, uint64_t* out_block_count, uint64_t* out_stored_bytes)
+{
+    return ingest_sweep_impl(chunker_api, hash_api, codec_api, tag, nfiles, names, datas, sizes, target_chunk_size, max_block_size,
+                             max_chunks_per_block, n_workers, workers, reps, out_seconds, out_chunk_count, out_block_count,
+                             out_stored_bytes);
 }
 
 int refh_cpu_count(void) { return (int)Longtail_GetCPUCount(); }

@@ -135,6 +135,7 @@ class Ref:
         sig("refh_cpu_count", i32, [])
         sig("refh_get_existing_store_index", i32, [vp, u64, vp, u32, u32, C.POINTER(vp), C.POINTER(u64)])
         sig("refh_ingest_sweep", i32, [u32, u32, vp, vp, vp, u32, u32, u32, u32, vp, u32, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)])
+        sig("refh_ingest_sweep_apis", i32, [vp, vp, vp, u32, u32, vp, vp, vp, u32, u32, u32, u32, vp, u32, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)])
         sig("refh_chunk_stream_failing_feeder", i64, [vp, vp, u64, u32, u32, u32, u64, i32, vp, u64, vp])
         sig("refh_version_index_cancel", i32, [vp, vp, u32, vp, vp, vp, u32, i32, u32, C.POINTER(i32), C.POINTER(u32)])
         sig("refh_tree_file_infos", i32, [u32, vp, vp, vp, C.POINTER(vp), C.POINTER(u64)])
@@ -276,15 +277,18 @@ class Ref:
         self.dll.refh_free(buf)
         return out
 
-    def ingest_sweep(self, files, target_chunk_size, max_block_size, max_chunks_per_block, tag, workers, reps):
+    def ingest_sweep(self, files, target_chunk_size, max_block_size, max_chunks_per_block, tag, workers, reps,
+                     chunker_api=None, hash_api=None, codec_api=None):
         """One tree, then CreateVersionIndex + CreateMissingContent + WriteContent timed for every W of `workers`, `reps` times.
-        -> dict(err, chunks, blocks, stored_bytes, seconds[w][r] = (index, missing, write))"""
+        -> dict(err, chunks, blocks, stored_bytes, seconds[w][r] = (index, missing, write)).  chunker_api / hash_api / codec_api: the
+        embedder's plugin objects in the unmodified core instead of the reference's (the drop-in measurement)."""
         n, c_names, c_datas, c_sizes, keep = self._tree_args(files)
         w = np.ascontiguousarray(workers, dtype=np.int32)
         secs = np.zeros((len(w), reps, 3), np.float64)
         nchunks, nblocks, stored = u64(0), u64(0), u64(0)
-        err = self.dll.refh_ingest_sweep(tag, n, c_names, c_datas, c_sizes, target_chunk_size, max_block_size, max_chunks_per_block,
-                                         len(w), w.ctypes.data, reps, secs.ctypes.data, C.byref(nchunks), C.byref(nblocks), C.byref(stored))
+        err = self.dll.refh_ingest_sweep_apis(chunker_api, hash_api, codec_api, tag, n, c_names, c_datas, c_sizes, target_chunk_size,
+                                              max_block_size, max_chunks_per_block, len(w), w.ctypes.data, reps, secs.ctypes.data,
+                                              C.byref(nchunks), C.byref(nblocks), C.byref(stored))
         return dict(err=err, chunks=nchunks.value, blocks=nblocks.value, stored_bytes=stored.value, seconds=secs)
 
 

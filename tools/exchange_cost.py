@@ -3,9 +3,8 @@
 Three legs, one JSON object (profiles/r05_exchange_cost.json):
 
   flow8   the real flow with R = 8 processes on the one GPU: `bench.py --gpus 8 --launch plain` over the shared-memory stand-in for
-          RCCL (LTHIP_COMM_TRANSPORT=shm), 8 x --gib of the headline tree -- once plain (phase_ms of the step as bench.py reports
-          it) and once with --exchange-profile (exchange + index split into host / device / transport; the "transport" here is the
-          host-staged stand-in, NOT xGMI).  Eight contexts time-slice one GPU, so device and transport figures of this leg say
+          RCCL (LTHIP_COMM_TRANSPORT=shm), 8 x --gib of the headline tree with --exchange-profile (exchange + index split into
+          host / device / transport; the "transport" here is the host-staged stand-in, NOT xGMI).  Eight contexts time-slice one GPU, so device and transport figures of this leg say
           "the flow runs at R = 8 and where its time goes", not what 8 GPUs would do.
   full    ONE rank's exchange + index at the FULL weak-scaling size (8 x 64 GiB: 524 288 jobs, ~17.3 M chunks, 2.16 M of them this
           rank's) with the collectives replaced by local copies of the right sizes (a loopback communicator): the host part and the
@@ -38,8 +37,10 @@ def leg_flow8(gib: float, world: int):
         env.pop(k, None)
     base = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--launch", "plain", "--gib", str(gib), "--batch-gib", "2", "--steps", "2",
             "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--no-live-traffic"]
-    out = {}
-    for name, extra in (("plain", []), ("profiled", ["--exchange-profile"])):
+    out = {"note": "only the PROFILED flow is run: unprofiled, eight processes contend for one GPU's hardware queues out of step, and every "
+                   "host-staged copy of the stand-in transport waits for a time slice behind another process's kernels (round 5's first "
+                   "run: 45 s of 'exchange' per step against 0.28 s in step) -- an artefact of one GPU standing in for eight, not of the flow"}
+    for name, extra in (("profiled", ["--exchange-profile"]),):
         r = subprocess.run(base + extra, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
