@@ -411,13 +411,18 @@ class Bench:
     def host_fed_rates(self, kinds=("random", "mixed"), slices=2, slice_gib=8.0, rounds=3):
         """secondary.host_fed -- the ingest path fed from HOST memory (what the reference's path starts from: StorageAPI.Read,
         src/longtail.c:1923-1960; block assembly :4640-4721), as the double-buffered loop INTEGRATION.md recommends to an embedder:
-        pinned slice k+1 -> H2D on a copy stream | lthip_chunk_hash + lthip_ingest_index / _write / _finish of slice k on the compute
-        stream | stored-block images of slice k-1 packed (lthip_gather_ranges over lthip_ingest_images) -> D2H on a second copy stream.
-        Every slice is a session of its own (its VersionIndex / StoreIndex land in pinned memory as in the headline); `slices` distinct
-        slices of the headline tree live in pinned host memory and are streamed `rounds` times.  PCIe is the ceiling here: the value
-        is reported next to the box's measured H2D / D2H rates."""
+        pinned slice k+1 -> HBM on a copy stream | lthip_chunk_hash + lthip_ingest_index / _write / _finish of slice k on the compute
+        stream | stored-block images of slice k-1 (lthip_ingest_images) -> pinned host memory on a second copy stream.
+        Each direction can be moved by the copy engines (hipMemcpyAsync; the images are packed on the device first) or by the compute
+        units (lthip_link_copy in, lthip_gather_ranges straight into pinned host memory out).  Which pair moves both directions at
+        once fastest differs from box to box and from process to process (tools/pcie_duplex_probe.py: two hipMemcpyAsync streams
+        were served one after the other in one lease -- a slice took the SUM of its two copies -- and side by side in the next; kernel
+        copies reached 46 GB/s per direction in the first and 34 in the second), so the loop times the four pairs on its own streams
+        first and takes the fastest.  Every slice is a session of its own (its VersionIndex / StoreIndex land in pinned memory as in
+        the headline); `slices` distinct slices of the headline tree live in pinned host memory and are streamed `rounds` times.
+        PCIe is the ceiling: the value is reported as a fraction of what the link did for the same bytes in the same directions."""
         torch, ctx, args = self.torch, self.ctx, self.args
-        from longtail_amd.lib import Ingest, chunker_params
+        from longtail_amd.lib import Context, Ingest, chunker_params
 
         FILE = 1 << 20
         nfiles = int(slice_gib * (1 << 30)) // FILE
@@ -434,7 +439,6 @@ class Bench:
         pin_s = time.perf_counter() - t0
         data = [self.buf("data", n + 256), self.buf("hf_data1", n + 256)]
         arena = [self.buf("arena", arena_bytes), self.buf("hf_arena1", arena_bytes)]
-        packed = [self.buf("hf_packed0", arena_bytes), self.buf("hf_packed1", arena_bytes)]
         plan = ctx.make_plan(p_off, p_size, mn, av, mx)
         cap = max(1, plan.capacity)
         out_offs, out_lens, out_hash = self.buf("offs", cap * 8, torch.int64), self.buf("lens", cap * 4, torch.int32), self.buf("hash", cap * 8, torch.int64)
@@ -445,30 +449,61 @@ class Bench:
         job_asset = np.arange(nfiles, dtype=np.uint32)
         h2d, d2h = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
         cur = torch.cuda.current_stream(self.dev)
+        ctx_in = Context(self.dev.index, stream=h2d.cuda_stream, lib=self.lib)
+        ctx_out = Context(self.dev.index, stream=d2h.cuda_stream, lib=self.lib)
 
-        def link_rate(dst, src):
+        def move_in(mode, dst, src, nbytes):  # on the h2d stream
+            if mode == "kernel":
+                ctx_in.link_copy(dst, src, nbytes)
+            else:
+                with torch.cuda.stream(h2d):
+                    dst[:nbytes].copy_(src[:nbytes], non_blocking=True)
+
+        def move_out(mode, dst, src, nbytes):  # on the d2h stream
+            if mode == "kernel":
+                ctx_out.link_copy(dst, src, nbytes)
+            else:
+                with torch.cuda.stream(d2h):
+                    dst[:nbytes].copy_(src[:nbytes], non_blocking=True)
+
+        def link_time(*legs):
             best = None
             for _ in range(3):
                 torch.cuda.synchronize(self.dev)
                 t0 = time.perf_counter()
-                dst[:n].copy_(src[:n], non_blocking=True)
+                for f in legs:
+                    f()
                 torch.cuda.synchronize(self.dev)
                 t = time.perf_counter() - t0
                 best = t if best is None or t < best else best
-            return n / best / 1e9
+            return best
 
-        out = {"workload": f"{slices} x {slice_gib:g} GiB slices of the headline tree in pinned host memory, streamed {rounds} x: H2D | chunk+hash+index+write | "
-                           "stored-block images D2H, double buffered on three streams; a session (VersionIndex + StoreIndex + images) per slice",
+        out = {"workload": f"{slices} x {slice_gib:g} GiB slices of the headline tree in pinned host memory, streamed {rounds} x: slice in | chunk+hash+index+write | "
+                           "stored-block images out to pinned host memory, double buffered on three streams; a session (VersionIndex + StoreIndex + images) per slice",
                "unit": "GB/s of input", "pinned_alloc_s": round(pin_s, 2)}
+        # ---- the link, measured on the loop's own streams: each direction alone, then the four pairs ----
+        link = {"bytes_per_direction": n}
+        for m in ("engine", "kernel"):
+            link[f"in_{m}_GBps"] = round(n / link_time(lambda: move_in(m, data[0], host_in[0], n)) / 1e9, 2)
+            link[f"out_{m}_GBps"] = round(n / link_time(lambda: move_out(m, host_out[0], data[1], n)) / 1e9, 2)
+        pairs = {}
+        for mi in ("engine", "kernel"):
+            for mo in ("engine", "kernel"):
+                pairs[(mi, mo)] = link_time(lambda: move_in(mi, data[0], host_in[0], n), lambda: move_out(mo, host_out[0], data[1], n))
+                link[f"both_in_{mi}_out_{mo}_GBps_per_direction"] = round(n / pairs[(mi, mo)] / 1e9, 2)
+        mode_in, mode_out = min(pairs, key=pairs.get)
+        link["chosen"] = {"in": mode_in, "out": mode_out}
+        out["link"] = link
+        out["h2d_GBps"] = max(link["in_engine_GBps"], link["in_kernel_GBps"])
+        out["d2h_GBps"] = max(link["out_engine_GBps"], link["out_kernel_GBps"])
+        duplex = n / pairs[(mode_in, mode_out)] / 1e9
+        packed = [self.buf("hf_packed0", arena_bytes), self.buf("hf_packed1", arena_bytes)] if mode_out == "engine" else None
         for kind in kinds:
             for i in range(slices):
                 ctx.synth_fill(data[0], p_off, p_size, asset_seeds(0x10C0FFEE, i * nfiles, nfiles), KINDS[kind])
                 ctx.sync()
                 host_in[i][:n].copy_(data[0][:n])
             torch.cuda.synchronize(self.dev)
-            if "h2d_GBps" not in out:
-                out["h2d_GBps"] = round(link_rate(data[0], host_in[0]), 2)
-                out["d2h_GBps"] = round(link_rate(host_out[0], data[0]), 2)
             ing = Ingest(ctx, args.target_chunk_size, args.block_size, args.max_chunks_per_block, "lz4", batch_bytes=n)
             ev_in = [torch.cuda.Event() for _ in range(2)]
             ev_done = [torch.cuda.Event() for _ in range(2)]
@@ -476,13 +511,13 @@ class Bench:
             total_slices = slices * rounds
             image_bytes = 0
             res = None
+            keep_alive = [None, None]
 
             def upload(k):
                 b = k % 2
                 h2d.wait_event(ev_done[b])  # (the session of slice k - 2 has read data[b] to the end)
-                with torch.cuda.stream(h2d):
-                    data[b][:n].copy_(host_in[k % slices][:n], non_blocking=True)
-                    ev_in[b].record(h2d)
+                move_in(mode_in, data[b], host_in[k % slices], n)
+                ev_in[b].record(h2d)
 
             def one_pass(count):
                 nonlocal image_bytes, res
@@ -493,7 +528,7 @@ class Bench:
                     if k + 1 < count:
                         upload(k + 1)
                     cur.wait_event(ev_in[b])
-                    cur.wait_event(ev_out[b])  # (packed[b] has left for the host)
+                    cur.wait_event(ev_out[b])  # (the images of slice k - 2 have left arena[b] / packed[b] for the host)
                     plan.reaim(p_off, p_size)
                     ctx.chunk_hash(plan, data[b], outputs=(out_offs, out_lens, out_hash, out_first), sync=False)
                     ctx._check(self.lib.dll.lthip_copy_d2h(ctx.h, h_first.data_ptr(), out_first.data_ptr(), (nfiles + 1) * 4), "lthip_copy_d2h")
@@ -509,13 +544,18 @@ class Bench:
                     dst = np.zeros(len(offs) + 1, np.int64)
                     np.cumsum((sizes.astype(np.int64) + 7) // 8 * 8, out=dst[1:])
                     tot = int(dst[-1])
-                    ctx.gather_ranges(arena[b], torch.from_numpy(offs.view(np.int64)).to(self.dev), torch.from_numpy(sizes.view(np.int32)).to(self.dev),
-                                      packed[b], torch.from_numpy(dst[:-1].copy()).to(self.dev))
+                    t_offs, t_sizes = torch.from_numpy(offs.view(np.int64)).to(self.dev), torch.from_numpy(sizes.view(np.int32)).to(self.dev)
+                    t_dst = torch.from_numpy(dst[:-1].copy()).to(self.dev)
+                    if mode_out == "engine":  # pack on the compute stream, then one copy
+                        ctx.gather_ranges(arena[b], t_offs, t_sizes, packed[b], t_dst)
                     ev_done[b].record(cur)
                     d2h.wait_event(ev_done[b])
-                    with torch.cuda.stream(d2h):
-                        host_out[b][:tot].copy_(packed[b][:tot], non_blocking=True)
-                        ev_out[b].record(d2h)
+                    if mode_out == "engine":
+                        move_out("engine", host_out[b], packed[b], tot)
+                    else:
+                        ctx_out.gather_ranges(arena[b], t_offs, t_sizes, host_out[b], t_dst)  # device ranges -> pinned host memory
+                    ev_out[b].record(d2h)
+                    keep_alive[b] = (t_offs, t_sizes, t_dst)  # (read by the gather on the d2h stream)
                     image_bytes += tot
                 torch.cuda.synchronize(self.dev)
 
@@ -525,9 +565,16 @@ class Bench:
             dt = time.perf_counter() - t0
             ing.close()
             gbps = total_slices * n / dt / 1e9
+            back = image_bytes / (total_slices * n)
+            # the link's ceiling for this slice: n bytes in beside back * n bytes out -- the both-directions rate while both run
+            # (the shorter transfer's length), the one-direction rate for the rest
+            one_way = out["h2d_GBps"]
+            t_link = min(back, 1.0) * n / duplex / 1e9 + abs(1.0 - back) * n / one_way / 1e9
             out[kind] = {"value": round(gbps, 2), "ms_per_slice": round(dt / total_slices * 1e3, 2), "ratio": round(res.raw_bytes / max(1, res.compressed_bytes), 3),
-                         "image_bytes_per_input_byte": round(image_bytes / (total_slices * n), 4),
-                         "frac_of_h2d": round(gbps / out["h2d_GBps"], 3)}
+                         "image_bytes_per_input_byte": round(back, 4), "frac_of_h2d": round(gbps / one_way, 3),
+                         "link_ms_per_slice": round(t_link * 1e3, 2), "frac_of_link": round(t_link / (dt / total_slices), 3)}
+        ctx_in.close()
+        ctx_out.close()
         plan.close()
         for k in [k for k in self.bufs if k.startswith("hf_")]:
             self.bufs[k] = None

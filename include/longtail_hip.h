@@ -121,6 +121,12 @@ LTHIP_EXPORT int lthip_malloc_pinned(lthip_ctx* ctx, size_t bytes, void** out);
 LTHIP_EXPORT void lthip_free_pinned(lthip_ctx* ctx, void* p);
 LTHIP_EXPORT int lthip_copy_h2d(lthip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 LTHIP_EXPORT int lthip_copy_d2h(lthip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+/* The same copy made by the compute units instead of the copy engines, either direction, `dst` and `src` 16-byte aligned, the
+ * host side PINNED (lthip_malloc_pinned / hipHostMalloc).  On the MI355X boxes measured (profiles/r05_pcie_duplex.json) the copy
+ * engines serve one direction at a time -- h2d and d2h queued on two streams take the sum of their times -- while kernel copies
+ * in both directions overlap (46 GB/s each against 57 GB/s alone): a loop that streams slices in and block images out uses this
+ * (and lthip_gather_ranges, which accepts pinned host memory as source or destination too) on contexts of their own. */
+LTHIP_EXPORT int lthip_link_copy(lthip_ctx* ctx, void* dst, const void* src, size_t bytes);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py roofline leg). */
 enum lthip_kernel_id

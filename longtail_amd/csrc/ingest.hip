@@ -221,7 +221,7 @@ struct IngTrace
     size_t len;
     explicit IngTrace(const char* w) : what(w), len(0)
     {
-        static LthipEnvInt env{"LTHIP_INGEST_TRACE"};
+        LTHIP_ABLATION_ENV(env, "LTHIP_INGEST_TRACE");
         on = env.get() > 0;
         if (on)
             t0 = last = std::chrono::steady_clock::now();
@@ -539,7 +539,7 @@ static int ingest_vi_start(lthip_ingest* g)
         return 0;
     g->vi_pending = false;
     lthip_ctx* ctx = g->ctx;
-    static LthipEnvInt env_vit{"LTHIP_INGEST_VI_THREAD"};
+    LTHIP_ABLATION_ENV(env_vit, "LTHIP_INGEST_VI_THREAD");
     if (env_vit.get() == 0)
         return ingest_vi_work(g, ctx);
     if (!g->vi_ctx && lthip_ctx_create(ctx->device, LTHIP_STREAM_PRIVATE, &g->vi_ctx) != 0)
@@ -708,7 +708,7 @@ extern "C" int lthip_ingest_index(lthip_ingest* g, const lthip_ingest_tree* t, c
     // stream next to the codec kernels (ev_offs, ev_hashes)
     uint32_t head = nm;
     {
-        static LthipEnvInt env_slices{"LTHIP_INGEST_PACK_SLICES"};
+        LTHIP_ABLATION_ENV(env_slices, "LTHIP_INGEST_PACK_SLICES");
         uint64_t tree_bytes = 0;
         for (uint32_t a = 0; a < na; ++a)
             tree_bytes += t->asset_sizes[a];

@@ -230,29 +230,9 @@ __device__ __forceinline__ void b3_parent(uint32_t* __restrict__ left, const uin
     reinterpret_cast<uint4*>(left)[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
 }
 
-// small trees: one thread reduces one range in place (stride doubling keeps every node at the slot of its
-// left-most leaf; an odd node simply stays put == carried up)
-__global__ __launch_bounds__(256) void k_blake3_parents_small(const uint32_t* __restrict__ lens,
-                                                              const uint32_t* __restrict__ leaf_prefix,
-                                                              uint64_t count_bound, const uint32_t* __restrict__ n_dev,
-                                                              uint32_t* __restrict__ cvs, uint64_t* __restrict__ hashes)
-{
-    const uint32_t count = (uint32_t)(n_dev ? (*n_dev < count_bound ? *n_dev : count_bound) : count_bound);
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= count)
-        return;
-    const uint32_t slot0 = leaf_prefix[c];
-    const uint32_t n = leaf_prefix[c + 1] - slot0;
-    uint32_t* base = cvs + (uint64_t)slot0 * 8u;
-    for (uint32_t stride = 1; stride < n; stride <<= 1)
-    {
-        const uint32_t last = (stride << 1) >= n; // top level: exactly one merge, it carries ROOT
-        for (uint32_t k = 0; k + stride < n; k += stride << 1)
-            b3_parent(base + (uint64_t)k * 8u, base + (uint64_t)(k + stride) * 8u,
-                      (uint32_t)F_PARENT | (last ? (uint32_t)F_ROOT : 0u));
-    }
-    hashes[c] = (uint64_t)base[0] | ((uint64_t)base[1] << 32);
-}
+#ifdef LTHIP_ABLATIONS
+#include "ablations/k_blake3_parents_small.inc"
+#endif
 
 // ONE small input (<= 64 KiB) in ONE launch, read where it lies -- pinned host memory, over the bus -- and answered into pinned host
 // memory: the plugin layer's HashBuffer of a path string, a chunk-hash array or a block's hash array (src/longtail.c:1272, 2522,
@@ -627,7 +607,8 @@ int lthip_launch_blake3(lthip_ctx* ctx, const uint8_t* d_data, const uint64_t* d
         return err;
     {
         LaunchTimer t(ctx, LTHIP_K_B3_LEAF);
-        static const int pad_lds = getenv("LTHIP_B3_PAD_LDS") ? atoi(getenv("LTHIP_B3_PAD_LDS")) : 0; // experiment: unused LDS limits the waves per CU
+        LTHIP_ABLATION_ENV(env_pad, "LTHIP_B3_PAD_LDS"); // experiment: unused LDS limits the waves per CU
+        const int pad_lds = env_pad.get() > 0 ? env_pad.get() : 0;
         hipLaunchKernelGGL(k_blake3_leaves, dim3((uint32_t)div_up_u64(leaf_bound, 256)), dim3(256), (size_t)pad_lds, ctx->stream, d_data,
                            d_offsets, d_lens, (const uint32_t*)lp, count_bound, d_count, (uint32_t*)cv, (uint32_t*)wf);
         LTHIP_LAUNCH_CHECK(ctx);
@@ -635,11 +616,13 @@ int lthip_launch_blake3(lthip_ctx* ctx, const uint8_t* d_data, const uint64_t* d
     if (small_trees)
     {
         LaunchTimer t(ctx, LTHIP_K_B3_PARENT);
-        static const bool serial = getenv("LTHIP_B3_SERIAL_PARENTS") != nullptr; // ablation: one thread per tree
-        if (serial)
+#ifdef LTHIP_ABLATIONS
+        LTHIP_ABLATION_ENV(env_serial, "LTHIP_B3_SERIAL_PARENTS"); // one thread per tree
+        if (env_serial.get() >= 0)
             hipLaunchKernelGGL(k_blake3_parents_small, dim3((uint32_t)div_up_u64(count_bound, 256)), dim3(256), 0, ctx->stream,
                                d_lens, (const uint32_t*)lp, count_bound, d_count, (uint32_t*)cv, d_hashes);
         else
+#endif
             hipLaunchKernelGGL(k_blake3_parents_window, dim3((uint32_t)div_up_u64(leaf_bound, PW)), dim3(PW_THREADS), 0, ctx->stream,
                                (const uint32_t*)lp, count_bound, d_count, (const uint32_t*)cv, (const uint32_t*)wf, d_hashes);
         LTHIP_LAUNCH_CHECK(ctx);

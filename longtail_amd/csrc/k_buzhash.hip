@@ -2,19 +2,19 @@
 //
 // Reference behaviour: lib/hpcdcchunker/longtail_hpcdcchunker.c (Longtail_HPCDCNextChunk :225-310).
 // MI355X formulation:
-//   K1 buzhash_candidates : H(p) = XOR_{j<48} rotl(T[byte[p-1-j]], j) is a pure function of the 48 bytes before
-//                           p, so every position of every part is evaluated independently.  ONE persistent
-//                           768-thread workgroup per CU (12 waves, 156 VGPRs, no scratch); each WAVE owns 4 KiB
-//                           wave-tiles end to end -- no workgroup barrier in the loop: the next tile is
-//                           prefetched into registers (coalesced 16-byte loads) while the current one is hashed
-//                           from the wave's private LDS rows (17-dword pitch, conflict-free); every lane rolls
-//                           the 48-byte window over its own 64-byte run.  T[256] is replicated 64x in LDS with
-//                           a 256-byte stride (one copy per lane): the LDS address of T[b] is {lane*4, b} =
-//                           ONE v_perm_b32 of the data dword, and lookups never conflict.  `H % d == d-1` is a
-//                           3-instruction necessary test on the odd part of d, the exact multiply-add + rotate
-//                           + compare only in the rare wave-uniform branch.  Output is a two level bitmap:
-//                           level 0 one bit per byte (only non-zero words are stored), level 1 one bit per
-//                           64-byte run (wave ballot, always stored).
+//   K1 k_buzhash_prefix_dma: H(p) = XOR_{j<48} rotl(T[byte[p-1-j]], j) is a pure function of the 48 bytes before p, so every
+//                           position of every part is evaluated independently.  ONE persistent workgroup of 16 waves per CU;
+//                           each WAVE owns 4 KiB wave-tiles end to end -- no workgroup barrier in the loop.  The tile comes
+//                           straight from global memory into the wave's LDS buffer (global_load_lds_dwordx4), every lane
+//                           keeps the SUFFIX XORs of its own 64-byte run in registers (prefix-XOR formulation: one table
+//                           look-up per byte, no 48-byte warm-up; the neighbour's suffixes through one v_xor_b32_dpp).
+//                           T[256] is replicated 64x in LDS with a 256-byte stride (one copy per lane): the LDS address of
+//                           T[b] is {lane*4, b} = ONE v_perm_b32 of the data dword, and lookups never conflict.
+//                           `H % d == d-1` is a necessary test on the odd part of d accumulated over eight steps, the exact
+//                           multiply-add + rotate + compare only in the rare wave-uniform branch.  Output is a two level
+//                           bitmap: level 0 one bit per byte (only non-zero words are stored), level 1 one bit per 64-byte
+//                           run (wave ballot, always stored).  (Earlier formulations -- the rolling-window kernel of
+//                           rounds 1-2, register staging -- live in ablations/ and are compiled by `make ablations` only.)
 //   K2 select_cuts        : one wave per part walks chunk by chunk: wave-wide load of the level-1 words that
 //                           cover (start+min, start+max], first flagged run, one level-0 word, ffs.
 //   K3 compact            : scan of per-part counts, gather into dense (offset,len) arrays.
@@ -30,8 +30,6 @@ __constant__ uint32_t c_buztab[256] = {
 #include "buzhash_table.inc"
 };
 
-constexpr int K1_WAVES = 12;                 // one workgroup per CU: 3 waves per SIMD, <= 168 VGPRs each (16 waves at 128 VGPRs spill and gain nothing: measured)
-constexpr int K1_THREADS = 64 * K1_WAVES;
 constexpr int RUN = 64;                      // bytes per thread
 constexpr int TILE = 256 * RUN;              // 16 KiB: the plan's tile (four wave-tiles)
 constexpr int ROW_DW = 17;                   // 16 data dwords + 1 pad: thread-strided ds_read_b32 hits 32 distinct banks
@@ -103,210 +101,11 @@ __global__ void k_tile_table(const PartDev* __restrict__ parts, uint32_t nparts,
 // rows; waves of a workgroup share nothing but the read-only table, so there is no barrier in the loop.  The loads
 // of the next wave-tile are issued before the current one is hashed (register double buffering).
 constexpr int WROWS = 64 + 1;            // 64 data rows + 1 halo row
-constexpr int WVECS = WROWS * 4;         // 260 16-byte vectors per wave-tile
 constexpr int WTILE = 64 * RUN;          // 4 KiB
 
-struct TileRegs
-{
-    uint4 q[5];
-};
-
-__device__ __forceinline__ void tile_load(TileRegs& r, const uint8_t* __restrict__ data, const PartDev& pd,
-                                          uint64_t span_start, int lane)
-{
-    const uint8_t* src = data + pd.off;
-#pragma unroll
-    for (int u = 0; u < 5; ++u)
-    {
-        const int v = lane + u * 64;
-        uint4 q = make_uint4(0, 0, 0, 0);
-        if (v < WVECS)
-        {
-            const int64_t g = (int64_t)span_start - 64 + 16 * (int64_t)v;
-            if (g >= 0)
-            {
-                if ((uint64_t)g + 16 <= pd.size)
-                    q = *reinterpret_cast<const uint4*>(src + g);
-                else if ((uint64_t)g < pd.size)
-                {
-                    uint32_t w[4] = {0, 0, 0, 0};
-                    const uint32_t n = (uint32_t)(pd.size - (uint64_t)g);
-                    for (uint32_t b = 0; b < n; ++b)
-                        w[b >> 2] |= (uint32_t)src[g + b] << (8 * (b & 3));
-                    q = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-            }
-        }
-        r.q[u] = q;
-    }
-}
-
-__device__ __forceinline__ void tile_store(const TileRegs& r, uint32_t* __restrict__ rows, int lane)
-{
-#pragma unroll
-    for (int u = 0; u < 5; ++u)
-    {
-        const int v = lane + u * 64;
-        if (v < WVECS)
-        {
-            uint32_t* d = rows + (v >> 2) * ROW_DW + (v & 3) * 4;
-            d[0] = r.q[u].x;
-            d[1] = r.q[u].y;
-            d[2] = r.q[u].z;
-            d[3] = r.q[u].w;
-        }
-    }
-}
-
-template <int MODE> // 0 = general d (multiply test), 1 = power-of-two d (mask test)
-__global__ __launch_bounds__(K1_THREADS, 1) void k_buzhash_candidates(const uint8_t* __restrict__ data,
-                                                                       const PartDev* __restrict__ parts,
-                                                                       const uint32_t* __restrict__ tile_part,
-                                                                       uint32_t ntiles, DivTest dv,
-                                                                       uint64_t* __restrict__ bm0,
-                                                                       uint64_t* __restrict__ bm1)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t* tab = smem; // [256][TAB_REP]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: tile bookkeeping stays in SGPRs
-    uint32_t* rows = smem + 256 * TAB_REP + wave * (WROWS * ROW_DW); // this wave's [WROWS][ROW_DW]
-
-    // replicated substitution table: tab[v*TAB_REP + r] = T[v]
-    if (tid < 256)
-    {
-        const uint32_t tv = c_buztab[tid];
-        uint4 q = make_uint4(tv, tv, tv, tv);
-        uint4* dst = reinterpret_cast<uint4*>(tab + tid * TAB_REP);
-#pragma unroll
-        for (int j = 0; j < TAB_REP / 4; ++j)
-            dst[j] = q;
-    }
-    __syncthreads(); // the only barrier: table visible to every wave
-    // The table is the first thing in LDS and the kernel has no static LDS, so its LDS address is 0 and a lookup address
-    // is the v_perm result itself (no base add); checked, not assumed.
-    if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)smem != 0u)
-        __builtin_trap();
-    const uint32_t lane4 = (uint32_t)lane * 4u;
-    // x divisible by odd d' <=> x * d'^-1 mod 2^32 <= (2^32-1)/d'
-    const uint32_t qodd = MODE == 1 ? 0u : 0xFFFFFFFFu / (dv.d >> dv.k2);
-
-    const uint64_t nwt = (uint64_t)ntiles * 4u; // wave-tiles; wave-tile wt is quarter (wt & 3) of 16 KiB tile (wt >> 2)
-    const uint64_t wstride = (uint64_t)gridDim.x * (uint64_t)K1_WAVES;
-    uint64_t wt = (uint64_t)blockIdx.x * (uint64_t)K1_WAVES + (uint64_t)wave;
-    if (wt >= nwt)
-        return;
-    PartDev pd = parts[tile_part[wt >> 2]];
-    uint64_t span = ((wt >> 2) - pd.tile_base) * (uint64_t)TILE + (wt & 3u) * (uint64_t)WTILE; // part-relative
-    TileRegs regs;
-    tile_load(regs, data, pd, span, lane);
-
-    for (;;)
-    {
-        __builtin_amdgcn_wave_barrier();
-        tile_store(regs, rows, lane);
-        __builtin_amdgcn_wave_barrier();
-
-        // issue the next wave-tile's global loads now; they land while this one is being hashed
-        const uint64_t next = wt + wstride;
-        PartDev npd = pd;
-        uint64_t next_span = 0;
-        if (next < nwt)
-        {
-            npd = parts[tile_part[next >> 2]];
-            next_span = ((next >> 2) - npd.tile_base) * (uint64_t)TILE + (next & 3u) * (uint64_t)WTILE;
-            tile_load(regs, data, npd, next_span, lane);
-        }
-
-        const uint64_t q0 = span + (uint64_t)lane * RUN; // first byte of my run
-        uint32_t mlo = 0, mhi = 0;
-        if (q0 < pd.size)
-        {
-            // window bytes: j in [0,112): j<48 = the 48 bytes before the run, j>=48 = the run
-            uint32_t win[28];
-            const uint32_t* prev = rows + lane * ROW_DW;
-#pragma unroll
-            for (int i = 0; i < 12; ++i)
-                win[i] = prev[4 + i];
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                win[12 + i] = prev[ROW_DW + i];
-
-            // T[byte] of the window bytes is fetched in two batches of independent LDS reads (80 + 32) that stream
-            // through the LDS pipe back to back, each followed by pure register arithmetic.  The value that enters
-            // the hash at step k leaves it at step k+48 (hpcdcchunker.c:294-296; rotl(T[out], 48 & 31)).
-            uint32_t tv[48 + RUN];
-            uint32_t h = 0;
-    // byte offset of T[b] for this lane = b * 256 + lane * 4 = bytes {lane4, b, 0, 0}
-#define LT_LOOKUP(j)                                                                                                 \
-    tv[j] = lds_load_u32(__builtin_amdgcn_perm(win[(j) >> 2], lane4, 0x0c0c0400u | ((uint32_t)((j) & 3) << 8)))
-#define LT_STEP(k)                                                                                                   \
-    {                                                                                                                \
-        h = rotl32(h, 1) ^ rotl32(tv[k], 16) ^ tv[48 + (k)];                                                         \
-        bool pre;                                                                                                    \
-        if (MODE == 1)                                                                                               \
-            pre = (h & (dv.d - 1u)) == dv.d - 1u;                                                                    \
-        else /* necessary: the odd part of d divides h+1 (3 ops); the exact test waits in the rare branch */        \
-            pre = h * dv.inv + dv.inv <= qodd;                                                                       \
-        if (__builtin_amdgcn_ballot_w64(pre) != 0ull) /* wave-uniform and rare (1 position in d's odd part) */       \
-        {                                                                                                            \
-            asm volatile(""); /* keep this a real scalar branch (no if-conversion of the bit-set) */                 \
-            const bool hit = MODE == 1 ? pre : rotr32(h * dv.inv + dv.addc, dv.k2) <= dv.qlim; /* h % d == d-1 */   \
-            /* 0/1 shifted by an inline constant: a select between 0 and 1 << k would park 64 constants in VGPRs */ \
-            uint32_t hb;                                                                                             \
-            asm volatile("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(hb) : "s"(__builtin_amdgcn_ballot_w64(hit)));       \
-            if ((k) < 32)                                                                                            \
-                mlo |= hb << (k);                                                                                    \
-            else                                                                                                     \
-                mhi |= hb << ((k)-32);                                                                               \
-        }                                                                                                            \
-    }
-#pragma unroll
-            for (int j = 0; j < 80; ++j)
-                LT_LOOKUP(j);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 48; ++j)
-                h = rotl32(h, 1) ^ tv[j];
-#pragma unroll
-            for (int k = 0; k < 32; ++k)
-                LT_STEP(k)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 80; j < 48 + RUN; ++j)
-                LT_LOOKUP(j);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 32; k < RUN; ++k)
-                LT_STEP(k)
-#undef LT_LOOKUP
-#undef LT_STEP
-            // bit k <=> cut position p = q0+k+1 ; legal cuts are 48 <= p <= size
-            uint64_t m = ((uint64_t)mhi << 32) | mlo;
-            if (q0 < 47)
-                m &= ~0ull << (47 - q0);
-            const uint64_t remain = pd.size - q0; // >= 1
-            if (remain < 64)
-                m &= (1ull << remain) - 1ull;
-            mlo = (uint32_t)m;
-            mhi = (uint32_t)(m >> 32);
-        }
-        const uint64_t m = ((uint64_t)mhi << 32) | mlo;
-        const uint64_t summary = __builtin_amdgcn_ballot_w64(m != 0ull);
-        if (m != 0ull)
-            bm0[pd.bm0_base + (span >> 6) + (uint64_t)lane] = m; // one word per 64-byte run
-        if (lane == 0)
-            bm1[pd.bm1_base + (span >> 12)] = summary;            // one word per 4 KiB
-
-        if (next >= nwt)
-            break;
-        wt = next;
-        pd = npd;
-        span = next_span;
-    }
-}
+#ifdef LTHIP_ABLATIONS
+#include "ablations/k_buzhash_roll.inc"
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // K1, prefix-XOR formulation (round 3; the default).
@@ -537,78 +336,9 @@ __device__ __forceinline__ void prefix_table_init(uint32_t* tab, int tid, int nt
         __builtin_trap(); // a look-up address is the v_perm result itself (see k_buzhash_candidates)
 }
 
-// Flavour 1: wave-tiles staged through registers into padded rows (the round-1/2 loader).
-template <int MODE, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 1) void k_buzhash_prefix(const uint8_t* __restrict__ data,
-                                                                   const PartDev* __restrict__ parts,
-                                                                   const uint32_t* __restrict__ tile_part,
-                                                                   uint32_t ntiles, DivTest dv,
-                                                                   uint64_t* __restrict__ bm0,
-                                                                   uint64_t* __restrict__ bm1)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint32_t* rows = smem + 256 * TAB_REP + wave * (WROWS * ROW_DW + HALO_DW); // this wave's [WROWS][ROW_DW] + halo suffixes
-    uint32_t* halo = rows + WROWS * ROW_DW;
-    prefix_table_init(smem, tid, 64 * WAVES);
-
-    const uint32_t rows_byte = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)rows;
-    PrefixConsts pc;
-    pc.lane4 = (uint32_t)lane * 4u;
-    pc.hj = 63u - (uint32_t)lane;
-    pc.halo_byte = rows_byte + WROWS * ROW_DW * 4u;
-    pc.thr = MODE == 1 ? 0u : 0xFFFFFFFFu / (dv.d >> dv.k2);
-    pc.exact_add = dv.addc - dv.inv;
-
-    const uint64_t nwt = (uint64_t)ntiles * 4u;
-    const uint64_t wstride = (uint64_t)gridDim.x * (uint64_t)WAVES;
-    uint64_t wt = (uint64_t)blockIdx.x * (uint64_t)WAVES + (uint64_t)wave;
-    if (wt >= nwt)
-        return;
-    PartDev pd = parts[tile_part[wt >> 2]];
-    uint64_t span = ((wt >> 2) - pd.tile_base) * (uint64_t)TILE + (wt & 3u) * (uint64_t)WTILE; // part-relative
-    TileRegs regs;
-    tile_load(regs, data, pd, span, lane);
-
-    for (;;)
-    {
-        __builtin_amdgcn_wave_barrier();
-        tile_store(regs, rows, lane);
-        __builtin_amdgcn_wave_barrier();
-
-        const uint64_t next = wt + wstride;
-        PartDev npd = pd;
-        uint64_t next_span = 0;
-        if (next < nwt)
-        {
-            npd = parts[tile_part[next >> 2]];
-            next_span = ((next >> 2) - npd.tile_base) * (uint64_t)TILE + (next & 3u) * (uint64_t)WTILE;
-            tile_load(regs, data, npd, next_span, lane);
-        }
-
-        uint32_t win[16];
-        const uint32_t* own = rows + (lane + 1) * ROW_DW;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            win[i] = own[i];
-        const uint32_t hb = lds_load_u8(rows_byte + pc.hj); // row 0 = the halo row
-        const uint64_t m = prefix_legal(prefix_tile<MODE>(win, hb, pc, dv, lane, halo), span + (uint64_t)lane * RUN, pd.size);
-
-        const uint64_t summary = __builtin_amdgcn_ballot_w64(m != 0ull);
-        if (m != 0ull)
-            bm0[pd.bm0_base + (span >> 6) + (uint64_t)lane] = m; // one word per 64-byte run
-        if (lane == 0)
-            bm1[pd.bm1_base + (span >> 12)] = summary;            // one word per 4 KiB
-
-        if (next >= nwt)
-            break;
-        wt = next;
-        pd = npd;
-        span = next_span;
-    }
-}
+#ifdef LTHIP_ABLATIONS
+#include "ablations/k_buzhash_prefix_regs.inc"
+#endif
 
 // Flavour 2 (default): the wave-tile comes straight from global memory into LDS (global_load_lds_dwordx4, 1 KiB per
 // instruction, no staging registers and no ds_write pass).  The LDS image of an LDS-DMA is lane-linear (base + instruction
@@ -1083,14 +813,26 @@ int lthip_launch_tile_table(lthip_ctx* ctx, lthip_plan* plan)
     return 0;
 }
 
+#ifdef LTHIP_ABLATIONS
+constexpr bool K1_HAS_REG_FLAVOUR = true;
+#else
+constexpr bool K1_HAS_REG_FLAVOUR = false;
+#endif
+
 template <int WAVES, bool DMA>
 static int launch_buzhash_prefix(lthip_ctx* ctx, const lthip_plan* plan, const uint8_t* d_data, uint64_t* bm0, uint64_t* bm1)
 {
+    static_assert(DMA || K1_HAS_REG_FLAVOUR, "the register-staged flavour is compiled by the ablation build only");
     constexpr size_t per_wave = DMA ? (DMA_BUF_B >> 2) + HALO_DW : WROWS * ROW_DW + HALO_DW;
     static_assert(sizeof(uint32_t) * (256 * TAB_REP + WAVES * per_wave) <= 160 * 1024, "LDS budget: one workgroup per CU");
     const size_t lds = sizeof(uint32_t) * (256 * TAB_REP + WAVES * per_wave);
+#ifdef LTHIP_ABLATIONS
     auto k0 = DMA ? &k_buzhash_prefix_dma<0, WAVES> : &k_buzhash_prefix<0, WAVES>;
     auto k1 = DMA ? &k_buzhash_prefix_dma<1, WAVES> : &k_buzhash_prefix<1, WAVES>;
+#else
+    auto k0 = &k_buzhash_prefix_dma<0, WAVES>;
+    auto k1 = &k_buzhash_prefix_dma<1, WAVES>;
+#endif
     static bool granted[64] = {}; // per device: more than 64 KiB of dynamic LDS has to be granted explicitly
     if (ctx->device < 0 || ctx->device >= 64 || !granted[ctx->device])
     {
@@ -1111,8 +853,9 @@ static int launch_buzhash_prefix(lthip_ctx* ctx, const lthip_plan* plan, const u
     return 0;
 }
 
-// LTHIP_K1: "dma16" (default) / "dma12" = the prefix-XOR kernel fed by LDS-DMA, 16 / 12 waves per CU; "prefix16" / "prefix12" =
-// the same with register staging; "roll" = the rolling-window kernel of rounds 1-2 (ablations)
+#ifdef LTHIP_ABLATIONS
+// LTHIP_K1 (ablation build): "dma16" (the product's kernel) / "dma12" = the prefix-XOR kernel fed by LDS-DMA, 16 / 12 waves per CU;
+// "prefix16" / "prefix12" = the same with register staging; "roll" = the rolling-window kernel of rounds 1-2
 static int k1_flavour()
 {
     // (read again after lthip_debug_reload_env: tools/k1_stress_tib.py runs two flavours against each other in one process)
@@ -1129,19 +872,8 @@ static int k1_flavour()
     return f.load(std::memory_order_relaxed);
 }
 
-int lthip_launch_buzhash(lthip_ctx* ctx, const lthip_plan* plan, const uint8_t* d_data, uint64_t* bm0, uint64_t* bm1)
+static int launch_buzhash_roll(lthip_ctx* ctx, const lthip_plan* plan, const uint8_t* d_data, uint64_t* bm0, uint64_t* bm1)
 {
-    if (plan->ntiles == 0)
-        return 0;
-    const int flavour = k1_flavour();
-    if (flavour == 0)
-        return launch_buzhash_prefix<16, true>(ctx, plan, d_data, bm0, bm1);
-    if (flavour == 1)
-        return launch_buzhash_prefix<12, true>(ctx, plan, d_data, bm0, bm1);
-    if (flavour == 2)
-        return launch_buzhash_prefix<16, false>(ctx, plan, d_data, bm0, bm1);
-    if (flavour == 3)
-        return launch_buzhash_prefix<12, false>(ctx, plan, d_data, bm0, bm1);
     static_assert(sizeof(uint32_t) * (256 * TAB_REP + K1_WAVES * WROWS * ROW_DW) <= 160 * 1024, "LDS budget: one workgroup per CU");
     const size_t lds = sizeof(uint32_t) * (256 * TAB_REP + K1_WAVES * WROWS * ROW_DW);
     if (!ctx->k1_lds_enabled) // per context = per device: more than 64 KiB of dynamic LDS has to be granted explicitly
@@ -1165,6 +897,25 @@ int lthip_launch_buzhash(lthip_ctx* ctx, const lthip_plan* plan, const uint8_t* 
                            plan->d_tile_part, (uint32_t)plan->ntiles, plan->div, bm0, bm1);
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
+}
+#endif
+
+int lthip_launch_buzhash(lthip_ctx* ctx, const lthip_plan* plan, const uint8_t* d_data, uint64_t* bm0, uint64_t* bm1)
+{
+    if (plan->ntiles == 0)
+        return 0;
+#ifdef LTHIP_ABLATIONS
+    const int flavour = k1_flavour();
+    if (flavour == 1)
+        return launch_buzhash_prefix<12, true>(ctx, plan, d_data, bm0, bm1);
+    if (flavour == 2)
+        return launch_buzhash_prefix<16, false>(ctx, plan, d_data, bm0, bm1);
+    if (flavour == 3)
+        return launch_buzhash_prefix<12, false>(ctx, plan, d_data, bm0, bm1);
+    if (flavour == 4)
+        return launch_buzhash_roll(ctx, plan, d_data, bm0, bm1);
+#endif
+    return launch_buzhash_prefix<16, true>(ctx, plan, d_data, bm0, bm1);
 }
 
 int lthip_launch_select(lthip_ctx* ctx, const lthip_plan* plan, const uint64_t* bm0, const uint64_t* bm1, uint2* region,

@@ -51,6 +51,29 @@ __global__ __launch_bounds__(GT) void k_gather_ranges(const uint8_t* __restrict_
         d[done + tid] = s[done + tid];
 }
 
+// Pinned host memory <-> HBM by the CUs.  The box's SDMA engines move ONE direction at a time (tools/pcie_duplex_probe.py,
+// profiles/r05_pcie_duplex.json: hipMemcpyAsync h2d + d2h on two streams take the SUM of their times, 57 GB/s in total), a kernel
+// that loads / stores over the link does not share them: kernel copies in both directions at once reach 46 GB/s EACH.  A host-fed
+// ingest loop therefore fetches its slices and returns its block images with this kernel (and lthip_gather_ranges, whose
+// destination may be pinned host memory too), on streams of their own beside the compute stream.
+__global__ __launch_bounds__(GT) void k_link_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t nvec, uint32_t tail)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * GT;
+    uint64_t v = (uint64_t)blockIdx.x * GT + threadIdx.x;
+    for (; v + 3u * stride < nvec; v += 4u * stride) // four 16-byte requests of every lane in flight (1 KiB per wave and request)
+    {
+        const uint4 a = src[v], b = src[v + stride], c = src[v + 2u * stride], d = src[v + 3u * stride];
+        dst[v] = a;
+        dst[v + stride] = b;
+        dst[v + 2u * stride] = c;
+        dst[v + 3u * stride] = d;
+    }
+    for (; v < nvec; v += stride)
+        dst[v] = src[v];
+    if (blockIdx.x == 0 && threadIdx.x < tail)
+        reinterpret_cast<uint8_t*>(dst + nvec)[threadIdx.x] = reinterpret_cast<const uint8_t*>(src + nvec)[threadIdx.x];
+}
+
 // positions of a rank's chunks in job order (the multi-GPU exchange): chunk k of the rank lies in its own job m with
 // part_first[m] <= k < part_first[m + 1] (lthip_chunk_hash's part table: one part per own job, ascending) and is the tree's chunk
 // job_gfirst[m] + (k - part_first[m])
@@ -162,6 +185,25 @@ extern "C" int lthip_gather_ranges(lthip_ctx* ctx, const void* d_src, uint64_t r
     LaunchTimer t(ctx, LTHIP_K_GATHER);
     hipLaunchKernelGGL(k_gather_ranges, dim3((uint32_t)range_count), dim3(GT), 0, ctx->stream, (const uint8_t*)d_src,
                        d_src_offsets, d_lens, d_dst_offsets, range_count, (uint8_t*)d_dst);
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+extern "C" int lthip_link_copy(lthip_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src)))
+        return EINVAL;
+    if (bytes == 0)
+        return 0;
+    if (((uintptr_t)dst | (uintptr_t)src) & 15u)
+        return lthip_fail(ctx, EINVAL, "lthip_link_copy", "source and destination must be 16-byte aligned");
+    LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint64_t nvec = (uint64_t)bytes >> 4;
+    uint64_t grid = div_up_u64(nvec ? nvec : 1, (uint64_t)GT * 4u);
+    if (grid > 1024)
+        grid = 1024; // (enough requests in flight for the link; the waves mostly wait, the compute stream's kernels run beside them)
+    LaunchTimer t(ctx, LTHIP_K_OTHER);
+    hipLaunchKernelGGL(k_link_copy, dim3((uint32_t)grid), dim3(GT), 0, ctx->stream, (const uint4*)src, (uint4*)dst, nvec, (uint32_t)(bytes & 15u));
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
 }

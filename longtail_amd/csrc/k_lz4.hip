@@ -357,7 +357,7 @@ constexpr uint32_t Z_PIECE = 128u << 10; // zstd Block_Maximum_Size (ZB_BLOCK_MA
 // wants history: tools/lz4_lane_model.c -- mixed 1.72 at 8 x 1280, 1.85 at 16 x 2048, 1.89 at 16 x 2560; reference 1.92)
 constexpr int LZ4_TAB_LZ4 = 1024 + 256;
 constexpr int LZ4_TAB_ZSTD = 1024 + 256;
-constexpr int LZ4_TAB_LANES = 2560;
+[[maybe_unused]] constexpr int LZ4_TAB_LANES = 2560; // (round 2's lane kernel: ablations/)
 constexpr int LZ4_TAB_SHARED = 1536, LZ4_SH_LOG2 = 13; // lane parser with the group's shared table: 64 + 48 + 32 KiB of LDS
 
 // ---------------------------------------------------------------------------------------------------
@@ -407,373 +407,9 @@ __device__ __forceinline__ uint32_t sub_shfl(uint32_t x, int s, bool rev, uint32
     return (s < 0 || s > 63) ? ident : v;
 }
 
-template <int TAB, int FMT, int SH>
-__device__ __forceinline__ void lz4_lane_parse(const uint32_t* sdata, uint32_t head, uint16_t* tab, const uint32_t* shr, uint32_t sh_base, int lane,
-                                               uint32_t my_start,
-                                               uint32_t my_len, int32_t start_limit, uint32_t end_limit, uint32_t sub, uint8_t* __restrict__ out,
-                                               uint64_t* __restrict__ zrecs, uint64_t* __restrict__ lrecs, Lz4Seq& st, uint32_t dbg K5P_ARG)
-{
-    const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(sdata);
-    const bool rev = !(dbg & 128u);
-    const int sidx = rev ? 63 - lane : lane; // my sub-unit
-    const uint32_t unit_end = my_start + my_len;
-    const uint32_t s0 = my_start + (uint32_t)sidx * sub;
-    const uint32_t lend = s0 + sub < unit_end ? s0 + sub : unit_end;
-    uint32_t p = s0, anchor = s0, nrec = 0, last_end = 0;
-    uint32_t nmiss = 0; // consecutive misses of this lane: it steps 1 + nmiss / 4 bytes (the reference accelerates the same way,
-                        // lz4.c:1044-1053, only 16 times slower; tools/lz4_lane_model.c: half the iterations for 0.3 % of the ratio)
-    const uint32_t ashift = (dbg >> 16) & 7u; // 0: dense, then aligned (the default); n: step 1 + misses >> n
-    const uint32_t dense = 4u >> ((dbg >> 29) & 3u); // one-byte steps before the aligned ones (LTHIP_LZ4_DBG bits 29-30: 4, 2, 1, 0)
-    // (The four one-byte steps are there for repeats whose distance is not a multiple of 4.  On data made of aligned structures they
-    // are wasted -- 0 instead of 4: 8-12 % of the kernel's time on the synthetic kinds -- and on text (tools/text_ratio_probe.py: words of
-    // 3..11 bytes) 0 costs 5 % of the ratio.  A rule that drops to one step while a wave's hits all have distances that are multiples
-    // of 4 was built: text unchanged, records / tokens 5 % faster, the mixed tree of bench.py 0.2 %: not kept.)
-    uint64_t* myrecs = lrecs + (uint32_t)sidx * LZ4_LANE_MAXREC;
-
-    // A verified hit WAITS (the lane keeps its position and candidate, `pend`) until at least `wait_for` lanes hold one or nobody can
-    // probe any more: the extension below costs the wave the same whether one lane or sixty need it, the probe of the others is
-    // cheap, so hits are measured in bulk.
-    const uint32_t wait_for = (dbg >> 20) & 63u ? (dbg >> 20) & 63u : 8u; // (2 .. 12 measure the same, 16: 2 % slower, 32: 6 %)
-    bool pend = false;
-    uint32_t cand = 0u;
-    // (the lane parser's tables hold 0 for "nothing here": a candidate 0 is position 0 of the window, verified like any other)
-    for (;;)
-    {
-        const bool act = !pend && p < lend && (int32_t)p <= start_limit && nrec < LZ4_LANE_MAXREC && !(dbg & 2048u);
-        const uint64_t am = __builtin_amdgcn_ballot_w64(act);
-        if (am == 0ull && __builtin_amdgcn_ballot_w64(pend) == 0ull)
-            break;
-        if (am)
-        {
-            uint32_t v = 0, h = 0, c = 0u;
-            [[maybe_unused]] uint32_t c2 = 0xFFFFFFFFu; // SH: the group's earliest aligned occurrence of these four bytes
-            if (act)
-            {
-                v = lds_read32(sdata, p + head);
-                const uint32_t prod = v * 2654435761u;
-                h = __umulhi(prod, (uint32_t)TAB);
-                c = tab[h];
-                if constexpr (SH != 0)
-                    c2 = shr[prod >> (32 - SH)] - sh_base; // (another group's entry: far above any position)
-            }
-            if (act)
-            {
-                // every lane has read before anyone writes (one wave: LDS operations execute in order) ... and reads again after
-                // everyone has written: when several lanes insert the same slot in this step the entry that survives (the lowest
-                // position: lanes are mapped to sub-units in reverse) is a candidate for the others at once
-                tab[h] = (uint16_t)p;
-                // (with the group's shared table behind it -- which holds every aligned position, this unit's too -- the second read
-                // finds next to nothing the first candidates do not: off there unless LTHIP_LZ4_DBG bit 28 asks for it; mixed 2.0976 ->
-                // 2.0960, lines 19.86 -> 19.33, 2-8 % of the kernel's time)
-                if (SH != 0 ? (dbg & (1u << 28)) != 0u : !(dbg & 512u))
-                {
-                    uint32_t hr = h;
-                    asm volatile("" : "+v"(hr)); // the compiler must not know that this is the slot just written (it would forward the store)
-                    const uint32_t fresh = tab[hr];
-                    if (fresh < p)
-                        c = fresh;
-                }
-            }
-            bool hit = false;
-            if constexpr (SH != 0)
-            {
-                // both candidates' bytes in one round trip; the private table's (the nearer one) first
-                const uint32_t x1 = act && c < p ? lds_read32(sdata, c + head) : ~v;
-                const uint32_t x2 = act && c2 < p ? lds_read32(sdata, c2 + head) : ~v;
-                hit = x1 == v || x2 == v;
-                c = x1 == v ? c : c2;
-            }
-            else if (act && c < p)
-                hit = lds_read32(sdata, c + head) == v;
-            if (hit)
-            {
-                pend = true;
-                cand = c;
-            }
-            else if (act)
-            {
-                // Four misses step one byte each (all byte phases of a dword get their probe); after that only the positions whose
-                // four bytes are an address-aligned dword are probed -- the ones the history was inserted at, so that where the
-                // lane lands does not depend on where its sub-unit began.  (Rounds 1-2 stepped 1 + misses / 4 bytes: on data whose
-                // structures do not start on the sub-unit grid the lanes skipped the keys of the history -- "tokens" 1.69 -> 1.49,
-                // "mixed" 1.92 -> 1.81 at odd block offsets; tools/lz4_lane_model.c.  LTHIP_LZ4_DBG bits 16-18 = n keeps that rule.)
-                if (ashift)
-                    p += 1u + (nmiss >> ashift);
-                else
-                    p = nmiss < dense ? p + 1u : (((p + head) | 3u) + 1u - head);
-                ++nmiss;
-            }
-        }
-        K5P(3);
-        K5P_COUNT(10, 1);
-        const uint64_t pm = __builtin_amdgcn_ballot_w64(pend);
-        if (pm == 0ull)
-            continue;
-        if ((uint32_t)__builtin_popcountll(pm) < wait_for &&
-            __builtin_amdgcn_ballot_w64(!pend && p < lend && (int32_t)p <= start_limit && nrec < LZ4_LANE_MAXREC) != 0ull)
-            continue; // somebody can still probe: let the hits pile up
-        const bool ok0 = pend;
-        bool ok = ok0;
-        pend = false;
-        K5P_COUNT(11, 1);
-        K5P_COUNT(12, (unsigned)__builtin_popcountll(pm));
-        // ---- forwards, every hit lane for itself: 16 bytes per LDS round trip, at most 36 bytes ----
-        uint32_t mlen = ok ? 4u : 0u;
-        bool grow = ok;
-        const uint32_t maxlen = ok ? end_limit - p : 0u; // p <= start_limit: at least 4
-#pragma unroll 1
-        for (int t = 0; t < 2; ++t)
-        {
-            if (__builtin_amdgcn_ballot_w64(grow) == 0ull)
-                break;
-            if (grow)
-            {
-                const uint32_t a0 = p + mlen + head, b0 = cand + mlen + head;
-                const uint32_t x0 = lds_read32(sdata, a0) ^ lds_read32(sdata, b0);
-                const uint32_t x1 = lds_read32(sdata, a0 + 4u) ^ lds_read32(sdata, b0 + 4u);
-                const uint32_t x2 = lds_read32(sdata, a0 + 8u) ^ lds_read32(sdata, b0 + 8u);
-                const uint32_t x3 = lds_read32(sdata, a0 + 12u) ^ lds_read32(sdata, b0 + 12u);
-                uint32_t add = 16u;
-                if (x0)
-                    add = (uint32_t)__builtin_ctz(x0) >> 3;
-                else if (x1)
-                    add = 4u + ((uint32_t)__builtin_ctz(x1) >> 3);
-                else if (x2)
-                    add = 8u + ((uint32_t)__builtin_ctz(x2) >> 3);
-                else if (x3)
-                    add = 12u + ((uint32_t)__builtin_ctz(x3) >> 3);
-                mlen += add;
-                if (add != 16u)
-                    grow = false;
-                if (mlen >= maxlen)
-                {
-                    mlen = maxlen;
-                    grow = false;
-                }
-            }
-        }
-        // ---- backwards, at most 8 bytes (the history was inserted every 4th position: a match is found up to 3 bytes late) ----
-        uint32_t nbk = 0;
-        if (ok && cand >= 8u && p - anchor != 0u)
-        {
-            const uint32_t x = lds_read32(sdata, p - 4u + head) ^ lds_read32(sdata, cand - 4u + head);
-            const uint32_t y = lds_read32(sdata, p - 8u + head) ^ lds_read32(sdata, cand - 8u + head);
-            nbk = x ? (uint32_t)__builtin_clz(x) >> 3 : (y ? 4u + ((uint32_t)__builtin_clz(y) >> 3) : 8u);
-            nbk = nbk < p - anchor ? nbk : p - anchor;
-        }
-        // ---- matches still equal after 36 bytes: extended by the whole wave, lowest position first; the lanes whose position
-        // such a match covers give up what they hold (it would be dropped below anyway) and continue behind it ----
-        uint64_t longs = __builtin_amdgcn_ballot_w64(grow);
-        bool covered = false;
-        K5P(4);
-        while (longs)
-        {
-            K5P_COUNT(13, 1);
-            const int f = rev ? 63 - __builtin_clzll(longs) : __builtin_ctzll(longs);
-            longs &= ~(1ull << f);
-            const uint32_t pf = __builtin_amdgcn_readlane(p, f), cf = __builtin_amdgcn_readlane(cand, f);
-            uint32_t ml = __builtin_amdgcn_readlane(mlen, f);
-            for (;;)
-            {
-                const uint32_t i = pf + ml + 4u * (uint32_t)lane;
-                uint32_t cnt = 0; // equal bytes of my four, as far as the unit goes
-                if (i < end_limit)
-                {
-                    const uint32_t x = lds_read32(sdata, i + head) ^ lds_read32(sdata, cf + ml + 4u * (uint32_t)lane + head);
-                    const uint32_t lim = end_limit - i < 4u ? end_limit - i : 4u;
-                    cnt = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
-                    cnt = cnt < lim ? cnt : lim;
-                }
-                const uint64_t diff = __builtin_amdgcn_ballot_w64(cnt < 4u);
-                if (diff)
-                {
-                    const int g = __builtin_ctzll(diff);
-                    ml += 4u * (uint32_t)g + __builtin_amdgcn_readlane(cnt, g);
-                    break;
-                }
-                ml += 256u;
-            }
-            if (lane == f)
-                mlen = ml;
-            const uint32_t cov = pf + ml;
-            const bool cv = lane != f && p > pf && p < cov;
-            if (cv)
-            {
-                p = cov;
-                anchor = anchor > cov ? anchor : cov;
-                ok = false;
-                covered = true;
-            }
-            longs &= ~__builtin_amdgcn_ballot_w64(cv);
-        }
-        if (ok)
-        {
-            const uint32_t s = p - nbk, len = mlen + nbk;
-            myrecs[nrec] = (uint64_t)s | ((uint64_t)len << 16) | ((uint64_t)(p - cand) << 32);
-            ++nrec;
-            p = s + len;
-            anchor = p;
-            last_end = p;
-            nmiss = 0;
-        }
-        else if (ok0 && !covered)
-        {
-            // (cannot happen: a waiting hit is either recorded or covered) -- step on so that the loop always advances
-            p += 1u;
-        }
-        K5P(5);
-    }
-
-    // ---- what earlier sub-units' matches cover is dropped: exclusive prefix maximum of the match ends, in sub-unit order ----
-    uint32_t incl = last_end;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
-    {
-        const uint32_t o = sub_shfl(incl, sidx - d, rev, 0u);
-        incl = incl > o ? incl : o;
-    }
-    const uint32_t cover = sub_shfl(incl, sidx - 1, rev, 0u);
-    uint32_t k0 = 0; // my first record that starts at or after the cover
-    while (k0 < nrec && (uint32_t)(myrecs[k0] & 0xFFFFu) < cover)
-        ++k0;
-    const bool have = k0 < nrec;
-    const uint32_t first_start_v = have ? (uint32_t)(myrecs[k0] & 0xFFFFu) : 0u;
-    // previous kept end = where the literals of my first kept sequence begin
-    uint32_t kincl = have ? last_end : 0u;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
-    {
-        const uint32_t o = sub_shfl(kincl, sidx - d, rev, 0u);
-        kincl = kincl > o ? kincl : o;
-    }
-    uint32_t prev0 = sub_shfl(kincl, sidx - 1, rev, 0u);
-    prev0 = prev0 > my_start ? prev0 : my_start;
-    // sizes
-    uint32_t bytes = 0, nlit = 0;
-    {
-        uint32_t prev = prev0;
-        for (uint32_t k = k0; k < nrec; ++k)
-        {
-            const uint64_t r = myrecs[k];
-            const uint32_t s = (uint32_t)(r & 0xFFFFu), len = (uint32_t)(r >> 16) & 0xFFFFu;
-            const uint32_t lit = s - prev;
-            bytes += 1u + lz4_len_bytes(lit) + lit + 2u + lz4_len_bytes(len - 4u);
-            nlit += lit;
-            prev = s + len;
-        }
-    }
-    const uint32_t cnt = have ? nrec - k0 : 0u;
-    // exclusive prefix sums in sub-unit order: output bytes (FMT 0) or literal bytes and sequence numbers (FMT 1)
-    uint32_t a_incl = FMT == 1 ? nlit : bytes, c_incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
-    {
-        a_incl += sub_shfl(a_incl, sidx - d, rev, 0u);
-        if constexpr (FMT == 1)
-            c_incl += sub_shfl(c_incl, sidx - d, rev, 0u);
-    }
-    const uint32_t a_total = sub_shfl(a_incl, 63, rev, 0u);
-    uint32_t o_pos = a_incl - (FMT == 1 ? nlit : bytes);
-    uint32_t q_pos = FMT == 1 ? c_incl - cnt : 0u;
-    const uint32_t last_kept_end = sub_shfl(kincl, 63, rev, 0u);
-
-    K5P(6);
-    // ---- emission: every lane writes its own sequences; literal runs above 16 bytes are copied by the whole wave ----
-    {
-        uint32_t prev = prev0;
-        uint32_t kmax = cnt;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1)
-        {
-            const uint32_t o = __shfl_xor(kmax, d, 64);
-            kmax = kmax > o ? kmax : o;
-        }
-        if (dbg & 1024u)
-            kmax = 0; // ablation: no emission (the output is garbage)
-        for (uint32_t t = 0; t < kmax; ++t)
-        {
-            const bool on = t < cnt;
-            uint32_t lit = 0, lit_src = 0, lit_dst = 0;
-            if (on)
-            {
-                const uint64_t r = myrecs[k0 + t];
-                const uint32_t s = (uint32_t)(r & 0xFFFFu), len = (uint32_t)(r >> 16) & 0xFFFFu, off = (uint32_t)(r >> 32);
-                lit = s - prev;
-                lit_src = prev;
-                if constexpr (FMT == 1)
-                {
-                    lit_dst = o_pos;
-                    zrecs[q_pos] = (uint64_t)lit | ((uint64_t)len << 16) | ((uint64_t)off << 32);
-                    ++q_pos;
-                    o_pos += lit;
-                }
-                else
-                {
-                    uint8_t* o = out + o_pos;
-                    const uint32_t mcode = len - 4u;
-                    o[0] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
-                    uint32_t idx = 1u;
-                    if (lit >= 15u)
-                    {
-                        uint32_t rem = lit - 15u;
-                        for (; rem >= 255u; rem -= 255u)
-                            o[idx++] = 255;
-                        o[idx++] = (uint8_t)rem;
-                    }
-                    lit_dst = o_pos + idx;
-                    idx += lit;
-                    o[idx] = (uint8_t)off;
-                    o[idx + 1u] = (uint8_t)(off >> 8);
-                    idx += 2u;
-                    if (mcode >= 15u)
-                    {
-                        uint32_t rem = mcode - 15u;
-                        for (; rem >= 255u; rem -= 255u)
-                            o[idx++] = 255;
-                        o[idx++] = (uint8_t)rem;
-                    }
-                    o_pos += idx;
-                }
-                prev = s + len;
-                if (lit <= 16u)
-                {
-                    uint8_t* o = out + lit_dst;
-                    for (uint32_t j = 0; j < lit; ++j)
-                        o[j] = sbytes[lit_src + j + head];
-                }
-            }
-            uint64_t big = __builtin_amdgcn_ballot_w64(on && lit > 16u);
-            while (big)
-            {
-                const int f = __builtin_ctzll(big);
-                big &= big - 1ull;
-                wave_copy_lds_to_global(out + __builtin_amdgcn_readlane(lit_dst, f), sdata, __builtin_amdgcn_readlane(lit_src, f) + head,
-                                        __builtin_amdgcn_readlane(lit, f), lane);
-            }
-        }
-    }
-    K5P(7);
-    // ---- the unit's result, as the batch parser leaves it ----
-    const uint64_t hm = __builtin_amdgcn_ballot_w64(have);
-    st.have_first = hm != 0ull;
-    st.anchor = hm ? last_kept_end : my_start;
-    if constexpr (FMT == 1)
-    {
-        st.op = a_total; // literal bytes so far
-        st.nseq = sub_shfl(c_incl, 63, rev, 0u);
-    }
-    else
-    {
-        st.op = a_total;
-        if (hm)
-        {
-            const int f = rev ? 63 - __builtin_clzll(hm) : __builtin_ctzll(hm); // the lane of the first sub-unit with a sequence
-            const uint32_t first_start = __builtin_amdgcn_readlane(first_start_v, f);
-            st.first_lit = first_start - my_start;
-            st.first_hdr = 1u + lz4_len_bytes(st.first_lit);
-        }
-    }
-}
+#ifdef LTHIP_ABLATIONS
+#include "ablations/k_lz4_lane_parse_r3.inc" // lz4_lane_parse: the round-3 formulation of the parse below (same payloads)
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // K5, lane-sequential parse, second formulation (round 4; PV = 2 of k_lz4_segments).  The parse is the one above -- same probe rule,
@@ -1280,22 +916,21 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
 }
 
 // TAB = entries of a wave's private table (any multiple of 8: the index is mulhi(hash, TAB), not a mask); G = units per window
-// group = waves per workgroup; MODE 0 = batch parser, 1 = lane parser for groups whose probe finds redundancy (incompressible
-// groups are skimmed by the batch parser's miss mode either way)
-// CLS (MODE 0 only) = classification pass of the two-pass scheme: groups without redundancy are skimmed here and now (the fast
-// geometry: 24 waves per CU), groups with redundancy are only NOTED -- the 16-unit group they belong to goes onto `worklist` --
-// and left to the lane parser, which then runs over that list.
-// PV (lane parser only) = formulation of the parse: 0 lz4_lane_parse, 2 lz4_lane_parse2 (same payloads)
-template <int G, int TAB, int FMT, int MODE, int CLS = 0, int SH = 0, int PV = 0>
-__global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
+// group = waves per workgroup: the batch parser, 8 x 4 KiB units per 32 KiB window group, THREE workgroups per CU.
+// CLS = classification pass of the two-pass scheme: groups without redundancy are skimmed here and now (the fast geometry: 24 waves
+// per CU), groups with redundancy are only NOTED -- the 16-unit group they belong to goes onto `worklist` -- and left to the lane
+// parser (k_lz4_lanes2), which then runs over that list.  CLS 0 = the batch parser for everything: unit sizes other than 4 KiB.
+// (The lane parser used to be MODE 1 of this template: ablations/k_lz4_segments_modes.inc.)
+template <int G, int TAB, int FMT, int CLS = 0>
+__global__ __launch_bounds__(64 * G, 6) void k_lz4_segments(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
                                                              uint32_t nblocks, uint32_t grp0, uint32_t sub_bytes,
                                                              uint8_t* __restrict__ streams, Lz4Meta* __restrict__ meta,
                                                              uint64_t* __restrict__ zrecs, uint8_t* __restrict__ spec_dst, uint32_t dbg,
                                                              uint64_t* __restrict__ lane_recs, uint32_t ngroups, uint32_t* __restrict__ worklist)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    constexpr bool PAD = PV == 2; // the window is the padded one (lds_dw / lz4_window_lds_bytes)
-    const uint32_t data_bytes = lz4_window_lds_bytes(G * sub_bytes + 64u + (PAD ? LZ4_LPAD : 0u), PAD);
+    constexpr bool PAD = false; // (the padded window is the lane parser's)
+    const uint32_t data_bytes = lz4_window_lds_bytes(G * sub_bytes + 64u, PAD);
     uint32_t* sdata = smem;
     const uint8_t* sbytes = reinterpret_cast<const uint8_t*>(sdata);
     uint32_t* flag = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes); // 16 bytes
@@ -1303,44 +938,10 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint16_t* tab = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u) + (size_t)wave * TAB;
-    // SH (lane parser, round 3): a table of 2^SH 32-bit slots behind the private ones, shared by the group's waves
-    [[maybe_unused]] uint32_t* shr = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u + (size_t)G * TAB * 2);
-
-    // MODE 0: one window group per workgroup.  MODE 1: the workgroup is alone on its CU (144 KiB of LDS), so it is PERSISTENT over
-    // the groups grp0 + blockIdx.x, + gridDim.x, ... and the next group's bytes are fetched into registers (80 bytes per thread)
-    // while the current one is parsed -- without that the memory pipe idles during every parse and the ALUs during every load.
-    uint4 pre[5];
-    bool have_pre = false;
     K5P_DECL
-    // with a worklist (MODE 1 behind the classification pass) the loop runs over its entries: worklist[0] = count, then group ids
-    const bool listed = MODE == 1 && worklist != nullptr;
-    const uint32_t grp_end = listed ? worklist[0] : (MODE == 1 ? grp0 + ngroups : grp0 + blockIdx.x + 1u);
-    const uint32_t grp_step = MODE == 1 ? gridDim.x : 1u;
-    [[maybe_unused]] uint32_t sh_gen = 0; // SH: tag of the group's entries in the shared table (upper 16 bits), counting down
-    // The listed groups differ in what they cost (the classes of the data: a group of "lines" takes a third of a group of "tokens"), so
-    // the workgroups DRAW the entries of the list -- the first gridDim.x by their index, then a ticket each (the word behind the
-    // flags, zero at launch), drawn one group ahead because the next group's bytes are fetched during the parse.  With the fixed stride
-    // the slowest of 256 workgroups set the time of every launch (LTHIP_LZ4_DBG bit 27 keeps the stride).
-    const bool ticketed = listed && !(dbg & (1u << 27));
-    uint32_t next_gidx = 0;
-    for (uint32_t gidx = blockIdx.x + (listed ? 0u : grp0); gidx < grp_end; gidx = ticketed ? next_gidx : gidx + grp_step)
+    // one window group per workgroup
     {
-    if constexpr (SH != 0)
-    {
-        if (sh_gen == 0u)
-        {
-            // (first group of this workgroup, and again after 65535 of them: everything "older than any group")
-            uint4* hv = reinterpret_cast<uint4*>(shr);
-            const uint4 none = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            for (uint32_t v = tid; v < (4u << SH) / 16u; v += 64 * G)
-                hv[v] = none;
-            __syncthreads();
-            sh_gen = (dbg & (1u << 26)) ? 3u : 0xFFFFu; // (LTHIP_LZ4_DBG bit 26, tests: the counter runs out every third group)
-        }
-        --sh_gen;
-    }
-    [[maybe_unused]] const uint32_t sh_base = sh_gen << 16;
-    const uint32_t grp = listed ? worklist[1u + gidx] : gidx;
+    const uint32_t grp = grp0 + blockIdx.x;
     uint32_t lo = 0, hi = nblocks;
     while (hi - lo > 1)
     {
@@ -1360,65 +961,11 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     const uint32_t head_src = (uint32_t)((uintptr_t)g & 15u);
     // LDS byte address of position 0 of the group: the source's misalignment (the window is staged in aligned 16-byte lines) and, for
     // the second formulation of the lane parser, one line of padding in front (its extension reads 8 bytes below a position)
-    const uint32_t head = head_src + (PV == 2 ? LZ4_LPAD : 0u);
+    const uint32_t head = head_src;
     {
         const uint4* gv = reinterpret_cast<const uint4*>(g - head_src);
         const uint32_t nvec = (head_src + glen + 15u) >> 4;
         uint4* sv = reinterpret_cast<uint4*>(sdata);
-        // line v of the source goes to window bytes 16 v (+ the pad line of PV 2); in the padded window a line stays whole (16 | 128) but
-        // is only dword aligned
-        [[maybe_unused]] auto put_line = [&](uint32_t v, const uint4& x) {
-            if constexpr (PAD)
-            {
-                const uint32_t D = 4u * (v + LZ4_LPAD / 16u);
-                uint32_t* q = sdata + lds_pidx<true>(D);
-                q[0] = x.x;
-                q[1] = x.y;
-                q[2] = x.z;
-                q[3] = x.w;
-                if ((D & 31u) == 0u && D != 0u) // the first line of a row: its first dwords are repeated behind the row before
-                {
-                    static_assert(LZ4_ROW_DUP == 3, "three repeated dwords");
-                    q[-3] = x.x;
-                    q[-2] = x.y;
-                    q[-1] = x.z;
-                }
-            }
-            else
-                sv[v] = x;
-        };
-        // SH: the aligned dwords of the group enter the shared table straight from the registers that stage them (whoever holds a
-        // line inserts it: the minimum does not care); entries carry the group's tag in their upper half -- it counts DOWN, so a
-        // newer group's entry is smaller than any older one and the table is never cleared between groups
-        [[maybe_unused]] auto seed_line = [&](const uint4& line, uint32_t v) {
-            if constexpr (SH != 0)
-            {
-                const uint32_t q = 16u * v - head_src; // position of the line's first byte (line 0: "negative" = above the group)
-                const uint32_t g4[4] = {line.x, line.y, line.z, line.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                {
-                    const uint32_t pk = q + 4u * k;
-                    if (pk < glen)
-                        (void)__hip_atomic_fetch_min(&shr[(g4[k] * 2654435761u) >> (32 - SH)], sh_base | pk, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        };
-        if (MODE == 1 && PV != 2 && have_pre)
-        {
-#pragma unroll
-            for (int u = 0; u < 5; ++u)
-            {
-                const uint32_t v = u * 64 * G + tid;
-                if (v < nvec)
-                {
-                    put_line(v, pre[u]);
-                    seed_line(pre[u], v);
-                }
-            }
-        }
-        else
         for (uint32_t v0 = 0; v0 < nvec; v0 += 64 * G * 4)
         {
             uint4 q[4];
@@ -1433,72 +980,27 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
             {
                 const uint32_t v = v0 + u * 64 * G + tid;
                 if (v < nvec)
-                {
-                    put_line(v, q[u]);
-                    if (MODE == 1)
-                        seed_line(q[u], v);
-                }
+                    sv[v] = q[u];
             }
         }
         uint4* tv = reinterpret_cast<uint4*>(tab);
-        const uint32_t e1 = MODE == 1 ? 0u : 0xFFFFFFFFu; // lane parser: 0 = empty, so that tables merge by a packed maximum
+        const uint32_t e1 = 0xFFFFFFFFu;
         const uint4 e = make_uint4(e1, e1, e1, e1);
 #pragma unroll
         for (uint32_t v = 0; v < (TAB * 2 / 16 + 63) / 64; ++v) // TAB * 2 bytes, 64 lanes x 16 bytes per step
             if (v * 64 + lane < TAB * 2 / 16)
                 tv[v * 64 + lane] = e;
         if (tid == 0)
-        {
             *flag = 0u;
-            if (MODE == 1 && ticketed)
-                flag[1] = gridDim.x + atomicAdd(worklist + 2u * ngroups + 1u, 1u);
-        }
     }
     __syncthreads();
     K5P(0);
-    if constexpr (MODE == 1)
-    {
-        // the next group of this workgroup: its loads are in flight during the parse below
-        const uint32_t nidx = ticketed ? flag[1] : gidx + grp_step;
-        next_gidx = nidx;
-        have_pre = false;
-        // (PV 2 does without the register prefetch: its 20 VGPRs are the parser's records and window now, and with the prefetch off --
-        // LTHIP_LZ4_DBG bit 12 -- the round-3 kernel measured the same time: the staging loads of one workgroup hide behind the parse of
-        // nothing, but they are 5 % of the group's time)
-        if (PV != 2 && nidx < grp_end && !(dbg & 4096u))
-        {
-            const uint32_t nxt = listed ? worklist[1u + nidx] : nidx;
-            uint32_t lo2 = 0, hi2 = nblocks;
-            while (hi2 - lo2 > 1)
-            {
-                const uint32_t mid = lo2 + ((hi2 - lo2) >> 1);
-                if (blocks[mid].grp_base <= nxt)
-                    lo2 = mid;
-                else
-                    hi2 = mid;
-            }
-            const Lz4Block b2 = blocks[lo2];
-            const uint32_t gs2 = (nxt - b2.grp_base) * G * sub_bytes;
-            const uint32_t gl2 = b2.size - gs2 < G * sub_bytes ? b2.size - gs2 : G * sub_bytes;
-            const uint8_t* g2 = src + b2.src_off + gs2;
-            const uint32_t head2 = (uint32_t)((uintptr_t)g2 & 15u);
-            const uint4* gv2 = reinterpret_cast<const uint4*>(g2 - head2);
-            const uint32_t nvec2 = (head2 + gl2 + 15u) >> 4;
-#pragma unroll
-            for (int u = 0; u < 5; ++u)
-            {
-                const uint32_t v = u * 64 * G + tid;
-                pre[u] = v < nvec2 ? gv2[v] : make_uint4(0, 0, 0, 0);
-            }
-            have_pre = true;
-        }
-    }
 
     K5P(1);
     // ---- my unit, positions relative to the group start ----
     const uint32_t my_start = (uint32_t)wave * sub_bytes;
     const bool have_unit = my_start < glen;
-    bool emit_unit = have_unit; // (the lane kernel leaves the units of a half-group alone that the classification pass has already written)
+    const bool emit_unit = have_unit;
     const uint32_t my_len = have_unit ? (glen - my_start < sub_bytes ? glen - my_start : sub_bytes) : 0u;
     const uint32_t unit = blk.seg_base + gi * G + (uint32_t)wave;
     // parsing limits (lz4.c:963-964: mflimit / matchlimit, applied at the BLOCK end)
@@ -1524,175 +1026,6 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     uint32_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0, ps0 = 1, ps1 = 1, ps2 = 1, ps3 = 1; // the probe batches (SGPRs)
     static_assert(LZ4_PROBE_BATCHES == 4, "probe bookkeeping is unrolled by hand");
 
-    if constexpr (MODE == 1)
-    {
-        // sub-unit pitch = unit / 64 bytes.  (An odd number of dwords -- 68 bytes, 61 lanes busy -- so that lanes running in phase do
-        // not all hit the same two LDS banks was measured: 6 % SLOWER and a worse ratio; dbg bit 8 keeps the experiment.)
-        const uint32_t sub = (dbg & 256u) ? ((sub_bytes >> 6) | 4u) : sub_bytes >> 6;
-        // every group this kernel sees holds redundancy (the classification pass listed it; LTHIP_LZ4_DBG bit 14 sends ALL groups
-        // here, an ablation): no probe, no rendezvous -- the waves of the group only share the window
-        //
-        // History (round 3).  A unit's table has to start with the positions of the units before it.  Rounds 1-2 let every wave
-        // insert all of that itself: sum over w of w * 1024 inserts per group, LDS-write bound, and wave 15 worked while wave 0
-        // waited at the group's barrier (21 % of the kernel's wave time).  Now every wave inserts only ITS OWN unit (every 4th
-        // position, the aligned dwords of the window) into its table, and the tables are combined by a prefix "sum" over the
-        // waves whose operator is the packed 16-bit maximum -- a later unit's position is the larger one, 0 = empty --: four
-        // Hillis-Steele rounds, each one conflict-free ds_read_b128 sweep of another wave's table (5 KiB) + 20 v_pk_max_u16 +
-        // a sweep back.  Table k then holds units 0..k: wave k parses with table k-1 (wave 0 with a cleared one).  Same work for
-        // every wave, 16 inserts per lane instead of up to 108, and the far history is complete instead of every 16th position.
-        uint16_t* ptab = tab; // the table this wave parses with
-        // a half of the group (8 units) in which the classification pass saw no redundancy was skimmed and written there: its
-        // units only lend their bytes to the others' history here (LTHIP_LZ4_DBG bit 19: parse them again, the round-2 behaviour)
-        if (listed && !(dbg & 524288u) && !((worklist[1u + ngroups + grp] >> ((uint32_t)wave / (uint32_t)(G / 2))) & 1u))
-            emit_unit = false;
-        if constexpr (SH != 0)
-        {
-            // History, second take (round 3): ONE table for the group that keeps the EARLIEST position of every aligned dword's hash
-            // (LDS atomic minimum; the dwords are inserted by whoever stages them, see seed_line) -- whatever a lane probes, every occurrence but the
-            // group's first finds the first one, in whichever unit it lies; the private tables (1536 entries now) hold the unit before
-            // (below) and what the wave's own parse inserts, and give the nearer candidate when they have one.  Against the prefix maximum over the
-            // waves' tables above: no sweeps, the far history no longer competes for 2560 slots with the near one ("tokens": a
-            // vocabulary of 2 x 1024 keys lost 40 % of its entries), tools/lz4_lane_model.c: mixed 1.89 -> 2.02 (reference 1.94),
-            // tokens 1.64 -> 2.13 (1.98), records 2.45 -> 2.53 (2.56) with 17 % fewer probe steps.
-            // (inserted while the group was staged, see seed_line; the barrier behind the staging covers it)
-            //
-            // The private table starts with the aligned dwords of the unit BEFORE mine (16 stores per lane, my own table: no barrier): the
-            // shared table answers with the group's EARLIEST occurrence, up to 64 KiB back, and a decoder pays for far offsets -- its
-            // LDS ring holds 8 KiB, sources beyond it are fetched from memory one match at a time (own "records" payloads decoded at
-            // 104 GB/s instead of 155 when half of their offsets were far; the model: 51 % -> 25 % above 6400 at the same ratio).
-            if (have_unit && wave > 0 && !(dbg & 1u))
-            {
-                const uint4* s128 = reinterpret_cast<const uint4*>(sdata);
-                const uint32_t p0 = my_start - sub_bytes;
-                const uint32_t l0 = (p0 + head) >> 4, l1 = (my_start + head + 15u) >> 4; // 16-byte lines that hold the unit before mine
-                for (uint32_t j0 = l0; j0 < l1; j0 += 256)
-                {
-                    uint4 w[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                    {
-                        const uint32_t j = j0 + u * 64 + (uint32_t)lane;
-                        if constexpr (PAD)
-                        {
-                            const uint32_t* q = sdata + lds_pidx<true>(4u * j);
-                            w[u] = j < l1 ? make_uint4(q[0], q[1], q[2], q[3]) : make_uint4(0, 0, 0, 0);
-                        }
-                        else
-                        w[u] = j < l1 ? s128[j] : make_uint4(0, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                    {
-                        const uint32_t j = j0 + u * 64 + (uint32_t)lane;
-                        const uint32_t q = 16u * j - head; // position of the line's first byte (may be "negative" in line 0)
-                        const uint32_t g4[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                        {
-                            const uint32_t pk = q + 4u * k;
-                            if (j < l1 && pk >= p0 && pk < my_start) // (a wrapped "negative" position is above the unit)
-                                tab[lz4_tab_slot<TAB, PV>(g4[k] * 2654435761u)] = (uint16_t)pk;
-                        }
-                    }
-                }
-            }
-        }
-        else if (!(dbg & 1u))
-        {
-            typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-            static_assert((TAB * 2) % (16 * 64) == 0, "a table is a whole number of 1 KiB sweeps");
-            constexpr int NV = TAB * 2 / (16 * 64);
-            if (have_unit)
-            {
-                const uint4* s128 = reinterpret_cast<const uint4*>(sdata);
-                const uint32_t l0 = (my_start + head) >> 4, l1 = (my_start + my_len + head + 15u) >> 4; // 16-byte lines that hold my unit
-                for (uint32_t j0 = l0; j0 < l1; j0 += 256)
-                {
-                    uint4 w[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                    {
-                        const uint32_t j = j0 + u * 64 + (uint32_t)lane;
-                        w[u] = j < l1 ? s128[j] : make_uint4(0, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                    {
-                        const uint32_t j = j0 + u * 64 + (uint32_t)lane;
-                        const uint32_t q = 16u * j - head; // position of the line's first byte (may be "negative" in line 0)
-                        const uint32_t g4[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                        {
-                            const uint32_t pk = q + 4u * k;
-                            if (j < l1 && pk >= my_start && pk < my_start + my_len) // (a wrapped "negative" position is above the unit)
-                                tab[__umulhi(g4[k] * 2654435761u, (uint32_t)TAB)] = (uint16_t)pk;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            uint4* own = reinterpret_cast<uint4*>(tab);
-            uint4 mine[NV];
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-                mine[v] = own[v * 64 + lane];
-#pragma unroll
-            for (int d = 1; d < G; d <<= 1)
-            {
-                uint4 other[NV];
-                if (wave >= d)
-                {
-                    const uint4* src_tab = reinterpret_cast<const uint4*>(tab - (size_t)d * TAB);
-#pragma unroll
-                    for (int v = 0; v < NV; ++v)
-                        other[v] = src_tab[v * 64 + lane];
-                }
-                __syncthreads(); // every wave has read the round's input before anybody overwrites it
-                if (wave >= d)
-                {
-#pragma unroll
-                    for (int v = 0; v < NV; ++v)
-                    {
-                        uint32_t a4[4] = {mine[v].x, mine[v].y, mine[v].z, mine[v].w};
-                        const uint32_t b4[4] = {other[v].x, other[v].y, other[v].z, other[v].w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                        {
-                            const u16x2 x = __builtin_bit_cast(u16x2, a4[k]), y = __builtin_bit_cast(u16x2, b4[k]);
-                            a4[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(x, y));
-                        }
-                        mine[v] = make_uint4(a4[0], a4[1], a4[2], a4[3]);
-                        own[v * 64 + lane] = mine[v];
-                    }
-                }
-                __syncthreads();
-            }
-            // table k = units 0..k; mine is the one before (wave 0 takes the last one, which nobody needs, and clears it)
-            ptab = (wave == 0 ? tab + (size_t)(G - 1) * TAB : tab - (size_t)TAB);
-            if (wave == 0)
-            {
-                uint4* tv = reinterpret_cast<uint4*>(ptab);
-#pragma unroll
-                for (int v = 0; v < NV; ++v)
-                    tv[v * 64 + lane] = make_uint4(0, 0, 0, 0);
-            }
-        }
-        {
-            if (emit_unit)
-            {
-                K5P(2);
-                if constexpr (PV == 2)
-                    lz4_lane_parse2<TAB, FMT, SH>(sdata, head, ptab, shr, sh_base, lane, my_start, my_len, start_limit, end_limit, sub, out, recs, st,
-                                                  dbg K5P_PASS);
-                else
-                    lz4_lane_parse<TAB, FMT, SH>(sdata, head, ptab, shr, sh_base, lane, my_start, my_len, start_limit, end_limit, sub, out, recs,
-                                                 lane_recs + (uint64_t)unit * (64u * LZ4_LANE_MAXREC), st, dbg K5P_PASS);
-            }
-        }
-    }
-
-    if constexpr (MODE == 0)
     for (;;)
     {
         const bool more = have_unit && (int32_t)pos <= start_limit;
@@ -2099,13 +1432,13 @@ __global__ __launch_bounds__(64 * G, MODE == 0 ? 6 : 4) void k_lz4_segments(cons
     }
     } // FMT 0
     K5P(8);
-    if constexpr (MODE == 1)
-        __syncthreads(); // every wave is done with the window before the next group overwrites it
     K5P(9);
-    } // groups of this workgroup
-    if constexpr (MODE == 1)
-        K5P_FLUSH;
+    } // the group
 }
+
+#ifdef LTHIP_ABLATIONS
+#include "ablations/k_lz4_segments_modes.inc"
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // K5 lane parser, round 4: HALF-GROUPS as the unit of work.  The classification pass flags redundancy per 32 KiB half of a 64 KiB
@@ -2788,118 +2121,132 @@ extern "C" __attribute__((visibility("default"))) int lthip_k5_prof_dump(int res
 
 static bool lz4_lane_parser()
 {
+#ifdef LTHIP_ABLATIONS
     static const bool v = [] {
-        const char* e = getenv("LTHIP_LZ4_PARSER");
+        const char* e = getenv("LTHIP_LZ4_PARSER"); // "batch": the round-1 batch parser for everything
         return !(e && strcmp(e, "batch") == 0);
     }();
     return v;
+#else
+    return true;
+#endif
 }
 
-template <int G, int TAB, int FMT, int MODE, int CLS = 0, int SH = 0, int PV = 0>
+// the batch parser's geometry: classification pass (CLS 1) or the parser for everything (CLS 0)
+template <int FMT, int CLS>
 static int launch_segments(lthip_ctx* ctx, uint32_t groups, uint32_t SEG, const void* d_src, const Lz4Block* d_blocks, uint32_t block_count,
-                           uint32_t g0, uint8_t* streams, Lz4Meta* meta, uint64_t* zrecs, uint8_t* spec_dst, uint32_t dbg, uint64_t* lane_recs,
-                           uint32_t ngroups, uint32_t* worklist)
+                           uint32_t g0, uint8_t* streams, Lz4Meta* meta, uint64_t* zrecs, uint8_t* spec_dst, uint32_t dbg, uint32_t ngroups,
+                           uint32_t* worklist)
 {
-    const size_t lds = (size_t)lz4_window_lds_bytes(G * SEG + 64u + (PV == 2 ? LZ4_LPAD : 0u), PV == 2) + 16 + (size_t)G * TAB * 2 + (SH ? (size_t)4 << SH : 0);
-    if (lds > 64u * 1024u && !ctx->k5_lds_enabled)
+    constexpr int TAB = FMT == 1 ? LZ4_TAB_ZSTD : LZ4_TAB_LZ4;
+    const size_t lds = (size_t)lz4_window_lds_bytes(LZ4_G_BATCH * SEG + 64u, false) + 16 + (size_t)LZ4_G_BATCH * TAB * 2;
+    if (lds > 64u * 1024u && !ctx->k5_lds_enabled[FMT][CLS]) // (8 KiB units)
     {
-        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_SHARED, 0, 1, 0, LZ4_SH_LOG2, 2>),
+        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_BATCH, TAB, FMT, CLS>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_SHARED, 1, 1, 0, LZ4_SH_LOG2, 2>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_SHARED, 0, 1, 0, LZ4_SH_LOG2>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_SHARED, 1, 1, 0, LZ4_SH_LOG2>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_LANES, 0, 1>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments<LZ4_G_LANES, LZ4_TAB_LANES, 1, 1>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ctx->k5_lds_enabled = true;
+        ctx->k5_lds_enabled[FMT][CLS] = true;
     }
-    uint32_t grid = groups;
-    if (MODE == 1)
-    {
-        int ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        grid = groups < (uint32_t)ncu ? groups : (uint32_t)ncu; // one persistent workgroup per CU
-    }
-    hipLaunchKernelGGL((k_lz4_segments<G, TAB, FMT, MODE, CLS, SH, PV>), dim3(grid), dim3(64 * G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
-                       block_count, g0, SEG, streams, meta, zrecs, spec_dst, dbg, lane_recs, ngroups, worklist);
+    hipLaunchKernelGGL((k_lz4_segments<LZ4_G_BATCH, TAB, FMT, CLS>), dim3(groups), dim3(64 * LZ4_G_BATCH), lds, ctx->stream, (const uint8_t*)d_src,
+                       d_blocks, block_count, g0, SEG, streams, meta, zrecs, spec_dst, dbg, nullptr, ngroups, worklist);
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
 }
 
-// The match finder of one batch (FMT 0: LZ4 streams, FMT 1: zstd sequences).  Lane parser (default): two passes -- the batch parser's
-// geometry (8 units per group, 24 waves per CU) classifies every group with its four probe batches and skims the ones without
-// redundancy on the spot (incompressible data never sees the slower one-workgroup-per-CU geometry); the 16-unit groups that hold
-// redundancy are listed and parsed by the lane kernel, persistent over the list.
+#ifdef LTHIP_ABLATIONS
+// the lane parser inside the segments kernel (rounds 2-4: ablations/k_lz4_segments_modes.inc), persistent, one workgroup per CU
+template <int TAB, int FMT, int SH = 0, int PV = 0>
+static int launch_segments_lane_mode(lthip_ctx* ctx, uint32_t groups, uint32_t SEG, const void* d_src, const Lz4Block* d_blocks, uint32_t block_count,
+                                     uint8_t* streams, Lz4Meta* meta, uint64_t* zrecs, uint8_t* spec_dst, uint32_t dbg, uint64_t* lane_recs,
+                                     uint32_t ngroups, uint32_t* worklist)
+{
+    constexpr int G = LZ4_G_LANES;
+    const size_t lds = (size_t)lz4_window_lds_bytes(G * SEG + 64u + (PV == 2 ? LZ4_LPAD : 0u), PV == 2) + 16 + (size_t)G * TAB * 2 + (SH ? (size_t)4 << SH : 0);
+    static bool granted[64] = {}; // per device and instance: more than 64 KiB of dynamic LDS has to be granted explicitly
+    if (ctx->device < 0 || ctx->device >= 64 || !granted[ctx->device])
+    {
+        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_segments_modes<G, TAB, FMT, 1, 0, SH, PV>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (ctx->device >= 0 && ctx->device < 64)
+            granted[ctx->device] = true;
+    }
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const uint32_t grid = groups < (uint32_t)ncu ? groups : (uint32_t)ncu;
+    hipLaunchKernelGGL((k_lz4_segments_modes<G, TAB, FMT, 1, 0, SH, PV>), dim3(grid), dim3(64 * G), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
+                       block_count, 0u, SEG, streams, meta, zrecs, spec_dst, dbg, lane_recs, ngroups, worklist);
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
+}
+#endif
+
+// The match finder of one batch (FMT 0: LZ4 streams, FMT 1: zstd sequences), two passes: the batch parser's geometry (8 units per group,
+// 24 waves per CU) classifies every 32 KiB half-group with its four probe batches and skims the ones without redundancy on the spot
+// (incompressible data never sees the slower one-workgroup-per-CU geometry); the 16-unit groups that hold redundancy are listed, the
+// list becomes items of two half-groups (k_lz4_pair_halves), and the lane kernel (k_lz4_lanes2) is persistent over the items.
+// `lanes` false (unit sizes other than 4 KiB): the batch parser for everything.
 template <int FMT>
 static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const void* d_src, const Lz4Block* d_blocks, uint32_t block_count,
                                uint32_t g0, uint32_t g1, uint64_t ngrp, uint64_t ncgrp, uint8_t* streams, Lz4Meta* meta, uint64_t* zrecs,
-                               uint8_t* spec_dst, uint32_t dbg, uint64_t* lane_recs)
+                               uint8_t* spec_dst, uint32_t dbg, [[maybe_unused]] uint64_t* lane_recs)
 {
     if (!lanes)
-        return launch_segments<LZ4_G_BATCH, FMT == 1 ? LZ4_TAB_ZSTD : LZ4_TAB_LZ4, FMT, 0>(ctx, g1 - g0, SEG, d_src, d_blocks, block_count, g0, streams,
-                                                                                            meta, zrecs, spec_dst, dbg, nullptr, 0, nullptr);
+        return launch_segments<FMT, 0>(ctx, g1 - g0, SEG, d_src, d_blocks, block_count, g0, streams, meta, zrecs, spec_dst, dbg, 0, nullptr);
+#ifdef LTHIP_ABLATIONS
     // LTHIP_LZ4_SHARED=0: round 2/3a's history (prefix maximum over the waves' 2560-entry tables) instead of the shared table
-    static LthipEnvInt env_shared{"LTHIP_LZ4_SHARED"};
+    LTHIP_ABLATION_ENV(env_shared, "LTHIP_LZ4_SHARED");
     const bool shared = env_shared.get() != 0;
-    static LthipEnvInt env_pv{"LTHIP_LZ4_PV"}; // 0: the round-3 formulation of the lane parse (lz4_lane_parse), default: the round-4 one
+    LTHIP_ABLATION_ENV(env_pv, "LTHIP_LZ4_PV"); // 0: the round-3 formulation of the lane parse (lz4_lane_parse), default: the round-4 one
     const bool pv2 = shared && env_pv.get() != 0;
-    if (pv2 && (dbg & 16384u))
-        return launch_segments<LZ4_G_LANES, LZ4_TAB_SHARED, FMT, 1, 0, LZ4_SH_LOG2, 2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta,
-                                                                                      zrecs, spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr);
-    if (dbg & 16384u) // ablation: the lane kernel alone, with its own probe
-        return shared ? launch_segments<LZ4_G_LANES, LZ4_TAB_SHARED, FMT, 1, 0, LZ4_SH_LOG2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams,
-                                                                                            meta, zrecs, spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr)
-                      : launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, FMT, 1>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta, zrecs,
-                                                                           spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr);
+    if (dbg & 16384u) // the lane kernel alone, with its own probe
+        return pv2      ? launch_segments_lane_mode<LZ4_TAB_SHARED, FMT, LZ4_SH_LOG2, 2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, streams, meta, zrecs,
+                                                                                        spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr)
+               : shared ? launch_segments_lane_mode<LZ4_TAB_SHARED, FMT, LZ4_SH_LOG2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, streams, meta, zrecs,
+                                                                                     spec_dst, dbg, lane_recs, (uint32_t)ngrp, nullptr)
+                        : launch_segments_lane_mode<LZ4_TAB_LANES, FMT>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, streams, meta, zrecs, spec_dst,
+                                                                        dbg, lane_recs, (uint32_t)ngrp, nullptr);
+#endif
     void* wl;
     int err = lthip_scratch(ctx, S_LZ4_CLASSIFY, 4 * (11 * (size_t)ngrp + 16), &wl);
     if (err)
         return err;
     LTHIP_CHECK(ctx, hipMemsetAsync(wl, 0, 4 * (2 * (size_t)ngrp + 4), ctx->stream));
-    if ((err = launch_segments<LZ4_G_BATCH, FMT == 1 ? LZ4_TAB_ZSTD : LZ4_TAB_LZ4, FMT, 0, 1>(ctx, (uint32_t)ncgrp, SEG, d_src, d_blocks, block_count, 0,
-                                                                                             streams, meta, zrecs, spec_dst, dbg, nullptr,
-                                                                                             (uint32_t)ngrp, (uint32_t*)wl)))
+    if ((err = launch_segments<FMT, 1>(ctx, (uint32_t)ncgrp, SEG, d_src, d_blocks, block_count, 0, streams, meta, zrecs, spec_dst, dbg, (uint32_t)ngrp,
+                                       (uint32_t*)wl)))
         return err;
-    static LthipEnvInt env_halves{"LTHIP_LZ4_HALVES"}; // 0: whole groups as the unit of work (a group's incompressible half idles eight waves)
-    if (pv2 && env_halves.get() != 0)
+#ifdef LTHIP_ABLATIONS
+    LTHIP_ABLATION_ENV(env_halves, "LTHIP_LZ4_HALVES"); // 0: whole groups as the unit of work (a group's incompressible half idles eight waves)
+    if (!pv2 || env_halves.get() == 0)
+        return pv2      ? launch_segments_lane_mode<LZ4_TAB_SHARED, FMT, LZ4_SH_LOG2, 2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, streams, meta, zrecs,
+                                                                                        spec_dst, dbg, lane_recs, (uint32_t)ngrp, (uint32_t*)wl)
+               : shared ? launch_segments_lane_mode<LZ4_TAB_SHARED, FMT, LZ4_SH_LOG2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, streams, meta, zrecs,
+                                                                                     spec_dst, dbg, lane_recs, (uint32_t)ngrp, (uint32_t*)wl)
+                        : launch_segments_lane_mode<LZ4_TAB_LANES, FMT>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, streams, meta, zrecs, spec_dst,
+                                                                        dbg, lane_recs, (uint32_t)ngrp, (uint32_t*)wl);
+#endif
+    // the list of groups -> items of two half-groups (k_lz4_pair_halves), then the lane kernel over the items
+    const uint32_t nthreads = 256, ng = (uint32_t)ngrp;
+    // history halves: the zstd flavour at its "high" and "max" settings
+    const uint32_t hist = (FMT == 1 && (dbg & (LZ4_DBG_Q_HIGH | LZ4_DBG_Q_MAX))) ? 1u : 0u;
+    hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng + nthreads - 1) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 0u, d_blocks, block_count, hist);
+    hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng / 2 + nthreads) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 1u, d_blocks, block_count, hist);
+    LTHIP_LAUNCH_CHECK(ctx);
+    const size_t lds = (size_t)lz4_window_lds_bytes(LZ4_G_LANES * SEG + 64u + LZ4_LPAD + 32u, true) + 16 + (size_t)LZ4_G_LANES * LZ4_TAB_SHARED * 2 +
+                       ((size_t)4 << LZ4_SH_LOG2);
+    if (!ctx->k5h_lds_enabled[FMT])
     {
-        // the list of groups -> items of two half-groups (k_lz4_pair_halves), then the lane kernel over the items
-        const uint32_t nthreads = 256, ng = (uint32_t)ngrp;
-        // history halves: the zstd flavour at its "high" and "max" settings
-        const uint32_t hist = (FMT == 1 && (dbg & (LZ4_DBG_Q_HIGH | LZ4_DBG_Q_MAX))) ? 1u : 0u;
-        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng + nthreads - 1) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 0u, d_blocks, block_count, hist);
-        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng / 2 + nthreads) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 1u, d_blocks, block_count, hist);
-        LTHIP_LAUNCH_CHECK(ctx);
-        const size_t lds = (size_t)lz4_window_lds_bytes(LZ4_G_LANES * SEG + 64u + LZ4_LPAD + 32u, true) + 16 + (size_t)LZ4_G_LANES * LZ4_TAB_SHARED * 2 +
-                           ((size_t)4 << LZ4_SH_LOG2);
-        if (!ctx->k5h_lds_enabled[FMT])
-        {
-            LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_lanes2<FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            ctx->k5h_lds_enabled[FMT] = true;
-        }
-        int ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        // zstd flavour: a match must be one byte longer from 2^a bytes away and two from 2^b, and c bytes long when it reaches into a
-        // history half (LTHIP_LZ4_FAR = a + 256 b + 65536 c; default 10, 12, 8; a = b = 31 and c = 4: no rule)
-        static LthipEnvInt env_far{"LTHIP_LZ4_FAR"};
-        const uint32_t farlog = env_far.get() >= 0 ? (uint32_t)env_far.get() : (10u | (12u << 8) | (8u << 16));
-        hipLaunchKernelGGL((k_lz4_lanes2<FMT>), dim3((uint32_t)ncu), dim3(64 * LZ4_G_LANES), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
-                           block_count, SEG, streams, meta, zrecs, spec_dst, dbg, ng, (uint32_t*)wl, farlog);
-        LTHIP_LAUNCH_CHECK(ctx);
-        return 0;
+        LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_lanes2<FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->k5h_lds_enabled[FMT] = true;
     }
-    if (pv2)
-        return launch_segments<LZ4_G_LANES, LZ4_TAB_SHARED, FMT, 1, 0, LZ4_SH_LOG2, 2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta,
-                                                                                      zrecs, spec_dst, dbg, lane_recs, (uint32_t)ngrp, (uint32_t*)wl);
-    if (shared)
-        return launch_segments<LZ4_G_LANES, LZ4_TAB_SHARED, FMT, 1, 0, LZ4_SH_LOG2>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta,
-                                                                                   zrecs, spec_dst, dbg, lane_recs, (uint32_t)ngrp, (uint32_t*)wl);
-    return launch_segments<LZ4_G_LANES, LZ4_TAB_LANES, FMT, 1>(ctx, (uint32_t)ngrp, SEG, d_src, d_blocks, block_count, 0, streams, meta, zrecs,
-                                                               spec_dst, dbg, lane_recs, (uint32_t)ngrp, (uint32_t*)wl);
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    // zstd flavour: a match must be one byte longer from 2^a bytes away and two from 2^b, and c bytes long when it reaches into a
+    // history half (a + 256 b + 65536 c = 10, 12, 8; a = b = 31 and c = 4: no rule; the ablation build reads LTHIP_LZ4_FAR)
+    LTHIP_ABLATION_ENV(env_far, "LTHIP_LZ4_FAR");
+    const uint32_t farlog = env_far.get() >= 0 ? (uint32_t)env_far.get() : (10u | (12u << 8) | (8u << 16));
+    hipLaunchKernelGGL((k_lz4_lanes2<FMT>), dim3((uint32_t)ncu), dim3(64 * LZ4_G_LANES), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
+                       block_count, SEG, streams, meta, zrecs, spec_dst, dbg, ng, (uint32_t*)wl, farlog);
+    LTHIP_LAUNCH_CHECK(ctx);
+    return 0;
 }
 
 static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_count, const uint64_t* src_offsets,
@@ -2921,12 +2268,13 @@ uint64_t lthip_codec_batch_bytes()
 // Budget (MiB) of the arena the restore paths execute dependent payloads on ORIGINS in (4 bytes per byte of output of the payloads in
 // flight; k_lz4_decode.hip, k_zstd.hip).  The payloads of a call go through it in rounds, one small launch per unit row and round: 512
 // sliding-window LZ4 blocks of 8 MiB take 25.2 ms with 4 GiB (four rounds), 21.7 with 8, 20.1 with 16 (one round).  An explicit
-// setting (LTHIP_LZ4_ORG_MIB / LTHIP_ZSTD_ORG_MIB) wins; otherwise a quarter of what the device has free when the question is first
-// asked, between 4 and 16 GiB.
-uint64_t lthip_origin_budget_mib(int explicit_mib)
+// setting (LTHIP_ORIGIN_MIB, one of the product's documented switches) wins; otherwise a quarter of what the device has free when
+// the question is first asked, between 4 and 16 GiB.
+uint64_t lthip_origin_budget_mib()
 {
-    if (explicit_mib > 0)
-        return (uint64_t)explicit_mib;
+    static LthipEnvInt env_org{"LTHIP_ORIGIN_MIB"};
+    if (env_org.get() > 0)
+        return (uint64_t)env_org.get();
     static const uint64_t v = [] {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
@@ -2996,7 +2344,8 @@ static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_
     // be cut into up to four slices by bytes with slice i's stitch on the context's second stream while slice i+1 is
     // parsed on the main one.  MEASURED SLOWER on MI355X (64 GiB random: 151.6 vs 137.6 ms per step: the copy's traffic
     // lengthens every probe's LDS-fill latency and both kernels lose more than the overlap wins), hence off by default.
-    const uint32_t dbg = (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0);
+    LTHIP_ABLATION_ENV(env_dbg, "LTHIP_LZ4_DBG"); // (ablation build: bits that switch parts of the match finder off or over; 0 in the product)
+    const uint32_t dbg = env_dbg.get() > 0 ? (uint32_t)env_dbg.get() : 0u;
     uint64_t total_bytes = 0;
     for (uint32_t b = 0; b < block_count; ++b)
         total_bytes += src_sizes[b];
@@ -3026,7 +2375,7 @@ static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_
     // the kernel's registers let a CU hold (72 VGPRs: 7 workgroups of 4 waves, not 8 -- with 8 per CU the eighth ran its share of the list
     // after the others were through: 23.9 instead of 18.1 ms on the compressible 64 GiB tree; twice that many, half the share each, evens
     // the tail: 17.8).  LTHIP_LZ4_STITCH_WGS = workgroups per CU.
-    static LthipEnvInt env_swg{"LTHIP_LZ4_STITCH_WGS"};
+    LTHIP_ABLATION_ENV(env_swg, "LTHIP_LZ4_STITCH_WGS");
     int stitch_wgs = 7;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&stitch_wgs, k_lz4_stitch_copy, K6_THREADS, 0) != hipSuccess || stitch_wgs < 1)
         stitch_wgs = 7;
@@ -3114,7 +2463,8 @@ int lthip_launch_lz_sequences(lthip_ctx* ctx, const void* d_src, uint32_t block_
     if (nseg)
     {
         LaunchTimer t(ctx, LTHIP_K_LZ4_SEG);
-        uint32_t dbg = (uint32_t)(getenv("LTHIP_LZ4_DBG") ? atoi(getenv("LTHIP_LZ4_DBG")) : 0);
+        LTHIP_ABLATION_ENV(env_dbg, "LTHIP_LZ4_DBG");
+        uint32_t dbg = env_dbg.get() > 0 ? (uint32_t)env_dbg.get() : 0u;
         // the parse the zstd setting asks for (LTHIP_ZSTD_Q_*): bit 15 = "high" (history halves: k_lz4_pair_halves), bit 31 = "max" (high +
         // the private table read again after the step's inserts); launch_match_finder and lz4_lane_parse2 read them
         if (quality >= 1)

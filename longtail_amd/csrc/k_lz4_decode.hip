@@ -20,115 +20,9 @@ struct Lz4Block // one payload and where its bytes go
     uint32_t pad;
 };
 
-// ---------------------------------------------------------------------------------------------------
-// decoder: LZ4_decompress_safe rules (lz4.c:2215-2435), one wave per block
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_lz4_decode(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks,
-                                                   uint32_t nblocks, uint8_t* __restrict__ dst,
-                                                   uint32_t* __restrict__ out_sizes)
-{
-    const uint32_t b = blockIdx.x;
-    if (b >= nblocks)
-        return;
-    const int lane = threadIdx.x;
-    const Lz4Block blk = blocks[b];
-    const uint8_t* in = src + blk.src_off;
-    uint8_t* out = dst + blk.dst_off;
-    const int64_t n = blk.size, cap = blk.dst_cap;
-    uint32_t result = 0xFFFFFFFFu;
-    if (cap == 0)
-    {
-        if (n == 1 && in[0] == 0)
-            result = 0;
-    }
-    else if (n > 0)
-    {
-        int64_t ip = 0, op = 0;
-        for (;;)
-        {
-            if (ip >= n)
-                break;
-            const uint32_t token = in[ip++];
-            int64_t len = token >> 4;
-            bool bad = false;
-            if (len == 15)
-            { // read_variable_length(&ip, iend-RUN_MASK, 1), lz4.c:1979-2013
-                uint32_t v;
-                if (ip >= n - 15)
-                    bad = true;
-                else
-                    do
-                    {
-                        v = in[ip++];
-                        len += v;
-                        if (ip > n - 15)
-                        {
-                            bad = true;
-                            break;
-                        }
-                    } while (v == 255);
-            }
-            if (bad)
-                break;
-            if (op + len > cap - 12 || ip + len > n - 8)
-            {
-                if (ip + len != n || op + len > cap)
-                    break;
-                for (int64_t j = lane; j < len; j += 64)
-                    out[op + j] = in[ip + j];
-                result = (uint32_t)(op + len);
-                break;
-            }
-            for (int64_t j = lane; j < len; j += 64)
-                out[op + j] = in[ip + j];
-            ip += len;
-            op += len;
-            const uint32_t off = (uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8);
-            ip += 2;
-            if (off == 0 || (int64_t)off > op)
-                break;
-            int64_t ml = token & 15;
-            if (ml == 15)
-            {
-                uint32_t v;
-                do
-                {
-                    if (ip >= n - 5 + 1)
-                    {
-                        bad = true;
-                        break;
-                    }
-                    v = in[ip++];
-                    ml += v;
-                } while (v == 255);
-            }
-            if (bad)
-                break;
-            ml += 4;
-            if (op + ml > cap - 5)
-                break;
-            // the literal bytes written above must be visible to every lane before they are read back
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_waitcnt(0);
-            if ((int64_t)off >= ml)
-            {
-                for (int64_t j = lane; j < ml; j += 64)
-                    out[op + j] = out[op - off + j];
-            }
-            else
-            {
-                // overlapping copy: byte j of the match equals byte (j mod off) of the seed
-                for (int64_t j = lane; j < ml; j += 64)
-                    out[op + j] = out[op - off + (j % (int64_t)off)];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_waitcnt(0);
-            op += ml;
-        }
-    }
-    if (lane == 0)
-        out_sizes[blk.out_index] = result;
-}
+#ifdef LTHIP_ABLATIONS
+#include "ablations/k_lz4_decode_plain.inc"
+#endif
 
 // The same rules, restructured around what made the wave-per-block decoder above slow: every
 // token, length byte and offset was a dependent GLOBAL load, every literal and match a wave-wide byte store, and every match a
@@ -1426,134 +1320,9 @@ struct PdTickets
     uint32_t uniform; // != 0: every block has `rows` units (ticket = row * uniform + block)
 };
 
-template <typename I>
-__global__ __launch_bounds__(64) void k_lz4_pd_units(const uint8_t* __restrict__ src, const PdBlock* __restrict__ blocks, uint8_t* __restrict__ dst,
-                                                     const PdTile* __restrict__ tiles, const uint32_t* __restrict__ tile_op,
-                                                     const uint32_t* __restrict__ unit_tile, PdState* __restrict__ state,
-                                                     uint32_t* __restrict__ done, uint32_t* __restrict__ counters, PdTickets tk,
-                                                     uint32_t dec_nobatch, volatile uint32_t* dbg, const uint32_t* __restrict__ first,
-                                                     uint32_t* __restrict__ unit_mode)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN];
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[DEC_RING];
-    const int lane = threadIdx.x;
-    for (;;)
-    {
-        // Every lane takes part in the ticket draw (lane 0 adds one, the others zero; the compiler turns it into one atomic per
-        // wave).  With "if (lane == 0) t = atomicAdd(..)" hipcc (ROCm 7.2) threaded the loop: lane 0 and the other 63 lanes came
-        // back to the loop head separately, the 63 with t = 0, and decoded ticket 0 a second time without lane 0 -- a hang.
-        __builtin_amdgcn_wave_barrier();
-        uint32_t t = atomicAdd(&counters[0], lane == 0 ? 1u : 0u);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (dbg && lane == 0)
-            dbg[blockIdx.x * 8 + 0] = t + 1;
-        if (t >= tk.total)
-            break;
-        uint32_t k, b;
-        if (tk.uniform)
-        {
-            k = t / tk.uniform;
-            b = t - k * tk.uniform;
-        }
-        else
-        {
-            uint32_t lo = 0, hi = tk.rows; // last row whose base <= t
-            while (hi - lo > 1)
-            {
-                const uint32_t mid = lo + (hi - lo) / 2;
-                if (tk.row_base[mid] <= t)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            k = lo;
-            b = tk.order[t - tk.row_base[k]];
-        }
-        const PdBlock blk = blocks[b];
-        uint32_t* const flag = done + blk.unit_base + k;
-        // the link pass ran in an earlier launch: its tables are plain global data here
-        const PdState st = state[b];
-        uint32_t result = DEC_UNIT_OK;
-        const uint32_t f_pos = first[3 * b + 1], f_len = first[3 * b + 2];
-        if (k + 1u < st.nunits && (uint64_t)(k + 1u) * PD_UNIT <= f_len)
-        {
-            // The whole unit lies inside the literals of the block's first sequence (a block of incompressible data is one sequence):
-            // a plain copy, nothing to parse.  The sequence itself is checked by the unit in which it ends (never this one).
-            const uint8_t* from = src + blk.src_off + f_pos + (uint64_t)k * PD_UNIT;
-            uint8_t* to = dst + blk.dst_off + (uint64_t)k * PD_UNIT;
-            const uint32_t head = (uint32_t)((16u - ((uintptr_t)to & 15u)) & 15u); // bytes up to the first aligned vector
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)to, 0, (int)PD_UNIT, 0x00020000);
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            typedef u32x4 u32x4_a1 __attribute__((aligned(1)));
-            if ((uint32_t)lane < head)
-                __builtin_amdgcn_raw_buffer_store_b8(from[lane], rs, lane, 0, 16);
-            const uint32_t nvec = (PD_UNIT - head) >> 4;
-            for (uint32_t v0 = 0; v0 < nvec; v0 += 256u) // four loads in flight per lane
-            {
-                u32x4 q[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                {
-                    const uint32_t v = v0 + (uint32_t)(u * 64 + lane);
-                    q[u] = *reinterpret_cast<const u32x4_a1*>(from + head + 16u * (v < nvec ? v : 0u));
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                {
-                    const uint32_t v = v0 + (uint32_t)(u * 64 + lane);
-                    if (v < nvec)
-                        __builtin_amdgcn_raw_buffer_store_b128(q[u], rs, (int)(head + 16u * v), 0, 16);
-                }
-            }
-            const uint32_t done_b = head + (nvec << 4);
-            if ((uint32_t)lane < PD_UNIT - done_b)
-                __builtin_amdgcn_raw_buffer_store_b8(from[done_b + (uint32_t)lane], rs, (int)(done_b + (uint32_t)lane), 0, 16);
-        }
-        else if (k < st.nunits)
-        {
-            const uint32_t j = unit_tile[blk.unit_base + k];
-            PdUnit un;
-            un.lo = (int64_t)k * PD_UNIT;
-            un.hi = un.lo + PD_UNIT;
-            un.last = k + 1 == st.nunits;
-            un.ip0 = k == 0 ? 0 : (int64_t)tiles[blk.tile_base + j].entry;
-            un.op0 = k == 0 ? 0 : (int64_t)tile_op[blk.tile_base + j];
-            un.prev_done = k ? flag - 1 : nullptr;
-            un.defer = unit_mode != nullptr;
-            un.timeout = &counters[1];
-            un.dbg = dbg ? dbg + blockIdx.x * 8 : nullptr;
-            if (dbg && lane == 0)
-            {
-                dbg[blockIdx.x * 8 + 1] = k;
-                dbg[blockIdx.x * 8 + 2] = (uint32_t)un.ip0;
-                dbg[blockIdx.x * 8 + 3] = (uint32_t)un.op0;
-            }
-            result = lz4_decode_one<I, true>(src + blk.src_off, dst + blk.dst_off, (I)blk.size, (I)blk.dst_cap, dec_nobatch, s_in, s_ring, lane, un);
-            if (dbg && lane == 0)
-                dbg[blockIdx.x * 8 + 4] = 0xAAAA0000u + result;
-            if (lane == 0)
-            {
-                if (result == DEC_ERROR)
-                    atomicOr(&state[b].err, 1u);
-                else if (result == DEC_UNIT_END)
-                    atomicOr(&state[b].end_ok, 1u);
-                else if (result == DEC_UNIT_DEFER)
-                {
-                    unit_mode[blk.unit_base + k] = 1u; // a match reaches into the unit before: executed on origins (k_lz4_po_trace)
-                    atomicAdd(&counters[2], 1u);
-                }
-            }
-        }
-        // publish: every store of this wave has landed (they were write-through), then the flag
-        if (dbg && lane == 0)
-            dbg[blockIdx.x * 8 + 5] = 0xBBBBu;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
-            __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (dbg && lane == 0)
-            dbg[blockIdx.x * 8 + 6] = 0xCCCCu;
-    }
-}
+#ifdef LTHIP_ABLATIONS
+#include "ablations/k_lz4_pd_units.inc"
+#endif
 
 
 // ---------------------------------------------------------------------------------------------------
@@ -1981,8 +1750,9 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     uint32_t* d_done = (uint32_t*)(t8 + o_done);
     uint32_t* d_cnt = (uint32_t*)(t8 + o_cnt);
     uint32_t* d_first = (uint32_t*)(t8 + o_first);
-    static const bool stats = getenv("LTHIP_LZ4_PD_STATS") != nullptr;
-    static const bool trace = getenv("LTHIP_LZ4_PD_TRACE") != nullptr; // debugging: synchronize and report after every launch
+    LTHIP_ABLATION_ENV(env_stats, "LTHIP_LZ4_PD_STATS");
+    LTHIP_ABLATION_ENV(env_trace, "LTHIP_LZ4_PD_TRACE"); // debugging: synchronize and report after every launch
+    const bool stats = env_stats.get() >= 0, trace = env_trace.get() >= 0;
 #define PD_TRACE(what)                                                                 \
     do                                                                                 \
     {                                                                                  \
@@ -2014,11 +1784,8 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     tk.uniform = uniform ? nb : 0u;
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    static const uint32_t per_cu = [] {
-        const char* e = getenv("LTHIP_LZ4_PD_WG_PER_CU");
-        const int v = e ? atoi(e) : 0;
-        return (uint32_t)(v > 0 ? v : 16); // 10 KiB of LDS each
-    }();
+    LTHIP_ABLATION_ENV(env_per_cu, "LTHIP_LZ4_PD_WG_PER_CU");
+    const uint32_t per_cu = (uint32_t)(env_per_cu.get() > 0 ? env_per_cu.get() : 16); // 10 KiB of LDS each
     const uint64_t resident = (uint64_t)ncu * per_cu;
     const uint32_t grid = (uint32_t)(tk.total < resident ? tk.total : resident);
     volatile uint32_t* dbg = nullptr;
@@ -2030,33 +1797,41 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
         dbg = (volatile uint32_t*)hp; // host-visible progress words, freed below once the kernel is through
     }
     // LTHIP_LZ4_PD_WAIT=1: round 2's way -- a unit whose matches reach into the unit before WAITS for it (a chain of units)
-    static LthipEnvInt env_wait{"LTHIP_LZ4_PD_WAIT"};
+    LTHIP_ABLATION_ENV(env_wait, "LTHIP_LZ4_PD_WAIT");
     const bool wait_mode = env_wait.get() > 0;
     uint32_t* d_mode = wait_mode ? nullptr : (uint32_t*)(t8 + o_mode);
-    static LthipEnvInt env_px{"LTHIP_LZ4_PX"}; // 0: the unit decoder of round 2 (lz4_decode_one<UNIT> through an LDS ring)
+    LTHIP_ABLATION_ENV(env_px, "LTHIP_LZ4_PX"); // 0: the unit decoder of round 2 (lz4_decode_one<UNIT> through an LDS ring: ablations/k_lz4_pd_units.inc)
     const bool px = d_mode && env_px.get() != 0;
+#ifndef LTHIP_ABLATIONS
+    (void)d_done;
+    (void)grid;
+    (void)dbg;
+    (void)small;
+    (void)nobatch;
+#endif
     if (px)
         hipLaunchKernelGGL(k_lz4_po_trace<true>, dim3((uint32_t)nunits), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, nb, 0u,
                            (const PdTile*)d_tiles, (const uint32_t*)d_top, (const uint32_t*)d_ut, d_state, d_mode, (uint32_t*)nullptr,
                            (uint8_t*)d_dst, (const uint32_t*)d_first, d_cnt);
+#ifdef LTHIP_ABLATIONS
     else if (small)
         hipLaunchKernelGGL(k_lz4_pd_units<int32_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, (uint8_t*)d_dst, d_tiles,
                            d_top, d_ut, d_state, d_done, d_cnt, tk, nobatch, dbg, (const uint32_t*)d_first, d_mode);
     else
         hipLaunchKernelGGL(k_lz4_pd_units<int64_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, (uint8_t*)d_dst, d_tiles,
                            d_top, d_ut, d_state, d_done, d_cnt, tk, nobatch, dbg, (const uint32_t*)d_first, d_mode);
+#endif
     LTHIP_LAUNCH_CHECK(ctx);
     if (d_mode)
     {
         // units that were given up (a payload with a sliding window): on origins, as many blocks at a time as the arena's budget
-        // allows (4 bytes per byte of output; LTHIP_LZ4_ORG_MIB, default: lthip_origin_budget_mib).  The one place where this call waits for the device.
+        // allows (4 bytes per byte of output; LTHIP_ORIGIN_MIB, default: lthip_origin_budget_mib).  The one place where this call waits for the device.
         uint32_t given_up = 0;
         LTHIP_CHECK(ctx, hipMemcpyAsync(&given_up, d_cnt + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
         LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (given_up)
         {
-            static LthipEnvInt env_org{"LTHIP_LZ4_ORG_MIB"};
-            const uint64_t budget_units = (lthip_origin_budget_mib(env_org.get()) << 20) / ((uint64_t)PD_UNIT * 4u);
+            const uint64_t budget_units = (lthip_origin_budget_mib() << 20) / ((uint64_t)PD_UNIT * 4u);
             uint64_t most = 0;
             for (uint32_t g0 = 0; g0 < nb;)
             {
@@ -2131,9 +1906,11 @@ extern "C" int lthip_lz4_decompress_blocks(lthip_ctx* ctx, const void* d_src, ui
     if (block_count == 0)
         return 0;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
-    static const bool plain = getenv("LTHIP_LZ4_PLAIN_DECODER") != nullptr;   // ablation: every byte through global memory
-    static const bool serial_only = getenv("LTHIP_LZ4_SERIAL_DECODER") != nullptr; // ablation: one wave per block for every block
-    const uint32_t nobatch = getenv("LTHIP_LZ4_NO_BATCH_DECODE") ? 1u : 0u;   // ablation: one sequence per step only
+    LTHIP_ABLATION_ENV(env_plain, "LTHIP_LZ4_PLAIN_DECODER");     // every byte through global memory (ablations/k_lz4_decode_plain.inc)
+    LTHIP_ABLATION_ENV(env_serial, "LTHIP_LZ4_SERIAL_DECODER");   // one wave per block for every block
+    LTHIP_ABLATION_ENV(env_nobatch, "LTHIP_LZ4_NO_BATCH_DECODE"); // one sequence per step only
+    const bool plain = env_plain.get() >= 0, serial_only = env_serial.get() >= 0;
+    const uint32_t nobatch = env_nobatch.get() >= 0 ? 1u : 0u;
     // blocks of at least two units go to the block-parallel path, the rest to the wave-per-block decoder
     std::vector<uint32_t> par;
     std::vector<Lz4Block> hb;
@@ -2171,9 +1948,12 @@ extern "C" int lthip_lz4_decompress_blocks(lthip_ctx* ctx, const void* d_src, ui
     if ((err = lthip_stage_upload(ctx, p, hb.data(), sizeof(Lz4Block) * (size_t)ns, ctx->stream))) // no host stall
         return err;
     Lz4Block* d_blocks = (Lz4Block*)p;
+#ifdef LTHIP_ABLATIONS
     if (plain)
         hipLaunchKernelGGL(k_lz4_decode, dim3(ns), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, ns, (uint8_t*)d_dst, d_out_sizes);
-    else if (small)
+    else
+#endif
+    if (small)
         hipLaunchKernelGGL(k_lz4_decode_lds<int32_t>, dim3(ns), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, d_blocks, ns, (uint8_t*)d_dst,
                            d_out_sizes, nobatch);
     else

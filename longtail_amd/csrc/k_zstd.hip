@@ -355,8 +355,12 @@ __global__ __launch_bounds__(64, 4) void k_zstd_encode(const ZBlock* __restrict_
         if (threadIdx.x == 0)
             g_zb_last[blockIdx.x] = wall_clock64();
 #endif
+#ifdef LTHIP_ABLATIONS /* (one block per 128 KiB piece, round 2's frame layout: LTHIP_ZSTD_SUB=0) */
         const uint32_t n = sub_sizes ? zb_encode_piece_sub(&in, &sc, &sh, threadIdx.x, sub_sizes + (uint64_t)zb * ZB_MAX_UNITS)
                                      : zb_encode_block(&in, &sc, &sh, threadIdx.x);
+#else
+        const uint32_t n = zb_encode_piece_sub(&in, &sc, &sh, threadIdx.x, sub_sizes + (uint64_t)zb * ZB_MAX_UNITS);
+#endif
         if (threadIdx.x == 0)
             enc_size[zb] = n;
         __syncthreads();
@@ -480,11 +484,12 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
     const uint32_t nwg = (uint32_t)(nzb < (uint64_t)ncu * 16 ? nzb : (uint64_t)ncu * 16);
     void *d_blocks, *d_rle, *d_zdst, *d_enc, *d_encsz, *d_work, *d_sub, *d_trail;
     // sub-blocks (default): one zstd block per 4 KiB unit and a directory in the trailer; LTHIP_ZSTD_SUB=0: one block per 128 KiB piece
-    const bool sub = !(getenv("LTHIP_ZSTD_SUB") && atoi(getenv("LTHIP_ZSTD_SUB")) == 0);
+    LTHIP_ABLATION_ENV(env_sub, "LTHIP_ZSTD_SUB");
+    const bool sub = env_sub.get() != 0;
     // LTHIP_ZSTD_REP=1: block-local repeat-offset codes (sub-block layout only; the trailer says so: version 3).  Off by default -- on
     // every kind measured they are worth < 0.1 % of the compressed size (offsets rarely repeat inside a 4 KiB block:
     // profiles/r04_zstd_ratio_table*.txt) and cost the encoder 4 % and the lane decoder 5-9 %
-    static LthipEnvInt env_rep{"LTHIP_ZSTD_REP"};
+    LTHIP_ABLATION_ENV(env_rep, "LTHIP_ZSTD_REP");
     const bool rep = sub && env_rep.get() == 1;
     if ((err = lthip_scratch(ctx, S_LZ4_BLOCKS, sizeof(ZBlock) * (size_t)block_count, &d_blocks)))
         return err;
@@ -505,7 +510,7 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
         return err;
     if (nzb)
     {
-        static LthipEnvInt env_tickets{"LTHIP_ZSTD_TICKETS"};
+        LTHIP_ABLATION_ENV(env_tickets, "LTHIP_ZSTD_TICKETS");
 
         uint32_t* d_ticket = env_tickets.get() == 0 ? nullptr : (uint32_t*)d_encsz + nzb + 1; // (the size list has four spare words)
         if (d_ticket)
@@ -518,9 +523,10 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
         LTHIP_LAUNCH_CHECK(ctx);
     }
     LaunchTimer t(ctx, LTHIP_K_OTHER);
+    LTHIP_ABLATION_ENV(env_zdbg, "LTHIP_ZSTD_DBG");
     hipLaunchKernelGGL(k_zstd_scan, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
                        block_count, (const uint8_t*)d_rle, (const uint32_t*)d_encsz, (uint32_t*)d_zdst, d_out_sizes, (uint8_t*)d_dst,
-                       (uint32_t)(getenv("LTHIP_ZSTD_DBG") ? atoi(getenv("LTHIP_ZSTD_DBG")) : 0), // bit 1: no trailer
+                       env_zdbg.get() > 0 ? (uint32_t)env_zdbg.get() : 0u, // (ablation build) bit 1: no trailer
                        sub ? (rep ? 2u : 1u) : 0u, (uint32_t*)d_trail);
     hipLaunchKernelGGL(k_zstd_headers, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
                        block_count, (const uint32_t*)d_out_sizes, (uint8_t*)d_dst);
@@ -938,109 +944,9 @@ __global__ __launch_bounds__(64) void k_zstd_decode(const uint8_t* __restrict__ 
         __syncthreads();
     }
 }
-// ---------------------------------------------------------------------------------------------------
-// Two-stage decoding of pieces.  The serial piece decoder above spends 3/4 of its time in the sequence decoder: lane 0 of a wave
-// walks the FSE state machine with vector instructions and a dependent global load per sequence, and then the whole wave copies ONE
-// sequence through global memory.  Here:
-//   k_zstd_prepare  runs the decoder core up to the sequence loop (block header, literals -- Huffman streams on four lanes --, the
-//                   three FSE tables) and exports the literals and the tables of the piece to global memory, the tables with the
-//                   code's baseline and extra-bit count folded into every entry;
-//   k_zstd_execute  per piece: the state machine runs on the SCALAR unit (tables and bit-stream are read-only here, every load is
-//                   an s_load; 64 sequences at a time, each dropped into "its" lane with v_writelane), then the vector unit executes
-//                   the 64 sequences together: prefix sums place them, short literal runs and matches are copied by the
-//                   sequences' own lanes (dependency rounds as in the LZ4 batch decoder), long ones by the whole wave, all through
-//                   an 8 KiB LDS ring that leaves for global memory with aligned 16-byte stores.
-// Anything unusual (a check that fails, a table or literal form the export does not cover) marks the piece ZP_SERIAL: the serial
-// piece decoder then decodes it and reports errors exactly as it always did.
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_zstd_prepare(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, const ZItem* __restrict__ items,
-                                                     const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
-                                                     uint8_t* __restrict__ dst, uint8_t* __restrict__ lit_scratch, uint64_t* __restrict__ tables,
-                                                     ZPrep* __restrict__ prep, const uint32_t* __restrict__ out_sizes)
-{
-    __shared__ ZdShared sh;
-    const uint32_t nitems = *item_count < item1 ? *item_count : item1;
-    const int lane = threadIdx.x;
-    for (uint32_t i = item0 + blockIdx.x; i < nitems; i += gridDim.x)
-    {
-        const ZItem it = items[i];
-        if (it.kind != 2u || it.aux != 0u) // (aux != 0: one Raw / RLE block of a directory frame -- k_zstd_plain_pieces)
-            continue;
-        const ZBlock blk = blocks[it.payload];
-        const uint32_t slot = i - item0;
-        uint8_t* lits = lit_scratch + (uint64_t)slot * (ZD_LIT_MAX + 64u);
-        if (lane == 0)
-            sh.v[ZDV_PREP] = 1;
-#ifdef LTHIP_ZB_PROF
-        if (lane == 0)
-            g_zb_last[blockIdx.x] = wall_clock64();
+#ifdef LTHIP_ABLATIONS
+#include "ablations/k_zstd_prepare.inc"
 #endif
-        __syncthreads();
-        const uint32_t content = out_sizes[it.payload] == ZD_ERROR ? 0u : out_sizes[it.payload]; // k_zstd_split stated it
-        const uint32_t expect = content > it.out0 ? (content - it.out0 < ZB ? content - it.out0 : ZB) : 0u;
-        const uint32_t n = zd_decode_payload_ex(src + it.src_off, it.size, dst + blk.dst_off, blk.dst_cap, lits, &sh, lane, it.out0);
-#ifdef LTHIP_ZB_PROF
-        ZB_MARK(13); /* prepare: 11 = up to the block, 12 = literals, 13 = sequence header + tables, 14 = export */
-#endif
-        ZPrep pr;
-        pr.bits_off = 0;
-        pr.bits_size = pr.nbseq = pr.nlit = 0;
-        pr.log[0] = pr.log[1] = pr.log[2] = 0;
-        pr.expect = expect;
-        pr.status = ZP_SERIAL;
-        if (n == ZD_PREPARED)
-        {
-            pr.bits_off = it.src_off + sh.v[ZDV_OFF];
-            pr.bits_size = sh.v[ZDV_LEN];
-            pr.nbseq = sh.v[ZDV_LL];
-            pr.nlit = sh.v[ZDV_ML];
-            bool ok = expect != 0u && pr.bits_size != 0u;
-            uint64_t* tp = tables + (uint64_t)slot * 3u * ZT_ENTRIES;
-            for (int t = 0; t < 3; ++t)
-            {
-                const ZdFse* f = &sh.fse[t];
-                const uint32_t size = f->valid == 2u ? 1u : f->valid == 1u ? 1u << f->log : 0u;
-                ok = ok && size != 0u && size <= ZT_ENTRIES;
-                pr.log[t] = f->valid == 2u ? 0u : f->log;
-                for (uint32_t e = lane; e < size && size <= ZT_ENTRIES; e += 64)
-                {
-                    const uint32_t sym = f->sym[e];
-                    uint32_t baseline, ebits;
-                    if (t == ZT_LL)
-                    {
-                        baseline = zb_ll_base(sym & 63u);
-                        ebits = zb_ll_bits(sym & 63u);
-                        ok = ok && sym <= 35u;
-                    }
-                    else if (t == ZT_ML)
-                    {
-                        baseline = zb_ml_base(sym & 63u) + 3u;
-                        ebits = zb_ml_bits(sym & 63u);
-                        ok = ok && sym <= 52u;
-                    }
-                    else
-                    {
-                        baseline = 1u << (sym & 31u);
-                        ebits = sym & 31u;
-                        ok = ok && sym <= 31u;
-                    }
-                    tp[(uint32_t)t * ZT_ENTRIES + e] = (uint64_t)(((uint32_t)t * ZT_ENTRIES + f->base[e]) * 8u) | ((uint64_t)f->nb[e] << 16) | ((uint64_t)ebits << 24) |
-                                                       ((uint64_t)baseline << 32);
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull)
-                pr.status = ZP_READY;
-        }
-        else if (n != ZD_ERROR && n == expect && content != 0u)
-            pr.status = ZP_DONE; // a raw or RLE block, or one without sequences: the core has written it
-        if (lane == 0)
-            prep[i] = pr;
-#ifdef LTHIP_ZB_PROF
-        ZB_MARK(14);
-#endif
-        __syncthreads();
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // Pieces that are runs of SUB-BLOCKS (kind 3): k_zstd_sub_entropy + k_zstd_execute<true>.
@@ -3196,222 +3102,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 }
 
-// A payload of another encoder, its blocks one after the other (k_zstd_blk_entropy has decoded their streams): one wave per payload.
-// Raw and RLE blocks go through the ring like literals; a Compressed_Block's records are executed 64 at a time by zx_batch, after
-// their offset values have been turned into offsets IN ORDER (repeat offsets: RFC 8878 3.1.1.5, the history lives in three scalars).
-// Positions are relative to the frame's start, the ring and its flush state carry on from block to block; matches reach as far
-// back as the frame allows (sources that have left the ring are read from the output, as in the piece decoders).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_zstd_execute_payload(
-    const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, uint32_t pb0, uint32_t pb1, const uint32_t* __restrict__ f_nblocks,
-    uint8_t* __restrict__ dst, const uint8_t* __restrict__ lit_scratch, const uint64_t* __restrict__ rec_scratch,
-    const ZPrep* __restrict__ fprep, uint32_t* __restrict__ retry)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZX_RING];
-    __shared__ __attribute__((aligned(16))) uint8_t s_lit[ZX_LIT];
-    const uint32_t b = pb0 + blockIdx.x;
-    if (b >= pb1)
-        return;
-    const uint32_t nb = f_nblocks[b];
-    if (nb == 0u || retry[b])
-        return;
-    const int lane = threadIdx.x;
-    const ZBlock blk = blocks[b];
-    const ZFrameHdr fh = z_frame_header(src + blk.src_off, blk.size);
-    const uint32_t content = (uint32_t)fh.content;
-    uint8_t* out = dst + blk.dst_off;
-    ZxOut zx;
-    zx.s_ring = s_ring;
-    zx.s_lit = s_lit;
-    zx.g = (uint32_t)((uintptr_t)out & 15u);
-    zx.out_al = out - zx.g;
-    zx.lh = 0;
-    zx.lit_al = src;
-    zx.nlit = 0;
-    zx.cap = content;
-    zx.lane = lane;
-    zx.op = 0;
-    zx.flushed = zx.drained = 0;
-    zx.lwa = -(int32_t)ZX_LIT;
-    uint32_t why = 0;
-    bool bad = !fh.ok;
-    uint32_t produced = 0;
-#ifdef LTHIP_ZB_PROF
-    unsigned long long acc_rep = 0, acc_bat = 0; // 100 MHz ticks: records + repeat offsets / zx_batch
+#ifdef LTHIP_ABLATIONS
+#include "ablations/k_zstd_execute_payload.inc"
 #endif
-    uint32_t rep0 = 1, rep1 = 4, rep2 = 8; // Repeated_Offsets at the start of a frame
-    for (uint32_t k = 0; k < nb && !bad; ++k)
-    {
-        const uint32_t fi = blk.pad + k;
-        const ZPrep pr = fprep[fi];
-        if (pr.status == ZP_SERIAL || pr.expect > content - produced || pr.expect > ZB)
-        {
-            { bad = true; why = __LINE__; }
-            break;
-        }
-        if (pr.log[0] == 2u)
-        {
-            // RLE_Block
-            const uint8_t v = src[pr.bits_off];
-            uint32_t left = pr.expect;
-            while (left)
-            {
-                const uint32_t c = left < ZX_FLUSH ? left : ZX_FLUSH;
-                for (uint32_t j = lane; j < c; j += 64)
-                    s_ring[zx.ring(zx.op + j)] = v;
-                zx.op += c;
-                left -= c;
-                zx.maybe_flush();
-            }
-            produced += pr.expect;
-            continue;
-        }
-        // the block's literal source: its literal buffer, or (Raw_Block) the block's own bytes
-        const uint8_t* lits = pr.log[0] == 1u ? src + pr.bits_off : lit_scratch + pr.bits_off;
-        zx.lh = (uint32_t)((uintptr_t)lits & 15u);
-        zx.lit_al = lits - zx.lh;
-        zx.nlit = pr.log[0] == 1u ? pr.expect : pr.nlit;
-        zx.lwa = -(int32_t)ZX_LIT - 64; // (nothing of the window is valid for this source)
-        if (pr.log[0] == 1u)
-        {
-            // Raw_Block: from the payload into the ring, 16 bytes per lane and trip, never reading past the block
-            typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
-            typedef uint32_t u32_a1 __attribute__((aligned(1)));
-            const uint8_t* from = src + pr.bits_off;
-            uint32_t left = pr.expect;
-            while (left)
-            {
-                const uint32_t c = left < ZX_FLUSH ? left : ZX_FLUSH;
-                for (uint32_t j = 16u * (uint32_t)lane; j < c; j += 1024u)
-                {
-                    const uint32_t r0 = zx.ring(zx.op + j);
-                    if (j + 16u <= c && r0 <= ZX_RING - 16u)
-                    {
-                        const u32x4_a1 v = *reinterpret_cast<const u32x4_a1*>(from + j);
-                        *reinterpret_cast<u32_a1*>(s_ring + r0) = v.x;
-                        *reinterpret_cast<u32_a1*>(s_ring + r0 + 4u) = v.y;
-                        *reinterpret_cast<u32_a1*>(s_ring + r0 + 8u) = v.z;
-                        *reinterpret_cast<u32_a1*>(s_ring + r0 + 12u) = v.w;
-                    }
-                    else
-                        for (uint32_t q = 0; q < 16u && j + q < c; ++q)
-                            s_ring[zx.ring(zx.op + j + q)] = from[j + q];
-                }
-                from += c;
-                zx.op += c;
-                left -= c;
-                zx.maybe_flush();
-            }
-            produced += pr.expect;
-            continue;
-        }
-        const uint64_t* recs = rec_scratch + pr.rec_at;
-        const uint32_t block_start = produced;
-        uint32_t litpos = 0;
-        uint64_t r_next = (uint32_t)lane < pr.nbseq ? recs[lane] : 0ull; // (a lone wave: the next batch's records are loaded a batch ahead)
-#ifdef LTHIP_ZB_PROF
-        unsigned long long t0 = wall_clock64();
-#endif
-        for (uint32_t s0 = 0; s0 < pr.nbseq && !bad; s0 += 64u)
-        {
-            const uint32_t cnt = pr.nbseq - s0 < 64u ? pr.nbseq - s0 : 64u;
-            const uint64_t r = r_next;
-            r_next = s0 + 64u + (uint32_t)lane < pr.nbseq ? recs[s0 + 64u + (uint32_t)lane] : 0ull;
-            const uint32_t r_ll = (uint32_t)r & 0xFFFFFu, r_ml = (uint32_t)(r >> 20) & 0xFFFFFu;
-            uint32_t r_off = (uint32_t)(r >> 40); // Offset_Value: 1..3 = repeat offsets
-            const uint64_t repm = __builtin_amdgcn_ballot_w64((uint32_t)lane < cnt && r_off <= 3u);
-            if (repm == 0ull)
-            {
-                // no repeat offset in the batch: the history is simply its last three offsets
-                const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)r_off, (int)(cnt - 1u)) - 3u;
-                if (cnt >= 3u)
-                {
-                    rep2 = (uint32_t)__builtin_amdgcn_readlane((int)r_off, (int)(cnt - 3u)) - 3u;
-                    rep1 = (uint32_t)__builtin_amdgcn_readlane((int)r_off, (int)(cnt - 2u)) - 3u;
-                }
-                else if (cnt == 2u)
-                {
-                    rep2 = rep0;
-                    rep1 = (uint32_t)__builtin_amdgcn_readlane((int)r_off, 0) - 3u;
-                }
-                else
-                {
-                    rep2 = rep1;
-                    rep1 = rep0;
-                }
-                rep0 = o1;
-            }
-            else
-            {
-                for (uint32_t q = 0; q < cnt; ++q)
-                {
-                    const uint32_t ov = (uint32_t)__builtin_amdgcn_readlane((int)r_off, (int)q);
-                    uint32_t o;
-                    if (ov > 3u)
-                    {
-                        o = ov - 3u;
-                        rep2 = rep1;
-                        rep1 = rep0;
-                        rep0 = o;
-                    }
-                    else
-                    {
-                        const uint32_t idx = ov + ((uint32_t)__builtin_amdgcn_readlane((int)r_ll, (int)q) == 0u ? 1u : 0u); // 1..4
-                        if (idx == 1u)
-                            o = rep0;
-                        else
-                        {
-                            o = idx == 4u ? rep0 - 1u : idx == 2u ? rep1 : rep2;
-                            if (idx >= 3u)
-                                rep2 = rep1;
-                            rep1 = rep0;
-                            rep0 = o;
-                        }
-                        if ((uint32_t)lane == q)
-                            r_off = o + 3u; // (0 becomes 3: zx_batch rejects it like the serial decoder does)
-                    }
-                }
-                rep0 = zx_u(rep0);
-                rep1 = zx_u(rep1);
-                rep2 = zx_u(rep2);
-            }
-#ifdef LTHIP_ZB_PROF
-            const unsigned long long t1 = wall_clock64();
-#endif
-            zx_batch(zx, s_ring, s_lit, lane, cnt, r_ll, r_ml, r_off, litpos, produced, pr.nlit, content, bad);
-#ifdef LTHIP_ZB_PROF
-            const unsigned long long t2 = wall_clock64();
-            acc_rep += t1 - t0;
-            acc_bat += t2 - t1;
-            t0 = t2;
-#endif
-        }
-        if (!bad)
-        {
-            // the block's last literals; it must have regenerated what k_zstd_blk_entropy counted
-            const uint32_t rest = pr.nlit - litpos;
-            if (produced - block_start + rest != pr.expect)
-                { bad = true; why = __LINE__; }
-            else
-            {
-                zx.copy_lits(litpos, rest);
-                produced += rest;
-            }
-        }
-    }
-    if (!bad && produced != content)
-        { bad = true; why = __LINE__; }
-    if (!bad)
-        zx.flush(zx.op + zx.g);
-    if (bad && lane == 0)
-        retry[b] = why ? why : 1u; // the serial decoder gives the verdict (and the bytes); the value says where it was sent from
-#ifdef LTHIP_ZB_PROF
-    if (lane == 0)
-    {
-        atomicAdd(&g_zb_prof[24], acc_rep);
-        atomicAdd(&g_zb_prof[25], acc_bat);
-    }
-#endif
-}
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -3801,7 +3494,10 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
     // 8 single-wave workgroups per CU (12 would be resident at 143 VGPRs, measured slower: 190 vs 160 ms for 512 blocks)
     uint32_t nwg = nitems < (uint64_t)ncu * 8u ? (uint32_t)nitems : (uint32_t)ncu * 8u;
-    static LthipEnvInt env_nwg{"LTHIP_ZSTD_NWG"}, env_dbg{"LTHIP_ZSTD_DBG"}, env_ablate{"LTHIP_ZSTD_ABLATE"}, env_zpx{"LTHIP_ZSTD_PX"};
+    LTHIP_ABLATION_ENV(env_nwg, "LTHIP_ZSTD_NWG");
+    LTHIP_ABLATION_ENV(env_dbg, "LTHIP_ZSTD_DBG");
+    LTHIP_ABLATION_ENV(env_ablate, "LTHIP_ZSTD_ABLATE");
+    LTHIP_ABLATION_ENV(env_zpx, "LTHIP_ZSTD_PX");
     // the sub-block pieces' sequences: 1 (default) = the kernel chooses per piece between the LDS ring (zx_batch) and bytes through memory
     // (zo_batch_bytes), 0 = always the ring (round 2), 2 = always through memory
     const uint32_t zpx = env_zpx.get() < 0 ? 1u : (uint32_t)env_zpx.get();
@@ -3851,7 +3547,9 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
                        (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes, (const ZPrep*)nullptr);
     LTHIP_LAUNCH_CHECK(ctx);
     // pieces, in rounds of ZROUND whose literals and tables / sequence records live in scratch:
-    //   one block per piece (kind 2):        k_zstd_prepare + k_zstd_execute<false>; what they leave (ZP_SERIAL) goes to the serial piece decoder
+    //   one block per piece (kind 2):        the serial piece decoder (k_zstd_decode<true>).  Only the ablation build's encoder writes such
+    //                                        frames (LTHIP_ZSTD_SUB=0); that build decodes them in two stages, k_zstd_prepare +
+    //                                        k_zstd_execute<false>, and what they leave (ZP_SERIAL) goes to the serial piece decoder
     //   a run of sub-blocks per piece (3):   k_zstd_sub_entropy + k_zstd_execute<true>; what they leave goes, payload-wise, to the serial decoder
     // LTHIP_ZSTD_DBG & 4: the serial piece decoder for every one-block piece.
     ZPrep* d_prep = nullptr;
@@ -3876,6 +3574,7 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
             hipLaunchKernelGGL(k_zstd_plain_pieces, dim3(n), dim3(256), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                                (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, d_prep);
             LTHIP_LAUNCH_CHECK(ctx);
+#ifdef LTHIP_ABLATIONS
             if (!(dbg & 4u))
             {
                 hipLaunchKernelGGL(k_zstd_prepare, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
@@ -3887,6 +3586,9 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
                                    (const uint64_t*)d_tabs, (const ZPrep*)d_prep, &d_prep->status, d_retry, 0u);
                 LTHIP_LAUNCH_CHECK(ctx);
             }
+#else
+            (void)d_tabs;
+#endif
             hipLaunchKernelGGL(k_zstd_sub_entropy, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                                (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_plits, (uint64_t*)d_recs, d_prep,
                                (const uint32_t*)d_out_sizes, d_retry, d_tickets + (size_t)(i0 / per_round));
@@ -3920,7 +3622,7 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
             const uint32_t n = (uint32_t)f_blocks;
             // few blocks: their sequences on the block's own wave; VERY few (a wave or two per CU: one to eight frames of 8 MiB): on the
             // scalar unit of a wave of their own, which walks a block's chain of sequences twice as fast as a lane (LTHIP_ZSTD_SEQ_SCALAR=0: off)
-            static LthipEnvInt env_scal{"LTHIP_ZSTD_SEQ_SCALAR"};
+            LTHIP_ABLATION_ENV(env_scal, "LTHIP_ZSTD_SEQ_SCALAR");
             int ncu = 256;
             (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
             const bool scalar_seqs = env_scal.get() != 0 && (n <= 2u * (uint32_t)ncu || env_scal.get() == 2); // (2: always -- tests)
@@ -3939,6 +3641,7 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
             hipLaunchKernelGGL(k_zstd_blk_sequences, dim3((n + 63u) / 64u), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZItem*)d_fitems,
                                (const uint32_t*)d_slist, (const uint32_t*)d_scount, (const uint64_t*)d_ftabs, (uint64_t*)d_frecs, d_fprep, d_retry);
             LTHIP_LAUNCH_CHECK(ctx);
+#ifdef LTHIP_ABLATIONS
             if (dbg & 16u) // (round 2's way: a payload's blocks one after the other on ONE wave)
             {
                 hipLaunchKernelGGL(k_zstd_execute_payload, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks, 0u,
@@ -3947,15 +3650,14 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
                 LTHIP_LAUNCH_CHECK(ctx);
             }
             else
+#endif
             {
                 // execution on origins, all blocks at once; the origins (4 bytes per byte of output) of as many payloads at a time as
-                // the arena's budget allows (LTHIP_ZSTD_ORG_MIB, default: lthip_origin_budget_mib)
+                // the arena's budget allows (LTHIP_ORIGIN_MIB, default: lthip_origin_budget_mib)
                 void *d_fr, *d_org;
                 if ((err = lthip_scratch(ctx, S_Z_FR, sizeof(ZFr) * nfslots, &d_fr)))
                     return err;
-                static LthipEnvInt env_org{"LTHIP_ZSTD_ORG_MIB"};
-                const int org_mib = env_org.get();
-                const uint64_t budget_items = (lthip_origin_budget_mib(org_mib) << 20) / ((uint64_t)ZB * 4u);
+                const uint64_t budget_items = (lthip_origin_budget_mib() << 20) / ((uint64_t)ZB * 4u);
                 uint64_t most = 0;
                 for (uint32_t p0 = 0; p0 < block_count;)
                 {
@@ -3995,7 +3697,11 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     }
     hipLaunchKernelGGL(k_zstd_decode<true>, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                        (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes,
+#ifdef LTHIP_ABLATIONS
                        (dbg & 4u) ? (const ZPrep*)nullptr : (const ZPrep*)d_prep);
+#else
+                       (const ZPrep*)nullptr);
+#endif
     hipLaunchKernelGGL(k_zstd_decode_retry, dim3(block_count < nwg ? block_count : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src,
                        (const ZBlock*)d_blocks, block_count, (const uint32_t*)d_retry, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes);
     LTHIP_LAUNCH_CHECK(ctx);

@@ -76,7 +76,7 @@ extern "C" int lthip_ctx_create(int device, void* hip_stream, lthip_ctx** out_ct
     ctx->z_last_retry = nullptr;
     ctx->z_last_payloads = 0;
     ctx->z_last_foreign_blocks = 0;
-    ctx->k5_lds_enabled = false;
+    memset(ctx->k5_lds_enabled, 0, sizeof ctx->k5_lds_enabled);
     memset(ctx->scratch_cap, 0, sizeof ctx->scratch_cap);
     memset(ctx->total_ms, 0, sizeof ctx->total_ms);
     memset(ctx->launches, 0, sizeof ctx->launches);
@@ -257,7 +257,7 @@ int lthip_stage_upload(lthip_ctx* ctx, void* d_dst, const void* h_src, size_t by
     if (bytes == 0)
         return 0;
     const bool small = bytes <= LTHIP_STAGE_SMALL;
-    static LthipEnvInt env_slots{"LTHIP_STAGE_SLOTS"}; // (experiment: 8 = the ring of rounds 1-2)
+    LTHIP_ABLATION_ENV(env_slots, "LTHIP_STAGE_SLOTS"); // (experiment: 8 = the ring of rounds 1-2)
     const size_t nsmall = env_slots.get() > 0 && env_slots.get() < 64 ? (size_t)env_slots.get() : sizeof(ctx->stage_small) / sizeof(ctx->stage_small[0]);
     lthip_ctx::Stage& st = small ? ctx->stage_small[ctx->stage_small_next++ % nsmall]
                                  : ctx->stage[ctx->stage_next++ % (sizeof(ctx->stage) / sizeof(ctx->stage[0]))];

@@ -124,7 +124,7 @@ struct lthip_ctx
     size_t stage_small_next;
     size_t stage_next;
     bool k1_lds_enabled; // hipFuncAttributeMaxDynamicSharedMemorySize set for K1 on this context's device
-    bool k5_lds_enabled; // ... and for the lane-parser flavours of K5
+    bool k5_lds_enabled[2][2]; // ... and for k_lz4_segments<.., FMT, CLS> with units above 4 KiB
     bool k5h_lds_enabled[2]; // ... and for k_lz4_lanes2<FMT>
     void* scratch[S_COUNT];
     size_t scratch_cap[S_COUNT];
@@ -162,13 +162,28 @@ struct LthipEnvInt
         return value.load(std::memory_order_relaxed);
     }
 };
+// The PRODUCT library reads ten environment variables, all documented in README.md ("Environment"): LONGTAIL_HIP_DEVICE / _BATCH /
+// _CODEC_BATCH / _LARGE_WINDOWS / _SMALL_WINDOWS (plugin layer), LTHIP_BATCH_BYTES, LTHIP_ORIGIN_MIB, LTHIP_COMM_TRANSPORT /
+// _TIMEOUT_S / _SHM_SLOT.  Every other LTHIP_* switch selects an earlier formulation of a kernel, a debug path or an experiment's
+// parameter; those exist in the ABLATION build only (`make ablations`: -DLTHIP_ABLATIONS, build/ablations/liblongtail_hip.so, loaded
+// by the differential tests and the A/B tools through LTHIP_LIB_PATH).  In the product build such a switch is a constant "not set",
+// so the branches it guards fold away, and the kernels they launch are not compiled (#ifdef LTHIP_ABLATIONS around them).
+#ifdef LTHIP_ABLATIONS
+#define LTHIP_ABLATION_ENV(var, name) static LthipEnvInt var{name}
+#else
+struct LthipEnvOff
+{
+    constexpr int get() const { return -1; }
+};
+#define LTHIP_ABLATION_ENV(var, name) constexpr LthipEnvOff var{}
+#endif
 int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out);
 // A second in-order queue of the context for work that should overlap the main stream (callers order the two with
 // events from lthip_sync_event and must make the main stream wait for the side stream before they return).
 int lthip_second_stream(lthip_ctx* ctx, hipStream_t* out);
 hipEvent_t lthip_sync_event(lthip_ctx* ctx);
 uint64_t lthip_codec_batch_bytes(); // input bytes per internal codec batch (LTHIP_BATCH_BYTES, default 8 GiB)
-uint64_t lthip_origin_budget_mib(int explicit_mib); // arena of the restore paths' execution on origins (k_lz4.hip)
+uint64_t lthip_origin_budget_mib(); // (LTHIP_ORIGIN_MIB) arena of the restore paths' execution on origins (k_lz4.hip)
 // Host table -> device without stalling the caller: the bytes are copied into one of a ring of pinned staging buffers and
 // queued on `stream`; `h_src` may be freed on return, and the host does not wait for earlier work of the stream (a
 // pageable hipMemcpyAsync + hipStreamSynchronize would wait for every kernel queued before it).

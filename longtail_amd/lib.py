@@ -106,6 +106,7 @@ class HipLib:
         sig("lthip_free_pinned", None, [vp, vp])
         sig("lthip_copy_h2d", i32, [vp, vp, vp, sz])
         sig("lthip_copy_d2h", i32, [vp, vp, vp, sz])
+        sig("lthip_link_copy", i32, [vp, vp, vp, sz])
         sig("lthip_timing_enable", i32, [vp, i32])
         sig("lthip_timing_reset", i32, [vp])
         sig("lthip_timing_get", i32, [vp, i32, P(C.c_double), P(u64)])
@@ -178,6 +179,25 @@ class HipLib:
 
 
 _lib: Optional[HipLib] = None
+
+
+ABLATIONS_LIB_PATH = Path(__file__).resolve().parent.parent / "build" / "ablations" / "liblongtail_hip.so"
+_abl = None
+
+
+def load_ablations() -> HipLib:
+    """The ABLATION build of the same sources (`make ablations`: -DLTHIP_ABLATIONS): earlier formulations of the kernels and debug
+    paths behind LTHIP_* switches, kept as second implementations for the differential tests and the A/B tools.  The product
+    library has none of them.  A separate handle: load() keeps returning the product library."""
+    global _abl
+    if _abl is None:
+        if os.environ.get("LTHIP_LIB_PATH"):
+            _abl = load()  # (the whole process runs on the library named there)
+        else:
+            if not ABLATIONS_LIB_PATH.exists():
+                raise FileNotFoundError(f"{ABLATIONS_LIB_PATH} is missing: run `make ablations` (or __graft_entry__.build())")
+            _abl = HipLib(ABLATIONS_LIB_PATH)
+    return _abl
 
 
 def load(path: Optional[os.PathLike] = None) -> HipLib:
@@ -408,6 +428,10 @@ class Context:
         return out[: size.value].tobytes()
 
     # -- block assembly --
+    def link_copy(self, dst, src, nbytes: int):
+        """dst[:nbytes] = src[:nbytes] by the compute units (pinned host <-> device, either direction; include/longtail_hip.h)."""
+        self._check(self.lib.dll.lthip_link_copy(self.h, _ptr(dst), _ptr(src), nbytes), "lthip_link_copy")
+
     def gather_ranges(self, src, src_offsets, lens, dst, dst_offsets):
         n = int(src_offsets.numel())
         self._check(self.lib.dll.lthip_gather_ranges(self.h, _ptr(src), n, _ptr(src_offsets), _ptr(lens), _ptr(dst),

@@ -70,12 +70,28 @@ def gpu(hiplib):
     ctx.close()
 
 
+@pytest.fixture(scope="session")
+def gpu_abl(hiplib):
+    """A Context of the ABLATION build (build/ablations/liblongtail_hip.so, `make ablations`): the differential tests that switch to an
+    earlier formulation of a kernel or a debug path (LTHIP_* variables the product library does not read) run on it."""
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from longtail_amd.lib import Context, load_ablations
+
+    ctx = Context(0, lib=load_ablations())
+    yield ctx
+    ctx.close()
+
+
 @pytest.fixture(autouse=True)
 def _library_rereads_its_switches(request):
     """The library caches its environment switches per process; a test that sets one (monkeypatch) must not leak the cached value
     into the next test: read them again after every GPU test."""
     yield
     if request.node.get_closest_marker("gpu") is not None:
-        from longtail_amd.lib import load
+        import longtail_amd.lib as L
 
-        load().dll.lthip_debug_reload_env()
+        L.load().dll.lthip_debug_reload_env()
+        if L._abl is not None:  # (loaded by a test of this session)
+            L._abl.dll.lthip_debug_reload_env()

@@ -123,7 +123,7 @@ def zmode(request, oracle, monkeypatch):
     block per piece (LTHIP_ZSTD_SUB=0); the host model follows."""
     import ctypes as C
 
-    from longtail_amd.lib import load
+    from longtail_amd.lib import load_ablations
 
     oracle.dll.ltz_model_sub_blocks.argtypes = [C.c_int]
     oracle.dll.ltz_model_sub_blocks.restype = None
@@ -131,14 +131,23 @@ def zmode(request, oracle, monkeypatch):
     oracle.dll.ltz_model_flags.restype = None
     monkeypatch.setenv("LTHIP_ZSTD_SUB", "1" if request.param else "0")
     monkeypatch.setenv("LTHIP_ZSTD_REP", "1" if request.param == 2 else "0")
-    load().dll.lthip_debug_reload_env()
+    if request.param != 1:  # (the two other layouts exist in the ablation build only: zgpu below)
+        load_ablations().dll.lthip_debug_reload_env()
     oracle.dll.ltz_model_sub_blocks(1 if request.param else 0)
     oracle.dll.ltz_model_flags(1 if request.param == 2 else 0)
     yield request.param
     oracle.dll.ltz_model_sub_blocks(0)
     oracle.dll.ltz_model_flags(0)
     monkeypatch.delenv("LTHIP_ZSTD_REP")
-    load().dll.lthip_debug_reload_env()
+    monkeypatch.delenv("LTHIP_ZSTD_SUB")
+    if request.param != 1:
+        load_ablations().dll.lthip_debug_reload_env()
+
+
+@pytest.fixture
+def zgpu(request, zmode):
+    """The context a zmode test encodes with: the PRODUCT library for the default layout, the ablation build for the two others."""
+    return request.getfixturevalue("gpu" if zmode == 1 else "gpu_abl")
 
 
 def gpu_zstd(gpu, blocks, quality=0):
@@ -200,7 +209,8 @@ def zstd_pieces(frame: np.ndarray):
     return [(typ, frame[p0 + 3 : p0 + n]) for typ, p0, n in blocks]
 
 
-def test_zstd_frames_decode_with_reference(gpu, oracle, ref, zmode):
+def test_zstd_frames_decode_with_reference(zgpu, oracle, ref, zmode):
+    gpu = zgpu
     blocks = [oracle.synth(n, 40 + n, k) for k in (0, 1, 2, 11, 12, 13) for n in (0, 1, 100, 5000, 131071, 131072, 131073, 400000)]
     blocks.append(oracle.synth((8 << 20) + 12345, 7, 1))
     rng = np.random.default_rng(3)
@@ -216,7 +226,8 @@ def test_zstd_frames_decode_with_reference(gpu, oracle, ref, zmode):
     assert z and len(frames[z[0]]) < 100 + (12 + 2 * 98 if zmode else 0)  # (+ the directory: one u16 per 4 KiB unit)
 
 
-def test_zstd_compresses(gpu, oracle, zmode):
+def test_zstd_compresses(zgpu, oracle, zmode):
+    gpu = zgpu
     """Compressed_Blocks are really produced, and beat the LZ4 payload of the same parse on entropy-codable data."""
     blocks = [oracle.synth(2 << 20, 3, k) for k in (1, 11, 12, 13)]
     frames = gpu_zstd(gpu, blocks)
@@ -261,7 +272,8 @@ def _check_against_model(gpu, d, blocks, frames):
     return checked
 
 
-def test_zstd_entropy_stage_is_bit_exact_with_host_model(gpu, oracle, zmode):
+def test_zstd_entropy_stage_is_bit_exact_with_host_model(zgpu, oracle, zmode):
+    gpu = zgpu
     """k_zstd_encode and oracle/zstd_model.c compile the SAME zstd_block_core.h (64 lanes vs 1): fed with the GPU match
     finder's own output, the host model must reproduce every Compressed_Block byte for byte."""
     d = _model_src(oracle)
@@ -272,7 +284,8 @@ def test_zstd_entropy_stage_is_bit_exact_with_host_model(gpu, oracle, zmode):
     assert _check_against_model(gpu, d, blocks, frames) >= 10
 
 
-def test_zstd_table_builders_all_lanes_equal_the_serial_ones(gpu, oracle, ref, zmode):
+def test_zstd_table_builders_all_lanes_equal_the_serial_ones(zgpu, oracle, ref, zmode):
+    gpu = zgpu
     """The kernel builds the Huffman code and the three FSE tables with all lanes (zb_huffman_build_par, zb_normalize_par,
     zb_build_enc_table_par), the one-lane host model with the serial builders: literal and sequence statistics that reach the
     builders' corners -- two literal symbols, all 256 equally often, geometric counts (depths far above 11: the length limit and
@@ -311,7 +324,8 @@ def test_zstd_table_builders_all_lanes_equal_the_serial_ones(gpu, oracle, ref, z
     assert len(frames[0]) < n // 2 and len(frames[4]) < n // 20  # (two symbols; one symbol with rare others)
 
 
-def test_zstd_unaligned_sources_and_literals_read_from_the_source(gpu, oracle, ref, zmode):
+def test_zstd_unaligned_sources_and_literals_read_from_the_source(zgpu, oracle, ref, zmode):
+    gpu = zgpu
     """Units without a sequence keep their literals in the source (no copy by the match finder), wherever the block lies:
     blocks at odd device offsets, with entropy-codable literals but no matches (Huffman from the source), noise (sampled
     early-out -> Raw, bytes placed by the match finder), and a mix, must equal the host model and decode with the reference."""
@@ -354,7 +368,8 @@ def gpu_zstd_decode(gpu, frames, caps):
     return [None if int(s) == 0xFFFFFFFF else host[o : o + int(s)].copy() for o, s in zip(d_offs, sizes)]
 
 
-def test_zstd_decoder_reads_reference_and_own_frames(gpu, oracle, ref, zmode):
+def test_zstd_decoder_reads_reference_and_own_frames(zgpu, oracle, ref, zmode):
+    gpu = zgpu
     """The HIP zstd decoder against frames from the REFERENCE encoder (all five longtail settings: levels 3, 3, 22, 8, 22)
     and from the HIP encoder: decoded bytes identical to the original."""
     rng = np.random.default_rng(8)
@@ -379,7 +394,8 @@ def test_zstd_decoder_reads_reference_and_own_frames(gpu, oracle, ref, zmode):
         assert o is not None and len(o) == len(r) and (o == r).all()
 
 
-def test_zstd_decoder_agrees_with_host_model_and_reference_on_damaged_frames(gpu, oracle, ref, zmode):
+def test_zstd_decoder_agrees_with_host_model_and_reference_on_damaged_frames(zgpu, oracle, ref, zmode):
+    gpu = zgpu
     """Same source on host and device (zstd_decode_core.h): identical verdict and bytes on mutated frames; whatever the
     decoder accepts the reference accepts with the same bytes (it is stricter than the reference's fast Huffman path,
     which does not check that a literal stream is consumed exactly, so the converse is not required)."""
@@ -422,7 +438,8 @@ def test_zstd_decoder_agrees_with_host_model_and_reference_on_damaged_frames(gpu
 MARKER = bytes([0x5D, 0x2A, 0x4D, 0x18, 4, 0, 0, 0]) + b"LTP\x01"  # k_zstd.hip z_write_trailer
 
 
-def test_zstd_piece_decoder_is_the_serial_decoder_on_own_frames_and_strict_on_false_promises(gpu, oracle, ref, monkeypatch):
+def test_zstd_piece_decoder_is_the_serial_decoder_on_own_frames_and_strict_on_false_promises(gpu_abl, oracle, ref, monkeypatch):
+    gpu = gpu_abl  # (the switches this test sets exist in the ablation build only)
     """Frames of two or more pieces end with the independence marker and are decoded piece by piece on separate waves.
     (1) same bytes as the serial decoder (LTHIP_ZSTD_DBG=1) and as the reference on the encoder's own frames, also damaged ones:
         the piece decoder never ACCEPTS what the serial one rejects, and what it accepts is identical;
@@ -472,7 +489,8 @@ def test_zstd_piece_decoder_is_the_serial_decoder_on_own_frames_and_strict_on_fa
         assert o is None or (len(o) == len(r) and (o == r).all())
 
 
-def test_zstd_sub_block_decoder_is_the_serial_decoder_and_strict(gpu, oracle, ref, monkeypatch):
+def test_zstd_sub_block_decoder_is_the_serial_decoder_and_strict(gpu_abl, oracle, ref, monkeypatch):
+    gpu = gpu_abl  # (the switches this test sets exist in the ablation build only)
     """Frames in the sub-block layout (one zstd block per 4 KiB unit, directory in the trailer) are decoded with one lane per block
     (k_zstd_sub_entropy + k_zstd_execute<true>).
     (1) the encoder's own frames: same bytes as the serial decoder (LTHIP_ZSTD_DBG=1) and the reference;
@@ -552,7 +570,8 @@ def test_zstd_sub_block_decoder_is_the_serial_decoder_and_strict(gpu, oracle, re
         assert o is not None and len(o) == len(r) and (o == r).all()
 
 
-def test_zstd_reference_frames_block_parallel_is_the_serial_decoder(gpu, oracle, ref, monkeypatch):
+def test_zstd_reference_frames_block_parallel_is_the_serial_decoder(gpu_abl, oracle, ref, monkeypatch):
+    gpu = gpu_abl  # (the switches this test sets exist in the ablation build only)
     """Frames of the REFERENCE encoder (blocks that depend on each other: window = the frame, repeat offsets, repeated tables,
     treeless literals) are decoded block-parallel: every block's streams on a wave / lane of its own (k_zstd_blk_entropy,
     k_zstd_blk_sequences), then a payload's blocks in order on one wave (k_zstd_execute_payload); whatever that path declines goes to
@@ -778,7 +797,8 @@ def test_lz4_block_parallel_decoder_differential_fuzz(gpu, oracle):
 
 
 @pytest.mark.gpu
-def test_origin_execution_is_the_chained_execution(gpu, oracle, ref, monkeypatch):
+def test_origin_execution_is_the_chained_execution(gpu_abl, oracle, ref, monkeypatch):
+    gpu = gpu_abl  # (the switches this test sets exist in the ablation build only)
     """Payloads whose matches cross the pieces they are decoded in -- LZ4 blocks with a sliding window (the reference's parse), zstd
     frames of the reference encoder -- are executed on ORIGINS (origin_exec.h: k_lz4_po_trace/_gather, k_zstd_fr_reps/_chain/_trace/
     _gather).  Chain-heavy data (every token / record / line repeats an earlier one: the closure of what depends on the piece before
@@ -803,8 +823,7 @@ def test_origin_execution_is_the_chained_execution(gpu, oracle, ref, monkeypatch
 
     results = {}
     for budget in ("1", "4096"):  # MiB of origins in flight: one block per group / all of them
-        monkeypatch.setenv("LTHIP_LZ4_ORG_MIB", budget)
-        monkeypatch.setenv("LTHIP_ZSTD_ORG_MIB", budget)
+        monkeypatch.setenv("LTHIP_ORIGIN_MIB", budget)
         gpu.lib.dll.lthip_debug_reload_env()
         results["lz4", budget] = run_lz4()
         results["zstd", budget] = gpu_zstd_decode(gpu, zs, caps)
@@ -821,7 +840,8 @@ def test_origin_execution_is_the_chained_execution(gpu, oracle, ref, monkeypatch
 
 
 @pytest.mark.gpu
-def test_lane_parser_shared_table_tag_runs_out(gpu, oracle, monkeypatch):
+def test_lane_parser_shared_table_tag_runs_out(gpu_abl, oracle, monkeypatch):
+    gpu = gpu_abl  # (the switches this test sets exist in the ablation build only)
     """The lane parser's shared history table is never cleared between the groups of a workgroup: entries carry a group tag that
     counts down from 0xFFFF and the table is cleared when it runs out (after 65535 groups = 4 GiB per workgroup).  LTHIP_LZ4_DBG bit 26
     makes it run out every third group: same bytes as without, and they decode."""
@@ -837,7 +857,8 @@ def test_lane_parser_shared_table_tag_runs_out(gpu, oracle, monkeypatch):
         assert n == len(r) and (out[:n] == r).all()
 
 
-def test_lane_parser_tickets_give_the_payloads_of_the_fixed_stride(gpu, oracle, monkeypatch):
+def test_lane_parser_tickets_give_the_payloads_of_the_fixed_stride(gpu_abl, oracle, monkeypatch):
+    gpu = gpu_abl  # (the switches this test sets exist in the ablation build only)
     """The lane parser's workgroups DRAW the listed groups (a ticket each, one group ahead) instead of striding over the list; a
     payload is a function of its block, whoever parsed its groups and in which order: blocks that are no multiples of the 64 KiB
     groups, the block list forwards and backwards, tickets and LTHIP_LZ4_DBG bit 27 (the fixed stride) -- the same bytes."""
@@ -855,7 +876,8 @@ def test_lane_parser_tickets_give_the_payloads_of_the_fixed_stride(gpu, oracle, 
         assert n == len(r) and (out[:n] == r).all()
 
 
-def test_zstd_repcode_frames_stay_on_the_lane_decoder(gpu, oracle, ref, monkeypatch):
+def test_zstd_repcode_frames_stay_on_the_lane_decoder(gpu_abl, oracle, ref, monkeypatch):
+    gpu = gpu_abl  # (the switches this test sets exist in the ablation build only)
     """LTHIP_ZSTD_REP=1: the frames say so in their trailer (version 3), their blocks use repeat-offset codes only for history entries
     the block itself has set, the reference decodes them, and this library's lane-per-block decoder resolves the codes itself --
     none of the payloads is handed back to the serial decoder.  Smaller than the same frames with plain offsets."""
@@ -892,8 +914,6 @@ def test_zstd_settings_are_three_parses(gpu, oracle, ref, monkeypatch):
     after a step's inserts.  Both are smaller than the default on every synthetic kind with structure, all three decode with the
     reference, and with this library's lane-per-block decoder WITHOUT a payload going back to the serial one: the history never
     leaves the 128 KiB piece, so the pieces stay independent."""
-    monkeypatch.setenv("LTHIP_ZSTD_SUB", "1")
-    gpu.lib.dll.lthip_debug_reload_env()
     blocks = [oracle.synth((2 << 20) + 4097 * k, 70 + k, k) for k in (1, 11, 12, 13)]
     blocks.append(oracle.synth(300000, 5, 12))
     blocks.append(oracle.synth(1 << 20, 6, 0))  # incompressible: the same at every setting

@@ -300,3 +300,41 @@ def test_duplicate_bearing_tree_at_8_gib_matches_reference(gpu, ref):
     res = sess["res"]
     assert res.unique_all == len(uh) and 0.70 * res.chunks_all < res.unique_all < 0.80 * res.chunks_all  # a quarter of the files repeat
     assert res.gathered_blocks > 0 and res.gathered_bytes > 0 and res.raw_bytes == int(us.astype(np.int64).sum())
+
+
+@pytest.mark.gpu
+def test_link_copy_moves_pinned_host_memory_both_ways(gpu):
+    """lthip_link_copy (the host-fed loop's transfer, include/longtail_hip.h): pinned host -> device and device -> pinned host by the
+    compute units, sizes with a tail below 16 bytes, on two contexts at once; a misaligned pointer is refused.  lthip_gather_ranges
+    writes block images straight into pinned host memory."""
+    from longtail_amd.lib import Context, LongtailHipError
+
+    rng = np.random.default_rng(5)
+    s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
+    c_in, c_out = Context(0, stream=s_in.cuda_stream, lib=gpu.lib), Context(0, stream=s_out.cuda_stream, lib=gpu.lib)
+    for n in (1, 15, 16, 17, 4096 + 7, (64 << 20) + 13):
+        src = torch.from_numpy(rng.integers(0, 256, n + 32, dtype=np.uint8)).pin_memory()
+        back = torch.zeros(n + 32, dtype=torch.uint8).pin_memory()
+        dev_a = torch.zeros(n + 32, dtype=torch.uint8, device="cuda")
+        dev_b = torch.from_numpy(rng.integers(0, 256, n + 32, dtype=np.uint8)).cuda()
+        torch.cuda.synchronize()
+        c_in.link_copy(dev_a, src, n)
+        c_out.link_copy(back, dev_b, n)
+        c_in.sync()
+        c_out.sync()
+        assert (dev_a[:n].cpu() == src[:n]).all() and int(dev_a[n:].sum()) == 0, n
+        assert (back[:n] == dev_b[:n].cpu()).all() and int(back[n:].sum()) == 0, n
+    with pytest.raises(LongtailHipError):
+        c_in.link_copy(dev_a[1:], src, 64)
+    # ranges of a device arena -> pinned host memory
+    offs = np.array([16, 100000, 7 << 20], np.int64)
+    lens = np.array([4093, 65536, 1 << 20], np.int32)
+    dst = np.array([0, 4096, 4096 + 65536], np.int64)
+    host = torch.zeros(int(dst[-1] + lens[-1]), dtype=torch.uint8).pin_memory()
+    c_out.gather_ranges(dev_b, torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), host, torch.from_numpy(dst).cuda())
+    c_out.sync()
+    ref_b = dev_b.cpu()
+    for o, l, d in zip(offs, lens, dst):
+        assert (host[d : d + l] == ref_b[o : o + l]).all()
+    c_in.close()
+    c_out.close()

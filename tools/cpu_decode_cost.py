@@ -3,6 +3,7 @@
 CompressionAPI, longtail_zstd.c:144-177) timed on one host core over frames of this library's encoder in both layouts (one zstd block per
 4 KiB unit sharing the piece's tables = the default; one block per 128 KiB piece = LTHIP_ZSTD_SUB=0) and over the reference encoder's own
 frames of the same data; LZ4 payloads of both encoders beside it.  usage: tools/cpu_decode_cost.py [blocks] [kind]"""
+import _ablations  # noqa: F401  (first: the LTHIP_* switches used here exist in the ablation build only)
 import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

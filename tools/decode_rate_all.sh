@@ -1,6 +1,8 @@
 #!/bin/bash
 # The restore-side table of DESIGN.md §6: tools/decode_rate.py over the data kinds and 512 / 64 / 1 blocks of 8 MiB in flight,
 # then the serial paths and per-kernel times of the 4 GiB mixed case.  usage: tools/decode_rate_all.sh > profiles/<tag>_decode_rate.txt
+# (the LTHIP_* switches used here exist in the ablation build only: `make ablations`)
+export LTHIP_LIB_PATH=${LTHIP_LIB_PATH:-$(cd "$(dirname "$0")/.." && pwd)/build/ablations/liblongtail_hip.so}
 for k in mixed records tokens lines random; do
   for g in 4 0.5 0.0078125; do
     echo "== $k, $g GiB"

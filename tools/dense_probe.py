@@ -2,6 +2,7 @@
 """LZ4 ratio of the lane parser against the number of one-byte steps a lane takes after a hit or at its start before it only probes
 address-aligned positions (LTHIP_LZ4_DBG bits 29-30: 4, 2, 1, 0), on data whose structure is NOT aligned to the addresses: word soup
 (text), and the synthetic kinds copied to an address that is 1 mod 4.  python tools/dense_probe.py"""
+import _ablations  # noqa: F401  (first: the LTHIP_* switches used here exist in the ablation build only)
 import os
 import sys
 from pathlib import Path

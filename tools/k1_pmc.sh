@@ -1,5 +1,7 @@
 #!/bin/bash
 # PMC of K1 per flavour: instruction counts and busy cycles (8 GiB, one step)
+# (the LTHIP_* switches used here exist in the ablation build only: `make ablations`)
+export LTHIP_LIB_PATH=${LTHIP_LIB_PATH:-$(cd "$(dirname "$0")/.." && pwd)/build/ablations/liblongtail_hip.so}
 for f in dma16 roll; do
   echo "== LTHIP_K1=$f"
   export LTHIP_K1=$f

@@ -4,6 +4,7 @@ formulation fed by LDS-DMA with hand-written exec-masked LDS reads -- against th
 itself three times per pass (a stale-register hand-off showed as one wrong cut in ~10^6 chunks, and not in every run).  The contract is
 bit-exact (lib/hpcdcchunker/longtail_hpcdcchunker.c:266-306); the rolling kernel is pinned against the reference by the -m gpu tests.
 usage: python tools/k1_stress_tib.py [tib] [gib_per_pass]"""
+import _ablations  # noqa: F401  (first: the LTHIP_* switches used here exist in the ablation build only)
 import os
 import sys
 import time

@@ -2,6 +2,7 @@
 """Is the LZ4 / zstd payload of a block a function of the block alone?  Compresses the same blocks several times (alone, in another
 order of the call's block list, with tickets and with the fixed stride) and compares the payload bytes.
 python tools/k5_determinism.py [gib] [codec] [ragged|-] [zstd quality 0..2]"""
+import _ablations  # noqa: F401  (first: the LTHIP_* switches used here exist in the ablation build only)
 import os
 import sys
 from pathlib import Path

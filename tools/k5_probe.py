@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """K5 experiment loop: LZ4-compress N GiB of each synthetic kind as 8 MiB blocks, print ratio and the match finder's time for a
 list of LTHIP_LZ4_DBG settings (read per call).  python tools/k5_probe.py [gib] [dbg,dbg,...] [kinds]"""
+import _ablations  # noqa: F401  (first: the LTHIP_* switches used here exist in the ablation build only)
 import os
 import sys
 from pathlib import Path

@@ -1,5 +1,7 @@
 #!/bin/bash
 # Ablations of the LZ4 segment encoder through LTHIP_LZ4_DBG (bit0 no pre-seed, bit1 no in-batch candidates, bit2 cooperative-only)
+# (the LTHIP_* switches used here exist in the ablation build only: `make ablations`)
+export LTHIP_LIB_PATH=${LTHIP_LIB_PATH:-$(cd "$(dirname "$0")/.." && pwd)/build/ablations/liblongtail_hip.so}
 mkdir -p gpurun_out
 for dbg in "$@"; do
   for kind in ${KINDS:-random mixed}; do

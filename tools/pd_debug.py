@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """Debugging aid for the block-parallel LZ4 decoder: one block per call, kind by kind (run with LTHIP_LZ4_PD_TRACE=1 LTHIP_LZ4_PD_STATS=1)."""
+import _ablations  # noqa: F401  (first: the LTHIP_* switches used here exist in the ablation build only)
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

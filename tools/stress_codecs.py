@@ -1,4 +1,5 @@
 """Randomised GPU stress (not part of the pytest suite): usage  python tools/<this>.py [seed]"""
+import _ablations  # noqa: F401  (first: the LTHIP_* switches used here exist in the ablation build only)
 import sys, numpy as np, torch
 sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent))
 from tests._libs import oracle, ref

@@ -1,3 +1,4 @@
+import _ablations  # noqa: F401  (first: the LTHIP_* switches used here exist in the ablation build only)
 import sys
 sys.path.insert(0,'/root/repo')
 import os, numpy as np, torch

@@ -3,6 +3,7 @@
 LTHIP_ZSTD_REP=0 in the environment: without repeat-offset codes) next to the reference encoder at longtail's settings
 ztd1..ztd4 (levels 3 / 3 / 22 / 8, lib/zstd/longtail_zstd.c:11-28) on the synthetic kinds and on text, 8 MiB blocks.  The reference frames
 are checked through the HIP decoder, ours through the reference decoder.  usage: tools/zstd_ratio_table.py [blocks per kind]"""
+import _ablations  # noqa: F401  (first: the LTHIP_* switches used here exist in the ablation build only)
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

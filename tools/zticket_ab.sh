@@ -1,5 +1,7 @@
 #!/bin/bash
 # same-box A/B of the zstd encoder's work distribution: tickets (default) against the fixed stride (LTHIP_ZSTD_TICKETS=0)
+# (the LTHIP_* switches used here exist in the ablation build only: `make ablations`)
+export LTHIP_LIB_PATH=${LTHIP_LIB_PATH:-$(cd "$(dirname "$0")/.." && pwd)/build/ablations/liblongtail_hip.so}
 run() { python bench.py "$@" --no-cpu-baseline --no-live-traffic --no-secondary --steps 3 --warmup 1 2>&1 | grep -E "^\{" | python3 -c "
 import json,sys
 for l in sys.stdin:
