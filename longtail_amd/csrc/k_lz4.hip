@@ -426,6 +426,9 @@ __device__ __forceinline__ uint32_t sub_shfl(uint32_t x, int s, bool rev, uint32
 //     scans, the size pass and the emission each read back through the memory system (1 B/B written and read on "tokens").
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t LZ4_LPAD = 16; // PV 2: LDS byte offset of the staged window
+constexpr uint32_t LZ4_QUIET = 3;  // lane parser: probe rounds without a hit at an unaligned position before the one-byte steps stop
+                                   // (profiles/r05_adaptive_stepping.txt: 6 / 4 / 3 / 2 / 1 rounds: match finder 161.6 / 160.3 / 159.0 / 158.1 /
+                                   // 156.4 ms per 64 GiB of "mixed", word-soup text 2.0284 / 2.0284 / 2.0283 / 2.0282 / 2.0249; fixed rule 169.9, 2.0284)
 constexpr uint32_t LZ4_DBG_Q_HIGH = 1u << 15, LZ4_DBG_Q_MAX = 1u << 31; // quality bits of `dbg` (zstd settings, lthip_launch_lz_sequences)
 
 // slot of a private table of TAB entries for the (multiplied) hash `prod`.  PV 0: mulhi(prod, TAB), a quarter-rate 32-bit multiply;
@@ -496,6 +499,18 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
     // round 4's first "high" setting; with the history halves it measures WORSE than without on every synthetic kind (and a third slower)
     const bool q_high = (dbg & 8192u) != 0u, q_max = (dbg & LZ4_DBG_Q_MAX) != 0u;
     const uint32_t dense = q_high ? 0xFFFFu : 4u >> ((dbg >> 29) & 3u);
+    // Round 5, ADAPTIVE miss stepping.  After a hit (and at a sub-unit's start) a lane steps `dense` single bytes before it probes
+    // aligned dwords only -- history enters the tables at aligned dwords, so a probe at an unaligned position is what finds a repeat
+    // whose distance is not a multiple of four.  Data made of aligned structures (records, tables, tokens: what compresses in an asset
+    // store) never answers such a probe: on bench.py's compressible tree the one-byte steps were 19 ms of the match finder's 166 and
+    // bought nothing (profiles/r05_lane_dense_sweep.txt: none of them 314 GB/s at ratio 2.011, four of them 288 at 2.000; on word-soup
+    // text none of them costs 5 % of the ratio, tools/text_ratio_probe.py).  So the WAVE
+    // keeps count: after LZ4_QUIET probe rounds without a single hit at an unaligned position the one-byte steps stop; the first such
+    // hit -- the probe behind a match's end stands wherever the match ended -- brings them back.  Wave-uniform, from ballots: a function
+    // of the unit's data alone.  (LTHIP_LZ4_DBG bit 16, or an explicit step count in bits 29-30: the fixed rule.)
+    const bool adaptive = !q_high && !(dbg & 65536u) && ((dbg >> 29) & 3u) == 0u;
+    const uint32_t quiet_rounds = (dbg >> 17) & 7u ? (dbg >> 17) & 7u : LZ4_QUIET; // (bits 17-19: the sweep of profiles/r05_adaptive_stepping.txt)
+    uint32_t dense_w = dense, quiet = 0;
     // lanes that must hold a hit before the wave turns to the extension: 4 (round 4, VALU bound: 2 GiB mixed 4.25 ms at 8, 4.12 at 4,
     // 4.16 / 4.37 / 4.76 at 16 / 32 / 48; tokens 5.97 / 5.93 / 6.03 / 6.80 / 7.78 -- waiting lanes are idle lanes)
     const uint32_t wait_for = (dbg >> 20) & 63u ? (dbg >> 20) & 63u : 4u;
@@ -515,6 +530,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
             break;
         if (am)
         {
+            bool hit_un = false;
             if (__builtin_amdgcn_ballot_w64(act && stale))
             {
                 if (act && stale)
@@ -561,12 +577,13 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 if (h1 || h2 || h3)
                 {
                     pend = true;
+                    hit_un = ((p + head) & 3u) != 0u;
                     cand = h1 ? c : (h2 ? c2 : c3); // the private table's (the nearest one) first, the history's last
                     cand2 = (q_high && h1 && h2 && c != c2) ? c2 : 0xFFFFFFFFu;
                 }
                 else
                 {
-                    const uint32_t np = nmiss < dense ? p + 1u : (((p + head) | 3u) + 1u - head);
+                    const uint32_t np = nmiss < dense_w ? p + 1u : (((p + head) | 3u) + 1u - head);
                     if (((np + head) >> 2) != W) // at most one dword further
                     {
                         w0 = w1;
@@ -577,6 +594,16 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                     p = np;
                     ++nmiss;
                 }
+            }
+            if (adaptive)
+            {
+                if (__builtin_amdgcn_ballot_w64(hit_un) != 0ull)
+                {
+                    quiet = 0;
+                    dense_w = dense;
+                }
+                else if (++quiet == quiet_rounds)
+                    dense_w = 0;
             }
         }
         K5P(3);

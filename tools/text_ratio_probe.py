@@ -19,8 +19,9 @@ blocks = [text(4 << 20) for _ in range(8)]
 dev, offs = to_device(blocks)
 sizes = [len(b) for b in blocks]
 for codec in ("lz4", "zstd"):
-    for dbg in (0, 1 << 31, (3 << 29) | (1 << 31)):
+    for dbg in (1 << 16, 0, 3 << 17, 2 << 17, 1 << 17, 3 << 29):  # fixed four one-byte steps; adaptive with 6 (default), 3, 2, 1 quiet rounds; no one-byte steps
         os.environ["LTHIP_LZ4_DBG"] = str(dbg)
+        ctx.lib.dll.lthip_debug_reload_env()
         caps = [s + s // 255 + 16 if codec == "lz4" else s + (s >> 8) + 64 for s in sizes]
         d_offs, total = layout([np.zeros(c, np.uint8) for c in caps])
         dst = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
