@@ -25,6 +25,36 @@ def test_header_symbols_are_exported(hiplib):
     assert not missing, missing
 
 
+def test_product_reads_only_its_documented_switches(hiplib):
+    """README.md "Environment": the product library reads ten variables.  Every other LTHIP_* switch of rounds 1-4 (kernel flavours,
+    debug masks, experiments) is compiled by the ablation build only (make ablations, csrc/ablations/*.inc) -- neither their names
+    nor the kernels they select are in the shipped binary; the ablation build has both and the same C interface."""
+    import subprocess
+
+    def names(path):
+        out = subprocess.run(["strings", "-a", str(path)], capture_output=True, text=True, check=True).stdout
+        return sorted(set(re.findall(r"^(?:LTHIP|LONGTAIL_HIP)_[A-Z0-9_]+$", out, flags=re.M)))
+
+    documented = sorted(re.findall(r"`((?:LTHIP|LONGTAIL_HIP)_[A-Z0-9_]+)`", (ROOT / "README.md").read_text().split("## Environment")[1].split("Everything else")[0]))
+    documented += ["LONGTAIL_HIP_LARGE_WINDOWS", "LTHIP_COMM_SHM_SLOT"] if "LONGTAIL_HIP_LARGE_WINDOWS" not in documented else []
+    got = names(hiplib.path)
+    assert got == sorted(set(documented)), (got, documented)
+    assert len(got) == 10
+    symbols = subprocess.run(["strings", "-a", str(hiplib.path)], capture_output=True, text=True, check=True).stdout
+    for gone in ("k_buzhash_candidates", "k_lz4_segments_modes", "k_lz4_pd_units", "k_zstd_prepare", "k_zstd_execute_payload", "k_blake3_parents_small"):
+        assert gone not in symbols, f"{gone} is an ablation-only kernel"
+    from longtail_amd.lib import ABLATIONS_LIB_PATH
+
+    if ABLATIONS_LIB_PATH.exists():  # (built by make all / __graft_entry__.build())
+        abl = C.CDLL(str(ABLATIONS_LIB_PATH))
+        missing = [n for n in declared_symbols() if not hasattr(abl, n)]
+        assert not missing, missing
+        abl_names = names(ABLATIONS_LIB_PATH)
+        assert set(got) <= set(abl_names) and len(abl_names) >= 35, abl_names
+        abl_syms = subprocess.run(["strings", "-a", str(ABLATIONS_LIB_PATH)], capture_output=True, text=True, check=True).stdout
+        assert "k_lz4_segments_modes" in abl_syms and "k_buzhash_candidates" in abl_syms
+
+
 def test_library_is_built_from_this_tree(hiplib):
     """lthip_build_id() is the hash of csrc/ + include/ the Makefile baked in; a stale .so (round 1: k_zstd.o older than
     zstd_decode_core.h) must fail here and in tests/test_gpu_build_id.py on the GPU box."""
