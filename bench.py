@@ -1143,6 +1143,9 @@ def run_cpu_baseline(args):
             codec_api = d.Longtail_CreateHipLZ4CompressionAPI() if args.codec == "lz4" else d.Longtail_CreateHipZStdCompressionAPI()
             r.version_index(files[: min(1024, len(files))], args.target_chunk_size, w_drop, 0, chunker, hasher)  # warm-up: contexts, window pool
             hip = measure(files, [w_drop], (chunker, hasher, codec_api))
+            # ... and what INTEGRATION.md recommends to an embedder that changes nothing but constructors: the HIP chunker + hash (they pay
+            # inside the unmodified core) with the reference's own CPU codec (one block per Compress call never feeds a GPU codec)
+            mixed_apis = measure(files, [w_drop], (chunker, hasher, None))
             if hip:
                 h, c = hip[str(w_drop)], by_w[str(w_drop)]
                 nbytes = sum(len(x) for _, x in files)
@@ -1155,6 +1158,11 @@ def run_cpu_baseline(args):
                            "write_content_GBps": {"hip_plugins": round(nbytes / h["write_s"] / 1e9, 3), "cpu_plugins": round(nbytes / c["write_s"] / 1e9, 3),
                                                   "ratio": round(c["write_s"] / h["write_s"], 3)},
                            "seconds": {"hip_plugins": h, "cpu_plugins": c}}
+                if mixed_apis:
+                    m = mixed_apis[str(w_drop)]
+                    drop_in["upsync_GBps"]["hip_chunker_hash_cpu_codec"] = m["GBps"]
+                    drop_in["upsync_GBps"]["ratio_hip_chunker_hash_cpu_codec"] = round(m["GBps"] / c["GBps"], 3)
+                    drop_in["seconds"]["hip_chunker_hash_cpu_codec"] = m
         except Exception as e:  # (the baseline itself must not fail with it)
             drop_in = {"error": repr(e)}
     del files
