@@ -1511,7 +1511,13 @@ __global__ void k_lz4_pair_halves(uint32_t* __restrict__ wl, uint32_t ngroups, u
         if (i >= wl[0])
             return;
         const uint32_t g = wl[1u + i], bits = wl[1u + ngroups + g] & 3u;
-        if (hist)
+        if (hist == 2u) // (LTHIP_LZ4_SPLITWG: every flagged half an item of its own)
+        {
+            for (uint32_t hh = 0; hh < 2u; ++hh)
+                if ((bits >> hh) & 1u)
+                    lone[atomicAdd(&wl[2u * ngroups + 3u], 1u)] = 2u * g + hh;
+        }
+        else if (hist)
         {
             const uint32_t b = lz4_block_of_group(blocks, nblocks, g);
             const bool piece_first = ((g - blocks[b].grp_base) & 1u) == 0u; // (a piece = two groups)
@@ -1546,6 +1552,17 @@ __global__ void k_lz4_pair_halves(uint32_t* __restrict__ wl, uint32_t ngroups, u
     else
     {
         const uint32_t nl = wl[2u * ngroups + 3u];
+        if (hist == 2u)
+        {
+            if (i >= nl)
+                return;
+            const uint32_t k = atomicAdd(&wl[2u * ngroups + 2u], 1u);
+            items[4u * k] = lone[i];
+            items[4u * k + 1u] = LZ4_HALF_NONE;
+            items[4u * k + 2u] = lz4_block_of_group(blocks, nblocks, lone[i] >> 1);
+            items[4u * k + 3u] = 0u;
+            return;
+        }
         if (2u * i >= nl)
             return;
         const uint32_t k = atomicAdd(&wl[2u * ngroups + 2u], 1u);
@@ -1557,8 +1574,12 @@ __global__ void k_lz4_pair_halves(uint32_t* __restrict__ wl, uint32_t ngroups, u
     }
 }
 
-template <int FMT>
-__global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks, uint32_t nblocks,
+// WG = waves per workgroup: 16 (the product: an item of two halves per workgroup, one workgroup per CU), or 8 (experiment of round 5,
+// ablation build, LTHIP_LZ4_SPLITWG=1: every flagged half an item of its own, TWO independent workgroups of eight waves per CU with
+// half the window and half the shared table each -- no half ever waits for another at a barrier, and one workgroup's staging runs beside
+// the other's parse; the price: no half sees the half before it).
+template <int FMT, int WG = 16>
+__global__ __launch_bounds__(64 * WG, 4) void k_lz4_lanes2(const uint8_t* __restrict__ src, const Lz4Block* __restrict__ blocks, uint32_t nblocks,
                                                        uint32_t sub_bytes, uint8_t* __restrict__ streams, Lz4Meta* __restrict__ meta,
                                                        uint64_t* __restrict__ zrecs, uint8_t* __restrict__ spec_dst, uint32_t dbg,
                                                        uint32_t ngroups, uint32_t* __restrict__ worklist, uint32_t farlog)
@@ -1568,7 +1589,8 @@ __global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restric
     constexpr bool PAD = true;
     constexpr uint32_t GAP = 32u; // LDS bytes between the windows of two unlinked halves
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t data_bytes = lz4_window_lds_bytes(G * sub_bytes + 64u + LZ4_LPAD + GAP, true);
+    static_assert(WG == 16 || WG == 8, "two halves per workgroup, or one");
+    const uint32_t data_bytes = lz4_window_lds_bytes((uint32_t)WG * sub_bytes + 64u + LZ4_LPAD + GAP, true);
     uint32_t* sdata = smem;
     uint32_t* flag = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes); // 16 bytes
     const int tid = threadIdx.x;
@@ -1576,7 +1598,8 @@ __global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t hsel = (uint32_t)wave >> 3, wih = (uint32_t)wave & 7u; // my half of the item, my unit in the half
     uint16_t* tab = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u) + (size_t)wave * TAB;
-    uint32_t* shr = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u + (size_t)G * TAB * 2);
+    uint32_t* shr = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes + 16u + (size_t)WG * TAB * 2);
+    constexpr uint32_t SH_BYTES = WG == 16 ? (4u << SH) : (2u << SH); // (a lone half uses the lower half of the table)
     const uint32_t* items = worklist + lz4_items_off(ngroups);
     const uint32_t nitems = worklist[2u * ngroups + 2u];
     const uint32_t half_bytes = (uint32_t)(G / 2) * sub_bytes;
@@ -1592,7 +1615,7 @@ __global__ __launch_bounds__(1024, 4) void k_lz4_lanes2(const uint8_t* __restric
         {
             uint4* hv = reinterpret_cast<uint4*>(shr);
             const uint4 none = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            for (uint32_t v = tid; v < (4u << SH) / 16u; v += 64 * G)
+            for (uint32_t v = tid; v < SH_BYTES / 16u; v += 64 * WG)
                 hv[v] = none;
             __syncthreads();
             sh_gen = (dbg & (1u << 26)) ? 3u : 0xFFFFu;
@@ -2253,7 +2276,32 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
     // the list of groups -> items of two half-groups (k_lz4_pair_halves), then the lane kernel over the items
     const uint32_t nthreads = 256, ng = (uint32_t)ngrp;
     // history halves: the zstd flavour at its "high" and "max" settings
-    const uint32_t hist = (FMT == 1 && (dbg & (LZ4_DBG_Q_HIGH | LZ4_DBG_Q_MAX))) ? 1u : 0u;
+    uint32_t hist = (FMT == 1 && (dbg & (LZ4_DBG_Q_HIGH | LZ4_DBG_Q_MAX))) ? 1u : 0u;
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    LTHIP_ABLATION_ENV(env_far, "LTHIP_LZ4_FAR");
+    const uint32_t farlog = env_far.get() >= 0 ? (uint32_t)env_far.get() : (10u | (12u << 8) | (8u << 16));
+#ifdef LTHIP_ABLATIONS
+    LTHIP_ABLATION_ENV(env_split, "LTHIP_LZ4_SPLITWG"); // experiment (round 5): half-items on two 8-wave workgroups per CU
+    if (env_split.get() > 0 && hist == 0u)
+    {
+        hist = 2u;
+        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng + nthreads - 1) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 0u, d_blocks, block_count, hist);
+        hipLaunchKernelGGL(k_lz4_pair_halves, dim3((2u * ng + nthreads) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 1u, d_blocks, block_count, hist);
+        LTHIP_LAUNCH_CHECK(ctx);
+        const size_t lds8 = (size_t)lz4_window_lds_bytes(8u * SEG + 64u + LZ4_LPAD + 32u, true) + 16 + (size_t)8 * LZ4_TAB_SHARED * 2 + ((size_t)2 << LZ4_SH_LOG2);
+        static bool granted8[2] = {false, false};
+        if (!granted8[FMT])
+        {
+            LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_lanes2<FMT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            granted8[FMT] = true;
+        }
+        hipLaunchKernelGGL((k_lz4_lanes2<FMT, 8>), dim3(2u * (uint32_t)ncu), dim3(64 * 8), lds8, ctx->stream, (const uint8_t*)d_src, d_blocks, block_count, SEG,
+                           streams, meta, zrecs, spec_dst, dbg, ng, (uint32_t*)wl, farlog);
+        LTHIP_LAUNCH_CHECK(ctx);
+        return 0;
+    }
+#endif
     hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng + nthreads - 1) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 0u, d_blocks, block_count, hist);
     hipLaunchKernelGGL(k_lz4_pair_halves, dim3((ng / 2 + nthreads) / nthreads), dim3(nthreads), 0, ctx->stream, (uint32_t*)wl, ng, 1u, d_blocks, block_count, hist);
     LTHIP_LAUNCH_CHECK(ctx);
@@ -2264,12 +2312,8 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
         LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lz4_lanes2<FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->k5h_lds_enabled[FMT] = true;
     }
-    int ncu = 256;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    // zstd flavour: a match must be one byte longer from 2^a bytes away and two from 2^b, and c bytes long when it reaches into a
-    // history half (a + 256 b + 65536 c = 10, 12, 8; a = b = 31 and c = 4: no rule; the ablation build reads LTHIP_LZ4_FAR)
-    LTHIP_ABLATION_ENV(env_far, "LTHIP_LZ4_FAR");
-    const uint32_t farlog = env_far.get() >= 0 ? (uint32_t)env_far.get() : (10u | (12u << 8) | (8u << 16));
+    // zstd flavour (farlog above): a match must be one byte longer from 2^a bytes away and two from 2^b, and c bytes long when it reaches
+    // into a history half (a + 256 b + 65536 c = 10, 12, 8; a = b = 31 and c = 4: no rule; the ablation build reads LTHIP_LZ4_FAR)
     hipLaunchKernelGGL((k_lz4_lanes2<FMT>), dim3((uint32_t)ncu), dim3(64 * LZ4_G_LANES), lds, ctx->stream, (const uint8_t*)d_src, d_blocks,
                        block_count, SEG, streams, meta, zrecs, spec_dst, dbg, ng, (uint32_t*)wl, farlog);
     LTHIP_LAUNCH_CHECK(ctx);
