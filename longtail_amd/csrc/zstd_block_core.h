@@ -373,6 +373,10 @@ ZB_FN void zb_normalize(const uint32_t* hist, uint32_t nsym, uint32_t total, uin
             uint32_t take = sum - size;
             if (take > (uint32_t)norm[best] - 1u)
                 take = (uint32_t)norm[best] - 1u;
+            if (take == 0u)
+                break; /* cannot happen: a largest count of 1 with sum > size needs more present symbols than cells, and the callers
+                        * choose tl >= 5, and >= 6 for more than 32 of the at most 64 symbols (zb_build_seq_tables) -- but a loop
+                        * that cannot end is the wrong way to find out */
             norm[best] = (int16_t)(norm[best] - (int)take);
             sum -= take;
         }
@@ -520,6 +524,8 @@ ZB_FN void zb_normalize_par(const uint32_t* hist, uint32_t nsym, uint32_t total,
             uint32_t take = sum - size;
             if (take > mx - 1u)
                 take = mx - 1u;
+            if (take == 0u)
+                break; /* (cannot happen: see zb_normalize) */
             if (zl == best)
                 v -= take;
             sum -= take;
@@ -956,7 +962,9 @@ ZB_FN void zb_huffman_build_par(ZbShared* sh, uint32_t zl)
     }
     ZB_SYNC_LDS();
     /* L is non-increasing (rarest symbol first).  Limit to 11 bits and restore Kraft equality: as in zb_huffman_build */
-    if (L[0] > ZB_HUF_MAXBITS)
+    const uint32_t too_deep = L[0] > ZB_HUF_MAXBITS; /* (every lane has asked before lane 0 changes L below) */
+    ZB_SYNC_LDS();
+    if (too_deep)
     {
         ZB_SERIAL(zl)
         {

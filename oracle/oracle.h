@@ -92,6 +92,11 @@ int lto_ingest(const uint8_t* data, uint64_t size, uint64_t part_size, uint32_t 
 size_t ltz_model_bound(size_t n);
 int ltz_model_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n);
 int ltz_model_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n);
+/* 0: the one-lane model; 1 / 2: the sub-block encoder runs with SIXTY-FOUR lanes on the host (zstd_model_lanes.c: the code the kernel
+ * compiles, as 64 fibers), the lanes in ascending / descending order between two meeting points.  ltz_model_compress returns -2 when the
+ * lanes do not keep step; ltz_lanes_bad_site(0 / 1) then give the two source lines of zstd_block_core.h they stood at. */
+void ltz_model_lanes64(int mode);
+uint32_t ltz_lanes_bad_site(int k);
 uint32_t ltz_model_encode_block_src(const void* unit_meta, const uint8_t* unit_lits, const uint64_t* unit_recs, uint32_t nunits,
                                     uint32_t raw_size, const uint8_t* src, uint8_t* out); /* units without a sequence: literals = src */
 uint32_t ltz_model_encode_block(const void* unit_meta, const uint8_t* unit_lits, const uint64_t* unit_recs, uint32_t nunits,

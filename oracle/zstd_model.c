@@ -35,6 +35,17 @@ static uint16_t g_ltz_last_sub[ZB_MAX_UNITS];
 void ltz_model_sub_blocks(int on) { g_ltz_sub = on; }
 const uint16_t* ltz_model_last_sub(void) { return g_ltz_last_sub; }
 
+/* 1: the sub-block encoder runs with 64 lanes (zstd_model_lanes.c: the kernel's all-lanes code on the host) instead of one */
+static int g_ltz_lanes64;
+void ltz_lanes_order(int descending);
+void ltz_model_lanes64(int on) /* 0: one lane; 1: 64 lanes, run in ascending order between meeting points; 2: descending */
+{
+    g_ltz_lanes64 = on;
+    ltz_lanes_order(on == 2);
+}
+uint32_t ltz_lanes_encode_piece_sub(const void* meta, const uint8_t* unit_lits, const uint64_t* unit_recs, uint32_t nunits, uint32_t raw_size,
+                                    const uint8_t* src, uint32_t flags, uint8_t* out, uint16_t* sub);
+
 #include "oracle.h"
 
 /* src != NULL: units without a sequence have no literal buffer, their literals are src + u * 4096 (ZbInput.src) */
@@ -43,8 +54,11 @@ uint32_t ltz_model_encode_block_src(const void* meta, const uint8_t* unit_lits, 
 {
     ZbInput in;
     ZbScratch sc;
-    ZbShared* sh = (ZbShared*)calloc(1, sizeof(ZbShared));
+    ZbShared* sh;
     uint32_t n;
+    if (g_ltz_sub && g_ltz_lanes64)
+        return ltz_lanes_encode_piece_sub(meta, unit_lits, unit_recs, nunits, raw_size, src, g_ltz_flags, out, g_ltz_last_sub);
+    sh = (ZbShared*)calloc(1, sizeof(ZbShared));
     in.meta = (const ZbUnitMeta*)meta;
     in.unit_lits = unit_lits;
     in.unit_recs = unit_recs;
@@ -168,6 +182,14 @@ int ltz_model_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, s
         }
         model_match_block(src, off, size, table, meta, unit_lits, unit_recs);
         csize = ltz_model_encode_block_src(meta, unit_lits, unit_recs, (size + ZB_UNIT - 1u) / ZB_UNIT, size, src + off, enc);
+        if (csize == 0xFFFFFFFFu) /* (64-lane execution: the lanes did not keep step, zstd_model_lanes.c) */
+        {
+            free(table);
+            free(unit_lits);
+            free(unit_recs);
+            free(enc);
+            return -2;
+        }
         if (g_ltz_sub && csize)
         {
             /* the sub-blocks carry their own headers: only Last_Block is left to set */

@@ -305,3 +305,75 @@ def test_block_local_repeat_offset_codes(model, layout, seed):
     finally:
         d.ltz_model_flags(0)
     assert sizes[1] < sizes[0], sizes
+
+
+def _builder_corners():
+    """the statistics of tests/test_gpu_codecs.py::test_zstd_table_builders_all_lanes_equal_the_serial_ones (the builders' corners)"""
+    rng = np.random.default_rng(77)
+    n = 262144 + 4096 + 37
+    yield "two literal symbols", rng.integers(0, 2, n).astype(np.uint8) * 200 + 7
+    yield "256 symbols equally often", rng.permutation(np.arange(n, dtype=np.int64) % 256).astype(np.uint8)
+    yield "geometric counts (depths far above 11)", np.minimum(rng.geometric(0.5, n) - 1, 60).astype(np.uint8) * 3 + 1
+    yield "geometric, high bytes (FSE-compressed tree)", (255 - np.minimum(rng.geometric(0.35, n) - 1, 200)).astype(np.uint8)
+    rare = np.full(n, 65, np.uint8)
+    rare[rng.integers(0, n, 300)] = rng.integers(0, 256, 300).astype(np.uint8)
+    yield "one value with rare others", rare
+    rec = rng.integers(0, 256, 16).astype(np.uint8)
+    yield "one match length, one literal length (RLE tables)", np.concatenate([np.concatenate([rec, rng.integers(0, 256, 1).astype(np.uint8)]) for _ in range(n // 17)])
+    few = rng.integers(0, 256, n).astype(np.uint8)
+    for k in range(0, n - 70000, 65536):
+        few[k + 5000 : k + 5040] = few[k + 100 : k + 140]
+    yield "a handful of sequences (predefined tables)", few
+    varied = rng.integers(0, 256, n).astype(np.uint8)
+    pos = 3000
+    while pos + 400 < n:
+        ln = int(rng.integers(4, 300))
+        src = int(rng.integers(max(0, pos - 60000), pos - ln)) if pos - ln > 0 else 0
+        varied[pos : pos + ln] = varied[src : src + ln]
+        pos += ln + int(rng.integers(1, 40))
+    yield "many lengths at many distances", varied
+
+
+def _lane_inputs():
+    for kind in (0, 1, 2, 11, 12, 13):
+        for n in (100, 5000, 131072, 400000):
+            yield f"kind{kind}-{n}", ("synth", n, 2000 + n + kind, kind)
+    for name, data in _alphabets():
+        yield name, ("data", data)
+    for name, data in _builder_corners():
+        yield name, ("data", data)
+
+
+@pytest.mark.parametrize("name,what", list(_lane_inputs()), ids=[n for n, _ in _lane_inputs()])
+def test_sixty_four_lanes_on_the_host_write_the_one_lane_models_bytes(model, name, what):
+    """oracle/zstd_model_lanes.c: zstd_block_core.h instantiated with ZB_LANES = 64 on the host (64 fibers that meet where the wave
+    meets) -- the code the KERNEL compiles, with its all-lanes table builders (zb_normalize_par, zb_build_enc_table_par,
+    zb_huffman_build_par) that the one-lane model never runs.  Its frames must be the one-lane model's, byte for byte, and decode with
+    the reference: a divergence of the all-lanes code shows without a GPU (the GPU test of the same claim:
+    tests/test_gpu_codecs.py::test_zstd_table_builders_all_lanes_equal_the_serial_ones)."""
+    d = model.dll
+    d.ltz_model_lanes64.restype = None
+    d.ltz_model_lanes64.argtypes = [C.c_int]
+    data = model.synth(what[1], what[2], what[3]) if what[0] == "synth" else what[1]
+    d.ltz_model_sub_blocks(1)
+    d.ltz_lanes_bad_site.restype = C.c_uint32
+    d.ltz_lanes_bad_site.argtypes = [C.c_int]
+    try:
+        one = compress(model, data)
+        for order in (1, 2):  # the lanes run 0 .. 63 / 63 .. 0 between two meeting points
+            d.ltz_model_lanes64(order)
+            b = np.ascontiguousarray(data, dtype=np.uint8)
+            cap = d.ltz_model_bound(len(b))
+            many = np.zeros(cap + 8, np.uint8)
+            n = C.c_size_t(0)
+            rc = d.ltz_model_compress(b.ctypes.data, len(b), many.ctypes.data, cap, C.byref(n))
+            assert rc == 0, (f"{name}: the 64 lanes did not keep step (zstd_block_core.h lines {d.ltz_lanes_bad_site(0) & 0x7FFFFFFF} / "
+                             f"{d.ltz_lanes_bad_site(1) & 0x7FFFFFFF}): a collective in divergent control flow, or a value read and written "
+                             "by different lanes without a ZB_SYNC_LDS between")
+            many = many[: n.value]
+            assert len(one) == len(many) and (one == many).all(), f"{name}: 64 lanes (order {order}) wrote {len(many)} bytes, one lane {len(one)}"
+    finally:
+        d.ltz_model_lanes64(0)
+        d.ltz_model_sub_blocks(0)
+    err, out = get_ref().decompress(CODEC_ZSTD, many, len(data))
+    assert err == 0 and len(out) == len(data) and (out == np.ascontiguousarray(data, dtype=np.uint8)).all()
