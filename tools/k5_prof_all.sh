@@ -1,5 +1,7 @@
-cp longtail_amd/liblongtail_hip.so build/cur.so
-cp build/prof/liblongtail_hip_prof.so longtail_amd/liblongtail_hip.so
+#!/bin/bash
+# Per-phase wave cycles of the LZ4 lane parser on every kind (debug build build/prof/liblongtail_hip_prof.so: make prof, -DLTHIP_K5_PROF),
+# blocks 12 345 bytes into the data (blocks at chunk offsets, like bench.py).  usage: tools/k5_prof_all.sh > profiles/<tag>_k5_phases_shifted.txt
+export LTHIP_LIB_PATH=$(cd "$(dirname "$0")/.." && pwd)/build/prof/liblongtail_hip_prof.so
 for kind in mixed tokens records lines; do
 python - $kind <<'PY'
 import sys, os
@@ -11,4 +13,3 @@ exec(open("tools/k5_probe.py").read())
 L.load().dll.lthip_k5_prof_dump(1)
 PY
 done
-cp build/cur.so longtail_amd/liblongtail_hip.so
