@@ -281,10 +281,15 @@ LTHIP_EXPORT int lthip_zstd_compress_blocks(lthip_ctx* ctx, const void* d_src, u
  *   LTHIP_ZSTD_Q_HIGH     'ztd4': every redundant 32 KiB half of a 128 KiB piece but the piece's first is parsed with the 32 KiB in
  *                         front of it as HISTORY (matches reach 32 .. 64 KiB back wherever the half lies; by default a half only sees
  *                         what its 64 KiB group holds in front of it).  About half the match finder's throughput.
- *   LTHIP_ZSTD_Q_MAX      'ztd3', 'ztd5': Q_HIGH, and the wave's table is read again after the step's inserts (what the lanes beside
- *                         this one have just put there is a candidate at once)
- * Every quality writes the same frame format (sub-blocks; the pieces of a frame stay independent of each other), and each is smaller
- * than the one before on the synthetic kinds (profiles/r04_zstd_ratio_table.txt).
+ *   LTHIP_ZSTD_Q_MAX      'ztd3', 'ztd5': the history ALSO for a piece's first half -- matches reach into the piece before -- except in
+ *                         every eighth piece of a block, and the wave's table is read again after the step's inserts.  The frame's
+ *                         trailer says so (directory version 4): this library's decoder runs the eight pieces in between as a CHAIN
+ *                         (a piece is executed when the one before it is complete; the chains of a call side by side).  On "tokens"
+ *                         2.92 / 3.33 / 3.76 (default / high / max), records 3.00 / 3.12 / 3.24 = the reference encoder's default;
+ *                         restore of such frames 0.7-0.9 x the other settings' rate at 512 blocks per call, one block 2-6 ms
+ *                         against 0.5-1.4 (profiles/r05_zstd_ratio_table.txt, r05_zstd_quality_rates.txt).
+ * Every quality writes standard zstd frames in the sub-block layout; at the first two the pieces of a frame are independent of each
+ * other; each is smaller than the one before on the synthetic kinds with structure.
  * lthip_zstd_quality_of_settings: the quality a settings id ('ztd?' as a big-endian u32, the value blocks carry) stands for. */
 #define LTHIP_ZSTD_Q_DEFAULT 0
 #define LTHIP_ZSTD_Q_HIGH 1

@@ -351,6 +351,7 @@ __device__ __forceinline__ void lz4_coop_sequence(const uint8_t* __restrict__ sb
 constexpr int LZ4_G_BATCH = 8;   // MODE 0 (batch parser): 8 x 4 KiB units per 32 KiB window group
 constexpr int LZ4_G_LANES = 16;  // MODE 1 (lane parser): 16 x 4 KiB units per 64 KiB window group, one workgroup per CU
 constexpr int LZ4_PROBE_BATCHES = 4;
+constexpr uint32_t LZ4_Z_CHAIN = LTHIP_ZSTD_CHAIN;
 constexpr uint32_t Z_PIECE = 128u << 10; // zstd Block_Maximum_Size (ZB_BLOCK_MAX of zstd_block_core.h, asserted in k_zstd.hip)
 // table entries per wave.  MODE 0: 32 KiB window + 8 x 2.5 KiB tables = 52 KiB: THREE workgroups (24 waves) per CU.
 // MODE 1: 64 KiB window + 16 x 5 KiB tables = 144 KiB: one workgroup of 16 waves per CU (the lane parser is not issue bound, it
@@ -1520,7 +1521,9 @@ __global__ void k_lz4_pair_halves(uint32_t* __restrict__ wl, uint32_t ngroups, u
         else if (hist)
         {
             const uint32_t b = lz4_block_of_group(blocks, nblocks, g);
-            const bool piece_first = ((g - blocks[b].grp_base) & 1u) == 0u; // (a piece = two groups)
+            // (a piece = two groups; hist 3 -- the "max" setting -- lets a piece's first half see the piece before, except every
+            // LZ4_Z_CHAIN-th piece of the block: the decoder runs the pieces in between as a chain, k_zstd.hip)
+            const bool piece_first = hist == 3u ? ((g - blocks[b].grp_base) % (2u * LZ4_Z_CHAIN)) == 0u : ((g - blocks[b].grp_base) & 1u) == 0u;
             for (uint32_t hh = 0; hh < 2u; ++hh)
                 if ((bits >> hh) & 1u)
                 {
@@ -2276,7 +2279,7 @@ static int launch_match_finder(lthip_ctx* ctx, bool lanes, uint32_t SEG, const v
     // the list of groups -> items of two half-groups (k_lz4_pair_halves), then the lane kernel over the items
     const uint32_t nthreads = 256, ng = (uint32_t)ngrp;
     // history halves: the zstd flavour at its "high" and "max" settings
-    uint32_t hist = (FMT == 1 && (dbg & (LZ4_DBG_Q_HIGH | LZ4_DBG_Q_MAX))) ? 1u : 0u;
+    uint32_t hist = (FMT == 1 && (dbg & LZ4_DBG_Q_MAX)) ? 3u : (FMT == 1 && (dbg & LZ4_DBG_Q_HIGH)) ? 1u : 0u;
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
     LTHIP_ABLATION_ENV(env_far, "LTHIP_LZ4_FAR");

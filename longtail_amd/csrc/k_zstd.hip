@@ -141,7 +141,13 @@ __device__ __forceinline__ void z_write_trailer2_head(uint8_t* d, uint64_t conte
     for (uint32_t i = 0; i < ZTRAILER; ++i)
         d[i] = t[i];
 }
-// 0: not a directory trailer; else its version (2 or 3)
+// version 4 (round 5, the "max" setting): the match finder gave every redundant half the 32 KiB in front of it as history, also a piece's
+// first half -- matches reach into the piece before -- except in every ZCHAIN-th piece of the frame: pieces k ZCHAIN .. k ZCHAIN + 7 are
+// a CHAIN for the decoder (a piece is executed when the one before it is complete), the chains of a frame are independent of each other.
+// (One chain per frame was measured first: a frame of 64 pieces then decodes in 14-40 ms however many waves idle -- 100 / 78 GB/s on
+// mixed / tokens at 512 blocks, 0.2-0.6 GB/s for one block; chains of eight keep 7/8 of the ratio gain.)
+constexpr uint32_t ZCHAIN = LTHIP_ZSTD_CHAIN;
+// 0: not a directory trailer; else its version (2, 3 or 4)
 __device__ __forceinline__ uint32_t z_is_trailer2_head(const uint8_t* d, uint64_t content)
 {
     const uint32_t n = 4u + 2u * z_units(content);
@@ -150,7 +156,7 @@ __device__ __forceinline__ uint32_t z_is_trailer2_head(const uint8_t* d, uint64_
     for (uint32_t i = 0; i + 1u < ZTRAILER; ++i)
         same &= d[i] == t[i];
     const uint32_t ver = d[ZTRAILER - 1u];
-    return same && (ver == 2u || ver == 3u) ? ver : 0u;
+    return same && (ver >= 2u && ver <= 4u) ? ver : 0u;
 }
 
 // serial per stored block: destination offset of every piece, total size
@@ -180,7 +186,7 @@ __global__ void k_zstd_scan(const ZBlock* __restrict__ blocks, uint32_t nblocks,
     {
         if (sub)
         {
-            z_write_trailer2_head(dst + blk.dst_off + pos, blk.size, sub == 2u ? 3u : 2u); // (the directory: k_zstd_emit, every piece its own entries)
+            z_write_trailer2_head(dst + blk.dst_off + pos, blk.size, sub == 2u ? 3u : sub == 3u ? 4u : 2u); // (the directory: k_zstd_emit, every piece its own entries)
             trailer_at[b] = (uint32_t)pos;
         }
         else
@@ -527,7 +533,7 @@ static int zstd_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block
     hipLaunchKernelGGL(k_zstd_scan, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
                        block_count, (const uint8_t*)d_rle, (const uint32_t*)d_encsz, (uint32_t*)d_zdst, d_out_sizes, (uint8_t*)d_dst,
                        env_zdbg.get() > 0 ? (uint32_t)env_zdbg.get() : 0u, // (ablation build) bit 1: no trailer
-                       sub ? (rep ? 2u : 1u) : 0u, (uint32_t*)d_trail);
+                       sub ? (rep ? 2u : (quality >= LTHIP_ZSTD_Q_MAX ? 3u : 1u)) : 0u, (uint32_t*)d_trail);
     hipLaunchKernelGGL(k_zstd_headers, dim3((block_count + 63) / 64), dim3(64), 0, ctx->stream, (const ZBlock*)d_blocks,
                        block_count, (const uint32_t*)d_out_sizes, (uint8_t*)d_dst);
     if (nzb)
@@ -773,6 +779,13 @@ __global__ __launch_bounds__(64) void k_zstd_split(const uint8_t* __restrict__ s
             (uint64_t)blk.size >= (uint64_t)ZHDR + 3u + z_trailer2_size(content))
             dir = z_is_trailer2_head(p + blk.size - z_trailer2_size(content), content);
     }
+    if (dir == 4u && blk.dst_cap >= 0x7FFFFFFFu)
+    {
+        // pieces that depend on each other, positions beyond 31 bits: the payload's blocks in order, on one wave (the serial decoder)
+        if (lane == 0)
+            z_split_walk(p, blk, b, items, item_count, out_sizes, dbg | 1u);
+        return;
+    }
     if (!dir)
     {
         if (lane == 0)
@@ -845,7 +858,9 @@ __global__ __launch_bounds__(64) void k_zstd_split(const uint8_t* __restrict__ s
                 it.payload = b;
                 it.kind = kind;
                 it.aux = (uint32_t)(d - p) + 2u * i * ZB_MAX_UNITS;
-                it.pad = dir == 3u ? 1u : 0u; // kind 3: the frame's blocks may use block-local repeat-offset codes
+                // kind 3: bit 0 the frame's blocks may use block-local repeat-offset codes; bit 1 (version 4) the piece's matches may
+                // reach into the pieces before it: k_zstd_execute runs such a frame's pieces as a chain
+                it.pad = (dir == 3u ? 1u : 0u) | (dir == 4u ? 2u : 0u);
                 out[i] = it;
             }
             if ((uint64_t)pos + total > (uint64_t)blk.size)
@@ -878,6 +893,52 @@ __global__ __launch_bounds__(64) void k_zstd_split(const uint8_t* __restrict__ s
             out = items + base;
         }
     }
+}
+
+// The item list in LINK-MAJOR order (round 5): row k = the pieces whose index in their frame is k modulo ZCHAIN, of every payload
+// (whole-payload items: row 0) -- all chain heads first, then every chain's second piece, ...  The rounds below go over the items in
+// this order, so that the chains of the frames whose pieces depend on each other (trailer version 4) all run side by side: the heads
+// fill the machine, the workgroups of a launch are dispatched in order, a piece only ever waits for a workgroup that was dispatched
+// before it (or belongs to an earlier launch), and by the time a row's workgroups get a slot most of the row before is done.  (Measured
+// with the rows = piece indices: one link of one chain per frame at a time, 512 waves at work: 134 GB/s on "mixed" at 512 blocks.)
+// Three small kernels: count the rows, scan them, fill (the order inside a row is whatever the atomics give: every kernel of a round
+// uses the same table).
+__global__ void k_zstd_rows(const ZItem* __restrict__ items, const uint32_t* __restrict__ item_count, uint32_t nrows, uint32_t* __restrict__ row_cnt,
+                            uint32_t* __restrict__ row_start, uint32_t* __restrict__ perm, uint32_t phase)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = *item_count;
+    if (phase == 1u) // exclusive scan of the row counts, one wave
+    {
+        uint32_t base = 0;
+        for (uint32_t r0 = 0; r0 < nrows; r0 += 64u)
+        {
+            const uint32_t r = r0 + threadIdx.x;
+            const uint32_t c = r < nrows ? row_cnt[r] : 0u;
+            uint32_t incl = c;
+            for (int d = 1; d < 64; d <<= 1)
+            {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if ((int)threadIdx.x >= d)
+                    incl += o;
+            }
+            if (r < nrows)
+            {
+                row_start[r] = base + incl - c;
+                row_cnt[r] = 0u; // (the fill counts again)
+            }
+            base += __shfl(incl, 63, 64);
+        }
+        return;
+    }
+    if (i >= n)
+        return;
+    const ZItem it = items[i];
+    const uint32_t k = it.kind == 2u || it.kind == 3u ? (it.out0 / ZB) % nrows : 0u;
+    if (phase == 0u)
+        atomicAdd(&row_cnt[k], 1u);
+    else
+        perm[row_start[k] + atomicAdd(&row_cnt[k], 1u)] = i;
 }
 
 // What k_zstd_prepare leaves for k_zstd_execute about one piece
@@ -1154,7 +1215,7 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
                                                          const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
                                                          uint8_t* __restrict__ lit_scratch, uint64_t* __restrict__ rec_scratch,
                                                          ZPrep* __restrict__ prep, const uint32_t* __restrict__ out_sizes,
-                                                         uint32_t* __restrict__ retry, uint32_t* __restrict__ ticket)
+                                                         uint32_t* __restrict__ retry, uint32_t* __restrict__ ticket, const uint32_t* __restrict__ perm)
 {
     __shared__ ZdShared sh;
     __shared__ uint4 s_streams[4 * ZB_MAX_UNITS]; // {source offset inside the piece, bytes, literal offset, symbols}
@@ -1173,9 +1234,9 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
         __builtin_amdgcn_wave_barrier();
         uint32_t t = atomicAdd(ticket, lane == 0 ? 1u : 0u);
         t = __builtin_amdgcn_readfirstlane(t);
-        const uint32_t i = item0 + t;
-        if (i >= nitems)
+        if (item0 + t >= nitems)
             break;
+        const uint32_t i = perm[item0 + t]; // (piece-major order: k_zstd_rows)
         const ZItem it = items[i];
         if (it.kind != 3u)
             continue;
@@ -1185,7 +1246,7 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
             g_zb_last[blockIdx.x] = wall_clock64();
 #endif
         const ZBlock blk = blocks[it.payload];
-        const uint32_t slot = i - item0;
+        const uint32_t slot = t;
         uint8_t* lits = lit_scratch + (uint64_t)slot * (ZD_LIT_MAX + 64u);
         uint64_t* recs = rec_scratch + (uint64_t)slot * ZREC_MAX;
         const uint8_t* p = src + it.src_off;
@@ -2288,11 +2349,11 @@ __global__ __launch_bounds__(64) void k_zstd_blk_sequences(const uint8_t* __rest
 // the directory): a copy / a fill, 256 threads per piece -- no reason to send them through the decoder core.
 __global__ __launch_bounds__(256) void k_zstd_plain_pieces(const uint8_t* __restrict__ src, const ZBlock* __restrict__ blocks, const ZItem* __restrict__ items,
                                                            const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
-                                                           uint8_t* __restrict__ dst, ZPrep* __restrict__ prep)
+                                                           uint8_t* __restrict__ dst, ZPrep* __restrict__ prep, const uint32_t* __restrict__ perm)
 {
-    const uint32_t i = item0 + blockIdx.x;
-    if (i >= item1 || i >= *item_count)
+    if (item0 + blockIdx.x >= item1 || item0 + blockIdx.x >= *item_count)
         return;
+    const uint32_t i = perm[item0 + blockIdx.x];
     const ZItem it = items[i];
     if (it.kind != 2u || it.aux == 0u)
         return;
@@ -2880,14 +2941,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                      const uint32_t* __restrict__ item_count, uint32_t item0, uint32_t item1,
                                                      uint8_t* __restrict__ dst, const uint8_t* __restrict__ lit_scratch,
                                                      const uint64_t* __restrict__ tables, const ZPrep* __restrict__ prep,
-                                                     uint32_t* __restrict__ status_out, uint32_t* __restrict__ retry, uint32_t px)
+                                                     uint32_t* __restrict__ status_out, uint32_t* __restrict__ retry, uint32_t px,
+                                                     const uint32_t* __restrict__ perm, uint32_t* __restrict__ done)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZX_RING];
     __shared__ __attribute__((aligned(16))) uint8_t s_lit[ZX_LIT];
     __shared__ uint32_t s_ia[64], s_om[64]; // (px: the batch's prefix sums, zo_batch_bytes)
-    const uint32_t i = item0 + blockIdx.x;
-    if (i >= item1 || i >= *item_count)
+    if (item0 + blockIdx.x >= item1 || item0 + blockIdx.x >= *item_count)
         return;
+    const uint32_t i = perm ? perm[item0 + blockIdx.x] : item0 + blockIdx.x; // (piece-major order: k_zstd_rows)
     const ZItem it = items[i];
     if (it.kind != (RECS ? 3u : 2u))
         return;
@@ -2896,7 +2958,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         return;
     const int lane = threadIdx.x;
     const ZBlock blk = blocks[it.payload];
-    const uint32_t slot = i - item0;
+    const uint32_t slot = blockIdx.x;
+    // A piece of a frame whose pieces depend on each other (trailer version 4: it.pad bit 1) may copy from the pieces before it: it is
+    // executed on bytes through memory with positions relative to the FRAME, and not before the piece in front of it is complete --
+    // the items of a payload are consecutive, the piece before is item i - 1, and in the piece-major order its workgroup was dispatched
+    // before this one (an earlier row), or belongs to an earlier launch.  Pieces the executor does not run (Raw / RLE pieces of
+    // k_zstd_plain_pieces: an earlier kernel of the round; pieces given back by k_zstd_sub_entropy: the payload goes to the serial decoder
+    // anyway) are not waited for.
+    const bool in_chain = RECS && done != nullptr && (it.pad & 2u) != 0u;  // (tells the piece behind it when it is done)
+    const uint32_t link = in_chain ? (it.out0 / ZB) % ZCHAIN : 0u;          // my place in the chain: 0 = its head, which waits for nobody
+    const bool chained = link != 0u;
+    const uint32_t frame_pos = link * ZB; // position of the piece's first byte in what zo_batch_bytes addresses: the chain from its head
+    bool pred_failed = false;
+    if (chained)
+    {
+        const ZItem before = items[i - 1u];
+        if (before.kind == 3u && before.payload == it.payload)
+        {
+            const uint32_t st = prep[i - 1u].status;
+            if (st == ZP_READY)
+            {
+                // (relaxed polls: an acquire per poll would invalidate the CU's vector cache under the waves that are at work; one
+                // acquire fence once the flag is up)
+                uint32_t f;
+                while ((f = __hip_atomic_load(&done[i - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u)
+                    __builtin_amdgcn_s_sleep(32);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                pred_failed = f != 1u;
+            }
+            else if (st != ZP_DONE)
+                pred_failed = true;
+        }
+    }
+    if (chained)
+        px = 2u; // (bytes through memory: a source in an earlier piece is an address like any other)
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(tables + (uint64_t)slot * 3u * ZT_ENTRIES); // states are byte offsets into this
     const uint64_t* recs = tables + (uint64_t)slot * ZREC_MAX;
     const uint8_t* lits = lit_scratch + (uint64_t)slot * (ZD_LIT_MAX + 64u);
@@ -2921,7 +3016,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const uint64_t base_bit = pr.bits_off * 8ull;
     const uint32_t* arena = reinterpret_cast<const uint32_t*>(src - ((uintptr_t)src & 3u)); // dword view; bit b of src = bit b + 8 * skew here
     const uint64_t skew_bits = 8ull * ((uintptr_t)src & 3u);
-    bool bad = false;
+    bool bad = pred_failed;
     uint32_t pos = 0; // bits of the stream not consumed yet
     if (!RECS)
     {
@@ -3057,9 +3152,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const uint32_t i_l = zx_scan_incl(ll), i_a = zx_scan_incl(ll + ml);
             const uint32_t batch_ll = (uint32_t)__builtin_amdgcn_readlane((int)i_l, 63), batch_adv = (uint32_t)__builtin_amdgcn_readlane((int)i_a, 63);
             const bool wrong = act && (r_off <= 3u || ll > 131072u || ml > 131075u || litpos + i_l > pr.nlit || produced + i_a > pr.expect ||
-                                       off > produced + i_a - ml);
+                                       off > frame_pos + produced + i_a - ml);
             if (__builtin_amdgcn_ballot_w64(wrong) ||
-                !zo_batch_bytes(out, lits, lane, act, ll, litpos + (i_l - ll), ml, off, i_a, produced, s_ia, s_om))
+                !zo_batch_bytes(out - frame_pos, lits, lane, act, ll, litpos + (i_l - ll), ml, off, i_a, frame_pos + produced, s_ia, s_om))
             {
                 bad = true;
                 break;
@@ -3099,6 +3194,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         status_out[(size_t)i * (sizeof(ZPrep) / 4u)] = ZP_SERIAL; // = prep[i].status (a second view: `prep` itself is read-only here)
         if (RECS)
             retry[it.payload] = 1u; // a run of sub-blocks has no serial piece decoder: the whole payload, serially
+    }
+    if (in_chain)
+    {
+        // the piece's bytes are in memory before the next piece of the chain is told so (1), or that it need not bother (2)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0)
+            __hip_atomic_store(&done[i], bad ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -3540,9 +3643,25 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
         const uint32_t a = (uint32_t)env_ablate.get();
         LTHIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_zd_ablate), &a, sizeof(a)));
     }
+    // the items in piece-major order (k_zstd_rows), and a done flag per item for the frames whose pieces form a chain
+    const uint32_t nrows = ZCHAIN;
+    void* d_pm;
+    if ((err = lthip_scratch(ctx, S_Z_PERM, 4 * (2 * (size_t)nitems + 2 * (size_t)nrows + 16), &d_pm)))
+        return err;
+    uint32_t* d_perm = (uint32_t*)d_pm;
+    uint32_t* d_done = d_perm + nitems;
+    uint32_t* d_row_cnt = d_done + nitems;
+    uint32_t* d_row_start = d_row_cnt + nrows;
+    LTHIP_CHECK(ctx, hipMemsetAsync(d_done, 0, 4 * ((size_t)nitems + nrows), ctx->stream));
     LaunchTimer t(ctx, LTHIP_K_OTHER);
     hipLaunchKernelGGL(k_zstd_split, dim3(block_count), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                        block_count, (ZItem*)d_items, d_count, d_out_sizes, dbg, d_fitems, d_fnb, d_flist);
+    {
+        const uint32_t g = (uint32_t)((nitems + 255) / 256);
+        hipLaunchKernelGGL(k_zstd_rows, dim3(g), dim3(256), 0, ctx->stream, (const ZItem*)d_items, (const uint32_t*)d_count, nrows, d_row_cnt, d_row_start, d_perm, 0u);
+        hipLaunchKernelGGL(k_zstd_rows, dim3(1), dim3(64), 0, ctx->stream, (const ZItem*)d_items, (const uint32_t*)d_count, nrows, d_row_cnt, d_row_start, d_perm, 1u);
+        hipLaunchKernelGGL(k_zstd_rows, dim3(g), dim3(256), 0, ctx->stream, (const ZItem*)d_items, (const uint32_t*)d_count, nrows, d_row_cnt, d_row_start, d_perm, 2u);
+    }
     hipLaunchKernelGGL(k_zstd_decode<false>, dim3(nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                        (const ZItem*)d_items, (const uint32_t*)d_count, (uint8_t*)d_dst, (uint8_t*)d_lits, d_out_sizes, (const ZPrep*)nullptr);
     LTHIP_LAUNCH_CHECK(ctx);
@@ -3572,18 +3691,18 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
             const uint32_t i1 = (uint32_t)(i0 + per_round < nitems ? i0 + per_round : nitems);
             const uint32_t n = i1 - (uint32_t)i0;
             hipLaunchKernelGGL(k_zstd_plain_pieces, dim3(n), dim3(256), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
-                               (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, d_prep);
+                               (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, d_prep, (const uint32_t*)d_perm);
             LTHIP_LAUNCH_CHECK(ctx);
 #ifdef LTHIP_ABLATIONS
             if (!(dbg & 4u))
             {
                 hipLaunchKernelGGL(k_zstd_prepare, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                                    (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, (uint8_t*)d_plits,
-                                   (uint64_t*)d_tabs, d_prep, (const uint32_t*)d_out_sizes);
+                                   (uint64_t*)d_tabs, d_prep, (const uint32_t*)d_out_sizes, (const uint32_t*)d_perm);
                 LTHIP_LAUNCH_CHECK(ctx);
                 hipLaunchKernelGGL(k_zstd_execute<false>, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                                    (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, (const uint8_t*)d_plits,
-                                   (const uint64_t*)d_tabs, (const ZPrep*)d_prep, &d_prep->status, d_retry, 0u);
+                                   (const uint64_t*)d_tabs, (const ZPrep*)d_prep, &d_prep->status, d_retry, 0u, (const uint32_t*)d_perm, (uint32_t*)nullptr);
                 LTHIP_LAUNCH_CHECK(ctx);
             }
 #else
@@ -3591,11 +3710,11 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
 #endif
             hipLaunchKernelGGL(k_zstd_sub_entropy, dim3(n < nwg ? n : nwg), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                                (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_plits, (uint64_t*)d_recs, d_prep,
-                               (const uint32_t*)d_out_sizes, d_retry, d_tickets + (size_t)(i0 / per_round));
+                               (const uint32_t*)d_out_sizes, d_retry, d_tickets + (size_t)(i0 / per_round), (const uint32_t*)d_perm);
             LTHIP_LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(k_zstd_execute<true>, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)d_src, (const ZBlock*)d_blocks,
                                (const ZItem*)d_items, (const uint32_t*)d_count, (uint32_t)i0, i1, (uint8_t*)d_dst, (const uint8_t*)d_plits,
-                               (const uint64_t*)d_recs, (const ZPrep*)d_prep, &d_prep->status, d_retry, zpx);
+                               (const uint64_t*)d_recs, (const ZPrep*)d_prep, &d_prep->status, d_retry, zpx, (const uint32_t*)d_perm, d_done);
             LTHIP_LAUNCH_CHECK(ctx);
         }
     }

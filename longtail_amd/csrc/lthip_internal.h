@@ -90,6 +90,7 @@ enum ScratchSlot
     S_B3_WINDOWS,   // first range of every window of leaf slots (parents kernel)
     S_Z_FR,         // zstd decoder, frames of other encoders: per block {history in, start, history out}
     S_Z_ORG,        // ... and the origins (u32 per byte of output) of the payloads in flight
+    S_Z_PERM,       // zstd decoder: the items in piece-major order, per-row counters, per-item done flags
     S_XCHG,         // multi-GPU exchange: range tables of lthip_exchange_reorder
     S_XCHG2,        // ... and the job tables of lthip_job_ordinals
     S_COUNT
@@ -182,6 +183,9 @@ int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out);
 // events from lthip_sync_event and must make the main stream wait for the side stream before they return).
 int lthip_second_stream(lthip_ctx* ctx, hipStream_t* out);
 hipEvent_t lthip_sync_event(lthip_ctx* ctx);
+// zstd frames of the "max" setting: 128 KiB pieces per chain (the match finder -- k_lz4.hip -- lets a piece see the one before it except
+// in every LTHIP_ZSTD_CHAIN-th piece of a block; the decoder -- k_zstd.hip -- runs the pieces in between in order)
+constexpr uint32_t LTHIP_ZSTD_CHAIN = 8;
 uint64_t lthip_codec_batch_bytes(); // input bytes per internal codec batch (LTHIP_BATCH_BYTES, default 8 GiB)
 uint64_t lthip_origin_budget_mib(); // (LTHIP_ORIGIN_MIB) arena of the restore paths' execution on origins (k_lz4.hip)
 // Host table -> device without stalling the caller: the bytes are copied into one of a ring of pinned staging buffers and

@@ -910,10 +910,11 @@ def test_zstd_repcode_frames_stay_on_the_lane_decoder(gpu_abl, oracle, ref, monk
 
 def test_zstd_settings_are_three_parses(gpu, oracle, ref, monkeypatch):
     """LTHIP_ZSTD_Q_DEFAULT / _HIGH / _MAX ('ztd1'/'ztd2', 'ztd4', 'ztd3'/'ztd5' of lib/zstd/longtail_zstd.c:11-28): "high" gives every
-    redundant 32 KiB half of a piece the half in front of it as history (k_lz4_pair_halves), "max" also reads the private table again
-    after a step's inserts.  Both are smaller than the default on every synthetic kind with structure, all three decode with the
-    reference, and with this library's lane-per-block decoder WITHOUT a payload going back to the serial one: the history never
-    leaves the 128 KiB piece, so the pieces stay independent."""
+    redundant 32 KiB half of a piece the half in front of it as history (k_lz4_pair_halves) -- inside the piece: its pieces stay
+    independent --, "max" gives it to EVERY redundant half but a block's first (history across the pieces: trailer version 4, the
+    decoder runs such a frame's pieces as a chain) and reads the private table again after a step's inserts.  Both are smaller than
+    the default on every synthetic kind with structure, all three decode with the reference, and with this library's lane-per-block
+    decoder WITHOUT a payload going back to the serial one."""
     blocks = [oracle.synth((2 << 20) + 4097 * k, 70 + k, k) for k in (1, 11, 12, 13)]
     blocks.append(oracle.synth(300000, 5, 12))
     blocks.append(oracle.synth(1 << 20, 6, 0))  # incompressible: the same at every setting
@@ -931,5 +932,80 @@ def test_zstd_settings_are_three_parses(gpu, oracle, ref, monkeypatch):
     for i in range(5):
         assert sizes[1][i] < sizes[0][i] and sizes[2][i] < sizes[0][i], (i, [s[i] for s in sizes])
     assert sizes[0][5] == sizes[1][5] == sizes[2][5]
-    # "tokens": the vocabulary's first occurrences inside a half are what the history buys -- more than 8 %
-    assert sizes[1][2] < 0.92 * sizes[0][2]
+    # "tokens": the vocabulary's first occurrences inside a half are what the history buys -- more than 8 %, and more than 8 % again
+    # when a piece's first half has it too
+    assert sizes[1][2] < 0.92 * sizes[0][2] and sizes[2][2] < 0.92 * sizes[1][2]
+
+
+def test_zstd_max_setting_frames_are_chains_of_pieces(gpu, gpu_abl, oracle, ref, monkeypatch):
+    """'max' ('ztd3' / 'ztd5'): matches reach into the piece before, the frame says so (directory trailer version 4) and
+    k_zstd_execute<true> runs its pieces in order -- a piece waits for the flag of the piece in front of it; the items of a call are
+    taken in piece-major order (k_zstd_rows) so that all frames' chains run side by side, also across the rounds of a large call.
+    (1) many frames of ragged sizes in one call, more pieces than one round holds: the data, no payload back to the serial decoder;
+    (2) the version byte forged: a chain frame marked independent (2) goes back to the serial decoder and decodes, an independent
+        frame marked as a chain (4) decodes as a chain;
+    (3) damaged chain frames: never accepted where the serial decoder (ablation build, LTHIP_ZSTD_DBG=1) rejects, same bytes where
+        accepted -- a piece that fails tells the pieces behind it."""
+    rng = np.random.default_rng(33)
+    sizes = [(8 << 20) + 77, 131072, 131073, 4097, 100, 600000, (3 << 20) + 5] + [8 << 20] * 132  # 132 x 64 + ... pieces: more than one round of 8192
+    kinds = [1, 12, 11, 13, 1, 12, 1] + [1, 11, 12] * 44
+    datas = [oracle.synth(n, 500 + i, k) for i, (n, k) in enumerate(zip(sizes, kinds))]
+    assert sum((n + 131071) // 131072 for n in sizes) > 8192 + 64
+    frames = gpu_zstd(gpu, datas, quality=2)
+    for f, d in zip(frames, datas):
+        nu = (len(d) + 4095) // 4096
+        assert bytes(f[-(12 + 2 * nu) :][8:12]) == b"LTP\x04"
+    for f, d in list(zip(frames, datas))[:9]:
+        err, out = ref.decompress(1, f, len(d))
+        assert err == 0 and len(out) == len(d) and (out == d).all()
+    got = gpu_zstd_decode(gpu, frames, [len(d) for d in datas])
+    assert all(g is not None and len(g) == len(d) and (g == d).all() for g, d in zip(got, datas))
+    stats = gpu.zstd_last_decode_stats()
+    assert stats[0] == len(datas) and stats[2] == 0, stats
+    # (2) forged version bytes
+    forged, raws = [], []
+    for f, d in list(zip(frames, datas))[:7]:
+        x = f.copy()
+        x[len(x) - 2 * ((len(d) + 4095) // 4096) - 1] = 2
+        forged.append(x)
+        raws.append(d)
+    plain = gpu_zstd(gpu, datas[:7], quality=1)
+    for f, d in zip(plain, datas[:7]):
+        x = f.copy()
+        k = len(x) - 2 * ((len(d) + 4095) // 4096) - 1
+        assert x[k] == 2
+        x[k] = 4
+        forged.append(x)
+        raws.append(d)
+    got = gpu_zstd_decode(gpu, forged, [len(d) for d in raws])
+    assert all(g is not None and len(g) == len(d) and (g == d).all() for g, d in zip(got, raws))
+    stats = gpu.zstd_last_decode_stats()
+    assert stats[2] >= 3, stats  # (the large chain frames marked independent: cross-piece offsets are not what version 2 promises)
+    # (3) damage
+    bad, caps = [], []
+    for f, d in list(zip(frames, datas))[:8]:
+        nu = (len(d) + 4095) // 4096
+        tl = 12 + 2 * nu
+        for _ in range(20):
+            x = f.copy()
+            k = rng.integers(0, 4)
+            if k == 0 and len(x) - tl > 14:
+                x = np.concatenate([x[: rng.integers(13, len(x) - tl)], x[-tl:]])
+            elif k == 1:
+                x[len(x) - 2 * nu + rng.integers(0, 2 * nu)] ^= np.uint8(1 << rng.integers(0, 8))
+            else:
+                for _ in range(int(rng.integers(1, 4))):
+                    x[rng.integers(0, len(x) - tl)] ^= np.uint8(1 << rng.integers(0, 8))
+            bad.append(x)
+            caps.append(len(d))
+    fast = gpu_zstd_decode(gpu, bad, caps)
+    monkeypatch.setenv("LTHIP_ZSTD_DBG", "1")
+    gpu_abl.lib.dll.lthip_debug_reload_env()
+    serial = gpu_zstd_decode(gpu_abl, bad, caps)
+    monkeypatch.delenv("LTHIP_ZSTD_DBG")
+    gpu_abl.lib.dll.lthip_debug_reload_env()
+    for i, (p_out, s_out) in enumerate(zip(fast, serial)):
+        assert (p_out is None) == (s_out is None), i
+        if p_out is not None:
+            assert len(p_out) == len(s_out) and (p_out == s_out).all(), i
+    assert sum(o is None for o in fast) > 20
