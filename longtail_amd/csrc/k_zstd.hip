@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(64) void k_zstd_sub_entropy(const uint8_t* __restri
         t = __builtin_amdgcn_readfirstlane(t);
         if (item0 + t >= nitems)
             break;
-        const uint32_t i = perm[item0 + t]; // (piece-major order: k_zstd_rows)
+        const uint32_t i = perm[item0 + t]; // (link-major order: k_zstd_rows)
         const ZItem it = items[i];
         if (it.kind != 3u)
             continue;
@@ -2949,7 +2949,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     __shared__ uint32_t s_ia[64], s_om[64]; // (px: the batch's prefix sums, zo_batch_bytes)
     if (item0 + blockIdx.x >= item1 || item0 + blockIdx.x >= *item_count)
         return;
-    const uint32_t i = perm ? perm[item0 + blockIdx.x] : item0 + blockIdx.x; // (piece-major order: k_zstd_rows)
+    const uint32_t i = perm ? perm[item0 + blockIdx.x] : item0 + blockIdx.x; // (link-major order: k_zstd_rows)
     const ZItem it = items[i];
     if (it.kind != (RECS ? 3u : 2u))
         return;
@@ -2961,7 +2961,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const uint32_t slot = blockIdx.x;
     // A piece of a frame whose pieces depend on each other (trailer version 4: it.pad bit 1) may copy from the pieces before it: it is
     // executed on bytes through memory with positions relative to the FRAME, and not before the piece in front of it is complete --
-    // the items of a payload are consecutive, the piece before is item i - 1, and in the piece-major order its workgroup was dispatched
+    // the items of a payload are consecutive, the piece before is item i - 1, and in the link-major order its workgroup was dispatched
     // before this one (an earlier row), or belongs to an earlier launch.  Pieces the executor does not run (Raw / RLE pieces of
     // k_zstd_plain_pieces: an earlier kernel of the round; pieces given back by k_zstd_sub_entropy: the payload goes to the serial decoder
     // anyway) are not waited for.
@@ -3643,7 +3643,7 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
         const uint32_t a = (uint32_t)env_ablate.get();
         LTHIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_zd_ablate), &a, sizeof(a)));
     }
-    // the items in piece-major order (k_zstd_rows), and a done flag per item for the frames whose pieces form a chain
+    // the items in link-major order (k_zstd_rows), and a done flag per item for the frames whose pieces form a chain
     const uint32_t nrows = ZCHAIN;
     void* d_pm;
     if ((err = lthip_scratch(ctx, S_Z_PERM, 4 * (2 * (size_t)nitems + 2 * (size_t)nrows + 16), &d_pm)))
