@@ -2960,7 +2960,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const ZBlock blk = blocks[it.payload];
     const uint32_t slot = blockIdx.x;
     // A piece of a frame whose pieces depend on each other (trailer version 4: it.pad bit 1) may copy from the pieces before it: it is
-    // executed on bytes through memory with positions relative to the FRAME, and not before the piece in front of it is complete --
+    // executed on bytes through memory with positions relative to the start of the piece before it, and not before that piece is complete --
     // the items of a payload are consecutive, the piece before is item i - 1, and in the link-major order its workgroup was dispatched
     // before this one (an earlier row), or belongs to an earlier launch.  Pieces the executor does not run (Raw / RLE pieces of
     // k_zstd_plain_pieces: an earlier kernel of the round; pieces given back by k_zstd_sub_entropy: the payload goes to the serial decoder
@@ -2968,7 +2968,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const bool in_chain = RECS && done != nullptr && (it.pad & 2u) != 0u;  // (tells the piece behind it when it is done)
     const uint32_t link = in_chain ? (it.out0 / ZB) % ZCHAIN : 0u;          // my place in the chain: 0 = its head, which waits for nobody
     const bool chained = link != 0u;
-    const uint32_t frame_pos = link * ZB; // position of the piece's first byte in what zo_batch_bytes addresses: the chain from its head
+    // position of the piece's first byte in what zo_batch_bytes addresses: the piece BEFORE it and itself.  (The encoder's matches reach
+    // less than 64 KiB back; a frame that claims more -- forged, damaged -- goes to the serial decoder: bytes further back would need the
+    // flag of a piece this one does not wait for when the piece in between is a Raw / RLE piece.)
+    const uint32_t frame_pos = chained ? ZB : 0u;
     bool pred_failed = false;
     if (chained)
     {
