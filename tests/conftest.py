@@ -77,8 +77,12 @@ def gpu_abl(hiplib):
     import torch
 
     assert torch.cuda.is_available(), "GPU tests need a GPU"
-    from longtail_amd.lib import Context, load_ablations
+    from longtail_amd.lib import ABLATIONS_LIB_PATH, Context, load_ablations
 
+    if not ABLATIONS_LIB_PATH.exists() and not os.environ.get("LTHIP_LIB_PATH"):
+        import subprocess
+
+        subprocess.run(["make", "-C", str(ROOT), "-j", str(max(2, os.cpu_count() or 2)), "ablations"], check=True, capture_output=True)
     ctx = Context(0, lib=load_ablations())
     yield ctx
     ctx.close()
