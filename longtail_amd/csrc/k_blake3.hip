@@ -238,26 +238,73 @@ __device__ __forceinline__ void b3_parent(uint32_t* __restrict__ left, const uin
 // memory: the plugin layer's HashBuffer of a path string, a chunk-hash array or a block's hash array (src/longtail.c:1272, 2522,
 // 3757), which used to cost two uploads, seven launches (counts, scan, leaves, parents) and a download per call.  Lane l hashes leaf
 // l byte by byte (speed is irrelevant here: the call is a bus round trip), lane 0 reduces the tree.
+constexpr uint32_t B3_ONE_PITCH = 1024u + 4u; // LDS bytes per staged leaf: lanes read their leaves a dword at a time, 257 dwords apart
 __global__ __launch_bounds__(64) void k_blake3_one(const uint8_t* __restrict__ in, uint32_t len, uint64_t* __restrict__ out)
 {
-    __shared__ uint32_t s_cv[64 * 8];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_one[]; // [8 x 64 chaining values][leaves x B3_ONE_PITCH bytes of input]
+    uint32_t* s_cv = s_one;
+    uint32_t* s_in = s_one + 64 * 8;
     const uint32_t lane = threadIdx.x;
     const uint32_t nleaf = leaves_of(len);
+    // The input is the caller's PINNED HOST block as a rule (plugin_hash.c): a lane that reads its 1 KiB leaf where it lies pays a
+    // trip over the link per load, sixteen dependent rounds of them (byte loads: 115 us per 1 KiB call, 16-byte loads: 47).  So the wave
+    // first brings the whole input into LDS with coalesced 16-byte loads that are all in flight together, then every lane hashes its
+    // leaf from there (tools/hash_latency.py: 8 KiB 130 -> 31 us per HashBuffer call; 17 of them are the launch and the wait).
+    {
+        const uint32_t nvec = (((uintptr_t)in & 15u) == 0u) ? len >> 4 : 0u;
+        const uint4* in4 = reinterpret_cast<const uint4*>(in);
+        for (uint32_t v0 = 0; v0 < nvec; v0 += 64u * 8u)
+        {
+            uint4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+                const uint32_t v = v0 + (uint32_t)u * 64u + lane;
+                q[u] = v < nvec ? in4[v] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+                const uint32_t v = v0 + (uint32_t)u * 64u + lane;
+                if (v < nvec)
+                {
+                    uint32_t* d = s_in + (v >> 6) * (B3_ONE_PITCH / 4u) + (v & 63u) * 4u; // (64 vectors per leaf)
+                    d[0] = q[u].x;
+                    d[1] = q[u].y;
+                    d[2] = q[u].z;
+                    d[3] = q[u].w;
+                }
+            }
+        }
+        for (uint32_t j = (nvec << 4) + lane; j < len; j += 64u) // the tail (or everything, from an unaligned address): bytes
+            reinterpret_cast<uint8_t*>(s_in)[(j >> 10) * B3_ONE_PITCH + (j & 1023u)] = in[j];
+    }
+    __syncthreads();
     if (lane < nleaf)
     {
         const uint32_t llen = len - (lane << 10) < 1024u ? len - (lane << 10) : 1024u;
-        const uint8_t* p = in + ((size_t)lane << 10);
+        const uint32_t* pw = s_in + lane * (B3_ONE_PITCH / 4u);
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(pw);
         const uint32_t nblocks = llen ? (llen + 63u) >> 6 : 1u;
         uint32_t cv[8] = {B3_IV0, B3_IV1, B3_IV2, B3_IV3, B3_IV4, B3_IV5, B3_IV6, B3_IV7};
         for (uint32_t b = 0; b < nblocks; ++b)
         {
             const uint32_t bl = llen - b * 64u < 64u ? llen - b * 64u : 64u;
             uint32_t m[16];
+            if (bl == 64u)
+            {
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                m[i] = 0u;
-            for (uint32_t j = 0; j < bl; ++j)
-                m[j >> 2] |= (uint32_t)p[b * 64u + j] << (8u * (j & 3u));
+                for (int i = 0; i < 16; ++i)
+                    m[i] = pw[b * 16u + (uint32_t)i];
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    m[i] = 0u;
+                for (uint32_t j = 0; j < bl; ++j)
+                    m[j >> 2] |= (uint32_t)p[b * 64u + j] << (8u * (j & 3u));
+            }
             uint32_t fl = b == 0 ? (uint32_t)F_CHUNK_START : 0u;
             if (b + 1 == nblocks)
                 fl |= (uint32_t)F_CHUNK_END | (nleaf == 1u ? (uint32_t)F_ROOT : 0u);
@@ -268,16 +315,18 @@ __global__ __launch_bounds__(64) void k_blake3_one(const uint8_t* __restrict__ i
             s_cv[lane * 8 + i] = cv[i];
     }
     __syncthreads();
-    if (lane == 0)
+    // the tree, level by level: the merges of a level are independent (left-heavy tree == in-place stride doubling with the odd node
+    // carried), lane j takes the j-th of them (64 leaves: six rounds instead of 63 merges on one lane)
+    for (uint32_t stride = 1; stride < nleaf; stride <<= 1)
     {
-        for (uint32_t stride = 1; stride < nleaf; stride <<= 1)
-        {
-            const uint32_t last = (stride << 1) >= nleaf;
-            for (uint32_t k = 0; k + stride < nleaf; k += stride << 1)
-                b3_parent(s_cv + k * 8u, s_cv + (k + stride) * 8u, (uint32_t)F_PARENT | (last ? (uint32_t)F_ROOT : 0u));
-        }
-        *out = (uint64_t)s_cv[0] | ((uint64_t)s_cv[1] << 32);
+        const uint32_t last = (stride << 1) >= nleaf;
+        const uint32_t k = lane * (stride << 1);
+        if (k + stride < nleaf)
+            b3_parent(s_cv + k * 8u, s_cv + (k + stride) * 8u, (uint32_t)F_PARENT | (last ? (uint32_t)F_ROOT : 0u));
+        __syncthreads();
     }
+    if (lane == 0)
+        *out = (uint64_t)s_cv[0] | ((uint64_t)s_cv[1] << 32);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -649,7 +698,18 @@ int lthip_launch_blake3_one(lthip_ctx* ctx, const void* in, uint32_t len, uint64
     if (len > 65536u)
         return lthip_fail(ctx, EINVAL, "blake3_one", "input above 64 KiB");
     LaunchTimer t(ctx, LTHIP_K_B3_LEAF);
-    hipLaunchKernelGGL(k_blake3_one, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t*)in, len, out);
+    const size_t lds = 64 * 8 * 4 + (size_t)(len ? (len + 1023u) >> 10 : 1u) * B3_ONE_PITCH;
+    if (lds > 64u * 1024u)
+    {
+        static bool granted[64] = {}; // per device: more than 64 KiB of dynamic LDS has to be granted explicitly
+        if (ctx->device < 0 || ctx->device >= 64 || !granted[ctx->device])
+        {
+            LTHIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_blake3_one), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            if (ctx->device >= 0 && ctx->device < 64)
+                granted[ctx->device] = true;
+        }
+    }
+    hipLaunchKernelGGL(k_blake3_one, dim3(1), dim3(64), lds, ctx->stream, (const uint8_t*)in, len, out);
     LTHIP_LAUNCH_CHECK(ctx);
     return 0;
 }
