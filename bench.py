@@ -923,7 +923,8 @@ def main():
         secondary = {}
         for name, over in (("compressible", dict(kind="mixed")), ("dedup", dict(kind="mixed", dups=True)),
                            ("north_star_tree", dict(tree="mixed-sizes")),
-                           ("north_star_tree_compressible", dict(tree="mixed-sizes", kind="mixed"))):
+                           ("north_star_tree_compressible", dict(tree="mixed-sizes", kind="mixed")),
+                           ("zstd_compressible", dict(kind="mixed", codec="zstd"))):  # (the settings id of --zstd-settings: 'ztd2' by default)
             r = b.run(dict(cfg, **over), max(1, min(args.steps, 2)), 1)
             secondary[name] = {"value": round(r["value"], 3), "unit": "GB/s", "ms_per_step": round(r["ms_per_step"], 3),
                                "workload": r["workload"], "ratio": r["result"]["ratio"], "phase_ms": r["phase_ms"],
