@@ -2420,6 +2420,7 @@ struct ZxOut
     uint8_t* out_al;       // piece output byte q is out_al[q + g]
     const uint8_t* lit_al; // literal p is lit_al[p + lh]
     uint32_t g, lh, nlit, cap;
+    uint32_t lo; // aligned offset of the first byte that is this piece's to write (g; a chain member: the piece before it lies below)
     int lane;
     uint32_t op, flushed, drained;
     int32_t lwa; // aligned literal offset of s_lit[0]
@@ -2438,11 +2439,11 @@ struct ZxOut
                 if (P >= stop)
                     continue;
                 const uint8_t* r = s_ring + (P & (ZX_RING - 1u));
-                if (P >= g && P + 16u <= lim)
+                if (P >= lo && P + 16u <= lim)
                     *reinterpret_cast<uint4*>(out_al + P) = *reinterpret_cast<const uint4*>(r);
                 else
                     for (uint32_t k = 0; k < 16u; ++k)
-                        if (P + k >= g && P + k < lim)
+                        if (P + k >= lo && P + k < lim)
                             out_al[P + k] = r[k];
             }
             flushed = stop;
@@ -2598,7 +2599,7 @@ struct ZxBits
 // literal buffer / the output the ring belongs to (updated); nlit_total / out_limit: how many there are / may be.
 __device__ __forceinline__ void zx_batch(ZxOut& zx, uint8_t* s_ring, uint8_t* s_lit, const int lane, const uint32_t cnt, const uint32_t r_ll,
                                          const uint32_t r_ml, const uint32_t r_off, uint32_t& litpos, uint32_t& produced, const uint32_t nlit_total,
-                                         const uint32_t out_limit, bool& bad)
+                                         const uint32_t out_limit, bool& bad, const uint32_t frame_pos = 0u)
 {
     // ---- vector unit: the serial decoder's checks for all of them at once, then execution ----
     const uint32_t ll = (uint32_t)lane < cnt ? r_ll : 0u, ml = (uint32_t)lane < cnt ? r_ml : 0u, off = r_off - 3u;
@@ -2609,7 +2610,7 @@ __device__ __forceinline__ void zx_batch(ZxOut& zx, uint8_t* s_ring, uint8_t* s_
         batch_adv = (uint32_t)__builtin_amdgcn_readlane((int)i_a, 63);
         // a piece may not use repeat offsets (ov <= 3); literals and output must fit; an offset may not reach below the piece
         const bool wrong = (uint32_t)lane < cnt && (r_off <= 3u || ll > 131072u || ml > 131075u || litpos + i_l > nlit_total ||
-                                                     produced + i_a > out_limit || off > produced + i_a - ml);
+                                                     produced + i_a > out_limit || off > frame_pos + produced + i_a - ml);
         if (__builtin_amdgcn_ballot_w64(wrong))
         {
             bad = true;
@@ -2960,7 +2961,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const ZBlock blk = blocks[it.payload];
     const uint32_t slot = blockIdx.x;
     // A piece of a frame whose pieces depend on each other (trailer version 4: it.pad bit 1) may copy from the pieces before it: it is
-    // executed on bytes through memory with positions relative to the start of the piece before it, and not before that piece is complete --
+    // executed with positions relative to the start of the piece before it (through memory that is an address like any other; the ring
+    // starts out holding that piece's last 8 KiB), and not before that piece is complete --
     // the items of a payload are consecutive, the piece before is item i - 1, and in the link-major order its workgroup was dispatched
     // before this one (an earlier row), or belongs to an earlier launch.  Pieces the executor does not run (Raw / RLE pieces of
     // k_zstd_plain_pieces: an earlier kernel of the round; pieces given back by k_zstd_sub_entropy: the payload goes to the serial decoder
@@ -2993,8 +2995,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 pred_failed = true;
         }
     }
-    if (chained)
-        px = 2u; // (bytes through memory: a source in an earlier piece is an address like any other)
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(tables + (uint64_t)slot * 3u * ZT_ENTRIES); // states are byte offsets into this
     const uint64_t* recs = tables + (uint64_t)slot * ZREC_MAX;
     const uint8_t* lits = lit_scratch + (uint64_t)slot * (ZD_LIT_MAX + 64u);
@@ -3004,14 +3004,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     zx.s_ring = s_ring;
     zx.s_lit = s_lit;
     zx.g = (uint32_t)((uintptr_t)out & 15u);
-    zx.out_al = out - zx.g;
+    zx.out_al = out - frame_pos - zx.g; // (ZB is a multiple of the ring: positions keep their place in it)
     zx.lh = (uint32_t)((uintptr_t)lits & 15u);
     zx.lit_al = lits - zx.lh;
     zx.nlit = pr.nlit;
-    zx.cap = pr.expect;
+    zx.cap = frame_pos + pr.expect;
+    zx.lo = frame_pos + zx.g;
     zx.lane = lane;
-    zx.op = 0;
-    zx.flushed = zx.drained = 0;
+    zx.op = frame_pos;
+    zx.flushed = zx.drained = frame_pos; // (what lies below was written, and released, by the piece before)
     zx.lwa = -(int32_t)ZX_LIT;
 
     // ---- the bit-stream, read backwards: bit k of the stream is bit (8 * bits_off + k) of the arena; a sequence takes at most 89 bits
@@ -3072,6 +3073,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         far_long = zx_scan_incl(far_long);
         far_long = (uint32_t)__builtin_amdgcn_readlane((int)far_long, 63);
         px = far_long * 8u > pr.nbseq ? 2u : 0u;
+    }
+    if (chained && !pred_failed && !(RECS && px))
+    {
+        // the ring as the piece before left it: its last 8 KiB (the aligned lines below and around the seam; the bytes of the seam's line
+        // that are this piece's are written before they are read)
+        const uint32_t a0 = frame_pos + 16u - ZX_RING;
+#pragma unroll
+        for (uint32_t u = 0; u < ZX_RING / 1024u; ++u)
+        {
+            const uint32_t A = a0 + 16u * (u * 64u + (uint32_t)lane);
+            *reinterpret_cast<uint4*>(s_ring + (A & (ZX_RING - 1u))) = *reinterpret_cast<const uint4*>(zx.out_al + A);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     for (uint32_t s0 = 0; s0 < pr.nbseq && !bad; s0 += 64u)
     {
@@ -3166,7 +3181,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             produced += batch_adv;
         }
         else
-            zx_batch(zx, s_ring, s_lit, lane, cnt, r_ll, r_ml, r_off, litpos, produced, pr.nlit, pr.expect, bad);
+            zx_batch(zx, s_ring, s_lit, lane, cnt, r_ll, r_ml, r_off, litpos, produced, pr.nlit, pr.expect, bad, frame_pos);
         if (bad)
             break;
     }
