@@ -498,8 +498,15 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
     uint32_t p = s0, anchor = s0, nrec = 0, last_end = 0, nmiss = 0;
     // LTHIP_LZ4_DBG bit 13, "deep": every byte position is probed and, where both tables' candidates verify, the longer match wins --
     // round 4's first "high" setting; with the history halves it measures WORSE than without on every synthetic kind (and a third slower)
-    const bool q_high = (dbg & 8192u) != 0u, q_max = (dbg & LZ4_DBG_Q_MAX) != 0u;
-    const uint32_t dense = q_high ? 0xFFFFu : 4u >> ((dbg >> 29) & 3u);
+    // the experiments' switches (LTHIP_LZ4_DBG) exist in the ablation build; in the product they are compile-time zeros, not
+    // wave-uniform branches and selects in the probe loop
+#ifdef LTHIP_ABLATIONS
+    const uint32_t xdbg = dbg;
+#else
+    constexpr uint32_t xdbg = 0u;
+#endif
+    const bool q_high = (xdbg & 8192u) != 0u, q_max = FMT == 1 && (dbg & LZ4_DBG_Q_MAX) != 0u;
+    const uint32_t dense = q_high ? 0xFFFFu : 4u >> ((xdbg >> 29) & 3u);
     // Round 5, ADAPTIVE miss stepping.  After a hit (and at a sub-unit's start) a lane steps `dense` single bytes before it probes
     // aligned dwords only -- history enters the tables at aligned dwords, so a probe at an unaligned position is what finds a repeat
     // whose distance is not a multiple of four.  Data made of aligned structures (records, tables, tokens: what compresses in an asset
@@ -509,51 +516,52 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
     // keeps count: after LZ4_QUIET probe rounds without a single hit at an unaligned position the one-byte steps stop; the first such
     // hit -- the probe behind a match's end stands wherever the match ended -- brings them back.  Wave-uniform, from ballots: a function
     // of the unit's data alone.  (LTHIP_LZ4_DBG bit 16, or an explicit step count in bits 29-30: the fixed rule.)
-    const bool adaptive = !q_high && !(dbg & 65536u) && ((dbg >> 29) & 3u) == 0u;
-    const uint32_t quiet_rounds = (dbg >> 17) & 7u ? (dbg >> 17) & 7u : LZ4_QUIET; // (bits 17-19: the sweep of profiles/r05_adaptive_stepping.txt)
-    uint32_t dense_w = dense, quiet = 0;
+    const bool adaptive = !q_high && !(xdbg & 65536u) && ((xdbg >> 29) & 3u) == 0u;
+    const uint32_t quiet_rounds = (xdbg >> 17) & 7u ? (xdbg >> 17) & 7u : LZ4_QUIET; // (bits 17-19: the sweep of profiles/r05_adaptive_stepping.txt)
+    // (the state: bit k of qhist = an unaligned hit k probe rounds ago; bit 0 also stands for the unit's start)
+    uint32_t qhist = 1u;
+    bool dense_now = true;
     // lanes that must hold a hit before the wave turns to the extension: 4 (round 4, VALU bound: 2 GiB mixed 4.25 ms at 8, 4.12 at 4,
     // 4.16 / 4.37 / 4.76 at 16 / 32 / 48; tokens 5.97 / 5.93 / 6.03 / 6.80 / 7.78 -- waiting lanes are idle lanes)
-    const uint32_t wait_for = (dbg >> 20) & 63u ? (dbg >> 20) & 63u : 4u;
+    const uint32_t wait_for = (xdbg >> 20) & 63u ? (xdbg >> 20) & 63u : 4u;
     uint32_t rsl[8], roff[8]; // records: start | length << 16, offset
     uint32_t cand2 = 0xFFFFFFFFu; // "high": the other verified candidate of the probe (0xFFFFFFFF: none)
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         rsl[k] = roff[k] = 0u;
-    bool pend = false, stale = true;
     uint32_t cand = 0u;
-    uint32_t w0 = 0, w1 = 0, w2 = 0, W = 0; // the dwords W, W + 1, W + 2 of the window: the lane's next 9..12 bytes
+    // The loop's conditions, one compare each (a ballot of a compare IS the compare; a ballot of a combination of conditions costs a
+    // select and a second compare -- and the kernel is bound by the number of vector instructions it issues): a lane probes while
+    // p < plim (the end of its sub-unit, the unit's last start; 0 once its records are full), and a hit that waits for its extension
+    // sets p's top bit -- which also takes the lane out of p < plim.
+    constexpr uint32_t PEND = 0x80000000u;
+    const uint32_t stop0 = start_limit < 0 ? 0u : ((uint32_t)start_limit + 1u < lend ? (uint32_t)start_limit + 1u : lend);
+    uint32_t plim = (xdbg & 2048u) ? 0u : stop0;
     for (;;)
     {
-        const bool act = !pend && p < lend && (int32_t)p <= start_limit && nrec < LZ4_LANE_MAXREC && !(dbg & 2048u);
+        const bool act = p < plim;
         const uint64_t am = __builtin_amdgcn_ballot_w64(act);
-        if (am == 0ull && __builtin_amdgcn_ballot_w64(pend) == 0ull)
+        if (am == 0ull && __builtin_amdgcn_ballot_w64((int32_t)p < 0) == 0ull)
             break;
+        const uint32_t x = p + head; // (the LDS byte address of position p)
+        const uint64_t unm = __builtin_amdgcn_ballot_w64((x & 3u) != 0u); // lanes that stand at an unaligned position
         if (am)
         {
-            bool hit_un = false;
-            if (__builtin_amdgcn_ballot_w64(act && stale))
-            {
-                if (act && stale)
-                {
-                    W = (p + head) >> 2;
-                    uint32_t r3[3];
-                    lds_run<PAD, 3>(sdata, W, r3);
-                    w0 = r3[0];
-                    w1 = r3[1];
-                    w2 = r3[2];
-                    stale = false;
-                }
-            }
             if (act)
             {
-                const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, (p + head) & 3u);
+                // the four bytes at p: two aligned dwords, read where they are needed (round 4 kept the lane's next dwords in a register
+                // window that slid with p to save this round trip; since the kernel is bound by the vector instructions it issues, the
+                // window's bookkeeping -- reload after every jump, shift at every crossing, and the copies the three versions of
+                // every register cost at the loop's joins -- was 20 of a probe round's 110 instructions, the round trip is hidden)
+                uint32_t d2[2];
+                lds_run<PAD, 2>(sdata, x >> 2, d2);
+                const uint32_t v = __builtin_amdgcn_alignbyte(d2[1], d2[0], x & 3u);
                 const uint32_t prod = v * 2654435761u;
                 const uint32_t h = lz4_tab_slot<TAB, 2>(prod);
                 uint32_t c = tab[h];
                 const uint32_t c2 = shr[(prod >> sh_shift) + sh_off] - sh_base; // (another group's entry: far above any position)
                 tab[h] = (uint16_t)p;
-                if ((dbg & (1u << 28)) || q_max) // "max": the slot is read again after the step's inserts (entries of lanes in phase)
+                if ((xdbg & (1u << 28)) || q_max) // "max": the slot is read again after the step's inserts (entries of lanes in phase)
                 {
                     uint32_t hr = h;
                     asm volatile("" : "+v"(hr));
@@ -568,7 +576,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 const bool h1 = v1 && r1 == v, h2 = v2 && r2 == v;
                 bool h3 = false;
                 uint32_t c3 = 0u;
-                if (hist)
+                if (FMT == 1 && hist)
                 {
                     const uint32_t e3 = shr[prod >> sh_shift] - sh_base; // (another item's entry: above 0xFFFF)
                     c3 = 0xFFFFu - e3;
@@ -577,47 +585,32 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 }
                 if (h1 || h2 || h3)
                 {
-                    pend = true;
-                    hit_un = ((p + head) & 3u) != 0u;
+                    p |= PEND;
                     cand = h1 ? c : (h2 ? c2 : c3); // the private table's (the nearest one) first, the history's last
                     cand2 = (q_high && h1 && h2 && c != c2) ? c2 : 0xFFFFFFFFu;
                 }
                 else
                 {
-                    const uint32_t np = nmiss < dense_w ? p + 1u : (((p + head) | 3u) + 1u - head);
-                    if (((np + head) >> 2) != W) // at most one dword further
-                    {
-                        w0 = w1;
-                        w1 = w2;
-                        W += 1u;
-                        w2 = lds_dw<PAD>(sdata, W + 2u); // consumed at the next crossing at the earliest
-                    }
-                    p = np;
+                    p = ((dense_now && nmiss < dense) ? x : (x | 3u)) + 1u - head;
                     ++nmiss;
                 }
-            }
-            if (adaptive)
-            {
-                if (__builtin_amdgcn_ballot_w64(hit_un) != 0ull)
-                {
-                    quiet = 0;
-                    dense_w = dense;
-                }
-                else if (++quiet == quiet_rounds)
-                    dense_w = 0;
             }
         }
         K5P(3);
         K5P_COUNT(10, 1);
-        const uint64_t pm = __builtin_amdgcn_ballot_w64(pend);
+        const uint64_t pm = __builtin_amdgcn_ballot_w64((int32_t)p < 0);
+        if (am != 0ull && adaptive) // (scalar: the hits of this round are the waiting lanes that probed)
+        {
+            qhist = (unm & pm & am) != 0ull ? (qhist << 1) | 1u : qhist << 1;
+            dense_now = (qhist & ((1u << quiet_rounds) - 1u)) != 0u;
+        }
         if (pm == 0ull)
             continue;
-        if ((uint32_t)__builtin_popcountll(pm) < wait_for &&
-            __builtin_amdgcn_ballot_w64(!pend && p < lend && (int32_t)p <= start_limit && nrec < LZ4_LANE_MAXREC) != 0ull)
+        if ((uint32_t)__builtin_popcountll(pm) < wait_for && __builtin_amdgcn_ballot_w64(p < plim) != 0ull)
             continue; // somebody can still probe: let the hits pile up
-        const bool ok0 = pend;
+        const bool ok0 = (int32_t)p < 0;
         bool ok = ok0;
-        pend = false;
+        p &= ~PEND;
         K5P_COUNT(11, 1);
         K5P_COUNT(12, (unsigned)__builtin_popcountll(pm));
         // ---- one round trip: 8 bytes backwards and the first 16 bytes forwards of every hit ----
@@ -745,7 +738,6 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 anchor = anchor > cov ? anchor : cov;
                 ok = false;
                 covered = true;
-                stale = true;
             }
             longs &= ~__builtin_amdgcn_ballot_w64(cv);
         }
@@ -756,7 +748,6 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
             ok = false;
             p += 1u;
             ++nmiss;
-            stale = true;
         }
         else if (ok)
         {
@@ -770,11 +761,12 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                     roff[k] = of;
                 }
             ++nrec;
+            if (nrec == LZ4_LANE_MAXREC)
+                plim = 0u;
             p = s + len;
             anchor = p;
             last_end = p;
             nmiss = 0;
-            stale = true;
         }
         else if (ok0 && !covered)
             p += 1u; // (cannot happen: a waiting hit is either recorded or covered)
@@ -846,7 +838,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
 
     K5P(6);
     // ---- emission: every lane writes its own sequences; literal runs above 16 bytes are copied by the whole wave ----
-    if (!(dbg & 1024u))
+    if (!(xdbg & 1024u))
     {
         uint32_t prev = prev0;
         const uint64_t anyrec = __builtin_amdgcn_ballot_w64(cnt != 0u);
