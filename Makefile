@@ -69,7 +69,7 @@ prof: $(LIB)
 	mkdir -p build/prof
 	$(HIPCC) $(HIPFLAGS) -DLTHIP_ABLATIONS -DLTHIP_ZB_PROF -c $(CSRC)/k_zstd.hip -o build/prof/k_zstd.o
 	$(HIPCC) $(HIPFLAGS) -DLTHIP_ABLATIONS -DLTHIP_DEC_PROF -c $(CSRC)/k_lz4_decode.hip -o build/prof/k_lz4_decode.o
-	$(HIPCC) $(HIPFLAGS) -DLTHIP_ABLATIONS -DLTHIP_K5_PROF -c $(CSRC)/k_lz4.hip -o build/prof/k_lz4.o
+	$(HIPCC) $(HIPFLAGS) -DLTHIP_K5_PROF -c $(CSRC)/k_lz4.hip -o build/prof/k_lz4.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/prof/liblongtail_hip_prof.so $(filter-out $(OBJDIR)/k_zstd.o $(OBJDIR)/k_lz4_decode.o $(OBJDIR)/k_lz4.o,$(HIP_OBJ)) build/prof/k_zstd.o build/prof/k_lz4_decode.o build/prof/k_lz4.o $(C_OBJ) -lpthread
 
 clean:

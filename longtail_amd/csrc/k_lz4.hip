@@ -523,7 +523,9 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
     bool dense_now = true;
     // lanes that must hold a hit before the wave turns to the extension: 4 (round 4, VALU bound: 2 GiB mixed 4.25 ms at 8, 4.12 at 4,
     // 4.16 / 4.37 / 4.76 at 16 / 32 / 48; tokens 5.97 / 5.93 / 6.03 / 6.80 / 7.78 -- waiting lanes are idle lanes)
-    const uint32_t wait_for = (xdbg >> 20) & 63u ? (xdbg >> 20) & 63u : 4u;
+    // (round 5, with the probe round at half its instructions: mixed 147.2 / 146.2 / 145.6 / 145.0 / 145.4 / 148.4 ms of match finder per
+    // 64 GiB at 4 / 6 / 8 / 12 / 16 / 24, tokens 165.8 / 163.4 / 162.0 / 160.5 / 161.3 / 169.5 -- tools/wait_for_sweep.sh: 12)
+    const uint32_t wait_for = (xdbg >> 20) & 63u ? (xdbg >> 20) & 63u : 12u;
     uint32_t rsl[8], roff[8]; // records: start | length << 16, offset
     uint32_t cand2 = 0xFFFFFFFFu; // "high": the other verified candidate of the probe (0xFFFFFFFF: none)
 #pragma unroll
@@ -683,19 +685,16 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
             }
         }
         // ---- matches of 20 bytes and more: one more 16-byte round of their own (at most 36 bytes), then the whole wave ----
-        if (__builtin_amdgcn_ballot_w64(grow))
+        if (grow)
         {
-            if (grow)
+            const uint32_t add = lds_cmp16<PAD>(sdata, p + mlen + head, cand + mlen + head);
+            mlen += add;
+            if (add != 16u)
+                grow = false;
+            if (mlen >= maxlen)
             {
-                const uint32_t add = lds_cmp16<PAD>(sdata, p + mlen + head, cand + mlen + head);
-                mlen += add;
-                if (add != 16u)
-                    grow = false;
-                if (mlen >= maxlen)
-                {
-                    mlen = maxlen;
-                    grow = false;
-                }
+                mlen = maxlen;
+                grow = false;
             }
         }
         uint64_t longs = __builtin_amdgcn_ballot_w64(grow);
