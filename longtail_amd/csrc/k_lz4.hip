@@ -119,7 +119,23 @@ __device__ __forceinline__ const uint32_t* lds_ptr(const uint32_t* sdata, uint32
 {
     const uint32_t xa = x & ~3u;
     const uint32_t a = PAD ? __umul24(xa >> 7, 4u * LZ4_ROW_DUP) + xa : xa;
+    if constexpr (PAD)
+    {
+        // The padded window is the lane parser's, and there it is the kernel's dynamic LDS, which starts at LDS address 0 (k_lz4_lanes2
+        // has no static LDS and checks this once): the byte offset IS the address.  Through `sdata` the compiler adds the window's base
+        // to every address -- a constant it learns too late to fold --, one more vector instruction per address in a kernel that is
+        // bound by their number.
+        typedef __attribute__((address_space(3))) const uint32_t* lds_cptr_t;
+        return (const uint32_t*)(lds_cptr_t)(uintptr_t)a;
+    }
     return reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(sdata) + a);
+}
+// (what lds_ptr<true> relies on; a kernel with a padded window calls this first)
+__device__ __forceinline__ void lds_window_must_start_at_zero(const uint32_t* sdata)
+{
+    typedef __attribute__((address_space(3))) const uint32_t* lds_cptr_t;
+    if ((uint32_t)(uintptr_t)(lds_cptr_t)sdata != 0u)
+        __builtin_trap();
 }
 template <bool PAD>
 __device__ __forceinline__ uint32_t lds_dw(const uint32_t* sdata, uint32_t D)
@@ -139,7 +155,12 @@ __device__ __forceinline__ void lds_run(const uint32_t* sdata, uint32_t D, uint3
 template <bool PAD>
 __device__ __forceinline__ uint32_t lds_byte(const uint32_t* sdata, uint32_t x)
 {
-    return reinterpret_cast<const uint8_t*>(sdata)[PAD ? x + __umul24(x >> 7, 4u * LZ4_ROW_DUP) : x];
+    if constexpr (PAD) // (the offset is the address: see lds_ptr)
+    {
+        typedef __attribute__((address_space(3))) const uint8_t* lds_bptr_t;
+        return *(const uint8_t*)(lds_bptr_t)(uintptr_t)(x + __umul24(x >> 7, 4u * LZ4_ROW_DUP));
+    }
+    return reinterpret_cast<const uint8_t*>(sdata)[x];
 }
 template <bool PAD>
 __device__ __forceinline__ uint32_t lds_read32x(const uint32_t* sdata, uint32_t byte_idx)
@@ -1586,6 +1607,7 @@ __global__ __launch_bounds__(64 * WG, 4) void k_lz4_lanes2(const uint8_t* __rest
     static_assert(WG == 16 || WG == 8, "two halves per workgroup, or one");
     const uint32_t data_bytes = lz4_window_lds_bytes((uint32_t)WG * sub_bytes + 64u + LZ4_LPAD + GAP, true);
     uint32_t* sdata = smem;
+    lds_window_must_start_at_zero(sdata);
     uint32_t* flag = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + data_bytes); // 16 bytes
     const int tid = threadIdx.x;
     const int lane = tid & 63;
