@@ -169,7 +169,7 @@ __device__ __forceinline__ uint32_t lds_read32x(const uint32_t* sdata, uint32_t 
         return lds_read32(sdata, byte_idx);
     uint32_t d[2];
     lds_run<true, 2>(sdata, byte_idx >> 2, d);
-    return __builtin_amdgcn_alignbyte(d[1], d[0], byte_idx & 3u);
+    return __builtin_amdgcn_alignbyte(d[1], d[0], byte_idx); // (v_alignbyte_b32 shifts by the selector's two low bits: no mask)
 }
 // bytes of LDS a window of n data bytes occupies
 __host__ __device__ constexpr uint32_t lz4_window_lds_bytes(uint32_t n, bool pad)
@@ -469,7 +469,7 @@ __device__ __forceinline__ uint32_t lz4_tab_slot(uint32_t prod)
 template <bool PAD>
 __device__ __forceinline__ uint32_t lds_cmp16(const uint32_t* sdata, uint32_t qa, uint32_t qb)
 {
-    const uint32_t wa = qa >> 2, wb = qb >> 2, da = qa & 3u, db = qb & 3u;
+    const uint32_t wa = qa >> 2, wb = qb >> 2, da = qa, db = qb; // (v_alignbyte_b32 takes the two low bits)
     uint32_t ra[4], rb[4];
     lds_run<PAD, 4>(sdata, wa, ra);
     lds_run<PAD, 4>(sdata, wb, rb);
@@ -578,7 +578,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 // every register cost at the loop's joins -- was 20 of a probe round's 110 instructions, the round trip is hidden)
                 uint32_t d2[2];
                 lds_run<PAD, 2>(sdata, x >> 2, d2);
-                const uint32_t v = __builtin_amdgcn_alignbyte(d2[1], d2[0], x & 3u);
+                const uint32_t v = __builtin_amdgcn_alignbyte(d2[1], d2[0], x);
                 const uint32_t prod = v * 2654435761u;
                 const uint32_t h = lz4_tab_slot<TAB, 2>(prod);
                 uint32_t c = tab[h];
@@ -643,7 +643,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
         if (ok)
         {
             const uint32_t qo = p + head - 8u, qc = cand + head - 8u;
-            const uint32_t bo = qo >> 2, bc = qc >> 2, dlo = qo & 3u, dlc = qc & 3u;
+            const uint32_t bo = qo >> 2, bc = qc >> 2, dlo = qo, dlc = qc; // (v_alignbyte_b32 takes the two low bits)
             uint32_t Do[8], Dc[8];
             lds_run<PAD, 4>(sdata, bo, Do);
             lds_run<PAD, 4>(sdata, bo + 4u, Do + 4);
