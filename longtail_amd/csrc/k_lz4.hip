@@ -558,6 +558,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
     // p < plim (the end of its sub-unit, the unit's last start; 0 once its records are full), and a hit that waits for its extension
     // sets p's top bit -- which also takes the lane out of p < plim.
     constexpr uint32_t PEND = 0x80000000u;
+    const uint32_t headm1 = head - 1u;
     const uint32_t stop0 = start_limit < 0 ? 0u : ((uint32_t)start_limit + 1u < lend ? (uint32_t)start_limit + 1u : lend);
     uint32_t plim = (xdbg & 2048u) ? 0u : stop0;
     for (;;)
@@ -614,7 +615,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 }
                 else
                 {
-                    p = ((dense_now && nmiss < dense) ? x : (x | 3u)) + 1u - head;
+                    p = ((dense_now && nmiss < dense) ? x : (x | 3u)) - headm1;
                     ++nmiss;
                 }
             }
@@ -624,7 +625,10 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
         const uint64_t pm = __builtin_amdgcn_ballot_w64((int32_t)p < 0);
         if (am != 0ull && adaptive) // (scalar: the hits of this round are the waiting lanes that probed)
         {
-            qhist = (unm & pm & am) != 0ull ? (qhist << 1) | 1u : qhist << 1;
+            const uint64_t t = unm & pm & am;
+            uint32_t bit; // t != 0 as 0 / 1 (written out: the compiler takes the truth value through a vector register)
+            asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(bit) : "s"(t) : "scc");
+            qhist = (qhist << 1) | bit;
             dense_now = (qhist & ((1u << quiet_rounds) - 1u)) != 0u;
         }
         if (pm == 0ull)
