@@ -1089,8 +1089,16 @@ __global__ __launch_bounds__(64 * G, 6) void k_lz4_segments(const uint8_t* __res
                         const uint32_t g16 = blk.grp_base + gi / (uint32_t)(LZ4_G_LANES / LZ4_G_BATCH);
                         // (bit h of the group's word: its half h holds redundancy; a half WITHOUT it is skimmed by this pass, and the
                         // lane kernel only takes its bytes as history)
+#ifdef LTHIP_ABLATIONS
+                        // (the whole-group experiments, LTHIP_LZ4_HALVES=0, run over a LIST of the noted groups)
                         if (atomicOr(&worklist[1u + ngroups + g16], 1u << (gi & 1u)) == 0u)
                             worklist[1u + atomicAdd(&worklist[0], 1u)] = g16;
+#else
+                        // one atomic nobody waits for: k_lz4_pair_halves reads the groups' words.  (Round 5: the list of noted groups
+                        // that this thread used to build -- an atomic OR whose answer decides about an atomic add whose answer is the
+                        // slot -- kept a workgroup that had nothing left to do on its CU for two round trips to memory.)
+                        (void)__hip_atomic_fetch_or(&worklist[1u + ngroups + g16], 1u << (gi & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                     }
                     return;
                 }
@@ -1495,7 +1503,7 @@ __global__ __launch_bounds__(64 * G, 6) void k_lz4_segments(const uint8_t* __res
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t LZ4_HALF_NONE = 0xFFFFFFFFu;
 constexpr uint32_t LZ4_HALF_HIST = 0x40000000u; // on an item's first half: staged as HISTORY of the second, not parsed (k_lz4_pair_halves, hist)
-// worklist layout behind the classification pass (ngroups = groups of the batch): [0] listed groups, [1 .. ngroups] their ids,
+// worklist layout behind the classification pass (ngroups = groups of the batch): [0] listed groups, [1 .. ngroups] their ids (ablation build only: the product notes the half bits and nothing else),
 // [1 + ngroups ..) per-group half bits, [2 ngroups + 1] ticket, [2 ngroups + 2] items, [2 ngroups + 3] lone halves,
 // [2 ngroups + 4 ..) items of four words {half a, half b, block of a, block of b} (up to two per group), [10 ngroups + 4 ..) lone halves
 __host__ __device__ constexpr uint32_t lz4_items_off(uint32_t ngroups) { return (2u * ngroups + 4u + 3u) & ~3u; } // (16-byte aligned: items are read as uint4)
@@ -1525,9 +1533,12 @@ __global__ void k_lz4_pair_halves(uint32_t* __restrict__ wl, uint32_t ngroups, u
     uint32_t* lone = items + 8u * ngroups;
     if (phase == 0u)
     {
-        if (i >= wl[0])
+        // every group of the batch: which of its halves did the classification pass note?
+        if (i >= ngroups)
             return;
-        const uint32_t g = wl[1u + i], bits = wl[1u + ngroups + g] & 3u;
+        const uint32_t g = i, bits = wl[1u + ngroups + g] & 3u;
+        if (bits == 0u)
+            return;
         if (hist == 2u) // (LTHIP_LZ4_SPLITWG: every flagged half an item of its own)
         {
             for (uint32_t hh = 0; hh < 2u; ++hh)
