@@ -755,7 +755,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
             if (lane == f)
                 mlen = ml;
             const uint32_t cov = pf + ml;
-            const bool cv = lane != f && p > pf && p < cov;
+            const bool cv = p - (pf + 1u) < ml - 1u; // pf < p < cov, one compare (lane f itself stands at pf; waiting lanes' p carries no flag here)
             if (cv)
             {
                 p = cov;
