@@ -1894,7 +1894,8 @@ __global__ __launch_bounds__(64) void k_lz4_stitch_scan(const Lz4Block* __restri
                                                         const Lz4Meta* __restrict__ meta, Lz4Plan* __restrict__ plan,
                                                         uint32_t* __restrict__ runs, Lz4BlockOut* __restrict__ bout,
                                                         uint32_t* __restrict__ out_sizes, uint8_t* __restrict__ dst, uint32_t spec,
-                                                        uint32_t* __restrict__ worklist /* [0] = count, then group ids */)
+                                                        uint32_t* __restrict__ worklist /* [0] = count, then group ids, then (from 1 + wl_cap) their blocks */,
+                                                        uint32_t wl_cap)
 {
     const uint32_t b = blockIdx.x + b0;
     if (b >= nblocks)
@@ -1999,7 +2000,10 @@ __global__ __launch_bounds__(64) void k_lz4_stitch_scan(const Lz4Block* __restri
                 base = atomicAdd(worklist, blk.ngrp);
             base = __builtin_amdgcn_readfirstlane(base);
             for (uint32_t k = lane; k < blk.ngrp; k += 64)
+            {
                 worklist[1u + base + k] = blk.grp_base + k;
+                worklist[1u + wl_cap + base + k] = b; // (the copy kernel used to search the block table for it: ten dependent loads per group)
+            }
         }
     }
     if (lane == 0)
@@ -2067,22 +2071,15 @@ __global__ __launch_bounds__(K6_THREADS) void k_lz4_stitch_copy(const uint8_t* _
                                                                  const uint32_t* __restrict__ runs,
                                                                  const Lz4BlockOut* __restrict__ bout,
                                                                  uint8_t* __restrict__ dst, const uint32_t* __restrict__ worklist,
-                                                                 uint32_t gunits /* units per window group */)
+                                                                 uint32_t gunits /* units per window group */, uint32_t wl_cap)
 {
     const int tid = threadIdx.x;
     const uint32_t nwork = worklist[0];
+    (void)nblocks;
   for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x)
   {
     const uint32_t grp = worklist[1u + wi];
-    uint32_t lo = 0, hi = nblocks;
-    while (hi - lo > 1)
-    {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (blocks[mid].grp_base <= grp)
-            lo = mid;
-        else
-            hi = mid;
-    }
+    const uint32_t lo = worklist[1u + wl_cap + wi]; // the group's block (k_lz4_stitch_scan)
     const Lz4Block blk = blocks[lo];
     const Lz4BlockOut bo = bout[lo];
     uint8_t* d = dst + blk.dst_off;
@@ -2469,7 +2466,7 @@ static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_
         grp_first[b + 1] = grp_first[b] + (uint32_t)(((((uint64_t)src_sizes[b] + SEG - 1) / SEG) + GU - 1) / GU);
     const bool overlap = cut.size() > 2;
     void* worklist;
-    if ((err = lthip_scratch(ctx, S_LZ4_WORKLIST, 4 * ((size_t)ngrp64 + 1) * (cut.size() - 1), &worklist)))
+    if ((err = lthip_scratch(ctx, S_LZ4_WORKLIST, 4 * (2 * (size_t)ngrp64 + 1) * (cut.size() - 1), &worklist)))
         return err;
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -2508,15 +2505,15 @@ static int lz4_compress_batch(lthip_ctx* ctx, const void* d_src, uint32_t block_
         }
         {
             LaunchTimer t(ctx, LTHIP_K_LZ4_STITCH, s2);
-            uint32_t* wl = (uint32_t*)worklist + (size_t)i * ((size_t)ngrp64 + 1); // one list per slice
+            uint32_t* wl = (uint32_t*)worklist + (size_t)i * (2 * (size_t)ngrp64 + 1); // one list per slice: count, group ids, their blocks
             LTHIP_CHECK(ctx, hipMemsetAsync(wl, 0, 4, s2));
             hipLaunchKernelGGL(k_lz4_stitch_scan, dim3(b1 - b0), dim3(64), 0, s2, d_blocks, b0, b1, SEG, (const Lz4Meta*)meta,
-                               (Lz4Plan*)plan, (uint32_t*)runs, (Lz4BlockOut*)bout, d_out_sizes, (uint8_t*)d_dst, (dbg & 64u) ? 0u : 1u, wl);
+                               (Lz4Plan*)plan, (uint32_t*)runs, (Lz4BlockOut*)bout, d_out_sizes, (uint8_t*)d_dst, (dbg & 64u) ? 0u : 1u, wl, (uint32_t)ngrp64);
             if (g1 > g0)
                 hipLaunchKernelGGL(k_lz4_stitch_copy, dim3(g1 - g0 < copy_grid ? g1 - g0 : copy_grid), dim3(K6_THREADS), 0, s2,
                                    (const uint8_t*)d_src, d_blocks, block_count, SEG, (const uint8_t*)streams, (const Lz4Meta*)meta,
                                    (const Lz4Plan*)plan, (const uint32_t*)runs, (const Lz4BlockOut*)bout, (uint8_t*)d_dst,
-                                   (const uint32_t*)wl, GU);
+                                   (const uint32_t*)wl, GU, (uint32_t)ngrp64);
             if (i + 2 == cut.size())
                 hipLaunchKernelGGL(k_lz4_empty_blocks, dim3((block_count + 255) / 256), dim3(256), 0, s2, d_blocks, block_count,
                                    (const Lz4BlockOut*)bout, (uint8_t*)d_dst);
