@@ -563,78 +563,84 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
     uint32_t plim = (xdbg & 2048u) ? 0u : stop0;
     for (;;)
     {
-        const bool act = p < plim;
-        const uint64_t am = __builtin_amdgcn_ballot_w64(act);
-        if (am == 0ull && __builtin_amdgcn_ballot_w64((int32_t)p < 0) == 0ull)
-            break;
-        const uint32_t x = p + head; // (the LDS byte address of position p)
-        const uint64_t unm = __builtin_amdgcn_ballot_w64((x & 3u) != 0u); // lanes that stand at an unaligned position
-        if (am)
+        // ---- probe rounds, until enough hits wait (or nobody can probe any more) ----
+        uint64_t pm = 0ull;
+        for (;;)
         {
-            if (act)
+            const bool act = p < plim;
+            const uint64_t am = __builtin_amdgcn_ballot_w64(act);
+            if (am == 0ull)
+                break;
+            const uint32_t x = p + head; // (the LDS byte address of position p)
+            const uint64_t unm = __builtin_amdgcn_ballot_w64((x & 3u) != 0u); // lanes that stand at an unaligned position
+            if (am)
             {
-                // the four bytes at p: two aligned dwords, read where they are needed (round 4 kept the lane's next dwords in a register
-                // window that slid with p to save this round trip; since the kernel is bound by the vector instructions it issues, the
-                // window's bookkeeping -- reload after every jump, shift at every crossing, and the copies the three versions of
-                // every register cost at the loop's joins -- was 20 of a probe round's 110 instructions, the round trip is hidden)
-                uint32_t d2[2];
-                lds_run<PAD, 2>(sdata, x >> 2, d2);
-                const uint32_t v = __builtin_amdgcn_alignbyte(d2[1], d2[0], x);
-                const uint32_t prod = v * 2654435761u;
-                const uint32_t h = lz4_tab_slot<TAB, 2>(prod);
-                uint32_t c = tab[h];
-                const uint32_t c2 = shr[(prod >> sh_shift) + sh_off] - sh_base; // (another group's entry: far above any position)
-                tab[h] = (uint16_t)p;
-                if ((xdbg & (1u << 28)) || q_max) // "max": the slot is read again after the step's inserts (entries of lanes in phase)
+                if (act)
                 {
-                    uint32_t hr = h;
-                    asm volatile("" : "+v"(hr));
-                    const uint32_t fresh = tab[hr];
-                    if (fresh < p)
-                        c = fresh;
-                }
-                // both candidates' bytes in one round trip (an invalid one reads my own position and is masked)
-                const bool v1 = c < p && c >= lo_bound && c != not_private, v2 = c2 < p && c2 >= lo_bound;
-                const uint32_t r1 = lds_read32x<PAD>(sdata, (v1 ? c : p) + head);
-                const uint32_t r2 = lds_read32x<PAD>(sdata, (v2 ? c2 : p) + head);
-                const bool h1 = v1 && r1 == v, h2 = v2 && r2 == v;
-                bool h3 = false;
-                uint32_t c3 = 0u;
-                if (FMT == 1 && hist)
-                {
-                    const uint32_t e3 = shr[prod >> sh_shift] - sh_base; // (another item's entry: above 0xFFFF)
-                    c3 = 0xFFFFu - e3;
-                    const bool v3 = e3 <= 0xFFFFu;
-                    h3 = v3 && lds_read32x<PAD>(sdata, (v3 ? c3 : p) + head) == v;
-                }
-                if (h1 || h2 || h3)
-                {
-                    p |= PEND;
-                    cand = h1 ? c : (h2 ? c2 : c3); // the private table's (the nearest one) first, the history's last
-                    cand2 = (q_high && h1 && h2 && c != c2) ? c2 : 0xFFFFFFFFu;
-                }
-                else
-                {
-                    p = ((dense_now && nmiss < dense) ? x : (x | 3u)) - headm1;
-                    ++nmiss;
+                    // the four bytes at p: two aligned dwords, read where they are needed (round 4 kept the lane's next dwords in a register
+                    // window that slid with p to save this round trip; since the kernel is bound by the vector instructions it issues, the
+                    // window's bookkeeping -- reload after every jump, shift at every crossing, and the copies the three versions of
+                    // every register cost at the loop's joins -- was 20 of a probe round's 110 instructions, the round trip is hidden)
+                    uint32_t d2[2];
+                    lds_run<PAD, 2>(sdata, x >> 2, d2);
+                    const uint32_t v = __builtin_amdgcn_alignbyte(d2[1], d2[0], x);
+                    const uint32_t prod = v * 2654435761u;
+                    const uint32_t h = lz4_tab_slot<TAB, 2>(prod);
+                    uint32_t c = tab[h];
+                    const uint32_t c2 = shr[(prod >> sh_shift) + sh_off] - sh_base; // (another group's entry: far above any position)
+                    tab[h] = (uint16_t)p;
+                    if ((xdbg & (1u << 28)) || q_max) // "max": the slot is read again after the step's inserts (entries of lanes in phase)
+                    {
+                        uint32_t hr = h;
+                        asm volatile("" : "+v"(hr));
+                        const uint32_t fresh = tab[hr];
+                        if (fresh < p)
+                            c = fresh;
+                    }
+                    // both candidates' bytes in one round trip (an invalid one reads my own position and is masked)
+                    const bool v1 = c < p && c >= lo_bound && c != not_private, v2 = c2 < p && c2 >= lo_bound;
+                    const uint32_t r1 = lds_read32x<PAD>(sdata, (v1 ? c : p) + head);
+                    const uint32_t r2 = lds_read32x<PAD>(sdata, (v2 ? c2 : p) + head);
+                    const bool h1 = v1 && r1 == v, h2 = v2 && r2 == v;
+                    bool h3 = false;
+                    uint32_t c3 = 0u;
+                    if (FMT == 1 && hist)
+                    {
+                        const uint32_t e3 = shr[prod >> sh_shift] - sh_base; // (another item's entry: above 0xFFFF)
+                        c3 = 0xFFFFu - e3;
+                        const bool v3 = e3 <= 0xFFFFu;
+                        h3 = v3 && lds_read32x<PAD>(sdata, (v3 ? c3 : p) + head) == v;
+                    }
+                    if (h1 || h2 || h3)
+                    {
+                        p |= PEND;
+                        cand = h1 ? c : (h2 ? c2 : c3); // the private table's (the nearest one) first, the history's last
+                        cand2 = (q_high && h1 && h2 && c != c2) ? c2 : 0xFFFFFFFFu;
+                    }
+                    else
+                    {
+                        p = ((dense_now && nmiss < dense) ? x : (x | 3u)) - headm1;
+                        ++nmiss;
+                    }
                 }
             }
+            K5P(3);
+            K5P_COUNT(10, 1);
+            pm = __builtin_amdgcn_ballot_w64((int32_t)p < 0);
+            if (adaptive) // (scalar: the hits of this round are the waiting lanes that probed)
+            {
+                const uint64_t t = unm & pm & am;
+                uint32_t bit; // t != 0 as 0 / 1 (written out: the compiler takes the truth value through a vector register)
+                asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(bit) : "s"(t) : "scc");
+                qhist = (qhist << 1) | bit;
+                dense_now = (qhist & ((1u << quiet_rounds) - 1u)) != 0u;
+            }
+            if ((uint32_t)__builtin_popcountll(pm) >= wait_for)
+                break; // (fewer: somebody may still probe -- let the hits pile up)
         }
-        K5P(3);
-        K5P_COUNT(10, 1);
-        const uint64_t pm = __builtin_amdgcn_ballot_w64((int32_t)p < 0);
-        if (am != 0ull && adaptive) // (scalar: the hits of this round are the waiting lanes that probed)
-        {
-            const uint64_t t = unm & pm & am;
-            uint32_t bit; // t != 0 as 0 / 1 (written out: the compiler takes the truth value through a vector register)
-            asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(bit) : "s"(t) : "scc");
-            qhist = (qhist << 1) | bit;
-            dense_now = (qhist & ((1u << quiet_rounds) - 1u)) != 0u;
-        }
+        pm = __builtin_amdgcn_ballot_w64((int32_t)p < 0);
         if (pm == 0ull)
-            continue;
-        if ((uint32_t)__builtin_popcountll(pm) < wait_for && __builtin_amdgcn_ballot_w64(p < plim) != 0ull)
-            continue; // somebody can still probe: let the hits pile up
+            break; // nobody probes, nobody waits: the unit is parsed
         const bool ok0 = (int32_t)p < 0;
         bool ok = ok0;
         p &= ~PEND;
