@@ -433,6 +433,31 @@ __device__ __forceinline__ uint32_t sub_shfl(uint32_t x, int s, bool rev, uint32
 #include "ablations/k_lz4_lane_parse_r3.inc" // lz4_lane_parse: the round-3 formulation of the parse below (same payloads)
 #endif
 
+// Scans in SUB-UNIT order with the reverse mapping (sub-unit 63 - lane): a prefix over the sub-units is a SUFFIX over the lanes.  Round 5:
+// with DPP moves -- four row shifts inside the rows of 16 (a lane takes the value n lanes above it; beyond the row: nothing), then the
+// rows above a lane's row through three v_readlane -- instead of six ds_bpermute round trips with their index arithmetic (36 vector
+// instructions and six LDS operations a scan; the three or four scans behind a unit's parse were 3 % of the kernel).
+template <bool MAX>
+__device__ __forceinline__ uint32_t lane_suffix_scan(uint32_t v, int lane)
+{
+    auto op = [](uint32_t a, uint32_t b) { return MAX ? (a > b ? a : b) : a + b; };
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true)); // row_shl:1
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xf, 0xf, true)); // row_shl:2
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0xf, true)); // row_shl:4
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x108, 0xf, 0xf, true)); // row_shl:8
+    // a row's first lane holds the row: rows above mine
+    const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16), t2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32),
+                   t3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t s1 = op(t2, t3), s0 = op(t1, s1);
+    const uint32_t above = lane < 16 ? s0 : (lane < 32 ? s1 : (lane < 48 ? t3 : 0u));
+    return op(v, above);
+}
+// the value of the sub-unit before mine (the lane above; the first sub-unit: 0)
+__device__ __forceinline__ uint32_t lane_from_sub_before(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); // wave_shl:1
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K5, lane-sequential parse, second formulation (round 4; PV = 2 of k_lz4_segments).  The parse is the one above -- same probe rule,
 // same candidates, same extension limits, same cover rule: the payloads are byte-identical -- restated around what the per-phase
@@ -804,14 +829,9 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
     }
 
     // ---- what earlier sub-units' matches cover is dropped: exclusive prefix maximum of the match ends, in sub-unit order ----
-    uint32_t incl = last_end;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
-    {
-        const uint32_t o = sub_shfl(incl, sidx - d, rev, 0u);
-        incl = incl > o ? incl : o;
-    }
-    const uint32_t cover = sub_shfl(incl, sidx - 1, rev, 0u);
+    static_assert(rev, "the scans below run in lane order from the top");
+    const uint32_t incl = lane_suffix_scan<true>(last_end, lane);
+    const uint32_t cover = lane_from_sub_before(incl);
     uint32_t k0 = 0; // my first record that starts at or after the cover (starts ascend)
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -825,14 +845,8 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
     if (!have)
         first_start_v = 0u;
     // previous kept end = where the literals of my first kept sequence begin
-    uint32_t kincl = have ? last_end : 0u;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
-    {
-        const uint32_t o = sub_shfl(kincl, sidx - d, rev, 0u);
-        kincl = kincl > o ? kincl : o;
-    }
-    uint32_t prev0 = sub_shfl(kincl, sidx - 1, rev, 0u);
+    const uint32_t kincl = lane_suffix_scan<true>(have ? last_end : 0u, lane);
+    uint32_t prev0 = lane_from_sub_before(kincl);
     prev0 = prev0 > my_start ? prev0 : my_start;
     // sizes
     uint32_t bytes = 0, nlit = 0;
@@ -853,18 +867,12 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
         }
     }
     const uint32_t cnt = have ? nrec - k0 : 0u;
-    uint32_t a_incl = FMT == 1 ? nlit : bytes, c_incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
-    {
-        a_incl += sub_shfl(a_incl, sidx - d, rev, 0u);
-        if constexpr (FMT == 1)
-            c_incl += sub_shfl(c_incl, sidx - d, rev, 0u);
-    }
-    const uint32_t a_total = sub_shfl(a_incl, 63, rev, 0u);
+    const uint32_t a_incl = lane_suffix_scan<false>(FMT == 1 ? nlit : bytes, lane);
+    const uint32_t c_incl = FMT == 1 ? lane_suffix_scan<false>(cnt, lane) : 0u;
+    const uint32_t a_total = (uint32_t)__builtin_amdgcn_readlane((int)a_incl, 0); // (the last sub-unit is lane 0's)
     uint32_t o_pos = a_incl - (FMT == 1 ? nlit : bytes);
     uint32_t q_pos = FMT == 1 ? c_incl - cnt : 0u;
-    const uint32_t last_kept_end = sub_shfl(kincl, 63, rev, 0u);
+    const uint32_t last_kept_end = (uint32_t)__builtin_amdgcn_readlane((int)kincl, 0);
 
     K5P(6);
     // ---- emission: every lane writes its own sequences; literal runs above 16 bytes are copied by the whole wave ----
@@ -950,7 +958,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
     if constexpr (FMT == 1)
     {
         st.op = a_total; // literal bytes so far
-        st.nseq = sub_shfl(c_incl, 63, rev, 0u);
+        st.nseq = (uint32_t)__builtin_amdgcn_readlane((int)c_incl, 0);
     }
     else
     {
