@@ -883,7 +883,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
 #pragma unroll
         for (int k = 0; k < 8; ++k)
         {
-            const bool on = (uint32_t)k >= k0 && (uint32_t)k < nrec;
+            const bool on = (uint32_t)k - k0 < cnt; // k0 <= k < nrec, one compare (cnt = nrec - k0, or 0)
             if (anyrec == 0ull || __builtin_amdgcn_ballot_w64(on) == 0ull)
                 continue;
             uint32_t lit = 0, lit_src = 0, lit_dst = 0;
@@ -940,7 +940,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                         o[j] = (uint8_t)lds_byte<PAD>(sdata, lit_src + j + head);
                 }
             }
-            uint64_t big = __builtin_amdgcn_ballot_w64(on && lit > 16u);
+            uint64_t big = __builtin_amdgcn_ballot_w64(lit > 16u); // (lit is 0 where the lane has no k-th sequence)
             while (big)
             {
                 const int f = __builtin_ctzll(big);
@@ -1730,18 +1730,21 @@ __global__ __launch_bounds__(64 * WG, 4) void k_lz4_lanes2(const uint8_t* __rest
                         // slots, which the LDS serialises (21 % of the kernel on "lines")
                         // ... and the same for the dword at the same place of the line before (the lane before holds it): zero pages
                         // and other runs leave one update per wave
-                        const bool nb = lane != 0 && pq >= wbase + 16u;
-                        bool dup[4] = {false, g4[1] == g4[0], g4[2] == g4[0] || g4[2] == g4[1], g4[3] == g4[1] || g4[3] == g4[2] || g4[3] == g4[0]};
+                        // (all of it unconditional, the truth values combined with | and &: as a chain of || and && the compiler wrapped every
+                        // neighbour test into its own exec-mask region -- 28 scalar instructions a line in a phase where all sixteen waves
+                        // of the CU queue at its one scalar unit)
+                        const bool nb = (lane != 0) & (pq >= wbase + 16u);
+                        bool dup[4] = {false, g4[1] == g4[0], (bool)((g4[2] == g4[0]) | (g4[2] == g4[1])), (bool)((g4[3] == g4[1]) | (g4[3] == g4[2]) | (g4[3] == g4[0]))};
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            dup[k] = dup[k] || (nb && (uint32_t)__builtin_amdgcn_update_dpp((int)~g4[k], (int)g4[k], 0x138 /* wave_shr:1 */, 0xf, 0xf, false) == g4[k]);
+                            dup[k] = (bool)(dup[k] | (nb & ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)g4[k], 0x138 /* wave_shr:1 */, 0xf, 0xf, true) == g4[k])));
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                         {
                             const uint32_t pk = pq + 4u * (uint32_t)k;
                             // (line 0 may begin before the half: a wrapped value is above it -- and then dword k may be the half's first
                             // occurrence although an earlier dword of the line equals it: line 0 takes no shortcut)
-                            if (pk >= wbase && pk < wbase + hlen && (!dup[k] || v == 0u || sh_inv != 0u)) // (a history half keeps the LATEST: no shortcut)
+                            if ((pk - wbase < hlen) & (!dup[k] | (v == 0u) | (sh_inv != 0u))) // (inside the half; a history half keeps the LATEST: no shortcut)
                                 (void)__hip_atomic_fetch_min(&shr[((g4[k] * 2654435761u) >> sh_shift) + sh_off], sh_base | (pk ^ sh_inv), __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
