@@ -490,6 +490,14 @@ __device__ __forceinline__ uint32_t lz4_tab_slot(uint32_t prod)
         return __umulhi(prod, (uint32_t)TAB);
 }
 
+// the first nonzero byte of four XOR words (16: none) without a branch: as an if / else-if chain every level is an exec-mask region
+// of its own, three scalar instructions each, and all levels are walked anyway as soon as one lane of the wave gets there
+__device__ __forceinline__ uint32_t lz4_first_diff16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
+{
+    const uint64_t lo = (uint64_t)x0 | ((uint64_t)x1 << 32), hi = (uint64_t)x2 | ((uint64_t)x3 << 32);
+    const uint32_t nlo = (uint32_t)__builtin_ctzll(lo | (1ull << 63)) >> 3, nhi = 8u + ((uint32_t)__builtin_ctzll(hi | (1ull << 63)) >> 3);
+    return lo ? nlo : (hi ? nhi : 16u);
+}
 // equal leading bytes (0..16) of the 16 bytes at LDS byte addresses qa and qb (any alignment): five aligned dwords per side
 template <bool PAD>
 __device__ __forceinline__ uint32_t lds_cmp16(const uint32_t* sdata, uint32_t qa, uint32_t qb)
@@ -504,16 +512,7 @@ __device__ __forceinline__ uint32_t lds_cmp16(const uint32_t* sdata, uint32_t qa
     const uint32_t x1 = __builtin_amdgcn_alignbyte(a2, a1, da) ^ __builtin_amdgcn_alignbyte(b2, b1, db);
     const uint32_t x2 = __builtin_amdgcn_alignbyte(a3, a2, da) ^ __builtin_amdgcn_alignbyte(b3, b2, db);
     const uint32_t x3 = __builtin_amdgcn_alignbyte(a4, a3, da) ^ __builtin_amdgcn_alignbyte(b4, b3, db);
-    uint32_t n = 16u;
-    if (x0)
-        n = (uint32_t)__builtin_ctz(x0) >> 3;
-    else if (x1)
-        n = 4u + ((uint32_t)__builtin_ctz(x1) >> 3);
-    else if (x2)
-        n = 8u + ((uint32_t)__builtin_ctz(x2) >> 3);
-    else if (x3)
-        n = 12u + ((uint32_t)__builtin_ctz(x3) >> 3);
-    return n;
+    return lz4_first_diff16(x0, x1, x2, x3);
 }
 
 template <int TAB, int FMT, int SH>
@@ -688,15 +687,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
 #pragma unroll
             for (int k = 0; k < 7; ++k)
                 X[k] = __builtin_amdgcn_alignbyte(Do[k + 1], Do[k], dlo) ^ __builtin_amdgcn_alignbyte(Dc[k + 1], Dc[k], dlc);
-            uint32_t add = 16u; // bytes p + 4 .. p + 20
-            if (X[3])
-                add = (uint32_t)__builtin_ctz(X[3]) >> 3;
-            else if (X[4])
-                add = 4u + ((uint32_t)__builtin_ctz(X[4]) >> 3);
-            else if (X[5])
-                add = 8u + ((uint32_t)__builtin_ctz(X[5]) >> 3);
-            else if (X[6])
-                add = 12u + ((uint32_t)__builtin_ctz(X[6]) >> 3);
+            const uint32_t add = lz4_first_diff16(X[3], X[4], X[5], X[6]); // bytes p + 4 .. p + 20
             mlen = 4u + add;
             grow = add == 16u;
             if (mlen >= maxlen)
