@@ -665,8 +665,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
         pm = __builtin_amdgcn_ballot_w64((int32_t)p < 0);
         if (pm == 0ull)
             break; // nobody probes, nobody waits: the unit is parsed
-        const bool ok0 = (int32_t)p < 0;
-        bool ok = ok0;
+        bool ok = (int32_t)p < 0;
         p &= ~PEND;
         K5P_COUNT(11, 1);
         K5P_COUNT(12, (unsigned)__builtin_popcountll(pm));
@@ -695,10 +694,14 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 mlen = maxlen;
                 grow = false;
             }
-            if (cand >= lo_bound + 8u && p - anchor != 0u)
             {
-                nbk = X[1] ? (uint32_t)__builtin_clz(X[1]) >> 3 : (X[0] ? 4u + ((uint32_t)__builtin_clz(X[0]) >> 3) : 8u);
+                // (unconditional: the distance to the anchor bounds it -- 0 at the anchor --, a candidate too close to the window's
+                // lower bound takes none)
+                const uint64_t bw = ((uint64_t)X[1] << 32) | (uint64_t)X[0];
+                nbk = (uint32_t)__builtin_clzll(bw | 1ull) >> 3;
+                nbk = bw ? nbk : 8u;
                 nbk = nbk < p - anchor ? nbk : p - anchor;
+                nbk = cand >= lo_bound + 8u ? nbk : 0u;
             }
         }
         // ---- "high": where the probe verified BOTH candidates, the other one's first 16 bytes too; the longer match wins (the nearer on a
@@ -745,7 +748,6 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
             }
         }
         uint64_t longs = __builtin_amdgcn_ballot_w64(grow);
-        bool covered = false;
         K5P(4);
         while (longs)
         {
@@ -783,7 +785,6 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
                 p = cov;
                 anchor = anchor > cov ? anchor : cov;
                 ok = false;
-                covered = true;
             }
             longs &= ~__builtin_amdgcn_ballot_w64(cv);
         }
@@ -814,8 +815,7 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
             last_end = p;
             nmiss = 0;
         }
-        else if (ok0 && !covered)
-            p += 1u; // (cannot happen: a waiting hit is either recorded or covered)
+        // (a waiting hit is either recorded or covered: nothing else to do)
         K5P(5);
     }
 
