@@ -83,6 +83,9 @@ constexpr uint32_t LZ4_EMPTY = 0xFFFFu;
 
 __host__ __device__ __forceinline__ uint32_t lz4_stream_stride(uint32_t seg) { return (seg + seg / 255u + 16u + 15u) & ~15u; }
 __host__ __device__ __forceinline__ uint32_t lz4_len_bytes(uint32_t len) { return len >= 15u ? (len - 15u) / 255u + 1u : 0u; }
+// ... of a length below 65 536 (what a lane's record holds) without a branch and without a 32-bit multiply: (len + 240) / 255 is the
+// same number for every len (0 below 15), and n / 255 = n * 0x8081 >> 23 is exact for n < 66 299
+__device__ __forceinline__ uint32_t lz4_len_bytes16(uint32_t len) { return __umul24(len + 240u, 0x8081u) >> 23; }
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -840,24 +843,24 @@ __device__ __forceinline__ void lz4_lane_parse2(const uint32_t* sdata, uint32_t 
     uint32_t prev0 = lane_from_sub_before(kincl);
     prev0 = prev0 > my_start ? prev0 : my_start;
     // sizes
+    const uint32_t cnt = have ? nrec - k0 : 0u;
     uint32_t bytes = 0, nlit = 0;
     {
         uint32_t prev = prev0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < 8; ++k) // (a branch per slot on purpose: the last slots are rarely anybody's, and then the whole wave skips them)
         {
-            const bool on = (uint32_t)k >= k0 && (uint32_t)k < nrec;
+            const bool on = (uint32_t)k - k0 < cnt;
             const uint32_t s = rsl[k] & 0xFFFFu, len = rsl[k] >> 16;
             const uint32_t lit = s - prev;
             if (on)
             {
-                bytes += 1u + lz4_len_bytes(lit) + lit + 2u + lz4_len_bytes(len - 4u);
+                bytes += 3u + lz4_len_bytes16(lit) + lit + lz4_len_bytes16(len - 4u);
                 nlit += lit;
                 prev = s + len;
             }
         }
     }
-    const uint32_t cnt = have ? nrec - k0 : 0u;
     const uint32_t a_incl = lane_suffix_scan<false>(FMT == 1 ? nlit : bytes, lane);
     const uint32_t c_incl = FMT == 1 ? lane_suffix_scan<false>(cnt, lane) : 0u;
     const uint32_t a_total = (uint32_t)__builtin_amdgcn_readlane((int)a_incl, 0); // (the last sub-unit is lane 0's)
