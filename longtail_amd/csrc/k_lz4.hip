@@ -465,15 +465,21 @@ __device__ __forceinline__ uint32_t lane_from_sub_before(uint32_t v)
 // K5, lane-sequential parse, second formulation (round 4; PV = 2 of k_lz4_segments).  The parse is the one above -- same probe rule,
 // same candidates, same extension limits, same cover rule: the payloads are byte-identical -- restated around what the per-phase
 // cycle counters said it costs (profiles/r04_k5_prof.txt: a probe step took 1500 cycles for ~100 instructions):
-//   * PROBE in two LDS round trips instead of four.  The lane's next bytes live in a three-dword REGISTER window that slides with p
-//     (one exec-masked dword read ahead per crossing, consumed a step later), so the four bytes at p cost no round trip; the private
-//     and the shared candidate's bytes are read by ONE pair of unconditional reads (an invalid candidate reads the lane's own position
-//     and is masked) -- the compiler had serialised the two predicated reads, each with its own s_waitcnt.
+//   * PROBE in three LDS round trips instead of four: the private and the shared candidate's bytes are read by ONE pair of
+//     unconditional reads (an invalid candidate reads the lane's own position and is masked) -- the compiler had serialised the two
+//     predicated reads, each with its own s_waitcnt.  (Round 4 also kept the lane's next bytes in a three-dword register window that
+//     slid with p, for two round trips; round 5 took it out again: the kernel had become bound by the number of instructions it
+//     issues, and the window's bookkeeping was a fifth of the probe round's.)
 //   * EXTENSION in one round trip: the 28 bytes p-8 .. p+20 of both sides are eight aligned dwords each (the window is staged 16
 //     bytes into LDS so that "8 bytes before position 0" is a legal address), read together; the backward count and the first 16
 //     forward bytes come out of the same registers.  Matches of 20 bytes and more take a second 16-byte round, then the wave.
 //   * RECORDS in registers (8 x {start | length << 16, offset}) instead of a global scratch area of 4 KiB per unit that the cover
 //     scans, the size pass and the emission each read back through the memory system (1 B/B written and read on "tokens").
+// Round 5 (tools/isa_blocks.py): the same parse, byte for byte, in a quarter fewer instructions -- vector AND
+// scalar, which issue at the same aggregate rate.  The rules that came out of it: a ballot wants ONE compare (a combination of
+// conditions costs a select and a second compare); wave-uniform state wants the scalar unit; switches of experiments want to be
+// compile-time zeros in the product; code that every wave walks anyway wants | and & and selects instead of || / && / else-if (an
+// exec-mask region is three scalar instructions), code that whole waves usually skip wants the branch.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t LZ4_LPAD = 16; // PV 2: LDS byte offset of the staged window
 constexpr uint32_t LZ4_QUIET = 3;  // lane parser: probe rounds without a hit at an unaligned position before the one-byte steps stop
