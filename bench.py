@@ -117,11 +117,65 @@ def plain_comm(lib, ctx, rank, world, idfile=None, timeout_s=120):
     return Comm(ctx, world, rank, open(idfile, "rb").read(), lib=lib)
 
 
+def comm_library(lib):
+    """(path, rule) of the RCCL the C ABI binds to (comm.hip: $LTHIP_RCCL_PATH, a copy already mapped -- torch's --, the loader's path,
+    beside libtorch), or what was tried."""
+    d = lib.dll
+    d.lthip_comm_library.restype = ctypes.c_char_p
+    d.lthip_comm_library.argtypes = [ctypes.POINTER(ctypes.c_char_p)]
+    how = ctypes.c_char_p()
+    path = d.lthip_comm_library(ctypes.byref(how))
+    return (path or b"").decode(), (how.value or b"").decode()
+
+
+def _report_path(rank):
+    key = os.path.basename(os.environ.get("LTHIP_COMM_ID_FILE", "")) or ("port" + os.environ.get("MASTER_PORT", "0"))
+    return f"/tmp/lthip_preflight.{key}.rank{rank}.json"
+
+
+def preflight_report(rank, world, stage, error=None, **extra):
+    """One rank's account of the first-contact steps of an N > 1 launch: the stage it reached (or failed in), its device, the transport's
+    own error text.  Written to a per-rank file the launcher (or rank 0) merges; a FAILING rank 0 also prints it as the run's one JSON
+    line, so that a failed multi-GPU record is a diagnosis and not the tail of a traceback."""
+    rep = {"rank": rank, "stage": stage, "ok": error is None, "error": None if error is None else str(error)[:800],
+           "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()}
+    rep.update(extra)
+    try:
+        with open(_report_path(rank) + ".tmp", "w") as f:
+            json.dump(rep, f)
+        os.replace(_report_path(rank) + ".tmp", _report_path(rank))
+    except OSError:
+        pass
+    return rep
+
+
+def preflight_failure_line(world, mine, wait_s=3.0):
+    """The ONE line of a failed first contact: the failing stage, the transport's text, and what every rank that got far enough to
+    write its report says about itself (device ids included)."""
+    t0 = time.time()
+    ranks = {}
+    while time.time() - t0 < wait_s and len(ranks) < world:
+        for r in range(world):
+            if r not in ranks and os.path.exists(_report_path(r)):
+                try:
+                    ranks[r] = json.load(open(_report_path(r)))
+                except (OSError, ValueError):
+                    pass
+        time.sleep(0.05)
+    failed = [v for _, v in sorted(ranks.items()) if not v.get("ok")] or ([mine] if mine else [])
+    first = failed[0] if failed else {}
+    return {"handshake": False, "n_gpus_asked": world, "failed_stage": first.get("stage"), "error": first.get("error"),
+            "failed_ranks": [v["rank"] for v in failed], "ranks": [ranks.get(r, {"rank": r, "stage": "no report (the process did not get that far)"}) for r in range(world)],
+            "rccl": first.get("rccl") or (mine or {}).get("rccl")}
+
+
 def handshake_only(args):
     """--handshake-only: everything a plain launch does BEFORE the first kernel -- the id file, lthip_comm_create, a barrier, the
     reductions bench.py makes (max / sum through an all-gather) and one all-to-all -- and a JSON line from rank 0.  With
     LTHIP_COMM_TRANSPORT=shm it needs no GPU (tests/test_comm_shm.py); on an N-GPU node it is the 10-second check that RCCL sees N
-    ranks before a lease is spent on the measurement."""
+    ranks before a lease is spent on the measurement.  A failure is reported with the STAGE it happened in (device / id hand-over /
+    lthip_comm_create = ncclCommInitRank / first all-gather / all-to-all / verdict), the transport's own text and every rank's device:
+    one JSON line, exit code 1."""
     import torch
 
     from longtail_amd.lib import Context, load
@@ -131,37 +185,63 @@ def handshake_only(args):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     lib = load()
     shm = os.environ.get("LTHIP_COMM_TRANSPORT") == "shm"
-    ctx = None
-    if torch.cuda.is_available() and lib.device_count() > 0:
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        dev = local % torch.cuda.device_count() if shm else local
-        torch.cuda.set_device(dev)
-        ctx = Context(dev)
-    elif not shm:
-        raise SystemExit("no GPU: the handshake needs RCCL's devices (LTHIP_COMM_TRANSPORT=shm is the stand-in)")
-    device = "cuda" if ctx is not None else "cpu"
-    comm = plain_comm(lib, ctx, rank, world)
-    info = comm.info()
-    vals = torch.tensor([float(rank + 1), 10.0 * (rank + 1)], dtype=torch.float64, device=device)
-    g = comm.allgather(vals).view(world, -1)
-    comm.sync()
-    ok = bool(g[:, 0].max().item() == world and g[:, 1].sum().item() == 10.0 * world * (world + 1) / 2)
-    # all-to-all: rank r sends (r + 1) * (p + 1) copies of the value 1000 * r + p to rank p
-    sc = [(rank + 1) * (p + 1) for p in range(world)]
-    rc = [(p + 1) * (rank + 1) for p in range(world)]
-    send = torch.cat([torch.full((sc[p],), 1000 * rank + p, dtype=torch.int64, device=device) for p in range(world)])
-    recv = comm.alltoallv(send, sc, rc)
-    comm.sync()
-    want = torch.cat([torch.full((rc[p],), 1000 * p + rank, dtype=torch.int64, device=device) for p in range(world)])
-    ok = ok and bool(torch.equal(recv, want))
-    oks = comm.allgather(torch.tensor([1 if ok else 0], dtype=torch.int32, device=device))
-    comm.sync()
-    all_ok = bool(oks.min().item() == 1)
-    comm.close()
-    if rank == 0:
-        print(json.dumps({"handshake": all_ok, "n_gpus": world, "comm": info, "device": device}))
-    if not all_ok:
+    extra = {"rccl": None if shm else dict(zip(("path", "found_by"), comm_library(lib))), "transport_asked": "host-shm" if shm else "rccl"}
+    stage = "device"
+    try:
+        if os.path.exists(_report_path(rank)):
+            os.unlink(_report_path(rank))
+        ctx = None
+        if torch.cuda.is_available() and lib.device_count() > 0:
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            dev = local % torch.cuda.device_count() if shm else local
+            if dev >= torch.cuda.device_count():
+                raise RuntimeError(f"LOCAL_RANK {local} but this node shows {torch.cuda.device_count()} GPU(s)")
+            torch.cuda.set_device(dev)
+            ctx = Context(dev)
+            props = torch.cuda.get_device_properties(dev)
+            extra.update(device_index=dev, device_name=props.name, devices_visible=torch.cuda.device_count(),
+                         pci_bus_id=getattr(props, "pci_bus_id", None), visible_devices_env=os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES"))
+        elif not shm:
+            raise RuntimeError("no GPU: the handshake needs RCCL's devices (LTHIP_COMM_TRANSPORT=shm is the stand-in)")
+        device = "cuda" if ctx is not None else "cpu"
+        if os.environ.get("LTHIP_HANDSHAKE_FAIL_AT") == f"{rank}:device":  # (tests: a rank that dies before it reaches the others)
+            raise RuntimeError("injected failure (LTHIP_HANDSHAKE_FAIL_AT)")
+        stage = "id hand-over + lthip_comm_create" + ("" if shm else " (ncclCommInitRank)")
+        comm = plain_comm(lib, ctx, rank, world, timeout_s=int(os.environ.get("LTHIP_COMM_TIMEOUT_S", "120")))
+        info = comm.info()
+        stage = "first all-gather"
+        vals = torch.tensor([float(rank + 1), 10.0 * (rank + 1)], dtype=torch.float64, device=device)
+        g = comm.allgather(vals).view(world, -1)
+        comm.sync()
+        ok = bool(g[:, 0].max().item() == world and g[:, 1].sum().item() == 10.0 * world * (world + 1) / 2)
+        if not ok:
+            raise RuntimeError(f"the all-gather delivered {g.tolist()}")
+        stage = "all-to-all"
+        # all-to-all: rank r sends (r + 1) * (p + 1) copies of the value 1000 * r + p to rank p
+        sc = [(rank + 1) * (p + 1) for p in range(world)]
+        rc = [(p + 1) * (rank + 1) for p in range(world)]
+        send = torch.cat([torch.full((sc[p],), 1000 * rank + p, dtype=torch.int64, device=device) for p in range(world)])
+        recv = comm.alltoallv(send, sc, rc)
+        comm.sync()
+        want = torch.cat([torch.full((rc[p],), 1000 * p + rank, dtype=torch.int64, device=device) for p in range(world)])
+        ok = bool(torch.equal(recv, want))
+        stage = "verdict all-gather"
+        oks = comm.allgather(torch.tensor([1 if ok else 0], dtype=torch.int32, device=device))
+        comm.sync()
+        all_ok = bool(oks.min().item() == 1)
+        if not all_ok:
+            raise RuntimeError(f"all-to-all results wrong on ranks {[r for r, v in enumerate(oks.tolist()) if v != 1]}")
+        comm.close()
+    except BaseException as e:  # (SystemExit of the id hand-over's timeout included)
+        mine = preflight_report(rank, world, stage, error=f"{type(e).__name__}: {e}", **extra)
+        if rank == 0 and os.environ.get("LTHIP_PREFLIGHT_MERGED_BY_LAUNCHER") != "1":
+            print(json.dumps(preflight_failure_line(world, mine)), flush=True)
+        else:
+            print(json.dumps(mine), file=sys.stderr, flush=True)
         raise SystemExit(1)
+    preflight_report(rank, world, "done", **extra)
+    if rank == 0:
+        print(json.dumps({"handshake": True, "n_gpus": world, "comm": info, "device": device, "rccl": extra["rccl"]}), flush=True)
 
 
 def self_launch(args):
@@ -186,28 +266,56 @@ def self_launch(args):
         port = s.getsockname()[1]
         s.close()
         env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n))
-    procs = []
-    for r in range(n):
-        procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), *sys.argv[1:]], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc, pending = 0, set(range(n))
+    def run_ranks(argv, env, quiet=False):
+        procs = []
+        for r in range(n):
+            procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), *argv], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                          stdout=(subprocess.PIPE if quiet else None) if r == 0 else subprocess.DEVNULL,
+                                          stderr=subprocess.DEVNULL if quiet else None, text=True))
+        rc, pending = 0, set(range(n))
+        try:
+            while pending:
+                for r in sorted(pending):
+                    code = procs[r].poll()
+                    if code is None:
+                        continue
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        if not quiet:
+                            print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                        for q in pending:
+                            procs[q].terminate()  # exactly the processes started above
+                time.sleep(0.05)
+        finally:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+        return rc, (procs[0].stdout.read() if quiet else None)
+
+    # ---- first contact, by itself: the handshake (id hand-over, lthip_comm_create = ncclCommInitRank, an all-gather, an all-to-all)
+    # BEFORE any measurement.  A failure is ONE JSON line naming the stage, the transport's text and every rank's device; rc != 0.
+    hs_id = tempfile.mktemp(prefix="lthip_comm_id.", dir="/tmp")
+    hs_env = dict(env, LONGTAIL_LAUNCH="plain", LTHIP_COMM_ID_FILE=hs_id, LTHIP_PREFLIGHT_MERGED_BY_LAUNCHER="1")
+    # (LONGTAIL_DIST_BACKEND=gloo is the functional stand-in on a box with fewer GPUs: its collectives are not RCCL's, nothing to shake hands with)
+    do_handshake = args.handshake_only or args.launch == "plain" or os.environ.get("LONGTAIL_DIST_BACKEND", "nccl") == "nccl"
     try:
-        while pending:
-            for r in sorted(pending):
-                code = procs[r].poll()
-                if code is None:
-                    continue
-                pending.discard(r)
-                if code != 0 and rc == 0:
-                    rc = code
-                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
-                    for q in pending:
-                        procs[q].terminate()  # exactly the processes started above
-            time.sleep(0.05)
+        rc, out0 = run_ranks(["--gpus", str(n), "--handshake-only"], hs_env, quiet=True) if do_handshake else (0, "")
+        if rc != 0:
+            os.environ["LTHIP_COMM_ID_FILE"] = hs_id  # (the key of the ranks' report files)
+            print(json.dumps(preflight_failure_line(n, None)), flush=True)
+            return rc
+        if args.handshake_only:
+            sys.stdout.write(out0)
+            sys.stdout.flush()
+            return 0
     finally:
-        for pr in procs:
-            if pr.poll() is None:
-                pr.kill()
+        for f in [hs_id] + [f"/tmp/lthip_preflight.{os.path.basename(hs_id)}.rank{r}.json" for r in range(n)]:
+            if os.path.exists(f):
+                os.unlink(f)
+    try:
+        rc, _ = run_ranks(sys.argv[1:], env)
+    finally:
         if idfile and os.path.exists(idfile):
             os.unlink(idfile)
     return rc
@@ -249,10 +357,34 @@ class Bench:
         # id travels through a file
         if self.world > 1 and not self.plain:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.dev)
-            else:
-                dist.init_process_group(self.backend)
+            # first contact under a launcher (the driver's torch.distributed.run): staged, so that a failure is one JSON line naming
+            # the stage (rendezvous + ncclCommInitRank / first all-reduce), the error text and this rank's device -- not a traceback
+            import datetime
+
+            stage = f"init_process_group({self.backend})"
+            extra = {"device_index": dev_index, "devices_visible": torch.cuda.device_count(), "device_name": torch.cuda.get_device_name(dev_index),
+                     "backend": self.backend, "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+                     "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+            try:
+                if self.backend == "nccl":
+                    dist.init_process_group("nccl", device_id=self.dev, timeout=datetime.timedelta(seconds=int(os.environ.get("LTHIP_COMM_TIMEOUT_S", "300"))))
+                else:
+                    dist.init_process_group(self.backend, timeout=datetime.timedelta(seconds=int(os.environ.get("LTHIP_COMM_TIMEOUT_S", "300"))))
+                stage = "first all-reduce"
+                t = torch.ones(1, dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+                dist.all_reduce(t)
+                if self.backend == "nccl":
+                    torch.cuda.synchronize(self.dev)
+                if int(t.item()) != self.world:
+                    raise RuntimeError(f"the all-reduce of ones over {self.world} ranks gave {t.item()}")
+                preflight_report(self.rank, self.world, "done", **extra)
+            except BaseException as e:
+                mine = preflight_report(self.rank, self.world, stage, error=f"{type(e).__name__}: {e}", **extra)
+                if self.rank == 0:
+                    print(json.dumps(preflight_failure_line(self.world, mine)), flush=True)
+                else:
+                    print(json.dumps(mine), file=sys.stderr, flush=True)
+                raise SystemExit(1)
         self.ctx = Context(dev_index)
         self.bufs = {}
         # --collective c: the exchange's collectives through the C ABI instead of torch.distributed; the unique id travels through the

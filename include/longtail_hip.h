@@ -313,6 +313,13 @@ LTHIP_EXPORT int lthip_zstd_last_decode_stats(lthip_ctx* ctx, uint32_t out[4]);
 /* Tests only: the library caches its environment switches (LTHIP_ZSTD_DBG, LTHIP_LZ4_PD_WAIT, LTHIP_LZ4_SHARED, ...) per process; after
  * this call they are read again, so that one process can run a path and its ablation. */
 LTHIP_EXPORT void lthip_debug_reload_env(void);
+/* Tests only, ABLATION build only (the product library answers ENOTSUP / -1 and has no counter in its allocation path): make the
+ * library's own device / pinned allocations number after+1 .. after+count FROM NOW fail with out-of-memory (after < 0: off);
+ * lthip_debug_alloc_calls = allocations attempted by this process so far, *out_failed = how many were made to fail.  The device-side
+ * counterpart of the reference's FailableStorageAPI tests (test/test.cpp:5677-5752): ENOMEM must come out of CreateVersionIndex /
+ * WriteContent, nothing may leak, the same objects must work on the next call. */
+LTHIP_EXPORT int lthip_debug_fail_alloc(int64_t after, int64_t count);
+LTHIP_EXPORT int64_t lthip_debug_alloc_calls(int64_t* out_failed);
 /* Diagnostics (parity tests): match-finder output of the last lthip_zstd_compress_blocks call (its last internal batch:
  * calls above LTHIP_BATCH_BYTES = 8 GiB of input are processed in several) on this context for the
  * 4 KiB units [first, first + count) -- 16 bytes of meta {nseq, nlit, tail, 0}, 4096 literal bytes and 1024 u64
@@ -548,6 +555,10 @@ typedef struct lthip_comm lthip_comm;
 LTHIP_EXPORT int lthip_comm_unique_id(void* id128);
 LTHIP_EXPORT int lthip_comm_create(lthip_ctx* ctx, int nranks, int rank, const void* id128, lthip_comm** out);
 LTHIP_EXPORT int lthip_comm_destroy(lthip_comm* comm);
+/* The file RCCL was bound from -- $LTHIP_RCCL_PATH, else a librccl already mapped into the process (torch's), else librccl.so.1 /
+ * librccl.so on the loader's path and in /opt/rocm/lib, else beside a mapped libtorch -- or, when none was found, what was tried;
+ * *out_how (may be NULL) names the rule.  Loads the library on first use. */
+LTHIP_EXPORT const char* lthip_comm_library(const char** out_how);
 LTHIP_EXPORT int lthip_comm_info(const lthip_comm* comm, int* out_nranks, int* out_rank, int* out_transport);
 LTHIP_EXPORT int lthip_comm_allgather(lthip_ctx* ctx, lthip_comm* comm, const void* d_send, void* d_recv, uint64_t count,
                                       uint32_t elem_bytes);

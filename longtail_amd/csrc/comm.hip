@@ -13,6 +13,7 @@
 #include <atomic>
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <link.h>
 #include <rccl/rccl.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -35,18 +36,89 @@ struct Rccl
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    const char* (*GetLastError)(ncclComm_t) = nullptr; // optional: the transport's own text of what went wrong
     bool ok = false;
+    char path[512] = {0};  // where the library was found (lthip_comm_library), or what was tried
+    char how[64] = {0};    // which rule found it
+    // "<ncclGetErrorString>: <ncclGetLastError>" of a failed call (a diagnosis for the handshake's JSON line, not just a code)
+    const char* text(ncclResult_t e, ncclComm_t c, char* buf, size_t cap) const
+    {
+        const char* last = GetLastError ? GetLastError(c) : nullptr;
+        snprintf(buf, cap, "%s%s%s", GetErrorString ? GetErrorString(e) : "?", last && last[0] ? ": " : "", last && last[0] ? last : "");
+        return buf;
+    }
 };
+
+// An RCCL that is ALREADY mapped into this process (torch's bundled torch/lib/librccl.so on a box without /opt/rocm/lib/librccl.so.1,
+// or one the embedder linked) is the one to bind to: two copies of the runtime in one process do not share communicators.
+struct FindLoaded
+{
+    char rccl[512];
+    char torch_dir[512];
+};
+int find_loaded_cb(struct dl_phdr_info* info, size_t, void* data)
+{
+    FindLoaded* f = (FindLoaded*)data;
+    const char* n = info->dlpi_name;
+    if (!n || !n[0])
+        return 0;
+    const char* base = strrchr(n, '/');
+    base = base ? base + 1 : n;
+    if (!f->rccl[0] && !strncmp(base, "librccl.so", 10) && strlen(n) < sizeof f->rccl)
+        strcpy(f->rccl, n);
+    if (!f->torch_dir[0] && (!strncmp(base, "libtorch_hip.so", 15) || !strncmp(base, "libtorch_cpu.so", 15)) && (size_t)(base - n) < sizeof f->torch_dir)
+    {
+        memcpy(f->torch_dir, n, (size_t)(base - n));
+        f->torch_dir[base - n] = 0;
+    }
+    return 0;
+}
 
 Rccl& rccl()
 {
     static Rccl r = [] {
         Rccl x;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        // 1. $LTHIP_RCCL_PATH (the embedder knows best)  2. a copy already mapped into the process  3. the loader's search path and
+        // ROCm's directory  4. beside a mapped libtorch (torch/lib/librccl.so: where the GPU boxes of this project keep theirs)
+        auto open_as = [&](const char* name, const char* how) {
+            if (x.so || !name || !name[0])
+                return;
             if ((x.so = dlopen(name, RTLD_NOW | RTLD_LOCAL)))
-                break;
+            {
+                snprintf(x.path, sizeof x.path, "%s", name);
+                snprintf(x.how, sizeof x.how, "%s", how);
+            }
+        };
+        open_as(getenv("LTHIP_RCCL_PATH"), "LTHIP_RCCL_PATH");
+        FindLoaded f;
+        memset(&f, 0, sizeof f);
+        dl_iterate_phdr(find_loaded_cb, &f);
+        open_as(f.rccl, "already loaded in this process");
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+            open_as(name, "loader search path");
+        if (f.torch_dir[0])
+        {
+            char beside[600];
+            for (const char* leaf : {"librccl.so", "librccl.so.1"})
+            {
+                snprintf(beside, sizeof beside, "%s%s", f.torch_dir, leaf);
+                open_as(beside, "beside the loaded libtorch");
+            }
+        }
         if (!x.so)
+        {
+            snprintf(x.path, sizeof x.path, "not found (tried $LTHIP_RCCL_PATH, a loaded librccl, librccl.so.1, librccl.so, /opt/rocm/lib, %s)",
+                     f.torch_dir[0] ? f.torch_dir : "no libtorch loaded");
             return x;
+        }
+        {
+            // the file behind the handle (the loader may have resolved a bare name)
+            void* sym = dlsym(x.so, "ncclGetUniqueId");
+            Dl_info di;
+            if (sym && dladdr(sym, &di) && di.dli_fname && di.dli_fname[0])
+                snprintf(x.path, sizeof x.path, "%s", di.dli_fname);
+        }
+        x.GetLastError = (decltype(x.GetLastError))dlsym(x.so, "ncclGetLastError");
         x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(x.so, "ncclGetUniqueId");
         x.CommInitRank = (decltype(x.CommInitRank))dlsym(x.so, "ncclCommInitRank");
         x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.so, "ncclCommDestroy");
@@ -428,7 +500,14 @@ static int shm_create(lthip_ctx* ctx, int nranks, int rank, const uint8_t* id, l
     k->shm.h->attached.fetch_add(1);
     const int b = shm_barrier(k->shm); // like ncclCommInitRank: returns once every rank is there
     if (b)
+    {
+        // this rank counted itself in and leaves without a communicator: count it out again, and the last one out takes the name
+        // with it (a partial failure -- some ranks through the barrier, this one timed out -- would otherwise leave the survivors'
+        // "last one to leave unlinks" at one forever and the segment in /dev/shm)
+        if (k->shm.h->attached.fetch_sub(1) == 1 && rank != 0)
+            unlink(k->shm.path);
         return fail(b, p);
+    }
     *out = k;
     return 0;
 }
@@ -443,14 +522,17 @@ extern "C" int lthip_comm_create(lthip_ctx* ctx, int nranks, int rank, const voi
         return EINVAL; // RCCL moves device memory on a context's stream
     Rccl& r = rccl();
     if (!r.ok)
-        return lthip_fail(ctx, ENOSYS, "lthip_comm_create", "librccl.so.1 not found");
+        return lthip_fail(ctx, ENOSYS, "lthip_comm_create: librccl", r.path);
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     ncclComm_t c = nullptr;
     const ncclResult_t e = r.CommInitRank(&c, nranks, id, rank);
     if (e != ncclSuccess)
-        return lthip_fail(ctx, EIO, "ncclCommInitRank", r.GetErrorString(e));
+    {
+        char buf[256];
+        return lthip_fail(ctx, EIO, "ncclCommInitRank", r.text(e, nullptr, buf, sizeof buf));
+    }
     lthip_comm* k = new lthip_comm;
     k->transport = LTHIP_COMM_RCCL;
     k->comm = c;
@@ -481,6 +563,15 @@ extern "C" int lthip_comm_destroy(lthip_comm* comm)
         (void)r.CommDestroy(comm->comm);
     delete comm;
     return 0;
+}
+
+// Where the RCCL this library binds to was found (and by which rule), or what was tried: first-contact diagnosis of an N > 1 launch.
+extern "C" const char* lthip_comm_library(const char** out_how)
+{
+    Rccl& r = rccl();
+    if (out_how)
+        *out_how = r.how;
+    return r.path;
 }
 
 extern "C" int lthip_comm_info(const lthip_comm* comm, int* out_nranks, int* out_rank, int* out_transport)
@@ -518,11 +609,14 @@ extern "C" int lthip_comm_allgather(lthip_ctx* ctx, lthip_comm* comm, const void
     }
     Rccl& r = rccl();
     if (!r.ok)
-        return lthip_fail(ctx, ENOSYS, "lthip_comm_allgather", "librccl.so.1 not found");
+        return lthip_fail(ctx, ENOSYS, "lthip_comm_allgather", r.path);
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     const ncclResult_t e = r.AllGather(d_send, d_recv, (size_t)count * elem_bytes, ncclUint8, comm->comm, ctx->stream);
     if (e != ncclSuccess)
-        return lthip_fail(ctx, EIO, "ncclAllGather", r.GetErrorString(e));
+    {
+        char buf[256];
+        return lthip_fail(ctx, EIO, "ncclAllGather", r.text(e, comm->comm, buf, sizeof buf));
+    }
     return 0;
 }
 
@@ -547,7 +641,7 @@ extern "C" int lthip_comm_alltoallv(lthip_ctx* ctx, lthip_comm* comm, const void
     }
     Rccl& r = rccl();
     if (!r.ok)
-        return lthip_fail(ctx, ENOSYS, "lthip_comm_alltoallv", "librccl.so.1 not found");
+        return lthip_fail(ctx, ENOSYS, "lthip_comm_alltoallv", r.path);
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     // one group: every pair's send and receive are posted together, RCCL runs them concurrently over the xGMI links (point to
     // point: the natural shape of an all-to-all on this fabric); a rank's own share is a send to itself
@@ -563,6 +657,9 @@ extern "C" int lthip_comm_alltoallv(lthip_ctx* ctx, lthip_comm* comm, const void
     if (e == ncclSuccess)
         e = g;
     if (e != ncclSuccess)
-        return lthip_fail(ctx, EIO, "ncclSend/ncclRecv", r.GetErrorString(e));
+    {
+        char buf[256];
+        return lthip_fail(ctx, EIO, "ncclSend/ncclRecv", r.text(e, comm->comm, buf, sizeof buf));
+    }
     return 0;
 }

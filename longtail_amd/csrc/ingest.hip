@@ -52,7 +52,7 @@ int reserve_dev(lthip_ctx* ctx, DBuf& b, size_t bytes)
         b.cap = 0;
     }
     const size_t cap = bytes + bytes / 8 + 4096;
-    LTHIP_CHECK(ctx, hipMalloc(&b.p, cap));
+    LTHIP_CHECK(ctx, lthip_hip_malloc(&b.p, cap));
     b.cap = cap;
     return 0;
 }
@@ -71,7 +71,7 @@ int reserve_pinned(lthip_ctx* ctx, HBuf& b, size_t bytes)
         b.cap = 0;
     }
     const size_t cap = bytes + bytes / 8 + 4096;
-    LTHIP_CHECK(ctx, hipHostMalloc(&b.p, cap, hipHostMallocDefault));
+    LTHIP_CHECK(ctx, lthip_hip_host_malloc(&b.p, cap, hipHostMallocDefault));
     b.cap = cap;
     return 0;
 }
@@ -208,7 +208,8 @@ struct lthip_ingest
     // sizes are completed by lthip_ingest_finish (they need the compressed sizes)
     uint64_t img_first;
     std::vector<uint64_t> img_offsets;
-    std::vector<uint32_t> img_sizes;
+    std::vector<uint32_t> img_sizes; // header + payload per image: computed by every lthip_ingest_finish from img_hdr (calling it twice adds nothing twice)
+    std::vector<uint32_t> img_hdr;   // BlockIndex + [raw][compressed] of the last batch's images
 };
 
 // LTHIP_INGEST_TRACE=1: host time between the marks of lthip_ingest_index / _write, to stderr
@@ -837,6 +838,7 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
     g->img_first = 0;
     g->img_offsets.clear();
     g->img_sizes.clear();
+    g->img_hdr.clear();
     std::vector<uint64_t> src_off, dst_off, img_off, g_src, g_dst, bfirst;
     std::vector<uint32_t> src_size, dst_cap, g_len, braw;
     // more blocks, when the batch being put together has taken all there are and chunks are left
@@ -1028,9 +1030,10 @@ extern "C" int lthip_ingest_write(lthip_ingest* g, const void* d_data, void* d_a
         }
         g->img_first = b0;
         g->img_offsets.assign(img_off.begin(), img_off.end());
-        g->img_sizes.resize(cnt);
+        g->img_hdr.resize(cnt);
         for (size_t b = b0; b < b1; ++b)
-            g->img_sizes[b - b0] = (uint32_t)lthip_stored_block_header_size((uint32_t)(g->b_first[b + 1] - g->b_first[b]));
+            g->img_hdr[b - b0] = (uint32_t)lthip_stored_block_header_size((uint32_t)(g->b_first[b + 1] - g->b_first[b]));
+        g->img_sizes = g->img_hdr; // (headers only until lthip_ingest_finish knows the payload sizes)
         b0 = b1;
     }
     if ((err = ingest_vi_start(g)) || (err = ingest_blocks_done(g))) // (nothing to write)
@@ -1060,6 +1063,10 @@ extern "C" int lthip_ingest_finish(lthip_ingest* g, void* h_store_index, size_t 
     if (!g || !g->indexed)
         return EINVAL;
     lthip_ctx* ctx = g->ctx;
+    // (the caller says how large ITS struct is: a header older or newer than this library's never gets written past its end.  Checked
+    // before any work: a call that is going to be refused changes nothing)
+    if (out && (out->struct_size < 16 || out->struct_size > 4096))
+        return lthip_fail(ctx, EINVAL, "lthip_ingest_finish", "out_result->struct_size must be set to sizeof(lthip_ingest_result)");
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     {
         int err = ingest_blocks_done(g); // (an index without lthip_ingest_write)
@@ -1110,15 +1117,12 @@ extern "C" int lthip_ingest_finish(lthip_ingest* g, void* h_store_index, size_t 
     if (g->written)
     {
         const uint32_t* comp = (const uint32_t*)((const uint8_t*)g->h_comp.p + 8);
-        for (size_t i = 0; i < g->img_sizes.size(); ++i)
-            g->img_sizes[i] += comp[g->img_first + i]; // header (BlockIndex + [raw][compressed]) + payload
+        for (size_t i = 0; i < g->img_hdr.size(); ++i)
+            g->img_sizes[i] = g->img_hdr[i] + comp[g->img_first + i]; // header (BlockIndex + [raw][compressed]) + payload
     }
     if (out)
     {
-        // (the caller says how large ITS struct is: a header older or newer than this library's never gets written past its end)
         const uint64_t have = out->struct_size;
-        if (have < 16 || have > 4096)
-            return lthip_fail(ctx, EINVAL, "lthip_ingest_finish", "out_result->struct_size must be set to sizeof(lthip_ingest_result)");
         g->res.struct_size = have < sizeof g->res ? have : sizeof g->res;
         memcpy(out, &g->res, (size_t)g->res.struct_size);
     }

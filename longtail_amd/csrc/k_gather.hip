@@ -119,6 +119,12 @@ extern "C" int lthip_exchange_reorder(lthip_ctx* ctx, const void* d_gathered, vo
         return 0;
     if (range_count > 0x7FFFFFFFull)
         return lthip_fail(ctx, EINVAL, "lthip_exchange_reorder", "too many ranges");
+    // k_scale_ranges holds a range's length in bytes in 32 bits (k_gather_ranges' table format): a range of count * elem_bytes above
+    // that would be copied in part, silently -- refused instead (lthip_exchange_ranges cuts ranges at max_piece ELEMENTS; a caller
+    // that passes a large max_piece with 8-byte elements lands here)
+    for (uint64_t i = 0; i < range_count; ++i)
+        if ((uint64_t)range_cnt[i] * elem_bytes > 0xFFFFFFFFull)
+            return lthip_fail(ctx, EINVAL, "lthip_exchange_reorder", "a range of more than 4 GiB - 1 bytes: cut the ranges smaller (max_piece)");
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     // tables: {src, dst} u64 + cnt u32 in elements, then the same in bytes
     const size_t n = (size_t)range_count, n8 = (n + 1) & ~(size_t)1;

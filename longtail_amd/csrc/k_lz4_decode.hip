@@ -1792,7 +1792,7 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     if (trace)
     {
         void* hp = nullptr;
-        LTHIP_CHECK(ctx, hipHostMalloc(&hp, 32 * (size_t)grid, hipHostMallocMapped));
+        LTHIP_CHECK(ctx, lthip_hip_host_malloc(&hp, 32 * (size_t)grid, hipHostMallocMapped));
         memset(hp, 0, 32 * (size_t)grid);
         dbg = (volatile uint32_t*)hp; // host-visible progress words, freed below once the kernel is through
     }

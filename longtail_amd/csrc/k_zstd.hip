@@ -2985,11 +2985,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             {
                 // (relaxed polls: an acquire per poll would invalidate the CU's vector cache under the waves that are at work; one
                 // acquire fence once the flag is up)
+                // The wait is BOUNDED.  Forward progress here rests on the piece before having been dispatched already (lower
+                // blockIdx in the link-major order, or an earlier launch) -- true of the command processor's in-order dispatch on
+                // this hardware, but not a promise of HIP: a different partition mode, queue preemption or a debugger may hold the
+                // predecessor's workgroup back while waiters occupy the slots it needs.  ZX_WAIT_TICKS of the 100 MHz wall clock
+                // (1 s: a piece executes in well under a millisecond, a chain of ZCHAIN in a few) and the piece gives up: it reports
+                // failure like any other (status ZP_SERIAL, retry[payload], done = 2 for the piece behind it), the payload goes to
+                // the serial decoder, and the slot is free again -- a slow restore instead of a hung GPU.
+                constexpr unsigned long long ZX_WAIT_TICKS = 100000000ull;
                 uint32_t f;
+                const unsigned long long t_wait = wall_clock64();
+                bool gave_up = false;
                 while ((f = __hip_atomic_load(&done[i - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u)
+                {
                     __builtin_amdgcn_s_sleep(32);
+                    if (wall_clock64() - t_wait > ZX_WAIT_TICKS)
+                    {
+                        gave_up = true;
+                        break;
+                    }
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                pred_failed = f != 1u;
+                pred_failed = gave_up || f != 1u;
             }
             else if (st != ZP_DONE)
                 pred_failed = true;

@@ -29,7 +29,7 @@ int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out)
             ctx->scratch_cap[slot] = 0;
         }
         size_t cap = bytes + bytes / 8 + 4096; // head-room so slowly growing batches do not realloc
-        LTHIP_CHECK(ctx, hipMalloc(&ctx->scratch[slot], cap));
+        LTHIP_CHECK(ctx, lthip_hip_malloc(&ctx->scratch[slot], cap));
         ctx->scratch_cap[slot] = cap;
     }
     *out = ctx->scratch[slot];
@@ -38,6 +38,71 @@ int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out)
 
 volatile uint32_t g_lthip_env_gen = 1;
 extern "C" void lthip_debug_reload_env(void) { g_lthip_env_gen = g_lthip_env_gen + 1u; }
+
+// ---- allocation-failure injection (ablation build only; the product build answers ENOTSUP and has no counter in its allocation path) ----
+#ifdef LTHIP_ABLATIONS
+namespace
+{
+std::atomic<int64_t> g_alloc_calls{0};            // allocations attempted by this process (both kinds)
+std::atomic<int64_t> g_fail_first{INT64_MAX};     // 1-based number of the first allocation that fails
+std::atomic<int64_t> g_fail_last{INT64_MAX};      // ... and of the last one (inclusive)
+std::atomic<int64_t> g_alloc_failed{0};           // how many were made to fail
+bool inject_failure()
+{
+    const int64_t n = g_alloc_calls.fetch_add(1, std::memory_order_relaxed) + 1;
+    if (n < g_fail_first.load(std::memory_order_relaxed) || n > g_fail_last.load(std::memory_order_relaxed))
+        return false;
+    g_alloc_failed.fetch_add(1, std::memory_order_relaxed);
+    return true;
+}
+} // namespace
+hipError_t lthip_hip_malloc(void** p, size_t bytes)
+{
+    if (inject_failure())
+    {
+        *p = nullptr;
+        return hipErrorOutOfMemory;
+    }
+    return hipMalloc(p, bytes);
+}
+hipError_t lthip_hip_host_malloc(void** p, size_t bytes, unsigned flags)
+{
+    if (inject_failure())
+    {
+        *p = nullptr;
+        return hipErrorOutOfMemory;
+    }
+    return hipHostMalloc(p, bytes, flags);
+}
+extern "C" int lthip_debug_fail_alloc(int64_t after, int64_t count)
+{
+    if (after < 0 || count <= 0)
+    {
+        g_fail_first = INT64_MAX; // off
+        g_fail_last = INT64_MAX;
+        return 0;
+    }
+    const int64_t now = g_alloc_calls.load();
+    g_fail_last = INT64_MAX;
+    g_fail_first = now + after + 1;
+    g_fail_last = count > INT64_MAX - (now + after) ? INT64_MAX : now + after + count;
+    return 0;
+}
+extern "C" int64_t lthip_debug_alloc_calls(int64_t* out_failed)
+{
+    if (out_failed)
+        *out_failed = g_alloc_failed.load();
+    return g_alloc_calls.load();
+}
+#else
+extern "C" int lthip_debug_fail_alloc(int64_t, int64_t) { return ENOTSUP; }
+extern "C" int64_t lthip_debug_alloc_calls(int64_t* out_failed)
+{
+    if (out_failed)
+        *out_failed = 0;
+    return -1;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // context
@@ -158,7 +223,7 @@ extern "C" int lthip_malloc_device(lthip_ctx* ctx, size_t bytes, void** out)
     if (!ctx || !out)
         return EINVAL;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
-    LTHIP_CHECK(ctx, hipMalloc(out, bytes ? bytes : 16));
+    LTHIP_CHECK(ctx, lthip_hip_malloc(out, bytes ? bytes : 16));
     return 0;
 }
 
@@ -179,7 +244,7 @@ extern "C" int lthip_malloc_pinned(lthip_ctx* ctx, size_t bytes, void** out)
     if (!ctx || !out)
         return EINVAL;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
-    LTHIP_CHECK(ctx, hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+    LTHIP_CHECK(ctx, lthip_hip_host_malloc(out, bytes ? bytes : 16, hipHostMallocDefault));
     return 0;
 }
 
@@ -270,7 +335,7 @@ int lthip_stage_upload(lthip_ctx* ctx, void* d_dst, const void* h_src, size_t by
         st.p = nullptr;
         st.cap = 0;
         const size_t want = small ? LTHIP_STAGE_SMALL : bytes + bytes / 2 + 4096;
-        LTHIP_CHECK(ctx, hipHostMalloc(&st.p, want, hipHostMallocDefault));
+        LTHIP_CHECK(ctx, lthip_hip_host_malloc(&st.p, want, hipHostMallocDefault));
         st.cap = want;
     }
     if (!st.done)
@@ -554,9 +619,9 @@ extern "C" int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const uint
     plan->cap_parts = part_count ? part_count : 1;
     plan->cap_tiles = tiles ? tiles : 1;
 
-    hipError_t e = hipMalloc((void**)&plan->d_parts, sizeof(PartDev) * (part_count ? part_count : 1));
+    hipError_t e = lthip_hip_malloc((void**)&plan->d_parts, sizeof(PartDev) * (part_count ? part_count : 1));
     if (e == hipSuccess)
-        e = hipMalloc((void**)&plan->d_tile_part, sizeof(uint32_t) * (tiles ? tiles : 1));
+        e = lthip_hip_malloc((void**)&plan->d_tile_part, sizeof(uint32_t) * (tiles ? tiles : 1));
     if (e == hipSuccess && part_count)
         e = hipMemcpyAsync(plan->d_parts, parts.data(), sizeof(PartDev) * part_count, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)

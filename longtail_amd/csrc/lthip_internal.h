@@ -163,9 +163,9 @@ struct LthipEnvInt
         return value.load(std::memory_order_relaxed);
     }
 };
-// The PRODUCT library reads ten environment variables, all documented in README.md ("Environment"): LONGTAIL_HIP_DEVICE / _BATCH /
+// The PRODUCT library reads eleven environment variables, all documented in README.md ("Environment"): LONGTAIL_HIP_DEVICE / _BATCH /
 // _CODEC_BATCH / _LARGE_WINDOWS / _SMALL_WINDOWS (plugin layer), LTHIP_BATCH_BYTES, LTHIP_ORIGIN_MIB, LTHIP_COMM_TRANSPORT /
-// _TIMEOUT_S / _SHM_SLOT.  Every other LTHIP_* switch selects an earlier formulation of a kernel, a debug path or an experiment's
+// _TIMEOUT_S / _SHM_SLOT / LTHIP_RCCL_PATH.  Every other LTHIP_* switch selects an earlier formulation of a kernel, a debug path or an experiment's
 // parameter; those exist in the ABLATION build only (`make ablations`: -DLTHIP_ABLATIONS, build/ablations/liblongtail_hip.so, loaded
 // by the differential tests and the A/B tools through LTHIP_LIB_PATH).  In the product build such a switch is a constant "not set",
 // so the branches it guards fold away, and the kernels they launch are not compiled (#ifdef LTHIP_ABLATIONS around them).
@@ -177,6 +177,17 @@ struct LthipEnvOff
     constexpr int get() const { return -1; }
 };
 #define LTHIP_ABLATION_ENV(var, name) constexpr LthipEnvOff var{}
+#endif
+// Every device / pinned allocation of the library goes through these two.  Product build: hipMalloc / hipHostMalloc, nothing else.
+// Ablation build: counted, and lthip_debug_fail_alloc(after, count) makes allocations after+1 .. after+count of the process fail with
+// hipErrorOutOfMemory (tests/test_gpu_alloc_failures.py: ENOMEM out of CreateVersionIndex / WriteContent, nothing leaked, the same
+// objects usable again -- the device-side counterpart of the reference's FailableStorageAPI tests, test/test.cpp:5677-5752).
+#ifdef LTHIP_ABLATIONS
+hipError_t lthip_hip_malloc(void** p, size_t bytes);
+hipError_t lthip_hip_host_malloc(void** p, size_t bytes, unsigned flags);
+#else
+static inline hipError_t lthip_hip_malloc(void** p, size_t bytes) { return hipMalloc(p, bytes); }
+static inline hipError_t lthip_hip_host_malloc(void** p, size_t bytes, unsigned flags) { return hipHostMalloc(p, bytes, flags); }
 #endif
 int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out);
 // A second in-order queue of the context for work that should overlap the main stream (callers order the two with

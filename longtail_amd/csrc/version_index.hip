@@ -27,7 +27,7 @@ struct DevBuf
     }
     int alloc(lthip_ctx* ctx, size_t bytes)
     {
-        LTHIP_CHECK(ctx, hipMalloc(&p, bytes ? bytes : 16));
+        LTHIP_CHECK(ctx, lthip_hip_malloc(&p, bytes ? bytes : 16));
         return 0;
     }
 };

@@ -128,6 +128,8 @@ class HipLib:
         sig("lthip_zstd_debug_units", i32, [vp, u64, u64, vp, vp, vp])
         sig("lthip_zstd_last_decode_stats", i32, [vp, vp])
         sig("lthip_debug_reload_env", None, [])
+        sig("lthip_debug_fail_alloc", i32, [C.c_int64, C.c_int64])
+        sig("lthip_debug_alloc_calls", C.c_int64, [P(C.c_int64)])
         sig("lthip_stored_block_header_size", sz, [u32])
         sig("lthip_write_stored_block_headers", i32, [vp, u32, vp, vp, vp, u32, u32, vp, vp, vp, vp])
         sig("lthip_create_missing_content", i32, [vp, u64, vp, u64, vp, vp, vp, u32, u32, u32, vp, sz, vp])

@@ -15,6 +15,7 @@
 #include "lib/compressblockstore/longtail_compressblockstore.h"
 #include "lib/compressionregistry/longtail_compression_registry.h"
 #include "lib/fsblockstore/longtail_fsblockstore.h"
+#include "lib/hashregistry/longtail_hash_registry.h"
 #include "lib/hpcdcchunker/longtail_hpcdcchunker.h"
 #include "lib/lz4/longtail_lz4.h"
 #include "lib/memstorage/longtail_memstorage.h"
@@ -29,7 +30,7 @@
 #include <time.h>
 #include <unistd.h>
 
-int refh_version(void) { return 3; }
+int refh_version(void) { return 4; }
 
 /* ------------------------------------------------------------------------------------------------
  * algorithm probes through the reference's plugin structs
@@ -824,8 +825,8 @@ static struct Longtail_CompressionRegistryAPI* make_registry(struct Longtail_Com
  * `tag` is `codec_api` (0 => reference), then RESTORE the tree with a reference-only registry
  * (Longtail_WriteVersion) and compare every file byte for byte.
  * Returns 0 when everything round-trips; stats in out_*. */
-static int ingest_impl(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_HashAPI* hash_api,
-                       struct Longtail_CompressionAPI* codec_api, uint32_t tag, uint32_t nfiles,
+static int ingest_core(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_HashAPI* hash_api,
+                       struct Longtail_CompressionRegistryAPI* reg_w /* disposed here */, uint32_t tag, uint32_t nfiles,
                        const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
                        uint32_t target_chunk_size, uint32_t max_block_size, uint32_t max_chunks_per_block,
                        int workers, int verify, uint64_t* out_chunk_count, uint64_t* out_block_count,
@@ -838,16 +839,18 @@ static int ingest_impl(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_
     struct Longtail_StoreIndex* existing = 0;
     struct Longtail_StoreIndex* missing = 0;
     struct timespec a, b;
-    int err = tree_make(&t, nfiles, names, datas, sizes, workers, tag);
+    int err = reg_w ? tree_make(&t, nfiles, names, datas, sizes, workers, tag) : ENOMEM;
     if (err)
+    {
+        SAFE_DISPOSE_API(reg_w);
         return err;
+    }
     if (!chunker_api)
         chunker_api = own_c = Longtail_CreateHPCDCChunkerAPI();
     if (!hash_api)
         hash_api = own_h = Longtail_CreateBlake3HashAPI();
 
     struct Longtail_StorageAPI* target = Longtail_CreateInMemStorageAPI();
-    struct Longtail_CompressionRegistryAPI* reg_w = make_registry(codec_api, tag);
     struct Longtail_BlockStoreAPI* fs = verify ? Longtail_CreateFSBlockStoreAPI(t.jobs, target, "store", 0, 0) : make_null_store();
     struct Longtail_BlockStoreAPI* cbs = Longtail_CreateCompressBlockStoreAPI(fs, reg_w);
 
@@ -933,6 +936,84 @@ static int ingest_impl(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_
     return err;
 }
 
+static int ingest_impl(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_HashAPI* hash_api,
+                       struct Longtail_CompressionAPI* codec_api, uint32_t tag, uint32_t nfiles,
+                       const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
+                       uint32_t target_chunk_size, uint32_t max_block_size, uint32_t max_chunks_per_block,
+                       int workers, int verify, uint64_t* out_chunk_count, uint64_t* out_block_count,
+                       uint64_t* out_stored_bytes, double* out_seconds_index, double* out_seconds_write)
+{
+    return ingest_core(chunker_api, hash_api, make_registry(codec_api, tag), tag, nfiles, names, datas, sizes, target_chunk_size,
+                       max_block_size, max_chunks_per_block, workers, verify, out_chunk_count, out_block_count, out_stored_bytes,
+                       out_seconds_index, out_seconds_write);
+}
+
+/* The embedding exactly as INTEGRATION.md prints it (the registries OWN the plugin objects, created lazily through the exported
+ * factories and disposed with the registry -- lib/compressionregistry/longtail_compression_registry.c:50-146,
+ * lib/hashregistry/longtail_hash_registry.c:41-67):
+ *     Longtail_CreateDefaultCompressionRegistry(3, {CreateForHipLZ4, CreateForHipZstd, Longtail_CompressionRegistry_CreateForLZ4})
+ *     Longtail_CreateDefaultHashRegistry(1, {Longtail_GetBlake3HashType()}, {Longtail_CreateHipBlake3HashAPI()})
+ * The function pointers come from liblongtail_hip.so (this library is not linked against it); the hash API is looked up
+ * through GetHashAPI with the reference's type id.  UpSync with those, restore through a REFERENCE-ONLY registry, compare the files.
+ * out_apis_created: how many CompressionAPI objects the registry's factories were asked to make that succeeded (one per type USED). */
+typedef struct Longtail_CompressionAPI* (*refh_create_for_type)(uint32_t, uint32_t*);
+typedef struct Longtail_HashAPI* (*refh_create_hash)(void);
+typedef struct Longtail_ChunkerAPI* (*refh_create_chunker)(void);
+static refh_create_for_type g_emb_lz4, g_emb_zstd;
+static int g_emb_created;
+static struct Longtail_CompressionAPI* emb_for_lz4(uint32_t type, uint32_t* out_settings)
+{
+    struct Longtail_CompressionAPI* a = g_emb_lz4(type, out_settings);
+    g_emb_created += a != 0;
+    return a;
+}
+static struct Longtail_CompressionAPI* emb_for_zstd(uint32_t type, uint32_t* out_settings)
+{
+    struct Longtail_CompressionAPI* a = g_emb_zstd(type, out_settings);
+    g_emb_created += a != 0;
+    return a;
+}
+
+int refh_ingest_registry_embedding(void* create_for_hip_lz4, void* create_for_hip_zstd, void* create_hip_hash,
+                                   void* create_hip_chunker, uint32_t tag, uint32_t nfiles, const char* const* names,
+                                   const uint8_t* const* datas, const uint64_t* sizes, uint32_t target_chunk_size,
+                                   uint32_t max_block_size, uint32_t max_chunks_per_block, int workers, uint64_t* out_chunk_count,
+                                   uint64_t* out_block_count, uint64_t* out_stored_bytes, int* out_apis_created)
+{
+    if (!create_for_hip_lz4 || !create_for_hip_zstd || !create_hip_hash || !create_hip_chunker)
+        return EINVAL;
+    g_emb_lz4 = (refh_create_for_type)create_for_hip_lz4;
+    g_emb_zstd = (refh_create_for_type)create_for_hip_zstd;
+    g_emb_created = 0;
+    Longtail_CompressionRegistry_CreateForTypeFunc funcs[3] = {emb_for_lz4, emb_for_zstd, Longtail_CompressionRegistry_CreateForLZ4};
+    struct Longtail_CompressionRegistryAPI* reg = Longtail_CreateDefaultCompressionRegistry(3, funcs);
+    const uint32_t hash_types[1] = {Longtail_GetBlake3HashType()};
+    const struct Longtail_HashAPI* hash_apis[1] = {((refh_create_hash)create_hip_hash)()};
+    if (!hash_apis[0])
+    {
+        SAFE_DISPOSE_API(reg);
+        return ENODEV;
+    }
+    struct Longtail_HashRegistryAPI* hreg = Longtail_CreateDefaultHashRegistry(1, hash_types, hash_apis);
+    struct Longtail_HashAPI* hash_api = 0;
+    int err = hreg ? hreg->GetHashAPI(hreg, Longtail_GetBlake3HashType(), &hash_api) : ENOMEM;
+    struct Longtail_ChunkerAPI* chunker_api = err ? 0 : ((refh_create_chunker)create_hip_chunker)();
+    if (!err && !chunker_api)
+        err = ENODEV;
+    if (!err && hash_api->GetIdentifier(hash_api) != Longtail_GetBlake3HashType())
+        err = 2100;
+    if (!err) /* (ingest_core disposes the compression registry, and with it the HIP CompressionAPI objects it created) */
+        err = ingest_core(chunker_api, hash_api, reg, tag, nfiles, names, datas, sizes, target_chunk_size, max_block_size,
+                          max_chunks_per_block, workers, 1, out_chunk_count, out_block_count, out_stored_bytes, 0, 0);
+    else
+        SAFE_DISPOSE_API(reg);
+    if (out_apis_created)
+        *out_apis_created = g_emb_created;
+    SAFE_DISPOSE_API(chunker_api);
+    SAFE_DISPOSE_API(hreg); /* disposes the HIP HashAPI */
+    return err;
+}
+
 int refh_ingest_roundtrip(struct Longtail_ChunkerAPI* chunker_api, struct Longtail_HashAPI* hash_api,
                           struct Longtail_CompressionAPI* codec_api, uint32_t tag, uint32_t nfiles,
                           const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
@@ -963,6 +1044,8 @@ int refh_ingest_time(uint32_t tag, uint32_t nfiles, const char* const* names, co
  *     -> Longtail_WriteContent (compressblockstore over a null block sink)
  * with the reference's plugins and Longtail_CreateBikeshedJobAPI(W, 0).  out_seconds[(w * reps + r) * 3 + {0,1,2}] = seconds of
  * the three calls. */
+static uint64_t g_last_raw_bytes;
+uint64_t refh_last_raw_bytes(void) { return g_last_raw_bytes; } /* of the last refh_ingest_sweep*: bytes of the chunks written */
 static int ingest_sweep_impl(struct Longtail_ChunkerAPI* foreign_chunker, struct Longtail_HashAPI* foreign_hash,
                              struct Longtail_CompressionAPI* foreign_codec, uint32_t tag, uint32_t nfiles, const char* const* names,
                              const uint8_t* const* datas, const uint64_t* sizes, uint32_t target_chunk_size, uint32_t max_block_size,
@@ -1021,6 +1104,11 @@ static int ingest_sweep_impl(struct Longtail_ChunkerAPI* foreign_chunker, struct
                     *out_block_count = *missing->m_BlockCount;
                 if (out_stored_bytes)
                     *out_stored_bytes = st.m_StatU64[Longtail_BlockStoreAPI_StatU64_PutStoredBlock_Byte_Count];
+                /* what reached the codec: the unique chunks' bytes (the stored bytes above are [raw][compressed] + payload per block) */
+                uint64_t raw = 0;
+                for (uint32_t c = 0; c < *missing->m_ChunkCount; ++c)
+                    raw += missing->m_ChunkSizes[c];
+                g_last_raw_bytes = raw;
             }
             SAFE_DISPOSE_API(cbs);
             SAFE_DISPOSE_API(reg);

@@ -141,6 +141,9 @@ class Ref:
         sig("refh_tree_file_infos", i32, [u32, vp, vp, vp, C.POINTER(vp), C.POINTER(u64)])
         sig("refh_missing_content", i32, [vp, u32, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(u64)])
         sig("refh_open_stored_block", i32, [vp, u64, u32, vp, vp, u32, vp, u64, C.POINTER(u64)])
+        sig("refh_ingest_registry_embedding", i32, [vp, vp, vp, vp, u32, u32, vp, vp, vp, u32, u32, u32, i32, C.POINTER(u64), C.POINTER(u64),
+                                                   C.POINTER(u64), C.POINTER(i32)])
+        sig("refh_last_raw_bytes", u64, [])
         self.lz4_type = int(d.refh_lz4_type())
         self.zstd_default = int(d.refh_zstd_type(1))
 
@@ -253,6 +256,19 @@ class Ref:
         return dict(err=err, chunks=nchunks.value, blocks=nblocks.value, stored_bytes=stored.value,
                     seconds_index=t_index.value, seconds_write=t_write.value)
 
+
+    def ingest_registry_embedding(self, hip_dll, files, target_chunk_size, max_block_size, max_chunks_per_block, tag, workers=0):
+        """UpSync + reference-only restore with the registries INTEGRATION.md prints: Longtail_CreateDefaultCompressionRegistry over the
+        exported Longtail_CompressionRegistry_CreateForHipLZ4 / ...HipZstd factories (+ the reference's LZ4 one) and a
+        Longtail_CreateDefaultHashRegistry entry holding Longtail_CreateHipBlake3HashAPI(); the registries own and dispose the objects."""
+        n, c_names, c_datas, c_sizes, keep = self._tree_args(files)
+        fn = lambda name: C.cast(getattr(hip_dll, name), vp)
+        nchunks, nblocks, stored, made = u64(0), u64(0), u64(0), i32(0)
+        err = self.dll.refh_ingest_registry_embedding(fn("Longtail_CompressionRegistry_CreateForHipLZ4"), fn("Longtail_CompressionRegistry_CreateForHipZstd"),
+                                                      fn("Longtail_CreateHipBlake3HashAPI"), fn("Longtail_CreateHipChunkerAPI"), tag, n, c_names,
+                                                      c_datas, c_sizes, target_chunk_size, max_block_size, max_chunks_per_block, workers,
+                                                      C.byref(nchunks), C.byref(nblocks), C.byref(stored), C.byref(made))
+        return dict(err=err, chunks=nchunks.value, blocks=nblocks.value, stored_bytes=stored.value, apis_created=made.value)
 
     def ingest_time(self, files, target_chunk_size, max_block_size, max_chunks_per_block, tag, workers):
         n, c_names, c_datas, c_sizes, keep = self._tree_args(files)

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported(hiplib):
 
 
 def test_product_reads_only_its_documented_switches(hiplib):
-    """README.md "Environment": the product library reads ten variables.  Every other LTHIP_* switch of rounds 1-4 (kernel flavours,
+    """README.md "Environment": the product library reads eleven variables.  Every other LTHIP_* switch of rounds 1-4 (kernel flavours,
     debug masks, experiments) is compiled by the ablation build only (make ablations, csrc/ablations/*.inc) -- neither their names
     nor the kernels they select are in the shipped binary; the ablation build has both and the same C interface."""
     import subprocess
@@ -39,7 +39,7 @@ def test_product_reads_only_its_documented_switches(hiplib):
     documented += ["LONGTAIL_HIP_LARGE_WINDOWS", "LTHIP_COMM_SHM_SLOT"] if "LONGTAIL_HIP_LARGE_WINDOWS" not in documented else []
     got = names(hiplib.path)
     assert got == sorted(set(documented)), (got, documented)
-    assert len(got) == 10
+    assert len(got) == 11
     symbols = subprocess.run(["strings", "-a", str(hiplib.path)], capture_output=True, text=True, check=True).stdout
     for gone in ("k_buzhash_candidates", "k_lz4_segments_modes", "k_lz4_pd_units", "k_zstd_prepare", "k_zstd_execute_payload", "k_blake3_parents_small"):
         assert gone not in symbols, f"{gone} is an ablation-only kernel"

@@ -190,3 +190,34 @@ def test_no_line_for_fewer_ranks_than_gpus():
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"],
                          capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
     assert out.returncode != 0 and '"n_gpus"' not in out.stdout and "WORLD_SIZE=1" in out.stderr
+
+
+def test_failed_handshake_is_one_json_line_with_the_stage():
+    """First contact that FAILS (a rank dies before it reaches the others; the survivors time out in lthip_comm_create's barrier):
+    `bench.py --gpus N` prints ONE JSON line -- no measurement keys -- naming the failing stage, the error text and what every rank
+    reported about itself, and exits non-zero: a failed multi-GPU record is a diagnosis, not a traceback tail."""
+    out = _bench("--gpus", "2", "--handshake-only", env={"LTHIP_COMM_TRANSPORT": "shm", "LTHIP_COMM_TIMEOUT_S": "3", "LTHIP_HANDSHAKE_FAIL_AT": "1:device"})
+    assert out.returncode != 0
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["handshake"] is False and j["n_gpus_asked"] == 2 and "metric" not in j and "value" not in j
+    assert j["failed_stage"] == "device" and "injected failure" in j["error"] and 1 in j["failed_ranks"]
+    assert len(j["ranks"]) == 2 and j["ranks"][1]["rank"] == 1 and j["ranks"][1]["ok"] is False
+    # the same through the full launch: the handshake runs first, by itself, and the measurement never starts
+    out = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--gib", "0.01", "--no-cpu-baseline", "--no-secondary", "--launch", "plain",
+                 env={"LTHIP_COMM_TRANSPORT": "shm", "LTHIP_COMM_TIMEOUT_S": "3", "LTHIP_HANDSHAKE_FAIL_AT": "0:device"})
+    assert out.returncode != 0
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["failed_stage"] == "device" and '"metric"' not in out.stdout
+
+
+def test_rccl_library_resolution_is_reported():
+    """lthip_comm_library: $LTHIP_RCCL_PATH first, then a copy already mapped into the process (torch's), then the loader's path; a
+    path that does not exist falls through to the next rule instead of failing the launch."""
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); import torch; from longtail_amd.lib import load; import bench; "
+            "print(bench.comm_library(load()))" % str(ROOT))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, LTHIP_RCCL_PATH="/nonexistent/librccl.so"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    path, how = eval(out.stdout.strip().splitlines()[-1])
+    assert "librccl" in path and how in ("already loaded in this process", "loader search path", "beside the loaded libtorch"), (path, how)

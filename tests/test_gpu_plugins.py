@@ -273,6 +273,23 @@ def test_plugins_do_not_leak_under_the_reference_memtracer():
     assert int(line[-1]) >= 4  # the objects were really counted while alive
 
 
+def test_registry_embedding_as_integration_md_prints_it():
+    """INTEGRATION.md's embedding, executed: the reference's Longtail_CreateDefaultCompressionRegistry builds its CompressionAPI objects
+    through the EXPORTED Longtail_CompressionRegistry_CreateForHipLZ4 / ...HipZstd factories and owns them, the hash API comes out of a
+    Longtail_CreateDefaultHashRegistry entry for Longtail_GetBlake3HashType(); UpSync + reference-only restore on LZ4- and zstd-tagged
+    trees at W = 0 and 4; after the registries are disposed nothing is pinned and the memtracer has nothing outstanding
+    (lib/compressionregistry/longtail_compression_registry.c:50-146, lib/hashregistry/longtail_hash_registry.c:41-67)."""
+    import subprocess
+    import sys
+
+    from tests._libs import ROOT
+
+    out = subprocess.run([sys.executable, str(ROOT / "tools" / "registry_embedding_check.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("embedding ok")][-1].split()
+    assert int(line[2]) == 6 and int(line[4]) == 0 and int(line[6]) == 0, line
+
+
 def _stream(api_ptr, pieces):
     """BeginContext / Hash... / EndContext over an iterable of numpy byte arrays, as longtail_blake3.c:24-79 is driven."""
     h = HashAPIStruct.from_address(api_ptr)
