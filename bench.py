@@ -1050,32 +1050,56 @@ def main():
     main_res = b.run(cfg, args.steps, args.warmup)
     secondary = None
     default_headline = args.tree == "files" and args.kind == "random" and args.codec == "lz4" and not args.no_compress
-    if not args.no_secondary and default_headline:
-        # "report both" -- the compressible variant (match path + a real ratio) and the north-star tree
-        secondary = {}
-        for name, over in (("compressible", dict(kind="mixed")), ("dedup", dict(kind="mixed", dups=True)),
-                           ("north_star_tree", dict(tree="mixed-sizes")),
-                           ("north_star_tree_compressible", dict(tree="mixed-sizes", kind="mixed")),
-                           ("zstd_compressible", dict(kind="mixed", codec="zstd"))):  # (the settings id of --zstd-settings: 'ztd2' by default)
-            r = b.run(dict(cfg, **over), max(1, min(args.steps, 2)), 1)
-            secondary[name] = {"value": round(r["value"], 3), "unit": "GB/s", "ms_per_step": round(r["ms_per_step"], 3),
-                               "workload": r["workload"], "ratio": r["result"]["ratio"], "phase_ms": r["phase_ms"],
-                               "dominant_kernel": r["roofline"] and {k: r["roofline"][k] for k in ("kernel", "achieved", "frac")}}
-            if over.get("dups"):
-                # first-seen hits, CreateMissingContent with chunks to drop, blocks assembled from non-contiguous unique chunks
-                secondary[name].update({k: r["result"][k] for k in ("chunks", "unique_chunks", "blocks", "raw_bytes_written",
-                                                                    "gathered_blocks_rank0", "gathered_bytes_rank0", "gather_GBps_rank0")})
-                secondary[name]["dedup_table"] = args.dedup if b.world > 1 else "single rank"
-        if b.world == 1:
-            secondary["restore"] = b.restore_rates()
-            secondary["host_fed"] = b.host_fed_rates()
+    # the reference's CPU path beside EVERY number ("same tree on W cores"): one CpuReference for the headline and the
+    # secondary workloads, rank 0 of a single-GPU run only
+    cr = CpuReference(b, args) if (b.rank == 0 and b.world == 1 and not args.no_cpu_baseline) else None
     cpu_baseline = None
-    if b.rank == 0 and b.world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(args)
-        if cpu_baseline and cpu_baseline.get("drop_in") is not None:
-            if secondary is None:
-                secondary = {}
-            secondary["drop_in"] = cpu_baseline.pop("drop_in")
+    try:
+        if not args.no_secondary and default_headline:
+            # "report both" -- the compressible variant (match path + a real ratio) and the north-star tree; and
+            # BASELINE.json configs[4]'s shape (4 x 16 GiB PAK-style files, ZStd 'ztd2') on data the codec can compress
+            secondary = {}
+            legs = (("compressible", dict(kind="mixed"), 4.0, True), ("dedup", dict(kind="mixed", dups=True), 2.0, False),
+                    ("north_star_tree", dict(tree="mixed-sizes"), 2.0, False),
+                    ("north_star_tree_compressible", dict(tree="mixed-sizes", kind="mixed"), 2.0, False),
+                    ("zstd_compressible", dict(kind="mixed", codec="zstd"), 4.0, True),  # (the settings id of --zstd-settings: 'ztd2' by default)
+                    ("pak_zstd", dict(kind="mixed", codec="zstd", file_mib=16384.0), 4.0, True))
+            for name, over, cpu_gib, with_drop_in in legs:
+                if name == "pak_zstd" and args.gib < 16:
+                    continue  # (the shape needs at least one whole 16 GiB file)
+                c = dict(cfg, **over)
+                r = b.run(c, max(1, min(args.steps, 2)), 1)
+                secondary[name] = {"value": round(r["value"], 3), "unit": "GB/s", "ms_per_step": round(r["ms_per_step"], 3),
+                                   "workload": r["workload"], "ratio": r["result"]["ratio"], "phase_ms": r["phase_ms"],
+                                   "dominant_kernel": r["roofline"] and {k: r["roofline"][k] for k in ("kernel", "achieved", "frac")}}
+                if over.get("dups"):
+                    # first-seen hits, CreateMissingContent with chunks to drop, blocks assembled from non-contiguous unique chunks
+                    secondary[name].update({k: r["result"][k] for k in ("chunks", "unique_chunks", "blocks", "raw_bytes_written",
+                                                                        "gathered_blocks_rank0", "gathered_bytes_rank0", "gather_GBps_rank0")})
+                    secondary[name]["dedup_table"] = args.dedup if b.world > 1 else "single rank"
+                if cr is not None:
+                    cb = cr.leg(c, min(cpu_gib, args.cpu_gib, args.gib), drop_in=with_drop_in)
+                    if "drop_in" in cb:
+                        secondary[name]["drop_in"] = cb.pop("drop_in")
+                    secondary[name]["reference_ratio"] = cb.get("reference_ratio")
+                    secondary[name]["cpu_baseline"] = cb
+                    if cb.get("value"):
+                        secondary[name]["vs_cpu_baseline"] = round(secondary[name]["value"] / cb["value"], 1)
+            if b.world == 1:
+                secondary["restore"] = b.restore_rates()
+                secondary["host_fed"] = b.host_fed_rates()
+        if cr is not None:
+            sweep = sorted({min(32, cr.ncpu), cr.physical, cr.ncpu} - {1}) or [1]
+            cpu_baseline = cr.leg(cfg, min(args.cpu_gib, args.gib), sweep=sweep, drop_in=True, one_gib=1.0)
+            if "error" not in cpu_baseline and cr.have_ref:
+                cpu_baseline["configs0_one_256MiB_file"] = cr.configs0(sorted({sweep[0], cr.ncpu}))
+            if cpu_baseline.get("drop_in") is not None:
+                if secondary is None:
+                    secondary = {}
+                secondary["drop_in"] = cpu_baseline.pop("drop_in")
+    finally:
+        if cr is not None:
+            cr.close()
     if b.rank == 0:
         line = {
             "metric": "ingest GB/s (chunk+hash+compress)",
@@ -1196,120 +1220,219 @@ def dry_run(args):
     }
 
 
-def run_cpu_baseline(args):
-    """SURVEY.md §8(d) protocol: the reference's own code (oracle/_ref: Longtail_CreateVersionIndex + Longtail_CreateMissingContent +
-    Longtail_WriteContent with the reference hpcdc + BLAKE3 + LZ4/ZStd plugins and Longtail_CreateBikeshedJobAPI(W, 0)), source tree
-    on tmpfs behind the reference's file storage, null block sink, W in {1, 32, physical cores, all hardware threads}, 3 repetitions,
-    median; on a bounded sample of the headline tree and on BASELINE.json configs[0] (one 256 MiB file: only 4 non-empty jobs).
-    Without the reference build: the single-thread C restatement (oracle/)."""
-    from tests._libs import have_ref, oracle, ref
+class CpuReference:
+    """SURVEY.md §8(d) protocol, for the headline AND for every secondary workload: the reference's own code (oracle/_ref:
+    Longtail_CreateVersionIndex + Longtail_CreateMissingContent + Longtail_WriteContent with the reference hpcdc + BLAKE3 + LZ4/ZStd
+    plugins and Longtail_CreateBikeshedJobAPI(W, 0)), source tree on tmpfs behind the reference's file storage, null block sink, 3
+    repetitions, median -- on a bounded SAMPLE of the same tree (the same generator, seeds and kind; the bytes are synthesized by the
+    GPU's k_synth_fill, bit-identical to the oracle's generator, and copied to the host: the sample is not what is timed).  Beside it,
+    on the same files: the reference codec's ratio (`reference_ratio`) and the unmodified core with this library's plugin objects
+    (`drop_in`).  Without the reference build: the single-thread C restatement (oracle/)."""
 
-    o = oracle()
-    ncpu = os.cpu_count() or 1
-    kind = KINDS[args.kind]
-    file_bytes = int(args.file_mib * (1 << 20))
-    file_bytes -= file_bytes % 16
+    REPS = 3
 
-    def make_files(n, nbytes, first=0):
-        seeds = asset_seeds(0x10C0FFEE, first, n)
-        return [(f"dir{i % 256:03d}/file{i:06d}.bin", o.synth(nbytes, int(seeds[i]), kind)) for i in range(n)]
+    def __init__(self, b, args):
+        from tests._libs import have_ref, oracle
 
-    if not have_ref():
+        self.b, self.args, self.o = b, args, oracle()
+        self.ncpu = os.cpu_count() or 1
+        self.physical = max(1, self.ncpu // 2)
+        self.w = min(32, self.ncpu)
+        self.have_ref = have_ref()
+        self.storage = "reference in-memory storage"
+        self.hip = None
+        if self.have_ref:
+            from tests._libs import ref
+
+            self.r = ref()
+            shm = "/dev/shm"
+            try:
+                st = os.statvfs(shm)
+                if os.access(shm, os.W_OK) and st.f_bavail * st.f_frsize > (24 << 30):
+                    self.r.dll.refh_set_tree_dir.argtypes = [ctypes.c_char_p]
+                    self.r.dll.refh_set_tree_dir(shm.encode())
+                    self.storage = f"reference file storage on tmpfs ({shm})"
+            except OSError:
+                pass
+
+    def cores_text(self):
+        return (f"W = {self.w} bikeshed workers on a host with {self.ncpu} hardware threads ({self.physical} cores): the reference stops scaling "
+                "at a few dozen workers on this tree (by_workers of the headline leg), so the ratio to this figure is 'vs the reference's best "
+                "worker count', not 'vs every hardware thread busy'")
+
+    def plugins(self, codec):
+        """This library's plugin objects for the drop-in legs (made once, kept until close())."""
+        if self.hip is None:
+            from longtail_amd.lib import load
+
+            d = load().dll
+            self.hip = {"chunker": d.Longtail_CreateHipChunkerAPI(), "hash": d.Longtail_CreateHipBlake3HashAPI(),
+                        "lz4": d.Longtail_CreateHipLZ4CompressionAPI(), "zstd": d.Longtail_CreateHipZStdCompressionAPI()}
+            if not all(self.hip.values()):
+                raise RuntimeError("a HIP plugin constructor returned NULL")
+        return self.hip["chunker"], self.hip["hash"], self.hip[codec]
+
+    def close(self):
+        if self.hip:
+            dispose = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+            for ptr in self.hip.values():
+                dispose(ctypes.c_void_p.from_address(ptr).value)(ptr)
+            self.hip = None
+        if self.b is not None:
+            self.b.bufs["cpu_sample"] = None
+
+    def sample_files(self, cfg, sample_bytes):
+        """[(path, bytes)] of a tree of `sample_bytes` made by the SAME generator as the measured tree: tree 'files' -> the first files of
+        it (a file larger than the sample -- the 16 GiB PAK files -- is represented by its own first `sample_bytes`), 'mixed-sizes' -> the
+        log-uniform size generator run to that total, dups -> the same repeat / shift pattern."""
+        file_bytes = int(cfg["file_mib"] * (1 << 20))
+        file_bytes -= file_bytes % 16
+        if cfg["tree"] == "files" and file_bytes > sample_bytes:
+            file_bytes = sample_bytes - sample_bytes % 16
+        tree = make_tree(cfg["tree"], sample_bytes, file_bytes, dups=cfg.get("dups", False))
+        sizes, n = tree["sizes"], tree["nfiles"]
+        offs = np.zeros(n, np.uint64)
+        if n > 1:
+            np.cumsum(((sizes + np.uint64(15)) // np.uint64(16) * np.uint64(16))[:-1], out=offs[1:])
+        total = int(offs[-1] + sizes[-1])
+        seeds = asset_seeds(0x10C0FFEE, 0, n)[tree["seed_of"]]
+        names = [f"dir{i % 256:03d}/file{i:06d}.bin" for i in range(n)]
+        kind = KINDS[cfg["kind"]]
+        if self.b is not None:
+            b = self.b
+            dev = b.buf("data", total + 256)
+            b.ctx.synth_fill(dev, offs, sizes, seeds, kind, skips=tree["shift"])
+            b.ctx.sync()
+            host = b.buf("cpu_sample", total, pinned=True)
+            host[:total].copy_(dev[:total])
+            b.torch.cuda.synchronize(b.dev)
+            arr = host.numpy()
+            return [(names[i], arr[int(offs[i]) : int(offs[i]) + int(sizes[i])]) for i in range(n)], int(sizes.sum())
+        return [(names[i], self.o.synth(int(sizes[i]), int(seeds[i]), kind, int(tree["shift"][i]))) for i in range(n)], int(sizes.sum())
+
+    def _median(self, res, workers, nbytes):
+        out = {}
+        for wi, w in enumerate(workers):
+            tot = res["seconds"][wi].sum(axis=1)
+            med = int(np.argsort(tot)[self.REPS // 2])
+            sec = res["seconds"][wi][med]
+            out[str(w)] = {"GBps": round(nbytes / float(tot[med]) / 1e9, 3), "median_s": round(float(tot[med]), 4),
+                           "index_s": round(float(sec[0]), 4), "missing_s": round(float(sec[1]), 4), "write_s": round(float(sec[2]), 4)}
+        return out
+
+    def leg(self, cfg, sample_gib, sweep=None, drop_in=True, one_gib=0.0):
+        """cpu_baseline (+ reference_ratio, + drop_in) of one workload.  sweep: worker counts (default: W = 32 only)."""
+        args = self.args
+        if not self.have_ref:
+            return self.port_leg(cfg)
+        r = self.r
+        codec = cfg["codec"]
+        tag = r.lz4_type if codec == "lz4" else r.zstd_default
+        sample_bytes = int(sample_gib * (1 << 30))
+        files, nbytes = self.sample_files(cfg, sample_bytes)
+        sweep = sorted(set(sweep or [self.w]))
+        common = (args.target_chunk_size, args.block_size, args.max_chunks_per_block, tag)
+        tree = r.tree_create(files, tag)
+        try:
+            res = r.ingest_sweep_tree(tree, *common, sweep, self.REPS)
+            if res["err"]:
+                return {"error": f"reference ingest failed: errno {res['err']}"}
+            by_w = self._median(res, sweep, nbytes)
+            payload = res["stored_bytes"] - 8 * res["blocks"]  # ([raw][compressed] heads each stored block, compressblockstore.c:134-136)
+            ref_ratio = round(res["raw_bytes"] / payload, 4) if payload > 0 else None
+            best = max(by_w, key=lambda k: by_w[k]["GBps"])
+            out = {"value": by_w[best]["GBps"], "unit": "GB/s", "cores": int(best), "kind": "reference",
+                   "sample": f"{len(files)} file(s), {nbytes} B = {nbytes / (1 << 30):.2f} GiB of this workload's tree (same generator, seeds, kind '{cfg['kind']}'"
+                             f"{', repeats' if cfg.get('dups') else ''}); Longtail_CreateVersionIndex + Longtail_CreateMissingContent + Longtail_WriteContent, "
+                             f"reference hpcdc+BLAKE3+{codec.upper()}{' level 3 (ztd2)' if codec == 'zstd' else ''}, {self.storage}, null block sink; "
+                             f"median of {self.REPS}; " + self.cores_text(),
+                   "by_workers": by_w, "physical_cores": self.physical, "host_cpus": self.ncpu,
+                   "reference_ratio": ref_ratio, "reference_chunks": res["chunks"], "reference_blocks": res["blocks"],
+                   "sample_fraction_of_tree": round(nbytes / float(int(cfg["gib"] * (1 << 30))), 4)}
+            if drop_in and str(self.w) in by_w:
+                try:
+                    out["drop_in"] = self.drop_in(tree, files, nbytes, cfg, common, by_w[str(self.w)], ref_ratio)
+                except Exception as e:  # (the baseline itself must not fail with it)
+                    out["drop_in"] = {"error": repr(e)}
+        finally:
+            r.tree_destroy(tree)
+        if one_gib and 1 not in sweep:
+            # the single-thread leg on a smaller sample (0.5 GB/s would take 16 s per repetition on 8 GiB)
+            n1 = max(1, min(len(files), int(one_gib * (1 << 30)) // max(1, len(files[0][1]))))
+            one = r.ingest_sweep(files[:n1], *common, [1], self.REPS)
+            if not one["err"]:
+                out["by_workers"]["1"] = dict(self._median(one, [1], sum(len(d) for _, d in files[:n1]))["1"], sample_files=n1)
+        return out
+
+    def drop_in(self, tree, files, nbytes, cfg, common, cpu, ref_ratio):
+        """secondary.*.drop_in: the SAME sample, storage and worker count with this library's plugin objects in the unmodified core --
+        what a longtail embedder gets by switching constructors and nothing else (host buffers in, host buffers out: PCIe, the
+        pull-style per-chunk API and the core's own file reads are all inside) -- all three, and chunker + hash with the CPU codec."""
+        r, w = self.r, self.w
+        chunker, hasher, codec_api = self.plugins(cfg["codec"])
+        r.version_index(files[: min(256, len(files))] if len(files) > 1 else [(files[0][0], files[0][1][: 256 << 20])],
+                        self.args.target_chunk_size, w, 0, chunker, hasher)  # warm-up: contexts, window pool
+        hip = r.ingest_sweep_tree(tree, *common, [w], self.REPS, chunker, hasher, codec_api)
+        if hip["err"]:
+            return {"error": f"errno {hip['err']}"}
+        h = self._median(hip, [w], nbytes)[str(w)]
+        payload = hip["stored_bytes"] - 8 * hip["blocks"]
+        out = {"what": "the unmodified reference core (oracle/_ref) with Longtail_CreateHipChunkerAPI + HipBlake3HashAPI + Hip"
+                       f"{cfg['codec'].upper()}CompressionAPI against its own CPU plugins: same files, same storage, W = {w}, median of {self.REPS}",
+               "workers": w, "sample_files": len(files),
+               "upsync_GBps": {"hip_plugins": h["GBps"], "cpu_plugins": cpu["GBps"], "ratio": round(h["GBps"] / cpu["GBps"], 3)},
+               "create_version_index_GBps": {"hip_plugins": round(nbytes / h["index_s"] / 1e9, 3), "cpu_plugins": round(nbytes / cpu["index_s"] / 1e9, 3),
+                                             "ratio": round(cpu["index_s"] / h["index_s"], 3)},
+               "write_content_GBps": {"hip_plugins": round(nbytes / h["write_s"] / 1e9, 3), "cpu_plugins": round(nbytes / cpu["write_s"] / 1e9, 3),
+                                      "ratio": round(cpu["write_s"] / h["write_s"], 3)},
+               "ratio_hip_codec": round(hip["raw_bytes"] / payload, 4) if payload > 0 else None, "ratio_reference_codec": ref_ratio,
+               "seconds": {"hip_plugins": h, "cpu_plugins": cpu}}
+        # ... and what INTEGRATION.md recommends where one block per Compress call does not feed a GPU codec: HIP chunker + hash, CPU codec
+        mixed = r.ingest_sweep_tree(tree, *common, [w], self.REPS, chunker, hasher, None)
+        if not mixed["err"]:
+            m = self._median(mixed, [w], nbytes)[str(w)]
+            out["upsync_GBps"]["hip_chunker_hash_cpu_codec"] = m["GBps"]
+            out["upsync_GBps"]["ratio_hip_chunker_hash_cpu_codec"] = round(m["GBps"] / cpu["GBps"], 3)
+            out["seconds"]["hip_chunker_hash_cpu_codec"] = m
+        return out
+
+    def configs0(self, sweep):
+        """BASELINE.json configs[0]: one 256 MiB random file (only 4 non-empty jobs)."""
+        if not self.have_ref:
+            return None
+        r, args = self.r, self.args
+        files, nbytes = self.sample_files(dict(tree="files", kind="random", codec="lz4", file_mib=256.0, gib=0.25), 268_435_456)
+        res = r.ingest_sweep(files, args.target_chunk_size, args.block_size, args.max_chunks_per_block, r.lz4_type, sweep, self.REPS)
+        return None if res["err"] else self._median(res, sweep, nbytes)
+
+    def port_leg(self, cfg):
         from tests._libs import IngestResult
 
-        files = make_files(64, file_bytes)
-        blob = np.concatenate([d for _, d in files])
+        o, args = self.o, self.args
+        file_bytes = int(cfg["file_mib"] * (1 << 20))
+        file_bytes = min(file_bytes - file_bytes % 16, 1 << 20)
+        seeds = asset_seeds(0x10C0FFEE, 0, 64)
+        blob = np.concatenate([o.synth(file_bytes, int(seeds[i]), KINDS[cfg["kind"]]) for i in range(64)])
         out = IngestResult()
         err = o.dll.lto_ingest(blob.ctypes.data, len(blob), file_bytes, args.target_chunk_size, args.block_size, 1, out)
         secs = out.seconds_chunk + out.seconds_hash + out.seconds_compress
         return {"value": round(len(blob) / secs / 1e9, 3) if not err else None, "unit": "GB/s", "cores": 1, "kind": "port",
-                "sample": f"64 x {file_bytes} B files, single-thread C restatement (oracle/)", "host_cpus": ncpu}
-    r = ref()
-    tag = r.lz4_type if args.codec == "lz4" else r.zstd_default
-    storage = "reference in-memory storage"
-    shm = "/dev/shm"
+                "sample": f"64 x {file_bytes} B files, single-thread C restatement (oracle/), LZ4", "host_cpus": self.ncpu}
+
+
+def run_cpu_baseline(args, b=None, cfg=None):
+    """The headline's cpu_baseline: the full worker sweep {1, 32, physical cores, all hardware threads} on --cpu-gib of the headline tree,
+    BASELINE.json configs[0], and the drop-in measurement on the same sample."""
+    cfg = cfg or dict(tree=args.tree, kind=args.kind, codec=args.codec, gib=args.gib, file_mib=args.file_mib, dups=args.dups)
+    cr = CpuReference(b, args)
     try:
-        st = os.statvfs(shm)
-        if os.access(shm, os.W_OK) and st.f_bavail * st.f_frsize > (24 << 30):
-            r.dll.refh_set_tree_dir.argtypes = [ctypes.c_char_p]
-            r.dll.refh_set_tree_dir(shm.encode())
-            storage = f"reference file storage on tmpfs ({shm})"
-    except OSError:
-        pass
-    physical = max(1, ncpu // 2)
-    sweep = sorted({1, min(32, ncpu), physical, ncpu})
-    reps = 3
-
-    def measure(files, workers, apis=(None, None, None)):
-        res = r.ingest_sweep(files, args.target_chunk_size, args.block_size, args.max_chunks_per_block, tag, workers, reps, *apis)
-        if res["err"]:
-            return None
-        nbytes = sum(len(d) for _, d in files)
-        out = {}
-        for wi, w in enumerate(workers):
-            tot = np.sort(res["seconds"][wi].sum(axis=1))
-            med = int(np.argsort(res["seconds"][wi].sum(axis=1))[reps // 2])
-            s = res["seconds"][wi][med]
-            out[str(w)] = {"GBps": round(nbytes / float(tot[reps // 2]) / 1e9, 3), "median_s": round(float(tot[reps // 2]), 4),
-                           "index_s": round(float(s[0]), 4), "missing_s": round(float(s[1]), 4), "write_s": round(float(s[2]), 4)}
+        sweep = sorted({min(32, cr.ncpu), cr.physical, cr.ncpu} - {1}) or [1]
+        out = cr.leg(cfg, args.cpu_gib, sweep=sweep, drop_in=True, one_gib=1.0)
+        if "error" not in out and cr.have_ref:
+            out["configs0_one_256MiB_file"] = cr.configs0(sorted({sweep[0], cr.ncpu}))
         return out
-
-    # the single-thread leg on a smaller sample (0.5 GB/s would take 16 s per repetition on 8 GiB)
-    n_big = max(1, int(args.cpu_gib * (1 << 30)) // file_bytes)
-    n_small = max(1, min(n_big, (1 << 30) // file_bytes))
-    files = make_files(n_big, file_bytes)
-    by_w = measure(files, [w for w in sweep if w > 1]) or {}
-    one = measure(files[:n_small], [1])
-    if one:
-        by_w["1"] = dict(one["1"], sample_files=n_small)
-    # ---- secondary.drop_in: the SAME sample, harness and worker count with this library's plugin objects in the unmodified core --
-    # what a longtail embedder gets by switching the three constructors and nothing else (host buffers in, host buffers out: PCIe,
-    # the pull-style per-chunk API and the core's own file reads are all inside)
-    drop_in = None
-    w_drop = min(32, ncpu)
-    if str(w_drop) in by_w:
-        try:
-            from longtail_amd.lib import load
-
-            d = load().dll
-            chunker, hasher = d.Longtail_CreateHipChunkerAPI(), d.Longtail_CreateHipBlake3HashAPI()
-            codec_api = d.Longtail_CreateHipLZ4CompressionAPI() if args.codec == "lz4" else d.Longtail_CreateHipZStdCompressionAPI()
-            r.version_index(files[: min(1024, len(files))], args.target_chunk_size, w_drop, 0, chunker, hasher)  # warm-up: contexts, window pool
-            hip = measure(files, [w_drop], (chunker, hasher, codec_api))
-            # ... and what INTEGRATION.md recommends to an embedder that changes nothing but constructors: the HIP chunker + hash (they pay
-            # inside the unmodified core) with the reference's own CPU codec (one block per Compress call never feeds a GPU codec)
-            mixed_apis = measure(files, [w_drop], (chunker, hasher, None))
-            if hip:
-                h, c = hip[str(w_drop)], by_w[str(w_drop)]
-                nbytes = sum(len(x) for _, x in files)
-                drop_in = {"what": "the unmodified reference core (oracle/_ref) with Longtail_CreateHipChunkerAPI + HipBlake3HashAPI + Hip"
-                                   f"{args.codec.upper()}CompressionAPI against its own CPU plugins: same files, same storage, same bikeshed worker count, median of {reps}",
-                           "workers": w_drop, "sample_files": len(files),
-                           "upsync_GBps": {"hip_plugins": h["GBps"], "cpu_plugins": c["GBps"], "ratio": round(h["GBps"] / c["GBps"], 3)},
-                           "create_version_index_GBps": {"hip_plugins": round(nbytes / h["index_s"] / 1e9, 3), "cpu_plugins": round(nbytes / c["index_s"] / 1e9, 3),
-                                                         "ratio": round(c["index_s"] / h["index_s"], 3)},
-                           "write_content_GBps": {"hip_plugins": round(nbytes / h["write_s"] / 1e9, 3), "cpu_plugins": round(nbytes / c["write_s"] / 1e9, 3),
-                                                  "ratio": round(c["write_s"] / h["write_s"], 3)},
-                           "seconds": {"hip_plugins": h, "cpu_plugins": c}}
-                if mixed_apis:
-                    m = mixed_apis[str(w_drop)]
-                    drop_in["upsync_GBps"]["hip_chunker_hash_cpu_codec"] = m["GBps"]
-                    drop_in["upsync_GBps"]["ratio_hip_chunker_hash_cpu_codec"] = round(m["GBps"] / c["GBps"], 3)
-                    drop_in["seconds"]["hip_chunker_hash_cpu_codec"] = m
-        except Exception as e:  # (the baseline itself must not fail with it)
-            drop_in = {"error": repr(e)}
-    del files
-    cfg0 = measure(make_files(1, 268_435_456, first=1), [w for w in sweep if w > 1][:1] + [ncpu])  # BASELINE.json configs[0]
-    if not by_w:
-        return {"error": "reference ingest failed"}
-    best_w = max(by_w, key=lambda k: by_w[k]["GBps"])
-    return {"value": by_w[best_w]["GBps"], "unit": "GB/s", "cores": int(best_w), "kind": "reference",
-            "sample": f"{n_big} x {file_bytes} B files of the headline tree ({n_small} files for W=1); Longtail_CreateVersionIndex + "
-                      f"Longtail_CreateMissingContent + Longtail_WriteContent, reference hpcdc+BLAKE3+{args.codec.upper()}, bikeshed W workers, "
-                      f"{storage}, null block sink; median of {reps}; value = best W",
-            "by_workers": by_w, "physical_cores": physical, "host_cpus": ncpu,
-            "configs0_one_256MiB_file": cfg0, "drop_in": drop_in,
-            "sample_fraction_of_tree": round(n_big * file_bytes / float(int(args.gib * (1 << 30))), 4)}
+    finally:
+        cr.close()
 
 
 if __name__ == "__main__":

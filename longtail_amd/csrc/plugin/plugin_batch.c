@@ -200,6 +200,15 @@ static void* dispatcher(void* arg)
             g_arena_err = err;
         pthread_cond_broadcast(&g_slot_cv);
         pthread_mutex_unlock(&g_lock);
+        if (err)
+        {
+            /* no arena, no slots, so no request can ever be queued: this dispatcher is done.  The requester that reads g_arena_err
+             * collects the thread, and the NEXT request starts another dispatcher that tries again -- running out of memory once is
+             * the error of the calls that met it, not a state the ChunkerAPI objects stay in (tests/test_gpu_alloc_failures.py) */
+            if (st.ctx)
+                lthip_ctx_destroy(st.ctx);
+            return 0;
+        }
     }
     for (;;)
     {
@@ -299,6 +308,18 @@ int ltp_batch_chunk_hash(struct ltp_chunk_window* w, uint64_t have, uint32_t min
     if (g_arena_err)
     {
         const int e = g_arena_err;
+        if (g_running && !g_joining)
+        {
+            /* the dispatcher that could not make its arena has exited (above): collect it; the next request starts a fresh one */
+            g_joining = 1;
+            g_running = 0;
+            const pthread_t t = g_thread;
+            pthread_mutex_unlock(&g_lock);
+            pthread_join(t, 0);
+            pthread_mutex_lock(&g_lock);
+            g_joining = 0;
+            pthread_cond_broadcast(&g_done);
+        }
         pthread_mutex_unlock(&g_lock);
         return e;
     }

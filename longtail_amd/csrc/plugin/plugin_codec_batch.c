@@ -87,13 +87,6 @@ static void* dispatcher(void* arg)
     (void)arg;
     lthip_ctx* ctx = 0;
     void *d_sizes = 0, *h_sizes = 0;
-    int init_err = lthip_ctx_create(ltp_device(), LTHIP_STREAM_PRIVATE, &ctx) != 0 ? ENODEV : 0;
-    if (init_err)
-        ctx = 0;
-    if (!init_err)
-        init_err = lthip_malloc_device(ctx, LTC_MAX * 4 + 64, &d_sizes);
-    if (!init_err)
-        init_err = lthip_malloc_pinned(ctx, LTC_MAX * 4 + 64, &h_sizes);
     for (;;)
     {
         struct ltc_req* reqs[LTC_MAX];
@@ -129,6 +122,19 @@ static void* dispatcher(void* arg)
         g_tail = keep_tail;
         pthread_mutex_unlock(&g_lock);
 
+        /* the dispatcher's own context and its two small buffers: made for the first submission and, should that fail (out of
+         * memory at that moment), made AGAIN for the next one -- a failed set-up is the error of the requests that met it, not a
+         * state the CompressionAPI objects stay in (tests/test_gpu_alloc_failures.py) */
+        int init_err = 0;
+        if (!ctx && lthip_ctx_create(ltp_device(), LTHIP_STREAM_PRIVATE, &ctx) != 0)
+        {
+            ctx = 0;
+            init_err = ENODEV;
+        }
+        if (!init_err && !d_sizes)
+            init_err = lthip_malloc_device(ctx, LTC_MAX * 4 + 64, &d_sizes);
+        if (!init_err && !h_sizes)
+            init_err = lthip_malloc_pinned(ctx, LTC_MAX * 4 + 64, &h_sizes);
         int errs[LTC_MAX];
         uint32_t submissions = 1;
         const int err = init_err ? init_err : run_batch(ctx, d_sizes, (uint32_t*)h_sizes, reqs, n);

@@ -378,7 +378,8 @@ static int tree_make(struct refh_tree* t, uint32_t nfiles, const char* const* na
     memset(t, 0, sizeof *t);
     if (g_tree_dir[0])
     {
-        snprintf(t->root, sizeof t->root, "%s/refh_tree_%d", g_tree_dir, (int)getpid());
+        static unsigned serial; /* (a tree of its own per call: bench.py keeps one alive across several sweeps while others come and go) */
+        snprintf(t->root, sizeof t->root, "%s/refh_tree_%d_%u", g_tree_dir, (int)getpid(), __atomic_add_fetch(&serial, 1u, __ATOMIC_RELAXED));
         t->storage = Longtail_CreateFSStorageAPI();
     }
     else
@@ -1046,16 +1047,14 @@ int refh_ingest_time(uint32_t tag, uint32_t nfiles, const char* const* names, co
  * the three calls. */
 static uint64_t g_last_raw_bytes;
 uint64_t refh_last_raw_bytes(void) { return g_last_raw_bytes; } /* of the last refh_ingest_sweep*: bytes of the chunks written */
-static int ingest_sweep_impl(struct Longtail_ChunkerAPI* foreign_chunker, struct Longtail_HashAPI* foreign_hash,
-                             struct Longtail_CompressionAPI* foreign_codec, uint32_t tag, uint32_t nfiles, const char* const* names,
-                             const uint8_t* const* datas, const uint64_t* sizes, uint32_t target_chunk_size, uint32_t max_block_size,
-                             uint32_t max_chunks_per_block, uint32_t n_workers, const int* workers, uint32_t reps, double* out_seconds,
-                             uint64_t* out_chunk_count, uint64_t* out_block_count, uint64_t* out_stored_bytes)
+
+/* the timed part, on a tree that exists: for every W of `workers` and every repetition the three calls */
+static int ingest_sweep_on_tree(struct refh_tree* t, struct Longtail_ChunkerAPI* foreign_chunker, struct Longtail_HashAPI* foreign_hash,
+                                struct Longtail_CompressionAPI* foreign_codec, uint32_t tag, uint32_t target_chunk_size, uint32_t max_block_size,
+                                uint32_t max_chunks_per_block, uint32_t n_workers, const int* workers, uint32_t reps, double* out_seconds,
+                                uint64_t* out_chunk_count, uint64_t* out_block_count, uint64_t* out_stored_bytes)
 {
-    struct refh_tree t;
-    int err = tree_make(&t, nfiles, names, datas, sizes, 1, tag);
-    if (err)
-        return err;
+    int err = 0;
     /* a plugin object handed in (the embedder's: liblongtail_hip.so's constructors) replaces the reference's; it stays the caller's */
     struct Longtail_ChunkerAPI* chunker_api = foreign_chunker ? foreign_chunker : Longtail_CreateHPCDCChunkerAPI();
     struct Longtail_HashAPI* hash_api = foreign_hash ? foreign_hash : Longtail_CreateBlake3HashAPI();
@@ -1073,7 +1072,7 @@ static int ingest_sweep_impl(struct Longtail_ChunkerAPI* foreign_chunker, struct
             double* secs = out_seconds + ((size_t)w * reps + r) * 3;
             struct timespec a, b;
             clock_gettime(CLOCK_MONOTONIC, &a);
-            err = Longtail_CreateVersionIndex(t.storage, hash_api, chunker_api, jobs, 0, 0, 0, t.root, t.files, t.tags,
+            err = Longtail_CreateVersionIndex(t->storage, hash_api, chunker_api, jobs, 0, 0, 0, t->root, t->files, t->tags,
                                               target_chunk_size, 0, &vi);
             clock_gettime(CLOCK_MONOTONIC, &b);
             secs[0] = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
@@ -1089,7 +1088,7 @@ static int ingest_sweep_impl(struct Longtail_ChunkerAPI* foreign_chunker, struct
             if (!err)
             {
                 clock_gettime(CLOCK_MONOTONIC, &a);
-                err = Longtail_WriteContent(t.storage, cbs, jobs, 0, 0, 0, missing, vi, t.root);
+                err = Longtail_WriteContent(t->storage, cbs, jobs, 0, 0, 0, missing, vi, t->root);
                 clock_gettime(CLOCK_MONOTONIC, &b);
                 secs[2] = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
             }
@@ -1123,8 +1122,55 @@ static int ingest_sweep_impl(struct Longtail_ChunkerAPI* foreign_chunker, struct
         SAFE_DISPOSE_API(chunker_api);
     if (!foreign_hash)
         SAFE_DISPOSE_API(hash_api);
+    return err;
+}
+
+static int ingest_sweep_impl(struct Longtail_ChunkerAPI* foreign_chunker, struct Longtail_HashAPI* foreign_hash,
+                             struct Longtail_CompressionAPI* foreign_codec, uint32_t tag, uint32_t nfiles, const char* const* names,
+                             const uint8_t* const* datas, const uint64_t* sizes, uint32_t target_chunk_size, uint32_t max_block_size,
+                             uint32_t max_chunks_per_block, uint32_t n_workers, const int* workers, uint32_t reps, double* out_seconds,
+                             uint64_t* out_chunk_count, uint64_t* out_block_count, uint64_t* out_stored_bytes)
+{
+    struct refh_tree t;
+    int err = tree_make(&t, nfiles, names, datas, sizes, 1, tag);
+    if (err)
+        return err;
+    err = ingest_sweep_on_tree(&t, foreign_chunker, foreign_hash, foreign_codec, tag, target_chunk_size, max_block_size, max_chunks_per_block,
+                               n_workers, workers, reps, out_seconds, out_chunk_count, out_block_count, out_stored_bytes);
     tree_free(&t);
     return err;
+}
+
+/* One source tree kept across several sweeps (bench.py: the reference's plugins, then the embedder's, on the SAME files without
+ * writing them to tmpfs again): refh_tree_create -> refh_ingest_sweep_tree ... -> refh_tree_destroy. */
+void* refh_tree_create(uint32_t tag, uint32_t nfiles, const char* const* names, const uint8_t* const* datas, const uint64_t* sizes)
+{
+    struct refh_tree* t = (struct refh_tree*)malloc(sizeof *t);
+    if (!t)
+        return 0;
+    if (tree_make(t, nfiles, names, datas, sizes, 1, tag))
+    {
+        free(t);
+        return 0;
+    }
+    return t;
+}
+void refh_tree_destroy(void* tree)
+{
+    if (!tree)
+        return;
+    tree_free((struct refh_tree*)tree);
+    free(tree);
+}
+int refh_ingest_sweep_tree(void* tree, struct Longtail_ChunkerAPI* chunker_api, struct Longtail_HashAPI* hash_api,
+                           struct Longtail_CompressionAPI* codec_api, uint32_t tag, uint32_t target_chunk_size, uint32_t max_block_size,
+                           uint32_t max_chunks_per_block, uint32_t n_workers, const int* workers, uint32_t reps, double* out_seconds,
+                           uint64_t* out_chunk_count, uint64_t* out_block_count, uint64_t* out_stored_bytes)
+{
+    if (!tree)
+        return EINVAL;
+    return ingest_sweep_on_tree((struct refh_tree*)tree, chunker_api, hash_api, codec_api, tag, target_chunk_size, max_block_size,
+                                max_chunks_per_block, n_workers, workers, reps, out_seconds, out_chunk_count, out_block_count, out_stored_bytes);
 }
 
 int refh_ingest_sweep(uint32_t tag, uint32_t nfiles, const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,

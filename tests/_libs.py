@@ -144,6 +144,9 @@ class Ref:
         sig("refh_ingest_registry_embedding", i32, [vp, vp, vp, vp, u32, u32, vp, vp, vp, u32, u32, u32, i32, C.POINTER(u64), C.POINTER(u64),
                                                    C.POINTER(u64), C.POINTER(i32)])
         sig("refh_last_raw_bytes", u64, [])
+        sig("refh_tree_create", vp, [u32, u32, vp, vp, vp])
+        sig("refh_tree_destroy", None, [vp])
+        sig("refh_ingest_sweep_tree", i32, [vp, vp, vp, vp, u32, u32, u32, u32, u32, vp, u32, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)])
         self.lz4_type = int(d.refh_lz4_type())
         self.zstd_default = int(d.refh_zstd_type(1))
 
@@ -306,6 +309,31 @@ class Ref:
                                               max_block_size, max_chunks_per_block, len(w), w.ctypes.data, reps, secs.ctypes.data,
                                               C.byref(nchunks), C.byref(nblocks), C.byref(stored))
         return dict(err=err, chunks=nchunks.value, blocks=nblocks.value, stored_bytes=stored.value, seconds=secs)
+
+
+    def tree_create(self, files, tag):
+        """The source tree of several sweeps (the reference's file storage on tmpfs when refh_set_tree_dir was called): a handle for
+        ingest_sweep_tree / tree_destroy."""
+        n, c_names, c_datas, c_sizes, keep = self._tree_args(files)
+        h = self.dll.refh_tree_create(tag, n, c_names, c_datas, c_sizes)
+        if not h:
+            raise RuntimeError("refh_tree_create failed")
+        return h
+
+    def tree_destroy(self, handle):
+        self.dll.refh_tree_destroy(handle)
+
+    def ingest_sweep_tree(self, handle, target_chunk_size, max_block_size, max_chunks_per_block, tag, workers, reps,
+                          chunker_api=None, hash_api=None, codec_api=None):
+        """ingest_sweep on a tree made by tree_create; additionally raw_bytes = the bytes of the chunks written (what reached the codec)."""
+        w = np.ascontiguousarray(workers, dtype=np.int32)
+        secs = np.zeros((len(w), reps, 3), np.float64)
+        nchunks, nblocks, stored = u64(0), u64(0), u64(0)
+        err = self.dll.refh_ingest_sweep_tree(handle, chunker_api, hash_api, codec_api, tag, target_chunk_size, max_block_size,
+                                              max_chunks_per_block, len(w), w.ctypes.data, reps, secs.ctypes.data,
+                                              C.byref(nchunks), C.byref(nblocks), C.byref(stored))
+        return dict(err=err, chunks=nchunks.value, blocks=nblocks.value, stored_bytes=stored.value, seconds=secs,
+                    raw_bytes=int(self.dll.refh_last_raw_bytes()))
 
 
 _oracle = None

@@ -338,3 +338,68 @@ def test_link_copy_moves_pinned_host_memory_both_ways(gpu):
         assert (host[d : d + l] == ref_b[o : o + l]).all()
     c_in.close()
     c_out.close()
+
+
+@pytest.mark.parametrize("codec", ["lz4", "zstd"])
+def test_images_as_a_host_fed_embedder_downloads_them(gpu, oracle, ref, codec):
+    """lthip_ingest_images (include/longtail_hip.h: "exactly what Longtail_WriteStoredBlockToBuffer produces"): every image, cut out of
+    the arena by the offsets and sizes the call returns, opens with the reference's Longtail_ReadStoredBlockFromBuffer and decodes with
+    the reference codec to the block's chunk bytes.  lthip_ingest_finish may be called again (a retry with a larger StoreIndex buffer,
+    as res.store_index_size invites): the image sizes stay header + payload, not header + 2 * payload.  The result struct is written
+    up to the size the CALLER states and never past it; an unset struct_size is EINVAL before any work."""
+    from longtail_amd.lib import IngestResult, LongtailHipError
+
+    target, max_block, max_chunks = 4096, 1 << 20, 64
+    files = make_files(oracle, target)
+    tag = ref.lz4_type if codec == "lz4" else ref.zstd_default
+    probe = rank_session(gpu, ref, files, target, 1, 0, "range", codec, max_block, max_chunks, tag)
+    lists = {int(j): (probe["d_hash"][int(probe["first"][m]) : int(probe["first"][m + 1])], probe["d_len"][int(probe["first"][m]) : int(probe["first"][m + 1])])
+             for m, j in enumerate(probe["mine"])}
+    sess = rank_session(gpu, ref, files, target, 1, 0, "range", codec, max_block, max_chunks, tag, lists, arena_bytes=96 << 20)
+    ing, res = sess["ing"], sess["res"]
+    first, offs, sizes = ing.images()
+    assert first == 0 and len(offs) == res.blocks == len(sizes)
+    dll = gpu.lib.dll
+    # ---- a second finish: too small a buffer (ENOMEM + the size wanted), then the retry; sizes unchanged ----
+    small = torch.zeros(16, dtype=torch.uint8).pin_memory()
+    with pytest.raises(LongtailHipError) as e:
+        ing.finish(small)
+    assert e.value.code == 12
+    si2 = torch.zeros(res.store_index_size, dtype=torch.uint8).pin_memory()
+    res2 = ing.finish(si2)
+    assert bytes(si2.numpy()[: res2.store_index_size]) == sess["si"]
+    f2, offs2, sizes2 = ing.images()
+    assert f2 == first and (offs2 == offs).all() and (sizes2 == sizes).all(), "a second finish changed the image sizes"
+    # ---- struct_size: 16 -> two fields written, the canary behind them untouched; 0 -> EINVAL ----
+    buf = (C.c_uint64 * 12)(*([0xA5A5A5A5A5A5A5A5] * 12))
+    buf[0] = 16
+    assert dll.lthip_ingest_finish(ing.h, None, 0, C.byref(buf)) == 0
+    assert buf[0] == 16 and buf[1] == res.chunks_all and all(buf[i] == 0xA5A5A5A5A5A5A5A5 for i in range(2, 12))
+    unset = IngestResult()
+    assert dll.lthip_ingest_finish(ing.h, None, 0, C.byref(unset)) == 22  # EINVAL
+    assert (ing.images()[2] == sizes).all()
+    # ---- the images through the reference ----
+    si = parse_store_index(sess["si"])
+    host = sess["arena"].cpu().numpy()
+    data_host = sess["dev"].cpu().numpy()
+    l_off = sess["d_off"].cpu().numpy().view(np.uint64)[: sess["total"]]
+    l_len = sess["d_len"].cpu().numpy().view(np.uint32)[: sess["total"]]
+    l_hash = sess["d_hash"].cpu().numpy().view(np.uint64)[: sess["total"]]
+    where = {}
+    for k in range(sess["total"]):
+        where.setdefault(int(l_hash[k]), (int(l_off[k]), int(l_len[k])))
+    for b in range(res.blocks):
+        c0, n = int(si["block_offsets"][b]), int(si["block_counts"][b])
+        raw = int(si["chunk_sizes"][c0 : c0 + n].astype(np.int64).sum())
+        image = host[int(offs[b]) : int(offs[b]) + int(sizes[b])].copy()
+        assert int(sizes[b]) == int(dll.lthip_stored_block_header_size(n)) + int(sess["comp"][b])
+        h = np.ascontiguousarray(si["chunk_hashes"][c0 : c0 + n])
+        s = np.ascontiguousarray(si["chunk_sizes"][c0 : c0 + n])
+        out = np.zeros(raw + 8, np.uint8)
+        got = C.c_uint64(0)
+        err = ref.dll.refh_open_stored_block(image.ctypes.data, len(image), n, h.ctypes.data, s.ctypes.data, int(si["block_tags"][b]),
+                                             out.ctypes.data, raw, C.byref(got))
+        assert err == 0, (b, err)
+        expect = np.concatenate([data_host[where[int(x)][0] : where[int(x)][0] + where[int(x)][1]] for x in h])
+        assert got.value == raw and (out[:raw] == expect).all(), b
+    ing.close()
