@@ -13,6 +13,21 @@
 #define LTP_LZ4_TYPE ((((uint32_t)'l') << 24) + (((uint32_t)'z') << 16) + (((uint32_t)'4') << 8) + ((uint32_t)'2'))
 #define LTP_ZSTD_TYPE ((((uint32_t)'z') << 24) + (((uint32_t)'t') << 16) + (((uint32_t)'d') << 8))
 
+/* How a block crosses the link.  The copy engines of the MI355X boxes measured serve ONE direction at a time (h2d and d2h queued on two
+ * streams take the sum of their times, profiles/r05_pcie_duplex.json) while a copy made by the compute units runs beside an engine
+ * copy in the other direction: payloads come back through lthip_link_copy (k_link_copy), blocks go up through the engines, so that
+ * one worker's download overlaps another worker's upload. */
+#ifdef LTP_D2H_ENGINE
+#define LTP_FETCH lthip_copy_d2h
+#else
+#define LTP_FETCH lthip_link_copy
+#endif
+#ifdef LTP_H2D_KERNEL
+#define LTP_SEND lthip_link_copy
+#else
+#define LTP_SEND lthip_copy_h2d
+#endif
+
 enum
 {
     CODEC_LZ4 = 0,
@@ -72,7 +87,7 @@ static int fetch_payload(struct ltp_thread_state* ts, int codec, int decompress,
     if (produced)
     {
         uint8_t* stage = (uint8_t*)ts->h_pin.p + 64;
-        err = lthip_copy_d2h(ts->ctx, stage, ts->d_out.p, produced);
+        err = LTP_FETCH(ts->ctx, stage, ts->d_out.p, produced);
         if (!err)
             err = lthip_ctx_sync(ts->ctx);
         if (!err)
@@ -109,7 +124,7 @@ static int run_block(int codec, int decompress, int quality, const char* src, ch
     if (n)
     {
         memcpy(stage, src, n);
-        err = lthip_copy_h2d(ctx, ts->d_in.p, stage, n);
+        err = LTP_SEND(ctx, ts->d_in.p, stage, n);
         if (err)
             return err;
     }

@@ -14,6 +14,9 @@
 #include "plugin_common.h"
 
 #define LTC_MAX 64
+#ifndef LTC_MIN
+#define LTC_MIN 16 /* up to this many queued blocks a submission takes them all */
+#endif
 
 struct ltc_req
 {
@@ -99,14 +102,24 @@ static void* dispatcher(void* arg)
             pthread_mutex_unlock(&g_lock);
             break;
         }
-        /* everything queued for the operation of the oldest request, in arrival order; the rest waits for the next round */
+        /* What is queued for the operation of the oldest request, in arrival order -- but only the older HALF of it once more than
+         * LTC_MIN are waiting; the rest waits for the next round.  Compress is a blocking call: a worker cannot overlap its own
+         * upload, kernel and download, only different workers can overlap theirs.  When one submission takes everybody, the W
+         * workers move in lock step -- all upload, all wait for the kernels, all download -- and the link runs one direction at a
+         * time (round 5: 21 GB/s of WriteContent at W = 32 on a link that does 55 each way).  Taking half leaves the other half
+         * uploading while these compute and downloading while the next ones upload: the workers fall into staggered groups and both
+         * directions of the link and the kernels run at once. */
+        uint32_t queued = 0;
+        for (const struct ltc_req* q = g_head; q; q = q->next)
+            ++queued;
+        const uint32_t take = queued <= LTC_MIN ? queued : (queued + 1) / 2 > LTC_MIN ? (queued + 1) / 2 : LTC_MIN;
         struct ltc_req *keep_head = 0, *keep_tail = 0, *r = g_head;
         const int kind = r->kind;
         while (r)
         {
             struct ltc_req* nx = r->next;
             r->next = 0;
-            if (n < LTC_MAX && r->kind == kind)
+            if (n < LTC_MAX && n < take && r->kind == kind)
                 reqs[n++] = r;
             else
             {

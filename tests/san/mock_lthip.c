@@ -82,6 +82,12 @@ int lthip_copy_d2h(lthip_ctx* c, void* h, const void* d, size_t n)
     memcpy(h, d, n);
     return 0;
 }
+int lthip_link_copy(lthip_ctx* c, void* dst, const void* src, size_t n)
+{
+    (void)c;
+    memcpy(dst, src, n);
+    return 0;
+}
 int lthip_plan_create(lthip_ctx* c, uint32_t parts, const uint64_t* offs, const uint64_t* sizes, uint32_t mn, uint32_t av, uint32_t mx,
                       lthip_plan** out)
 {
