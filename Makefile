@@ -11,7 +11,7 @@ CSRC    := longtail_amd/csrc
 OBJDIR  := build/obj
 LIB     := longtail_amd/liblongtail_hip.so
 
-HIP_SRC := $(CSRC)/lthip_ctx.hip $(CSRC)/k_buzhash.hip $(CSRC)/k_blake3.hip $(CSRC)/k_lz4.hip $(CSRC)/k_lz4_decode.hip $(CSRC)/k_zstd.hip \
+HIP_SRC := $(CSRC)/lthip_ctx.hip $(CSRC)/k_buzhash.hip $(CSRC)/k_blake3.hip $(CSRC)/k_lz4.hip $(CSRC)/k_lz4_decode.hip $(CSRC)/k_zstd.hip $(CSRC)/k_zstd_decode.hip \
            $(CSRC)/k_dedup.hip $(CSRC)/k_gather.hip $(CSRC)/k_synth.hip $(CSRC)/version_index.hip $(CSRC)/ingest.hip $(CSRC)/comm.hip
 C_SRC   := $(CSRC)/plugin/plugin_common.c $(CSRC)/plugin/plugin_chunker.c $(CSRC)/plugin/plugin_hash.c \
            $(CSRC)/plugin/plugin_codec.c $(CSRC)/plugin/plugin_codec_batch.c $(CSRC)/plugin/plugin_batch.c $(CSRC)/plugin/build_id.c $(CSRC)/plugin/partition.c
@@ -68,9 +68,10 @@ ablations: $(ABL_LIB)
 prof: $(LIB)
 	mkdir -p build/prof
 	$(HIPCC) $(HIPFLAGS) -DLTHIP_ABLATIONS -DLTHIP_ZB_PROF -c $(CSRC)/k_zstd.hip -o build/prof/k_zstd.o
+	$(HIPCC) $(HIPFLAGS) -DLTHIP_ABLATIONS -DLTHIP_ZB_PROF -c $(CSRC)/k_zstd_decode.hip -o build/prof/k_zstd_decode.o
 	$(HIPCC) $(HIPFLAGS) -DLTHIP_ABLATIONS -DLTHIP_DEC_PROF -c $(CSRC)/k_lz4_decode.hip -o build/prof/k_lz4_decode.o
 	$(HIPCC) $(HIPFLAGS) -DLTHIP_K5_PROF -c $(CSRC)/k_lz4.hip -o build/prof/k_lz4.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/prof/liblongtail_hip_prof.so $(filter-out $(OBJDIR)/k_zstd.o $(OBJDIR)/k_lz4_decode.o $(OBJDIR)/k_lz4.o,$(HIP_OBJ)) build/prof/k_zstd.o build/prof/k_lz4_decode.o build/prof/k_lz4.o $(C_OBJ) -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/prof/liblongtail_hip_prof.so $(filter-out $(OBJDIR)/k_zstd.o $(OBJDIR)/k_zstd_decode.o $(OBJDIR)/k_lz4_decode.o $(OBJDIR)/k_lz4.o,$(HIP_OBJ)) build/prof/k_zstd.o build/prof/k_zstd_decode.o build/prof/k_lz4_decode.o build/prof/k_lz4.o $(C_OBJ) -lpthread
 
 clean:
 	rm -rf build $(LIB)

@@ -858,7 +858,7 @@ static int launch_buzhash_prefix(lthip_ctx* ctx, const lthip_plan* plan, const u
 // "prefix16" / "prefix12" = the same with register staging; "roll" = the rolling-window kernel of rounds 1-2
 static int k1_flavour()
 {
-    // (read again after lthip_debug_reload_env: tools/k1_stress_tib.py runs two flavours against each other in one process)
+    // (read again after lthip_debug_reload_env: tools/ablations/k1_stress_tib.py runs two flavours against each other in one process)
     static std::atomic<int> f{-1};
     static std::atomic<uint32_t> seen{0};
     const uint32_t gen = g_lthip_env_gen;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Phase-2 codec comparison on 8 GiB per data kind: tools/codec_sweep.sh [kinds...]
+# Phase-2 codec comparison on 8 GiB per data kind: tools/ablations/codec_sweep.sh [kinds...]
 mkdir -p gpurun_out
 for kind in ${@:-random mixed records tokens lines}; do for codec in lz4 zstd; do
   python bench.py --gib 8 --steps 2 --warmup 1 --kind $kind --codec $codec --no-cpu-baseline 2>gpurun_out/codec_sweep.err | python -c "

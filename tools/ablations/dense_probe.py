@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """LZ4 ratio of the lane parser against the number of one-byte steps a lane takes after a hit or at its start before it only probes
 address-aligned positions (LTHIP_LZ4_DBG bits 29-30: 4, 2, 1, 0), on data whose structure is NOT aligned to the addresses: word soup
-(text), and the synthetic kinds copied to an address that is 1 mod 4.  python tools/dense_probe.py"""
+(text), and the synthetic kinds copied to an address that is 1 mod 4.  python tools/ablations/dense_probe.py"""
 import _ablations  # noqa: F401  (first: the LTHIP_* switches used here exist in the ablation build only)
 import os
 import sys
@@ -10,7 +10,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from bench import KINDS, asset_seeds  # noqa: E402
 from longtail_amd.lib import Context  # noqa: E402
 from tests.gpu_util import u32  # noqa: E402

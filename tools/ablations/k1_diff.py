@@ -1,7 +1,7 @@
-"""Where does a K1 flavour disagree with itself / with the first run?  usage: LTHIP_K1=... python tools/k1_diff.py [gib] [part_mib] [runs]"""
+"""Where does a K1 flavour disagree with itself / with the first run?  usage: LTHIP_K1=... python tools/ablations/k1_diff.py [gib] [part_mib] [runs]"""
 import _ablations  # noqa: F401  (first: the LTHIP_* switches used here exist in the ablation build only)
 import sys, numpy as np, torch
-sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent.parent))
 from longtail_amd.lib import Context
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 16
 part = int(float(sys.argv[2]) * (1 << 20)) if len(sys.argv) > 2 else (1 << 20)

@@ -3,7 +3,7 @@ formulation fed by LDS-DMA with hand-written exec-masked LDS reads -- against th
 (LTHIP_K1=roll, another formulation of hpcdcchunker.c:266-306) on fresh data every pass, cut for cut, plus the shipped kernel against
 itself three times per pass (a stale-register hand-off showed as one wrong cut in ~10^6 chunks, and not in every run).  The contract is
 bit-exact (lib/hpcdcchunker/longtail_hpcdcchunker.c:266-306); the rolling kernel is pinned against the reference by the -m gpu tests.
-usage: python tools/k1_stress_tib.py [tib] [gib_per_pass]"""
+usage: python tools/ablations/k1_stress_tib.py [tib] [gib_per_pass]"""
 import _ablations  # noqa: F401  (first: the LTHIP_* switches used here exist in the ablation build only)
 import os
 import sys
@@ -13,7 +13,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from bench import asset_seeds  # noqa: E402
 from longtail_amd.lib import Context  # noqa: E402
 

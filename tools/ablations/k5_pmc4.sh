@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: PMC of the lane parser on one kind: the round-3 formulation (LTHIP_LZ4_PV=0: k_lz4_segments<16,...,0>) and the shipped one
-# (k_lz4_lanes2: register records + register window + padded LDS rows + half-groups); usage: tools/k5_pmc4.sh <kind>
+# (k_lz4_lanes2: register records + register window + padded LDS rows + half-groups); usage: tools/ablations/k5_pmc4.sh <kind>
 # (the LTHIP_* switches used here exist in the ablation build only: `make ablations`)
 export LTHIP_LIB_PATH=${LTHIP_LIB_PATH:-$(cd "$(dirname "$0")/.." && pwd)/build/ablations/liblongtail_hip.so}
 kind=${1:-tokens}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/k5_pmc4b.sh <kind> <pv> <dbg>: LDS counters + timing of the lane parser for one setting
+# usage: tools/ablations/k5_pmc4b.sh <kind> <pv> <dbg>: LDS counters + timing of the lane parser for one setting
 # (the LTHIP_* switches used here exist in the ablation build only: `make ablations`)
 export LTHIP_LIB_PATH=${LTHIP_LIB_PATH:-$(cd "$(dirname "$0")/.." && pwd)/build/ablations/liblongtail_hip.so}
 kind=$1; export LTHIP_LZ4_PV=$2; dbg=$3

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of two builds of the library on the LZ4 path: tools/lz4_ab.sh build/a.so build/b.so
+# A/B of two builds of the library on the LZ4 path: tools/ablations/lz4_ab.sh build/a.so build/b.so
 mkdir -p gpurun_out
 cp longtail_amd/liblongtail_hip.so build/cur.so
 for so in "$@"; do

@@ -2,7 +2,7 @@
 """One block above 1 GiB through the LZ4 codec (the 64-bit index flavour of the decoders): round trip on the device."""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 from bench import asset_seeds
 from longtail_amd.lib import Context

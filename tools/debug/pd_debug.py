@@ -3,7 +3,7 @@
 import _ablations  # noqa: F401  (first: the LTHIP_* switches used here exist in the ablation build only)
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 from tests._libs import oracle as get_oracle
 from tests.gpu_util import layout, to_device, u32

@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """What would a slice-wise pipeline buy?  Hash (BLAKE3 ranges) then LZ4-compress the SAME slice while it may still sit in the
 256 MiB memory-side cache, slice after slice, against one hash pass + one codec pass over everything.  Kernel times from the
-library's own HIP-event timers, so the extra launches of the slice loop do not count.  usage: tools/slice_probe.py [gib]"""
+library's own HIP-event timers, so the extra launches of the slice loop do not count.  usage: tools/debug/slice_probe.py [gib]"""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 from bench import asset_seeds
 from longtail_amd.lib import Context

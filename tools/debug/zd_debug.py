@@ -2,7 +2,7 @@
 """Debugging aid for the two-stage zstd piece decoder: own frames of several kinds / sizes, first mismatch per block."""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 from tests._libs import oracle as get_oracle
 from tests.gpu_util import layout, to_device, u32

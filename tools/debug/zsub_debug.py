@@ -2,7 +2,7 @@
 """debug: sub-block frames of the HIP zstd encoder through the reference decoder"""
 import sys, os
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 from tests._libs import oracle as get_oracle, ref as get_ref
 from longtail_amd.lib import Context
