@@ -405,6 +405,10 @@ class Bench:
                 raise SystemExit(f"rank {self.rank}: the communicator has {self.comm_info['nranks']} ranks, expected {self.world}")
         elif self.world > 1:
             self.comm_info = {"nranks": dist.get_world_size(), "rank": dist.get_rank(), "transport": f"torch.distributed/{dist.get_backend()}"}
+        if self.comm_info is not None and any(t in str(self.comm_info.get("transport")) for t in ("rccl", "nccl")):
+            # which RCCL: the file the C ABI binds (comm.hip: $LTHIP_RCCL_PATH, a copy already mapped -- torch's --, the loader's path)
+            path, how = comm_library(self.lib)
+            self.comm_info["rccl_library"] = {"path": path, "found_by": how}
 
     def measure_peak(self, gib=4):
         """What this box's memory system delivers to plain streaming kernels (tools/hbm_peak.py, SURVEY.md §8d "use the measured peak
