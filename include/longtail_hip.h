@@ -44,7 +44,13 @@ LTHIP_EXPORT struct Longtail_ChunkerAPI* Longtail_CreateHipChunkerAPI(void);
  * GPU already computed; any other buffer is hashed on the GPU on demand. */
 LTHIP_EXPORT struct Longtail_HashAPI* Longtail_CreateHipBlake3HashAPI(void);
 
-/* Replaces Longtail_CreateLZ4CompressionAPI() / Longtail_CompressionRegistry_CreateForLZ4()
+/* WHEN TO CONSTRUCT THE CODEC OBJECTS.  One stored block per Compress call crosses the link twice: the HIP codec objects pay on data that
+ * compresses -- WriteContent at 32 bikeshed workers: LZ4 31-47 GB/s against the reference codec's 22-25, ZStd 33-35 against 7-14 -- and
+ * lose on incompressible bytes, where the CPU's LZ4 is a memcpy (25-29 against 56-105 GB/s): there bind the reference's own LZ4 beside
+ * the HIP chunker + hash, or use the bulk session (lthip_ingest_*), which never brings payload bytes back through Compress
+ * (INTEGRATION.md "Which codec object to bind"; numbers: the bench line's secondary.*.drop_in, profiles/r06h_*).
+ *
+ * Replaces Longtail_CreateLZ4CompressionAPI() / Longtail_CompressionRegistry_CreateForLZ4()
  * (lib/lz4/longtail_lz4.h:10-12, longtail_lz4.c:12-23,47-123).  Same type id 'lz42', same bound
  * (n + n/255 + 16), payload = one LZ4 *block* that LZ4_decompress_safe decodes. */
 LTHIP_EXPORT struct Longtail_CompressionAPI* Longtail_CreateHipLZ4CompressionAPI(void);
