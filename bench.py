@@ -984,7 +984,7 @@ class Bench:
         }
 
 
-def main():
+def make_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -1024,7 +1024,11 @@ def main():
     ap.add_argument("--exchange-profile", action="store_true",
                     help="N > 1: split the exchange + index phases of every step into host / device / transport time (waits for the device at "
                          "every mark: a breakdown, not the metric; tools/exchange_cost.py)")
-    args = ap.parse_args()
+    return ap
+
+
+def main():
+    args = make_parser().parse_args()
     if args.dry_run:
         print(json.dumps(dry_run(args)))
         return
@@ -1093,7 +1097,7 @@ def main():
                 secondary["restore"] = b.restore_rates()
                 secondary["host_fed"] = b.host_fed_rates()
         if cr is not None:
-            sweep = sorted({min(32, cr.ncpu), cr.physical, cr.ncpu} - {1}) or [1]
+            sweep = sorted(({min(32, cr.ncpu), cr.physical, cr.ncpu} | ({max(2, int(cr.quota))} if cr.quota else set())) - {1}) or [1]
             cpu_baseline = cr.leg(cfg, min(args.cpu_gib, args.gib), sweep=sweep, drop_in=True, one_gib=1.0)
             if "error" not in cpu_baseline and cr.have_ref:
                 cpu_baseline["configs0_one_256MiB_file"] = cr.configs0(sorted({sweep[0], cr.ncpu}))
@@ -1242,6 +1246,24 @@ class CpuReference:
         self.ncpu = os.cpu_count() or 1
         self.physical = max(1, self.ncpu // 2)
         self.w = min(32, self.ncpu)
+        # what the CONTAINER grants, whatever os.cpu_count() says: the cgroup's CPU bandwidth (cpu.max "quota period": quota / period
+        # CPU-seconds per second for all threads of the process together) and the affinity mask
+        self.quota = None
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                self.quota = round(int(q) / int(per), 2)
+        except (OSError, ValueError):
+            try:
+                q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    self.quota = round(q / per, 2)
+            except (OSError, ValueError):
+                pass
+        try:
+            self.affinity = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            self.affinity = self.ncpu
         self.have_ref = have_ref()
         self.storage = "reference in-memory storage"
         self.hip = None
@@ -1260,9 +1282,10 @@ class CpuReference:
                 pass
 
     def cores_text(self):
-        return (f"W = {self.w} bikeshed workers on a host with {self.ncpu} hardware threads ({self.physical} cores): the reference stops scaling "
-                "at a few dozen workers on this tree (by_workers of the headline leg), so the ratio to this figure is 'vs the reference's best "
-                "worker count', not 'vs every hardware thread busy'")
+        quota = (f"; the container's cgroup grants this process {self.quota:g} CPUs' worth of time (cpu.max) whatever the {self.ncpu} visible hardware "
+                 f"threads suggest -- THAT is the core count of this baseline, and why more than a few dozen workers are no faster (by_workers)") if self.quota else ""
+        return (f"W = {self.w} bikeshed workers on a host with {self.ncpu} hardware threads ({self.physical} cores){quota}: the ratio to this "
+                "figure is 'vs the reference at its best worker count on what the box grants', not 'vs every hardware thread busy'")
 
     def plugins(self, codec):
         """This library's plugin objects for the drop-in legs (made once, kept until close())."""
@@ -1350,7 +1373,8 @@ class CpuReference:
                              f"{', repeats' if cfg.get('dups') else ''}); Longtail_CreateVersionIndex + Longtail_CreateMissingContent + Longtail_WriteContent, "
                              f"reference hpcdc+BLAKE3+{codec.upper()}{' level 3 (ztd2)' if codec == 'zstd' else ''}, {self.storage}, null block sink; "
                              f"median of {self.REPS}; " + self.cores_text(),
-                   "by_workers": by_w, "physical_cores": self.physical, "host_cpus": self.ncpu,
+                   "by_workers": by_w, "physical_cores": self.physical, "host_cpus": self.ncpu, "cpu_quota_cores": self.quota,
+                   "affinity_cpus": self.affinity,
                    "reference_ratio": ref_ratio, "reference_chunks": res["chunks"], "reference_blocks": res["blocks"],
                    "sample_fraction_of_tree": round(nbytes / float(int(cfg["gib"] * (1 << 30))), 4)}
             if drop_in and str(self.w) in by_w:
@@ -1391,6 +1415,18 @@ class CpuReference:
                                       "ratio": round(cpu["write_s"] / h["write_s"], 3)},
                "ratio_hip_codec": round(hip["raw_bytes"] / payload, 4) if payload > 0 else None, "ratio_reference_codec": ref_ratio,
                "seconds": {"hip_plugins": h, "cpu_plugins": cpu}}
+        # The HIP plugins' callers WAIT (for the link, for a submission): an embedder is free to give the job system more workers than
+        # the CPU plugins can use -- the same three objects at 2 W and 4 W
+        more = [x for x in (2 * w,) if x <= max(self.ncpu, w)]
+        if os.environ.get("LTHIP_BENCH_DROPIN_SWEEP", "1") not in ("0", "1"):
+            more = [int(x) for x in os.environ["LTHIP_BENCH_DROPIN_SWEEP"].split(",")]
+        if more and os.environ.get("LTHIP_BENCH_DROPIN_SWEEP", "1") != "0":
+            wide = r.ingest_sweep_tree(tree, *common, more, self.REPS, chunker, hasher, codec_api)
+            if not wide["err"]:
+                by = self._median(wide, more, nbytes)
+                out["hip_plugins_by_workers"] = {str(w): {"upsync_GBps": h["GBps"], "index_GBps": round(nbytes / h["index_s"] / 1e9, 3), "write_GBps": round(nbytes / h["write_s"] / 1e9, 3)}}
+                for k, v in by.items():
+                    out["hip_plugins_by_workers"][k] = {"upsync_GBps": v["GBps"], "index_GBps": round(nbytes / v["index_s"] / 1e9, 3), "write_GBps": round(nbytes / v["write_s"] / 1e9, 3)}
         # ... and what INTEGRATION.md recommends where one block per Compress call does not feed a GPU codec: HIP chunker + hash, CPU codec
         mixed = r.ingest_sweep_tree(tree, *common, [w], self.REPS, chunker, hasher, None)
         if not mixed["err"]:

@@ -249,7 +249,7 @@ int xfer(lthip_ctx* ctx, void* dst, const void* src, size_t n, bool to_host)
 int xfer_wait(lthip_ctx* ctx)
 {
     if (ctx)
-        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
     return 0;
 }
 

@@ -46,7 +46,7 @@ int reserve_dev(lthip_ctx* ctx, DBuf& b, size_t bytes)
         return 0;
     if (b.p)
     {
-        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
         LTHIP_CHECK(ctx, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -65,7 +65,7 @@ int reserve_pinned(lthip_ctx* ctx, HBuf& b, size_t bytes)
         return 0;
     if (b.p)
     {
-        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
         LTHIP_CHECK(ctx, hipHostFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -1106,7 +1106,7 @@ extern "C" int lthip_ingest_finish(lthip_ingest* g, void* h_store_index, size_t 
             memcpy(w, g->h_mu_len.p, m * 4); // m_ChunkSizes
         }
     }
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
     LTHIP_CHECK(ctx, hipEventSynchronize(g->ev_hashes)); // (the side stream's copies)
     {
         const int vi_err = ingest_vi_join(g); // the VersionIndex is in the caller's buffer (or could not be made)

@@ -632,7 +632,7 @@ int lthip_launch_blake3(lthip_ctx* ctx, const uint8_t* d_data, const uint64_t* d
         if (d_count)
         {
             LTHIP_CHECK(ctx, hipMemcpyAsync(&host_count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-            LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
             if (host_count > count_bound)
                 host_count = (uint32_t)count_bound;
         }
@@ -640,7 +640,7 @@ int lthip_launch_blake3(lthip_ctx* ctx, const uint8_t* d_data, const uint64_t* d
             host_count = (uint32_t)count_bound;
         uint32_t total = 0;
         LTHIP_CHECK(ctx, hipMemcpyAsync(&total, (const uint32_t*)lp + host_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
         leaf_bound = total;
         if (host_count == 0)
             return 0;

@@ -1758,7 +1758,7 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     {                                                                                  \
         if (trace)                                                                     \
         {                                                                              \
-            const hipError_t e__ = hipStreamSynchronize(ctx->stream);                  \
+            const hipError_t e__ = lthip_stream_wait(ctx);                  \
             fprintf(stderr, "lz4 parallel decode: %s -> %s\n", what, hipGetErrorString(e__)); \
         }                                                                              \
     } while (0)
@@ -1828,7 +1828,7 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
         // allows (4 bytes per byte of output; LTHIP_ORIGIN_MIB, default: lthip_origin_budget_mib).  The one place where this call waits for the device.
         uint32_t given_up = 0;
         LTHIP_CHECK(ctx, hipMemcpyAsync(&given_up, d_cnt + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
-        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
         if (given_up)
         {
             const uint64_t budget_units = (lthip_origin_budget_mib() << 20) / ((uint64_t)PD_UNIT * 4u);
@@ -1889,7 +1889,7 @@ static int lz4_decompress_parallel(lthip_ctx* ctx, const void* d_src, const std:
     {
         uint32_t h[8] = {0};
         LTHIP_CHECK(ctx, hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
         fprintf(stderr, "lz4 parallel decode: %u blocks, %llu tiles (%u walked again by the link pass), %llu units, %u tickets, timeouts %u\n", nb,
                 (unsigned long long)ntiles, h[4], (unsigned long long)nunits, tk.total, h[1]);
         fprintf(stderr, "   link pass: %u Kcycles in all, %u Kcycles walking tiles again (summed over the blocks)\n", h[7], h[6]);

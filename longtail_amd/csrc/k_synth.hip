@@ -99,7 +99,7 @@ extern "C" int lthip_synth_fill_ranges(lthip_ctx* ctx, void* d_dst, uint32_t ass
     if (err)
         return err;
     LTHIP_CHECK(ctx, hipMemcpyAsync(p, h.data(), sizeof(SynthAsset) * h.size(), hipMemcpyHostToDevice, ctx->stream));
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
     uint64_t blocks = div_up_u64(nvec, 256);
     if (blocks > 256 * 32)
         blocks = 256 * 32;

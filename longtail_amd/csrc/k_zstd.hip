@@ -400,7 +400,7 @@ extern "C" int lthip_zstd_debug_units(lthip_ctx* ctx, uint64_t first, uint64_t c
     if (!ctx || !ctx->scratch[S_Z_LITS] || !ctx->scratch[S_Z_RECS] || !ctx->scratch[S_LZ4_META])
         return EINVAL;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
     if (h_meta)
         LTHIP_CHECK(ctx, hipMemcpy(h_meta, (const uint8_t*)ctx->scratch[S_LZ4_META] + first * sizeof(ZbUnitMeta), count * sizeof(ZbUnitMeta),
                                    hipMemcpyDeviceToHost));

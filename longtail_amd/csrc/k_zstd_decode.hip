@@ -478,7 +478,7 @@ extern "C" int lthip_zstd_last_decode_stats(lthip_ctx* ctx, uint32_t out[4])
     if (!ctx || !out)
         return EINVAL;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
     std::vector<uint32_t> r(ctx->z_last_payloads);
     if (ctx->z_last_payloads)
         LTHIP_CHECK(ctx, hipMemcpy(r.data(), ctx->z_last_retry, 4 * (size_t)ctx->z_last_payloads, hipMemcpyDeviceToHost));
@@ -652,7 +652,7 @@ extern "C" int lthip_zstd_decompress_blocks(lthip_ctx* ctx, const void* d_src, u
     {
         uint32_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         LTHIP_CHECK(ctx, hipMemcpyAsync(counters, d_count, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
-        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
         const uint32_t* totals = counters + 4;
         const uint32_t f_most = counters[1]; // the most blocks a frame of another encoder has
         const uint64_t f_blocks = totals[0], f_bytes = ((uint64_t)totals[3] << 32) | totals[2];

@@ -23,7 +23,7 @@ int lthip_scratch(lthip_ctx* ctx, int slot, size_t bytes, void** out)
         if (ctx->scratch[slot])
         {
             // the old buffer may still be in use by work queued on the stream
-            LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
             LTHIP_CHECK(ctx, hipFree(ctx->scratch[slot]));
             ctx->scratch[slot] = nullptr;
             ctx->scratch_cap[slot] = 0;
@@ -163,6 +163,29 @@ extern "C" int lthip_ctx_create(int device, void* hip_stream, lthip_ctx** out_ct
     return 0;
 }
 
+hipError_t lthip_stream_wait(lthip_ctx* ctx) { return hipStreamSynchronize(ctx->stream); }
+
+// The plugin layer's waits SLEEP.  A Longtail_*API call is a blocking call made from every worker of the embedder's job system at
+// once -- 32 to 256 threads, each waiting for its own upload, its submission, its download -- and the runtime's default wait polls the
+// completion signal: a third of the drop-in path's CPU time went there, and in a container with a CPU quota (the measured boxes grant
+// 16 CPUs of 256: cgroup cpu.max) CPU time IS the path's throughput.  hipDeviceScheduleBlockingSync makes a waiting thread sleep until
+// the interrupt: CreateVersionIndex through the plugins 30 -> 40 GB/s at W = 32, 16 -> 39 at W = 64, UpSync 12 -> 16.5 (round 6,
+// tools/dropin_scaling.py).  It is the DEVICE's policy, process-wide: set when the first plugin object is made
+// (Longtail_Hip_SetBlockingWaits(0) before that keeps the runtime's default), never by the bulk API on its own.
+extern "C" int lthip_set_blocking_waits(int device, int on)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n)
+        return ENODEV;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess)
+        return EIO;
+    const hipError_t e = hipSetDeviceFlags(on ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto);
+    (void)hipSetDevice(prev);
+    return e == hipSuccess ? 0 : EIO;
+}
+
 extern "C" void lthip_ctx_destroy(lthip_ctx* ctx)
 {
     if (!ctx)
@@ -209,7 +232,7 @@ extern "C" int lthip_ctx_sync(lthip_ctx* ctx)
 {
     if (!ctx)
         return EINVAL;
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
     return 0;
 }
 
@@ -234,7 +257,7 @@ extern "C" void lthip_free_device(lthip_ctx* ctx, void* p)
     if (ctx)
     {
         (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)lthip_stream_wait(ctx);
     }
     (void)hipFree(p);
 }
@@ -255,7 +278,7 @@ extern "C" void lthip_free_pinned(lthip_ctx* ctx, void* p)
     if (ctx)
     {
         (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)lthip_stream_wait(ctx);
     }
     (void)hipHostFree(p);
 }
@@ -374,7 +397,7 @@ static int timing_collect(lthip_ctx* ctx)
 {
     if (ctx->pending.empty())
         return 0;
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
     for (auto& r : ctx->pending)
     {
         float ms = 0.f;
@@ -625,7 +648,7 @@ extern "C" int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const uint
     if (e == hipSuccess && part_count)
         e = hipMemcpyAsync(plan->d_parts, parts.data(), sizeof(PartDev) * part_count, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
-        e = hipStreamSynchronize(ctx->stream); // `parts` is a local
+        e = lthip_stream_wait(ctx); // `parts` is a local
     if (e != hipSuccess)
     {
         lthip_plan_destroy(ctx, plan);
@@ -727,7 +750,7 @@ extern "C" void lthip_plan_destroy(lthip_ctx* ctx, lthip_plan* plan)
     // context only its stream is drained; without one the whole device is.
     (void)hipSetDevice(plan->device);
     if (ctx)
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)lthip_stream_wait(ctx);
     else
         (void)hipDeviceSynchronize();
     if (plan->d_parts)
@@ -782,7 +805,7 @@ extern "C" int lthip_chunk_hash(lthip_ctx* ctx, const lthip_plan* plan, const vo
     {
         uint32_t total = 0;
         LTHIP_CHECK(ctx, hipMemcpyAsync(&total, d_part_first + plan->nparts, 4, hipMemcpyDeviceToHost, ctx->stream));
-        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
         *out_total = total;
     }
     return 0;
@@ -813,7 +836,7 @@ extern "C" int lthip_chunk_from_buffer(lthip_ctx* ctx, const void* d_data, uint6
         return err;
     uint64_t len = 0;
     LTHIP_CHECK(ctx, hipMemcpyAsync(&len, d_out, 8, hipMemcpyDeviceToHost, ctx->stream));
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
     *out_len = len;
     return 0;
 }

@@ -139,6 +139,9 @@ struct lthip_ctx
 };
 
 int lthip_fail(lthip_ctx* ctx, int code, const char* what, const char* detail);
+// Waits for everything queued on the context's stream (the one place the library waits for a stream).  HOW a host thread waits is
+// the device's scheduling policy: lthip_set_blocking_waits below.
+hipError_t lthip_stream_wait(lthip_ctx* ctx);
 
 // Environment switches (ablations, debug paths) are read once per process and cached -- not per call: the plugins call from up to 256
 // threads.  lthip_debug_reload_env() (tests: one process tries a path and its ablation) bumps the generation; a cache re-reads then.

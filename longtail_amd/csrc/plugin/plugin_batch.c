@@ -19,6 +19,34 @@
 #define LTB_ARENA_SLOTS 160          /* slots of the device arena: a submission in flight + the uploads of the next one + spare */
 #define LTB_SLOT_BYTES ((uint64_t)LTP_WINDOW_SMALL)
 
+#ifdef LTP_TIMING /* debug build only (tools/dropin_scaling.py with a library built -DLTP_TIMING): where the submitters and the dispatcher spend their time */
+#include <stdio.h>
+#include <time.h>
+static double ltb_now(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+static double g_t[8]; /* 0 slot wait, 1 upload + sync, 2 queue wait (submitters, summed over threads); 3 dispatcher idle, 4 run_batch, 5 of it: device, 6 wake */
+static uint64_t g_tn[8];
+#define LTB_T0 double t0__ = ltb_now()
+#define LTB_T(i)                                 \
+    do                                           \
+    {                                            \
+        const double n__ = ltb_now();            \
+        __atomic_fetch_add(&g_tn[i], 1, __ATOMIC_RELAXED); \
+        pthread_mutex_lock(&g_tlock);            \
+        g_t[i] += n__ - t0__;                    \
+        pthread_mutex_unlock(&g_tlock);          \
+        t0__ = n__;                              \
+    } while (0)
+static pthread_mutex_t g_tlock = PTHREAD_MUTEX_INITIALIZER;
+#else
+#define LTB_T0 ((void)0)
+#define LTB_T(i) ((void)0)
+#endif
+
 struct ltb_req
 {
     struct ltp_chunk_window* w;
@@ -27,6 +55,11 @@ struct ltb_req
     int done, err;
     uint64_t total;
     int slot; /* arena slot the submitting thread has uploaded the window into */
+    /* the submitter sleeps on a condition variable of ITS OWN (with g_lock): the dispatcher wakes exactly the threads whose windows are
+     * done.  One shared variable + broadcast woke every waiting worker after every submission, each to take g_lock, see "not mine" and
+     * sleep again -- a herd that grows with the job system's worker count: at 128 bikeshed workers a submission of 20 windows took
+     * 2 ms instead of 0.3 and CreateVersionIndex fell from 32 to 10 GB/s (round 6, tools/dropin_scaling.py). */
+    pthread_cond_t cv;
     struct ltb_req* next;
 };
 
@@ -137,6 +170,7 @@ static int run_batch(struct ltb_state* st, struct ltb_req** reqs, uint32_t n)
     if (!err) err = ltp_pin_reserve(ctx, &st->h_res, o_len + (size_t)cap * 4);
     if (err)
         return err;
+    LTB_T0;
     if (!err)
         err = lthip_chunk_hash(ctx, st->plan, g_arena, (uint64_t*)st->d_off.p, (uint32_t*)st->d_len.p, (uint64_t*)st->d_hash.p,
                                (uint32_t*)st->d_first.p, 0);
@@ -150,6 +184,7 @@ static int run_batch(struct ltb_state* st, struct ltb_req** reqs, uint32_t n)
     if (!err) err = lthip_copy_d2h(ctx, h + o_hash, st->d_hash.p, (size_t)ub * 8);
     if (!err) err = lthip_copy_d2h(ctx, h + o_len, st->d_len.p, (size_t)ub * 4);
     if (!err) err = lthip_ctx_sync(ctx);
+    LTB_T(5);
     if (err)
         return err;
     const uint32_t* first = (const uint32_t*)h;
@@ -214,9 +249,11 @@ static void* dispatcher(void* arg)
     {
         struct ltb_req* reqs[LTB_SLOTS];
         uint32_t n = 0;
+        LTB_T0;
         pthread_mutex_lock(&g_lock);
         while (!g_head && !g_stop)
             pthread_cond_wait(&g_work, &g_lock);
+        LTB_T(3);
         if (!g_head && g_stop)
         {
             pthread_mutex_unlock(&g_lock);
@@ -246,6 +283,7 @@ static void* dispatcher(void* arg)
         pthread_mutex_unlock(&g_lock);
 
         const int err = run_batch(&st, reqs, n);
+        LTB_T(4);
 
         pthread_mutex_lock(&g_lock);
         g_stat_batches += 1;
@@ -256,11 +294,16 @@ static void* dispatcher(void* arg)
                 reqs[i]->err = err;
             g_free_slots[g_free_count++] = reqs[i]->slot;
             reqs[i]->done = 1;
+            pthread_cond_signal(&reqs[i]->cv);
+            pthread_cond_signal(&g_slot_cv); /* one freed slot, one waiter (if any) */
         }
-        pthread_cond_broadcast(&g_done);
-        pthread_cond_broadcast(&g_slot_cv);
         pthread_mutex_unlock(&g_lock);
+        LTB_T(6);
     }
+#ifdef LTP_TIMING
+    fprintf(stderr, "ltb timing: submitters slot-wait %.3f s (%llu)  upload+sync %.3f s  queue-wait %.3f s | dispatcher idle %.3f s  run_batch %.3f s (%llu; device part %.3f s)  wake %.3f s\n",
+            g_t[0], (unsigned long long)g_tn[0], g_t[1], g_t[2], g_t[3], g_t[4], (unsigned long long)g_tn[4], g_t[5], g_t[6]);
+#endif
     pthread_mutex_lock(&g_lock);
     void* a = g_arena;
     g_arena = 0;
@@ -287,6 +330,8 @@ int ltp_batch_chunk_hash(struct ltp_chunk_window* w, uint64_t have, uint32_t min
     lthip_ctx* my = ltp_thread_ctx();
     if (!my)
         return ENODEV;
+    pthread_cond_init(&r.cv, 0);
+    LTB_T0;
     pthread_mutex_lock(&g_lock);
     while (g_joining) /* a shutdown is collecting the previous dispatcher: start the next one only when it is gone */
         pthread_cond_wait(&g_done, &g_lock);
@@ -299,6 +344,7 @@ int ltp_batch_chunk_hash(struct ltp_chunk_window* w, uint64_t have, uint32_t min
         if (pthread_create(&g_thread, 0, dispatcher, 0) != 0)
         {
             pthread_mutex_unlock(&g_lock);
+            pthread_cond_destroy(&r.cv);
             return EAGAIN;
         }
         g_running = 1;
@@ -321,23 +367,27 @@ int ltp_batch_chunk_hash(struct ltp_chunk_window* w, uint64_t have, uint32_t min
             pthread_cond_broadcast(&g_done);
         }
         pthread_mutex_unlock(&g_lock);
+        pthread_cond_destroy(&r.cv);
         return e;
     }
     r.slot = g_free_slots[--g_free_count];
     uint8_t* dst = (uint8_t*)g_arena + (uint64_t)r.slot * LTB_SLOT_BYTES;
     pthread_mutex_unlock(&g_lock);
+    LTB_T(0);
 
     /* my window goes up on MY stream, next to the other threads' uploads and under the dispatcher's kernels */
     int err = lthip_copy_h2d(my, dst, w->h_win, (size_t)have);
     if (!err)
         err = lthip_ctx_sync(my);
+    LTB_T(1);
 
     pthread_mutex_lock(&g_lock);
     if (err)
     {
         g_free_slots[g_free_count++] = r.slot;
-        pthread_cond_broadcast(&g_slot_cv);
+        pthread_cond_signal(&g_slot_cv);
         pthread_mutex_unlock(&g_lock);
+        pthread_cond_destroy(&r.cv);
         return err;
     }
     if (g_tail)
@@ -347,8 +397,10 @@ int ltp_batch_chunk_hash(struct ltp_chunk_window* w, uint64_t have, uint32_t min
     g_tail = &r;
     pthread_cond_signal(&g_work);
     while (!r.done)
-        pthread_cond_wait(&g_done, &g_lock);
+        pthread_cond_wait(&r.cv, &g_lock);
     pthread_mutex_unlock(&g_lock);
+    LTB_T(2);
+    pthread_cond_destroy(&r.cv);
     *out_total = r.total;
     return r.err;
 }

@@ -25,6 +25,7 @@ struct ltc_req
     void* d_out;
     uint32_t n, cap, produced;
     int done, err;
+    pthread_cond_t cv; /* the caller's own (with g_lock): a finished submission wakes its callers, not every waiting worker (plugin_batch.c) */
     struct ltc_req* next;
 };
 
@@ -170,8 +171,8 @@ static void* dispatcher(void* arg)
         {
             reqs[i]->err = errs[i];
             reqs[i]->done = 1;
+            pthread_cond_signal(&reqs[i]->cv);
         }
-        pthread_cond_broadcast(&g_done);
         pthread_mutex_unlock(&g_lock);
     }
     if (ctx)
@@ -196,6 +197,7 @@ int ltp_codec_batch(int codec, int decompress, int quality, const void* d_in, ui
     r.d_out = d_out;
     r.n = n;
     r.cap = cap;
+    pthread_cond_init(&r.cv, 0);
     pthread_mutex_lock(&g_lock);
     while (g_joining) /* a shutdown is collecting the previous dispatcher: start the next one only when it is gone */
         pthread_cond_wait(&g_done, &g_lock);
@@ -205,6 +207,7 @@ int ltp_codec_batch(int codec, int decompress, int quality, const void* d_in, ui
         if (pthread_create(&g_thread, 0, dispatcher, 0) != 0)
         {
             pthread_mutex_unlock(&g_lock);
+            pthread_cond_destroy(&r.cv);
             return EAGAIN;
         }
         g_running = 1;
@@ -216,8 +219,9 @@ int ltp_codec_batch(int codec, int decompress, int quality, const void* d_in, ui
     g_tail = &r;
     pthread_cond_signal(&g_work);
     while (!r.done)
-        pthread_cond_wait(&g_done, &g_lock);
+        pthread_cond_wait(&r.cv, &g_lock);
     pthread_mutex_unlock(&g_lock);
+    pthread_cond_destroy(&r.cv);
     *produced = r.produced;
     return r.err;
 }

@@ -111,7 +111,7 @@ extern "C" int lthip_build_version_index(lthip_ctx* ctx, uint32_t asset_count, c
     {
         LTHIP_CHECK(ctx, hipMemcpyAsync(d_off.p, h_off.data(), (size_t)asset_count * 8, hipMemcpyHostToDevice, ctx->stream));
         LTHIP_CHECK(ctx, hipMemcpyAsync(d_len.p, h_len.data(), (size_t)asset_count * 4, hipMemcpyHostToDevice, ctx->stream));
-        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // h_off / h_len are reused below
+        LTHIP_CHECK(ctx, lthip_stream_wait(ctx)); // h_off / h_len are reused below
         if ((err = lthip_hash_ranges(ctx, d_chunk_hashes ? (const void*)d_chunk_hashes : d_paths.p, asset_count, (const uint64_t*)d_off.p,
                                      (const uint32_t*)d_len.p, max_len, (uint64_t*)d_ch.p)))
             return err;
@@ -127,12 +127,12 @@ extern "C" int lthip_build_version_index(lthip_ctx* ctx, uint32_t asset_count, c
         LTHIP_CHECK(ctx, hipMemcpyAsync(d_paths.p, path_data, path_data_size, hipMemcpyHostToDevice, ctx->stream));
         LTHIP_CHECK(ctx, hipMemcpyAsync(d_off.p, h_off.data(), (size_t)asset_count * 8, hipMemcpyHostToDevice, ctx->stream));
         LTHIP_CHECK(ctx, hipMemcpyAsync(d_len.p, h_len.data(), (size_t)asset_count * 4, hipMemcpyHostToDevice, ctx->stream));
-        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
         if ((err = lthip_hash_ranges(ctx, d_paths.p, asset_count, (const uint64_t*)d_off.p, (const uint32_t*)d_len.p, max_len,
                                      (uint64_t*)d_ph.p)))
             return err;
     }
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
 
     // ---- serialized layout (Longtail_BuildVersionIndex :2757-2806 over InitVersionIndexFromData's section order) ----
     const size_t size = lthip_version_index_size(asset_count, unique, n, path_data_size);
@@ -226,7 +226,7 @@ extern "C" int lthip_write_stored_block_headers(lthip_ctx* ctx, uint32_t block_c
     LTHIP_CHECK(ctx, hipMemcpyAsync(d_len.p, lens.data(), (size_t)block_count * 4, hipMemcpyHostToDevice, ctx->stream));
     LTHIP_CHECK(ctx, hipMemcpyAsync(d_raw.p, raw_sizes, (size_t)block_count * 4, hipMemcpyHostToDevice, ctx->stream));
     LTHIP_CHECK(ctx, hipMemcpyAsync(d_img.p, image_offsets, (size_t)block_count * 8, hipMemcpyHostToDevice, ctx->stream));
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // host vectors go out of scope
+    LTHIP_CHECK(ctx, lthip_stream_wait(ctx)); // host vectors go out of scope
     if ((err = lthip_hash_ranges(ctx, d_chunk_hashes, block_count, (const uint64_t*)d_off.p, (const uint32_t*)d_len.p, max_len,
                                  (uint64_t*)d_bh.p)))
         return err;
@@ -235,7 +235,7 @@ extern "C" int lthip_write_stored_block_headers(lthip_ctx* ctx, uint32_t block_c
                        d_chunk_hashes, d_chunk_lens, (const uint64_t*)d_bh.p, hash_identifier, tag, (const uint32_t*)nullptr, (const uint32_t*)d_raw.p, d_comp_sizes,
                        (const uint64_t*)d_img.p, (uint8_t*)d_arena);
     LTHIP_LAUNCH_CHECK(ctx);
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // the DevBufs are freed on return
+    LTHIP_CHECK(ctx, lthip_stream_wait(ctx)); // the DevBufs are freed on return
     return 0;
 }
 
@@ -278,7 +278,7 @@ extern "C" int lthip_create_missing_content(lthip_ctx* ctx, uint64_t existing_co
         LTHIP_CHECK(ctx, hipMemcpyAsync(lens.data(), d_chunk_lens, n * 4, hipMemcpyDeviceToHost, ctx->stream));
         LTHIP_CHECK(ctx, hipMemcpyAsync(hashes.data(), d_chunk_hashes, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
-    LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
     // the missing chunks, version order
     std::vector<uint64_t> m_hash;
     std::vector<uint32_t> m_size, m_tag;
@@ -325,11 +325,11 @@ extern "C" int lthip_create_missing_content(lthip_ctx* ctx, uint64_t existing_co
         LTHIP_CHECK(ctx, hipMemcpyAsync(d_mh.p, m_hash.data(), m * 8, hipMemcpyHostToDevice, ctx->stream));
         LTHIP_CHECK(ctx, hipMemcpyAsync(d_o.p, o.data(), nb * 8, hipMemcpyHostToDevice, ctx->stream));
         LTHIP_CHECK(ctx, hipMemcpyAsync(d_l.p, l.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
-        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
         if ((err = lthip_hash_ranges(ctx, d_mh.p, nb, (const uint64_t*)d_o.p, (const uint32_t*)d_l.p, max_len, (uint64_t*)d_bh.p)))
             return err;
         LTHIP_CHECK(ctx, hipMemcpyAsync(b_hash.data(), d_bh.p, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
-        LTHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
     }
     // Longtail_GetStoreIndexDataSize, :8913-8931
     const size_t size = 16 + nb * 8 + m * 8 + nb * 12 + m * 4;

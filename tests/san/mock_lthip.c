@@ -82,6 +82,12 @@ int lthip_copy_d2h(lthip_ctx* c, void* h, const void* d, size_t n)
     memcpy(h, d, n);
     return 0;
 }
+int lthip_set_blocking_waits(int device, int on)
+{
+    (void)device;
+    (void)on;
+    return 0;
+}
 int lthip_link_copy(lthip_ctx* c, void* dst, const void* src, size_t n)
 {
     (void)c;
