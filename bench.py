@@ -1356,6 +1356,7 @@ class CpuReference:
         codec = cfg["codec"]
         tag = r.lz4_type if codec == "lz4" else r.zstd_default
         sample_bytes = int(sample_gib * (1 << 30))
+        self._sample_request_bytes = sample_bytes
         files, nbytes = self.sample_files(cfg, sample_bytes)
         sweep = sorted(set(sweep or [self.w]))
         common = (args.target_chunk_size, args.block_size, args.max_chunks_per_block, tag)
@@ -1393,47 +1394,77 @@ class CpuReference:
         return out
 
     def drop_in(self, tree, files, nbytes, cfg, common, cpu, ref_ratio):
-        """secondary.*.drop_in: the SAME sample, storage and worker count with this library's plugin objects in the unmodified core --
-        what a longtail embedder gets by switching constructors and nothing else (host buffers in, host buffers out: PCIe, the
-        pull-style per-chunk API and the core's own file reads are all inside) -- all three, and chunker + hash with the CPU codec."""
-        r, w = self.r, self.w
-        chunker, hasher, codec_api = self.plugins(cfg["codec"])
-        r.version_index(files[: min(256, len(files))] if len(files) > 1 else [(files[0][0], files[0][1][: 256 << 20])],
-                        self.args.target_chunk_size, w, 0, chunker, hasher)  # warm-up: contexts, window pool
-        hip = r.ingest_sweep_tree(tree, *common, [w], self.REPS, chunker, hasher, codec_api)
-        if hip["err"]:
-            return {"error": f"errno {hip['err']}"}
-        h = self._median(hip, [w], nbytes)[str(w)]
-        payload = hip["stored_bytes"] - 8 * hip["blocks"]
+        """secondary.*.drop_in: the SAME sample (generator, seeds, size), storage and worker count with this library's plugin objects in the
+        unmodified core -- what a longtail embedder gets by switching constructors and nothing else (host buffers in, host buffers out:
+        PCIe, the pull-style per-chunk API and the core's own file reads are all inside) -- all three, and chunker + hash with the CPU
+        codec.  Measured in a PROCESS OF ITS OWN (tools/drop_in_child.py) that makes Longtail_Hip_SetBlockingWaits(1) its first call, as
+        include/longtail_hip.h tells an embedder to: the wait policy has to be set before a process touches the GPU, and this one long has.
+        If the child fails or takes too long, the measurement is made here, with the runtime's default (polling) waits, and says so."""
+        w = self.w
+        more = [x for x in (2 * w,) if x <= max(self.ncpu, w)]
+        if os.environ.get("LTHIP_BENCH_DROPIN_SWEEP", "1") not in ("0", "1"):
+            more = [int(x) for x in os.environ["LTHIP_BENCH_DROPIN_SWEEP"].split(",")]
+        child, how = None, "a process of its own, Longtail_Hip_SetBlockingWaits(1) first (tools/drop_in_child.py)"
+        if os.environ.get("LTHIP_BENCH_DROPIN_INPROCESS") != "1":
+            import subprocess
+
+            req = {"cfg": {k: cfg[k] for k in ("tree", "kind", "codec", "file_mib", "gib") if k in cfg} | {"dups": bool(cfg.get("dups"))},
+                   "sample_bytes": int(nbytes if cfg["tree"] != "files" else max(nbytes, 1)), "workers": w, "more_workers": more, "reps": self.REPS,
+                   "target_chunk_size": self.args.target_chunk_size, "block_size": self.args.block_size, "max_chunks_per_block": self.args.max_chunks_per_block}
+            req["sample_bytes"] = self._sample_request_bytes
+            try:
+                res = subprocess.run([sys.executable, str(ROOT / "tools" / "drop_in_child.py"), json.dumps(req)], capture_output=True, text=True, timeout=240,
+                                     env={k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "ROCPROF"))})
+                lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+                if res.returncode == 0 and lines:
+                    child = json.loads(lines[-1])
+                    if "hip" not in child or child.get("nbytes") != nbytes:
+                        child = None
+            except Exception:
+                child = None
+        if child is None:
+            how = "in this process, the runtime's default (polling) waits"
+            child = self._drop_in_here(tree, files, nbytes, cfg, common, more)
+            if "error" in child:
+                return child
+        h = child["hip"][str(w)]
+        payload = child["hip_stored_bytes"] - 8 * child["hip_blocks"]
         out = {"what": "the unmodified reference core (oracle/_ref) with Longtail_CreateHipChunkerAPI + HipBlake3HashAPI + Hip"
                        f"{cfg['codec'].upper()}CompressionAPI against its own CPU plugins: same files, same storage, W = {w}, median of {self.REPS}",
+               "measured": how, "blocking_waits_rc": child.get("blocking_waits_rc"),
                "workers": w, "sample_files": len(files),
                "upsync_GBps": {"hip_plugins": h["GBps"], "cpu_plugins": cpu["GBps"], "ratio": round(h["GBps"] / cpu["GBps"], 3)},
                "create_version_index_GBps": {"hip_plugins": round(nbytes / h["index_s"] / 1e9, 3), "cpu_plugins": round(nbytes / cpu["index_s"] / 1e9, 3),
                                              "ratio": round(cpu["index_s"] / h["index_s"], 3)},
                "write_content_GBps": {"hip_plugins": round(nbytes / h["write_s"] / 1e9, 3), "cpu_plugins": round(nbytes / cpu["write_s"] / 1e9, 3),
                                       "ratio": round(cpu["write_s"] / h["write_s"], 3)},
-               "ratio_hip_codec": round(hip["raw_bytes"] / payload, 4) if payload > 0 else None, "ratio_reference_codec": ref_ratio,
+               "ratio_hip_codec": round(child["hip_raw_bytes"] / payload, 4) if payload > 0 else None, "ratio_reference_codec": ref_ratio,
                "seconds": {"hip_plugins": h, "cpu_plugins": cpu}}
-        # The HIP plugins' callers WAIT (for the link, for a submission): an embedder is free to give the job system more workers than
-        # the CPU plugins can use -- the same three objects at 2 W and 4 W
-        more = [x for x in (2 * w,) if x <= max(self.ncpu, w)]
-        if os.environ.get("LTHIP_BENCH_DROPIN_SWEEP", "1") not in ("0", "1"):
-            more = [int(x) for x in os.environ["LTHIP_BENCH_DROPIN_SWEEP"].split(",")]
-        if more and os.environ.get("LTHIP_BENCH_DROPIN_SWEEP", "1") != "0":
-            wide = r.ingest_sweep_tree(tree, *common, more, self.REPS, chunker, hasher, codec_api)
-            if not wide["err"]:
-                by = self._median(wide, more, nbytes)
-                out["hip_plugins_by_workers"] = {str(w): {"upsync_GBps": h["GBps"], "index_GBps": round(nbytes / h["index_s"] / 1e9, 3), "write_GBps": round(nbytes / h["write_s"] / 1e9, 3)}}
-                for k, v in by.items():
-                    out["hip_plugins_by_workers"][k] = {"upsync_GBps": v["GBps"], "index_GBps": round(nbytes / v["index_s"] / 1e9, 3), "write_GBps": round(nbytes / v["write_s"] / 1e9, 3)}
-        # ... and what INTEGRATION.md recommends where one block per Compress call does not feed a GPU codec: HIP chunker + hash, CPU codec
-        mixed = r.ingest_sweep_tree(tree, *common, [w], self.REPS, chunker, hasher, None)
-        if not mixed["err"]:
-            m = self._median(mixed, [w], nbytes)[str(w)]
+        if len(child["hip"]) > 1:
+            # the HIP plugins' callers WAIT (for the link, for a submission): the same three objects with more workers than the CPU plugins can use
+            out["hip_plugins_by_workers"] = {k: {"upsync_GBps": v["GBps"], "index_GBps": round(nbytes / v["index_s"] / 1e9, 3), "write_GBps": round(nbytes / v["write_s"] / 1e9, 3)}
+                                             for k, v in child["hip"].items()}
+        m = child.get("hip_chunker_hash_cpu_codec")
+        if m:  # what INTEGRATION.md recommends where one block per Compress call does not feed a GPU codec: HIP chunker + hash, CPU codec
             out["upsync_GBps"]["hip_chunker_hash_cpu_codec"] = m["GBps"]
             out["upsync_GBps"]["ratio_hip_chunker_hash_cpu_codec"] = round(m["GBps"] / cpu["GBps"], 3)
             out["seconds"]["hip_chunker_hash_cpu_codec"] = m
+        return out
+
+    def _drop_in_here(self, tree, files, nbytes, cfg, common, more):
+        r, w = self.r, self.w
+        chunker, hasher, codec_api = self.plugins(cfg["codec"])
+        r.version_index(files[: min(256, len(files))] if len(files) > 1 else [(files[0][0], files[0][1][: 256 << 20])],
+                        self.args.target_chunk_size, w, 0, chunker, hasher)  # warm-up: contexts, window pool
+        ws = [w] + list(more)
+        hip = r.ingest_sweep_tree(tree, *common, ws, self.REPS, chunker, hasher, codec_api)
+        if hip["err"]:
+            return {"error": f"errno {hip['err']}"}
+        out = {"hip": self._median(hip, ws, nbytes), "hip_raw_bytes": hip["raw_bytes"], "hip_stored_bytes": hip["stored_bytes"], "hip_blocks": hip["blocks"],
+               "blocking_waits_rc": None}
+        mixed = r.ingest_sweep_tree(tree, *common, [w], self.REPS, chunker, hasher, None)
+        if not mixed["err"]:
+            out["hip_chunker_hash_cpu_codec"] = self._median(mixed, [w], nbytes)[str(w)]
         return out
 
     def configs0(self, sweep):

@@ -74,13 +74,15 @@ LTHIP_EXPORT void Longtail_Hip_SetAllocator(Longtail_Hip_AllocFunc alloc_func, L
 
 /* GPU used by plugin objects created afterwards (default: $LONGTAIL_HIP_DEVICE or 0). */
 LTHIP_EXPORT int Longtail_Hip_SetDevice(int device);
-/* How the host threads of the plugin layer wait for the GPU.  Default 1: the first plugin object made sets the device's scheduling
- * policy to hipDeviceScheduleBlockingSync -- a waiting worker sleeps until the interrupt instead of polling (the job system calls these
- * blocking APIs from 32-256 threads at once; polling was a third of the drop-in path's CPU time, and under a container's CPU quota that
- * is throughput: CreateVersionIndex 30 -> 40 GB/s at 32 workers, 16 -> 39 at 64).  The policy is the device's, process-wide: an embedder
- * with latency-critical HIP work of its own on the same device calls Longtail_Hip_SetBlockingWaits(0) before constructing anything. */
-LTHIP_EXPORT void Longtail_Hip_SetBlockingWaits(int on);
-LTHIP_EXPORT int lthip_set_blocking_waits(int device, int on); /* the call behind it (hipSetDeviceFlags on `device`) */
+/* OPTIONAL, and if used the embedder's FIRST call into this library, before the process has touched the GPU: host threads waiting
+ * for the device SLEEP until the interrupt (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) on the plugin device) instead of polling.
+ * The job system calls the blocking Longtail_*API functions from 32-256 threads at once; polling was a third of the drop-in path's
+ * CPU time, and under a container's CPU quota that is throughput: CreateVersionIndex through the plugins 30 -> 40 GB/s at 32 workers,
+ * UpSync 13.9 -> 16.5 (profiles/r06_dropin_scaling.txt; bench.py's drop_in legs run in a process of their own that makes this call).
+ * It is the device's policy, PROCESS-WIDE, and must not be switched in a process that already ran GPU work: waits on completion signals
+ * made before the switch may never return (observed).  Returns 0 or an errno; the library never makes this call on its own. */
+LTHIP_EXPORT int Longtail_Hip_SetBlockingWaits(int on);
+LTHIP_EXPORT int lthip_set_blocking_waits(int device, int on); /* the call behind it */
 
 /* HashAPI.Hash / EndContext return no error code (longtail_blake3.c:43-79 cannot fail; a GPU path can: allocation, copy, no
  * device).  The first errno of such a call on the calling thread is latched; this returns and clears it (0 = none). */

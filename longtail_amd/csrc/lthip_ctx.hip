@@ -165,13 +165,17 @@ extern "C" int lthip_ctx_create(int device, void* hip_stream, lthip_ctx** out_ct
 
 hipError_t lthip_stream_wait(lthip_ctx* ctx) { return hipStreamSynchronize(ctx->stream); }
 
-// The plugin layer's waits SLEEP.  A Longtail_*API call is a blocking call made from every worker of the embedder's job system at
-// once -- 32 to 256 threads, each waiting for its own upload, its submission, its download -- and the runtime's default wait polls the
-// completion signal: a third of the drop-in path's CPU time went there, and in a container with a CPU quota (the measured boxes grant
-// 16 CPUs of 256: cgroup cpu.max) CPU time IS the path's throughput.  hipDeviceScheduleBlockingSync makes a waiting thread sleep until
-// the interrupt: CreateVersionIndex through the plugins 30 -> 40 GB/s at W = 32, 16 -> 39 at W = 64, UpSync 12 -> 16.5 (round 6,
-// tools/dropin_scaling.py).  It is the DEVICE's policy, process-wide: set when the first plugin object is made
-// (Longtail_Hip_SetBlockingWaits(0) before that keeps the runtime's default), never by the bulk API on its own.
+// How host threads wait for this device: hipDeviceScheduleBlockingSync (a waiting thread sleeps until the interrupt) instead of the
+// runtime's default, which polls the completion signal.  The plugin layer's callers are the embedder's job-system workers, 32-256
+// threads each blocked in a Longtail_*API call: polling was a third of the drop-in path's CPU time, and in a container with a CPU
+// quota (the measured boxes grant 16 CPUs of 256: cgroup cpu.max) CPU time IS that path's throughput -- CreateVersionIndex through the
+// plugins 30 -> 40 GB/s at 32 workers, 16-20 -> 39 at 64 (tools/dropin_scaling.py, profiles/r06_dropin_scaling.txt).
+// It is the DEVICE's policy, process-wide, and it has to be set BEFORE the process uses the device: switched in a process that had
+// already run kernels and sessions, a later event wait of the ingest session never returned (bench.py, round 6: the completion signals
+// made under the polling policy do not interrupt).  So the library never sets it on its own: Longtail_Hip_SetBlockingWaits(1) is the
+// embedder's FIRST call (include/longtail_hip.h).  Measured and not used instead: an event made with hipEventBlockingSync in place of
+// hipStreamSynchronize (polls like the default), hipStreamQuery + nanosleep (user time 8.5 -> 2.5 s but the timer slack's 50 us per wait
+// cost more than the CPU time bought: 12.4 GB/s of UpSync against 13.9 with the default and 15.5-16.5 with the policy).
 extern "C" int lthip_set_blocking_waits(int device, int on)
 {
     int n = 0;

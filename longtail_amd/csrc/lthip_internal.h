@@ -139,8 +139,8 @@ struct lthip_ctx
 };
 
 int lthip_fail(lthip_ctx* ctx, int code, const char* what, const char* detail);
-// Waits for everything queued on the context's stream (the one place the library waits for a stream).  HOW a host thread waits is
-// the device's scheduling policy: lthip_set_blocking_waits below.
+// Waits for everything queued on the context's stream (the one place the library waits for a stream).  HOW a thread waits is the
+// device's scheduling policy: lthip_set_blocking_waits (lthip_ctx.hip).
 hipError_t lthip_stream_wait(lthip_ctx* ctx);
 
 // Environment switches (ablations, debug paths) are read once per process and cached -- not per call: the plugins call from up to 256

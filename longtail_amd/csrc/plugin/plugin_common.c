@@ -76,16 +76,7 @@ int Longtail_Hip_GetLastError(void)
     return e;
 }
 
-/* waits of the plugin layer sleep (include/longtail_hip.h): applied once, when the first thread state is made */
-static int g_blocking_waits = 1, g_waits_applied;
-void Longtail_Hip_SetBlockingWaits(int on) { __atomic_store_n(&g_blocking_waits, on ? 1 : 0, __ATOMIC_RELEASE); }
-static void apply_wait_policy(void)
-{
-    int expected = 0;
-    if (__atomic_compare_exchange_n(&g_waits_applied, &expected, 1, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) &&
-        __atomic_load_n(&g_blocking_waits, __ATOMIC_ACQUIRE))
-        (void)lthip_set_blocking_waits(ltp_device(), 1);
-}
+int Longtail_Hip_SetBlockingWaits(int on) { return lthip_set_blocking_waits(ltp_device(), on); } /* (include/longtail_hip.h: first call, or never) */
 
 static pthread_key_t g_key;
 static pthread_once_t g_key_once = PTHREAD_ONCE_INIT;
@@ -117,7 +108,6 @@ struct ltp_thread_state* ltp_thread_state_get(void)
     ts = (struct ltp_thread_state*)calloc(1, sizeof *ts);
     if (!ts)
         return 0;
-    apply_wait_policy();
     if (lthip_ctx_create(ltp_device(), LTHIP_STREAM_PRIVATE, &ts->ctx) != 0)
     {
         free(ts);
