@@ -290,6 +290,27 @@ def test_registry_embedding_as_integration_md_prints_it():
     assert int(line[2]) == 6 and int(line[4]) == 0 and int(line[6]) == 0, line
 
 
+def test_blocking_waits_first_call_then_the_drop_in_sequence():
+    """Longtail_Hip_SetBlockingWaits(1) as an embedder's FIRST call (include/longtail_hip.h: the device's wait policy, set before the
+    process touches the GPU), then the three plugin objects in the unmodified core -- in a process of its own, which is how bench.py
+    measures its drop_in legs (tools/drop_in_child.py): the call succeeds, UpSync + the CPU-codec pairing run, the HIP codec's stored
+    bytes are a real compression of the compressible sample."""
+    import json
+    import subprocess
+    import sys
+
+    from tests._libs import ROOT
+
+    req = {"cfg": {"tree": "files", "kind": "mixed", "codec": "lz4", "file_mib": 1.0, "gib": 0.125, "dups": False}, "sample_bytes": 128 << 20,
+           "workers": 8, "more_workers": [16], "reps": 1, "target_chunk_size": 65536, "block_size": 8 << 20, "max_chunks_per_block": 1024}
+    out = subprocess.run([sys.executable, str(ROOT / "tools" / "drop_in_child.py"), json.dumps(req)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["blocking_waits_rc"] == 0 and "error" not in j, j
+    assert set(j["hip"]) == {"8", "16"} and j["hip"]["8"]["GBps"] > 0 and j["hip_chunker_hash_cpu_codec"]["GBps"] > 0
+    assert j["nbytes"] == 128 << 20 and 0 < j["hip_stored_bytes"] < 0.7 * j["hip_raw_bytes"]
+
+
 def _stream(api_ptr, pieces):
     """BeginContext / Hash... / EndContext over an iterable of numpy byte arrays, as longtail_blake3.c:24-79 is driven."""
     h = HashAPIStruct.from_address(api_ptr)
