@@ -1491,20 +1491,5 @@ class CpuReference:
                 "sample": f"64 x {file_bytes} B files, single-thread C restatement (oracle/), LZ4", "host_cpus": self.ncpu}
 
 
-def run_cpu_baseline(args, b=None, cfg=None):
-    """The headline's cpu_baseline: the full worker sweep {1, 32, physical cores, all hardware threads} on --cpu-gib of the headline tree,
-    BASELINE.json configs[0], and the drop-in measurement on the same sample."""
-    cfg = cfg or dict(tree=args.tree, kind=args.kind, codec=args.codec, gib=args.gib, file_mib=args.file_mib, dups=args.dups)
-    cr = CpuReference(b, args)
-    try:
-        sweep = sorted({min(32, cr.ncpu), cr.physical, cr.ncpu} - {1}) or [1]
-        out = cr.leg(cfg, args.cpu_gib, sweep=sweep, drop_in=True, one_gib=1.0)
-        if "error" not in out and cr.have_ref:
-            out["configs0_one_256MiB_file"] = cr.configs0(sorted({sweep[0], cr.ncpu}))
-        return out
-    finally:
-        cr.close()
-
-
 if __name__ == "__main__":
     main()
