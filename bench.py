@@ -20,9 +20,12 @@ Workload (default = BASELINE.json configs[2]): a tree of 1 MiB random files, 64 
 N x 64 GiB) or in total (--scaling strong, configs[3]); the tree's jobs are assigned to ranks by lthip_partition_jobs
 (byte-balanced contiguous ranges by default: an asset's parts may straddle ranks, configs[4]); every rank synthesizes only its own
 parts.  value = bytes of the whole tree / max-over-ranks wall time of K steps (barrier + synchronize on both sides).
-The default run also measures, after the headline, the compressible variant and the north-star mixed-size tree ("secondary";
-at N=1 also "restore": the device decoders' GB/s on 512 stored blocks of the compressible workload, round trip verified),
-and times the reference's bikeshed-threaded CPU path on a bounded sample ("cpu_baseline").
+The default run also measures, after the headline, the compressible variant, the north-star mixed-size tree, the zstd codec and
+BASELINE.json configs[4]'s shape (4 x 16 GiB files, ZStd) on compressible bytes ("secondary"; at N=1 also "restore": the device
+decoders' GB/s on 512 stored blocks of the compressible workload, round trip verified, and "host_fed": the session fed from pinned
+host memory), and times the reference's bikeshed-threaded CPU path on a bounded sample of EVERY one of those trees ("cpu_baseline",
+with the reference codec's ratio and the container's CPU quota beside it; class CpuReference) -- plus, in a process of its own
+(tools/drop_in_child.py), the unmodified reference core with this library's plugin objects on the same sample ("drop_in").
 """
 from __future__ import annotations
 
