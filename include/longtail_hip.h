@@ -182,6 +182,10 @@ LTHIP_EXPORT int lthip_plan_reaim(lthip_ctx* ctx, lthip_plan* plan, uint32_t par
 LTHIP_EXPORT void lthip_plan_destroy(lthip_ctx* ctx, lthip_plan* plan);
 /* upper bound on the number of chunks the plan can produce (size the output arrays with it) */
 LTHIP_EXPORT uint64_t lthip_plan_chunk_capacity(const lthip_plan* plan);
+/* 2 when lthip_chunk_hash runs this plan as two slices on two streams (plans of >= 1 GiB in >= 2 parts: the candidate scan of the
+ * second half of the parts beside the leaf hashing of the first; results identical to the single pass), else 1.  Per-kernel timings
+ * (lthip_timing_get) of the scan and the leaf hashing then OVERLAP: their sum exceeds the wall time of the call. */
+LTHIP_EXPORT uint32_t lthip_plan_slices(const lthip_plan* plan);
 
 /* Runs buzhash scan -> cut selection -> compaction -> (if d_chunk_hashes) BLAKE3 on the stream.
  * Outputs (device pointers, capacity >= lthip_plan_chunk_capacity):

@@ -131,6 +131,7 @@ extern "C" int lthip_ctx_create(int device, void* hip_stream, lthip_ctx** out_ct
     if (!ctx)
         return ENOMEM;
     ctx->device = device;
+    ctx->slice_ctx = nullptr;
     ctx->err[0] = 0;
     ctx->timing = false;
     memset(ctx->scratch, 0, sizeof ctx->scratch);
@@ -196,6 +197,8 @@ extern "C" void lthip_ctx_destroy(lthip_ctx* ctx)
         return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->slice_ctx)
+        lthip_ctx_destroy(ctx->slice_ctx);
     for (auto& r : ctx->pending)
     {
         (void)hipEventDestroy(r.a);
@@ -423,6 +426,8 @@ extern "C" int lthip_timing_enable(lthip_ctx* ctx, int on)
         return EINVAL;
     int err = timing_collect(ctx);
     ctx->timing = on != 0;
+    if (ctx->slice_ctx)
+        (void)lthip_timing_enable(ctx->slice_ctx, on);
     return err;
 }
 
@@ -433,6 +438,8 @@ extern "C" int lthip_timing_reset(lthip_ctx* ctx)
     int err = timing_collect(ctx);
     memset(ctx->total_ms, 0, sizeof ctx->total_ms);
     memset(ctx->launches, 0, sizeof ctx->launches);
+    if (ctx->slice_ctx)
+        (void)lthip_timing_reset(ctx->slice_ctx);
     return err;
 }
 
@@ -441,10 +448,22 @@ extern "C" int lthip_timing_get(lthip_ctx* ctx, int kernel_id, double* out_total
     if (!ctx || kernel_id < 0 || kernel_id >= LTHIP_K_COUNT)
         return EINVAL;
     int err = timing_collect(ctx);
+    double ms = ctx->total_ms[kernel_id];
+    uint64_t n = ctx->launches[kernel_id];
+    if (ctx->slice_ctx) // (the second slice of lthip_chunk_hash runs on a context of its own: its launches count here)
+    {
+        double ms2 = 0;
+        uint64_t n2 = 0;
+        if (lthip_timing_get(ctx->slice_ctx, kernel_id, &ms2, &n2) == 0)
+        {
+            ms += ms2;
+            n += n2;
+        }
+    }
     if (out_total_ms)
-        *out_total_ms = ctx->total_ms[kernel_id];
+        *out_total_ms = ms;
     if (out_launches)
-        *out_launches = ctx->launches[kernel_id];
+        *out_launches = n;
     return err;
 }
 
@@ -578,9 +597,60 @@ extern "C" int lthip_divtest_eval(uint32_t discriminator, uint32_t hash)
     return r <= t.qlim;
 }
 
+static int plan_create_impl(lthip_ctx* ctx, uint32_t part_count, const uint64_t* part_offsets, const uint64_t* part_sizes,
+                            uint32_t min_chunk, uint32_t avg_chunk, uint32_t max_chunk, lthip_plan** out_plan);
+
+// where a plan's parts are cut into two halves of about equal bytes: parts [0, split) and [split, n); 0 = do not slice
+static uint32_t plan_split_point(uint32_t part_count, const uint64_t* part_sizes)
+{
+    if (part_count < 2)
+        return 0;
+    uint64_t total = 0;
+    for (uint32_t p = 0; p < part_count; ++p)
+        total += part_sizes[p];
+    if (total < LTHIP_SLICE_MIN_BYTES)
+        return 0;
+    uint64_t acc = 0;
+    uint32_t p = 0;
+    while (p < part_count && acc + part_sizes[p] / 2 < total / 2)
+        acc += part_sizes[p++];
+    return p < 1 ? 1 : (p > part_count - 1 ? part_count - 1 : p);
+}
+
 extern "C" int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const uint64_t* part_offsets,
                                  const uint64_t* part_sizes, uint32_t min_chunk, uint32_t avg_chunk, uint32_t max_chunk,
                                  lthip_plan** out_plan)
+{
+    int err = plan_create_impl(ctx, part_count, part_offsets, part_sizes, min_chunk, avg_chunk, max_chunk, out_plan);
+    if (err)
+        return err;
+    // the two halves (lthip_chunk_hash): plans of their own over the same bytes.  Optional: a half that cannot be made leaves the
+    // plan unsliced, it is never an error of the call.
+    lthip_plan* plan = *out_plan;
+    const uint32_t split = plan_split_point(part_count, part_sizes);
+    if (split)
+    {
+        lthip_plan *a = nullptr, *b = nullptr;
+        if (plan_create_impl(ctx, split, part_offsets, part_sizes, min_chunk, avg_chunk, max_chunk, &a) == 0 &&
+            plan_create_impl(ctx, part_count - split, part_offsets + split, part_sizes + split, min_chunk, avg_chunk, max_chunk, &b) == 0)
+        {
+            plan->half[0] = a;
+            plan->half[1] = b;
+            plan->split = split;
+            plan->sliced = true;
+        }
+        else
+        {
+            lthip_plan_destroy(ctx, a);
+            lthip_plan_destroy(ctx, b);
+            ctx->err[0] = 0;
+        }
+    }
+    return 0;
+}
+
+static int plan_create_impl(lthip_ctx* ctx, uint32_t part_count, const uint64_t* part_offsets, const uint64_t* part_sizes,
+                            uint32_t min_chunk, uint32_t avg_chunk, uint32_t max_chunk, lthip_plan** out_plan)
 {
     if (!ctx || !out_plan || (part_count && (!part_offsets || !part_sizes)))
         return EINVAL;
@@ -698,8 +768,37 @@ extern "C" int lthip_plan_resize_single(lthip_ctx* ctx, lthip_plan* plan, uint64
 // table it was created with): no allocation and no synchronisation -- the part table goes through the pinned staging ring, the
 // tile -> part table is rebuilt by its kernel on the stream.  What the plugin layer's batcher needs: one plan, a different set of
 // windows in every submission (plugin_batch.c).
+static int plan_reaim_impl(lthip_ctx* ctx, lthip_plan* plan, uint32_t part_count, const uint64_t* part_offsets, const uint64_t* part_sizes);
+
 extern "C" int lthip_plan_reaim(lthip_ctx* ctx, lthip_plan* plan, uint32_t part_count, const uint64_t* part_offsets,
                                 const uint64_t* part_sizes)
+{
+    int err = plan_reaim_impl(ctx, plan, part_count, part_offsets, part_sizes);
+    if (err || !plan->half[0])
+        return err;
+    // the halves follow when the new parts fit them (they do when the layout is the one the plan was created with: bench.py's
+    // steps); otherwise this aim runs unsliced
+    plan->sliced = false;
+    const uint32_t split = plan_split_point(part_count, part_sizes);
+    if (!split || split > plan->half[0]->cap_parts || part_count - split > plan->half[1]->cap_parts)
+        return 0;
+    uint64_t t0 = 0, t1 = 0;
+    for (uint32_t p = 0; p < part_count; ++p)
+        (p < split ? t0 : t1) += div_up_u64(part_sizes[p], 16384);
+    if (t0 > plan->half[0]->cap_tiles || t1 > plan->half[1]->cap_tiles)
+        return 0;
+    if (plan_reaim_impl(ctx, plan->half[0], split, part_offsets, part_sizes) ||
+        plan_reaim_impl(ctx, plan->half[1], part_count - split, part_offsets + split, part_sizes + split))
+    {
+        ctx->err[0] = 0;
+        return 0;
+    }
+    plan->split = split;
+    plan->sliced = true;
+    return 0;
+}
+
+static int plan_reaim_impl(lthip_ctx* ctx, lthip_plan* plan, uint32_t part_count, const uint64_t* part_offsets, const uint64_t* part_sizes)
 {
     if (!ctx || !plan || (part_count && (!part_offsets || !part_sizes)))
         return EINVAL;
@@ -761,14 +860,39 @@ extern "C" void lthip_plan_destroy(lthip_ctx* ctx, lthip_plan* plan)
         (void)hipFree(plan->d_parts);
     if (plan->d_tile_part)
         (void)hipFree(plan->d_tile_part);
+    lthip_plan_destroy(ctx, plan->half[0]);
+    lthip_plan_destroy(ctx, plan->half[1]);
     delete plan;
 }
 
 extern "C" uint64_t lthip_plan_chunk_capacity(const lthip_plan* plan) { return plan ? plan->chunk_cap : 0; }
+extern "C" uint32_t lthip_plan_slices(const lthip_plan* plan) { return plan && plan->sliced && plan->half[0] && plan->half[1] ? 2u : 1u; }
 
 // ---------------------------------------------------------------------------------------------------
 // phase 1
 // ---------------------------------------------------------------------------------------------------
+static int chunk_hash_one(lthip_ctx* ctx, const lthip_plan* plan, const void* d_data, uint64_t* d_chunk_offsets, uint32_t* d_chunk_lens,
+                          uint64_t* d_chunk_hashes, uint32_t* d_part_first);
+
+// the second slice's lists behind the first one's: totalA = part_first[0] (= the first slice's chunk count, final), list B goes to
+// [totalA, totalA + totalB), its part table is shifted by totalA
+__global__ void k_slice_join(const uint64_t* __restrict__ b_off, const uint32_t* __restrict__ b_len, const uint64_t* __restrict__ b_hash,
+                             const uint32_t* __restrict__ b_first, uint32_t nparts_b, uint32_t* __restrict__ part_first /* at the split */,
+                             uint64_t* __restrict__ offs, uint32_t* __restrict__ lens, uint64_t* __restrict__ hashes)
+{
+    const uint32_t total_a = part_first[0], total_b = b_first[nparts_b];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total_b)
+    {
+        offs[total_a + i] = b_off[i];
+        lens[total_a + i] = b_len[i];
+        if (hashes)
+            hashes[total_a + i] = b_hash[i];
+    }
+    if (i >= 1 && i <= nparts_b) // (entry 0 is total_a itself: every thread reads it)
+        part_first[i] = b_first[i] + total_a;
+}
+
 extern "C" int lthip_chunk_hash(lthip_ctx* ctx, const lthip_plan* plan, const void* d_data, uint64_t* d_chunk_offsets,
                                 uint32_t* d_chunk_lens, uint64_t* d_chunk_hashes, uint32_t* d_part_first,
                                 uint64_t* out_total)
@@ -776,6 +900,68 @@ extern "C" int lthip_chunk_hash(lthip_ctx* ctx, const lthip_plan* plan, const vo
     if (!ctx || !plan || !d_chunk_offsets || !d_chunk_lens || !d_part_first || (plan->total_bytes && !d_data))
         return EINVAL;
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int err = 0;
+    bool done = false;
+    // ---- two slices on two streams (plans of >= 1 GiB in >= 2 parts, with hashes): the candidate scan (K1: four waves per SIMD, its
+    // issue slots 72 % used, LDS-heavy) of the second half of the parts runs beside the leaf hashing (K3: VALU bound, no LDS) of the
+    // first -- the scan takes its residency first (one persistent workgroup per CU), the hashing's workgroups fill what is left.
+    // 26.0 -> 24.0 ms per 32 GiB (tools/k1k3_overlap_probe.py, round 6); the lists are the ones of the single pass, bit for bit: the
+    // second slice's go to scratch and are joined behind the first's.
+    LTHIP_ABLATION_ENV(env_slices, "LTHIP_SLICES"); // (ablation build: 1 = the single pass, for profiles of K1 / K3 alone)
+    if (plan->sliced && plan->half[0] && plan->half[1] && d_chunk_hashes && env_slices.get() != 1)
+    {
+        if (!ctx->slice_ctx && lthip_ctx_create(ctx->device, LTHIP_STREAM_PRIVATE, &ctx->slice_ctx) != 0)
+            ctx->slice_ctx = nullptr;
+        lthip_ctx* c2 = ctx->slice_ctx;
+        const lthip_plan *pa = plan->half[0], *pb = plan->half[1];
+        void *b_off = nullptr, *b_len = nullptr, *b_hash = nullptr, *b_first = nullptr;
+        if (c2 && !lthip_scratch(c2, S_SLICE_OFFS, (pb->chunk_cap + 1) * 8, &b_off) && !lthip_scratch(c2, S_SLICE_LENS, (pb->chunk_cap + 1) * 4, &b_len) &&
+            !lthip_scratch(c2, S_SLICE_HASH, (pb->chunk_cap + 1) * 8, &b_hash) && !lthip_scratch(c2, S_SLICE_FIRST, ((size_t)pb->nparts + 1) * 4, &b_first))
+        {
+            c2->timing = ctx->timing;
+            hipEvent_t ready = lthip_sync_event(ctx); // the data (and whatever else the caller queued) before the second slice starts
+            LTHIP_CHECK(ctx, hipEventRecord(ready, ctx->stream));
+            LTHIP_CHECK(ctx, hipStreamWaitEvent(c2->stream, ready, 0));
+            err = chunk_hash_one(ctx, pa, d_data, d_chunk_offsets, d_chunk_lens, d_chunk_hashes, d_part_first);
+            if (!err)
+            {
+                err = chunk_hash_one(c2, pb, d_data, (uint64_t*)b_off, (uint32_t*)b_len, (uint64_t*)b_hash, (uint32_t*)b_first);
+                if (err)
+                    (void)lthip_fail(ctx, err, "lthip_chunk_hash (second slice)", c2->err);
+            }
+            hipEvent_t joined = lthip_sync_event(ctx); // (also after a failure: the first stream never runs ahead of the second)
+            LTHIP_CHECK(ctx, hipEventRecord(joined, c2->stream));
+            LTHIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, joined, 0));
+            if (err)
+                return err;
+            const uint64_t n = pb->chunk_cap > (uint64_t)pb->nparts + 1 ? pb->chunk_cap : (uint64_t)pb->nparts + 1;
+            LaunchTimer t(ctx, LTHIP_K_COMPACT);
+            hipLaunchKernelGGL(k_slice_join, dim3((uint32_t)div_up_u64(n, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)b_off, (const uint32_t*)b_len,
+                               (const uint64_t*)b_hash, (const uint32_t*)b_first, pb->nparts, d_part_first + plan->split, d_chunk_offsets, d_chunk_lens,
+                               d_chunk_hashes);
+            LTHIP_LAUNCH_CHECK(ctx);
+            done = true;
+        }
+        else
+            ctx->err[0] = 0; // (no second context / scratch: the single pass)
+    }
+    if (!done)
+        err = chunk_hash_one(ctx, plan, d_data, d_chunk_offsets, d_chunk_lens, d_chunk_hashes, d_part_first);
+    if (err)
+        return err;
+    if (out_total)
+    {
+        uint32_t total = 0;
+        LTHIP_CHECK(ctx, hipMemcpyAsync(&total, d_part_first + plan->nparts, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
+        *out_total = total;
+    }
+    return 0;
+}
+
+static int chunk_hash_one(lthip_ctx* ctx, const lthip_plan* plan, const void* d_data, uint64_t* d_chunk_offsets, uint32_t* d_chunk_lens,
+                          uint64_t* d_chunk_hashes, uint32_t* d_part_first)
+{
     void *bm0, *bm1, *region, *pcount;
     int err;
     if ((err = lthip_scratch(ctx, S_BM0, plan->bm0_words * 8, &bm0)))
@@ -804,13 +990,6 @@ extern "C" int lthip_chunk_hash(lthip_ctx* ctx, const lthip_plan* plan, const vo
                                        d_part_first + plan->nparts, plan->chunk_cap, plan->leaf_cap, plan->max_chunk,
                                        d_chunk_hashes)))
             return err;
-    }
-    if (out_total)
-    {
-        uint32_t total = 0;
-        LTHIP_CHECK(ctx, hipMemcpyAsync(&total, d_part_first + plan->nparts, 4, hipMemcpyDeviceToHost, ctx->stream));
-        LTHIP_CHECK(ctx, lthip_stream_wait(ctx));
-        *out_total = total;
     }
     return 0;
 }

@@ -57,7 +57,13 @@ struct lthip_plan
     uint64_t cap_tiles;
     PartDev* d_parts;
     uint32_t* d_tile_part;
+    // A plan of many parts and >= LTHIP_SLICE_MIN_BYTES also exists as TWO plans over its first and second half of the bytes
+    // (lthip_chunk_hash runs them on two streams: the candidate scan of the second half beside the leaf hashing of the first)
+    lthip_plan* half[2];
+    uint32_t split; // parts [0, split) are half[0]'s
+    bool sliced;    // the halves are aimed at the plan's current parts
 };
+constexpr uint64_t LTHIP_SLICE_MIN_BYTES = 1ull << 30;
 
 // ---------------------------------------------------------------------------------------------------
 // context
@@ -93,6 +99,10 @@ enum ScratchSlot
     S_Z_PERM,       // zstd decoder: the items in piece-major order, per-row counters, per-item done flags
     S_XCHG,         // multi-GPU exchange: range tables of lthip_exchange_reorder
     S_XCHG2,        // ... and the job tables of lthip_job_ordinals
+    S_SLICE_OFFS,   // lthip_chunk_hash in two slices: the second slice's chunk offsets / lengths / hashes / part table before the join
+    S_SLICE_LENS,
+    S_SLICE_HASH,
+    S_SLICE_FIRST,
     S_COUNT
 };
 
@@ -107,6 +117,7 @@ struct lthip_ctx
     int device;
     hipStream_t stream;
     bool own_stream;
+    lthip_ctx* slice_ctx;                // lazily created: context (private stream, scratch of its own) of lthip_chunk_hash's second slice
     hipStream_t stream2;                 // lazily created side stream (non-blocking), see lthip_second_stream
     std::vector<hipEvent_t> sync_events; // ordering events between the two streams, reused round-robin
     size_t sync_next;

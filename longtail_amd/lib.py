@@ -114,6 +114,7 @@ class HipLib:
         sig("lthip_plan_destroy", None, [vp, vp])
         sig("lthip_plan_resize_single", i32, [vp, vp, u64])
         sig("lthip_plan_chunk_capacity", u64, [vp])
+        sig("lthip_plan_slices", u32, [vp])
         sig("lthip_chunk_hash", i32, [vp, vp, vp, vp, vp, vp, vp, P(u64)])
         sig("lthip_chunk_from_buffer", i32, [vp, vp, u64, u32, u32, u32, P(u64)])
         sig("lthip_hash_ranges", i32, [vp, vp, u64, vp, vp, u32, vp])
@@ -695,6 +696,11 @@ class Plan:
         self.h = h
         self.capacity = int(ctx.lib.dll.lthip_plan_chunk_capacity(h))
         self.total_bytes = int(s.sum()) if len(s) else 0
+
+    @property
+    def slices(self) -> int:
+        """2 when chunk_hash runs this plan as two slices on two streams (per-kernel timings of scan and leaf hashing then overlap)."""
+        return int(self.ctx.lib.dll.lthip_plan_slices(self.h))
 
     def reaim(self, part_offsets, part_sizes):
         """The plan aimed at another set of parts (lthip_plan_reaim): no more parts / 16 KiB tiles than it was created with; the part
