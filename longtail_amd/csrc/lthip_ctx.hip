@@ -600,21 +600,36 @@ extern "C" int lthip_divtest_eval(uint32_t discriminator, uint32_t hash)
 static int plan_create_impl(lthip_ctx* ctx, uint32_t part_count, const uint64_t* part_offsets, const uint64_t* part_sizes,
                             uint32_t min_chunk, uint32_t avg_chunk, uint32_t max_chunk, lthip_plan** out_plan);
 
-// where a plan's parts are cut into two halves of about equal bytes: parts [0, split) and [split, n); 0 = do not slice
-static uint32_t plan_split_point(uint32_t part_count, const uint64_t* part_sizes)
+// where a plan's parts are cut into S runs of about equal bytes: first[0] = 0 < first[1] < ... < first[S] = n; returns S (0 = do not slice)
+static uint32_t plan_slice_points(uint32_t part_count, const uint64_t* part_sizes, uint32_t want, uint32_t* first)
 {
-    if (part_count < 2)
+    if (part_count < 2 || want < 2)
         return 0;
     uint64_t total = 0;
     for (uint32_t p = 0; p < part_count; ++p)
         total += part_sizes[p];
     if (total < LTHIP_SLICE_MIN_BYTES)
         return 0;
+    uint32_t S = want > part_count ? part_count : want;
+    while (S > 2 && total / S < LTHIP_SLICE_MIN_BYTES / 2)
+        --S;
     uint64_t acc = 0;
     uint32_t p = 0;
-    while (p < part_count && acc + part_sizes[p] / 2 < total / 2)
-        acc += part_sizes[p++];
-    return p < 1 ? 1 : (p > part_count - 1 ? part_count - 1 : p);
+    first[0] = 0;
+    for (uint32_t k = 1; k < S; ++k)
+    {
+        const uint64_t goal = total / S * k;
+        while (p < part_count - (S - k) && acc + part_sizes[p] / 2 < goal)
+            acc += part_sizes[p++];
+        if (p <= first[k - 1])
+        {
+            acc += part_sizes[p];
+            ++p;
+        }
+        first[k] = p;
+    }
+    first[S] = part_count;
+    return S;
 }
 
 extern "C" int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const uint64_t* part_offsets,
@@ -624,25 +639,33 @@ extern "C" int lthip_plan_create(lthip_ctx* ctx, uint32_t part_count, const uint
     int err = plan_create_impl(ctx, part_count, part_offsets, part_sizes, min_chunk, avg_chunk, max_chunk, out_plan);
     if (err)
         return err;
-    // the two halves (lthip_chunk_hash): plans of their own over the same bytes.  Optional: a half that cannot be made leaves the
-    // plan unsliced, it is never an error of the call.
+    // the slices (lthip_chunk_hash): plans of their own over the same bytes.  Optional: a slice that cannot be made leaves the plan
+    // unsliced, it is never an error of the call.
     lthip_plan* plan = *out_plan;
-    const uint32_t split = plan_split_point(part_count, part_sizes);
-    if (split)
+    int want = LTHIP_SLICES;
+    LTHIP_ABLATION_ENV(env_slices, "LTHIP_SLICES"); // (ablation build: 1 = the single pass, for profiles of K1 / K3 alone; 2..8)
+    if (env_slices.get() > 0)
+        want = env_slices.get() > 8 ? 8 : env_slices.get();
+    uint32_t first[9];
+    const uint32_t S = plan_slice_points(part_count, part_sizes, (uint32_t)want, first);
+    if (S)
     {
-        lthip_plan *a = nullptr, *b = nullptr;
-        if (plan_create_impl(ctx, split, part_offsets, part_sizes, min_chunk, avg_chunk, max_chunk, &a) == 0 &&
-            plan_create_impl(ctx, part_count - split, part_offsets + split, part_sizes + split, min_chunk, avg_chunk, max_chunk, &b) == 0)
+        bool ok = true;
+        for (uint32_t k = 0; k < S && ok; ++k)
+            ok = plan_create_impl(ctx, first[k + 1] - first[k], part_offsets + first[k], part_sizes + first[k], min_chunk, avg_chunk, max_chunk, &plan->slice[k]) == 0;
+        if (ok)
         {
-            plan->half[0] = a;
-            plan->half[1] = b;
-            plan->split = split;
+            memcpy(plan->slice_first, first, sizeof(uint32_t) * (S + 1));
+            plan->nslices = S;
             plan->sliced = true;
         }
         else
         {
-            lthip_plan_destroy(ctx, a);
-            lthip_plan_destroy(ctx, b);
+            for (uint32_t k = 0; k < S; ++k)
+            {
+                lthip_plan_destroy(ctx, plan->slice[k]);
+                plan->slice[k] = nullptr;
+            }
             ctx->err[0] = 0;
         }
     }
@@ -774,26 +797,29 @@ extern "C" int lthip_plan_reaim(lthip_ctx* ctx, lthip_plan* plan, uint32_t part_
                                 const uint64_t* part_sizes)
 {
     int err = plan_reaim_impl(ctx, plan, part_count, part_offsets, part_sizes);
-    if (err || !plan->half[0])
+    if (err || !plan->nslices)
         return err;
-    // the halves follow when the new parts fit them (they do when the layout is the one the plan was created with: bench.py's
-    // steps); otherwise this aim runs unsliced
+    // the slices follow when the new parts fit them (they do when the layout is the one the plan was created with: bench.py's
+    // steps); otherwise this aim runs as one
     plan->sliced = false;
-    const uint32_t split = plan_split_point(part_count, part_sizes);
-    if (!split || split > plan->half[0]->cap_parts || part_count - split > plan->half[1]->cap_parts)
+    uint32_t first[9];
+    if (plan_slice_points(part_count, part_sizes, plan->nslices, first) != plan->nslices)
         return 0;
-    uint64_t t0 = 0, t1 = 0;
-    for (uint32_t p = 0; p < part_count; ++p)
-        (p < split ? t0 : t1) += div_up_u64(part_sizes[p], 16384);
-    if (t0 > plan->half[0]->cap_tiles || t1 > plan->half[1]->cap_tiles)
-        return 0;
-    if (plan_reaim_impl(ctx, plan->half[0], split, part_offsets, part_sizes) ||
-        plan_reaim_impl(ctx, plan->half[1], part_count - split, part_offsets + split, part_sizes + split))
+    for (uint32_t k = 0; k < plan->nslices; ++k)
     {
-        ctx->err[0] = 0;
-        return 0;
+        uint64_t tiles = 0;
+        for (uint32_t p = first[k]; p < first[k + 1]; ++p)
+            tiles += div_up_u64(part_sizes[p], 16384);
+        if (first[k + 1] - first[k] > plan->slice[k]->cap_parts || tiles > plan->slice[k]->cap_tiles)
+            return 0;
     }
-    plan->split = split;
+    for (uint32_t k = 0; k < plan->nslices; ++k)
+        if (plan_reaim_impl(ctx, plan->slice[k], first[k + 1] - first[k], part_offsets + first[k], part_sizes + first[k]))
+        {
+            ctx->err[0] = 0;
+            return 0;
+        }
+    memcpy(plan->slice_first, first, sizeof(uint32_t) * (plan->nslices + 1));
     plan->sliced = true;
     return 0;
 }
@@ -860,37 +886,36 @@ extern "C" void lthip_plan_destroy(lthip_ctx* ctx, lthip_plan* plan)
         (void)hipFree(plan->d_parts);
     if (plan->d_tile_part)
         (void)hipFree(plan->d_tile_part);
-    lthip_plan_destroy(ctx, plan->half[0]);
-    lthip_plan_destroy(ctx, plan->half[1]);
+    for (uint32_t k = 0; k < 8; ++k)
+        lthip_plan_destroy(ctx, plan->slice[k]);
     delete plan;
 }
 
 extern "C" uint64_t lthip_plan_chunk_capacity(const lthip_plan* plan) { return plan ? plan->chunk_cap : 0; }
-extern "C" uint32_t lthip_plan_slices(const lthip_plan* plan) { return plan && plan->sliced && plan->half[0] && plan->half[1] ? 2u : 1u; }
+extern "C" uint32_t lthip_plan_slices(const lthip_plan* plan) { return plan && plan->sliced && plan->nslices ? plan->nslices : 1u; }
 
 // ---------------------------------------------------------------------------------------------------
 // phase 1
 // ---------------------------------------------------------------------------------------------------
-static int chunk_hash_one(lthip_ctx* ctx, const lthip_plan* plan, const void* d_data, uint64_t* d_chunk_offsets, uint32_t* d_chunk_lens,
-                          uint64_t* d_chunk_hashes, uint32_t* d_part_first);
+static int chunk_scan_one(lthip_ctx* ctx, const lthip_plan* plan, const void* d_data, uint64_t* d_chunk_offsets, uint32_t* d_chunk_lens,
+                          uint32_t* d_part_first);
 
-// the second slice's lists behind the first one's: totalA = part_first[0] (= the first slice's chunk count, final), list B goes to
-// [totalA, totalA + totalB), its part table is shifted by totalA
+// a slice's lists behind the slices before it: base = part_first[0] (= the chunk count of everything before the slice, final by now),
+// its lists go to [base, base + total), its part table is shifted by base
 __global__ void k_slice_join(const uint64_t* __restrict__ b_off, const uint32_t* __restrict__ b_len, const uint64_t* __restrict__ b_hash,
-                             const uint32_t* __restrict__ b_first, uint32_t nparts_b, uint32_t* __restrict__ part_first /* at the split */,
+                             const uint32_t* __restrict__ b_first, uint32_t nparts_b, uint32_t* __restrict__ part_first /* at the slice's first part */,
                              uint64_t* __restrict__ offs, uint32_t* __restrict__ lens, uint64_t* __restrict__ hashes)
 {
-    const uint32_t total_a = part_first[0], total_b = b_first[nparts_b];
+    const uint32_t base = part_first[0], total_b = b_first[nparts_b];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total_b)
     {
-        offs[total_a + i] = b_off[i];
-        lens[total_a + i] = b_len[i];
-        if (hashes)
-            hashes[total_a + i] = b_hash[i];
+        offs[base + i] = b_off[i];
+        lens[base + i] = b_len[i];
+        hashes[base + i] = b_hash[i];
     }
-    if (i >= 1 && i <= nparts_b) // (entry 0 is total_a itself: every thread reads it)
-        part_first[i] = b_first[i] + total_a;
+    if (i >= 1 && i <= nparts_b) // (entry 0 is the base itself: every thread reads it)
+        part_first[i] = b_first[i] + base;
 }
 
 extern "C" int lthip_chunk_hash(lthip_ctx* ctx, const lthip_plan* plan, const void* d_data, uint64_t* d_chunk_offsets,
@@ -902,43 +927,89 @@ extern "C" int lthip_chunk_hash(lthip_ctx* ctx, const lthip_plan* plan, const vo
     LTHIP_CHECK(ctx, hipSetDevice(ctx->device));
     int err = 0;
     bool done = false;
-    // ---- two slices on two streams (plans of >= 1 GiB in >= 2 parts, with hashes): the candidate scan (K1: four waves per SIMD, its
-    // issue slots 72 % used, LDS-heavy) of the second half of the parts runs beside the leaf hashing (K3: VALU bound, no LDS) of the
-    // first -- the scan takes its residency first (one persistent workgroup per CU), the hashing's workgroups fill what is left.
-    // 26.0 -> 24.0 ms per 32 GiB (tools/k1k3_overlap_probe.py, round 6); the lists are the ones of the single pass, bit for bit: the
-    // second slice's go to scratch and are joined behind the first's.
-    LTHIP_ABLATION_ENV(env_slices, "LTHIP_SLICES"); // (ablation build: 1 = the single pass, for profiles of K1 / K3 alone)
-    if (plan->sliced && plan->half[0] && plan->half[1] && d_chunk_hashes && env_slices.get() != 1)
+    // ---- slices on two streams (plans of >= 1 GiB in >= 2 parts, with hashes).  The candidate scan (K1: four waves per SIMD, its issue
+    // slots 72 % used, LDS-heavy) and the leaf hashing (K3: VALU bound, no LDS) are both bound by instruction issue and leave each other
+    // room: with the parts cut into S slices, the scans (+ cut selection + compaction) of the slices run one after the other on the
+    // context's stream and the hashing of every slice behind its scan on a second stream -- scan i + 1 beside hashing i; the scan
+    // takes its residency first (one persistent workgroup per CU), the hashing's workgroups fill what is left.  The lists are the
+    // ones of the single pass, bit for bit: slice 0 writes the caller's arrays, the others go to scratch and are joined behind it in
+    // order (their place depends on the counts before them).  tools/k1k3_overlap_probe.py, DESIGN.md §3.
+    if (plan->sliced && plan->nslices >= 2 && d_chunk_hashes)
     {
         if (!ctx->slice_ctx && lthip_ctx_create(ctx->device, LTHIP_STREAM_PRIVATE, &ctx->slice_ctx) != 0)
             ctx->slice_ctx = nullptr;
         lthip_ctx* c2 = ctx->slice_ctx;
-        const lthip_plan *pa = plan->half[0], *pb = plan->half[1];
-        void *b_off = nullptr, *b_len = nullptr, *b_hash = nullptr, *b_first = nullptr;
-        if (c2 && !lthip_scratch(c2, S_SLICE_OFFS, (pb->chunk_cap + 1) * 8, &b_off) && !lthip_scratch(c2, S_SLICE_LENS, (pb->chunk_cap + 1) * 4, &b_len) &&
-            !lthip_scratch(c2, S_SLICE_HASH, (pb->chunk_cap + 1) * 8, &b_hash) && !lthip_scratch(c2, S_SLICE_FIRST, ((size_t)pb->nparts + 1) * 4, &b_first))
+        const uint32_t S = plan->nslices;
+        uint64_t cap_rest = 0, parts_rest = 0; // slices 1 .. S-1 in scratch, back to back
+        for (uint32_t k = 1; k < S; ++k)
+        {
+            cap_rest += plan->slice[k]->chunk_cap + 1;
+            parts_rest += (uint64_t)plan->slice[k]->nparts + 1;
+        }
+        void *x_off = nullptr, *x_len = nullptr, *x_hash = nullptr, *x_first = nullptr;
+        if (c2 && !lthip_scratch(ctx, S_SLICE_OFFS, cap_rest * 8, &x_off) && !lthip_scratch(ctx, S_SLICE_LENS, cap_rest * 4, &x_len) &&
+            !lthip_scratch(ctx, S_SLICE_HASH, cap_rest * 8, &x_hash) && !lthip_scratch(ctx, S_SLICE_FIRST, parts_rest * 4, &x_first))
         {
             c2->timing = ctx->timing;
-            hipEvent_t ready = lthip_sync_event(ctx); // the data (and whatever else the caller queued) before the second slice starts
-            LTHIP_CHECK(ctx, hipEventRecord(ready, ctx->stream));
-            LTHIP_CHECK(ctx, hipStreamWaitEvent(c2->stream, ready, 0));
-            err = chunk_hash_one(ctx, pa, d_data, d_chunk_offsets, d_chunk_lens, d_chunk_hashes, d_part_first);
-            if (!err)
+            // all candidate scans back to back on the context's stream (scan k + 1 takes the CUs the moment scan k leaves them: its one
+            // workgroup per CU needs 117 KiB of LDS and four waves per SIMD, and would wait for a whole grid of hashing workgroups to
+            // drain if those got there first); cut selection, compaction and hashing of slice k on the second stream behind scan k
+            void *bm0 = nullptr, *bm1 = nullptr;
+            if ((err = lthip_scratch(ctx, S_BM0, plan->bm0_words * 8, &bm0)) || (err = lthip_scratch(ctx, S_BM1, plan->bm1_words * 8, &bm1)))
+                return err;
+            uint64_t co = 0, po = 0, b0 = 0, b1 = 0;
+            uint64_t* offs_k[8];
+            uint32_t *lens_k[8], *first_k[8];
+            uint64_t* hash_k[8];
+            for (uint32_t k = 0; k < S && !err; ++k)
             {
-                err = chunk_hash_one(c2, pb, d_data, (uint64_t*)b_off, (uint32_t*)b_len, (uint64_t*)b_hash, (uint32_t*)b_first);
+                const lthip_plan* pk = plan->slice[k];
+                offs_k[k] = k ? (uint64_t*)x_off + co : d_chunk_offsets;
+                lens_k[k] = k ? (uint32_t*)x_len + co : d_chunk_lens;
+                hash_k[k] = k ? (uint64_t*)x_hash + co : d_chunk_hashes;
+                first_k[k] = k ? (uint32_t*)x_first + po : d_part_first;
+                if (k)
+                {
+                    co += pk->chunk_cap + 1;
+                    po += (uint64_t)pk->nparts + 1;
+                }
+                uint64_t* bm0_k = (uint64_t*)bm0 + b0;
+                uint64_t* bm1_k = (uint64_t*)bm1 + b1;
+                b0 += pk->bm0_words;
+                b1 += pk->bm1_words;
+                if (pk->nparts && (err = lthip_launch_buzhash(ctx, pk, (const uint8_t*)d_data, bm0_k, bm1_k)))
+                    break;
+                hipEvent_t scanned = lthip_sync_event(ctx);
+                LTHIP_CHECK(ctx, hipEventRecord(scanned, ctx->stream));
+                LTHIP_CHECK(ctx, hipStreamWaitEvent(c2->stream, scanned, 0));
+                void *region = nullptr, *pcount = nullptr;
+                if ((err = lthip_scratch(c2, S_REGION, pk->chunk_cap * sizeof(uint2), &region)) ||
+                    (err = lthip_scratch(c2, S_PART_COUNT, ((size_t)pk->nparts + 1) * 4, &pcount)))
+                    break;
+                if (pk->nparts)
+                    err = lthip_launch_select(c2, pk, bm0_k, bm1_k, (uint2*)region, (uint32_t*)pcount);
+                if (!err)
+                    err = lthip_launch_compact(c2, pk, (const uint2*)region, (const uint32_t*)pcount, first_k[k], offs_k[k], lens_k[k]);
+                if (!err)
+                    err = lthip_launch_blake3(c2, (const uint8_t*)d_data, offs_k[k], lens_k[k], first_k[k] + pk->nparts, pk->chunk_cap, pk->leaf_cap,
+                                              pk->max_chunk, hash_k[k]);
                 if (err)
-                    (void)lthip_fail(ctx, err, "lthip_chunk_hash (second slice)", c2->err);
+                    (void)lthip_fail(ctx, err, "lthip_chunk_hash (a slice on the second stream)", c2->err);
             }
-            hipEvent_t joined = lthip_sync_event(ctx); // (also after a failure: the first stream never runs ahead of the second)
-            LTHIP_CHECK(ctx, hipEventRecord(joined, c2->stream));
-            LTHIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, joined, 0));
+            hipEvent_t hashed = lthip_sync_event(ctx); // (also after a failure: the first stream never runs ahead of the second)
+            LTHIP_CHECK(ctx, hipEventRecord(hashed, c2->stream));
+            LTHIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, hashed, 0));
             if (err)
                 return err;
-            const uint64_t n = pb->chunk_cap > (uint64_t)pb->nparts + 1 ? pb->chunk_cap : (uint64_t)pb->nparts + 1;
             LaunchTimer t(ctx, LTHIP_K_COMPACT);
-            hipLaunchKernelGGL(k_slice_join, dim3((uint32_t)div_up_u64(n, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)b_off, (const uint32_t*)b_len,
-                               (const uint64_t*)b_hash, (const uint32_t*)b_first, pb->nparts, d_part_first + plan->split, d_chunk_offsets, d_chunk_lens,
-                               d_chunk_hashes);
+            for (uint32_t k = 1; k < S; ++k) // in order: slice k's base is the total behind slice k - 1's join
+            {
+                const lthip_plan* pk = plan->slice[k];
+                const uint64_t n = pk->chunk_cap > (uint64_t)pk->nparts + 1 ? pk->chunk_cap : (uint64_t)pk->nparts + 1;
+                hipLaunchKernelGGL(k_slice_join, dim3((uint32_t)div_up_u64(n, 256)), dim3(256), 0, ctx->stream, (const uint64_t*)offs_k[k], (const uint32_t*)lens_k[k],
+                                   (const uint64_t*)hash_k[k], (const uint32_t*)first_k[k], pk->nparts, d_part_first + plan->slice_first[k], d_chunk_offsets,
+                                   d_chunk_lens, d_chunk_hashes);
+            }
             LTHIP_LAUNCH_CHECK(ctx);
             done = true;
         }
@@ -946,7 +1017,12 @@ extern "C" int lthip_chunk_hash(lthip_ctx* ctx, const lthip_plan* plan, const vo
             ctx->err[0] = 0; // (no second context / scratch: the single pass)
     }
     if (!done)
-        err = chunk_hash_one(ctx, plan, d_data, d_chunk_offsets, d_chunk_lens, d_chunk_hashes, d_part_first);
+    {
+        err = chunk_scan_one(ctx, plan, d_data, d_chunk_offsets, d_chunk_lens, d_part_first);
+        if (!err && d_chunk_hashes)
+            err = lthip_launch_blake3(ctx, (const uint8_t*)d_data, d_chunk_offsets, d_chunk_lens, d_part_first + plan->nparts, plan->chunk_cap,
+                                      plan->leaf_cap, plan->max_chunk, d_chunk_hashes);
+    }
     if (err)
         return err;
     if (out_total)
@@ -959,8 +1035,9 @@ extern "C" int lthip_chunk_hash(lthip_ctx* ctx, const lthip_plan* plan, const vo
     return 0;
 }
 
-static int chunk_hash_one(lthip_ctx* ctx, const lthip_plan* plan, const void* d_data, uint64_t* d_chunk_offsets, uint32_t* d_chunk_lens,
-                          uint64_t* d_chunk_hashes, uint32_t* d_part_first)
+// candidate scan + cut selection + compaction of one plan on the context's stream
+static int chunk_scan_one(lthip_ctx* ctx, const lthip_plan* plan, const void* d_data, uint64_t* d_chunk_offsets, uint32_t* d_chunk_lens,
+                          uint32_t* d_part_first)
 {
     void *bm0, *bm1, *region, *pcount;
     int err;
@@ -984,13 +1061,6 @@ static int chunk_hash_one(lthip_ctx* ctx, const lthip_plan* plan, const void* d_
     if ((err = lthip_launch_compact(ctx, plan, (const uint2*)region, (const uint32_t*)pcount, d_part_first,
                                     d_chunk_offsets, d_chunk_lens)))
         return err;
-    if (d_chunk_hashes)
-    {
-        if ((err = lthip_launch_blake3(ctx, (const uint8_t*)d_data, d_chunk_offsets, d_chunk_lens,
-                                       d_part_first + plan->nparts, plan->chunk_cap, plan->leaf_cap, plan->max_chunk,
-                                       d_chunk_hashes)))
-            return err;
-    }
     return 0;
 }
 

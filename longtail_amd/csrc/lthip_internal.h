@@ -57,13 +57,18 @@ struct lthip_plan
     uint64_t cap_tiles;
     PartDev* d_parts;
     uint32_t* d_tile_part;
-    // A plan of many parts and >= LTHIP_SLICE_MIN_BYTES also exists as TWO plans over its first and second half of the bytes
-    // (lthip_chunk_hash runs them on two streams: the candidate scan of the second half beside the leaf hashing of the first)
-    lthip_plan* half[2];
-    uint32_t split; // parts [0, split) are half[0]'s
-    bool sliced;    // the halves are aimed at the plan's current parts
+    // A plan of many parts and >= LTHIP_SLICE_MIN_BYTES also exists as LTHIP_SLICES plans over consecutive runs of its parts of
+    // about equal bytes (lthip_chunk_hash: the candidate scans of the slices one after the other on one stream, the leaf hashing of
+    // every slice behind its scan on a second stream -- the scan of slice i + 1 runs beside the hashing of slice i)
+    lthip_plan* slice[8];
+    uint32_t slice_first[9]; // slice i = parts [slice_first[i], slice_first[i + 1])
+    uint32_t nslices;        // 0: the plan is run as one
+    bool sliced;             // the slices are aimed at the plan's current parts
 };
 constexpr uint64_t LTHIP_SLICE_MIN_BYTES = 1ull << 30;
+#ifndef LTHIP_SLICES
+#define LTHIP_SLICES 2 /* measured 2 .. 8 with the scans back to back (round 6): 2 is as good as any -- what the hashing gains is the issue slots the scans leave free while they run, whatever the granularity */
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // context
