@@ -905,6 +905,13 @@ class Bench:
                         "algorithmic_bytes_per_launch": int(alg_bytes[dom] / launches), "avg_launch_ms": round(avg_ms, 3),
                         "algorithmic_bytes": "SURVEY.md §8(d): N read per phase-1 kernel; N read + N_out written for the codec kernels",
                         "frac_over_input_only": round(alg_input_only[dom] / launches / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            if slices > 1:
+                roofline["dominant_kernel_choice"] = (
+                    f"the longest kernel that had the device to itself; the candidate scan and the leaf hashing run CONCURRENTLY on {slices} slices of the "
+                    f"parts (lthip_chunk_hash), so their event / rocprof durations overlap each other -- buzhash {kern.get('buzhash', {}).get('ms_per_step')} + "
+                    f"blake3_leaf {kern.get('blake3_leaf', {}).get('ms_per_step')} ms inside a phase of {kern['chunk_hash_phase']['ms_per_step']} ms; run one "
+                    "after the other (ablation build, LTHIP_SLICES=1: profiles/*_one_slice_kernel_stats.csv) they take 24.0 and 25.7 ms per step, both below "
+                    "the classification pass")
             pm = getattr(self, "peak_measured", None)
             if pm:
                 # the box's own memory system beside the nominal figure: a device copy for kernels that read and write (the codec),

@@ -48,7 +48,7 @@ LTHIP_EXPORT struct Longtail_HashAPI* Longtail_CreateHipBlake3HashAPI(void);
  * compresses -- WriteContent at 32 bikeshed workers: LZ4 31-47 GB/s against the reference codec's 22-25, ZStd 33-35 against 7-14 -- and
  * lose on incompressible bytes, where the CPU's LZ4 is a memcpy (25-29 against 56-105 GB/s): there bind the reference's own LZ4 beside
  * the HIP chunker + hash, or use the bulk session (lthip_ingest_*), which never brings payload bytes back through Compress
- * (INTEGRATION.md "Which codec object to bind"; numbers: the bench line's secondary.*.drop_in, profiles/r06m_*).
+ * (INTEGRATION.md "Which codec object to bind"; numbers: the bench line's secondary.*.drop_in, profiles/r06q_*).
  *
  * Replaces Longtail_CreateLZ4CompressionAPI() / Longtail_CompressionRegistry_CreateForLZ4()
  * (lib/lz4/longtail_lz4.h:10-12, longtail_lz4.c:12-23,47-123).  Same type id 'lz42', same bound
